@@ -1,0 +1,60 @@
+"""Deterministic synthetic R9.4 reads for tests and bench.py.
+
+A read is: L uniform-random bases, K = L-k+1 k-mers; every k-mer emits 0 events w.p. 0.08, else
+1 + Bern(.45) + Bern(.15) events; each event mean ~ N(scale*mu_k + shift, (var*sigma_k)^2) from the
+r9.4_450bps nucleotide 6-mer table; per-read shift ~ U(-5,5), scale ~ U(.9,1.1), var ~ U(1,1.4), drift 0.
+Odd read ids are reverse-strand reads: the reference is revcomp(read sequence).
+The generator is numpy-only so that the same arrays feed the CPU oracle and the HIP path.
+"""
+import numpy as np
+
+BASES = np.frombuffer(b"ACGT", np.uint8)
+SEED0 = 0xC0FFEE
+
+
+def nucleotide_kmer_ranks(codes, k=6):
+    """ranks of all k-mers of a base-code array (A0 C1 G2 T3), as Alphabet::kmer_rank orders them"""
+    codes = np.asarray(codes, np.int64)
+    n = len(codes) - k + 1
+    r = np.zeros(n, np.int64)
+    for j in range(k):
+        r = r * 4 + codes[j:j + n]
+    return r.astype(np.uint32)
+
+
+def revcomp(seq):
+    return seq[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+def synth_read(read_id, model, L=5000, k=6, seed0=SEED0):
+    rng = np.random.default_rng(seed0 + int(read_id))
+    codes = rng.integers(0, 4, L)
+    seq = BASES[codes].tobytes().decode()
+    ranks = nucleotide_kmer_ranks(codes, k)
+    K = len(ranks)
+    n_ev = np.where(rng.random(K) < 0.08, 0, 1 + (rng.random(K) < 0.45) + (rng.random(K) < 0.15)).astype(np.int64)
+    shift = rng.uniform(-5, 5)
+    scale = rng.uniform(0.9, 1.1)
+    var = rng.uniform(1.0, 1.4)
+    rk = np.repeat(ranks, n_ev)
+    mu = scale * model["level_mean"][rk] + shift
+    sd = var * model["level_stdv"][rk]
+    events = (mu + sd * rng.standard_normal(len(rk))).astype(np.float32)
+    return dict(read_id=int(read_id), seq=seq, codes=codes.astype(np.uint8), ranks=ranks, events=events,
+                shift=float(shift), scale=float(scale), var=float(var), rc=bool(read_id & 1))
+
+
+def synth_batch(read_ids, model, L=5000, k=6, seed0=SEED0):
+    """CSR batch: events/event_off, ranks/rank_off, per-read scalars."""
+    reads = [synth_read(r, model, L, k, seed0) for r in read_ids]
+    event_off = np.zeros(len(reads) + 1, np.int64)
+    rank_off = np.zeros(len(reads) + 1, np.int64)
+    event_off[1:] = np.cumsum([len(r["events"]) for r in reads])
+    rank_off[1:] = np.cumsum([len(r["ranks"]) for r in reads])
+    return dict(reads=reads,
+                events=np.concatenate([r["events"] for r in reads]),
+                event_off=event_off,
+                ranks=np.concatenate([r["ranks"] for r in reads]).astype(np.uint32),
+                rank_off=rank_off,
+                shift=np.array([r["shift"] for r in reads]), scale=np.array([r["scale"] for r in reads]),
+                var=np.array([r["var"] for r in reads]), rc=np.array([r["rc"] for r in reads], np.uint8))
