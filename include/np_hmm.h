@@ -1,0 +1,229 @@
+/* include/np_hmm.h -- C ABI of the MI355X-native nanopolish signal-HMM hot path.
+ *
+ * nanopolish (v0.14.0) has no plugin/FFI layer: its "boundary" for this path is the C++ free-function
+ * API
+ *     float profile_hmm_score(const HMMInputSequence&, const HMMInputData&, uint32_t flags)      src/hmm/nanopolish_profile_hmm.h:24
+ *     float profile_hmm_score(const HMMInputSequence&, const std::vector<HMMInputData>&, uint32) src/hmm/nanopolish_profile_hmm.h:25
+ *     float profile_hmm_score_set(const std::vector<HMMInputSequence>&, const HMMInputData&, u32) src/hmm/nanopolish_profile_hmm.h:28
+ *     std::vector<HMMAlignmentState> profile_hmm_align(const HMMInputSequence&, const HMMInputData&, u32)  :31
+ *     std::vector<AlignedPair> adaptive_banded_simple_event_align(SquiggleRead&, const PoreModel&, const std::string&)
+ *                                                                                                src/nanopolish_raw_loader.h:22-24
+ * This header is what a thin shim behind those signatures binds (nanopolish_amd/csrc/np_dropin.hpp is that
+ * shim; INTEGRATION.md shows where it plugs into the reference).  Plain pointers and sizes only; no C++ or
+ * torch types.  Every function returns NP_OK (0) or a negative error code and never throws.
+ *
+ * Two flavours of every entry point:
+ *   *_host  : caller passes host buffers (what the per-call C++ API hands over); the library packs,
+ *             uploads, launches, downloads.  Synchronous, thread-safe (internal lock).
+ *   *_dev   : caller passes device-resident SoA buffers (HBM) and a stream; nothing is copied, the call
+ *             only enqueues kernels.  This is the throughput path fed at the BamProcessor batch boundary
+ *             (src/common/nanopolish_bam_processor.cpp:90-119).
+ */
+#ifndef NP_HMM_H
+#define NP_HMM_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NP_OK 0
+#define NP_ERR_INVALID (-1)     /* bad argument */
+#define NP_ERR_DEVICE (-2)      /* HIP error (see np_last_error) */
+#define NP_ERR_NOMEM (-3)
+#define NP_ERR_UNSUPPORTED (-4) /* problem outside what the kernels cover (e.g. > NP_MAX_KMERS k-mers) */
+
+/* HMMAlignmentFlags, src/hmm/nanopolish_profile_hmm.h:34-38 */
+#define NP_HAF_ALLOW_PRE_CLIP 1u
+#define NP_HAF_ALLOW_POST_CLIP 2u
+
+#define NP_MAX_KMERS 1024      /* k-mers per profile_hmm_* call (reference callers stay <= 260) */
+#define NP_ALN_BANDWIDTH 100   /* ALN_BANDWIDTH, src/nanopolish_raw_loader.cpp:72 */
+
+typedef struct np_ctx np_ctx;
+
+/* Behaviour knobs that are globals / compile-time constants in the reference. */
+typedef struct np_params {
+    double hmm_indel_bias_factor;   /* src/hmm/nanopolish_profile_hmm_r9.cpp:19 (1.0; variants sets .8/.9) */
+    double min_average_log_emission;/* src/nanopolish_raw_loader.cpp:92  (-5.0) */
+    int32_t max_gap_threshold;      /* src/nanopolish_raw_loader.cpp:93  (50)   */
+    int32_t reserved;
+} np_params;
+
+void np_default_params(np_params* p);
+
+/* ---- context ------------------------------------------------------------------------------------- */
+/* device: HIP device ordinal.  Fails (returns NULL, see np_last_error(NULL)) if no gfx950 device/HIP
+ * runtime is usable: there is NO CPU fallback in this library. */
+np_ctx* np_create(int device, const np_params* params);
+void    np_destroy(np_ctx* ctx);
+const char* np_last_error(const np_ctx* ctx);
+const char* np_version(void);
+
+/* Upload a pore model (PoreModel::states, src/pore_model/nanopolish_poremodel.h:20-67,107): the three
+ * per-state doubles the path reads.  Returns a model id >= 0, or a negative error. */
+int np_register_model(np_ctx* ctx, int k, int n_states,
+                      const double* level_mean, const double* level_stdv, const double* level_log_stdv);
+
+/* ---- host-side helpers (pure CPU, no device): alphabets & transitions ------------------------------ */
+/* Alphabets of src/common/nanopolish_alphabet.{h,cpp}: "nucleotide","cpg","gpc","dam","dcm","u_to_t_rna" */
+int      np_alphabet_id(const char* name);
+uint32_t np_alphabet_size(int alphabet);
+uint32_t np_kmer_rank(int alphabet, const char* kmer, uint32_t k);                 /* Alphabet::kmer_rank          */
+int      np_reverse_complement(int alphabet, const char* in, size_t n, char* out); /* Alphabet::reverse_complement */
+int      np_methylate(int alphabet, const char* in, size_t n, char* out);          /* Alphabet::methylate          */
+int      np_unmethylate(int alphabet, const char* in, size_t n, char* out);        /* Alphabet::unmethylate        */
+int      np_is_motif_match(int alphabet, const char* str, size_t n, size_t i);     /* Alphabet::is_motif_match     */
+/* HMMInputSequence::get_kmer_rank for every k-mer (src/hmm/nanopolish_hmm_input_sequence.h:76-91).
+ * rc_seq may be NULL (then reverse_complement(seq) is used, as the 1- and 2-argument constructors do). */
+int      np_sequence_kmer_ranks(int alphabet, const char* seq, const char* rc_seq, size_t n, uint32_t k,
+                                int do_rc, uint16_t* out_ranks);
+/* calculate_transitions (src/hmm/nanopolish_profile_hmm_r9.inl:17-76) with host libm, exactly as the reference */
+void     np_calculate_transitions(double events_per_base, double indel_bias, float out[10]);
+/* estimate_scalings_using_mom (src/nanopolish_raw_loader.cpp:17-60) */
+void     np_estimate_scalings_mom(const double* model_level_mean, const uint16_t* kmer_ranks, uint32_t n_kmers,
+                                  const float* event_mean, uint32_t n_events, double* shift, double* scale);
+/* motif scan + grouping of calculate_methylation_for_read (src/basemods/nanopolish_basemods.cpp:298-320) */
+int      np_scan_motif_groups(int alphabet, const char* ref_seq, size_t n, int min_separation,
+                              int32_t* first_site, int32_t* last_site, int32_t* n_motif, int cap);
+
+/* Work items of calculate_methylation_for_read (src/basemods/nanopolish_basemods.cpp:298-378) for an identity-aligned
+ * read (bench/test layout): groups, windows, boundary rule, methylated/unmethylated k-mer ranks, and the read-strand
+ * k-mer positions (kpos) whose closest events bound each window.  Returns #jobs or a negative error. */
+int      np_cm_build_jobs_identity(int alphabet, const char* ref_seq, size_t n, int read_rc, uint32_t k,
+                                   int min_separation, int min_flank, int cap_jobs, int64_t cap_ranks,
+                                   int32_t* first_site, int32_t* last_site, int32_t* n_motif,
+                                   int32_t* kpos, int32_t* job_n_kmers,
+                                   uint16_t* ranks_unmeth, uint16_t* ranks_meth, int64_t* rank_off);
+
+/* ---- per-call ("drop-in") entry points, host buffers ------------------------------------------------- */
+/* One profile_hmm_score / profile_hmm_align problem, flattened from (HMMInputSequence, HMMInputData):
+ *   event_mean   read->events[strand][*].mean (drift == 0 on the R9 path)     src/nanopolish_squiggle_read.h:149-154
+ *   kmer_rank    HMMInputSequence::get_kmer_rank(i, k, data.rc), i = 0..n_kmers-1
+ *   e_start/e_stop/stride   HMMInputData::event_start_idx/event_stop_idx/event_stride
+ *   scale/shift/var         read->scalings[strand]                           src/nanopolish_squiggle_read.h:63-93
+ *   events_per_base         read->events_per_base[strand]
+ */
+typedef struct np_hmm_job {
+    const float*    event_mean;      /* whole-read event means; indexed by event idx */
+    uint32_t        n_events_total;
+    uint32_t        e_start, e_stop;
+    int32_t         stride;          /* +1 / -1 */
+    const uint16_t* kmer_rank;
+    uint32_t        n_kmers;
+    int32_t         model;           /* id from np_register_model */
+    double          scale, shift, var;
+    double          events_per_base;
+    uint32_t        flags;           /* NP_HAF_* */
+    uint32_t        reserved;
+} np_hmm_job;
+
+/* HMMAlignmentState, src/common/nanopolish_common.h:65-73 (l_posterior / log_transition_probability are
+ * always -INFINITY in the reference and are not transported) */
+typedef struct np_hmm_state {
+    uint32_t event_idx;
+    uint32_t kmer_idx;
+    double   l_fm;
+    char     state;     /* 'K','B','M' */
+    char     pad[7];
+} np_hmm_state;
+
+/* AlignedPair, src/alignment/nanopolish_anchor.h:18-22 */
+typedef struct np_pair { int32_t ref_pos; int32_t read_pos; } np_pair;
+
+typedef struct np_align_job {
+    const float*    event_mean;   /* read.events[0][*].mean */
+    uint32_t        n_events;
+    const uint16_t* kmer_rank;    /* nucleotide k-mer ranks of `sequence` */
+    uint32_t        n_kmers;
+    int32_t         model;
+    double          scale, shift; /* read.scalings[0] (var = 1, drift = 0 at the call site, raw_loader.cpp:52) */
+    double          var;
+} np_align_job;
+
+int np_hmm_score_host(np_ctx* ctx, int n_jobs, const np_hmm_job* jobs, float* out_scores);
+/* profile_hmm_score_set: set q is jobs[set_off[q] .. set_off[q+1]) (sequence 0 first); one combined score per set. */
+int np_hmm_score_set_host(np_ctx* ctx, int n_sets, const int32_t* set_off, const np_hmm_job* jobs, float* out_scores);
+/* out_states: concatenated; out_off[n_jobs+1] offsets; cap = capacity of out_states.
+ * A job for which the reference would hit an assert reports count 0. */
+int np_hmm_align_host(np_ctx* ctx, int n_jobs, const np_hmm_job* jobs,
+                      np_hmm_state* out_states, int64_t cap, int64_t* out_off);
+/* out_pairs: concatenated; out_off[n_jobs+1]; an empty range == the reference's empty vector (QC failure). */
+int np_event_align_host(np_ctx* ctx, int n_jobs, const np_align_job* jobs,
+                        np_pair* out_pairs, int64_t cap, int64_t* out_off);
+
+/* ---- batched device-resident entry points ------------------------------------------------------------- */
+/* All pointers below are DEVICE pointers unless stated otherwise; `stream` is a hipStream_t (0 = the
+ * context's own stream).  The calls only enqueue work. */
+
+/* Per-read record (device).  Filled by np_fill_read_host() on the host, then uploaded by the caller. */
+typedef struct np_read_dev {
+    double  scale, shift, var, log_var;  /* SquiggleScalings used for emissions                      */
+    double  lp_skip, lp_stay, lp_step, lp_trim; /* aligner constants, src/nanopolish_raw_loader.cpp:99-108 */
+    int64_t event_off;                   /* offset of this read's events in the batch event array    */
+    int64_t rank_off;                    /* offset of this read's nucleotide k-mer ranks             */
+    uint32_t n_events;
+    uint32_t n_kmers;
+    float   trans[10];                   /* calculate_transitions order (r9.h:75-95), HMM scoring    */
+    uint32_t flags;
+    uint32_t reserved;
+} np_read_dev;
+
+/* Host helper: fills the aligner constants with host libm exactly as the reference does. */
+void np_fill_read_host(np_read_dev* r, double shift, double scale, double var,
+                       int64_t event_off, uint32_t n_events, int64_t rank_off, uint32_t n_kmers);
+
+/* One HMM work item (device). */
+typedef struct np_hmm_job_dev {
+    int64_t  rank_off;     /* into the job k-mer rank array (uint16) */
+    uint32_t n_kmers;
+    uint32_t read;         /* index into np_read_dev[] */
+    uint32_t e_start, e_stop;
+    int32_t  stride;
+    uint32_t flags;
+} np_hmm_job_dev;
+
+/* Event alignment of a batch of reads (kernel A).
+ *   pairs_out : np_pair[pair_off[n_reads]] ; pair_off (device int64[n_reads+1]) must give each read room for
+ *               n_events + n_kmers + 2 pairs.  The alignment of read r is written ascending into
+ *               pairs_out[pair_off[r] + pair_begin[r] .. pair_off[r+1])  -- right-aligned --
+ *   pair_begin (int32[n_reads]) and n_pairs (int32[n_reads], 0 == QC failure) are outputs.
+ *   max_bands : max over the batch of n_events + n_kmers + 2 (sizes the per-wave trace scratch). */
+int np_event_align_dev(np_ctx* ctx, void* stream, int n_reads, const np_read_dev* reads,
+                       const float* event_mean, const uint16_t* kmer_rank, int model, int64_t max_bands,
+                       const int64_t* pair_off, np_pair* pairs_out, int32_t* pair_begin, int32_t* n_pairs);
+
+/* Forward scores of a batch of HMM work items (kernel B).
+ *   order (host pointer, may be NULL): nothing to provide; the library bins jobs by size on the device. */
+int np_hmm_score_dev(np_ctx* ctx, void* stream, int64_t n_jobs, const np_hmm_job_dev* jobs,
+                     const np_read_dev* reads, const float* event_mean, const uint16_t* job_kmer_rank,
+                     int model, float* out_scores);
+
+/* Read-level glue between the two kernels (src/nanopolish_squiggle_read.cpp:161-186,273-301):
+ * builds base_to_event_map[].start for every read from kernel A's pairs, events_per_base and the
+ * HMM transitions, then resolves each work item's event bounds
+ *     e_start = get_closest_event_to(kpos_start), e_stop = get_closest_event_to(kpos_stop)
+ * and applies the skip rule |e2-e1| <= 10 (src/basemods/nanopolish_basemods.cpp:356): skipped items get
+ * n_kmers = 0 and score NaN.
+ *   map_start : int32[sum n_kmers] scratch/output (per read at rank_off)
+ *   kpos      : int32[2*n_jobs] read-strand k-mer positions bounding each item
+ *   events_per_base : double[n_reads] output */
+int np_resolve_jobs_dev(np_ctx* ctx, void* stream, int n_reads, np_read_dev* reads,
+                        const int64_t* pair_off, const np_pair* pairs, const int32_t* pair_begin, const int32_t* n_pairs,
+                        int32_t* map_start, double* events_per_base,
+                        int64_t n_jobs, np_hmm_job_dev* jobs, const int32_t* kpos);
+
+/* Synchronise the context's stream (or the given one). */
+int np_sync(np_ctx* ctx, void* stream);
+
+/* Time (ms) spent in the most recent launch of each kernel family on the device, measured with HIP events
+ * on the launching stream.  which: 0 = event align, 1 = hmm score, 2 = resolve, 3 = hmm viterbi. */
+int np_last_kernel_ms(np_ctx* ctx, int which, float* ms);
+/* Accumulated device time (ms) and launch count of a kernel family since the last reset (call after np_sync). */
+int np_kernel_time(np_ctx* ctx, int which, double* total_ms, int64_t* launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

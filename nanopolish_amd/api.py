@@ -1,0 +1,228 @@
+"""Host-side mirror of the reference's entry points for this path, on top of the C ABI (include/np_hmm.h).
+
+Names and argument meaning follow the reference:
+    profile_hmm_score / profile_hmm_score_set / profile_hmm_align   src/hmm/nanopolish_profile_hmm.h:24-31
+    adaptive_banded_simple_event_align, estimate_scalings_using_mom src/nanopolish_raw_loader.h:16-24
+so the parity tests read like calls into nanopolish.  Everything computes on the MI355X through libnp_hip.so;
+nothing here falls back to a CPU implementation.
+"""
+import ctypes as C
+import numpy as np
+
+from . import lib as _l
+
+HAF_ALLOW_PRE_CLIP = 1
+HAF_ALLOW_POST_CLIP = 2
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+# ---- pure-host helpers (Alphabet / HMMInputSequence) -------------------------------------------------------
+def alphabet_id(name):
+    r = _l.load_library().np_alphabet_id(name.encode())
+    if r < 0:
+        raise ValueError("unknown alphabet %r" % name)
+    return r
+
+
+def kmer_rank(alphabet, kmer):
+    return _l.load_library().np_kmer_rank(alphabet_id(alphabet), kmer.encode(), len(kmer))
+
+
+def _strfn(fn, alphabet, s):
+    out = C.create_string_buffer(len(s) + 1)
+    getattr(_l.load_library(), fn)(alphabet_id(alphabet), s.encode(), len(s), out)
+    return out.value.decode()
+
+
+def reverse_complement(alphabet, s):
+    return _strfn("np_reverse_complement", alphabet, s)
+
+
+def methylate(alphabet, s):
+    return _strfn("np_methylate", alphabet, s)
+
+
+def unmethylate(alphabet, s):
+    return _strfn("np_unmethylate", alphabet, s)
+
+
+def is_motif_match(alphabet, s, i):
+    return bool(_l.load_library().np_is_motif_match(alphabet_id(alphabet), s.encode(), len(s), i))
+
+
+def sequence_kmer_ranks(alphabet, seq, rc_seq=None, k=6, do_rc=False):
+    """HMMInputSequence(seq[, rc_seq], alphabet).get_kmer_rank(i, k, do_rc) for all i."""
+    out = np.zeros(len(seq) - k + 1, np.uint16)
+    rc = _l.load_library().np_sequence_kmer_ranks(alphabet_id(alphabet), seq.encode(), rc_seq.encode() if rc_seq else None,
+                                                  len(seq), k, int(do_rc), _p(out, _l.c_u16p))
+    if rc != 0:
+        raise ValueError("np_sequence_kmer_ranks failed")
+    return out
+
+
+def calculate_transitions(events_per_base, indel_bias=1.0):
+    out = np.zeros(10, np.float32)
+    _l.load_library().np_calculate_transitions(events_per_base, indel_bias, _p(out, _l.c_f32p))
+    return out
+
+
+def estimate_scalings_using_mom(model, ranks, events):
+    lm = np.ascontiguousarray(model["level_mean"], np.float64)
+    ranks = np.ascontiguousarray(ranks, np.uint16)
+    events = np.ascontiguousarray(events, np.float32)
+    sh = C.c_double(); sc = C.c_double()
+    _l.load_library().np_estimate_scalings_mom(_p(lm, _l.c_f64p), _p(ranks, _l.c_u16p), len(ranks), _p(events, _l.c_f32p),
+                                               len(events), C.byref(sh), C.byref(sc))
+    return sh.value, sc.value
+
+
+def scan_motif_groups(alphabet, ref_seq, min_separation=10):
+    cap = len(ref_seq) + 1
+    f = np.zeros(cap, np.int32); l = np.zeros(cap, np.int32); c = np.zeros(cap, np.int32)
+    n = _l.load_library().np_scan_motif_groups(alphabet_id(alphabet), ref_seq.encode(), len(ref_seq), min_separation,
+                                               _p(f, _l.c_i32p), _p(l, _l.c_i32p), _p(c, _l.c_i32p), cap)
+    return f[:n].copy(), l[:n].copy(), c[:n].copy()
+
+
+def cm_build_jobs_identity(ref_seq, read_rc, k=6, alphabet="cpg", min_separation=10, min_flank=10):
+    """Work items of calculate_methylation_for_read for an identity-aligned read (see np_cm_build_jobs_identity)."""
+    n = len(ref_seq)
+    cap_jobs = n // 2 + 1
+    cap_ranks = 4 * n + 1024
+    f = np.zeros(cap_jobs, np.int32); l = np.zeros(cap_jobs, np.int32); c = np.zeros(cap_jobs, np.int32)
+    kpos = np.zeros(2 * cap_jobs, np.int32); nk = np.zeros(cap_jobs, np.int32)
+    ru = np.zeros(cap_ranks, np.uint16); rm = np.zeros(cap_ranks, np.uint16); ro = np.zeros(cap_jobs + 1, np.int64)
+    nj = _l.load_library().np_cm_build_jobs_identity(alphabet_id(alphabet), ref_seq.encode(), n, int(read_rc), k,
+                                                     min_separation, min_flank, cap_jobs, cap_ranks,
+                                                     _p(f, _l.c_i32p), _p(l, _l.c_i32p), _p(c, _l.c_i32p), _p(kpos, _l.c_i32p),
+                                                     _p(nk, _l.c_i32p), _p(ru, _l.c_u16p), _p(rm, _l.c_u16p), _p(ro, _l.c_i64p))
+    if nj < 0:
+        raise RuntimeError("np_cm_build_jobs_identity: %d" % nj)
+    w = int(ro[nj])
+    return dict(first=f[:nj].copy(), last=l[:nj].copy(), n_motif=c[:nj].copy(), kpos=kpos[:2 * nj].reshape(-1, 2).copy(),
+                n_kmers=nk[:nj].copy(), ranks_unmeth=ru[:w].copy(), ranks_meth=rm[:w].copy(), rank_off=ro[:nj + 1].copy())
+
+
+# ---- device context ---------------------------------------------------------------------------------------------
+class Context:
+    """np_ctx wrapper.  Raises RuntimeError if no gfx950 device is usable (no CPU fallback)."""
+
+    def __init__(self, device=0, indel_bias=1.0):
+        self.L = _l.load_library()
+        p = _l.Params()
+        self.L.np_default_params(C.byref(p))
+        p.hmm_indel_bias_factor = indel_bias
+        self.h = self.L.np_create(device, C.byref(p))
+        if not self.h:
+            raise RuntimeError("np_create failed: %s" % self.L.np_last_error(None).decode())
+        self.models = {}
+
+    def close(self):
+        if self.h:
+            self.L.np_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.L.np_last_error(self.h).decode()))
+
+    def register_model(self, model, name=None):
+        lm = np.ascontiguousarray(model["level_mean"], np.float64)
+        ls = np.ascontiguousarray(model["level_stdv"], np.float64)
+        ll = np.ascontiguousarray(model["level_log_stdv"], np.float64)
+        mid = self.L.np_register_model(self.h, int(model["k"]), len(lm), _p(lm, _l.c_f64p), _p(ls, _l.c_f64p), _p(ll, _l.c_f64p))
+        if mid < 0:
+            self._chk(mid, "np_register_model")
+        if name:
+            self.models[name] = mid
+        return mid
+
+    # -- drop-in entry points (host buffers) --------------------------------------------------------------------
+    def _hmm_jobs(self, jobs):
+        arr = (_l.HmmJob * len(jobs))()
+        keep = []
+        for i, j in enumerate(jobs):
+            ev = np.ascontiguousarray(j["events"], np.float32)
+            rk = np.ascontiguousarray(j["ranks"], np.uint16)
+            keep.append((ev, rk))
+            a = arr[i]
+            a.event_mean = _p(ev, _l.c_f32p); a.n_events_total = len(ev)
+            a.e_start = int(j["e_start"]); a.e_stop = int(j["e_stop"]); a.stride = int(j["stride"])
+            a.kmer_rank = _p(rk, _l.c_u16p); a.n_kmers = len(rk); a.model = int(j["model"])
+            a.scale = j["scale"]; a.shift = j["shift"]; a.var = j["var"]; a.events_per_base = j["events_per_base"]
+            a.flags = int(j.get("flags", 0))
+        return arr, keep
+
+    def profile_hmm_score(self, jobs):
+        """jobs: list of dicts (events, ranks, e_start, e_stop, stride, model, scale, shift, var, events_per_base, flags).
+        Returns float32 scores, one per job, as profile_hmm_score would."""
+        arr, keep = self._hmm_jobs(jobs)
+        out = np.zeros(len(jobs), np.float32)
+        self._chk(self.L.np_hmm_score_host(self.h, len(jobs), arr, _p(out, _l.c_f32p)), "np_hmm_score_host")
+        return out
+
+    def profile_hmm_score_set(self, job_sets):
+        """job_sets: list of lists of jobs (sequence 0 under the nucleotide model, the others under their alphabets'
+        models).  Combination as profile_hmm_score_set (src/hmm/nanopolish_profile_hmm.cpp:32-56)."""
+        flat = [j for s in job_sets for j in s]
+        arr, keep = self._hmm_jobs(flat)
+        off = np.zeros(len(job_sets) + 1, np.int32)
+        off[1:] = np.cumsum([len(s) for s in job_sets])
+        out = np.zeros(len(job_sets), np.float32)
+        self._chk(self.L.np_hmm_score_set_host(self.h, len(job_sets), _p(off, _l.c_i32p), arr, _p(out, _l.c_f32p)),
+                  "np_hmm_score_set_host")
+        return out
+
+    def profile_hmm_align(self, jobs):
+        """Returns a list of (event_idx, kmer_idx, l_fm, state) arrays, one tuple per job (HMMAlignmentState fields)."""
+        arr, keep = self._hmm_jobs(jobs)
+        cap = sum(abs(int(j["e_stop"]) - int(j["e_start"])) + 1 + len(j["ranks"]) + 1 for j in jobs)
+        st = (_l.HmmState * cap)()
+        off = np.zeros(len(jobs) + 1, np.int64)
+        self._chk(self.L.np_hmm_align_host(self.h, len(jobs), arr, st, cap, _p(off, _l.c_i64p)), "np_hmm_align_host")
+        raw = np.frombuffer(st, dtype=np.dtype([("event_idx", "<u4"), ("kmer_idx", "<u4"), ("l_fm", "<f8"), ("state", "u1"),
+                                                ("pad", "u1", 7)]))
+        res = []
+        for i in range(len(jobs)):
+            r = raw[off[i]:off[i + 1]]
+            res.append((r["event_idx"].copy(), r["kmer_idx"].copy(), r["l_fm"].copy(), r["state"].copy()))
+        return res
+
+    def adaptive_banded_simple_event_align(self, reads):
+        """reads: list of dicts (events, ranks [nucleotide], model, scale, shift, var=1).  Returns a list of (n,2) int32
+        arrays of AlignedPair{ref_pos, read_pos}; an empty array is the reference's empty vector (QC failure)."""
+        n = len(reads)
+        arr = (_l.AlignJob * n)()
+        keep = []
+        cap = 0
+        for i, r in enumerate(reads):
+            ev = np.ascontiguousarray(r["events"], np.float32)
+            rk = np.ascontiguousarray(r["ranks"], np.uint16)
+            keep.append((ev, rk))
+            a = arr[i]
+            a.event_mean = _p(ev, _l.c_f32p); a.n_events = len(ev); a.kmer_rank = _p(rk, _l.c_u16p); a.n_kmers = len(rk)
+            a.model = int(r["model"]); a.scale = r["scale"]; a.shift = r["shift"]; a.var = r.get("var", 1.0)
+            cap += len(ev) + len(rk) + 2
+        pairs = np.zeros((cap, 2), np.int32)
+        off = np.zeros(n + 1, np.int64)
+        self._chk(self.L.np_event_align_host(self.h, n, arr, pairs.ctypes.data_as(C.POINTER(_l.Pair)), cap, _p(off, _l.c_i64p)),
+                  "np_event_align_host")
+        return [pairs[off[i]:off[i + 1]].copy() for i in range(n)]
+
+    # -- timing -----------------------------------------------------------------------------------------------------
+    def sync(self, stream=None):
+        self._chk(self.L.np_sync(self.h, stream), "np_sync")
+
+    def kernel_time(self, which, reset=False):
+        ms = C.c_double(); n = C.c_int64()
+        self._chk(self.L.np_kernel_time(self.h, which, C.byref(ms), C.byref(n), int(reset)), "np_kernel_time")
+        return ms.value, n.value

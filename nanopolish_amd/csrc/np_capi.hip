@@ -1,0 +1,542 @@
+// np_capi.hip -- the C ABI (include/np_hmm.h): context, model registry, host-buffer entry points that pack /
+// upload / launch / download, and device-resident entry points that only enqueue kernels.
+// No CPU fallback exists: every compute entry point needs a live gfx950 device and fails loudly otherwise.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include "np_kernels.h"
+#include "np_logf.h"
+
+#define NP_VERSION_STR "nanopolish_amd 0.1 (gfx950)"
+#define NP_FLANK_LEN (1u << 20)
+#define NP_NUM_FAMILIES 4
+
+namespace {
+
+struct dev_buf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { e = hipMalloc(&p, bytes); want = bytes; }
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct model_t {
+    int k = 0, n_states = 0;
+    np_state_dev* d_states = nullptr;
+    std::vector<double> level_mean;
+};
+
+struct timing_t {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<hipEvent_t> pool;
+    double total_ms = 0.0;
+    long launches = 0;
+    float last_ms = 0.f;
+};
+
+} // namespace
+
+struct np_ctx {
+    int device = 0;
+    int n_cu = 256;
+    np_params params;
+    hipStream_t stream = nullptr;
+    std::vector<model_t> models;
+    float* d_logsum = nullptr;
+    std::vector<float> h_logsum;
+    float* d_flank = nullptr;
+    uint32_t* d_counters = nullptr;   // [0..6] class counts, [8..15] work-queue heads, [16] align queue head
+    dev_buf order, trace;
+    // host-API staging
+    dev_buf b_jobs, b_reads, b_events, b_ranks, b_out, b_pair_off, b_pairs, b_pair_begin, b_n_pairs,
+            b_vm, b_bp, b_cell_off, b_state_off, b_states, b_n_states;
+    timing_t timing[NP_NUM_FAMILIES];
+    std::mutex lock;
+    std::string err;
+    int align_blocks_per_cu = 8, hmm_blocks_per_cu = 2;
+};
+
+namespace {
+
+std::string g_create_err;
+
+#define NP_HIP(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e__ = (call);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                   \
+            return NP_ERR_DEVICE;                                                              \
+        }                                                                                      \
+    } while (0)
+
+struct family_timer {
+    np_ctx* c; int which; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    family_timer(np_ctx* ctx, int w, hipStream_t st) : c(ctx), which(w), s(st)
+    {
+        timing_t& t = c->timing[which];
+        auto get = [&]() { hipEvent_t e = nullptr; if (!t.pool.empty()) { e = t.pool.back(); t.pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
+        a = get(); b = get();
+        (void)hipEventRecord(a, s);
+    }
+    ~family_timer() { (void)hipEventRecord(b, s); c->timing[which].pending.push_back({a, b}); }
+};
+
+void drain_timing(np_ctx* c)
+{
+    for (int w = 0; w < NP_NUM_FAMILIES; ++w) {
+        timing_t& t = c->timing[w];
+        for (auto& pr : t.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { t.total_ms += ms; t.launches += 1; t.last_ms = ms; }
+            t.pool.push_back(pr.first); t.pool.push_back(pr.second);
+        }
+        t.pending.clear();
+    }
+}
+
+hipStream_t pick_stream(np_ctx* c, void* s) { return s ? (hipStream_t)s : c->stream; }
+
+int persistent_blocks(np_ctx* c, int64_t work_items, int per_block, int blocks_per_cu)
+{
+    int64_t need = (work_items + per_block - 1) / per_block;
+    int64_t maxb = (int64_t)c->n_cu * blocks_per_cu;
+    if (need < 1) need = 1;
+    return (int)std::min(need, maxb);
+}
+
+// ---- kernel B driver: classify + one persistent launch per non-empty size class ----------------------
+int run_hmm_forward(np_ctx* c, hipStream_t s, int64_t n_jobs, const np_hmm_job_dev* jobs, const np_read_dev* reads,
+                    const float* event_mean, const uint16_t* ranks, int model, float* out)
+{
+    if (n_jobs <= 0) return NP_OK;
+    if (model < 0 || model >= (int)c->models.size()) { c->err = "bad model id"; return NP_ERR_INVALID; }
+    if (n_jobs > 0xffffffffll) { c->err = "too many jobs in one call"; return NP_ERR_UNSUPPORTED; }
+    NP_HIP(c, c->order.reserve((size_t)NP_NUM_CLASSES * (size_t)n_jobs * sizeof(uint32_t)));
+    NP_HIP(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint32_t), s));
+    family_timer tm(c, 1, s);
+    NP_HIP(c, np_launch_classify(jobs, n_jobs, c->d_counters, c->order.as<uint32_t>(), out, NP_FLANK_LEN, s));
+    for (int cls = 0; cls < NP_NUM_CLASSES; ++cls) {
+        np_hmm_args a{};
+        a.jobs = jobs; a.order = c->order.as<uint32_t>() + (size_t)cls * (size_t)n_jobs; a.n_class_jobs = c->d_counters + cls;
+        a.reads = reads; a.event_mean = event_mean; a.ranks = ranks; a.model = c->models[model].d_states;
+        a.logsum = c->d_logsum; a.flank = c->d_flank; a.counter = c->d_counters + 8 + cls; a.out = out;
+        const int jobs_per_block = (np_hmm_block_threads() / 64) * (64 / NP_CLASS_SEG[cls]);
+        const int nb = persistent_blocks(c, n_jobs, jobs_per_block, c->hmm_blocks_per_cu);
+        NP_HIP(c, np_launch_hmm_forward(cls, a, nb, s));
+    }
+    return NP_OK;
+}
+
+int run_event_align(np_ctx* c, hipStream_t s, int n_reads, const np_read_dev* reads, const float* event_mean,
+                    const uint16_t* ranks, int model, int64_t max_bands, const int64_t* pair_off, np_pair* pairs,
+                    int32_t* pair_begin, int32_t* n_pairs)
+{
+    if (n_reads <= 0) return NP_OK;
+    if (model < 0 || model >= (int)c->models.size()) { c->err = "bad model id"; return NP_ERR_INVALID; }
+    const int waves_per_block = np_align_block_threads() / 64;
+    const int nb = persistent_blocks(c, n_reads, waves_per_block, c->align_blocks_per_cu);
+    const uint64_t stride = ((uint64_t)max_bands * 4 + 15) & ~15ull;
+    NP_HIP(c, c->trace.reserve((size_t)nb * waves_per_block * stride * sizeof(uint64_t)));
+    NP_HIP(c, hipMemsetAsync(c->d_counters + 16, 0, sizeof(uint32_t), s));
+    np_align_args a{};
+    a.reads = reads; a.event_mean = event_mean; a.ranks = ranks; a.model = c->models[model].d_states;
+    a.pair_off = pair_off; a.pairs = pairs; a.pair_begin = pair_begin; a.n_pairs = n_pairs;
+    a.trace = c->trace.as<uint64_t>(); a.trace_stride = stride; a.counter = c->d_counters + 16;
+    a.n_reads = n_reads; a.max_gap_threshold = c->params.max_gap_threshold;
+    a.min_average_log_emission = c->params.min_average_log_emission;
+    family_timer tm(c, 0, s);
+    NP_HIP(c, np_launch_event_align(a, nb, s));
+    return NP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* np_version(void) { return NP_VERSION_STR; }
+
+const char* np_last_error(const np_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+np_ctx* np_create(int device, const np_params* params)
+{
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        g_create_err = std::string("np_create: no HIP device (") + hipGetErrorString(e) + "); this library has no CPU fallback";
+        return nullptr;
+    }
+    if (device < 0 || device >= n_dev) { g_create_err = "np_create: bad device ordinal"; return nullptr; }
+    if ((e = hipSetDevice(device)) != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return nullptr; }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { g_create_err = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e); return nullptr; }
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+        g_create_err = std::string("np_create: device is ") + prop.gcnArchName + ", kernels are built for gfx950 only";
+        return nullptr;
+    }
+    np_ctx* c = new np_ctx();
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount;
+    if (params) c->params = *params; else np_default_params(&c->params);
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+
+    // p7_FLogsum table, src/common/logsum.cpp:57-69 (host libm, as the reference's static initialiser)
+    std::vector<float> tbl(NP_LOGSUM_TBL);
+    for (int i = 0; i < NP_LOGSUM_TBL; i++) tbl[i] = (float)log(1. + exp((double)-i / 1000.f));
+    // universal clip-flank table: pre_flank[i] (src/hmm/nanopolish_profile_hmm_r9.inl:204-226); post_flank[i] of an
+    // e-event window is the same sequence read backwards, post_flank[i] == flank[e-1-i] (r9.inl:236-259).
+    std::vector<float> flank(NP_FLANK_LEN);
+    {
+        const double TRANS_CLIP_SELF = 0.9, TRANS_START_TO_CLIP = 0.5;
+        const float bg = -3.0f;   // log_probability_background, src/hmm/nanopolish_emissions.h:98-103
+        flank[0] = (float)log(1 - TRANS_START_TO_CLIP);
+        flank[1] = (float)(log(TRANS_START_TO_CLIP) + bg + log(1 - TRANS_CLIP_SELF));
+        for (size_t i = 2; i < flank.size(); ++i) flank[i] = (float)(log(TRANS_CLIP_SELF) + bg + flank[i - 1]);
+    }
+    // the device code carries (float)log(0.3989422804014327) as a literal: check it against this host's libm
+    if ((float)log(0.3989422804014327) != -0.918938518f) { g_create_err = "np_create: log_inv_sqrt_2pi literal mismatch"; ok = false; }
+
+    c->h_logsum = tbl;
+    ok = ok && hipMalloc((void**)&c->d_logsum, tbl.size() * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_flank, flank.size() * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_counters, 64 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemcpy(c->d_logsum, tbl.data(), tbl.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(c->d_flank, flank.data(), flank.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemset(c->d_counters, 0, 64 * sizeof(uint32_t)) == hipSuccess;
+    if (!ok) {
+        if (g_create_err.empty()) g_create_err = "np_create: device allocation failed";
+        np_destroy(c);
+        return nullptr;
+    }
+    g_create_err.clear();
+    return c;
+}
+
+void np_destroy(np_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& m : c->models) if (m.d_states) (void)hipFree(m.d_states);
+    if (c->d_logsum) (void)hipFree(c->d_logsum);
+    if (c->d_flank) (void)hipFree(c->d_flank);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    dev_buf* bufs[] = {&c->order, &c->trace, &c->b_jobs, &c->b_reads, &c->b_events, &c->b_ranks, &c->b_out, &c->b_pair_off,
+                       &c->b_pairs, &c->b_pair_begin, &c->b_n_pairs, &c->b_vm, &c->b_bp, &c->b_cell_off, &c->b_state_off,
+                       &c->b_states, &c->b_n_states};
+    for (dev_buf* b : bufs) b->release();
+    for (auto& t : c->timing) {
+        for (auto& pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        for (auto& ev : t.pool) (void)hipEventDestroy(ev);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int np_register_model(np_ctx* c, int k, int n_states, const double* level_mean, const double* level_stdv,
+                      const double* level_log_stdv)
+{
+    if (!c || n_states <= 0 || n_states > 65536 || !level_mean || !level_stdv || !level_log_stdv) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    std::vector<np_state_dev> st(n_states);
+    for (int i = 0; i < n_states; ++i) { st[i].level_mean = level_mean[i]; st[i].level_stdv = level_stdv[i]; st[i].level_log_stdv = level_log_stdv[i]; st[i].pad = 0; }
+    model_t m; m.k = k; m.n_states = n_states; m.level_mean.assign(level_mean, level_mean + n_states);
+    NP_HIP(c, hipMalloc((void**)&m.d_states, st.size() * sizeof(np_state_dev)));
+    NP_HIP(c, hipMemcpy(m.d_states, st.data(), st.size() * sizeof(np_state_dev), hipMemcpyHostToDevice));
+    c->models.push_back(std::move(m));
+    return (int)c->models.size() - 1;
+}
+
+int np_sync(np_ctx* c, void* stream)
+{
+    if (!c) return NP_ERR_INVALID;
+    NP_HIP(c, hipStreamSynchronize(pick_stream(c, stream)));
+    drain_timing(c);
+    return NP_OK;
+}
+
+int np_kernel_time(np_ctx* c, int which, double* total_ms, int64_t* launches, int reset)
+{
+    if (!c || which < 0 || which >= NP_NUM_FAMILIES) return NP_ERR_INVALID;
+    drain_timing(c);
+    if (total_ms) *total_ms = c->timing[which].total_ms;
+    if (launches) *launches = c->timing[which].launches;
+    if (reset) { c->timing[which].total_ms = 0; c->timing[which].launches = 0; }
+    return NP_OK;
+}
+
+int np_last_kernel_ms(np_ctx* c, int which, float* ms)
+{
+    if (!c || which < 0 || which >= NP_NUM_FAMILIES || !ms) return NP_ERR_INVALID;
+    drain_timing(c);
+    *ms = c->timing[which].last_ms;
+    return NP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// device-resident entry points
+// ---------------------------------------------------------------------------------------------------------
+int np_event_align_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* reads, const float* event_mean,
+                       const uint16_t* kmer_rank, int model, int64_t max_bands, const int64_t* pair_off,
+                       np_pair* pairs_out, int32_t* pair_begin, int32_t* n_pairs)
+{
+    if (!c) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    return run_event_align(c, pick_stream(c, stream), n_reads, reads, event_mean, kmer_rank, model, max_bands,
+                           pair_off, pairs_out, pair_begin, n_pairs);
+}
+
+int np_hmm_score_dev(np_ctx* c, void* stream, int64_t n_jobs, const np_hmm_job_dev* jobs, const np_read_dev* reads,
+                     const float* event_mean, const uint16_t* job_kmer_rank, int model, float* out_scores)
+{
+    if (!c) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    return run_hmm_forward(c, pick_stream(c, stream), n_jobs, jobs, reads, event_mean, job_kmer_rank, model, out_scores);
+}
+
+int np_resolve_jobs_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* reads, const int64_t* pair_off,
+                        const np_pair* pairs, const int32_t* pair_begin, const int32_t* n_pairs, int32_t* map_start,
+                        double* events_per_base, int64_t n_jobs, np_hmm_job_dev* jobs, const int32_t* kpos)
+{
+    if (!c) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = pick_stream(c, stream);
+    family_timer tm(c, 2, s);
+    NP_HIP(c, np_launch_build_map(n_reads, reads, pair_off, pairs, pair_begin, n_pairs, map_start, events_per_base,
+                                  c->params.hmm_indel_bias_factor, s));
+    NP_HIP(c, np_launch_resolve(n_jobs, jobs, reads, n_pairs, events_per_base, map_start, kpos, s));
+    return NP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host-buffer ("drop-in") entry points: pack -> upload -> kernels -> download, synchronous
+// ---------------------------------------------------------------------------------------------------------
+static int pack_hmm_jobs(np_ctx* c, int n_jobs, const np_hmm_job* jobs, std::vector<np_hmm_job_dev>& dj,
+                         std::vector<np_read_dev>& dr, std::vector<float>& ev, std::vector<uint16_t>& rk, int* model_out)
+{
+    int model = -1;
+    dj.resize(n_jobs); dr.resize(n_jobs);
+    for (int j = 0; j < n_jobs; ++j) {
+        const np_hmm_job& q = jobs[j];
+        if (!q.event_mean || !q.kmer_rank || q.n_kmers == 0 || q.n_kmers > NP_MAX_KMERS ||
+            (q.stride != 1 && q.stride != -1) || q.e_start >= q.n_events_total || q.e_stop >= q.n_events_total) {
+            c->err = "np_hmm_job: invalid field"; return q.n_kmers > NP_MAX_KMERS ? NP_ERR_UNSUPPORTED : NP_ERR_INVALID;
+        }
+        // the reference asserts rc <=> stride == -1 and walks events from e_start by stride (r9.inl:275,342)
+        if ((q.stride == 1 && q.e_stop < q.e_start) || (q.stride == -1 && q.e_stop > q.e_start)) { c->err = "np_hmm_job: stride disagrees with e_start/e_stop"; return NP_ERR_INVALID; }
+        if (model < 0) model = q.model; else if (model != q.model) { c->err = "one model per batch"; return NP_ERR_UNSUPPORTED; }
+        const uint32_t lo = std::min(q.e_start, q.e_stop), hi = std::max(q.e_start, q.e_stop);
+        if ((uint64_t)(hi - lo) + 1 > NP_FLANK_LEN) { c->err = "event window too long"; return NP_ERR_UNSUPPORTED; }
+        np_read_dev& r = dr[j];
+        memset(&r, 0, sizeof(r));
+        r.scale = q.scale; r.shift = q.shift; r.var = q.var; r.log_var = log(q.var);
+        r.event_off = (int64_t)ev.size() - (int64_t)lo;      // ev[event_off + event_idx] addresses the packed window
+        r.n_events = q.n_events_total;
+        np_transitions(q.events_per_base, c->params.hmm_indel_bias_factor, r.trans);
+        ev.insert(ev.end(), q.event_mean + lo, q.event_mean + hi + 1);
+        np_hmm_job_dev& d = dj[j];
+        d.rank_off = (int64_t)rk.size(); d.n_kmers = q.n_kmers; d.read = (uint32_t)j;
+        d.e_start = q.e_start; d.e_stop = q.e_stop; d.stride = q.stride; d.flags = q.flags;
+        rk.insert(rk.end(), q.kmer_rank, q.kmer_rank + q.n_kmers);
+    }
+    *model_out = model;
+    return NP_OK;
+}
+
+int np_hmm_score_host(np_ctx* c, int n_jobs, const np_hmm_job* jobs, float* out_scores)
+{
+    if (!c || n_jobs < 0 || (n_jobs > 0 && (!jobs || !out_scores))) return NP_ERR_INVALID;
+    if (n_jobs == 0) return NP_OK;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    std::vector<np_hmm_job_dev> dj; std::vector<np_read_dev> dr; std::vector<float> ev; std::vector<uint16_t> rk;
+    int model = -1;
+    int rc = pack_hmm_jobs(c, n_jobs, jobs, dj, dr, ev, rk, &model);
+    if (rc != NP_OK) return rc;
+    hipStream_t s = c->stream;
+    NP_HIP(c, c->b_jobs.reserve(dj.size() * sizeof(np_hmm_job_dev)));
+    NP_HIP(c, c->b_reads.reserve(dr.size() * sizeof(np_read_dev)));
+    NP_HIP(c, c->b_events.reserve(ev.size() * sizeof(float)));
+    NP_HIP(c, c->b_ranks.reserve(rk.size() * sizeof(uint16_t)));
+    NP_HIP(c, c->b_out.reserve((size_t)n_jobs * sizeof(float)));
+    NP_HIP(c, hipMemcpyAsync(c->b_jobs.p, dj.data(), dj.size() * sizeof(np_hmm_job_dev), hipMemcpyHostToDevice, s));
+    NP_HIP(c, hipMemcpyAsync(c->b_reads.p, dr.data(), dr.size() * sizeof(np_read_dev), hipMemcpyHostToDevice, s));
+    NP_HIP(c, hipMemcpyAsync(c->b_events.p, ev.data(), ev.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    NP_HIP(c, hipMemcpyAsync(c->b_ranks.p, rk.data(), rk.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+    rc = run_hmm_forward(c, s, n_jobs, c->b_jobs.as<np_hmm_job_dev>(), c->b_reads.as<np_read_dev>(),
+                         c->b_events.as<float>(), c->b_ranks.as<uint16_t>(), model, c->b_out.as<float>());
+    if (rc != NP_OK) return rc;
+    NP_HIP(c, hipMemcpyAsync(out_scores, c->b_out.p, (size_t)n_jobs * sizeof(float), hipMemcpyDeviceToHost, s));
+    NP_HIP(c, hipStreamSynchronize(s));
+    drain_timing(c);
+    return NP_OK;
+}
+
+// profile_hmm_score_set (src/hmm/nanopolish_profile_hmm.cpp:32-56): the per-sequence forward scores come from the
+// device; the (tiny) combination  score = (+)_j (score_j - log n)  is done here in double with the same table.
+int np_hmm_score_set_host(np_ctx* c, int n_sets, const int32_t* set_off, const np_hmm_job* jobs, float* out_scores)
+{
+    if (!c || n_sets < 0 || (n_sets > 0 && (!set_off || !jobs || !out_scores))) return NP_ERR_INVALID;
+    if (n_sets == 0) return NP_OK;
+    const int n_jobs = set_off[n_sets];
+    std::vector<float> sc(n_jobs);
+    const int rc = np_hmm_score_host(c, n_jobs, jobs, sc.data());
+    if (rc != NP_OK) return rc;
+    const float* tbl = c->h_logsum.data();
+    auto add_logs = [&](double a, double b) -> double {      // add_logs -> p7_FLogsum, nanopolish_common.h:97-104
+        const float fa = (float)a, fb = (float)b;
+        const float mx = fa > fb ? fa : fb, mn = fa < fb ? fa : fb;
+        return (mn == -INFINITY || (mx - mn) >= 15.7f) ? mx : mx + tbl[(int)((mx - mn) * 1000.f)];
+    };
+    for (int q = 0; q < n_sets; ++q) {
+        const int b = set_off[q], n = set_off[q + 1] - b;
+        if (n <= 0) { out_scores[q] = -INFINITY; continue; }
+        const double pen = log((double)(size_t)n);
+        double score = sc[b] - pen;
+        for (int t = 1; t < n; ++t) { const double alt = sc[b + t] - pen; score = add_logs(score, alt); }
+        out_scores[q] = (float)score;
+    }
+    return NP_OK;
+}
+
+int np_hmm_align_host(np_ctx* c, int n_jobs, const np_hmm_job* jobs, np_hmm_state* out_states, int64_t cap, int64_t* out_off)
+{
+    if (!c || n_jobs < 0 || (n_jobs > 0 && (!jobs || !out_states || !out_off))) return NP_ERR_INVALID;
+    if (n_jobs == 0) return NP_OK;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    std::vector<np_hmm_job_dev> dj; std::vector<np_read_dev> dr; std::vector<float> ev; std::vector<uint16_t> rk;
+    int model = -1;
+    int rc = pack_hmm_jobs(c, n_jobs, jobs, dj, dr, ev, rk, &model);
+    if (rc != NP_OK) return rc;
+    std::vector<int64_t> cell_off(n_jobs + 1, 0), state_off(n_jobs + 1, 0);
+    for (int j = 0; j < n_jobs; ++j) {
+        const int64_t e = (int64_t)(dj[j].e_stop > dj[j].e_start ? dj[j].e_stop - dj[j].e_start : dj[j].e_start - dj[j].e_stop) + 1;
+        cell_off[j + 1] = cell_off[j] + e * 3 * (int64_t)dj[j].n_kmers;
+        state_off[j + 1] = state_off[j] + e + (int64_t)dj[j].n_kmers + 1;     // path length bound: e rows + n silent K hops
+    }
+    hipStream_t s = c->stream;
+    NP_HIP(c, c->b_jobs.reserve(dj.size() * sizeof(np_hmm_job_dev)));
+    NP_HIP(c, c->b_reads.reserve(dr.size() * sizeof(np_read_dev)));
+    NP_HIP(c, c->b_events.reserve(ev.size() * sizeof(float)));
+    NP_HIP(c, c->b_ranks.reserve(rk.size() * sizeof(uint16_t)));
+    NP_HIP(c, c->b_vm.reserve((size_t)cell_off[n_jobs] * sizeof(float)));
+    NP_HIP(c, c->b_bp.reserve((size_t)cell_off[n_jobs]));
+    NP_HIP(c, c->b_cell_off.reserve(cell_off.size() * sizeof(int64_t)));
+    NP_HIP(c, c->b_state_off.reserve(state_off.size() * sizeof(int64_t)));
+    NP_HIP(c, c->b_states.reserve((size_t)state_off[n_jobs] * sizeof(np_hmm_state)));
+    NP_HIP(c, c->b_n_states.reserve((size_t)n_jobs * sizeof(int32_t)));
+    NP_HIP(c, c->order.reserve((size_t)NP_NUM_CLASSES * (size_t)n_jobs * sizeof(uint32_t)));
+    NP_HIP(c, hipMemcpyAsync(c->b_jobs.p, dj.data(), dj.size() * sizeof(np_hmm_job_dev), hipMemcpyHostToDevice, s));
+    NP_HIP(c, hipMemcpyAsync(c->b_reads.p, dr.data(), dr.size() * sizeof(np_read_dev), hipMemcpyHostToDevice, s));
+    NP_HIP(c, hipMemcpyAsync(c->b_events.p, ev.data(), ev.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    NP_HIP(c, hipMemcpyAsync(c->b_ranks.p, rk.data(), rk.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+    NP_HIP(c, hipMemcpyAsync(c->b_cell_off.p, cell_off.data(), cell_off.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    NP_HIP(c, hipMemcpyAsync(c->b_state_off.p, state_off.data(), state_off.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    NP_HIP(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint32_t), s));
+    {
+        family_timer tm(c, 3, s);
+        NP_HIP(c, np_launch_classify(c->b_jobs.as<np_hmm_job_dev>(), n_jobs, c->d_counters, c->order.as<uint32_t>(), nullptr, NP_FLANK_LEN, s));
+        np_hmm_args a{};
+        a.jobs = c->b_jobs.as<np_hmm_job_dev>(); a.reads = c->b_reads.as<np_read_dev>(); a.event_mean = c->b_events.as<float>();
+        a.ranks = c->b_ranks.as<uint16_t>(); a.model = c->models[model].d_states; a.logsum = c->d_logsum; a.flank = c->d_flank;
+        a.vm = c->b_vm.as<float>(); a.bp = c->b_bp.as<uint8_t>(); a.cell_off = c->b_cell_off.as<int64_t>();
+        a.states = c->b_states.as<np_hmm_state>(); a.state_off = c->b_state_off.as<int64_t>(); a.n_states = c->b_n_states.as<int32_t>();
+        for (int cls = 0; cls < NP_NUM_CLASSES; ++cls) {
+            a.order = c->order.as<uint32_t>() + (size_t)cls * (size_t)n_jobs; a.n_class_jobs = c->d_counters + cls;
+            a.counter = c->d_counters + 8 + cls;
+            const int jobs_per_block = (np_hmm_block_threads() / 64) * (64 / NP_CLASS_SEG[cls]);
+            NP_HIP(c, np_launch_hmm_viterbi(cls, a, persistent_blocks(c, n_jobs, jobs_per_block, c->hmm_blocks_per_cu), s));
+        }
+        NP_HIP(c, np_launch_hmm_backtrack(a, n_jobs, s));
+    }
+    std::vector<int32_t> ns(n_jobs);
+    std::vector<np_hmm_state> st((size_t)state_off[n_jobs]);
+    NP_HIP(c, hipMemcpyAsync(ns.data(), c->b_n_states.p, ns.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    NP_HIP(c, hipMemcpyAsync(st.data(), c->b_states.p, st.size() * sizeof(np_hmm_state), hipMemcpyDeviceToHost, s));
+    NP_HIP(c, hipStreamSynchronize(s));
+    drain_timing(c);
+    int64_t w = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        out_off[j] = w;
+        if (w + ns[j] > cap) { c->err = "np_hmm_align_host: output capacity too small"; return NP_ERR_NOMEM; }
+        memcpy(out_states + w, st.data() + state_off[j], (size_t)ns[j] * sizeof(np_hmm_state));
+        w += ns[j];
+    }
+    out_off[n_jobs] = w;
+    return NP_OK;
+}
+
+int np_event_align_host(np_ctx* c, int n_jobs, const np_align_job* jobs, np_pair* out_pairs, int64_t cap, int64_t* out_off)
+{
+    if (!c || n_jobs < 0 || (n_jobs > 0 && (!jobs || !out_pairs || !out_off))) return NP_ERR_INVALID;
+    if (n_jobs == 0) return NP_OK;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    std::vector<np_read_dev> dr(n_jobs); std::vector<float> ev; std::vector<uint16_t> rk;
+    std::vector<int64_t> pair_off(n_jobs + 1, 0);
+    int model = -1; int64_t max_bands = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const np_align_job& q = jobs[j];
+        if (!q.event_mean || !q.kmer_rank || q.n_events == 0 || q.n_kmers == 0) { c->err = "np_align_job: invalid field"; return NP_ERR_INVALID; }
+        if (model < 0) model = q.model; else if (model != q.model) { c->err = "one model per batch"; return NP_ERR_UNSUPPORTED; }
+        np_fill_read_host(&dr[j], q.shift, q.scale, q.var, (int64_t)ev.size(), q.n_events, (int64_t)rk.size(), q.n_kmers);
+        ev.insert(ev.end(), q.event_mean, q.event_mean + q.n_events);
+        rk.insert(rk.end(), q.kmer_rank, q.kmer_rank + q.n_kmers);
+        const int64_t nb = (int64_t)q.n_events + q.n_kmers + 2;
+        pair_off[j + 1] = pair_off[j] + nb;
+        max_bands = std::max(max_bands, nb);
+    }
+    hipStream_t s = c->stream;
+    NP_HIP(c, c->b_reads.reserve(dr.size() * sizeof(np_read_dev)));
+    NP_HIP(c, c->b_events.reserve(ev.size() * sizeof(float)));
+    NP_HIP(c, c->b_ranks.reserve(rk.size() * sizeof(uint16_t)));
+    NP_HIP(c, c->b_pair_off.reserve(pair_off.size() * sizeof(int64_t)));
+    NP_HIP(c, c->b_pairs.reserve((size_t)pair_off[n_jobs] * sizeof(np_pair)));
+    NP_HIP(c, c->b_pair_begin.reserve((size_t)n_jobs * sizeof(int32_t)));
+    NP_HIP(c, c->b_n_pairs.reserve((size_t)n_jobs * sizeof(int32_t)));
+    NP_HIP(c, hipMemcpyAsync(c->b_reads.p, dr.data(), dr.size() * sizeof(np_read_dev), hipMemcpyHostToDevice, s));
+    NP_HIP(c, hipMemcpyAsync(c->b_events.p, ev.data(), ev.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    NP_HIP(c, hipMemcpyAsync(c->b_ranks.p, rk.data(), rk.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+    NP_HIP(c, hipMemcpyAsync(c->b_pair_off.p, pair_off.data(), pair_off.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    int rc = run_event_align(c, s, n_jobs, c->b_reads.as<np_read_dev>(), c->b_events.as<float>(), c->b_ranks.as<uint16_t>(),
+                             model, max_bands, c->b_pair_off.as<int64_t>(), c->b_pairs.as<np_pair>(),
+                             c->b_pair_begin.as<int32_t>(), c->b_n_pairs.as<int32_t>());
+    if (rc != NP_OK) return rc;
+    std::vector<np_pair> hp((size_t)pair_off[n_jobs]);
+    std::vector<int32_t> hb(n_jobs), hn(n_jobs);
+    NP_HIP(c, hipMemcpyAsync(hp.data(), c->b_pairs.p, hp.size() * sizeof(np_pair), hipMemcpyDeviceToHost, s));
+    NP_HIP(c, hipMemcpyAsync(hb.data(), c->b_pair_begin.p, hb.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    NP_HIP(c, hipMemcpyAsync(hn.data(), c->b_n_pairs.p, hn.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    NP_HIP(c, hipStreamSynchronize(s));
+    drain_timing(c);
+    int64_t w = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        out_off[j] = w;
+        if (w + hn[j] > cap) { c->err = "np_event_align_host: output capacity too small"; return NP_ERR_NOMEM; }
+        memcpy(out_pairs + w, hp.data() + pair_off[j] + hb[j], (size_t)hn[j] * sizeof(np_pair));
+        w += hn[j];
+    }
+    out_off[n_jobs] = w;
+    return NP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,68 @@
+// np_device.h -- shared device-side definitions for the gfx950 kernels.
+//
+// Numerics contract: every expression below keeps the reference's
+// evaluation order and rounding points; the translation units are compiled with -ffp-contract=off so
+// hipcc never fuses a*b+c (the reference x86-64 build has no FMA, Makefile:12-13 of the reference).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/np_hmm.h"
+
+#define NP_LOGSUM_TBL 16000
+#define NP_NEG_INF (-__builtin_inff())
+
+// Pore-model state on the device: the three doubles the path reads, padded to 32 B so one state is
+// two aligned 16-byte loads (PoreModelStateParams, src/pore_model/nanopolish_poremodel.h:20-36).
+struct __attribute__((aligned(32))) np_state_dev {
+    double level_mean, level_stdv, level_log_stdv, pad;
+};
+
+// p7_FLogsum (src/common/logsum.h:55-66) on an LDS-resident copy of flogsum_lookup.
+// Both-(-inf) inputs: max-min is NaN, the (min == -inf) test selects max, the clamped index is discarded.
+__device__ __forceinline__ float np_lse(float a, float b, const float* __restrict__ tbl)
+{
+    const float mx = a > b ? a : b;   // ESL_MAX
+    const float mn = a < b ? a : b;   // ESL_MIN
+    const float d = mx - mn;
+    uint32_t idx = (uint32_t)(int)(d * 1000.f);      // (int) truncation, as the reference
+    idx = idx < (NP_LOGSUM_TBL - 1) ? idx : (NP_LOGSUM_TBL - 1);
+    const float t = tbl[idx];
+    return (mn == NP_NEG_INF || d >= 15.7f) ? mx : mx + t;
+}
+
+// get_scaled_gaussian_from_pore_model_state (src/nanopolish_squiggle_read.h:217-226): double math, float store.
+// Returns (mean, stdv, log_inv_sqrt_2pi - log_stdv): the last is the left-associated prefix of
+// log_normal_pdf (src/hmm/nanopolish_emissions.h:51-55).
+struct np_gauss { float mean, stdv, cl; };
+__device__ __forceinline__ np_gauss np_scale_state(const np_state_dev* __restrict__ model, uint32_t rank,
+                                                   double scale, double shift, double var, double log_var)
+{
+    const double lm = model[rank].level_mean, ls = model[rank].level_stdv, ll = model[rank].level_log_stdv;
+    np_gauss g;
+    g.mean = (float)(scale * lm + shift);
+    g.stdv = (float)(ls * var);
+    const float log_stdv = (float)(ll + log_var);
+    const float log_inv_sqrt_2pi = -0.918938518f;   // (float)log(0.3989422804014327), emissions.h:43; checked on the host at np_create
+    g.cl = log_inv_sqrt_2pi - log_stdv;
+    return g;
+}
+
+// log_probability_match_r9 (src/hmm/nanopolish_emissions.h:57-68) with drift == 0.
+__device__ __forceinline__ float np_emission(float x, const np_gauss& g)
+{
+    const float a = (x - g.mean) / g.stdv;     // IEEE-correct fp32 divide (hipcc default for HIP)
+    return g.cl + (-0.5f * a * a);
+}
+
+// Wave-level shift by one lane towards higher lane ids (lane j receives lane j-1); lane 0 receives `fill`.
+// DPP wave_shr:1 (0x138) exists on gfx9-family ISAs including gfx950.
+__device__ __forceinline__ float np_wave_shr1(float v, float fill)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v),
+                                                                 0x138, 0xf, 0xf, false));
+}
+// Rotate right by one lane across the whole wave (lane j receives lane j-1, lane 0 receives lane 63): wave_ror:1 (0x13C).
+__device__ __forceinline__ float np_wave_ror1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xf, 0xf, false));
+}

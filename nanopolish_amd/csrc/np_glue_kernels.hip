@@ -1,0 +1,161 @@
+// np_glue_kernels.hip -- the read-level glue between the aligner and the HMM, kept on the device so the
+// fused call-methylation pass needs no host round trip:
+//   * np_build_map_kernel : base_to_event_map[].start + events_per_base (src/nanopolish_squiggle_read.cpp:273-301)
+//                           and the per-read HMM transitions (src/hmm/nanopolish_profile_hmm_r9.inl:17-76)
+//   * np_resolve_kernel   : get_closest_event_to (src/nanopolish_squiggle_read.cpp:161-186) for both window
+//                           bounds of every work item + the skip rules of calculate_methylation_for_read
+//                           (src/basemods/nanopolish_basemods.cpp:352-358) and the events-per-base QC
+//                           (src/nanopolish_squiggle_read.cpp:332)
+//   * np_classify_kernel  : bins HMM work items into the (lanes, blocks-per-lane) size classes of np_hmm_kernels.hip
+#include "np_kernels.h"
+#include "np_logf.h"
+
+namespace {
+
+__global__ void __launch_bounds__(64) np_build_map_kernel(int n_reads, np_read_dev* reads, const int64_t* pair_off,
+                                                          const np_pair* pairs, const int32_t* pair_begin,
+                                                          const int32_t* n_pairs, int32_t* map_start,
+                                                          double* events_per_base, double indel_bias)
+{
+    const int ri = blockIdx.x;
+    if (ri >= n_reads) return;
+    const int lane = threadIdx.x;
+    np_read_dev* rd = reads + ri;
+    const int K = (int)rd->n_kmers;
+    int32_t* ms = map_start + rd->rank_off;
+    for (int k = lane; k < K; k += 64) ms[k] = -1;            // IndexPair(): start = -1
+    const int np_ = n_pairs[ri];
+    if (np_ <= 0) {
+        // failed alignment: events cleared, events_per_base = 0 (squiggle_read.cpp:324-329)
+        if (lane == 0) { events_per_base[ri] = 0.0; np_transitions(0.0, indel_bias, rd->trans); }
+        return;
+    }
+    __syncthreads();
+    const np_pair* p = pairs + pair_off[ri] + pair_begin[ri];
+    for (int i = lane; i < np_; i += 64) {
+        const np_pair c = p[i];
+        const int prev_e = i > 0 ? p[i - 1].read_pos : -1;    // prev_event_idx = -1 initially (:281)
+        if (c.read_pos != prev_e)                              // only the first k-mer an event touches records it
+            atomicMin((unsigned int*)&ms[c.ref_pos], (unsigned int)c.read_pos);   // first (== smallest) wins: elem.start
+    }
+    if (lane == 0) {
+        const size_t min_event = (size_t)p[0].read_pos, max_event = (size_t)p[np_ - 1].read_pos;  // path is monotone
+        const double epb = (double)(max_event - min_event) / (double)(size_t)K;                    // :301
+        events_per_base[ri] = epb;
+        np_transitions(epb, indel_bias, rd->trans);
+    }
+}
+
+// get_next_event / get_closest_event_to, squiggle_read.cpp:161-186
+__device__ __forceinline__ int closest_event(const int32_t* ms, int K, int k_idx)
+{
+    const int stop_before = 0 > k_idx - 1000 ? 0 : k_idx - 1000;
+    const int stop_after = k_idx + 1000 < K - 1 ? k_idx + 1000 : K - 1;
+    int event_before = -1, event_after = -1;
+    for (int s = k_idx; s != stop_before; s -= 1) { const int ei = ms[s]; if (ei != -1) { event_before = ei; break; } }
+    if (event_before != -1) return event_before;
+    for (int s = k_idx; s != stop_after; s += 1) { const int ei = ms[s]; if (ei != -1) { event_after = ei; break; } }
+    return event_after;
+}
+
+__global__ void __launch_bounds__(256) np_resolve_kernel(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads,
+                                                         const int32_t* n_pairs, const double* events_per_base,
+                                                         const int32_t* map_start, const int32_t* kpos)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_jobs) return;
+    np_hmm_job_dev job = jobs[j];
+    const np_read_dev* rd = reads + job.read;
+    bool ok = n_pairs[job.read] > 0 && !(events_per_base[job.read] > 5.0);
+    int e1 = -1, e2 = -1;
+    if (ok) {
+        const int32_t* ms = map_start + rd->rank_off;
+        const int K = (int)rd->n_kmers;
+        const int k1 = kpos[2 * j], k2 = kpos[2 * j + 1];
+        if (k1 < 0 || k1 >= K || k2 < 0 || k2 >= K) ok = false;
+        else {
+            e1 = closest_event(ms, K, k1);
+            e2 = closest_event(ms, K, k2);
+            const int d = e2 - e1;
+            if (e1 < 0 || e2 < 0 || (d < 0 ? -d : d) <= 10) ok = false;     // basemods.cpp:356
+        }
+    }
+    if (ok) {
+        job.e_start = (uint32_t)e1; job.e_stop = (uint32_t)e2;
+        job.stride = e1 <= e2 ? 1 : -1;                                      // basemods.cpp:370
+    } else {
+        job.n_kmers = 0;
+    }
+    jobs[j] = job;
+}
+
+__device__ __forceinline__ int size_class(uint32_t n)
+{
+    if (n == 0) return -1;
+    if (n <= 16) return 0;
+    if (n <= 32) return 1;
+    if (n <= 64) return 2;
+    if (n <= 128) return 3;
+    if (n <= 256) return 4;
+    if (n <= 512) return 5;
+    if (n <= 1024) return 6;
+    return -1;
+}
+
+__global__ void __launch_bounds__(256) np_classify_kernel(const np_hmm_job_dev* jobs, int64_t n_jobs,
+                                                          uint32_t* class_count, uint32_t* order, float* out_scores, uint32_t flank_len)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int cls = -1;
+    if (j < n_jobs) {
+        const np_hmm_job_dev jb = jobs[j];
+        const uint32_t e = (jb.e_stop > jb.e_start ? jb.e_stop - jb.e_start : jb.e_start - jb.e_stop) + 1u;
+        cls = e <= flank_len ? size_class(jb.n_kmers) : -1;
+        if (cls < 0 && out_scores) out_scores[j] = __builtin_nanf("");
+    }
+    // wave-aggregated append: one atomic per (wave, class)
+#pragma unroll
+    for (int c = 0; c < NP_NUM_CLASSES; ++c) {
+        const uint64_t m = __ballot(cls == c);
+        if (m == 0) continue;
+        const int leader = __ffsll((unsigned long long)m) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&class_count[c], (uint32_t)__popcll(m));
+        base = __shfl(base, leader, 64);
+        if (cls == c) {
+            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            order[(size_t)c * (size_t)n_jobs + pos] = (uint32_t)j;
+        }
+    }
+}
+
+} // namespace
+
+hipError_t np_launch_classify(const np_hmm_job_dev* jobs, int64_t n_jobs, uint32_t* class_count, uint32_t* order,
+                              float* out_scores, uint32_t flank_len, hipStream_t s)
+{
+    if (n_jobs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(np_classify_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, s,
+                       jobs, n_jobs, class_count, order, out_scores, flank_len);
+    return hipGetLastError();
+}
+
+hipError_t np_launch_build_map(int n_reads, np_read_dev* reads, const int64_t* pair_off, const np_pair* pairs,
+                               const int32_t* pair_begin, const int32_t* n_pairs, int32_t* map_start,
+                               double* events_per_base, double indel_bias, hipStream_t s)
+{
+    if (n_reads <= 0) return hipSuccess;
+    hipLaunchKernelGGL(np_build_map_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, reads, pair_off, pairs,
+                       pair_begin, n_pairs, map_start, events_per_base, indel_bias);
+    return hipGetLastError();
+}
+
+hipError_t np_launch_resolve(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads, const int32_t* n_pairs,
+                             const double* events_per_base, const int32_t* map_start, const int32_t* kpos, hipStream_t s)
+{
+    if (n_jobs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(np_resolve_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, s,
+                       n_jobs, jobs, reads, n_pairs, events_per_base, map_start, kpos);
+    return hipGetLastError();
+}

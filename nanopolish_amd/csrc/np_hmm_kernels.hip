@@ -1,0 +1,370 @@
+// np_hmm_kernels.hip -- profile-HMM forward (profile_hmm_score) and Viterbi (profile_hmm_align) for gfx950.
+//
+// Replaces profile_hmm_fill_generic_r9 (src/hmm/nanopolish_profile_hmm_r9.inl:265-433) and its two output
+// writers (r9.inl:79-197).  Design (DESIGN.md section "Kernel B"):
+//   * The lattice never exists in memory for the forward pass.  A job (e events x n k-mer blocks x 3 states)
+//     is swept along anti-diagonals: lane j owns C consecutive k-mer blocks and, at step t, computes row
+//     r = t - j of them.  Row r-1 of its own blocks is in its registers, rows r and r-1 of the block to its
+//     left arrive through one DPP wave_shr:1 per state per step.  K(r,b) <- K(r,b-1) chains through the lane's
+//     own C blocks inside the step and across lanes through the anti-diagonal skew.
+//   * Jobs are short (typ. 38 x 16), so 64/SEG jobs share a wave in SEG-lane segments (SEG = 16/32/64).
+//   * p7_FLogsum's 16000-entry table (64 KB) lives in LDS, one copy per 512-thread workgroup.
+//   * Reduction order is the reference's: six terms in HMMMovementType order for M (r9.h:61-70), lp_end
+//     accumulated row-ascending M,B,K by the lane that owns the last k-mer (r9.inl:388-396).
+// All arithmetic is fp32 exactly as the reference; compile with -ffp-contract=off.
+#include "np_kernels.h"
+
+#define NP_HMM_BLOCK 512
+
+namespace {
+
+template <int C>
+struct lane_state {
+    float M[C], B[C], K[C];
+};
+
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        int w = __shfl_xor(v, o, 64);
+        v = v > w ? v : w;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Forward
+// ---------------------------------------------------------------------------------------------------
+template <int SEG, int C>
+__global__ void __launch_bounds__(NP_HMM_BLOCK) np_hmm_forward_kernel(np_hmm_args a)
+{
+    __shared__ float tbl[NP_LOGSUM_TBL];
+    for (int i = threadIdx.x; i < NP_LOGSUM_TBL; i += NP_HMM_BLOCK) tbl[i] = a.logsum[i];
+    __syncthreads();
+
+    constexpr int JPW = 64 / SEG;                 // jobs per wave
+    const int lane = threadIdx.x & 63;
+    const int seg = lane / SEG, sl = lane % SEG;
+    const uint32_t n_jobs = *a.n_class_jobs;
+    const uint32_t n_packs = (n_jobs + JPW - 1) / JPW;
+
+    for (;;) {
+        uint32_t pack = 0;
+        if (lane == 0) pack = atomicAdd(a.counter, 1u);
+        pack = __builtin_amdgcn_readfirstlane(pack);
+        if (pack >= n_packs) break;
+
+        const uint32_t slot = pack * JPW + seg;
+        const bool has = slot < n_jobs;
+        const uint32_t jidx = has ? a.order[slot] : 0u;
+        const np_hmm_job_dev job = a.jobs[jidx];
+        const np_read_dev* rd = a.reads + job.read;
+        const int n = has ? (int)job.n_kmers : 0;
+        const int e = has ? (int)(job.e_stop > job.e_start ? job.e_stop - job.e_start : job.e_start - job.e_stop) + 1 : 0;
+        const int stride = job.stride;
+        const int lanes_used = (n + C - 1) / C;
+        const bool lane_on = has && sl < lanes_used;
+        const float* ev = a.event_mean + rd->event_off;
+        const bool pre_clip = (job.flags & NP_HAF_ALLOW_PRE_CLIP) != 0;
+        const bool post_clip = (job.flags & NP_HAF_ALLOW_POST_CLIP) != 0;
+
+        // per-read transitions (BlockTransitions, r9.h:75-95; identical for every k-mer, r9.inl:25-73)
+        const float lp_mm_self = rd->trans[0], lp_mb = rd->trans[1], lp_mk = rd->trans[2], lp_mm_next = rd->trans[3],
+                    lp_bb = rd->trans[4], lp_bk = rd->trans[5], lp_bm_next = rd->trans[6], lp_bm_self = rd->trans[7],
+                    lp_kk = rd->trans[8], lp_km = rd->trans[9];
+
+        // per-lane scaled Gaussians of this lane's C k-mer blocks
+        np_gauss g[C];
+        {
+            const double scale = rd->scale, shift = rd->shift, var = rd->var, log_var = rd->log_var;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int b = sl * C + c;
+                const uint32_t rank = (lane_on && b < n) ? a.ranks[job.rank_off + b] : 0u;
+                g[c] = np_scale_state(a.model, rank, scale, shift, var, log_var);
+            }
+        }
+
+        lane_state<C> cur;
+#pragma unroll
+        for (int c = 0; c < C; ++c) cur.M[c] = cur.B[c] = cur.K[c] = NP_NEG_INF;   // row 0 (r9.cpp:21-33)
+        float oM = NP_NEG_INF, oB = NP_NEG_INF, oK = NP_NEG_INF;   // left neighbour, row r-1
+        float lp_end = NP_NEG_INF;
+        const int last_lane = (n - 1) / C, last_c = (n - 1) % C;
+
+        const int steps = wave_max_i32(has ? e + lanes_used - 1 : 0);
+        for (int t = 1; t <= steps; ++t) {
+            // left neighbour's row r (what lane j-1 computed in step t-1); segment heads see block 0 = -inf
+            float nM = np_wave_shr1(cur.M[C - 1], NP_NEG_INF);
+            float nB = np_wave_shr1(cur.B[C - 1], NP_NEG_INF);
+            float nK = np_wave_shr1(cur.K[C - 1], NP_NEG_INF);
+            if (sl == 0) { nM = NP_NEG_INF; nB = NP_NEG_INF; nK = NP_NEG_INF; }
+
+            const int r = t - sl;
+            const bool act = lane_on && r >= 1 && r <= e;
+            if (act) {
+                const uint32_t event_idx = job.e_start + (uint32_t)((r - 1) * stride);   // r9.inl:342
+                const float x = ev[event_idx];
+                float lM_r = nM, lB_r = nB, lK_r = nK;     // block to the left, row r
+                float lM_p = oM, lB_p = oB, lK_p = oK;     // block to the left, row r-1
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float em = np_emission(x, g[c]);
+                    // PSR9_MATCH: HMT_FROM_SAME_M, PREV_M, SAME_B, PREV_B, PREV_K, SOFT (r9.inl:350-365)
+                    float s = lp_mm_self + cur.M[c];
+                    s = np_lse(s, lp_mm_next + lM_p, tbl);
+                    s = np_lse(s, lp_bm_self + cur.B[c], tbl);
+                    s = np_lse(s, lp_bm_next + lB_p, tbl);
+                    s = np_lse(s, lp_km + lK_p, tbl);
+                    if (c == 0) {
+                        const float soft = (sl == 0 && (r == 1 || pre_clip)) ? a.flank[r - 1] : NP_NEG_INF;
+                        s = np_lse(s, soft, tbl);
+                    }
+                    const float newM = s + em;
+                    // PSR9_BAD_EVENT (r9.inl:368-374): only SAME_M and SAME_B are finite; emission 0
+                    const float newB = np_lse(lp_mb + cur.M[c], lp_bb + cur.B[c], tbl);
+                    // PSR9_KMER_SKIP (r9.inl:377-383): PREV_M, PREV_B, PREV_K of the SAME row
+                    const float newK = np_lse(np_lse(lp_mk + lM_r, lp_bk + lB_r, tbl), lp_kk + lK_r, tbl);
+
+                    lM_p = cur.M[c]; lB_p = cur.B[c]; lK_p = cur.K[c];
+                    lM_r = newM; lB_r = newB; lK_r = newK;
+                    cur.M[c] = newM; cur.B[c] = newB; cur.K[c] = newK;
+
+                    // end state (r9.inl:388-396): last k-mer, M then B then K
+                    if (sl == last_lane && c == last_c && (post_clip || r == e)) {
+                        const float pf = a.flank[e - r];          // post_flank[row-1]
+                        lp_end = np_lse(lp_end, newM + pf, tbl);
+                        lp_end = np_lse(lp_end, newB + pf, tbl);
+                        lp_end = np_lse(lp_end, newK + pf, tbl);
+                    }
+                }
+            }
+            oM = nM; oB = nB; oK = nK;
+        }
+        if (has && sl == last_lane) a.out[jidx] = lp_end;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Viterbi fill (ProfileHMMViterbiOutputR9, r9.inl:130-197): same sweep, max/arg-max with later-wins ties,
+// lattice + back-pointers streamed to HBM in row-major [row][3*n] (block 0 / terminal block omitted).
+// ---------------------------------------------------------------------------------------------------
+struct vmax { float v; uint8_t from; };
+__device__ __forceinline__ void vit_step(vmax& m, float x, uint8_t i)
+{
+    m.v = x > m.v ? x : m.v;
+    m.from = (m.v == x) ? i : m.from;
+}
+
+template <int SEG, int C>
+__global__ void __launch_bounds__(NP_HMM_BLOCK) np_hmm_viterbi_kernel(np_hmm_args a)
+{
+    constexpr int JPW = 64 / SEG;
+    const int lane = threadIdx.x & 63;
+    const int seg = lane / SEG, sl = lane % SEG;
+    const uint32_t n_jobs = *a.n_class_jobs;
+    const uint32_t n_packs = (n_jobs + JPW - 1) / JPW;
+
+    for (;;) {
+        uint32_t pack = 0;
+        if (lane == 0) pack = atomicAdd(a.counter, 1u);
+        pack = __builtin_amdgcn_readfirstlane(pack);
+        if (pack >= n_packs) break;
+
+        const uint32_t slot = pack * JPW + seg;
+        const bool has = slot < n_jobs;
+        const uint32_t jidx = has ? a.order[slot] : 0u;
+        const np_hmm_job_dev job = a.jobs[jidx];
+        const np_read_dev* rd = a.reads + job.read;
+        const int n = has ? (int)job.n_kmers : 0;
+        const int e = has ? (int)(job.e_stop > job.e_start ? job.e_stop - job.e_start : job.e_start - job.e_stop) + 1 : 0;
+        const int stride = job.stride;
+        const int lanes_used = (n + C - 1) / C;
+        const bool lane_on = has && sl < lanes_used;
+        const float* ev = a.event_mean + rd->event_off;
+        const bool pre_clip = (job.flags & NP_HAF_ALLOW_PRE_CLIP) != 0;
+        const int64_t cell0 = has ? a.cell_off[jidx] : 0;
+        float* vm = a.vm + cell0;          // [(row-1)*3n + 3*b + state], rows 1..e
+        uint8_t* bp = a.bp + cell0;
+        const int rowlen = 3 * n;
+
+        const float lp_mm_self = rd->trans[0], lp_mb = rd->trans[1], lp_mk = rd->trans[2], lp_mm_next = rd->trans[3],
+                    lp_bb = rd->trans[4], lp_bk = rd->trans[5], lp_bm_next = rd->trans[6], lp_bm_self = rd->trans[7],
+                    lp_kk = rd->trans[8], lp_km = rd->trans[9];
+
+        np_gauss g[C];
+        {
+            const double scale = rd->scale, shift = rd->shift, var = rd->var, log_var = rd->log_var;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int b = sl * C + c;
+                const uint32_t rank = (lane_on && b < n) ? a.ranks[job.rank_off + b] : 0u;
+                g[c] = np_scale_state(a.model, rank, scale, shift, var, log_var);
+            }
+        }
+
+        lane_state<C> cur;
+#pragma unroll
+        for (int c = 0; c < C; ++c) cur.M[c] = cur.B[c] = cur.K[c] = NP_NEG_INF;
+        float oM = NP_NEG_INF, oB = NP_NEG_INF, oK = NP_NEG_INF;
+
+        const int steps = wave_max_i32(has ? e + lanes_used - 1 : 0);
+        for (int t = 1; t <= steps; ++t) {
+            float nM = np_wave_shr1(cur.M[C - 1], NP_NEG_INF);
+            float nB = np_wave_shr1(cur.B[C - 1], NP_NEG_INF);
+            float nK = np_wave_shr1(cur.K[C - 1], NP_NEG_INF);
+            if (sl == 0) { nM = NP_NEG_INF; nB = NP_NEG_INF; nK = NP_NEG_INF; }
+
+            const int r = t - sl;
+            const bool act = lane_on && r >= 1 && r <= e;
+            if (act) {
+                const uint32_t event_idx = job.e_start + (uint32_t)((r - 1) * stride);
+                const float x = ev[event_idx];
+                float lM_r = nM, lB_r = nB, lK_r = nK;
+                float lM_p = oM, lB_p = oB, lK_p = oK;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const int b = sl * C + c;
+                    const float em = np_emission(x, g[c]);
+                    // MATCH: all six candidates in enum order, later index wins ties (r9.inl:138-143)
+                    vmax m; m.v = lp_mm_self + cur.M[c]; m.from = 0;
+                    vit_step(m, lp_mm_next + lM_p, 1);
+                    vit_step(m, lp_bm_self + cur.B[c], 2);
+                    vit_step(m, lp_bm_next + lB_p, 3);
+                    vit_step(m, lp_km + lK_p, 4);
+                    const float soft = (c == 0 && sl == 0 && (r == 1 || pre_clip)) ? a.flank[r - 1] : NP_NEG_INF;
+                    vit_step(m, soft, 5);
+                    const float newM = m.v + em;
+                    // BAD_EVENT: x = [mb+M, -inf, bb+B, -inf, -inf, -inf]
+                    vmax mb; mb.v = lp_mb + cur.M[c]; mb.from = 0;
+                    vit_step(mb, NP_NEG_INF, 1);
+                    vit_step(mb, lp_bb + cur.B[c], 2);
+                    vit_step(mb, NP_NEG_INF, 3); vit_step(mb, NP_NEG_INF, 4); vit_step(mb, NP_NEG_INF, 5);
+                    const float newB = mb.v + 0.0f;
+                    // KMER_SKIP: x = [-inf, mk+M(r,b-1), -inf, bk+B(r,b-1), kk+K(r,b-1), -inf]
+                    vmax mk; mk.v = NP_NEG_INF; mk.from = 0;
+                    vit_step(mk, lp_mk + lM_r, 1);
+                    vit_step(mk, NP_NEG_INF, 2);
+                    vit_step(mk, lp_bk + lB_r, 3);
+                    vit_step(mk, lp_kk + lK_r, 4);
+                    vit_step(mk, NP_NEG_INF, 5);
+                    const float newK = mk.v + 0.0f;
+
+                    lM_p = cur.M[c]; lB_p = cur.B[c]; lK_p = cur.K[c];
+                    lM_r = newM; lB_r = newB; lK_r = newK;
+                    cur.M[c] = newM; cur.B[c] = newB; cur.K[c] = newK;
+
+                    if (b < n) {
+                        const int64_t o = (int64_t)(r - 1) * rowlen + 3 * b;
+                        vm[o + 0] = newK; vm[o + 1] = newB; vm[o + 2] = newM;      // PSR9_KMER_SKIP=0, BAD_EVENT=1, MATCH=2
+                        bp[o + 0] = mk.from; bp[o + 1] = mb.from; bp[o + 2] = m.from;
+                    }
+                }
+            }
+            oM = nM; oB = nB; oK = nK;
+        }
+    }
+}
+
+// Backtrack (profile_hmm_align_r9, r9.cpp:117-196): one lane per job walks the back-pointers from
+// (last row, MATCH of last k-mer).  Output is written descending then reversed in place.
+__global__ void np_hmm_backtrack_kernel(np_hmm_args a, int64_t n_jobs_total)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_jobs_total) return;
+    const np_hmm_job_dev job = a.jobs[j];
+    const int n = (int)job.n_kmers;
+    if (n <= 0) { a.n_states[j] = 0; return; }
+    const int e = (int)(job.e_stop > job.e_start ? job.e_stop - job.e_start : job.e_start - job.e_stop) + 1;
+    if (e < 2) { a.n_states[j] = 0; return; }                 // assert(n_events >= 2), r9.cpp:88
+    const float* vm = a.vm + a.cell_off[j];
+    const uint8_t* bp = a.bp + a.cell_off[j];
+    np_hmm_state* out = a.states + a.state_off[j];
+    const int rowlen = 3 * n;
+    int cnt = 0;
+    bool bad = false;
+    int row = e;                 // n_rows - 1
+    int kmer = n - 1, ps = 2;    // col = 3*n_kmers + PSR9_MATCH  -> block n (k-mer n-1), MATCH
+    while (row > 0) {
+        if (kmer < 0) { bad = true; break; }                  // assert(block > 0)
+        const int64_t o = (int64_t)(row - 1) * rowlen + 3 * kmer + ps;
+        const float v = vm[o];
+        if (v == NP_NEG_INF) { bad = true; break; }            // assert(get(vm,row,col) != -INFINITY)
+        np_hmm_state st;
+        st.event_idx = job.e_start + (uint32_t)((row - 1) * job.stride);
+        st.kmer_idx = (uint32_t)kmer;
+        st.l_fm = (double)v;
+        st.state = "KBMNS"[ps];
+        for (int q = 0; q < 7; ++q) st.pad[q] = 0;
+        out[cnt++] = st;
+        const int mv = bp[o];
+        if (mv == 5) break;                                   // HMT_FROM_SOFT
+        int next_ps = 2;
+        switch (mv) {
+            case 0: next_ps = 2; break;
+            case 1: kmer -= 1; next_ps = 2; break;
+            case 2: next_ps = 1; break;
+            case 3: kmer -= 1; next_ps = 1; break;
+            case 4: kmer -= 1; next_ps = 0; break;
+        }
+        if (ps != 0) row -= 1;                                // K states are silent (r9.cpp:176-178)
+        ps = next_ps;
+    }
+    if (bad) { a.n_states[j] = 0; return; }
+    for (int i = 0, k = cnt - 1; i < k; ++i, --k) { np_hmm_state t = out[i]; out[i] = out[k]; out[k] = t; }
+    a.n_states[j] = cnt;
+}
+
+template <int SEG, int C>
+hipError_t launch_fwd(const np_hmm_args& a, int n_blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL((np_hmm_forward_kernel<SEG, C>), dim3(n_blocks), dim3(NP_HMM_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+template <int SEG, int C>
+hipError_t launch_vit(const np_hmm_args& a, int n_blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL((np_hmm_viterbi_kernel<SEG, C>), dim3(n_blocks), dim3(NP_HMM_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
+} // namespace
+
+int np_hmm_block_threads(void) { return NP_HMM_BLOCK; }
+
+hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s)
+{
+    switch (cls) {
+        case 0: return launch_fwd<16, 1>(a, n_blocks, s);
+        case 1: return launch_fwd<32, 1>(a, n_blocks, s);
+        case 2: return launch_fwd<64, 1>(a, n_blocks, s);
+        case 3: return launch_fwd<64, 2>(a, n_blocks, s);
+        case 4: return launch_fwd<64, 4>(a, n_blocks, s);
+        case 5: return launch_fwd<64, 8>(a, n_blocks, s);
+        case 6: return launch_fwd<64, 16>(a, n_blocks, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t np_launch_hmm_viterbi(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s)
+{
+    switch (cls) {
+        case 0: return launch_vit<16, 1>(a, n_blocks, s);
+        case 1: return launch_vit<32, 1>(a, n_blocks, s);
+        case 2: return launch_vit<64, 1>(a, n_blocks, s);
+        case 3: return launch_vit<64, 2>(a, n_blocks, s);
+        case 4: return launch_vit<64, 4>(a, n_blocks, s);
+        case 5: return launch_vit<64, 8>(a, n_blocks, s);
+        case 6: return launch_vit<64, 16>(a, n_blocks, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t np_launch_hmm_backtrack(const np_hmm_args& a, int64_t n_jobs, hipStream_t s)
+{
+    if (n_jobs <= 0) return hipSuccess;
+    const int bs = 64;
+    hipLaunchKernelGGL(np_hmm_backtrack_kernel, dim3((unsigned)((n_jobs + bs - 1) / bs)), dim3(bs), 0, s, a, n_jobs);
+    return hipGetLastError();
+}

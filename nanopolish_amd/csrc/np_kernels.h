@@ -1,0 +1,62 @@
+// np_kernels.h -- host-visible launch interface of the HIP kernels (internal to the library).
+#pragma once
+#include "np_device.h"
+
+struct np_hmm_args {
+    const np_hmm_job_dev* jobs;
+    const uint32_t* order;         // job indices of this size class
+    const uint32_t* n_class_jobs;  // device counter: number of entries in `order`
+    const np_read_dev* reads;
+    const float* event_mean;
+    const uint16_t* ranks;
+    const np_state_dev* model;
+    const float* logsum;           // flogsum_lookup[16000]
+    const float* flank;            // universal clip-flank table (see np_capi: flank[i] == pre_flank[i] == post_flank[e-1-i])
+    uint32_t* counter;             // work-queue head, zeroed before launch
+    float* out;                    // forward scores, indexed by job
+    // Viterbi only
+    uint8_t* bp;                   // back-pointer scratch
+    float* vm;                     // lattice scratch
+    const int64_t* cell_off;       // per job offset into bp / vm (in cells)
+    np_hmm_state* states;          // output
+    const int64_t* state_off;
+    int32_t* n_states;
+};
+
+struct np_align_args {
+    const np_read_dev* reads;
+    const float* event_mean;
+    const uint16_t* ranks;
+    const np_state_dev* model;
+    const int64_t* pair_off;
+    np_pair* pairs;
+    int32_t* pair_begin;
+    int32_t* n_pairs;
+    uint64_t* trace;               // scratch: n_wave_slots * trace_stride u64
+    uint64_t trace_stride;         // u64 per resident wave (>= 4 * max_bands)
+    uint32_t* counter;
+    int32_t n_reads;
+    int32_t max_gap_threshold;
+    double min_average_log_emission;
+};
+
+#define NP_NUM_CLASSES 7
+// size classes of the HMM kernels: (lanes per job, k-mer blocks per lane)
+static const int NP_CLASS_SEG[NP_NUM_CLASSES] = {16, 32, 64, 64, 64, 64, 64};
+static const int NP_CLASS_C[NP_NUM_CLASSES] = {1, 1, 1, 2, 4, 8, 16};
+
+hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s);
+hipError_t np_launch_hmm_viterbi(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s);
+hipError_t np_launch_hmm_backtrack(const np_hmm_args& a, int64_t n_jobs, hipStream_t s);
+hipError_t np_launch_event_align(const np_align_args& a, int n_blocks, hipStream_t s);
+int np_align_block_threads(void);
+int np_hmm_block_threads(void);
+
+// glue kernels
+hipError_t np_launch_classify(const np_hmm_job_dev* jobs, int64_t n_jobs, uint32_t* class_count /*[7]*/,
+                              uint32_t* order /*[7][n_jobs]*/, float* out_scores, uint32_t flank_len, hipStream_t s);
+hipError_t np_launch_build_map(int n_reads, np_read_dev* reads, const int64_t* pair_off, const np_pair* pairs,
+                               const int32_t* pair_begin, const int32_t* n_pairs, int32_t* map_start,
+                               double* events_per_base, double indel_bias, hipStream_t s);
+hipError_t np_launch_resolve(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads, const int32_t* n_pairs,
+                             const double* events_per_base, const int32_t* map_start, const int32_t* kpos, hipStream_t s);

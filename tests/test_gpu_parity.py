@@ -1,0 +1,134 @@
+"""GPU parity: the HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs, and vs the
+committed golden vectors produced by the reference itself.  Bit-exact for indices and scores."""
+import numpy as np
+import pytest
+
+from cases import K, HAF_PRE, HAF_POST, methylation_jobs, eventalign_segments, synth_read
+
+pytestmark = pytest.mark.gpu
+
+
+def _reads(models, ids, L):
+    return [synth_read(i, models["nucleotide"], L=L) for i in ids]
+
+
+def _align_inputs(ctx, orc, mn, rd):
+    sh, sc = orc.estimate_scalings_mom(mn, rd["ranks"], rd["events"])
+    return dict(events=rd["events"], ranks=rd["ranks"], model=ctx.models["nucleotide"], scale=sc, shift=sh, var=1.0), (sh, sc)
+
+
+def test_event_align_matches_oracle(ctx, orc, models):
+    mn = orc.model(models["nucleotide"])
+    reads = _reads(models, range(0, 12), 700) + _reads(models, range(12, 16), 2500) + _reads(models, [16, 17], 130)
+    jobs, moms = zip(*[_align_inputs(ctx, orc, mn, rd) for rd in reads])
+    got = ctx.adaptive_banded_simple_event_align(list(jobs))
+    for rd, (sh, sc), g in zip(reads, moms, got):
+        want = orc.event_align(mn, orc.scalings(sh, sc, 1.0), rd["events"], rd["ranks"])
+        assert want is not None
+        assert g.shape == want.shape and np.array_equal(g, want), "read %d" % rd["read_id"]
+
+
+def test_event_align_qc_failure_is_empty(ctx, orc, models):
+    mn = orc.model(models["nucleotide"])
+    rd = synth_read(40, models["nucleotide"], L=600)
+    other = synth_read(41, models["nucleotide"], L=600)
+    bad = dict(rd, ranks=other["ranks"])                 # events do not belong to this sequence
+    job, (sh, sc) = _align_inputs(ctx, orc, mn, bad)
+    want = orc.event_align(mn, orc.scalings(sh, sc, 1.0), bad["events"], bad["ranks"])
+    got = ctx.adaptive_banded_simple_event_align([job])[0]
+    assert want is not None and len(want) == 0 and len(got) == 0
+
+
+def _score_jobs(ctx, orc, models, reads):
+    mn = orc.model(models["nucleotide"]); mc = orc.model(models["cpg"])
+    jobs, want = [], []
+    for rd in reads:
+        sh, sc = orc.estimate_scalings_mom(mn, rd["ranks"], rd["events"])
+        pairs = orc.event_align(mn, orc.scalings(sh, sc, 1.0), rd["events"], rd["ranks"])
+        epb, mj = methylation_jobs(orc, rd, pairs)
+        S = orc.scalings(rd["shift"], rd["scale"], rd["var"])
+        for j in mj:
+            for s, r in ((j["subseq"], j["rc_subseq"]), (j["m_subseq"], j["rc_m_subseq"])):
+                ranks = orc.sequence_kmer_ranks("cpg", s, r, K, j["rc"])
+                jobs.append(dict(events=rd["events"], ranks=ranks, e_start=j["e1"], e_stop=j["e2"], stride=j["stride"],
+                                 model=ctx.models["cpg"], scale=rd["scale"], shift=rd["shift"], var=rd["var"],
+                                 events_per_base=epb, flags=HAF_PRE | HAF_POST))
+                want.append(orc.hmm_score(mc, S, rd["events"], ranks, j["e1"], j["e2"], j["stride"], epb, 1.0, HAF_PRE | HAF_POST))
+    return jobs, np.array(want, np.float32)
+
+
+def test_hmm_score_matches_oracle(ctx, orc, models):
+    jobs, want = _score_jobs(ctx, orc, models, _reads(models, range(20, 28), 1200))
+    got = ctx.profile_hmm_score(jobs)
+    assert len(got) > 300
+    assert np.array_equal(got, want), "max |d| = %g" % np.max(np.abs(got - want))
+    llr_g = got[1::2].astype(np.float64) - got[0::2]; llr_w = want[1::2].astype(np.float64) - want[0::2]
+    assert np.max(np.abs(llr_g - llr_w)) <= 1e-4          # north-star tolerance (we are bit-equal, so 0)
+
+
+def test_hmm_score_flags_and_long_windows(ctx, orc, models):
+    """flags 0 / PRE / POST and windows of 17..400 k-mers (all size classes incl. several blocks per lane)."""
+    mn = orc.model(models["nucleotide"])
+    rd = synth_read(30, models["nucleotide"], L=1500)
+    S = orc.scalings(rd["shift"], rd["scale"], rd["var"])
+    jobs, want = [], []
+    for n_k, e0 in ((11, 50), (17, 100), (33, 150), (65, 300), (100, 420), (129, 500), (260, 700), (400, 900)):
+        ranks = rd["ranks"][e0 // 2: e0 // 2 + n_k]
+        for flags in (0, HAF_PRE, HAF_POST, HAF_PRE | HAF_POST):
+            e1, e2 = e0, e0 + int(1.5 * n_k)
+            jobs.append(dict(events=rd["events"], ranks=ranks, e_start=e1, e_stop=e2, stride=1, model=ctx.models["nucleotide"],
+                             scale=rd["scale"], shift=rd["shift"], var=rd["var"], events_per_base=1.6, flags=flags))
+            want.append(orc.hmm_score(mn, S, rd["events"], ranks.astype(np.uint32), e1, e2, 1, 1.6, 1.0, flags))
+    got = ctx.profile_hmm_score(jobs)
+    assert np.array_equal(got, np.array(want, np.float32))
+
+
+def test_hmm_align_matches_oracle(ctx, orc, models):
+    mn = orc.model(models["nucleotide"])
+    jobs, want = [], []
+    for rd in _reads(models, [50, 52, 54], 1500):
+        sh, sc = orc.estimate_scalings_mom(mn, rd["ranks"], rd["events"])
+        pairs = orc.event_align(mn, orc.scalings(sh, sc, 1.0), rd["events"], rd["ranks"])
+        epb, segs = eventalign_segments(orc, rd, pairs)
+        S = orc.scalings(rd["shift"], rd["scale"], rd["var"])
+        for sg in segs:
+            ranks = orc.sequence_kmer_ranks("nucleotide", sg["seq"], None, K, 0)
+            jobs.append(dict(events=rd["events"], ranks=ranks, e_start=sg["e1"], e_stop=sg["e2"], stride=1,
+                             model=ctx.models["nucleotide"], scale=rd["scale"], shift=rd["shift"], var=rd["var"],
+                             events_per_base=epb, flags=0))
+            want.append(orc.hmm_align(mn, S, rd["events"], ranks, sg["e1"], sg["e2"], 1, epb))
+    got = ctx.profile_hmm_align(jobs)
+    assert len(got) > 20
+    for g, w in zip(got, want):
+        assert w is not None
+        for a, b in zip(g, w):
+            assert np.array_equal(a, b)
+
+
+def test_goldens_from_reference(ctx, models):
+    """The committed vectors were produced by the reference's own code (tests/gen_golden.py)."""
+    import os
+    from nanopolish_amd import api
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_reads.npz"))
+    for rid, L in zip(g["read_ids"], g["read_L"]):
+        rd = synth_read(int(rid), models["nucleotide"], L=int(L))
+        p = "r%d_" % rid
+        sh, sc = g[p + "mom"]
+        got = ctx.adaptive_banded_simple_event_align([dict(events=rd["events"], ranks=rd["ranks"], model=ctx.models["nucleotide"],
+                                                           scale=sc, shift=sh, var=1.0)])[0]
+        assert np.array_equal(got, g[p + "pairs"])
+        if p + "score_meth" not in g.files:
+            continue
+        epb = float(g[p + "epb"])
+        ref_seq = rd["seq"] if not rd["rc"] else api.reverse_complement("nucleotide", rd["seq"])
+        jb = api.cm_build_jobs_identity(ref_seq, rd["rc"])
+        firsts = list(jb["first"])
+        jobs = []
+        for f, e1, e2 in zip(g[p + "job_first"], g[p + "job_e1"], g[p + "job_e2"]):
+            i = firsts.index(f)
+            for rk in (jb["ranks_unmeth"], jb["ranks_meth"]):
+                jobs.append(dict(events=rd["events"], ranks=rk[jb["rank_off"][i]:jb["rank_off"][i + 1]], e_start=int(e1), e_stop=int(e2),
+                                 stride=1 if e1 <= e2 else -1, model=ctx.models["cpg"], scale=rd["scale"], shift=rd["shift"],
+                                 var=rd["var"], events_per_base=epb, flags=HAF_PRE | HAF_POST))
+        got = ctx.profile_hmm_score(jobs)
+        assert np.array_equal(got[0::2], g[p + "score_unmeth"]) and np.array_equal(got[1::2], g[p + "score_meth"])
