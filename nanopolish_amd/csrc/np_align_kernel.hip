@@ -86,11 +86,13 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK) np_event_align_kernel(np_align
     const int lane = threadIdx.x & 63;
     const int wave_slot = blockIdx.x * (NP_ALIGN_BLOCK / 64) + (threadIdx.x >> 6);
     uint64_t* __restrict__ trace = a.trace + (size_t)wave_slot * a.trace_stride;
+    if (a.dbg && wave_slot == 0 && lane == 0) a.dbg[8] = 10;
 
     for (;;) {
-        int ri = 0;
-        if (lane == 0) ri = (int)atomicAdd(a.counter, 1u);
-        ri = __builtin_amdgcn_readfirstlane(ri);
+        // Ticket grab without an `if (lane == 0)`: hipcc threads a lane-0 branch at the loop top together with a
+        // lane-0 branch at the loop bottom and then runs the (convergent) readfirstlane on a partial wave.
+        const int ri = __builtin_amdgcn_readfirstlane((int)atomicAdd(a.counter, lane == 0 ? 1u : 0u));
+        if (a.dbg && wave_slot == 0 && lane == 0) { a.dbg[8] = 11; a.dbg[9] = (uint32_t)ri; }
         if (ri >= a.n_reads) break;
 
         const np_read_dev* rd = a.reads + ri;
@@ -108,17 +110,20 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK) np_event_align_kernel(np_align
             continue;
         }
 
+        if (a.dbg && ri == 0 && lane == 0) { a.dbg[8] = 12; a.dbg[10] = (uint32_t)E; a.dbg[11] = (uint32_t)K; }
         // ---------------- fill ----------------
         int llk = -1 - NP_ALN_BANDWIDTH / 2;            // band_lower_left[0].kmer_idx, raw_loader.cpp:150-151
         slot_t s0, s1;
         s0.k = ring_kmer(lane, llk);      s0.g = load_kmer(a, rk, s0.k, K, scale, shift, var, log_var);
         s1.k = ring_kmer(lane + 64, llk); s1.g = load_kmer(a, rk, s1.k, K, scale, shift, var, log_var);
+        if (a.dbg && ri == 0 && lane == 0) a.dbg[8] = 13;
         float p0 = NP_NEG_INF, p1 = NP_NEG_INF;   // band b-1
         float d0 = NP_NEG_INF, d1 = NP_NEG_INF;   // band b-2 rotated by one slot
         float best = NP_NEG_INF; int best_e = 0;  // end-cell search (:309-324), tracked by the owner of k-mer K-1
         const int end_slot = (K - 1) & (NP_RING - 1);
 
         for (int b = 0; b < n_bands; ++b) {
+            if (a.dbg && ri == 0 && lane == 0) { a.dbg[0] = 1; a.dbg[1] = (uint32_t)b; a.dbg[3] = (uint32_t)n_bands; }
             if (b >= 2) {
                 // Suzuki's rule on band b-1 (:179-195)
                 const float ll = ring_read(p0, p1, llk & (NP_RING - 1));
@@ -184,6 +189,7 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK) np_event_align_kernel(np_align
         double sum_emission = 0.0;
         if (best_u != NP_NEG_INF) {
             while (curr_k >= 0 && curr_e >= 0) {
+                if (a.dbg && ri == 0 && lane == 0) { a.dbg[0] = 2; a.dbg[2] = (uint32_t)n_out; a.dbg[4] = (uint32_t)curr_k; a.dbg[5] = (uint32_t)curr_e; }
                 if (lane == 0) { np_pair p; p.ref_pos = curr_k; p.read_pos = curr_e; pairs[cap - 1 - n_out] = p; }
                 n_out++;
                 const np_gauss g = load_kmer(a, rk, curr_k, K, scale, shift, var, log_var);
@@ -198,6 +204,7 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK) np_event_align_kernel(np_align
                 else { curr_k -= 1; curr_gap += 1; max_gap = curr_gap > max_gap ? curr_gap : max_gap; }
             }
         }
+        if (a.dbg && ri == 0 && lane == 0) a.dbg[0] = 3;
         if (lane == 0) {
             bool failed = true;
             if (n_out > 0) {

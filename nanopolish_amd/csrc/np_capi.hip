@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
+#include <time.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -159,8 +161,21 @@ int run_event_align(np_ctx* c, hipStream_t s, int n_reads, const np_read_dev* re
     a.trace = c->trace.as<uint64_t>(); a.trace_stride = stride; a.counter = c->d_counters + 16;
     a.n_reads = n_reads; a.max_gap_threshold = c->params.max_gap_threshold;
     a.min_average_log_emission = c->params.min_average_log_emission;
-    family_timer tm(c, 0, s);
-    NP_HIP(c, np_launch_event_align(a, nb, s));
+    uint32_t* dbg = nullptr;
+    if (getenv("NP_DEBUG_ALIGN")) { NP_HIP(c, hipHostMalloc((void**)&dbg, 64 * sizeof(uint32_t), hipHostMallocCoherent)); memset(dbg, 0, 256); a.dbg = dbg; }
+    {
+        family_timer tm(c, 0, s);
+        NP_HIP(c, np_launch_event_align(a, nb, s));
+    }
+    if (dbg) {
+        for (int i = 0; i < 50; ++i) {
+            if (hipStreamQuery(s) == hipSuccess) break;
+            struct timespec ts = {0, 100000000}; nanosleep(&ts, nullptr);
+            fprintf(stderr, "[np dbg] t=%.1fs phase=%u band=%u/%u n_out=%u k=%d e=%d nb=%d stride=%llu entry=%u ri=%u E=%u K=%u q=%d\n", 0.1 * (i + 1), dbg[0], dbg[1], dbg[3], dbg[2], (int)dbg[4], (int)dbg[5], nb, (unsigned long long)stride, dbg[8], dbg[9], dbg[10], dbg[11], (int)hipStreamQuery(s));
+            if (i > 3) break;
+            fflush(stderr);
+        }
+    }
     return NP_OK;
 }
 

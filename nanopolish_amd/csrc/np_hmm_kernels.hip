@@ -50,9 +50,8 @@ __global__ void __launch_bounds__(NP_HMM_BLOCK) np_hmm_forward_kernel(np_hmm_arg
     const uint32_t n_packs = (n_jobs + JPW - 1) / JPW;
 
     for (;;) {
-        uint32_t pack = 0;
-        if (lane == 0) pack = atomicAdd(a.counter, 1u);
-        pack = __builtin_amdgcn_readfirstlane(pack);
+        // (no `if (lane == 0)` around the atomic: see np_align_kernel.hip)
+        const uint32_t pack = __builtin_amdgcn_readfirstlane(atomicAdd(a.counter, lane == 0 ? 1u : 0u));
         if (pack >= n_packs) break;
 
         const uint32_t slot = pack * JPW + seg;
@@ -167,9 +166,8 @@ __global__ void __launch_bounds__(NP_HMM_BLOCK) np_hmm_viterbi_kernel(np_hmm_arg
     const uint32_t n_packs = (n_jobs + JPW - 1) / JPW;
 
     for (;;) {
-        uint32_t pack = 0;
-        if (lane == 0) pack = atomicAdd(a.counter, 1u);
-        pack = __builtin_amdgcn_readfirstlane(pack);
+        // (no `if (lane == 0)` around the atomic: see np_align_kernel.hip)
+        const uint32_t pack = __builtin_amdgcn_readfirstlane(atomicAdd(a.counter, lane == 0 ? 1u : 0u));
         if (pack >= n_packs) break;
 
         const uint32_t slot = pack * JPW + seg;
