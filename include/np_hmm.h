@@ -37,6 +37,8 @@ extern "C" {
 /* HMMAlignmentFlags, src/hmm/nanopolish_profile_hmm.h:34-38 */
 #define NP_HAF_ALLOW_PRE_CLIP 1u
 #define NP_HAF_ALLOW_POST_CLIP 2u
+/* device work items only: set by np_resolve_jobs_dev on items the reference would skip (score = NaN) */
+#define NP_JOB_SKIP 0x80000000u
 
 #define NP_MAX_KMERS 1024      /* k-mers per profile_hmm_* call (reference callers stay <= 260) */
 #define NP_ALN_BANDWIDTH 100   /* ALN_BANDWIDTH, src/nanopolish_raw_loader.cpp:72 */
@@ -205,7 +207,7 @@ int np_hmm_score_dev(np_ctx* ctx, void* stream, int64_t n_jobs, const np_hmm_job
  * HMM transitions, then resolves each work item's event bounds
  *     e_start = get_closest_event_to(kpos_start), e_stop = get_closest_event_to(kpos_stop)
  * and applies the skip rule |e2-e1| <= 10 (src/basemods/nanopolish_basemods.cpp:356): skipped items get
- * n_kmers = 0 and score NaN.
+ * the NP_JOB_SKIP flag and score NaN.
  *   map_start : int32[sum n_kmers] scratch/output (per read at rank_off)
  *   kpos      : int32[2*n_jobs] read-strand k-mer positions bounding each item
  *   events_per_base : double[n_reads] output */

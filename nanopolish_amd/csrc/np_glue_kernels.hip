@@ -83,8 +83,10 @@ __global__ void __launch_bounds__(256) np_resolve_kernel(int64_t n_jobs, np_hmm_
     if (ok) {
         job.e_start = (uint32_t)e1; job.e_stop = (uint32_t)e2;
         job.stride = e1 <= e2 ? 1 : -1;                                      // basemods.cpp:370
+        job.flags &= ~NP_JOB_SKIP;
     } else {
-        job.n_kmers = 0;
+        job.e_start = 0; job.e_stop = 0; job.stride = 1;
+        job.flags |= NP_JOB_SKIP;                                            // classify drops it, score = NaN
     }
     jobs[j] = job;
 }
@@ -111,7 +113,7 @@ __global__ void __launch_bounds__(256) np_classify_kernel(const np_hmm_job_dev* 
     if (j < n_jobs) {
         const np_hmm_job_dev jb = jobs[j];
         const uint32_t e = (jb.e_stop > jb.e_start ? jb.e_stop - jb.e_start : jb.e_start - jb.e_stop) + 1u;
-        cls = e <= flank_len ? size_class(jb.n_kmers) : -1;
+        cls = (e <= flank_len && !(jb.flags & NP_JOB_SKIP)) ? size_class(jb.n_kmers) : -1;
         if (cls < 0 && out_scores) out_scores[j] = __builtin_nanf("");
     }
     // wave-aggregated append: one atomic per (wave, class)

@@ -1,0 +1,173 @@
+"""Device-resident call-methylation pass over a batch of reads (the north-star path):
+
+    adaptive_banded_simple_event_align  (kernel A, one wave per read)
+      -> base_to_event_map / events_per_base / transitions / window event bounds  (glue kernels)
+      -> 2 x profile_hmm_score per CpG group (kernel B)
+
+mirroring SquiggleRead::load_from_raw (src/nanopolish_squiggle_read.cpp:270-301) followed by
+calculate_methylation_for_read (src/basemods/nanopolish_basemods.cpp:238-457) for reads laid out as in
+SURVEY.md section 8d (identity alignment to their own sequence; odd read ids are reverse-strand).
+Inputs are uploaded once; `step()` only enqueues kernels through the C ABI's *_dev entry points.
+torch is used for device memory only.
+"""
+import ctypes as C
+import numpy as np
+
+from . import lib as _l
+from . import api
+from .synth import synth_read
+
+READ_DT = np.dtype([("scale", "<f8"), ("shift", "<f8"), ("var", "<f8"), ("log_var", "<f8"),
+                    ("lp_skip", "<f8"), ("lp_stay", "<f8"), ("lp_step", "<f8"), ("lp_trim", "<f8"),
+                    ("event_off", "<i8"), ("rank_off", "<i8"), ("n_events", "<u4"), ("n_kmers", "<u4"),
+                    ("trans", "<f4", (10,)), ("flags", "<u4"), ("reserved", "<u4")])
+JOB_DT = np.dtype([("rank_off", "<i8"), ("n_kmers", "<u4"), ("read", "<u4"), ("e_start", "<u4"), ("e_stop", "<u4"),
+                   ("stride", "<i4"), ("flags", "<u4")])
+assert READ_DT.itemsize == C.sizeof(_l.ReadDev) and JOB_DT.itemsize == C.sizeof(_l.HmmJobDev)
+
+HAF = api.HAF_ALLOW_PRE_CLIP | api.HAF_ALLOW_POST_CLIP
+
+
+def build_host_batch(models, read_ids, L=5450, k=6):
+    """Host-side preparation of the distinct reads of a batch (numpy only)."""
+    L_ = _l.load_library()
+    nuc = models["nucleotide"]
+    reads = [synth_read(r, nuc, L=L, k=k) for r in read_ids]
+    n = len(reads)
+    event_off = np.zeros(n + 1, np.int64); rank_off = np.zeros(n + 1, np.int64)
+    event_off[1:] = np.cumsum([len(r["events"]) for r in reads]); rank_off[1:] = np.cumsum([len(r["ranks"]) for r in reads])
+    events = np.concatenate([r["events"] for r in reads]).astype(np.float32)
+    ranks = np.concatenate([r["ranks"] for r in reads]).astype(np.uint16)
+    reads_a = np.zeros(n, READ_DT); reads_b = np.zeros(n, READ_DT)
+    mom = np.zeros((n, 2))
+    jobs, kpos, jranks, meta = [], [], [], []
+    jr_off = 0
+    for i, r in enumerate(reads):
+        sh, sc = api.estimate_scalings_using_mom(nuc, r["ranks"], r["events"])
+        mom[i] = (sh, sc)
+        ne, nk = len(r["events"]), len(r["ranks"])
+        for arr, (shift, scale, var) in ((reads_a, (sh, sc, 1.0)), (reads_b, (r["shift"], r["scale"], r["var"]))):
+            L_.np_fill_read_host(C.cast(arr[i:i + 1].ctypes.data, C.POINTER(_l.ReadDev)), shift, scale, var,
+                                 int(event_off[i]), ne, int(rank_off[i]), nk)
+        ref_seq = api.reverse_complement("nucleotide", r["seq"]) if r["rc"] else r["seq"]
+        jb = api.cm_build_jobs_identity(ref_seq, r["rc"], k)
+        ng = len(jb["first"])
+        j = np.zeros(2 * ng, JOB_DT)
+        nk_j = jb["n_kmers"].astype(np.uint32)
+        ro = jb["rank_off"][:-1]
+        tot = int(jb["rank_off"][-1])
+        j["n_kmers"] = np.repeat(nk_j, 2)
+        j["read"] = i
+        j["flags"] = HAF
+        j["stride"] = 1
+        j["rank_off"][0::2] = jr_off + ro                 # unmethylated copy
+        j["rank_off"][1::2] = jr_off + tot + ro           # methylated copy
+        jobs.append(j)
+        kpos.append(np.repeat(jb["kpos"], 2, axis=0))
+        jranks.append(jb["ranks_unmeth"]); jranks.append(jb["ranks_meth"])
+        jr_off += 2 * tot
+        meta.append(dict(first=jb["first"], last=jb["last"], n_motif=jb["n_motif"]))
+    return dict(reads=reads, n=n, events=events, ranks=ranks, event_off=event_off, rank_off=rank_off,
+                reads_a=reads_a, reads_b=reads_b, mom=mom,
+                jobs=np.concatenate(jobs) if jobs else np.zeros(0, JOB_DT),
+                kpos=np.concatenate(kpos).astype(np.int32) if kpos else np.zeros((0, 2), np.int32),
+                job_ranks=np.concatenate(jranks).astype(np.uint16) if jranks else np.zeros(0, np.uint16),
+                job_off=np.concatenate([[0], np.cumsum([len(j) for j in jobs])]).astype(np.int64), meta=meta)
+
+
+def tile_host_batch(hb, tile):
+    """Replicate the distinct reads `tile` times (independent copies in HBM, shifted offsets)."""
+    if tile == 1:
+        return hb
+    n, ne, nr, nj, njr = hb["n"], len(hb["events"]), len(hb["ranks"]), len(hb["jobs"]), len(hb["job_ranks"])
+    out = dict(hb)
+    out["n"] = n * tile
+    out["events"] = np.tile(hb["events"], tile); out["ranks"] = np.tile(hb["ranks"], tile)
+    out["job_ranks"] = np.tile(hb["job_ranks"], tile); out["kpos"] = np.tile(hb["kpos"], (tile, 1))
+    for key in ("reads_a", "reads_b"):
+        a = np.tile(hb[key], tile)
+        a["event_off"] += np.repeat(np.arange(tile, dtype=np.int64) * ne, n)
+        a["rank_off"] += np.repeat(np.arange(tile, dtype=np.int64) * nr, n)
+        out[key] = a
+    j = np.tile(hb["jobs"], tile)
+    j["read"] += np.repeat(np.arange(tile, dtype=np.uint32) * n, nj).astype(np.uint32)
+    j["rank_off"] += np.repeat(np.arange(tile, dtype=np.int64) * njr, nj)
+    out["jobs"] = j
+    out["event_off"] = np.concatenate([hb["event_off"][:-1] + t * ne for t in range(tile)] + [[ne * tile]]).astype(np.int64)
+    out["rank_off"] = np.concatenate([hb["rank_off"][:-1] + t * nr for t in range(tile)] + [[nr * tile]]).astype(np.int64)
+    return out
+
+
+class CallMethylationBatch:
+    def __init__(self, ctx, hb, device="cuda:0"):
+        import torch
+        self.torch = torch
+        self.ctx = ctx
+        self.hb = hb
+        self.n_reads = hb["n"]
+        self.n_jobs = len(hb["jobs"])
+        dev = torch.device(device)
+
+        def up(a):
+            a = np.ascontiguousarray(a)
+            return torch.from_numpy(a.view(np.uint8).reshape(-1)).to(dev)
+
+        self.d_events = up(hb["events"]); self.d_ranks = up(hb["ranks"])
+        self.d_reads_a = up(hb["reads_a"]); self.d_reads_b = up(hb["reads_b"])
+        self.d_jobs = up(hb["jobs"]); self.d_kpos = up(hb["kpos"]); self.d_job_ranks = up(hb["job_ranks"])
+        ne = (hb["event_off"][1:] - hb["event_off"][:-1]); nk = (hb["rank_off"][1:] - hb["rank_off"][:-1])
+        bands = ne + nk + 2
+        self.max_bands = int(bands.max())
+        pair_off = np.zeros(self.n_reads + 1, np.int64); pair_off[1:] = np.cumsum(bands)
+        self.pair_off = pair_off
+        self.d_pair_off = up(pair_off)
+        self.d_pairs = torch.empty(int(pair_off[-1]) * 8, dtype=torch.uint8, device=dev)
+        self.d_pair_begin = torch.zeros(self.n_reads, dtype=torch.int32, device=dev)
+        self.d_n_pairs = torch.zeros(self.n_reads, dtype=torch.int32, device=dev)
+        self.d_map = torch.empty(len(hb["ranks"]), dtype=torch.int32, device=dev)
+        self.d_epb = torch.zeros(self.n_reads, dtype=torch.float64, device=dev)
+        self.d_scores = torch.zeros(max(self.n_jobs, 1), dtype=torch.float32, device=dev)
+        self.m_nuc = ctx.models["nucleotide"]; self.m_cpg = ctx.models["cpg"]
+        torch.cuda.synchronize()
+        # algorithmic bytes of one pass: kernel A 4E + 2K + 100(E+K+2) + 8E per read,
+        # kernel B 4e + 2n + 12n + 4 per call (e, n of every work item are only known after the pass; use the
+        # window sizes: n exact, e ~ events_per_kmer * n)
+        self.algo_bytes_align = int((4 * ne + 2 * nk + 100 * bands + 8 * ne).sum())
+        self.band_cells = int((100 * bands).sum())
+        self.total_events = int(ne.sum())
+
+    def step(self):
+        L, h = self.ctx.L, self.ctx.h
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rc = L.np_event_align_dev(h, None, self.n_reads, p(self.d_reads_a), p(self.d_events), p(self.d_ranks), self.m_nuc,
+                                  self.max_bands, p(self.d_pair_off), p(self.d_pairs), p(self.d_pair_begin), p(self.d_n_pairs))
+        self.ctx._chk(rc, "np_event_align_dev")
+        rc = L.np_resolve_jobs_dev(h, None, self.n_reads, p(self.d_reads_b), p(self.d_pair_off), p(self.d_pairs),
+                                   p(self.d_pair_begin), p(self.d_n_pairs), p(self.d_map), p(self.d_epb), self.n_jobs,
+                                   p(self.d_jobs), p(self.d_kpos))
+        self.ctx._chk(rc, "np_resolve_jobs_dev")
+        rc = L.np_hmm_score_dev(h, None, self.n_jobs, p(self.d_jobs), p(self.d_reads_b), p(self.d_events), p(self.d_job_ranks),
+                                self.m_cpg, p(self.d_scores))
+        self.ctx._chk(rc, "np_hmm_score_dev")
+
+    def sync(self):
+        self.ctx.sync()
+
+    # ---- results on the host (for checking) -------------------------------------------------------------
+    def scores(self):
+        self.sync()
+        return self.d_scores[:self.n_jobs].cpu().numpy()
+
+    def pairs_of(self, r):
+        self.sync()
+        nb = int(self.d_pair_begin[r]); n = int(self.d_n_pairs[r])
+        lo = int(self.pair_off[r]) + nb
+        return self.d_pairs[lo * 8:(lo + n) * 8].cpu().numpy().view(np.int32).reshape(-1, 2)
+
+    def jobs_host(self):
+        self.sync()
+        return self.d_jobs.cpu().numpy().view(JOB_DT)
+
+    def epb(self):
+        self.sync()
+        return self.d_epb.cpu().numpy()

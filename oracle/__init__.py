@@ -9,3 +9,4 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 The product (nanopolish_amd/) never does; it fails loudly if its HIP library is missing.
 """
 from .oracle_py import Oracle, RefOracle, load_models, have_ref  # noqa: F401
+from . import workloads  # noqa: F401

@@ -185,31 +185,28 @@ void npo_sequence_kmer_ranks(int a, const char* seq, const char* rc_seq, int n, 
  * p7_FLogsum -- src/common/logsum.h:55-66, table src/common/logsum.cpp:57-69
  * ===================================================================================== */
 static float g_flogsum[NPO_LOGSUM_TBL];
-static int g_flogsum_ready = 0;
 
-const float* npo_flogsum_table(void)
+/* static initialisation, as logsum.cpp:96-97 (Init_Caller) */
+__attribute__((constructor)) static void npo_flogsum_init(void)
 {
-    if(!g_flogsum_ready) {
-        #pragma omp critical(npo_flogsum_init)
-        if(!g_flogsum_ready) {
-            for(int i = 0; i < NPO_LOGSUM_TBL; i++)
-                g_flogsum[i] = log(1. + exp((double) -i / 1000.f));   /* logsum.cpp:65 */
-            g_flogsum_ready = 1;
-        }
-    }
-    return g_flogsum;
+    for(int i = 0; i < NPO_LOGSUM_TBL; i++)
+        g_flogsum[i] = log(1. + exp((double) -i / 1000.f));   /* logsum.cpp:65 */
+    if((float)log(0.3989422804014327) != -0x1.d67f1cp-1f) { fprintf(stderr, "npo: log_inv_sqrt_2pi literal mismatch\n"); abort(); }
 }
 
-float npo_flogsum(float a, float b)
+const float* npo_flogsum_table(void) { return g_flogsum; }
+
+static inline float flogsum_inl(float a, float b)
 {
-    const float* tbl = npo_flogsum_table();
     const float max = a > b ? a : b;  /* ESL_MAX */
     const float min = a < b ? a : b;  /* ESL_MIN */
-    return (min == -INFINITY || (max - min) >= 15.7f) ? max : max + tbl[(int)((max - min) * 1000.f)];
+    return (min == -INFINITY || (max - min) >= 15.7f) ? max : max + g_flogsum[(int)((max - min) * 1000.f)];
 }
 
+float npo_flogsum(float a, float b) { return flogsum_inl(a, b); }
+
 /* add_logs, src/common/nanopolish_common.h:97-104: double in, p7_FLogsum(float,float), double out */
-static inline double add_logs(double a, double b) { return npo_flogsum((float)a, (float)b); }
+static inline double add_logs(double a, double b) { return flogsum_inl((float)a, (float)b); }
 
 /* =====================================================================================
  * Scalings + emission
@@ -227,8 +224,10 @@ npo_scalings npo_set4(double shift, double scale, double drift, double var)
  *  + log_normal_pdf                    src/hmm/nanopolish_emissions.h:51-55 */
 float npo_log_probability_match_r9(const npo_model* m, const npo_scalings* s, uint32_t rank, float level_in, float time)
 {
-    static const double inv_sqrt_2pi_d = 0.3989422804014327;
-    const float log_inv_sqrt_2pi = log(inv_sqrt_2pi_d);            /* emissions.h:43 (double log -> float) */
+    /* static const float log_inv_sqrt_2pi = log(0.3989422804014327);  emissions.h:43 (double log -> float).
+     * Kept as a literal so the oracle does not pay a libm call per emission; checked against libm in
+     * npo_flogsum_table(). */
+    const float log_inv_sqrt_2pi = -0x1.d67f1cp-1f;
     float level = level_in - time * s->drift;                        /* float - (float*double) -> double -> float */
     float gp_mean = s->scale * m->level_mean[rank] + s->shift;       /* double math, float store */
     float gp_stdv = m->level_stdv[rank] * s->var;

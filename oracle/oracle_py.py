@@ -362,3 +362,38 @@ class RefOracle:
                                    shift, scale, var, events_per_base, indel_bias, flags,
                                    _p(ev, c_u32p), _p(km, c_u32p), _p(lf, c_f64p), st, cap)
         return ev[:n].copy(), km[:n].copy(), lf[:n].copy(), np.frombuffer(st.raw[:n], np.uint8).copy()
+
+    # -- bounded drivers for the CPU baseline (kind="reference") --------------------------------------------
+    def align_many(self, seqs, events, event_off, shift, scale, n_threads=1):
+        n = len(seqs)
+        event_off = np.ascontiguousarray(event_off, np.int64)
+        pair_off = np.zeros(n + 1, np.int64)
+        pair_off[1:] = np.cumsum((event_off[1:] - event_off[:-1]) + np.array([len(s) for s in seqs]) + 2)
+        out = np.zeros((int(pair_off[-1]), 2), np.int32); out_n = np.zeros(n, np.int32)
+        events = np.ascontiguousarray(events, np.float32)
+        shift = np.ascontiguousarray(shift, np.float64); scale = np.ascontiguousarray(scale, np.float64)
+        sa = (C.c_char_p * n)(*[s.encode() for s in seqs])
+        self.L.npref_align_many.argtypes = [C.c_char_p, C.c_int, c_f32p, c_i64p, C.POINTER(C.c_char_p), c_f64p, c_f64p,
+                                            c_i32p, c_i64p, c_i32p, C.c_int]
+        self.L.npref_align_many(self.KIT, n, _p(events, c_f32p), _p(event_off, c_i64p), sa, _p(shift, c_f64p),
+                                _p(scale, c_f64p), _p(out, c_i32p), _p(pair_off, c_i64p), _p(out_n, c_i32p), int(n_threads))
+        return out, pair_off, out_n
+
+    def score_many_reads(self, alphabet, events, event_off, shift, scale, var, epb, job_off, seqs, rc_seqs,
+                         e_start, e_stop, stride, rc, flags=3, n_threads=1):
+        n = len(event_off) - 1
+        nj = len(seqs)
+        a = lambda x, t: np.ascontiguousarray(x, t)
+        events = a(events, np.float32); event_off = a(event_off, np.int64); job_off = a(job_off, np.int64)
+        shift = a(shift, np.float64); scale = a(scale, np.float64); var = a(var, np.float64); epb = a(epb, np.float64)
+        e_start = a(e_start, np.uint32); e_stop = a(e_stop, np.uint32); stride = a(stride, np.int32); rc = a(rc, np.int32)
+        sa = (C.c_char_p * nj)(*[s.encode() for s in seqs]); ra = (C.c_char_p * nj)(*[s.encode() for s in rc_seqs])
+        out = np.zeros(nj, np.float32)
+        self.L.npref_score_many_reads.argtypes = [C.c_char_p, C.c_char_p, C.c_int, c_f32p, c_i64p, c_f64p, c_f64p, c_f64p,
+                                                  c_f64p, c_i64p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), c_u32p,
+                                                  c_u32p, c_i32p, c_i32p, C.c_uint32, c_f32p, C.c_int]
+        self.L.npref_score_many_reads(self.KIT, alphabet.encode(), n, _p(events, c_f32p), _p(event_off, c_i64p),
+                                      _p(shift, c_f64p), _p(scale, c_f64p), _p(var, c_f64p), _p(epb, c_f64p),
+                                      _p(job_off, c_i64p), sa, ra, _p(e_start, c_u32p), _p(e_stop, c_u32p),
+                                      _p(stride, c_i32p), _p(rc, c_i32p), flags, _p(out, c_f32p), int(n_threads))
+        return out
