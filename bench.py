@@ -98,12 +98,14 @@ def main():
     from nanopolish_amd.api import Context
     from nanopolish_amd.pipeline import build_host_batch, tile_host_batch, CallMethylationBatch
     from nanopolish_amd.sites import site_table
+    from nanopolish_amd.shard import shard_read_ids, reduce_site_table
 
     models = load_models()
     ctx = Context(local)
     ctx.register_model(models["nucleotide"], "nucleotide"); ctx.register_model(models["cpg"], "cpg")
     t_prep = time.perf_counter()
-    hb = build_host_batch(models, np.arange(args.pool) + rank * args.pool, L=args.read_len)
+    lo, hi = shard_read_ids(world * args.pool, rank, world)          # reads shard by contiguous id range
+    hb = build_host_batch(models, np.arange(lo, hi), L=args.read_len)
     hbt = tile_host_batch(hb, args.tile)
     batch = CallMethylationBatch(ctx, hbt, "cuda:%d" % local)
     t_prep = time.perf_counter() - t_prep
@@ -132,7 +134,7 @@ def main():
     if world > 1:
         sc = batch.d_scores[:batch.n_jobs].to(torch.float64)
         table = site_table(torch, first, n_motif, sc[1::2] - sc[0::2], args.read_len)
-        dist.all_reduce(table)          # RCCL: the job's only collective (final site-level reduction)
+        reduce_site_table(table)        # RCCL all-reduce(sum): the job's only collective (final site-level reduction)
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")

@@ -119,6 +119,8 @@ typedef struct np_hmm_job {
     double          events_per_base;
     uint32_t        flags;           /* NP_HAF_* */
     uint32_t        reserved;
+    double          indel_bias;      /* hmm_indel_bias_factor for this call (src/hmm/nanopolish_profile_hmm_r9.cpp:19);
+                                        0 = the context's np_params value */
 } np_hmm_job;
 
 /* HMMAlignmentState, src/common/nanopolish_common.h:65-73 (l_posterior / log_transition_probability are

@@ -159,7 +159,7 @@ class Context:
             a.e_start = int(j["e_start"]); a.e_stop = int(j["e_stop"]); a.stride = int(j["stride"])
             a.kmer_rank = _p(rk, _l.c_u16p); a.n_kmers = len(rk); a.model = int(j["model"])
             a.scale = j["scale"]; a.shift = j["shift"]; a.var = j["var"]; a.events_per_base = j["events_per_base"]
-            a.flags = int(j.get("flags", 0))
+            a.flags = int(j.get("flags", 0)); a.indel_bias = float(j.get("indel_bias", 0.0))
         return arr, keep
 
     def profile_hmm_score(self, jobs):

@@ -365,7 +365,7 @@ static int pack_hmm_jobs(np_ctx* c, int n_jobs, const np_hmm_job* jobs, std::vec
         r.scale = q.scale; r.shift = q.shift; r.var = q.var; r.log_var = log(q.var);
         r.event_off = (int64_t)ev.size() - (int64_t)lo;      // ev[event_off + event_idx] addresses the packed window
         r.n_events = q.n_events_total;
-        np_transitions(q.events_per_base, c->params.hmm_indel_bias_factor, r.trans);
+        np_transitions(q.events_per_base, q.indel_bias != 0.0 ? q.indel_bias : c->params.hmm_indel_bias_factor, r.trans);
         ev.insert(ev.end(), q.event_mean + lo, q.event_mean + hi + 1);
         np_hmm_job_dev& d = dj[j];
         d.rank_off = (int64_t)rk.size(); d.n_kmers = q.n_kmers; d.read = (uint32_t)j;
@@ -380,6 +380,25 @@ int np_hmm_score_host(np_ctx* c, int n_jobs, const np_hmm_job* jobs, float* out_
 {
     if (!c || n_jobs < 0 || (n_jobs > 0 && (!jobs || !out_scores))) return NP_ERR_INVALID;
     if (n_jobs == 0) return NP_OK;
+    // jobs under different pore models (profile_hmm_score_set scores each alphabet's sequence under that alphabet's
+    // model, profile_hmm.cpp:44-52) are launched model by model: a kernel launch binds one model table
+    {
+        bool mixed = false;
+        for (int j = 1; j < n_jobs && !mixed; ++j) mixed = jobs[j].model != jobs[0].model;
+        if (mixed) {
+            std::vector<int> models;
+            for (int j = 0; j < n_jobs; ++j) if (std::find(models.begin(), models.end(), jobs[j].model) == models.end()) models.push_back(jobs[j].model);
+            for (int m : models) {
+                std::vector<np_hmm_job> sub; std::vector<int> idx;
+                for (int j = 0; j < n_jobs; ++j) if (jobs[j].model == m) { sub.push_back(jobs[j]); idx.push_back(j); }
+                std::vector<float> so(sub.size());
+                const int rc = np_hmm_score_host(c, (int)sub.size(), sub.data(), so.data());
+                if (rc != NP_OK) return rc;
+                for (size_t q = 0; q < idx.size(); ++q) out_scores[idx[q]] = so[q];
+            }
+            return NP_OK;
+        }
+    }
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
     std::vector<np_hmm_job_dev> dj; std::vector<np_read_dev> dr; std::vector<float> ev; std::vector<uint16_t> rk;

@@ -1,0 +1,216 @@
+// np_dropin.cpp -- the reference-side shim: the reference's own entry points, same signatures, forwarding to the
+// C ABI (include/np_hmm.h).  It is compiled INSIDE a nanopolish build (it includes nanopolish's headers) in place of
+//     src/hmm/nanopolish_profile_hmm.cpp      (profile_hmm_score x2, profile_hmm_score_set, profile_hmm_align)
+//     src/nanopolish_raw_loader.cpp           (adaptive_banded_simple_event_align, estimate_scalings_using_mom)
+// so that every caller -- basemods.cpp:374,382, nanopolish_variant.cpp:249,789-790,834, nanopolish_call_variants.cpp,
+// nanopolish_eventalign.cpp:740, nanopolish_scorereads.cpp:164,191, nanopolish_phase_reads.cpp:289,292,
+// nanopolish_squiggle_read.cpp:270 -- links unchanged.  See INTEGRATION.md.  oracle/Makefile builds exactly this
+// configuration (`make -C oracle dropin`) and tests/test_gpu_dropin.py runs the reference's harness through it.
+//
+// One call = one tiny batch: correct, but launch-bound.  The throughput path is the *_dev batch API fed at the
+// BamProcessor batch boundary; this file is the drop-in for parity and for the minor callers.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include "nanopolish_profile_hmm.h"
+#include "nanopolish_profile_hmm_r9.h"
+#include "nanopolish_profile_hmm_r7.h"
+#include "nanopolish_raw_loader.h"
+#include "np_hmm.h"
+
+extern double hmm_indel_bias_factor;   // src/hmm/nanopolish_profile_hmm_r9.cpp:19 (still the caller-visible knob)
+
+namespace {
+
+struct Shim {
+    np_ctx* ctx = nullptr;
+    std::map<const PoreModel*, int> models;
+    std::mutex lock;
+
+    np_ctx* get()
+    {
+        std::lock_guard<std::mutex> g(lock);
+        if (!ctx) {
+            const char* dev = getenv("NP_DEVICE");
+            ctx = np_create(dev ? atoi(dev) : 0, NULL);
+            if (!ctx) { fprintf(stderr, "nanopolish_amd: %s\n", np_last_error(NULL)); exit(EXIT_FAILURE); }
+        }
+        return ctx;
+    }
+
+    int model_id(const PoreModel* m)
+    {
+        np_ctx* c = get();
+        std::lock_guard<std::mutex> g(lock);
+        auto it = models.find(m);
+        if (it != models.end()) return it->second;
+        const size_t n = m->states.size();
+        std::vector<double> lm(n), ls(n), ll(n);
+        for (size_t i = 0; i < n; ++i) { lm[i] = m->states[i].level_mean; ls[i] = m->states[i].level_stdv; ll[i] = m->states[i].level_log_stdv; }
+        const int id = np_register_model(c, (int)m->k, (int)n, lm.data(), ls.data(), ll.data());
+        if (id < 0) { fprintf(stderr, "nanopolish_amd: np_register_model: %s\n", np_last_error(c)); exit(EXIT_FAILURE); }
+        models[m] = id;
+        return id;
+    }
+};
+
+Shim& shim() { static Shim s; return s; }
+
+void fail(const char* what, int rc)
+{
+    fprintf(stderr, "nanopolish_amd: %s failed (%d): %s\n", what, rc, np_last_error(shim().get()));
+    exit(EXIT_FAILURE);
+}
+
+// (HMMInputSequence, HMMInputData) -> np_hmm_job.  `ev` and `ranks` own the flattened buffers.
+struct FlatJob {
+    std::vector<float> ev;
+    std::vector<uint16_t> ranks;
+    np_hmm_job job;
+};
+
+void flatten(const HMMInputSequence& sequence, const HMMInputData& data, uint32_t flags, FlatJob& f)
+{
+    const SquiggleRead* read = data.read;
+    const uint8_t strand = data.strand;
+    const SquiggleScalings& sc = read->scalings[strand];
+    assert(sc.drift == 0.0);                 // always 0 on the R9 path (squiggle_read.cpp:310, raw_loader.cpp:52)
+    assert((data.rc && data.event_stride == -1) || (!data.rc && data.event_stride == 1));   // r9.inl:275
+    const uint32_t k = data.pore_model->k;
+    const uint32_t n_kmers = sequence.length() - k + 1;
+    assert(data.pore_model->states.size() == sequence.get_num_kmer_ranks(k));               // r9.inl:305
+    const uint32_t lo = std::min(data.event_start_idx, data.event_stop_idx), hi = std::max(data.event_start_idx, data.event_stop_idx);
+    f.ev.resize(hi - lo + 1);
+    for (uint32_t e = lo; e <= hi; ++e) f.ev[e - lo] = read->events[strand][e].mean;
+    f.ranks.resize(n_kmers);
+    for (uint32_t i = 0; i < n_kmers; ++i) f.ranks[i] = (uint16_t)sequence.get_kmer_rank(i, k, data.rc);
+    np_hmm_job& j = f.job;
+    j.event_mean = f.ev.data() - lo;         // the library only touches indices [lo, hi]
+    j.n_events_total = (uint32_t)read->events[strand].size();
+    j.e_start = data.event_start_idx; j.e_stop = data.event_stop_idx; j.stride = data.event_stride;
+    j.kmer_rank = f.ranks.data(); j.n_kmers = n_kmers;
+    j.model = shim().model_id(data.pore_model);
+    j.scale = sc.scale; j.shift = sc.shift; j.var = sc.var;
+    j.events_per_base = read->events_per_base[strand];
+    j.flags = flags; j.reserved = 0;
+    j.indel_bias = hmm_indel_bias_factor;
+}
+
+} // namespace
+
+// src/hmm/nanopolish_profile_hmm.cpp:23-30
+float profile_hmm_score(const HMMInputSequence& sequence, const HMMInputData& data, const uint32_t flags)
+{
+    if (data.read->pore_type != PORETYPE_R9) return profile_hmm_score_r7(sequence, data, flags);
+    FlatJob f;
+    flatten(sequence, data, flags, f);
+    float out = 0.0f;
+    const int rc = np_hmm_score_host(shim().get(), 1, &f.job, &out);
+    if (rc != NP_OK) fail("np_hmm_score_host", rc);
+    return out;
+}
+
+// src/hmm/nanopolish_profile_hmm.cpp:14-21 -- one device batch over all reads, summed in index order in float
+float profile_hmm_score(const HMMInputSequence& sequence, const std::vector<HMMInputData>& data, const uint32_t flags)
+{
+    std::vector<FlatJob> f(data.size());
+    std::vector<np_hmm_job> jobs(data.size());
+    for (size_t i = 0; i < data.size(); ++i) {
+        assert(data[i].read->pore_type == PORETYPE_R9);
+        flatten(sequence, data[i], flags, f[i]);
+        jobs[i] = f[i].job;
+    }
+    std::vector<float> sc(data.size());
+    const int rc = np_hmm_score_host(shim().get(), (int)jobs.size(), jobs.data(), sc.data());
+    if (rc != NP_OK) fail("np_hmm_score_host", rc);
+    float score = 0.0f;
+    for (size_t i = 0; i < sc.size(); ++i) score += sc[i];
+    return score;
+}
+
+// src/hmm/nanopolish_profile_hmm.cpp:32-56
+float profile_hmm_score_set(const std::vector<HMMInputSequence>& sequences, const HMMInputData& data, const uint32_t flags)
+{
+    assert(!sequences.empty());
+    assert(std::string(sequences[0].get_alphabet()->get_name()) == "nucleotide");
+    assert(std::string(data.pore_model->pmalphabet->get_name()) == "nucleotide");
+    std::vector<FlatJob> f(sequences.size());
+    std::vector<np_hmm_job> jobs(sequences.size());
+    HMMInputData alt = data;
+    for (size_t s = 0; s < sequences.size(); ++s) {
+        if (s > 0) {
+            alt.pore_model = alt.read->get_model(alt.strand, sequences[s].get_alphabet()->get_name());
+            assert(alt.pore_model != NULL);
+        }
+        flatten(sequences[s], s == 0 ? data : alt, flags, f[s]);
+        jobs[s] = f[s].job;
+    }
+    const int32_t off[2] = {0, (int32_t)jobs.size()};
+    float out = 0.0f;
+    const int rc = np_hmm_score_set_host(shim().get(), 1, off, jobs.data(), &out);
+    if (rc != NP_OK) fail("np_hmm_score_set_host", rc);
+    return out;
+}
+
+// src/hmm/nanopolish_profile_hmm.cpp:58-65
+std::vector<HMMAlignmentState> profile_hmm_align(const HMMInputSequence& sequence, const HMMInputData& data, const uint32_t flags)
+{
+    if (data.read->pore_type != PORETYPE_R9) return profile_hmm_align_r7(sequence, data, flags);
+    FlatJob f;
+    flatten(sequence, data, flags, f);
+    const int64_t cap = (int64_t)f.ev.size() + f.job.n_kmers + 2;
+    std::vector<np_hmm_state> st(cap);
+    int64_t off[2] = {0, 0};
+    const int rc = np_hmm_align_host(shim().get(), 1, &f.job, st.data(), cap, off);
+    if (rc != NP_OK) fail("np_hmm_align_host", rc);
+    std::vector<HMMAlignmentState> out(off[1]);
+    for (int64_t i = 0; i < off[1]; ++i) {
+        out[i].event_idx = st[i].event_idx; out[i].kmer_idx = st[i].kmer_idx;
+        out[i].l_posterior = -INFINITY; out[i].l_fm = st[i].l_fm; out[i].log_transition_probability = -INFINITY;
+        out[i].state = st[i].state;
+    }
+    return out;
+}
+
+// src/nanopolish_raw_loader.cpp:17-60
+SquiggleScalings estimate_scalings_using_mom(const std::string& sequence, const PoreModel& pore_model, const event_table& et)
+{
+    const size_t k = pore_model.k, n_kmers = sequence.size() - k + 1;
+    std::vector<uint16_t> ranks(n_kmers);
+    for (size_t i = 0; i < n_kmers; ++i) ranks[i] = (uint16_t)pore_model.pmalphabet->kmer_rank(sequence.c_str() + i, k);
+    std::vector<double> lm(pore_model.states.size());
+    for (size_t i = 0; i < lm.size(); ++i) lm[i] = pore_model.states[i].level_mean;
+    std::vector<float> ev(et.n);
+    for (size_t i = 0; i < et.n; ++i) ev[i] = et.event[i].mean;
+    double shift, scale;
+    np_estimate_scalings_mom(lm.data(), ranks.data(), (uint32_t)n_kmers, ev.data(), (uint32_t)et.n, &shift, &scale);
+    SquiggleScalings out;
+    out.set4(shift, scale, 0.0, 1.0);
+    return out;
+}
+
+// src/nanopolish_raw_loader.cpp:77-379
+std::vector<AlignedPair> adaptive_banded_simple_event_align(SquiggleRead& read, const PoreModel& pore_model, const std::string& sequence)
+{
+    const size_t strand_idx = 0, k = pore_model.k;
+    const size_t n_events = read.events[strand_idx].size(), n_kmers = sequence.size() - k + 1;
+    assert(read.scalings[strand_idx].drift == 0.0);
+    std::vector<float> ev(n_events);
+    for (size_t i = 0; i < n_events; ++i) ev[i] = read.events[strand_idx][i].mean;
+    std::vector<uint16_t> ranks(n_kmers);
+    for (size_t i = 0; i < n_kmers; ++i) ranks[i] = (uint16_t)pore_model.pmalphabet->kmer_rank(sequence.c_str() + i, k);
+    np_align_job j;
+    j.event_mean = ev.data(); j.n_events = (uint32_t)n_events; j.kmer_rank = ranks.data(); j.n_kmers = (uint32_t)n_kmers;
+    j.model = shim().model_id(&pore_model);
+    j.scale = read.scalings[strand_idx].scale; j.shift = read.scalings[strand_idx].shift; j.var = read.scalings[strand_idx].var;
+    const int64_t cap = (int64_t)n_events + n_kmers + 2;
+    std::vector<np_pair> pairs(cap);
+    int64_t off[2] = {0, 0};
+    const int rc = np_event_align_host(shim().get(), 1, &j, pairs.data(), cap, off);
+    if (rc != NP_OK) fail("np_event_align_host", rc);
+    std::vector<AlignedPair> out(off[1]);
+    for (int64_t i = 0; i < off[1]; ++i) { out[i].ref_pos = pairs[i].ref_pos; out[i].read_pos = pairs[i].read_pos; }
+    return out;
+}

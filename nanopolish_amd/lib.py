@@ -32,7 +32,7 @@ class HmmJob(C.Structure):
     _fields_ = [("event_mean", c_f32p), ("n_events_total", C.c_uint32), ("e_start", C.c_uint32), ("e_stop", C.c_uint32),
                 ("stride", C.c_int32), ("kmer_rank", c_u16p), ("n_kmers", C.c_uint32), ("model", C.c_int32),
                 ("scale", C.c_double), ("shift", C.c_double), ("var", C.c_double), ("events_per_base", C.c_double),
-                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+                ("flags", C.c_uint32), ("reserved", C.c_uint32), ("indel_bias", C.c_double)]
 
 
 class HmmState(C.Structure):
@@ -82,6 +82,13 @@ def load_library():
         raise RuntimeError(
             "nanopolish_amd: %s is missing -- the HIP extension is not built (run `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C nanopolish_amd/csrc`).  There is no CPU fallback." % _LIB)
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.  Import torch first (when it is
+    # installed) so that libnp_hip.so binds to the runtime torch uses, whatever order the caller imports things in;
+    # without torch the library's rpath (/opt/rocm/lib) provides the runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(_LIB)
     vp = C.c_void_p
     L.np_create.restype = vp

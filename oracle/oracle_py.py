@@ -260,13 +260,15 @@ class RefOracle:
     """The reference's own code (oracle/_ref/libnp_ref.so). Only where it has been built."""
     KIT = b"r9.4_450bps"
 
-    def __init__(self):
-        if not have_ref():
+    def __init__(self, path=None):
+        """path: another build of the same harness, e.g. oracle/_ref/libnp_ref_dropin.so (the reference with its two
+        hot-path translation units replaced by the product's shim) -- used by tests/test_gpu_dropin.py."""
+        if path is None and not have_ref():
             if os.path.isdir("/root/reference"):
                 build_ref()
             else:
                 raise RuntimeError("oracle/_ref/libnp_ref.so not built and /root/reference absent")
-        L = self.L = C.CDLL(_REF)
+        L = self.L = C.CDLL(path or _REF)
         L.npref_add_logs.restype = C.c_float
         L.npref_add_logs.argtypes = [C.c_float, C.c_float]
         L.npref_log_probability_match_r9.restype = C.c_float

@@ -132,3 +132,64 @@ def test_goldens_from_reference(ctx, models):
                                  var=rd["var"], events_per_base=epb, flags=HAF_PRE | HAF_POST))
         got = ctx.profile_hmm_score(jobs)
         assert np.array_equal(got[0::2], g[p + "score_unmeth"]) and np.array_equal(got[1::2], g[p + "score_meth"])
+
+
+def test_fused_call_methylation_pass_matches_oracle(ctx, orc, models):
+    """The device-resident pass (align -> event map/transitions/bounds on device -> 2 x score per group) vs the
+    reference's per-read pass on the oracle: pairs bit-exact, events_per_base equal, every scored group equal,
+    skipped groups skipped."""
+    from cases import call_methylation_read
+    from nanopolish_amd.pipeline import build_host_batch, tile_host_batch, CallMethylationBatch
+    mn = orc.model(models["nucleotide"]); mc = orc.model(models["cpg"])
+    hb = build_host_batch(models, list(range(60, 72)), L=2000)
+    batch = CallMethylationBatch(ctx, tile_host_batch(hb, 2), "cuda:0")
+    batch.step(); batch.step()            # twice: the pass must be re-runnable on the same buffers
+    scores = batch.scores(); epb = batch.epb()
+    ng_read = [len(m["first"]) for m in hb["meta"]]
+    tot_groups = sum(ng_read)
+    g0 = 0
+    n_checked = 0
+    for i, rd in enumerate(hb["reads"]):
+        want = call_methylation_read(orc, mn, mc, rd)
+        for copy in (0, 1):
+            r = i + copy * hb["n"]
+            assert np.array_equal(batch.pairs_of(r), want["pairs"])
+            assert epb[r] == want["epb"]
+            base = g0 + copy * tot_groups
+            firsts = list(hb["meta"][i]["first"])
+            scored = set()
+            for f, u, m in zip(want["first"], want["unmeth"], want["meth"]):
+                g = base + firsts.index(f)
+                assert scores[2 * g] == u and scores[2 * g + 1] == m
+                scored.add(firsts.index(f)); n_checked += 1
+            for q in range(len(firsts)):
+                if q not in scored:
+                    assert np.isnan(scores[2 * (base + q)]) and np.isnan(scores[2 * (base + q) + 1])
+        g0 += ng_read[i]
+    assert n_checked > 1000
+
+
+def test_hmm_score_set_matches_golden(ctx, models):
+    import os
+    from nanopolish_amd import api
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_reads.npz"))
+    from cases import eventalign_segments
+    from oracle import Oracle
+    o = Oracle()
+    c9 = api.Context(0, indel_bias=0.9)
+    mn = c9.register_model(models["nucleotide"]); mc = c9.register_model(models["cpg"])
+    for rid, L in zip(g["read_ids"], g["read_L"]):
+        p = "r%d_" % rid
+        if p + "score_set" not in g.files:
+            continue
+        rd = synth_read(int(rid), models["nucleotide"], L=int(L))
+        epb, segs = eventalign_segments(o, rd, g[p + "pairs"])
+        sets = []
+        for sg in segs[:4]:
+            w = sg["seq"][:30]
+            common = dict(events=rd["events"], e_start=sg["e1"], e_stop=sg["e1"] + 40, stride=1, scale=rd["scale"],
+                          shift=rd["shift"], var=rd["var"], events_per_base=epb, flags=0)
+            sets.append([dict(common, ranks=api.sequence_kmer_ranks("nucleotide", w), model=mn),
+                         dict(common, ranks=api.sequence_kmer_ranks("cpg", api.methylate("cpg", w)), model=mc)])
+        assert np.array_equal(c9.profile_hmm_score_set(sets), g[p + "score_set"])
+    c9.close()

@@ -1,0 +1,112 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads, exports every symbol include/np_hmm.h
+declares, refuses to run without a GPU (no CPU fallback), and its host helpers agree with the oracle / goldens."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cases import K, methylation_jobs, synth_read, revcomp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from nanopolish_amd.lib import load_library, build_library, library_path
+    if not os.path.exists(library_path()):
+        build_library()
+    return load_library()
+
+
+def test_library_exports_every_declared_symbol(L):
+    from nanopolish_amd.lib import SYMBOLS
+    hdr = open(os.path.join(ROOT, "include", "np_hmm.h")).read()
+    declared = set(re.findall(r"\b(np_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(SYMBOLS), (declared ^ set(SYMBOLS))
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+def test_struct_layouts_match_header(L):
+    from nanopolish_amd import lib
+    assert C.sizeof(lib.ReadDev) == 136 and C.sizeof(lib.HmmJobDev) == 32 and C.sizeof(lib.Pair) == 8
+    assert C.sizeof(lib.HmmState) == 24 and C.sizeof(lib.HmmJob) == 88 and C.sizeof(lib.AlignJob) == 56
+
+
+def test_no_cpu_fallback_without_device(L):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from nanopolish_amd.api import Context
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Context(0)
+
+
+def test_alphabet_helpers_match_goldens(L):
+    from nanopolish_amd import api
+    t = np.load(os.path.join(ROOT, "tests", "golden", "golden_tables.npz"))
+    for a, s, rc, me, un, mo, r6 in zip(t["kat_alphabet"], t["kat_in"], t["kat_rc"], t["kat_meth"], t["kat_unmeth"],
+                                        t["kat_motif"], t["kat_rank6"]):
+        a, s = str(a), str(s)
+        assert api.reverse_complement(a, s) == str(rc)
+        base = s.replace("M", "A") if a == "dam" else s.replace("M", "C")
+        assert api.methylate(a, base) == str(me)
+        assert api.unmethylate(a, s) == str(un)
+        assert "".join("1" if api.is_motif_match(a, s, i) else "0" for i in range(max(len(s) - 1, 0))) == str(mo)
+        if r6 >= 0:
+            assert api.kmer_rank(a, s[:6]) == r6
+
+
+def test_transitions_and_logf_match_host_libm(L, orc):
+    """np_logf.h restates glibc logf; calculate_transitions must equal the oracle's (which calls libm logf)."""
+    from nanopolish_amd import api
+    rng = np.random.default_rng(3)
+    epbs = np.concatenate([rng.uniform(0.0, 6.0, 20000), np.linspace(1.0, 3.0, 20001), [0.0, 1.25, 5.0, 50.0]])
+    for bias in (1.0, 0.9, 0.8):
+        for e in epbs[:: (1 if bias == 1.0 else 7)]:
+            assert np.array_equal(api.calculate_transitions(float(e), bias), orc.calculate_transitions(float(e), bias)), (e, bias)
+
+
+def test_mom_ranks_and_jobs_match_oracle(L, orc, models):
+    from nanopolish_amd import api
+    mn = orc.model(models["nucleotide"])
+    for rid in (0, 1, 2, 3):
+        rd = synth_read(rid, models["nucleotide"], L=1500)
+        assert api.estimate_scalings_using_mom(models["nucleotide"], rd["ranks"], rd["events"]) == \
+            orc.estimate_scalings_mom(mn, rd["ranks"], rd["events"])
+        ref_seq = revcomp(rd["seq"]) if rd["rc"] else rd["seq"]
+        assert api.reverse_complement("nucleotide", rd["seq"]) == revcomp(rd["seq"])
+        jb = api.cm_build_jobs_identity(ref_seq, rd["rc"])
+        f, l, c = orc.scan_motif_groups("cpg", ref_seq)
+        f2, l2, c2 = api.scan_motif_groups("cpg", ref_seq)
+        assert np.array_equal(f, f2) and np.array_equal(l, l2) and np.array_equal(c, c2)
+        # every oracle work item appears in the product's list with identical k-mer ranks and bounding k-mers
+        sh, sc = orc.estimate_scalings_mom(mn, rd["ranks"], rd["events"])
+        pairs = orc.event_align(mn, orc.scalings(sh, sc, 1.0), rd["events"], rd["ranks"])
+        start, stop, epb = orc.build_base_to_event_map(pairs, len(rd["ranks"]))
+        epb2, jobs = methylation_jobs(orc, rd, pairs)
+        firsts = list(jb["first"])
+        assert len(jobs) > 10
+        for j in jobs:
+            i = firsts.index(j["first"])
+            lo, hi = jb["rank_off"][i], jb["rank_off"][i + 1]
+            assert np.array_equal(jb["ranks_unmeth"][lo:hi], orc.sequence_kmer_ranks("cpg", j["subseq"], j["rc_subseq"], K, j["rc"]))
+            assert np.array_equal(jb["ranks_meth"][lo:hi], orc.sequence_kmer_ranks("cpg", j["m_subseq"], j["rc_m_subseq"], K, j["rc"]))
+            assert orc.get_closest_event_to(start, jb["kpos"][i, 0]) == j["e1"]
+            assert orc.get_closest_event_to(start, jb["kpos"][i, 1]) == j["e2"]
+
+
+def test_fill_read_host_constants(L):
+    from nanopolish_amd import lib
+    import math
+    r = lib.ReadDev()
+    L.np_fill_read_host(C.byref(r), 1.5, 1.05, 1.2, 10, 8000, 20, 5445)
+    epk = 8000 / 5445
+    p_stay = 1 - (1 / (epk + 1))
+    assert r.lp_skip == math.log(1e-10) and r.lp_stay == math.log(p_stay) and r.lp_trim == math.log(0.01)
+    assert r.lp_step == math.log(1.0 - math.exp(r.lp_skip) - math.exp(r.lp_stay))
+    assert (r.shift, r.scale, r.var, r.log_var) == (1.5, 1.05, 1.2, math.log(1.2))
+    assert (r.event_off, r.n_events, r.rank_off, r.n_kmers) == (10, 8000, 20, 5445)

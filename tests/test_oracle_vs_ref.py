@@ -1,0 +1,77 @@
+"""Pins the portable oracle against the reference's own code compiled in place (oracle/_ref/libnp_ref.so).
+Only runs where that library exists (the build container; it also travels to the GPU box as a built .so)."""
+import numpy as np
+import pytest
+
+from oracle import have_ref
+from cases import K, HAF_PRE, HAF_POST, methylation_jobs, eventalign_segments, synth_read
+
+pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref/libnp_ref.so not built (needs /root/reference)")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle import RefOracle
+    return RefOracle()
+
+
+def test_models_and_table_match_fixture(ref, orc, models):
+    for a in ("nucleotide", "cpg"):
+        m = ref.model(a)
+        for f in ("level_mean", "level_stdv", "level_log_stdv"):
+            assert np.array_equal(m[f], models[a][f])
+    assert np.array_equal(ref.flogsum_table(), orc.flogsum_table())
+
+
+def test_alphabets_random_strings(ref, orc):
+    rng = np.random.default_rng(7)
+    for a in ("nucleotide", "cpg", "gpc", "dam", "dcm"):
+        for _ in range(300):
+            n = int(rng.integers(1, 30))
+            s = "".join(rng.choice(list("ACGT"), n))
+            m = ref.methylate(a, s)
+            assert orc.methylate(a, s) == m
+            for t in (s, m):
+                assert orc.reverse_complement(a, t) == ref.reverse_complement(a, t)
+                assert orc.unmethylate(a, t) == ref.unmethylate(a, t)
+                for i in range(max(n - 1, 0)):
+                    assert orc.is_motif_match(a, t, i) == ref.is_motif_match(a, t, i)
+                if n >= 6:
+                    assert orc.kmer_rank(a, t[:6]) == ref.kmer_rank(a, t[:6])
+
+
+@pytest.mark.parametrize("rid,L", [(100, 300), (101, 300), (102, 1000), (103, 1000), (104, 2600), (105, 2600)])
+def test_read_pipeline_bit_equal(ref, orc, models, rid, L):
+    mn = orc.model(models["nucleotide"]); mc = orc.model(models["cpg"])
+    rd = synth_read(rid, models["nucleotide"], L=L)
+    assert orc.estimate_scalings_mom(mn, rd["ranks"], rd["events"]) == ref.estimate_scalings_mom(rd["seq"], rd["events"])
+    sh, sc = ref.estimate_scalings_mom(rd["seq"], rd["events"])
+    p_ref = ref.event_align(rd["events"], rd["seq"], sh, sc)
+    p = orc.event_align(mn, orc.scalings(sh, sc, 1.0), rd["events"], rd["ranks"])
+    assert len(p_ref) > 0 and np.array_equal(p, p_ref)
+    epb, jobs = methylation_jobs(orc, rd, p)
+    S = orc.scalings(rd["shift"], rd["scale"], rd["var"])
+    for j in jobs:
+        for s, r in ((j["subseq"], j["rc_subseq"]), (j["m_subseq"], j["rc_m_subseq"])):
+            ranks = orc.sequence_kmer_ranks("cpg", s, r, K, j["rc"])
+            for flags, bias in ((HAF_PRE | HAF_POST, 1.0), (0, 0.9)):
+                a = orc.hmm_score(mc, S, rd["events"], ranks, j["e1"], j["e2"], j["stride"], epb, bias, flags)
+                b = ref.hmm_score("cpg", s, r, rd["events"], j["e1"], j["e2"], j["stride"], j["rc"], rd["shift"], rd["scale"],
+                                  rd["var"], epb, bias, flags)
+                assert a == b
+    if not rd["rc"]:
+        epb2, segs = eventalign_segments(orc, rd, p)
+        for sg in segs:
+            ranks = orc.sequence_kmer_ranks("nucleotide", sg["seq"], None, K, 0)
+            a = orc.hmm_align(mn, S, rd["events"], ranks, sg["e1"], sg["e2"], 1, epb2)
+            b = ref.hmm_align("nucleotide", sg["seq"], None, rd["events"], sg["e1"], sg["e2"], 1, 0, rd["shift"], rd["scale"],
+                              rd["var"], epb2)
+            assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_qc_failure_matches(ref, orc, models):
+    mn = orc.model(models["nucleotide"])
+    rd = synth_read(40, models["nucleotide"], L=600); other = synth_read(41, models["nucleotide"], L=600)
+    sh, sc = ref.estimate_scalings_mom(other["seq"], rd["events"])
+    assert len(ref.event_align(rd["events"], other["seq"], sh, sc)) == 0
+    assert len(orc.event_align(mn, orc.scalings(sh, sc, 1.0), rd["events"], other["ranks"])) == 0
