@@ -21,13 +21,15 @@ struct __attribute__((aligned(32))) np_state_dev {
 // Both-(-inf) inputs: max-min is NaN, the (min == -inf) test selects max, the clamped index is discarded.
 __device__ __forceinline__ float np_lse(float a, float b, const float* __restrict__ tbl)
 {
-    const float mx = a > b ? a : b;   // ESL_MAX
-    const float mn = a < b ? a : b;   // ESL_MIN
-    const float d = mx - mn;
-    uint32_t idx = (uint32_t)(int)(d * 1000.f);      // (int) truncation, as the reference
-    idx = idx < (NP_LOGSUM_TBL - 1) ? idx : (NP_LOGSUM_TBL - 1);
-    const float t = tbl[idx];
-    return (mn == NP_NEG_INF || d >= 15.7f) ? mx : mx + t;
+    // ESL_MAX / ESL_MIN: inputs are never NaN here (only finite values and -inf), so v_max/v_min are exact.
+    const float mx = __builtin_fmaxf(a, b);
+    const float mn = __builtin_fminf(a, b);
+    const float d = mx - mn;                          // +inf when only mn is -inf, NaN when both are
+    // (int) truncation as the reference.  The index is only used when d < 15.7f (< 15700); for larger d / inf /
+    // NaN the LDS read may be out of range, which returns garbage-or-zero without faulting, and is discarded.
+    const float t = tbl[(int)(d * 1000.f)];
+    // reference: (min == -inf || d >= 15.7f) ? max : max + t.  `!(d < 15.7f)` covers d >= 15.7, +inf and NaN.
+    return (d < 15.7f) ? mx + t : mx;
 }
 
 // get_scaled_gaussian_from_pore_model_state (src/nanopolish_squiggle_read.h:217-226): double math, float store.

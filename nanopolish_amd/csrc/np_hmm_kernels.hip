@@ -93,6 +93,12 @@ __global__ void __launch_bounds__(NP_HMM_BLOCK) np_hmm_forward_kernel(np_hmm_arg
         const int last_lane = (n - 1) / C, last_c = (n - 1) % C;
 
         const int steps = wave_max_i32(has ? e + lanes_used - 1 : 0);
+        const bool is_last = lane_on && sl == last_lane;
+        // software prefetch, one step ahead: event mean of the row this lane computes next, and the two clip-flank
+        // values only the first / last k-mer's lane needs (pre_flank[r-1], post_flank[r-1] == flank[e-r])
+        float xn = 0.0f, softn = NP_NEG_INF, pfn = 0.0f;
+        if (lane_on && sl == 0) { xn = ev[job.e_start]; softn = a.flank[0]; }      // row 1: event_idx == e_start (r9.inl:361)
+        if (is_last && sl == 0 && (post_clip || e == 1)) pfn = a.flank[e - 1];
         for (int t = 1; t <= steps; ++t) {
             // left neighbour's row r (what lane j-1 computed in step t-1); segment heads see block 0 = -inf
             float nM = np_wave_shr1(cur.M[C - 1], NP_NEG_INF);
@@ -102,9 +108,15 @@ __global__ void __launch_bounds__(NP_HMM_BLOCK) np_hmm_forward_kernel(np_hmm_arg
 
             const int r = t - sl;
             const bool act = lane_on && r >= 1 && r <= e;
+            const float x = xn, soft = softn, pf = pfn;
+            {
+                const int rn = r + 1;                     // the row of the next step
+                const bool actn = lane_on && rn >= 1 && rn <= e;
+                xn = actn ? ev[job.e_start + (uint32_t)((rn - 1) * stride)] : 0.0f;                    // r9.inl:342
+                softn = (actn && sl == 0 && (rn == 1 || pre_clip)) ? a.flank[rn - 1] : NP_NEG_INF;     // r9.inl:361-363
+                pfn = (actn && is_last && (post_clip || rn == e)) ? a.flank[e - rn] : 0.0f;           // r9.inl:388
+            }
             if (act) {
-                const uint32_t event_idx = job.e_start + (uint32_t)((r - 1) * stride);   // r9.inl:342
-                const float x = ev[event_idx];
                 float lM_r = nM, lB_r = nB, lK_r = nK;     // block to the left, row r
                 float lM_p = oM, lB_p = oB, lK_p = oK;     // block to the left, row r-1
 #pragma unroll
@@ -116,10 +128,7 @@ __global__ void __launch_bounds__(NP_HMM_BLOCK) np_hmm_forward_kernel(np_hmm_arg
                     s = np_lse(s, lp_bm_self + cur.B[c], tbl);
                     s = np_lse(s, lp_bm_next + lB_p, tbl);
                     s = np_lse(s, lp_km + lK_p, tbl);
-                    if (c == 0) {
-                        const float soft = (sl == 0 && (r == 1 || pre_clip)) ? a.flank[r - 1] : NP_NEG_INF;
-                        s = np_lse(s, soft, tbl);
-                    }
+                    if (c == 0) s = np_lse(s, soft, tbl);   // HMT_FROM_SOFT: -inf except for the first k-mer
                     const float newM = s + em;
                     // PSR9_BAD_EVENT (r9.inl:368-374): only SAME_M and SAME_B are finite; emission 0
                     const float newB = np_lse(lp_mb + cur.M[c], lp_bb + cur.B[c], tbl);
@@ -132,7 +141,6 @@ __global__ void __launch_bounds__(NP_HMM_BLOCK) np_hmm_forward_kernel(np_hmm_arg
 
                     // end state (r9.inl:388-396): last k-mer, M then B then K
                     if (sl == last_lane && c == last_c && (post_clip || r == e)) {
-                        const float pf = a.flank[e - r];          // post_flank[row-1]
                         lp_end = np_lse(lp_end, newM + pf, tbl);
                         lp_end = np_lse(lp_end, newB + pf, tbl);
                         lp_end = np_lse(lp_end, newK + pf, tbl);
