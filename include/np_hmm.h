@@ -218,6 +218,10 @@ int np_resolve_jobs_dev(np_ctx* ctx, void* stream, int n_reads, np_read_dev* rea
                         int32_t* map_start, double* events_per_base,
                         int64_t n_jobs, np_hmm_job_dev* jobs, const int32_t* kpos);
 
+/* Device self-test: the emission's exact fast division (reciprocal + two fused corrections) against the IEEE fp32
+ * divide on n_samples pseudo-random operand pairs; *n_mismatch must come back 0. */
+int np_selftest_division(np_ctx* ctx, uint64_t n_samples, uint64_t seed, uint64_t* n_mismatch);
+
 /* Synchronise the context's stream (or the given one). */
 int np_sync(np_ctx* ctx, void* stream);
 

@@ -10,11 +10,15 @@
 //     which is exactly the reference's is_offset_valid(...) ? BAND_ARRAY(...) : -INFINITY.
 //   * Suzuki's move rule reads the band's first and last cell (ll, ur) with v_readlane; all band geometry is
 //     wave-uniform scalar state.
+//   * Prologue per read: the scaled Gaussian of every k-mer (fp64 math of squiggle_read.h:217-226, plus the
+//     correctly rounded reciprocal of sigma) goes into a per-wave slab, 16 B per k-mer; the band loop then only
+//     does fp32 emissions and the reference's fp64 candidate sums.
 //   * The inner step is branch-free per lane: DP cells are computed by every lane and masked; the trim column
-//     (k-mer -1) and the end-cell search only exist while the window touches k = -1 / k = K-1, so they sit behind
-//     wave-uniform branches.  Event means are prefetched one band ahead; when the window moves right the slot that
-//     fell out is re-targeted 128 k-mers ahead through a 3-stage software pipeline (rank load -> model load ->
-//     fp64 scaling), so no load is ever waited for in the step that issued it.
+//     (k-mer -1) and the end-cell search only exist while the window touches k = -1 / k = K-1 and sit behind
+//     wave-uniform branches.  Event means are prefetched one band ahead into ping-pong registers (the band loop is
+//     unrolled by two so no register rotation -- and therefore no early s_waitcnt -- is needed).  A ring slot always
+//     holds the parameters of its next k-mer (k+128) in `pend`, requested when the slot is re-targeted and consumed
+//     128 right-moves later.
 //   * Candidates are evaluated as the reference does: fp32 cell + fp64 transition constant + fp32 emission in
 //     fp64, rounded to fp32, compared in fp32, later candidate wins ties (raw_loader.cpp:259-274).
 //   * The trace is 2 bits per cell, packed with 4 ballots per band into 32 bytes (vs 100 bytes in the
@@ -49,31 +53,25 @@ __device__ __forceinline__ float ring_read(float r0, float r1, int s)
     return (s & 64) ? b : a;
 }
 
-// One ring slot: the k-mer it currently represents, its scaled Gaussian, and the refill pipeline state.
-struct slot_t {
-    int k;
-    np_gauss g;
-    int st;                 // 0 idle, 1 rank in flight, 2 model state in flight
-    uint32_t pr;            // pending rank
-    double pm_mean, pm_stdv, pm_lstdv;   // pending unscaled state
-};
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__device__ __forceinline__ np_gauss scale_raw(double lm, double ls, double ll, double scale, double shift, double var, double log_var)
+// parameter record of k-mer k from this wave's slab; the index is clamped (never a branch, never a default value:
+// a conditional load would make hipcc wait for it on the spot) -- records of k outside [0,K) are never used
+__device__ __forceinline__ float4 load_kp(const float4* __restrict__ kp, int k, int K) { return kp[clampi(k, 0, K - 1)]; }
+
+__device__ __forceinline__ np_gauss as_gauss(const float4 v)
 {
-    np_gauss g;
-    g.mean = (float)(scale * lm + shift);
-    g.stdv = (float)(ls * var);
-    g.cl = -0.918938518f - (float)(ll + log_var);
+    np_gauss g; g.mean = v.x; g.stdv = v.y; g.cl = v.z; g.rinv = v.w;
     return g;
 }
 
 struct cell_out { float v; uint32_t from; };
 
 // DP cell (raw_loader.cpp:240-289), computed unconditionally and masked by `valid`.
-__device__ __forceinline__ cell_out dp_cell(bool valid, float x, const np_gauss& g, float up, float left, float diag,
+__device__ __forceinline__ cell_out dp_cell(bool valid, float x, const float4 gp, float up, float left, float diag,
                                             double lp_skip, double lp_stay, double lp_step)
 {
-    const float em = np_emission(x, g);
+    const float em = np_emission(x, as_gauss(gp));
     const float score_d = (float)((double)diag + lp_step + (double)em);
     const float score_u = (float)((double)up + lp_stay + (double)em);
     const float score_l = (float)((double)left + lp_skip);
@@ -86,11 +84,113 @@ __device__ __forceinline__ cell_out dp_cell(bool valid, float x, const np_gauss&
     return o;
 }
 
+// Everything the fill carries from band to band.
+struct fill_t {
+    int llk;                // band_lower_left[b].kmer_idx (wave-uniform)
+    int k0, k1;             // k-mer mapped to this lane's two ring slots
+    float4 g0, g1;          // their scaled Gaussians (mean, stdv, cl, 1/stdv)
+    float4 n0, n1;          // the records of k0+128 / k1+128, requested when the slot was last re-targeted
+    float p0, p1;           // band b-1
+    float d0, d1;           // band b-2 rotated by one slot
+    float best; int best_e; // end-cell search (:309-324), tracked by the owner of k-mer K-1
+};
+
+struct read_t {
+    int E, K, lane, end_slot;
+    const float* __restrict__ ev;
+    const float4* __restrict__ kp;
+    uint64_t* __restrict__ trace;
+    double lp_skip, lp_stay, lp_step, lp_trim;
+};
+
+// One band.  (xc0, xc1): event means of this band's cells (loaded during the previous band);
+// (xl0, xl1): receive the loads for the next band.
+__device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int b, const float xc0, const float xc1,
+                                          float& xl0, float& xl1)
+{
+    const int lane = R.lane, E = R.E, K = R.K;
+    if (b >= 2) {
+        // Suzuki's rule on band b-1 (:179-195)
+        const float ll = ring_read(F.p0, F.p1, F.llk & (NP_RING - 1));
+        const float ur = ring_read(F.p0, F.p1, (F.llk + NP_ALN_BANDWIDTH - 1) & (NP_RING - 1));
+        const bool ll_ob = ll == NP_NEG_INF, ur_ob = ur == NP_NEG_INF;
+        const bool right = (ll_ob && ur_ob) ? ((b & 1) == 1) : (ll < ur);
+        if (right) {
+            F.llk += 1;
+            // the slot that fell 14 behind the window takes its next k-mer (k+128), whose record was requested the
+            // last time the slot moved, and requests the one after that
+            // (branch-free on purpose: every lane re-requests its `next` record on every right move -- an L1 hit for all
+            //  but the re-targeted slot -- so that no load sits inside a divergent branch, where hipcc would wait for it
+            //  immediately; the record consumed here was requested at least one band ago)
+            const bool t0 = F.k0 < F.llk - NP_MARGIN, t1 = F.k1 < F.llk - NP_MARGIN;
+            F.g0.x = t0 ? F.n0.x : F.g0.x; F.g0.y = t0 ? F.n0.y : F.g0.y; F.g0.z = t0 ? F.n0.z : F.g0.z; F.g0.w = t0 ? F.n0.w : F.g0.w;
+            F.g1.x = t1 ? F.n1.x : F.g1.x; F.g1.y = t1 ? F.n1.y : F.g1.y; F.g1.z = t1 ? F.n1.z : F.g1.z; F.g1.w = t1 ? F.n1.w : F.g1.w;
+            F.k0 += t0 ? NP_RING : 0; F.k1 += t1 ? NP_RING : 0;
+            F.n0 = load_kp(R.kp, F.k0 + NP_RING, K);
+            F.n1 = load_kp(R.kp, F.k1 + NP_RING, K);
+        }
+    }
+    const int llk = F.llk;
+    // left sources: band b-1 rotated by one slot
+    const float r0 = np_wave_ror1(F.p0), r1 = np_wave_ror1(F.p1);
+    const float l0 = lane == 0 ? r1 : r0;
+    const float l1 = lane == 0 ? r0 : r1;
+
+    const int klo = llk > 0 ? llk : 0;
+    const int khi = (llk + NP_ALN_BANDWIDTH - 1) < (K - 1) ? (llk + NP_ALN_BANDWIDTH - 1) : (K - 1);
+    const int e0 = b - 2 - F.k0, e1 = b - 2 - F.k1;
+    const bool v0 = F.k0 >= klo && F.k0 <= khi && (unsigned)e0 < (unsigned)E;
+    const bool v1 = F.k1 >= klo && F.k1 <= khi && (unsigned)e1 < (unsigned)E;
+    // prefetch the next band's event means (same k-mer, next event), clamped: always a plain load
+    xl0 = R.ev[clampi(e0 + 1, 0, E - 1)];
+    xl1 = R.ev[clampi(e1 + 1, 0, E - 1)];
+
+    cell_out c0 = dp_cell(v0, xc0, F.g0, F.p0, l0, F.d0, R.lp_skip, R.lp_stay, R.lp_step);
+    cell_out c1 = dp_cell(v1, xc1, F.g1, F.p1, l1, F.d1, R.lp_skip, R.lp_stay, R.lp_step);
+
+    if (llk <= -1) {
+        // the window still contains k-mer -1: start cell of band 0 (:152-157) and the trim column (:216-225).
+        // k = -1 lives in ring slot 127 (lane 63, second register); its event is b - 1.
+        const int et = b - 1;
+        if (lane == 63 && F.k1 == -1) {
+            if (et == -1) { c1.v = 0.0f; c1.from = 0u; }
+            else if (et >= 0 && et < E) { c1.v = (float)(R.lp_trim * (double)(et + 1)); c1.from = 1u; }
+            else { c1.v = NP_NEG_INF; c1.from = 0u; }
+        }
+    }
+
+    // packed trace: 4 x 64-bit ballots per band
+    const uint64_t m00 = __ballot(c0.from & 1u), m01 = __ballot(c0.from >> 1);
+    const uint64_t m10 = __ballot(c1.from & 1u), m11 = __ballot(c1.from >> 1);
+    if (lane < 4) {
+        const uint64_t w = lane == 0 ? m00 : lane == 1 ? m01 : lane == 2 ? m10 : m11;
+        R.trace[(size_t)b * 4 + lane] = w;
+    }
+
+    if (khi == K - 1 && llk <= K - 1) {
+        // end search: cell (e, K-1) while it is inside the window, any e in [0,E) (:309-324)
+        const bool mine0 = (R.end_slot < 64) && lane == R.end_slot;
+        const bool mine1 = (R.end_slot >= 64) && lane == R.end_slot - 64;
+        if (mine0 || mine1) {
+            const int k = mine0 ? F.k0 : F.k1;
+            const int e = mine0 ? e0 : e1;
+            const float v = mine0 ? c0.v : c1.v;
+            if (k == K - 1 && e >= 0 && e < E) {
+                const float sc = (float)((double)v + (double)(E - e) * R.lp_trim);
+                if (sc > F.best) { F.best = sc; F.best_e = e; }
+            }
+        }
+    }
+    F.d0 = l0; F.d1 = l1;
+    F.p0 = c0.v; F.p1 = c1.v;
+}
+
 __global__ void __launch_bounds__(NP_ALIGN_BLOCK) np_event_align_kernel(np_align_args a)
 {
     const int lane = threadIdx.x & 63;
     const int wave_slot = blockIdx.x * (NP_ALIGN_BLOCK / 64) + (threadIdx.x >> 6);
     uint64_t* __restrict__ trace = a.trace + (size_t)wave_slot * a.trace_stride;
+    float4* __restrict__ kp = a.kparams + (size_t)wave_slot * a.kp_stride;     // per-wave slab of scaled k-mer parameters
 
     for (;;) {
         // Ticket grab without an `if (lane == 0)`: hipcc threads a lane-0 branch at the loop top together with a
@@ -104,110 +204,48 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK) np_event_align_kernel(np_align
         const uint16_t* __restrict__ rk = a.ranks + rd->rank_off;
         const np_state_dev* __restrict__ model = a.model;
         const double scale = rd->scale, shift = rd->shift, var = rd->var, log_var = rd->log_var;
-        const double lp_skip = rd->lp_skip, lp_stay = rd->lp_stay, lp_step = rd->lp_step, lp_trim = rd->lp_trim;
         const int n_bands = E + K + 2;
         const int64_t pbase = a.pair_off[ri];
         const int cap = (int)(a.pair_off[ri + 1] - pbase);
         np_pair* __restrict__ pairs = a.pairs + pbase;
 
-        const bool ok = !(E <= 0 || K <= 0 || (uint64_t)n_bands * 4 > a.trace_stride || cap < E + K + 2);
+        const bool ok = !(E <= 0 || K <= 0 || (uint64_t)n_bands * 4 > a.trace_stride || (uint64_t)K > a.kp_stride || cap < E + K + 2);
         int n_out = 0, max_gap = 0, last_k = -1;
         double sum_emission = 0.0;
         if (ok) {
+            // ---------------- prologue: per-k-mer scaled Gaussians ----------------
+            for (int k = lane; k < K; k += 64) {
+                const uint32_t r = rk[k];
+                const np_gauss g = np_make_gauss(model[r].level_mean, model[r].level_stdv, model[r].level_log_stdv, scale, shift, var, log_var);
+                kp[k] = make_float4(g.mean, g.stdv, g.cl, g.rinv);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+
             // ---------------- fill ----------------
-            int llk = -1 - NP_ALN_BANDWIDTH / 2;            // band_lower_left[0].kmer_idx, raw_loader.cpp:150-151
-            slot_t s0, s1;
-            s0.k = ring_kmer(lane, llk); s1.k = ring_kmer(lane + 64, llk);
-            {
-                const uint32_t r0 = (s0.k >= 0 && s0.k < K) ? rk[s0.k] : 0u, r1 = (s1.k >= 0 && s1.k < K) ? rk[s1.k] : 0u;
-                s0.g = scale_raw(model[r0].level_mean, model[r0].level_stdv, model[r0].level_log_stdv, scale, shift, var, log_var);
-                s1.g = scale_raw(model[r1].level_mean, model[r1].level_stdv, model[r1].level_log_stdv, scale, shift, var, log_var);
+            read_t R;
+            R.E = E; R.K = K; R.lane = lane; R.end_slot = (K - 1) & (NP_RING - 1);
+            R.ev = ev; R.kp = kp; R.trace = trace;
+            R.lp_skip = rd->lp_skip; R.lp_stay = rd->lp_stay; R.lp_step = rd->lp_step; R.lp_trim = rd->lp_trim;
+            fill_t F;
+            F.llk = -1 - NP_ALN_BANDWIDTH / 2;              // band_lower_left[0].kmer_idx, raw_loader.cpp:150-151
+            F.k0 = ring_kmer(lane, F.llk); F.k1 = ring_kmer(lane + 64, F.llk);
+            F.g0 = load_kp(kp, F.k0, K); F.g1 = load_kp(kp, F.k1, K);
+            F.n0 = load_kp(kp, F.k0 + NP_RING, K); F.n1 = load_kp(kp, F.k1 + NP_RING, K);
+            F.p0 = F.p1 = F.d0 = F.d1 = NP_NEG_INF;
+            F.best = NP_NEG_INF; F.best_e = 0;
+            float xa0 = 0.0f, xa1 = 0.0f, xb0 = 0.0f, xb1 = 0.0f;      // ping-pong event-mean registers
+            int b = 0;
+            for (; b + 1 < n_bands; b += 2) {
+                band_step(F, R, b, xa0, xa1, xb0, xb1);
+                band_step(F, R, b + 1, xb0, xb1, xa0, xa1);
             }
-            s0.st = s1.st = 0; s0.pr = s1.pr = 0u;
-            s0.pm_mean = s0.pm_stdv = s0.pm_lstdv = s1.pm_mean = s1.pm_stdv = s1.pm_lstdv = 0.0;
-            float p0 = NP_NEG_INF, p1 = NP_NEG_INF;   // band b-1
-            float d0 = NP_NEG_INF, d1 = NP_NEG_INF;   // band b-2 rotated by one slot
-            float best = NP_NEG_INF; int best_e = 0;  // end-cell search (:309-324), tracked by the owner of k-mer K-1
-            const int end_slot = (K - 1) & (NP_RING - 1);
-            float xn0 = 0.0f, xn1 = 0.0f;             // event means prefetched for the next band
-
-            for (int b = 0; b < n_bands; ++b) {
-                if (b >= 2) {
-                    // Suzuki's rule on band b-1 (:179-195)
-                    const float ll = ring_read(p0, p1, llk & (NP_RING - 1));
-                    const float ur = ring_read(p0, p1, (llk + NP_ALN_BANDWIDTH - 1) & (NP_RING - 1));
-                    const bool ll_ob = ll == NP_NEG_INF, ur_ob = ur == NP_NEG_INF;
-                    const bool right = (ll_ob && ur_ob) ? ((b & 1) == 1) : (ll < ur);
-                    if (right) {
-                        llk += 1;
-                        // refill pipeline, one stage per right move (a re-targeted slot re-enters the window 15 moves later)
-                        if (s0.st == 2) { s0.g = scale_raw(s0.pm_mean, s0.pm_stdv, s0.pm_lstdv, scale, shift, var, log_var); s0.st = 0; }
-                        else if (s0.st == 1) { s0.pm_mean = model[s0.pr].level_mean; s0.pm_stdv = model[s0.pr].level_stdv; s0.pm_lstdv = model[s0.pr].level_log_stdv; s0.st = 2; }
-                        if (s1.st == 2) { s1.g = scale_raw(s1.pm_mean, s1.pm_stdv, s1.pm_lstdv, scale, shift, var, log_var); s1.st = 0; }
-                        else if (s1.st == 1) { s1.pm_mean = model[s1.pr].level_mean; s1.pm_stdv = model[s1.pr].level_stdv; s1.pm_lstdv = model[s1.pr].level_log_stdv; s1.st = 2; }
-                        if (s0.k < llk - NP_MARGIN) { s0.k += NP_RING; s0.pr = (s0.k < K) ? rk[s0.k] : 0u; s0.st = 1; }
-                        if (s1.k < llk - NP_MARGIN) { s1.k += NP_RING; s1.pr = (s1.k < K) ? rk[s1.k] : 0u; s1.st = 1; }
-                    }
-                }
-                // left sources: band b-1 rotated by one slot
-                const float r0 = np_wave_ror1(p0), r1 = np_wave_ror1(p1);
-                const float l0 = lane == 0 ? r1 : r0;
-                const float l1 = lane == 0 ? r0 : r1;
-
-                const int klo = llk > 0 ? llk : 0;
-                const int khi = (llk + NP_ALN_BANDWIDTH - 1) < (K - 1) ? (llk + NP_ALN_BANDWIDTH - 1) : (K - 1);
-                const int e0 = b - 2 - s0.k, e1 = b - 2 - s1.k;
-                const bool v0 = s0.k >= klo && s0.k <= khi && (unsigned)e0 < (unsigned)E;
-                const bool v1 = s1.k >= klo && s1.k <= khi && (unsigned)e1 < (unsigned)E;
-                const float x0 = xn0, x1 = xn1;
-                // prefetch the next band's event means (same k-mer, next event); slots re-targeted meanwhile are outside the window
-                xn0 = ((unsigned)(e0 + 1) < (unsigned)E) ? ev[e0 + 1] : 0.0f;
-                xn1 = ((unsigned)(e1 + 1) < (unsigned)E) ? ev[e1 + 1] : 0.0f;
-
-                cell_out c0 = dp_cell(v0, x0, s0.g, p0, l0, d0, lp_skip, lp_stay, lp_step);
-                cell_out c1 = dp_cell(v1, x1, s1.g, p1, l1, d1, lp_skip, lp_stay, lp_step);
-
-                if (llk <= -1) {
-                    // the window still contains k-mer -1: start cell of band 0 (:152-157) and the trim column (:216-225).
-                    // k = -1 lives in ring slot 127 (lane 63, second register); its event is b - 1.
-                    const int et = b - 1;
-                    if (lane == 63 && s1.k == -1) {
-                        if (et == -1) { c1.v = 0.0f; c1.from = 0u; }
-                        else if (et >= 0 && et < E) { c1.v = (float)(lp_trim * (double)(et + 1)); c1.from = 1u; }
-                        else { c1.v = NP_NEG_INF; c1.from = 0u; }
-                    }
-                }
-
-                // packed trace: 4 x 64-bit ballots per band
-                const uint64_t m00 = __ballot(c0.from & 1u), m01 = __ballot(c0.from >> 1);
-                const uint64_t m10 = __ballot(c1.from & 1u), m11 = __ballot(c1.from >> 1);
-                if (lane < 4) {
-                    const uint64_t w = lane == 0 ? m00 : lane == 1 ? m01 : lane == 2 ? m10 : m11;
-                    trace[(size_t)b * 4 + lane] = w;
-                }
-
-                if (khi == K - 1 && llk <= K - 1) {
-                    // end search: cell (e, K-1) while it is inside the window, any e in [0,E) (:309-324)
-                    const bool mine0 = (end_slot < 64) && lane == end_slot;
-                    const bool mine1 = (end_slot >= 64) && lane == end_slot - 64;
-                    if (mine0 || mine1) {
-                        const int k = mine0 ? s0.k : s1.k;
-                        const int e = mine0 ? e0 : e1;
-                        const float v = mine0 ? c0.v : c1.v;
-                        if (k == K - 1 && e >= 0 && e < E) {
-                            const float sc = (float)((double)v + (double)(E - e) * lp_trim);
-                            if (sc > best) { best = sc; best_e = e; }
-                        }
-                    }
-                }
-                d0 = l0; d1 = l1;
-                p0 = c0.v; p1 = c1.v;
-            }
+            if (b < n_bands) band_step(F, R, b, xa0, xa1, xb0, xb1);
 
             // ---------------- backtrack (:326-361) + QC sums (:338-341) ----------------
-            const int owner = end_slot & 63;
-            const float best_u = readlane_f(best, owner);
-            int curr_e = __builtin_amdgcn_readlane(best_e, owner);
+            const int owner = R.end_slot & 63;
+            const float best_u = readlane_f(F.best, owner);
+            int curr_e = __builtin_amdgcn_readlane(F.best_e, owner);
             int curr_k = K - 1;
 
             // the trace was written by lanes 0..3 of this wave: complete the stores before other lanes read them back
@@ -261,9 +299,7 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK) np_event_align_kernel(np_align
                         if (lane < cnt) {
                             np_pair p; p.ref_pos = pk; p.read_pos = pe;
                             pairs[cap - 1 - (first + lane)] = p;
-                            const uint32_t r = rk[pk];
-                            const np_gauss g = scale_raw(model[r].level_mean, model[r].level_stdv, model[r].level_log_stdv, scale, shift, var, log_var);
-                            em = np_emission(ev[pe], g);
+                            em = np_emission(ev[pe], as_gauss(load_kp(kp, pk, K)));
                         }
                         for (int q = 0; q < cnt; ++q) sum_emission += (double)readlane_f(em, q);
                     }

@@ -63,7 +63,7 @@ struct np_ctx {
     std::vector<float> h_logsum;
     float* d_flank = nullptr;
     uint32_t* d_counters = nullptr;   // [0..6] class counts, [8..15] work-queue heads, [16] align queue head
-    dev_buf order, trace;
+    dev_buf order, trace, kparams;
     // host-API staging
     dev_buf b_jobs, b_reads, b_events, b_ranks, b_out, b_pair_off, b_pairs, b_pair_begin, b_n_pairs,
             b_vm, b_bp, b_cell_off, b_state_off, b_states, b_n_states;
@@ -154,11 +154,13 @@ int run_event_align(np_ctx* c, hipStream_t s, int n_reads, const np_read_dev* re
     const int nb = persistent_blocks(c, n_reads, waves_per_block, c->align_blocks_per_cu);
     const uint64_t stride = ((uint64_t)max_bands * 4 + 15) & ~15ull;
     NP_HIP(c, c->trace.reserve((size_t)nb * waves_per_block * stride * sizeof(uint64_t)));
+    const uint64_t kp_stride = ((uint64_t)max_bands + 63) & ~63ull;      // k-mers per read < bands per read
+    NP_HIP(c, c->kparams.reserve((size_t)nb * waves_per_block * kp_stride * sizeof(float4)));
     NP_HIP(c, hipMemsetAsync(c->d_counters + 16, 0, sizeof(uint32_t), s));
     np_align_args a{};
     a.reads = reads; a.event_mean = event_mean; a.ranks = ranks; a.model = c->models[model].d_states;
     a.pair_off = pair_off; a.pairs = pairs; a.pair_begin = pair_begin; a.n_pairs = n_pairs;
-    a.trace = c->trace.as<uint64_t>(); a.trace_stride = stride; a.counter = c->d_counters + 16;
+    a.trace = c->trace.as<uint64_t>(); a.trace_stride = stride; a.kparams = c->kparams.as<float4>(); a.kp_stride = kp_stride; a.counter = c->d_counters + 16;
     a.n_reads = n_reads; a.max_gap_threshold = c->params.max_gap_threshold;
     a.min_average_log_emission = c->params.min_average_log_emission;
     uint32_t* dbg = nullptr;
@@ -250,7 +252,7 @@ void np_destroy(np_ctx* c)
     if (c->d_logsum) (void)hipFree(c->d_logsum);
     if (c->d_flank) (void)hipFree(c->d_flank);
     if (c->d_counters) (void)hipFree(c->d_counters);
-    dev_buf* bufs[] = {&c->order, &c->trace, &c->b_jobs, &c->b_reads, &c->b_events, &c->b_ranks, &c->b_out, &c->b_pair_off,
+    dev_buf* bufs[] = {&c->order, &c->trace, &c->kparams, &c->b_jobs, &c->b_reads, &c->b_events, &c->b_ranks, &c->b_out, &c->b_pair_off,
                        &c->b_pairs, &c->b_pair_begin, &c->b_n_pairs, &c->b_vm, &c->b_bp, &c->b_cell_off, &c->b_state_off,
                        &c->b_states, &c->b_n_states};
     for (dev_buf* b : bufs) b->release();
@@ -275,6 +277,22 @@ int np_register_model(np_ctx* c, int k, int n_states, const double* level_mean, 
     NP_HIP(c, hipMemcpy(m.d_states, st.data(), st.size() * sizeof(np_state_dev), hipMemcpyHostToDevice));
     c->models.push_back(std::move(m));
     return (int)c->models.size() - 1;
+}
+
+// Device self-test of the exact fast division used by the emission (np_device.h:np_div_exact) against `/`.
+int np_selftest_division(np_ctx* c, uint64_t n_samples, uint64_t seed, uint64_t* n_mismatch)
+{
+    if (!c || !n_mismatch) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    unsigned long long* d = (unsigned long long*)(c->d_counters + 32);
+    NP_HIP(c, hipMemsetAsync(d, 0, sizeof(unsigned long long), c->stream));
+    NP_HIP(c, np_launch_selftest_div(n_samples, seed, d, c->stream));
+    unsigned long long h = 0;
+    NP_HIP(c, hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    NP_HIP(c, hipStreamSynchronize(c->stream));
+    *n_mismatch = h;
+    return NP_OK;
 }
 
 int np_sync(np_ctx* c, void* stream)

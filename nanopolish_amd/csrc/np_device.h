@@ -35,24 +35,46 @@ __device__ __forceinline__ float np_lse(float a, float b, const float* __restric
 // get_scaled_gaussian_from_pore_model_state (src/nanopolish_squiggle_read.h:217-226): double math, float store.
 // Returns (mean, stdv, log_inv_sqrt_2pi - log_stdv): the last is the left-associated prefix of
 // log_normal_pdf (src/hmm/nanopolish_emissions.h:51-55).
-struct np_gauss { float mean, stdv, cl; };
-__device__ __forceinline__ np_gauss np_scale_state(const np_state_dev* __restrict__ model, uint32_t rank,
-                                                   double scale, double shift, double var, double log_var)
+struct np_gauss { float mean, stdv, cl, rinv; };
+
+__device__ __forceinline__ np_gauss np_make_gauss(double lm, double ls, double ll, double scale, double shift, double var, double log_var)
 {
-    const double lm = model[rank].level_mean, ls = model[rank].level_stdv, ll = model[rank].level_log_stdv;
     np_gauss g;
     g.mean = (float)(scale * lm + shift);
     g.stdv = (float)(ls * var);
     const float log_stdv = (float)(ll + log_var);
     const float log_inv_sqrt_2pi = -0.918938518f;   // (float)log(0.3989422804014327), emissions.h:43; checked on the host at np_create
     g.cl = log_inv_sqrt_2pi - log_stdv;
+    g.rinv = (float)(1.0 / (double)g.stdv);        // correctly rounded reciprocal, once per k-mer (see np_div_exact)
     return g;
+}
+
+__device__ __forceinline__ np_gauss np_scale_state(const np_state_dev* __restrict__ model, uint32_t rank,
+                                                   double scale, double shift, double var, double log_var)
+{
+    return np_make_gauss(model[rank].level_mean, model[rank].level_stdv, model[rank].level_log_stdv, scale, shift, var, log_var);
+}
+
+// n / d, correctly rounded (== the IEEE fp32 quotient the reference computes), from a correctly rounded
+// reciprocal r = RN(1/d): q0 = RN(n r); two Markstein corrections q <- fma(fma(-d, q, n), r, q).  This is the
+// body of the hardware division expansion (v_div_scale/v_div_fmas/v_div_fixup only add range scaling, which
+// n = x - mean in [-1e3, 1e3] \ (0, 1e-6) and d = stdv in [0.05, 50] never need) with the reciprocal hoisted out
+// of the per-cell path: 5 VALU ops instead of ~11 incl. a quarter-rate v_rcp_f32.  Equality with `/` is checked
+// on the device by np_selftest_division (tests/test_gpu_parity.py) over 2^32 random operand pairs.
+__device__ __forceinline__ float np_div_exact(float n, float d, float r)
+{
+    float q = n * r;
+    float e = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e, r, q);
+    return q;
 }
 
 // log_probability_match_r9 (src/hmm/nanopolish_emissions.h:57-68) with drift == 0.
 __device__ __forceinline__ float np_emission(float x, const np_gauss& g)
 {
-    const float a = (x - g.mean) / g.stdv;     // IEEE-correct fp32 divide (hipcc default for HIP)
+    const float a = np_div_exact(x - g.mean, g.stdv, g.rinv);     // == (x - mean) / stdv, IEEE-correct
     return g.cl + (-0.5f * a * a);
 }
 

@@ -161,3 +161,46 @@ hipError_t np_launch_resolve(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read
                        n_jobs, jobs, reads, n_pairs, events_per_base, map_start, kpos);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Self-test: np_div_exact (np_device.h) against the IEEE fp32 divide on pseudo-random operand pairs drawn from
+// the ranges the emission uses (numerator x - mean, denominator stdv).  Counts bitwise mismatches.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ uint64_t splitmix64(uint64_t& s)
+{
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void __launch_bounds__(256) np_selftest_div_kernel(uint64_t n_per_thread, uint64_t seed, unsigned long long* mismatches)
+{
+    uint64_t s = seed + 0xD1B54A32D192ED03ull * ((uint64_t)blockIdx.x * 256 + threadIdx.x + 1);
+    unsigned long long bad = 0;
+    for (uint64_t i = 0; i < n_per_thread; ++i) {
+        const uint64_t u = splitmix64(s);
+        // denominator: random mantissa, exponent in [2^-5, 2^6)  (stdv after scaling lives in ~[0.3, 12])
+        const uint32_t dm = (uint32_t)u & 0x7fffffu, de = 122u + (uint32_t)((u >> 23) % 11u);
+        const float d = __builtin_bit_cast(float, (de << 23) | dm);
+        // numerator: random sign/mantissa, exponent in [2^-20, 2^10) and exact zero now and then
+        const uint32_t nm = (uint32_t)(u >> 32) & 0x7fffffu, ne = 107u + (uint32_t)((u >> 55) % 30u);
+        float n = __builtin_bit_cast(float, (ne << 23) | nm | ((uint32_t)(u >> 63) << 31));
+        if ((u & 0xfff000000ull) == 0) n = 0.0f;
+        const float r = (float)(1.0 / (double)d);
+        const float want = n / d;
+        const float got = np_div_exact(n, d, r);
+        bad += (__builtin_bit_cast(uint32_t, want) != __builtin_bit_cast(uint32_t, got));
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+} // namespace
+
+hipError_t np_launch_selftest_div(uint64_t n_samples, uint64_t seed, unsigned long long* d_mismatches, hipStream_t s)
+{
+    const unsigned blocks = 4096;
+    const uint64_t per_thread = (n_samples + (uint64_t)blocks * 256 - 1) / ((uint64_t)blocks * 256);
+    hipLaunchKernelGGL(np_selftest_div_kernel, dim3(blocks), dim3(256), 0, s, per_thread, seed, d_mismatches);
+    return hipGetLastError();
+}

@@ -34,6 +34,8 @@ struct np_align_args {
     int32_t* n_pairs;
     uint64_t* trace;               // scratch: n_wave_slots * trace_stride u64
     uint64_t trace_stride;         // u64 per resident wave (>= 4 * max_bands)
+    float4* kparams;               // scratch: n_wave_slots * kp_stride records (scaled Gaussian per k-mer of the read in flight)
+    uint64_t kp_stride;            // records per resident wave (>= max k-mers per read)
     uint32_t* counter;
     int32_t n_reads;
     int32_t max_gap_threshold;
@@ -61,3 +63,4 @@ hipError_t np_launch_build_map(int n_reads, np_read_dev* reads, const int64_t* p
                                double* events_per_base, double indel_bias, hipStream_t s);
 hipError_t np_launch_resolve(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads, const int32_t* n_pairs,
                              const double* events_per_base, const int32_t* map_start, const int32_t* kpos, hipStream_t s);
+hipError_t np_launch_selftest_div(uint64_t n_samples, uint64_t seed, unsigned long long* d_mismatches, hipStream_t s);

@@ -193,3 +193,11 @@ def test_hmm_score_set_matches_golden(ctx, models):
                          dict(common, ranks=api.sequence_kmer_ranks("cpg", api.methylate("cpg", w)), model=mc)])
         assert np.array_equal(c9.profile_hmm_score_set(sets), g[p + "score_set"])
     c9.close()
+
+
+def test_exact_fast_division_selftest(ctx):
+    """np_div_exact (reciprocal + two fused corrections) must equal the IEEE fp32 divide bit for bit."""
+    import ctypes as C
+    bad = C.c_uint64(123)
+    rc = ctx.L.np_selftest_division(ctx.h, 1 << 32, 20260924, C.byref(bad))
+    assert rc == 0 and bad.value == 0
