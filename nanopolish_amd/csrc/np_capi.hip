@@ -137,7 +137,7 @@ int run_hmm_forward(np_ctx* c, hipStream_t s, int64_t n_jobs, const np_hmm_job_d
         a.jobs = jobs; a.order = c->order.as<uint32_t>() + (size_t)cls * (size_t)n_jobs; a.n_class_jobs = c->d_counters + cls;
         a.reads = reads; a.event_mean = event_mean; a.ranks = ranks; a.model = c->models[model].d_states;
         a.logsum = c->d_logsum; a.flank = c->d_flank; a.counter = c->d_counters + 8 + cls; a.out = out;
-        const int jobs_per_block = (np_hmm_block_threads() / 64) * (64 / NP_CLASS_SEG[cls]);
+        const int jobs_per_block = (np_hmm_block_threads(cls) / 64) * (64 / NP_CLASS_SEG[cls]);
         const int nb = persistent_blocks(c, n_jobs, jobs_per_block, c->hmm_blocks_per_cu);
         NP_HIP(c, np_launch_hmm_forward(cls, a, nb, s));
     }
@@ -208,6 +208,9 @@ np_ctx* np_create(int device, const np_params* params)
     np_ctx* c = new np_ctx();
     c->device = device;
     c->n_cu = prop.multiProcessorCount;
+    // tuning knobs (persistent-grid sizes); defaults fill the CU up to the kernels' register-limited occupancy
+    if (const char* v = getenv("NP_ALIGN_BLOCKS_PER_CU")) c->align_blocks_per_cu = std::max(1, atoi(v));
+    if (const char* v = getenv("NP_HMM_BLOCKS_PER_CU")) c->hmm_blocks_per_cu = std::max(1, atoi(v));
     if (params) c->params = *params; else np_default_params(&c->params);
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
 
@@ -515,7 +518,7 @@ int np_hmm_align_host(np_ctx* c, int n_jobs, const np_hmm_job* jobs, np_hmm_stat
         for (int cls = 0; cls < NP_NUM_CLASSES; ++cls) {
             a.order = c->order.as<uint32_t>() + (size_t)cls * (size_t)n_jobs; a.n_class_jobs = c->d_counters + cls;
             a.counter = c->d_counters + 8 + cls;
-            const int jobs_per_block = (np_hmm_block_threads() / 64) * (64 / NP_CLASS_SEG[cls]);
+            const int jobs_per_block = (np_vit_block_threads() / 64) * (64 / NP_CLASS_SEG[cls]);
             NP_HIP(c, np_launch_hmm_viterbi(cls, a, persistent_blocks(c, n_jobs, jobs_per_block, c->hmm_blocks_per_cu), s));
         }
         NP_HIP(c, np_launch_hmm_backtrack(a, n_jobs, s));

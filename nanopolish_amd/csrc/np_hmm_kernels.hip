@@ -36,11 +36,13 @@ __device__ __forceinline__ int wave_max_i32(int v)
 // ---------------------------------------------------------------------------------------------------
 // Forward
 // ---------------------------------------------------------------------------------------------------
-template <int SEG, int C>
-__global__ void __launch_bounds__(NP_HMM_BLOCK) np_hmm_forward_kernel(np_hmm_args a)
+// BLK threads per workgroup share one LDS copy of the table.  One k-mer block per lane (C == 1) fits 64 VGPRs, so
+// those classes run 1024-thread workgroups, two per CU = 8 waves/SIMD; the others run 512-thread workgroups.
+template <int SEG, int C, int BLK>
+__global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_args a)
 {
     __shared__ float tbl[NP_LOGSUM_TBL];
-    for (int i = threadIdx.x; i < NP_LOGSUM_TBL; i += NP_HMM_BLOCK) tbl[i] = a.logsum[i];
+    for (int i = threadIdx.x; i < NP_LOGSUM_TBL; i += BLK) tbl[i] = a.logsum[i];
     __syncthreads();
 
     constexpr int JPW = 64 / SEG;                 // jobs per wave
@@ -325,7 +327,8 @@ __global__ void np_hmm_backtrack_kernel(np_hmm_args a, int64_t n_jobs_total)
 template <int SEG, int C>
 hipError_t launch_fwd(const np_hmm_args& a, int n_blocks, hipStream_t s)
 {
-    hipLaunchKernelGGL((np_hmm_forward_kernel<SEG, C>), dim3(n_blocks), dim3(NP_HMM_BLOCK), 0, s, a);
+    constexpr int BLK = C == 1 ? 1024 : NP_HMM_BLOCK;
+    hipLaunchKernelGGL((np_hmm_forward_kernel<SEG, C, BLK>), dim3(n_blocks), dim3(BLK), 0, s, a);
     return hipGetLastError();
 }
 template <int SEG, int C>
@@ -337,7 +340,8 @@ hipError_t launch_vit(const np_hmm_args& a, int n_blocks, hipStream_t s)
 
 } // namespace
 
-int np_hmm_block_threads(void) { return NP_HMM_BLOCK; }
+int np_hmm_block_threads(int cls) { return NP_CLASS_C[cls] == 1 ? 1024 : NP_HMM_BLOCK; }
+int np_vit_block_threads(void) { return NP_HMM_BLOCK; }
 
 hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s)
 {

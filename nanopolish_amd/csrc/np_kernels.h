@@ -53,7 +53,8 @@ hipError_t np_launch_hmm_viterbi(int cls, const np_hmm_args& a, int n_blocks, hi
 hipError_t np_launch_hmm_backtrack(const np_hmm_args& a, int64_t n_jobs, hipStream_t s);
 hipError_t np_launch_event_align(const np_align_args& a, int n_blocks, hipStream_t s);
 int np_align_block_threads(void);
-int np_hmm_block_threads(void);
+int np_hmm_block_threads(int cls);
+int np_vit_block_threads(void);
 
 // glue kernels
 hipError_t np_launch_classify(const np_hmm_job_dev* jobs, int64_t n_jobs, uint32_t* class_count /*[7]*/,
