@@ -346,10 +346,10 @@ int np_vit_block_threads(void) { return NP_HMM_BLOCK; }
 hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s)
 {
     switch (cls) {
-        case 0: return launch_fwd<16, 1>(a, n_blocks, s);
-        case 1: return launch_fwd<32, 1>(a, n_blocks, s);
-        case 2: return launch_fwd<64, 1>(a, n_blocks, s);
-        case 3: return launch_fwd<64, 2>(a, n_blocks, s);
+        case 0: return launch_fwd<4, 4>(a, n_blocks, s);
+        case 1: return launch_fwd<8, 4>(a, n_blocks, s);
+        case 2: return launch_fwd<16, 4>(a, n_blocks, s);
+        case 3: return launch_fwd<32, 4>(a, n_blocks, s);
         case 4: return launch_fwd<64, 4>(a, n_blocks, s);
         case 5: return launch_fwd<64, 8>(a, n_blocks, s);
         case 6: return launch_fwd<64, 16>(a, n_blocks, s);
@@ -360,10 +360,10 @@ hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, hi
 hipError_t np_launch_hmm_viterbi(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s)
 {
     switch (cls) {
-        case 0: return launch_vit<16, 1>(a, n_blocks, s);
-        case 1: return launch_vit<32, 1>(a, n_blocks, s);
-        case 2: return launch_vit<64, 1>(a, n_blocks, s);
-        case 3: return launch_vit<64, 2>(a, n_blocks, s);
+        case 0: return launch_vit<4, 4>(a, n_blocks, s);
+        case 1: return launch_vit<8, 4>(a, n_blocks, s);
+        case 2: return launch_vit<16, 4>(a, n_blocks, s);
+        case 3: return launch_vit<32, 4>(a, n_blocks, s);
         case 4: return launch_vit<64, 4>(a, n_blocks, s);
         case 5: return launch_vit<64, 8>(a, n_blocks, s);
         case 6: return launch_vit<64, 16>(a, n_blocks, s);

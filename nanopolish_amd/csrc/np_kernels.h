@@ -45,8 +45,8 @@ struct np_align_args {
 
 #define NP_NUM_CLASSES 7
 // size classes of the HMM kernels: (lanes per job, k-mer blocks per lane)
-static const int NP_CLASS_SEG[NP_NUM_CLASSES] = {16, 32, 64, 64, 64, 64, 64};
-static const int NP_CLASS_C[NP_NUM_CLASSES] = {1, 1, 1, 2, 4, 8, 16};
+static const int NP_CLASS_SEG[NP_NUM_CLASSES] = {4, 8, 16, 32, 64, 64, 64};
+static const int NP_CLASS_C[NP_NUM_CLASSES] = {4, 4, 4, 4, 4, 8, 16};
 
 hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s);
 hipError_t np_launch_hmm_viterbi(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s);
