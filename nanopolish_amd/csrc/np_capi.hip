@@ -62,7 +62,7 @@ struct np_ctx {
     float* d_logsum = nullptr;
     std::vector<float> h_logsum;
     float* d_flank = nullptr;
-    uint32_t* d_counters = nullptr;   // [0..6] class counts, [8..15] work-queue heads, [16] align queue head
+    uint32_t* d_counters = nullptr;   // [0..6] class counts, [8..15] work-queue heads, [16] align queue head, [32] self-test, [1024..] bins
     dev_buf order, trace, kparams;
     // host-API staging
     dev_buf b_jobs, b_reads, b_events, b_ranks, b_out, b_pair_off, b_pairs, b_pair_begin, b_n_pairs,
@@ -131,7 +131,7 @@ int run_hmm_forward(np_ctx* c, hipStream_t s, int64_t n_jobs, const np_hmm_job_d
     NP_HIP(c, c->order.reserve((size_t)NP_NUM_CLASSES * (size_t)n_jobs * sizeof(uint32_t)));
     NP_HIP(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint32_t), s));
     family_timer tm(c, 1, s);
-    NP_HIP(c, np_launch_classify(jobs, n_jobs, c->d_counters, c->order.as<uint32_t>(), out, NP_FLANK_LEN, s));
+    NP_HIP(c, np_launch_classify(jobs, n_jobs, c->d_counters, c->order.as<uint32_t>(), out, NP_FLANK_LEN, c->d_counters + 1024, s));
     for (int cls = 0; cls < NP_NUM_CLASSES; ++cls) {
         np_hmm_args a{};
         a.jobs = jobs; a.order = c->order.as<uint32_t>() + (size_t)cls * (size_t)n_jobs; a.n_class_jobs = c->d_counters + cls;
@@ -233,10 +233,10 @@ np_ctx* np_create(int device, const np_params* params)
     c->h_logsum = tbl;
     ok = ok && hipMalloc((void**)&c->d_logsum, tbl.size() * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_flank, flank.size() * sizeof(float)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&c->d_counters, 64 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_counters, 4096 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemcpy(c->d_logsum, tbl.data(), tbl.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(c->d_flank, flank.data(), flank.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemset(c->d_counters, 0, 64 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(c->d_counters, 0, 4096 * sizeof(uint32_t)) == hipSuccess;
     if (!ok) {
         if (g_create_err.empty()) g_create_err = "np_create: device allocation failed";
         np_destroy(c);
@@ -509,7 +509,7 @@ int np_hmm_align_host(np_ctx* c, int n_jobs, const np_hmm_job* jobs, np_hmm_stat
     NP_HIP(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint32_t), s));
     {
         family_timer tm(c, 3, s);
-        NP_HIP(c, np_launch_classify(c->b_jobs.as<np_hmm_job_dev>(), n_jobs, c->d_counters, c->order.as<uint32_t>(), nullptr, NP_FLANK_LEN, s));
+        NP_HIP(c, np_launch_classify(c->b_jobs.as<np_hmm_job_dev>(), n_jobs, c->d_counters, c->order.as<uint32_t>(), nullptr, NP_FLANK_LEN, c->d_counters + 1024, s));
         np_hmm_args a{};
         a.jobs = c->b_jobs.as<np_hmm_job_dev>(); a.reads = c->b_reads.as<np_read_dev>(); a.event_mean = c->b_events.as<float>();
         a.ranks = c->b_ranks.as<uint16_t>(); a.model = c->models[model].d_states; a.logsum = c->d_logsum; a.flank = c->d_flank;

@@ -104,42 +104,82 @@ __device__ __forceinline__ int size_class(uint32_t n)
     return -1;
 }
 
-__global__ void __launch_bounds__(256) np_classify_kernel(const np_hmm_job_dev* jobs, int64_t n_jobs,
-                                                          uint32_t* class_count, uint32_t* order, float* out_scores, uint32_t flank_len)
+// Work-item binning.  A bin is (size class, event-count bucket): items of one class are laid out by descending
+// event count, so the 64/SEG items that share a wave have nearly the same number of rows (no padding steps) and
+// the longest packs are issued first.  Counting sort in three small kernels: histogram -> exclusive scan -> scatter.
+#define NP_EBUCKETS 64
+#define NP_NBINS (NP_NUM_CLASSES * NP_EBUCKETS)
+
+__device__ __forceinline__ int job_bin(const np_hmm_job_dev& jb, uint32_t flank_len)
 {
+    const uint32_t e = (jb.e_stop > jb.e_start ? jb.e_stop - jb.e_start : jb.e_start - jb.e_stop) + 1u;
+    const int cls = (e <= flank_len && !(jb.flags & NP_JOB_SKIP)) ? size_class(jb.n_kmers) : -1;
+    if (cls < 0) return -1;
+    const uint32_t shift = 2u + (uint32_t)(cls < 3 ? cls : 3);            // bucket width 4, 8, 16, 32 events
+    const uint32_t bucket = (e >> shift) < (NP_EBUCKETS - 1) ? (e >> shift) : (NP_EBUCKETS - 1);
+    return cls * NP_EBUCKETS + (NP_EBUCKETS - 1 - (int)bucket);             // descending event count inside a class
+}
+
+__global__ void __launch_bounds__(256) np_bin_count_kernel(const np_hmm_job_dev* jobs, int64_t n_jobs, uint32_t* hist,
+                                                           float* out_scores, uint32_t flank_len)
+{
+    __shared__ uint32_t h[NP_NBINS];
+    for (int i = threadIdx.x; i < NP_NBINS; i += 256) h[i] = 0;
+    __syncthreads();
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    int cls = -1;
     if (j < n_jobs) {
-        const np_hmm_job_dev jb = jobs[j];
-        const uint32_t e = (jb.e_stop > jb.e_start ? jb.e_stop - jb.e_start : jb.e_start - jb.e_stop) + 1u;
-        cls = (e <= flank_len && !(jb.flags & NP_JOB_SKIP)) ? size_class(jb.n_kmers) : -1;
-        if (cls < 0 && out_scores) out_scores[j] = __builtin_nanf("");
+        const int bin = job_bin(jobs[j], flank_len);
+        if (bin >= 0) atomicAdd(&h[bin], 1u);
+        else if (out_scores) out_scores[j] = __builtin_nanf("");          // skipped / unsupported item
     }
-    // wave-aggregated append: one atomic per (wave, class)
-#pragma unroll
-    for (int c = 0; c < NP_NUM_CLASSES; ++c) {
-        const uint64_t m = __ballot(cls == c);
-        if (m == 0) continue;
-        const int leader = __ffsll((unsigned long long)m) - 1;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&class_count[c], (uint32_t)__popcll(m));
-        base = __shfl(base, leader, 64);
-        if (cls == c) {
-            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            order[(size_t)c * (size_t)n_jobs + pos] = (uint32_t)j;
-        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NP_NBINS; i += 256) if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+// one workgroup: per class, exclusive scan over its buckets -> cursor[]; class_count[] = class totals
+__global__ void __launch_bounds__(64) np_bin_scan_kernel(const uint32_t* hist, uint32_t* cursor, uint32_t* class_count)
+{
+    const int c = threadIdx.x;
+    if (c >= NP_NUM_CLASSES) return;
+    uint32_t run = 0;
+    for (int b = 0; b < NP_EBUCKETS; ++b) { cursor[c * NP_EBUCKETS + b] = run; run += hist[c * NP_EBUCKETS + b]; }
+    class_count[c] = run;
+}
+
+__global__ void __launch_bounds__(256) np_bin_scatter_kernel(const np_hmm_job_dev* jobs, int64_t n_jobs, uint32_t* cursor,
+                                                             uint32_t* order, uint32_t flank_len)
+{
+    __shared__ uint32_t h[NP_NBINS];       // per-block counts, then per-block base offsets
+    for (int i = threadIdx.x; i < NP_NBINS; i += 256) h[i] = 0;
+    __syncthreads();
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int bin = -1;
+    uint32_t local = 0;
+    if (j < n_jobs) {
+        bin = job_bin(jobs[j], flank_len);
+        if (bin >= 0) local = atomicAdd(&h[bin], 1u);
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NP_NBINS; i += 256) { const uint32_t n = h[i]; if (n) h[i] = atomicAdd(&cursor[i], n); }
+    __syncthreads();
+    if (bin >= 0) order[(size_t)(bin / NP_EBUCKETS) * (size_t)n_jobs + h[bin] + local] = (uint32_t)j;
 }
 
 } // namespace
 
+// bins: device scratch of 2 * NP_NBINS uint32 (histogram, cursors)
 hipError_t np_launch_classify(const np_hmm_job_dev* jobs, int64_t n_jobs, uint32_t* class_count, uint32_t* order,
-                              float* out_scores, uint32_t flank_len, hipStream_t s)
+                              float* out_scores, uint32_t flank_len, uint32_t* bins, hipStream_t s)
 {
     if (n_jobs <= 0) return hipSuccess;
-    hipLaunchKernelGGL(np_classify_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, s,
-                       jobs, n_jobs, class_count, order, out_scores, flank_len);
+    uint32_t* hist = bins;
+    uint32_t* cursor = bins + NP_NBINS;
+    hipError_t e = hipMemsetAsync(bins, 0, 2 * NP_NBINS * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    const unsigned nb = (unsigned)((n_jobs + 255) / 256);
+    hipLaunchKernelGGL(np_bin_count_kernel, dim3(nb), dim3(256), 0, s, jobs, n_jobs, hist, out_scores, flank_len);
+    hipLaunchKernelGGL(np_bin_scan_kernel, dim3(1), dim3(64), 0, s, hist, cursor, class_count);
+    hipLaunchKernelGGL(np_bin_scatter_kernel, dim3(nb), dim3(256), 0, s, jobs, n_jobs, cursor, order, flank_len);
     return hipGetLastError();
 }
 

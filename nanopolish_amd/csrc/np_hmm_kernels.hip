@@ -346,11 +346,11 @@ int np_vit_block_threads(void) { return NP_HMM_BLOCK; }
 hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s)
 {
     switch (cls) {
-        case 0: return launch_fwd<4, 4>(a, n_blocks, s);
-        case 1: return launch_fwd<8, 4>(a, n_blocks, s);
-        case 2: return launch_fwd<16, 4>(a, n_blocks, s);
-        case 3: return launch_fwd<32, 4>(a, n_blocks, s);
-        case 4: return launch_fwd<64, 4>(a, n_blocks, s);
+        case 0: return launch_fwd<2, 8>(a, n_blocks, s);
+        case 1: return launch_fwd<4, 8>(a, n_blocks, s);
+        case 2: return launch_fwd<8, 8>(a, n_blocks, s);
+        case 3: return launch_fwd<16, 8>(a, n_blocks, s);
+        case 4: return launch_fwd<32, 8>(a, n_blocks, s);
         case 5: return launch_fwd<64, 8>(a, n_blocks, s);
         case 6: return launch_fwd<64, 16>(a, n_blocks, s);
     }
@@ -360,11 +360,11 @@ hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, hi
 hipError_t np_launch_hmm_viterbi(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s)
 {
     switch (cls) {
-        case 0: return launch_vit<4, 4>(a, n_blocks, s);
-        case 1: return launch_vit<8, 4>(a, n_blocks, s);
-        case 2: return launch_vit<16, 4>(a, n_blocks, s);
-        case 3: return launch_vit<32, 4>(a, n_blocks, s);
-        case 4: return launch_vit<64, 4>(a, n_blocks, s);
+        case 0: return launch_vit<2, 8>(a, n_blocks, s);
+        case 1: return launch_vit<4, 8>(a, n_blocks, s);
+        case 2: return launch_vit<8, 8>(a, n_blocks, s);
+        case 3: return launch_vit<16, 8>(a, n_blocks, s);
+        case 4: return launch_vit<32, 8>(a, n_blocks, s);
         case 5: return launch_vit<64, 8>(a, n_blocks, s);
         case 6: return launch_vit<64, 16>(a, n_blocks, s);
     }

@@ -45,8 +45,8 @@ struct np_align_args {
 
 #define NP_NUM_CLASSES 7
 // size classes of the HMM kernels: (lanes per job, k-mer blocks per lane)
-static const int NP_CLASS_SEG[NP_NUM_CLASSES] = {4, 8, 16, 32, 64, 64, 64};
-static const int NP_CLASS_C[NP_NUM_CLASSES] = {4, 4, 4, 4, 4, 8, 16};
+static const int NP_CLASS_SEG[NP_NUM_CLASSES] = {2, 4, 8, 16, 32, 64, 64};
+static const int NP_CLASS_C[NP_NUM_CLASSES] = {8, 8, 8, 8, 8, 8, 16};
 
 hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s);
 hipError_t np_launch_hmm_viterbi(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s);
@@ -58,7 +58,7 @@ int np_vit_block_threads(void);
 
 // glue kernels
 hipError_t np_launch_classify(const np_hmm_job_dev* jobs, int64_t n_jobs, uint32_t* class_count /*[7]*/,
-                              uint32_t* order /*[7][n_jobs]*/, float* out_scores, uint32_t flank_len, hipStream_t s);
+                              uint32_t* order /*[7][n_jobs]*/, float* out_scores, uint32_t flank_len, uint32_t* bins /*[2*7*64]*/, hipStream_t s);
 hipError_t np_launch_build_map(int n_reads, np_read_dev* reads, const int64_t* pair_off, const np_pair* pairs,
                                const int32_t* pair_begin, const int32_t* n_pairs, int32_t* map_start,
                                double* events_per_base, double indel_bias, hipStream_t s);
