@@ -158,8 +158,16 @@ def main():
         a_avg_s = a_ms / max(a_n, 1) * 1e-3
         algo = batch.algo_bytes_align
         achieved = algo / a_avg_s / 1e9 if a_avg_s > 0 else 0.0
+        # HBM traffic per launch from the PMC passes (profiles/collect_pmc.sh -> profiles/r01_pmc_align.json): FETCH_SIZE +
+        # WRITE_SIZE per read of this kernel, measured on this workload shape in separate rocprofv3 --pmc runs
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_align.json")))
+            traffic = int((pm["fetch_bytes_per_read"] + pm["write_bytes_per_read"]) * n_reads)
+        except Exception:
+            pass
         roof = dict(bound="hbm", kernel="np_event_align_kernel", achieved=round(achieved, 2), peak=8000.0, unit="GB/s",
-                    frac=round(achieved / 8000.0, 5), traffic=None,
+                    frac=round(achieved / 8000.0, 5), traffic=traffic,
                     algo_bytes_per_launch=algo, avg_launch_ms=round(a_ms / max(a_n, 1), 3),
                     band_cells_per_s=round(batch.band_cells / a_avg_s / 1e9, 3) if a_avg_s > 0 else 0.0,
                     dominant_kernel_by_time=dom,
