@@ -58,3 +58,22 @@ def synth_batch(read_ids, model, L=5000, k=6, seed0=SEED0):
                 rank_off=rank_off,
                 shift=np.array([r["shift"] for r in reads]), scale=np.array([r["scale"] for r in reads]),
                 var=np.array([r["var"] for r in reads]), rc=np.array([r["rc"] for r in reads], np.uint8))
+
+
+def synth_read_from_codes(ref_codes, read_id, model, rc=False, k=6, seed0=SEED0):
+    """A read of a GIVEN reference (base codes A0 C1 G2 T3): the read strand is the reference (rc=False) or its reverse
+    complement (rc=True); events are emitted along the read strand.  Used for the variants-shaped cases, where many
+    reads must cover the same reference."""
+    rng = np.random.default_rng(seed0 + 7919 * int(read_id) + 13)
+    codes = np.asarray(ref_codes, np.int64)
+    if rc:
+        codes = 3 - codes[::-1]
+    seq = BASES[codes].tobytes().decode()
+    ranks = nucleotide_kmer_ranks(codes, k)
+    K = len(ranks)
+    n_ev = np.where(rng.random(K) < 0.08, 0, 1 + (rng.random(K) < 0.45) + (rng.random(K) < 0.15)).astype(np.int64)
+    shift = rng.uniform(-5, 5); scale = rng.uniform(0.9, 1.1); var = rng.uniform(1.0, 1.4)
+    rk = np.repeat(ranks, n_ev)
+    events = (scale * model["level_mean"][rk] + shift + var * model["level_stdv"][rk] * rng.standard_normal(len(rk))).astype(np.float32)
+    return dict(read_id=int(read_id), seq=seq, codes=codes.astype(np.uint8), ranks=ranks, events=events,
+                shift=float(shift), scale=float(scale), var=float(var), rc=bool(rc))

@@ -86,3 +86,112 @@ def call_methylation_read(orc, mn, mc, read):
     out["first"] = np.array([j["first"] for j in jobs], np.int64)
     out["unmeth"] = np.array(u, np.float32); out["meth"] = np.array(m, np.float32)
     return out
+
+
+def eventalign_read(orc, read, pairs, hmm_align_fn, align_stride=100, output_stride=50):
+    """align_read_to_ref's segment chain (src/alignment/nanopolish_eventalign.cpp:655-823) for an identity-aligned
+    synthetic read, parameterised by the profile_hmm_align implementation:
+        hmm_align_fn(fwd_subseq, rc_subseq, e_start, e_stop, stride, rc) -> (event_idx, kmer_idx, l_fm, state) or None
+    Returns the emitted (ref_position, event_idx, state) triples and the number of profile_hmm_align calls."""
+    seq = read["seq"]
+    L = len(seq)
+    n_kmers = L - K + 1
+    do_base_rc = bool(read["rc"])
+    ref_seq = revcomp(seq) if do_base_rc else seq
+    rc_ref_seq = revcomp(ref_seq)
+    start, stop, epb = orc.build_base_to_event_map(pairs, n_kmers)
+    max_kmer_idx = L - K
+    aligned = [(p, p) for p in range(L) if p <= max_kmer_idx]          # trim_aligned_pairs_to_kmer (:167-177)
+    flip = lambda i: L - i - K                                          # flip_k_strand, squiggle_read.h:229-233
+    closest = lambda k_idx: orc.get_closest_event_to(start, k_idx)
+
+    def get_end_pair(ref_pos_max, pair_idx):                            # :196-205
+        while pair_idx < len(aligned):
+            if aligned[pair_idx][0] > ref_pos_max:
+                return pair_idx - 1
+            pair_idx += 1
+        return len(aligned) - 1
+
+    read_kidx_start, read_kidx_end = aligned[0][1], aligned[-1][1]
+    if do_base_rc:
+        read_kidx_start, read_kidx_end = flip(read_kidx_start), flip(read_kidx_end)
+    first_event, last_event = closest(read_kidx_start), closest(read_kidx_end)
+    forward = first_event < last_event
+    curr_start_event, curr_start_ref, curr_pair_idx = first_event, aligned[0][0], 0
+    out, n_calls = [], 0
+    while (forward and curr_start_event < last_event) or (not forward and curr_start_event > last_event):
+        end_pair_idx = get_end_pair(curr_start_ref + align_stride, curr_pair_idx)
+        curr_end_ref, curr_end_read = aligned[end_pair_idx]
+        if do_base_rc:
+            curr_end_read = flip(curr_end_read)
+        s, l = curr_start_ref, curr_end_ref - curr_start_ref + 1
+        fwd_subseq = ref_seq[s:s + l]
+        rc_subseq = rc_ref_seq[len(ref_seq) - s - l:len(ref_seq) - s]
+        if len(fwd_subseq) < 2 * K:
+            break
+        e_start, e_stop = curr_start_event, closest(curr_end_read)
+        if abs(e_start - e_stop) < 2:
+            break
+        stride = 1 if e_start < e_stop else -1
+        res = hmm_align_fn(fwd_subseq, rc_subseq, e_start, e_stop, stride, do_base_rc)
+        n_calls += 1
+        if res is None:
+            break
+        ev, km, lf, st = res
+        last_section = end_pair_idx == len(aligned) - 1
+        num_output = 0
+        last_event_output = last_ref_kmer_output = 0
+        for i in range(len(ev)):
+            if not (num_output < output_stride or last_section):
+                break
+            if chr(st[i]) != 'K' and int(ev[i]) != curr_start_event:
+                out.append((curr_start_ref + int(km[i]), int(ev[i]), int(st[i])))
+                last_event_output = int(ev[i]); last_ref_kmer_output = curr_start_ref + int(km[i])
+                num_output += 1
+        curr_start_event, curr_start_ref = last_event_output, last_ref_kmer_output
+        curr_pair_idx = get_end_pair(curr_start_ref, curr_pair_idx)
+        if num_output == 0:
+            break
+    return out, n_calls, epb
+
+
+def variant_window_items(orc, ref_seq, reads_pairs, positions, flank=10):
+    """Work items of generate_candidate_single_base_edits + score_variant_thresholded
+    (src/nanopolish_call_variants.cpp:288-361, src/common/nanopolish_variant.cpp:765-799) for identity-aligned reads of one
+    reference: per position a 22-bp window, the base haplotype and its single-base substitutions / insertions / deletion;
+    per read the event bounds of the window (AlignmentDB::get_event_subsequences, alignment_db.cpp:172-221).
+    reads_pairs: list of (read dict, aligner pairs).  Returns a list of dicts(pos, seqs=[base, variants...],
+    per_read=[(read index, e1, e2, stride, rc)])."""
+    L = len(ref_seq)
+    recs = []
+    for rd, pairs in reads_pairs:
+        n_kmers = L - K + 1
+        start, stop, epb = orc.build_base_to_event_map(pairs, n_kmers)
+        ab = np.stack([np.arange(L), np.arange(L)], 1).astype(np.int32)
+        ae = orc.event_alignment_record(ab, L, K, rd["rc"], start)
+        stride = 1 if (len(ae) and ae[0, 1] < ae[-1, 1]) else -1
+        recs.append((ae, stride, epb))
+    items = []
+    for i in positions:
+        cs, ce = i - flank, i + 1 + flank
+        base = ref_seq[cs:ce + 1]
+        seqs = [base]
+        o = i - cs
+        ref_b = ref_seq[i]
+        for b in "ACGT":
+            if b != ref_b:
+                seqs.append(base[:o] + b + base[o + 1:])                 # substitution
+            if b != ref_b:
+                seqs.append(base[:o + 1] + b + base[o + 1:])             # insertion ref -> ref+b (not ref+ref)
+        if ref_seq[i - 1] != ref_seq[i]:
+            seqs.append(base[:o] + base[o + 1:])                         # deletion of base i (ref[i-1:i+1] -> ref[i-1])
+        per_read = []
+        for ri, (ae, stride, epb) in enumerate(recs):
+            b = orc.find_by_ref_bounds(ae, cs, ce) if len(ae) else None
+            if b is None:
+                continue
+            e1, e2 = b
+            if abs(e1 - e2) / abs(ce - cs) < 20.0:                       # MAX_EVENT_TO_BP_RATIO heuristic (:206-216)
+                per_read.append((ri, e1, e2, stride, int(reads_pairs[ri][0]["rc"]), epb))
+        items.append(dict(pos=i, seqs=seqs, per_read=per_read))
+    return items

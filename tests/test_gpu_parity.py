@@ -201,3 +201,76 @@ def test_exact_fast_division_selftest(ctx):
     bad = C.c_uint64(123)
     rc = ctx.L.np_selftest_division(ctx.h, 1 << 32, 20260924, C.byref(bad))
     assert rc == 0 and bad.value == 0
+
+
+def test_eventalign_segment_chain_matches_oracle(ctx, orc, models):
+    """BASELINE config 3 shape: the eventalign segment chain (each segment starts where the previous one stopped
+    emitting) driven by profile_hmm_align on the GPU vs on the oracle, forward and reverse-strand reads."""
+    from oracle.workloads import eventalign_read
+    mn = orc.model(models["nucleotide"])
+    total = 0
+    for rid in (80, 81, 82):
+        rd = synth_read(rid, models["nucleotide"], L=1800)
+        sh, sc = orc.estimate_scalings_mom(mn, rd["ranks"], rd["events"])
+        pairs = orc.event_align(mn, orc.scalings(sh, sc, 1.0), rd["events"], rd["ranks"])
+        S = orc.scalings(rd["shift"], rd["scale"], rd["var"])
+        epb = orc.build_base_to_event_map(pairs, len(rd["ranks"]))[2]
+
+        def cpu(fwd, rc_s, e1, e2, stride, rc):
+            return orc.hmm_align(mn, S, rd["events"], orc.sequence_kmer_ranks("nucleotide", fwd, rc_s, K, rc), e1, e2, stride, epb)
+
+        def gpu(fwd, rc_s, e1, e2, stride, rc):
+            from nanopolish_amd import api
+            r = ctx.profile_hmm_align([dict(events=rd["events"], ranks=api.sequence_kmer_ranks("nucleotide", fwd, rc_s, K, rc),
+                                            e_start=e1, e_stop=e2, stride=stride, model=ctx.models["nucleotide"], scale=rd["scale"],
+                                            shift=rd["shift"], var=rd["var"], events_per_base=epb, flags=0)])[0]
+            return r if len(r[0]) else None
+
+        want, n1, _ = eventalign_read(orc, rd, pairs, cpu)
+        got, n2, _ = eventalign_read(orc, rd, pairs, gpu)
+        assert n1 == n2 and n1 > 10 and want == got
+        total += len(want)
+    assert total > 3000
+
+
+def test_variant_screening_scores_match_oracle(ctx, orc, models):
+    """BASELINE config 4 shape: 22-bp windows x single-base edits x reads of both strands, profile_hmm_score_set under the
+    nucleotide model with hmm_indel_bias_factor 0.9 and PRE|POST clipping; Variant.quality = sum over reads."""
+    from nanopolish_amd import api
+    from nanopolish_amd.synth import synth_read_from_codes
+    from oracle.workloads import variant_window_items
+    mn = orc.model(models["nucleotide"])
+    rng = np.random.default_rng(99)
+    ref_codes = rng.integers(0, 4, 500)
+    reads_pairs = []
+    for rid in range(6):
+        rd = synth_read_from_codes(ref_codes, rid, models["nucleotide"], rc=bool(rid & 1))
+        sh, sc = orc.estimate_scalings_mom(mn, rd["ranks"], rd["events"])
+        pairs = orc.event_align(mn, orc.scalings(sh, sc, 1.0), rd["events"], rd["ranks"])
+        assert len(pairs) > 0
+        reads_pairs.append((rd, pairs))
+    ref_seq = "".join("ACGT"[c] for c in ref_codes)
+    items = variant_window_items(orc, ref_seq, reads_pairs, range(40, 460, 35))
+    sets, want = [], []
+    for it in items:
+        for seq in it["seqs"]:
+            for (ri, e1, e2, stride, rc, epb) in it["per_read"]:
+                rd = reads_pairs[ri][0]
+                ranks = orc.sequence_kmer_ranks("nucleotide", seq, None, K, rc)
+                S = orc.scalings(rd["shift"], rd["scale"], rd["var"])
+                want.append(orc.combine_score_set([orc.hmm_score(mn, S, rd["events"], ranks, e1, e2, stride, epb, 0.9, HAF_PRE | HAF_POST)]))
+                sets.append([dict(events=rd["events"], ranks=api.sequence_kmer_ranks("nucleotide", seq, None, K, rc), e_start=e1,
+                                  e_stop=e2, stride=stride, model=ctx.models["nucleotide"], scale=rd["scale"], shift=rd["shift"],
+                                  var=rd["var"], events_per_base=epb, flags=HAF_PRE | HAF_POST, indel_bias=0.9)])
+    got = ctx.profile_hmm_score_set(sets)
+    want = np.array(want, np.float32)
+    assert len(want) > 500 and np.array_equal(got, want)
+    # Variant.quality (variant.cpp:782-797 without the racy early-out): sum over reads of variant - base, in double
+    i = 0
+    for it in items:
+        nr = len(it["per_read"])
+        base_g, base_w = got[i:i + nr].astype(np.float64), want[i:i + nr].astype(np.float64)
+        for v in range(1, len(it["seqs"])):
+            vg, vw = got[i + v * nr:i + (v + 1) * nr].astype(np.float64), want[i + v * nr:i + (v + 1) * nr].astype(np.float64)
+            assert np.sum(vg - base_g) == np.sum(vw - base_w)
+        i += nr * len(it["seqs"])
