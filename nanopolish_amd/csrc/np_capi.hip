@@ -6,7 +6,6 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
-#include <time.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -151,33 +150,27 @@ int run_event_align(np_ctx* c, hipStream_t s, int n_reads, const np_read_dev* re
     if (n_reads <= 0) return NP_OK;
     if (model < 0 || model >= (int)c->models.size()) { c->err = "bad model id"; return NP_ERR_INVALID; }
     const int waves_per_block = np_align_block_threads() / 64;
-    const int nb = persistent_blocks(c, n_reads, waves_per_block, c->align_blocks_per_cu);
+    int nb = persistent_blocks(c, n_reads, waves_per_block, c->align_blocks_per_cu);
+    // per-resident-wave scratch: packed trace (32 B per band) and the k-mer parameter slab (16 B per k-mer).
+    // Ultra-long reads make the slabs large, so the persistent grid shrinks to keep the scratch under a budget
+    // (a 1M-event read needs ~56 MB per wave: 48 GB would hold ~850 resident waves instead of 5120).
     const uint64_t stride = ((uint64_t)max_bands * 4 + 15) & ~15ull;
-    NP_HIP(c, c->trace.reserve((size_t)nb * waves_per_block * stride * sizeof(uint64_t)));
     const uint64_t kp_stride = ((uint64_t)max_bands + 63) & ~63ull;      // k-mers per read < bands per read
+    const uint64_t per_block = (uint64_t)waves_per_block * (stride * sizeof(uint64_t) + kp_stride * sizeof(float4));
+    const uint64_t budget = 48ull << 30;
+    if ((uint64_t)nb * per_block > budget) nb = (int)std::max<uint64_t>(1, budget / per_block);
+    NP_HIP(c, c->trace.reserve((size_t)nb * waves_per_block * stride * sizeof(uint64_t)));
     NP_HIP(c, c->kparams.reserve((size_t)nb * waves_per_block * kp_stride * sizeof(float4)));
     NP_HIP(c, hipMemsetAsync(c->d_counters + 16, 0, sizeof(uint32_t), s));
     np_align_args a{};
     a.reads = reads; a.event_mean = event_mean; a.ranks = ranks; a.model = c->models[model].d_states;
     a.pair_off = pair_off; a.pairs = pairs; a.pair_begin = pair_begin; a.n_pairs = n_pairs;
-    a.trace = c->trace.as<uint64_t>(); a.trace_stride = stride; a.kparams = c->kparams.as<float4>(); a.kp_stride = kp_stride; a.counter = c->d_counters + 16;
+    a.trace = c->trace.as<uint64_t>(); a.trace_stride = stride; a.kparams = c->kparams.as<float4>(); a.kp_stride = kp_stride;
+    a.counter = c->d_counters + 16;
     a.n_reads = n_reads; a.max_gap_threshold = c->params.max_gap_threshold;
     a.min_average_log_emission = c->params.min_average_log_emission;
-    uint32_t* dbg = nullptr;
-    if (getenv("NP_DEBUG_ALIGN")) { NP_HIP(c, hipHostMalloc((void**)&dbg, 64 * sizeof(uint32_t), hipHostMallocCoherent)); memset(dbg, 0, 256); a.dbg = dbg; }
-    {
-        family_timer tm(c, 0, s);
-        NP_HIP(c, np_launch_event_align(a, nb, s));
-    }
-    if (dbg) {
-        for (int i = 0; i < 50; ++i) {
-            if (hipStreamQuery(s) == hipSuccess) break;
-            struct timespec ts = {0, 100000000}; nanosleep(&ts, nullptr);
-            fprintf(stderr, "[np dbg] t=%.1fs phase=%u band=%u/%u n_out=%u k=%d e=%d nb=%d stride=%llu entry=%u ri=%u E=%u K=%u q=%d\n", 0.1 * (i + 1), dbg[0], dbg[1], dbg[3], dbg[2], (int)dbg[4], (int)dbg[5], nb, (unsigned long long)stride, dbg[8], dbg[9], dbg[10], dbg[11], (int)hipStreamQuery(s));
-            if (i > 3) break;
-            fflush(stderr);
-        }
-    }
+    family_timer tm(c, 0, s);
+    NP_HIP(c, np_launch_event_align(a, nb, s));
     return NP_OK;
 }
 

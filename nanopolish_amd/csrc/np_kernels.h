@@ -40,7 +40,6 @@ struct np_align_args {
     int32_t n_reads;
     int32_t max_gap_threshold;
     double min_average_log_emission;
-    volatile uint32_t* dbg;        // optional host-visible progress words (debug), may be null
 };
 
 #define NP_NUM_CLASSES 7
