@@ -91,9 +91,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # one process per GPU.  NP_BENCH_BACKEND=gloo + fewer devices than ranks is a single-GPU rehearsal of the N>1 code path
+    backend = os.environ.get("NP_BENCH_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from nanopolish_amd.api import Context
     from nanopolish_amd.pipeline import build_host_batch, tile_host_batch, CallMethylationBatch
@@ -123,6 +129,11 @@ def main():
 
     for _ in range(args.warmup):
         batch.step()
+    if world > 1:
+        # warm the collective path too (RCCL communicator set-up is not part of a step)
+        ctx.sync()
+        sc = batch.d_scores[:batch.n_jobs].to(torch.float64)
+        reduce_site_table(site_table(torch, first, n_motif, sc[1::2] - sc[0::2], args.read_len))
     barrier()
     for w in range(4):
         ctx.kernel_time(w, reset=True)
