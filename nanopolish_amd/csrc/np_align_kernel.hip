@@ -21,7 +21,8 @@
 //     128 right-moves later.
 //   * Candidates are evaluated as the reference does: fp32 cell + fp64 transition constant + fp32 emission in
 //     fp64, rounded to fp32, compared in fp32, later candidate wins ties (raw_loader.cpp:259-274).
-//   * The trace is 2 bits per cell, packed with 4 ballots per band into 32 bytes (vs 100 bytes in the
+//   * The trace is 2 bits per cell: each lane packs the codes of its two slots, 4 bits per band, and stores one dword per
+//     8 bands (coalesced 256 B = 32 bytes per band, vs 100 bytes in the
 //     reference); unfilled cells read back as FROM_D exactly like the reference's zero-initialised trace.
 //   * Back-track: the walk state is scalar; the trace is pulled in 64-band chunks (lane i holds band hi-i, the
 //     next chunk is prefetched), each step is two v_readlane + bit tests.  Pairs are collected 64 at a time in a
@@ -49,8 +50,9 @@ __device__ __forceinline__ float readlane_f(float v, int l)
 // value of ring slot s (uniform) of a band held as (r0 = slots 0..63, r1 = slots 64..127)
 __device__ __forceinline__ float ring_read(float r0, float r1, int s)
 {
-    const float a = readlane_f(r0, s & 63), b = readlane_f(r1, s & 63);
-    return (s & 64) ? b : a;
+    const int a = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r0), s & 63);
+    const int b = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r1), s & 63);
+    return __builtin_bit_cast(float, (s & 64) ? b : a);      // both are SGPRs: a scalar select
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -93,13 +95,14 @@ struct fill_t {
     float p0, p1;           // band b-1
     float d0, d1;           // band b-2 rotated by one slot
     float best; int best_e; // end-cell search (:309-324), tracked by the owner of k-mer K-1
+    uint32_t tacc;          // trace codes of the current 8-band group (4 bits per band)
 };
 
 struct read_t {
     int E, K, lane, end_slot;
     const float* __restrict__ ev;
     const float4* __restrict__ kp;
-    uint64_t* __restrict__ trace;
+    uint32_t* __restrict__ trace32;
     double lp_skip, lp_stay, lp_step, lp_trim;
 };
 
@@ -142,8 +145,8 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
     const bool v0 = F.k0 >= klo && F.k0 <= khi && (unsigned)e0 < (unsigned)E;
     const bool v1 = F.k1 >= klo && F.k1 <= khi && (unsigned)e1 < (unsigned)E;
     // prefetch the next band's event means (same k-mer, next event), clamped: always a plain load
-    xl0 = R.ev[clampi(e0 + 1, 0, E - 1)];
-    xl1 = R.ev[clampi(e1 + 1, 0, E - 1)];
+    xl0 = R.ev[(uint32_t)clampi(e0 + 1, 0, E - 1)];
+    xl1 = R.ev[(uint32_t)clampi(e1 + 1, 0, E - 1)];
 
     cell_out c0 = dp_cell(v0, xc0, F.g0, F.p0, l0, F.d0, R.lp_skip, R.lp_stay, R.lp_step);
     cell_out c1 = dp_cell(v1, xc1, F.g1, F.p1, l1, F.d1, R.lp_skip, R.lp_stay, R.lp_step);
@@ -159,13 +162,10 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
         }
     }
 
-    // packed trace: 4 x 64-bit ballots per band
-    const uint64_t m00 = __ballot(c0.from & 1u), m01 = __ballot(c0.from >> 1);
-    const uint64_t m10 = __ballot(c1.from & 1u), m11 = __ballot(c1.from >> 1);
-    if (lane < 4) {
-        const uint64_t w = lane == 0 ? m00 : lane == 1 ? m01 : lane == 2 ? m10 : m11;
-        R.trace[(size_t)b * 4 + lane] = w;
-    }
+    // packed trace: every lane keeps the 2-bit codes of its two slots, 4 bits per band, and stores one dword per
+    // 8 bands (64 lanes x 4 B = 256 B coalesced = 32 B/band).  The back-track reads the word back into the SAME lane.
+    F.tacc |= (c0.from | (c1.from << 2)) << ((b & 7) * 4);
+    if ((b & 7) == 7) { R.trace32[(size_t)(b >> 3) * 64 + lane] = F.tacc; F.tacc = 0u; }
 
     if (khi == K - 1 && llk <= K - 1) {
         // end search: cell (e, K-1) while it is inside the window, any e in [0,E) (:309-324)
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK) np_event_align_kernel(np_align
         const int cap = (int)(a.pair_off[ri + 1] - pbase);
         np_pair* __restrict__ pairs = a.pairs + pbase;
 
-        const bool ok = !(E <= 0 || K <= 0 || (uint64_t)n_bands * 4 > a.trace_stride || (uint64_t)K > a.kp_stride || cap < E + K + 2);
+        const bool ok = !(E <= 0 || K <= 0 || (uint64_t)((n_bands + 7) >> 3) * 32 > a.trace_stride || (uint64_t)K > a.kp_stride || cap < E + K + 2);
         int n_out = 0, max_gap = 0, last_k = -1;
         double sum_emission = 0.0;
         if (ok) {
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK) np_event_align_kernel(np_align
             // ---------------- fill ----------------
             read_t R;
             R.E = E; R.K = K; R.lane = lane; R.end_slot = (K - 1) & (NP_RING - 1);
-            R.ev = ev; R.kp = kp; R.trace = trace;
+            R.ev = ev; R.kp = kp; R.trace32 = (uint32_t*)trace;
             R.lp_skip = rd->lp_skip; R.lp_stay = rd->lp_stay; R.lp_step = rd->lp_step; R.lp_trim = rd->lp_trim;
             fill_t F;
             F.llk = -1 - NP_ALN_BANDWIDTH / 2;              // band_lower_left[0].kmer_idx, raw_loader.cpp:150-151
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK) np_event_align_kernel(np_align
             F.g0 = load_kp(kp, F.k0, K); F.g1 = load_kp(kp, F.k1, K);
             F.n0 = load_kp(kp, F.k0 + NP_RING, K); F.n1 = load_kp(kp, F.k1 + NP_RING, K);
             F.p0 = F.p1 = F.d0 = F.d1 = NP_NEG_INF;
-            F.best = NP_NEG_INF; F.best_e = 0;
+            F.best = NP_NEG_INF; F.best_e = 0; F.tacc = 0u;
             float xa0 = 0.0f, xa1 = 0.0f, xb0 = 0.0f, xb1 = 0.0f;      // ping-pong event-mean registers
             int b = 0;
             for (; b + 1 < n_bands; b += 2) {
@@ -241,6 +241,7 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK) np_event_align_kernel(np_align
                 band_step(F, R, b + 1, xb0, xb1, xa0, xa1);
             }
             if (b < n_bands) band_step(F, R, b, xa0, xa1, xb0, xb1);
+            if ((n_bands & 7) != 0) R.trace32[(size_t)((n_bands - 1) >> 3) * 64 + lane] = F.tacc;      // last, partial group
 
             // ---------------- backtrack (:326-361) + QC sums (:338-341) ----------------
             const int owner = R.end_slot & 63;
@@ -253,24 +254,19 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK) np_event_align_kernel(np_align
             __builtin_amdgcn_s_waitcnt(0);
 
             if (best_u != NP_NEG_INF) {
-                // chunk registers: lane i holds the 8 dwords of band (chunk_hi - i); (na, nb) is the prefetched next chunk
-                uint4 ca = make_uint4(0, 0, 0, 0), cb = make_uint4(0, 0, 0, 0), na = ca, nb = cb;
-                int chunk_hi = -1, chunk_lo = 0;       // empty
-                int next_hi = curr_e + curr_k + 2;     // first chunk starts at the start cell's band
-                {
-                    const int bnd = next_hi - lane;
-                    if (bnd >= 0) { const uint4* t = (const uint4*)(trace + (size_t)bnd * 4); na = t[0]; nb = t[1]; }
-                }
+                // trace words: `cw` holds the 8-band group `cg` of the current cell for this lane's two slots, `nw` the
+                // group below it (prefetched: the walk only moves down, by one or two bands per step)
+                const uint32_t* __restrict__ t32 = (const uint32_t*)trace;
+                int cg = (curr_e + curr_k + 2) >> 3;
+                uint32_t cw = t32[(size_t)cg * 64 + lane];
+                uint32_t nw = cg > 0 ? t32[(size_t)(cg - 1) * 64 + lane] : 0u;
                 int pk = 0, pe = 0;                    // pair buffer: lane j holds pair number (n_out & ~63) + j
                 int curr_gap = 0;
                 while (curr_k >= 0 && curr_e >= 0) {
                     const int band = curr_e + curr_k + 2;
-                    if (band < chunk_lo || chunk_hi < 0) {
-                        // switch to the prefetched chunk and prefetch the one below it (the walk only moves down)
-                        ca = na; cb = nb; chunk_hi = next_hi; chunk_lo = next_hi - 63;
-                        next_hi = chunk_lo - 1;
-                        const int bnd = next_hi - lane;
-                        if (bnd >= 0) { const uint4* t = (const uint4*)(trace + (size_t)bnd * 4); na = t[0]; nb = t[1]; }
+                    if ((band >> 3) != cg) {
+                        cg -= 1; cw = nw;
+                        nw = cg > 0 ? t32[(size_t)(cg - 1) * 64 + lane] : 0u;
                     }
                     // record the pair
                     const int j = n_out & 63;
@@ -278,15 +274,10 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK) np_event_align_kernel(np_align
                     pe = lane == j ? curr_e : pe;
                     last_k = curr_k;
                     n_out++;
-                    // 2-bit trace code of cell (curr_e, curr_k): slot = k mod 128 -> (half, dword, bit)
+                    // 2-bit trace code of cell (curr_e, curr_k): the lane that owns slot k mod 128, nibble (band mod 8)
                     const int slot = curr_k & (NP_RING - 1);
-                    const bool half = (slot & 64) != 0, hi32 = (slot & 32) != 0;
-                    const uint32_t w0 = half ? (hi32 ? cb.y : cb.x) : (hi32 ? ca.y : ca.x);   // bit 0 plane
-                    const uint32_t w1 = half ? (hi32 ? cb.w : cb.z) : (hi32 ? ca.w : ca.z);   // bit 1 plane
-                    const int li = chunk_hi - band;
-                    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)w0, li);
-                    const uint32_t b1 = (uint32_t)__builtin_amdgcn_readlane((int)w1, li);
-                    const uint32_t from = ((b0 >> (slot & 31)) & 1u) | (((b1 >> (slot & 31)) & 1u) << 1);
+                    const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cw, slot & 63);
+                    const uint32_t from = (w >> ((band & 7) * 4 + ((slot >> 6) << 1))) & 3u;
                     if (from == 0u) { curr_k -= 1; curr_e -= 1; curr_gap = 0; }
                     else if (from == 1u) { curr_e -= 1; curr_gap = 0; }
                     else { curr_k -= 1; curr_gap += 1; max_gap = curr_gap > max_gap ? curr_gap : max_gap; }

@@ -154,7 +154,7 @@ int run_event_align(np_ctx* c, hipStream_t s, int n_reads, const np_read_dev* re
     // per-resident-wave scratch: packed trace (32 B per band) and the k-mer parameter slab (16 B per k-mer).
     // Ultra-long reads make the slabs large, so the persistent grid shrinks to keep the scratch under a budget
     // (a 1M-event read needs ~56 MB per wave: 48 GB would hold ~850 resident waves instead of 5120).
-    const uint64_t stride = ((uint64_t)max_bands * 4 + 15) & ~15ull;
+    const uint64_t stride = (((uint64_t)max_bands + 7) / 8) * 32;        // u64 units: one 256-byte row per 8 bands
     const uint64_t kp_stride = ((uint64_t)max_bands + 63) & ~63ull;      // k-mers per read < bands per read
     const uint64_t per_block = (uint64_t)waves_per_block * (stride * sizeof(uint64_t) + kp_stride * sizeof(float4));
     const uint64_t budget = 48ull << 30;

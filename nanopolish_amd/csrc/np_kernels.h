@@ -33,7 +33,7 @@ struct np_align_args {
     int32_t* pair_begin;
     int32_t* n_pairs;
     uint64_t* trace;               // scratch: n_wave_slots * trace_stride u64
-    uint64_t trace_stride;         // u64 per resident wave (>= 4 * max_bands)
+    uint64_t trace_stride;         // u64 per resident wave (>= 32 * ceil(max_bands / 8): 256 B per 8 bands)
     float4* kparams;               // scratch: n_wave_slots * kp_stride records (scaled Gaussian per k-mer of the read in flight)
     uint64_t kp_stride;            // records per resident wave (>= max k-mers per read)
     uint32_t* counter;
