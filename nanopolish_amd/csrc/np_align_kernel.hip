@@ -185,7 +185,7 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
     F.p0 = c0.v; F.p1 = c1.v;
 }
 
-__global__ void __launch_bounds__(NP_ALIGN_BLOCK) np_event_align_kernel(np_align_args a)
+__global__ void __launch_bounds__(NP_ALIGN_BLOCK, 7) np_event_align_kernel(np_align_args a)
 {
     const int lane = threadIdx.x & 63;
     const int wave_slot = blockIdx.x * (NP_ALIGN_BLOCK / 64) + (threadIdx.x >> 6);
