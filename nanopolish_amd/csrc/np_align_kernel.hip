@@ -125,12 +125,19 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
             // (branch-free on purpose: every lane re-requests its `next` record on every right move -- an L1 hit for all
             //  but the re-targeted slot -- so that no load sits inside a divergent branch, where hipcc would wait for it
             //  immediately; the record consumed here was requested at least one band ago)
-            const bool t0 = F.k0 < F.llk - NP_MARGIN, t1 = F.k1 < F.llk - NP_MARGIN;
-            F.g0.x = t0 ? F.n0.x : F.g0.x; F.g0.y = t0 ? F.n0.y : F.g0.y; F.g0.z = t0 ? F.n0.z : F.g0.z; F.g0.w = t0 ? F.n0.w : F.g0.w;
-            F.g1.x = t1 ? F.n1.x : F.g1.x; F.g1.y = t1 ? F.n1.y : F.g1.y; F.g1.z = t1 ? F.n1.z : F.g1.z; F.g1.w = t1 ? F.n1.w : F.g1.w;
-            F.k0 += t0 ? NP_RING : 0; F.k1 += t1 ? NP_RING : 0;
-            F.n0 = load_kp(R.kp, F.k0 + NP_RING, K);
-            F.n1 = load_kp(R.kp, F.k1 + NP_RING, K);
+            // Exactly one ring slot falls out per right move: slot (llk - 15) mod 128, i.e. one lane of ONE of the two
+            // slot registers -- which one is wave-uniform, so only that register is touched.
+            if (((F.llk - NP_MARGIN - 1) & 64) == 0) {
+                const bool t0 = F.k0 < F.llk - NP_MARGIN;
+                F.g0.x = t0 ? F.n0.x : F.g0.x; F.g0.y = t0 ? F.n0.y : F.g0.y; F.g0.z = t0 ? F.n0.z : F.g0.z; F.g0.w = t0 ? F.n0.w : F.g0.w;
+                F.k0 += t0 ? NP_RING : 0;
+                F.n0 = load_kp(R.kp, F.k0 + NP_RING, K);
+            } else {
+                const bool t1 = F.k1 < F.llk - NP_MARGIN;
+                F.g1.x = t1 ? F.n1.x : F.g1.x; F.g1.y = t1 ? F.n1.y : F.g1.y; F.g1.z = t1 ? F.n1.z : F.g1.z; F.g1.w = t1 ? F.n1.w : F.g1.w;
+                F.k1 += t1 ? NP_RING : 0;
+                F.n1 = load_kp(R.kp, F.k1 + NP_RING, K);
+            }
         }
     }
     const int llk = F.llk;
