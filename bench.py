@@ -41,12 +41,16 @@ def cpu_baseline(models, hb, n_sample, threads):
     rds = hb["reads"][:n]
     eo = hb["event_off"][:n + 1]; ro = hb["rank_off"][:n + 1]
     ev = hb["events"][:eo[-1]]; rk = hb["ranks"][:ro[-1]].astype(np.uint32)
-    t0 = time.perf_counter()
-    if ref:
-        pairs, pair_off, n_pairs = ref.align_many([r["seq"] for r in rds], ev, eo, hb["mom"][:n, 0], hb["mom"][:n, 1], threads)
-    else:
-        pairs, pair_off, n_pairs = orc.align_many(mn, ev, eo, rk, ro, hb["mom"][:n, 0], hb["mom"][:n, 1], threads)
-    t_align = time.perf_counter() - t0
+    # each leg runs twice (the first call also pays thread start-up and page faults); the faster run counts, and only
+    # the C call itself is timed (oracle_py.last_call_s), not the ctypes marshalling around it
+    t_align = 1e30
+    for _ in range(2):
+        if ref:
+            pairs, pair_off, n_pairs = ref.align_many([r["seq"] for r in rds], ev, eo, hb["mom"][:n, 0], hb["mom"][:n, 1], threads)
+            t_align = min(t_align, ref.last_call_s)
+        else:
+            pairs, pair_off, n_pairs = orc.align_many(mn, ev, eo, rk, ro, hb["mom"][:n, 0], hb["mom"][:n, 1], threads)
+            t_align = min(t_align, orc.last_call_s)
     # event map + window bounds through the oracle's glue (untimed host bookkeeping, tiny)
     job_read, e1, e2, stride, rcs, jr, jr_off, epb = [], [], [], [], [], [], [0], np.zeros(n)
     seqs, rc_seqs, first, job_off = [], [], [], [0]
@@ -64,12 +68,14 @@ def cpu_baseline(models, hb, n_sample, threads):
                 first.append((i, j["first"]))
         job_off.append(len(seqs))
     sh = [r["shift"] for r in rds]; sc_ = [r["scale"] for r in rds]; vr = [r["var"] for r in rds]
-    t0 = time.perf_counter()
-    if ref:
-        sc = ref.score_many_reads("cpg", ev, eo, sh, sc_, vr, epb, job_off, seqs, rc_seqs, e1, e2, stride, rcs, 3, threads)
-    else:
-        sc = orc.score_many(mc, job_read, ev, eo, sh, sc_, vr, epb, np.concatenate(jr), jr_off, e1, e2, stride, 1.0, 3, threads)
-    t_score = time.perf_counter() - t0
+    t_score = 1e30
+    for _ in range(2):
+        if ref:
+            sc = ref.score_many_reads("cpg", ev, eo, sh, sc_, vr, epb, job_off, seqs, rc_seqs, e1, e2, stride, rcs, 3, threads)
+            t_score = min(t_score, ref.last_call_s)
+        else:
+            sc = orc.score_many(mc, job_read, ev, eo, sh, sc_, vr, epb, np.concatenate(jr), jr_off, e1, e2, stride, 1.0, 3, threads)
+            t_score = min(t_score, orc.last_call_s)
     return dict(n=n, seconds=t_align + t_score, t_align=t_align, t_score=t_score, pairs=(pairs, pair_off, n_pairs),
                 first=first, scores=sc, kind="reference" if ref else "port")
 

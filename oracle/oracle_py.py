@@ -2,6 +2,7 @@
 import ctypes as C
 import os
 import subprocess
+import time
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -234,9 +235,11 @@ class Oracle:
         events = np.ascontiguousarray(events, np.float32); ranks = np.ascontiguousarray(ranks, np.uint32)
         event_off = np.ascontiguousarray(event_off, np.int64); rank_off = np.ascontiguousarray(rank_off, np.int64)
         shift = np.ascontiguousarray(shift, np.float64); scale = np.ascontiguousarray(scale, np.float64)
+        _t0 = time.perf_counter()
         self.L.npo_align_many(C.byref(model), n_reads, _p(events, c_f32p), _p(event_off, c_i64p), _p(ranks, c_u32p),
                               _p(rank_off, c_i64p), _p(shift, c_f64p), _p(scale, c_f64p), _p(out, c_i32p),
                               _p(pair_off, c_i64p), _p(out_n, c_i32p), int(n_threads))
+        self.last_call_s = time.perf_counter() - _t0
         return out, pair_off, out_n
 
     def score_many(self, model, job_read, events, event_off, shift, scale, var, epb, ranks, job_rank_off,
@@ -248,11 +251,13 @@ class Oracle:
         shift = a(shift, np.float64); scale = a(scale, np.float64); var = a(var, np.float64); epb = a(epb, np.float64)
         ranks = a(ranks, np.uint32); job_rank_off = a(job_rank_off, np.int64)
         e_start = a(e_start, np.uint32); e_stop = a(e_stop, np.uint32); stride = a(stride, np.int8)
+        _t0 = time.perf_counter()
         self.L.npo_score_many(C.byref(model), C.c_int64(n_jobs), _p(job_read, c_i32p), _p(events, c_f32p),
                               _p(event_off, c_i64p), _p(shift, c_f64p), _p(scale, c_f64p), _p(var, c_f64p),
                               _p(epb, c_f64p), _p(ranks, c_u32p), _p(job_rank_off, c_i64p), _p(e_start, c_u32p),
                               _p(e_stop, c_u32p), stride.ctypes.data_as(C.POINTER(C.c_int8)),
                               C.c_double(indel_bias), C.c_uint32(flags), _p(out, c_f32p), int(n_threads))
+        self.last_call_s = time.perf_counter() - _t0
         return out
 
 
@@ -377,8 +382,10 @@ class RefOracle:
         sa = (C.c_char_p * n)(*[s.encode() for s in seqs])
         self.L.npref_align_many.argtypes = [C.c_char_p, C.c_int, c_f32p, c_i64p, C.POINTER(C.c_char_p), c_f64p, c_f64p,
                                             c_i32p, c_i64p, c_i32p, C.c_int]
+        _t0 = time.perf_counter()
         self.L.npref_align_many(self.KIT, n, _p(events, c_f32p), _p(event_off, c_i64p), sa, _p(shift, c_f64p),
                                 _p(scale, c_f64p), _p(out, c_i32p), _p(pair_off, c_i64p), _p(out_n, c_i32p), int(n_threads))
+        self.last_call_s = time.perf_counter() - _t0
         return out, pair_off, out_n
 
     def score_many_reads(self, alphabet, events, event_off, shift, scale, var, epb, job_off, seqs, rc_seqs,
@@ -394,8 +401,10 @@ class RefOracle:
         self.L.npref_score_many_reads.argtypes = [C.c_char_p, C.c_char_p, C.c_int, c_f32p, c_i64p, c_f64p, c_f64p, c_f64p,
                                                   c_f64p, c_i64p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), c_u32p,
                                                   c_u32p, c_i32p, c_i32p, C.c_uint32, c_f32p, C.c_int]
+        _t0 = time.perf_counter()
         self.L.npref_score_many_reads(self.KIT, alphabet.encode(), n, _p(events, c_f32p), _p(event_off, c_i64p),
                                       _p(shift, c_f64p), _p(scale, c_f64p), _p(var, c_f64p), _p(epb, c_f64p),
                                       _p(job_off, c_i64p), sa, ra, _p(e_start, c_u32p), _p(e_stop, c_u32p),
                                       _p(stride, c_i32p), _p(rc, c_i32p), flags, _p(out, c_f32p), int(n_threads))
+        self.last_call_s = time.perf_counter() - _t0
         return out
