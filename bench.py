@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of synthetic R9.4 reads already resident in HBM:
-adaptive_banded_simple_event_align -> event map / window bounds -> 2 x profile_hmm_score per CpG group
+adaptive_banded_simple_event_align -> event map / recalibration / window bounds -> 2 x profile_hmm_score per CpG group
 (workload = BASELINE.json configs[1]: ~8k-event reads, r9.4_450bps CpG model).  Reads shard across ranks
 with no data-path collective (weak scaling); the only exchange is one all-reduce of the per-site table
 at the end of the timed region (N > 1).  Rank 0 prints ONE JSON line.
@@ -27,7 +27,7 @@ def load_models():
                     level_log_stdv=z[a + "_level_log_stdv"]) for a in ("nucleotide", "cpg")}
 
 
-def cpu_baseline(models, hb, n_sample, threads):
+def cpu_baseline(models, hb, n_sample, threads, calibrate):
     """CPU baseline on this box's host cores over a bounded sample of the same reads: align + 2 x score per group,
     OpenMP over reads like src/common/nanopolish_bam_processor.cpp:99.  Uses the reference's own code when
     oracle/_ref/libnp_ref.so travelled with the repo (kind="reference"), else the oracle port (kind="port").
@@ -54,10 +54,21 @@ def cpu_baseline(models, hb, n_sample, threads):
     # event map + window bounds through the oracle's glue (untimed host bookkeeping, tiny)
     job_read, e1, e2, stride, rcs, jr, jr_off, epb = [], [], [], [], [], [], [0], np.zeros(n)
     seqs, rc_seqs, first, job_off = [], [], [], [0]
+    sh = [r["shift"] for r in rds]; sc_ = [r["scale"] for r in rds]; vr = [r["var"] for r in rds]
+    t_calib = 0.0
     for i in range(n):
         p = pairs[pair_off[i]:pair_off[i] + n_pairs[i]]
         if len(p):
             epb[i], jobs = methylation_jobs(orc, rds[i], p)
+            if calibrate:      # recalibrate_model on the event map (oracle restatement; serial, its time is added below)
+                tc = time.perf_counter()
+                start, stop, _ = orc.build_base_to_event_map(p, len(rds[i]["ranks"]))
+                cal = orc.recalibrate(mn, rds[i]["events"], rds[i]["ranks"], start, stop)
+                t_calib += time.perf_counter() - tc
+                if cal is None or cal[2] > 2.5:
+                    jobs = []
+                else:
+                    sh[i], sc_[i], vr[i] = cal
             for j in (jobs if epb[i] <= 5.0 else []):
                 for s, r in ((j["subseq"], j["rc_subseq"]), (j["m_subseq"], j["rc_m_subseq"])):
                     job_read.append(i); e1.append(j["e1"]); e2.append(j["e2"]); stride.append(j["stride"]); rcs.append(j["rc"])
@@ -67,7 +78,7 @@ def cpu_baseline(models, hb, n_sample, threads):
                         jr.append(q); jr_off.append(jr_off[-1] + len(q))
                 first.append((i, j["first"]))
         job_off.append(len(seqs))
-    sh = [r["shift"] for r in rds]; sc_ = [r["scale"] for r in rds]; vr = [r["var"] for r in rds]
+    t_calib /= max(1, threads)          # as if spread over the cores like the other legs
     t_score = 1e30
     for _ in range(2):
         if ref:
@@ -76,7 +87,8 @@ def cpu_baseline(models, hb, n_sample, threads):
         else:
             sc = orc.score_many(mc, job_read, ev, eo, sh, sc_, vr, epb, np.concatenate(jr), jr_off, e1, e2, stride, 1.0, 3, threads)
             t_score = min(t_score, orc.last_call_s)
-    return dict(n=n, seconds=t_align + t_score, t_align=t_align, t_score=t_score, pairs=(pairs, pair_off, n_pairs),
+    return dict(n=n, seconds=t_align + t_calib + t_score, t_align=t_align, t_score=t_score, t_calib=t_calib,
+                pairs=(pairs, pair_off, n_pairs),
                 first=first, scores=sc, kind="reference" if ref else "port")
 
 
@@ -88,6 +100,9 @@ def main():
     ap.add_argument("--pool", type=int, default=1024, help="distinct synthetic reads per rank")
     ap.add_argument("--tile", type=int, default=16, help="independent HBM copies of the pool per batch")
     ap.add_argument("--read-len", type=int, default=5450, help="bases per read (5450 -> ~8k events)")
+    ap.add_argument("--calibrate", type=int, default=1,
+                    help="1: recalibrate each read on the device between the two kernels, as load_from_raw does (SURVEY 8 f1); "
+                         "0: score with the scalings the synthetic reads were made with")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1: ~8 per core, 0: skip)")
     args = ap.parse_args()
 
@@ -119,7 +134,7 @@ def main():
     lo, hi = shard_read_ids(world * args.pool, rank, world)          # reads shard by contiguous id range
     hb = build_host_batch(models, np.arange(lo, hi), L=args.read_len)
     hbt = tile_host_batch(hb, args.tile)
-    batch = CallMethylationBatch(ctx, hbt, "cuda:%d" % local)
+    batch = CallMethylationBatch(ctx, hbt, "cuda:%d" % local, calibrate=bool(args.calibrate))
     t_prep = time.perf_counter() - t_prep
     n_reads = batch.n_reads
 
@@ -195,10 +210,10 @@ def main():
         cores = len(os.sched_getaffinity(0))
         n_sample = args.cpu_sample if args.cpu_sample >= 0 else max(8, 8 * cores)
         if n_sample > 0 and world == 1:
-            cb = cpu_baseline(models, hb, n_sample, cores)
+            cb = cpu_baseline(models, hb, n_sample, cores, bool(args.calibrate))
             cpu = dict(value=round(cb["n"] / cb["seconds"], 2), unit="reads/s", cores=cores, kind=cb["kind"],
-                       sample="%d of the same synthetic reads, OpenMP over reads (align %.1fs + score %.1fs)"
-                              % (cb["n"], cb["t_align"], cb["t_score"]))
+                       sample="%d of the same synthetic reads, OpenMP over reads (align %.1fs + calibrate %.2fs + score %.1fs)"
+                              % (cb["n"], cb["t_align"], cb["t_calib"], cb["t_score"]))
             # parity of the GPU results with the oracle on that sample: pairs bit-exact, LLR within 1e-4
             pairs, pair_off, n_pairs = cb["pairs"]
             ok = True
@@ -218,7 +233,9 @@ def main():
                 g = gmap[key]
                 d.append((float(scores[2 * g + 1]) - float(scores[2 * g])) - (float(want[2 * q + 1]) - float(want[2 * q])))
             max_dllr = float(np.max(np.abs(d))) if d else 0.0
-            cpu["check"] = dict(reads=cb["n"], groups=len(d), pairs_bit_exact=bool(ok), max_abs_dLLR=max_dllr)
+            n_gpu_groups = int(np.isfinite(llr[:sum(len(m["first"]) for m in hb["meta"][:cb["n"]])]).sum())
+            cpu["check"] = dict(reads=cb["n"], groups=len(d), groups_scored_on_gpu=n_gpu_groups, pairs_bit_exact=bool(ok),
+                                max_abs_dLLR=max_dllr)
 
         value = world * n_reads * args.steps / dt
         out = dict(metric="call-methylation reads/sec", value=round(value, 2), unit="reads/s", n_gpus=world,
@@ -228,7 +245,7 @@ def main():
                                         "(BASELINE.json configs[1] shape)",
                                reads_per_step_per_gpu=n_reads, distinct_reads_per_gpu=args.pool, tile=args.tile,
                                read_len=args.read_len, mean_events=round(batch.total_events / n_reads, 1),
-                               groups_per_step_per_gpu=n_groups, reads_aligned_ok=n_ok,
+                               groups_per_step_per_gpu=n_groups, reads_aligned_ok=n_ok, calibrate_on_device=bool(args.calibrate),
                                parallelism="reads sharded over %d GPU(s), 1 process/GPU" % world),
                    cpg_site_groups_per_s=round(world * n_groups * args.steps / dt, 1),
                    max_abs_dLLR_vs_cpu=max_dllr, roofline=roof, cpu_baseline=cpu, host_prep_s=round(t_prep, 1))

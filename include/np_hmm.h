@@ -218,6 +218,18 @@ int np_resolve_jobs_dev(np_ctx* ctx, void* stream, int n_reads, np_read_dev* rea
                         int32_t* map_start, double* events_per_base,
                         int64_t n_jobs, np_hmm_job_dev* jobs, const int32_t* kpos);
 
+/* The same glue with load_from_raw's calibration step in between:
+ *   event map (start AND stop) -> recalibrate_model(scale_var, no drift; src/nanopolish_methyltrain.cpp:204-306) on the
+ *   'M' entries of get_eventalignment_for_1d_basecalls (src/nanopolish_squiggle_read.cpp:339-389) -> work-item bounds.
+ * reads[r] leaves with the calibrated shift/scale/var/log_var (and the HMM transitions); calibrated[r] = 0 marks reads
+ * with < 200 'M' events or var > 2.5 (events cleared in the reference, squiggle_read.cpp:320-323): their items are
+ * skipped.  event_mean / kmer_rank / model: the read's events, nucleotide k-mer ranks and base model, as for kernel A. */
+int np_calibrate_resolve_dev(np_ctx* ctx, void* stream, int n_reads, np_read_dev* reads,
+                             const float* event_mean, const uint16_t* kmer_rank, int model,
+                             const int64_t* pair_off, const np_pair* pairs, const int32_t* pair_begin, const int32_t* n_pairs,
+                             int32_t* map_start, int32_t* map_stop, double* events_per_base, int32_t* calibrated,
+                             int64_t n_jobs, np_hmm_job_dev* jobs, const int32_t* kpos);
+
 /* Device self-test: the emission's exact fast division (reciprocal + two fused corrections) against the IEEE fp32
  * divide on n_samples pseudo-random operand pairs; *n_mismatch must come back 0. */
 int np_selftest_division(np_ctx* ctx, uint64_t n_samples, uint64_t seed, uint64_t* n_mismatch);

@@ -349,9 +349,34 @@ int np_resolve_jobs_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* reads
     NP_HIP(c, hipSetDevice(c->device));
     hipStream_t s = pick_stream(c, stream);
     family_timer tm(c, 2, s);
-    NP_HIP(c, np_launch_build_map(n_reads, reads, pair_off, pairs, pair_begin, n_pairs, map_start, events_per_base,
+    NP_HIP(c, np_launch_build_map(n_reads, reads, pair_off, pairs, pair_begin, n_pairs, map_start, nullptr, events_per_base,
                                   c->params.hmm_indel_bias_factor, s));
-    NP_HIP(c, np_launch_resolve(n_jobs, jobs, reads, n_pairs, events_per_base, map_start, kpos, s));
+    NP_HIP(c, np_launch_resolve(n_jobs, jobs, reads, n_pairs, events_per_base, nullptr, map_start, kpos, s));
+    return NP_OK;
+}
+
+// The same glue with the calibration step of load_from_raw in between: event map ->
+// recalibrate_model on the device -> work-item bounds.  `reads` comes in with any scalings and leaves with the
+// calibrated shift/scale/var/log_var; reads that are not calibrated (< 200 'M' events) or exceed
+// MIN_CALIBRATION_VAR get calibrated[r] = 0 and all their work items are skipped, as their events are cleared in
+// the reference (squiggle_read.cpp:320-323).
+int np_calibrate_resolve_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* reads, const float* event_mean,
+                             const uint16_t* kmer_rank, int model, const int64_t* pair_off, const np_pair* pairs,
+                             const int32_t* pair_begin, const int32_t* n_pairs, int32_t* map_start, int32_t* map_stop,
+                             double* events_per_base, int32_t* calibrated, int64_t n_jobs, np_hmm_job_dev* jobs,
+                             const int32_t* kpos)
+{
+    if (!c || !calibrated || !map_stop) return NP_ERR_INVALID;
+    if (model < 0 || model >= (int)c->models.size()) { c->err = "bad model id"; return NP_ERR_INVALID; }
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = pick_stream(c, stream);
+    family_timer tm(c, 2, s);
+    NP_HIP(c, np_launch_build_map(n_reads, reads, pair_off, pairs, pair_begin, n_pairs, map_start, map_stop, events_per_base,
+                                  c->params.hmm_indel_bias_factor, s));
+    NP_HIP(c, np_launch_recalibrate(n_reads, reads, event_mean, kmer_rank, c->models[model].d_states, n_pairs, map_start,
+                                    calibrated, s));
+    NP_HIP(c, np_launch_resolve(n_jobs, jobs, reads, n_pairs, events_per_base, calibrated, map_start, kpos, s));
     return NP_OK;
 }
 

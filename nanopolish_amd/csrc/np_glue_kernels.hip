@@ -14,7 +14,7 @@ namespace {
 
 __global__ void __launch_bounds__(64) np_build_map_kernel(int n_reads, np_read_dev* reads, const int64_t* pair_off,
                                                           const np_pair* pairs, const int32_t* pair_begin,
-                                                          const int32_t* n_pairs, int32_t* map_start,
+                                                          const int32_t* n_pairs, int32_t* map_start, int32_t* map_stop,
                                                           double* events_per_base, double indel_bias)
 {
     const int ri = blockIdx.x;
@@ -23,7 +23,8 @@ __global__ void __launch_bounds__(64) np_build_map_kernel(int n_reads, np_read_d
     np_read_dev* rd = reads + ri;
     const int K = (int)rd->n_kmers;
     int32_t* ms = map_start + rd->rank_off;
-    for (int k = lane; k < K; k += 64) ms[k] = -1;            // IndexPair(): start = -1
+    int32_t* mp = map_stop ? map_stop + rd->rank_off : nullptr;
+    for (int k = lane; k < K; k += 64) { ms[k] = -1; if (mp) mp[k] = -1; }      // IndexPair(): start = stop = -1
     const int np_ = n_pairs[ri];
     if (np_ <= 0) {
         // failed alignment: events cleared, events_per_base = 0 (squiggle_read.cpp:324-329)
@@ -35,14 +36,128 @@ __global__ void __launch_bounds__(64) np_build_map_kernel(int n_reads, np_read_d
     for (int i = lane; i < np_; i += 64) {
         const np_pair c = p[i];
         const int prev_e = i > 0 ? p[i - 1].read_pos : -1;    // prev_event_idx = -1 initially (:281)
-        if (c.read_pos != prev_e)                              // only the first k-mer an event touches records it
+        if (c.read_pos != prev_e) {                            // only the first k-mer an event touches records it
             atomicMin((unsigned int*)&ms[c.ref_pos], (unsigned int)c.read_pos);   // first (== smallest) wins: elem.start
+            if (mp) atomicMax(&mp[c.ref_pos], c.read_pos);                        // last (== largest) wins:  elem.stop
+        }
     }
     if (lane == 0) {
         const size_t min_event = (size_t)p[0].read_pos, max_event = (size_t)p[np_ - 1].read_pos;  // path is monotone
         const double epb = (double)(max_event - min_event) / (double)(size_t)K;                    // :301
         events_per_base[ri] = epb;
         np_transitions(epb, indel_bias, rd->trans);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// f1: recalibrate_model(read, base_model, strand, alignment, scale_var = true, scale_drift = false)
+//     (src/nanopolish_methyltrain.cpp:204-306) on the 'M' entries of get_eventalignment_for_1d_basecalls
+//     (src/nanopolish_squiggle_read.cpp:339-389).  One wavefront per read.
+// Each k-mer that has events contributes exactly one candidate 'M' entry -- its first event -- and it is 'M' iff
+// its rank differs from the rank of the previous k-mer that has events (all events of one k-mer share its rank, so
+// later events of the run are 'E').  The five normal-equation sums and the residual sum are accumulated in the
+// reference's order (ascending k-mer): lanes form the terms 64 at a time, a v_readlane loop adds them in lane order.
+// The 2x2 solve restates Eigen's FullPivLU (see oracle/np_oracle.c:eigen_fullpivlu_solve_2x2).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ void fullpivlu_solve_2x2(double a00, double a01, double a10, double a11, double b0, double b1,
+                                                    double& x0, double& x1)
+{
+    double m00 = a00, m01 = a01, m10 = a10, m11 = a11;
+    int pr = 0, pc = 0; double big = fabs(m00);                    // first maximum in column-major visiting order
+    if (fabs(m10) > big) { big = fabs(m10); pr = 1; pc = 0; }
+    if (fabs(m01) > big) { big = fabs(m01); pr = 0; pc = 1; }
+    if (fabs(m11) > big) { big = fabs(m11); pr = 1; pc = 1; }
+    x0 = x1 = 0.0;
+    if (big == 0.0) return;
+    if (pr == 1) { double t = m00; m00 = m10; m10 = t; t = m01; m01 = m11; m11 = t; }
+    if (pc == 1) { double t = m00; m00 = m01; m01 = t; t = m10; m10 = m11; m11 = t; }
+    m10 /= m00;
+    m11 -= m10 * m01;
+    const double maxpivot = fabs(m00) > fabs(m11) ? fabs(m00) : fabs(m11);
+    const double thr = maxpivot * (2.220446049250313e-16 * 2);
+    const int rank = (fabs(m00) > thr) + (fabs(m11) > thr);
+    double c0 = pr == 1 ? b1 : b0, c1 = pr == 1 ? b0 : b1;
+    c1 -= m10 * c0;
+    double y1 = 0.0;
+    if (rank == 2) { y1 = c1 / m11; c0 -= y1 * m01; }
+    const double y0 = c0 / m00;
+    if (pc == 1) { x0 = y1; x1 = y0; } else { x0 = y0; x1 = y1; }
+}
+
+__global__ void __launch_bounds__(64) np_recalibrate_kernel(int n_reads, np_read_dev* reads, const float* event_mean,
+                                                            const uint16_t* ranks, const np_state_dev* model,
+                                                            const int32_t* n_pairs, const int32_t* map_start,
+                                                            int32_t* calibrated)
+{
+    const int ri = blockIdx.x;
+    if (ri >= n_reads) return;
+    const int lane = threadIdx.x;
+    np_read_dev* rd = reads + ri;
+    if (n_pairs[ri] <= 0) { if (lane == 0) calibrated[ri] = 0; return; }
+    const int K = (int)rd->n_kmers;
+    const int32_t* ms = map_start + rd->rank_off;
+    const uint16_t* rk = ranks + rd->rank_off;
+    const float* ev = event_mean + rd->event_off;
+
+    double shift = 0.0, scale = 0.0;
+    double a00 = 0., a01 = 0., a11 = 0., b0 = 0., b1 = 0., var = 0.;
+    long long n = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        int carry_rank = -1;                                     // prev_kmer_rank = -1 (squiggle_read.cpp:351)
+        for (int base = 0; base < K; base += 64) {
+            const int ki = base + lane;
+            const int st = ki < K ? ms[ki] : -1;
+            const bool has = st != -1;
+            const int rank = has ? (int)rk[ki] : -1;
+            const unsigned long long hm = __ballot(has);
+            const unsigned long long before = hm & ((1ull << lane) - 1ull);
+            const int src = before ? 63 - __clzll((long long)before) : 0;
+            const int prev = __shfl(rank, src, 64);
+            const bool isM = has && rank != (before ? prev : carry_rank);
+            double t0 = 0., t1 = 0., t2 = 0., t3 = 0., t4 = 0.;
+            if (isM) {
+                const double ls = model[rank].level_stdv, mu = model[rank].level_mean;
+                const double e = (double)ev[st];                 // raw_events: get_unscaled_level of the run's first event
+                if (pass == 0) {
+                    const double inv_var = 1. / (ls * ls);
+                    t0 = inv_var; t1 = mu * inv_var; t2 = mu * mu * inv_var; t3 = e * inv_var; t4 = mu * e * inv_var;
+                } else {
+                    const double yi = (e - shift - scale * mu);
+                    t0 = yi * yi / (ls * ls);
+                }
+            }
+            const unsigned long long mm = __ballot(isM);
+            if (mm) {
+                if (pass == 0) {
+                    for (int q = 0; q < 64; ++q) {                // ascending k-mer order == the reference's loop order
+                        a00 += readlane_f64(t0, q); a01 += readlane_f64(t1, q); a11 += readlane_f64(t2, q);
+                        b0 += readlane_f64(t3, q); b1 += readlane_f64(t4, q);
+                    }
+                    n += __popcll(mm);
+                } else {
+                    for (int q = 0; q < 64; ++q) var += readlane_f64(t0, q);
+                }
+            }
+            if (hm) carry_rank = __shfl(rank, 63 - __clzll((long long)hm), 64);
+        }
+        if (pass == 0) {
+            if (n < 200) { if (lane == 0) calibrated[ri] = 0; return; }      // minNumEventsToRescale: not recalibrated
+            fullpivlu_solve_2x2(a00, a01, a01, a11, b0, b1, shift, scale);
+        }
+    }
+    var /= (double)(unsigned long long)n;
+    var = sqrt(var);
+    if (lane == 0) {
+        rd->shift = shift; rd->scale = scale; rd->var = var; rd->log_var = log(var);   // set4 (squiggle_read.cpp:38-65)
+        calibrated[ri] = var > 2.5 ? 0 : 1;                                            // MIN_CALIBRATION_VAR (:320)
     }
 }
 
@@ -60,13 +175,14 @@ __device__ __forceinline__ int closest_event(const int32_t* ms, int K, int k_idx
 
 __global__ void __launch_bounds__(256) np_resolve_kernel(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads,
                                                          const int32_t* n_pairs, const double* events_per_base,
-                                                         const int32_t* map_start, const int32_t* kpos)
+                                                         const int32_t* calibrated, const int32_t* map_start, const int32_t* kpos)
 {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n_jobs) return;
     np_hmm_job_dev job = jobs[j];
     const np_read_dev* rd = reads + job.read;
-    bool ok = n_pairs[job.read] > 0 && !(events_per_base[job.read] > 5.0);
+    // failed alignment, failed calibration (squiggle_read.cpp:320-323) or events-per-base QC (:332): no events, no scoring
+    bool ok = n_pairs[job.read] > 0 && !(events_per_base[job.read] > 5.0) && (!calibrated || calibrated[job.read] != 0);
     int e1 = -1, e2 = -1;
     if (ok) {
         const int32_t* ms = map_start + rd->rank_off;
@@ -184,21 +300,22 @@ hipError_t np_launch_classify(const np_hmm_job_dev* jobs, int64_t n_jobs, uint32
 }
 
 hipError_t np_launch_build_map(int n_reads, np_read_dev* reads, const int64_t* pair_off, const np_pair* pairs,
-                               const int32_t* pair_begin, const int32_t* n_pairs, int32_t* map_start,
+                               const int32_t* pair_begin, const int32_t* n_pairs, int32_t* map_start, int32_t* map_stop,
                                double* events_per_base, double indel_bias, hipStream_t s)
 {
     if (n_reads <= 0) return hipSuccess;
     hipLaunchKernelGGL(np_build_map_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, reads, pair_off, pairs,
-                       pair_begin, n_pairs, map_start, events_per_base, indel_bias);
+                       pair_begin, n_pairs, map_start, map_stop, events_per_base, indel_bias);
     return hipGetLastError();
 }
 
 hipError_t np_launch_resolve(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads, const int32_t* n_pairs,
-                             const double* events_per_base, const int32_t* map_start, const int32_t* kpos, hipStream_t s)
+                             const double* events_per_base, const int32_t* calibrated, const int32_t* map_start,
+                             const int32_t* kpos, hipStream_t s)
 {
     if (n_jobs <= 0) return hipSuccess;
     hipLaunchKernelGGL(np_resolve_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, s,
-                       n_jobs, jobs, reads, n_pairs, events_per_base, map_start, kpos);
+                       n_jobs, jobs, reads, n_pairs, events_per_base, calibrated, map_start, kpos);
     return hipGetLastError();
 }
 
@@ -242,5 +359,15 @@ hipError_t np_launch_selftest_div(uint64_t n_samples, uint64_t seed, unsigned lo
     const unsigned blocks = 4096;
     const uint64_t per_thread = (n_samples + (uint64_t)blocks * 256 - 1) / ((uint64_t)blocks * 256);
     hipLaunchKernelGGL(np_selftest_div_kernel, dim3(blocks), dim3(256), 0, s, per_thread, seed, d_mismatches);
+    return hipGetLastError();
+}
+
+hipError_t np_launch_recalibrate(int n_reads, np_read_dev* reads, const float* event_mean, const uint16_t* ranks,
+                                 const np_state_dev* model, const int32_t* n_pairs, const int32_t* map_start,
+                                 int32_t* calibrated, hipStream_t s)
+{
+    if (n_reads <= 0) return hipSuccess;
+    hipLaunchKernelGGL(np_recalibrate_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, reads, event_mean, ranks, model,
+                       n_pairs, map_start, calibrated);
     return hipGetLastError();
 }

@@ -19,7 +19,7 @@ SYMBOLS = [
     "np_alphabet_id", "np_alphabet_size", "np_kmer_rank", "np_reverse_complement", "np_methylate", "np_unmethylate",
     "np_is_motif_match", "np_sequence_kmer_ranks", "np_calculate_transitions", "np_estimate_scalings_mom",
     "np_scan_motif_groups", "np_cm_build_jobs_identity", "np_fill_read_host", "np_hmm_score_host", "np_hmm_score_set_host", "np_hmm_align_host", "np_event_align_host",
-    "np_event_align_dev", "np_hmm_score_dev", "np_resolve_jobs_dev", "np_sync", "np_last_kernel_ms", "np_kernel_time", "np_selftest_division",
+    "np_event_align_dev", "np_hmm_score_dev", "np_resolve_jobs_dev", "np_calibrate_resolve_dev", "np_sync", "np_last_kernel_ms", "np_kernel_time", "np_selftest_division",
 ]
 
 
@@ -124,6 +124,7 @@ def load_library():
     L.np_hmm_score_dev.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, C.c_int, vp]
     L.np_resolve_jobs_dev.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int64, vp, vp]
     L.np_selftest_division.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.np_calibrate_resolve_dev.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int64, vp, vp]
     L.np_sync.argtypes = [vp, vp]
     L.np_last_kernel_ms.argtypes = [vp, C.c_int, c_f32p]
     L.np_kernel_time.argtypes = [vp, C.c_int, c_f64p, c_i64p, C.c_int]

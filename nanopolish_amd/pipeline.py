@@ -2,6 +2,7 @@
 
     adaptive_banded_simple_event_align  (kernel A, one wave per read)
       -> base_to_event_map / events_per_base / transitions / window event bounds  (glue kernels)
+         [calibrate=True: + recalibrate_model on the event map, src/nanopolish_methyltrain.cpp:204-306, SURVEY 8 f1]
       -> 2 x profile_hmm_score per CpG group (kernel B)
 
 mirroring SquiggleRead::load_from_raw (src/nanopolish_squiggle_read.cpp:270-301) followed by
@@ -99,9 +100,13 @@ def tile_host_batch(hb, tile):
 
 
 class CallMethylationBatch:
-    def __init__(self, ctx, hb, device="cuda:0"):
+    def __init__(self, ctx, hb, device="cuda:0", calibrate=False):
+        """calibrate=False: kernel B scores with the scalings the caller put in hb["reads_b"] (a read whose
+        calibration was done elsewhere).  calibrate=True: the pass recalibrates every read on the device from its
+        own event alignment, as load_from_raw does (squiggle_read.cpp:304-323), and reads_b is overwritten."""
         import torch
         self.torch = torch
+        self.calibrate = bool(calibrate)
         self.ctx = ctx
         self.hb = hb
         self.n_reads = hb["n"]
@@ -126,6 +131,8 @@ class CallMethylationBatch:
         self.d_n_pairs = torch.zeros(self.n_reads, dtype=torch.int32, device=dev)
         self.d_map = torch.empty(len(hb["ranks"]), dtype=torch.int32, device=dev)
         self.d_epb = torch.zeros(self.n_reads, dtype=torch.float64, device=dev)
+        self.d_map_stop = torch.empty(len(hb["ranks"]) if self.calibrate else 1, dtype=torch.int32, device=dev)
+        self.d_calibrated = torch.ones(self.n_reads, dtype=torch.int32, device=dev)
         self.d_scores = torch.zeros(max(self.n_jobs, 1), dtype=torch.float32, device=dev)
         self.m_nuc = ctx.models["nucleotide"]; self.m_cpg = ctx.models["cpg"]
         torch.cuda.synchronize()
@@ -142,10 +149,17 @@ class CallMethylationBatch:
         rc = L.np_event_align_dev(h, None, self.n_reads, p(self.d_reads_a), p(self.d_events), p(self.d_ranks), self.m_nuc,
                                   self.max_bands, p(self.d_pair_off), p(self.d_pairs), p(self.d_pair_begin), p(self.d_n_pairs))
         self.ctx._chk(rc, "np_event_align_dev")
-        rc = L.np_resolve_jobs_dev(h, None, self.n_reads, p(self.d_reads_b), p(self.d_pair_off), p(self.d_pairs),
-                                   p(self.d_pair_begin), p(self.d_n_pairs), p(self.d_map), p(self.d_epb), self.n_jobs,
-                                   p(self.d_jobs), p(self.d_kpos))
-        self.ctx._chk(rc, "np_resolve_jobs_dev")
+        if self.calibrate:
+            rc = L.np_calibrate_resolve_dev(h, None, self.n_reads, p(self.d_reads_b), p(self.d_events), p(self.d_ranks),
+                                            self.m_nuc, p(self.d_pair_off), p(self.d_pairs), p(self.d_pair_begin),
+                                            p(self.d_n_pairs), p(self.d_map), p(self.d_map_stop), p(self.d_epb),
+                                            p(self.d_calibrated), self.n_jobs, p(self.d_jobs), p(self.d_kpos))
+            self.ctx._chk(rc, "np_calibrate_resolve_dev")
+        else:
+            rc = L.np_resolve_jobs_dev(h, None, self.n_reads, p(self.d_reads_b), p(self.d_pair_off), p(self.d_pairs),
+                                       p(self.d_pair_begin), p(self.d_n_pairs), p(self.d_map), p(self.d_epb), self.n_jobs,
+                                       p(self.d_jobs), p(self.d_kpos))
+            self.ctx._chk(rc, "np_resolve_jobs_dev")
         rc = L.np_hmm_score_dev(h, None, self.n_jobs, p(self.d_jobs), p(self.d_reads_b), p(self.d_events), p(self.d_job_ranks),
                                 self.m_cpg, p(self.d_scores))
         self.ctx._chk(rc, "np_hmm_score_dev")
@@ -171,3 +185,16 @@ class CallMethylationBatch:
     def epb(self):
         self.sync()
         return self.d_epb.cpu().numpy()
+
+    def reads_scored(self):
+        """np_read_dev records kernel B used (after device calibration when calibrate=True)."""
+        self.sync()
+        return self.d_reads_b.cpu().numpy().view(READ_DT)
+
+    def calibrated(self):
+        self.sync()
+        return self.d_calibrated.cpu().numpy()
+
+    def event_map(self):
+        self.sync()
+        return self.d_map.cpu().numpy(), (self.d_map_stop.cpu().numpy() if self.calibrate else None)

@@ -860,3 +860,93 @@ void npo_score_many(const npo_model* m, int64_t n_jobs, const int32_t* job_read,
                                        e_start[j], e_stop[j], stride[j], events_per_base[r], indel_bias, flags);
     }
 }
+
+/* =====================================================================================
+ * f1: calibration between the aligner and the HMM
+ *   get_eventalignment_for_1d_basecalls  src/nanopolish_squiggle_read.cpp:339-389 (shift_offset 0)
+ *   recalibrate_model(..., scale_var = true, scale_drift = false)  src/nanopolish_methyltrain.cpp:204-306
+ * The 2x2 solve is Eigen 3.3.7 `A.fullPivLu().solve(b)` (methyltrain.cpp:283).  Eigen is NOT in this container, so
+ * the restatement below follows Eigen's published algorithm (FullPivLU::computeInPlace + _solve_impl: complete
+ * pivoting with the first maximum in column-major order, in-place elimination, rank from the default threshold
+ * epsilon * diagonalSize, unit-lower then upper triangular solves, inverse column permutation) and is
+ * "parity unpinned" for that step.
+ * ===================================================================================== */
+static void eigen_fullpivlu_solve_2x2(const double Ain[4] /* row-major a00 a01 a10 a11 */, const double bin[2], double x[2])
+{
+    double m[2][2] = {{Ain[0], Ain[1]}, {Ain[2], Ain[3]}};
+    /* k = 0: biggest |coeff| of the whole matrix, first maximum in column-major visiting order */
+    int pr = 0, pc = 0; double big = fabs(m[0][0]);
+    if(fabs(m[1][0]) > big) { big = fabs(m[1][0]); pr = 1; pc = 0; }
+    if(fabs(m[0][1]) > big) { big = fabs(m[0][1]); pr = 0; pc = 1; }
+    if(fabs(m[1][1]) > big) { big = fabs(m[1][1]); pr = 1; pc = 1; }
+    x[0] = x[1] = 0.0;
+    if(big == 0.0) return;                                   /* zero matrix: rank 0, solution 0 */
+    if(pr == 1) { double t; t = m[0][0]; m[0][0] = m[1][0]; m[1][0] = t; t = m[0][1]; m[0][1] = m[1][1]; m[1][1] = t; }
+    if(pc == 1) { double t; t = m[0][0]; m[0][0] = m[0][1]; m[0][1] = t; t = m[1][0]; m[1][0] = m[1][1]; m[1][1] = t; }
+    m[1][0] /= m[0][0];
+    m[1][1] -= m[1][0] * m[0][1];
+    const double maxpivot = fabs(m[0][0]) > fabs(m[1][1]) ? fabs(m[0][0]) : fabs(m[1][1]);   /* m_maxpivot */
+    const double thr = maxpivot * (2.220446049250313e-16 * 2);                                 /* epsilon * diagonalSize */
+    const int rank = (fabs(m[0][0]) > thr) + (fabs(m[1][1]) > thr);
+    double c0 = pr == 1 ? bin[1] : bin[0], c1 = pr == 1 ? bin[0] : bin[1];                     /* P b */
+    c1 -= m[1][0] * c0;                                                                       /* unit-lower solve */
+    double y0, y1 = 0.0;
+    if(rank == 2) { y1 = c1 / m[1][1]; c0 -= y1 * m[0][1]; }                                   /* upper solve, top-left rank block */
+    y0 = c0 / m[0][0];
+    if(pc == 1) { x[0] = y1; x[1] = y0; } else { x[0] = y0; x[1] = y1; }                       /* Q y */
+}
+
+/* returns 1 if recalibrated (>= 200 'M' events), else 0 and leaves the outputs untouched */
+int npo_recalibrate(const npo_model* m, const float* event_mean, const uint32_t* kmer_ranks, uint32_t n_kmers,
+                    const int32_t* map_start, const int32_t* map_stop, double* shift_out, double* scale_out, double* var_out)
+{
+    /* get_eventalignment_for_1d_basecalls + the 'M' filter of recalibrate_model (methyltrain.cpp:221-240) */
+    size_t cap = 0;
+    for(uint32_t ki = 0; ki < n_kmers; ++ki) if(map_start[ki] != -1) cap += (size_t)(map_stop[ki] - map_start[ki] + 1);
+    double* raw_events = (double*)malloc(sizeof(double) * (cap + 1));
+    double* level_means = (double*)malloc(sizeof(double) * (cap + 1));
+    double* level_stdvs = (double*)malloc(sizeof(double) * (cap + 1));
+    size_t n = 0;
+    size_t prev_kmer_rank = (size_t)-1;
+    for(uint32_t ki = 0; ki < n_kmers; ++ki) {
+        if(map_start[ki] == -1) continue;
+        for(int32_t event_idx = map_start[ki]; event_idx <= map_stop[ki]; event_idx++) {
+            size_t kmer_rank = kmer_ranks[ki];
+            if(prev_kmer_rank != kmer_rank) {                  /* hmm_state 'M' */
+                raw_events[n] = event_mean[event_idx];
+                level_means[n] = m->level_mean[kmer_rank];
+                level_stdvs[n] = m->level_stdv[kmer_rank];
+                n++;
+            }
+            prev_kmer_rank = kmer_rank;
+        }
+    }
+    int recalibrated = 0;
+    if(n >= 200) {                                             /* minNumEventsToRescale */
+        double A[4] = {0., 0., 0., 0.}, b[2] = {0., 0.};
+        for(size_t i = 0; i < n; i++) {
+            double inv_var = 1. / (level_stdvs[i] * level_stdvs[i]);
+            double mu = level_means[i];
+            double e = raw_events[i];
+            A[0] += inv_var; A[1] += mu * inv_var;
+            A[3] += mu * mu * inv_var;
+            b[0] += e * inv_var;
+            b[1] += mu * e * inv_var;
+        }
+        A[2] = A[1];
+        double x[2];
+        eigen_fullpivlu_solve_2x2(A, b, x);
+        double shift = x[0], scale = x[1];
+        double var = 0.;
+        for(size_t i = 0; i < n; i++) {
+            double yi = (raw_events[i] - shift - scale * level_means[i]);
+            var += yi * yi / (level_stdvs[i] * level_stdvs[i]);
+        }
+        var /= n;
+        var = sqrt(var);
+        *shift_out = shift; *scale_out = scale; *var_out = var;
+        recalibrated = 1;
+    }
+    free(raw_events); free(level_means); free(level_stdvs);
+    return recalibrated;
+}

@@ -200,6 +200,14 @@ class Oracle:
                                            _p(start, c_i32p), _p(stop, c_i32p), C.byref(epb))
         return start, stop, epb.value
 
+    def recalibrate(self, model, events, ranks, map_start, map_stop):
+        events = np.ascontiguousarray(events, np.float32); ranks = np.ascontiguousarray(ranks, np.uint32)
+        ms = np.ascontiguousarray(map_start, np.int32); mp = np.ascontiguousarray(map_stop, np.int32)
+        sh = C.c_double(); sc = C.c_double(); va = C.c_double()
+        ok = self.L.npo_recalibrate(C.byref(model), _p(events, c_f32p), _p(ranks, c_u32p), C.c_uint32(len(ranks)),
+                                    _p(ms, c_i32p), _p(mp, c_i32p), C.byref(sh), C.byref(sc), C.byref(va))
+        return (sh.value, sc.value, va.value) if ok else None
+
     def get_closest_event_to(self, start, k_idx):
         start = np.ascontiguousarray(start, np.int32)
         return self.L.npo_get_closest_event_to(_p(start, c_i32p), len(start), int(k_idx))

@@ -61,22 +61,32 @@ def eventalign_segments(orc, read, pairs, stride_bp=100):
     return epb, segs
 
 
-def call_methylation_read(orc, mn, mc, read):
+def call_methylation_read(orc, mn, mc, read, calibrate=False):
     """The reference's per-read pass on the oracle: MoM scalings -> adaptive_banded_simple_event_align ->
-    base_to_event_map -> work items -> profile_hmm_score(unmethylated), profile_hmm_score(methylated).
-    mn / mc: oracle model handles (nucleotide / cpg)."""
+    base_to_event_map -> [calibrate: recalibrate_model, squiggle_read.cpp:304-323] -> work items ->
+    profile_hmm_score(unmethylated), profile_hmm_score(methylated).
+    mn / mc: oracle model handles (nucleotide / cpg).  calibrate=False scores with the read's given scalings."""
     sh, sc = orc.estimate_scalings_mom(mn, read["ranks"], read["events"])
     pairs = orc.event_align(mn, orc.scalings(sh, sc, 1.0), read["events"], read["ranks"])
     out = dict(mom=(sh, sc), pairs=pairs, epb=0.0, first=np.zeros(0, np.int64), unmeth=np.zeros(0, np.float32),
-               meth=np.zeros(0, np.float32), jobs=[])
+               meth=np.zeros(0, np.float32), jobs=[], calibrated=False, scalings=None)
     if pairs is None or len(pairs) == 0:
         return out
     epb, jobs = methylation_jobs(orc, read, pairs)
     out["epb"] = epb; out["jobs"] = jobs
+    cal = (read["shift"], read["scale"], read["var"])
+    if calibrate:
+        start, stop, _ = orc.build_base_to_event_map(pairs, len(read["ranks"]))
+        cal = orc.recalibrate(mn, read["events"], read["ranks"], start, stop)
+        if cal is None or cal[2] > 2.5:       # not recalibrated / MIN_CALIBRATION_VAR: events cleared (:320-323)
+            out["scalings"] = cal
+            out["jobs"] = []
+            return out
+    out["calibrated"] = True; out["scalings"] = cal
     if epb > 5.0:          # events-per-base QC, src/nanopolish_squiggle_read.cpp:332
         out["jobs"] = []
         return out
-    S = orc.scalings(read["shift"], read["scale"], read["var"])
+    S = orc.scalings(*cal)
     u, m = [], []
     for j in jobs:
         ru = orc.sequence_kmer_ranks("cpg", j["subseq"], j["rc_subseq"], K, j["rc"])

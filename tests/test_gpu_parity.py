@@ -169,6 +169,50 @@ def test_fused_call_methylation_pass_matches_oracle(ctx, orc, models):
     assert n_checked > 1000
 
 
+def test_calibrated_pass_matches_oracle(ctx, orc, models):
+    """the pass with recalibrate_model on the device between kernel A and kernel B.
+    shift/scale/var are bit-equal to the restatement (same term order, same 2x2 full-pivot solve); log_var comes from
+    the device's log() and may differ from libm's by one ulp (tolerance below); scores are compared bit for bit.
+    Read 84 has too few events to calibrate (< 200 'M' entries) and must be skipped whole."""
+    from cases import call_methylation_read
+    from nanopolish_amd.pipeline import build_host_batch, CallMethylationBatch
+    mn = orc.model(models["nucleotide"]); mc = orc.model(models["cpg"])
+    hb = build_host_batch(models, list(range(72, 84)), L=2000)
+    short = build_host_batch(models, [84], L=150)
+    # append the short read by hand: simplest is a second batch
+    n_scored = 0
+    for h in (hb, short):
+        batch = CallMethylationBatch(ctx, h, "cuda:0", calibrate=True)
+        batch.step(); batch.step()
+        scores = batch.scores(); rds = batch.reads_scored(); cal = batch.calibrated()
+        ms, mp = batch.event_map()
+        g0 = 0
+        for i, rd in enumerate(h["reads"]):
+            want = call_methylation_read(orc, mn, mc, rd, calibrate=True)
+            assert np.array_equal(batch.pairs_of(i), want["pairs"])
+            lo, hi = int(h["rank_off"][i]), int(h["rank_off"][i + 1])
+            ws, wp, _ = orc.build_base_to_event_map(want["pairs"], hi - lo)
+            assert np.array_equal(ms[lo:hi], ws) and np.array_equal(mp[lo:hi], wp)
+            assert bool(cal[i]) == want["calibrated"]
+            firsts = list(h["meta"][i]["first"])
+            if want["scalings"] is not None:
+                sh, sc, va = want["scalings"]
+                assert rds["shift"][i] == sh and rds["scale"][i] == sc and rds["var"][i] == va
+                assert abs(rds["log_var"][i] - np.log(va)) <= np.spacing(abs(np.log(va)))
+            scored = set()
+            for f, u, m in zip(want["first"], want["unmeth"], want["meth"]):
+                g = g0 + firsts.index(f)
+                assert scores[2 * g] == u and scores[2 * g + 1] == m
+                scored.add(firsts.index(f)); n_scored += 1
+            for q in range(len(firsts)):
+                if q not in scored:
+                    assert np.isnan(scores[2 * (g0 + q)])
+            g0 += len(firsts)
+        if h is short:
+            assert not cal[0]
+    assert n_scored > 500
+
+
 def test_hmm_score_set_matches_golden(ctx, models):
     import os
     from nanopolish_amd import api

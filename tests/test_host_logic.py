@@ -110,3 +110,35 @@ def test_fill_read_host_constants(L):
     assert r.lp_step == math.log(1.0 - math.exp(r.lp_skip) - math.exp(r.lp_stay))
     assert (r.shift, r.scale, r.var, r.log_var) == (1.5, 1.05, 1.2, math.log(1.2))
     assert (r.event_off, r.n_events, r.rank_off, r.n_kmers) == (10, 8000, 20, 5445)
+
+
+def test_oracle_recalibrate_solves_the_weighted_normal_equations(orc, models):
+    """f1 restatement (parity unpinned: methyltrain.cpp needs Eigen, not buildable here): check npo_recalibrate against an
+    independent numpy solve of the same weighted least squares on the same 'M' entries, and that it recovers the
+    planted scalings of a synthetic read; < 200 'M' entries -> not recalibrated."""
+    from cases import synth_read
+    mn = orc.model(models["nucleotide"])
+    nuc = models["nucleotide"]
+    rd = synth_read(7, nuc, L=3000)
+    sh, sc = orc.estimate_scalings_mom(mn, rd["ranks"], rd["events"])
+    pairs = orc.event_align(mn, orc.scalings(sh, sc, 1.0), rd["events"], rd["ranks"])
+    start, stop, _ = orc.build_base_to_event_map(pairs, len(rd["ranks"]))
+    got = orc.recalibrate(mn, rd["events"], rd["ranks"], start, stop)
+    assert got is not None
+    # independent: 'M' entries = first event of each k-mer that has events and whose rank differs from the previous such k-mer
+    ks = [k for k in range(len(start)) if start[k] != -1]
+    m_k = [k for q, k in enumerate(ks) if q == 0 or rd["ranks"][k] != rd["ranks"][ks[q - 1]]]
+    mu = nuc["level_mean"][rd["ranks"][m_k]]; sd = nuc["level_stdv"][rd["ranks"][m_k]]
+    e = rd["events"][start[m_k]].astype(np.float64)
+    w = 1.0 / sd ** 2
+    A = np.array([[w.sum(), (mu * w).sum()], [(mu * w).sum(), (mu * mu * w).sum()]])
+    b = np.array([(e * w).sum(), (mu * e * w).sum()])
+    x = np.linalg.solve(A, b)
+    var = np.sqrt((((e - x[0] - x[1] * mu) / sd) ** 2).sum() / len(m_k))
+    assert np.allclose(got, (x[0], x[1], var), rtol=1e-9, atol=1e-9)
+    assert abs(got[1] - rd["scale"]) < 0.05 and abs(got[0] - rd["shift"]) < 3.0
+    short = synth_read(8, nuc, L=150)
+    sh, sc = orc.estimate_scalings_mom(mn, short["ranks"], short["events"])
+    p2 = orc.event_align(mn, orc.scalings(sh, sc, 1.0), short["events"], short["ranks"])
+    s2, t2, _ = orc.build_base_to_event_map(p2, len(short["ranks"]))
+    assert orc.recalibrate(mn, short["events"], short["ranks"], s2, t2) is None
