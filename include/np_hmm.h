@@ -210,6 +210,8 @@ int np_hmm_score_dev(np_ctx* ctx, void* stream, int64_t n_jobs, const np_hmm_job
  *     e_start = get_closest_event_to(kpos_start), e_stop = get_closest_event_to(kpos_stop)
  * and applies the skip rule |e2-e1| <= 10 (src/basemods/nanopolish_basemods.cpp:356): skipped items get
  * the NP_JOB_SKIP flag and score NaN.
+ *   pairs     : what np_event_align_dev wrote (a monotone path that advances one k-mer and/or one event per
+ *               entry -- the event map relies on that to run without atomics)
  *   map_start : int32[sum n_kmers] scratch/output (per read at rank_off)
  *   kpos      : int32[2*n_jobs] read-strand k-mer positions bounding each item
  *   events_per_base : double[n_reads] output */

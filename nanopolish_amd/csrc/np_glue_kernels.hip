@@ -33,12 +33,26 @@ __global__ void __launch_bounds__(64) np_build_map_kernel(int n_reads, np_read_d
     }
     __syncthreads();
     const np_pair* p = pairs + pair_off[ri] + pair_begin[ri];
+    // The path kernel A emits is monotone and moves one k-mer and/or one event per step, so every k-mer's start/stop has
+    // exactly one writer and no atomics are needed.  A pair "records" when its event differs from the previous pair's
+    // (:283).  Of the pairs of one k-mer only the first can fail to record (it shares its event with the previous
+    // k-mer); every later pair of that k-mer advanced the event.  Hence
+    //   start[k] = event of the k-mer's first pair if that records, else of its second pair (if it has one);
+    //   stop[k]  = event of the k-mer's last pair, unless that pair is also its first and does not record.
     for (int i = lane; i < np_; i += 64) {
         const np_pair c = p[i];
-        const int prev_e = i > 0 ? p[i - 1].read_pos : -1;    // prev_event_idx = -1 initially (:281)
-        if (c.read_pos != prev_e) {                            // only the first k-mer an event touches records it
-            atomicMin((unsigned int*)&ms[c.ref_pos], (unsigned int)c.read_pos);   // first (== smallest) wins: elem.start
-            if (mp) atomicMax(&mp[c.ref_pos], c.read_pos);                        // last (== largest) wins:  elem.stop
+        const np_pair a = i > 0 ? p[i - 1] : np_pair{-1, -1};      // prev_event_idx = -1 initially (:281)
+        const bool first_of_k = a.ref_pos != c.ref_pos;
+        const bool records = c.read_pos != a.read_pos;
+        bool is_start = first_of_k && records;
+        if (!first_of_k) {                                          // second pair of k: start if the first did not record
+            const np_pair b = i > 1 ? p[i - 2] : np_pair{-1, -1};
+            is_start = b.ref_pos != c.ref_pos && a.read_pos == b.read_pos;
+        }
+        if (is_start) ms[c.ref_pos] = c.read_pos;
+        if (mp) {
+            const bool last_of_k = i + 1 >= np_ || p[i + 1].ref_pos != c.ref_pos;
+            if (last_of_k && (records || !first_of_k)) mp[c.ref_pos] = c.read_pos;
         }
     }
     if (lane == 0) {
@@ -56,7 +70,8 @@ __global__ void __launch_bounds__(64) np_build_map_kernel(int n_reads, np_read_d
 // Each k-mer that has events contributes exactly one candidate 'M' entry -- its first event -- and it is 'M' iff
 // its rank differs from the rank of the previous k-mer that has events (all events of one k-mer share its rank, so
 // later events of the run are 'E').  The five normal-equation sums and the residual sum are accumulated in the
-// reference's order (ascending k-mer): lanes form the terms 64 at a time, a v_readlane loop adds them in lane order.
+// reference's order (ascending k-mer): lanes form the terms 64 at a time, stage them in LDS, and one lane per sum adds
+// its row front to back.
 // The 2x2 solve restates Eigen's FullPivLU (see oracle/np_oracle.c:eigen_fullpivlu_solve_2x2).
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double readlane_f64(double v, int l)
@@ -107,8 +122,9 @@ __global__ void __launch_bounds__(64) np_recalibrate_kernel(int n_reads, np_read
     const uint16_t* rk = ranks + rd->rank_off;
     const float* ev = event_mean + rd->event_off;
 
+    __shared__ double terms[5][66];                              // row stride 66: the five readers hit distinct banks
     double shift = 0.0, scale = 0.0;
-    double a00 = 0., a01 = 0., a11 = 0., b0 = 0., b1 = 0., var = 0.;
+    double acc = 0.0;                                            // lane 0..4: a00, a01, a11, b0, b1; then lane 0: var
     long long n = 0;
     for (int pass = 0; pass < 2; ++pass) {
         int carry_rank = -1;                                     // prev_kmer_rank = -1 (squiggle_read.cpp:351)
@@ -134,25 +150,32 @@ __global__ void __launch_bounds__(64) np_recalibrate_kernel(int n_reads, np_read
                     t0 = yi * yi / (ls * ls);
                 }
             }
-            const unsigned long long mm = __ballot(isM);
-            if (mm) {
-                if (pass == 0) {
-                    for (int q = 0; q < 64; ++q) {                // ascending k-mer order == the reference's loop order
-                        a00 += readlane_f64(t0, q); a01 += readlane_f64(t1, q); a11 += readlane_f64(t2, q);
-                        b0 += readlane_f64(t3, q); b1 += readlane_f64(t4, q);
-                    }
-                    n += __popcll(mm);
-                } else {
-                    for (int q = 0; q < 64; ++q) var += readlane_f64(t0, q);
+            // ordered accumulation: the terms go through LDS, lane c (0..4) owns sum c and adds its 64 terms in k-mer order
+            // (a zero term leaves a non-negative-zero sum unchanged, so lanes that are not 'M' entries need no masking)
+            if (__ballot(isM)) {
+                __syncthreads();
+                terms[0][lane] = t0;
+                if (pass == 0) { terms[1][lane] = t1; terms[2][lane] = t2; terms[3][lane] = t3; terms[4][lane] = t4; }
+                __syncthreads();
+                if (lane < (pass == 0 ? 5 : 1)) {
+                    const double* row = terms[lane];
+#pragma unroll 16
+                    for (int q = 0; q < 64; ++q) acc += row[q];
                 }
+                n += __popcll(__ballot(isM));
             }
             if (hm) carry_rank = __shfl(rank, 63 - __clzll((long long)hm), 64);
         }
         if (pass == 0) {
             if (n < 200) { if (lane == 0) calibrated[ri] = 0; return; }      // minNumEventsToRescale: not recalibrated
+            const double a00 = readlane_f64(acc, 0), a01 = readlane_f64(acc, 1), a11 = readlane_f64(acc, 2);
+            const double b0 = readlane_f64(acc, 3), b1 = readlane_f64(acc, 4);
             fullpivlu_solve_2x2(a00, a01, a01, a11, b0, b1, shift, scale);
+            n = 0;
+            acc = 0.0;
         }
     }
+    double var = readlane_f64(acc, 0);
     var /= (double)(unsigned long long)n;
     var = sqrt(var);
     if (lane == 0) {
