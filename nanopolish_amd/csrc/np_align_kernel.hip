@@ -67,30 +67,35 @@ __device__ __forceinline__ np_gauss as_gauss(const float4 v)
     return g;
 }
 
-struct cell_out { float v; uint32_t from; };
+typedef float f2 __attribute__((ext_vector_type(2)));
 
-// DP cell (raw_loader.cpp:240-289), computed unconditionally and masked by `valid`.
-__device__ __forceinline__ cell_out dp_cell(bool valid, float x, const float4 gp, float up, float left, float diag,
-                                            double lp_skip, double lp_stay, double lp_step)
+// Range-checked loads through buffer descriptors: an offset outside [0, bytes) -- negative included, it wraps to a
+// huge unsigned -- returns 0 instead of faulting, so neither the event-mean prefetch nor the parameter refill needs
+// a clamp.  Whatever an out-of-range load returns only ever feeds a masked cell.
+// (the operands go through readfirstlane: they are wave-uniform but may sit in VGPRs, and a descriptor the compiler
+//  cannot prove scalar costs a waterfall loop per load)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes)
 {
-    const float em = np_emission(x, as_gauss(gp));
-    const float score_d = (float)((double)diag + lp_step + (double)em);
-    const float score_u = (float)((double)up + lp_stay + (double)em);
-    const float score_l = (float)((double)left + lp_skip);
-    float mx = score_d; uint32_t from = 0;                                   // FROM_D
-    mx = score_u > mx ? score_u : mx; from = (mx == score_u) ? 1u : from;   // FROM_U
-    mx = score_l > mx ? score_l : mx; from = (mx == score_l) ? 2u : from;   // FROM_L
-    cell_out o;
-    o.v = valid ? mx : NP_NEG_INF;
-    o.from = valid ? from : 0u;
-    return o;
+    const uint64_t u = (uint64_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    void* q = (void*)(((uint64_t)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+__device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, int off)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ float4 buf_f32x4(__amdgpu_buffer_rsrc_t r, int off)
+{
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
 
 // Everything the fill carries from band to band.
 struct fill_t {
     int llk;                // band_lower_left[b].kmer_idx (wave-uniform)
-    int k0, k1;             // k-mer mapped to this lane's two ring slots
-    float4 g0, g1;          // their scaled Gaussians (mean, stdv, cl, 1/stdv)
+    int kb0, kb1;           // 4 * (k-mer mapped to this lane's two ring slots)
+    f2 gm, gs, gc, gr;      // their scaled Gaussians: mean, stdv, log-constant, 1/stdv, as (slot, slot + 64) pairs
     float4 n0, n1;          // the records of k0+128 / k1+128, requested when the slot was last re-targeted
     float p0, p1;           // band b-1
     float d0, d1;           // band b-2 rotated by one slot
@@ -100,102 +105,153 @@ struct fill_t {
 
 struct read_t {
     int E, K, lane, end_slot;
-    const float* __restrict__ ev;
-    const float4* __restrict__ kp;
+    __amdgpu_buffer_rsrc_t ev;      // event means of the read, E * 4 bytes
+    __amdgpu_buffer_rsrc_t kp;      // this wave's k-mer parameter slab, K * 16 bytes
     uint32_t* __restrict__ trace32;
     double lp_skip, lp_stay, lp_step, lp_trim;
 };
 
-// One band.  (xc0, xc1): event means of this band's cells (loaded during the previous band);
-// (xl0, xl1): receive the loads for the next band.
-__device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int b, const float xc0, const float xc1,
-                                          float& xl0, float& xl1)
+// bit pattern of ring slot s (uniform) of a band held as (r0 = slots 0..63, r1 = slots 64..127); all scalar
+__device__ __forceinline__ int ring_read_bits(float r0, float r1, int s)
+{
+    int a = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r0), s & 63);
+    int b = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r1), s & 63);
+    asm("" : "+s"(a)); asm("" : "+s"(b));
+    return (s & 64) ? b : a;
+}
+// total order of non-NaN floats on their bit patterns (so that the move rule stays on the scalar unit, which has no
+// float compare on this ISA).  -0.0 would order below +0.0; band scores are sums of log-probabilities and the
+// origin's +0.0, never -0.0.
+// keeps a wave-uniform value in a scalar register, so that what is computed from it is selected onto the scalar unit
+__device__ __forceinline__ int pin_s(int x) { asm("" : "+s"(x)); return x; }
+// wave_ror:1 where every lane has a source lane, so the destination's previous content needs no initialisation
+__device__ __forceinline__ float wave_ror1_all(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x13C, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int float_order_key(int bits) { return bits ^ ((bits >> 31) & 0x7fffffff); }
+
+// One band.  xc: event means of this band's two cells (loaded during the previous band); xl receives the loads for
+// the next band.  TRIM: the window may still contain k-mer -1.  END: the window may contain k-mer K-1.
+template <bool TRIM, bool END>
+__device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int b, const f2 xc, f2& xl)
 {
     const int lane = R.lane, E = R.E, K = R.K;
-    if (b >= 2) {
-        // Suzuki's rule on band b-1 (:179-195)
-        const float ll = ring_read(F.p0, F.p1, F.llk & (NP_RING - 1));
-        const float ur = ring_read(F.p0, F.p1, (F.llk + NP_ALN_BANDWIDTH - 1) & (NP_RING - 1));
-        const bool ll_ob = ll == NP_NEG_INF, ur_ob = ur == NP_NEG_INF;
-        const bool right = (ll_ob && ur_ob) ? ((b & 1) == 1) : (ll < ur);
-        if (right) {
-            F.llk += 1;
-            // the slot that fell 14 behind the window takes its next k-mer (k+128), whose record was requested the
-            // last time the slot moved, and requests the one after that
-            // (branch-free on purpose: every lane re-requests its `next` record on every right move -- an L1 hit for all
-            //  but the re-targeted slot -- so that no load sits inside a divergent branch, where hipcc would wait for it
-            //  immediately; the record consumed here was requested at least one band ago)
-            // Exactly one ring slot falls out per right move: slot (llk - 15) mod 128, i.e. one lane of ONE of the two
-            // slot registers -- which one is wave-uniform, so only that register is touched.
-            if (((F.llk - NP_MARGIN - 1) & 64) == 0) {
-                const bool t0 = F.k0 < F.llk - NP_MARGIN;
-                F.g0.x = t0 ? F.n0.x : F.g0.x; F.g0.y = t0 ? F.n0.y : F.g0.y; F.g0.z = t0 ? F.n0.z : F.g0.z; F.g0.w = t0 ? F.n0.w : F.g0.w;
-                F.k0 += t0 ? NP_RING : 0;
-                F.n0 = load_kp(R.kp, F.k0 + NP_RING, K);
-            } else {
-                const bool t1 = F.k1 < F.llk - NP_MARGIN;
-                F.g1.x = t1 ? F.n1.x : F.g1.x; F.g1.y = t1 ? F.n1.y : F.g1.y; F.g1.z = t1 ? F.n1.z : F.g1.z; F.g1.w = t1 ? F.n1.w : F.g1.w;
-                F.k1 += t1 ? NP_RING : 0;
-                F.n1 = load_kp(R.kp, F.k1 + NP_RING, K);
-            }
-        }
-    }
     const int llk = F.llk;
     // left sources: band b-1 rotated by one slot
-    const float r0 = np_wave_ror1(F.p0), r1 = np_wave_ror1(F.p1);
+    const float r0 = wave_ror1_all(F.p0), r1 = wave_ror1_all(F.p1);
     const float l0 = lane == 0 ? r1 : r0;
     const float l1 = lane == 0 ? r0 : r1;
 
+    // A slot holds a cell of this band iff its k-mer is inside the window and its event e = b-2-k exists, i.e. iff
+    // e is in [max(0, b-2-khi), min(E-1, b-2-klo)]: one unsigned range test on 4*(e+1), the byte offset of the NEXT
+    // band's event mean, which the prefetch needs anyway.
     const int klo = llk > 0 ? llk : 0;
     const int khi = (llk + NP_ALN_BANDWIDTH - 1) < (K - 1) ? (llk + NP_ALN_BANDWIDTH - 1) : (K - 1);
-    const int e0 = b - 2 - F.k0, e1 = b - 2 - F.k1;
-    const bool v0 = F.k0 >= klo && F.k0 <= khi && (unsigned)e0 < (unsigned)E;
-    const bool v1 = F.k1 >= klo && F.k1 <= khi && (unsigned)e1 < (unsigned)E;
-    // prefetch the next band's event means (same k-mer, next event), clamped: always a plain load
-    xl0 = R.ev[(uint32_t)clampi(e0 + 1, 0, E - 1)];
-    xl1 = R.ev[(uint32_t)clampi(e1 + 1, 0, E - 1)];
+    const int elo = (b - 2 - khi) > 0 ? (b - 2 - khi) : 0;
+    const int ehi = (b - 2 - klo) < (E - 1) ? (b - 2 - klo) : (E - 1);
+    const int cnt = ehi - elo + 1 > 0 ? ehi - elo + 1 : 0;
+    const int off0 = 4 * (b - 1) - F.kb0, off1 = 4 * (b - 1) - F.kb1;
+    const int tb = pin_s(4 * (b - 1) - 4 * (elo + 1));           // one scalar, so the test is one subtract + one compare
+    const bool v0 = (uint32_t)(tb - F.kb0) < (uint32_t)(4 * cnt);
+    const bool v1 = (uint32_t)(tb - F.kb1) < (uint32_t)(4 * cnt);
+    xl.x = buf_f32(R.ev, off0);
+    xl.y = buf_f32(R.ev, off1);
 
-    cell_out c0 = dp_cell(v0, xc0, F.g0, F.p0, l0, F.d0, R.lp_skip, R.lp_stay, R.lp_step);
-    cell_out c1 = dp_cell(v1, xc1, F.g1, F.p1, l1, F.d1, R.lp_skip, R.lp_stay, R.lp_step);
+    // emissions of both cells, two floats per instruction (v_pk_*_f32): np_emission / np_div_exact, operation for operation
+    const f2 nn = xc - F.gm;
+    f2 q = nn * F.gr;
+    f2 er = __builtin_elementwise_fma(-F.gs, q, nn);
+    q = __builtin_elementwise_fma(er, F.gr, q);
+    er = __builtin_elementwise_fma(-F.gs, q, nn);
+    q = __builtin_elementwise_fma(er, F.gr, q);
+    const f2 em = F.gc + (-0.5f * q * q);
 
-    if (llk <= -1) {
+    // DP cells (raw_loader.cpp:240-289), computed unconditionally and masked: fp32 cell + fp64 constant + fp32 emission
+    // in fp64, rounded to fp32; max, then FROM_U / FROM_L override on equality in that order (later candidate wins)
+    const double em0 = (double)em.x, em1 = (double)em.y;
+    const float sd0 = (float)((double)F.d0 + R.lp_step + em0), sd1 = (float)((double)F.d1 + R.lp_step + em1);
+    const float su0 = (float)((double)F.p0 + R.lp_stay + em0), su1 = (float)((double)F.p1 + R.lp_stay + em1);
+    const float sl0 = (float)((double)l0 + R.lp_skip), sl1 = (float)((double)l1 + R.lp_skip);
+    const float m0 = __builtin_fmaxf(__builtin_fmaxf(sd0, su0), sl0);
+    const float m1 = __builtin_fmaxf(__builtin_fmaxf(sd1, su1), sl1);
+    // the code of a slot outside the band is never read back: the walk only visits finite cells, whose best
+    // predecessor is finite, hence inside its band
+    uint32_t f0 = (m0 == sl0) ? 2u : ((m0 == su0) ? 1u : 0u);
+    uint32_t f1 = (m1 == sl1) ? 2u : ((m1 == su1) ? 1u : 0u);
+    float c0 = v0 ? m0 : NP_NEG_INF;
+    float c1 = v1 ? m1 : NP_NEG_INF;
+
+    if (TRIM && llk <= -1) {
         // the window still contains k-mer -1: start cell of band 0 (:152-157) and the trim column (:216-225).
         // k = -1 lives in ring slot 127 (lane 63, second register); its event is b - 1.
         const int et = b - 1;
-        if (lane == 63 && F.k1 == -1) {
-            if (et == -1) { c1.v = 0.0f; c1.from = 0u; }
-            else if (et >= 0 && et < E) { c1.v = (float)(R.lp_trim * (double)(et + 1)); c1.from = 1u; }
-            else { c1.v = NP_NEG_INF; c1.from = 0u; }
+        if (lane == 63 && F.kb1 == -4) {
+            if (et == -1) { c1 = 0.0f; f1 = 0u; }
+            else if (et >= 0 && et < E) { c1 = (float)(R.lp_trim * (double)(et + 1)); f1 = 1u; }
+            else { c1 = NP_NEG_INF; f1 = 0u; }
         }
     }
 
     // packed trace: every lane keeps the 2-bit codes of its two slots, 4 bits per band, and stores one dword per
     // 8 bands (64 lanes x 4 B = 256 B coalesced = 32 B/band).  The back-track reads the word back into the SAME lane.
-    F.tacc |= (c0.from | (c1.from << 2)) << ((b & 7) * 4);
+    F.tacc |= (f0 | (f1 << 2)) << ((b & 7) * 4);
     if ((b & 7) == 7) { R.trace32[(size_t)(b >> 3) * 64 + lane] = F.tacc; F.tacc = 0u; }
 
-    if (khi == K - 1 && llk <= K - 1) {
+    if (END && khi == K - 1 && llk <= K - 1) {
         // end search: cell (e, K-1) while it is inside the window, any e in [0,E) (:309-324)
         const bool mine0 = (R.end_slot < 64) && lane == R.end_slot;
         const bool mine1 = (R.end_slot >= 64) && lane == R.end_slot - 64;
         if (mine0 || mine1) {
-            const int k = mine0 ? F.k0 : F.k1;
-            const int e = mine0 ? e0 : e1;
-            const float v = mine0 ? c0.v : c1.v;
-            if (k == K - 1 && e >= 0 && e < E) {
+            const int kb = mine0 ? F.kb0 : F.kb1;
+            const int e = b - 2 - (kb >> 2);
+            const float v = mine0 ? c0 : c1;
+            if (kb == 4 * (K - 1) && e >= 0 && e < E) {
                 const float sc = (float)((double)v + (double)(E - e) * R.lp_trim);
                 if (sc > F.best) { F.best = sc; F.best_e = e; }
             }
         }
     }
     F.d0 = l0; F.d1 = l1;
-    F.p0 = c0.v; F.p1 = c1.v;
+    F.p0 = c0; F.p1 = c1;
+
+    if (b >= 1) {
+        // Suzuki's rule for band b+1, on this band (:179-195).  It sits at the end of the step so that the parameter
+        // request below is the youngest load in flight: the next step only waits for the event means issued above.
+        const int ll = pin_s(ring_read_bits(c0, c1, llk & (NP_RING - 1)));
+        const int ur = pin_s(ring_read_bits(c0, c1, (llk + NP_ALN_BANDWIDTH - 1) & (NP_RING - 1)));
+        const int ninf = (int)0xff800000;
+        const bool right = (ll == ninf && ur == ninf) ? ((b & 1) == 0) : (float_order_key(ll) < float_order_key(ur));
+        if (right) {
+            F.llk = llk + 1;
+            // Exactly one ring slot falls out per right move: slot (llk - 15) mod 128, i.e. one lane of ONE of the two
+            // slot registers -- which one is wave-uniform, so only that register is touched.  The slot takes its next
+            // k-mer (k+128), whose record was requested the last time the slot moved, and requests the one after that.
+            // Every lane of the register re-requests its `next` record (an L1 hit for all but the re-targeted slot), so
+            // that no load sits inside a divergent branch, where hipcc would wait for it on the spot; the record consumed
+            // here was requested 128 right-moves ago.
+            const int lim = 4 * (F.llk - NP_MARGIN);
+            if (((F.llk - NP_MARGIN - 1) & 64) == 0) {
+                const bool t = F.kb0 < lim;
+                F.gm.x = t ? F.n0.x : F.gm.x; F.gs.x = t ? F.n0.y : F.gs.x; F.gc.x = t ? F.n0.z : F.gc.x; F.gr.x = t ? F.n0.w : F.gr.x;
+                F.kb0 += t ? 4 * NP_RING : 0;
+                F.n0 = buf_f32x4(R.kp, F.kb0 * 4 + 16 * NP_RING);
+            } else {
+                const bool t = F.kb1 < lim;
+                F.gm.y = t ? F.n1.x : F.gm.y; F.gs.y = t ? F.n1.y : F.gs.y; F.gc.y = t ? F.n1.z : F.gc.y; F.gr.y = t ? F.n1.w : F.gr.y;
+                F.kb1 += t ? 4 * NP_RING : 0;
+                F.n1 = buf_f32x4(R.kp, F.kb1 * 4 + 16 * NP_RING);
+            }
+        }
+    }
 }
 
 __global__ void __launch_bounds__(NP_ALIGN_BLOCK, 7) np_event_align_kernel(np_align_args a)
 {
     const int lane = threadIdx.x & 63;
-    const int wave_slot = blockIdx.x * (NP_ALIGN_BLOCK / 64) + (threadIdx.x >> 6);
+    // readfirstlane: tells the compiler the value is wave-uniform, so pointers derived from it stay in SGPRs (buffer
+    // descriptors must be scalar; a VGPR descriptor costs a waterfall loop per load)
+    const int wave_slot = __builtin_amdgcn_readfirstlane(blockIdx.x * (NP_ALIGN_BLOCK / 64) + (threadIdx.x >> 6));
     uint64_t* __restrict__ trace = a.trace + (size_t)wave_slot * a.trace_stride;
     float4* __restrict__ kp = a.kparams + (size_t)wave_slot * a.kp_stride;     // per-wave slab of scaled k-mer parameters
 
@@ -232,22 +288,37 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, 7) np_event_align_kernel(np_al
             // ---------------- fill ----------------
             read_t R;
             R.E = E; R.K = K; R.lane = lane; R.end_slot = (K - 1) & (NP_RING - 1);
-            R.ev = ev; R.kp = kp; R.trace32 = (uint32_t*)trace;
+            R.ev = make_rsrc(ev, (uint32_t)E * 4u); R.kp = make_rsrc(kp, (uint32_t)K * 16u); R.trace32 = (uint32_t*)trace;
             R.lp_skip = rd->lp_skip; R.lp_stay = rd->lp_stay; R.lp_step = rd->lp_step; R.lp_trim = rd->lp_trim;
             fill_t F;
             F.llk = -1 - NP_ALN_BANDWIDTH / 2;              // band_lower_left[0].kmer_idx, raw_loader.cpp:150-151
-            F.k0 = ring_kmer(lane, F.llk); F.k1 = ring_kmer(lane + 64, F.llk);
-            F.g0 = load_kp(kp, F.k0, K); F.g1 = load_kp(kp, F.k1, K);
-            F.n0 = load_kp(kp, F.k0 + NP_RING, K); F.n1 = load_kp(kp, F.k1 + NP_RING, K);
+            {
+                const int k0 = ring_kmer(lane, F.llk), k1 = ring_kmer(lane + 64, F.llk);
+                F.kb0 = 4 * k0; F.kb1 = 4 * k1;
+                const float4 g0 = buf_f32x4(R.kp, 16 * k0), g1 = buf_f32x4(R.kp, 16 * k1);
+                F.gm = f2{g0.x, g1.x}; F.gs = f2{g0.y, g1.y}; F.gc = f2{g0.z, g1.z}; F.gr = f2{g0.w, g1.w};
+                F.n0 = buf_f32x4(R.kp, 16 * (k0 + NP_RING)); F.n1 = buf_f32x4(R.kp, 16 * (k1 + NP_RING));
+            }
             F.p0 = F.p1 = F.d0 = F.d1 = NP_NEG_INF;
             F.best = NP_NEG_INF; F.best_e = 0; F.tacc = 0u;
-            float xa0 = 0.0f, xa1 = 0.0f, xb0 = 0.0f, xb1 = 0.0f;      // ping-pong event-mean registers
+            f2 xa = {0.0f, 0.0f}, xb = {0.0f, 0.0f};                   // ping-pong event-mean registers
             int b = 0;
-            for (; b + 1 < n_bands; b += 2) {
-                band_step(F, R, b, xa0, xa1, xb0, xb1);
-                band_step(F, R, b + 1, xb0, xb1, xa0, xa1);
+            // three phases, so that the trim column and the end search cost nothing in the long middle of the read:
+            // the window only ever moves right, it contains k-mer -1 while llk <= -1 and reaches k-mer K-1 once
+            // llk + 99 >= K-1 (a pair of bands moves llk by at most 2)
+            for (; b + 1 < n_bands && F.llk <= -1; b += 2) {
+                band_step<true, true>(F, R, b, xa, xb);
+                band_step<true, true>(F, R, b + 1, xb, xa);
             }
-            if (b < n_bands) band_step(F, R, b, xa0, xa1, xb0, xb1);
+            for (; b + 1 < n_bands && F.llk + NP_ALN_BANDWIDTH + 1 < K - 1; b += 2) {
+                band_step<false, false>(F, R, b, xa, xb);
+                band_step<false, false>(F, R, b + 1, xb, xa);
+            }
+            for (; b + 1 < n_bands; b += 2) {
+                band_step<true, true>(F, R, b, xa, xb);
+                band_step<true, true>(F, R, b + 1, xb, xa);
+            }
+            if (b < n_bands) band_step<true, true>(F, R, b, xa, xb);
             if ((n_bands & 7) != 0) R.trace32[(size_t)((n_bands - 1) >> 3) * 64 + lane] = F.tacc;      // last, partial group
 
             // ---------------- backtrack (:326-361) + QC sums (:338-341) ----------------
