@@ -13,12 +13,19 @@
 //   * Prologue per read: the scaled Gaussian of every k-mer (fp64 math of squiggle_read.h:217-226, plus the
 //     correctly rounded reciprocal of sigma) goes into a per-wave slab, 16 B per k-mer; the band loop then only
 //     does fp32 emissions and the reference's fp64 candidate sums.
-//   * The inner step is branch-free per lane: DP cells are computed by every lane and masked; the trim column
-//     (k-mer -1) and the end-cell search only exist while the window touches k = -1 / k = K-1 and sit behind
-//     wave-uniform branches.  Event means are prefetched one band ahead into ping-pong registers (the band loop is
-//     unrolled by two so no register rotation -- and therefore no early s_waitcnt -- is needed).  A ring slot always
-//     holds the parameters of its next k-mer (k+128) in `pend`, requested when the slot is re-targeted and consumed
-//     128 right-moves later.
+//   * The inner step is branch-free per lane: DP cells are computed by every lane and masked.  The band loop runs in
+//     three phases: a generic step (band geometry, trim column k = -1, end-cell search) for the first and last ~300
+//     bands, and a FAST step for the middle of the read, where every cell of the 100-wide window exists, so validity
+//     is a pair of wave-uniform lane masks that only change on a right move.
+//   * Event means are prefetched one band ahead straight into the loop-carried register (the load is issued after
+//     the emission has consumed the old value), through a range-checked buffer descriptor: out-of-range events read
+//     as 0 and only feed masked cells, so there is no clamp.  A ring slot always holds the parameters of its next
+//     k-mer (k+128) in `n0/n1`, requested when the slot is re-targeted and consumed 128 right-moves later; the
+//     re-target itself is five v_mov under a one-lane exec mask.
+//   * Issue-cycle budget (tools/valu_rates.hip, measured on MI355X): fp32 add/fma/mov/int add issue in ~2 cycles per
+//     wave, fp64 ops, conversions, v_cmp, v_cndmask (VOP3), DPP, v_readlane and 3-operand integer ops in ~4, and the
+//     scalar unit also sustains one instruction per ~4 cycles per SIMD -- so scalar band bookkeeping is as expensive
+//     as vector work and is kept out of the FAST step.  Back-to-back VOP2 v_cndmask (implicit VCC) issue at ~20.
 //   * Candidates are evaluated as the reference does: fp32 cell + fp64 transition constant + fp32 emission in
 //     fp64, rounded to fp32, compared in fp32, later candidate wins ties (raw_loader.cpp:259-274).
 //   * The trace is 2 bits per cell: each lane packs the codes of its two slots, 4 bits per band, and stores one dword per
@@ -33,6 +40,7 @@
 #define NP_ALIGN_BLOCK 256
 #define NP_RING 128
 #define NP_MARGIN 14   // (128 - 100) / 2
+
 
 namespace {
 
@@ -67,8 +75,6 @@ __device__ __forceinline__ np_gauss as_gauss(const float4 v)
     return g;
 }
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-
 // Range-checked loads through buffer descriptors: an offset outside [0, bytes) -- negative included, it wraps to a
 // huge unsigned -- returns 0 instead of faulting, so neither the event-mean prefetch nor the parameter refill needs
 // a clamp.  Whatever an out-of-range load returns only ever feeds a masked cell.
@@ -82,25 +88,45 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint3
     void* q = (void*)(((uint64_t)hi << 32) | lo);
     return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+template <class T> __device__ __forceinline__ T* uniform_ptr(T* p)
+{
+    const uint64_t u = (uint64_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    return (T*)(((uint64_t)hi << 32) | lo);
+}
+// The byte offset goes to the instruction as ONE register: the compiler would otherwise split `x + c` into a register
+// part and the instruction's immediate offset, and the hardware range-checks their sum without 32-bit wrap-around --
+// a negative register part with a positive immediate (true offset in range) would then read as 0.
+__device__ __forceinline__ int whole_offset(int off) { asm("" : "+v"(off)); return off; }
 __device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, int off)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, whole_offset(off), 0, 0));
 }
 __device__ __forceinline__ float4 buf_f32x4(__amdgpu_buffer_rsrc_t r, int off)
 {
-    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, whole_offset(off), 0, 0));
 }
 
 // Everything the fill carries from band to band.
 struct fill_t {
     int llk;                // band_lower_left[b].kmer_idx (wave-uniform)
     int kb0, kb1;           // 4 * (k-mer mapped to this lane's two ring slots)
-    f2 gm, gs, gc, gr;      // their scaled Gaussians: mean, stdv, log-constant, 1/stdv, as (slot, slot + 64) pairs
+    float g0m, g0s, g0c, g0r;   // scaled Gaussian of slot l: mean, stdv, log-constant, 1/stdv (scalars, so that a
+    float g1m, g1s, g1c, g1r;   // re-target can update them in place) -- and of slot l + 64
     float4 n0, n1;          // the records of k0+128 / k1+128, requested when the slot was last re-targeted
     float p0, p1;           // band b-1
     float d0, d1;           // band b-2 rotated by one slot
     float best; int best_e; // end-cell search (:309-324), tracked by the owner of k-mer K-1
-    uint32_t tacc;          // trace codes of the current 8-band group (4 bits per band)
+    uint32_t tacc;          // trace codes of the last (up to) 8 bands, 4 bits per band, newest in the top nibble
+    uint64_t vm0, vm1;      // FAST phase: lanes whose slot (l, l + 64) is inside the window (wave-uniform lane masks)
 };
 
 struct read_t {
@@ -119,9 +145,6 @@ __device__ __forceinline__ int ring_read_bits(float r0, float r1, int s)
     asm("" : "+s"(a)); asm("" : "+s"(b));
     return (s & 64) ? b : a;
 }
-// total order of non-NaN floats on their bit patterns (so that the move rule stays on the scalar unit, which has no
-// float compare on this ISA).  -0.0 would order below +0.0; band scores are sums of log-probabilities and the
-// origin's +0.0, never -0.0.
 // keeps a wave-uniform value in a scalar register, so that what is computed from it is selected onto the scalar unit
 __device__ __forceinline__ int pin_s(int x) { asm("" : "+s"(x)); return x; }
 // wave_ror:1 where every lane has a source lane, so the destination's previous content needs no initialisation
@@ -129,12 +152,46 @@ __device__ __forceinline__ float wave_ror1_all(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x13C, 0xf, 0xf, false));
 }
-__device__ __forceinline__ int float_order_key(int bits) { return bits ^ ((bits >> 31) & 0x7fffffff); }
+// t where the lane's bit of the (wave-uniform) mask m is set, else f: one v_cndmask_b32_e64 on an SGPR pair
+__device__ __forceinline__ float sel_mask(uint64_t m, float t, float f)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+    return r;
+}
+// lanes of slot register `half` (0: slots 0..63, 1: slots 64..127) whose slot is inside the window [llk, llk+99]
+__device__ __forceinline__ uint64_t window_mask(int lane, int half, int llk)
+{
+    return __builtin_amdgcn_ballot_w64((uint32_t)((lane + 64 * half - llk) & (NP_RING - 1)) < (uint32_t)NP_ALN_BANDWIDTH);
+}
 
-// One band.  xc: event means of this band's two cells (loaded during the previous band); xl receives the loads for
-// the next band.  TRIM: the window may still contain k-mer -1.  END: the window may contain k-mer K-1.
-template <bool TRIM, bool END>
-__device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int b, const f2 xc, f2& xl)
+// The lane selected by m0 (slot register 0) or m1 (slot register 1) -- one of the two masks is empty -- takes over its
+// pending record and moves on by 128 k-mers.  Plain v_mov under a one-lane exec mask: straight-line code that updates
+// the registers in place (selects cost twice the issue cycles, and a branch per register costs the compiler's copies).
+__device__ __forceinline__ void retarget(fill_t& F, uint64_t m0, uint64_t m1)
+{
+    uint64_t save;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "s_mov_b64 exec, %[m0]\n\t"
+                 "v_mov_b32 %[a0], %[x0]\n\tv_mov_b32 %[a1], %[x1]\n\tv_mov_b32 %[a2], %[x2]\n\tv_mov_b32 %[a3], %[x3]\n\t"
+                 "v_add_u32 %[k0], 0x200, %[k0]\n\t"
+                 "s_mov_b64 exec, %[m1]\n\t"
+                 "v_mov_b32 %[b0], %[y0]\n\tv_mov_b32 %[b1], %[y1]\n\tv_mov_b32 %[b2], %[y2]\n\tv_mov_b32 %[b3], %[y3]\n\t"
+                 "v_add_u32 %[k1], 0x200, %[k1]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(save), [a0] "+v"(F.g0m), [a1] "+v"(F.g0s), [a2] "+v"(F.g0c), [a3] "+v"(F.g0r), [k0] "+v"(F.kb0),
+                   [b0] "+v"(F.g1m), [b1] "+v"(F.g1s), [b2] "+v"(F.g1c), [b3] "+v"(F.g1r), [k1] "+v"(F.kb1)
+                 : [m0] "s"(m0), [m1] "s"(m1), [x0] "v"(F.n0.x), [x1] "v"(F.n0.y), [x2] "v"(F.n0.z), [x3] "v"(F.n0.w),
+                   [y0] "v"(F.n1.x), [y1] "v"(F.n1.y), [y2] "v"(F.n1.z), [y3] "v"(F.n1.w));
+}
+
+// One band.  (x0, x1): event means of this band's two cells on entry (loaded during the previous band), of the next
+// band's on exit.  TRIM: the window may still contain k-mer -1.  END: the window may contain k-mer K-1.
+// FAST: the middle of the read -- every cell of the window [llk, llk+99] exists (0 <= llk, llk+99 < K-1, and the events
+// of the window's first and last k-mer are inside [0, E)), so a slot is valid iff it is inside the window, which only
+// changes on a right move: the lane masks F.vm0/F.vm1 replace the per-band geometry.
+template <bool TRIM, bool END, bool FAST>
+__device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int b, float& x0, float& x1)
 {
     const int lane = R.lane, E = R.E, K = R.K;
     const int llk = F.llk;
@@ -148,28 +205,29 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
     // band's event mean, which the prefetch needs anyway.
     const int klo = llk > 0 ? llk : 0;
     const int khi = (llk + NP_ALN_BANDWIDTH - 1) < (K - 1) ? (llk + NP_ALN_BANDWIDTH - 1) : (K - 1);
-    const int elo = (b - 2 - khi) > 0 ? (b - 2 - khi) : 0;
-    const int ehi = (b - 2 - klo) < (E - 1) ? (b - 2 - klo) : (E - 1);
-    const int cnt = ehi - elo + 1 > 0 ? ehi - elo + 1 : 0;
     const int off0 = 4 * (b - 1) - F.kb0, off1 = 4 * (b - 1) - F.kb1;
-    const int tb = pin_s(4 * (b - 1) - 4 * (elo + 1));           // one scalar, so the test is one subtract + one compare
-    const bool v0 = (uint32_t)(tb - F.kb0) < (uint32_t)(4 * cnt);
-    const bool v1 = (uint32_t)(tb - F.kb1) < (uint32_t)(4 * cnt);
-    xl.x = buf_f32(R.ev, off0);
-    xl.y = buf_f32(R.ev, off1);
+    bool v0 = false, v1 = false;
+    if (!FAST) {
+        const int elo = (b - 2 - khi) > 0 ? (b - 2 - khi) : 0;
+        const int ehi = (b - 2 - klo) < (E - 1) ? (b - 2 - klo) : (E - 1);
+        const int cnt = ehi - elo + 1 > 0 ? ehi - elo + 1 : 0;
+        const int tb = pin_s(4 * (b - 1) - 4 * (elo + 1));       // one scalar, so the test is one subtract + one compare
+        v0 = (uint32_t)(tb - F.kb0) < (uint32_t)(4 * cnt);
+        v1 = (uint32_t)(tb - F.kb1) < (uint32_t)(4 * cnt);
+    }
 
-    // emissions of both cells, two floats per instruction (v_pk_*_f32): np_emission / np_div_exact, operation for operation
-    const f2 nn = xc - F.gm;
-    f2 q = nn * F.gr;
-    f2 er = __builtin_elementwise_fma(-F.gs, q, nn);
-    q = __builtin_elementwise_fma(er, F.gr, q);
-    er = __builtin_elementwise_fma(-F.gs, q, nn);
-    q = __builtin_elementwise_fma(er, F.gr, q);
-    const f2 em = F.gc + (-0.5f * q * q);
+    // emissions of both cells: np_emission / np_div_exact, operation for operation (v_pk_*_f32 would halve the
+    // instruction count but not the issue cycles -- tools/valu_rates.hip -- and forces the parameters into register pairs)
+    const float emx = np_emission(x0, np_gauss{F.g0m, F.g0s, F.g0c, F.g0r});
+    const float emy = np_emission(x1, np_gauss{F.g1m, F.g1s, F.g1c, F.g1r});
+    // the next band's event means (same k-mer, next event) go into the registers the emissions have just released: the
+    // loop-carried value is the load's own destination, so nothing is copied (a copy would have to wait for the load)
+    x0 = buf_f32(R.ev, off0);
+    x1 = buf_f32(R.ev, off1);
 
     // DP cells (raw_loader.cpp:240-289), computed unconditionally and masked: fp32 cell + fp64 constant + fp32 emission
     // in fp64, rounded to fp32; max, then FROM_U / FROM_L override on equality in that order (later candidate wins)
-    const double em0 = (double)em.x, em1 = (double)em.y;
+    const double em0 = (double)emx, em1 = (double)emy;
     const float sd0 = (float)((double)F.d0 + R.lp_step + em0), sd1 = (float)((double)F.d1 + R.lp_step + em1);
     const float su0 = (float)((double)F.p0 + R.lp_stay + em0), su1 = (float)((double)F.p1 + R.lp_stay + em1);
     const float sl0 = (float)((double)l0 + R.lp_skip), sl1 = (float)((double)l1 + R.lp_skip);
@@ -179,8 +237,9 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
     // predecessor is finite, hence inside its band
     uint32_t f0 = (m0 == sl0) ? 2u : ((m0 == su0) ? 1u : 0u);
     uint32_t f1 = (m1 == sl1) ? 2u : ((m1 == su1) ? 1u : 0u);
-    float c0 = v0 ? m0 : NP_NEG_INF;
-    float c1 = v1 ? m1 : NP_NEG_INF;
+    float c0, c1;
+    if (FAST) { c0 = sel_mask(F.vm0, m0, NP_NEG_INF); c1 = sel_mask(F.vm1, m1, NP_NEG_INF); }
+    else { c0 = v0 ? m0 : NP_NEG_INF; c1 = v1 ? m1 : NP_NEG_INF; }
 
     if (TRIM && llk <= -1) {
         // the window still contains k-mer -1: start cell of band 0 (:152-157) and the trim column (:216-225).
@@ -195,8 +254,9 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
 
     // packed trace: every lane keeps the 2-bit codes of its two slots, 4 bits per band, and stores one dword per
     // 8 bands (64 lanes x 4 B = 256 B coalesced = 32 B/band).  The back-track reads the word back into the SAME lane.
-    F.tacc |= (f0 | (f1 << 2)) << ((b & 7) * 4);
-    if ((b & 7) == 7) { R.trace32[(size_t)(b >> 3) * 64 + lane] = F.tacc; F.tacc = 0u; }
+    // (the word shifts down one nibble per band, so after 8 bands band b%8 == 0 sits in bits 0..3: no variable shift)
+    F.tacc = (F.tacc >> 4) | ((f0 | (f1 << 2)) << 28);
+    if ((b & 7) == 7) R.trace32[(size_t)(b >> 3) * 64 + lane] = F.tacc;
 
     if (END && khi == K - 1 && llk <= K - 1) {
         // end search: cell (e, K-1) while it is inside the window, any e in [0,E) (:309-324)
@@ -220,28 +280,24 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
         // request below is the youngest load in flight: the next step only waits for the event means issued above.
         const int ll = pin_s(ring_read_bits(c0, c1, llk & (NP_RING - 1)));
         const int ur = pin_s(ring_read_bits(c0, c1, (llk + NP_ALN_BANDWIDTH - 1) & (NP_RING - 1)));
-        const int ninf = (int)0xff800000;
-        const bool right = (ll == ninf && ur == ninf) ? ((b & 1) == 0) : (float_order_key(ll) < float_order_key(ur));
+        // both -inf (the AND of two non-NaN patterns is -inf's only then): alternate; else right iff ll < ur, where a
+        // single -inf compares as the reference's is_offset_valid ? value : -INFINITY does
+        const bool both_ob = (ll & ur) == (int)0xff800000;
+        const bool right = both_ob ? ((b & 1) == 0) : (__builtin_bit_cast(float, ll) < __builtin_bit_cast(float, ur));
         if (right) {
             F.llk = llk + 1;
-            // Exactly one ring slot falls out per right move: slot (llk - 15) mod 128, i.e. one lane of ONE of the two
-            // slot registers -- which one is wave-uniform, so only that register is touched.  The slot takes its next
-            // k-mer (k+128), whose record was requested the last time the slot moved, and requests the one after that.
-            // Every lane of the register re-requests its `next` record (an L1 hit for all but the re-targeted slot), so
-            // that no load sits inside a divergent branch, where hipcc would wait for it on the spot; the record consumed
-            // here was requested 128 right-moves ago.
-            const int lim = 4 * (F.llk - NP_MARGIN);
-            if (((F.llk - NP_MARGIN - 1) & 64) == 0) {
-                const bool t = F.kb0 < lim;
-                F.gm.x = t ? F.n0.x : F.gm.x; F.gs.x = t ? F.n0.y : F.gs.x; F.gc.x = t ? F.n0.z : F.gc.x; F.gr.x = t ? F.n0.w : F.gr.x;
-                F.kb0 += t ? 4 * NP_RING : 0;
-                F.n0 = buf_f32x4(R.kp, F.kb0 * 4 + 16 * NP_RING);
-            } else {
-                const bool t = F.kb1 < lim;
-                F.gm.y = t ? F.n1.x : F.gm.y; F.gs.y = t ? F.n1.y : F.gs.y; F.gc.y = t ? F.n1.z : F.gc.y; F.gr.y = t ? F.n1.w : F.gr.y;
-                F.kb1 += t ? 4 * NP_RING : 0;
-                F.n1 = buf_f32x4(R.kp, F.kb1 * 4 + 16 * NP_RING);
-            }
+            // Exactly one ring slot falls out per right move: slot (llk - 15) mod 128, one lane of one of the two slot
+            // registers.  It takes its next k-mer (k+128), whose record was requested the last time the slot moved
+            // (128 right-moves ago), and requests the one after that.  Every lane re-requests its `next` record (an L1
+            // hit for all but the re-targeted slot): no load sits inside a divergent branch, where hipcc would wait for
+            // it on the spot.
+            const int out = (F.llk - NP_MARGIN - 1) & (NP_RING - 1);
+            const uint64_t bit = 1ull << (out & 63);
+            retarget(F, (out & 64) ? 0ull : bit, (out & 64) ? bit : 0ull);
+            __builtin_amdgcn_sched_barrier(0);      // request after the moves have read the old records: same registers
+            F.n0 = buf_f32x4(R.kp, F.kb0 * 4 + 16 * NP_RING);
+            F.n1 = buf_f32x4(R.kp, F.kb1 * 4 + 16 * NP_RING);
+            if (FAST) { F.vm0 = window_mask(lane, 0, F.llk); F.vm1 = window_mask(lane, 1, F.llk); }
         }
     }
 }
@@ -288,38 +344,43 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, 7) np_event_align_kernel(np_al
             // ---------------- fill ----------------
             read_t R;
             R.E = E; R.K = K; R.lane = lane; R.end_slot = (K - 1) & (NP_RING - 1);
-            R.ev = make_rsrc(ev, (uint32_t)E * 4u); R.kp = make_rsrc(kp, (uint32_t)K * 16u); R.trace32 = (uint32_t*)trace;
-            R.lp_skip = rd->lp_skip; R.lp_stay = rd->lp_stay; R.lp_step = rd->lp_step; R.lp_trim = rd->lp_trim;
+            R.ev = make_rsrc(ev, (uint32_t)E * 4u); R.kp = make_rsrc(kp, (uint32_t)K * 16u); R.trace32 = 
+ uniform_ptr((uint32_t*)trace);
+
+            // wave-uniform constants in scalar registers (a VALU fp64 add takes one SGPR-pair operand): 8 VGPRs saved
+            R.lp_skip = uniform_f64(rd->lp_skip); R.lp_stay = uniform_f64(rd->lp_stay);
+            R.lp_step = uniform_f64(rd->lp_step); R.lp_trim = uniform_f64(rd->lp_trim);
             fill_t F;
             F.llk = -1 - NP_ALN_BANDWIDTH / 2;              // band_lower_left[0].kmer_idx, raw_loader.cpp:150-151
             {
                 const int k0 = ring_kmer(lane, F.llk), k1 = ring_kmer(lane + 64, F.llk);
                 F.kb0 = 4 * k0; F.kb1 = 4 * k1;
                 const float4 g0 = buf_f32x4(R.kp, 16 * k0), g1 = buf_f32x4(R.kp, 16 * k1);
-                F.gm = f2{g0.x, g1.x}; F.gs = f2{g0.y, g1.y}; F.gc = f2{g0.z, g1.z}; F.gr = f2{g0.w, g1.w};
+                F.g0m = g0.x; F.g0s = g0.y; F.g0c = g0.z; F.g0r = g0.w; F.g1m = g1.x; F.g1s = g1.y; F.g1c = g1.z; F.g1r = g1.w;
                 F.n0 = buf_f32x4(R.kp, 16 * (k0 + NP_RING)); F.n1 = buf_f32x4(R.kp, 16 * (k1 + NP_RING));
             }
             F.p0 = F.p1 = F.d0 = F.d1 = NP_NEG_INF;
             F.best = NP_NEG_INF; F.best_e = 0; F.tacc = 0u;
-            f2 xa = {0.0f, 0.0f}, xb = {0.0f, 0.0f};                   // ping-pong event-mean registers
+            float x0 = 0.0f, x1 = 0.0f;                     // event means of the current band's two cells
             int b = 0;
-            // three phases, so that the trim column and the end search cost nothing in the long middle of the read:
-            // the window only ever moves right, it contains k-mer -1 while llk <= -1 and reaches k-mer K-1 once
-            // llk + 99 >= K-1 (a pair of bands moves llk by at most 2)
-            for (; b + 1 < n_bands && F.llk <= -1; b += 2) {
-                band_step<true, true>(F, R, b, xa, xb);
-                band_step<true, true>(F, R, b + 1, xb, xa);
+            // Three phases, so that the long middle of the read pays for no band geometry, trim column or end search.
+            // llk and u = b-2-llk (the event of the window's first k-mer) never decrease and exactly one of them grows
+            // per band, so the FAST conditions
+            //   llk >= 0,  u >= 99  (the window's last k-mer has event u-99 >= 0)  -- become true once, and
+            //   llk + 99 < K-1,  u <= E-1                                           -- become false once;
+            // and while min(K-2 - (llk+99), E-1 - u) = s > 0 the next s bands are FAST whatever the moves are.
+            for (; b < n_bands && !(F.llk >= 0 && b - 2 - F.llk >= NP_ALN_BANDWIDTH - 1); ++b)
+                band_step<true, true, false>(F, R, b, x0, x1);
+            F.vm0 = window_mask(lane, 0, F.llk); F.vm1 = window_mask(lane, 1, F.llk);
+            for (;;) {
+                const int ks = (K - 2) - (F.llk + NP_ALN_BANDWIDTH - 1), es = (E - 1) - (b - 2 - F.llk);
+                int stop = b + (ks < es ? ks : es);
+                stop = stop < n_bands ? stop : n_bands;
+                if (stop <= b) break;
+                for (; b < stop; ++b) band_step<false, false, true>(F, R, b, x0, x1);
             }
-            for (; b + 1 < n_bands && F.llk + NP_ALN_BANDWIDTH + 1 < K - 1; b += 2) {
-                band_step<false, false>(F, R, b, xa, xb);
-                band_step<false, false>(F, R, b + 1, xb, xa);
-            }
-            for (; b + 1 < n_bands; b += 2) {
-                band_step<true, true>(F, R, b, xa, xb);
-                band_step<true, true>(F, R, b + 1, xb, xa);
-            }
-            if (b < n_bands) band_step<true, true>(F, R, b, xa, xb);
-            if ((n_bands & 7) != 0) R.trace32[(size_t)((n_bands - 1) >> 3) * 64 + lane] = F.tacc;      // last, partial group
+            for (; b < n_bands; ++b) band_step<true, true, false>(F, R, b, x0, x1);
+            if ((n_bands & 7) != 0) R.trace32[(size_t)((n_bands - 1) >> 3) * 64 + lane] = F.tacc >> (4 * (8 - (n_bands & 7)));   // last, partial group
 
             // ---------------- backtrack (:326-361) + QC sums (:338-341) ----------------
             const int owner = R.end_slot & 63;

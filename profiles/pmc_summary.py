@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Per-kernel PMC summary from the rocprofv3 --pmc passes of profiles/collect_pmc.sh.
+
+    pmc_summary.py gpurun_out reads_per_launch bands_per_read > profiles/rNN_pmc.json
+
+Sums every counter per kernel over the launches of the run and reports per-launch / per-read figures for the three
+hot kernels.  FETCH_SIZE / WRITE_SIZE are reported as rocprofv3 gives them (KB -> x1024 bytes) with no further
+correction: the loads of these kernels are narrow (4 B per lane), the x2 of the guide applies to 16 B/lane streams.
+"""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+root, reads, bands = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
+tot = defaultdict(lambda: defaultdict(float))
+launches = defaultdict(set)
+dur = defaultdict(float)
+for f in sorted(glob.glob(root + "/pmc*/*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        for key in ("event_align", "hmm_forward", "recalibrate", "build_map"):
+            if key in k:
+                tot[key][r["Counter_Name"]] += float(r["Counter_Value"])
+                launches[(key, f)].add(r["Dispatch_Id"])
+out = {}
+for key, c in tot.items():
+    n = max(len(v) for (k, f), v in launches.items() if k == key)
+    d = {"launches_per_pass": n}
+    for name, v in sorted(c.items()):
+        d[name + "_per_launch"] = v / n
+    if key == "event_align":
+        per_read = lambda x: c.get(x, 0.0) / n / reads
+        d.update(reads_per_launch=reads,
+                 fetch_bytes_per_read=per_read("FETCH_SIZE") * 1024, write_bytes_per_read=per_read("WRITE_SIZE") * 1024,
+                 valu_insts_per_read=per_read("SQ_INSTS_VALU"), salu_insts_per_read=per_read("SQ_INSTS_SALU"),
+                 vmem_rd_per_read=per_read("SQ_INSTS_VMEM_RD"), vmem_wr_per_read=per_read("SQ_INSTS_VMEM_WR"),
+                 valu_insts_per_band=per_read("SQ_INSTS_VALU") / bands, salu_insts_per_band=per_read("SQ_INSTS_SALU") / bands)
+    if "SQ_BUSY_CYCLES" in c and "SQ_ACTIVE_INST_VALU" in c:
+        d["valu_active_over_busy"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_BUSY_CYCLES"]
+    if "SQ_WAVE_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
+        d["mean_waves_in_flight_per_busy_cycle"] = c["SQ_WAVE_CYCLES"] / c["SQ_BUSY_CYCLES"]
+    out[key] = d
+out["note"] = ("FETCH_SIZE/WRITE_SIZE: rocprofv3 KB x1024, uncorrected (narrow dword loads); counters are summed over all "
+               "XCDs/SEs as rocprofv3 reports them")
+json.dump(out, sys.stdout, indent=1)
+print()

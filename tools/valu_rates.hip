@@ -1,0 +1,142 @@
+// valu_rates.hip -- issue cost (cycles per wave-instruction) of the VALU ops the two kernels are made of, measured on
+// the device with s_memtime around long independent instruction streams.  One wave per SIMD (no contention), 8
+// independent destination registers per op so that latency does not limit issue.  Build + run:
+//   hipcc -O2 --offload-arch=gfx950 tools/valu_rates.hip -o /tmp/valu_rates && /tmp/valu_rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <string>
+
+#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+
+template <int OP> __global__ void k(unsigned long long* out, float* sink, int iters)
+{
+    float a0 = threadIdx.x, a1 = 1.5f, a2 = 2.5f, a3 = 3.5f, a4 = 4.5f, a5 = 5.5f, a6 = 6.5f, a7 = 7.5f;
+    double d0 = 1.0, d1 = 2.0, d2 = 3.0, d3 = 4.0, d4 = 5.0, d5 = 6.0, d6 = 7.0, d7 = 8.0;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p0 = {1.f, 2.f}, p1 = p0, p2 = p0, p3 = p0, p4 = p0, p5 = p0, p6 = p0, p7 = p0;
+    int s0 = 0; int q0 = 0, q1 = 1, q2 = 2, q3 = 3, q4 = 4, q5 = 5, q6 = 6, q7 = 7;
+    asm volatile("v_cmp_gt_f32 vcc, 1.0, %0\n s_mov_b64 s[10:11], vcc" : : "v"(a0) : "vcc", "s10", "s11");
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; ++i) {
+#define CVT64(n) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d##n) : "v"(a##n));
+#define CVT32(n) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a##n) : "v"(d##n));
+#define ADD64(n) asm volatile("v_add_f64 %0, %1, %1" : "=v"(d##n) : "v"(d##n));
+#define FMA32(n) asm volatile("v_fma_f32 %0, %1, %1, %1" : "=v"(a##n) : "v"(a##n));
+#define PKFMA(n) asm volatile("v_pk_fma_f32 %0, %1, %1, %1" : "=v"(p##n) : "v"(p##n));
+#define PKMUL(n) asm volatile("v_pk_mul_f32 %0, %1, %1" : "=v"(p##n) : "v"(p##n));
+#define MAX3(n) asm volatile("v_max3_f32 %0, %1, %1, %1" : "=v"(a##n) : "v"(a##n));
+#define CNDM(n) asm volatile("v_cndmask_b32 %0, %1, %1, vcc" : "=v"(a##n) : "v"(a##n));
+#define DPPM(n) asm volatile("v_mov_b32_dpp %0, %1 wave_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(a##n) : "v"(a##n));
+#define RDLN(n) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(s0) : "v"(a##n));
+#define CMPF(n) asm volatile("v_cmp_eq_f32 vcc, %0, %0" : : "v"(a##n) : "vcc");
+#define FMA64(n) asm volatile("v_fma_f64 %0, %1, %1, %1" : "=v"(d##n) : "v"(d##n));
+#define ADDF(n) asm volatile("v_add_f32 %0, %1, %1" : "=v"(a##n) : "v"(a##n));
+#define CND64(n) asm volatile("v_cndmask_b32_e64 %0, %1, %2, s[10:11]" : "=v"(a##n) : "v"(a##n), "v"(a0) : "s10", "s11");
+#define CNDV2(n) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(a##n) : "v"(a##n), "v"(a0));
+#define SUBU(n) asm volatile("v_sub_u32 %0, %1, %1" : "=v"(a##n) : "v"(a##n));
+#define MAXF(n) asm volatile("v_max_f32 %0, %1, %1" : "=v"(a##n) : "v"(a##n));
+#define PKADD(n) asm volatile("v_pk_add_f32 %0, %1, %1" : "=v"(p##n) : "v"(p##n));
+#define MOVB(n) asm volatile("v_mov_b32 %0, %1" : "=v"(a##n) : "v"(a##n));
+#define FMA3(n) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(a##n) : "v"(a##n), "v"(a0), "v"(a1));
+#define MAX3D(n) asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(a##n) : "v"(a##n), "v"(a0), "v"(a1));
+#define CMPS(n) asm volatile("v_cmp_eq_f32_e64 s[10:11], %0, %0" : : "v"(a##n) : "s10", "s11");
+#define CNDE64V(n) asm volatile("v_cndmask_b32_e64 %0, %1, %2, vcc" : "=v"(a##n) : "v"(a##n), "v"(a0));
+#define ADDC(n) asm volatile("v_addc_co_u32 %0, vcc, %1, %1, vcc" : "=v"(a##n) : "v"(a##n) : "vcc");
+#define CNDS0(n) asm volatile("v_cndmask_b32_e64 %0, %1, %2, s[0:1]" : "=v"(a##n) : "v"(a##n), "v"(a0));
+#define CNDMIX(n) asm volatile("v_cmp_gt_f32 vcc, %1, %2\n v_cndmask_b32 %0, %1, %2, vcc" : "=v"(a##n) : "v"(a##n), "v"(a0) : "vcc");
+#define CNDMIXS(n) asm volatile("v_cmp_gt_f32_e64 s[10:11], %1, %2\n v_cndmask_b32_e64 %0, %1, %2, s[10:11]" : "=v"(a##n) : "v"(a##n), "v"(a0) : "s10", "s11");
+#define C1CND4 asm volatile("v_cmp_gt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %2, %2, %1, vcc\n v_cndmask_b32 %3, %3, %1, vcc\n v_cndmask_b32 %4, %4, %1, vcc" : "+v"(a1), "+v"(a0), "+v"(a2), "+v"(a3), "+v"(a4) : : "vcc");
+#define C1CND4S asm volatile("v_cmp_gt_f32_e64 s[10:11], %0, %1\n v_cndmask_b32_e64 %0, %0, %1, s[10:11]\n v_cndmask_b32_e64 %2, %2, %1, s[10:11]\n v_cndmask_b32_e64 %3, %3, %1, s[10:11]\n v_cndmask_b32_e64 %4, %4, %1, s[10:11]" : "+v"(a1), "+v"(a0), "+v"(a2), "+v"(a3), "+v"(a4) : : "s10", "s11");
+#define C1CND4E asm volatile("v_cmp_gt_f32 vcc, %0, %1\n v_cndmask_b32_e64 %0, %0, %1, vcc\n v_cndmask_b32_e64 %2, %2, %1, vcc\n v_cndmask_b32_e64 %3, %3, %1, vcc\n v_cndmask_b32_e64 %4, %4, %1, vcc" : "+v"(a1), "+v"(a0), "+v"(a2), "+v"(a3), "+v"(a4) : : "vcc");
+#define C1X4CND asm volatile("v_cmp_gt_f32 vcc, %0, %1\n v_add_f32 %2, %2, %2\n v_add_f32 %3, %3, %3\n v_add_f32 %4, %4, %4\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a1), "+v"(a0), "+v"(a2), "+v"(a3), "+v"(a4) : : "vcc");
+#define SADD(n) asm volatile("s_add_i32 %0, %0, 1" : "+s"(q##n) : : "scc");
+#define SMIX(n) asm volatile("s_add_i32 %0, %0, 1\n v_add_f32 %1, %1, %1" : "+s"(q##n), "+v"(a##n) : : "scc");
+#define SCMP(n) asm volatile("s_cmp_lt_i32 %0, 5\n s_cselect_b32 %0, %0, 3" : "+s"(q##n) : : "scc");
+#define CMPU(n) asm volatile("v_cmp_gt_u32 vcc, %0, %0" : : "v"(a##n) : "vcc");
+#define LSHL(n) asm volatile("v_lshl_or_b32 %0, %1, 2, %1" : "=v"(a##n) : "v"(a##n));
+#define MUL64(n) asm volatile("v_mul_f64 %0, %1, %1" : "=v"(d##n) : "v"(d##n));
+#define CVTI(n) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(d##n) : "v"(a##n));
+        if (OP == 0) { REP8(CVT64) REP8(CVT64) }
+        if (OP == 1) { REP8(CVT32) REP8(CVT32) }
+        if (OP == 2) { REP8(ADD64) REP8(ADD64) }
+        if (OP == 3) { REP8(FMA32) REP8(FMA32) }
+        if (OP == 4) { REP8(PKFMA) REP8(PKFMA) }
+        if (OP == 5) { REP8(PKMUL) REP8(PKMUL) }
+        if (OP == 6) { REP8(MAX3) REP8(MAX3) }
+        if (OP == 7) { REP8(CNDM) REP8(CNDM) }
+        if (OP == 8) { REP8(DPPM) REP8(DPPM) }
+        if (OP == 9) { REP8(RDLN) REP8(RDLN) }
+        if (OP == 10) { REP8(CMPF) REP8(CMPF) }
+        if (OP == 11) { REP8(FMA64) REP8(FMA64) }
+        if (OP == 12) { REP8(ADDF) REP8(ADDF) }
+        if (OP == 13) { REP8(CND64) REP8(CND64) }
+        if (OP == 26) { REP8(CNDE64V) REP8(CNDE64V) }
+        if (OP == 27) { REP8(ADDC) REP8(ADDC) }
+        if (OP == 28) { asm volatile("s_mov_b64 vcc, s[10:11]" ::: "vcc"); REP8(CNDM) REP8(CNDM) }
+        if (OP == 29) { REP8(CNDMIX) }
+        if (OP == 30) { REP8(CNDMIXS) }
+        if (OP == 31) { C1CND4 C1CND4 C1CND4 }
+        if (OP == 32) { C1CND4S C1CND4S C1CND4S }
+        if (OP == 33) { C1CND4E C1CND4E C1CND4E }
+        if (OP == 34) { C1X4CND C1X4CND C1X4CND }
+        if (OP == 35) { REP8(SADD) REP8(SADD) }
+        if (OP == 36) { REP8(SMIX) }
+        if (OP == 37) { REP8(SCMP) }
+        if (OP == 17) { REP8(CNDV2) REP8(CNDV2) }
+        if (OP == 18) { REP8(SUBU) REP8(SUBU) }
+        if (OP == 19) { REP8(MAXF) REP8(MAXF) }
+        if (OP == 20) { REP8(PKADD) REP8(PKADD) }
+        if (OP == 21) { REP8(MOVB) REP8(MOVB) }
+        if (OP == 22) { REP8(FMA3) REP8(FMA3) }
+        if (OP == 23) { REP8(MAX3D) REP8(MAX3D) }
+        if (OP == 24) { REP8(CMPS) REP8(CMPS) }
+        if (OP == 25) { REP8(CMPU) REP8(CMPU) }
+        if (OP == 14) { REP8(LSHL) REP8(LSHL) }
+        if (OP == 15) { REP8(MUL64) REP8(MUL64) }
+        if (OP == 16) { REP8(CVTI) REP8(CVTI) }
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+    sink[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7) +
+                                          p0.x + p1.y + p2.x + p3.y + p4.x + p5.x + p6.x + p7.x + s0 + q0 + q1 + q2 + q3 + q4 + q5 + q6 + q7;
+}
+
+template <int OP> double run(const char* name, int waves_per_simd)
+{
+    const int blocks = 1024 * waves_per_simd, iters = 4000;
+    unsigned long long* d; float* s;
+    hipMalloc(&d, blocks * 8); hipMalloc(&s, blocks * 64 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(64), 0, 0, d, s, 10);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(64), 0, 0, d, s, iters);
+    hipEventRecord(e1); hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(blocks);
+    hipMemcpy(h.data(), d, blocks * 8, hipMemcpyDeviceToHost);
+    double avg = 0; for (auto v : h) avg += v; avg /= blocks;
+    // wall-clock based: instructions per SIMD = waves_per_simd * iters * 16
+    const double inst = (double)waves_per_simd * iters * 16;
+    printf("%-14s waves/simd=%d  %.3f ms  -> %.2f ns/inst/SIMD  (s_memtime ticks/inst/wave %.2f)\n", name, waves_per_simd, ms,
+           ms * 1e6 / inst, avg / (iters * 16.0));
+    hipFree(d); hipFree(s);
+    return ms;
+}
+
+int main()
+{
+    for (int w : {2, 8}) {
+        run<12>("v_add_f32", w); run<3>("v_fma_f32", w); run<4>("v_pk_fma_f32", w); run<5>("v_pk_mul_f32", w);
+        run<0>("v_cvt_f64_f32", w); run<1>("v_cvt_f32_f64", w); run<16>("v_cvt_f64_u32", w); run<2>("v_add_f64", w);
+        run<15>("v_mul_f64", w); run<11>("v_fma_f64", w);
+        run<6>("v_max3_f32", w); run<7>("v_cndmask_b32", w); run<8>("v_mov_dpp ror", w); run<9>("v_readlane", w);
+        run<10>("v_cmp_eq_f32", w); run<24>("v_cmp_e64 sgpr", w); run<25>("v_cmp_gt_u32", w); run<14>("v_lshl_or_b32", w);
+        run<13>("cndmask e64 s", w); run<17>("cndmask 2src vcc", w); run<18>("v_sub_u32", w); run<19>("v_max_f32", w);
+        run<26>("cndmask e64 vcc", w); run<27>("v_addc vcc", w); run<28>("cndmask vcc<-salu", w); run<29>("cmp+cnd vcc (x2)", w); run<30>("cmp+cnd sgpr (x2)", w);
+        run<31>("1cmp+4cnd e32 (15/16)", w); run<32>("1cmp+4cnd sgpr (15/16)", w); run<33>("1cmp+4cnd e64 vcc", w); run<34>("cmp,3add,cnd e32", w);
+        run<35>("s_add_i32", w); run<36>("s_add+v_add (x2)", w); run<37>("s_cmp+s_cselect (x2)", w);
+        run<20>("v_pk_add_f32", w); run<21>("v_mov_b32", w); run<22>("v_fma_f32 3src", w); run<23>("v_max3 3src", w);
+    }
+    return 0;
+}
