@@ -275,9 +275,14 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
     F.d0 = l0; F.d1 = l1;
     F.p0 = c0; F.p1 = c1;
 
+    // The event means requested above must have landed before the parameter request below is issued: loads return in
+    // order, and a wait placed after a conditional request would have to assume it was not made and drain everything.
+    // Here they have had the whole band to arrive; the parameter records then have the whole next band.
+    // (the band's results are operands too, which pins the statement -- and so the wait -- behind the band's arithmetic)
+    asm volatile("" : "+v"(x0), "+v"(x1), "+v"(c0), "+v"(c1));
+    F.p0 = c0; F.p1 = c1;
     if (b >= 1) {
-        // Suzuki's rule for band b+1, on this band (:179-195).  It sits at the end of the step so that the parameter
-        // request below is the youngest load in flight: the next step only waits for the event means issued above.
+        // Suzuki's rule for band b+1, on this band (:179-195).
         const int ll = pin_s(ring_read_bits(c0, c1, llk & (NP_RING - 1)));
         const int ur = pin_s(ring_read_bits(c0, c1, (llk + NP_ALN_BANDWIDTH - 1) & (NP_RING - 1)));
         // both -inf (the AND of two non-NaN patterns is -inf's only then): alternate; else right iff ll < ur, where a
