@@ -98,7 +98,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pool", type=int, default=1024, help="distinct synthetic reads per rank")
-    ap.add_argument("--tile", type=int, default=16, help="independent HBM copies of the pool per batch")
+    ap.add_argument("--tile", type=int, default=32, help="independent HBM copies of the pool per batch (32768 reads/step by default:\n"
+                    "                    per-read kernel time keeps falling up to ~100k reads per launch, tools/sweep_batch.sh)")
     ap.add_argument("--read-len", type=int, default=5450, help="bases per read (5450 -> ~8k events)")
     ap.add_argument("--calibrate", type=int, default=1,
                     help="1: recalibrate each read on the device between the two kernels, as load_from_raw does (SURVEY 8 f1); "

@@ -15,6 +15,8 @@ template <int OP> __global__ void k(unsigned long long* out, float* sink, int it
     double d0 = 1.0, d1 = 2.0, d2 = 3.0, d3 = 4.0, d4 = 5.0, d5 = 6.0, d6 = 7.0, d7 = 8.0;
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 p0 = {1.f, 2.f}, p1 = p0, p2 = p0, p3 = p0, p4 = p0, p5 = p0, p6 = p0, p7 = p0;
+    __shared__ float lds[4096]; lds[threadIdx.x] = 1.0f; __syncthreads();
+    int l0 = threadIdx.x * 4, l1 = l0 + 256, l2 = l0 + 512, l3 = l0 + 768, l4 = l0 + 1024, l5 = l0 + 1280, l6 = l0 + 1536, l7 = l0 + 1792;
     int s0 = 0; int q0 = 0, q1 = 1, q2 = 2, q3 = 3, q4 = 4, q5 = 5, q6 = 6, q7 = 7;
     asm volatile("v_cmp_gt_f32 vcc, 1.0, %0\n s_mov_b64 s[10:11], vcc" : : "v"(a0) : "vcc", "s10", "s11");
     unsigned long long t0 = __builtin_readcyclecounter();
@@ -53,6 +55,20 @@ template <int OP> __global__ void k(unsigned long long* out, float* sink, int it
 #define SADD(n) asm volatile("s_add_i32 %0, %0, 1" : "+s"(q##n) : : "scc");
 #define SMIX(n) asm volatile("s_add_i32 %0, %0, 1\n v_add_f32 %1, %1, %1" : "+s"(q##n), "+v"(a##n) : : "scc");
 #define SCMP(n) asm volatile("s_cmp_lt_i32 %0, 5\n s_cselect_b32 %0, %0, 3" : "+s"(q##n) : : "scc");
+#define CVTU(n) asm volatile("v_cvt_u32_f32 %0, %1" : "=v"(a##n) : "v"(a##n));
+#define CVTI32(n) asm volatile("v_cvt_i32_f32 %0, %1" : "=v"(a##n) : "v"(a##n));
+#define MINU(n) asm volatile("v_min_u32 %0, %1, %1" : "=v"(a##n) : "v"(a##n));
+#define MINF(n) asm volatile("v_min_f32 %0, %1, %1" : "=v"(a##n) : "v"(a##n));
+#define MULF(n) asm volatile("v_mul_f32 %0, %1, %1" : "=v"(a##n) : "v"(a##n));
+#define MULFA(n) asm volatile("v_mul_f32 %0, |%1|, %1" : "=v"(a##n) : "v"(a##n));
+#define LSHLR(n) asm volatile("v_lshlrev_b32 %0, 2, %1" : "=v"(a##n) : "v"(a##n));
+#define ANDB(n) asm volatile("v_and_b32 %0, %1, %1" : "=v"(a##n) : "v"(a##n));
+#define DSRD(n) asm volatile("ds_read_b32 %0, %1" : "=v"(a##n) : "v"(l##n));
+#define MED3(n) asm volatile("v_med3_i32 %0, %1, %1, %1" : "=v"(a##n) : "v"(a##n));
+#define MAXI(n) asm volatile("v_max_i32 %0, %1, %1" : "=v"(a##n) : "v"(a##n));
+#define SUBF(n) asm volatile("v_sub_f32 %0, %1, %1" : "=v"(a##n) : "v"(a##n));
+#define ADDU(n) asm volatile("v_add_u32 %0, %1, %1" : "=v"(a##n) : "v"(a##n));
+#define LSHLADD(n) asm volatile("v_lshl_add_u32 %0, %1, 2, %1" : "=v"(a##n) : "v"(a##n));
 #define CMPU(n) asm volatile("v_cmp_gt_u32 vcc, %0, %0" : : "v"(a##n) : "vcc");
 #define LSHL(n) asm volatile("v_lshl_or_b32 %0, %1, 2, %1" : "=v"(a##n) : "v"(a##n));
 #define MUL64(n) asm volatile("v_mul_f64 %0, %1, %1" : "=v"(d##n) : "v"(d##n));
@@ -83,6 +99,20 @@ template <int OP> __global__ void k(unsigned long long* out, float* sink, int it
         if (OP == 35) { REP8(SADD) REP8(SADD) }
         if (OP == 36) { REP8(SMIX) }
         if (OP == 37) { REP8(SCMP) }
+        if (OP == 40) { REP8(CVTU) REP8(CVTU) }
+        if (OP == 41) { REP8(CVTI32) REP8(CVTI32) }
+        if (OP == 42) { REP8(MINU) REP8(MINU) }
+        if (OP == 43) { REP8(MINF) REP8(MINF) }
+        if (OP == 44) { REP8(MULF) REP8(MULF) }
+        if (OP == 45) { REP8(MULFA) REP8(MULFA) }
+        if (OP == 46) { REP8(LSHLR) REP8(LSHLR) }
+        if (OP == 47) { REP8(ANDB) REP8(ANDB) }
+        if (OP == 48) { REP8(DSRD) REP8(DSRD) asm volatile("s_waitcnt lgkmcnt(0)"); }
+        if (OP == 49) { REP8(MED3) REP8(MED3) }
+        if (OP == 50) { REP8(MAXI) REP8(MAXI) }
+        if (OP == 51) { REP8(SUBF) REP8(SUBF) }
+        if (OP == 52) { REP8(ADDU) REP8(ADDU) }
+        if (OP == 53) { REP8(LSHLADD) REP8(LSHLADD) }
         if (OP == 17) { REP8(CNDV2) REP8(CNDV2) }
         if (OP == 18) { REP8(SUBU) REP8(SUBU) }
         if (OP == 19) { REP8(MAXF) REP8(MAXF) }
@@ -126,7 +156,7 @@ template <int OP> double run(const char* name, int waves_per_simd)
 
 int main()
 {
-    for (int w : {2, 8}) {
+    for (int w : {8}) {
         run<12>("v_add_f32", w); run<3>("v_fma_f32", w); run<4>("v_pk_fma_f32", w); run<5>("v_pk_mul_f32", w);
         run<0>("v_cvt_f64_f32", w); run<1>("v_cvt_f32_f64", w); run<16>("v_cvt_f64_u32", w); run<2>("v_add_f64", w);
         run<15>("v_mul_f64", w); run<11>("v_fma_f64", w);
@@ -136,6 +166,9 @@ int main()
         run<26>("cndmask e64 vcc", w); run<27>("v_addc vcc", w); run<28>("cndmask vcc<-salu", w); run<29>("cmp+cnd vcc (x2)", w); run<30>("cmp+cnd sgpr (x2)", w);
         run<31>("1cmp+4cnd e32 (15/16)", w); run<32>("1cmp+4cnd sgpr (15/16)", w); run<33>("1cmp+4cnd e64 vcc", w); run<34>("cmp,3add,cnd e32", w);
         run<35>("s_add_i32", w); run<36>("s_add+v_add (x2)", w); run<37>("s_cmp+s_cselect (x2)", w);
+        run<40>("v_cvt_u32_f32", w); run<41>("v_cvt_i32_f32", w); run<42>("v_min_u32", w); run<43>("v_min_f32", w); run<44>("v_mul_f32", w);
+        run<45>("v_mul_f32 |abs|", w); run<46>("v_lshlrev_b32", w); run<47>("v_and_b32", w); run<48>("ds_read_b32", w); run<49>("v_med3_i32", w);
+        run<50>("v_max_i32", w); run<51>("v_sub_f32", w); run<52>("v_add_u32", w); run<53>("v_lshl_add_u32", w);
         run<20>("v_pk_add_f32", w); run<21>("v_mov_b32", w); run<22>("v_fma_f32 3src", w); run<23>("v_max3 3src", w);
     }
     return 0;
