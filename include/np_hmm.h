@@ -232,6 +232,50 @@ int np_calibrate_resolve_dev(np_ctx* ctx, void* stream, int n_reads, np_read_dev
                              int32_t* map_start, int32_t* map_stop, double* events_per_base, int32_t* calibrated,
                              int64_t n_jobs, np_hmm_job_dev* jobs, const int32_t* kpos);
 
+/* The event aligner's per-read constants {lp_skip, lp_stay, lp_step, lp_trim} (src/nanopolish_raw_loader.cpp:99-108) computed
+ * with the library's restatement of glibc's log/exp (csrc/np_log.h) -- what np_mom_fill_dev computes on the device -- and
+ * the restated functions themselves (out_log[i] = log(x[i]), out_exp[i] = exp(-x[i])); host-only, for verification. */
+void np_aligner_constants(uint32_t n_events, uint32_t n_kmers, double out[4]);
+void np_restated_log_exp(const double* x, size_t n, double* out_log, double* out_exp);
+
+/* ---- f2: the stage in front of the event aligner ------------------------------------------ */
+/* detector_param, src/thirdparty/scrappie/event_detection.h:6-12 */
+typedef struct np_detector_param {
+    uint32_t window_length1, window_length2;
+    float threshold1, threshold2, peak_height;
+} np_detector_param;
+/* event_detection_defaults (rna == 0, :15-21) / event_detection_rna (rna != 0, :23-29) */
+void np_event_detection_params(np_detector_param* p, int rna);
+
+#define NP_ED_OVERFLOW (-1)   /* n_events[r]: more events than the caller's capacity for the read                      */
+#define NP_ED_INEXACT  (-2)   /* n_events[r]: the detector's double-precision sums are not provably exact for this read, */
+                              /* so an order-independent evaluation could differ from the reference in the last bit      */
+
+/* detect_events (src/thirdparty/scrappie/event_detection.c:268-319) on the WHOLE raw table of every read, as
+ * SquiggleRead::load_from_raw runs it (src/nanopolish_squiggle_read.cpp:229-236; the trim it computes is discarded there).
+ *   raw / raw_off      : float[total samples] (pA), int64[n_reads+1]
+ *   max_samples        : largest read (host value, sizes the launch)
+ *   tstat              : scratch, 2 floats per sample (8-byte aligned)
+ *   event_off          : int64[n_reads+1], per-read CAPACITY offsets into the event arrays (n_samples/2+2 is always enough:
+ *                        boundaries of one detector are at least two samples apart)
+ *   event_start/length/mean/stdv : event_t fields (scrappie_structures.h:8-15) of the detected events
+ *   n_events           : per read: the event count (1 + #boundaries), 0 if no boundary was found (undefined in the
+ *                        reference), or NP_ED_OVERFLOW / NP_ED_INEXACT */
+int np_detect_events_dev(np_ctx* ctx, void* stream, int n_reads, const float* raw, const int64_t* raw_off, int64_t max_samples,
+                         const np_detector_param* params, float* tstat, const int64_t* event_off, int64_t max_events,
+                         uint32_t* event_start, float* event_length, float* event_mean, float* event_stdv, int32_t* n_events);
+/* Host-pointer convenience form for one batch of reads (copies in and out). out_* are concatenated, out_off[n_reads+1]. */
+int np_detect_events_host(np_ctx* ctx, int n_reads, const float* const* raw, const uint32_t* n_samples,
+                          const np_detector_param* params, uint32_t* out_start, float* out_length, float* out_mean,
+                          float* out_stdv, int64_t cap, int64_t* out_off);
+
+/* estimate_scalings_using_mom (src/nanopolish_raw_loader.cpp:30-75) + the event aligner's per-read constants (:99-108) on the
+ * device: completes reads[r] (event_off, rank_off, n_kmers already set by the caller) with n_events, shift/scale (var = 1)
+ * and lp_skip/lp_stay/lp_step/lp_trim, computed with glibc's log/exp restated (csrc/np_log.h).  reads_b (nullable): a second
+ * record array (the one kernel B reads) that receives n_events. */
+int np_mom_fill_dev(np_ctx* ctx, void* stream, int n_reads, np_read_dev* reads, np_read_dev* reads_b, const float* event_mean,
+                    const int32_t* n_events, const uint16_t* kmer_rank, int model);
+
 /* Device self-test: the emission's exact fast division (reciprocal + two fused corrections) against the IEEE fp32
  * divide on n_samples pseudo-random operand pairs; *n_mismatch must come back 0. */
 int np_selftest_division(np_ctx* ctx, uint64_t n_samples, uint64_t seed, uint64_t* n_mismatch);

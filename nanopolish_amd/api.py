@@ -218,6 +218,27 @@ class Context:
                   "np_event_align_host")
         return [pairs[off[i]:off[i + 1]].copy() for i in range(n)]
 
+    def detect_events(self, raws, rna=False, params=None):
+        """detect_events (src/thirdparty/scrappie/event_detection.c:268-319) on whole raw tables, as load_from_raw calls it.
+        raws: list of float32 arrays (pA).  Returns a list of dicts(start u32, length f32, mean f32, stdv f32)."""
+        n = len(raws)
+        keep = [np.ascontiguousarray(r, np.float32) for r in raws]
+        ptrs = (_l.c_f32p * n)(*[_p(r, _l.c_f32p) for r in keep])
+        ns = np.array([len(r) for r in keep], np.uint32)
+        prm = _l.DetectorParam()
+        self.L.np_event_detection_params(C.byref(prm), int(bool(rna)))
+        if params:
+            prm.window_length1, prm.window_length2 = params["w1"], params["w2"]
+            prm.threshold1, prm.threshold2, prm.peak_height = params["t1"], params["t2"], params["peak_height"]
+        cap = int((ns.astype(np.int64) // 2 + 2).sum())
+        st = np.zeros(cap, np.uint32); ln = np.zeros(cap, np.float32); mn = np.zeros(cap, np.float32); sd = np.zeros(cap, np.float32)
+        off = np.zeros(n + 1, np.int64)
+        self._chk(self.L.np_detect_events_host(self.h, n, ptrs, ns.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(prm),
+                                               st.ctypes.data_as(C.POINTER(C.c_uint32)), _p(ln, _l.c_f32p), _p(mn, _l.c_f32p),
+                                               _p(sd, _l.c_f32p), cap, _p(off, _l.c_i64p)), "np_detect_events_host")
+        return [dict(start=st[off[i]:off[i + 1]].copy(), length=ln[off[i]:off[i + 1]].copy(), mean=mn[off[i]:off[i + 1]].copy(),
+                     stdv=sd[off[i]:off[i + 1]].copy()) for i in range(n)]
+
     # -- timing -----------------------------------------------------------------------------------------------------
     def sync(self, stream=None):
         self._chk(self.L.np_sync(self.h, stream), "np_sync")

@@ -15,7 +15,7 @@
 
 #define NP_VERSION_STR "nanopolish_amd 0.1 (gfx950)"
 #define NP_FLANK_LEN (1u << 20)
-#define NP_NUM_FAMILIES 4
+#define NP_NUM_FAMILIES 6      // 0 event align, 1 forward HMM, 2 glue, 3 Viterbi, 4 event detection, 5 MoM scalings
 
 namespace {
 
@@ -66,6 +66,8 @@ struct np_ctx {
     // host-API staging
     dev_buf b_jobs, b_reads, b_events, b_ranks, b_out, b_pair_off, b_pairs, b_pair_begin, b_n_pairs,
             b_vm, b_bp, b_cell_off, b_state_off, b_states, b_n_states;
+    dev_buf ed_status, ed_tstat;      // event detection scratch
+    dev_buf b_raw, b_raw_off, b_ev_off, b_ev_start, b_ev_len, b_ev_mean, b_ev_stdv, b_n_events;
     timing_t timing[NP_NUM_FAMILIES];
     std::mutex lock;
     std::string err;
@@ -250,7 +252,8 @@ void np_destroy(np_ctx* c)
     if (c->d_counters) (void)hipFree(c->d_counters);
     dev_buf* bufs[] = {&c->order, &c->trace, &c->kparams, &c->b_jobs, &c->b_reads, &c->b_events, &c->b_ranks, &c->b_out, &c->b_pair_off,
                        &c->b_pairs, &c->b_pair_begin, &c->b_n_pairs, &c->b_vm, &c->b_bp, &c->b_cell_off, &c->b_state_off,
-                       &c->b_states, &c->b_n_states};
+                       &c->b_states, &c->b_n_states, &c->ed_status, &c->ed_tstat, &c->b_raw, &c->b_raw_off, &c->b_ev_off, &c->b_ev_start,
+                       &c->b_ev_len, &c->b_ev_mean, &c->b_ev_stdv, &c->b_n_events};
     for (dev_buf* b : bufs) b->release();
     for (auto& t : c->timing) {
         for (auto& pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -609,6 +612,118 @@ int np_event_align_host(np_ctx* c, int n_jobs, const np_align_job* jobs, np_pair
         w += hn[j];
     }
     out_off[n_jobs] = w;
+    return NP_OK;
+}
+
+// ---- f2: event detection + MoM scalings ------------------------------------------------------------------------------
+void np_event_detection_params(np_detector_param* p, int rna)
+{
+    if (!p) return;
+    if (!rna) { p->window_length1 = 3; p->window_length2 = 6; p->threshold1 = 1.4f; p->threshold2 = 9.0f; p->peak_height = 0.2f; }   // event_detection.h:15-21
+    else { p->window_length1 = 7; p->window_length2 = 14; p->threshold1 = 2.5f; p->threshold2 = 9.0f; p->peak_height = 1.0f; }      // :23-29
+}
+
+static int detect_events_locked(np_ctx* c, hipStream_t s, int n_reads, const float* raw, const int64_t* raw_off, int64_t max_samples,
+                                const np_detector_param* params, float* tstat, int64_t total_samples_hint, const int64_t* event_off,
+                                int64_t max_events, uint32_t* event_start, float* event_length, float* event_mean, float* event_stdv,
+                                int32_t* n_events)
+{
+    np_detector_param p;
+    if (params) p = *params; else np_event_detection_params(&p, 0);
+    if (p.window_length1 > 16 || p.window_length2 > 16) { c->err = "np_detect_events: window length > 16"; return NP_ERR_UNSUPPORTED; }
+    NP_HIP(c, c->ed_status.reserve((size_t)n_reads * sizeof(int32_t)));
+    if (!tstat) {
+        NP_HIP(c, c->ed_tstat.reserve((size_t)total_samples_hint * sizeof(float2)));
+        tstat = c->ed_tstat.as<float>();
+    }
+    family_timer tm(c, 4, s);
+    NP_HIP(c, np_launch_detect_events(n_reads, raw, raw_off, max_samples, p, (float2*)tstat, c->ed_status.as<int32_t>(), event_off,
+                                      max_events, event_start, event_length, event_mean, event_stdv, n_events, s));
+    return NP_OK;
+}
+
+int np_detect_events_dev(np_ctx* c, void* stream, int n_reads, const float* raw, const int64_t* raw_off, int64_t max_samples,
+                         const np_detector_param* params, float* tstat, const int64_t* event_off, int64_t max_events,
+                         uint32_t* event_start, float* event_length, float* event_mean, float* event_stdv, int32_t* n_events)
+{
+    if (!c || n_reads < 0 || (n_reads > 0 && (!raw || !raw_off || !tstat || !event_off || !event_start || !event_length || !event_mean ||
+                                             !event_stdv || !n_events))) return NP_ERR_INVALID;
+    if (n_reads == 0) return NP_OK;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    return detect_events_locked(c, pick_stream(c, stream), n_reads, raw, raw_off, max_samples, params, tstat, 0, event_off, max_events,
+                                event_start, event_length, event_mean, event_stdv, n_events);
+}
+
+int np_detect_events_host(np_ctx* c, int n_reads, const float* const* raw, const uint32_t* n_samples, const np_detector_param* params,
+                          uint32_t* out_start, float* out_length, float* out_mean, float* out_stdv, int64_t cap, int64_t* out_off)
+{
+    if (!c || n_reads < 0 || (n_reads > 0 && (!raw || !n_samples || !out_start || !out_length || !out_mean || !out_stdv || !out_off)))
+        return NP_ERR_INVALID;
+    if (n_reads == 0) return NP_OK;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    std::vector<int64_t> raw_off(n_reads + 1, 0), ev_off(n_reads + 1, 0);
+    int64_t max_samples = 0, max_events = 0;
+    for (int r = 0; r < n_reads; ++r) {
+        if (!raw[r] && n_samples[r]) { c->err = "np_detect_events_host: null raw table"; return NP_ERR_INVALID; }
+        raw_off[r + 1] = raw_off[r] + n_samples[r];
+        const int64_t ecap = (int64_t)n_samples[r] / 2 + 2;
+        ev_off[r + 1] = ev_off[r] + ecap;
+        max_samples = std::max<int64_t>(max_samples, n_samples[r]); max_events = std::max(max_events, ecap);
+    }
+    hipStream_t s = c->stream;
+    const size_t ns = (size_t)raw_off[n_reads], ne = (size_t)ev_off[n_reads];
+    NP_HIP(c, c->b_raw.reserve(ns * sizeof(float) + 16));
+    NP_HIP(c, c->b_raw_off.reserve(raw_off.size() * sizeof(int64_t)));
+    NP_HIP(c, c->b_ev_off.reserve(ev_off.size() * sizeof(int64_t)));
+    NP_HIP(c, c->b_ev_start.reserve(ne * sizeof(uint32_t))); NP_HIP(c, c->b_ev_len.reserve(ne * sizeof(float)));
+    NP_HIP(c, c->b_ev_mean.reserve(ne * sizeof(float))); NP_HIP(c, c->b_ev_stdv.reserve(ne * sizeof(float)));
+    NP_HIP(c, c->b_n_events.reserve((size_t)n_reads * sizeof(int32_t)));
+    for (int r = 0; r < n_reads; ++r)
+        if (n_samples[r])
+            NP_HIP(c, hipMemcpyAsync(c->b_raw.as<float>() + raw_off[r], raw[r], (size_t)n_samples[r] * sizeof(float), hipMemcpyHostToDevice, s));
+    NP_HIP(c, hipMemcpyAsync(c->b_raw_off.p, raw_off.data(), raw_off.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    NP_HIP(c, hipMemcpyAsync(c->b_ev_off.p, ev_off.data(), ev_off.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    int rc = detect_events_locked(c, s, n_reads, c->b_raw.as<float>(), c->b_raw_off.as<int64_t>(), max_samples, params, nullptr, (int64_t)ns,
+                                  c->b_ev_off.as<int64_t>(), max_events, c->b_ev_start.as<uint32_t>(), c->b_ev_len.as<float>(),
+                                  c->b_ev_mean.as<float>(), c->b_ev_stdv.as<float>(), c->b_n_events.as<int32_t>());
+    if (rc != NP_OK) return rc;
+    std::vector<int32_t> hn(n_reads);
+    std::vector<uint32_t> hs(ne); std::vector<float> hl(ne), hm(ne), hd(ne);
+    NP_HIP(c, hipMemcpyAsync(hn.data(), c->b_n_events.p, hn.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    NP_HIP(c, hipMemcpyAsync(hs.data(), c->b_ev_start.p, ne * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    NP_HIP(c, hipMemcpyAsync(hl.data(), c->b_ev_len.p, ne * sizeof(float), hipMemcpyDeviceToHost, s));
+    NP_HIP(c, hipMemcpyAsync(hm.data(), c->b_ev_mean.p, ne * sizeof(float), hipMemcpyDeviceToHost, s));
+    NP_HIP(c, hipMemcpyAsync(hd.data(), c->b_ev_stdv.p, ne * sizeof(float), hipMemcpyDeviceToHost, s));
+    NP_HIP(c, hipStreamSynchronize(s));
+    drain_timing(c);
+    int64_t w = 0;
+    for (int r = 0; r < n_reads; ++r) {
+        out_off[r] = w;
+        if (hn[r] == NP_ED_INEXACT) { c->err = "np_detect_events_host: a read's prefix sums are not provably exact (NP_ED_INEXACT)"; return NP_ERR_UNSUPPORTED; }
+        if (hn[r] < 0) { c->err = "np_detect_events_host: event capacity exceeded"; return NP_ERR_NOMEM; }
+        if (w + hn[r] > cap) { c->err = "np_detect_events_host: output capacity too small"; return NP_ERR_NOMEM; }
+        const size_t o = (size_t)ev_off[r];
+        memcpy(out_start + w, hs.data() + o, (size_t)hn[r] * sizeof(uint32_t)); memcpy(out_length + w, hl.data() + o, (size_t)hn[r] * sizeof(float));
+        memcpy(out_mean + w, hm.data() + o, (size_t)hn[r] * sizeof(float)); memcpy(out_stdv + w, hd.data() + o, (size_t)hn[r] * sizeof(float));
+        w += hn[r];
+    }
+    out_off[n_reads] = w;
+    return NP_OK;
+}
+
+int np_mom_fill_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* reads, np_read_dev* reads_b, const float* event_mean,
+                    const int32_t* n_events, const uint16_t* kmer_rank, int model)
+{
+    if (!c || n_reads < 0 || (n_reads > 0 && (!reads || !event_mean || !n_events || !kmer_rank))) return NP_ERR_INVALID;
+    if (model < 0 || model >= (int)c->models.size()) { c->err = "bad model id"; return NP_ERR_INVALID; }
+    if (n_reads == 0) return NP_OK;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = pick_stream(c, stream);
+    family_timer tm(c, 5, s);
+    NP_HIP(c, np_launch_mom_fill(n_reads, reads, reads_b, event_mean, n_events, kmer_rank, c->models[model].d_states, s));
     return NP_OK;
 }
 

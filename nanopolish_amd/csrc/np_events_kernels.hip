@@ -1,0 +1,336 @@
+// np_events_kernels.hip -- the stage in front of the event aligner, for gfx950:
+//   * scrappie event detection (src/thirdparty/scrappie/event_detection.c:268-319) as SquiggleRead::load_from_raw runs it
+//     (src/nanopolish_squiggle_read.cpp:229-236): on the WHOLE raw table -- trim_and_segment_raw's result is discarded
+//     there -- with event_detection_defaults;
+//   * estimate_scalings_using_mom (src/nanopolish_raw_loader.cpp:30-75) and the aligner's per-read constants
+//     (:99-108) on the device, so that raw signal -> events -> alignment -> calibration -> scoring needs no host step.
+//
+// Parity argument for the detector.  The reference accumulates double-precision prefix sums of the samples and of
+// their fp32 squares serially and only ever uses DIFFERENCES of two prefix values (windows of 3 and 6 samples, event
+// spans).  Samples are fp32, so all of them are multiples of one power of two g; as long as n * max|x| < 2^53 g every
+// partial sum of any subset is representable, every one of the reference's additions is exact, and a difference of
+// two prefix values IS the exact sum of the samples in between -- in any order.  np_ed_check_kernel proves that bound
+// per read (for the samples and for their squares); reads that pass are segmented from window sums computed directly
+// (no prefix arrays, no serial scan), and the result is bit-identical to the reference.  A read that fails the bound
+// (samples below ~4 pA in a 130k-sample read would do it) reports NP_ED_INEXACT instead of a result that might differ
+// in the last bit; there is no approximate path.
+//
+// The t-statistics are embarrassingly parallel (one thread per sample, neighbours through LDS).  The short/long peak
+// picker is a sequential state machine per read: one lane per read, 64 reads per wave, t-statistics streamed with
+// a four-sample register prefetch.  Event means/stdv are one thread per event.
+#include "np_kernels.h"
+#include "np_log.h"
+
+#define NP_ED_TILE 256
+#define NP_ED_HALO 16          // >= the largest window (event_detection_rna: 14)
+
+namespace {
+
+__device__ __forceinline__ double dbl_readlane(double v, int l)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// exactness bound of the prefix sums, one block per read
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) np_ed_check_kernel(int n_reads, const float* __restrict__ raw, const int64_t* __restrict__ raw_off,
+                                                           int32_t* __restrict__ status)
+{
+    const int r = blockIdx.x;
+    if (r >= n_reads) return;
+    const float* x = raw + raw_off[r];
+    const int64_t n = raw_off[r + 1] - raw_off[r];
+    // bit patterns of non-negative floats order like the floats; inf/nan patterns (>= 0x7f800000) end up in the maximum
+    uint32_t amax = 0u, amin = 0xffffffffu, qmax = 0u, qmin = 0xffffffffu;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const float v = x[i];
+        const float q = v * v;
+        const uint32_t a = __builtin_bit_cast(uint32_t, v) & 0x7fffffffu, b = __builtin_bit_cast(uint32_t, q);
+        amax = a > amax ? a : amax; qmax = b > qmax ? b : qmax;
+        if (a != 0u) amin = a < amin ? a : amin;
+        if (b != 0u) qmin = b < qmin ? b : qmin;
+    }
+    __shared__ uint32_t red[4][256];
+    red[0][threadIdx.x] = amax; red[1][threadIdx.x] = amin; red[2][threadIdx.x] = qmax; red[3][threadIdx.x] = qmin;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            red[0][threadIdx.x] = max(red[0][threadIdx.x], red[0][threadIdx.x + s]);
+            red[1][threadIdx.x] = min(red[1][threadIdx.x], red[1][threadIdx.x + s]);
+            red[2][threadIdx.x] = max(red[2][threadIdx.x], red[2][threadIdx.x + s]);
+            red[3][threadIdx.x] = min(red[3][threadIdx.x], red[3][threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        bool ok = true;
+        for (int w = 0; w < 2; ++w) {
+            const uint32_t mx = red[2 * w][0], mn = red[2 * w + 1][0];
+            if (mx >= 0x7f800000u) { ok = false; continue; }               // inf / nan
+            if (mn == 0xffffffffu) continue;                                // all zero
+            if ((mn >> 23) == 0u) { ok = false; continue; }                 // a denormal term: no bound attempted
+            const int g = (int)(mn >> 23) - 127 - 23;                       // every term is a multiple of 2^g
+            const double bound = (double)n * (double)__builtin_bit_cast(float, mx);
+            ok = ok && bound < ldexp(1.0, 53 + g);
+        }
+        status[r] = ok ? 0 : NP_ED_INEXACT;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// compute_tstat (event_detection.c:63-119) for both windows, one thread per sample
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float tstat_at(const float* __restrict__ s, int c, int64_t i, int64_t n, int w)
+{
+    // s[c] is sample i of the read; the window [i-w, i+w) is inside the staged tile
+    if (w < 2 || n < 2 * (int64_t)w || i < w || i > n - w) return 0.0f;        // quick return and fudged boundaries
+    const float w_lengthf = (float)w;
+    double sum1 = 0.0, sumsq1 = 0.0, sum2d = 0.0, sumsq2d = 0.0;
+    for (int j = -w; j < 0; ++j) { const float v = s[c + j]; sum1 += (double)v; sumsq1 += (double)(v * v); }
+    for (int j = 0; j < w; ++j) { const float v = s[c + j]; sum2d += (double)v; sumsq2d += (double)(v * v); }
+    const float sum2 = (float)sum2d, sumsq2 = (float)sumsq2d;
+    const float mean1 = (float)(sum1 / (double)w_lengthf);
+    const float mean2 = sum2 / w_lengthf;
+    float combined_var = (float)(sumsq1 / (double)w_lengthf - (double)(mean1 * mean1) + (double)(sumsq2 / w_lengthf) - (double)(mean2 * mean2));
+    combined_var = fmaxf(combined_var, 1.17549435e-38f);                       // FLT_MIN
+    const float delta_mean = mean2 - mean1;
+    return (float)(fabs((double)delta_mean) / sqrt((double)(combined_var / w_lengthf)));
+}
+
+__global__ void __launch_bounds__(NP_ED_TILE) np_ed_tstat_kernel(int n_reads, const float* __restrict__ raw, const int64_t* __restrict__ raw_off,
+                                                                 const int32_t* __restrict__ status, int w1, int w2, float2* __restrict__ tstat)
+{
+    const int r = blockIdx.x;                               // (reads on x: the y extent of a grid stops at 65535)
+    if (r >= n_reads || status[r] != 0) return;
+    const int64_t n = raw_off[r + 1] - raw_off[r];
+    const int64_t base = (int64_t)blockIdx.y * NP_ED_TILE;
+    if (base >= n) return;
+    const float* x = raw + raw_off[r];
+    __shared__ float s[NP_ED_TILE + 2 * NP_ED_HALO];
+    for (int t = threadIdx.x; t < NP_ED_TILE + 2 * NP_ED_HALO; t += NP_ED_TILE) {
+        const int64_t i = base - NP_ED_HALO + t;
+        s[t] = (i >= 0 && i < n) ? x[i] : 0.0f;
+    }
+    __syncthreads();
+    const int64_t i = base + threadIdx.x;
+    if (i >= n) return;
+    const int c = NP_ED_HALO + (int)threadIdx.x;
+    tstat[raw_off[r] + i] = make_float2(tstat_at(s, c, i, n, w1), tstat_at(s, c, i, n, w2));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// short_long_peak_detector (event_detection.c:126-207), one lane per read
+// ---------------------------------------------------------------------------------------------------------------
+struct detector {
+    int64_t masked_to; int peak_pos; float peak_value; bool valid_peak;
+};
+
+__global__ void __launch_bounds__(64) np_ed_peaks_kernel(int n_reads, const int64_t* __restrict__ raw_off, const float2* __restrict__ tstat,
+                                                          const int32_t* __restrict__ status, np_detector_param p,
+                                                          const int64_t* __restrict__ event_off, uint32_t* __restrict__ event_start,
+                                                          int32_t* __restrict__ n_events)
+{
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    const bool live = r < n_reads && status[r] == 0;
+    const int64_t n = live ? raw_off[r + 1] - raw_off[r] : 0;
+    const float2* ts = tstat + (live ? raw_off[r] : 0);
+    uint32_t* es = event_start + (live ? event_off[r] : 0);
+    const int64_t cap = live ? event_off[r + 1] - event_off[r] : 0;
+    const float DEF_PEAK_VAL = 3.40282347e+38f;                                // FLT_MAX
+    detector d[2];
+    for (int k = 0; k < 2; ++k) { d[k].masked_to = 0; d[k].peak_pos = -1; d[k].peak_value = DEF_PEAK_VAL; d[k].valid_peak = false; }
+    const float threshold[2] = {p.threshold1, p.threshold2};
+    const int64_t window_length[2] = {(int64_t)p.window_length1, (int64_t)p.window_length2};
+    int64_t peak_count = 0;
+    bool overflow = false;
+    if (live && cap > 0) es[0] = 0u;
+
+    // wave-uniform trip count; every lane walks its own read, four samples per prefetched group
+    int64_t nmax = n;
+    for (int o = 32; o > 0; o >>= 1) { const int64_t v = __shfl_xor(nmax, o, 64); nmax = v > nmax ? v : nmax; }
+    float2 cur[4], nxt[4];
+    for (int q = 0; q < 4; ++q) nxt[q] = (q < n) ? ts[q] : make_float2(0.f, 0.f);
+    for (int64_t i0 = 0; i0 < nmax; i0 += 4) {
+        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+        for (int q = 0; q < 4; ++q) { const int64_t j = i0 + 4 + q; nxt[q] = (j < n) ? ts[j] : make_float2(0.f, 0.f); }
+        for (int q = 0; q < 4; ++q) {
+            const int64_t i = i0 + q;
+            if (i >= n) break;
+            for (int k = 0; k < 2; ++k) {
+                detector& dt = d[k];
+                if (dt.masked_to >= i) continue;                               // masked out
+                const float current_value = k == 0 ? cur[q].x : cur[q].y;
+                if (dt.peak_pos == -1) {
+                    // CASE 1: no maximum recorded yet
+                    if (current_value < dt.peak_value) {
+                        dt.peak_value = current_value;
+                    } else if (current_value - dt.peak_value > p.peak_height) {
+                        dt.peak_value = current_value;
+                        dt.peak_pos = (int)i;
+                    }
+                } else {
+                    // CASE 2: in a peak, waiting to see whether it is good
+                    if (current_value > dt.peak_value) { dt.peak_value = current_value; dt.peak_pos = (int)i; }
+                    if (k == 0) {
+                        // the short detector dominates the long one if it is going to fire
+                        if (dt.peak_value > threshold[0]) {
+                            d[1].masked_to = (int64_t)dt.peak_pos + window_length[0];
+                            d[1].peak_pos = -1;
+                            d[1].peak_value = DEF_PEAK_VAL;
+                            d[1].valid_peak = false;
+                        }
+                    }
+                    if (dt.peak_value - current_value > p.peak_height && dt.peak_value > threshold[k]) dt.valid_peak = true;
+                    if (dt.valid_peak && (i - dt.peak_pos) > window_length[k] / 2) {
+                        // emit the boundary and reset
+                        peak_count++;
+                        if (peak_count < cap) es[peak_count] = (uint32_t)dt.peak_pos; else overflow = true;
+                        dt.peak_pos = -1;
+                        dt.peak_value = current_value;
+                        dt.valid_peak = false;
+                    }
+                }
+            }
+        }
+    }
+    if (r < n_reads) {
+        // create_events (:243-266): one event more than there are peaks; no peak at all is undefined in the reference
+        n_events[r] = !live ? status[r] : (overflow ? NP_ED_OVERFLOW : (peak_count > 0 ? (int32_t)(peak_count + 1) : 0));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// create_event (event_detection.c:223-241), one thread per event
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) np_ed_events_kernel(int n_reads, const float* __restrict__ raw, const int64_t* __restrict__ raw_off,
+                                                            const int64_t* __restrict__ event_off, const uint32_t* __restrict__ event_start,
+                                                            const int32_t* __restrict__ n_events, float* __restrict__ event_length,
+                                                            float* __restrict__ event_mean, float* __restrict__ event_stdv)
+{
+    const int r = blockIdx.x;
+    if (r >= n_reads) return;
+    const int n_ev = n_events[r];
+    const int e = blockIdx.y * 256 + threadIdx.x;
+    if (e >= n_ev) return;
+    const float* x = raw + raw_off[r];
+    const int64_t n = raw_off[r + 1] - raw_off[r];
+    const int64_t eo = event_off[r];
+    const int64_t start = event_start[eo + e];
+    const int64_t end = e + 1 < n_ev ? (int64_t)event_start[eo + e + 1] : n;
+    // (peaks come in the order the two detectors emit them; should a later one lie before an earlier one the reference's
+    //  unsigned arithmetic wraps -- sums[end] - sums[start] is then minus the sum in between)
+    double s = 0.0, q = 0.0;
+    const int64_t lo = start < end ? start : end, hi = start < end ? end : start;
+    for (int64_t i = lo; i < hi; ++i) { const float v = x[i]; s += (double)v; q += (double)(v * v); }
+    if (end < start) { s = -s; q = -q; }
+    const float length = (float)((uint64_t)end - (uint64_t)start);
+    const float mean = (float)s / length;
+    const float deltasqr = (float)q;
+    const float var = deltasqr / length - mean * mean;
+    event_length[eo + e] = length;
+    event_mean[eo + e] = mean;
+    event_stdv[eo + e] = sqrtf(fmaxf(var, 0.0f));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// estimate_scalings_using_mom (raw_loader.cpp:30-75) + the aligner's per-read constants (:99-108) + set4.
+// One wave per read; every sum is accumulated in the reference's order (terms staged 64 at a time in LDS, one lane
+// per sum adds its row front to back).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) np_mom_fill_kernel(int n_reads, np_read_dev* __restrict__ reads, np_read_dev* __restrict__ reads_b,
+                                                          const float* __restrict__ event_mean, const int32_t* __restrict__ n_events,
+                                                          const uint16_t* __restrict__ ranks, const np_state_dev* __restrict__ model)
+{
+    const int r = blockIdx.x;
+    if (r >= n_reads) return;
+    const int lane = threadIdx.x;
+    np_read_dev* rd = reads + r;
+    const int ne = n_events[r] > 0 ? n_events[r] : 0;
+    const int K = (int)rd->n_kmers;
+    const float* ev = event_mean + rd->event_off;
+    const uint16_t* rk = ranks + rd->rank_off;
+    __shared__ double terms[2][66];
+    double acc = 0.0;                                   // lane 0 / lane 1 own the sums of the current pass
+
+    // pass 1: event_level_sum
+    for (int base = 0; base < ne; base += 64) {
+        const int i = base + lane;
+        __syncthreads();
+        terms[0][lane] = i < ne ? (double)ev[i] : 0.0;
+        __syncthreads();
+        if (lane == 0) { for (int q = 0; q < 64; ++q) acc += terms[0][q]; }
+    }
+    const double event_level_sum = dbl_readlane(acc, 0);
+    // pass 2: kmer_level_sum, kmer_level_sq_sum (pow(l, 2) == l * l)
+    acc = 0.0;
+    for (int base = 0; base < K; base += 64) {
+        const int i = base + lane;
+        const double l = i < K ? model[rk[i]].level_mean : 0.0;
+        __syncthreads();
+        terms[0][lane] = l; terms[1][lane] = l * l;
+        __syncthreads();
+        if (lane < 2) { const double* row = terms[lane]; for (int q = 0; q < 64; ++q) acc += row[q]; }
+    }
+    const double kmer_level_sum = dbl_readlane(acc, 0), kmer_level_sq_sum = dbl_readlane(acc, 1);
+    const double shift = event_level_sum / (double)(uint32_t)ne - kmer_level_sum / (double)(uint32_t)K;
+    // pass 3: event_level_sq_sum
+    acc = 0.0;
+    for (int base = 0; base < ne; base += 64) {
+        const int i = base + lane;
+        double t = 0.0;
+        if (i < ne) { const double dlt = (double)ev[i] - shift; t = dlt * dlt; }
+        __syncthreads();
+        terms[0][lane] = t;
+        __syncthreads();
+        if (lane == 0) { for (int q = 0; q < 64; ++q) acc += terms[0][q]; }
+    }
+    const double event_level_sq_sum = dbl_readlane(acc, 0);
+    const double scale = (event_level_sq_sum / (double)(uint32_t)ne) / (kmer_level_sq_sum / (double)(uint32_t)K);
+
+    if (lane == 0) {
+        rd->n_events = (uint32_t)ne;
+        rd->scale = scale; rd->shift = shift; rd->var = 1.0; rd->log_var = 0.0;      // set4(shift, scale, 0, 1): log(1) == 0
+        // raw_loader.cpp:99-108, with glibc's log / exp restated (np_log.h)
+        const double events_per_kmer = (double)(uint32_t)ne / (double)(uint32_t)K;
+        const double p_stay = 1 - (1 / (events_per_kmer + 1));
+        const double epsilon = 1e-10;
+        rd->lp_skip = np_log_glibc(epsilon);
+        rd->lp_stay = np_log_glibc(p_stay);
+        rd->lp_step = np_log_glibc(1.0 - np_exp_glibc(rd->lp_skip) - np_exp_glibc(rd->lp_stay));
+        rd->lp_trim = np_log_glibc(0.01);
+        if (reads_b) reads_b[r].n_events = (uint32_t)ne;
+    }
+}
+
+} // namespace
+
+hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t* raw_off, int64_t max_samples, const np_detector_param& p,
+                                   float2* tstat, int32_t* status, const int64_t* event_off, int64_t max_events, uint32_t* event_start,
+                                   float* event_length, float* event_mean, float* event_stdv, int32_t* n_events, hipStream_t s)
+{
+    if (n_reads <= 0) return hipSuccess;
+    hipLaunchKernelGGL(np_ed_check_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, raw, raw_off, status);
+    const unsigned tiles = (unsigned)((max_samples + NP_ED_TILE - 1) / NP_ED_TILE);
+    if (tiles > 0)
+        hipLaunchKernelGGL(np_ed_tstat_kernel, dim3(n_reads, tiles), dim3(NP_ED_TILE), 0, s, n_reads, raw, raw_off, status,
+                           (int)p.window_length1, (int)p.window_length2, tstat);
+    hipLaunchKernelGGL(np_ed_peaks_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, raw_off, tstat, status, p, event_off,
+                       event_start, n_events);
+    const unsigned eblocks = (unsigned)((max_events + 255) / 256);
+    if (eblocks > 0)
+        hipLaunchKernelGGL(np_ed_events_kernel, dim3(n_reads, eblocks), dim3(256), 0, s, n_reads, raw, raw_off, event_off, event_start,
+                           n_events, event_length, event_mean, event_stdv);
+    return hipGetLastError();
+}
+
+hipError_t np_launch_mom_fill(int n_reads, np_read_dev* reads, np_read_dev* reads_b, const float* event_mean, const int32_t* n_events,
+                              const uint16_t* ranks, const np_state_dev* model, hipStream_t s)
+{
+    if (n_reads <= 0) return hipSuccess;
+    hipLaunchKernelGGL(np_mom_fill_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, reads, reads_b, event_mean, n_events, ranks, model);
+    return hipGetLastError();
+}

@@ -9,6 +9,7 @@
 //   * np_classify_kernel  : bins HMM work items into the (lanes, blocks-per-lane) size classes of np_hmm_kernels.hip
 #include "np_kernels.h"
 #include "np_logf.h"
+#include "np_log.h"
 
 namespace {
 
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(64) np_recalibrate_kernel(int n_reads, np_read
     var /= (double)(unsigned long long)n;
     var = sqrt(var);
     if (lane == 0) {
-        rd->shift = shift; rd->scale = scale; rd->var = var; rd->log_var = log(var);   // set4 (squiggle_read.cpp:38-65)
+        rd->shift = shift; rd->scale = scale; rd->var = var; rd->log_var = np_log_glibc(var);   // set4 (squiggle_read.cpp:38-65), glibc's log restated
         calibrated[ri] = var > 2.5 ? 0 : 1;                                            // MIN_CALIBRATION_VAR (:320)
     }
 }

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include "../../include/np_hmm.h"
 #include "np_logf.h"
+#include "np_log.h"
 
 namespace {
 
@@ -271,6 +272,24 @@ void np_fill_read_host(np_read_dev* r, double shift, double scale, double var,
     r->lp_step = log(1.0 - exp(r->lp_skip) - exp(r->lp_stay));
     r->lp_trim = log(0.01);
     r->event_off = event_off; r->rank_off = rank_off; r->n_events = n_events; r->n_kmers = n_kmers;
+}
+
+// The aligner's per-read constants (raw_loader.cpp:99-108) exactly as np_mom_fill_dev computes them on the device: glibc's
+// log / exp restated in np_log.h instead of libm calls.  Exposed so that the restatement can be checked against the
+// host's libm without a GPU (tests/test_host_logic.py).
+void np_aligner_constants(uint32_t n_events, uint32_t n_kmers, double out[4])
+{
+    const double events_per_kmer = (double)n_events / (double)n_kmers;
+    const double p_stay = 1 - (1 / (events_per_kmer + 1));
+    const double epsilon = 1e-10;
+    out[0] = np_log_glibc(epsilon);
+    out[1] = np_log_glibc(p_stay);
+    out[2] = np_log_glibc(1.0 - np_exp_glibc(out[0]) - np_exp_glibc(out[1]));
+    out[3] = np_log_glibc(0.01);
+}
+void np_restated_log_exp(const double* x, size_t n, double* out_log, double* out_exp)
+{
+    for (size_t i = 0; i < n; ++i) { out_log[i] = np_log_glibc(x[i]); out_exp[i] = np_exp_glibc(-x[i]); }
 }
 
 } // extern "C"

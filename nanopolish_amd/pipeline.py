@@ -1,5 +1,7 @@
 """Device-resident call-methylation pass over a batch of reads (the north-star path):
 
+    [from_raw=True: detect_events (scrappie) -> estimate_scalings_using_mom + aligner constants, all on the device
+     (SURVEY 8 f2): the batch then starts from raw current samples instead of events]
     adaptive_banded_simple_event_align  (kernel A, one wave per read)
       -> base_to_event_map / events_per_base / transitions / window event bounds  (glue kernels)
          [calibrate=True: + recalibrate_model on the event map, src/nanopolish_methyltrain.cpp:204-306, SURVEY 8 f1]
@@ -16,7 +18,7 @@ import numpy as np
 
 from . import lib as _l
 from . import api
-from .synth import synth_read
+from .synth import synth_read, synth_raw
 
 READ_DT = np.dtype([("scale", "<f8"), ("shift", "<f8"), ("var", "<f8"), ("log_var", "<f8"),
                     ("lp_skip", "<f8"), ("lp_stay", "<f8"), ("lp_step", "<f8"), ("lp_trim", "<f8"),
@@ -29,12 +31,17 @@ assert READ_DT.itemsize == C.sizeof(_l.ReadDev) and JOB_DT.itemsize == C.sizeof(
 HAF = api.HAF_ALLOW_PRE_CLIP | api.HAF_ALLOW_POST_CLIP
 
 
-def build_host_batch(models, read_ids, L=5450, k=6):
-    """Host-side preparation of the distinct reads of a batch (numpy only)."""
+def build_host_batch(models, read_ids, L=5450, k=6, raw=False):
+    """Host-side preparation of the distinct reads of a batch (numpy only).
+    raw=True: reads carry synthetic raw signal (synth_raw); the event arrays are then sized as CAPACITY for the device
+    detector (n_samples/2 + 2 per read) and hold no data, and the per-read records only carry offsets and n_kmers."""
     L_ = _l.load_library()
     nuc = models["nucleotide"]
-    reads = [synth_read(r, nuc, L=L, k=k) for r in read_ids]
+    reads = [(synth_raw if raw else synth_read)(r, nuc, L=L, k=k) for r in read_ids]
     n = len(reads)
+    if raw:
+        for r in reads:
+            r["events"] = np.zeros(len(r["raw"]) // 2 + 2, np.float32)          # capacity only
     event_off = np.zeros(n + 1, np.int64); rank_off = np.zeros(n + 1, np.int64)
     event_off[1:] = np.cumsum([len(r["events"]) for r in reads]); rank_off[1:] = np.cumsum([len(r["ranks"]) for r in reads])
     events = np.concatenate([r["events"] for r in reads]).astype(np.float32)
@@ -44,7 +51,7 @@ def build_host_batch(models, read_ids, L=5450, k=6):
     jobs, kpos, jranks, meta = [], [], [], []
     jr_off = 0
     for i, r in enumerate(reads):
-        sh, sc = api.estimate_scalings_using_mom(nuc, r["ranks"], r["events"])
+        sh, sc = (0.0, 1.0) if raw else api.estimate_scalings_using_mom(nuc, r["ranks"], r["events"])
         mom[i] = (sh, sc)
         ne, nk = len(r["events"]), len(r["ranks"])
         for arr, (shift, scale, var) in ((reads_a, (sh, sc, 1.0)), (reads_b, (r["shift"], r["scale"], r["var"]))):
@@ -68,8 +75,12 @@ def build_host_batch(models, read_ids, L=5450, k=6):
         jranks.append(jb["ranks_unmeth"]); jranks.append(jb["ranks_meth"])
         jr_off += 2 * tot
         meta.append(dict(first=jb["first"], last=jb["last"], n_motif=jb["n_motif"]))
+    extra = {}
+    if raw:
+        raw_off = np.zeros(n + 1, np.int64); raw_off[1:] = np.cumsum([len(r["raw"]) for r in reads])
+        extra = dict(raw=np.concatenate([r["raw"] for r in reads]).astype(np.float32), raw_off=raw_off)
     return dict(reads=reads, n=n, events=events, ranks=ranks, event_off=event_off, rank_off=rank_off,
-                reads_a=reads_a, reads_b=reads_b, mom=mom,
+                reads_a=reads_a, reads_b=reads_b, mom=mom, **extra,
                 jobs=np.concatenate(jobs) if jobs else np.zeros(0, JOB_DT),
                 kpos=np.concatenate(kpos).astype(np.int32) if kpos else np.zeros((0, 2), np.int32),
                 job_ranks=np.concatenate(jranks).astype(np.uint16) if jranks else np.zeros(0, np.uint16),
@@ -94,19 +105,24 @@ def tile_host_batch(hb, tile):
     j["read"] += np.repeat(np.arange(tile, dtype=np.uint32) * n, nj).astype(np.uint32)
     j["rank_off"] += np.repeat(np.arange(tile, dtype=np.int64) * njr, nj)
     out["jobs"] = j
+    if "raw" in hb:
+        ns = len(hb["raw"])
+        out["raw"] = np.tile(hb["raw"], tile)
+        out["raw_off"] = np.concatenate([hb["raw_off"][:-1] + t * ns for t in range(tile)] + [[ns * tile]]).astype(np.int64)
     out["event_off"] = np.concatenate([hb["event_off"][:-1] + t * ne for t in range(tile)] + [[ne * tile]]).astype(np.int64)
     out["rank_off"] = np.concatenate([hb["rank_off"][:-1] + t * nr for t in range(tile)] + [[nr * tile]]).astype(np.int64)
     return out
 
 
 class CallMethylationBatch:
-    def __init__(self, ctx, hb, device="cuda:0", calibrate=False):
+    def __init__(self, ctx, hb, device="cuda:0", calibrate=False, from_raw=False):
         """calibrate=False: kernel B scores with the scalings the caller put in hb["reads_b"] (a read whose
         calibration was done elsewhere).  calibrate=True: the pass recalibrates every read on the device from its
         own event alignment, as load_from_raw does (squiggle_read.cpp:304-323), and reads_b is overwritten."""
         import torch
         self.torch = torch
         self.calibrate = bool(calibrate)
+        self.from_raw = bool(from_raw)
         self.ctx = ctx
         self.hb = hb
         self.n_reads = hb["n"]
@@ -118,6 +134,20 @@ class CallMethylationBatch:
             return torch.from_numpy(a.view(np.uint8).reshape(-1)).to(dev)
 
         self.d_events = up(hb["events"]); self.d_ranks = up(hb["ranks"])
+        if self.from_raw:
+            # raw signal in, events out: the detector writes event means into d_events at the capacity offsets
+            self.d_raw = up(hb["raw"]); self.d_raw_off = up(hb["raw_off"]); self.d_event_off = up(hb["event_off"])
+            ns = hb["raw_off"][1:] - hb["raw_off"][:-1]
+            self.max_samples = int(ns.max()); self.total_samples = int(ns.sum())
+            ecap = hb["event_off"][1:] - hb["event_off"][:-1]
+            self.max_events = int(ecap.max())
+            nev = int(hb["event_off"][-1])
+            self.d_tstat = torch.empty(self.total_samples * 2, dtype=torch.float32, device=dev)
+            self.d_ev_start = torch.empty(nev, dtype=torch.int32, device=dev)
+            self.d_ev_len = torch.empty(nev, dtype=torch.float32, device=dev)
+            self.d_ev_stdv = torch.empty(nev, dtype=torch.float32, device=dev)
+            self.d_n_events = torch.zeros(self.n_reads, dtype=torch.int32, device=dev)
+            self.prm = _l.DetectorParam(); ctx.L.np_event_detection_params(C.byref(self.prm), 0)
         self.d_reads_a = up(hb["reads_a"]); self.d_reads_b = up(hb["reads_b"])
         self.d_jobs = up(hb["jobs"]); self.d_kpos = up(hb["kpos"]); self.d_job_ranks = up(hb["job_ranks"])
         ne = (hb["event_off"][1:] - hb["event_off"][:-1]); nk = (hb["rank_off"][1:] - hb["rank_off"][:-1])
@@ -146,6 +176,14 @@ class CallMethylationBatch:
     def step(self):
         L, h = self.ctx.L, self.ctx.h
         p = lambda t: C.c_void_p(t.data_ptr())
+        if self.from_raw:
+            rc = L.np_detect_events_dev(h, None, self.n_reads, p(self.d_raw), p(self.d_raw_off), self.max_samples, C.byref(self.prm),
+                                        p(self.d_tstat), p(self.d_event_off), self.max_events, p(self.d_ev_start), p(self.d_ev_len),
+                                        p(self.d_events), p(self.d_ev_stdv), p(self.d_n_events))
+            self.ctx._chk(rc, "np_detect_events_dev")
+            rc = L.np_mom_fill_dev(h, None, self.n_reads, p(self.d_reads_a), p(self.d_reads_b), p(self.d_events), p(self.d_n_events),
+                                   p(self.d_ranks), self.m_nuc)
+            self.ctx._chk(rc, "np_mom_fill_dev")
         rc = L.np_event_align_dev(h, None, self.n_reads, p(self.d_reads_a), p(self.d_events), p(self.d_ranks), self.m_nuc,
                                   self.max_bands, p(self.d_pair_off), p(self.d_pairs), p(self.d_pair_begin), p(self.d_n_pairs))
         self.ctx._chk(rc, "np_event_align_dev")
@@ -190,6 +228,19 @@ class CallMethylationBatch:
         """np_read_dev records kernel B used (after device calibration when calibrate=True)."""
         self.sync()
         return self.d_reads_b.cpu().numpy().view(READ_DT)
+
+    def detected(self, r):
+        """(n_events, start, length, mean, stdv) of read r as the device detector left them (from_raw=True)."""
+        self.sync()
+        n = int(self.d_n_events[r]); lo = int(self.hb["event_off"][r])
+        f = lambda t, dt: t[lo:lo + max(n, 0)].cpu().numpy().view(dt)
+        return n, f(self.d_ev_start, np.uint32), f(self.d_ev_len, np.float32), f(self.d_events.view(self.torch.float32), np.float32), \
+            f(self.d_ev_stdv, np.float32)
+
+    def reads_aligned(self):
+        """np_read_dev records kernel A used (MoM scalings + aligner constants; filled on the device when from_raw=True)."""
+        self.sync()
+        return self.d_reads_a.cpu().numpy().view(READ_DT)
 
     def calibrated(self):
         self.sync()

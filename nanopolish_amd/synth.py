@@ -77,3 +77,21 @@ def synth_read_from_codes(ref_codes, read_id, model, rc=False, k=6, seed0=SEED0)
     events = (scale * model["level_mean"][rk] + shift + var * model["level_stdv"][rk] * rng.standard_normal(len(rk))).astype(np.float32)
     return dict(read_id=int(read_id), seq=seq, codes=codes.astype(np.uint8), ranks=ranks, events=events,
                 shift=float(shift), scale=float(scale), var=float(var), rc=bool(rc))
+
+
+def synth_raw(read_id, model, L=5000, k=6, seed0=SEED0, samples_per_kmer=8.9, noise=1.0):
+    """Synthetic RAW current trace (pA, float32) of a read, for the event-detection stage:
+    the read of synth_read(read_id) dwells on every k-mer for 1 + Poisson(samples_per_kmer - 1) samples (4 kHz sampling
+    at 450 bases/s is ~8.9 samples per base) at its scaled model level, with white noise of the k-mer's scaled stdv.
+    Values are kept >= 8 pA, like real open-channel-normalised signal (and comfortably inside the range where the
+    detector's double-precision prefix sums are exact)."""
+    rd = synth_read(read_id, model, L, k, seed0)
+    rng = np.random.default_rng(seed0 + 104729 * (int(read_id) + 1))
+    K = len(rd["ranks"])
+    dwell = 1 + rng.poisson(samples_per_kmer - 1.0, K)
+    rk = np.repeat(rd["ranks"], dwell)
+    mu = rd["scale"] * model["level_mean"][rk] + rd["shift"]
+    sd = noise * rd["var"] * model["level_stdv"][rk]
+    raw = np.maximum(mu + sd * rng.standard_normal(len(rk)), 8.0).astype(np.float32)
+    rd = dict(rd); rd["raw"] = raw; rd["dwell"] = dwell
+    return rd

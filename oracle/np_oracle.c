@@ -950,3 +950,143 @@ int npo_recalibrate(const npo_model* m, const float* event_mean, const uint32_t*
     free(raw_events); free(level_means); free(level_stdvs);
     return recalibrated;
 }
+
+/* =====================================================================================
+ * f2: scrappie event detection -- src/thirdparty/scrappie/event_detection.c (vendored in the reference),
+ * called on the whole raw table by SquiggleRead::load_from_raw (src/nanopolish_squiggle_read.cpp:229-236;
+ * trim_and_segment_raw's result is discarded there, so no trimming takes effect).
+ * Pinned against the reference's own object code (oracle/_ref) by tests/test_oracle_vs_ref.py.
+ * ===================================================================================== */
+typedef struct {
+    int def_peak_pos; float def_peak_val;
+    const float* signal; size_t signal_length; float threshold; size_t window_length;
+    size_t masked_to; int peak_pos; float peak_value; int valid_peak;
+} ed_detector;                                          /* Detector, event_detection.c:10-21 */
+
+/* compute_tstat, event_detection.c:63-119 */
+static void ed_compute_tstat(const double* sum, const double* sumsq, size_t d_length, size_t w_length, float* tstat)
+{
+    const float eta = 1.17549435e-38f;                  /* FLT_MIN */
+    const float w_lengthf = (float)w_length;
+    for(size_t i = 0; i < d_length; ++i) tstat[i] = 0.0f;                       /* calloc + quick return / boundaries */
+    if(d_length < 2 * w_length || w_length < 2) return;
+    for(size_t i = w_length; i <= d_length - w_length; ++i) {
+        double sum1 = sum[i];
+        double sumsq1 = sumsq[i];
+        if(i > w_length) { sum1 -= sum[i - w_length]; sumsq1 -= sumsq[i - w_length]; }
+        float sum2 = (float)(sum[i + w_length] - sum[i]);
+        float sumsq2 = (float)(sumsq[i + w_length] - sumsq[i]);
+        float mean1 = sum1 / w_lengthf;
+        float mean2 = sum2 / w_lengthf;
+        float combined_var = sumsq1 / w_lengthf - mean1 * mean1 + sumsq2 / w_lengthf - mean2 * mean2;
+        combined_var = fmaxf(combined_var, eta);
+        const float delta_mean = mean2 - mean1;
+        tstat[i] = fabs(delta_mean) / sqrt(combined_var / w_lengthf);
+    }
+}
+
+/* short_long_peak_detector, event_detection.c:126-207; returns the number of peaks written */
+static size_t ed_peaks(ed_detector* sd, ed_detector* ld, float peak_height, size_t* peaks)
+{
+    ed_detector* detectors[2] = { sd, ld };
+    size_t peak_count = 0;
+    for(size_t i = 0; i < sd->signal_length; i++) {
+        for(int k = 0; k < 2; k++) {
+            ed_detector* d = detectors[k];
+            if(d->masked_to >= i) continue;
+            float current_value = d->signal[i];
+            if(d->peak_pos == d->def_peak_pos) {
+                if(current_value < d->peak_value) {
+                    d->peak_value = current_value;
+                } else if(current_value - d->peak_value > peak_height) {
+                    d->peak_value = current_value;
+                    d->peak_pos = (int)i;
+                }
+            } else {
+                if(current_value > d->peak_value) { d->peak_value = current_value; d->peak_pos = (int)i; }
+                if(d == sd) {
+                    if(d->peak_value > d->threshold) {
+                        ld->masked_to = d->peak_pos + d->window_length;
+                        ld->peak_pos = ld->def_peak_pos;
+                        ld->peak_value = ld->def_peak_val;
+                        ld->valid_peak = 0;
+                    }
+                }
+                if(d->peak_value - current_value > peak_height && d->peak_value > d->threshold) d->valid_peak = 1;
+                if(d->valid_peak && (i - d->peak_pos) > d->window_length / 2) {
+                    peaks[peak_count++] = (size_t)d->peak_pos;
+                    d->peak_pos = d->def_peak_pos;
+                    d->peak_value = current_value;
+                    d->valid_peak = 0;
+                }
+            }
+        }
+    }
+    return peak_count;
+}
+
+/* detect_events, event_detection.c:268-319 (compute_sum_sumsq :35-50, create_event :223-241, create_events :243-266).
+ * Returns the number of events (1 + #peaks); 0 when there is no peak at all -- the reference then reads peaks[-1]
+ * (undefined behaviour), which no read with real signal reaches. */
+int npo_detect_events(const float* raw, size_t n, size_t w1, size_t w2, float t1, float t2, float peak_height,
+                      uint64_t* out_start, float* out_length, float* out_mean, float* out_stdv, size_t cap)
+{
+    double* sums = (double*)calloc(n + 1, sizeof(double));
+    double* sumsqs = (double*)calloc(n + 1, sizeof(double));
+    float* ts1 = (float*)malloc(sizeof(float) * (n ? n : 1));
+    float* ts2 = (float*)malloc(sizeof(float) * (n ? n : 1));
+    size_t* peaks = (size_t*)calloc(n ? n : 1, sizeof(size_t));
+    sums[0] = 0.0f; sumsqs[0] = 0.0f;
+    for(size_t i = 0; i < n; ++i) {
+        sums[i + 1] = sums[i] + raw[i];
+        sumsqs[i + 1] = sumsqs[i] + raw[i] * raw[i];          /* float product, double accumulation (:47) */
+    }
+    ed_compute_tstat(sums, sumsqs, n, w1, ts1);
+    ed_compute_tstat(sums, sumsqs, n, w2, ts2);
+    ed_detector sd = { -1, 3.40282347e+38f, ts1, n, t1, w1, 0, -1, 3.40282347e+38f, 0 };
+    ed_detector ld = { -1, 3.40282347e+38f, ts2, n, t2, w2, 0, -1, 3.40282347e+38f, 0 };
+    const size_t n_peaks = ed_peaks(&sd, &ld, peak_height, peaks);
+    int n_ev = 0;
+    if(n_peaks > 0) {
+        n_ev = (int)n_peaks + 1;
+        for(size_t ev = 0; ev < (size_t)n_ev && ev < cap; ++ev) {
+            const size_t start = ev == 0 ? 0 : peaks[ev - 1];
+            const size_t end = ev == (size_t)n_ev - 1 ? n : peaks[ev];
+            const float length = (float)(end - start);
+            const float mean = (float)(sums[end] - sums[start]) / length;
+            const float deltasqr = (sumsqs[end] - sumsqs[start]);
+            const float var = deltasqr / length - mean * mean;
+            out_start[ev] = (uint64_t)start; out_length[ev] = length; out_mean[ev] = mean; out_stdv[ev] = sqrtf(fmaxf(var, 0.0f));
+        }
+    }
+    free(sums); free(sumsqs); free(ts1); free(ts2); free(peaks);
+    return n_ev;
+}
+
+/* bounded driver for bench.py's cpu_baseline (kind = "port") */
+void npo_detect_events_many(int n_reads, const float* raw, const int64_t* raw_off, float* out_mean, const int64_t* ev_off,
+                            int32_t* out_n, int n_threads)
+{
+#pragma omp parallel for schedule(dynamic) num_threads(n_threads)
+    for(int r = 0; r < n_reads; ++r) {
+        const size_t n = (size_t)(raw_off[r + 1] - raw_off[r]);
+        const size_t cap = (size_t)(ev_off[r + 1] - ev_off[r]);
+        uint64_t* st = (uint64_t*)malloc(sizeof(uint64_t) * (cap ? cap : 1));
+        float* ln = (float*)malloc(sizeof(float) * (cap ? cap : 1));
+        float* sv = (float*)malloc(sizeof(float) * (cap ? cap : 1));
+        out_n[r] = npo_detect_events(raw + raw_off[r], n, 3, 6, 1.4f, 9.0f, 0.2f, st, ln, out_mean + ev_off[r], sv, cap);
+        free(st); free(ln); free(sv);
+    }
+}
+
+/* the aligner's per-read constants on their own (raw_loader.cpp:99-108), for checking the device's restated log/exp */
+void npo_aligner_constants(uint32_t n_events, uint32_t n_kmers, double out[4])
+{
+    double events_per_kmer = (double)n_events / n_kmers;
+    double p_stay = 1 - (1 / (events_per_kmer + 1));
+    double epsilon = 1e-10;
+    out[0] = log(epsilon);
+    out[1] = log(p_stay);
+    out[2] = log(1.0 - exp(out[0]) - exp(out[1]));
+    out[3] = log(0.01);
+}

@@ -11,6 +11,7 @@
 #ifndef NP_ORACLE_H
 #define NP_ORACLE_H
 #include <stdint.h>
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -91,6 +92,14 @@ int  npo_get_closest_event_to(const int32_t* start, uint32_t n_kmers, int k_idx)
  * scale_var, no drift).  Returns 1 if recalibrated.  The Eigen fullPivLu step is restated without Eigen (unpinned). */
 int  npo_recalibrate(const npo_model* m, const float* event_mean, const uint32_t* kmer_ranks, uint32_t n_kmers,
                      const int32_t* map_start, const int32_t* map_stop, double* shift, double* scale, double* var);
+
+/* ---- f2: scrappie event detection (src/thirdparty/scrappie/event_detection.c:268-319) on a whole raw table ------- */
+int  npo_detect_events(const float* raw, size_t n, size_t w1, size_t w2, float t1, float t2, float peak_height,
+                       uint64_t* out_start, float* out_length, float* out_mean, float* out_stdv, size_t cap);
+void npo_detect_events_many(int n_reads, const float* raw, const int64_t* raw_off, float* out_mean, const int64_t* ev_off,
+                            int32_t* out_n, int n_threads);
+
+void npo_aligner_constants(uint32_t n_events, uint32_t n_kmers, double out[4]);   /* raw_loader.cpp:99-108 */
 
 /* ---- call-methylation work-item rules: src/basemods/nanopolish_basemods.cpp:298-358 ---------------- */
 /* EventAlignmentRecord (src/alignment/nanopolish_alignment_db.cpp:55-91): maps aligned bases to events.

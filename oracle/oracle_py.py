@@ -53,6 +53,36 @@ class _Scalings(C.Structure):
                 ("var", C.c_double), ("log_var", C.c_double)]
 
 
+ED_DEFAULTS = dict(w1=3, w2=6, t1=1.4, t2=9.0, peak_height=0.2)      # event_detection_defaults, event_detection.h:15-21
+ED_RNA = dict(w1=7, w2=14, t1=2.5, t2=9.0, peak_height=1.0)           # event_detection_rna, :23-29
+
+
+def _detect_events(L, prefix, raw, w1, w2, t1, t2, peak_height):
+    """detect_events on a whole raw table -> dict(start u64, length f32, mean f32, stdv f32) (f2)."""
+    raw = np.ascontiguousarray(raw, np.float32)
+    cap = len(raw) + 1
+    st = np.zeros(cap, np.uint64); ln = np.zeros(cap, np.float32); mn = np.zeros(cap, np.float32); sd = np.zeros(cap, np.float32)
+    fn = getattr(L, prefix + "_detect_events")
+    fn.argtypes = [c_f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float, C.c_float, C.c_float,
+                   C.POINTER(C.c_uint64), c_f32p, c_f32p, c_f32p, C.c_size_t]
+    n = fn(_p(raw, c_f32p), len(raw), w1, w2, t1, t2, peak_height, st.ctypes.data_as(C.POINTER(C.c_uint64)),
+           _p(ln, c_f32p), _p(mn, c_f32p), _p(sd, c_f32p), cap)
+    n = max(n, 0)
+    return dict(start=st[:n].copy(), length=ln[:n].copy(), mean=mn[:n].copy(), stdv=sd[:n].copy())
+
+
+def _detect_events_many(L, prefix, raw, raw_off, n_threads):
+    raw = np.ascontiguousarray(raw, np.float32); raw_off = np.ascontiguousarray(raw_off, np.int64)
+    n = len(raw_off) - 1
+    ev_off = np.zeros(n + 1, np.int64); ev_off[1:] = np.cumsum((raw_off[1:] - raw_off[:-1]) // 2 + 2)
+    out = np.zeros(int(ev_off[-1]), np.float32); out_n = np.zeros(n, np.int32)
+    fn = getattr(L, prefix + "_detect_events_many")
+    fn.argtypes = [C.c_int, c_f32p, c_i64p, c_f32p, c_i64p, c_i32p, C.c_int]
+    t0 = time.perf_counter()
+    fn(n, _p(raw, c_f32p), _p(raw_off, c_i64p), _p(out, c_f32p), _p(ev_off, c_i64p), _p(out_n, c_i32p), int(n_threads))
+    return out, ev_off, out_n, time.perf_counter() - t0
+
+
 class Oracle:
     """The portable C restatement (oracle/np_oracle.c)."""
 
@@ -233,6 +263,18 @@ class Oracle:
                                          _p(f, c_i32p), _p(l, c_i32p), _p(c, c_i32p), cap)
         return f[:n].copy(), l[:n].copy(), c[:n].copy()
 
+    def detect_events(self, raw, w1=3, w2=6, t1=1.4, t2=9.0, peak_height=0.2):
+        return _detect_events(self.L, "npo", raw, w1, w2, t1, t2, peak_height)
+
+    def aligner_constants(self, n_events, n_kmers):
+        out = np.zeros(4)
+        self.L.npo_aligner_constants(C.c_uint32(n_events), C.c_uint32(n_kmers), _p(out, c_f64p))
+        return tuple(float(v) for v in out)
+
+    def detect_events_many(self, raw, raw_off, n_threads=1):
+        out, ev_off, out_n, self.last_call_s = _detect_events_many(self.L, "npo", raw, raw_off, n_threads)
+        return out, ev_off, out_n
+
     # -- bounded drivers for the CPU baseline ---------------------------------------------------------------
     def align_many(self, model, events, event_off, ranks, rank_off, shift, scale, n_threads=1):
         n_reads = len(event_off) - 1
@@ -377,6 +419,13 @@ class RefOracle:
                                    shift, scale, var, events_per_base, indel_bias, flags,
                                    _p(ev, c_u32p), _p(km, c_u32p), _p(lf, c_f64p), st, cap)
         return ev[:n].copy(), km[:n].copy(), lf[:n].copy(), np.frombuffer(st.raw[:n], np.uint8).copy()
+
+    def detect_events(self, raw, w1=3, w2=6, t1=1.4, t2=9.0, peak_height=0.2):
+        return _detect_events(self.L, "npref", raw, w1, w2, t1, t2, peak_height)
+
+    def detect_events_many(self, raw, raw_off, n_threads=1):
+        out, ev_off, out_n, self.last_call_s = _detect_events_many(self.L, "npref", raw, raw_off, n_threads)
+        return out, ev_off, out_n
 
     # -- bounded drivers for the CPU baseline (kind="reference") --------------------------------------------
     def align_many(self, seqs, events, event_off, shift, scale, n_threads=1):

@@ -304,4 +304,38 @@ void npref_score_many_reads(const char* kit, const char* alphabet, int n_reads,
     }
 }
 
+// ---- f2: scrappie event detection (src/thirdparty/scrappie/event_detection.c:268-319), as called by
+//      SquiggleRead::load_from_raw (src/nanopolish_squiggle_read.cpp:229-236) on the whole raw table -----------------
+extern "C" {
+#include "event_detection.h"
+}
+int npref_detect_events(const float* raw, size_t n, size_t w1, size_t w2, float t1, float t2, float peak_height,
+                        uint64_t* out_start, float* out_length, float* out_mean, float* out_stdv, size_t cap)
+{
+    raw_table rt; rt.n = n; rt.start = 0; rt.end = n; rt.raw = const_cast<float*>(raw);
+    detector_param p; p.window_length1 = w1; p.window_length2 = w2; p.threshold1 = t1; p.threshold2 = t2; p.peak_height = peak_height;
+    event_table et = detect_events(rt, p);
+    if (et.event == NULL) return -1;
+    const size_t m = et.n < cap ? et.n : cap;
+    for (size_t i = 0; i < m; ++i) {
+        out_start[i] = et.event[i].start; out_length[i] = et.event[i].length; out_mean[i] = et.event[i].mean; out_stdv[i] = et.event[i].stdv;
+    }
+    const int n_ev = (int)et.n;
+    free(et.event);
+    return n_ev;
+}
+void npref_detect_events_many(int n_reads, const float* raw, const int64_t* raw_off, float* out_mean, const int64_t* ev_off, int32_t* out_n,
+                              int n_threads)
+{
+#pragma omp parallel for schedule(dynamic) num_threads(n_threads)
+    for (int r = 0; r < n_reads; ++r) {
+        raw_table rt; rt.n = (size_t)(raw_off[r + 1] - raw_off[r]); rt.start = 0; rt.end = rt.n; rt.raw = const_cast<float*>(raw + raw_off[r]);
+        event_table et = detect_events(rt, event_detection_defaults);
+        const size_t cap = (size_t)(ev_off[r + 1] - ev_off[r]);
+        for (size_t i = 0; i < et.n && i < cap; ++i) out_mean[ev_off[r] + i] = et.event[i].mean;
+        out_n[r] = (int32_t)et.n;
+        free(et.event);
+    }
+}
+
 } // extern "C"

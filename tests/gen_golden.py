@@ -123,6 +123,20 @@ def main():
                                             sg["e1"], sg["e1"] + 40, 1, 0, rd["shift"], rd["scale"], rd["var"], epb2, 0.9, 0))
             g[p + "score_set"] = np.array(ss, np.float32)
     np.savez_compressed(os.path.join(GOLD, "golden_reads.npz"), **g)
+
+    # ---------------- f2: event detection on synthetic raw signal (reference's own scrappie objects) ----------------
+    from nanopolish_amd.synth import synth_raw
+    from oracle.oracle_py import ED_DEFAULTS, ED_RNA
+    e = dict(read_ids=np.array([0, 1, 2]), read_L=np.array([600, 1500, 300]))
+    for rid, L in zip(e["read_ids"], e["read_L"]):
+        rd = synth_raw(int(rid), nuc, L=int(L))
+        for tag, prm in (("dna", ED_DEFAULTS), ("rna", ED_RNA)):
+            ev = ref.detect_events(rd["raw"], **prm)
+            q = "r%d_%s_" % (rid, tag)
+            for k2 in ("start", "length", "mean", "stdv"):
+                e[q + k2] = ev[k2]
+        e["r%d_raw_crc" % rid] = np.array([np.frombuffer(rd["raw"].tobytes(), np.uint32).sum(dtype=np.uint64)])
+    np.savez_compressed(os.path.join(GOLD, "golden_events.npz"), **e)
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
 

@@ -1,0 +1,77 @@
+"""GPU parity of the stage in front of the event aligner: scrappie event detection, the
+method-of-moments scalings and the aligner's per-read constants on the device, vs the oracle (which is pinned to the
+reference's own scrappie objects) and the committed goldens.  Bit-exact."""
+import os
+import numpy as np
+import pytest
+
+from cases import call_methylation_read
+from nanopolish_amd.synth import synth_raw
+from oracle.oracle_py import ED_DEFAULTS, ED_RNA
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    return all(np.array_equal(a[k], np.asarray(b[k]).astype(a[k].dtype), equal_nan=True) for k in ("start", "length", "mean", "stdv"))
+
+
+def test_detect_events_matches_oracle_and_goldens(ctx, orc, models):
+    rng = np.random.default_rng(5)
+    raws = [synth_raw(r, models["nucleotide"], L=L)["raw"] for r, L in ((3, 400), (4, 2000), (5, 120), (6, 5450))]
+    raws.append((80 + 10 * rng.standard_normal(3000)).astype(np.float32))            # white noise
+    raws.append(np.repeat(rng.uniform(60, 120, 60), 25).astype(np.float32))           # noiseless steps: zero-variance windows
+    raws.append(synth_raw(7, models["nucleotide"], L=300)["raw"][:40])                # shorter than a few windows
+    for rna, prm in ((False, ED_DEFAULTS), (True, ED_RNA)):
+        got = ctx.detect_events(raws, rna=rna)
+        for raw, g in zip(raws, got):
+            want = orc.detect_events(raw, **prm)
+            assert len(g["mean"]) == len(want["mean"]) and _same(g, want)
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_events.npz"))
+    for rid, L in zip(gold["read_ids"], gold["read_L"]):
+        raw = synth_raw(int(rid), models["nucleotide"], L=int(L))["raw"]
+        for tag, rna in (("dna", False), ("rna", True)):
+            g = ctx.detect_events([raw], rna=rna)[0]
+            assert _same(g, {k: gold["r%d_%s_%s" % (rid, tag, k)] for k in ("start", "length", "mean", "stdv")})
+
+
+def test_detector_declines_reads_whose_sums_are_not_provably_exact(ctx, models):
+    """A 50k-sample read with one sample of 1e-3 pA: the reference's double prefix sums of squares round, so an
+    order-independent evaluation is no longer guaranteed identical -- the library says so instead of approximating."""
+    raw = synth_raw(8, models["nucleotide"], L=5450)["raw"].copy()
+    raw[1234] = 1e-3
+    with pytest.raises(RuntimeError):
+        ctx.detect_events([raw])
+
+
+def test_pass_from_raw_signal_matches_oracle(ctx, orc, models):
+    """raw samples -> detect_events -> MoM scalings + aligner constants -> event align -> recalibrate -> 2 x score per CpG group,
+    every stage on the device, vs the same chain on the oracle."""
+    from nanopolish_amd.pipeline import build_host_batch, CallMethylationBatch
+    mn = orc.model(models["nucleotide"]); mc = orc.model(models["cpg"])
+    hb = build_host_batch(models, list(range(90, 98)), L=2000, raw=True)
+    batch = CallMethylationBatch(ctx, hb, "cuda:0", calibrate=True, from_raw=True)
+    batch.step(); batch.step()
+    scores = batch.scores(); ra = batch.reads_aligned(); cal = batch.calibrated(); rb = batch.reads_scored()
+    g0 = 0; n_scored = 0
+    for i, rd in enumerate(hb["reads"]):
+        ev = orc.detect_events(rd["raw"], **ED_DEFAULTS)
+        n, st, ln, mean, sd = batch.detected(i)
+        assert n == len(ev["mean"]) and np.array_equal(mean, ev["mean"]) and np.array_equal(sd, ev["stdv"])
+        assert np.array_equal(st, ev["start"].astype(np.uint32)) and np.array_equal(ln, ev["length"])
+        rd2 = dict(rd, events=ev["mean"])
+        want = call_methylation_read(orc, mn, mc, rd2, calibrate=True)
+        assert (ra["shift"][i], ra["scale"][i]) == want["mom"]
+        assert (ra["lp_skip"][i], ra["lp_stay"][i], ra["lp_step"][i], ra["lp_trim"][i]) == orc.aligner_constants(len(ev["mean"]), len(rd["ranks"]))
+        assert np.array_equal(batch.pairs_of(i), want["pairs"])
+        assert bool(cal[i]) == want["calibrated"]
+        if want["scalings"] is not None:
+            assert (rb["shift"][i], rb["scale"][i], rb["var"][i]) == want["scalings"]
+            assert rb["log_var"][i] == orc.scalings(*want["scalings"]).log_var          # set4's log(var), glibc's log restated
+        firsts = list(hb["meta"][i]["first"])
+        for f, u, m in zip(want["first"], want["unmeth"], want["meth"]):
+            g = g0 + firsts.index(f)
+            assert scores[2 * g] == u and scores[2 * g + 1] == m
+            n_scored += 1
+        g0 += len(firsts)
+    assert n_scored > 300

@@ -171,8 +171,8 @@ def test_fused_call_methylation_pass_matches_oracle(ctx, orc, models):
 
 def test_calibrated_pass_matches_oracle(ctx, orc, models):
     """the pass with recalibrate_model on the device between kernel A and kernel B.
-    shift/scale/var are bit-equal to the restatement (same term order, same 2x2 full-pivot solve); log_var comes from
-    the device's log() and may differ from libm's by one ulp (tolerance below); scores are compared bit for bit.
+    shift/scale/var are bit-equal to the restatement (same term order, same 2x2 full-pivot solve); log_var comes from the
+    library's restatement of glibc's log (csrc/np_log.h) and is bit-equal too; scores are compared bit for bit.
     Read 84 has too few events to calibrate (< 200 'M' entries) and must be skipped whole."""
     from cases import call_methylation_read
     from nanopolish_amd.pipeline import build_host_batch, CallMethylationBatch
@@ -198,7 +198,7 @@ def test_calibrated_pass_matches_oracle(ctx, orc, models):
             if want["scalings"] is not None:
                 sh, sc, va = want["scalings"]
                 assert rds["shift"][i] == sh and rds["scale"][i] == sc and rds["var"][i] == va
-                assert abs(rds["log_var"][i] - np.log(va)) <= np.spacing(abs(np.log(va)))
+                assert rds["log_var"][i] == orc.scalings(sh, sc, va).log_var          # glibc's log restated on the device
             scored = set()
             for f, u, m in zip(want["first"], want["unmeth"], want["meth"]):
                 g = g0 + firsts.index(f)

@@ -142,3 +142,27 @@ def test_oracle_recalibrate_solves_the_weighted_normal_equations(orc, models):
     p2 = orc.event_align(mn, orc.scalings(sh, sc, 1.0), short["events"], short["ranks"])
     s2, t2, _ = orc.build_base_to_event_map(p2, len(short["ranks"]))
     assert orc.recalibrate(mn, short["events"], short["ranks"], s2, t2) is None
+
+
+def test_restated_glibc_log_exp_match_host_libm(L):
+    """csrc/np_log.h restates glibc's double log/exp (FMA build); the device computes the aligner's per-read constants and
+    set4's log(var) with it.  Checked against this host's libm (scalar calls through ctypes) and, through
+    np_aligner_constants, against np_fill_read_host, which calls libm as the reference does."""
+    import ctypes as C
+    from nanopolish_amd import lib as _l
+    m = C.CDLL("libm.so.6")
+    m.log.restype = C.c_double; m.log.argtypes = [C.c_double]; m.exp.restype = C.c_double; m.exp.argtypes = [C.c_double]
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(1e-12, 3, 60000), np.exp(rng.uniform(-30, 30, 30000)), 1 + rng.uniform(-0.07, 0.07, 60000),
+                        [1.0, 0.5, 2.0, 1e-10, 0.01, 1 - 1e-10, 0.9375, 1.06469]])
+    ol = np.zeros_like(x); oe = np.zeros_like(x)
+    L.np_restated_log_exp(x.ctypes.data_as(_l.c_f64p), len(x), ol.ctypes.data_as(_l.c_f64p), oe.ctypes.data_as(_l.c_f64p))
+    assert np.array_equal(ol, np.array([m.log(float(v)) for v in x]))
+    dom = x < 512.0                                           # np_exp_glibc covers |x| < 512 (log-probabilities)
+    assert np.array_equal(oe[dom], np.array([m.exp(-float(v)) for v in x[dom]])) and np.isnan(oe[~dom]).all()
+    rd = _l.ReadDev(); out = np.zeros(4)
+    for ne in range(50, 30000, 61):
+        for nk in (97, 1000, 5445):
+            L.np_fill_read_host(C.byref(rd), 0.0, 1.0, 1.0, 0, ne, 0, nk)
+            L.np_aligner_constants(ne, nk, out.ctypes.data_as(_l.c_f64p))
+            assert (out[0], out[1], out[2], out[3]) == (rd.lp_skip, rd.lp_stay, rd.lp_step, rd.lp_trim), (ne, nk)

@@ -102,3 +102,19 @@ def test_reads_align_score_viterbi(orc, models, greads):
                 ss.append(orc.combine_score_set([s0, s1]))
             assert np.array_equal(np.array(ss, np.float32), g[p + "score_set"])
     assert n_scores > 200 and n_states > 1000
+
+
+def test_event_detection_matches_reference_goldens(orc, models):
+    """f2: npo_detect_events vs the events the reference's own scrappie objects produced (tests/gen_golden.py)."""
+    import os
+    from nanopolish_amd.synth import synth_raw
+    from oracle.oracle_py import ED_DEFAULTS, ED_RNA
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_events.npz"))
+    for rid, L in zip(g["read_ids"], g["read_L"]):
+        rd = synth_raw(int(rid), models["nucleotide"], L=int(L))
+        assert np.frombuffer(rd["raw"].tobytes(), np.uint32).sum(dtype=np.uint64) == g["r%d_raw_crc" % rid][0], "synthetic raw changed"
+        for tag, prm in (("dna", ED_DEFAULTS), ("rna", ED_RNA)):
+            ev = orc.detect_events(rd["raw"], **prm)
+            for k in ("start", "length", "mean", "stdv"):
+                assert np.array_equal(ev[k], g["r%d_%s_%s" % (rid, tag, k)]), (rid, tag, k)
+        assert len(ev["mean"]) > 50

@@ -75,3 +75,19 @@ def test_qc_failure_matches(ref, orc, models):
     sh, sc = ref.estimate_scalings_mom(other["seq"], rd["events"])
     assert len(ref.event_align(rd["events"], other["seq"], sh, sc)) == 0
     assert len(orc.event_align(mn, orc.scalings(sh, sc, 1.0), rd["events"], other["ranks"])) == 0
+
+
+def test_event_detection_bit_equal(ref, orc, models):
+    """f2: the restated detector vs the reference's scrappie objects on seeded raw signal, incl. degenerate inputs."""
+    from nanopolish_amd.synth import synth_raw
+    from oracle.oracle_py import ED_DEFAULTS, ED_RNA
+    rng = np.random.default_rng(5)
+    raws = [synth_raw(r, models["nucleotide"], L=L)["raw"] for r, L in ((3, 400), (4, 2000), (5, 120))]
+    raws.append((80 + 10 * rng.standard_normal(3000)).astype(np.float32))            # white noise
+    raws.append(np.repeat(rng.uniform(60, 120, 60), 25).astype(np.float32))           # noiseless steps (zero variance windows)
+    raws.append(synth_raw(6, models["nucleotide"], L=300)["raw"][:40])                # very short
+    for raw in raws:
+        for prm in (ED_DEFAULTS, ED_RNA):
+            a, b = orc.detect_events(raw, **prm), ref.detect_events(raw, **prm)
+            for k in a:
+                assert np.array_equal(a[k], b[k], equal_nan=True), k
