@@ -4,7 +4,8 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of synthetic R9.4 reads already resident in HBM:
-adaptive_banded_simple_event_align -> event map / recalibration / window bounds -> 2 x profile_hmm_score per CpG group
+[scrappie event detection -> MoM scalings ->] adaptive_banded_simple_event_align -> event map / recalibration / window
+bounds -> 2 x profile_hmm_score per CpG group
 (workload = BASELINE.json configs[1]: ~8k-event reads, r9.4_450bps CpG model).  Reads shard across ranks
 with no data-path collective (weak scaling); the only exchange is one all-reduce of the per-site table
 at the end of the timed region (N > 1).  Rank 0 prints ONE JSON line.
@@ -27,7 +28,7 @@ def load_models():
                     level_log_stdv=z[a + "_level_log_stdv"]) for a in ("nucleotide", "cpg")}
 
 
-def cpu_baseline(models, hb, n_sample, threads, calibrate):
+def cpu_baseline(models, hb, n_sample, threads, calibrate, from_raw=False):
     """CPU baseline on this box's host cores over a bounded sample of the same reads: align + 2 x score per group,
     OpenMP over reads like src/common/nanopolish_bam_processor.cpp:99.  Uses the reference's own code when
     oracle/_ref/libnp_ref.so travelled with the repo (kind="reference"), else the oracle port (kind="port").
@@ -39,17 +40,33 @@ def cpu_baseline(models, hb, n_sample, threads, calibrate):
     mn = orc.model(models["nucleotide"]); mc = orc.model(models["cpg"])
     n = min(n_sample, len(hb["reads"]))
     rds = hb["reads"][:n]
-    eo = hb["event_off"][:n + 1]; ro = hb["rank_off"][:n + 1]
-    ev = hb["events"][:eo[-1]]; rk = hb["ranks"][:ro[-1]].astype(np.uint32)
+    t_detect = 0.0
+    mom = hb["mom"][:n].copy()
+    if from_raw:
+        # event detection with the reference's own scrappie objects (kind="reference") or the port, then MoM on the host
+        wo = hb["raw_off"][:n + 1]
+        t_detect = 1e30
+        for _ in range(2):
+            evm, evo, evn = (ref or orc).detect_events_many(hb["raw"][:wo[-1]], wo, threads)
+            t_detect = min(t_detect, (ref or orc).last_call_s)
+        rds = [dict(r, events=evm[evo[i]:evo[i] + evn[i]].copy()) for i, r in enumerate(rds)]
+        for i, r in enumerate(rds):
+            mom[i] = orc.estimate_scalings_mom(mn, r["ranks"], r["events"])
+        eo = np.zeros(n + 1, np.int64); eo[1:] = np.cumsum(evn)
+        ev = np.concatenate([r["events"] for r in rds]).astype(np.float32)
+        ro = hb["rank_off"][:n + 1]; rk = hb["ranks"][:ro[-1]].astype(np.uint32)
+    else:
+        eo = hb["event_off"][:n + 1]; ro = hb["rank_off"][:n + 1]
+        ev = hb["events"][:eo[-1]]; rk = hb["ranks"][:ro[-1]].astype(np.uint32)
     # each leg runs twice (the first call also pays thread start-up and page faults); the faster run counts, and only
     # the C call itself is timed (oracle_py.last_call_s), not the ctypes marshalling around it
     t_align = 1e30
     for _ in range(2):
         if ref:
-            pairs, pair_off, n_pairs = ref.align_many([r["seq"] for r in rds], ev, eo, hb["mom"][:n, 0], hb["mom"][:n, 1], threads)
+            pairs, pair_off, n_pairs = ref.align_many([r["seq"] for r in rds], ev, eo, mom[:, 0], mom[:, 1], threads)
             t_align = min(t_align, ref.last_call_s)
         else:
-            pairs, pair_off, n_pairs = orc.align_many(mn, ev, eo, rk, ro, hb["mom"][:n, 0], hb["mom"][:n, 1], threads)
+            pairs, pair_off, n_pairs = orc.align_many(mn, ev, eo, rk, ro, mom[:, 0], mom[:, 1], threads)
             t_align = min(t_align, orc.last_call_s)
     # event map + window bounds through the oracle's glue (untimed host bookkeeping, tiny)
     job_read, e1, e2, stride, rcs, jr, jr_off, epb = [], [], [], [], [], [], [0], np.zeros(n)
@@ -87,7 +104,8 @@ def cpu_baseline(models, hb, n_sample, threads, calibrate):
         else:
             sc = orc.score_many(mc, job_read, ev, eo, sh, sc_, vr, epb, np.concatenate(jr), jr_off, e1, e2, stride, 1.0, 3, threads)
             t_score = min(t_score, orc.last_call_s)
-    return dict(n=n, seconds=t_align + t_calib + t_score, t_align=t_align, t_score=t_score, t_calib=t_calib,
+    return dict(n=n, seconds=t_detect + t_align + t_calib + t_score, t_align=t_align, t_score=t_score, t_calib=t_calib, t_detect=t_detect,
+                n_events=[len(r["events"]) for r in rds],
                 pairs=(pairs, pair_off, n_pairs),
                 first=first, scores=sc, kind="reference" if ref else "port")
 
@@ -104,6 +122,9 @@ def main():
     ap.add_argument("--calibrate", type=int, default=1,
                     help="1: recalibrate each read on the device between the two kernels, as load_from_raw does (SURVEY 8 f1); "
                          "0: score with the scalings the synthetic reads were made with")
+    ap.add_argument("--from-raw", type=int, default=0,
+                    help="1: a step starts from raw current samples (scrappie event detection + MoM scalings on the device, "
+                         "SURVEY 8 f2); 0: from pre-detected events")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1: ~8 per core, 0: skip)")
     args = ap.parse_args()
 
@@ -133,9 +154,9 @@ def main():
     ctx.register_model(models["nucleotide"], "nucleotide"); ctx.register_model(models["cpg"], "cpg")
     t_prep = time.perf_counter()
     lo, hi = shard_read_ids(world * args.pool, rank, world)          # reads shard by contiguous id range
-    hb = build_host_batch(models, np.arange(lo, hi), L=args.read_len)
+    hb = build_host_batch(models, np.arange(lo, hi), L=args.read_len, raw=bool(args.from_raw))
     hbt = tile_host_batch(hb, args.tile)
-    batch = CallMethylationBatch(ctx, hbt, "cuda:%d" % local, calibrate=bool(args.calibrate))
+    batch = CallMethylationBatch(ctx, hbt, "cuda:%d" % local, calibrate=bool(args.calibrate), from_raw=bool(args.from_raw))
     t_prep = time.perf_counter() - t_prep
     n_reads = batch.n_reads
 
@@ -157,7 +178,7 @@ def main():
         sc = batch.d_scores[:batch.n_jobs].to(torch.float64)
         reduce_site_table(site_table(torch, first, n_motif, sc[1::2] - sc[0::2], args.read_len))
     barrier()
-    for w in range(4):
+    for w in range(6):
         ctx.kernel_time(w, reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -177,7 +198,7 @@ def main():
 
     if rank == 0:
         k_ms = {}
-        for name, w in (("event_align", 0), ("hmm_score", 1), ("resolve", 2)):
+        for name, w in (("event_align", 0), ("hmm_score", 1), ("resolve", 2), ("event_detect", 4), ("mom_scalings", 5)):
             ms, n = ctx.kernel_time(w)
             k_ms[name] = (ms, n)
         scores = batch.scores()
@@ -189,6 +210,13 @@ def main():
         dom = max(k_ms, key=lambda k: k_ms[k][0])
         a_ms, a_n = k_ms["event_align"]
         a_avg_s = a_ms / max(a_n, 1) * 1e-3
+        if args.from_raw:
+            # the event counts only exist after the detector has run: algorithmic bytes from the detected counts
+            nev = batch.d_n_events.clamp(min=0).to(torch.int64).cpu().numpy()
+            nk = (hbt["rank_off"][1:] - hbt["rank_off"][:-1])
+            bands = nev + nk + 2
+            batch.algo_bytes_align = int((4 * nev + 2 * nk + 100 * bands + 8 * nev).sum())
+            batch.band_cells = int((100 * bands).sum()); batch.total_events = int(nev.sum())
         algo = batch.algo_bytes_align
         achieved = algo / a_avg_s / 1e9 if a_avg_s > 0 else 0.0
         # HBM traffic per launch from the PMC passes (profiles/collect_pmc.sh -> profiles/r01_pmc_align.json): FETCH_SIZE +
@@ -211,13 +239,15 @@ def main():
         cores = len(os.sched_getaffinity(0))
         n_sample = args.cpu_sample if args.cpu_sample >= 0 else max(8, 8 * cores)
         if n_sample > 0 and world == 1:
-            cb = cpu_baseline(models, hb, n_sample, cores, bool(args.calibrate))
+            cb = cpu_baseline(models, hb, n_sample, cores, bool(args.calibrate), bool(args.from_raw))
             cpu = dict(value=round(cb["n"] / cb["seconds"], 2), unit="reads/s", cores=cores, kind=cb["kind"],
-                       sample="%d of the same synthetic reads, OpenMP over reads (align %.1fs + calibrate %.2fs + score %.1fs)"
-                              % (cb["n"], cb["t_align"], cb["t_calib"], cb["t_score"]))
+                       sample="%d of the same synthetic reads, OpenMP over reads (detect %.2fs + align %.1fs + calibrate %.2fs + score %.1fs)"
+                              % (cb["n"], cb["t_detect"], cb["t_align"], cb["t_calib"], cb["t_score"]))
             # parity of the GPU results with the oracle on that sample: pairs bit-exact, LLR within 1e-4
             pairs, pair_off, n_pairs = cb["pairs"]
             ok = True
+            if args.from_raw:
+                ok &= np.array_equal(batch.d_n_events[:cb["n"]].cpu().numpy(), np.array(cb["n_events"]))
             for i in range(cb["n"]):
                 g = batch.pairs_of(i)
                 ok &= np.array_equal(g, pairs[pair_off[i]:pair_off[i] + n_pairs[i]])
@@ -246,7 +276,7 @@ def main():
                                         "(BASELINE.json configs[1] shape)",
                                reads_per_step_per_gpu=n_reads, distinct_reads_per_gpu=args.pool, tile=args.tile,
                                read_len=args.read_len, mean_events=round(batch.total_events / n_reads, 1),
-                               groups_per_step_per_gpu=n_groups, reads_aligned_ok=n_ok, calibrate_on_device=bool(args.calibrate),
+                               groups_per_step_per_gpu=n_groups, reads_aligned_ok=n_ok, calibrate_on_device=bool(args.calibrate), from_raw_signal=bool(args.from_raw),
                                parallelism="reads sharded over %d GPU(s), 1 process/GPU" % world),
                    cpg_site_groups_per_s=round(world * n_groups * args.steps / dt, 1),
                    max_abs_dLLR_vs_cpu=max_dllr, roofline=roof, cpu_baseline=cpu, host_prep_s=round(t_prep, 1))

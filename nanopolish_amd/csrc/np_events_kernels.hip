@@ -84,21 +84,43 @@ __global__ void __launch_bounds__(256) np_ed_check_kernel(int n_reads, const flo
 // ---------------------------------------------------------------------------------------------------------------
 // compute_tstat (event_detection.c:63-119) for both windows, one thread per sample
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float tstat_at(const float* __restrict__ s, int c, int64_t i, int64_t n, int w)
+// x / d for a divisor whose correctly rounded reciprocal r is known (the window length: two values per launch): the
+// Markstein sequence of np_div_exact, in double and in float.  ~5 multiply-adds instead of the ~40-instruction IEEE
+// division expansion; tests/test_gpu_events.py compares every t-statistic with the reference's bit for bit.
+__device__ __forceinline__ double div_exact_f64(double n, double d, double r)
 {
-    // s[c] is sample i of the read; the window [i-w, i+w) is inside the staged tile
+    double q = n * r;
+    double e = __builtin_fma(-d, q, n);
+    q = __builtin_fma(e, r, q);
+    e = __builtin_fma(-d, q, n);
+    return __builtin_fma(e, r, q);
+}
+
+// sd / sq: the tile's samples and their fp32 squares, widened to double once per sample; the window sums are then
+// plain (exact) double additions.  [lo, hi) relative to the centre c.
+__device__ __forceinline__ void window_sums(const double* __restrict__ sd, const double* __restrict__ sq, int c, int lo, int hi,
+                                            double& s, double& q)
+{
+    s = 0.0; q = 0.0;
+    for (int j = lo; j < hi; ++j) { s += sd[c + j]; q += sq[c + j]; }
+}
+
+__device__ __forceinline__ float tstat_from_sums(double sum1, double sumsq1, double sum2d, double sumsq2d, int64_t i, int64_t n, int w)
+{
     if (w < 2 || n < 2 * (int64_t)w || i < w || i > n - w) return 0.0f;        // quick return and fudged boundaries
     const float w_lengthf = (float)w;
-    double sum1 = 0.0, sumsq1 = 0.0, sum2d = 0.0, sumsq2d = 0.0;
-    for (int j = -w; j < 0; ++j) { const float v = s[c + j]; sum1 += (double)v; sumsq1 += (double)(v * v); }
-    for (int j = 0; j < w; ++j) { const float v = s[c + j]; sum2d += (double)v; sumsq2d += (double)(v * v); }
     const float sum2 = (float)sum2d, sumsq2 = (float)sumsq2d;
-    const float mean1 = (float)(sum1 / (double)w_lengthf);
-    const float mean2 = sum2 / w_lengthf;
-    float combined_var = (float)(sumsq1 / (double)w_lengthf - (double)(mean1 * mean1) + (double)(sumsq2 / w_lengthf) - (double)(mean2 * mean2));
+    const double wd = (double)w_lengthf, rwd = 1.0 / wd;                      // (uniform: once per wave)
+    const float rwf = (float)rwd;                                             // RN(1/w) in fp32: 1/w is not a rounding tie
+    const float mean1 = (float)div_exact_f64(sum1, wd, rwd);
+    const float mean2 = np_div_exact(sum2, w_lengthf, rwf);
+    float combined_var = (float)(div_exact_f64(sumsq1, wd, rwd) - (double)(mean1 * mean1) + (double)np_div_exact(sumsq2, w_lengthf, rwf) -
+                                 (double)(mean2 * mean2));
     combined_var = fmaxf(combined_var, 1.17549435e-38f);                       // FLT_MIN
     const float delta_mean = mean2 - mean1;
-    return (float)(fabs((double)delta_mean) / sqrt((double)(combined_var / w_lengthf)));
+    // (a variance clamped to FLT_MIN has a denormal quotient, outside what the correction steps cover: plain division there)
+    const float cvw = combined_var < 1e-30f ? combined_var / w_lengthf : np_div_exact(combined_var, w_lengthf, rwf);
+    return (float)(fabs((double)delta_mean) / sqrt((double)cvw));
 }
 
 __global__ void __launch_bounds__(NP_ED_TILE) np_ed_tstat_kernel(int n_reads, const float* __restrict__ raw, const int64_t* __restrict__ raw_off,
@@ -110,24 +132,66 @@ __global__ void __launch_bounds__(NP_ED_TILE) np_ed_tstat_kernel(int n_reads, co
     const int64_t base = (int64_t)blockIdx.y * NP_ED_TILE;
     if (base >= n) return;
     const float* x = raw + raw_off[r];
-    __shared__ float s[NP_ED_TILE + 2 * NP_ED_HALO];
+    __shared__ double sd[NP_ED_TILE + 2 * NP_ED_HALO], sq[NP_ED_TILE + 2 * NP_ED_HALO];
     for (int t = threadIdx.x; t < NP_ED_TILE + 2 * NP_ED_HALO; t += NP_ED_TILE) {
         const int64_t i = base - NP_ED_HALO + t;
-        s[t] = (i >= 0 && i < n) ? x[i] : 0.0f;
+        const float v = (i >= 0 && i < n) ? x[i] : 0.0f;
+        sd[t] = (double)v; sq[t] = (double)(v * v);          // fp32 product, as the reference's sumsq (:47)
     }
     __syncthreads();
     const int64_t i = base + threadIdx.x;
     if (i >= n) return;
     const int c = NP_ED_HALO + (int)threadIdx.x;
-    tstat[raw_off[r] + i] = make_float2(tstat_at(s, c, i, n, w1), tstat_at(s, c, i, n, w2));
+    // the inner window's sums are part of the outer window's (every addition here is exact, so regrouping is free)
+    const int wa = w1 < w2 ? w1 : w2, wb = w1 < w2 ? w2 : w1;
+    double la, lqa, ra, rqa, lx, lqx, rx, rqx;
+    window_sums(sd, sq, c, -wa, 0, la, lqa); window_sums(sd, sq, c, 0, wa, ra, rqa);
+    window_sums(sd, sq, c, -wb, -wa, lx, lqx); window_sums(sd, sq, c, wa, wb, rx, rqx);
+    const float ta = tstat_from_sums(la, lqa, ra, rqa, i, n, wa);
+    const float tb = tstat_from_sums(lx + la, lqx + lqa, ra + rx, rqa + rqx, i, n, wb);
+    tstat[raw_off[r] + i] = w1 < w2 ? make_float2(ta, tb) : make_float2(tb, ta);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // short_long_peak_detector (event_detection.c:126-207), one lane per read
 // ---------------------------------------------------------------------------------------------------------------
-struct detector {
-    int64_t masked_to; int peak_pos; float peak_value; bool valid_peak;
-};
+
+// One lane per read.  The two detectors' nested branches are flattened into predicates (every lane of the wave is in a
+// different state, so a branchy body would execute all of its paths anyway):
+//   CASE 1 (no maximum yet):  a deeper minimum, or a rise of more than peak_height that starts a peak;
+//   CASE 2 (in a peak):       a higher maximum; [short detector] masking of the long one once it is going to fire;
+//                             the fall that validates the peak; emission once the peak is window/2 samples behind.
+struct detector { int masked_to, peak_pos; float peak_value; int valid_peak; };
+
+template <int K>
+__device__ __forceinline__ bool detector_step(detector& dt, detector& other, int i, float current_value, float peak_height, float threshold,
+                                              int window_length, int& emitted_pos)
+{
+    const bool act = !(dt.masked_to >= i);
+    const bool inpk = dt.peak_pos != -1;
+    const bool c1 = act && !inpk, c2 = act && inpk;
+    const bool deeper = c1 && current_value < dt.peak_value;
+    const bool rise = c1 && !(current_value < dt.peak_value) && (current_value - dt.peak_value > peak_height);
+    const bool higher = c2 && current_value > dt.peak_value;
+    dt.peak_value = (deeper || rise || higher) ? current_value : dt.peak_value;
+    dt.peak_pos = (rise || higher) ? i : dt.peak_pos;
+    const bool over = dt.peak_value > threshold;
+    if (K == 0) {
+        // the short detector dominates the long one if it is going to fire
+        const bool dom = c2 && over;
+        other.masked_to = dom ? dt.peak_pos + window_length : other.masked_to;
+        other.peak_pos = dom ? -1 : other.peak_pos;
+        other.peak_value = dom ? 3.40282347e+38f : other.peak_value;
+        other.valid_peak = dom ? 0 : other.valid_peak;
+    }
+    dt.valid_peak = (c2 && over && (dt.peak_value - current_value > peak_height)) ? 1 : dt.valid_peak;
+    const bool emit = c2 && dt.valid_peak != 0 && (i - dt.peak_pos) > window_length / 2;
+    emitted_pos = dt.peak_pos;
+    dt.peak_pos = emit ? -1 : dt.peak_pos;
+    dt.peak_value = emit ? current_value : dt.peak_value;
+    dt.valid_peak = emit ? 0 : dt.valid_peak;
+    return emit;
+}
 
 __global__ void __launch_bounds__(64) np_ed_peaks_kernel(int n_reads, const int64_t* __restrict__ raw_off, const float2* __restrict__ tstat,
                                                           const int32_t* __restrict__ status, np_detector_param p,
@@ -136,64 +200,37 @@ __global__ void __launch_bounds__(64) np_ed_peaks_kernel(int n_reads, const int6
 {
     const int r = blockIdx.x * 64 + threadIdx.x;
     const bool live = r < n_reads && status[r] == 0;
-    const int64_t n = live ? raw_off[r + 1] - raw_off[r] : 0;
+    const int n = live ? (int)(raw_off[r + 1] - raw_off[r]) : 0;
     const float2* ts = tstat + (live ? raw_off[r] : 0);
     uint32_t* es = event_start + (live ? event_off[r] : 0);
-    const int64_t cap = live ? event_off[r + 1] - event_off[r] : 0;
-    const float DEF_PEAK_VAL = 3.40282347e+38f;                                // FLT_MAX
-    detector d[2];
-    for (int k = 0; k < 2; ++k) { d[k].masked_to = 0; d[k].peak_pos = -1; d[k].peak_value = DEF_PEAK_VAL; d[k].valid_peak = false; }
-    const float threshold[2] = {p.threshold1, p.threshold2};
-    const int64_t window_length[2] = {(int64_t)p.window_length1, (int64_t)p.window_length2};
-    int64_t peak_count = 0;
+    const int cap = live ? (int)(event_off[r + 1] - event_off[r]) : 0;
+    detector d0 = {0, -1, 3.40282347e+38f, 0}, d1 = {0, -1, 3.40282347e+38f, 0};       // DEF_PEAK_POS, DEF_PEAK_VAL = FLT_MAX
+    const int w1 = (int)p.window_length1, w2 = (int)p.window_length2;
+    int peak_count = 0;
     bool overflow = false;
     if (live && cap > 0) es[0] = 0u;
 
     // wave-uniform trip count; every lane walks its own read, four samples per prefetched group
-    int64_t nmax = n;
-    for (int o = 32; o > 0; o >>= 1) { const int64_t v = __shfl_xor(nmax, o, 64); nmax = v > nmax ? v : nmax; }
+    int nmax = n;
+    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(nmax, o, 64); nmax = v > nmax ? v : nmax; }
     float2 cur[4], nxt[4];
     for (int q = 0; q < 4; ++q) nxt[q] = (q < n) ? ts[q] : make_float2(0.f, 0.f);
-    for (int64_t i0 = 0; i0 < nmax; i0 += 4) {
+    for (int i0 = 0; i0 < nmax; i0 += 4) {
         for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
-        for (int q = 0; q < 4; ++q) { const int64_t j = i0 + 4 + q; nxt[q] = (j < n) ? ts[j] : make_float2(0.f, 0.f); }
+        for (int q = 0; q < 4; ++q) { const int j = i0 + 4 + q; nxt[q] = (j < n) ? ts[j] : make_float2(0.f, 0.f); }
+#pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int64_t i = i0 + q;
-            if (i >= n) break;
-            for (int k = 0; k < 2; ++k) {
-                detector& dt = d[k];
-                if (dt.masked_to >= i) continue;                               // masked out
-                const float current_value = k == 0 ? cur[q].x : cur[q].y;
-                if (dt.peak_pos == -1) {
-                    // CASE 1: no maximum recorded yet
-                    if (current_value < dt.peak_value) {
-                        dt.peak_value = current_value;
-                    } else if (current_value - dt.peak_value > p.peak_height) {
-                        dt.peak_value = current_value;
-                        dt.peak_pos = (int)i;
-                    }
-                } else {
-                    // CASE 2: in a peak, waiting to see whether it is good
-                    if (current_value > dt.peak_value) { dt.peak_value = current_value; dt.peak_pos = (int)i; }
-                    if (k == 0) {
-                        // the short detector dominates the long one if it is going to fire
-                        if (dt.peak_value > threshold[0]) {
-                            d[1].masked_to = (int64_t)dt.peak_pos + window_length[0];
-                            d[1].peak_pos = -1;
-                            d[1].peak_value = DEF_PEAK_VAL;
-                            d[1].valid_peak = false;
-                        }
-                    }
-                    if (dt.peak_value - current_value > p.peak_height && dt.peak_value > threshold[k]) dt.valid_peak = true;
-                    if (dt.valid_peak && (i - dt.peak_pos) > window_length[k] / 2) {
-                        // emit the boundary and reset
-                        peak_count++;
-                        if (peak_count < cap) es[peak_count] = (uint32_t)dt.peak_pos; else overflow = true;
-                        dt.peak_pos = -1;
-                        dt.peak_value = current_value;
-                        dt.valid_peak = false;
-                    }
-                }
+            const int i = i0 + q;
+            const bool in = i < n;
+            int pos;
+            // (a lane past the end of its read is masked by making both detectors inactive: masked_to >= i)
+            if (detector_step<0>(d0, d1, in ? i : -1, cur[q].x, p.peak_height, p.threshold1, w1, pos)) {
+                peak_count++;
+                if (peak_count < cap) es[peak_count] = (uint32_t)pos; else overflow = true;
+            }
+            if (detector_step<1>(d1, d0, in ? i : -1, cur[q].y, p.peak_height, p.threshold2, w2, pos)) {
+                peak_count++;
+                if (peak_count < cap) es[peak_count] = (uint32_t)pos; else overflow = true;
             }
         }
     }
@@ -214,11 +251,10 @@ __global__ void __launch_bounds__(256) np_ed_events_kernel(int n_reads, const fl
     const int r = blockIdx.x;
     if (r >= n_reads) return;
     const int n_ev = n_events[r];
-    const int e = blockIdx.y * 256 + threadIdx.x;
-    if (e >= n_ev) return;
     const float* x = raw + raw_off[r];
     const int64_t n = raw_off[r + 1] - raw_off[r];
     const int64_t eo = event_off[r];
+    for (int e = threadIdx.x; e < n_ev; e += 256) {
     const int64_t start = event_start[eo + e];
     const int64_t end = e + 1 < n_ev ? (int64_t)event_start[eo + e + 1] : n;
     // (peaks come in the order the two detectors emit them; should a later one lie before an earlier one the reference's
@@ -234,6 +270,7 @@ __global__ void __launch_bounds__(256) np_ed_events_kernel(int n_reads, const fl
     event_length[eo + e] = length;
     event_mean[eo + e] = mean;
     event_stdv[eo + e] = sqrtf(fmaxf(var, 0.0f));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -320,10 +357,9 @@ hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t*
                            (int)p.window_length1, (int)p.window_length2, tstat);
     hipLaunchKernelGGL(np_ed_peaks_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, raw_off, tstat, status, p, event_off,
                        event_start, n_events);
-    const unsigned eblocks = (unsigned)((max_events + 255) / 256);
-    if (eblocks > 0)
-        hipLaunchKernelGGL(np_ed_events_kernel, dim3(n_reads, eblocks), dim3(256), 0, s, n_reads, raw, raw_off, event_off, event_start,
-                           n_events, event_length, event_mean, event_stdv);
+    (void)max_events;
+    hipLaunchKernelGGL(np_ed_events_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, raw, raw_off, event_off, event_start,
+                       n_events, event_length, event_mean, event_stdv);
     return hipGetLastError();
 }
 
