@@ -219,11 +219,11 @@ def main():
             batch.band_cells = int((100 * bands).sum()); batch.total_events = int(nev.sum())
         algo = batch.algo_bytes_align
         achieved = algo / a_avg_s / 1e9 if a_avg_s > 0 else 0.0
-        # HBM traffic per launch from the PMC passes (profiles/collect_pmc.sh -> profiles/r01_pmc_align.json): FETCH_SIZE +
+        # HBM traffic per launch from the PMC passes (profiles/collect_pmc.sh + profiles/pmc_summary.py -> profiles/r01_pmc.json): FETCH_SIZE +
         # WRITE_SIZE per read of this kernel, measured on this workload shape in separate rocprofv3 --pmc runs
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_align.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))["event_align"]
             traffic = int((pm["fetch_bytes_per_read"] + pm["write_bytes_per_read"]) * n_reads)
         except Exception:
             pass
