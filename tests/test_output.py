@@ -1,0 +1,61 @@
+"""f4: TSV record formatting and per-site frequency aggregation vs the reference's own script
+(tests/golden/golden_frequency*.tsv, produced by scripts/calculate_methylation_frequency.py in tests/gen_golden_frequency.py),
+and the device-side site table (nanopolish_amd/sites.py, here on CPU tensors) vs the text path."""
+import ctypes as C
+import os
+import numpy as np
+
+from nanopolish_amd.output import (methylation_tsv_header, format_methylation_tsv, calculate_methylation_frequency,
+                                   site_records_from_scores)
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_frequency_matches_reference_script_output():
+    calls = open(os.path.join(GOLD, "golden_calls.tsv")).readlines()
+    for tag, split in (("", False), ("_split", True)):
+        want = open(os.path.join(GOLD, "golden_frequency%s.tsv" % tag)).read().splitlines()
+        assert calculate_methylation_frequency(calls, split_groups=split) == want
+
+
+def test_tsv_generator_is_stable_and_formats_like_printf():
+    from gen_golden_frequency import synthetic_calls
+    assert "".join(synthetic_calls()) == open(os.path.join(GOLD, "golden_calls.tsv")).read()
+    assert methylation_tsv_header().split("\t")[5] == "log_lik_ratio"
+    libc = C.CDLL(None)
+    libc.snprintf.restype = C.c_int
+    rng = np.random.default_rng(2)
+    vals = np.concatenate([rng.normal(0, 50, 3000), np.arange(-200, 200) * 0.005, [0.125, 0.135, 2.675, -0.005, 1e-9, -1e-9]])
+    buf = C.create_string_buffer(64)
+    for v in vals:
+        libc.snprintf(buf, C.c_size_t(64), b"%.2lf", C.c_double(float(v)))
+        assert buf.value.decode() == "%.2f" % float(v)
+
+
+def test_site_records_follow_scored_site_rules():
+    ref = "TTACGTTTTTACGACGTTTTTTTTTTACGTTT"
+    recs = site_records_from_scores("chr", ref, 1000, [3, 11, 27], [3, 14, 27], [1, 2, 1], [-10.0, float("nan"), -30.0], [-8.0, -1.0, -33.5], k=6)
+    assert [r["start_position"] for r in recs] == [1003, 1027] and recs[1]["end_position"] == 1027
+    assert recs[0]["sequence"] == ref[3 - 5:3 + 6] and recs[0]["n_motif"] == 1
+    line = format_methylation_tsv(recs, "r1", False)[0].rstrip("\n").split("\t")
+    assert line[:4] == ["chr", "+", "1003", "1003"] and line[5:8] == ["2.00", "-8.00", "-10.00"]
+
+
+def test_device_site_table_equals_text_aggregation():
+    import torch
+    from gen_golden_frequency import synthetic_calls
+    from nanopolish_amd.sites import site_table
+    lines, recs = synthetic_calls(with_records=True)
+    first = torch.tensor([r["start_position"] for r in recs], dtype=torch.int64)
+    nm = torch.tensor([r["n_motif"] for r in recs], dtype=torch.int64)
+    llr = torch.tensor([(r["ll_methylated"][0] + r["ll_methylated"][1]) - (r["ll_unmethylated"][0] + r["ll_unmethylated"][1]) for r in recs],
+                       dtype=torch.float64)
+    table = site_table(torch, first, nm, llr, 20000).numpy()
+    freq = calculate_methylation_frequency(lines)[1:]
+    seen = 0
+    for ln in freq:
+        f = ln.split("\t")
+        s, called, meth = int(f[1]), int(f[4]), int(f[5])
+        assert table[s, 1] == called and table[s, 2] == meth
+        seen += 1
+    assert seen > 30 and int((table[:, 1] > 0).sum()) == seen
