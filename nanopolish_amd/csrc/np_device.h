@@ -18,19 +18,26 @@ struct __attribute__((aligned(32))) np_state_dev {
 };
 
 // p7_FLogsum (src/common/logsum.h:55-66) on an LDS-resident copy of flogsum_lookup.
-// Both-(-inf) inputs: max-min is NaN, the (min == -inf) test selects max, the clamped index is discarded.
+//   reference: (min == -inf || max - min >= 15.7f) ? max : max + tbl[(int)((max - min) * 1000.f)]
+// Branch-free and select-free form.  max - min == |a - b| exactly (a subtraction and its mirror round alike), so no
+// minimum is formed.  The LDS copy of the table is ZERO from entry NP_LOGSUM_CUT = 15700 on (np_lse_load_table), and the
+// index saturates at the last entry:
+//   * |a-b| < 15.7f   <=>  trunc(|a-b| * 1000.f) <= 15699 (15.7f * 1000.f rounds to 15700.0f, its predecessor to 15699.99..),
+//                          so exactly the reference's table cases read a non-zero entry, the same one;
+//   * |a-b| >= 15.7f, or +inf (one operand -inf): a zero entry, max + 0.0f == max (scores are never -0.0f);
+//   * NaN (both -inf): the conversion gives index 0, and -inf + tbl[0] == -inf.
+// Two thirds of the log-sums of a forward pass have a -inf or far-away operand (counted on the oracle); those lanes all
+// read the same last entry -- one broadcast access -- which takes them out of the bank conflicts that bound this kernel.
+#define NP_LOGSUM_CUT 15700
 __device__ __forceinline__ float np_lse(float a, float b, const float* __restrict__ tbl)
 {
-    // ESL_MAX / ESL_MIN: inputs are never NaN here (only finite values and -inf), so v_max/v_min are exact.
-    const float mx = __builtin_fmaxf(a, b);
-    const float mn = __builtin_fminf(a, b);
-    const float d = mx - mn;                          // +inf when only mn is -inf, NaN when both are
-    // (int) truncation as the reference.  The index is only used when d < 15.7f (< 15700); for larger d / inf /
-    // NaN the LDS read may be out of range, which returns garbage-or-zero without faulting, and is discarded.
-    const float t = tbl[(int)(d * 1000.f)];
-    // reference: (min == -inf || d >= 15.7f) ? max : max + t.  `!(d < 15.7f)` covers d >= 15.7, +inf and NaN.
-    return (d < 15.7f) ? mx + t : mx;
+    const float mx = __builtin_fmaxf(a, b);            // inputs are never NaN (finite or -inf): v_max is exact
+    const float d = __builtin_fabsf(a - b);
+    uint32_t i = (uint32_t)(d * 1000.f);               // v_cvt_u32_f32: truncates, saturates, NaN -> 0
+    i = i < (uint32_t)(NP_LOGSUM_TBL - 1) ? i : (uint32_t)(NP_LOGSUM_TBL - 1);
+    return mx + tbl[i];
 }
+__device__ __forceinline__ float np_lse_table_entry(const float* __restrict__ logsum, int i) { return i < NP_LOGSUM_CUT ? logsum[i] : 0.0f; }
 
 // get_scaled_gaussian_from_pore_model_state (src/nanopolish_squiggle_read.h:217-226): double math, float store.
 // Returns (mean, stdv, log_inv_sqrt_2pi - log_stdv): the last is the left-associated prefix of

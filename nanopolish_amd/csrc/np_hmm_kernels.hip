@@ -42,7 +42,7 @@ template <int SEG, int C, int BLK>
 __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_args a)
 {
     __shared__ float tbl[NP_LOGSUM_TBL];
-    for (int i = threadIdx.x; i < NP_LOGSUM_TBL; i += BLK) tbl[i] = a.logsum[i];
+    for (int i = threadIdx.x; i < NP_LOGSUM_TBL; i += BLK) tbl[i] = np_lse_table_entry(a.logsum, i);
     __syncthreads();
 
     constexpr int JPW = 64 / SEG;                 // jobs per wave
