@@ -27,15 +27,18 @@ struct __attribute__((aligned(32))) np_state_dev {
 //   * |a-b| >= 15.7f, or +inf (one operand -inf): a zero entry, max + 0.0f == max (scores are never -0.0f);
 //   * NaN (both -inf): the conversion gives index 0, and -inf + tbl[0] == -inf.
 // Two thirds of the log-sums of a forward pass have a -inf or far-away operand (counted on the oracle); those lanes all
-// read the same last entry -- one broadcast access -- which takes them out of the bank conflicts that bound this kernel.
+// read the same last entry (one broadcast access).  What bounds the kernel is the gather of the remaining third: PMC
+// shows the LDS pipe busy for the whole kernel at 4.2 cycles per ds_read, half of them bank-conflict cycles.
 #define NP_LOGSUM_CUT 15700
 __device__ __forceinline__ float np_lse(float a, float b, const float* __restrict__ tbl)
 {
     const float mx = __builtin_fmaxf(a, b);            // inputs are never NaN (finite or -inf): v_max is exact
     const float d = __builtin_fabsf(a - b);
-    uint32_t i = (uint32_t)(d * 1000.f);               // v_cvt_u32_f32: truncates, saturates, NaN -> 0
-    i = i < (uint32_t)(NP_LOGSUM_TBL - 1) ? i : (uint32_t)(NP_LOGSUM_TBL - 1);
-    return mx + tbl[i];
+    // byte offset of the entry without a shift: RN(d * 4000.f) == 4 * RN(d * 1000.f) (scaling by 4 is exact) and
+    // trunc(4y) & ~3 == 4 * trunc(y); v_cvt_u32_f32 truncates, saturates (+inf -> 0xffffffff) and maps NaN to 0
+    uint32_t off = (uint32_t)(d * 4000.f) & ~3u;
+    off = off < 4u * (NP_LOGSUM_TBL - 1) ? off : 4u * (NP_LOGSUM_TBL - 1);
+    return mx + *(const float*)((const char*)tbl + off);
 }
 __device__ __forceinline__ float np_lse_table_entry(const float* __restrict__ logsum, int i) { return i < NP_LOGSUM_CUT ? logsum[i] : 0.0f; }
 

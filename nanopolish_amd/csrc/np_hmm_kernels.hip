@@ -38,6 +38,9 @@ __device__ __forceinline__ int wave_max_i32(int v)
 // ---------------------------------------------------------------------------------------------------
 // BLK threads per workgroup share one LDS copy of the table.  One k-mer block per lane (C == 1) fits 64 VGPRs, so
 // those classes run 1024-thread workgroups, two per CU = 8 waves/SIMD; the others run 512-thread workgroups.
+#ifndef NP_HMM_FWD_BLOCK
+#define NP_HMM_FWD_BLOCK 512
+#endif
 template <int SEG, int C, int BLK>
 __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_args a)
 {
@@ -327,7 +330,7 @@ __global__ void np_hmm_backtrack_kernel(np_hmm_args a, int64_t n_jobs_total)
 template <int SEG, int C>
 hipError_t launch_fwd(const np_hmm_args& a, int n_blocks, hipStream_t s)
 {
-    constexpr int BLK = C == 1 ? 1024 : NP_HMM_BLOCK;
+    constexpr int BLK = NP_HMM_FWD_BLOCK;
     hipLaunchKernelGGL((np_hmm_forward_kernel<SEG, C, BLK>), dim3(n_blocks), dim3(BLK), 0, s, a);
     return hipGetLastError();
 }
@@ -340,7 +343,7 @@ hipError_t launch_vit(const np_hmm_args& a, int n_blocks, hipStream_t s)
 
 } // namespace
 
-int np_hmm_block_threads(int cls) { return NP_CLASS_C[cls] == 1 ? 1024 : NP_HMM_BLOCK; }
+int np_hmm_block_threads(int cls) { (void)cls; return NP_HMM_FWD_BLOCK; }
 int np_vit_block_threads(void) { return NP_HMM_BLOCK; }
 
 hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s)
