@@ -228,10 +228,10 @@ np_ctx* np_create(int device, const np_params* params)
     c->h_logsum = tbl;
     ok = ok && hipMalloc((void**)&c->d_logsum, tbl.size() * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_flank, flank.size() * sizeof(float)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&c->d_counters, 4096 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_counters, 8192 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemcpy(c->d_logsum, tbl.data(), tbl.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(c->d_flank, flank.data(), flank.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemset(c->d_counters, 0, 4096 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(c->d_counters, 0, 8192 * sizeof(uint32_t)) == hipSuccess;
     if (!ok) {
         if (g_create_err.empty()) g_create_err = "np_create: device allocation failed";
         np_destroy(c);

@@ -244,11 +244,13 @@ __device__ __forceinline__ int size_class(uint32_t n)
     return -1;
 }
 
-// Work-item binning.  A bin is (size class, event-count bucket): items of one class are laid out by descending
-// event count, so the 64/SEG items that share a wave have nearly the same number of rows (no padding steps) and
-// the longest packs are issued first.  Counting sort in three small kernels: histogram -> exclusive scan -> scatter.
-#define NP_EBUCKETS 64
-#define NP_NBINS (NP_NUM_CLASSES * NP_EBUCKETS)
+// Work-item binning.  A bin is (size class, k-mer blocks per lane, event-count bucket): the items that share a wave
+// then need the same number of blocks per lane (the forward kernel runs every lane for the wave's maximum) and have
+// nearly the same number of rows (no padding steps); inside a class the widest and longest packs are issued first.
+// Counting sort in three small kernels: histogram -> exclusive scan -> scatter.
+#define NP_EBUCKETS 32
+#define NP_CPL 8                 // blocks-per-lane groups inside a class (ceil(n / SEG) scaled to 1..8)
+#define NP_NBINS (NP_NUM_CLASSES * NP_CPL * NP_EBUCKETS)
 
 __device__ __forceinline__ int job_bin(const np_hmm_job_dev& jb, uint32_t flank_len)
 {
@@ -257,7 +259,12 @@ __device__ __forceinline__ int job_bin(const np_hmm_job_dev& jb, uint32_t flank_
     if (cls < 0) return -1;
     const uint32_t shift = 2u + (uint32_t)(cls < 3 ? cls : 3);            // bucket width 4, 8, 16, 32 events
     const uint32_t bucket = (e >> shift) < (NP_EBUCKETS - 1) ? (e >> shift) : (NP_EBUCKETS - 1);
-    return cls * NP_EBUCKETS + (NP_EBUCKETS - 1 - (int)bucket);             // descending event count inside a class
+    // blocks per lane the item needs: ceil(n / SEG), in units of the class' C / 8 (C = 8: 1..8; C = 16: pairs)
+    const int seg = (2 << cls) < 64 ? (2 << cls) : 64, cu = (cls == NP_NUM_CLASSES - 1 ? 16 : 8) / NP_CPL;   // NP_CLASS_SEG / NP_CLASS_C
+    const int cpl = ((int)jb.n_kmers + seg - 1) / seg;
+    const int cg = (cpl + cu - 1) / cu;                                     // 1..8
+    // descending blocks per lane, then descending event count, inside a class
+    return (cls * NP_CPL + (NP_CPL - cg)) * NP_EBUCKETS + (NP_EBUCKETS - 1 - (int)bucket);
 }
 
 __global__ void __launch_bounds__(256) np_bin_count_kernel(const np_hmm_job_dev* jobs, int64_t n_jobs, uint32_t* hist,
@@ -282,7 +289,7 @@ __global__ void __launch_bounds__(64) np_bin_scan_kernel(const uint32_t* hist, u
     const int c = threadIdx.x;
     if (c >= NP_NUM_CLASSES) return;
     uint32_t run = 0;
-    for (int b = 0; b < NP_EBUCKETS; ++b) { cursor[c * NP_EBUCKETS + b] = run; run += hist[c * NP_EBUCKETS + b]; }
+    for (int b = 0; b < NP_CPL * NP_EBUCKETS; ++b) { cursor[c * NP_CPL * NP_EBUCKETS + b] = run; run += hist[c * NP_CPL * NP_EBUCKETS + b]; }
     class_count[c] = run;
 }
 
@@ -302,7 +309,7 @@ __global__ void __launch_bounds__(256) np_bin_scatter_kernel(const np_hmm_job_de
     __syncthreads();
     for (int i = threadIdx.x; i < NP_NBINS; i += 256) { const uint32_t n = h[i]; if (n) h[i] = atomicAdd(&cursor[i], n); }
     __syncthreads();
-    if (bin >= 0) order[(size_t)(bin / NP_EBUCKETS) * (size_t)n_jobs + h[bin] + local] = (uint32_t)j;
+    if (bin >= 0) order[(size_t)(bin / (NP_CPL * NP_EBUCKETS)) * (size_t)n_jobs + h[bin] + local] = (uint32_t)j;
 }
 
 } // namespace

@@ -67,7 +67,11 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
         const int n = has ? (int)job.n_kmers : 0;
         const int e = has ? (int)(job.e_stop > job.e_start ? job.e_stop - job.e_start : job.e_start - job.e_stop) + 1 : 0;
         const int stride = job.stride;
-        const int lanes_used = (n + C - 1) / C;
+        // k-mer blocks per lane: the wave runs every lane for cw = the largest ceil(n / SEG) among its items (the items
+        // of a pack were binned by that number), instead of always C -- a 2-site CpG window of 18..26 k-mers on 4 lanes
+        // then costs 5..7 block updates per step, not 8
+        const int cw = __builtin_amdgcn_readfirstlane(wave_max_i32(has ? (n + SEG - 1) / SEG : 1));
+        const int lanes_used = (n + cw - 1) / cw;
         const bool lane_on = has && sl < lanes_used;
         const float* ev = a.event_mean + rd->event_off;
         const bool pre_clip = (job.flags & NP_HAF_ALLOW_PRE_CLIP) != 0;
@@ -78,14 +82,14 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
                     lp_bb = rd->trans[4], lp_bk = rd->trans[5], lp_bm_next = rd->trans[6], lp_bm_self = rd->trans[7],
                     lp_kk = rd->trans[8], lp_km = rd->trans[9];
 
-        // per-lane scaled Gaussians of this lane's C k-mer blocks
+        // per-lane scaled Gaussians of this lane's k-mer blocks
         np_gauss g[C];
         {
             const double scale = rd->scale, shift = rd->shift, var = rd->var, log_var = rd->log_var;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const int b = sl * C + c;
-                const uint32_t rank = (lane_on && b < n) ? a.ranks[job.rank_off + b] : 0u;
+                const int b = sl * cw + c;
+                const uint32_t rank = (lane_on && c < cw && b < n) ? a.ranks[job.rank_off + b] : 0u;
                 g[c] = np_scale_state(a.model, rank, scale, shift, var, log_var);
             }
         }
@@ -95,7 +99,7 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
         for (int c = 0; c < C; ++c) cur.M[c] = cur.B[c] = cur.K[c] = NP_NEG_INF;   // row 0 (r9.cpp:21-33)
         float oM = NP_NEG_INF, oB = NP_NEG_INF, oK = NP_NEG_INF;   // left neighbour, row r-1
         float lp_end = NP_NEG_INF;
-        const int last_lane = (n - 1) / C, last_c = (n - 1) % C;
+        const int last_lane = n > 0 ? (n - 1) / cw : 0, last_c = n > 0 ? (n - 1) % cw : 0;
 
         const int steps = wave_max_i32(has ? e + lanes_used - 1 : 0);
         const bool is_last = lane_on && sl == last_lane;
@@ -105,10 +109,14 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
         if (lane_on && sl == 0) { xn = ev[job.e_start]; softn = a.flank[0]; }      // row 1: event_idx == e_start (r9.inl:361)
         if (is_last && sl == 0 && (post_clip || e == 1)) pfn = a.flank[e - 1];
         for (int t = 1; t <= steps; ++t) {
-            // left neighbour's row r (what lane j-1 computed in step t-1); segment heads see block 0 = -inf
-            float nM = np_wave_shr1(cur.M[C - 1], NP_NEG_INF);
-            float nB = np_wave_shr1(cur.B[C - 1], NP_NEG_INF);
-            float nK = np_wave_shr1(cur.K[C - 1], NP_NEG_INF);
+            // left neighbour's row r (what lane j-1 computed in step t-1 for its last block, cw-1: a wave-uniform index);
+            // segment heads see block 0 = -inf
+            float tM = cur.M[0], tB = cur.B[0], tK = cur.K[0];
+#pragma unroll
+            for (int c = 1; c < C; ++c) if (c == cw - 1) { tM = cur.M[c]; tB = cur.B[c]; tK = cur.K[c]; }
+            float nM = np_wave_shr1(tM, NP_NEG_INF);
+            float nB = np_wave_shr1(tB, NP_NEG_INF);
+            float nK = np_wave_shr1(tK, NP_NEG_INF);
             if (sl == 0) { nM = NP_NEG_INF; nB = NP_NEG_INF; nK = NP_NEG_INF; }
 
             const int r = t - sl;
@@ -126,6 +134,7 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
                 float lM_p = oM, lB_p = oB, lK_p = oK;     // block to the left, row r-1
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
+                    if (c >= cw) continue;                     // wave-uniform
                     const float em = np_emission(x, g[c]);
                     // PSR9_MATCH: HMT_FROM_SAME_M, PREV_M, SAME_B, PREV_B, PREV_K, SOFT (r9.inl:350-365)
                     float s = lp_mm_self + cur.M[c];
