@@ -33,6 +33,41 @@ def test_ragged_event_align_batch(ctx, orc, models):
     assert n_ok >= 5
 
 
+def test_event_align_band_phase_boundaries(ctx, orc, models):
+    """Reads that push the band along unusual paths, so that kernel A's three phases (generic / FAST middle / generic) hand
+    over at odd places: over-segmented reads (3 events per k-mer: the band runs along the event axis), under-segmented
+    reads (fewer events than k-mers), reads barely longer than the band, a 20k-base read, and event streams whose
+    second half belongs to another read (the alignment leaves the diagonal and fails QC)."""
+    mn = orc.model(models["nucleotide"])
+    rng = np.random.default_rng(9)
+    cases = []
+    for i, L in enumerate((1500, 1500, 1500, 106, 140, 20000)):
+        rd = synth_read(400 + i, models["nucleotide"], L=L)
+        ev = rd["events"]
+        if i == 0:
+            ev = (np.repeat(ev, 2) + rng.normal(0, 0.3, 2 * len(ev))).astype(np.float32)         # ~3 events per k-mer
+        elif i == 1:
+            ev = ev[::2].copy()                                                                   # ~0.7 events per k-mer
+        elif i == 2:
+            other = synth_read(450, models["nucleotide"], L=L)["events"]
+            ev = np.concatenate([ev[:len(ev) // 2], other[len(other) // 2:]]).astype(np.float32)
+        cases.append((rd, ev))
+    jobs, want = [], []
+    for rd, ev in cases:
+        sh, sc = orc.estimate_scalings_mom(mn, rd["ranks"], ev)
+        jobs.append(dict(events=ev, ranks=rd["ranks"], model=ctx.models["nucleotide"], scale=sc, shift=sh, var=1.0))
+        want.append(orc.event_align(mn, orc.scalings(sh, sc, 1.0), ev, rd["ranks"]))
+    got = ctx.adaptive_banded_simple_event_align(jobs)
+    n_ok = 0
+    for (rd, ev), g, w in zip(cases, got, want):
+        if w is None:
+            assert len(g) == 0
+            continue
+        assert np.array_equal(g, w), (len(rd["seq"]), len(ev))
+        n_ok += len(w) > 0
+    assert n_ok >= 3
+
+
 def test_hmm_window_extremes(ctx, orc, models):
     """1- and 2-event windows, the largest supported sequence (1024 k-mers), events_per_base extremes, both strides."""
     mn = orc.model(models["nucleotide"])
