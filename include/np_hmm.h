@@ -255,7 +255,7 @@ void np_event_detection_params(np_detector_param* p, int rna);
  * SquiggleRead::load_from_raw runs it (src/nanopolish_squiggle_read.cpp:229-236; the trim it computes is discarded there).
  *   raw / raw_off      : float[total samples] (pA), int64[n_reads+1]
  *   max_samples        : largest read (host value, sizes the launch)
- *   tstat              : scratch, 2 floats per sample (8-byte aligned)
+ *   tstat              : scratch, 2 floats per sample + 64 bytes, 64-byte aligned (read back in whole cache lines)
  *   event_off          : int64[n_reads+1], per-read CAPACITY offsets into the event arrays (n_samples/2+2 is always enough:
  *                        boundaries of one detector are at least two samples apart)
  *   event_start/length/mean/stdv : event_t fields (scrappie_structures.h:8-15) of the detected events

@@ -631,9 +631,10 @@ static int detect_events_locked(np_ctx* c, hipStream_t s, int n_reads, const flo
     np_detector_param p;
     if (params) p = *params; else np_event_detection_params(&p, 0);
     if (p.window_length1 > 16 || p.window_length2 > 16) { c->err = "np_detect_events: window length > 16"; return NP_ERR_UNSUPPORTED; }
+    if (tstat && ((uintptr_t)tstat & 63u)) { c->err = "np_detect_events: tstat scratch must be 64-byte aligned"; return NP_ERR_INVALID; }
     NP_HIP(c, c->ed_status.reserve((size_t)n_reads * sizeof(int32_t)));
     if (!tstat) {
-        NP_HIP(c, c->ed_tstat.reserve((size_t)total_samples_hint * sizeof(float2)));
+        NP_HIP(c, c->ed_tstat.reserve((size_t)total_samples_hint * sizeof(float2) + 64));
         tstat = c->ed_tstat.as<float>();
     }
     family_timer tm(c, 4, s);

@@ -23,6 +23,8 @@
 
 #define NP_ED_TILE 256
 #define NP_ED_HALO 16          // >= the largest window (event_detection_rna: 14)
+#define NP_ED_WARMUP 256       // samples a segment of the parallel peak walk starts early (see np_ed_peaks_par_kernel)
+#define NP_ED_PAR_MIN 2048     // reads shorter than this take the lane-per-read walk
 
 namespace {
 
@@ -199,7 +201,8 @@ __global__ void __launch_bounds__(64) np_ed_peaks_kernel(int n_reads, const int6
                                                           int32_t* __restrict__ n_events)
 {
     const int r = blockIdx.x * 64 + threadIdx.x;
-    const bool live = r < n_reads && status[r] == 0;
+    const bool mine = r < n_reads && (raw_off[r + 1] - raw_off[r] < NP_ED_PAR_MIN || status[r] != 0);   // long reads: np_ed_peaks_par_kernel
+    const bool live = mine && status[r] == 0;
     const int n = live ? (int)(raw_off[r + 1] - raw_off[r]) : 0;
     const float2* ts = tstat + (live ? raw_off[r] : 0);
     uint32_t* es = event_start + (live ? event_off[r] : 0);
@@ -234,10 +237,145 @@ __global__ void __launch_bounds__(64) np_ed_peaks_kernel(int n_reads, const int6
             }
         }
     }
-    if (r < n_reads) {
+    if (mine) {
         // create_events (:243-266): one event more than there are peaks; no peak at all is undefined in the reference
         n_events[r] = !live ? status[r] : (overflow ? NP_ED_OVERFLOW : (peak_count > 0 ? (int32_t)(peak_count + 1) : 0));
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same walk, 64 segments of one read at a time (one wave per read).  The detectors forget their past quickly (every
+// emission resets one, the short one keeps resetting the long one), so a lane that starts NP_ED_WARMUP samples before
+// its segment from the initial state almost always reaches the segment in the true state.  "Almost" is not good enough
+// for bit-exact output, so it is checked: the state with which lane j enters its segment must equal the state with
+// which lane j-1 left the previous one.  Lane 0 starts from the true initial state, hence by induction every lane whose
+// check passes walked its segment exactly as the serial detector does.  A lane whose check fails walks its segment
+// again from its left neighbour's exit state (no warm-up), and the check is repeated until nothing changes -- at
+// worst 63 rounds, i.e. the serial walk; in practice none.  Emissions are buffered per lane (in the event arrays that
+// create_event fills later) and concatenated in lane order, which is emission order.
+// ---------------------------------------------------------------------------------------------------------------
+
+struct walk_state { detector d0, d1; };
+
+__device__ __forceinline__ bool same_state(const walk_state& a, const walk_state& b)
+{
+    return a.d0.masked_to == b.d0.masked_to && a.d0.peak_pos == b.d0.peak_pos && a.d0.valid_peak == b.d0.valid_peak &&
+           __builtin_bit_cast(uint32_t, a.d0.peak_value) == __builtin_bit_cast(uint32_t, b.d0.peak_value) &&
+           a.d1.masked_to == b.d1.masked_to && a.d1.peak_pos == b.d1.peak_pos && a.d1.valid_peak == b.d1.valid_peak &&
+           __builtin_bit_cast(uint32_t, a.d1.peak_value) == __builtin_bit_cast(uint32_t, b.d1.peak_value);
+}
+__device__ __forceinline__ walk_state shfl_up_state(const walk_state& s)
+{
+    walk_state o;
+    o.d0.masked_to = __shfl_up(s.d0.masked_to, 1, 64); o.d0.peak_pos = __shfl_up(s.d0.peak_pos, 1, 64);
+    o.d0.peak_value = __shfl_up(s.d0.peak_value, 1, 64); o.d0.valid_peak = __shfl_up(s.d0.valid_peak, 1, 64);
+    o.d1.masked_to = __shfl_up(s.d1.masked_to, 1, 64); o.d1.peak_pos = __shfl_up(s.d1.peak_pos, 1, 64);
+    o.d1.peak_value = __shfl_up(s.d1.peak_value, 1, 64); o.d1.valid_peak = __shfl_up(s.d1.valid_peak, 1, 64);
+    return o;
+}
+
+// walks samples [begin, end) of this lane's read (`trip` = wave-uniform maximum of end - begin); with RECORD, emissions go to
+// tmp.  Every lane streams its own segment, so the t-statistics are fetched in whole 64-byte lines: blocks of eight
+// samples aligned in the batch-wide array (ts_all, 64-byte aligned; base = the read's first sample in it), four 16-byte
+// loads per block, one block prefetched.  (Private streams of 64 lanes x 8 waves do not fit L1: a line must be consumed
+// by the loads that miss on it.)
+template <bool RECORD>
+__device__ __forceinline__ void walk_segment(const float2* __restrict__ ts_all, int64_t base, int begin, int end, int trip, bool lane_active,
+                                             walk_state& st, const np_detector_param& p, uint32_t* tmp, int tmp_cap, int& cnt)
+{
+    const int w1 = (int)p.window_length1, w2 = (int)p.window_length2;
+    const int64_t a_begin = base + begin, a_end = base + end;
+    int64_t blk = a_begin >> 3;                               // this lane's first block
+    const int n_blk = (trip + 7) / 8 + 1;                     // a misaligned range of `trip` samples touches at most this many
+    const float4* lines = (const float4*)ts_all;
+    float4 cur[4], nxt[4];
+    {
+        const bool need = lane_active && (blk << 3) < a_end;
+        for (int q = 0; q < 4; ++q) nxt[q] = need ? lines[blk * 4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int t = 0; t < n_blk; ++t) {
+        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+        {
+            const bool need = lane_active && ((blk + 1) << 3) < a_end;
+            for (int q = 0; q < 4; ++q) nxt[q] = need ? lines[(blk + 1) * 4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int64_t a = (blk << 3) + q;
+            const bool in = lane_active && a >= a_begin && a < a_end;
+            const int i = (int)(a - base);
+            const float t1 = (q & 1) ? cur[q >> 1].z : cur[q >> 1].x, t2 = (q & 1) ? cur[q >> 1].w : cur[q >> 1].y;
+            int pos;
+            if (detector_step<0>(st.d0, st.d1, in ? i : -1, t1, p.peak_height, p.threshold1, w1, pos) && RECORD) {
+                if (cnt < tmp_cap) tmp[cnt] = (uint32_t)pos;
+                cnt++;
+            }
+            if (detector_step<1>(st.d1, st.d0, in ? i : -1, t2, p.peak_height, p.threshold2, w2, pos) && RECORD) {
+                if (cnt < tmp_cap) tmp[cnt] = (uint32_t)pos;
+                cnt++;
+            }
+        }
+        blk += 1;
+    }
+}
+
+__global__ void __launch_bounds__(64) np_ed_peaks_par_kernel(int n_reads, const int64_t* __restrict__ raw_off, const float2* __restrict__ tstat,
+                                                              const int32_t* __restrict__ status, np_detector_param p,
+                                                              const int64_t* __restrict__ event_off, uint32_t* __restrict__ event_start,
+                                                              uint32_t* __restrict__ scratch_a, uint32_t* __restrict__ scratch_b,
+                                                              uint32_t* __restrict__ scratch_c, int32_t* __restrict__ n_events)
+{
+    const int r = blockIdx.x;
+    if (r >= n_reads) return;
+    const int64_t n64 = raw_off[r + 1] - raw_off[r];
+    if (n64 < NP_ED_PAR_MIN || status[r] != 0) return;            // short reads / declined reads: the other kernel
+    const int n = (int)n64;
+    const int lane = threadIdx.x;
+    const int64_t base = raw_off[r];
+    const int64_t eo = event_off[r];
+    const int cap = (int)(event_off[r + 1] - eo);
+    uint32_t* es = event_start + eo;
+    // per-lane emission buffers: three arrays of `cap` entries, 22 / 21 / 21 lanes each
+    const int grp = lane < 22 ? 0 : (lane < 43 ? 1 : 2), idx = lane - (grp == 0 ? 0 : (grp == 1 ? 22 : 43));
+    const int tmp_cap = cap / 22;
+    uint32_t* tmp = (grp == 0 ? scratch_a : (grp == 1 ? scratch_b : scratch_c)) + eo + (int64_t)idx * tmp_cap;
+
+    const int S = (n + 63) / 64;
+    const int start = lane * S < n ? lane * S : n;
+    const int end = start + S < n ? start + S : n;
+    const int begin = start - NP_ED_WARMUP > 0 ? start - NP_ED_WARMUP : 0;
+    const detector fresh = {0, -1, 3.40282347e+38f, 0};            // DEF_PEAK_POS, DEF_PEAK_VAL = FLT_MAX
+    walk_state st = {fresh, fresh};
+    int cnt = 0;
+    walk_segment<false>(tstat, base, begin, start, NP_ED_WARMUP, start < end, st, p, tmp, tmp_cap, cnt);   // warm-up, nothing recorded
+    walk_state entry = st;                                                                           // state at the segment's first sample
+    walk_segment<true>(tstat, base, start, end, S, start < end, st, p, tmp, tmp_cap, cnt);
+
+    // verification / repair rounds
+    for (int round = 0; round < 64; ++round) {
+        walk_state left = shfl_up_state(st);
+        // an empty segment's exit state is its left neighbour's; make that transitive for the check below
+        if (lane > 0 && start >= end) { st = left; entry = left; }
+        left = shfl_up_state(st);
+        const bool bad = lane > 0 && start < end && !same_state(entry, left);
+        if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;
+        walk_state redo = left;
+        int c2 = 0;
+        walk_segment<true>(tstat, base, start, end, S, bad, redo, p, tmp, tmp_cap, c2);
+        if (bad) { st = redo; entry = left; cnt = c2; }
+    }
+
+    // concatenate in lane order
+    int off = cnt;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(off, o, 64); if (lane >= o) off += v; }
+    const int total = __shfl(off, 63, 64);
+    off -= cnt;
+    const bool over = __builtin_amdgcn_ballot_w64(cnt > tmp_cap) != 0ull || total + 1 > cap;
+    if (!over) {
+        if (lane == 0) es[0] = 0u;
+        for (int q = 0; q < cnt; ++q) es[1 + off + q] = tmp[q];
+    }
+    if (lane == 0) n_events[r] = over ? NP_ED_OVERFLOW : (total > 0 ? total + 1 : 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -357,6 +495,9 @@ hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t*
                            (int)p.window_length1, (int)p.window_length2, tstat);
     hipLaunchKernelGGL(np_ed_peaks_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, raw_off, tstat, status, p, event_off,
                        event_start, n_events);
+    if (max_samples >= NP_ED_PAR_MIN)
+        hipLaunchKernelGGL(np_ed_peaks_par_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, raw_off, tstat, status, p, event_off, event_start,
+                           (uint32_t*)event_length, (uint32_t*)event_mean, (uint32_t*)event_stdv, n_events);
     (void)max_events;
     hipLaunchKernelGGL(np_ed_events_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, raw, raw_off, event_off, event_start,
                        n_events, event_length, event_mean, event_stdv);

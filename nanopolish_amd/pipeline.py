@@ -142,7 +142,7 @@ class CallMethylationBatch:
             ecap = hb["event_off"][1:] - hb["event_off"][:-1]
             self.max_events = int(ecap.max())
             nev = int(hb["event_off"][-1])
-            self.d_tstat = torch.empty(self.total_samples * 2, dtype=torch.float32, device=dev)
+            self.d_tstat = torch.empty(self.total_samples * 2 + 16, dtype=torch.float32, device=dev)
             self.d_ev_start = torch.empty(nev, dtype=torch.int32, device=dev)
             self.d_ev_len = torch.empty(nev, dtype=torch.float32, device=dev)
             self.d_ev_stdv = torch.empty(nev, dtype=torch.float32, device=dev)
