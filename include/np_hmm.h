@@ -63,6 +63,11 @@ void    np_destroy(np_ctx* ctx);
 const char* np_last_error(const np_ctx* ctx);
 const char* np_version(void);
 
+/* Tuning / test knobs (defaults are what bench.py measures): "align_blocks_per_cu", "hmm_blocks_per_cu" (persistent grid
+ * sizes), "ed_warmup" (samples each segment of the parallel peak walk starts early; 0 forces every segment through the
+ * repair path -- results never depend on it). */
+int np_set_option(np_ctx* ctx, const char* name, int64_t value);
+
 /* Upload a pore model (PoreModel::states, src/pore_model/nanopolish_poremodel.h:20-67,107): the three
  * per-state doubles the path reads.  Returns a model id >= 0, or a negative error. */
 int np_register_model(np_ctx* ctx, int k, int n_states,

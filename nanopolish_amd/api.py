@@ -135,6 +135,9 @@ class Context:
         if rc != 0:
             raise RuntimeError("%s failed (%d): %s" % (what, rc, self.L.np_last_error(self.h).decode()))
 
+    def set_option(self, name, value):
+        self._chk(self.L.np_set_option(self.h, name.encode(), int(value)), "np_set_option")
+
     def register_model(self, model, name=None):
         lm = np.ascontiguousarray(model["level_mean"], np.float64)
         ls = np.ascontiguousarray(model["level_stdv"], np.float64)

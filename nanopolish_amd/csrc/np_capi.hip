@@ -72,6 +72,7 @@ struct np_ctx {
     std::mutex lock;
     std::string err;
     int align_blocks_per_cu = 8, hmm_blocks_per_cu = 2;
+    int ed_warmup = -1;               // parallel peak walk: samples of warm-up per segment (< 0: the kernel's default)
 };
 
 namespace {
@@ -615,6 +616,19 @@ int np_event_align_host(np_ctx* c, int n_jobs, const np_align_job* jobs, np_pair
     return NP_OK;
 }
 
+// tuning / test knobs
+int np_set_option(np_ctx* c, const char* name, int64_t value)
+{
+    if (!c || !name) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    const std::string k(name);
+    if (k == "align_blocks_per_cu") c->align_blocks_per_cu = (int)std::max<int64_t>(1, value);
+    else if (k == "hmm_blocks_per_cu") c->hmm_blocks_per_cu = (int)std::max<int64_t>(1, value);
+    else if (k == "ed_warmup") c->ed_warmup = (int)value;
+    else { c->err = "np_set_option: unknown option " + k; return NP_ERR_INVALID; }
+    return NP_OK;
+}
+
 // ---- f2: event detection + MoM scalings ------------------------------------------------------------------------------
 void np_event_detection_params(np_detector_param* p, int rna)
 {
@@ -639,7 +653,7 @@ static int detect_events_locked(np_ctx* c, hipStream_t s, int n_reads, const flo
     }
     family_timer tm(c, 4, s);
     NP_HIP(c, np_launch_detect_events(n_reads, raw, raw_off, max_samples, p, (float2*)tstat, c->ed_status.as<int32_t>(), event_off,
-                                      max_events, event_start, event_length, event_mean, event_stdv, n_events, s));
+                                      max_events, event_start, event_length, event_mean, event_stdv, n_events, c->ed_warmup, s));
     return NP_OK;
 }
 

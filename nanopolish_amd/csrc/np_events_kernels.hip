@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(64) np_ed_peaks_par_kernel(int n_reads, const 
                                                               const int32_t* __restrict__ status, np_detector_param p,
                                                               const int64_t* __restrict__ event_off, uint32_t* __restrict__ event_start,
                                                               uint32_t* __restrict__ scratch_a, uint32_t* __restrict__ scratch_b,
-                                                              uint32_t* __restrict__ scratch_c, int32_t* __restrict__ n_events)
+                                                              uint32_t* __restrict__ scratch_c, int32_t* __restrict__ n_events, int warmup)
 {
     const int r = blockIdx.x;
     if (r >= n_reads) return;
@@ -343,11 +343,11 @@ __global__ void __launch_bounds__(64) np_ed_peaks_par_kernel(int n_reads, const 
     const int S = (n + 63) / 64;
     const int start = lane * S < n ? lane * S : n;
     const int end = start + S < n ? start + S : n;
-    const int begin = start - NP_ED_WARMUP > 0 ? start - NP_ED_WARMUP : 0;
+    const int begin = start - warmup > 0 ? start - warmup : 0;
     const detector fresh = {0, -1, 3.40282347e+38f, 0};            // DEF_PEAK_POS, DEF_PEAK_VAL = FLT_MAX
     walk_state st = {fresh, fresh};
     int cnt = 0;
-    walk_segment<false>(tstat, base, begin, start, NP_ED_WARMUP, start < end, st, p, tmp, tmp_cap, cnt);   // warm-up, nothing recorded
+    walk_segment<false>(tstat, base, begin, start, warmup, start < end, st, p, tmp, tmp_cap, cnt);   // warm-up, nothing recorded
     walk_state entry = st;                                                                           // state at the segment's first sample
     walk_segment<true>(tstat, base, start, end, S, start < end, st, p, tmp, tmp_cap, cnt);
 
@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(64) np_mom_fill_kernel(int n_reads, np_read_de
 
 hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t* raw_off, int64_t max_samples, const np_detector_param& p,
                                    float2* tstat, int32_t* status, const int64_t* event_off, int64_t max_events, uint32_t* event_start,
-                                   float* event_length, float* event_mean, float* event_stdv, int32_t* n_events, hipStream_t s)
+                                   float* event_length, float* event_mean, float* event_stdv, int32_t* n_events, int warmup, hipStream_t s)
 {
     if (n_reads <= 0) return hipSuccess;
     hipLaunchKernelGGL(np_ed_check_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, raw, raw_off, status);
@@ -497,7 +497,7 @@ hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t*
                        event_start, n_events);
     if (max_samples >= NP_ED_PAR_MIN)
         hipLaunchKernelGGL(np_ed_peaks_par_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, raw_off, tstat, status, p, event_off, event_start,
-                           (uint32_t*)event_length, (uint32_t*)event_mean, (uint32_t*)event_stdv, n_events);
+                           (uint32_t*)event_length, (uint32_t*)event_mean, (uint32_t*)event_stdv, n_events, warmup < 0 ? NP_ED_WARMUP : warmup);
     (void)max_events;
     hipLaunchKernelGGL(np_ed_events_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, raw, raw_off, event_off, event_start,
                        n_events, event_length, event_mean, event_stdv);

@@ -15,7 +15,7 @@ c_i64p = C.POINTER(C.c_int64)
 
 # exported symbols of include/np_hmm.h (tests check that every one resolves)
 SYMBOLS = [
-    "np_default_params", "np_create", "np_destroy", "np_last_error", "np_version", "np_register_model",
+    "np_default_params", "np_create", "np_destroy", "np_last_error", "np_version", "np_set_option", "np_register_model",
     "np_alphabet_id", "np_alphabet_size", "np_kmer_rank", "np_reverse_complement", "np_methylate", "np_unmethylate",
     "np_is_motif_match", "np_sequence_kmer_ranks", "np_calculate_transitions", "np_estimate_scalings_mom",
     "np_scan_motif_groups", "np_cm_build_jobs_identity", "np_fill_read_host", "np_hmm_score_host", "np_hmm_score_set_host", "np_hmm_align_host", "np_event_align_host",
@@ -102,6 +102,7 @@ def load_library():
     L.np_last_error.restype = C.c_char_p
     L.np_last_error.argtypes = [vp]
     L.np_version.restype = C.c_char_p
+    L.np_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.np_register_model.argtypes = [vp, C.c_int, C.c_int, c_f64p, c_f64p, c_f64p]
     L.np_alphabet_id.argtypes = [C.c_char_p]
     L.np_alphabet_size.restype = C.c_uint32

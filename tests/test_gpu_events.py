@@ -35,6 +35,50 @@ def test_detect_events_matches_oracle_and_goldens(ctx, orc, models):
             assert _same(g, {k: gold["r%d_%s_%s" % (rid, tag, k)] for k in ("start", "length", "mean", "stdv")})
 
 
+def quiet_stretch_raw(models):
+    """Raw signal with a 3000-sample stretch whose t-statistics stay within (0, peak_height] after touching exactly 0: the
+    detectors' running minimum is then older than any warm-up window, so the segments of the parallel walk that start
+    inside the stretch enter with the wrong state and have to be repaired (np_ed_peaks_par_kernel)."""
+    rng = np.random.default_rng(21)
+    a = synth_raw(9, models["nucleotide"], L=400)["raw"]
+    period3 = np.tile(np.array([80.0, 100.0, 120.0], np.float32), 20)                                  # window sums equal: t == 0
+    quiet = (np.tile(np.array([80.0, 100.0, 120.0]), 1000) + rng.normal(0, 0.02, 3000)).astype(np.float32)
+    b = synth_raw(10, models["nucleotide"], L=800)["raw"]
+    return np.concatenate([a, period3, quiet, b]).astype(np.float32)
+
+
+def test_parallel_peak_walk_is_exact_without_any_warmup(ctx, orc, models):
+    """ed_warmup = 0: every segment of the parallel walk starts from the initial state at its first sample, i.e. with the
+    wrong state almost everywhere, and the verify/repair rounds have to rebuild the serial walk (up to 63 rounds)."""
+    raws = [synth_raw(r, models["nucleotide"], L=L)["raw"] for r, L in ((11, 1200), (12, 5450))] + [quiet_stretch_raw(models)]
+    ctx.set_option("ed_warmup", 0)
+    try:
+        got = ctx.detect_events(raws)
+    finally:
+        ctx.set_option("ed_warmup", -1)
+    for raw, g in zip(raws, got):
+        assert _same(g, orc.detect_events(raw, **ED_DEFAULTS))
+    ctx.set_option("ed_warmup", 3)
+    try:
+        got = ctx.detect_events(raws, rna=True)
+    finally:
+        ctx.set_option("ed_warmup", -1)
+    for raw, g in zip(raws, got):
+        assert _same(g, orc.detect_events(raw, **ED_RNA))
+
+
+def test_parallel_peak_walk_repairs_unconverged_segments(ctx, orc, models):
+    raw = quiet_stretch_raw(models)
+    assert len(raw) > 8192
+    want = orc.detect_events(raw, **ED_DEFAULTS)
+    got = ctx.detect_events([raw, raw[:5000], raw[2000:]])
+    assert _same(got[0], want) and len(want["mean"]) > 500
+    assert _same(got[1], orc.detect_events(raw[:5000], **ED_DEFAULTS)) and _same(got[2], orc.detect_events(raw[2000:], **ED_DEFAULTS))
+    # the stretch really is event-free (otherwise it would not exercise the repair path)
+    lo = len(synth_raw(9, models["nucleotide"], L=400)["raw"]) + 200
+    assert not np.any((want["start"] > lo) & (want["start"] < lo + 2500))
+
+
 def test_detector_declines_reads_whose_sums_are_not_provably_exact(ctx, models):
     """A 50k-sample read with one sample of 1e-3 pA: the reference's double prefix sums of squares round, so an
     order-independent evaluation is no longer guaranteed identical -- the library says so instead of approximating."""

@@ -86,6 +86,8 @@ def test_event_detection_bit_equal(ref, orc, models):
     raws.append((80 + 10 * rng.standard_normal(3000)).astype(np.float32))            # white noise
     raws.append(np.repeat(rng.uniform(60, 120, 60), 25).astype(np.float32))           # noiseless steps (zero variance windows)
     raws.append(synth_raw(6, models["nucleotide"], L=300)["raw"][:40])                # very short
+    from test_gpu_events import quiet_stretch_raw
+    raws.append(quiet_stretch_raw(models))                                            # long event-free stretch with tiny t-statistics
     for raw in raws:
         for prm in (ED_DEFAULTS, ED_RNA):
             a, b = orc.detect_events(raw, **prm), ref.detect_events(raw, **prm)
