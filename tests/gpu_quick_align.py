@@ -1,6 +1,6 @@
 """Debug helper (not a test): event-align parity of a few reads against the oracle, for A/B library builds (NP_HIP_LIB)."""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oracle import Oracle, load_models
 from nanopolish_amd.api import Context
