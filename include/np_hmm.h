@@ -243,6 +243,24 @@ int np_calibrate_resolve_dev(np_ctx* ctx, void* stream, int n_reads, np_read_dev
 void np_aligner_constants(uint32_t n_events, uint32_t n_kmers, double out[4]);
 void np_restated_log_exp(const double* x, size_t n, double* out_log, double* out_exp);
 
+/* ---- f3: work-item generation on the device ------------------------------------------------ */
+/* Device twin of np_cm_build_jobs_identity for a batch of identity-aligned reads: motif scan and grouping
+ * (src/basemods/nanopolish_basemods.cpp:298-320), window and boundary rules (:328-345; src/alignment/nanopolish_alignment_db.cpp:
+ * 65-71,697-708), methylated / unmethylated k-mer ranks of every window (Alphabet::methylate / reverse_complement,
+ * HMMInputSequence::get_kmer_rank).  alphabet: cpg or gpc.  All pointers are device pointers.
+ *   ref_seq / seq_off : the reference strand of every read (A/C/G/T bytes, concatenated), int64[n_reads+1]
+ *   group_off         : int64[n_reads+1], per-read CAPACITY in groups (slots); total_group_slots = group_off[n_reads] (host value)
+ *   rank_off          : int64[n_reads+1], per-read capacity in job k-mer ranks (both versions of all windows)
+ *   jobs              : 2 work items per group slot (unmethylated, methylated), ready for np_resolve_jobs_dev /
+ *                       np_calibrate_resolve_dev; unused slots carry NP_JOB_SKIP
+ *   kpos              : 2 x int32 per work item; first_site / last_site / n_motif: per group slot
+ *   n_groups          : per read: groups written, or -1 if a capacity was too small */
+int np_cm_build_jobs_identity_dev(np_ctx* ctx, void* stream, int n_reads, const char* ref_seq, const int64_t* seq_off,
+                                  const uint8_t* read_rc, int alphabet, uint32_t k, int min_separation, int min_flank,
+                                  const int64_t* group_off, int64_t total_group_slots, const int64_t* rank_off,
+                                  np_hmm_job_dev* jobs, int32_t* kpos, uint16_t* job_ranks,
+                                  int32_t* first_site, int32_t* last_site, int32_t* n_motif, int32_t* n_groups);
+
 /* ---- f2: the stage in front of the event aligner ------------------------------------------ */
 /* detector_param, src/thirdparty/scrappie/event_detection.h:6-12 */
 typedef struct np_detector_param {

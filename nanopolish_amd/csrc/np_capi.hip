@@ -67,6 +67,7 @@ struct np_ctx {
     dev_buf b_jobs, b_reads, b_events, b_ranks, b_out, b_pair_off, b_pairs, b_pair_begin, b_n_pairs,
             b_vm, b_bp, b_cell_off, b_state_off, b_states, b_n_states;
     dev_buf ed_status, ed_tstat;      // event detection scratch
+    dev_buf cm_group_rank_off;        // work-item generation scratch
     dev_buf b_raw, b_raw_off, b_ev_off, b_ev_start, b_ev_len, b_ev_mean, b_ev_stdv, b_n_events;
     timing_t timing[NP_NUM_FAMILIES];
     std::mutex lock;
@@ -254,7 +255,7 @@ void np_destroy(np_ctx* c)
     dev_buf* bufs[] = {&c->order, &c->trace, &c->kparams, &c->b_jobs, &c->b_reads, &c->b_events, &c->b_ranks, &c->b_out, &c->b_pair_off,
                        &c->b_pairs, &c->b_pair_begin, &c->b_n_pairs, &c->b_vm, &c->b_bp, &c->b_cell_off, &c->b_state_off,
                        &c->b_states, &c->b_n_states, &c->ed_status, &c->ed_tstat, &c->b_raw, &c->b_raw_off, &c->b_ev_off, &c->b_ev_start,
-                       &c->b_ev_len, &c->b_ev_mean, &c->b_ev_stdv, &c->b_n_events};
+                       &c->b_ev_len, &c->b_ev_mean, &c->b_ev_stdv, &c->b_n_events, &c->cm_group_rank_off};
     for (dev_buf* b : bufs) b->release();
     for (auto& t : c->timing) {
         for (auto& pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -613,6 +614,27 @@ int np_event_align_host(np_ctx* c, int n_jobs, const np_align_job* jobs, np_pair
         w += hn[j];
     }
     out_off[n_jobs] = w;
+    return NP_OK;
+}
+
+// ---- f3: work-item generation on the device ---------------------------------------------------------------------------
+int np_cm_build_jobs_identity_dev(np_ctx* c, void* stream, int n_reads, const char* ref_seq, const int64_t* seq_off, const uint8_t* read_rc,
+                                  int alphabet, uint32_t k, int min_separation, int min_flank, const int64_t* group_off,
+                                  int64_t total_group_slots, const int64_t* rank_off, np_hmm_job_dev* jobs, int32_t* kpos,
+                                  uint16_t* job_ranks, int32_t* first_site, int32_t* last_site, int32_t* n_motif, int32_t* n_groups)
+{
+    if (!c || n_reads < 0 || (n_reads > 0 && (!ref_seq || !seq_off || !read_rc || !group_off || !rank_off || !jobs || !kpos || !job_ranks ||
+                                             !first_site || !last_site || !n_motif || !n_groups))) return NP_ERR_INVALID;
+    if (alphabet != 1 && alphabet != 2) { c->err = "np_cm_build_jobs_identity_dev: cpg or gpc only (dinucleotide sites)"; return NP_ERR_UNSUPPORTED; }
+    if (k < 1 || k > 6) { c->err = "np_cm_build_jobs_identity_dev: k must be 1..6 (uint16 ranks over 5 letters)"; return NP_ERR_UNSUPPORTED; }
+    if (n_reads == 0) return NP_OK;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = pick_stream(c, stream);
+    NP_HIP(c, c->cm_group_rank_off.reserve((size_t)total_group_slots * sizeof(int64_t)));
+    family_timer tm(c, 2, s);
+    NP_HIP(c, np_launch_cm_build_jobs(n_reads, ref_seq, seq_off, read_rc, alphabet, (int)k, min_separation, min_flank, group_off, rank_off, jobs,
+                                      kpos, job_ranks, first_site, last_site, n_motif, c->cm_group_rank_off.as<int64_t>(), n_groups, s));
     return NP_OK;
 }
 

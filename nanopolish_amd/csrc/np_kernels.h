@@ -76,3 +76,9 @@ hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t*
                                    hipStream_t s);
 hipError_t np_launch_mom_fill(int n_reads, np_read_dev* reads, np_read_dev* reads_b, const float* event_mean, const int32_t* n_events,
                               const uint16_t* ranks, const np_state_dev* model, hipStream_t s);
+
+// ---- f3: call-methylation work items of identity-aligned reads (np_jobs_kernels.hip) -----------------------------------
+hipError_t np_launch_cm_build_jobs(int n_reads, const char* seq, const int64_t* seq_off, const uint8_t* read_rc, int alphabet, int k,
+                                   int min_separation, int min_flank, const int64_t* group_off, const int64_t* rank_off_cap,
+                                   np_hmm_job_dev* jobs, int32_t* kpos, uint16_t* job_ranks, int32_t* first_site, int32_t* last_site,
+                                   int32_t* n_motif, int64_t* group_rank_off, int32_t* n_groups, hipStream_t s);

@@ -48,7 +48,7 @@ def build_host_batch(models, read_ids, L=5450, k=6, raw=False):
     ranks = np.concatenate([r["ranks"] for r in reads]).astype(np.uint16)
     reads_a = np.zeros(n, READ_DT); reads_b = np.zeros(n, READ_DT)
     mom = np.zeros((n, 2))
-    jobs, kpos, jranks, meta = [], [], [], []
+    jobs, kpos, jranks, meta, ref_seqs = [], [], [], [], []
     jr_off = 0
     for i, r in enumerate(reads):
         sh, sc = (0.0, 1.0) if raw else api.estimate_scalings_using_mom(nuc, r["ranks"], r["events"])
@@ -58,6 +58,7 @@ def build_host_batch(models, read_ids, L=5450, k=6, raw=False):
             L_.np_fill_read_host(C.cast(arr[i:i + 1].ctypes.data, C.POINTER(_l.ReadDev)), shift, scale, var,
                                  int(event_off[i]), ne, int(rank_off[i]), nk)
         ref_seq = api.reverse_complement("nucleotide", r["seq"]) if r["rc"] else r["seq"]
+        ref_seqs.append(ref_seq)
         jb = api.cm_build_jobs_identity(ref_seq, r["rc"], k)
         ng = len(jb["first"])
         j = np.zeros(2 * ng, JOB_DT)
@@ -80,7 +81,7 @@ def build_host_batch(models, read_ids, L=5450, k=6, raw=False):
         raw_off = np.zeros(n + 1, np.int64); raw_off[1:] = np.cumsum([len(r["raw"]) for r in reads])
         extra = dict(raw=np.concatenate([r["raw"] for r in reads]).astype(np.float32), raw_off=raw_off)
     return dict(reads=reads, n=n, events=events, ranks=ranks, event_off=event_off, rank_off=rank_off,
-                reads_a=reads_a, reads_b=reads_b, mom=mom, **extra,
+                reads_a=reads_a, reads_b=reads_b, mom=mom, ref_seqs=ref_seqs, k=k, **extra,
                 jobs=np.concatenate(jobs) if jobs else np.zeros(0, JOB_DT),
                 kpos=np.concatenate(kpos).astype(np.int32) if kpos else np.zeros((0, 2), np.int32),
                 job_ranks=np.concatenate(jranks).astype(np.uint16) if jranks else np.zeros(0, np.uint16),
@@ -105,6 +106,7 @@ def tile_host_batch(hb, tile):
     j["read"] += np.repeat(np.arange(tile, dtype=np.uint32) * n, nj).astype(np.uint32)
     j["rank_off"] += np.repeat(np.arange(tile, dtype=np.int64) * njr, nj)
     out["jobs"] = j
+    out["ref_seqs"] = hb["ref_seqs"] * tile
     if "raw" in hb:
         ns = len(hb["raw"])
         out["raw"] = np.tile(hb["raw"], tile)
@@ -115,7 +117,7 @@ def tile_host_batch(hb, tile):
 
 
 class CallMethylationBatch:
-    def __init__(self, ctx, hb, device="cuda:0", calibrate=False, from_raw=False):
+    def __init__(self, ctx, hb, device="cuda:0", calibrate=False, from_raw=False, jobs_on_device=False):
         """calibrate=False: kernel B scores with the scalings the caller put in hb["reads_b"] (a read whose
         calibration was done elsewhere).  calibrate=True: the pass recalibrates every read on the device from its
         own event alignment, as load_from_raw does (squiggle_read.cpp:304-323), and reads_b is overwritten."""
@@ -123,6 +125,7 @@ class CallMethylationBatch:
         self.torch = torch
         self.calibrate = bool(calibrate)
         self.from_raw = bool(from_raw)
+        self.jobs_on_device = bool(jobs_on_device)
         self.ctx = ctx
         self.hb = hb
         self.n_reads = hb["n"]
@@ -149,7 +152,32 @@ class CallMethylationBatch:
             self.d_n_events = torch.zeros(self.n_reads, dtype=torch.int32, device=dev)
             self.prm = _l.DetectorParam(); ctx.L.np_event_detection_params(C.byref(self.prm), 0)
         self.d_reads_a = up(hb["reads_a"]); self.d_reads_b = up(hb["reads_b"])
-        self.d_jobs = up(hb["jobs"]); self.d_kpos = up(hb["kpos"]); self.d_job_ranks = up(hb["job_ranks"])
+        if self.jobs_on_device:
+            # work items are generated on the device from the reads' reference strands: group slots at
+            # per-read capacity offsets (groups are > min_separation apart), two work items per slot
+            MINSEP, FLANK = 10, 10
+            seqs = hb["ref_seqs"]
+            ln = np.array([len(q) for q in seqs], np.int64)
+            self.seq_off = np.zeros(self.n_reads + 1, np.int64); self.seq_off[1:] = np.cumsum(ln)
+            gcap = ln // (MINSEP + 1) + 2
+            self.group_off = np.zeros(self.n_reads + 1, np.int64); self.group_off[1:] = np.cumsum(gcap)
+            rcap = 2 * (ln + (2 * FLANK + 1) * gcap)
+            jr_off = np.zeros(self.n_reads + 1, np.int64); jr_off[1:] = np.cumsum(rcap)
+            self.n_slots = int(self.group_off[-1])
+            self.n_jobs = 2 * self.n_slots
+            self.d_seq = up(np.frombuffer("".join(seqs).encode(), np.uint8).copy()); self.d_seq_off = up(self.seq_off)
+            self.d_rc = up(np.array([r["rc"] for r in hb["reads"]] * (self.n_reads // len(hb["reads"])), np.uint8))
+            self.d_group_off = up(self.group_off); self.d_jr_off = up(jr_off)
+            self.d_jobs = torch.zeros(self.n_jobs * JOB_DT.itemsize, dtype=torch.uint8, device=dev)
+            self.d_kpos = torch.zeros(2 * self.n_jobs, dtype=torch.int32, device=dev)
+            self.d_job_ranks = torch.zeros(int(jr_off[-1]), dtype=torch.int16, device=dev)
+            self.d_first = torch.zeros(self.n_slots, dtype=torch.int32, device=dev)
+            self.d_last = torch.zeros(self.n_slots, dtype=torch.int32, device=dev)
+            self.d_n_motif = torch.zeros(self.n_slots, dtype=torch.int32, device=dev)
+            self.d_n_groups = torch.zeros(self.n_reads, dtype=torch.int32, device=dev)
+            self.cm = (MINSEP, FLANK, int(hb.get("k", 6)))
+        else:
+            self.d_jobs = up(hb["jobs"]); self.d_kpos = up(hb["kpos"]); self.d_job_ranks = up(hb["job_ranks"])
         ne = (hb["event_off"][1:] - hb["event_off"][:-1]); nk = (hb["rank_off"][1:] - hb["rank_off"][:-1])
         bands = ne + nk + 2
         self.max_bands = int(bands.max())
@@ -176,6 +204,12 @@ class CallMethylationBatch:
     def step(self):
         L, h = self.ctx.L, self.ctx.h
         p = lambda t: C.c_void_p(t.data_ptr())
+        if self.jobs_on_device:
+            rc = L.np_cm_build_jobs_identity_dev(h, None, self.n_reads, p(self.d_seq), p(self.d_seq_off), p(self.d_rc), api.alphabet_id("cpg"),
+                                                 self.cm[2], self.cm[0], self.cm[1], p(self.d_group_off), self.n_slots, p(self.d_jr_off),
+                                                 p(self.d_jobs), p(self.d_kpos), p(self.d_job_ranks), p(self.d_first), p(self.d_last),
+                                                 p(self.d_n_motif), p(self.d_n_groups))
+            self.ctx._chk(rc, "np_cm_build_jobs_identity_dev")
         if self.from_raw:
             rc = L.np_detect_events_dev(h, None, self.n_reads, p(self.d_raw), p(self.d_raw_off), self.max_samples, C.byref(self.prm),
                                         p(self.d_tstat), p(self.d_event_off), self.max_events, p(self.d_ev_start), p(self.d_ev_len),
@@ -241,6 +275,13 @@ class CallMethylationBatch:
         """np_read_dev records kernel A used (MoM scalings + aligner constants; filled on the device when from_raw=True)."""
         self.sync()
         return self.d_reads_a.cpu().numpy().view(READ_DT)
+
+    def groups_of(self, r):
+        """(first_site positions, n_motif, unmethylated scores, methylated scores) of read r's groups (jobs_on_device=True)."""
+        self.sync()
+        ng = int(self.d_n_groups[r]); g0 = int(self.group_off[r])
+        sc = self.d_scores[2 * g0:2 * (g0 + ng)].cpu().numpy()
+        return self.d_first[g0:g0 + ng].cpu().numpy(), self.d_n_motif[g0:g0 + ng].cpu().numpy(), sc[0::2], sc[1::2]
 
     def calibrated(self):
         self.sync()
