@@ -261,6 +261,39 @@ int np_cm_build_jobs_identity_dev(np_ctx* ctx, void* stream, int n_reads, const 
                                   np_hmm_job_dev* jobs, int32_t* kpos, uint16_t* job_ranks,
                                   int32_t* first_site, int32_t* last_site, int32_t* n_motif, int32_t* n_groups);
 
+/* CIGAR-driven twin: the reads' base-to-reference alignments come from BAM CIGARs instead of
+ * the identity.  Replaces, per read, SequenceAlignmentRecord / get_aligned_segments (src/alignment/nanopolish_alignment_db.cpp:
+ * 30-50, src/alignment/nanopolish_anchor.cpp:20-95), the pair filter of EventAlignmentRecord (:63-72) and
+ * AlignmentDB::_find_by_ref_bounds (:688-731) for both ends of every window; the aligned pairs are never materialised (a
+ * per-read scan of the CIGAR operations + binary searches).  All pointers are device pointers.
+ *   genome               : the contig(s), resident on the device (A/C/G/T, already disambiguated)
+ *   ref_begin / ref_len  : int64[n_reads] / int32[n_reads]: the segment the reference fetches for read r,
+ *                          contig[pos .. bam_endpos] inclusive, clipped to the contig (basemods.cpp:259-270), as an offset into genome
+ *   cigar / cigar_off    : uint32 BAM words (length << 4 | op) of all reads, int64[n_reads+1]; a spliced record (N) yields no items
+ *   read_len / read_rc   : SquiggleRead::read_sequence.length(), bam_is_rev
+ *   deg_kpos             : int32[2*n_reads] output for np_cm_discard_degenerate_dev
+ * first_site / last_site are relative to the record's pos.  Other arguments as np_cm_build_jobs_identity_dev. */
+int np_cm_build_jobs_cigar_dev(np_ctx* ctx, void* stream, int n_reads, const char* genome, const int64_t* ref_begin,
+                               const int32_t* ref_len, const uint32_t* cigar, const int64_t* cigar_off, int64_t total_cigar_ops,
+                               const int32_t* read_len, const uint8_t* read_rc, int alphabet, uint32_t k, int min_separation,
+                               int min_flank, const int64_t* group_off, int64_t total_group_slots, const int64_t* rank_off,
+                               np_hmm_job_dev* jobs, int32_t* kpos, uint16_t* job_ranks,
+                               int32_t* first_site, int32_t* last_site, int32_t* n_motif, int32_t* n_groups, int32_t* deg_kpos);
+/* After np_resolve_jobs_dev / np_calibrate_resolve_dev: drops every work item of a read whose first and last aligned event
+ * coincide (the "degenerate alignment" rule of EventAlignmentRecord, alignment_db.cpp:83-86). */
+int np_cm_discard_degenerate_dev(np_ctx* ctx, void* stream, const np_read_dev* reads, const int32_t* map_start,
+                                 const int32_t* deg_kpos, int64_t n_jobs, np_hmm_job_dev* jobs);
+
+/* Host mirrors (pure CPU): get_aligned_segments for a non-spliced record (returns the number of aligned pairs; NP_ERR_INVALID
+ * for a spliced or malformed CIGAR), and the work items of a CIGAR-aligned read (see np_cm_build_jobs_identity;
+ * ref_seq[0..n) is the fetched reference segment, deg_kpos[2] as above). */
+int np_cigar_aligned_bases(const uint32_t* cigar, int n_cigar, int ref_pos0, int32_t* ref_pos, int32_t* read_pos, int cap);
+int np_cm_build_jobs_cigar(int alphabet, const char* ref_seq, size_t n, const uint32_t* cigar, int n_cigar,
+                           int read_len, int read_rc, uint32_t k, int min_separation, int min_flank,
+                           int cap_jobs, int64_t cap_ranks, int32_t* first_site, int32_t* last_site, int32_t* n_motif,
+                           int32_t* kpos, int32_t* job_n_kmers, uint16_t* ranks_unmeth, uint16_t* ranks_meth,
+                           int64_t* rank_off, int32_t* deg_kpos);
+
 /* ---- f2: the stage in front of the event aligner ------------------------------------------ */
 /* detector_param, src/thirdparty/scrappie/event_detection.h:6-12 */
 typedef struct np_detector_param {

@@ -106,6 +106,50 @@ def cm_build_jobs_identity(ref_seq, read_rc, k=6, alphabet="cpg", min_separation
                 n_kmers=nk[:nj].copy(), ranks_unmeth=ru[:w].copy(), ranks_meth=rm[:w].copy(), rank_off=ro[:nj + 1].copy())
 
 
+CIGAR_OPS = "MIDNSHP=X"
+
+
+def cigar_words(ops):
+    """[(op_char, length), ...] -> uint32 BAM CIGAR words (length << 4 | op)"""
+    return np.array([(int(n) << 4) | CIGAR_OPS.index(o) for o, n in ops], np.uint32)
+
+
+def cigar_aligned_bases(cigar, ref_pos0=0):
+    """get_aligned_segments of a non-spliced record (see np_cigar_aligned_bases): int32[n, 2] of (ref_pos, read_pos)"""
+    cg = np.ascontiguousarray(cigar, np.uint32)
+    L = _l.load_library()
+    n = L.np_cigar_aligned_bases(_p(cg, _l.c_u32p), len(cg), int(ref_pos0), None, None, 0)
+    if n < 0:
+        raise ValueError("np_cigar_aligned_bases: %d (spliced or malformed CIGAR)" % n)
+    rp, qp = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    L.np_cigar_aligned_bases(_p(cg, _l.c_u32p), len(cg), int(ref_pos0), _p(rp, _l.c_i32p), _p(qp, _l.c_i32p), n)
+    return np.stack([rp, qp], 1)
+
+
+def cm_build_jobs_cigar(ref_seq, cigar, read_len, read_rc, k=6, alphabet="cpg", min_separation=10, min_flank=10):
+    """Work items of calculate_methylation_for_read for a CIGAR-aligned read (see np_cm_build_jobs_cigar).
+    ref_seq: the fetched reference segment contig[pos .. bam_endpos] (clipped); first/last are relative to pos."""
+    n = len(ref_seq)
+    cg = np.ascontiguousarray(cigar, np.uint32)
+    cap_jobs = n // 2 + 1
+    cap_ranks = 4 * n + 1024
+    f = np.zeros(cap_jobs, np.int32); l = np.zeros(cap_jobs, np.int32); c = np.zeros(cap_jobs, np.int32)
+    kpos = np.zeros(2 * cap_jobs, np.int32); nk = np.zeros(cap_jobs, np.int32)
+    ru = np.zeros(cap_ranks, np.uint16); rm = np.zeros(cap_ranks, np.uint16); ro = np.zeros(cap_jobs + 1, np.int64)
+    deg = np.zeros(2, np.int32)
+    nj = _l.load_library().np_cm_build_jobs_cigar(alphabet_id(alphabet), ref_seq.encode(), n, _p(cg, _l.c_u32p), len(cg), int(read_len),
+                                                  int(read_rc), k, min_separation, min_flank, cap_jobs, cap_ranks,
+                                                  _p(f, _l.c_i32p), _p(l, _l.c_i32p), _p(c, _l.c_i32p), _p(kpos, _l.c_i32p),
+                                                  _p(nk, _l.c_i32p), _p(ru, _l.c_u16p), _p(rm, _l.c_u16p), _p(ro, _l.c_i64p),
+                                                  _p(deg, _l.c_i32p))
+    if nj < 0:
+        raise RuntimeError("np_cm_build_jobs_cigar: %d" % nj)
+    w = int(ro[nj])
+    return dict(first=f[:nj].copy(), last=l[:nj].copy(), n_motif=c[:nj].copy(), kpos=kpos[:2 * nj].reshape(-1, 2).copy(),
+                n_kmers=nk[:nj].copy(), ranks_unmeth=ru[:w].copy(), ranks_meth=rm[:w].copy(), rank_off=ro[:nj + 1].copy(),
+                deg_kpos=deg.copy())
+
+
 # ---- device context ---------------------------------------------------------------------------------------------
 class Context:
     """np_ctx wrapper.  Raises RuntimeError if no gfx950 device is usable (no CPU fallback)."""

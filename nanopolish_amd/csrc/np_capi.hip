@@ -67,7 +67,7 @@ struct np_ctx {
     dev_buf b_jobs, b_reads, b_events, b_ranks, b_out, b_pair_off, b_pairs, b_pair_begin, b_n_pairs,
             b_vm, b_bp, b_cell_off, b_state_off, b_states, b_n_states;
     dev_buf ed_status, ed_tstat;      // event detection scratch
-    dev_buf cm_group_rank_off;        // work-item generation scratch
+    dev_buf cm_group_rank_off, cm_cigar_scratch;        // work-item generation scratch
     dev_buf b_raw, b_raw_off, b_ev_off, b_ev_start, b_ev_len, b_ev_mean, b_ev_stdv, b_n_events;
     timing_t timing[NP_NUM_FAMILIES];
     std::mutex lock;
@@ -255,7 +255,7 @@ void np_destroy(np_ctx* c)
     dev_buf* bufs[] = {&c->order, &c->trace, &c->kparams, &c->b_jobs, &c->b_reads, &c->b_events, &c->b_ranks, &c->b_out, &c->b_pair_off,
                        &c->b_pairs, &c->b_pair_begin, &c->b_n_pairs, &c->b_vm, &c->b_bp, &c->b_cell_off, &c->b_state_off,
                        &c->b_states, &c->b_n_states, &c->ed_status, &c->ed_tstat, &c->b_raw, &c->b_raw_off, &c->b_ev_off, &c->b_ev_start,
-                       &c->b_ev_len, &c->b_ev_mean, &c->b_ev_stdv, &c->b_n_events, &c->cm_group_rank_off};
+                       &c->b_ev_len, &c->b_ev_mean, &c->b_ev_stdv, &c->b_n_events, &c->cm_group_rank_off, &c->cm_cigar_scratch};
     for (dev_buf* b : bufs) b->release();
     for (auto& t : c->timing) {
         for (auto& pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -635,6 +635,47 @@ int np_cm_build_jobs_identity_dev(np_ctx* c, void* stream, int n_reads, const ch
     family_timer tm(c, 2, s);
     NP_HIP(c, np_launch_cm_build_jobs(n_reads, ref_seq, seq_off, read_rc, alphabet, (int)k, min_separation, min_flank, group_off, rank_off, jobs,
                                       kpos, job_ranks, first_site, last_site, n_motif, c->cm_group_rank_off.as<int64_t>(), n_groups, s));
+    return NP_OK;
+}
+
+int np_cm_build_jobs_cigar_dev(np_ctx* c, void* stream, int n_reads, const char* genome, const int64_t* ref_begin, const int32_t* ref_len,
+                               const uint32_t* cigar, const int64_t* cigar_off, int64_t total_cigar_ops, const int32_t* read_len,
+                               const uint8_t* read_rc, int alphabet, uint32_t k, int min_separation, int min_flank, const int64_t* group_off,
+                               int64_t total_group_slots, const int64_t* rank_off, np_hmm_job_dev* jobs, int32_t* kpos, uint16_t* job_ranks,
+                               int32_t* first_site, int32_t* last_site, int32_t* n_motif, int32_t* n_groups, int32_t* deg_kpos)
+{
+    if (!c || n_reads < 0 || total_cigar_ops < 0 ||
+        (n_reads > 0 && (!genome || !ref_begin || !ref_len || !cigar || !cigar_off || !read_len || !read_rc || !group_off || !rank_off || !jobs ||
+                         !kpos || !job_ranks || !first_site || !last_site || !n_motif || !n_groups || !deg_kpos))) return NP_ERR_INVALID;
+    if (alphabet != 1 && alphabet != 2) { c->err = "np_cm_build_jobs_cigar_dev: cpg or gpc only (dinucleotide sites)"; return NP_ERR_UNSUPPORTED; }
+    if (k < 1 || k > 6) { c->err = "np_cm_build_jobs_cigar_dev: k must be 1..6 (uint16 ranks over 5 letters)"; return NP_ERR_UNSUPPORTED; }
+    if (n_reads == 0) return NP_OK;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = pick_stream(c, stream);
+    const size_t n_idx = (size_t)total_cigar_ops + (size_t)n_reads;
+    NP_HIP(c, c->cm_group_rank_off.reserve((size_t)total_group_slots * sizeof(int64_t)));
+    NP_HIP(c, c->cm_cigar_scratch.reserve(2 * n_idx * sizeof(int32_t) + (size_t)n_reads * 16 + 2 * (size_t)total_group_slots * sizeof(int32_t)));
+    int32_t* op_ref = c->cm_cigar_scratch.as<int32_t>();
+    int32_t* op_read = op_ref + n_idx;
+    int32_t* cig_reads = op_read + n_idx;                      // 16 B per read
+    int32_t* group_kpos = cig_reads + 4 * (size_t)n_reads;
+    family_timer tm(c, 2, s);
+    NP_HIP(c, np_launch_cm_build_jobs_cigar(n_reads, genome, ref_begin, ref_len, cigar, cigar_off, read_len, read_rc, alphabet, (int)k,
+                                            min_separation, min_flank, group_off, rank_off, jobs, kpos, job_ranks, first_site, last_site, n_motif,
+                                            c->cm_group_rank_off.as<int64_t>(), n_groups, deg_kpos, op_ref, op_read, cig_reads, group_kpos, s));
+    return NP_OK;
+}
+
+int np_cm_discard_degenerate_dev(np_ctx* c, void* stream, const np_read_dev* reads, const int32_t* map_start, const int32_t* deg_kpos,
+                                 int64_t n_jobs, np_hmm_job_dev* jobs)
+{
+    if (!c || n_jobs < 0 || (n_jobs > 0 && (!reads || !map_start || !deg_kpos || !jobs))) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = pick_stream(c, stream);
+    family_timer tm(c, 2, s);
+    NP_HIP(c, np_launch_discard_degenerate(n_jobs, jobs, reads, map_start, deg_kpos, s));
     return NP_OK;
 }
 

@@ -340,6 +340,38 @@ hipError_t np_launch_build_map(int n_reads, np_read_dev* reads, const int64_t* p
     return hipGetLastError();
 }
 
+namespace {
+// EventAlignmentRecord discards a record whose first and last aligned event coincide (alignment_db.cpp:83-86): every
+// work item of such a read is unbounded.  deg_kpos holds, per read, the read-strand k-mer positions of the first and last
+// aligned base that pass the record's filter (-1: none).  Thread per work item, after np_resolve_kernel.
+__global__ void __launch_bounds__(256) np_discard_degenerate_kernel(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads,
+                                                                    const int32_t* map_start, const int32_t* deg_kpos)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_jobs) return;
+    np_hmm_job_dev job = jobs[j];
+    if (job.flags & NP_JOB_SKIP) return;
+    const np_read_dev* rd = reads + job.read;
+    const int K = (int)rd->n_kmers;
+    const int k1 = deg_kpos[2 * job.read], k2 = deg_kpos[2 * job.read + 1];
+    bool drop = k1 < 0 || k1 >= K || k2 < 0 || k2 >= K;
+    if (!drop) {
+        const int32_t* ms = map_start + rd->rank_off;
+        drop = closest_event(ms, K, k1) == closest_event(ms, K, k2);
+    }
+    if (drop) { job.e_start = 0; job.e_stop = 0; job.stride = 1; job.flags |= NP_JOB_SKIP; jobs[j] = job; }
+}
+} // namespace
+
+hipError_t np_launch_discard_degenerate(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads, const int32_t* map_start,
+                                        const int32_t* deg_kpos, hipStream_t s)
+{
+    if (n_jobs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(np_discard_degenerate_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, s, n_jobs, jobs, reads,
+                       map_start, deg_kpos);
+    return hipGetLastError();
+}
+
 hipError_t np_launch_resolve(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads, const int32_t* n_pairs,
                              const double* events_per_base, const int32_t* calibrated, const int32_t* map_start,
                              const int32_t* kpos, hipStream_t s)

@@ -258,6 +258,101 @@ int np_cm_build_jobs_identity(int alphabet, const char* ref_seq, size_t n, int r
     return nj;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// CIGAR-driven work items: the same as above for a read whose base-to-reference alignment
+// comes from a BAM record's CIGAR.
+// ---------------------------------------------------------------------------------------------------------------------
+// get_aligned_segments (src/alignment/nanopolish_anchor.cpp:20-95) for a non-spliced record: M/=/X emit a pair and advance
+// both, D advances the reference, I and S advance the read, H and P neither; N (a second segment) is what
+// SequenceAlignmentRecord rejects (alignment_db.cpp:43-47) and returns NP_ERR_INVALID here.  ref positions start at ref_pos0.
+int np_cigar_aligned_bases(const uint32_t* cigar, int n_cigar, int ref_pos0, int32_t* ref_pos, int32_t* read_pos, int cap)
+{
+    int n = 0, rp = ref_pos0, qp = 0;
+    for (int ci = 0; ci < n_cigar; ++ci) {
+        const int len = (int)(cigar[ci] >> 4), op = (int)(cigar[ci] & 0xf);
+        const bool aligned = op == 0 || op == 7 || op == 8;
+        if (op == 3 || op > 8) return NP_ERR_INVALID;
+        const int ref_inc = (aligned || op == 2) ? 1 : 0, read_inc = (aligned || op == 1 || op == 4) ? 1 : 0;
+        if (aligned) {
+            for (int j = 0; j < len; ++j) { if (n < cap) { ref_pos[n] = rp + j; read_pos[n] = qp + j; } ++n; }
+        }
+        rp += ref_inc * len; qp += read_inc * len;
+    }
+    return n;
+}
+
+namespace {
+// EventAlignmentRecord's filter (alignment_db.cpp:63-72) + AlignmentDB::_find_iter_by_ref_bounds (:688-711) on the aligned
+// BASES: the aligned events are these pairs with read_pos replaced by an event index, so the bounding pairs are the same.
+// Returns false when unbounded; else the read positions (reference strand) of the two bounding pairs.
+bool cigar_find_bounds(const std::vector<int32_t>& rp, const std::vector<int32_t>& qp, int ref_start, int ref_stop, int& q1, int& q2)
+{
+    const auto b = rp.begin(), e = rp.end();
+    const auto it1 = std::lower_bound(b, e, ref_start), it2 = std::lower_bound(b, e, ref_stop);
+    if (it1 == e || it2 == e) return false;
+    const bool left_bounded = *it1 <= ref_start || it1 != b;      // (start_iter - 1)->ref_pos <= ref_start always holds
+    // right_bounded: stop_iter->ref_pos >= ref_stop holds for every lower_bound result
+    if (!left_bounded) return false;
+    q1 = qp[it1 - b]; q2 = qp[it2 - b];
+    return true;
+}
+}
+
+// Work items of calculate_methylation_for_read for a CIGAR-aligned read.
+//   ref_seq[0..n)   the reference segment the reference fetches: contig[pos .. bam_endpos] inclusive, clipped to the contig
+//                   (basemods.cpp:259-270), already disambiguated; window coordinates are relative to pos
+//   cigar / read_len / read_rc   the record's CIGAR, SquiggleRead::read_sequence.length(), bam_is_rev
+//   deg_kpos[2]     read-strand k-mer positions of the first and last aligned event: when their closest events coincide the
+//                   reference discards the record (alignment_db.cpp:83-86); -1, -1 when the record has no aligned events
+// Other outputs as np_cm_build_jobs_identity.  Returns the number of jobs, NP_ERR_NOMEM or NP_ERR_INVALID.
+int np_cm_build_jobs_cigar(int alphabet, const char* ref_seq, size_t n, const uint32_t* cigar, int n_cigar,
+                           int read_len, int read_rc, uint32_t k, int min_separation, int min_flank,
+                           int cap_jobs, int64_t cap_ranks, int32_t* first_site, int32_t* last_site, int32_t* n_motif,
+                           int32_t* kpos, int32_t* job_n_kmers, uint16_t* ranks_unmeth, uint16_t* ranks_meth,
+                           int64_t* rank_off, int32_t* deg_kpos)
+{
+    const int n_al = np_cigar_aligned_bases(cigar, n_cigar, 0, nullptr, nullptr, 0);
+    if (n_al < 0) return n_al;
+    std::vector<int32_t> arp(n_al), aqp(n_al), rp, qp;
+    np_cigar_aligned_bases(cigar, n_cigar, 0, arp.data(), aqp.data(), n_al);
+    for (int i = 0; i < n_al; ++i)
+        if (aqp[i] >= (int)k && aqp[i] + (int)k < read_len) { rp.push_back(arp[i]); qp.push_back(aqp[i]); }
+    auto flip = [&](int q) { return read_rc ? read_len - q - (int)k : q; };     // flip_k_strand, squiggle_read.h:229-233
+    deg_kpos[0] = rp.empty() ? -1 : flip(qp.front());
+    deg_kpos[1] = rp.empty() ? -1 : flip(qp.back());
+
+    std::vector<int32_t> f(n + 1), l(n + 1), c(n + 1);
+    const int ng = np_scan_motif_groups(alphabet, ref_seq, n, min_separation, f.data(), l.data(), c.data(), (int)n + 1);
+    int nj = 0;
+    int64_t w = 0;
+    rank_off[0] = 0;
+    std::string sub, rc_sub, m_sub, rc_m_sub;
+    for (int g = 0; g < ng; ++g) {
+        const int sub_start = f[g] - min_flank, sub_end = l[g] + min_flank, span = l[g] - f[g];
+        if (sub_start <= min_separation || span > 200) continue;                       // basemods.cpp:334
+        int q1 = 0, q2 = 0;
+        if (!cigar_find_bounds(rp, qp, sub_start, sub_end, q1, q2)) continue;          // :346-358, `bounded`
+        if ((size_t)sub_end >= n) continue;          // cannot happen for a bounded window: the segment covers every aligned base
+        const size_t len = (size_t)(sub_end - sub_start + 1);
+        const uint32_t nk = (uint32_t)(len - k + 1);
+        if (nj >= cap_jobs || w + nk > cap_ranks) return NP_ERR_NOMEM;
+        sub.assign(ref_seq + sub_start, len);
+        rc_sub.resize(len + 1); m_sub.resize(len + 1); rc_m_sub.resize(len + 1);
+        np_reverse_complement(alphabet, sub.c_str(), len, &rc_sub[0]);
+        np_methylate(alphabet, sub.c_str(), len, &m_sub[0]);
+        np_reverse_complement(alphabet, m_sub.c_str(), len, &rc_m_sub[0]);
+        np_sequence_kmer_ranks(alphabet, sub.c_str(), rc_sub.c_str(), len, k, read_rc, ranks_unmeth + w);
+        np_sequence_kmer_ranks(alphabet, m_sub.c_str(), rc_m_sub.c_str(), len, k, read_rc, ranks_meth + w);
+        first_site[nj] = f[g]; last_site[nj] = l[g]; n_motif[nj] = c[g];
+        kpos[2 * nj] = flip(q1);
+        kpos[2 * nj + 1] = flip(q2);
+        job_n_kmers[nj] = (int32_t)nk;
+        w += nk;
+        rank_off[++nj] = w;
+    }
+    return nj;
+}
+
 void np_fill_read_host(np_read_dev* r, double shift, double scale, double var,
                        int64_t event_off, uint32_t n_events, int64_t rank_off, uint32_t n_kmers)
 {

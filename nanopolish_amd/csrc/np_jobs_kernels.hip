@@ -1,11 +1,17 @@
-// np_jobs_kernels.hip -- call-methylation work-item generation on the device for reads that
-// are identity-aligned to their reference strand (the bench/test layout; a CIGAR-driven caller supplies kpos itself):
+// np_jobs_kernels.hip -- call-methylation work-item generation on the device, for reads that
+// are identity-aligned to their reference strand (the bench layout) and for reads aligned by a BAM record's CIGAR:
+//   CIGAR walk                       get_aligned_segments, src/alignment/nanopolish_anchor.cpp:20-95
+//   aligned-event filter, bounds     EventAlignmentRecord, AlignmentDB::_find_iter_by_ref_bounds,
+//                                    src/alignment/nanopolish_alignment_db.cpp:63-72,688-711
 //   motif scan + grouping            calculate_methylation_for_read, src/basemods/nanopolish_basemods.cpp:298-320
 //   window rule / boundary rules     :328-345, EventAlignmentRecord bounds src/alignment/nanopolish_alignment_db.cpp:65-71,697-708
 //   methylated / unmethylated k-mers Alphabet::methylate / reverse_complement (src/common/nanopolish_alphabet.h:59-253) and
 //                                    HMMInputSequence::get_kmer_rank (src/hmm/nanopolish_hmm_input_sequence.h:76-91)
 // for the methylation alphabets whose recognition site is a dinucleotide (cpg: CG -> MG, gpc: GC -> GM).  It is the device
-// twin of np_cm_build_jobs_identity (np_host.cpp), against which tests/test_gpu_jobs.py compares it item by item.
+// twin of np_cm_build_jobs_identity / np_cm_build_jobs_cigar (np_host.cpp), against which tests/test_gpu_jobs.py compares it
+// item by item.
+// CIGAR mode never materialises the aligned pairs: a per-read exclusive scan of the operations' reference / read advances
+// (np_cigar_index_kernel) turns every lower_bound of the reference into one binary search over the operations.
 #include "np_kernels.h"
 
 namespace {
@@ -39,8 +45,137 @@ __device__ __forceinline__ char rc_meth_char(const char* __restrict__ ref, int w
     return comp(c);
 }
 
+
+// ---- CIGAR view ---------------------------------------------------------------------------------------------------------
+struct cig_view {
+    const uint32_t* cigar;     // BAM words: length << 4 | op
+    const int32_t* op_ref;     // reference offset (relative to the record's pos) at the start of every operation, n + 1 entries
+    const int32_t* op_read;    // read offset (reference strand) likewise
+    int n;
+};
+__device__ __forceinline__ bool op_aligned(uint32_t w) { const uint32_t op = w & 0xf; return op == 0 || op == 7 || op == 8; }
+
+// first aligned pair with ref_pos >= x: the operation that contains x is the last one starting at or before it
+__device__ __forceinline__ bool first_aligned_ref_ge(const cig_view& c, int x, int& q, int& r)
+{
+    int lo = 0, hi = c.n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (c.op_ref[mid] <= x) lo = mid + 1; else hi = mid; }
+    for (int i = lo > 0 ? lo - 1 : 0; i < c.n; ++i) {
+        const uint32_t w = c.cigar[i];
+        const int len = (int)(w >> 4);
+        if (!op_aligned(w) || len == 0) continue;
+        const int off = x - c.op_ref[i] > 0 ? x - c.op_ref[i] : 0;
+        if (off < len) { q = c.op_read[i] + off; r = c.op_ref[i] + off; return true; }
+    }
+    return false;
+}
+// first aligned pair with read_pos >= y
+__device__ __forceinline__ bool first_aligned_read_ge(const cig_view& c, int y, int& q, int& r)
+{
+    int lo = 0, hi = c.n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (c.op_read[mid] <= y) lo = mid + 1; else hi = mid; }
+    for (int i = lo > 0 ? lo - 1 : 0; i < c.n; ++i) {
+        const uint32_t w = c.cigar[i];
+        const int len = (int)(w >> 4);
+        if (!op_aligned(w) || len == 0) continue;
+        const int off = y - c.op_read[i] > 0 ? y - c.op_read[i] : 0;
+        if (off < len) { q = c.op_read[i] + off; r = c.op_ref[i] + off; return true; }
+    }
+    return false;
+}
+// last aligned pair with read_pos <= y
+__device__ __forceinline__ bool last_aligned_read_le(const cig_view& c, int y, int& q)
+{
+    int lo = 0, hi = c.n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (c.op_read[mid] <= y) lo = mid + 1; else hi = mid; }
+    for (int i = lo - 1; i >= 0; --i) {
+        const uint32_t w = c.cigar[i];
+        const int len = (int)(w >> 4);
+        if (!op_aligned(w) || len == 0) continue;
+        const int off = y - c.op_read[i] < len - 1 ? y - c.op_read[i] : len - 1;
+        if (off >= 0) { q = c.op_read[i] + off; return true; }
+    }
+    return false;
+}
+
+// per read: (first filtered read_pos, last filtered read_pos) of the aligned events, or (-1, -1); [2] = 1 if the CIGAR is usable
+struct cig_read_t { int32_t first_q, last_q, ok, pad; };
+
+// EventAlignmentRecord keeps the aligned pairs with k <= read_pos and read_pos + k < read_len (alignment_db.cpp:63-72);
+// _find_iter_by_ref_bounds (:688-711) takes lower_bound(ref_start) / lower_bound(ref_stop) on them.  Both coordinates grow
+// along the pairs, so the first kept pair with ref_pos >= x is the later of "first pair with ref_pos >= x" and "first kept
+// pair".  Returns false when unbounded, else the reference-strand read positions of the bounding pairs.
+__device__ __forceinline__ bool cigar_find_bounds(const cig_view& c, const cig_read_t& R, int ref_start, int ref_stop, int& q1, int& q2)
+{
+    if (R.first_q < 0) return false;
+    int qa, ra, qb, rb;
+    if (!first_aligned_ref_ge(c, ref_start, qa, ra) || !first_aligned_ref_ge(c, ref_stop, qb, rb)) return false;
+    bool is_first = false;
+    if (qa <= R.first_q) { is_first = true; if (qa < R.first_q) { int t; first_aligned_read_ge(c, R.first_q, t, ra); qa = R.first_q; } }
+    if (qb < R.first_q) qb = R.first_q;
+    if (qa > R.last_q || qb > R.last_q) return false;                                   // lower_bound == end()
+    if (is_first && ra > ref_start) return false;                                      // not left-bounded (:701-702)
+    q1 = qa; q2 = qb;
+    return true;
+}
+
+// pass 0 (CIGAR mode), one wave per read: exclusive scan of the operations' advances, then the kept range of pairs
+__global__ void __launch_bounds__(64) np_cigar_index_kernel(int n_reads, const uint32_t* __restrict__ cigar, const int64_t* __restrict__ cigar_off,
+                                                            const int32_t* __restrict__ read_len, int k, int32_t* __restrict__ op_ref,
+                                                            int32_t* __restrict__ op_read, cig_read_t* __restrict__ out)
+{
+    const int r = blockIdx.x;
+    if (r >= n_reads) return;
+    const int lane = threadIdx.x;
+    const uint32_t* cg = cigar + cigar_off[r];
+    const int n = (int)(cigar_off[r + 1] - cigar_off[r]);
+    int32_t* oref = op_ref + cigar_off[r] + r;            // n + 1 entries per read
+    int32_t* oread = op_read + cigar_off[r] + r;
+    int base_ref = 0, base_read = 0;
+    bool bad = false;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        int dr = 0, dq = 0;
+        if (i < n) {
+            const uint32_t w = cg[i];
+            const int len = (int)(w >> 4);
+            const uint32_t op = w & 0xf;
+            if (op == 3 || op > 8) bad = true;                                           // spliced / unknown: rejected by the reference
+            dr = (op == 0 || op == 7 || op == 8 || op == 2) ? len : 0;
+            dq = (op == 0 || op == 7 || op == 8 || op == 1 || op == 4) ? len : 0;
+        }
+        int sr = dr, sq = dq;                                                            // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int tr = __shfl_up(sr, o, 64), tq = __shfl_up(sq, o, 64);
+            if (lane >= o) { sr += tr; sq += tq; }
+        }
+        if (i < n) { oref[i] = base_ref + sr - dr; oread[i] = base_read + sq - dq; }
+        base_ref += __shfl(sr, 63, 64); base_read += __shfl(sq, 63, 64);
+    }
+    if (lane == 0) { oref[n] = base_ref; oread[n] = base_read; }
+    bad = __any(bad);
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        cig_read_t R; R.first_q = -1; R.last_q = -1; R.ok = bad ? 0 : 1; R.pad = 0;
+        if (!bad) {
+            const cig_view c{cg, oref, oread, n};
+            int q = 0, rr = 0, ql = 0;
+            const int hi_q = read_len[r] - k - 1;
+            if (first_aligned_read_ge(c, k, q, rr) && q <= hi_q && last_aligned_read_le(c, hi_q, ql) && ql >= q) { R.first_q = q; R.last_q = ql; }
+        }
+        out[r] = R;
+    }
+}
+
 // pass 1, one lane per read: sequential motif scan and grouping, the skip rules, slot and k-mer offsets
 __global__ void __launch_bounds__(64) np_cm_groups_kernel(int n_reads, const char* __restrict__ seq, const int64_t* __restrict__ seq_off,
+                                                           const int32_t* __restrict__ seq_len, const uint8_t* __restrict__ read_rc,
+                                                           const uint32_t* __restrict__ cigar, const int64_t* __restrict__ cigar_off,
+                                                           const int32_t* __restrict__ read_len, const int32_t* __restrict__ op_ref,
+                                                           const int32_t* __restrict__ op_read, const cig_read_t* __restrict__ cig_reads,
+                                                           int32_t* __restrict__ group_kpos, int32_t* __restrict__ deg_kpos,
                                                            int alphabet, int k, int min_separation, int min_flank,
                                                            const int64_t* __restrict__ group_off, const int64_t* __restrict__ rank_off_cap,
                                                            int32_t* __restrict__ first_site, int32_t* __restrict__ last_site,
@@ -50,25 +185,47 @@ __global__ void __launch_bounds__(64) np_cm_groups_kernel(int n_reads, const cha
     const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= n_reads) return;
     const char* ref = seq + seq_off[r];
-    const int n = (int)(seq_off[r + 1] - seq_off[r]);
+    const int n = seq_len ? seq_len[r] : (int)(seq_off[r + 1] - seq_off[r]);
     const site2 s = site_of(alphabet);
     const int64_t g0 = group_off[r];
     const int cap = (int)(group_off[r + 1] - g0);
     const int64_t rank_cap = rank_off_cap[r + 1] - rank_off_cap[r];
+    // CIGAR mode: the read's operations, their scanned offsets and the kept range of aligned pairs
+    const bool by_cigar = cigar != nullptr;
+    cig_view cv{nullptr, nullptr, nullptr, 0};
+    cig_read_t cr{-1, -1, 0, 0};
+    bool rc = false;
+    int rl = 0;
+    if (by_cigar) {
+        cv.cigar = cigar + cigar_off[r]; cv.n = (int)(cigar_off[r + 1] - cigar_off[r]);
+        cv.op_ref = op_ref + cigar_off[r] + r; cv.op_read = op_read + cigar_off[r] + r;
+        cr = cig_reads[r]; rc = read_rc[r] != 0; rl = read_len[r];
+        // flip_k_strand for reverse-strand reads (squiggle_read.h:229-233); the degenerate-record test needs these two
+        deg_kpos[2 * r] = cr.first_q < 0 ? -1 : (rc ? rl - cr.first_q - k : cr.first_q);
+        deg_kpos[2 * r + 1] = cr.first_q < 0 ? -1 : (rc ? rl - cr.last_q - k : cr.last_q);
+    }
     int ng = 0, first = -1, last = -1, cnt = 0;
     int64_t w = 0;
     bool overflow = false;
     auto close_group = [&]() {
         if (cnt == 0) return;
         const int sub_start = first - min_flank, sub_end = last + min_flank, span = last - first;
-        const bool skip = sub_start <= min_separation || span > 200 ||                       // basemods.cpp:334
-                          sub_start < k || sub_end + k >= n;                                 // alignment_db.cpp:65-71,697-708
+        bool skip = sub_start <= min_separation || span > 200;                               // basemods.cpp:334
+        int q1 = 0, q2 = 0;
+        if (!skip) {
+            if (by_cigar) skip = !cigar_find_bounds(cv, cr, sub_start, sub_end, q1, q2) || sub_end >= n;
+            else skip = sub_start < k || sub_end + k >= n;                                   // alignment_db.cpp:65-71,697-708
+        }
         if (!skip) {
             const int nk = sub_end - sub_start + 1 - k + 1;
             if (ng >= cap || w + 2 * (int64_t)nk > rank_cap) { overflow = true; }
             else {
                 first_site[g0 + ng] = first; last_site[g0 + ng] = last; n_motif[g0 + ng] = cnt;
                 group_rank_off[g0 + ng] = rank_off_cap[r] + w;
+                if (by_cigar) {
+                    group_kpos[2 * (g0 + ng)] = rc ? rl - q1 - k : q1;
+                    group_kpos[2 * (g0 + ng) + 1] = rc ? rl - q2 - k : q2;
+                }
                 w += 2 * (int64_t)nk;
                 ng++;
             }
@@ -88,6 +245,7 @@ __global__ void __launch_bounds__(64) np_cm_groups_kernel(int n_reads, const cha
 
 // pass 2, one block per read: every group's two work items and their k-mer ranks
 __global__ void __launch_bounds__(256) np_cm_items_kernel(int n_reads, const char* __restrict__ seq, const int64_t* __restrict__ seq_off,
+                                                          const int32_t* __restrict__ seq_len, const int32_t* __restrict__ group_kpos,
                                                           const uint8_t* __restrict__ read_rc, int alphabet, int k, int min_flank,
                                                           const int64_t* __restrict__ group_off, const int32_t* __restrict__ first_site,
                                                           const int32_t* __restrict__ last_site, const int64_t* __restrict__ group_rank_off,
@@ -97,7 +255,7 @@ __global__ void __launch_bounds__(256) np_cm_items_kernel(int n_reads, const cha
     const int r = blockIdx.x;
     if (r >= n_reads) return;
     const char* ref = seq + seq_off[r];
-    const int n = (int)(seq_off[r + 1] - seq_off[r]);
+    const int n = seq_len ? seq_len[r] : (int)(seq_off[r + 1] - seq_off[r]);
     const bool rc = read_rc[r] != 0;
     const site2 s = site_of(alphabet);
     const int64_t g0 = group_off[r];
@@ -122,8 +280,8 @@ __global__ void __launch_bounds__(256) np_cm_items_kernel(int n_reads, const cha
             jb.flags = NP_HAF_ALLOW_PRE_CLIP | NP_HAF_ALLOW_POST_CLIP;                        // basemods.cpp:363
             jobs[2 * (g0 + g) + v] = jb;
             // read-strand k-mer positions of the window ends (flip_k_strand for reverse-strand reads, squiggle_read.h:229-233)
-            kpos[2 * (2 * (g0 + g) + v)] = rc ? n - sub_start - k : sub_start;
-            kpos[2 * (2 * (g0 + g) + v) + 1] = rc ? n - sub_end - k : sub_end;
+            kpos[2 * (2 * (g0 + g) + v)] = group_kpos ? group_kpos[2 * (g0 + g)] : (rc ? n - sub_start - k : sub_start);
+            kpos[2 * (2 * (g0 + g) + v) + 1] = group_kpos ? group_kpos[2 * (g0 + g) + 1] : (rc ? n - sub_end - k : sub_end);
         }
         for (int i = threadIdx.x; i < nk; i += 256) {
             // HMMInputSequence::get_kmer_rank(i, k, do_rc): the forward k-mer at i, or the reverse-complement string's k-mer at
@@ -150,9 +308,32 @@ hipError_t np_launch_cm_build_jobs(int n_reads, const char* seq, const int64_t* 
                                    int32_t* n_motif, int64_t* group_rank_off, int32_t* n_groups, hipStream_t s)
 {
     if (n_reads <= 0) return hipSuccess;
-    hipLaunchKernelGGL(np_cm_groups_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, seq, seq_off, alphabet, k, min_separation,
+    hipLaunchKernelGGL(np_cm_groups_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, seq, seq_off, nullptr, read_rc, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, alphabet, k, min_separation,
                        min_flank, group_off, rank_off_cap, first_site, last_site, n_motif, group_rank_off, n_groups);
-    hipLaunchKernelGGL(np_cm_items_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, seq, seq_off, read_rc, alphabet, k, min_flank, group_off,
-                       first_site, last_site, group_rank_off, n_groups, jobs, kpos, job_ranks);
+    hipLaunchKernelGGL(np_cm_items_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, seq, seq_off, nullptr, nullptr, read_rc, alphabet, k, min_flank,
+                       group_off, first_site, last_site, group_rank_off, n_groups, jobs, kpos, job_ranks);
+    return hipGetLastError();
+}
+
+// CIGAR mode.  genome: the contig(s) resident on the device; ref_begin[r] / ref_len[r]: the segment the reference fetches
+// for read r (contig[pos .. bam_endpos], clipped).  scratch: op_ref / op_read (cigar_off[n_reads] + n_reads int32 each),
+// cig_reads (16 B per read), group_kpos (2 int32 per group slot).
+hipError_t np_launch_cm_build_jobs_cigar(int n_reads, const char* genome, const int64_t* ref_begin, const int32_t* ref_len,
+                                         const uint32_t* cigar, const int64_t* cigar_off, const int32_t* read_len, const uint8_t* read_rc,
+                                         int alphabet, int k, int min_separation, int min_flank, const int64_t* group_off,
+                                         const int64_t* rank_off_cap, np_hmm_job_dev* jobs, int32_t* kpos, uint16_t* job_ranks,
+                                         int32_t* first_site, int32_t* last_site, int32_t* n_motif, int64_t* group_rank_off,
+                                         int32_t* n_groups, int32_t* deg_kpos, int32_t* op_ref, int32_t* op_read, void* cig_reads,
+                                         int32_t* group_kpos, hipStream_t s)
+{
+    if (n_reads <= 0) return hipSuccess;
+    hipLaunchKernelGGL(np_cigar_index_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, cigar, cigar_off, read_len, k, op_ref, op_read,
+                       (cig_read_t*)cig_reads);
+    hipLaunchKernelGGL(np_cm_groups_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, genome, ref_begin, ref_len, read_rc, cigar,
+                       cigar_off, read_len, op_ref, op_read, (const cig_read_t*)cig_reads, group_kpos, deg_kpos, alphabet, k, min_separation,
+                       min_flank, group_off, rank_off_cap, first_site, last_site, n_motif, group_rank_off, n_groups);
+    hipLaunchKernelGGL(np_cm_items_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, genome, ref_begin, ref_len, group_kpos, read_rc, alphabet, k,
+                       min_flank, group_off, first_site, last_site, group_rank_off, n_groups, jobs, kpos, job_ranks);
     return hipGetLastError();
 }

@@ -64,6 +64,8 @@ hipError_t np_launch_build_map(int n_reads, np_read_dev* reads, const int64_t* p
 hipError_t np_launch_recalibrate(int n_reads, np_read_dev* reads, const float* event_mean, const uint16_t* ranks,
                                  const np_state_dev* model, const int32_t* n_pairs, const int32_t* map_start,
                                  int32_t* calibrated, hipStream_t s);
+hipError_t np_launch_discard_degenerate(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads, const int32_t* map_start,
+                                        const int32_t* deg_kpos, hipStream_t s);
 hipError_t np_launch_resolve(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads, const int32_t* n_pairs,
                              const double* events_per_base, const int32_t* calibrated, const int32_t* map_start,
                              const int32_t* kpos, hipStream_t s);
@@ -82,3 +84,10 @@ hipError_t np_launch_cm_build_jobs(int n_reads, const char* seq, const int64_t* 
                                    int min_separation, int min_flank, const int64_t* group_off, const int64_t* rank_off_cap,
                                    np_hmm_job_dev* jobs, int32_t* kpos, uint16_t* job_ranks, int32_t* first_site, int32_t* last_site,
                                    int32_t* n_motif, int64_t* group_rank_off, int32_t* n_groups, hipStream_t s);
+hipError_t np_launch_cm_build_jobs_cigar(int n_reads, const char* genome, const int64_t* ref_begin, const int32_t* ref_len,
+                                         const uint32_t* cigar, const int64_t* cigar_off, const int32_t* read_len, const uint8_t* read_rc,
+                                         int alphabet, int k, int min_separation, int min_flank, const int64_t* group_off,
+                                         const int64_t* rank_off_cap, np_hmm_job_dev* jobs, int32_t* kpos, uint16_t* job_ranks,
+                                         int32_t* first_site, int32_t* last_site, int32_t* n_motif, int64_t* group_rank_off,
+                                         int32_t* n_groups, int32_t* deg_kpos, int32_t* op_ref, int32_t* op_read, void* cig_reads,
+                                         int32_t* group_kpos, hipStream_t s);

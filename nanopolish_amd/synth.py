@@ -95,3 +95,64 @@ def synth_raw(read_id, model, L=5000, k=6, seed0=SEED0, samples_per_kmer=8.9, no
     raw = np.maximum(mu + sd * rng.standard_normal(len(rk)), 8.0).astype(np.float32)
     rd = dict(rd); rd["raw"] = raw; rd["dwell"] = dwell
     return rd
+
+
+def synth_raw_from_codes(codes, read_id, model, k=6, seed0=SEED0, samples_per_kmer=8.9, noise=1.0):
+    """synth_raw for a GIVEN read sequence (base codes A0 C1 G2 T3, the read's own strand)."""
+    rng = np.random.default_rng(seed0 + 15485863 * (int(read_id) + 1))
+    codes = np.asarray(codes, np.int64)
+    seq = BASES[codes].tobytes().decode()
+    ranks = nucleotide_kmer_ranks(codes, k)
+    shift = rng.uniform(-5, 5); scale = rng.uniform(0.9, 1.1); var = rng.uniform(1.0, 1.4)
+    dwell = 1 + rng.poisson(samples_per_kmer - 1.0, len(ranks))
+    rk = np.repeat(ranks, dwell)
+    mu = scale * model["level_mean"][rk] + shift
+    sd = noise * var * model["level_stdv"][rk]
+    raw = np.maximum(mu + sd * rng.standard_normal(len(rk)), 8.0).astype(np.float32)
+    return dict(read_id=int(read_id), seq=seq, codes=codes.astype(np.uint8), ranks=ranks, raw=raw, dwell=dwell,
+                shift=float(shift), scale=float(scale), var=float(var))
+
+
+def synth_cigar_read(read_id, contig_codes, model, span=1200, k=6, seed0=SEED0, p_sub=0.02, p_ins=0.015, p_del=0.015,
+                     max_indel=4, soft_clip=(0, 12), rc=None):
+    """A read sequenced from a window of a contig with substitutions, insertions, deletions and soft clips, together with
+    the BAM record an aligner would report for it: pos, CIGAR (ops as [(char, length)]), SEQ on the reference strand, the
+    reverse flag.  The read's own sequence (what the basecaller emitted, and what the signal is generated from) is SEQ
+    for a forward read and its reverse complement for a reverse read."""
+    rng = np.random.default_rng(seed0 + 32452843 * (int(read_id) + 1))
+    contig_codes = np.asarray(contig_codes, np.int64)
+    G = len(contig_codes)
+    span = min(span, G)
+    pos = int(rng.integers(0, G - span + 1))
+    rc = bool(read_id & 1) if rc is None else bool(rc)
+    out, ops = [], []
+
+    def push(op, n):
+        if n <= 0:
+            return
+        if ops and ops[-1][0] == op:
+            ops[-1][1] += n
+        else:
+            ops.append([op, n])
+
+    lead = int(rng.integers(soft_clip[0], soft_clip[1] + 1)); tail = int(rng.integers(soft_clip[0], soft_clip[1] + 1))
+    out.extend(rng.integers(0, 4, lead).tolist()); push("S", lead)
+    i, end = pos, pos + span
+    first = True
+    while i < end:
+        u = rng.random()
+        if not first and u < p_ins:
+            n = int(rng.integers(1, max_indel + 1)); out.extend(rng.integers(0, 4, n).tolist()); push("I", n)
+        elif not first and u < p_ins + p_del and i + max_indel + 1 < end:
+            n = int(rng.integers(1, max_indel + 1)); i += n; push("D", n)
+        b = int(contig_codes[i])
+        if rng.random() < p_sub:
+            b = (b + int(rng.integers(1, 4))) & 3
+        out.append(b); push("M", 1); i += 1
+        first = False
+    out.extend(rng.integers(0, 4, tail).tolist()); push("S", tail)
+    bam_codes = np.array(out, np.int64)
+    read_codes = 3 - bam_codes[::-1] if rc else bam_codes
+    rd = synth_raw_from_codes(read_codes, read_id, model, k, seed0)
+    rd.update(rc=rc, pos=pos, cigar_ops=[(o, n) for o, n in ops], bam_seq=BASES[bam_codes].tobytes().decode(), ref_span=span)
+    return rd

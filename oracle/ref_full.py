@@ -1,0 +1,162 @@
+"""ctypes binding of oracle/_ref/libnp_ref_full.so (TEST INFRASTRUCTURE, see oracle/__init__.py): the reference's own
+read-level code -- SquiggleRead::load_from_raw, EventAlignmentRecord, calculate_methylation_for_read,
+create_modbam_record, align_read_to_ref -- compiled in place from /root/reference (oracle/Makefile target `full`,
+veneer oracle/ref_full_harness.cpp).  Exists only where /root/reference does; it pins the portable restatement and
+generates tests/golden/golden_reflevel.npz (tests/gen_golden_reflevel.py)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_FULL = os.path.join(_HERE, "_ref", "libnp_ref_full.so")
+
+_i32p = C.POINTER(C.c_int32)
+_u32p = C.POINTER(C.c_uint32)
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+
+CIGAR_OPS = "MIDNSHP=X"
+
+
+def have_full():
+    return os.path.exists(_FULL)
+
+
+def build_full():
+    subprocess.check_call(["make", "-s", "-j8", "-C", _HERE, "ref", "full"])
+
+
+def cigar_words(ops):
+    """[(op_char, length), ...] -> uint32 BAM cigar words (length << 4 | op)"""
+    return np.array([(int(l) << 4) | CIGAR_OPS.index(o) for o, l in ops], np.uint32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+class FullRead:
+    """A SquiggleRead built by the reference from raw samples (SquiggleRead(sequence, Fast5Data, flags))."""
+
+    def __init__(self, lib, name, sequence, raw, sample_rate=4000.0):
+        self.L = lib
+        raw = np.ascontiguousarray(raw, np.float32)
+        self.sequence = sequence
+        self.h = lib.npfull_read_create(name.encode(), sequence.encode(), _p(raw, _f32p), len(raw), float(sample_rate))
+        n_ev, mp = C.c_int(), C.c_int()
+        sh, sc, va, epb = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        lib.npfull_read_summary(self.h, C.byref(n_ev), C.byref(sh), C.byref(sc), C.byref(va), C.byref(epb), C.byref(mp))
+        self.n_events, self.map_size = n_ev.value, mp.value
+        self.shift, self.scale, self.var, self.events_per_base = sh.value, sc.value, va.value, epb.value
+
+    def close(self):
+        if self.h:
+            self.L.npfull_read_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def events(self):
+        out = np.zeros(self.n_events, np.float32)
+        if self.n_events:
+            self.L.npfull_read_events(self.h, _p(out, _f32p))
+        return out
+
+    def event_map(self):
+        s, e = np.zeros(self.map_size, np.int32), np.zeros(self.map_size, np.int32)
+        if self.map_size:
+            self.L.npfull_read_event_map(self.h, _p(s, _i32p), _p(e, _i32p))
+        return s, e
+
+    def closest_event(self, k_idx):
+        return int(self.L.npfull_closest_event(self.h, int(k_idx)))
+
+    def event_alignment_record(self, is_rev, pos, cigar, bam_seq):
+        cig = np.ascontiguousarray(cigar, np.uint32)
+        cap = len(bam_seq) + 8
+        rp, ev = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        rc, stride = C.c_int(), C.c_int()
+        n = self.L.npfull_event_alignment_record(self.h, int(is_rev), int(pos), _p(cig, _u32p), len(cig), bam_seq.encode(), cap,
+                                                 _p(rp, _i32p), _p(ev, _i32p), C.byref(rc), C.byref(stride))
+        return np.stack([rp[:n], ev[:n]], 1), rc.value, stride.value
+
+    def call_methylation(self, is_rev, pos, cigar, bam_seq, contig_seq, methylation_type="cpg", modbam=True, cap=4096):
+        """calculate_methylation_for_read: dict of per-site arrays (+ the Mm / Ml tag payloads of create_modbam_record)"""
+        cig = np.ascontiguousarray(cigar, np.uint32)
+        st, en, nm = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        lu, lm = np.zeros(cap, np.float64), np.zeros(cap, np.float64)
+        seqs = C.create_string_buffer(cap * 256)
+        mm_cap = 16 * cap + 64
+        mm = C.create_string_buffer(mm_cap)
+        ml = np.zeros(4 * cap, np.uint8)
+        n_ml = C.c_int(-1)
+        want_mod = modbam and methylation_type == "cpg"
+        n = self.L.npfull_call_methylation(self.h, int(is_rev), int(pos), _p(cig, _u32p), len(cig), bam_seq.encode(),
+                                           contig_seq.encode(), methylation_type.encode(), cap, _p(st, _i32p), _p(en, _i32p),
+                                           _p(nm, _i32p), _p(lu, _f64p), _p(lm, _f64p), seqs,
+                                           mm if want_mod else None, mm_cap, _p(ml, _u8p), len(ml), C.byref(n_ml))
+        assert n <= cap
+        raw = seqs.raw
+        out = dict(start=st[:n].copy(), end=en[:n].copy(), n_motif=nm[:n].copy(), ll_unmeth=lu[:n].copy(), ll_meth=lm[:n].copy(),
+                   sequence=[raw[i * 256:(i + 1) * 256].split(b"\0", 1)[0].decode() for i in range(n)])
+        if want_mod:
+            out["Mm"] = mm.value.decode()
+            out["Ml"] = ml[:n_ml.value].copy()
+        return out
+
+    def eventalign(self, is_rev, pos, cigar, bam_seq, contig_seq, cap=None):
+        cig = np.ascontiguousarray(cigar, np.uint32)
+        cap = cap or (4 * max(self.n_events, 1) + 64)
+        rp, ev = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        st = C.create_string_buffer(cap)
+        rk, mk = C.create_string_buffer(cap * 8), C.create_string_buffer(cap * 8)
+        n = self.L.npfull_eventalign(self.h, int(is_rev), int(pos), _p(cig, _u32p), len(cig), bam_seq.encode(), contig_seq.encode(),
+                                     cap, _p(rp, _i32p), _p(ev, _i32p), st, rk, mk)
+        assert n <= cap
+        ks = lambda b: [b.raw[i * 8:(i + 1) * 8].split(b"\0", 1)[0].decode() for i in range(n)]
+        return dict(ref_position=rp[:n].copy(), event_idx=ev[:n].copy(), hmm_state=np.frombuffer(st.raw[:n], np.uint8).copy(),
+                    ref_kmer=ks(rk), model_kmer=ks(mk))
+
+
+class FullRef:
+    def __init__(self):
+        if not have_full():
+            raise RuntimeError("oracle/_ref/libnp_ref_full.so is not built (needs /root/reference; `make -C oracle full`)")
+        L = C.CDLL(_FULL)
+        L.npfull_read_create.restype = C.c_void_p
+        L.npfull_read_create.argtypes = [C.c_char_p, C.c_char_p, _f32p, C.c_size_t, C.c_double]
+        L.npfull_read_destroy.argtypes = [C.c_void_p]
+        L.npfull_read_summary.argtypes = [C.c_void_p, C.POINTER(C.c_int), _f64p, _f64p, _f64p, _f64p, C.POINTER(C.c_int)]
+        L.npfull_read_events.argtypes = [C.c_void_p, _f32p]
+        L.npfull_read_event_map.argtypes = [C.c_void_p, _i32p, _i32p]
+        L.npfull_closest_event.argtypes = [C.c_void_p, C.c_int]
+        L.npfull_aligned_bases.argtypes = [C.c_int, C.c_int, _u32p, C.c_int, C.c_char_p, C.c_int, _i32p, _i32p]
+        L.npfull_event_alignment_record.argtypes = [C.c_void_p, C.c_int, C.c_int, _u32p, C.c_int, C.c_char_p, C.c_int, _i32p, _i32p,
+                                                    C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.npfull_find_by_ref_bounds.argtypes = [_i32p, _i32p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.npfull_call_methylation.argtypes = [C.c_void_p, C.c_int, C.c_int, _u32p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int,
+                                              _i32p, _i32p, _i32p, _f64p, _f64p, C.c_char_p, C.c_char_p, C.c_int, _u8p, C.c_int,
+                                              C.POINTER(C.c_int)]
+        L.npfull_eventalign.argtypes = [C.c_void_p, C.c_int, C.c_int, _u32p, C.c_int, C.c_char_p, C.c_char_p, C.c_int, _i32p, _i32p,
+                                        C.c_char_p, C.c_char_p, C.c_char_p]
+        self.L = L
+
+    def read(self, name, sequence, raw, sample_rate=4000.0):
+        return FullRead(self.L, name, sequence, raw, sample_rate)
+
+    def aligned_bases(self, is_rev, pos, cigar, bam_seq):
+        cig = np.ascontiguousarray(cigar, np.uint32)
+        cap = len(bam_seq) + 8
+        rp, qp = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        n = self.L.npfull_aligned_bases(int(is_rev), int(pos), _p(cig, _u32p), len(cig), bam_seq.encode(), cap, _p(rp, _i32p), _p(qp, _i32p))
+        return np.stack([rp[:n], qp[:n]], 1)
+
+    def find_by_ref_bounds(self, pairs, ref_start, ref_stop):
+        pairs = np.asarray(pairs, np.int32).reshape(-1, 2)
+        rp, qp = np.ascontiguousarray(pairs[:, 0]), np.ascontiguousarray(pairs[:, 1])
+        r1, r2 = C.c_int(), C.c_int()
+        ok = self.L.npfull_find_by_ref_bounds(_p(rp, _i32p), _p(qp, _i32p), len(rp), int(ref_start), int(ref_stop), C.byref(r1), C.byref(r2))
+        return (r1.value, r2.value) if ok else None

@@ -1,0 +1,256 @@
+// oracle/ref_full_harness.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// C-ABI veneer over the reference's own READ-LEVEL call-methylation / eventalign code, compiled in place from
+// /root/reference by `make -C oracle full` into oracle/_ref/libnp_ref_full.so (nothing from the reference is copied):
+//   SquiggleRead(sequence, Fast5Data, flags) -> load_from_raw      src/nanopolish_squiggle_read.cpp:141-336
+//       scrappie detect_events, estimate_scalings_using_mom, adaptive_banded_simple_event_align, base_to_event_map,
+//       get_eventalignment_for_1d_basecalls, recalibrate_model (src/nanopolish_methyltrain.cpp:204-306), QC gates
+//   SquiggleRead::get_closest_event_to                             src/nanopolish_squiggle_read.cpp:161-186
+//   SequenceAlignmentRecord / get_aligned_segments (CIGAR walk)    src/alignment/nanopolish_alignment_db.cpp:30-50,
+//                                                                  src/alignment/nanopolish_anchor.cpp:20-95
+//   EventAlignmentRecord, AlignmentDB::_find_by_ref_bounds         src/alignment/nanopolish_alignment_db.cpp:55-91,688-731
+//   calculate_methylation_for_read                                 src/basemods/nanopolish_basemods.cpp:236-419
+//   create_modbam_record (Mm / Ml tags)                            src/basemods/nanopolish_basemods.cpp:50-177
+//   align_read_to_ref (eventalign segment chain)                   src/alignment/nanopolish_eventalign.cpp:612-826
+// Third-party pieces that are absent from this image are stood in for by oracle/stubs_full/ (htslib record layout and
+// accessors from the SAM/BAM specification; Eigen's 2x2 full-pivot LU restated; slow5 opaque) -- see the headers there.
+// The functions of htslib that EXECUTE on these paths are defined below (in-memory contig table, bam_dup1, aux capture);
+// everything else the translation units reference but never call is an aborting stub (gen_abort_stubs.py).
+// Used to pin oracle/np_oracle.c's read-level helpers and to generate tests/golden/golden_reflevel.npz.
+#include <cstring>
+#include <cstdlib>
+#include <string>
+#include <vector>
+#include <map>
+#include "htslib/faidx.h"
+#include "htslib/sam.h"
+#include "nanopolish_squiggle_read.h"
+#include "nanopolish_alignment_db.h"
+#include "nanopolish_basemods.h"
+#include "nanopolish_eventalign.h"
+#include "nanopolish_alphabet.h"
+
+// ---- htslib stand-ins that execute -------------------------------------------------------------------------------
+struct faidx_t { std::string name; std::string seq; };
+
+extern "C" {
+const char seq_nt16_str[] = "=ACMGRSVTWYHKDBN";                  // SAMv1 section 4.2.3
+const unsigned char seq_nt16_table[256] = {
+    15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15,
+    15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15, 0,15,15,
+    15, 1,14, 2, 13,15,15, 4, 11,15,15,12, 15, 3,15,15, 15,15, 5, 6,  8,15, 7, 9, 15,10,15,15, 15,15,15,15,
+    15, 1,14, 2, 13,15,15, 4, 11,15,15,12, 15, 3,15,15, 15,15, 5, 6,  8,15, 7, 9, 15,10,15,15, 15,15,15,15,
+    15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15,
+    15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15,
+    15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15,
+    15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15, 15,15,15,15 };
+
+// htslib faidx_fetch_seq: [p_beg_i, p_end_i] zero-based inclusive, clipped to the contig; caller frees
+char* faidx_fetch_seq(const faidx_t* fai, const char* c_name, int p_beg_i, int p_end_i, int* len)
+{
+    if(fai->name != c_name) { *len = -2; return NULL; }
+    const int n = (int)fai->seq.size();
+    if(p_beg_i < 0) p_beg_i = 0;
+    if(p_end_i >= n) p_end_i = n - 1;
+    if(p_beg_i > p_end_i) { *len = 0; char* s = (char*)malloc(1); s[0] = 0; return s; }
+    const int l = p_end_i - p_beg_i + 1;
+    char* s = (char*)malloc(l + 1);
+    memcpy(s, fai->seq.data() + p_beg_i, l);
+    s[l] = 0;
+    *len = l;
+    return s;
+}
+int faidx_seq_len(const faidx_t* fai, const char* seq) { return fai->name == seq ? (int)fai->seq.size() : -1; }
+
+bam1_t* bam_init1(void) { return (bam1_t*)calloc(1, sizeof(bam1_t)); }
+void bam_destroy1(bam1_t* b) { if(b) { free(b->data); free(b); } }
+bam1_t* bam_dup1(const bam1_t* b)
+{
+    bam1_t* d = bam_init1();
+    *d = *b;
+    d->data = (uint8_t*)malloc(b->l_data > 0 ? b->l_data : 1);
+    memcpy(d->data, b->data, b->l_data);
+    d->m_data = b->l_data;
+    return d;
+}
+// aux capture: the oracle only needs the tag payloads create_modbam_record computes
+static std::map<const bam1_t*, std::string> g_aux_str;
+static std::map<const bam1_t*, std::vector<uint8_t> > g_aux_arr;
+int bam_aux_update_str(bam1_t* b, const char tag[2], int len, const char* data)
+{
+    (void)tag; g_aux_str[b] = std::string(data, len > 0 ? len - 1 : 0); return 0;
+}
+int bam_aux_update_array(bam1_t* b, const char tag[2], uint8_t type, uint32_t items, void* data)
+{
+    (void)tag; (void)type; g_aux_arr[b] = std::vector<uint8_t>((uint8_t*)data, (uint8_t*)data + items); return 0;
+}
+} // extern "C"
+
+namespace {
+
+struct Record {
+    bam1_t b;
+    std::vector<uint8_t> data;
+    sam_hdr_t hdr;
+    char* names[1];
+    uint32_t lens[1];
+    faidx_t fai;
+    // one contig "contig"; the record's SEQ is the read as BAM stores it (reverse-complemented for reverse-strand reads)
+    Record(const char* qname, int is_rev, int pos, const uint32_t* cigar, int n_cigar, const char* seq, const char* contig_seq)
+    {
+        memset(&b, 0, sizeof(b));
+        const size_t lq = strlen(qname) + 1;
+        const size_t lq_pad = (lq + 3) & ~(size_t)3;                 // keeps the CIGAR words 4-byte aligned
+        const size_t ls = strlen(seq);
+        data.assign(lq_pad + 4 * (size_t)n_cigar + (ls + 1) / 2 + ls, 0);
+        memcpy(data.data(), qname, lq);
+        memcpy(data.data() + lq_pad, cigar, 4 * (size_t)n_cigar);
+        uint8_t* ps = data.data() + lq_pad + 4 * (size_t)n_cigar;
+        for(size_t i = 0; i < ls; ++i) bam_set_seqi(ps, i, seq_nt16_table[(unsigned char)seq[i]]);
+        memset(ps + (ls + 1) / 2, 30, ls);
+        b.core.pos = pos; b.core.tid = 0; b.core.qual = 60; b.core.flag = is_rev ? BAM_FREVERSE : 0;
+        b.core.l_qname = (uint16_t)lq_pad; b.core.l_extranul = (uint8_t)(lq_pad - lq);
+        b.core.n_cigar = n_cigar; b.core.l_qseq = (int32_t)ls; b.core.mtid = -1; b.core.mpos = -1;
+        b.data = data.data(); b.l_data = (int)data.size(); b.m_data = (uint32_t)data.size();
+        static char cname[] = "contig";
+        names[0] = cname; lens[0] = (uint32_t)strlen(contig_seq);
+        hdr.n_targets = 1; hdr.target_len = lens; hdr.target_name = names;
+        fai.name = "contig"; fai.seq = contig_seq;
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+// ---- SquiggleRead from raw samples -----------------------------------------------------------------------------
+void* npfull_read_create(const char* name, const char* sequence, const float* raw, size_t n_raw, double sample_rate)
+{
+    Fast5Data d;
+    d.is_valid = true;
+    d.read_name = name;
+    d.sequencing_kit = "sqk-lsk109";
+    d.experiment_type = "genomic_dna";
+    d.channel_params.digitisation = 8192; d.channel_params.offset = 0; d.channel_params.range = 1400;
+    d.channel_params.sample_rate = sample_rate; d.channel_params.channel_id = 1;
+    d.start_time = 0;
+    d.rt.n = n_raw; d.rt.start = 0; d.rt.end = n_raw;
+    d.rt.raw = (float*)malloc(sizeof(float) * (n_raw + 1));
+    memcpy(d.rt.raw, raw, sizeof(float) * n_raw);
+    SquiggleRead* sr = new SquiggleRead(std::string(sequence), d, 0);
+    free(d.rt.raw);
+    return sr;
+}
+void npfull_read_destroy(void* h) { delete (SquiggleRead*)h; }
+
+// n_events is 0 when the read failed alignment / calibration / events-per-base QC (events cleared, :320-335)
+void npfull_read_summary(void* h, int* n_events, double* shift, double* scale, double* var, double* events_per_base, int* map_size)
+{
+    SquiggleRead* sr = (SquiggleRead*)h;
+    *n_events = (int)sr->events[0].size();
+    *shift = sr->scalings[0].shift; *scale = sr->scalings[0].scale; *var = sr->scalings[0].var;
+    *events_per_base = sr->events_per_base[0];
+    *map_size = (int)sr->base_to_event_map.size();
+}
+void npfull_read_events(void* h, float* mean)
+{
+    SquiggleRead* sr = (SquiggleRead*)h;
+    for(size_t i = 0; i < sr->events[0].size(); ++i) mean[i] = sr->events[0][i].mean;
+}
+void npfull_read_event_map(void* h, int32_t* start, int32_t* stop)
+{
+    SquiggleRead* sr = (SquiggleRead*)h;
+    for(size_t i = 0; i < sr->base_to_event_map.size(); ++i) {
+        start[i] = sr->base_to_event_map[i].indices[0].start;
+        stop[i] = sr->base_to_event_map[i].indices[0].stop;
+    }
+}
+int npfull_closest_event(void* h, int k_idx) { return ((SquiggleRead*)h)->get_closest_event_to(k_idx, 0); }
+
+// ---- CIGAR -> aligned bases -> aligned events ---------------------------------------------------------------------
+int npfull_aligned_bases(int is_rev, int pos, const uint32_t* cigar, int n_cigar, const char* seq, int cap, int32_t* ref_pos, int32_t* read_pos)
+{
+    Record r("read", is_rev, pos, cigar, n_cigar, seq, "A");
+    SequenceAlignmentRecord sar(&r.b);
+    const int n = (int)sar.aligned_bases.size();
+    for(int i = 0; i < n && i < cap; ++i) { ref_pos[i] = sar.aligned_bases[i].ref_pos; read_pos[i] = sar.aligned_bases[i].read_pos; }
+    return n;
+}
+int npfull_event_alignment_record(void* h, int is_rev, int pos, const uint32_t* cigar, int n_cigar, const char* seq, int cap,
+                                  int32_t* ref_pos, int32_t* event_idx, int* rc, int* stride)
+{
+    Record r("read", is_rev, pos, cigar, n_cigar, seq, "A");
+    SequenceAlignmentRecord sar(&r.b);
+    EventAlignmentRecord ear((SquiggleRead*)h, 0, sar);
+    const int n = (int)ear.aligned_events.size();
+    for(int i = 0; i < n && i < cap; ++i) { ref_pos[i] = ear.aligned_events[i].ref_pos; event_idx[i] = ear.aligned_events[i].read_pos; }
+    *rc = ear.rc; *stride = ear.stride;
+    return n;
+}
+int npfull_find_by_ref_bounds(const int32_t* ref_pos, const int32_t* read_pos, int n, int ref_start, int ref_stop, int* r1, int* r2)
+{
+    std::vector<AlignedPair> pairs(n);
+    for(int i = 0; i < n; ++i) { pairs[i].ref_pos = ref_pos[i]; pairs[i].read_pos = read_pos[i]; }
+    return AlignmentDB::_find_by_ref_bounds(pairs, ref_start, ref_stop, *r1, *r2) ? 1 : 0;
+}
+
+// ---- calculate_methylation_for_read --------------------------------------------------------------------------------
+// sites come back in ascending start position (the reference's std::map order); seq_out: cap x 256 bytes
+int npfull_call_methylation(void* h, int is_rev, int pos, const uint32_t* cigar, int n_cigar, const char* seq, const char* contig_seq,
+                            const char* methylation_type, int cap, int32_t* start, int32_t* end, int32_t* n_motif,
+                            double* ll_unmeth, double* ll_meth, char* seq_out,
+                            char* mm_out, int mm_cap, uint8_t* ml_out, int ml_cap, int* n_ml)
+{
+    SquiggleRead* sr = (SquiggleRead*)h;
+    Record r(sr->read_name.c_str(), is_rev, pos, cigar, n_cigar, seq, contig_seq);
+    OutputHandles handles;
+    MethylationCallingResult result;
+    MethylationCallingParameters params;
+    params.methylation_type = methylation_type;
+    params.alphabet = get_alphabet_by_name(methylation_type);
+    calculate_methylation_for_read(handles, result, *sr, params, &r.fai, &r.hdr, &r.b, 0, -1, -1);
+    const std::map<int, ScoredSite>& sites = result[&r.b];
+    int n = 0;
+    for(std::map<int, ScoredSite>::const_iterator it = sites.begin(); it != sites.end(); ++it, ++n) {
+        if(n >= cap) continue;
+        const ScoredSite& s = it->second;
+        start[n] = s.start_position; end[n] = s.end_position; n_motif[n] = s.n_motif;
+        ll_unmeth[n] = s.ll_unmethylated[0] + s.ll_unmethylated[1];        // summed over strands, call_methylation.cpp:536-538
+        ll_meth[n] = s.ll_methylated[0] + s.ll_methylated[1];
+        strncpy(seq_out + (size_t)n * 256, s.sequence.c_str(), 255);
+        seq_out[(size_t)n * 256 + 255] = 0;
+    }
+    if(n_ml) *n_ml = -1;
+    if(mm_out && std::string(methylation_type) == "cpg") {
+        // modBAM tags of the same calls: create_modbam_record (basemods.cpp:107-177)
+        bam1_t* m = create_modbam_record(&r.b, sites, params);
+        const std::string& mm = g_aux_str[m];
+        const std::vector<uint8_t>& ml = g_aux_arr[m];
+        strncpy(mm_out, mm.c_str(), mm_cap - 1); mm_out[mm_cap - 1] = 0;
+        *n_ml = (int)ml.size();
+        for(int i = 0; i < (int)ml.size() && i < ml_cap; ++i) ml_out[i] = ml[i];
+        g_aux_str.erase(m); g_aux_arr.erase(m);
+        bam_destroy1(m);
+    }
+    return n;
+}
+
+// ---- align_read_to_ref (eventalign) ----------------------------------------------------------------------------------
+int npfull_eventalign(void* h, int is_rev, int pos, const uint32_t* cigar, int n_cigar, const char* seq, const char* contig_seq,
+                      int cap, int32_t* ref_position, int32_t* event_idx, char* hmm_state, char* ref_kmer, char* model_kmer)
+{
+    SquiggleRead* sr = (SquiggleRead*)h;
+    Record r(sr->read_name.c_str(), is_rev, pos, cigar, n_cigar, seq, contig_seq);
+    EventAlignmentParameters params;
+    params.sr = sr; params.fai = &r.fai; params.hdr = &r.hdr; params.record = &r.b; params.strand_idx = 0; params.read_idx = 0;
+    std::vector<EventAlignment> out = align_read_to_ref(params);
+    const int n = (int)out.size();
+    for(int i = 0; i < n && i < cap; ++i) {
+        ref_position[i] = out[i].ref_position; event_idx[i] = out[i].event_idx; hmm_state[i] = out[i].hmm_state;
+        strncpy(ref_kmer + (size_t)i * 8, out[i].ref_kmer.c_str(), 7); ref_kmer[(size_t)i * 8 + 7] = 0;
+        strncpy(model_kmer + (size_t)i * 8, out[i].model_kmer.c_str(), 7); model_kmer[(size_t)i * 8 + 7] = 0;
+    }
+    return n;
+}
+
+} // extern "C"
