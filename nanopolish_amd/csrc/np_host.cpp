@@ -263,15 +263,15 @@ int np_cm_build_jobs_identity(int alphabet, const char* ref_seq, size_t n, int r
 // comes from a BAM record's CIGAR.
 // ---------------------------------------------------------------------------------------------------------------------
 // get_aligned_segments (src/alignment/nanopolish_anchor.cpp:20-95) for a non-spliced record: M/=/X emit a pair and advance
-// both, D advances the reference, I and S advance the read, H and P neither; N (a second segment) is what
-// SequenceAlignmentRecord rejects (alignment_db.cpp:43-47) and returns NP_ERR_INVALID here.  ref positions start at ref_pos0.
+// both, D advances the reference, I and S advance the read, H neither; N (a second segment) is what SequenceAlignmentRecord
+// rejects (alignment_db.cpp:43-47) and P / B hit the reference's "Unhandled cigar operation" assert: NP_ERR_INVALID here.  ref positions start at ref_pos0.
 int np_cigar_aligned_bases(const uint32_t* cigar, int n_cigar, int ref_pos0, int32_t* ref_pos, int32_t* read_pos, int cap)
 {
     int n = 0, rp = ref_pos0, qp = 0;
     for (int ci = 0; ci < n_cigar; ++ci) {
         const int len = (int)(cigar[ci] >> 4), op = (int)(cigar[ci] & 0xf);
         const bool aligned = op == 0 || op == 7 || op == 8;
-        if (op == 3 || op > 8) return NP_ERR_INVALID;
+        if (op == 3 || op == 6 || op > 8) return NP_ERR_INVALID;     // N: second segment; P and beyond: the reference asserts
         const int ref_inc = (aligned || op == 2) ? 1 : 0, read_inc = (aligned || op == 1 || op == 4) ? 1 : 0;
         if (aligned) {
             for (int j = 0; j < len; ++j) { if (n < cap) { ref_pos[n] = rp + j; read_pos[n] = qp + j; } ++n; }

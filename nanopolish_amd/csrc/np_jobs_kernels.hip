@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(64) np_cigar_index_kernel(int n_reads, const u
             const uint32_t w = cg[i];
             const int len = (int)(w >> 4);
             const uint32_t op = w & 0xf;
-            if (op == 3 || op > 8) bad = true;                                           // spliced / unknown: rejected by the reference
+            if (op == 3 || op == 6 || op > 8) bad = true;                                // spliced / pad / unknown: rejected by the reference
             dr = (op == 0 || op == 7 || op == 8 || op == 2) ? len : 0;
             dq = (op == 0 || op == 7 || op == 8 || op == 1 || op == 4) ? len : 0;
         }

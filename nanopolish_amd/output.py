@@ -8,7 +8,11 @@
 * `site_records_from_scores()`: ScoredSite assembly of calculate_methylation_for_read (src/basemods/nanopolish_basemods.cpp:
   384-413) for one strand of one read: start/end position, n_motif and the k-mer-padded group sequence.
 
-modBAM (Mm/Ml tags) needs htslib and is not built.  The device-resident `sites.site_table` computes the
+* `modbam_tags()`: the `Mm` / `Ml` tag payloads create_modbam_record attaches to a read's BAM record
+  (src/basemods/nanopolish_basemods.cpp:50-177): per-call probability codes and the run-length "C+m?" delta string.
+  Writing the BAM record itself is htslib's job and is not rebuilt.
+
+The device-resident `sites.site_table` computes the
 same per-site counts as `calculate_methylation_frequency` without going through text; tests/test_output.py checks the
 two against each other and against the output of the reference's own script (tests/golden/golden_frequency.tsv).
 """
@@ -97,3 +101,54 @@ def calculate_methylation_frequency(tsv_lines, call_threshold=2.0, split_groups=
             out.append("%s\t%s\t%s\t%d\t%d\t%d\t%.3f\t%s" % (key[0], key[1], key[2], st["group_size"], st["called_sites"],
                                                              st["called_sites_methylated"], f, st["sequence"]))
     return out
+
+
+def modbam_tags(sites, cigar, pos, bam_seq, is_rev, alphabet="cpg"):
+    """Mm / Ml tag payloads of create_modbam_record (src/basemods/nanopolish_basemods.cpp:107-177) for one read.
+    sites: dicts(start_position, sequence, ll_methylated[2], ll_unmethylated[2]) as site_records_from_scores returns them
+    (any order; the reference iterates a std::map keyed by start position); cigar / pos / bam_seq / is_rev: the read's BAM
+    record (CIGAR words, 0-based position, SEQ as stored -- on the reference strand -- and the reverse flag).
+    Returns (mm_string, ml_codes: list of ints 0..255)."""
+    import math
+    from . import api
+    if alphabet != "cpg":
+        raise ValueError("create_modbam_record asserts the cpg alphabet (basemods.cpp:137)")
+    unmodified_symbol = "C"                                   # get_modification_symbols: the base under the M of "MG"
+    # calculate_call_vectors (:50-81)
+    call_reference_positions, call_probabilities = [], []
+    for call in sorted(sites, key=lambda c: c["start_position"]):
+        seq = call["sequence"]
+        m_seq = api.methylate(alphabet, seq)
+        flank_offset = m_seq.find("M")
+        assert flank_offset != -1
+        llm, llu = float(call["ll_methylated"][0]), float(call["ll_unmethylated"][0])
+        em, eu = math.exp(llm), math.exp(llu)
+        den = em + eu
+        # the reference computes (int)(p * 255) on a double; 0/0 (both likelihoods underflow) converts to INT_MIN there,
+        # whose low byte is 0
+        p = em / den if den != 0.0 else float("nan")
+        code = min(255, int(p * 255)) & 0xFF if p == p else 0
+        for j, ch in enumerate(m_seq):
+            if ch == "M":
+                call_reference_positions.append(call["start_position"] + j - flank_offset)
+                call_probabilities.append(code)
+    # reference position -> index into the ORIGINAL read sequence (:122-127)
+    aligned = api.cigar_aligned_bases(cigar, pos)
+    original_sequence = bam_seq if not is_rev else api.reverse_complement("nucleotide", bam_seq)
+    n = len(original_sequence)
+    ref_to_read = {int(rp): (int(qp) if not is_rev else n - int(qp) - 1) for rp, qp in aligned}
+    strand_offset = 1 if is_rev else 0                        # on the opposite strand the read base of interest pairs with the G
+    idx, probs = [], []
+    for rp, pr in zip(call_reference_positions, call_probabilities):
+        ri = ref_to_read.get(rp + strand_offset)
+        if ri is not None and original_sequence[ri] == unmodified_symbol:
+            idx.append(ri); probs.append(pr)
+    if is_rev:
+        idx.reverse(); probs.reverse()
+    # generate_mm_tag (:83-105)
+    parts = [unmodified_symbol + "+m?"]
+    count_start = 0
+    for i in idx:
+        parts.append(",%d" % original_sequence[count_start:i].count(unmodified_symbol))
+        count_start = i + 1
+    return "".join(parts) + ";", probs

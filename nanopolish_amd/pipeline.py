@@ -88,6 +88,67 @@ def build_host_batch(models, read_ids, L=5450, k=6, raw=False):
                 job_off=np.concatenate([[0], np.cumsum([len(j) for j in jobs])]).astype(np.int64), meta=meta)
 
 
+def build_host_batch_records(models, records, contig, k=6):
+    """Host-side preparation of a batch of reads given EXPLICITLY, each with its raw signal and the BAM record of its
+    base-to-reference alignment: records = dicts(seq: the read's own sequence, raw: float32 samples, rc: bam_is_rev,
+    pos: 0-based leftmost reference position, cigar: uint32 BAM words).  contig: the reference the records align to.
+    The batch starts from raw signal (from_raw) and its work items follow the CIGARs: the host builder's
+    items are in hb["jobs"] / hb["kpos"]; the device builder needs hb["cigar"], hb["ref_begin"], ... (same numbering)."""
+    L_ = _l.load_library()
+    from .synth import nucleotide_kmer_ranks
+    lut = np.zeros(256, np.int64); lut[ord("C")] = 1; lut[ord("G")] = 2; lut[ord("T")] = 3
+    reads = []
+    for r in records:
+        codes = lut[np.frombuffer(r["seq"].encode(), np.uint8)]
+        reads.append(dict(seq=r["seq"], rc=bool(r["rc"]), raw=np.ascontiguousarray(r["raw"], np.float32), ranks=nucleotide_kmer_ranks(codes, k),
+                          events=np.zeros(len(r["raw"]) // 2 + 2, np.float32), shift=0.0, scale=1.0, var=1.0,
+                          pos=int(r["pos"]), cigar=np.ascontiguousarray(r["cigar"], np.uint32)))
+    n = len(reads)
+    event_off = np.zeros(n + 1, np.int64); rank_off = np.zeros(n + 1, np.int64)
+    event_off[1:] = np.cumsum([len(r["events"]) for r in reads]); rank_off[1:] = np.cumsum([len(r["ranks"]) for r in reads])
+    reads_a = np.zeros(n, READ_DT); reads_b = np.zeros(n, READ_DT)
+    jobs, kpos, jranks, meta, ref_seqs = [], [], [], [], []
+    deg = np.zeros((n, 2), np.int32)
+    ref_begin = np.zeros(n, np.int64); ref_len = np.zeros(n, np.int32)
+    jr_off = 0
+    for i, r in enumerate(reads):
+        for arr in (reads_a, reads_b):
+            L_.np_fill_read_host(C.cast(arr[i:i + 1].ctypes.data, C.POINTER(_l.ReadDev)), 0.0, 1.0, 1.0,
+                                 int(event_off[i]), len(r["events"]), int(rank_off[i]), len(r["ranks"]))
+        # the segment calculate_methylation_for_read fetches: contig[pos .. bam_endpos] inclusive, clipped (basemods.cpp:259-270)
+        span = int(sum(int(w) >> 4 for w in r["cigar"] if (int(w) & 0xf) in (0, 2, 3, 7, 8)))
+        endpos = r["pos"] + (span if span > 0 else 1)
+        seg = contig[r["pos"]:min(endpos + 1, len(contig))]
+        ref_seqs.append(seg); ref_begin[i] = r["pos"]; ref_len[i] = len(seg)
+        jb = api.cm_build_jobs_cigar(seg, r["cigar"], len(r["seq"]), r["rc"], k)
+        deg[i] = jb["deg_kpos"]
+        ng = len(jb["first"])
+        j = np.zeros(2 * ng, JOB_DT)
+        ro = jb["rank_off"][:-1]
+        tot = int(jb["rank_off"][-1])
+        j["n_kmers"] = np.repeat(jb["n_kmers"].astype(np.uint32), 2)
+        j["read"] = i; j["flags"] = HAF; j["stride"] = 1
+        j["rank_off"][0::2] = jr_off + ro
+        j["rank_off"][1::2] = jr_off + tot + ro
+        jobs.append(j)
+        kpos.append(np.repeat(jb["kpos"], 2, axis=0))
+        jranks.append(jb["ranks_unmeth"]); jranks.append(jb["ranks_meth"])
+        jr_off += 2 * tot
+        meta.append(dict(first=jb["first"], last=jb["last"], n_motif=jb["n_motif"]))
+    raw_off = np.zeros(n + 1, np.int64); raw_off[1:] = np.cumsum([len(r["raw"]) for r in reads])
+    cigar_off = np.zeros(n + 1, np.int64); cigar_off[1:] = np.cumsum([len(r["cigar"]) for r in reads])
+    return dict(reads=reads, n=n, events=np.concatenate([r["events"] for r in reads]), ranks=np.concatenate([r["ranks"] for r in reads]).astype(np.uint16),
+                event_off=event_off, rank_off=rank_off, reads_a=reads_a, reads_b=reads_b, mom=np.zeros((n, 2)), ref_seqs=ref_seqs, k=k,
+                raw=np.concatenate([r["raw"] for r in reads]), raw_off=raw_off,
+                jobs=np.concatenate(jobs) if jobs else np.zeros(0, JOB_DT),
+                kpos=np.concatenate(kpos).astype(np.int32) if kpos else np.zeros((0, 2), np.int32),
+                job_ranks=np.concatenate(jranks).astype(np.uint16) if jranks else np.zeros(0, np.uint16),
+                job_off=np.concatenate([[0], np.cumsum([len(j) for j in jobs])]).astype(np.int64), meta=meta,
+                genome=np.frombuffer(contig.encode(), np.uint8).copy(), ref_begin=ref_begin, ref_len=ref_len,
+                cigar=np.concatenate([r["cigar"] for r in reads]).astype(np.uint32), cigar_off=cigar_off,
+                read_len=np.array([len(r["seq"]) for r in reads], np.int32), deg_kpos=deg)
+
+
 def tile_host_batch(hb, tile):
     """Replicate the distinct reads `tile` times (independent copies in HBM, shifted offsets)."""
     if tile == 1:
@@ -126,6 +187,7 @@ class CallMethylationBatch:
         self.calibrate = bool(calibrate)
         self.from_raw = bool(from_raw)
         self.jobs_on_device = bool(jobs_on_device)
+        self.by_cigar = "cigar" in hb          # work items follow BAM CIGARs (build_host_batch_records)
         self.ctx = ctx
         self.hb = hb
         self.n_reads = hb["n"]
@@ -158,6 +220,11 @@ class CallMethylationBatch:
             MINSEP, FLANK = 10, 10
             seqs = hb["ref_seqs"]
             ln = np.array([len(q) for q in seqs], np.int64)
+            if self.by_cigar:
+                # the contig stays resident; reads carry (offset, length) of their reference segment and their CIGAR
+                self.d_genome = up(hb["genome"]); self.d_ref_begin = up(hb["ref_begin"]); self.d_ref_len = up(hb["ref_len"])
+                self.d_cigar = up(hb["cigar"]); self.d_cigar_off = up(hb["cigar_off"]); self.d_read_len = up(hb["read_len"])
+                self.n_cigar_ops = int(hb["cigar_off"][-1])
             self.seq_off = np.zeros(self.n_reads + 1, np.int64); self.seq_off[1:] = np.cumsum(ln)
             gcap = ln // (MINSEP + 1) + 2
             self.group_off = np.zeros(self.n_reads + 1, np.int64); self.group_off[1:] = np.cumsum(gcap)
@@ -178,6 +245,8 @@ class CallMethylationBatch:
             self.cm = (MINSEP, FLANK, int(hb.get("k", 6)))
         else:
             self.d_jobs = up(hb["jobs"]); self.d_kpos = up(hb["kpos"]); self.d_job_ranks = up(hb["job_ranks"])
+        if self.by_cigar:
+            self.d_deg = up(hb["deg_kpos"]) if not self.jobs_on_device else torch.zeros(2 * self.n_reads, dtype=torch.int32, device=dev)
         ne = (hb["event_off"][1:] - hb["event_off"][:-1]); nk = (hb["rank_off"][1:] - hb["rank_off"][:-1])
         bands = ne + nk + 2
         self.max_bands = int(bands.max())
@@ -204,7 +273,14 @@ class CallMethylationBatch:
     def step(self):
         L, h = self.ctx.L, self.ctx.h
         p = lambda t: C.c_void_p(t.data_ptr())
-        if self.jobs_on_device:
+        if self.jobs_on_device and self.by_cigar:
+            rc = L.np_cm_build_jobs_cigar_dev(h, None, self.n_reads, p(self.d_genome), p(self.d_ref_begin), p(self.d_ref_len), p(self.d_cigar),
+                                              p(self.d_cigar_off), self.n_cigar_ops, p(self.d_read_len), p(self.d_rc), api.alphabet_id("cpg"),
+                                              self.cm[2], self.cm[0], self.cm[1], p(self.d_group_off), self.n_slots, p(self.d_jr_off),
+                                              p(self.d_jobs), p(self.d_kpos), p(self.d_job_ranks), p(self.d_first), p(self.d_last),
+                                              p(self.d_n_motif), p(self.d_n_groups), p(self.d_deg))
+            self.ctx._chk(rc, "np_cm_build_jobs_cigar_dev")
+        elif self.jobs_on_device:
             rc = L.np_cm_build_jobs_identity_dev(h, None, self.n_reads, p(self.d_seq), p(self.d_seq_off), p(self.d_rc), api.alphabet_id("cpg"),
                                                  self.cm[2], self.cm[0], self.cm[1], p(self.d_group_off), self.n_slots, p(self.d_jr_off),
                                                  p(self.d_jobs), p(self.d_kpos), p(self.d_job_ranks), p(self.d_first), p(self.d_last),
@@ -232,6 +308,9 @@ class CallMethylationBatch:
                                        p(self.d_pair_begin), p(self.d_n_pairs), p(self.d_map), p(self.d_epb), self.n_jobs,
                                        p(self.d_jobs), p(self.d_kpos))
             self.ctx._chk(rc, "np_resolve_jobs_dev")
+        if self.by_cigar:
+            rc = L.np_cm_discard_degenerate_dev(h, None, p(self.d_reads_b), p(self.d_map), p(self.d_deg), self.n_jobs, p(self.d_jobs))
+            self.ctx._chk(rc, "np_cm_discard_degenerate_dev")
         rc = L.np_hmm_score_dev(h, None, self.n_jobs, p(self.d_jobs), p(self.d_reads_b), p(self.d_events), p(self.d_job_ranks),
                                 self.m_cpg, p(self.d_scores))
         self.ctx._chk(rc, "np_hmm_score_dev")

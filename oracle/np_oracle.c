@@ -791,6 +791,34 @@ static int lower_bound_ref(const int32_t* pairs, int n, int v)
     return lo;
 }
 
+/* get_aligned_segments, src/alignment/nanopolish_anchor.cpp:20-95 (read_stride 1), first segment only: a BAM_CREF_SKIP
+ * starts a second segment, which SequenceAlignmentRecord rejects (alignment_db.cpp:43-47) -> -1 here. */
+int npo_cigar_aligned_bases(const uint32_t* cigar, int n_cigar, int pos, int32_t* out_pairs, int cap)
+{
+    int read_pos = 0, ref_pos = pos, n = 0;
+    for(int ci = 0; ci < n_cigar; ++ci) {
+        int cigar_len = cigar[ci] >> 4;
+        int cigar_op = cigar[ci] & 0xf;
+        int read_inc = 0, ref_inc = 0, is_aligned = 0;
+        if(cigar_op == 0 || cigar_op == 7 || cigar_op == 8) { is_aligned = 1; read_inc = 1; ref_inc = 1; }   /* M, =, X */
+        else if(cigar_op == 2) { ref_inc = 1; }                                                             /* D */
+        else if(cigar_op == 3) { return -1; }                                                               /* N */
+        else if(cigar_op == 1) { read_inc = 1; }                                                            /* I */
+        else if(cigar_op == 4) { read_inc = 1; }                                                            /* S */
+        else if(cigar_op == 5) { read_inc = 0; }                                                            /* H */
+        else { return -1; }                                        /* assert(false && "Unhandled cigar operation") */
+        for(int j = 0; j < cigar_len; ++j) {
+            if(is_aligned) {
+                if(n < cap) { out_pairs[2 * n] = ref_pos; out_pairs[2 * n + 1] = read_pos; }
+                n++;
+            }
+            read_pos += read_inc;
+            ref_pos += ref_inc;
+        }
+    }
+    return n;
+}
+
 /* _find_iter_by_ref_bounds + _find_by_ref_bounds, src/alignment/nanopolish_alignment_db.cpp:688-731 */
 int npo_find_by_ref_bounds(const int32_t* pairs, int n, int ref_start, int ref_stop, int* read_start, int* read_stop)
 {

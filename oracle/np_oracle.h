@@ -107,6 +107,10 @@ void npo_aligner_constants(uint32_t n_events, uint32_t n_kmers, double out[4]); 
  * returns count (0 if degenerate). */
 int  npo_event_alignment_record(const int32_t* aligned_bases, int n_bases, int read_length, int k, int seq_rc,
                                 const int32_t* map_start, uint32_t n_kmers, int32_t* out_aligned_events);
+/* get_aligned_segments (src/alignment/nanopolish_anchor.cpp:20-95) for the single segment SequenceAlignmentRecord accepts
+ * (src/alignment/nanopolish_alignment_db.cpp:41-49): (ref_pos, read_pos) pairs of the M/=/X operations of a BAM CIGAR
+ * (uint32 words, length << 4 | op).  Returns the number of pairs (counted even beyond cap), or -1 for a spliced record. */
+int  npo_cigar_aligned_bases(const uint32_t* cigar, int n_cigar, int pos, int32_t* out_pairs, int cap);
 /* AlignmentDB::_find_by_ref_bounds (src/alignment/nanopolish_alignment_db.cpp:688-731) */
 int  npo_find_by_ref_bounds(const int32_t* pairs, int n, int ref_start, int ref_stop, int* read_start, int* read_stop);
 /* Motif scan + grouping (:298-320) and window rule (:328-338). Outputs per group: first/last motif site

@@ -250,6 +250,15 @@ class Oracle:
                                               _p(ms, c_i32p), C.c_uint32(len(ms)), _p(out, c_i32p))
         return out[:n].copy()
 
+    def cigar_aligned_bases(self, cigar, pos=0):
+        cg = np.ascontiguousarray(cigar, np.uint32)
+        n = self.L.npo_cigar_aligned_bases(_p(cg, c_u32p), len(cg), int(pos), None, 0)
+        if n < 0:
+            return None
+        out = np.zeros((n, 2), np.int32)
+        self.L.npo_cigar_aligned_bases(_p(cg, c_u32p), len(cg), int(pos), _p(out, c_i32p), n)
+        return out
+
     def find_by_ref_bounds(self, pairs, ref_start, ref_stop):
         pairs = np.ascontiguousarray(pairs, np.int32)
         a = C.c_int(); b = C.c_int()

@@ -43,6 +43,91 @@ def methylation_jobs(orc, read, pairs, min_separation=10, min_flank=10):
     return epb, jobs
 
 
+def record_reference_segment(contig, pos, cigar_ops_or_words):
+    """What calculate_methylation_for_read fetches for a record (src/basemods/nanopolish_basemods.cpp:259-270):
+    contig[pos .. bam_endpos] INCLUSIVE (faidx_fetch_seq's end is inclusive), clipped to the contig."""
+    ref_len = 0
+    for w in cigar_ops_or_words:
+        op, n = (("MIDNSHP=X".index(w[0]), int(w[1])) if isinstance(w, (tuple, list)) else (int(w) & 0xf, int(w) >> 4))
+        if op in (0, 2, 3, 7, 8):
+            ref_len += n
+    endpos = pos + (ref_len if ref_len > 0 else 1)
+    return contig[pos:min(endpos + 1, len(contig))]
+
+
+def methylation_jobs_record(orc, rc, read_length, cigar, pos, ref_seq, map_start, alphabet="cpg", min_separation=10, min_flank=10):
+    """Work items of calculate_methylation_for_read (src/basemods/nanopolish_basemods.cpp:289-370) for a read aligned by a
+    BAM record: SequenceAlignmentRecord (CIGAR walk) -> EventAlignmentRecord -> motif groups -> _find_by_ref_bounds."""
+    aligned_bases = orc.cigar_aligned_bases(cigar, pos)
+    if aligned_bases is None:
+        raise ValueError("spliced alignment")
+    aligned_events = orc.event_alignment_record(aligned_bases, read_length, K, rc, map_start)
+    first, last, n_motif = orc.scan_motif_groups(alphabet, ref_seq, min_separation)
+    jobs = []
+    for f, l, nm in zip(first, last, n_motif):
+        sub_start, sub_end, span = int(f) - min_flank, int(l) + min_flank, int(l) - int(f)
+        if sub_start <= min_separation or span > 200:
+            continue
+        subseq = ref_seq[sub_start:sub_end + 1]
+        b = orc.find_by_ref_bounds(aligned_events, sub_start + pos, sub_end + pos) if len(aligned_events) else None
+        if b is None or abs(b[1] - b[0]) <= 10:
+            continue
+        e1, e2 = b
+        m_subseq = orc.methylate(alphabet, subseq)
+        jobs.append(dict(first=int(f) + pos, last=int(l) + pos, n_motif=int(nm), subseq=subseq, m_subseq=m_subseq,
+                         rc_subseq=orc.reverse_complement(alphabet, subseq),
+                         rc_m_subseq=orc.reverse_complement(alphabet, m_subseq),
+                         e1=e1, e2=e2, stride=1 if e1 <= e2 else -1, rc=int(rc),
+                         sequence=ref_seq[int(f) - K + 1:int(l) + K]))
+    return jobs
+
+
+def call_methylation_record(orc, mn, m_meth, read_seq, raw, rc, pos, cigar, contig, alphabet="cpg"):
+    """The reference's whole per-read pass restated on the oracle, from raw signal and a BAM record:
+    SquiggleRead::load_from_raw (src/nanopolish_squiggle_read.cpp:189-336: detect_events, MoM scalings, event alignment,
+    base_to_event_map, recalibrate_model, QC gates) then calculate_methylation_for_read.
+    mn / m_meth: oracle model handles (nucleotide / the methylation alphabet's).  Returns a dict with the read-level state
+    (events, scalings, events_per_base, event map) and the scored sites in ascending start position."""
+    L = len(read_seq)
+    codes = np.frombuffer(read_seq.encode(), np.uint8)
+    lut = np.zeros(256, np.int64); lut[ord("C")] = 1; lut[ord("G")] = 2; lut[ord("T")] = 3
+    c = lut[codes]
+    n_kmers = L - K + 1
+    ranks = np.zeros(n_kmers, np.int64)
+    for j in range(K):                                           # Alphabet::kmer_rank of every read k-mer (nucleotide)
+        ranks = ranks * 4 + c[j:j + n_kmers]
+    ranks = ranks.astype(np.uint32)
+    ev = orc.detect_events(raw)
+    events = ev["mean"] if isinstance(ev, dict) else ev[0]
+    out = dict(n_events=0, events=events, scalings=None, epb=0.0, map_start=None, map_stop=None, sites=[], jobs=[])
+    sh, sc = orc.estimate_scalings_mom(mn, ranks, events)
+    pairs = orc.event_align(mn, orc.scalings(sh, sc, 1.0), events, ranks)
+    if pairs is None or len(pairs) == 0:                          # failed alignment: events cleared (:324-329)
+        out["scalings"] = (sh, sc, 1.0)
+        return out
+    start, stop, epb = orc.build_base_to_event_map(pairs, n_kmers)
+    out["map_start"], out["map_stop"], out["epb"] = start, stop, epb
+    cal = orc.recalibrate(mn, events, ranks, start, stop)
+    out["scalings"] = cal if cal is not None else (sh, sc, 1.0)
+    if cal is None or cal[2] > 2.5:                               # not recalibrated / MIN_CALIBRATION_VAR (:320-323)
+        return out
+    if epb > 5.0:                                                 # events-per-base QC (:332)
+        return out
+    out["n_events"] = len(events)
+    ref_seq = record_reference_segment(contig, pos, cigar)
+    jobs = methylation_jobs_record(orc, rc, L, cigar, pos, ref_seq, start, alphabet)
+    S = orc.scalings(*cal)
+    for j in jobs:
+        ru = orc.sequence_kmer_ranks(alphabet, j["subseq"], j["rc_subseq"], K, j["rc"])
+        rm = orc.sequence_kmer_ranks(alphabet, j["m_subseq"], j["rc_m_subseq"], K, j["rc"])
+        u = orc.hmm_score(m_meth, S, events, ru, j["e1"], j["e2"], j["stride"], epb, 1.0, HAF_PRE | HAF_POST)
+        m = orc.hmm_score(m_meth, S, events, rm, j["e1"], j["e2"], j["stride"], epb, 1.0, HAF_PRE | HAF_POST)
+        out["sites"].append(dict(start=j["first"], end=j["last"], n_motif=j["n_motif"], ll_unmeth=float(np.float32(u)),
+                                 ll_meth=float(np.float32(m)), sequence=j["sequence"]))
+    out["jobs"] = jobs
+    return out
+
+
 def eventalign_segments(orc, read, pairs, stride_bp=100):
     """Consecutive ~100-bp segments as align_read_to_ref walks them (src/alignment/nanopolish_eventalign.cpp:668-812),
     simplified to fixed, non-chained windows of a forward identity-aligned read (enough to exercise

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/golden_reflevel.npz by running the REFERENCE'S OWN read-level code -- SquiggleRead::load_from_raw,
+EventAlignmentRecord, calculate_methylation_for_read, create_modbam_record, align_read_to_ref -- compiled in place from
+/root/reference (oracle/_ref/libnp_ref_full.so, `make -C oracle full`; veneer oracle/ref_full_harness.cpp).
+Run in the build container only:
+
+    python tests/gen_golden_reflevel.py
+
+Inputs are seeded synthetic reads: a 6 kb contig, reads sequenced from it with substitutions, insertions, deletions and
+soft clips (both strands) together with the BAM record an aligner would report, and their raw current traces; two
+identity-aligned reads for the eventalign chain.  Everything the tests need is stored (inputs and the reference's outputs),
+so the GPU box needs neither /root/reference nor numpy's RNG to reproduce them.
+"""
+import os
+import sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import load_models  # noqa: E402
+from oracle.ref_full import FullRef, cigar_words  # noqa: E402
+from nanopolish_amd.synth import synth_cigar_read, synth_raw, BASES  # noqa: E402
+
+GOLD = os.path.join(HERE, "golden")
+N_CIGAR_READS = 6
+EVENTALIGN_READS = (40, 41)
+
+
+def revcomp(s):
+    return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+def main():
+    models = load_models()
+    nuc = models["nucleotide"]
+    F = FullRef()
+    g = np.random.default_rng(20260924).integers(0, 4, 6000)
+    contig = BASES[g].tobytes().decode()
+    out = dict(contig=np.frombuffer(contig.encode(), np.uint8), n_reads=np.int64(N_CIGAR_READS))
+    for i in range(N_CIGAR_READS):
+        # read 4 is noisy enough to fail the calibration gate (var > MIN_CALIBRATION_VAR): no sites, events cleared
+        kw = dict(span=1300)
+        rd = synth_cigar_read(100 + i, g, nuc, **kw)
+        if i == 4:
+            rng = np.random.default_rng(7)
+            rd["raw"] = np.maximum(rd["raw"] + 9.0 * rng.standard_normal(len(rd["raw"])), 8.0).astype(np.float32)
+        cig = cigar_words(rd["cigar_ops"])
+        fr = F.read("read%d" % i, rd["seq"], rd["raw"])
+        p = "r%d_" % i
+        out[p + "seq"] = np.frombuffer(rd["seq"].encode(), np.uint8)
+        out[p + "bam_seq"] = np.frombuffer(rd["bam_seq"].encode(), np.uint8)
+        out[p + "raw"] = rd["raw"]
+        out[p + "cigar"] = cig
+        out[p + "rc_pos"] = np.array([int(rd["rc"]), rd["pos"]], np.int64)
+        out[p + "n_events"] = np.int64(fr.n_events)
+        out[p + "scalings"] = np.array([fr.shift, fr.scale, fr.var, fr.events_per_base], np.float64)
+        out[p + "events"] = fr.events()
+        ms, mp = fr.event_map()
+        out[p + "map_start"] = ms; out[p + "map_stop"] = mp
+        ae, rc_flag, stride = fr.event_alignment_record(rd["rc"], rd["pos"], cig, rd["bam_seq"]) if fr.n_events else (np.zeros((0, 2), np.int32), int(rd["rc"]), 1)
+        out[p + "aligned_events"] = ae
+        out[p + "ear_rc_stride"] = np.array([rc_flag, stride], np.int64)
+        res = fr.call_methylation(rd["rc"], rd["pos"], cig, rd["bam_seq"], contig)
+        out[p + "site_start"] = res["start"]; out[p + "site_end"] = res["end"]; out[p + "site_n_motif"] = res["n_motif"]
+        out[p + "site_ll_unmeth"] = res["ll_unmeth"]; out[p + "site_ll_meth"] = res["ll_meth"]
+        out[p + "site_sequence"] = np.array(res["sequence"] if res["sequence"] else [""], dtype="S64")[:len(res["sequence"])]
+        out[p + "Mm"] = np.frombuffer(res["Mm"].encode(), np.uint8)
+        out[p + "Ml"] = res["Ml"]
+        print("read %d rc=%d pos=%d cigar_ops=%d events=%d sites=%d var=%.3f" % (i, rd["rc"], rd["pos"], len(cig), fr.n_events,
+                                                                                 len(res["start"]), fr.var))
+    # eventalign: two identity-aligned reads (forward and reverse strand), align_read_to_ref's emitted rows
+    for j, rid in enumerate(EVENTALIGN_READS):
+        rd = synth_raw(rid, nuc, L=1500)
+        seq = rd["seq"]
+        fr = F.read("ea%d" % j, seq, rd["raw"])
+        ref = revcomp(seq) if rd["rc"] else seq
+        res = fr.eventalign(rd["rc"], 0, cigar_words([("M", len(seq))]), ref, ref)
+        p = "ea%d_" % j
+        out[p + "seq"] = np.frombuffer(seq.encode(), np.uint8)
+        out[p + "raw"] = rd["raw"]
+        out[p + "rc"] = np.int64(rd["rc"])
+        out[p + "scalings"] = np.array([fr.shift, fr.scale, fr.var, fr.events_per_base], np.float64)
+        out[p + "events"] = fr.events()
+        out[p + "ref_position"] = res["ref_position"]; out[p + "event_idx"] = res["event_idx"]; out[p + "hmm_state"] = res["hmm_state"]
+        out[p + "model_kmer"] = np.array(res["model_kmer"], dtype="S8")
+        print("eventalign read %d rc=%d rows=%d" % (rid, rd["rc"], len(res["event_idx"])))
+    path = os.path.join(GOLD, "golden_reflevel.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()
