@@ -5,14 +5,15 @@
  * bit-equality matter here, speed does not.  Compile like the reference: -O3, baseline x86-64,
  * -ffp-contract=off (the reference Makefile:12-13 never enables FMA).
  *
- * Parity status: PINNED.  tests/test_oracle_vs_ref.py compares every function below with the
- * reference's own code (oracle/_ref/libnp_ref.so) bit-for-bit on seeded inputs, and
- * tests/test_oracle_golden.py re-checks the committed vectors in tests/golden/ where the
- * reference is not available (GPU box).  The only pieces without a compiled-reference pin are
- * npo_build_base_to_event_map / npo_get_closest_event_to / npo_event_alignment_record /
- * npo_find_by_ref_bounds / npo_scan_motif_groups, whose reference translation units need
- * HDF5/htslib/Eigen and cannot be built here; they are restated by inspection ("parity unpinned"
- * for those five helpers only).
+ * Parity status: PINNED.  tests/test_oracle_vs_ref.py compares the HMM / aligner / detector functions below with the
+ * reference's own code (oracle/_ref/libnp_ref.so) bit-for-bit on seeded inputs; tests/test_oracle_vs_ref_full.py does the
+ * same for the read-level helpers (npo_build_base_to_event_map, npo_get_closest_event_to, npo_cigar_aligned_bases,
+ * npo_event_alignment_record, npo_find_by_ref_bounds, npo_scan_motif_groups, npo_recalibrate) against the reference's
+ * SquiggleRead::load_from_raw, EventAlignmentRecord, calculate_methylation_for_read and align_read_to_ref compiled in
+ * place (oracle/_ref/libnp_ref_full.so: htslib's record layout and accessors stood in for from the SAM specification,
+ * Eigen's 2x2 full-pivot LU restated in oracle/stubs_full/Eigen/Dense -- the one step that is a restatement on BOTH sides).
+ * tests/test_oracle_golden.py and tests/test_reflevel_golden.py re-check the committed vectors that code produced
+ * (tests/golden/) where the reference is not available (GPU box).
  */
 #include "np_oracle.h"
 #include <math.h>
@@ -896,8 +897,9 @@ void npo_score_many(const npo_model* m, int64_t n_jobs, const int32_t* job_read,
  * The 2x2 solve is Eigen 3.3.7 `A.fullPivLu().solve(b)` (methyltrain.cpp:283).  Eigen is NOT in this container, so
  * the restatement below follows Eigen's published algorithm (FullPivLU::computeInPlace + _solve_impl: complete
  * pivoting with the first maximum in column-major order, in-place elimination, rank from the default threshold
- * epsilon * diagonalSize, unit-lower then upper triangular solves, inverse column permutation) and is
- * "parity unpinned" for that step.
+ * epsilon * diagonalSize, unit-lower then upper triangular solves, inverse column permutation).  Everything around the
+ * solve is pinned against the reference's own recalibrate_model compiled in place (tests/test_oracle_vs_ref_full.py);
+ * the solve itself is "parity unpinned" (the same restatement stands in for Eigen there).
  * ===================================================================================== */
 static void eigen_fullpivlu_solve_2x2(const double Ain[4] /* row-major a00 a01 a10 a11 */, const double bin[2], double x[2])
 {

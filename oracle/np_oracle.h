@@ -89,7 +89,7 @@ void npo_build_base_to_event_map(const int32_t* pairs, int n_pairs, uint32_t n_k
 int  npo_get_closest_event_to(const int32_t* start, uint32_t n_kmers, int k_idx);
 
 /* f1: get_eventalignment_for_1d_basecalls (squiggle_read.cpp:339-389) + recalibrate_model (methyltrain.cpp:204-306,
- * scale_var, no drift).  Returns 1 if recalibrated.  The Eigen fullPivLu step is restated without Eigen (unpinned). */
+ * scale_var, no drift).  Returns 1 if recalibrated.  The Eigen fullPivLu step is restated without Eigen (the only unpinned step). */
 int  npo_recalibrate(const npo_model* m, const float* event_mean, const uint32_t* kmer_ranks, uint32_t n_kmers,
                      const int32_t* map_start, const int32_t* map_stop, double* shift, double* scale, double* var);
 

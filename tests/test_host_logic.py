@@ -113,7 +113,7 @@ def test_fill_read_host_constants(L):
 
 
 def test_oracle_recalibrate_solves_the_weighted_normal_equations(orc, models):
-    """f1 restatement (parity unpinned: methyltrain.cpp needs Eigen, not buildable here): check npo_recalibrate against an
+    """f1 restatement (its 2x2 Eigen solve is the one unpinned step, see tests/test_oracle_vs_ref_full.py for the rest): check npo_recalibrate against an
     independent numpy solve of the same weighted least squares on the same 'M' entries, and that it recovers the
     planted scalings of a synthetic read; < 200 'M' entries -> not recalibrated."""
     from cases import synth_read
