@@ -294,6 +294,30 @@ int np_cm_build_jobs_cigar(int alphabet, const char* ref_seq, size_t n, const ui
                            int32_t* kpos, int32_t* job_n_kmers, uint16_t* ranks_unmeth, uint16_t* ranks_meth,
                            int64_t* rank_off, int32_t* deg_kpos);
 
+/* ---- eventalign: the segment chain of align_read_to_ref on the device ---------------------------------------------------------- */
+/* Per-read status of np_eventalign_dev */
+#define NP_EA_OK          0
+#define NP_EA_OVERFLOW    1   /* a segment needs more lattice rows than the scratch holds, or the output capacity is too small */
+#define NP_EA_BAD_RECORD  2   /* the record points outside the read / the fetched reference (the reference asserts there) */
+/* align_read_to_ref (src/alignment/nanopolish_eventalign.cpp:612-826) for a batch of reads whose event alignment, event map
+ * and (calibrated) scalings are on the device (np_event_align_dev -> np_resolve_jobs_dev / np_calibrate_resolve_dev with
+ * n_jobs = 0 is enough): per read the chain of ~100-base segments, each one profile_hmm_align (flags 0, base model) from the
+ * previous segment's last emitted event, emitting ~50 aligned events per segment.  One wavefront per read.
+ *   reads / event_mean / map_start / n_pairs : as left by the calls above
+ *   genome, ref_begin, ref_len, cigar, cigar_off, read_len, read_rc : as np_cm_build_jobs_cigar_dev
+ *   out_off  : int64[n_reads+1], per-read output capacity (n_events + 1 rows always suffice)
+ *   out_ref / out_event / out_state : EventAlignment::ref_position (relative to the record's pos), ::event_idx, ::hmm_state
+ *              ('M' or 'B'), in the reference's output order
+ *   n_out / status / n_calls : rows written, NP_EA_*, number of profile_hmm_align calls (segments) per read
+ * A read that failed the aligner / calibration / events-per-base QC (no events in the reference) yields n_out = 0. */
+int np_eventalign_dev(np_ctx* ctx, void* stream, int n_reads, const np_read_dev* reads, const float* event_mean,
+                      const int32_t* map_start, const int32_t* n_pairs, const double* events_per_base, const int32_t* calibrated,
+                      int model, const char* genome, const int64_t* ref_begin, const int32_t* ref_len,
+                      const uint32_t* cigar, const int64_t* cigar_off, int64_t total_cigar_ops,
+                      const int32_t* read_len, const uint8_t* read_rc, uint32_t k,
+                      const int64_t* out_off, int32_t* out_ref, int32_t* out_event, uint8_t* out_state,
+                      int32_t* n_out, int32_t* status, int32_t* n_calls);
+
 /* ---- f2: the stage in front of the event aligner ------------------------------------------ */
 /* detector_param, src/thirdparty/scrappie/event_detection.h:6-12 */
 typedef struct np_detector_param {
@@ -340,7 +364,8 @@ int np_selftest_division(np_ctx* ctx, uint64_t n_samples, uint64_t seed, uint64_
 int np_sync(np_ctx* ctx, void* stream);
 
 /* Time (ms) spent in the most recent launch of each kernel family on the device, measured with HIP events
- * on the launching stream.  which: 0 = event align, 1 = hmm score, 2 = resolve, 3 = hmm viterbi. */
+ * on the launching stream.  which: 0 = event align, 1 = hmm score, 2 = resolve / calibrate / work items, 3 = hmm viterbi,
+ * 4 = event detection, 5 = MoM scalings, 6 = eventalign chain. */
 int np_last_kernel_ms(np_ctx* ctx, int which, float* ms);
 /* Accumulated device time (ms) and launch count of a kernel family since the last reset (call after np_sync). */
 int np_kernel_time(np_ctx* ctx, int which, double* total_ms, int64_t* launches, int reset);

@@ -15,7 +15,7 @@
 
 #define NP_VERSION_STR "nanopolish_amd 0.1 (gfx950)"
 #define NP_FLANK_LEN (1u << 20)
-#define NP_NUM_FAMILIES 6      // 0 event align, 1 forward HMM, 2 glue, 3 Viterbi, 4 event detection, 5 MoM scalings
+#define NP_NUM_FAMILIES 7      // 0 event align, 1 forward HMM, 2 glue, 3 Viterbi, 4 event detection, 5 MoM scalings, 6 eventalign chain
 
 namespace {
 
@@ -68,6 +68,8 @@ struct np_ctx {
             b_vm, b_bp, b_cell_off, b_state_off, b_states, b_n_states;
     dev_buf ed_status, ed_tstat;      // event detection scratch
     dev_buf cm_group_rank_off, cm_cigar_scratch;        // work-item generation scratch
+    dev_buf ea_bp, ea_path;                             // eventalign chain: per-wave back-pointer rows and path lists
+    int ea_rows_cap = 4096, ea_waves_per_cu = 16;
     dev_buf b_raw, b_raw_off, b_ev_off, b_ev_start, b_ev_len, b_ev_mean, b_ev_stdv, b_n_events;
     timing_t timing[NP_NUM_FAMILIES];
     std::mutex lock;
@@ -255,7 +257,7 @@ void np_destroy(np_ctx* c)
     dev_buf* bufs[] = {&c->order, &c->trace, &c->kparams, &c->b_jobs, &c->b_reads, &c->b_events, &c->b_ranks, &c->b_out, &c->b_pair_off,
                        &c->b_pairs, &c->b_pair_begin, &c->b_n_pairs, &c->b_vm, &c->b_bp, &c->b_cell_off, &c->b_state_off,
                        &c->b_states, &c->b_n_states, &c->ed_status, &c->ed_tstat, &c->b_raw, &c->b_raw_off, &c->b_ev_off, &c->b_ev_start,
-                       &c->b_ev_len, &c->b_ev_mean, &c->b_ev_stdv, &c->b_n_events, &c->cm_group_rank_off, &c->cm_cigar_scratch};
+                       &c->b_ev_len, &c->b_ev_mean, &c->b_ev_stdv, &c->b_n_events, &c->cm_group_rank_off, &c->cm_cigar_scratch, &c->ea_bp, &c->ea_path};
     for (dev_buf* b : bufs) b->release();
     for (auto& t : c->timing) {
         for (auto& pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -679,6 +681,50 @@ int np_cm_discard_degenerate_dev(np_ctx* c, void* stream, const np_read_dev* rea
     return NP_OK;
 }
 
+// ---- eventalign segment chain -----------------------------------------------------------------------------------------------
+int np_eventalign_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* reads, const float* event_mean, const int32_t* map_start,
+                      const int32_t* n_pairs, const double* events_per_base, const int32_t* calibrated, int model, const char* genome,
+                      const int64_t* ref_begin, const int32_t* ref_len, const uint32_t* cigar, const int64_t* cigar_off,
+                      int64_t total_cigar_ops, const int32_t* read_len, const uint8_t* read_rc, uint32_t k, const int64_t* out_off,
+                      int32_t* out_ref, int32_t* out_event, uint8_t* out_state, int32_t* n_out, int32_t* status, int32_t* n_calls)
+{
+    if (!c || n_reads < 0 || total_cigar_ops < 0 ||
+        (n_reads > 0 && (!reads || !event_mean || !map_start || !n_pairs || !events_per_base || !genome || !ref_begin || !ref_len || !cigar ||
+                         !cigar_off || !read_len || !read_rc || !out_off || !out_ref || !out_event || !out_state || !n_out || !status || !n_calls)))
+        return NP_ERR_INVALID;
+    if (model < 0 || model >= (int)c->models.size()) { c->err = "bad model id"; return NP_ERR_INVALID; }
+    if (c->models[model].n_states != 4096 || k != 6) { c->err = "np_eventalign_dev: nucleotide 6-mer base model only"; return NP_ERR_UNSUPPORTED; }
+    if (n_reads == 0) return NP_OK;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = pick_stream(c, stream);
+    const size_t n_idx = (size_t)total_cigar_ops + (size_t)n_reads;
+    NP_HIP(c, c->cm_cigar_scratch.reserve(2 * n_idx * sizeof(int32_t) + (size_t)n_reads * 16));
+    int32_t* op_ref = c->cm_cigar_scratch.as<int32_t>();
+    int32_t* op_read = op_ref + n_idx;
+    int32_t* cig_reads = op_read + n_idx;
+    const int rows_cap = c->ea_rows_cap;
+    const int nb = persistent_blocks(c, n_reads, 1, c->ea_waves_per_cu);
+    const size_t bp_stride = (size_t)rows_cap * 128, path_stride = (size_t)rows_cap + 256;
+    NP_HIP(c, c->ea_bp.reserve((size_t)nb * bp_stride));
+    NP_HIP(c, c->ea_path.reserve((size_t)nb * path_stride * sizeof(uint32_t)));
+    family_timer tm(c, 6, s);
+    NP_HIP(c, np_launch_cigar_index(n_reads, cigar, cigar_off, read_len, (int)k, op_ref, op_read, cig_reads, s));
+    NP_HIP(c, hipMemsetAsync(c->d_counters + 17, 0, sizeof(uint32_t), s));
+    np_ea_args a{};
+    a.n_reads = n_reads; a.reads = reads; a.event_mean = event_mean; a.map_start = map_start; a.n_pairs = n_pairs;
+    a.events_per_base = events_per_base; a.calibrated = calibrated;
+    a.model = c->models[model].d_states; a.flank = c->d_flank; a.genome = genome; a.ref_begin = ref_begin; a.ref_len = ref_len;
+    a.cigar = cigar; a.cigar_off = cigar_off; a.op_ref = op_ref; a.op_read = op_read; a.cig_reads = cig_reads;
+    a.read_len = read_len; a.read_rc = read_rc; a.k = (int)k;
+    a.bp = c->ea_bp.as<uint8_t>(); a.bp_stride = bp_stride; a.rows_cap = rows_cap;
+    a.path = c->ea_path.as<uint32_t>(); a.path_stride = path_stride;
+    a.out_off = out_off; a.out_ref = out_ref; a.out_event = out_event; a.out_state = out_state; a.n_out = n_out; a.status = status;
+    a.n_calls = n_calls; a.counter = c->d_counters + 17;
+    NP_HIP(c, np_launch_eventalign_chain(a, nb, s));
+    return NP_OK;
+}
+
 // tuning / test knobs
 int np_set_option(np_ctx* c, const char* name, int64_t value)
 {
@@ -688,6 +734,8 @@ int np_set_option(np_ctx* c, const char* name, int64_t value)
     if (k == "align_blocks_per_cu") c->align_blocks_per_cu = (int)std::max<int64_t>(1, value);
     else if (k == "hmm_blocks_per_cu") c->hmm_blocks_per_cu = (int)std::max<int64_t>(1, value);
     else if (k == "ed_warmup") c->ed_warmup = (int)value;
+    else if (k == "ea_rows_cap") c->ea_rows_cap = (int)std::min<int64_t>(65535, std::max<int64_t>(16, value));
+    else if (k == "ea_waves_per_cu") c->ea_waves_per_cu = (int)std::max<int64_t>(1, value);
     else { c->err = "np_set_option: unknown option " + k; return NP_ERR_INVALID; }
     return NP_OK;
 }

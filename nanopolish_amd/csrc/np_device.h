@@ -100,3 +100,17 @@ __device__ __forceinline__ float np_wave_ror1(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xf, 0xf, false));
 }
+
+// get_next_event / get_closest_event_to, src/nanopolish_squiggle_read.cpp:161-186: the start event of the nearest k-mer at or
+// below k_idx that has events (searching back at most 1000 k-mers, end-exclusive), else of the nearest one above.
+// ms = base_to_event_map[].start of the read (-1: no events), K = its size.
+__device__ __forceinline__ int closest_event(const int32_t* ms, int K, int k_idx)
+{
+    const int stop_before = 0 > k_idx - 1000 ? 0 : k_idx - 1000;
+    const int stop_after = k_idx + 1000 < K - 1 ? k_idx + 1000 : K - 1;
+    int event_before = -1, event_after = -1;
+    for (int s = k_idx; s != stop_before; s -= 1) { const int ei = ms[s]; if (ei != -1) { event_before = ei; break; } }
+    if (event_before != -1) return event_before;
+    for (int s = k_idx; s != stop_after; s += 1) { const int ei = ms[s]; if (ei != -1) { event_after = ei; break; } }
+    return event_after;
+}

@@ -1,0 +1,231 @@
+// np_eventalign_kernel.hip -- the eventalign segment chain on the device: align_read_to_ref
+// (src/alignment/nanopolish_eventalign.cpp:612-826) for a batch of reads, one wavefront per read.
+//
+// The reference realigns a read to its reference in ~100-base segments.  Every segment is one profile_hmm_align (Viterbi
+// fill + back-track, src/hmm/nanopolish_profile_hmm_r9.cpp:73-204, r9.inl:130-197, flags 0) over the events between the
+// segment's start event and the closest event of its last aligned base; of the aligned states only the first ~50 are
+// emitted, and the next segment starts at the last emitted (event, reference k-mer).  The chain is data-dependent from
+// segment to segment but independent between reads, so a persistent wave walks one read's chain from end to end:
+//   * segment geometry from the read's CIGAR without materialising aligned pairs (np_cigar.h; get_end_pair :196-205 is a
+//     "last aligned pair with ref_pos <= x" search), closest events from the read's event map (np_device.h);
+//   * Viterbi fill as an anti-diagonal sweep: lane j owns k-mer blocks 2j, 2j+1 (a segment has <= 96 k-mers), computes row
+//     t - j at step t; previous row in registers, left neighbour through DPP; six candidates in HMMMovementType order,
+//     later index wins ties; only back-pointers leave the wave: 6 bits per block and row (M: 3, B: 1, K: 2), one byte,
+//     128 B per row, into a per-wave scratch that stays in L2;
+//   * back-track by one lane, every visited state appended to a per-wave path list; then the wave reads the tail of the
+//     list back and emits it 64 entries at a time (ballot + prefix count reproduces the reference's "first 50 that are
+//     not K and not the start event" cut).
+// Output rows are (ref_position relative to the record's pos, event_idx, state 'M'/'B'); ref_kmer / model_kmer of the TSV
+// follow from them on the host (nanopolish_amd/eventalign.py).
+#include "np_kernels.h"
+#include "np_cigar.h"
+
+#define NP_EA_ROW_BYTES 128          // back-pointer bytes per lattice row (one per k-mer block; a segment has <= 96)
+#define NP_EA_MAX_KMERS 128
+
+namespace {
+
+struct vmax { float v; uint32_t from; };
+__device__ __forceinline__ void vit_step(vmax& m, float x, uint32_t i)
+{
+    m.v = x > m.v ? x : m.v;
+    m.from = (m.v == x) ? i : m.from;
+}
+
+__device__ __forceinline__ uint32_t base_code(char c) { return c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u; }   // disambiguated to ACGT upstream
+
+__global__ void __launch_bounds__(64) np_eventalign_chain_kernel(np_ea_args a)
+{
+    const int lane = threadIdx.x;
+    const int wave_slot = blockIdx.x;
+    uint8_t* __restrict__ bp = a.bp + (size_t)wave_slot * a.bp_stride;
+    uint32_t* __restrict__ path = a.path + (size_t)wave_slot * a.path_stride;
+    const int k = a.k;
+
+    for (;;) {
+        const int ri = __builtin_amdgcn_readfirstlane((int)atomicAdd(a.counter, lane == 0 ? 1u : 0u));
+        if (ri >= a.n_reads) break;
+        const np_read_dev* rd = a.reads + ri;
+        const float* __restrict__ ev = a.event_mean + rd->event_off;
+        const int32_t* __restrict__ ms = a.map_start + rd->rank_off;
+        const int K = (int)rd->n_kmers;
+        const char* __restrict__ ref = a.genome + a.ref_begin[ri];
+        const int ref_n = a.ref_len[ri];
+        const int rl = a.read_len[ri];
+        const bool rc = a.read_rc[ri] != 0;
+        const cig_view cv{a.cigar + a.cigar_off[ri], a.op_ref + a.cigar_off[ri] + ri, a.op_read + a.cigar_off[ri] + ri,
+                          (int)(a.cigar_off[ri + 1] - a.cigar_off[ri])};
+        const int64_t o0 = a.out_off[ri];
+        const int out_cap = (int)(a.out_off[ri + 1] - o0);
+        int n_out = 0, n_calls = 0, status = NP_EA_OK;
+
+        // aligned pairs trimmed to read_pos <= max_kmer_idx (trim_aligned_pairs_to_kmer, :167-177)
+        const int max_kmer_idx = rl - k;
+        int q_first = 0, r_first = 0, q_last = 0, r_last = 0;
+        // a read without events in the reference (failed alignment / calibration / events-per-base QC, squiggle_read.cpp:320-335) is skipped
+        bool have = a.cig_reads[4 * ri + 2] != 0 && rd->n_events > 0 && a.n_pairs[ri] > 0 && !(a.events_per_base[ri] > 5.0) &&
+                    (!a.calibrated || a.calibrated[ri] != 0) && first_aligned_read_ge(cv, 0, q_first, r_first) &&
+                    last_aligned_read_le_r(cv, max_kmer_idx, q_last, r_last) && q_first <= q_last;
+        int first_event = -1, last_event = -1;
+        if (have) {
+            const int ks = rc ? rl - q_first - k : q_first, ke = rc ? rl - q_last - k : q_last;      // flip_k_strand
+            if (ks < 0 || ks >= K || ke < 0 || ke >= K) { have = false; status = NP_EA_BAD_RECORD; }    // the reference asserts / reads out of range
+            else { first_event = closest_event(ms, K, ks); last_event = closest_event(ms, K, ke); }
+        }
+        const bool forward = first_event < last_event;
+        int curr_start_event = first_event, curr_start_ref = r_first;
+
+        const float lp_mm_self = rd->trans[0], lp_mb = rd->trans[1], lp_mk = rd->trans[2], lp_mm_next = rd->trans[3],
+                    lp_bb = rd->trans[4], lp_bk = rd->trans[5], lp_bm_next = rd->trans[6], lp_bm_self = rd->trans[7],
+                    lp_kk = rd->trans[8], lp_km = rd->trans[9];
+        const double scale = rd->scale, shift = rd->shift, var = rd->var, log_var = rd->log_var;
+
+        while (have && ((forward && curr_start_event < last_event) || (!forward && curr_start_event > last_event))) {
+            // ---- segment geometry (:695-735) ----
+            int q_end = 0, r_end = 0;
+            if (!last_aligned_ref_le(cv, curr_start_ref + 100, q_end, r_end)) break;      // cannot happen: curr_start_ref is an aligned position
+            if (q_end > q_last) { q_end = q_last; r_end = r_last; }
+            const bool last_section = q_end == q_last;
+            const int curr_end_read = rc ? rl - q_end - k : q_end;
+            const int l = r_end - curr_start_ref + 1;
+            if (l < 2 * k) break;                                                          // hmm_sequence.length() < 2 * k
+            if (curr_start_ref + l > ref_n || curr_end_read < 0 || curr_end_read >= K) { status = NP_EA_BAD_RECORD; break; }
+            const int e_start = curr_start_event, e_stop = closest_event(ms, K, curr_end_read);
+            const int span = e_start > e_stop ? e_start - e_stop : e_stop - e_start;
+            if (span < 2) break;
+            const int stride = e_start < e_stop ? 1 : -1;
+            const int e = span + 1, n = l - k + 1;
+            if (n > NP_EA_MAX_KMERS || e > a.rows_cap) { status = NP_EA_OVERFLOW; break; }
+            n_calls++;
+
+            // ---- Viterbi fill (ProfileHMMViterbiOutputR9, r9.inl:130-197): lane owns blocks 2*lane, 2*lane + 1 ----
+            np_gauss g[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int b = 2 * lane + c;
+                uint32_t rank = 0;
+                if (b < n) {
+                    // HMMInputSequence::get_kmer_rank(b, k, rc): the forward k-mer at b, or its reverse complement's rank
+                    for (int t = 0; t < k; ++t) {
+                        const uint32_t code = rc ? 3u - base_code(ref[curr_start_ref + b + k - 1 - t]) : base_code(ref[curr_start_ref + b + t]);
+                        rank = rank * 4u + code;
+                    }
+                }
+                g[c] = np_scale_state(a.model, rank, scale, shift, var, log_var);
+            }
+            const int lanes_used = (n + 1) >> 1;
+            const bool lane_on = lane < lanes_used;
+            float M[2] = {NP_NEG_INF, NP_NEG_INF}, B[2] = {NP_NEG_INF, NP_NEG_INF}, Kst[2] = {NP_NEG_INF, NP_NEG_INF};
+            float oM = NP_NEG_INF, oB = NP_NEG_INF, oK = NP_NEG_INF;
+            float end_m = NP_NEG_INF;                                  // M of the last k-mer in the last row: where the back-track starts
+            const int steps = e + lanes_used - 1;
+            for (int t = 1; t <= steps; ++t) {
+                float nM = np_wave_shr1(M[1], NP_NEG_INF), nB = np_wave_shr1(B[1], NP_NEG_INF), nK = np_wave_shr1(Kst[1], NP_NEG_INF);
+                if (lane == 0) { nM = NP_NEG_INF; nB = NP_NEG_INF; nK = NP_NEG_INF; }
+                const int r = t - lane;
+                if (lane_on && r >= 1 && r <= e) {
+                    const float x = ev[e_start + (r - 1) * stride];
+                    float lM_r = nM, lB_r = nB, lK_r = nK, lM_p = oM, lB_p = oB, lK_p = oK;
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const float em = np_emission(x, g[c]);
+                        vmax m; m.v = lp_mm_self + M[c]; m.from = 0;
+                        vit_step(m, lp_mm_next + lM_p, 1);
+                        vit_step(m, lp_bm_self + B[c], 2);
+                        vit_step(m, lp_bm_next + lB_p, 3);
+                        vit_step(m, lp_km + lK_p, 4);
+                        vit_step(m, (c == 0 && lane == 0 && r == 1) ? a.flank[0] : NP_NEG_INF, 5);      // HMT_FROM_SOFT: first event only (flags 0)
+                        const float newM = m.v + em;
+                        vmax mb; mb.v = lp_mb + M[c]; mb.from = 0;
+                        vit_step(mb, lp_bb + B[c], 2);
+                        const float newB = mb.v + 0.0f;
+                        vmax mk; mk.v = lp_mk + lM_r; mk.from = 1;
+                        vit_step(mk, lp_bk + lB_r, 3);
+                        vit_step(mk, lp_kk + lK_r, 4);
+                        const float newK = mk.v + 0.0f;
+                        lM_p = M[c]; lB_p = B[c]; lK_p = Kst[c];
+                        lM_r = newM; lB_r = newB; lK_r = newK;
+                        M[c] = newM; B[c] = newB; Kst[c] = newK;
+                        // only the back-pointers of finite cells are ever followed: 3 bits M, 1 bit B (0 | 2), 2 bits K (1 | 3 | 4)
+                        const uint32_t byte = m.from | ((mb.from >> 1) << 3) | ((mk.from == 1 ? 0u : mk.from == 3 ? 1u : 2u) << 4);
+                        packed |= byte << (8 * c);
+                        if (r == e && 2 * lane + c == n - 1) end_m = newM;
+                    }
+                    *(uint16_t*)(bp + (size_t)(r - 1) * NP_EA_ROW_BYTES + 2 * lane) = (uint16_t)packed;
+                }
+                oM = nM; oB = nB; oK = nK;
+            }
+            const float start_v = __shfl(end_m, (n - 1) >> 1, 64);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+
+            // ---- back-track (profile_hmm_align_r9, r9.cpp:117-196) by lane 0 ----
+            int cnt = 0;
+            if (start_v != NP_NEG_INF) {                    // assert(get(vm, row, col) != -INFINITY): no path, nothing to emit
+                if (lane == 0) {
+                    int row = e, kmer = n - 1, ps = 2;
+                    while (row > 0 && kmer >= 0) {
+                        path[cnt++] = (uint32_t)row | ((uint32_t)kmer << 16) | ((uint32_t)ps << 24);
+                        const uint32_t byte = bp[(size_t)(row - 1) * NP_EA_ROW_BYTES + kmer];
+                        const uint32_t mv = ps == 2 ? (byte & 7u) : ps == 1 ? ((byte >> 3) & 1u) * 2u : ((byte >> 4) == 0u ? 1u : (byte >> 4) == 1u ? 3u : 4u);
+                        if (mv == 5u) break;                // HMT_FROM_SOFT
+                        int next_ps = 2;
+                        if (mv == 1u) { kmer -= 1; } else if (mv == 2u) { next_ps = 1; } else if (mv == 3u) { kmer -= 1; next_ps = 1; }
+                        else if (mv == 4u) { kmer -= 1; next_ps = 0; }
+                        if (ps != 0) row -= 1;              // K states are silent (r9.cpp:176-178)
+                        ps = next_ps;
+                    }
+                }
+                cnt = __builtin_amdgcn_readfirstlane(cnt);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_waitcnt(0);
+            }
+
+            // ---- emit (:774-812): ascending order = the list read backwards ----
+            int num_output = 0, last_event_output = 0, last_ref_kmer_output = 0;
+            for (int base = 0; base < cnt && (num_output < 50 || last_section); base += 64) {
+                const int i = base + lane;
+                uint32_t p = 0; bool q = false; int evi = 0, km = 0, ps = 0;
+                if (i < cnt) {
+                    p = path[cnt - 1 - i];
+                    ps = (int)(p >> 24); km = (int)((p >> 16) & 0xff); evi = e_start + ((int)(p & 0xffff) - 1) * stride;
+                    q = ps != 0 && evi != curr_start_event;
+                }
+                const uint64_t qm = __builtin_amdgcn_ballot_w64(q);
+                const int before = __builtin_popcountll(qm & ((1ull << lane) - 1ull));
+                const int pos = num_output + before;
+                const bool wr = q && (pos < 50 || last_section);
+                if (wr) {
+                    if (n_out + before < out_cap) {
+                        a.out_ref[o0 + n_out + before] = curr_start_ref + km;
+                        a.out_event[o0 + n_out + before] = evi;
+                        a.out_state[o0 + n_out + before] = ps == 2 ? (uint8_t)'M' : (uint8_t)'B';
+                    }
+                }
+                const uint64_t wm = __builtin_amdgcn_ballot_w64(wr);
+                const int nw = __builtin_popcountll(wm);
+                if (nw > 0) {
+                    const int last_lane = 63 - __builtin_clzll(wm);
+                    last_event_output = __shfl(evi, last_lane, 64);
+                    last_ref_kmer_output = curr_start_ref + __shfl(km, last_lane, 64);
+                }
+                if (n_out + nw > out_cap) status = NP_EA_OVERFLOW;
+                n_out += nw; num_output += nw;
+            }
+            if (status != NP_EA_OK) break;
+            curr_start_event = last_event_output;
+            curr_start_ref = last_ref_kmer_output;
+            if (num_output == 0) break;
+        }
+        if (lane == 0) { a.n_out[ri] = n_out < out_cap ? n_out : out_cap; a.status[ri] = status; a.n_calls[ri] = n_calls; }
+    }
+}
+
+} // namespace
+
+hipError_t np_launch_eventalign_chain(const np_ea_args& a, int n_blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(np_eventalign_chain_kernel, dim3(n_blocks), dim3(64), 0, s, a);
+    return hipGetLastError();
+}

@@ -185,18 +185,6 @@ __global__ void __launch_bounds__(64) np_recalibrate_kernel(int n_reads, np_read
     }
 }
 
-// get_next_event / get_closest_event_to, squiggle_read.cpp:161-186
-__device__ __forceinline__ int closest_event(const int32_t* ms, int K, int k_idx)
-{
-    const int stop_before = 0 > k_idx - 1000 ? 0 : k_idx - 1000;
-    const int stop_after = k_idx + 1000 < K - 1 ? k_idx + 1000 : K - 1;
-    int event_before = -1, event_after = -1;
-    for (int s = k_idx; s != stop_before; s -= 1) { const int ei = ms[s]; if (ei != -1) { event_before = ei; break; } }
-    if (event_before != -1) return event_before;
-    for (int s = k_idx; s != stop_after; s += 1) { const int ei = ms[s]; if (ei != -1) { event_after = ei; break; } }
-    return event_after;
-}
-
 __global__ void __launch_bounds__(256) np_resolve_kernel(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads,
                                                          const int32_t* n_pairs, const double* events_per_base,
                                                          const int32_t* calibrated, const int32_t* map_start, const int32_t* kpos)

@@ -13,6 +13,7 @@
 // CIGAR mode never materialises the aligned pairs: a per-read exclusive scan of the operations' reference / read advances
 // (np_cigar_index_kernel) turns every lower_bound of the reference into one binary search over the operations.
 #include "np_kernels.h"
+#include "np_cigar.h"
 
 namespace {
 
@@ -45,58 +46,6 @@ __device__ __forceinline__ char rc_meth_char(const char* __restrict__ ref, int w
     return comp(c);
 }
 
-
-// ---- CIGAR view ---------------------------------------------------------------------------------------------------------
-struct cig_view {
-    const uint32_t* cigar;     // BAM words: length << 4 | op
-    const int32_t* op_ref;     // reference offset (relative to the record's pos) at the start of every operation, n + 1 entries
-    const int32_t* op_read;    // read offset (reference strand) likewise
-    int n;
-};
-__device__ __forceinline__ bool op_aligned(uint32_t w) { const uint32_t op = w & 0xf; return op == 0 || op == 7 || op == 8; }
-
-// first aligned pair with ref_pos >= x: the operation that contains x is the last one starting at or before it
-__device__ __forceinline__ bool first_aligned_ref_ge(const cig_view& c, int x, int& q, int& r)
-{
-    int lo = 0, hi = c.n;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (c.op_ref[mid] <= x) lo = mid + 1; else hi = mid; }
-    for (int i = lo > 0 ? lo - 1 : 0; i < c.n; ++i) {
-        const uint32_t w = c.cigar[i];
-        const int len = (int)(w >> 4);
-        if (!op_aligned(w) || len == 0) continue;
-        const int off = x - c.op_ref[i] > 0 ? x - c.op_ref[i] : 0;
-        if (off < len) { q = c.op_read[i] + off; r = c.op_ref[i] + off; return true; }
-    }
-    return false;
-}
-// first aligned pair with read_pos >= y
-__device__ __forceinline__ bool first_aligned_read_ge(const cig_view& c, int y, int& q, int& r)
-{
-    int lo = 0, hi = c.n;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (c.op_read[mid] <= y) lo = mid + 1; else hi = mid; }
-    for (int i = lo > 0 ? lo - 1 : 0; i < c.n; ++i) {
-        const uint32_t w = c.cigar[i];
-        const int len = (int)(w >> 4);
-        if (!op_aligned(w) || len == 0) continue;
-        const int off = y - c.op_read[i] > 0 ? y - c.op_read[i] : 0;
-        if (off < len) { q = c.op_read[i] + off; r = c.op_ref[i] + off; return true; }
-    }
-    return false;
-}
-// last aligned pair with read_pos <= y
-__device__ __forceinline__ bool last_aligned_read_le(const cig_view& c, int y, int& q)
-{
-    int lo = 0, hi = c.n;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (c.op_read[mid] <= y) lo = mid + 1; else hi = mid; }
-    for (int i = lo - 1; i >= 0; --i) {
-        const uint32_t w = c.cigar[i];
-        const int len = (int)(w >> 4);
-        if (!op_aligned(w) || len == 0) continue;
-        const int off = y - c.op_read[i] < len - 1 ? y - c.op_read[i] : len - 1;
-        if (off >= 0) { q = c.op_read[i] + off; return true; }
-    }
-    return false;
-}
 
 // per read: (first filtered read_pos, last filtered read_pos) of the aligned events, or (-1, -1); [2] = 1 if the CIGAR is usable
 struct cig_read_t { int32_t first_q, last_q, ok, pad; };
@@ -335,5 +284,14 @@ hipError_t np_launch_cm_build_jobs_cigar(int n_reads, const char* genome, const 
                        min_flank, group_off, rank_off_cap, first_site, last_site, n_motif, group_rank_off, n_groups);
     hipLaunchKernelGGL(np_cm_items_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, genome, ref_begin, ref_len, group_kpos, read_rc, alphabet, k,
                        min_flank, group_off, first_site, last_site, group_rank_off, n_groups, jobs, kpos, job_ranks);
+    return hipGetLastError();
+}
+
+hipError_t np_launch_cigar_index(int n_reads, const uint32_t* cigar, const int64_t* cigar_off, const int32_t* read_len, int k, int32_t* op_ref,
+                                 int32_t* op_read, void* cig_reads, hipStream_t s)
+{
+    if (n_reads <= 0) return hipSuccess;
+    hipLaunchKernelGGL(np_cigar_index_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, cigar, cigar_off, read_len, k, op_ref, op_read,
+                       (cig_read_t*)cig_reads);
     return hipGetLastError();
 }

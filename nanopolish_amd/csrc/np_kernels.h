@@ -23,6 +23,42 @@ struct np_hmm_args {
     int32_t* n_states;
 };
 
+struct np_ea_args {
+    int n_reads;
+    const np_read_dev* reads;      // calibrated scalings + HMM transitions (np_resolve_jobs_dev / np_calibrate_resolve_dev)
+    const float* event_mean;
+    const int32_t* map_start;      // base_to_event_map[].start per read at rank_off
+    const int32_t* n_pairs;        // aligner result per read (0: failed, events cleared)
+    const double* events_per_base;
+    const int32_t* calibrated;     // may be null
+    const np_state_dev* model;
+    const float* flank;
+    const char* genome;
+    const int64_t* ref_begin;
+    const int32_t* ref_len;
+    const uint32_t* cigar;
+    const int64_t* cigar_off;
+    const int32_t* op_ref;         // np_cigar_index_kernel output
+    const int32_t* op_read;
+    const int32_t* cig_reads;      // 4 x int32 per read (first_q, last_q, ok, pad)
+    const int32_t* read_len;
+    const uint8_t* read_rc;
+    int k;
+    uint8_t* bp;                   // per-wave back-pointer scratch: rows_cap x 128 B
+    size_t bp_stride;
+    int rows_cap;
+    uint32_t* path;                // per-wave path list: rows_cap + 128 entries
+    size_t path_stride;
+    const int64_t* out_off;
+    int32_t* out_ref;
+    int32_t* out_event;
+    uint8_t* out_state;
+    int32_t* n_out;
+    int32_t* status;
+    int32_t* n_calls;
+    uint32_t* counter;
+};
+
 struct np_align_args {
     const np_read_dev* reads;
     const float* event_mean;
@@ -84,6 +120,9 @@ hipError_t np_launch_cm_build_jobs(int n_reads, const char* seq, const int64_t* 
                                    int min_separation, int min_flank, const int64_t* group_off, const int64_t* rank_off_cap,
                                    np_hmm_job_dev* jobs, int32_t* kpos, uint16_t* job_ranks, int32_t* first_site, int32_t* last_site,
                                    int32_t* n_motif, int64_t* group_rank_off, int32_t* n_groups, hipStream_t s);
+hipError_t np_launch_eventalign_chain(const np_ea_args& a, int n_blocks, hipStream_t s);
+hipError_t np_launch_cigar_index(int n_reads, const uint32_t* cigar, const int64_t* cigar_off, const int32_t* read_len, int k, int32_t* op_ref,
+                                 int32_t* op_read, void* cig_reads, hipStream_t s);
 hipError_t np_launch_cm_build_jobs_cigar(int n_reads, const char* genome, const int64_t* ref_begin, const int32_t* ref_len,
                                          const uint32_t* cigar, const int64_t* cigar_off, const int32_t* read_len, const uint8_t* read_rc,
                                          int alphabet, int k, int min_separation, int min_flank, const int64_t* group_off,

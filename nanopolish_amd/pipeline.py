@@ -91,18 +91,24 @@ def build_host_batch(models, read_ids, L=5450, k=6, raw=False):
 def build_host_batch_records(models, records, contig, k=6):
     """Host-side preparation of a batch of reads given EXPLICITLY, each with its raw signal and the BAM record of its
     base-to-reference alignment: records = dicts(seq: the read's own sequence, raw: float32 samples, rc: bam_is_rev,
-    pos: 0-based leftmost reference position, cigar: uint32 BAM words).  contig: the reference the records align to.
+    pos: 0-based leftmost reference position, cigar: uint32 BAM words[, contig: this record's own reference]).  contig: the
+    reference the records align to (those without their own).
     The batch starts from raw signal (from_raw) and its work items follow the CIGARs: the host builder's
     items are in hb["jobs"] / hb["kpos"]; the device builder needs hb["cigar"], hb["ref_begin"], ... (same numbering)."""
     L_ = _l.load_library()
     from .synth import nucleotide_kmer_ranks
     lut = np.zeros(256, np.int64); lut[ord("C")] = 1; lut[ord("G")] = 2; lut[ord("T")] = 3
     reads = []
+    contigs, contig_base = [], {}
+    for r in records:
+        cs = r.get("contig", contig)
+        if cs not in contig_base:
+            contig_base[cs] = sum(len(x) for x in contigs); contigs.append(cs)
     for r in records:
         codes = lut[np.frombuffer(r["seq"].encode(), np.uint8)]
         reads.append(dict(seq=r["seq"], rc=bool(r["rc"]), raw=np.ascontiguousarray(r["raw"], np.float32), ranks=nucleotide_kmer_ranks(codes, k),
                           events=np.zeros(len(r["raw"]) // 2 + 2, np.float32), shift=0.0, scale=1.0, var=1.0,
-                          pos=int(r["pos"]), cigar=np.ascontiguousarray(r["cigar"], np.uint32)))
+                          pos=int(r["pos"]), cigar=np.ascontiguousarray(r["cigar"], np.uint32), contig=r.get("contig", contig)))
     n = len(reads)
     event_off = np.zeros(n + 1, np.int64); rank_off = np.zeros(n + 1, np.int64)
     event_off[1:] = np.cumsum([len(r["events"]) for r in reads]); rank_off[1:] = np.cumsum([len(r["ranks"]) for r in reads])
@@ -118,8 +124,8 @@ def build_host_batch_records(models, records, contig, k=6):
         # the segment calculate_methylation_for_read fetches: contig[pos .. bam_endpos] inclusive, clipped (basemods.cpp:259-270)
         span = int(sum(int(w) >> 4 for w in r["cigar"] if (int(w) & 0xf) in (0, 2, 3, 7, 8)))
         endpos = r["pos"] + (span if span > 0 else 1)
-        seg = contig[r["pos"]:min(endpos + 1, len(contig))]
-        ref_seqs.append(seg); ref_begin[i] = r["pos"]; ref_len[i] = len(seg)
+        seg = r["contig"][r["pos"]:min(endpos + 1, len(r["contig"]))]
+        ref_seqs.append(seg); ref_begin[i] = contig_base[r["contig"]] + r["pos"]; ref_len[i] = len(seg)
         jb = api.cm_build_jobs_cigar(seg, r["cigar"], len(r["seq"]), r["rc"], k)
         deg[i] = jb["deg_kpos"]
         ng = len(jb["first"])
@@ -144,7 +150,7 @@ def build_host_batch_records(models, records, contig, k=6):
                 kpos=np.concatenate(kpos).astype(np.int32) if kpos else np.zeros((0, 2), np.int32),
                 job_ranks=np.concatenate(jranks).astype(np.uint16) if jranks else np.zeros(0, np.uint16),
                 job_off=np.concatenate([[0], np.cumsum([len(j) for j in jobs])]).astype(np.int64), meta=meta,
-                genome=np.frombuffer(contig.encode(), np.uint8).copy(), ref_begin=ref_begin, ref_len=ref_len,
+                genome=np.frombuffer("".join(contigs).encode(), np.uint8).copy(), ref_begin=ref_begin, ref_len=ref_len,
                 cigar=np.concatenate([r["cigar"] for r in reads]).astype(np.uint32), cigar_off=cigar_off,
                 read_len=np.array([len(r["seq"]) for r in reads], np.int32), deg_kpos=deg)
 
@@ -220,11 +226,7 @@ class CallMethylationBatch:
             MINSEP, FLANK = 10, 10
             seqs = hb["ref_seqs"]
             ln = np.array([len(q) for q in seqs], np.int64)
-            if self.by_cigar:
-                # the contig stays resident; reads carry (offset, length) of their reference segment and their CIGAR
-                self.d_genome = up(hb["genome"]); self.d_ref_begin = up(hb["ref_begin"]); self.d_ref_len = up(hb["ref_len"])
-                self.d_cigar = up(hb["cigar"]); self.d_cigar_off = up(hb["cigar_off"]); self.d_read_len = up(hb["read_len"])
-                self.n_cigar_ops = int(hb["cigar_off"][-1])
+
             self.seq_off = np.zeros(self.n_reads + 1, np.int64); self.seq_off[1:] = np.cumsum(ln)
             gcap = ln // (MINSEP + 1) + 2
             self.group_off = np.zeros(self.n_reads + 1, np.int64); self.group_off[1:] = np.cumsum(gcap)
@@ -246,6 +248,12 @@ class CallMethylationBatch:
         else:
             self.d_jobs = up(hb["jobs"]); self.d_kpos = up(hb["kpos"]); self.d_job_ranks = up(hb["job_ranks"])
         if self.by_cigar:
+            # the contig(s) stay resident; reads carry (offset, length) of their reference segment and their CIGAR
+            self.d_genome = up(hb["genome"]); self.d_ref_begin = up(hb["ref_begin"]); self.d_ref_len = up(hb["ref_len"])
+            self.d_cigar = up(hb["cigar"]); self.d_cigar_off = up(hb["cigar_off"]); self.d_read_len = up(hb["read_len"])
+            self.n_cigar_ops = int(hb["cigar_off"][-1])
+            if not self.jobs_on_device:
+                self.d_rc = up(np.array([r["rc"] for r in hb["reads"]], np.uint8))
             self.d_deg = up(hb["deg_kpos"]) if not self.jobs_on_device else torch.zeros(2 * self.n_reads, dtype=torch.int32, device=dev)
         ne = (hb["event_off"][1:] - hb["event_off"][:-1]); nk = (hb["rank_off"][1:] - hb["rank_off"][:-1])
         bands = ne + nk + 2
@@ -314,6 +322,40 @@ class CallMethylationBatch:
         rc = L.np_hmm_score_dev(h, None, self.n_jobs, p(self.d_jobs), p(self.d_reads_b), p(self.d_events), p(self.d_job_ranks),
                                 self.m_cpg, p(self.d_scores))
         self.ctx._chk(rc, "np_hmm_score_dev")
+
+    def eventalign(self):
+        """align_read_to_ref for every read of the batch (np_eventalign_dev), after step(): the segment chain of
+        profile_hmm_align calls under the base model.  Returns a list of dicts(ref_position (absolute, record pos added),
+        event_idx, hmm_state, status, n_calls) per read.  Needs a record-based batch (build_host_batch_records)."""
+        assert self.by_cigar, "eventalign needs BAM records (build_host_batch_records)"
+        torch = self.torch
+        L, h = self.ctx.L, self.ctx.h
+        p = lambda t: C.c_void_p(t.data_ptr())
+        dev = self.d_events.device
+        if not hasattr(self, "d_ea_off"):
+            ecap = (self.hb["event_off"][1:] - self.hb["event_off"][:-1]) + 1
+            self.ea_off = np.zeros(self.n_reads + 1, np.int64); self.ea_off[1:] = np.cumsum(ecap)
+            tot = int(self.ea_off[-1])
+            self.d_ea_off = torch.from_numpy(self.ea_off).to(dev)
+            self.d_ea_ref = torch.zeros(tot, dtype=torch.int32, device=dev); self.d_ea_event = torch.zeros(tot, dtype=torch.int32, device=dev)
+            self.d_ea_state = torch.zeros(tot, dtype=torch.uint8, device=dev)
+            self.d_ea_n = torch.zeros(self.n_reads, dtype=torch.int32, device=dev); self.d_ea_status = torch.zeros(self.n_reads, dtype=torch.int32, device=dev)
+            self.d_ea_calls = torch.zeros(self.n_reads, dtype=torch.int32, device=dev)
+        rc = L.np_eventalign_dev(h, None, self.n_reads, p(self.d_reads_b), p(self.d_events), p(self.d_map), p(self.d_n_pairs), p(self.d_epb),
+                                 p(self.d_calibrated) if self.calibrate else None, self.m_nuc, p(self.d_genome), p(self.d_ref_begin),
+                                 p(self.d_ref_len), p(self.d_cigar), p(self.d_cigar_off), self.n_cigar_ops, p(self.d_read_len), p(self.d_rc),
+                                 int(self.hb.get("k", 6)), p(self.d_ea_off), p(self.d_ea_ref), p(self.d_ea_event), p(self.d_ea_state),
+                                 p(self.d_ea_n), p(self.d_ea_status), p(self.d_ea_calls))
+        self.ctx._chk(rc, "np_eventalign_dev")
+        self.sync()
+        n = self.d_ea_n.cpu().numpy(); st = self.d_ea_status.cpu().numpy(); nc = self.d_ea_calls.cpu().numpy()
+        ref, ev, hs = self.d_ea_ref.cpu().numpy(), self.d_ea_event.cpu().numpy(), self.d_ea_state.cpu().numpy()
+        out = []
+        for i in range(self.n_reads):
+            lo = int(self.ea_off[i]); m = int(n[i])
+            out.append(dict(ref_position=ref[lo:lo + m] + self.hb["reads"][i % len(self.hb["reads"])]["pos"], event_idx=ev[lo:lo + m].copy(),
+                            hmm_state=hs[lo:lo + m].copy(), status=int(st[i]), n_calls=int(nc[i])))
+        return out
 
     def sync(self):
         self.ctx.sync()

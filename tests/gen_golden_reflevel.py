@@ -68,6 +68,10 @@ def main():
         out[p + "site_sequence"] = np.array(res["sequence"] if res["sequence"] else [""], dtype="S64")[:len(res["sequence"])]
         out[p + "Mm"] = np.frombuffer(res["Mm"].encode(), np.uint8)
         out[p + "Ml"] = res["Ml"]
+        # align_read_to_ref on the same record (realign_read only calls it for reads that have events, eventalign.cpp:567-571)
+        ea = fr.eventalign(rd["rc"], rd["pos"], cig, rd["bam_seq"], contig) if fr.n_events else \
+            dict(ref_position=np.zeros(0, np.int32), event_idx=np.zeros(0, np.int32), hmm_state=np.zeros(0, np.uint8))
+        out[p + "ea_ref_position"] = ea["ref_position"]; out[p + "ea_event_idx"] = ea["event_idx"]; out[p + "ea_hmm_state"] = ea["hmm_state"]
         print("read %d rc=%d pos=%d cigar_ops=%d events=%d sites=%d var=%.3f" % (i, rd["rc"], rd["pos"], len(cig), fr.n_events,
                                                                                  len(res["start"]), fr.var))
     # eventalign: two identity-aligned reads (forward and reverse strand), align_read_to_ref's emitted rows

@@ -153,3 +153,37 @@ def test_device_cigar_items_equal_host_builder_on_adversarial_cigars(ctx, models
                 assert np.array_equal(kpos[2 * (g0 + gi) + v], want["kpos"][gi]), (i, gi)
                 n_items += 1
     assert n_items > 200
+
+
+def test_eventalign_chain_on_device_matches_align_read_to_ref(ctx, models, gold):
+    """BASELINE config 3: the whole eventalign realignment -- from raw signal: detection, scalings, event alignment, calibration,
+    then per read the chain of ~100-base Viterbi segments (np_eventalign_dev) -- against the rows the reference's own
+    align_read_to_ref emitted (both strands), and against the CIGAR reads' chain on the oracle."""
+    recs, want = [], []
+    for j in range(2):
+        p = "ea%d_" % j
+        seq = _s(gold[p + "seq"]); rc = int(gold[p + "rc"])
+        ref = api.reverse_complement("nucleotide", seq) if rc else seq
+        recs.append(dict(seq=seq, raw=gold[p + "raw"], rc=rc, pos=0, cigar=api.cigar_words([("M", len(seq))]), contig=ref))
+        want.append((gold[p + "ref_position"], gold[p + "event_idx"], gold[p + "hmm_state"]))
+    hb = build_host_batch_records(models, recs, "")
+    batch = CallMethylationBatch(ctx, hb, "cuda:0", calibrate=True, from_raw=True)
+    batch.step()
+    got = batch.eventalign()
+    for j, (g, w) in enumerate(zip(got, want)):
+        assert g["status"] == 0 and g["n_calls"] > 20
+        assert np.array_equal(g["ref_position"], w[0]) and np.array_equal(g["event_idx"], w[1]) and np.array_equal(g["hmm_state"], w[2]), j
+    # records with insertions, deletions and soft clips (and one read without events)
+    recs, _ = _records(gold)
+    hb = build_host_batch_records(models, recs, _s(gold["contig"]))
+    batch = CallMethylationBatch(ctx, hb, "cuda:0", calibrate=True, from_raw=True)
+    batch.step()
+    got = batch.eventalign()
+    rows = 0
+    for i, g in enumerate(got):
+        p = "r%d_" % i
+        assert g["status"] == 0
+        assert np.array_equal(g["ref_position"], gold[p + "ea_ref_position"]) and np.array_equal(g["event_idx"], gold[p + "ea_event_idx"]), i
+        assert np.array_equal(g["hmm_state"], gold[p + "ea_hmm_state"])
+        rows += len(g["event_idx"])
+    assert rows > 8000
