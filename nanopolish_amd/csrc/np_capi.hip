@@ -69,7 +69,7 @@ struct np_ctx {
     dev_buf ed_status, ed_tstat;      // event detection scratch
     dev_buf cm_group_rank_off, cm_cigar_scratch;        // work-item generation scratch
     dev_buf ea_bp, ea_path;                             // eventalign chain: per-wave back-pointer rows and path lists
-    int ea_rows_cap = 4096, ea_waves_per_cu = 16;
+    int ea_rows_cap = 4096, ea_waves_per_cu = 20;
     dev_buf b_raw, b_raw_off, b_ev_off, b_ev_start, b_ev_len, b_ev_mean, b_ev_stdv, b_n_events;
     timing_t timing[NP_NUM_FAMILIES];
     std::mutex lock;
@@ -210,6 +210,7 @@ np_ctx* np_create(int device, const np_params* params)
     // tuning knobs (persistent-grid sizes); defaults fill the CU up to the kernels' register-limited occupancy
     if (const char* v = getenv("NP_ALIGN_BLOCKS_PER_CU")) c->align_blocks_per_cu = std::max(1, atoi(v));
     if (const char* v = getenv("NP_HMM_BLOCKS_PER_CU")) c->hmm_blocks_per_cu = std::max(1, atoi(v));
+    if (const char* v = getenv("NP_EA_WAVES_PER_CU")) c->ea_waves_per_cu = std::max(1, atoi(v));
     if (params) c->params = *params; else np_default_params(&c->params);
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
 
@@ -705,7 +706,7 @@ int np_eventalign_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* r
     int32_t* cig_reads = op_read + n_idx;
     const int rows_cap = c->ea_rows_cap;
     const int nb = persistent_blocks(c, n_reads, 1, c->ea_waves_per_cu);
-    const size_t bp_stride = (size_t)rows_cap * 128, path_stride = (size_t)rows_cap + 256;
+    const size_t bp_stride = ((size_t)rows_cap + 1) * 128, path_stride = (size_t)rows_cap + 256;      // + the dump row
     NP_HIP(c, c->ea_bp.reserve((size_t)nb * bp_stride));
     NP_HIP(c, c->ea_path.reserve((size_t)nb * path_stride * sizeof(uint32_t)));
     family_timer tm(c, 6, s);

@@ -22,6 +22,7 @@
 
 #define NP_EA_ROW_BYTES 128          // back-pointer bytes per lattice row (one per k-mer block; a segment has <= 96)
 #define NP_EA_MAX_KMERS 128
+#define NP_EA_CHUNK 32               // lattice rows of back-pointers staged in LDS per back-track pass (4 KB per wave)
 
 namespace {
 
@@ -34,8 +35,9 @@ __device__ __forceinline__ void vit_step(vmax& m, float x, uint32_t i)
 
 __device__ __forceinline__ uint32_t base_code(char c) { return c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u; }   // disambiguated to ACGT upstream
 
-__global__ void __launch_bounds__(64) np_eventalign_chain_kernel(np_ea_args a)
+__global__ void __launch_bounds__(64, 5) np_eventalign_chain_kernel(np_ea_args a)
 {
+    __shared__ uint4 stage[NP_EA_CHUNK * NP_EA_ROW_BYTES / 16];
     const int lane = threadIdx.x;
     const int wave_slot = blockIdx.x;
     uint8_t* __restrict__ bp = a.bp + (size_t)wave_slot * a.bp_stride;
@@ -73,7 +75,7 @@ __global__ void __launch_bounds__(64) np_eventalign_chain_kernel(np_ea_args a)
             else { first_event = closest_event(ms, K, ks); last_event = closest_event(ms, K, ke); }
         }
         const bool forward = first_event < last_event;
-        int curr_start_event = first_event, curr_start_ref = r_first;
+        int curr_start_event = __builtin_amdgcn_readfirstlane(first_event), curr_start_ref = __builtin_amdgcn_readfirstlane(r_first);
 
         const float lp_mm_self = rd->trans[0], lp_mb = rd->trans[1], lp_mk = rd->trans[2], lp_mm_next = rd->trans[3],
                     lp_bb = rd->trans[4], lp_bk = rd->trans[5], lp_bm_next = rd->trans[6], lp_bm_self = rd->trans[7],
@@ -90,11 +92,12 @@ __global__ void __launch_bounds__(64) np_eventalign_chain_kernel(np_ea_args a)
             const int l = r_end - curr_start_ref + 1;
             if (l < 2 * k) break;                                                          // hmm_sequence.length() < 2 * k
             if (curr_start_ref + l > ref_n || curr_end_read < 0 || curr_end_read >= K) { status = NP_EA_BAD_RECORD; break; }
-            const int e_start = curr_start_event, e_stop = closest_event(ms, K, curr_end_read);
+            // (wave-uniform by construction; readfirstlane tells the compiler, so that loop control and addresses stay scalar)
+            const int e_start = __builtin_amdgcn_readfirstlane(curr_start_event), e_stop = __builtin_amdgcn_readfirstlane(closest_event(ms, K, curr_end_read));
             const int span = e_start > e_stop ? e_start - e_stop : e_stop - e_start;
             if (span < 2) break;
             const int stride = e_start < e_stop ? 1 : -1;
-            const int e = span + 1, n = l - k + 1;
+            const int e = span + 1, n = __builtin_amdgcn_readfirstlane(l - k + 1);
             if (n > NP_EA_MAX_KMERS || e > a.rows_cap) { status = NP_EA_OVERFLOW; break; }
             n_calls++;
 
@@ -114,70 +117,105 @@ __global__ void __launch_bounds__(64) np_eventalign_chain_kernel(np_ea_args a)
                 g[c] = np_scale_state(a.model, rank, scale, shift, var, log_var);
             }
             const int lanes_used = (n + 1) >> 1;
-            const bool lane_on = lane < lanes_used;
-            float M[2] = {NP_NEG_INF, NP_NEG_INF}, B[2] = {NP_NEG_INF, NP_NEG_INF}, Kst[2] = {NP_NEG_INF, NP_NEG_INF};
-            float oM = NP_NEG_INF, oB = NP_NEG_INF, oK = NP_NEG_INF;
+            float M0 = NP_NEG_INF, M1 = NP_NEG_INF, B0 = NP_NEG_INF, B1 = NP_NEG_INF, K0 = NP_NEG_INF, K1 = NP_NEG_INF;   // row r-1 of this lane's two blocks
+            float oM = NP_NEG_INF, oB = NP_NEG_INF, oK = NP_NEG_INF;                                                      // row r-1 of the block to the left
             float end_m = NP_NEG_INF;                                  // M of the last k-mer in the last row: where the back-track starts
             const int steps = e + lanes_used - 1;
+            const float flank0 = a.flank[0];
+            const int end_lane = (n - 1) >> 1, end_c = (n - 1) & 1;
+            // The sweep is branch-free: every lane updates its two blocks at every step.  A lane that is before its first row
+            // only moves -inf around (row 0 is all -inf), one that is past its last row or owns no block computes values nobody
+            // reads; both store their back-pointers into a dump row.  Event indices are clamped into the segment.
+            float xn = ev[e_start];                                     // row 1 (lane 0 at step 1); later lanes reach it later
             for (int t = 1; t <= steps; ++t) {
-                float nM = np_wave_shr1(M[1], NP_NEG_INF), nB = np_wave_shr1(B[1], NP_NEG_INF), nK = np_wave_shr1(Kst[1], NP_NEG_INF);
-                if (lane == 0) { nM = NP_NEG_INF; nB = NP_NEG_INF; nK = NP_NEG_INF; }
+                const float nM = np_wave_shr1(M1, NP_NEG_INF), nB = np_wave_shr1(B1, NP_NEG_INF), nK = np_wave_shr1(K1, NP_NEG_INF);   // lane 0: block -1 = -inf
                 const int r = t - lane;
-                if (lane_on && r >= 1 && r <= e) {
-                    const float x = ev[e_start + (r - 1) * stride];
-                    float lM_r = nM, lB_r = nB, lK_r = nK, lM_p = oM, lB_p = oB, lK_p = oK;
-                    uint32_t packed = 0;
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const float em = np_emission(x, g[c]);
-                        vmax m; m.v = lp_mm_self + M[c]; m.from = 0;
-                        vit_step(m, lp_mm_next + lM_p, 1);
-                        vit_step(m, lp_bm_self + B[c], 2);
-                        vit_step(m, lp_bm_next + lB_p, 3);
-                        vit_step(m, lp_km + lK_p, 4);
-                        vit_step(m, (c == 0 && lane == 0 && r == 1) ? a.flank[0] : NP_NEG_INF, 5);      // HMT_FROM_SOFT: first event only (flags 0)
-                        const float newM = m.v + em;
-                        vmax mb; mb.v = lp_mb + M[c]; mb.from = 0;
-                        vit_step(mb, lp_bb + B[c], 2);
-                        const float newB = mb.v + 0.0f;
-                        vmax mk; mk.v = lp_mk + lM_r; mk.from = 1;
-                        vit_step(mk, lp_bk + lB_r, 3);
-                        vit_step(mk, lp_kk + lK_r, 4);
-                        const float newK = mk.v + 0.0f;
-                        lM_p = M[c]; lB_p = B[c]; lK_p = Kst[c];
-                        lM_r = newM; lB_r = newB; lK_r = newK;
-                        M[c] = newM; B[c] = newB; Kst[c] = newK;
-                        // only the back-pointers of finite cells are ever followed: 3 bits M, 1 bit B (0 | 2), 2 bits K (1 | 3 | 4)
-                        const uint32_t byte = m.from | ((mb.from >> 1) << 3) | ((mk.from == 1 ? 0u : mk.from == 3 ? 1u : 2u) << 4);
-                        packed |= byte << (8 * c);
-                        if (r == e && 2 * lane + c == n - 1) end_m = newM;
-                    }
-                    *(uint16_t*)(bp + (size_t)(r - 1) * NP_EA_ROW_BYTES + 2 * lane) = (uint16_t)packed;
+                const float x = xn;
+                {
+                    int rn = r;                                         // 0-based index of the next row, clamped into [0, e)
+                    rn = rn < 0 ? 0 : (rn > e - 1 ? e - 1 : rn);
+                    xn = ev[e_start + rn * stride];
+                }
+                // HMT_FROM_SOFT (flags 0: first event only, r9.inl:361-363) reaches block 0 of row 1: lane 0 at step 1
+                const float soft = (t == 1 && lane == 0) ? flank0 : NP_NEG_INF;
+                uint32_t packed;
+                {
+                    // ---- block 2*lane: left neighbour = previous lane's block (nM.. row r, oM.. row r-1) ----
+                    const float em = np_emission(x, g[0]);
+                    const float a0 = lp_mm_self + M0, a1 = lp_mm_next + oM, a2 = lp_bm_self + B0, a3 = lp_bm_next + oB, a4 = lp_km + oK;
+                    const float v = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), __builtin_fmaxf(a2, a3)), __builtin_fmaxf(a4, soft));
+                    uint32_t from = (a1 == v) ? 1u : 0u;               // the largest index whose candidate equals the maximum
+                    from = (a2 == v) ? 2u : from; from = (a3 == v) ? 3u : from; from = (a4 == v) ? 4u : from; from = (soft == v) ? 5u : from;
+                    const float newM = v + em;
+                    const float b0 = lp_mb + M0, b2 = lp_bb + B0;
+                    const float newB = __builtin_fmaxf(b0, b2) + 0.0f;
+                    const uint32_t bbit = (b2 >= b0) ? 8u : 0u;
+                    const float k1 = lp_mk + nM, k3 = lp_bk + nB, k4 = lp_kk + nK;
+                    const float kv = __builtin_fmaxf(__builtin_fmaxf(k1, k3), k4);
+                    uint32_t kbits = (k3 == kv) ? 16u : 0u; kbits = (k4 == kv) ? 32u : kbits;
+                    const float newK = kv + 0.0f;
+                    packed = from | bbit | kbits;
+                    // ---- block 2*lane + 1: left neighbour = the block just computed (row r) and its previous row ----
+                    const float em1 = np_emission(x, g[1]);
+                    const float c0 = lp_mm_self + M1, c1 = lp_mm_next + M0, c2 = lp_bm_self + B1, c3 = lp_bm_next + B0, c4 = lp_km + K0;
+                    const float w = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(c0, c1), __builtin_fmaxf(c2, c3)), c4);
+                    uint32_t from1 = (c1 == w) ? 1u : 0u;
+                    from1 = (c2 == w) ? 2u : from1; from1 = (c3 == w) ? 3u : from1; from1 = (c4 == w) ? 4u : from1;
+                    const float newM1 = w + em1;
+                    const float d0 = lp_mb + M1, d2 = lp_bb + B1;
+                    const float newB1 = __builtin_fmaxf(d0, d2) + 0.0f;
+                    const uint32_t bbit1 = (d2 >= d0) ? 8u : 0u;
+                    const float j1 = lp_mk + newM, j3 = lp_bk + newB, j4 = lp_kk + newK;
+                    const float jv = __builtin_fmaxf(__builtin_fmaxf(j1, j3), j4);
+                    uint32_t kbits1 = (j3 == jv) ? 16u : 0u; kbits1 = (j4 == jv) ? 32u : kbits1;
+                    const float newK1 = jv + 0.0f;
+                    packed |= (from1 | bbit1 | kbits1) << 8;
+                    M0 = newM; B0 = newB; K0 = newK; M1 = newM1; B1 = newB1; K1 = newK1;
                 }
                 oM = nM; oB = nB; oK = nK;
+                const bool active = (uint32_t)(r - 1) < (uint32_t)e && lane < lanes_used;
+                const int srow = active ? r - 1 : a.rows_cap;              // the dump row sits behind the last real one
+                *(uint16_t*)(bp + (size_t)srow * NP_EA_ROW_BYTES + 2 * lane) = (uint16_t)packed;
+                end_m = (r == e && lane == end_lane) ? (end_c ? M1 : M0) : end_m;
             }
-            const float start_v = __shfl(end_m, (n - 1) >> 1, 64);
+            const float start_v = __shfl(end_m, end_lane, 64);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_s_waitcnt(0);
 
-            // ---- back-track (profile_hmm_align_r9, r9.cpp:117-196) by lane 0 ----
+            // ---- back-track (profile_hmm_align_r9, r9.cpp:117-196): the wave stages NP_EA_CHUNK rows of back-pointers at a
+            // time from its scratch into LDS (one coalesced pass) and walks them there.  The walk state is wave-uniform and
+            // lives in scalar registers (every lane reads the same LDS byte, readfirstlane makes it a scalar); visited states
+            // are collected 64 at a time in a register and flushed with one coalesced store. ----
             int cnt = 0;
             if (start_v != NP_NEG_INF) {                    // assert(get(vm, row, col) != -INFINITY): no path, nothing to emit
-                if (lane == 0) {
-                    int row = e, kmer = n - 1, ps = 2;
-                    while (row > 0 && kmer >= 0) {
-                        path[cnt++] = (uint32_t)row | ((uint32_t)kmer << 16) | ((uint32_t)ps << 24);
-                        const uint32_t byte = bp[(size_t)(row - 1) * NP_EA_ROW_BYTES + kmer];
+                int row = e, kmer = n - 1, ps = 2, stop = 0;
+                uint32_t pv = 0;
+                while (row > 0 && kmer >= 0 && !stop) {
+                    const int lo = row - (NP_EA_CHUNK - 1) > 1 ? row - (NP_EA_CHUNK - 1) : 1;
+                    const int n16 = (row - lo + 1) * (NP_EA_ROW_BYTES / 16);
+                    const uint4* __restrict__ src = (const uint4*)(bp + (size_t)(lo - 1) * NP_EA_ROW_BYTES);
+                    for (int i = lane; i < n16; i += 64) ((uint4*)stage)[i] = src[i];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_s_waitcnt(0);
+                    __builtin_amdgcn_wave_barrier();
+                    const uint8_t* sb = (const uint8_t*)stage;
+                    while (row >= lo && kmer >= 0) {
+                        const uint32_t entry = (uint32_t)row | ((uint32_t)kmer << 16) | ((uint32_t)ps << 24);
+                        pv = lane == (cnt & 63) ? entry : pv;
+                        cnt++;
+                        if ((cnt & 63) == 0) path[cnt - 64 + lane] = pv;
+                        const uint32_t byte = (uint32_t)__builtin_amdgcn_readfirstlane((int)sb[(row - lo) * NP_EA_ROW_BYTES + kmer]);
                         const uint32_t mv = ps == 2 ? (byte & 7u) : ps == 1 ? ((byte >> 3) & 1u) * 2u : ((byte >> 4) == 0u ? 1u : (byte >> 4) == 1u ? 3u : 4u);
-                        if (mv == 5u) break;                // HMT_FROM_SOFT
+                        if (mv == 5u) { stop = 1; break; }          // HMT_FROM_SOFT
                         int next_ps = 2;
                         if (mv == 1u) { kmer -= 1; } else if (mv == 2u) { next_ps = 1; } else if (mv == 3u) { kmer -= 1; next_ps = 1; }
                         else if (mv == 4u) { kmer -= 1; next_ps = 0; }
-                        if (ps != 0) row -= 1;              // K states are silent (r9.cpp:176-178)
+                        if (ps != 0) row -= 1;                  // K states are silent (r9.cpp:176-178)
                         ps = next_ps;
                     }
+                    __builtin_amdgcn_wave_barrier();
                 }
-                cnt = __builtin_amdgcn_readfirstlane(cnt);
+                if ((cnt & 63) != 0 && lane < (cnt & 63)) path[(cnt & ~63) + lane] = pv;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_s_waitcnt(0);
             }
@@ -214,8 +252,8 @@ __global__ void __launch_bounds__(64) np_eventalign_chain_kernel(np_ea_args a)
                 n_out += nw; num_output += nw;
             }
             if (status != NP_EA_OK) break;
-            curr_start_event = last_event_output;
-            curr_start_ref = last_ref_kmer_output;
+            curr_start_event = __builtin_amdgcn_readfirstlane(last_event_output);
+            curr_start_ref = __builtin_amdgcn_readfirstlane(last_ref_kmer_output);
             if (num_output == 0) break;
         }
         if (lane == 0) { a.n_out[ri] = n_out < out_cap ? n_out : out_cap; a.status[ri] = status; a.n_calls[ri] = n_calls; }

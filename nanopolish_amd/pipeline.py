@@ -178,13 +178,20 @@ def tile_host_batch(hb, tile):
         ns = len(hb["raw"])
         out["raw"] = np.tile(hb["raw"], tile)
         out["raw_off"] = np.concatenate([hb["raw_off"][:-1] + t * ns for t in range(tile)] + [[ns * tile]]).astype(np.int64)
+    if "cigar" in hb:
+        nc = len(hb["cigar"])
+        out["cigar"] = np.tile(hb["cigar"], tile)
+        out["cigar_off"] = np.concatenate([hb["cigar_off"][:-1] + t * nc for t in range(tile)] + [[nc * tile]]).astype(np.int64)
+        for key in ("ref_begin", "ref_len", "read_len"):          # every copy points at the same resident contig(s)
+            out[key] = np.tile(hb[key], tile)
+        out["deg_kpos"] = np.tile(hb["deg_kpos"], (tile, 1))
     out["event_off"] = np.concatenate([hb["event_off"][:-1] + t * ne for t in range(tile)] + [[ne * tile]]).astype(np.int64)
     out["rank_off"] = np.concatenate([hb["rank_off"][:-1] + t * nr for t in range(tile)] + [[nr * tile]]).astype(np.int64)
     return out
 
 
 class CallMethylationBatch:
-    def __init__(self, ctx, hb, device="cuda:0", calibrate=False, from_raw=False, jobs_on_device=False):
+    def __init__(self, ctx, hb, device="cuda:0", calibrate=False, from_raw=False, jobs_on_device=False, workload="call-methylation"):
         """calibrate=False: kernel B scores with the scalings the caller put in hb["reads_b"] (a read whose
         calibration was done elsewhere).  calibrate=True: the pass recalibrates every read on the device from its
         own event alignment, as load_from_raw does (squiggle_read.cpp:304-323), and reads_b is overwritten."""
@@ -193,6 +200,7 @@ class CallMethylationBatch:
         self.calibrate = bool(calibrate)
         self.from_raw = bool(from_raw)
         self.jobs_on_device = bool(jobs_on_device)
+        self.workload = workload       # "eventalign": a step ends with the segment chain instead of the methylation scoring
         self.by_cigar = "cigar" in hb          # work items follow BAM CIGARs (build_host_batch_records)
         self.ctx = ctx
         self.hb = hb
@@ -253,7 +261,7 @@ class CallMethylationBatch:
             self.d_cigar = up(hb["cigar"]); self.d_cigar_off = up(hb["cigar_off"]); self.d_read_len = up(hb["read_len"])
             self.n_cigar_ops = int(hb["cigar_off"][-1])
             if not self.jobs_on_device:
-                self.d_rc = up(np.array([r["rc"] for r in hb["reads"]], np.uint8))
+                self.d_rc = up(np.array([r["rc"] for r in hb["reads"]] * (self.n_reads // len(hb["reads"])), np.uint8))
             self.d_deg = up(hb["deg_kpos"]) if not self.jobs_on_device else torch.zeros(2 * self.n_reads, dtype=torch.int32, device=dev)
         ne = (hb["event_off"][1:] - hb["event_off"][:-1]); nk = (hb["rank_off"][1:] - hb["rank_off"][:-1])
         bands = ne + nk + 2
@@ -281,7 +289,11 @@ class CallMethylationBatch:
     def step(self):
         L, h = self.ctx.L, self.ctx.h
         p = lambda t: C.c_void_p(t.data_ptr())
-        if self.jobs_on_device and self.by_cigar:
+        ea = self.workload == "eventalign"
+        n_jobs = 0 if ea else self.n_jobs
+        if ea:
+            pass
+        elif self.jobs_on_device and self.by_cigar:
             rc = L.np_cm_build_jobs_cigar_dev(h, None, self.n_reads, p(self.d_genome), p(self.d_ref_begin), p(self.d_ref_len), p(self.d_cigar),
                                               p(self.d_cigar_off), self.n_cigar_ops, p(self.d_read_len), p(self.d_rc), api.alphabet_id("cpg"),
                                               self.cm[2], self.cm[0], self.cm[1], p(self.d_group_off), self.n_slots, p(self.d_jr_off),
@@ -309,13 +321,16 @@ class CallMethylationBatch:
             rc = L.np_calibrate_resolve_dev(h, None, self.n_reads, p(self.d_reads_b), p(self.d_events), p(self.d_ranks),
                                             self.m_nuc, p(self.d_pair_off), p(self.d_pairs), p(self.d_pair_begin),
                                             p(self.d_n_pairs), p(self.d_map), p(self.d_map_stop), p(self.d_epb),
-                                            p(self.d_calibrated), self.n_jobs, p(self.d_jobs), p(self.d_kpos))
+                                            p(self.d_calibrated), n_jobs, p(self.d_jobs), p(self.d_kpos))
             self.ctx._chk(rc, "np_calibrate_resolve_dev")
         else:
             rc = L.np_resolve_jobs_dev(h, None, self.n_reads, p(self.d_reads_b), p(self.d_pair_off), p(self.d_pairs),
-                                       p(self.d_pair_begin), p(self.d_n_pairs), p(self.d_map), p(self.d_epb), self.n_jobs,
+                                       p(self.d_pair_begin), p(self.d_n_pairs), p(self.d_map), p(self.d_epb), n_jobs,
                                        p(self.d_jobs), p(self.d_kpos))
             self.ctx._chk(rc, "np_resolve_jobs_dev")
+        if ea:
+            self.eventalign_enqueue()
+            return
         if self.by_cigar:
             rc = L.np_cm_discard_degenerate_dev(h, None, p(self.d_reads_b), p(self.d_map), p(self.d_deg), self.n_jobs, p(self.d_jobs))
             self.ctx._chk(rc, "np_cm_discard_degenerate_dev")
@@ -327,6 +342,10 @@ class CallMethylationBatch:
         """align_read_to_ref for every read of the batch (np_eventalign_dev), after step(): the segment chain of
         profile_hmm_align calls under the base model.  Returns a list of dicts(ref_position (absolute, record pos added),
         event_idx, hmm_state, status, n_calls) per read.  Needs a record-based batch (build_host_batch_records)."""
+        self.eventalign_enqueue()
+        return self.eventalign_results()
+
+    def eventalign_enqueue(self):
         assert self.by_cigar, "eventalign needs BAM records (build_host_batch_records)"
         torch = self.torch
         L, h = self.ctx.L, self.ctx.h
@@ -347,6 +366,8 @@ class CallMethylationBatch:
                                  int(self.hb.get("k", 6)), p(self.d_ea_off), p(self.d_ea_ref), p(self.d_ea_event), p(self.d_ea_state),
                                  p(self.d_ea_n), p(self.d_ea_status), p(self.d_ea_calls))
         self.ctx._chk(rc, "np_eventalign_dev")
+
+    def eventalign_results(self):
         self.sync()
         n = self.d_ea_n.cpu().numpy(); st = self.d_ea_status.cpu().numpy(); nc = self.d_ea_calls.cpu().numpy()
         ref, ev, hs = self.d_ea_ref.cpu().numpy(), self.d_ea_event.cpu().numpy(), self.d_ea_state.cpu().numpy()

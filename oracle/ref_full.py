@@ -142,7 +142,23 @@ class FullRef:
                                               C.POINTER(C.c_int)]
         L.npfull_eventalign.argtypes = [C.c_void_p, C.c_int, C.c_int, _u32p, C.c_int, C.c_char_p, C.c_char_p, C.c_int, _i32p, _i32p,
                                         C.c_char_p, C.c_char_p, C.c_char_p]
+        L.npfull_many_identity.argtypes = [C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int64), _f32p, C.POINTER(C.c_int64), _u8p, C.c_double,
+                                           C.c_int, _i32p]
         self.L = L
+
+    def many_identity(self, mode, seqs, raws, rcs, n_threads=0, sample_rate=4000.0):
+        """OpenMP-over-reads timing driver (see npfull_many_identity): mode 0 eventalign, 1 call-methylation.
+        Returns (rows per read, seconds)."""
+        import time
+        seq_off = np.zeros(len(seqs) + 1, np.int64); seq_off[1:] = np.cumsum([len(q) for q in seqs])
+        raw_off = np.zeros(len(raws) + 1, np.int64); raw_off[1:] = np.cumsum([len(r) for r in raws])
+        raw = np.ascontiguousarray(np.concatenate(raws), np.float32)
+        rc = np.ascontiguousarray(np.array(rcs, np.uint8))
+        rows = np.zeros(len(seqs), np.int32)
+        t0 = time.perf_counter()
+        self.L.npfull_many_identity(int(mode), len(seqs), "".join(seqs).encode(), _p(seq_off, C.POINTER(C.c_int64)), _p(raw, _f32p),
+                                    _p(raw_off, C.POINTER(C.c_int64)), _p(rc, _u8p), float(sample_rate), int(n_threads), _p(rows, _i32p))
+        return rows, time.perf_counter() - t0
 
     def read(self, name, sequence, raw, sample_rate=4000.0):
         return FullRead(self.L, name, sequence, raw, sample_rate)

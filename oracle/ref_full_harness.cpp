@@ -22,6 +22,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <omp.h>
 #include "htslib/faidx.h"
 #include "htslib/sam.h"
 #include "nanopolish_squiggle_read.h"
@@ -251,6 +252,39 @@ int npfull_eventalign(void* h, int is_rev, int pos, const uint32_t* cigar, int n
         strncpy(model_kmer + (size_t)i * 8, out[i].model_kmer.c_str(), 7); model_kmer[(size_t)i * 8 + 7] = 0;
     }
     return n;
+}
+
+// ---- timing drivers: OpenMP over reads, like BamProcessor::parallel_run (src/common/nanopolish_bam_processor.cpp:99) ----------
+// identity-aligned reads (CIGAR = <len>M at pos 0 of their own contig); mode 0: SquiggleRead from raw + align_read_to_ref,
+// mode 1: SquiggleRead from raw + calculate_methylation_for_read.  rows_out[i] = rows / sites of read i.
+void npfull_many_identity(int mode, int n_reads, const char* seqs, const int64_t* seq_off, const float* raw, const int64_t* raw_off,
+                          const uint8_t* rc, double sample_rate, int n_threads, int32_t* rows_out)
+{
+    if(n_threads > 0) omp_set_num_threads(n_threads);
+    #pragma omp parallel for schedule(dynamic)
+    for(int i = 0; i < n_reads; ++i) {
+        std::string seq(seqs + seq_off[i], seqs + seq_off[i + 1]);
+        void* h = npfull_read_create("r", seq.c_str(), raw + raw_off[i], (size_t)(raw_off[i + 1] - raw_off[i]), sample_rate);
+        SquiggleRead* sr = (SquiggleRead*)h;
+        int rows = 0;
+        if(!sr->events[0].empty()) {
+            std::string contig = rc[i] ? gDNAAlphabet.reverse_complement(seq) : seq;
+            uint32_t cig = (uint32_t)seq.size() << 4;
+            Record r("r", rc[i], 0, &cig, 1, contig.c_str(), contig.c_str());
+            if(mode == 0) {
+                EventAlignmentParameters params;
+                params.sr = sr; params.fai = &r.fai; params.hdr = &r.hdr; params.record = &r.b; params.strand_idx = 0; params.read_idx = i;
+                rows = (int)align_read_to_ref(params).size();
+            } else {
+                OutputHandles handles; MethylationCallingResult result; MethylationCallingParameters mp;
+                mp.alphabet = get_alphabet_by_name(mp.methylation_type);
+                calculate_methylation_for_read(handles, result, *sr, mp, &r.fai, &r.hdr, &r.b, i, -1, -1);
+                rows = (int)result[&r.b].size();
+            }
+        }
+        rows_out[i] = rows;
+        npfull_read_destroy(h);
+    }
 }
 
 } // extern "C"

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2] (eventalign) on one MI355X: reads/s of the whole realignment of a batch of synthetic R9.4 reads,
+raw signal resident in HBM -> scrappie event detection -> MoM scalings -> adaptive banded event alignment -> event map +
+recalibration -> align_read_to_ref's segment chain (np_eventalign_dev), beside the reference's own code on the host cores
+(SquiggleRead from raw + align_read_to_ref, oracle/_ref/libnp_ref_full.so, one read per thread).  Prints one JSON line.
+This is a measurement tool for DESIGN.md / profiles/, not the driver's bench (bench.py keeps the call-methylation metric).
+
+    python tools/bench_eventalign.py [--pool 256] [--tile 32] [--read-len 5450] [--steps 3] [--cpu-sample 64]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pool", type=int, default=256)
+    ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--read-len", type=int, default=5450)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1: 2 per core, 0: skip)")
+    args = ap.parse_args()
+    import torch
+    from oracle import load_models
+    from nanopolish_amd import api
+    from nanopolish_amd.api import Context
+    from nanopolish_amd.pipeline import build_host_batch_records, tile_host_batch, CallMethylationBatch
+    from nanopolish_amd.synth import synth_raw
+    models = load_models()
+    ctx = Context(0)
+    ctx.register_model(models["nucleotide"], "nucleotide"); ctx.register_model(models["cpg"], "cpg")
+    recs = []
+    for rid in range(args.pool):
+        rd = synth_raw(rid, models["nucleotide"], L=args.read_len)
+        ref = api.reverse_complement("nucleotide", rd["seq"]) if rd["rc"] else rd["seq"]
+        recs.append(dict(seq=rd["seq"], raw=rd["raw"], rc=rd["rc"], pos=0, cigar=api.cigar_words([("M", len(rd["seq"]))]), contig=ref))
+    hb = build_host_batch_records(models, recs, "")
+    batch = CallMethylationBatch(ctx, tile_host_batch(hb, args.tile), "cuda:0", calibrate=True, from_raw=True, workload="eventalign")
+    for _ in range(args.warmup):
+        batch.step()
+    ctx.sync(); torch.cuda.synchronize()
+    for w in range(7):
+        ctx.kernel_time(w, reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.step()
+    ctx.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = batch.eventalign_results()
+    fam = {name: ctx.kernel_time(w)[0] / max(1, args.steps) for w, name in ((0, "event_align"), (2, "map_calibrate"), (4, "event_detect"), (5, "mom_scalings"), (6, "eventalign_chain"))}
+    rows = int(sum(len(r["event_idx"]) for r in res)); calls = int(sum(r["n_calls"] for r in res))
+    out = dict(metric="eventalign reads/sec", value=round(batch.n_reads * args.steps / dt, 1), unit="reads/s", n_gpus=1, steps=args.steps,
+               ms_per_step=round(1e3 * dt / args.steps, 3), reads_per_step=batch.n_reads, rows_per_step=rows, hmm_align_calls_per_step=calls,
+               statuses=sorted(set(r["status"] for r in res)), kernel_ms_per_step={k: round(v, 3) for k, v in fam.items()},
+               config=dict(workload="eventalign from raw signal, synthetic R9.4 reads (BASELINE.json configs[2] shape)", read_len=args.read_len,
+                           distinct_reads=args.pool, tile=args.tile))
+    # CPU: the reference itself, one read per thread (ctypes releases the GIL)
+    n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 2 * (os.cpu_count() or 1)
+    n_cpu = min(n_cpu, args.pool)
+    try:
+        from oracle.ref_full import FullRef, have_full
+        if n_cpu > 0 and have_full():
+            F = FullRef()
+            threads = os.cpu_count() or 1
+            # timing: OpenMP over reads inside the reference-backed library; parity: the rows of a few reads, one by one
+            rows_cpu, t_cpu = F.many_identity(0, [r["seq"] for r in recs[:n_cpu]], [r["raw"] for r in recs[:n_cpu]], [r["rc"] for r in recs[:n_cpu]], threads)
+            ok = all(int(rows_cpu[i]) == len(res[i]["event_idx"]) for i in range(n_cpu))
+            for i in range(min(4, n_cpu)):
+                r = recs[i]
+                fr = F.read("r%d" % i, r["seq"], r["raw"])
+                ea = fr.eventalign(r["rc"], 0, r["cigar"], r["contig"], r["contig"]) if fr.n_events else None
+                ok = ok and ((ea is None and len(res[i]["event_idx"]) == 0) or
+                             (ea is not None and np.array_equal(ea["ref_position"], res[i]["ref_position"]) and
+                              np.array_equal(ea["event_idx"], res[i]["event_idx"]) and np.array_equal(ea["hmm_state"], res[i]["hmm_state"])))
+            out["cpu_baseline"] = dict(value=round(n_cpu / t_cpu, 2), unit="reads/s", cores=threads, kind="reference",
+                                       sample="%d of the same reads: SquiggleRead from raw + align_read_to_ref, OpenMP over reads" % n_cpu,
+                                       rows_match=bool(ok))
+    except Exception as e:  # noqa: BLE001
+        out["cpu_baseline"] = dict(error=str(e))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
