@@ -3,9 +3,10 @@
 raw signal resident in HBM -> scrappie event detection -> MoM scalings -> adaptive banded event alignment -> event map +
 recalibration -> align_read_to_ref's segment chain (np_eventalign_dev), beside the reference's own code on the host cores
 (SquiggleRead from raw + align_read_to_ref, oracle/_ref/libnp_ref_full.so, one read per thread).  Prints one JSON line.
-This is a measurement tool for DESIGN.md / profiles/, not the driver's bench (bench.py keeps the call-methylation metric).
+This is a measurement tool for DESIGN.md / profiles/, not the driver's bench (bench.py keeps the call-methylation metric); it
+lives under tests/ because its CPU leg runs the oracle.
 
-    python tools/bench_eventalign.py [--pool 256] [--tile 32] [--read-len 5450] [--steps 3] [--cpu-sample 64]
+    python tests/bench_eventalign.py [--pool 256] [--tile 32] [--read-len 5450] [--steps 3] [--cpu-sample 64]
 """
 import argparse
 import json
@@ -15,7 +16,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
 sys.path.insert(0, ROOT)
 
 

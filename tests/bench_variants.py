@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[3] (variants --consensus screening) on one MI355X: profile_hmm_score calls per second over candidate
+haplotypes.  A 10 kb draft, reads of both strands covering it (event alignment on the device first), and for every screened
+position a 22-base window with the base haplotype and its single-base substitutions / insertions / deletion
+(src/nanopolish_call_variants.cpp:288-361): one forward pass per (haplotype, read), nucleotide model, PRE|POST clipping, the
+window's event bounds resolved on the device from the reads' event maps.  The early-out of Variant scoring is not applied
+(kernel benchmark).  Prints one JSON line; a sample of the scores is checked against the reference's own
+profile_hmm_score (oracle/_ref) -- which is why this tool lives under tests/.
+
+    python tests/bench_variants.py [--reads 64] [--tile 8] [--stride 2] [--steps 3] [--cpu-sample 20000]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
+sys.path.insert(0, ROOT)
+K = 6
+FLANK = 10
+
+
+def haplotypes(ref, i):
+    cs, ce = i - FLANK, i + 1 + FLANK
+    base = ref[cs:ce + 1]
+    o = i - cs
+    seqs = [base]
+    for b in "ACGT":
+        if b != ref[i]:
+            seqs.append(base[:o] + b + base[o + 1:])          # substitution
+            seqs.append(base[:o + 1] + b + base[o + 1:])      # insertion
+    if ref[i - 1] != ref[i]:
+        seqs.append(base[:o] + base[o + 1:])                  # deletion
+    return cs, ce, seqs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--draft", type=int, default=10000)
+    ap.add_argument("--reads", type=int, default=64, help="distinct reads covering the draft")
+    ap.add_argument("--tile", type=int, default=8, help="independent copies of the read set in HBM")
+    ap.add_argument("--stride", type=int, default=2, help="screen every stride-th draft position")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-sample", type=int, default=20000, help="work items for the CPU baseline / parity check (0: skip)")
+    args = ap.parse_args()
+    import torch
+    from oracle import load_models
+    from nanopolish_amd import api, lib as _l
+    from nanopolish_amd.api import Context
+    from nanopolish_amd.pipeline import READ_DT, JOB_DT, HAF
+    from nanopolish_amd.synth import synth_read_from_codes, BASES
+    models = load_models()
+    nuc = models["nucleotide"]
+    ctx = Context(0)
+    m_nuc = ctx.register_model(nuc, "nucleotide")
+    L_ = ctx.L
+    rng = np.random.default_rng(4)
+    ref_codes = rng.integers(0, 4, args.draft)
+    ref = BASES[ref_codes].tobytes().decode()
+    reads = [synth_read_from_codes(ref_codes, rid, nuc, rc=bool(rid & 1)) for rid in range(args.reads)]
+    n = len(reads)
+    event_off = np.zeros(n + 1, np.int64); rank_off = np.zeros(n + 1, np.int64)
+    event_off[1:] = np.cumsum([len(r["events"]) for r in reads]); rank_off[1:] = np.cumsum([len(r["ranks"]) for r in reads])
+    reads_a = np.zeros(n, READ_DT); reads_b = np.zeros(n, READ_DT)
+    for i, r in enumerate(reads):
+        sh, sc = api.estimate_scalings_using_mom(nuc, r["ranks"], r["events"])
+        for arr, (shift, scale, var) in ((reads_a, (sh, sc, 1.0)), (reads_b, (r["shift"], r["scale"], r["var"]))):
+            L_.np_fill_read_host(C.cast(arr[i:i + 1].ctypes.data, C.POINTER(_l.ReadDev)), shift, scale, var, int(event_off[i]),
+                                 len(r["events"]), int(rank_off[i]), len(r["ranks"]))
+    # work items: (position, haplotype) x read; k-mer ranks per strand are shared by all reads of that strand
+    Ld = args.draft
+    positions = list(range(40, Ld - 40, args.stride))
+    ranks_fwd, ranks_rc, off, ends = [], [], [0], []
+    seq_list = []
+    for i in positions:
+        cs, ce, seqs = haplotypes(ref, i)
+        for q in seqs:
+            ranks_fwd.append(api.sequence_kmer_ranks("nucleotide", q, None, K, False))
+            ranks_rc.append(api.sequence_kmer_ranks("nucleotide", q, None, K, True))
+            off.append(off[-1] + len(ranks_fwd[-1])); ends.append((cs, ce)); seq_list.append(q)
+    n_seq = len(ends)
+    off = np.array(off, np.int64); tot = int(off[-1])
+    job_ranks = np.concatenate(ranks_fwd + ranks_rc).astype(np.uint16)          # [forward | reverse-complement]
+    ends = np.array(ends, np.int64)
+    nk = (off[1:] - off[:-1]).astype(np.uint32)
+    jobs = np.zeros(n_seq * n, JOB_DT)
+    kpos = np.zeros((n_seq * n, 2), np.int32)
+    for ri, r in enumerate(reads):
+        sl = slice(ri * n_seq, (ri + 1) * n_seq)
+        jobs["rank_off"][sl] = off[:-1] + (tot if r["rc"] else 0)
+        jobs["n_kmers"][sl] = nk; jobs["read"][sl] = ri; jobs["flags"][sl] = HAF; jobs["stride"][sl] = 1
+        # read-strand k-mer positions of the window ends (identity alignment; flip_k_strand for reverse-strand reads)
+        kpos[sl, 0] = (Ld - ends[:, 0] - K) if r["rc"] else ends[:, 0]
+        kpos[sl, 1] = (Ld - ends[:, 1] - K) if r["rc"] else ends[:, 1]
+    # tile the read set
+    T = args.tile
+    ne, nr = int(event_off[-1]), int(rank_off[-1])
+    events = np.tile(np.concatenate([r["events"] for r in reads]).astype(np.float32), T)
+    ranks = np.tile(np.concatenate([r["ranks"] for r in reads]).astype(np.uint16), T)
+    ra = np.tile(reads_a, T); rb = np.tile(reads_b, T)
+    for a in (ra, rb):
+        a["event_off"] += np.repeat(np.arange(T, dtype=np.int64) * ne, n); a["rank_off"] += np.repeat(np.arange(T, dtype=np.int64) * nr, n)
+    jt = np.tile(jobs, T); jt["read"] += np.repeat(np.arange(T, dtype=np.uint32) * n, len(jobs)).astype(np.uint32)
+    kt = np.tile(kpos, (T, 1))
+    N, NJ = n * T, len(jt)
+    dev = torch.device("cuda:0")
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+    d_events, d_ranks, d_ra, d_rb, d_jobs, d_kpos, d_jr = up(events), up(ranks), up(ra), up(rb), up(jt), up(kt), up(job_ranks)
+    bands = np.tile((event_off[1:] - event_off[:-1]) + (rank_off[1:] - rank_off[:-1]) + 2, T)
+    pair_off = np.zeros(N + 1, np.int64); pair_off[1:] = np.cumsum(bands)
+    d_pair_off = up(pair_off)
+    d_pairs = torch.empty(int(pair_off[-1]) * 8, dtype=torch.uint8, device=dev)
+    d_pb = torch.zeros(N, dtype=torch.int32, device=dev); d_np = torch.zeros(N, dtype=torch.int32, device=dev)
+    d_map = torch.empty(len(ranks), dtype=torch.int32, device=dev); d_epb = torch.zeros(N, dtype=torch.float64, device=dev)
+    d_scores = torch.zeros(NJ, dtype=torch.float32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    h = ctx.h
+    # once: event alignment + event map + window bounds (the reads' AlignmentDB in the reference)
+    ctx._chk(L_.np_event_align_dev(h, None, N, p(d_ra), p(d_events), p(d_ranks), m_nuc, int(bands.max()), p(d_pair_off), p(d_pairs), p(d_pb), p(d_np)), "align")
+    ctx._chk(L_.np_resolve_jobs_dev(h, None, N, p(d_rb), p(d_pair_off), p(d_pairs), p(d_pb), p(d_np), p(d_map), p(d_epb), NJ, p(d_jobs), p(d_kpos)), "resolve")
+
+    def step():
+        ctx._chk(L_.np_hmm_score_dev(h, None, NJ, p(d_jobs), p(d_rb), p(d_events), p(d_jr), m_nuc, p(d_scores)), "score")
+    for _ in range(args.warmup):
+        step()
+    ctx.sync(); torch.cuda.synchronize()
+    ctx.kernel_time(1, reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    sc = d_scores.cpu().numpy()
+    jh = d_jobs.cpu().numpy().view(JOB_DT)
+    scored = int(np.sum((jh["flags"] & 0x80000000) == 0))
+    out = dict(metric="variants screening profile_hmm_score calls/sec", value=round(scored * args.steps / dt, 1), unit="calls/s", n_gpus=1,
+               steps=args.steps, ms_per_step=round(1e3 * dt / args.steps, 3), calls_per_step=scored, items_per_step=NJ,
+               hmm_kernel_ms_per_step=round(ctx.kernel_time(1)[0] / args.steps, 3),
+               config=dict(workload="variants --consensus screening shape (BASELINE.json configs[3]): 22-base windows, base + single-base edits",
+                           draft=Ld, reads=N, distinct_reads=n, positions=len(positions), haplotypes=n_seq, indel_bias=1.0))
+    if args.cpu_sample > 0:
+        try:
+            from oracle import RefOracle, Oracle, have_ref
+            pick = np.flatnonzero((jh["flags"][:len(jobs)] & 0x80000000) == 0)
+            pick = pick[np.linspace(0, len(pick) - 1, min(args.cpu_sample, len(pick))).astype(np.int64)]
+            epb = d_epb.cpu().numpy()
+            threads = os.cpu_count() or 1
+            order = np.argsort(jh["read"][pick], kind="stable"); pick = pick[order]
+            rd_of = jh["read"][pick].astype(np.int64)
+            job_off = np.searchsorted(rd_of, np.arange(n + 1))
+            seqs = [seq_list[j % n_seq] for j in pick]
+            rcs = [api.reverse_complement("nucleotide", q) for q in seqs]
+            if have_ref():
+                refo = RefOracle()
+                got = refo.score_many_reads("nucleotide", events[:ne], event_off, [r["shift"] for r in reads], [r["scale"] for r in reads],
+                                            [r["var"] for r in reads], epb[:n], job_off, seqs, rcs, jh["e_start"][pick], jh["e_stop"][pick],
+                                            jh["stride"][pick], [int(reads[i]["rc"]) for i in rd_of], 3, threads)
+                t_cpu = refo.last_call_s
+                out["cpu_baseline"] = dict(value=round(len(pick) / t_cpu, 1), unit="calls/s", cores=threads, kind="reference",
+                                           sample="%d of the same work items, OpenMP over reads" % len(pick),
+                                           max_abs_diff=float(np.max(np.abs(got.astype(np.float64) - sc[pick].astype(np.float64)))))
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = dict(error=repr(e))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
