@@ -121,6 +121,17 @@ class FullRead:
                     ref_kmer=ks(rk), model_kmer=ks(mk))
 
 
+    def eventalign_tsv(self, is_rev, pos, cigar, bam_seq, contig_seq, read_idx=0):
+        """align_read_to_ref printed by the reference's emit_event_alignment_tsv (default options)"""
+        cig = np.ascontiguousarray(cigar, np.uint32)
+        cap = 160 * (4 * max(self.n_events, 1) + 64)
+        buf = C.create_string_buffer(cap)
+        n = self.L.npfull_eventalign_tsv(self.h, int(is_rev), int(pos), _p(cig, _u32p), len(cig), bam_seq.encode(), contig_seq.encode(),
+                                         int(read_idx), buf, cap)
+        assert n < cap
+        return buf.value.decode()
+
+
 class FullRef:
     def __init__(self):
         if not have_full():
@@ -142,6 +153,7 @@ class FullRef:
                                               C.POINTER(C.c_int)]
         L.npfull_eventalign.argtypes = [C.c_void_p, C.c_int, C.c_int, _u32p, C.c_int, C.c_char_p, C.c_char_p, C.c_int, _i32p, _i32p,
                                         C.c_char_p, C.c_char_p, C.c_char_p]
+        L.npfull_eventalign_tsv.argtypes = [C.c_void_p, C.c_int, C.c_int, _u32p, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
         L.npfull_many_identity.argtypes = [C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int64), _f32p, C.POINTER(C.c_int64), _u8p, C.c_double,
                                            C.c_int, _i32p]
         self.L = L

@@ -254,6 +254,26 @@ int npfull_eventalign(void* h, int is_rev, int pos, const uint32_t* cigar, int n
     return n;
 }
 
+// the same call, printed by the reference's own emit_event_alignment_tsv (eventalign.cpp:398-487, default options: read index,
+// model scaled to the read, no signal index / samples); returns the text length (the text is truncated to cap - 1)
+int npfull_eventalign_tsv(void* h, int is_rev, int pos, const uint32_t* cigar, int n_cigar, const char* seq, const char* contig_seq,
+                          int read_idx, char* out, int cap)
+{
+    SquiggleRead* sr = (SquiggleRead*)h;
+    Record r(sr->read_name.c_str(), is_rev, pos, cigar, n_cigar, seq, contig_seq);
+    EventAlignmentParameters params;
+    params.sr = sr; params.fai = &r.fai; params.hdr = &r.hdr; params.record = &r.b; params.strand_idx = 0; params.read_idx = read_idx;
+    std::vector<EventAlignment> al = align_read_to_ref(params);
+    char* buf = NULL; size_t len = 0;
+    FILE* fp = open_memstream(&buf, &len);
+    emit_event_alignment_tsv(fp, *sr, 0, params, al);
+    fclose(fp);
+    const int n = (int)len;
+    if(cap > 0) { const int m = n < cap - 1 ? n : cap - 1; memcpy(out, buf, m); out[m] = 0; }
+    free(buf);
+    return n;
+}
+
 // ---- timing drivers: OpenMP over reads, like BamProcessor::parallel_run (src/common/nanopolish_bam_processor.cpp:99) ----------
 // identity-aligned reads (CIGAR = <len>M at pos 0 of their own contig); mode 0: SquiggleRead from raw + align_read_to_ref,
 // mode 1: SquiggleRead from raw + calculate_methylation_for_read.  rows_out[i] = rows / sites of read i.

@@ -13,6 +13,7 @@ so the GPU box needs neither /root/reference nor numpy's RNG to reproduce them.
 """
 import os
 import sys
+import zlib
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -72,6 +73,9 @@ def main():
         ea = fr.eventalign(rd["rc"], rd["pos"], cig, rd["bam_seq"], contig) if fr.n_events else \
             dict(ref_position=np.zeros(0, np.int32), event_idx=np.zeros(0, np.int32), hmm_state=np.zeros(0, np.uint8))
         out[p + "ea_ref_position"] = ea["ref_position"]; out[p + "ea_event_idx"] = ea["event_idx"]; out[p + "ea_hmm_state"] = ea["hmm_state"]
+        # ... and as emit_event_alignment_tsv prints it (read index = i); zlib keeps the fixture small
+        tsv = fr.eventalign_tsv(rd["rc"], rd["pos"], cig, rd["bam_seq"], contig, i) if fr.n_events else ""
+        out[p + "ea_tsv_z"] = np.frombuffer(zlib.compress(tsv.encode(), 9), np.uint8)
         print("read %d rc=%d pos=%d cigar_ops=%d events=%d sites=%d var=%.3f" % (i, rd["rc"], rd["pos"], len(cig), fr.n_events,
                                                                                  len(res["start"]), fr.var))
     # eventalign: two identity-aligned reads (forward and reverse strand), align_read_to_ref's emitted rows

@@ -186,4 +186,20 @@ def test_eventalign_chain_on_device_matches_align_read_to_ref(ctx, models, gold)
         assert np.array_equal(g["ref_position"], gold[p + "ea_ref_position"]) and np.array_equal(g["event_idx"], gold[p + "ea_event_idx"]), i
         assert np.array_equal(g["hmm_state"], gold[p + "ea_hmm_state"])
         rows += len(g["event_idx"])
+        # ... and printed from what the device holds (detected events, calibrated scalings): the reference's TSV, byte for byte
+        import zlib
+        from nanopolish_amd.eventalign import format_eventalign_tsv
+        want_tsv = zlib.decompress(bytes(gold[p + "ea_tsv_z"])).decode()
+        if len(g["event_idx"]):
+            ne, _, length, mean, stdv = batch.detected(i)
+            r = batch.reads_scored()[i]
+            rec = recs[i]
+            contig = _s(gold["contig"])
+            span = int(sum(int(w) >> 4 for w in rec["cigar"] if (int(w) & 0xf) in (0, 2, 7, 8)))
+            seg = contig[rec["pos"]:min(rec["pos"] + span + 1, len(contig))]
+            got_tsv = format_eventalign_tsv(g, "contig", seg, rec["pos"], i, rec["rc"], mean, stdv, length, 4000.0, models["nucleotide"],
+                                            r["shift"], r["scale"], r["var"])
+            assert "".join(got_tsv) == want_tsv
+        else:
+            assert want_tsv == ""
     assert rows > 8000
