@@ -142,6 +142,8 @@ def cm_build_jobs_cigar(ref_seq, cigar, read_len, read_rc, k=6, alphabet="cpg", 
                                                   _p(f, _l.c_i32p), _p(l, _l.c_i32p), _p(c, _l.c_i32p), _p(kpos, _l.c_i32p),
                                                   _p(nk, _l.c_i32p), _p(ru, _l.c_u16p), _p(rm, _l.c_u16p), _p(ro, _l.c_i64p),
                                                   _p(deg, _l.c_i32p))
+    if nj == -1:                      # NP_ERR_INVALID: a spliced / padded CIGAR, which the reference rejects (exit / assert)
+        raise ValueError("np_cm_build_jobs_cigar: spliced or malformed CIGAR")
     if nj < 0:
         raise RuntimeError("np_cm_build_jobs_cigar: %d" % nj)
     w = int(ro[nj])

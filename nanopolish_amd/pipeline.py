@@ -126,7 +126,12 @@ def build_host_batch_records(models, records, contig, k=6):
         endpos = r["pos"] + (span if span > 0 else 1)
         seg = r["contig"][r["pos"]:min(endpos + 1, len(r["contig"]))]
         ref_seqs.append(seg); ref_begin[i] = contig_base[r["contig"]] + r["pos"]; ref_len[i] = len(seg)
-        jb = api.cm_build_jobs_cigar(seg, r["cigar"], len(r["seq"]), r["rc"], k)
+        try:
+            jb = api.cm_build_jobs_cigar(seg, r["cigar"], len(r["seq"]), r["rc"], k)
+        except ValueError:            # a record the reference refuses (spliced / padded CIGAR): no work items, as on the device
+            z = np.zeros(0, np.int32)
+            jb = dict(first=z, last=z, n_motif=z, kpos=np.zeros((0, 2), np.int32), n_kmers=z, ranks_unmeth=np.zeros(0, np.uint16),
+                      ranks_meth=np.zeros(0, np.uint16), rank_off=np.zeros(1, np.int64), deg_kpos=np.array([-1, -1], np.int32))
         deg[i] = jb["deg_kpos"]
         ng = len(jb["first"])
         j = np.zeros(2 * ng, JOB_DT)

@@ -203,3 +203,32 @@ def test_eventalign_chain_on_device_matches_align_read_to_ref(ctx, models, gold)
         else:
             assert want_tsv == ""
     assert rows > 8000
+
+
+def test_eventalign_chain_edge_cases(ctx, models, gold):
+    """scratch too small for a segment (status NP_EA_OVERFLOW, what was emitted before is a prefix of the full result),
+    a spliced record and a record whose CIGAR has no aligned base (no rows), an empty batch"""
+    import ctypes as C
+    recs, _ = _records(gold)
+    good = recs[0]
+    spliced = dict(good, cigar=api.cigar_words([("M", 300), ("N", 40), ("M", 300)]))
+    clipped = dict(good, cigar=api.cigar_words([("S", len(good["seq"]))]))
+    hb = build_host_batch_records(models, [good, spliced, clipped], _s(gold["contig"]))
+    batch = CallMethylationBatch(ctx, hb, "cuda:0", calibrate=True, from_raw=True, workload="eventalign")
+    batch.step()
+    full = batch.eventalign_results()
+    assert full[0]["status"] == 0 and np.array_equal(full[0]["event_idx"], gold["r0_ea_event_idx"])
+    assert len(full[1]["event_idx"]) == 0 and len(full[2]["event_idx"]) == 0
+    ctx._chk(ctx.L.np_set_option(ctx.h, b"ea_rows_cap", 100), "np_set_option")          # a ~165-row segment no longer fits
+    try:
+        batch.step()
+        part = batch.eventalign_results()
+    finally:
+        ctx._chk(ctx.L.np_set_option(ctx.h, b"ea_rows_cap", 4096), "np_set_option")
+    assert part[0]["status"] == 1
+    m = len(part[0]["event_idx"])
+    assert m < len(full[0]["event_idx"]) and np.array_equal(part[0]["event_idx"], full[0]["event_idx"][:m])
+    # empty batch
+    rc = ctx.L.np_eventalign_dev(ctx.h, None, 0, None, None, None, None, None, None, ctx.models["nucleotide"], None, None, None, None, None, 0,
+                                 None, None, 6, None, None, None, None, None, None, None)
+    assert rc == 0
