@@ -88,7 +88,7 @@ def build_host_batch(models, read_ids, L=5450, k=6, raw=False):
                 job_off=np.concatenate([[0], np.cumsum([len(j) for j in jobs])]).astype(np.int64), meta=meta)
 
 
-def build_host_batch_records(models, records, contig, k=6):
+def build_host_batch_records(models, records, contig, k=6, alphabet="cpg"):
     """Host-side preparation of a batch of reads given EXPLICITLY, each with its raw signal and the BAM record of its
     base-to-reference alignment: records = dicts(seq: the read's own sequence, raw: float32 samples, rc: bam_is_rev,
     pos: 0-based leftmost reference position, cigar: uint32 BAM words[, contig: this record's own reference]).  contig: the
@@ -127,7 +127,7 @@ def build_host_batch_records(models, records, contig, k=6):
         seg = r["contig"][r["pos"]:min(endpos + 1, len(r["contig"]))]
         ref_seqs.append(seg); ref_begin[i] = contig_base[r["contig"]] + r["pos"]; ref_len[i] = len(seg)
         try:
-            jb = api.cm_build_jobs_cigar(seg, r["cigar"], len(r["seq"]), r["rc"], k)
+            jb = api.cm_build_jobs_cigar(seg, r["cigar"], len(r["seq"]), r["rc"], k, alphabet)
         except ValueError:            # a record the reference refuses (spliced / padded CIGAR): no work items, as on the device
             z = np.zeros(0, np.int32)
             jb = dict(first=z, last=z, n_motif=z, kpos=np.zeros((0, 2), np.int32), n_kmers=z, ranks_unmeth=np.zeros(0, np.uint16),
@@ -157,7 +157,7 @@ def build_host_batch_records(models, records, contig, k=6):
                 job_off=np.concatenate([[0], np.cumsum([len(j) for j in jobs])]).astype(np.int64), meta=meta,
                 genome=np.frombuffer("".join(contigs).encode(), np.uint8).copy(), ref_begin=ref_begin, ref_len=ref_len,
                 cigar=np.concatenate([r["cigar"] for r in reads]).astype(np.uint32), cigar_off=cigar_off,
-                read_len=np.array([len(r["seq"]) for r in reads], np.int32), deg_kpos=deg)
+                read_len=np.array([len(r["seq"]) for r in reads], np.int32), deg_kpos=deg, alphabet=alphabet)
 
 
 def tile_host_batch(hb, tile):
@@ -282,7 +282,8 @@ class CallMethylationBatch:
         self.d_map_stop = torch.empty(len(hb["ranks"]) if self.calibrate else 1, dtype=torch.int32, device=dev)
         self.d_calibrated = torch.ones(self.n_reads, dtype=torch.int32, device=dev)
         self.d_scores = torch.zeros(max(self.n_jobs, 1), dtype=torch.float32, device=dev)
-        self.m_nuc = ctx.models["nucleotide"]; self.m_cpg = ctx.models["cpg"]
+        self.alphabet = hb.get("alphabet", "cpg")      # the methylation alphabet whose model scores the work items
+        self.m_nuc = ctx.models["nucleotide"]; self.m_cpg = ctx.models[self.alphabet]
         torch.cuda.synchronize()
         # algorithmic bytes of one pass: kernel A 4E + 2K + 100(E+K+2) + 8E per read,
         # kernel B 4e + 2n + 12n + 4 per call (e, n of every work item are only known after the pass; use the
@@ -300,7 +301,7 @@ class CallMethylationBatch:
             pass
         elif self.jobs_on_device and self.by_cigar:
             rc = L.np_cm_build_jobs_cigar_dev(h, None, self.n_reads, p(self.d_genome), p(self.d_ref_begin), p(self.d_ref_len), p(self.d_cigar),
-                                              p(self.d_cigar_off), self.n_cigar_ops, p(self.d_read_len), p(self.d_rc), api.alphabet_id("cpg"),
+                                              p(self.d_cigar_off), self.n_cigar_ops, p(self.d_read_len), p(self.d_rc), api.alphabet_id(self.alphabet),
                                               self.cm[2], self.cm[0], self.cm[1], p(self.d_group_off), self.n_slots, p(self.d_jr_off),
                                               p(self.d_jobs), p(self.d_kpos), p(self.d_job_ranks), p(self.d_first), p(self.d_last),
                                               p(self.d_n_motif), p(self.d_n_groups), p(self.d_deg))

@@ -76,6 +76,11 @@ def main():
         # ... and as emit_event_alignment_tsv prints it (read index = i); zlib keeps the fixture small
         tsv = fr.eventalign_tsv(rd["rc"], rd["pos"], cig, rd["bam_seq"], contig, i) if fr.n_events else ""
         out[p + "ea_tsv_z"] = np.frombuffer(zlib.compress(tsv.encode(), 9), np.uint8)
+        if i < 2:
+            # the same records under --methylation gpc (GC -> GM sites, r9.4_450bps gpc model)
+            gp = fr.call_methylation(rd["rc"], rd["pos"], cig, rd["bam_seq"], contig, methylation_type="gpc", modbam=False)
+            out[p + "gpc_start"] = gp["start"]; out[p + "gpc_n_motif"] = gp["n_motif"]
+            out[p + "gpc_ll_unmeth"] = gp["ll_unmeth"]; out[p + "gpc_ll_meth"] = gp["ll_meth"]
         print("read %d rc=%d pos=%d cigar_ops=%d events=%d sites=%d var=%.3f" % (i, rd["rc"], rd["pos"], len(cig), fr.n_events,
                                                                                  len(res["start"]), fr.var))
     # eventalign: two identity-aligned reads (forward and reverse strand), align_read_to_ref's emitted rows
@@ -94,6 +99,10 @@ def main():
         out[p + "ref_position"] = res["ref_position"]; out[p + "event_idx"] = res["event_idx"]; out[p + "hmm_state"] = res["hmm_state"]
         out[p + "model_kmer"] = np.array(res["model_kmer"], dtype="S8")
         print("eventalign read %d rc=%d rows=%d" % (rid, rd["rc"], len(res["event_idx"])))
+    # the gpc pore model as the reference loads it (fixture for the gpc parity tests)
+    from oracle import RefOracle
+    gm = RefOracle().model("gpc")
+    np.savez_compressed(os.path.join(GOLD, "models_r9.4_450bps_gpc.npz"), **{f: gm[f] for f in ("level_mean", "level_stdv", "level_log_stdv")})
     path = os.path.join(GOLD, "golden_reflevel.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -232,3 +232,27 @@ def test_eventalign_chain_edge_cases(ctx, models, gold):
     rc = ctx.L.np_eventalign_dev(ctx.h, None, 0, None, None, None, None, None, None, ctx.models["nucleotide"], None, None, None, None, None, 0,
                                  None, None, 6, None, None, None, None, None, None, None)
     assert rc == 0
+
+
+def test_gpc_chain_on_device_matches_reference(ctx, models, gold):
+    """the whole chain under --methylation gpc (device work items for GC sites, gpc model) vs the reference's own output"""
+    z = np.load(os.path.join(os.path.dirname(GOLD), "models_r9.4_450bps_gpc.npz"))
+    if "gpc" not in ctx.models:
+        ctx.register_model(dict(k=6, level_mean=z["level_mean"], level_stdv=z["level_stdv"], level_log_stdv=z["level_log_stdv"]), "gpc")
+    recs, _ = _records(gold)
+    recs = recs[:2]
+    hb = build_host_batch_records(models, recs, _s(gold["contig"]), alphabet="gpc")
+    for on_dev in (False, True):
+        batch = CallMethylationBatch(ctx, hb, "cuda:0", calibrate=True, from_raw=True, jobs_on_device=on_dev)
+        batch.step()
+        for i, rec in enumerate(recs):
+            want = {int(s): (float(u), float(m)) for s, u, m in zip(gold["r%d_gpc_start" % i], gold["r%d_gpc_ll_unmeth" % i], gold["r%d_gpc_ll_meth" % i])}
+            if on_dev:
+                first, nm, u, m = batch.groups_of(i)
+                got = {int(f) + rec["pos"]: (float(a), float(b)) for f, a, b in zip(first, u, m) if a == a}
+            else:
+                sc, jobs = batch.scores(), batch.jobs_host()
+                lo = int(hb["job_off"][i])
+                got = {int(f) + rec["pos"]: (float(sc[lo + 2 * g]), float(sc[lo + 2 * g + 1])) for g, f in enumerate(hb["meta"][i]["first"])
+                       if not (jobs[lo + 2 * g]["flags"] & 0x80000000)}
+            assert got == want and len(got) > 30, (on_dev, i)
