@@ -114,3 +114,32 @@ def test_argument_errors(ctx, models):
     with pytest.raises(RuntimeError):
         ctx.profile_hmm_score([dict(base, model=99)])
     assert np.isfinite(ctx.profile_hmm_score([base])[0])                  # the context survives the errors
+
+
+def test_host_entry_points_are_thread_safe(ctx, orc, models):
+    """the reference calls profile_hmm_score / adaptive_banded_simple_event_align concurrently from its OpenMP workers
+    (bam_processor.cpp:99); the single-call entry points of one context must give the serial answers from 8 threads at once"""
+    from concurrent.futures import ThreadPoolExecutor
+    from cases import synth_read, methylation_jobs, K
+    from nanopolish_amd import api
+    mn = orc.model(models["nucleotide"])
+    work = []
+    for rid in range(8):
+        rd = synth_read(700 + rid, models["nucleotide"], L=900)
+        sh, sc = orc.estimate_scalings_mom(mn, rd["ranks"], rd["events"])
+        pairs = orc.event_align(mn, orc.scalings(sh, sc, 1.0), rd["events"], rd["ranks"])
+        epb, jobs = methylation_jobs(orc, rd, pairs)
+        hj = [dict(events=rd["events"], ranks=api.sequence_kmer_ranks("cpg", j["subseq"], j["rc_subseq"], K, j["rc"]), e_start=j["e1"],
+                   e_stop=j["e2"], stride=j["stride"], model=ctx.models["cpg"], scale=rd["scale"], shift=rd["shift"], var=rd["var"],
+                   events_per_base=epb, flags=3) for j in jobs]
+        aj = dict(events=rd["events"], ranks=rd["ranks"], model=ctx.models["nucleotide"], scale=sc, shift=sh, var=1.0)
+        work.append((hj, aj))
+    serial = [(ctx.profile_hmm_score(hj), ctx.adaptive_banded_simple_event_align([aj])[0]) for hj, aj in work]
+
+    def one(i):
+        hj, aj = work[i % len(work)]
+        return ctx.profile_hmm_score(hj), ctx.adaptive_banded_simple_event_align([aj])[0]
+    with ThreadPoolExecutor(8) as ex:
+        par = list(ex.map(one, range(32)))
+    for i, (s, p) in enumerate(par):
+        assert np.array_equal(s, serial[i % len(work)][0]) and np.array_equal(p, serial[i % len(work)][1])
