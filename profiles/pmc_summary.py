@@ -4,8 +4,10 @@
     pmc_summary.py gpurun_out reads_per_launch bands_per_read > profiles/rNN_pmc.json
 
 Sums every counter per kernel over the launches of the run and reports per-launch / per-read figures for the three
-hot kernels.  FETCH_SIZE / WRITE_SIZE are reported as rocprofv3 gives them (KB -> x1024 bytes) with no further
-correction: the loads of these kernels are narrow (4 B per lane), the x2 of the guide applies to 16 B/lane streams.
+hot kernels.  FETCH_SIZE / WRITE_SIZE: KB -> x1024 bytes, then the gfx950 corrections measured on known byte counts in this
+kernel's own access widths (tools/hbm_counter_calib.hip, profiles/collect_counter_calib.sh: 1 GiB streamed once per kernel):
+FETCH_SIZE reports exactly 1/2 of the bytes of coalesced 4 B/lane AND 16 B/lane reads -> x2 (the guide's figure for wide reads
+holds for narrow ones too); WRITE_SIZE is exact for coalesced 4 B/lane and 8 B/lane stores -> x1.
 """
 import csv
 import glob
@@ -14,6 +16,7 @@ import sys
 from collections import defaultdict
 
 root, reads, bands = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
+FETCH_CORR, WRITE_CORR = 2.0, 1.0      # measured, see the docstring
 tot = defaultdict(lambda: defaultdict(float))
 launches = defaultdict(set)
 dur = defaultdict(float)
@@ -33,7 +36,8 @@ for key, c in tot.items():
     if key == "event_align":
         per_read = lambda x: c.get(x, 0.0) / n / reads
         d.update(reads_per_launch=reads,
-                 fetch_bytes_per_read=per_read("FETCH_SIZE") * 1024, write_bytes_per_read=per_read("WRITE_SIZE") * 1024,
+                 fetch_bytes_per_read=per_read("FETCH_SIZE") * 1024 * FETCH_CORR, write_bytes_per_read=per_read("WRITE_SIZE") * 1024 * WRITE_CORR,
+                 fetch_size_correction=FETCH_CORR, write_size_correction=WRITE_CORR,
                  valu_insts_per_read=per_read("SQ_INSTS_VALU"), salu_insts_per_read=per_read("SQ_INSTS_SALU"),
                  vmem_rd_per_read=per_read("SQ_INSTS_VMEM_RD"), vmem_wr_per_read=per_read("SQ_INSTS_VMEM_WR"),
                  valu_insts_per_band=per_read("SQ_INSTS_VALU") / bands, salu_insts_per_band=per_read("SQ_INSTS_SALU") / bands)
@@ -42,7 +46,7 @@ for key, c in tot.items():
     if "SQ_WAVE_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
         d["mean_waves_in_flight_per_busy_cycle"] = c["SQ_WAVE_CYCLES"] / c["SQ_BUSY_CYCLES"]
     out[key] = d
-out["note"] = ("FETCH_SIZE/WRITE_SIZE: rocprofv3 KB x1024, uncorrected (narrow dword loads); counters are summed over all "
-               "XCDs/SEs as rocprofv3 reports them")
+out["note"] = ("FETCH_SIZE/WRITE_SIZE per launch: raw rocprofv3 KB; *_bytes_per_read: x1024 and corrected (FETCH x2, WRITE x1, "
+               "calibrated with tools/hbm_counter_calib.hip); counters are summed over all XCDs/SEs as rocprofv3 reports them")
 json.dump(out, sys.stdout, indent=1)
 print()
