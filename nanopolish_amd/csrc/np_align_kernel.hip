@@ -75,19 +75,6 @@ __device__ __forceinline__ np_gauss as_gauss(const float4 v)
     return g;
 }
 
-// Range-checked loads through buffer descriptors: an offset outside [0, bytes) -- negative included, it wraps to a
-// huge unsigned -- returns 0 instead of faulting, so neither the event-mean prefetch nor the parameter refill needs
-// a clamp.  Whatever an out-of-range load returns only ever feeds a masked cell.
-// (the operands go through readfirstlane: they are wave-uniform but may sit in VGPRs, and a descriptor the compiler
-//  cannot prove scalar costs a waterfall loop per load)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes)
-{
-    const uint64_t u = (uint64_t)p;
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
-    void* q = (void*)(((uint64_t)hi << 32) | lo);
-    return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
-}
 __device__ __forceinline__ double uniform_f64(double v)
 {
     const uint64_t u = __builtin_bit_cast(uint64_t, v);
@@ -102,19 +89,6 @@ template <class T> __device__ __forceinline__ T* uniform_ptr(T* p)
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
     return (T*)(((uint64_t)hi << 32) | lo);
 }
-// The byte offset goes to the instruction as ONE register: the compiler would otherwise split `x + c` into a register
-// part and the instruction's immediate offset, and the hardware range-checks their sum without 32-bit wrap-around --
-// a negative register part with a positive immediate (true offset in range) would then read as 0.
-__device__ __forceinline__ int whole_offset(int off) { asm("" : "+v"(off)); return off; }
-__device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, int off)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, whole_offset(off), 0, 0));
-}
-__device__ __forceinline__ float4 buf_f32x4(__amdgpu_buffer_rsrc_t r, int off)
-{
-    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, whole_offset(off), 0, 0));
-}
-
 // Everything the fill carries from band to band.
 struct fill_t {
     int llk;                // band_lower_left[b].kmer_idx (wave-uniform)

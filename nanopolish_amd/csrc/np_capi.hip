@@ -706,7 +706,7 @@ int np_eventalign_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* r
     int32_t* cig_reads = op_read + n_idx;
     const int rows_cap = c->ea_rows_cap;
     const int nb = persistent_blocks(c, n_reads, 1, c->ea_waves_per_cu);
-    const size_t bp_stride = ((size_t)rows_cap + 1) * 128, path_stride = (size_t)rows_cap + 256;      // + the dump row
+    const size_t bp_stride = ((size_t)rows_cap + 64) * 128, path_stride = (size_t)rows_cap + 256;     // one line per sweep step: e + 63 at most
     NP_HIP(c, c->ea_bp.reserve((size_t)nb * bp_stride));
     NP_HIP(c, c->ea_path.reserve((size_t)nb * path_stride * sizeof(uint32_t)));
     family_timer tm(c, 6, s);

@@ -114,3 +114,36 @@ __device__ __forceinline__ int closest_event(const int32_t* ms, int K, int k_idx
     for (int s = k_idx; s != stop_after; s += 1) { const int ei = ms[s]; if (ei != -1) { event_after = ei; break; } }
     return event_after;
 }
+
+// ---- range-checked buffer access (shared by the event aligner and the eventalign chain) --------------------------------
+// Range-checked loads through buffer descriptors: an offset outside [0, bytes) -- negative included, it wraps to a
+// huge unsigned -- returns 0 instead of faulting, so neither the event-mean prefetch nor the parameter refill needs
+// a clamp.  Whatever an out-of-range load returns only ever feeds a masked cell.
+// (the operands go through readfirstlane: they are wave-uniform but may sit in VGPRs, and a descriptor the compiler
+//  cannot prove scalar costs a waterfall loop per load)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes)
+{
+    const uint64_t u = (uint64_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    void* q = (void*)(((uint64_t)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+// The byte offset goes to the instruction as ONE register: the compiler would otherwise split `x + c` into a register
+// part and the instruction's immediate offset, and the hardware range-checks their sum without 32-bit wrap-around --
+// a negative register part with a positive immediate (true offset in range) would then read as 0.
+__device__ __forceinline__ int whole_offset(int off) { asm("" : "+v"(off)); return off; }
+__device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, int off)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, whole_offset(off), 0, 0));
+}
+__device__ __forceinline__ float4 buf_f32x4(__amdgpu_buffer_rsrc_t r, int off)
+{
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, whole_offset(off), 0, 0));
+}
+
+// 16-bit store through a descriptor: an offset outside [0, bytes) is dropped by the hardware
+__device__ __forceinline__ void buf_store_u16(__amdgpu_buffer_rsrc_t r, int off, uint32_t v)
+{
+    __builtin_amdgcn_raw_buffer_store_b16((short)v, r, whole_offset(off), 0, 0);
+}

@@ -33,7 +33,96 @@ __device__ __forceinline__ void vit_step(vmax& m, float x, uint32_t i)
     m.from = (m.v == x) ? i : m.from;
 }
 
+__device__ __forceinline__ float readlane_f32(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
 __device__ __forceinline__ uint32_t base_code(char c) { return c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u; }   // disambiguated to ACGT upstream
+
+// The Viterbi sweep of one segment, as a separate (not inlined) function: the chain loop around it keeps ~100 wave-uniform values
+// alive (CIGAR view, read record, output cursors); inlined, the register allocator spills some of them INSIDE this loop.  Called
+// once per segment, the caller's state is parked around the call instead and the sweep gets the registers to itself.
+struct ea_trans { float mm_self, mb, mk, mm_next, bb, bk, bm_next, bm_self, kk, km; };
+__device__ __attribute__((noinline)) float ea_fill(const np_gauss g0, const np_gauss g1, const ea_trans tr, const float flank0_in,
+                                                   const float* __restrict__ ev, uint8_t* __restrict__ bp, const int e_start, const int stride,
+                                                   const int e, const int n, const int lane)
+{
+    const np_gauss g[2] = {g0, g1};
+    const float lp_mm_self = tr.mm_self, lp_mb = tr.mb, lp_mk = tr.mk, lp_mm_next = tr.mm_next, lp_bb = tr.bb, lp_bk = tr.bk,
+                lp_bm_next = tr.bm_next, lp_bm_self = tr.bm_self, lp_kk = tr.kk, lp_km = tr.km;
+    const int lanes_used = (n + 1) >> 1;
+    float M0 = NP_NEG_INF, M1 = NP_NEG_INF, B0 = NP_NEG_INF, B1 = NP_NEG_INF, K0 = NP_NEG_INF, K1 = NP_NEG_INF;   // row r-1 of this lane's two blocks
+    float oM = NP_NEG_INF, oB = NP_NEG_INF, oK = NP_NEG_INF;                                                      // row r-1 of the block to the left
+    const int steps = e + lanes_used - 1;
+    const float flank0 = flank0_in;
+    const int end_lane = (n - 1) >> 1, end_c = (n - 1) & 1;
+    // The sweep is branch-free: every lane updates its two blocks at every step.  A lane that is before its first row
+    // only moves -inf around (row 0 is all -inf), one that is past its last row or owns no block computes values nobody
+    // reads.  Loads and stores go through range-checked descriptors sized to the segment: an event outside it reads
+    // as 0 (it only feeds such cells), a back-pointer row outside [0, e) is dropped by the hardware -- so the
+    // per-lane addresses are plain running offsets (one add each per step) with no clamp, compare or select.
+    const __amdgpu_buffer_rsrc_t evr = make_rsrc(ev + (stride > 0 ? e_start : e_start - (e - 1)), (uint32_t)e * 4u);
+    // Events: every lane walks the same sequence of events, lane j one step behind lane j - 1.  So only lane 0 needs a new
+    // event per step and the others take their left neighbour's previous one (one DPP shift): the wave fetches 64 events
+    // at a time with one coalesced load (lane i holds row 64 * blk + i + 1), a block ahead, and each step reads its event
+    // out of that register with v_readlane -- no memory latency inside the sweep.
+    auto ev_off = [&](int idx) { return stride > 0 ? 4 * idx : 4 * (e - 1 - idx); };     // byte offset of 0-based row idx
+    float ecur = buf_f32(evr, ev_off(lane)), enxt = buf_f32(evr, ev_off(lane + 64));
+    float x = 0.0f;
+    for (int t = 1; t <= steps; ++t) {
+        const float nM = np_wave_shr1(M1, NP_NEG_INF), nB = np_wave_shr1(B1, NP_NEG_INF), nK = np_wave_shr1(K1, NP_NEG_INF);   // lane 0: block -1 = -inf
+        const int ti = (t - 1) & 63;
+        if (ti == 0 && t > 1) { ecur = enxt; enxt = buf_f32(evr, ev_off(t - 1 + 64 + lane)); }
+        const float x0 = readlane_f32(ecur, ti);                // the event of row t: lane 0's at this step
+        x = np_wave_shr1(x, x0);
+        // HMT_FROM_SOFT (flags 0: first event only, r9.inl:361-363) reaches block 0 of row 1: lane 0 at step 1
+        const float soft_t = t == 1 ? flank0 : NP_NEG_INF;      // (scalar)
+        const float soft = lane == 0 ? soft_t : NP_NEG_INF;
+        uint32_t packed;
+        {
+            // ---- block 2*lane: left neighbour = previous lane's block (nM.. row r, oM.. row r-1) ----
+            const float em = np_emission(x, g[0]);
+            const float a0 = lp_mm_self + M0, a1 = lp_mm_next + oM, a2 = lp_bm_self + B0, a3 = lp_bm_next + oB, a4 = lp_km + oK;
+            const float v = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), __builtin_fmaxf(a2, a3)), __builtin_fmaxf(a4, soft));
+            uint32_t from = (a1 == v) ? 1u : 0u;               // the largest index whose candidate equals the maximum
+            from = (a2 == v) ? 2u : from; from = (a3 == v) ? 3u : from; from = (a4 == v) ? 4u : from; from = (soft == v) ? 5u : from;
+            const float newM = v + em;
+            // (the B and K states emit 0: the reference's `+ lp_emission` leaves every value it can meet here unchanged)
+            const float b0 = lp_mb + M0, b2 = lp_bb + B0;
+            const float newB = __builtin_fmaxf(b0, b2);
+            const uint32_t bbit = (b2 >= b0) ? 8u : 0u;
+            const float k1 = lp_mk + nM, k3 = lp_bk + nB, k4 = lp_kk + nK;
+            const float newK = __builtin_fmaxf(__builtin_fmaxf(k1, k3), k4);
+            uint32_t kbits = (k3 == newK) ? 16u : 0u; kbits = (k4 == newK) ? 32u : kbits;
+            packed = from | bbit | kbits;
+            // ---- block 2*lane + 1: left neighbour = the block just computed (row r) and its previous row ----
+            const float em1 = np_emission(x, g[1]);
+            const float c0 = lp_mm_self + M1, c1 = lp_mm_next + M0, c2 = lp_bm_self + B1, c3 = lp_bm_next + B0, c4 = lp_km + K0;
+            const float w = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(c0, c1), __builtin_fmaxf(c2, c3)), c4);
+            uint32_t from1 = (c1 == w) ? 1u : 0u;
+            from1 = (c2 == w) ? 2u : from1; from1 = (c3 == w) ? 3u : from1; from1 = (c4 == w) ? 4u : from1;
+            const float newM1 = w + em1;
+            const float d0 = lp_mb + M1, d2 = lp_bb + B1;
+            const float newB1 = __builtin_fmaxf(d0, d2);
+            const uint32_t bbit1 = (d2 >= d0) ? 8u : 0u;
+            const float j1 = lp_mk + newM, j3 = lp_bk + newB, j4 = lp_kk + newK;
+            const float newK1 = __builtin_fmaxf(__builtin_fmaxf(j1, j3), j4);
+            uint32_t kbits1 = (j3 == newK1) ? 16u : 0u; kbits1 = (j4 == newK1) ? 32u : kbits1;
+            packed |= (from1 | bbit1 | kbits1) << 8;
+            M0 = newM; B0 = newB; K0 = newK; M1 = newM1; B1 = newB1; K1 = newK1;
+        }
+        oM = nM; oB = nB; oK = nK;
+        // back-pointers are laid out by sweep STEP, not by lattice row: step t writes one contiguous 128-byte line (lane l's two
+        // blocks at bytes 2l, 2l + 1), whatever row each lane is on.  Cell (row r, k-mer b) therefore lives in line r + b / 2 at
+        // byte b; lines and bytes that belong to no cell (lanes before their first / past their last row, or without a block)
+        // hold values nobody reads.  (Row-major, the same store touched 64 different cache lines per step.)
+        *(uint16_t*)(bp + (size_t)(t - 1) * NP_EA_ROW_BYTES + 2 * lane) = (uint16_t)packed;
+    }
+    // the lane that owns the last k-mer computes its last row in the last step, so its registers still hold it
+    const float end_m = end_c ? M1 : M0;
+    return __shfl(end_m, end_lane, 64);
+}
 
 __global__ void __launch_bounds__(64, 5) np_eventalign_chain_kernel(np_ea_args a)
 {
@@ -116,69 +205,8 @@ __global__ void __launch_bounds__(64, 5) np_eventalign_chain_kernel(np_ea_args a
                 }
                 g[c] = np_scale_state(a.model, rank, scale, shift, var, log_var);
             }
-            const int lanes_used = (n + 1) >> 1;
-            float M0 = NP_NEG_INF, M1 = NP_NEG_INF, B0 = NP_NEG_INF, B1 = NP_NEG_INF, K0 = NP_NEG_INF, K1 = NP_NEG_INF;   // row r-1 of this lane's two blocks
-            float oM = NP_NEG_INF, oB = NP_NEG_INF, oK = NP_NEG_INF;                                                      // row r-1 of the block to the left
-            float end_m = NP_NEG_INF;                                  // M of the last k-mer in the last row: where the back-track starts
-            const int steps = e + lanes_used - 1;
-            const float flank0 = a.flank[0];
-            const int end_lane = (n - 1) >> 1, end_c = (n - 1) & 1;
-            // The sweep is branch-free: every lane updates its two blocks at every step.  A lane that is before its first row
-            // only moves -inf around (row 0 is all -inf), one that is past its last row or owns no block computes values nobody
-            // reads; both store their back-pointers into a dump row.  Event indices are clamped into the segment.
-            float xn = ev[e_start];                                     // row 1 (lane 0 at step 1); later lanes reach it later
-            for (int t = 1; t <= steps; ++t) {
-                const float nM = np_wave_shr1(M1, NP_NEG_INF), nB = np_wave_shr1(B1, NP_NEG_INF), nK = np_wave_shr1(K1, NP_NEG_INF);   // lane 0: block -1 = -inf
-                const int r = t - lane;
-                const float x = xn;
-                {
-                    int rn = r;                                         // 0-based index of the next row, clamped into [0, e)
-                    rn = rn < 0 ? 0 : (rn > e - 1 ? e - 1 : rn);
-                    xn = ev[e_start + rn * stride];
-                }
-                // HMT_FROM_SOFT (flags 0: first event only, r9.inl:361-363) reaches block 0 of row 1: lane 0 at step 1
-                const float soft = (t == 1 && lane == 0) ? flank0 : NP_NEG_INF;
-                uint32_t packed;
-                {
-                    // ---- block 2*lane: left neighbour = previous lane's block (nM.. row r, oM.. row r-1) ----
-                    const float em = np_emission(x, g[0]);
-                    const float a0 = lp_mm_self + M0, a1 = lp_mm_next + oM, a2 = lp_bm_self + B0, a3 = lp_bm_next + oB, a4 = lp_km + oK;
-                    const float v = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), __builtin_fmaxf(a2, a3)), __builtin_fmaxf(a4, soft));
-                    uint32_t from = (a1 == v) ? 1u : 0u;               // the largest index whose candidate equals the maximum
-                    from = (a2 == v) ? 2u : from; from = (a3 == v) ? 3u : from; from = (a4 == v) ? 4u : from; from = (soft == v) ? 5u : from;
-                    const float newM = v + em;
-                    const float b0 = lp_mb + M0, b2 = lp_bb + B0;
-                    const float newB = __builtin_fmaxf(b0, b2) + 0.0f;
-                    const uint32_t bbit = (b2 >= b0) ? 8u : 0u;
-                    const float k1 = lp_mk + nM, k3 = lp_bk + nB, k4 = lp_kk + nK;
-                    const float kv = __builtin_fmaxf(__builtin_fmaxf(k1, k3), k4);
-                    uint32_t kbits = (k3 == kv) ? 16u : 0u; kbits = (k4 == kv) ? 32u : kbits;
-                    const float newK = kv + 0.0f;
-                    packed = from | bbit | kbits;
-                    // ---- block 2*lane + 1: left neighbour = the block just computed (row r) and its previous row ----
-                    const float em1 = np_emission(x, g[1]);
-                    const float c0 = lp_mm_self + M1, c1 = lp_mm_next + M0, c2 = lp_bm_self + B1, c3 = lp_bm_next + B0, c4 = lp_km + K0;
-                    const float w = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(c0, c1), __builtin_fmaxf(c2, c3)), c4);
-                    uint32_t from1 = (c1 == w) ? 1u : 0u;
-                    from1 = (c2 == w) ? 2u : from1; from1 = (c3 == w) ? 3u : from1; from1 = (c4 == w) ? 4u : from1;
-                    const float newM1 = w + em1;
-                    const float d0 = lp_mb + M1, d2 = lp_bb + B1;
-                    const float newB1 = __builtin_fmaxf(d0, d2) + 0.0f;
-                    const uint32_t bbit1 = (d2 >= d0) ? 8u : 0u;
-                    const float j1 = lp_mk + newM, j3 = lp_bk + newB, j4 = lp_kk + newK;
-                    const float jv = __builtin_fmaxf(__builtin_fmaxf(j1, j3), j4);
-                    uint32_t kbits1 = (j3 == jv) ? 16u : 0u; kbits1 = (j4 == jv) ? 32u : kbits1;
-                    const float newK1 = jv + 0.0f;
-                    packed |= (from1 | bbit1 | kbits1) << 8;
-                    M0 = newM; B0 = newB; K0 = newK; M1 = newM1; B1 = newB1; K1 = newK1;
-                }
-                oM = nM; oB = nB; oK = nK;
-                const bool active = (uint32_t)(r - 1) < (uint32_t)e && lane < lanes_used;
-                const int srow = active ? r - 1 : a.rows_cap;              // the dump row sits behind the last real one
-                *(uint16_t*)(bp + (size_t)srow * NP_EA_ROW_BYTES + 2 * lane) = (uint16_t)packed;
-                end_m = (r == e && lane == end_lane) ? (end_c ? M1 : M0) : end_m;
-            }
-            const float start_v = __shfl(end_m, end_lane, 64);
+            const ea_trans tr{lp_mm_self, lp_mb, lp_mk, lp_mm_next, lp_bb, lp_bk, lp_bm_next, lp_bm_self, lp_kk, lp_km};
+            const float start_v = ea_fill(g[0], g[1], tr, a.flank[0], ev, bp, e_start, stride, e, n, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_s_waitcnt(0);
 
@@ -191,20 +219,22 @@ __global__ void __launch_bounds__(64, 5) np_eventalign_chain_kernel(np_ea_args a
                 int row = e, kmer = n - 1, ps = 2, stop = 0;
                 uint32_t pv = 0;
                 while (row > 0 && kmer >= 0 && !stop) {
-                    const int lo = row - (NP_EA_CHUNK - 1) > 1 ? row - (NP_EA_CHUNK - 1) : 1;
-                    const int n16 = (row - lo + 1) * (NP_EA_ROW_BYTES / 16);
+                    // the line of cell (row, kmer) is row + kmer / 2; along the walk it never grows (each move lowers row or kmer)
+                    const int hi = row + (kmer >> 1);
+                    const int lo = hi - (NP_EA_CHUNK - 1) > 1 ? hi - (NP_EA_CHUNK - 1) : 1;
+                    const int n16 = (hi - lo + 1) * (NP_EA_ROW_BYTES / 16);
                     const uint4* __restrict__ src = (const uint4*)(bp + (size_t)(lo - 1) * NP_EA_ROW_BYTES);
                     for (int i = lane; i < n16; i += 64) ((uint4*)stage)[i] = src[i];
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     __builtin_amdgcn_s_waitcnt(0);
                     __builtin_amdgcn_wave_barrier();
                     const uint8_t* sb = (const uint8_t*)stage;
-                    while (row >= lo && kmer >= 0) {
+                    while (row > 0 && kmer >= 0 && row + (kmer >> 1) >= lo) {
                         const uint32_t entry = (uint32_t)row | ((uint32_t)kmer << 16) | ((uint32_t)ps << 24);
                         pv = lane == (cnt & 63) ? entry : pv;
                         cnt++;
                         if ((cnt & 63) == 0) path[cnt - 64 + lane] = pv;
-                        const uint32_t byte = (uint32_t)__builtin_amdgcn_readfirstlane((int)sb[(row - lo) * NP_EA_ROW_BYTES + kmer]);
+                        const uint32_t byte = (uint32_t)__builtin_amdgcn_readfirstlane((int)sb[(row + (kmer >> 1) - lo) * NP_EA_ROW_BYTES + kmer]);
                         const uint32_t mv = ps == 2 ? (byte & 7u) : ps == 1 ? ((byte >> 3) & 1u) * 2u : ((byte >> 4) == 0u ? 1u : (byte >> 4) == 1u ? 3u : 4u);
                         if (mv == 5u) { stop = 1; break; }          // HMT_FROM_SOFT
                         int next_ps = 2;
