@@ -1,0 +1,86 @@
+"""GPU: randomised stress of the two hot kernels and the Viterbi path against the CPU oracle -- many small problems with
+unusual shapes (events per base from 0.4 to 4, reads of 12 to 900 bases, heavy noise that trips the aligner's QC, windows
+of 6 to 300 k-mers over 2 to 600 events, both strides, every clip-flag combination).  Bit-exact or fail."""
+import numpy as np
+import pytest
+
+from nanopolish_amd.synth import nucleotide_kmer_ranks, BASES
+
+pytestmark = pytest.mark.gpu
+K = 6
+
+
+def _random_read(rng, nuc, L, rate, noise):
+    codes = rng.integers(0, 4, L)
+    ranks = nucleotide_kmer_ranks(codes, K)
+    n_ev = rng.poisson(rate, len(ranks))
+    shift = rng.uniform(-8, 8); scale = rng.uniform(0.8, 1.2); var = rng.uniform(0.8, 1.6)
+    rk = np.repeat(ranks, n_ev)
+    ev = (scale * nuc["level_mean"][rk] + shift + noise * var * nuc["level_stdv"][rk] * rng.standard_normal(len(rk))).astype(np.float32)
+    return dict(seq=BASES[codes].tobytes().decode(), ranks=ranks, events=ev, shift=shift, scale=scale, var=var)
+
+
+def test_event_align_fuzz(ctx, orc, models):
+    nuc = models["nucleotide"]
+    mn = orc.model(nuc)
+    rng = np.random.default_rng(2024)
+    reads = []
+    while len(reads) < 400:
+        L = int(rng.integers(12, 900))
+        rd = _random_read(rng, nuc, L, rate=float(rng.choice([0.4, 0.8, 1.5, 2.5, 4.0])), noise=float(rng.choice([0.5, 1.0, 1.0, 3.0, 8.0])))
+        if len(rd["events"]) >= 2:
+            reads.append(rd)
+    jobs, moms = [], []
+    for rd in reads:
+        sh, sc = orc.estimate_scalings_mom(mn, rd["ranks"], rd["events"])
+        moms.append((sh, sc))
+        jobs.append(dict(events=rd["events"], ranks=rd["ranks"], model=ctx.models["nucleotide"], scale=sc, shift=sh, var=1.0))
+    got = ctx.adaptive_banded_simple_event_align(jobs)
+    n_ok = n_fail = 0
+    for rd, (sh, sc), g in zip(reads, moms, got):
+        want = orc.event_align(mn, orc.scalings(sh, sc, 1.0), rd["events"], rd["ranks"])
+        if want is None:                       # the reference walks off its band there (known deviation 1)
+            assert len(g) == 0
+            continue
+        assert g.shape == want.shape and np.array_equal(g, want), (len(rd["events"]), len(rd["ranks"]))
+        n_ok += len(want) > 0; n_fail += len(want) == 0
+    assert n_ok > 80 and n_fail > 20           # both outcomes of the QC are exercised
+
+
+def test_hmm_score_and_align_fuzz(ctx, orc, models):
+    nuc, cpg = models["nucleotide"], models["cpg"]
+    mn, mc = orc.model(nuc), orc.model(cpg)
+    rng = np.random.default_rng(77)
+    rd = _random_read(rng, nuc, 2500, 1.6, 1.0)
+    ev = rd["events"]; E = len(ev)
+    S = orc.scalings(rd["shift"], rd["scale"], rd["var"])
+    jobs, want, vjobs, vwant = [], [], [], []
+    for t in range(600):
+        n = int(rng.choice([6, 7, 15, 16, 17, 31, 33, 64, 65, 129, 300])) if t % 3 == 0 else int(rng.integers(6, 120))
+        e = int(rng.integers(2, 600)) if t % 5 == 0 else int(rng.integers(2, 3 * n + 12))
+        e = min(e, E - 2)
+        e1 = int(rng.integers(0, E - e))
+        stride = 1 if rng.random() < 0.5 else -1
+        a, b = (e1, e1 + e - 1) if stride == 1 else (e1 + e - 1, e1)
+        flags = int(rng.integers(0, 4))
+        epb = float(rng.uniform(0.8, 4.0)); bias = float(rng.choice([1.0, 0.9]))
+        use_cpg = t % 2 == 0
+        ranks = rng.integers(0, 15625 if use_cpg else 4096, n).astype(np.uint32)
+        m, mid = (mc, ctx.models["cpg"]) if use_cpg else (mn, ctx.models["nucleotide"])
+        job = dict(events=ev, ranks=ranks.astype(np.uint16), e_start=a, e_stop=b, stride=stride, model=mid, scale=rd["scale"], shift=rd["shift"],
+                   var=rd["var"], events_per_base=epb, flags=flags, indel_bias=bias)
+        jobs.append(job); want.append(orc.hmm_score(m, S, ev, ranks, a, b, stride, epb, bias, flags))
+        if t % 4 == 0 and e >= 2:
+            vjobs.append(dict(job, flags=0)); vwant.append(orc.hmm_align(m, S, ev, ranks, a, b, stride, epb, bias, 0))
+    got = ctx.profile_hmm_score(jobs)
+    want = np.array(want, np.float32)
+    same = (got == want) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), np.flatnonzero(~same)[:5]
+    assert np.isfinite(want).sum() > 300
+    res = ctx.profile_hmm_align(vjobs)
+    for r, w in zip(res, vwant):
+        if w is None:
+            assert len(r[0]) == 0
+            continue
+        assert np.array_equal(r[0], w[0]) and np.array_equal(r[1], w[1]) and np.array_equal(r[3], w[3])
+        assert np.array_equal(r[2], np.asarray(w[2], np.float64))
