@@ -250,6 +250,74 @@ def eventalign_read(orc, read, pairs, hmm_align_fn, align_stride=100, output_str
     return out, n_calls, epb
 
 
+def eventalign_record(orc, read_seq, rc, pos, cigar, contig, map_start, hmm_align_fn, align_stride=100, output_stride=50):
+    """align_read_to_ref (src/alignment/nanopolish_eventalign.cpp:612-826) for a read aligned by a BAM record (CIGAR words,
+    0-based pos, reverse flag), parameterised by the profile_hmm_align implementation like eventalign_read:
+        hmm_align_fn(fwd_subseq, rc_subseq, e_start, e_stop, stride, rc) -> (event_idx, kmer_idx, l_fm, state) or None
+    Returns the emitted (ref_position, event_idx, state) triples and the number of profile_hmm_align calls."""
+    L = len(read_seq)
+    ref_seq = record_reference_segment(contig, pos, cigar)
+    rc_ref_seq = revcomp(ref_seq)
+    ab = orc.cigar_aligned_bases(cigar, pos)
+    max_kmer_idx = L - K
+    aligned = [(int(r), int(q)) for r, q in ab]
+    while aligned and aligned[-1][1] > max_kmer_idx:                    # trim_aligned_pairs_to_kmer (:167-177)
+        aligned.pop()
+    if not aligned:
+        return [], 0
+    flip = lambda i: L - i - K
+    closest = lambda k_idx: orc.get_closest_event_to(map_start, k_idx)
+
+    def get_end_pair(ref_pos_max, pair_idx):                            # :196-205
+        while pair_idx < len(aligned):
+            if aligned[pair_idx][0] > ref_pos_max:
+                return pair_idx - 1
+            pair_idx += 1
+        return len(aligned) - 1
+
+    ks, ke = aligned[0][1], aligned[-1][1]
+    if rc:
+        ks, ke = flip(ks), flip(ke)
+    first_event, last_event = closest(ks), closest(ke)
+    forward = first_event < last_event
+    curr_start_event, curr_start_ref, curr_pair_idx = first_event, aligned[0][0], 0
+    out, n_calls = [], 0
+    while (forward and curr_start_event < last_event) or (not forward and curr_start_event > last_event):
+        end_pair_idx = get_end_pair(curr_start_ref + align_stride, curr_pair_idx)
+        curr_end_ref, curr_end_read = aligned[end_pair_idx]
+        if rc:
+            curr_end_read = flip(curr_end_read)
+        s, l = curr_start_ref - pos, curr_end_ref - curr_start_ref + 1
+        fwd_subseq = ref_seq[s:s + l]
+        rc_subseq = rc_ref_seq[len(ref_seq) - s - l:len(ref_seq) - s]
+        if len(fwd_subseq) < 2 * K:
+            break
+        e_start, e_stop = curr_start_event, closest(curr_end_read)
+        if abs(e_start - e_stop) < 2:
+            break
+        stride = 1 if e_start < e_stop else -1
+        res = hmm_align_fn(fwd_subseq, rc_subseq, e_start, e_stop, stride, bool(rc))
+        n_calls += 1
+        if res is None:
+            break
+        ev, km, lf, st = res
+        last_section = end_pair_idx == len(aligned) - 1
+        num_output = 0
+        last_event_output = last_ref_kmer_output = 0
+        for i in range(len(ev)):
+            if not (num_output < output_stride or last_section):
+                break
+            if chr(st[i]) != 'K' and int(ev[i]) != curr_start_event:
+                out.append((curr_start_ref + int(km[i]), int(ev[i]), int(st[i])))
+                last_event_output = int(ev[i]); last_ref_kmer_output = curr_start_ref + int(km[i])
+                num_output += 1
+        curr_start_event, curr_start_ref = last_event_output, last_ref_kmer_output
+        curr_pair_idx = get_end_pair(curr_start_ref, curr_pair_idx)
+        if num_output == 0:
+            break
+    return out, n_calls
+
+
 def variant_window_items(orc, ref_seq, reads_pairs, positions, flank=10):
     """Work items of generate_candidate_single_base_edits + score_variant_thresholded
     (src/nanopolish_call_variants.cpp:288-361, src/common/nanopolish_variant.cpp:765-799) for identity-aligned reads of one

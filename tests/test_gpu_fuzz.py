@@ -84,3 +84,47 @@ def test_hmm_score_and_align_fuzz(ctx, orc, models):
             continue
         assert np.array_equal(r[0], w[0]) and np.array_equal(r[1], w[1]) and np.array_equal(r[3], w[3])
         assert np.array_equal(r[2], np.asarray(w[2], np.float64))
+
+
+def test_record_pipeline_fuzz(ctx, orc, models):
+    """24 reads with random substitutions / indels / clips on both strands: the whole device chain from raw signal and BAM
+    records (work items on the device) and the eventalign segment chain, against the oracle's restatement of the reference's
+    per-read pass (itself pinned to the reference, tests/test_oracle_vs_ref_full.py)"""
+    from nanopolish_amd import api
+    from nanopolish_amd.pipeline import build_host_batch_records, CallMethylationBatch
+    from nanopolish_amd.synth import synth_cigar_read
+    from oracle.workloads import call_methylation_record, eventalign_record
+    nuc = models["nucleotide"]
+    mn, mc = orc.model(nuc), orc.model(models["cpg"])
+    g = np.random.default_rng(31337).integers(0, 4, 9000)
+    contig = BASES[g].tobytes().decode()
+    rng = np.random.default_rng(5)
+    recs = []
+    for rid in range(24):
+        rd = synth_cigar_read(800 + rid, g, nuc, span=int(rng.integers(300, 1500)), p_sub=float(rng.choice([0.0, 0.02, 0.06])),
+                              p_ins=float(rng.choice([0.0, 0.02, 0.05])), p_del=float(rng.choice([0.0, 0.02, 0.05])),
+                              max_indel=int(rng.integers(1, 12)), soft_clip=(0, int(rng.integers(0, 40))))
+        recs.append(dict(seq=rd["seq"], raw=rd["raw"], rc=rd["rc"], pos=rd["pos"], cigar=api.cigar_words(rd["cigar_ops"])))
+    hb = build_host_batch_records(models, recs, contig)
+    batch = CallMethylationBatch(ctx, hb, "cuda:0", calibrate=True, from_raw=True, jobs_on_device=True)
+    batch.step()
+    ea = batch.eventalign()
+    n_sites = n_rows = 0
+    for i, r in enumerate(recs):
+        want = call_methylation_record(orc, mn, mc, r["seq"], r["raw"], r["rc"], r["pos"], r["cigar"], contig)
+        first, nm, u, m = batch.groups_of(i)
+        got = {int(f) + r["pos"]: (float(a), float(b)) for f, a, b in zip(first, u, m) if a == a}
+        assert got == {s["start"]: (s["ll_unmeth"], s["ll_meth"]) for s in want["sites"]}, i
+        n_sites += len(got)
+        if want["n_events"]:
+            ev = want["events"]; S = orc.scalings(*want["scalings"])
+
+            def cpu(fwd, rc_s, e1, e2, stride, do_rc):
+                return orc.hmm_align(mn, S, ev, orc.sequence_kmer_ranks("nucleotide", fwd, rc_s, K, do_rc), e1, e2, stride, want["epb"])
+            rows, _ = eventalign_record(orc, r["seq"], r["rc"], r["pos"], r["cigar"], contig, want["map_start"], cpu)
+        else:
+            rows = []
+        assert ea[i]["status"] == 0
+        assert list(zip(ea[i]["ref_position"].tolist(), ea[i]["event_idx"].tolist(), ea[i]["hmm_state"].tolist())) == rows, i
+        n_rows += len(rows)
+    assert n_sites > 300 and n_rows > 20000

@@ -116,3 +116,29 @@ def test_read_at_contig_edges_and_short_reads(full, orc, models):
         got = call_methylation_record(orc, mn, mc, rd["seq"], rd["raw"], rd["rc"], rd["pos"], cig, contig)
         assert [(s["start"], s["ll_unmeth"], s["ll_meth"]) for s in got["sites"]] == \
             list(zip(want["start"].tolist(), want["ll_unmeth"].tolist(), want["ll_meth"].tolist()))
+
+
+def test_eventalign_chain_on_indel_reads_matches_align_read_to_ref(full, orc, models):
+    """the oracle's restatement of the segment chain for CIGAR-aligned reads (fresh seeds) against the reference running live"""
+    from nanopolish_amd.synth import synth_cigar_read, BASES
+    from oracle.workloads import eventalign_record, K
+    mn = orc.model(models["nucleotide"])
+    g = np.random.default_rng(79).integers(0, 4, 5000)
+    contig = BASES[g].tobytes().decode()
+    rows = 0
+    for rid in range(500, 504):
+        rd = synth_cigar_read(rid, g, models["nucleotide"], span=1100, p_ins=0.03, p_del=0.03, max_indel=6)
+        cig = cigar_words(rd["cigar_ops"])
+        fr = full.read("r%d" % rid, rd["seq"], rd["raw"])
+        want = fr.eventalign(rd["rc"], rd["pos"], cig, rd["bam_seq"], contig)
+        ev = fr.events(); ms, _ = fr.event_map()
+        S = orc.scalings(fr.shift, fr.scale, fr.var)
+
+        def cpu(fwd, rc_s, e1, e2, stride, do_rc):
+            return orc.hmm_align(mn, S, ev, orc.sequence_kmer_ranks("nucleotide", fwd, rc_s, K, do_rc), e1, e2, stride, fr.events_per_base)
+
+        got, n_calls = eventalign_record(orc, rd["seq"], rd["rc"], rd["pos"], cig, contig, ms, cpu)
+        assert n_calls > 10
+        assert got == list(zip(want["ref_position"].tolist(), want["event_idx"].tolist(), want["hmm_state"].tolist()))
+        rows += len(got)
+    assert rows > 5000
