@@ -83,6 +83,34 @@ def main():
             out[p + "gpc_ll_unmeth"] = gp["ll_unmeth"]; out[p + "gpc_ll_meth"] = gp["ll_meth"]
         print("read %d rc=%d pos=%d cigar_ops=%d events=%d sites=%d var=%.3f" % (i, rd["rc"], rd["pos"], len(cig), fr.n_events,
                                                                                  len(res["start"]), fr.var))
+    # --methylation dam (GATC -> GMTC) and dcm (CCAGG / CCTGG -> CMAGG / CMTGG): a contig with those motifs planted every ~45 bases
+    # (single sites, pairs 7 bases apart and one motif cut by the contig end), two reads with indels, one per strand
+    rng = np.random.default_rng(424242)
+    mc = rng.integers(0, 4, 1800)
+    motifs = ["GATC", "CCAGG", "CCTGG", "GATC", "GATCNNNGATC", "CCAGGNNCCTGG"]
+    pos_m = 30
+    for j in range(36):
+        m = motifs[j % len(motifs)]
+        for t, ch in enumerate(m):
+            if ch != "N":
+                mc[pos_m + t] = "ACGT".index(ch)
+        pos_m += 45 + int(rng.integers(0, 8))
+    for t, ch in enumerate("GAT"):
+        mc[len(mc) - 3 + t] = "ACGT".index(ch)
+    mcontig = BASES[mc].tobytes().decode()
+    out["m_contig"] = np.frombuffer(mcontig.encode(), np.uint8)
+    for j in range(2):
+        rd = synth_cigar_read(200 + j, mc, nuc, span=1700, rc=bool(j), soft_clip=(0, 6))
+        cig = cigar_words(rd["cigar_ops"])
+        fr = F.read("mread%d" % j, rd["seq"], rd["raw"])
+        p = "m%d_" % j
+        out[p + "seq"] = np.frombuffer(rd["seq"].encode(), np.uint8); out[p + "raw"] = rd["raw"]; out[p + "cigar"] = cig
+        out[p + "rc_pos"] = np.array([int(rd["rc"]), rd["pos"]], np.int64)
+        for alpha in ("dam", "dcm"):
+            q = fr.call_methylation(rd["rc"], rd["pos"], cig, rd["bam_seq"], mcontig, methylation_type=alpha, modbam=False)
+            out[p + alpha + "_start"] = q["start"]; out[p + alpha + "_end"] = q["end"]; out[p + alpha + "_n_motif"] = q["n_motif"]
+            out[p + alpha + "_ll_unmeth"] = q["ll_unmeth"]; out[p + alpha + "_ll_meth"] = q["ll_meth"]
+            print("motif read %d %s: %d sites, n_motif max %d" % (j, alpha, len(q["start"]), int(q["n_motif"].max()) if len(q["start"]) else 0))
     # eventalign: two identity-aligned reads (forward and reverse strand), align_read_to_ref's emitted rows
     for j, rid in enumerate(EVENTALIGN_READS):
         rd = synth_raw(rid, nuc, L=1500)
@@ -101,8 +129,9 @@ def main():
         print("eventalign read %d rc=%d rows=%d" % (rid, rd["rc"], len(res["event_idx"])))
     # the gpc pore model as the reference loads it (fixture for the gpc parity tests)
     from oracle import RefOracle
-    gm = RefOracle().model("gpc")
-    np.savez_compressed(os.path.join(GOLD, "models_r9.4_450bps_gpc.npz"), **{f: gm[f] for f in ("level_mean", "level_stdv", "level_log_stdv")})
+    for alpha in ("gpc", "dam", "dcm"):
+        gm = RefOracle().model(alpha)
+        np.savez_compressed(os.path.join(GOLD, "models_r9.4_450bps_%s.npz" % alpha), **{f: gm[f] for f in ("level_mean", "level_stdv", "level_log_stdv")})
     path = os.path.join(GOLD, "golden_reflevel.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
