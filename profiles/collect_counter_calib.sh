@@ -1,5 +1,6 @@
 # FETCH_SIZE / WRITE_SIZE calibration on known byte counts (tools/hbm_counter_calib.hip); separate --pmc passes
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd /tmp
+[ -x $R/tools/hbm_counter_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 $R/tools/hbm_counter_calib.hip -o $R/tools/hbm_counter_calib
 timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/calib_f -o c -- $R/tools/hbm_counter_calib > $R/gpurun_out/calib_f.log 2>&1; echo rc=$?
 timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/calib_w -o c -- $R/tools/hbm_counter_calib > $R/gpurun_out/calib_w.log 2>&1; echo rc=$?
 python3 - <<'PY'
