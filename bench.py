@@ -243,6 +243,20 @@ def main():
             cpu = dict(value=round(cb["n"] / cb["seconds"], 2), unit="reads/s", cores=cores, kind=cb["kind"],
                        sample="%d of the same synthetic reads, OpenMP over reads (detect %.2fs + align %.1fs + calibrate %.2fs + score %.1fs)"
                               % (cb["n"], cb["t_detect"], cb["t_align"], cb["t_calib"], cb["t_score"]))
+            if args.from_raw and args.calibrate:
+                # the same sample through the reference's WHOLE per-read function: SquiggleRead(sequence, Fast5Data) -> load_from_raw
+                # -> calculate_methylation_for_read, compiled in place (oracle/_ref/libnp_ref_full.so), OpenMP over reads
+                try:
+                    from oracle.ref_full import FullRef, have_full
+                    if have_full():
+                        rds = hb["reads"][:cb["n"]]
+                        sites, t_full = FullRef().many_identity(1, [r["seq"] for r in rds], [r["raw"] for r in rds], [r["rc"] for r in rds], cores)
+                        n_gpu = [int(np.isfinite(llr[int(hb["job_off"][i]) // 2:int(hb["job_off"][i + 1]) // 2]).sum()) for i in range(cb["n"])]
+                        cpu["whole_function"] = dict(value=round(cb["n"] / t_full, 2), unit="reads/s",
+                                                     what="load_from_raw + calculate_methylation_for_read per read, reference code",
+                                                     sites_per_read_match_gpu=bool(np.array_equal(sites, np.array(n_gpu))))
+                except Exception as e:  # noqa: BLE001
+                    cpu["whole_function"] = dict(error=repr(e))
             # parity of the GPU results with the oracle on that sample: pairs bit-exact, LLR within 1e-4
             pairs, pair_off, n_pairs = cb["pairs"]
             ok = True
