@@ -55,3 +55,63 @@ def test_two_rank_site_reduction_equals_single_process(tmp_path):
     want = _rank_table(0, N_READS)
     assert want[:, 0].sum() > 10
     assert torch.equal(got, want)
+
+
+# ---- variants (BASELINE config 4): per-variant totals over reads, reads sharded over ranks -----------------------------------
+N_VREADS = 6
+
+
+def _variant_scores(lo, hi):
+    """scores [haplotype, read] of a few screened positions for reads lo..hi-1 of one 300-base reference (CPU oracle)"""
+    from oracle import Oracle, load_models
+    from oracle.workloads import variant_window_items, HAF_PRE, HAF_POST, K
+    from nanopolish_amd.synth import synth_read_from_codes
+    models = load_models(); orc = Oracle()
+    mn = orc.model(models["nucleotide"])
+    ref_codes = np.random.default_rng(3).integers(0, 4, 300)
+    ref_seq = "".join("ACGT"[c] for c in ref_codes)
+    reads_pairs = []
+    for rid in range(lo, hi):
+        rd = synth_read_from_codes(ref_codes, rid, models["nucleotide"], rc=bool(rid & 1))
+        sh, sc = orc.estimate_scalings_mom(mn, rd["ranks"], rd["events"])
+        reads_pairs.append((rd, orc.event_align(mn, orc.scalings(sh, sc, 1.0), rd["events"], rd["ranks"])))
+    items = variant_window_items(orc, ref_seq, reads_pairs, range(60, 240, 45))
+    rows, base_of = [], []
+    for it in items:
+        b = len(rows)
+        for seq in it["seqs"]:
+            row = np.full(hi - lo, np.nan, np.float32)
+            for (ri, e1, e2, stride, rc, epb) in it["per_read"]:
+                rd = reads_pairs[ri][0]
+                ranks = orc.sequence_kmer_ranks("nucleotide", seq, None, K, rc)
+                row[ri] = orc.combine_score_set([orc.hmm_score(mn, orc.scalings(rd["shift"], rd["scale"], rd["var"]), rd["events"], ranks,
+                                                               e1, e2, stride, epb, 0.9, HAF_PRE | HAF_POST)])
+            rows.append(row); base_of.append(b)
+    return torch.tensor(np.stack(rows)), torch.tensor(base_of, dtype=torch.int64)
+
+
+def _vworker(rank, world, port, out):
+    from nanopolish_amd.variants import variant_quality, reduce_variant_quality
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_read_ids(N_VREADS, rank, world)
+    sc, base_of = _variant_scores(lo, hi)
+    q = reduce_variant_quality(variant_quality(torch, sc, base_of))
+    if rank == 0:
+        torch.save(q, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_variant_qualities_equal_single_process(tmp_path):
+    from nanopolish_amd.variants import variant_quality
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "q.pt")
+    mp.spawn(_vworker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    sc, base_of = _variant_scores(0, N_VREADS)
+    want = variant_quality(torch, sc, base_of)
+    assert want.abs().max() > 1.0 and float(want[base_of.unique()].abs().max()) == 0.0          # base haplotypes score 0 against themselves
+    assert torch.allclose(got, want, rtol=0, atol=1e-9)                                          # summation order differs across ranks
+    # the true base usually wins: most single-base edits of a correct reference have negative quality
+    assert (want < 0).sum() > (want > 0).sum()
