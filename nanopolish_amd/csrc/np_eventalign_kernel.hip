@@ -11,27 +11,22 @@
 //   * Viterbi fill as an anti-diagonal sweep: lane j owns k-mer blocks 2j, 2j+1 (a segment has <= 96 k-mers), computes row
 //     t - j at step t; previous row in registers, left neighbour through DPP; six candidates in HMMMovementType order,
 //     later index wins ties; only back-pointers leave the wave: 6 bits per block and row (M: 3, B: 1, K: 2), one byte,
-//     128 B per row, into a per-wave scratch that stays in L2;
-//   * back-track by one lane, every visited state appended to a per-wave path list; then the wave reads the tail of the
-//     list back and emits it 64 entries at a time (ballot + prefix count reproduces the reference's "first 50 that are
-//     not K and not the start event" cut).
+//     one coalesced 128-byte line per sweep STEP (cell (row r, k-mer b) sits in line r + b / 2 at byte b), into a per-wave
+//     scratch that stays in L2; events reach the lanes by one block load per 64 steps + v_readlane + a DPP shift;
+//   * back-track with a wave-uniform (scalar) state over 32 lines at a time staged in LDS, every visited state appended
+//     to a per-wave path list (64 entries per coalesced flush); then the wave reads the tail of the list back and emits
+//     it 64 entries at a time (ballot + prefix count reproduces the reference's "first 50 that are not K and not the
+//     start event" cut).
 // Output rows are (ref_position relative to the record's pos, event_idx, state 'M'/'B'); ref_kmer / model_kmer of the TSV
 // follow from them on the host (nanopolish_amd/eventalign.py).
 #include "np_kernels.h"
 #include "np_cigar.h"
 
-#define NP_EA_ROW_BYTES 128          // back-pointer bytes per lattice row (one per k-mer block; a segment has <= 96)
+#define NP_EA_ROW_BYTES 128          // back-pointer bytes per sweep step (lane l's two blocks at bytes 2l, 2l + 1)
 #define NP_EA_MAX_KMERS 128
-#define NP_EA_CHUNK 32               // lattice rows of back-pointers staged in LDS per back-track pass (4 KB per wave)
+#define NP_EA_CHUNK 32               // back-pointer lines staged in LDS per back-track pass (4 KB per wave)
 
 namespace {
-
-struct vmax { float v; uint32_t from; };
-__device__ __forceinline__ void vit_step(vmax& m, float x, uint32_t i)
-{
-    m.v = x > m.v ? x : m.v;
-    m.from = (m.v == x) ? i : m.from;
-}
 
 __device__ __forceinline__ float readlane_f32(float v, int l)
 {
