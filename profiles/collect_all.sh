@@ -11,8 +11,8 @@ timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace_raw -o t -- python $R/b
 bash $R/profiles/collect_pmc.sh > $O/pmc.log 2>&1
 bash $R/profiles/collect_pmc_lds.sh >> $O/pmc.log 2>&1
 # 5. BASELINE configs 3 and 4: eventalign (from raw signal) and variants screening, with their reference-backed CPU legs
-timeout 600 python $R/tests/bench_eventalign.py --pool 256 --tile 64 --cpu-sample 256 > $O/bench_eventalign.json 2> $O/bench_eventalign.err
-timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace_ea -o t -- python $R/tests/bench_eventalign.py --pool 256 --tile 64 --cpu-sample 0 > $O/trace_ea.log 2>&1
+timeout 600 python $R/tests/bench_eventalign.py --pool 256 --tile 80 --cpu-sample 256 > $O/bench_eventalign.json 2> $O/bench_eventalign.err
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace_ea -o t -- python $R/tests/bench_eventalign.py --pool 256 --tile 80 --cpu-sample 0 > $O/trace_ea.log 2>&1
 timeout 400 python $R/tests/bench_variants.py > $O/bench_variants.json 2> $O/bench_variants.err
 bash $R/profiles/collect_pmc_eventalign.sh > $O/pmc_ea.txt 2>&1
 for d in trace trace_raw trace_ea; do f=$(find $O/$d -name "*results.db" | head -1); [ -n "$f" ] && python3 $R/profiles/summarize_rocpd.py $f > $O/$d.md; done
