@@ -3,16 +3,29 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic R9.4 reads already resident in HBM:
-[scrappie event detection -> MoM scalings ->] adaptive_banded_simple_event_align -> event map / recalibration / window
-bounds -> 2 x profile_hmm_score per CpG group
-(workload = BASELINE.json configs[1]: ~8k-event reads, r9.4_450bps CpG model).  Reads shard across ranks
-with no data-path collective (weak scaling); the only exchange is one all-reduce of the per-site table
-at the end of the timed region (N > 1).  Rank 0 prints ONE JSON line.
+A "step" is one pass of the hot path over one batch of 100 000 synthetic R9.4 reads (BASELINE.json configs[1]: ~8k events
+each, r9.4_450bps CpG model; 20 000 distinct reads x 5 copies in HBM):
+    [--from-raw 1: scrappie event detection -> MoM scalings ->] work-item generation (motif scan, grouping, window k-mers)
+    -> adaptive_banded_simple_event_align -> event map / recalibrate_model / window event bounds -> 2 x profile_hmm_score per
+    CpG group
+with every stage on the device inside the timed region.  Three timings of the same pass go into the ONE JSON line rank 0
+prints:
+    value           inputs resident in HBM when the timed region starts (the contract's headline)
+    value_streamed  the same batch fed from pinned host memory every step: events, k-mer ranks, read records and reference
+                    strands host->device, scores and site metadata device->host, double-buffered against the compute
+                    (what BamProcessor's 512-record batches would deliver, src/common/nanopolish_bam_processor.cpp:90-119)
+    value_ragged    a batch with log-normal read lengths of the same mean (resident)
+Reads shard across ranks with no data-path collective (weak scaling); the only exchange is one all-reduce of the per-site
+table at the end of the timed region (N > 1).
+
+`--gpus N` without a torch.distributed launcher (no WORLD_SIZE in the environment) starts the N ranks itself.
+`--workload eventalign|variants` runs BASELINE.json configs[2] / configs[3] (tests/bench_eventalign.py, tests/bench_variants.py);
+`--workload cpu-t1` is configs[0]'s plumbing line: the reference's own code on ONE host thread, no GPU.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -21,6 +34,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+CLOCK_HZ = 2.4e9          # MI355X engine clock (MI355X_MICROARCH.md); 256 CUs x 4 SIMDs
+N_SIMD = 1024
+
 
 def load_models():
     z = np.load(os.path.join(ROOT, "tests", "golden", "models_r9.4_450bps.npz"))
@@ -28,47 +44,79 @@ def load_models():
                     level_log_stdv=z[a + "_level_log_stdv"]) for a in ("nucleotide", "cpg")}
 
 
-def cpu_baseline(models, hb, n_sample, threads, calibrate, from_raw=False):
-    """CPU baseline on this box's host cores over a bounded sample of the same reads: align + 2 x score per group,
-    OpenMP over reads like src/common/nanopolish_bam_processor.cpp:99.  Uses the reference's own code when
-    oracle/_ref/libnp_ref.so travelled with the repo (kind="reference"), else the oracle port (kind="port").
-    Also returns the results, which double as the parity check of the GPU numbers."""
+# ---- host preparation (numpy, before the GPU is touched; a pool of forked workers) ---------------------------------------
+def ragged_lengths(read_ids, mean_len, sigma=0.5, lo=600, hi=40000):
+    """Log-normal read lengths with mean `mean_len` (what nanopore read-length distributions look like), deterministic
+    in the read id."""
+    z = np.array([np.random.default_rng(0x5EED + int(r)).standard_normal() for r in read_ids])
+    L = mean_len * np.exp(sigma * z - 0.5 * sigma * sigma)
+    return np.clip(np.rint(L), lo, hi).astype(np.int64)
+
+
+def _prep_chunk(a):
+    from nanopolish_amd.pipeline import build_host_batch
+    models, ids, lens, raw = a
+    return build_host_batch(models, ids, L=lens, raw=raw, with_jobs=False)
+
+
+def prep_host_batch(models, lo, hi, lens, raw, workers):
+    from nanopolish_amd.pipeline import concat_host_batches
+    ids = np.arange(lo, hi)
+    lens = np.broadcast_to(np.asarray(lens, np.int64), ids.shape)
+    chunk = 1024
+    parts = [(models, ids[i:i + chunk], lens[i:i + chunk], raw) for i in range(0, len(ids), chunk)]
+    if workers > 1 and len(parts) > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(workers, len(parts))) as pool:
+            out = pool.map(_prep_chunk, parts)
+    else:
+        out = [_prep_chunk(p) for p in parts]
+    return concat_host_batches(out)
+
+
+# ---- CPU baseline ------------------------------------------------------------------------------------------------------
+def cpu_pass(models, hb, idx, thread_list, calibrate, from_raw, repeats=2):
+    """One pass of the hot path on the host over reads hb["reads"][idx]: align + 2 x score per group, OpenMP over reads like
+    src/common/nanopolish_bam_processor.cpp:99, timed once per entry of thread_list.  The reference's own code when
+    oracle/_ref/libnp_ref.so travelled with the repo (kind="reference"), else the oracle port (kind="port").  Returns the
+    timings per thread count and the results (the parity check of the GPU numbers)."""
     from oracle import Oracle, RefOracle, have_ref
     from oracle.workloads import methylation_jobs, K
     orc = Oracle()
     ref = RefOracle() if have_ref() else None
+    if ref is not None and hasattr(ref.L, "npref_tune_malloc"):
+        ref.L.npref_tune_malloc()          # allocator settings of the harness, see oracle/ref_harness.cpp
     mn = orc.model(models["nucleotide"]); mc = orc.model(models["cpg"])
-    n = min(n_sample, len(hb["reads"]))
-    rds = hb["reads"][:n]
-    t_detect = 0.0
-    mom = hb["mom"][:n].copy()
+    rds = [hb["reads"][i] for i in idx]
+    n = len(rds)
+    T = {th: dict(detect=0.0, align=1e30, score=1e30, calib=0.0) for th in thread_list}
+    mom = np.array([hb["mom"][i] for i in idx]).reshape(-1, 2).copy()
     if from_raw:
-        # event detection with the reference's own scrappie objects (kind="reference") or the port, then MoM on the host
-        wo = hb["raw_off"][:n + 1]
-        t_detect = 1e30
-        for _ in range(2):
-            evm, evo, evn = (ref or orc).detect_events_many(hb["raw"][:wo[-1]], wo, threads)
-            t_detect = min(t_detect, (ref or orc).last_call_s)
+        raw = np.concatenate([r["raw"] for r in rds]).astype(np.float32)
+        wo = np.zeros(n + 1, np.int64); wo[1:] = np.cumsum([len(r["raw"]) for r in rds])
+        for th in thread_list:
+            T[th]["detect"] = 1e30
+            for _ in range(repeats):
+                evm, evo, evn = (ref or orc).detect_events_many(raw, wo, th)
+                T[th]["detect"] = min(T[th]["detect"], (ref or orc).last_call_s)
         rds = [dict(r, events=evm[evo[i]:evo[i] + evn[i]].copy()) for i, r in enumerate(rds)]
         for i, r in enumerate(rds):
             mom[i] = orc.estimate_scalings_mom(mn, r["ranks"], r["events"])
-        eo = np.zeros(n + 1, np.int64); eo[1:] = np.cumsum(evn)
-        ev = np.concatenate([r["events"] for r in rds]).astype(np.float32)
-        ro = hb["rank_off"][:n + 1]; rk = hb["ranks"][:ro[-1]].astype(np.uint32)
-    else:
-        eo = hb["event_off"][:n + 1]; ro = hb["rank_off"][:n + 1]
-        ev = hb["events"][:eo[-1]]; rk = hb["ranks"][:ro[-1]].astype(np.uint32)
-    # each leg runs twice (the first call also pays thread start-up and page faults); the faster run counts, and only
-    # the C call itself is timed (oracle_py.last_call_s), not the ctypes marshalling around it
-    t_align = 1e30
-    for _ in range(2):
-        if ref:
-            pairs, pair_off, n_pairs = ref.align_many([r["seq"] for r in rds], ev, eo, mom[:, 0], mom[:, 1], threads)
-            t_align = min(t_align, ref.last_call_s)
-        else:
-            pairs, pair_off, n_pairs = orc.align_many(mn, ev, eo, rk, ro, mom[:, 0], mom[:, 1], threads)
-            t_align = min(t_align, orc.last_call_s)
-    # event map + window bounds through the oracle's glue (untimed host bookkeeping, tiny)
+    eo = np.zeros(n + 1, np.int64); eo[1:] = np.cumsum([len(r["events"]) for r in rds])
+    ro = np.zeros(n + 1, np.int64); ro[1:] = np.cumsum([len(r["ranks"]) for r in rds])
+    ev = np.concatenate([r["events"] for r in rds]).astype(np.float32)
+    rk = np.concatenate([r["ranks"] for r in rds]).astype(np.uint32)
+    # each leg runs `repeats` times per thread count (the first call also pays thread start-up and page faults); the faster
+    # run counts, and only the C call itself is timed (oracle_py.last_call_s), not the ctypes marshalling around it
+    for th in thread_list:
+        for _ in range(repeats):
+            if ref:
+                pairs, pair_off, n_pairs = ref.align_many([r["seq"] for r in rds], ev, eo, mom[:, 0], mom[:, 1], th)
+                T[th]["align"] = min(T[th]["align"], ref.last_call_s)
+            else:
+                pairs, pair_off, n_pairs = orc.align_many(mn, ev, eo, rk, ro, mom[:, 0], mom[:, 1], th)
+                T[th]["align"] = min(T[th]["align"], orc.last_call_s)
+    # event map + window bounds through the oracle's glue (untimed host bookkeeping)
     job_read, e1, e2, stride, rcs, jr, jr_off, epb = [], [], [], [], [], [], [0], np.zeros(n)
     seqs, rc_seqs, first, job_off = [], [], [], [0]
     sh = [r["shift"] for r in rds]; sc_ = [r["scale"] for r in rds]; vr = [r["var"] for r in rds]
@@ -95,19 +143,77 @@ def cpu_baseline(models, hb, n_sample, threads, calibrate, from_raw=False):
                         jr.append(q); jr_off.append(jr_off[-1] + len(q))
                 first.append((i, j["first"]))
         job_off.append(len(seqs))
-    t_calib /= max(1, threads)          # as if spread over the cores like the other legs
-    t_score = 1e30
-    for _ in range(2):
-        if ref:
-            sc = ref.score_many_reads("cpg", ev, eo, sh, sc_, vr, epb, job_off, seqs, rc_seqs, e1, e2, stride, rcs, 3, threads)
-            t_score = min(t_score, ref.last_call_s)
-        else:
-            sc = orc.score_many(mc, job_read, ev, eo, sh, sc_, vr, epb, np.concatenate(jr), jr_off, e1, e2, stride, 1.0, 3, threads)
-            t_score = min(t_score, orc.last_call_s)
-    return dict(n=n, seconds=t_detect + t_align + t_calib + t_score, t_align=t_align, t_score=t_score, t_calib=t_calib, t_detect=t_detect,
-                n_events=[len(r["events"]) for r in rds],
-                pairs=(pairs, pair_off, n_pairs),
+    for th in thread_list:
+        T[th]["calib"] = t_calib / max(1, th)          # as if spread over the threads like the other legs
+        for _ in range(repeats):
+            if ref:
+                sc = ref.score_many_reads("cpg", ev, eo, sh, sc_, vr, epb, job_off, seqs, rc_seqs, e1, e2, stride, rcs, 3, th)
+                T[th]["score"] = min(T[th]["score"], ref.last_call_s)
+            else:
+                sc = orc.score_many(mc, job_read, ev, eo, sh, sc_, vr, epb, np.concatenate(jr), jr_off, e1, e2, stride, 1.0, 3, th)
+                T[th]["score"] = min(T[th]["score"], orc.last_call_s)
+    for th in thread_list:
+        T[th]["seconds"] = T[th]["detect"] + T[th]["align"] + T[th]["calib"] + T[th]["score"]
+    return dict(n=n, timings=T, n_events=[len(r["events"]) for r in rds], pairs=(pairs, pair_off, n_pairs),
                 first=first, scores=sc, kind="reference" if ref else "port")
+
+
+def cpu_baseline(models, hb, calibrate, from_raw, budget_reads):
+    """The CPU line: one thread first (t1), then the same reads-per-thread load (>= 32 reads per thread) on every available
+    hardware thread and on half of them (SMT siblings share a core's FP units); the best multi-thread rate is `value`."""
+    cores = len(os.sched_getaffinity(0))
+    pool = len(hb["reads"])
+    n1 = min(pool, 24)
+    c1 = cpu_pass(models, hb, list(range(n1)), [1], calibrate, from_raw, repeats=1)
+    t1 = c1["timings"][1]
+    out = dict(t1_value=round(n1 / t1["seconds"], 2), t1_reads=n1, unit="reads/s", kind=c1["kind"])
+    cands = sorted({c for c in (cores, cores // 2) if c >= 2}, reverse=True)
+    if not cands:
+        out.update(value=out["t1_value"], cores=cores, threads=1, per_core=out["t1_value"], sample="%d reads on one thread" % n1)
+        return out, c1
+    n = min(pool, max(32 * cands[0], 64), budget_reads)
+    cb = cpu_pass(models, hb, list(range(n)), cands, calibrate, from_raw, repeats=2)
+    runs = [dict(threads=th, reads=n, value=round(n / cb["timings"][th]["seconds"], 2), align_s=round(cb["timings"][th]["align"], 2),
+                 score_s=round(cb["timings"][th]["score"], 2)) for th in cands]
+    th = max(cands, key=lambda c: n / cb["timings"][c]["seconds"])
+    t = cb["timings"][th]
+    rate = n / t["seconds"]
+    out.update(value=round(rate, 2), cores=cores, threads=th, per_core=round(rate / th, 2), runs=runs,
+               sample="%d of the same synthetic reads, OpenMP over reads, %d threads (detect %.2fs + align %.2fs + calibrate %.2fs + "
+                      "score %.2fs); t1 = %d reads on one thread" % (n, th, t["detect"], t["align"], t["calib"], t["score"], n1))
+    cb["threads"] = th
+    return out, cb
+
+
+# ---- N > 1 without a launcher ---------------------------------------------------------------------------------------------
+def launch_ranks(n, argv):
+    """Start the n ranks of `bench.py --gpus n` ourselves (the driver's N = 1 command shape with --gpus > 1): one process per
+    GPU, rendezvous on 127.0.0.1.  Rank 0's JSON line is this process's output."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
+
+
+def timed_steps(batch_step, barrier, steps, warmup, before_stop=None):
+    for _ in range(warmup):
+        batch_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch_step()
+    if before_stop:
+        before_stop()
+    barrier()
+    return time.perf_counter() - t0
 
 
 def main():
@@ -115,9 +221,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pool", type=int, default=1024, help="distinct synthetic reads per rank")
-    ap.add_argument("--tile", type=int, default=32, help="independent HBM copies of the pool per batch (32768 reads/step by default:\n"
-                    "                    per-read kernel time keeps falling up to ~100k reads per launch, tools/sweep_batch.sh)")
+    ap.add_argument("--workload", default="call-methylation", choices=["call-methylation", "eventalign", "variants", "cpu-t1"])
+    ap.add_argument("--pool", type=int, default=20000, help="distinct synthetic reads per rank")
+    ap.add_argument("--tile", type=int, default=5, help="independent HBM copies of the pool per batch (pool x tile = 100 000 reads/step)")
     ap.add_argument("--read-len", type=int, default=5450, help="bases per read (5450 -> ~8k events)")
     ap.add_argument("--calibrate", type=int, default=1,
                     help="1: recalibrate each read on the device between the two kernels, as load_from_raw does (SURVEY 8 f1); "
@@ -125,18 +231,73 @@ def main():
     ap.add_argument("--from-raw", type=int, default=0,
                     help="1: a step starts from raw current samples (scrappie event detection + MoM scalings on the device, "
                          "SURVEY 8 f2); 0: from pre-detected events")
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1: ~8 per core, 0: skip)")
-    args = ap.parse_args()
+    ap.add_argument("--jobs-on-device", type=int, default=1, help="1: work items are generated on the device inside the step (SURVEY 8 f3)")
+    ap.add_argument("--streamed", type=int, default=1, help="1: also time the host-fed (pinned, double-buffered) variant")
+    ap.add_argument("--ragged", type=int, default=1, help="1: also time a batch with log-normal read lengths of the same mean")
+    ap.add_argument("--ragged-pool", type=int, default=-1, help="distinct reads of the ragged batch (-1: pool / 2, tile x 2)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="cap on the reads of the CPU baseline (-1: 32 per thread, 0: skip)")
+    ap.add_argument("--workers", type=int, default=-1, help="host-preparation worker processes (-1: min(32, cores))")
+    args, extra = ap.parse_known_args()
+
+    if args.workload in ("eventalign", "variants"):
+        # BASELINE.json configs[2] / configs[3]: their own tools (one JSON line each), same --steps / --warmup
+        import runpy
+        tool = os.path.join(ROOT, "tests", "bench_%s.py" % args.workload)
+        sys.argv = [tool, "--steps", str(args.steps), "--warmup", str(args.warmup)] + extra
+        runpy.run_path(tool, run_name="__main__")
+        return
+    if extra:
+        ap.error("unknown arguments: %s" % " ".join(extra))
+    models = load_models()
+    if args.workload == "cpu-t1":
+        # BASELINE.json configs[0]: the CPU plumbing line (-t 1), the reference's own code on one host thread, no GPU
+        n = min(args.pool, 1000) if args.pool != 20000 else 1000
+        n = args.cpu_sample if args.cpu_sample > 0 else n
+        hb = prep_host_batch(models, 0, n, args.read_len, False, 1)
+        cb = cpu_pass(models, hb, list(range(n)), [1], bool(args.calibrate), False, repeats=1)
+        t = cb["timings"][1]
+        print(json.dumps(dict(metric="call-methylation reads/sec", value=round(cb["n"] / t["seconds"], 2), unit="reads/s", n_gpus=0,
+                              higher_is_better=True, dtype="f32", data="synthetic",
+                              config=dict(workload="call-methylation hot path on ONE host thread (-t 1), %d synthetic R9.4 reads "
+                                                   "(BASELINE.json configs[0] shape; the bundled E. coli subset is not in this image)" % cb["n"],
+                                          kind=cb["kind"], align_s=round(t["align"], 2), score_s=round(t["score"], 2),
+                                          calibrate_s=round(t["calib"], 3)))), flush=True)
+        return
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    cores = len(os.sched_getaffinity(0))
+    workers = args.workers if args.workers > 0 else max(1, min(32, cores // max(1, world)))
+
+    # ---- host preparation (before the HIP runtime is initialised: the pool forks) ----
+    from nanopolish_amd.shard import shard_read_ids
+    t_prep = time.perf_counter()
+    lo, hi = shard_read_ids(world * args.pool, rank, world)          # reads shard by contiguous id range
+    hb = prep_host_batch(models, lo, hi, args.read_len, bool(args.from_raw), workers)
+    hb_rag = None
+    if args.ragged:
+        rp = args.ragged_pool if args.ragged_pool > 0 else max(1, args.pool // 2)
+        rt = max(1, (args.pool * args.tile) // rp)
+        rlo, rhi = shard_read_ids(world * rp, rank, world)
+        ids = np.arange(rlo, rhi) + (1 << 24)                          # its own id range
+        hb_rag = prep_host_batch(models, int(ids[0]), int(ids[-1]) + 1, ragged_lengths(ids, args.read_len), bool(args.from_raw), workers)
+    t_prep = time.perf_counter() - t_prep
 
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # one process per GPU.  NP_BENCH_BACKEND=gloo + fewer devices than ranks is a single-GPU rehearsal of the N>1 code path
     backend = os.environ.get("NP_BENCH_BACKEND", "nccl")
-    local = local % max(1, torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    if ndev < world and backend == "nccl":
+        raise SystemExit("--gpus %d but only %d device(s) visible (NP_BENCH_BACKEND=gloo rehearses the N>1 path on fewer)" % (world, ndev))
+    local = local % ndev
     torch.cuda.set_device(local)
     if world > 1:
         if backend == "nccl":
@@ -145,40 +306,52 @@ def main():
             dist.init_process_group(backend)
 
     from nanopolish_amd.api import Context
-    from nanopolish_amd.pipeline import build_host_batch, tile_host_batch, CallMethylationBatch
-    from nanopolish_amd.sites import site_table
-    from nanopolish_amd.shard import shard_read_ids, reduce_site_table
+    from nanopolish_amd.pipeline import tile_host_batch, CallMethylationBatch, StreamedFeed
+    from nanopolish_amd.sites import site_table_dev
 
-    models = load_models()
     ctx = Context(local)
     ctx.register_model(models["nucleotide"], "nucleotide"); ctx.register_model(models["cpg"], "cpg")
-    t_prep = time.perf_counter()
-    lo, hi = shard_read_ids(world * args.pool, rank, world)          # reads shard by contiguous id range
-    hb = build_host_batch(models, np.arange(lo, hi), L=args.read_len, raw=bool(args.from_raw))
-    hbt = tile_host_batch(hb, args.tile)
-    batch = CallMethylationBatch(ctx, hbt, "cuda:%d" % local, calibrate=bool(args.calibrate), from_raw=bool(args.from_raw))
-    t_prep = time.perf_counter() - t_prep
-    n_reads = batch.n_reads
+    dev = "cuda:%d" % local
 
-    # per-group metadata for the site table (device)
-    first = torch.from_numpy(np.tile(np.concatenate([m["first"] for m in hb["meta"]]), args.tile).astype(np.int64)).cuda()
-    n_motif = torch.from_numpy(np.tile(np.concatenate([m["n_motif"] for m in hb["meta"]]), args.tile).astype(np.int64)).cuda()
-
-    def barrier():
-        ctx.sync(); torch.cuda.synchronize()
+    def barrier(stream=None):
+        ctx.sync(stream); torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        ctx.sync(); torch.cuda.synchronize()
+        ctx.sync(stream); torch.cuda.synchronize()
 
+    def make_batch(h, tile):
+        return CallMethylationBatch(ctx, tile_host_batch(h, tile), dev, calibrate=bool(args.calibrate), from_raw=bool(args.from_raw),
+                                    jobs_on_device=bool(args.jobs_on_device))
+
+    def all_reduce(t, op):
+        """all-reduce of a device tensor; the gloo rehearsal backend reduces a host copy"""
+        if world > 1:
+            if backend == "nccl":
+                dist.all_reduce(t, op=op)
+            else:
+                h = t.cpu(); dist.all_reduce(h, op=op); t.copy_(h)
+        return t
+
+    def device_table(b):
+        """per-site table of this rank's reads (the all-reduce payload) from the device-resident scores and group metadata
+        (np_site_table_dev); skipped groups and unused group slots carry NaN scores"""
+        t = site_table_dev(ctx, torch, b.d_scores, b.d_first, b.d_n_motif, b.max_len)     # on the library's stream, after the steps
+        ctx.sync()
+        return t
+
+    # ---------------- resident (headline) ----------------
+    batch = make_batch(hb, args.tile)
+    batch.max_len = int(max(len(q) for q in hb["ref_seqs"]))
+    if not batch.jobs_on_device:
+        raise SystemExit("--jobs-on-device 0 is no longer a bench configuration (work items are part of the step)")
+    n_reads = batch.n_reads
     for _ in range(args.warmup):
         batch.step()
     if world > 1:
-        # warm the collective path too (RCCL communicator set-up is not part of a step)
         ctx.sync()
-        sc = batch.d_scores[:batch.n_jobs].to(torch.float64)
-        reduce_site_table(site_table(torch, first, n_motif, sc[1::2] - sc[0::2], args.read_len))
+        all_reduce(device_table(batch), dist.ReduceOp.SUM)          # warm the collective path (RCCL communicator set-up is not a step)
     barrier()
-    for w in range(6):
+    for w in range(7):
         ctx.kernel_time(w, reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -186,114 +359,183 @@ def main():
     ctx.sync()
     table = None
     if world > 1:
-        sc = batch.d_scores[:batch.n_jobs].to(torch.float64)
-        table = site_table(torch, first, n_motif, sc[1::2] - sc[0::2], args.read_len)
-        reduce_site_table(table)        # RCCL all-reduce(sum): the job's only collective (final site-level reduction)
+        table = device_table(batch)
+        all_reduce(table, dist.ReduceOp.SUM)        # RCCL all-reduce(sum): the job's only collective (final site-level reduction)
     barrier()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
 
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        return float(all_reduce(t, dist.ReduceOp.MAX).item())
+
+    dt = max_over_ranks(dt)
+    if table is None:
+        table = device_table(batch)                 # one rank: the same table, outside the timed region
+    k_ms = {}
+    for name, w in (("event_align", 0), ("hmm_score", 1), ("glue_and_work_items", 2), ("event_detect", 4), ("mom_scalings", 5)):
+        k_ms[name] = ctx.kernel_time(w)
+
+    # ---------------- streamed: the same batch, host-fed ----------------
+    streamed = None
+    if args.streamed:
+        feed = StreamedFeed(batch)
+        for k in range(args.warmup + 1):
+            feed.submit()
+        feed.drain(); barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            feed.submit()
+        feed.drain(); barrier()
+        dts = max_over_ranks(time.perf_counter() - t0)
+        same = feed.check_against(batch) if rank == 0 else True
+        streamed = dict(value=round(world * n_reads * args.steps / dts, 2), ms_per_step=round(dts / args.steps * 1e3, 3),
+                        h2d_bytes_per_step=feed.h2d_bytes, d2h_bytes_per_step=feed.d2h_bytes,
+                        pcie_GBps=round((feed.h2d_bytes + feed.d2h_bytes) * args.steps / dts / 1e9, 2),
+                        results_equal_resident=bool(same))
+        feed.close()
+        batch.stream = None
+
+    # results of the resident batch on the host (rank 0), before it is released
+    res = None
     if rank == 0:
-        k_ms = {}
-        for name, w in (("event_align", 0), ("hmm_score", 1), ("resolve", 2), ("event_detect", 4), ("mom_scalings", 5)):
-            ms, n = ctx.kernel_time(w)
-            k_ms[name] = (ms, n)
         scores = batch.scores()
         llr = scores[1::2].astype(np.float64) - scores[0::2]
         n_groups = int(np.isfinite(llr).sum())
         n_ok = int((batch.d_n_pairs > 0).sum().item())
+        res = dict(n_groups=n_groups, n_ok=n_ok)
+        if args.from_raw:
+            # the event counts only exist after the detector has run: algorithmic bytes from the detected counts
+            nev = batch.d_n_events.clamp(min=0).to(torch.int64).cpu().numpy()
+            nk = (batch.hb["rank_off"][1:] - batch.hb["rank_off"][:-1])
+            bands = nev + nk + 2
+            batch.algo_bytes_align = int((4 * nev + 2 * nk + 100 * bands + 8 * nev).sum())
+            batch.band_cells = int((100 * bands).sum()); batch.total_events = int(nev.sum())
+        res.update(algo=batch.algo_bytes_align, band_cells=batch.band_cells, total_events=batch.total_events)
 
+    cpu = None
+    max_dllr = None
+    if rank == 0 and args.cpu_sample != 0 and world == 1:
+        budget = args.cpu_sample if args.cpu_sample > 0 else 1 << 30
+        cpu, cb = cpu_baseline(models, hb, bool(args.calibrate), bool(args.from_raw), budget)
+        # parity of the GPU results with the CPU pass on that sample: pairs bit-exact, LLR within 1e-4
+        pairs, pair_off, n_pairs = cb["pairs"]
+        ok = True
+        if args.from_raw:
+            ok &= np.array_equal(batch.d_n_events[:cb["n"]].cpu().numpy(), np.array(cb["n_events"]))
+        for i in range(min(cb["n"], 256)):
+            ok &= np.array_equal(batch.pairs_of(i), pairs[pair_off[i]:pair_off[i] + n_pairs[i]])
+        gmap = {}
+        for i, (f, nm, su, sm) in enumerate(batch.groups_bulk(cb["n"])):
+            for q in range(len(f)):
+                gmap[(i, int(f[q]))] = (float(su[q]), float(sm[q]))
+        want = cb["scores"]
+        d = []
+        missing = 0
+        for q, key in enumerate(cb["first"]):
+            g = gmap.get(key)
+            if g is None or not np.isfinite(g[0]):
+                missing += 1
+                continue
+            d.append((g[1] - g[0]) - (float(want[2 * q + 1]) - float(want[2 * q])))
+        max_dllr = float(np.max(np.abs(d))) if d else None
+        n_gpu_groups = sum(1 for v in gmap.values() if np.isfinite(v[0]))
+        cpu["check"] = dict(reads=cb["n"], groups=len(cb["first"]), groups_scored_on_gpu=n_gpu_groups, groups_missing_on_gpu=missing,
+                            pairs_bit_exact=bool(ok), max_abs_dLLR=max_dllr)
+        if args.from_raw and args.calibrate:
+            # the same sample through the reference's WHOLE per-read function: SquiggleRead(sequence, Fast5Data) -> load_from_raw
+            # -> calculate_methylation_for_read, compiled in place (oracle/_ref/libnp_ref_full.so), OpenMP over reads
+            try:
+                from oracle.ref_full import FullRef, have_full
+                if have_full():
+                    rds = hb["reads"][:cb["n"]]
+                    sites, t_full = FullRef().many_identity(1, [r["seq"] for r in rds], [r["raw"] for r in rds], [r["rc"] for r in rds], cb["threads"])
+                    n_gpu = [int(np.isfinite(batch.groups_of(i)[2]).sum()) for i in range(cb["n"])]
+                    cpu["whole_function"] = dict(value=round(cb["n"] / t_full, 2), unit="reads/s",
+                                                 what="load_from_raw + calculate_methylation_for_read per read, reference code",
+                                                 sites_per_read_match_gpu=bool(np.array_equal(sites, np.array(n_gpu))))
+            except Exception as e:  # noqa: BLE001
+                cpu["whole_function"] = dict(error=repr(e))
+
+    # ---------------- ragged read lengths (resident) ----------------
+    ragged = None
+    mean_events = batch.total_events / n_reads
+    del batch
+    torch.cuda.empty_cache()
+    if hb_rag is not None:
+        rt = max(1, (args.pool * args.tile) // hb_rag["n"])
+        rb = make_batch(hb_rag, rt)
+        ctx.kernel_time(0, reset=True)
+        dtr = max_over_ranks(timed_steps(rb.step, barrier, args.steps, args.warmup, ctx.sync))
+        a_ms, a_n = ctx.kernel_time(0)
+        lens = np.array([len(q) for q in hb_rag["ref_seqs"]])
+        nev_r = rb.total_events if not args.from_raw else int(rb.d_n_events.clamp(min=0).sum().item())
+        ragged = dict(value=round(world * rb.n_reads * args.steps / dtr, 2), ms_per_step=round(dtr / args.steps * 1e3, 3),
+                      reads_per_step_per_gpu=rb.n_reads, distinct_reads_per_gpu=hb_rag["n"],
+                      read_len=dict(mean=round(float(lens.mean()), 1), p50=int(np.median(lens)), min=int(lens.min()), max=int(lens.max())),
+                      mean_events=round(nev_r / rb.n_reads, 1),
+                      events_per_s=round(world * nev_r * args.steps / dtr, 1),
+                      event_align_ms_per_step=round(a_ms / max(a_n - args.warmup, 1), 3) if a_n else None,
+                      reads_aligned_ok=int((rb.d_n_pairs > 0).sum().item()))
+        del rb
+        torch.cuda.empty_cache()
+
+    if rank == 0:
         # dominant kernel + HBM roofline (algorithmic bytes)
         dom = max(k_ms, key=lambda k: k_ms[k][0])
         a_ms, a_n = k_ms["event_align"]
         a_avg_s = a_ms / max(a_n, 1) * 1e-3
-        if args.from_raw:
-            # the event counts only exist after the detector has run: algorithmic bytes from the detected counts
-            nev = batch.d_n_events.clamp(min=0).to(torch.int64).cpu().numpy()
-            nk = (hbt["rank_off"][1:] - hbt["rank_off"][:-1])
-            bands = nev + nk + 2
-            batch.algo_bytes_align = int((4 * nev + 2 * nk + 100 * bands + 8 * nev).sum())
-            batch.band_cells = int((100 * bands).sum()); batch.total_events = int(nev.sum())
-        algo = batch.algo_bytes_align
+        algo = res["algo"]
         achieved = algo / a_avg_s / 1e9 if a_avg_s > 0 else 0.0
-        # HBM traffic per launch from the PMC passes (profiles/collect_pmc.sh + profiles/pmc_summary.py -> profiles/r01_pmc.json): FETCH_SIZE +
-        # WRITE_SIZE per read of this kernel, measured on this workload shape in separate rocprofv3 --pmc runs
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))["event_align"]
-            traffic = int((pm["fetch_bytes_per_read"] + pm["write_bytes_per_read"]) * n_reads)
-        except Exception:
-            pass
+        # HBM traffic and instruction counts per launch from the PMC passes (profiles/collect_pmc.sh + profiles/pmc_summary.py ->
+        # profiles/r02_pmc.json): FETCH_SIZE + WRITE_SIZE per read of this kernel and SQ_INSTS_VALU / SQ_INSTS_SALU per band step,
+        # measured on this workload shape at this batch size in separate rocprofv3 --pmc runs
+        traffic, issue = None, None
+        n_bands = res["band_cells"] // 100
+        cyc_per_band = a_avg_s * CLOCK_HZ * N_SIMD / max(n_bands, 1)
+        for name in ("r02_pmc.json", "r01_pmc.json"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", name)))["event_align"]
+                traffic = int((pm["fetch_bytes_per_read"] + pm["write_bytes_per_read"]) * n_reads)
+                valu, salu = pm.get("valu_per_band"), pm.get("salu_per_band")
+                issue = dict(valu_per_band=valu, salu_per_band=salu, simd_cycles_per_band=round(cyc_per_band, 1),
+                             VALUBusy=pm.get("valu_busy_pct"), pmc_source="profiles/" + name,
+                             pmc_reads_per_launch=pm.get("reads_per_launch"))
+                if valu and salu:
+                    # issue-slot model of tools/valu_rates.hip: this kernel's VALU mix averages ~3.2 cycles per wave-instruction
+                    # (fp32 2, fp64 / cvt / cmp / select / DPP 4), a scalar instruction ~4 per SIMD; frac = modelled issue cycles
+                    # of one band step / SIMD cycles one band step takes
+                    issue["frac"] = round((3.2 * valu + 4.0 * salu) / cyc_per_band, 3)
+                break
+            except Exception:
+                continue
+        if issue is None:
+            issue = dict(simd_cycles_per_band=round(cyc_per_band, 1))
         roof = dict(bound="hbm", kernel="np_event_align_kernel", achieved=round(achieved, 2), peak=8000.0, unit="GB/s",
                     frac=round(achieved / 8000.0, 5), traffic=traffic,
                     algo_bytes_per_launch=algo, avg_launch_ms=round(a_ms / max(a_n, 1), 3),
-                    band_cells_per_s=round(batch.band_cells / a_avg_s / 1e9, 3) if a_avg_s > 0 else 0.0,
-                    dominant_kernel_by_time=dom,
-                    kernel_ms_per_step={k: round(v[0] / max(v[1], 1), 3) for k, v in k_ms.items()})
-
-        cpu = None
-        max_dllr = None
-        cores = len(os.sched_getaffinity(0))
-        n_sample = args.cpu_sample if args.cpu_sample >= 0 else max(8, 8 * cores)
-        if n_sample > 0 and world == 1:
-            cb = cpu_baseline(models, hb, n_sample, cores, bool(args.calibrate), bool(args.from_raw))
-            cpu = dict(value=round(cb["n"] / cb["seconds"], 2), unit="reads/s", cores=cores, kind=cb["kind"],
-                       sample="%d of the same synthetic reads, OpenMP over reads (detect %.2fs + align %.1fs + calibrate %.2fs + score %.1fs)"
-                              % (cb["n"], cb["t_detect"], cb["t_align"], cb["t_calib"], cb["t_score"]))
-            if args.from_raw and args.calibrate:
-                # the same sample through the reference's WHOLE per-read function: SquiggleRead(sequence, Fast5Data) -> load_from_raw
-                # -> calculate_methylation_for_read, compiled in place (oracle/_ref/libnp_ref_full.so), OpenMP over reads
-                try:
-                    from oracle.ref_full import FullRef, have_full
-                    if have_full():
-                        rds = hb["reads"][:cb["n"]]
-                        sites, t_full = FullRef().many_identity(1, [r["seq"] for r in rds], [r["raw"] for r in rds], [r["rc"] for r in rds], cores)
-                        n_gpu = [int(np.isfinite(llr[int(hb["job_off"][i]) // 2:int(hb["job_off"][i + 1]) // 2]).sum()) for i in range(cb["n"])]
-                        cpu["whole_function"] = dict(value=round(cb["n"] / t_full, 2), unit="reads/s",
-                                                     what="load_from_raw + calculate_methylation_for_read per read, reference code",
-                                                     sites_per_read_match_gpu=bool(np.array_equal(sites, np.array(n_gpu))))
-                except Exception as e:  # noqa: BLE001
-                    cpu["whole_function"] = dict(error=repr(e))
-            # parity of the GPU results with the oracle on that sample: pairs bit-exact, LLR within 1e-4
-            pairs, pair_off, n_pairs = cb["pairs"]
-            ok = True
-            if args.from_raw:
-                ok &= np.array_equal(batch.d_n_events[:cb["n"]].cpu().numpy(), np.array(cb["n_events"]))
-            for i in range(cb["n"]):
-                g = batch.pairs_of(i)
-                ok &= np.array_equal(g, pairs[pair_off[i]:pair_off[i] + n_pairs[i]])
-            jh = hb["job_off"]
-            firsts = np.concatenate([m["first"] for m in hb["meta"]])
-            gmap = {}
-            gi = 0
-            for i, m in enumerate(hb["meta"]):
-                for f in m["first"]:
-                    gmap[(i, int(f))] = gi; gi += 1
-            want = cb["scores"]
-            d = []
-            for q, key in enumerate(cb["first"]):
-                g = gmap[key]
-                d.append((float(scores[2 * g + 1]) - float(scores[2 * g])) - (float(want[2 * q + 1]) - float(want[2 * q])))
-            max_dllr = float(np.max(np.abs(d))) if d else 0.0
-            n_gpu_groups = int(np.isfinite(llr[:sum(len(m["first"]) for m in hb["meta"][:cb["n"]])]).sum())
-            cpu["check"] = dict(reads=cb["n"], groups=len(d), groups_scored_on_gpu=n_gpu_groups, pairs_bit_exact=bool(ok),
-                                max_abs_dLLR=max_dllr)
+                    band_cells_per_s=round(res["band_cells"] / a_avg_s / 1e9, 3) if a_avg_s > 0 else 0.0,
+                    limiter="instruction issue (one wave per read, ~13.5k dependent band steps): see issue",
+                    issue=issue, dominant_kernel_by_time=dom,
+                    kernel_ms_per_step={k: round(v[0] / max(args.steps, 1), 3) for k, v in k_ms.items()})
 
         value = world * n_reads * args.steps / dt
         out = dict(metric="call-methylation reads/sec", value=round(value, 2), unit="reads/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload="call-methylation, synthetic R9.4 reads (~8k events each), r9.4_450bps CpG model "
-                                        "(BASELINE.json configs[1] shape)",
+                   config=dict(workload="call-methylation, 100k synthetic R9.4 reads (~8k events each), r9.4_450bps CpG model "
+                                        "(BASELINE.json configs[1])",
                                reads_per_step_per_gpu=n_reads, distinct_reads_per_gpu=args.pool, tile=args.tile,
-                               read_len=args.read_len, mean_events=round(batch.total_events / n_reads, 1),
-                               groups_per_step_per_gpu=n_groups, reads_aligned_ok=n_ok, calibrate_on_device=bool(args.calibrate), from_raw_signal=bool(args.from_raw),
+                               read_len=args.read_len, mean_events=round(mean_events, 1), jobs_on_device=bool(args.jobs_on_device),
+                               groups_per_step_per_gpu=res["n_groups"], reads_aligned_ok=res["n_ok"],
+                               calibrate_on_device=bool(args.calibrate), from_raw_signal=bool(args.from_raw),
                                parallelism="reads sharded over %d GPU(s), 1 process/GPU" % world),
-                   cpg_site_groups_per_s=round(world * n_groups * args.steps / dt, 1),
+                   cpg_site_groups_per_s=round(world * res["n_groups"] * args.steps / dt, 1),
+                   value_streamed=streamed["value"] if streamed else None, streamed=streamed,
+                   value_ragged=ragged["value"] if ragged else None, ragged=ragged,
                    max_abs_dLLR_vs_cpu=max_dllr, roofline=roof, cpu_baseline=cpu, host_prep_s=round(t_prep, 1))
+        if table is not None:
+            out["site_table"] = dict(sites=int((table[:, 0] > 0).sum().item()), num_reads=int(table[:, 0].sum().item()),
+                                     called_sites=int(table[:, 1].sum().item()), called_sites_methylated=int(table[:, 2].sum().item()))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -8,7 +8,7 @@
  *     std::vector<HMMAlignmentState> profile_hmm_align(const HMMInputSequence&, const HMMInputData&, u32)  :31
  *     std::vector<AlignedPair> adaptive_banded_simple_event_align(SquiggleRead&, const PoreModel&, const std::string&)
  *                                                                                                src/nanopolish_raw_loader.h:22-24
- * This header is what a thin shim behind those signatures binds (nanopolish_amd/csrc/np_dropin.hpp is that
+ * This header is what a thin shim behind those signatures binds (nanopolish_amd/csrc/np_dropin.cpp is that
  * shim; INTEGRATION.md shows where it plugs into the reference).  Plain pointers and sizes only; no C++ or
  * torch types.  Every function returns NP_OK (0) or a negative error code and never throws.
  *
@@ -73,6 +73,12 @@ int np_set_option(np_ctx* ctx, const char* name, int64_t value);
  * per-state doubles the path reads.  Returns a model id >= 0, or a negative error. */
 int np_register_model(np_ctx* ctx, int k, int n_states,
                       const double* level_mean, const double* level_stdv, const double* level_log_stdv);
+/* Replace the parameters of a registered model in place (same n_states).  The reference overwrites a registered PoreModel
+ * at the same address (PoreModelSet::register_model, src/pore_model/nanopolish_pore_model_set.cpp:70; methyltrain does so
+ * every training round), so a binding that caches ids by PoreModel* must refresh the device copy when the content changes
+ * (np_dropin.cpp does, by a content hash).  Waits for the work enqueued on the context so far. */
+int np_update_model(np_ctx* ctx, int model, int n_states,
+                    const double* level_mean, const double* level_stdv, const double* level_log_stdv);
 
 /* ---- host-side helpers (pure CPU, no device): alphabets & transitions ------------------------------ */
 /* Alphabets of src/common/nanopolish_alphabet.{h,cpp}: "nucleotide","cpg","gpc","dam","dcm","u_to_t_rna" */
@@ -165,7 +171,13 @@ int np_event_align_host(np_ctx* ctx, int n_jobs, const np_align_job* jobs,
 
 /* ---- batched device-resident entry points ------------------------------------------------------------- */
 /* All pointers below are DEVICE pointers unless stated otherwise; `stream` is a hipStream_t (0 = the
- * context's own stream).  The calls only enqueue work. */
+ * context's own stream).  The calls only enqueue work.
+ * ONE stream at a time per context: the work queues, class counters and scratch buffers of a context are shared by all of
+ * its calls, so a context serialises them.  When a call arrives on a different stream than the previous one (including a
+ * *_host call, which uses the context's own stream), the library makes the new stream wait for everything enqueued on the
+ * old one (an event wait on the device, nothing blocks the host).  For concurrent pipelines create one context per stream.
+ * Scratch grows on demand: the first call at a larger batch size reallocates (a device-wide synchronisation); steady-state
+ * calls do not. */
 
 /* Per-read record (device).  Filled by np_fill_read_host() on the host, then uploaded by the caller. */
 typedef struct np_read_dev {
@@ -209,6 +221,28 @@ int np_event_align_dev(np_ctx* ctx, void* stream, int n_reads, const np_read_dev
 int np_hmm_score_dev(np_ctx* ctx, void* stream, int64_t n_jobs, const np_hmm_job_dev* jobs,
                      const np_read_dev* reads, const float* event_mean, const uint16_t* job_kmer_rank,
                      int model, float* out_scores);
+
+/* profile_hmm_score_set on the device (src/hmm/nanopolish_profile_hmm.cpp:32-56).  The member sequences of a set are scored
+ * under different pore models (sequence 0 under the base model, the others under their alphabets' models), and one
+ * np_hmm_score_dev call binds one model: score the members model by model with np_hmm_score_dev (any layout), then combine
+ *     out[q] = (+)_{t in set q} (score_t - log n_q)      (add_logs = p7_FLogsum on float casts, accumulated in double)
+ * here.  Set q's members are member_scores[member_idx[set_off[q] .. set_off[q+1])] in sequence order (member_idx NULL: the
+ * scores are already laid out set by set).  set_off: int64[n_sets+1].  An empty set yields -inf. */
+int np_hmm_score_set_combine_dev(np_ctx* ctx, void* stream, int64_t n_sets, const int64_t* set_off, const int64_t* member_idx,
+                                 const float* member_scores, float* out_scores);
+
+/* f4 on the device: the per-site table of a batch of call-methylation results, i.e. what the reference's TSV writer
+ * (src/nanopolish_call_methylation.cpp:531-550, "%.2lf" of sum_ll_m - sum_ll_u) followed by
+ * scripts/calculate_methylation_frequency.py:16-23,41-49 (groups not split) accumulates:
+ *     table[row] += (1, n_motif, n_motif if llr > 0)    for every scored group with |llr| >= call_threshold * n_motif,
+ * llr = the group's log-likelihood ratio after the text round trip (correctly rounded to two decimals, ties to even, as
+ * printf does).  row = first_site[g] (+ read_base[jobs[2g].read] when read_base is given: the record's reference offset).
+ *   scores      : 2 floats per group (unmethylated, methylated), NaN = group skipped (as np_hmm_score_dev leaves them)
+ *   table       : int32[n_pos][3] = (num_reads, called_sites, called_sites_methylated), ACCUMULATED into (zero it first);
+ *                 this is the payload of the job's only inter-GPU exchange, one all-reduce(sum). */
+int np_site_table_dev(np_ctx* ctx, void* stream, int64_t n_groups, const float* scores, const int32_t* first_site,
+                      const int32_t* n_motif, const np_hmm_job_dev* jobs, const int64_t* read_base, double call_threshold,
+                      int64_t n_pos, int32_t* table);
 
 /* Read-level glue between the two kernels (src/nanopolish_squiggle_read.cpp:161-186,273-301):
  * builds base_to_event_map[].start for every read from kernel A's pairs, events_per_base and the

@@ -57,6 +57,9 @@ struct np_ctx {
     int n_cu = 256;
     np_params params;
     hipStream_t stream = nullptr;
+    hipStream_t last_stream = nullptr;   // the stream of the most recent compute call (use_stream)
+    bool have_last_stream = false;
+    hipEvent_t switch_ev = nullptr;
     std::vector<model_t> models;
     float* d_logsum = nullptr;
     std::vector<float> h_logsum;
@@ -117,6 +120,20 @@ void drain_timing(np_ctx* c)
 }
 
 hipStream_t pick_stream(np_ctx* c, void* s) { return s ? (hipStream_t)s : c->stream; }
+
+// The stream a compute entry point enqueues on.  A context's work queues, counters and scratch are shared by all of its
+// calls, so work on a new stream must not overtake what was enqueued on the previous one (include/np_hmm.h, "ONE stream at
+// a time per context"): on a switch the new stream waits for an event recorded at the old stream's tail.
+hipStream_t use_stream(np_ctx* c, void* s)
+{
+    hipStream_t st = pick_stream(c, s);
+    if (c->have_last_stream && st != c->last_stream && c->switch_ev) {
+        if (hipEventRecord(c->switch_ev, c->last_stream) == hipSuccess) (void)hipStreamWaitEvent(st, c->switch_ev, 0);
+        else (void)hipStreamSynchronize(c->last_stream);
+    }
+    c->last_stream = st; c->have_last_stream = true;
+    return st;
+}
 
 int persistent_blocks(np_ctx* c, int64_t work_items, int per_block, int blocks_per_cu)
 {
@@ -213,6 +230,7 @@ np_ctx* np_create(int device, const np_params* params)
     if (const char* v = getenv("NP_EA_WAVES_PER_CU")) c->ea_waves_per_cu = std::max(1, atoi(v));
     if (params) c->params = *params; else np_default_params(&c->params);
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->switch_ev, hipEventDisableTiming) == hipSuccess;
 
     // p7_FLogsum table, src/common/logsum.cpp:57-69 (host libm, as the reference's static initialiser)
     std::vector<float> tbl(NP_LOGSUM_TBL);
@@ -264,6 +282,7 @@ void np_destroy(np_ctx* c)
         for (auto& pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         for (auto& ev : t.pool) (void)hipEventDestroy(ev);
     }
+    if (c->switch_ev) (void)hipEventDestroy(c->switch_ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -283,6 +302,22 @@ int np_register_model(np_ctx* c, int k, int n_states, const double* level_mean, 
     return (int)c->models.size() - 1;
 }
 
+int np_update_model(np_ctx* c, int model, int n_states, const double* level_mean, const double* level_stdv,
+                    const double* level_log_stdv)
+{
+    if (!c || !level_mean || !level_stdv || !level_log_stdv) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    if (model < 0 || model >= (int)c->models.size() || n_states != c->models[model].n_states) { c->err = "np_update_model: bad model id or size"; return NP_ERR_INVALID; }
+    NP_HIP(c, hipSetDevice(c->device));
+    if (c->have_last_stream) NP_HIP(c, hipStreamSynchronize(c->last_stream));     // kernels in flight still read the old table
+    NP_HIP(c, hipStreamSynchronize(c->stream));
+    std::vector<np_state_dev> st(n_states);
+    for (int i = 0; i < n_states; ++i) { st[i].level_mean = level_mean[i]; st[i].level_stdv = level_stdv[i]; st[i].level_log_stdv = level_log_stdv[i]; st[i].pad = 0; }
+    NP_HIP(c, hipMemcpy(c->models[model].d_states, st.data(), st.size() * sizeof(np_state_dev), hipMemcpyHostToDevice));
+    c->models[model].level_mean.assign(level_mean, level_mean + n_states);
+    return NP_OK;
+}
+
 // Device self-test of the exact fast division used by the emission (np_device.h:np_div_exact) against `/`.
 int np_selftest_division(np_ctx* c, uint64_t n_samples, uint64_t seed, uint64_t* n_mismatch)
 {
@@ -290,6 +325,7 @@ int np_selftest_division(np_ctx* c, uint64_t n_samples, uint64_t seed, uint64_t*
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
     unsigned long long* d = (unsigned long long*)(c->d_counters + 32);
+    (void)use_stream(c, nullptr);
     NP_HIP(c, hipMemsetAsync(d, 0, sizeof(unsigned long long), c->stream));
     NP_HIP(c, np_launch_selftest_div(n_samples, seed, d, c->stream));
     unsigned long long h = 0;
@@ -335,7 +371,7 @@ int np_event_align_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* 
     if (!c) return NP_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    return run_event_align(c, pick_stream(c, stream), n_reads, reads, event_mean, kmer_rank, model, max_bands,
+    return run_event_align(c, use_stream(c, stream), n_reads, reads, event_mean, kmer_rank, model, max_bands,
                            pair_off, pairs_out, pair_begin, n_pairs);
 }
 
@@ -345,7 +381,32 @@ int np_hmm_score_dev(np_ctx* c, void* stream, int64_t n_jobs, const np_hmm_job_d
     if (!c) return NP_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    return run_hmm_forward(c, pick_stream(c, stream), n_jobs, jobs, reads, event_mean, job_kmer_rank, model, out_scores);
+    return run_hmm_forward(c, use_stream(c, stream), n_jobs, jobs, reads, event_mean, job_kmer_rank, model, out_scores);
+}
+
+int np_site_table_dev(np_ctx* c, void* stream, int64_t n_groups, const float* scores, const int32_t* first_site,
+                      const int32_t* n_motif, const np_hmm_job_dev* jobs, const int64_t* read_base, double call_threshold,
+                      int64_t n_pos, int32_t* table)
+{
+    if (!c || n_groups < 0 || n_pos < 0 || (n_groups > 0 && (!scores || !first_site || !n_motif || !table)) || (read_base && !jobs)) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = use_stream(c, stream);
+    family_timer tm(c, 2, s);
+    NP_HIP(c, np_launch_site_table(n_groups, scores, first_site, n_motif, jobs, read_base, call_threshold, n_pos, table, s));
+    return NP_OK;
+}
+
+int np_hmm_score_set_combine_dev(np_ctx* c, void* stream, int64_t n_sets, const int64_t* set_off, const int64_t* member_idx,
+                                 const float* member_scores, float* out_scores)
+{
+    if (!c || n_sets < 0 || (n_sets > 0 && (!set_off || !member_scores || !out_scores))) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = use_stream(c, stream);
+    family_timer tm(c, 1, s);
+    NP_HIP(c, np_launch_score_set_combine(n_sets, set_off, member_idx, member_scores, c->d_logsum, out_scores, s));
+    return NP_OK;
 }
 
 int np_resolve_jobs_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* reads, const int64_t* pair_off,
@@ -355,7 +416,7 @@ int np_resolve_jobs_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* reads
     if (!c) return NP_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = pick_stream(c, stream);
+    hipStream_t s = use_stream(c, stream);
     family_timer tm(c, 2, s);
     NP_HIP(c, np_launch_build_map(n_reads, reads, pair_off, pairs, pair_begin, n_pairs, map_start, nullptr, events_per_base,
                                   c->params.hmm_indel_bias_factor, s));
@@ -378,7 +439,7 @@ int np_calibrate_resolve_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* 
     if (model < 0 || model >= (int)c->models.size()) { c->err = "bad model id"; return NP_ERR_INVALID; }
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = pick_stream(c, stream);
+    hipStream_t s = use_stream(c, stream);
     family_timer tm(c, 2, s);
     NP_HIP(c, np_launch_build_map(n_reads, reads, pair_off, pairs, pair_begin, n_pairs, map_start, map_stop, events_per_base,
                                   c->params.hmm_indel_bias_factor, s));
@@ -419,6 +480,7 @@ static int pack_hmm_jobs(np_ctx* c, int n_jobs, const np_hmm_job* jobs, std::vec
         d.e_start = q.e_start; d.e_stop = q.e_stop; d.stride = q.stride; d.flags = q.flags;
         rk.insert(rk.end(), q.kmer_rank, q.kmer_rank + q.n_kmers);
     }
+    if (n_jobs > 0 && (model < 0 || model >= (int)c->models.size())) { c->err = "bad model id"; return NP_ERR_INVALID; }
     *model_out = model;
     return NP_OK;
 }
@@ -452,7 +514,7 @@ int np_hmm_score_host(np_ctx* c, int n_jobs, const np_hmm_job* jobs, float* out_
     int model = -1;
     int rc = pack_hmm_jobs(c, n_jobs, jobs, dj, dr, ev, rk, &model);
     if (rc != NP_OK) return rc;
-    hipStream_t s = c->stream;
+    hipStream_t s = use_stream(c, nullptr);
     NP_HIP(c, c->b_jobs.reserve(dj.size() * sizeof(np_hmm_job_dev)));
     NP_HIP(c, c->b_reads.reserve(dr.size() * sizeof(np_read_dev)));
     NP_HIP(c, c->b_events.reserve(ev.size() * sizeof(float)));
@@ -514,7 +576,7 @@ int np_hmm_align_host(np_ctx* c, int n_jobs, const np_hmm_job* jobs, np_hmm_stat
         cell_off[j + 1] = cell_off[j] + e * 3 * (int64_t)dj[j].n_kmers;
         state_off[j + 1] = state_off[j] + e + (int64_t)dj[j].n_kmers + 1;     // path length bound: e rows + n silent K hops
     }
-    hipStream_t s = c->stream;
+    hipStream_t s = use_stream(c, nullptr);
     NP_HIP(c, c->b_jobs.reserve(dj.size() * sizeof(np_hmm_job_dev)));
     NP_HIP(c, c->b_reads.reserve(dr.size() * sizeof(np_read_dev)));
     NP_HIP(c, c->b_events.reserve(ev.size() * sizeof(float)));
@@ -586,7 +648,7 @@ int np_event_align_host(np_ctx* c, int n_jobs, const np_align_job* jobs, np_pair
         pair_off[j + 1] = pair_off[j] + nb;
         max_bands = std::max(max_bands, nb);
     }
-    hipStream_t s = c->stream;
+    hipStream_t s = use_stream(c, nullptr);
     NP_HIP(c, c->b_reads.reserve(dr.size() * sizeof(np_read_dev)));
     NP_HIP(c, c->b_events.reserve(ev.size() * sizeof(float)));
     NP_HIP(c, c->b_ranks.reserve(rk.size() * sizeof(uint16_t)));
@@ -633,7 +695,7 @@ int np_cm_build_jobs_identity_dev(np_ctx* c, void* stream, int n_reads, const ch
     if (n_reads == 0) return NP_OK;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = pick_stream(c, stream);
+    hipStream_t s = use_stream(c, stream);
     NP_HIP(c, c->cm_group_rank_off.reserve((size_t)total_group_slots * sizeof(int64_t)));
     family_timer tm(c, 2, s);
     NP_HIP(c, np_launch_cm_build_jobs(n_reads, ref_seq, seq_off, read_rc, alphabet, (int)k, min_separation, min_flank, group_off, rank_off, jobs,
@@ -655,7 +717,7 @@ int np_cm_build_jobs_cigar_dev(np_ctx* c, void* stream, int n_reads, const char*
     if (n_reads == 0) return NP_OK;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = pick_stream(c, stream);
+    hipStream_t s = use_stream(c, stream);
     const size_t n_idx = (size_t)total_cigar_ops + (size_t)n_reads;
     NP_HIP(c, c->cm_group_rank_off.reserve((size_t)total_group_slots * sizeof(int64_t)));
     NP_HIP(c, c->cm_cigar_scratch.reserve(2 * n_idx * sizeof(int32_t) + (size_t)n_reads * 16 + 2 * (size_t)total_group_slots * sizeof(int32_t)));
@@ -676,7 +738,7 @@ int np_cm_discard_degenerate_dev(np_ctx* c, void* stream, const np_read_dev* rea
     if (!c || n_jobs < 0 || (n_jobs > 0 && (!reads || !map_start || !deg_kpos || !jobs))) return NP_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = pick_stream(c, stream);
+    hipStream_t s = use_stream(c, stream);
     family_timer tm(c, 2, s);
     NP_HIP(c, np_launch_discard_degenerate(n_jobs, jobs, reads, map_start, deg_kpos, s));
     return NP_OK;
@@ -698,7 +760,7 @@ int np_eventalign_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* r
     if (n_reads == 0) return NP_OK;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = pick_stream(c, stream);
+    hipStream_t s = use_stream(c, stream);
     const size_t n_idx = (size_t)total_cigar_ops + (size_t)n_reads;
     NP_HIP(c, c->cm_cigar_scratch.reserve(2 * n_idx * sizeof(int32_t) + (size_t)n_reads * 16));
     int32_t* op_ref = c->cm_cigar_scratch.as<int32_t>();
@@ -778,7 +840,7 @@ int np_detect_events_dev(np_ctx* c, void* stream, int n_reads, const float* raw,
     if (n_reads == 0) return NP_OK;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    return detect_events_locked(c, pick_stream(c, stream), n_reads, raw, raw_off, max_samples, params, tstat, 0, event_off, max_events,
+    return detect_events_locked(c, use_stream(c, stream), n_reads, raw, raw_off, max_samples, params, tstat, 0, event_off, max_events,
                                 event_start, event_length, event_mean, event_stdv, n_events);
 }
 
@@ -799,7 +861,7 @@ int np_detect_events_host(np_ctx* c, int n_reads, const float* const* raw, const
         ev_off[r + 1] = ev_off[r] + ecap;
         max_samples = std::max<int64_t>(max_samples, n_samples[r]); max_events = std::max(max_events, ecap);
     }
-    hipStream_t s = c->stream;
+    hipStream_t s = use_stream(c, nullptr);
     const size_t ns = (size_t)raw_off[n_reads], ne = (size_t)ev_off[n_reads];
     NP_HIP(c, c->b_raw.reserve(ns * sizeof(float) + 16));
     NP_HIP(c, c->b_raw_off.reserve(raw_off.size() * sizeof(int64_t)));
@@ -848,7 +910,7 @@ int np_mom_fill_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* reads, np
     if (n_reads == 0) return NP_OK;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = pick_stream(c, stream);
+    hipStream_t s = use_stream(c, stream);
     family_timer tm(c, 5, s);
     NP_HIP(c, np_launch_mom_fill(n_reads, reads, reads_b, event_mean, n_events, kmer_rank, c->models[model].d_states, s));
     return NP_OK;

@@ -405,6 +405,79 @@ __global__ void __launch_bounds__(256) np_selftest_div_kernel(uint64_t n_per_thr
 }
 } // namespace
 
+namespace {
+// f4: one thread per CpG group.  The TSV writer prints diff = sum_ll_m - sum_ll_u (doubles; for 1D reads the float scores
+// themselves) with "%.2lf" (src/nanopolish_call_methylation.cpp:538-545), and scripts/calculate_methylation_frequency.py:41-49
+// parses that text back: llr = float(text); skip if abs(llr) < call_threshold * num_motifs; methylated iff llr > 0.
+// printf's "%.2lf" is the correctly rounded (ties to even) decimal of the exact binary value: r = RN(100 x) as an integer,
+// corrected by the exact residual 100 x - r (one fma: x is a difference of two floats, so 100 x - r is representable);
+// float(text) is then the double nearest to r / 100, i.e. the correctly rounded quotient.
+__global__ void __launch_bounds__(256) np_site_table_kernel(int64_t n_groups, const float* scores, const int32_t* first_site,
+                                                            const int32_t* n_motif, const np_hmm_job_dev* jobs, const int64_t* read_base,
+                                                            double call_threshold, int64_t n_pos, int32_t* table)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_groups) return;
+    const float u = scores[2 * g], m = scores[2 * g + 1];
+    const double x = (double)m - (double)u;
+    if (!(__builtin_fabs(x) < __builtin_inf())) return;                 // NaN: a skipped group; +-inf never passes a real run
+    double r = __builtin_rint(x * 100.0);
+    const double e = __builtin_fma(x, 100.0, -r);
+    const bool odd = __builtin_fmod(__builtin_fabs(r), 2.0) == 1.0;
+    if (e > 0.5 || (e == 0.5 && odd)) r += 1.0;
+    else if (e < -0.5 || (e == -0.5 && odd)) r -= 1.0;
+    const double llr = r / 100.0;
+    const int nm = n_motif[g];
+    if (__builtin_fabs(llr) < call_threshold * (double)nm) return;      // ambiguous call
+    int64_t row = first_site[g];
+    if (read_base) row += read_base[jobs[2 * g].read];
+    if (row < 0 || row >= n_pos) return;
+    atomicAdd(&table[3 * row], 1);
+    atomicAdd(&table[3 * row + 1], nm);
+    if (llr > 0) atomicAdd(&table[3 * row + 2], nm);
+}
+
+// profile_hmm_score_set's combination (src/hmm/nanopolish_profile_hmm.cpp:41-55): score = (+)_j (score_j - log n) with
+// add_logs -> p7_FLogsum on (float) casts of the doubles (nanopolish_common.h:97-104), thread per set.
+__global__ void __launch_bounds__(256) np_score_set_combine_kernel(int64_t n_sets, const int64_t* set_off, const int64_t* member_idx,
+                                                                   const float* member_scores, const float* logsum, float* out)
+{
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_sets) return;
+    const int64_t b = set_off[q], n = set_off[q + 1] - b;
+    if (n <= 0) { out[q] = NP_NEG_INF; return; }
+    const double pen = np_log_glibc((double)(uint64_t)n);                     // glibc's log, restated (csrc/np_log.h)
+    auto sc = [&](int64_t t) { return (double)member_scores[member_idx ? member_idx[b + t] : b + t]; };
+    double score = sc(0) - pen;
+    for (int64_t t = 1; t < n; ++t) {
+        const double alt = sc(t) - pen;
+        const float fa = (float)score, fb = (float)alt;
+        const float mx = fa > fb ? fa : fb, mn = fa < fb ? fa : fb;
+        score = (mn == NP_NEG_INF || (mx - mn) >= 15.7f) ? (double)mx : (double)(mx + logsum[(int)((mx - mn) * 1000.f)]);
+    }
+    out[q] = (float)score;
+}
+} // namespace
+
+hipError_t np_launch_site_table(int64_t n_groups, const float* scores, const int32_t* first_site, const int32_t* n_motif,
+                                const np_hmm_job_dev* jobs, const int64_t* read_base, double call_threshold, int64_t n_pos,
+                                int32_t* table, hipStream_t s)
+{
+    if (n_groups <= 0) return hipSuccess;
+    hipLaunchKernelGGL(np_site_table_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, n_groups, scores, first_site,
+                       n_motif, jobs, read_base, call_threshold, n_pos, table);
+    return hipGetLastError();
+}
+
+hipError_t np_launch_score_set_combine(int64_t n_sets, const int64_t* set_off, const int64_t* member_idx, const float* member_scores,
+                                       const float* logsum, float* out, hipStream_t s)
+{
+    if (n_sets <= 0) return hipSuccess;
+    hipLaunchKernelGGL(np_score_set_combine_kernel, dim3((unsigned)((n_sets + 255) / 256)), dim3(256), 0, s, n_sets, set_off, member_idx,
+                       member_scores, logsum, out);
+    return hipGetLastError();
+}
+
 hipError_t np_launch_selftest_div(uint64_t n_samples, uint64_t seed, unsigned long long* d_mismatches, hipStream_t s)
 {
     const unsigned blocks = 4096;

@@ -1,6 +1,6 @@
 // np_host.cpp -- host-side (CPU, no device) parts of the C ABI: alphabets, k-mer ranks, methylation-aware
 // string transforms, transitions, MoM scaling estimate, motif grouping.  These mirror what the reference does
-// on the host *around* the two kernels, so that a caller (or nanopolish_amd/csrc/np_dropin.hpp) can flatten
+// on the host *around* the two kernels, so that a caller (or nanopolish_amd/csrc/np_dropin.cpp) can flatten
 // HMMInputSequence/HMMInputData into np_hmm_job without linking any reference code.
 //
 // Reference: src/common/nanopolish_alphabet.{h,cpp}, src/hmm/nanopolish_hmm_input_sequence.h,

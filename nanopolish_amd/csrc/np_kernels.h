@@ -105,6 +105,11 @@ hipError_t np_launch_discard_degenerate(int64_t n_jobs, np_hmm_job_dev* jobs, co
 hipError_t np_launch_resolve(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads, const int32_t* n_pairs,
                              const double* events_per_base, const int32_t* calibrated, const int32_t* map_start,
                              const int32_t* kpos, hipStream_t s);
+hipError_t np_launch_site_table(int64_t n_groups, const float* scores, const int32_t* first_site, const int32_t* n_motif,
+                                const np_hmm_job_dev* jobs, const int64_t* read_base, double call_threshold, int64_t n_pos,
+                                int32_t* table, hipStream_t s);
+hipError_t np_launch_score_set_combine(int64_t n_sets, const int64_t* set_off, const int64_t* member_idx, const float* member_scores,
+                                       const float* logsum, float* out, hipStream_t s);
 hipError_t np_launch_selftest_div(uint64_t n_samples, uint64_t seed, unsigned long long* d_mismatches, hipStream_t s);
 
 // ---- f2: event detection + method-of-moments scalings (np_events_kernels.hip) ------------------------------------

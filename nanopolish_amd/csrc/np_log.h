@@ -12,7 +12,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define NP_LOG_HD __host__ __device__
 #else
 #define NP_LOG_HD

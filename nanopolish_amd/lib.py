@@ -16,7 +16,7 @@ c_i64p = C.POINTER(C.c_int64)
 
 # exported symbols of include/np_hmm.h (tests check that every one resolves)
 SYMBOLS = [
-    "np_default_params", "np_create", "np_destroy", "np_last_error", "np_version", "np_set_option", "np_register_model",
+    "np_default_params", "np_create", "np_destroy", "np_last_error", "np_version", "np_set_option", "np_register_model", "np_update_model", "np_site_table_dev", "np_hmm_score_set_combine_dev",
     "np_alphabet_id", "np_alphabet_size", "np_kmer_rank", "np_reverse_complement", "np_methylate", "np_unmethylate",
     "np_is_motif_match", "np_sequence_kmer_ranks", "np_calculate_transitions", "np_estimate_scalings_mom",
     "np_scan_motif_groups", "np_cm_build_jobs_identity", "np_fill_read_host", "np_hmm_score_host", "np_hmm_score_set_host", "np_hmm_align_host", "np_event_align_host",
@@ -105,6 +105,7 @@ def load_library():
     L.np_version.restype = C.c_char_p
     L.np_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.np_register_model.argtypes = [vp, C.c_int, C.c_int, c_f64p, c_f64p, c_f64p]
+    L.np_update_model.argtypes = [vp, C.c_int, C.c_int, c_f64p, c_f64p, c_f64p]
     L.np_alphabet_id.argtypes = [C.c_char_p]
     L.np_alphabet_size.restype = C.c_uint32
     L.np_kmer_rank.restype = C.c_uint32
@@ -152,6 +153,8 @@ def load_library():
     L.np_restated_log_exp.argtypes = [c_f64p, C.c_size_t, c_f64p, c_f64p]
     L.np_restated_log_exp.restype = None
     L.np_sync.argtypes = [vp, vp]
+    L.np_site_table_dev.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, C.c_double, C.c_int64, vp]
+    L.np_hmm_score_set_combine_dev.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp]
     L.np_last_kernel_ms.argtypes = [vp, C.c_int, c_f32p]
     L.np_kernel_time.argtypes = [vp, C.c_int, c_f64p, c_i64p, C.c_int]
     _lib = L

@@ -31,13 +31,16 @@ assert READ_DT.itemsize == C.sizeof(_l.ReadDev) and JOB_DT.itemsize == C.sizeof(
 HAF = api.HAF_ALLOW_PRE_CLIP | api.HAF_ALLOW_POST_CLIP
 
 
-def build_host_batch(models, read_ids, L=5450, k=6, raw=False):
+def build_host_batch(models, read_ids, L=5450, k=6, raw=False, with_jobs=True):
     """Host-side preparation of the distinct reads of a batch (numpy only).
+    L: bases per read, one number or one per read (ragged batches).
     raw=True: reads carry synthetic raw signal (synth_raw); the event arrays are then sized as CAPACITY for the device
-    detector (n_samples/2 + 2 per read) and hold no data, and the per-read records only carry offsets and n_kmers."""
+    detector (n_samples/2 + 2 per read) and hold no data, and the per-read records only carry offsets and n_kmers.
+    with_jobs=False: no host-built work items (the device builds them, jobs_on_device=True): hb["jobs"] stays empty."""
     L_ = _l.load_library()
     nuc = models["nucleotide"]
-    reads = [(synth_raw if raw else synth_read)(r, nuc, L=L, k=k) for r in read_ids]
+    Ls = np.broadcast_to(np.asarray(L, np.int64), (len(read_ids),))
+    reads = [(synth_raw if raw else synth_read)(r, nuc, L=int(l), k=k) for r, l in zip(read_ids, Ls)]
     n = len(reads)
     if raw:
         for r in reads:
@@ -59,6 +62,8 @@ def build_host_batch(models, read_ids, L=5450, k=6, raw=False):
                                  int(event_off[i]), ne, int(rank_off[i]), nk)
         ref_seq = api.reverse_complement("nucleotide", r["seq"]) if r["rc"] else r["seq"]
         ref_seqs.append(ref_seq)
+        if not with_jobs:
+            continue
         jb = api.cm_build_jobs_identity(ref_seq, r["rc"], k)
         ng = len(jb["first"])
         j = np.zeros(2 * ng, JOB_DT)
@@ -86,6 +91,39 @@ def build_host_batch(models, read_ids, L=5450, k=6, raw=False):
                 kpos=np.concatenate(kpos).astype(np.int32) if kpos else np.zeros((0, 2), np.int32),
                 job_ranks=np.concatenate(jranks).astype(np.uint16) if jranks else np.zeros(0, np.uint16),
                 job_off=np.concatenate([[0], np.cumsum([len(j) for j in jobs])]).astype(np.int64), meta=meta)
+
+
+def concat_host_batches(parts):
+    """Join host batches built for consecutive read-id ranges (identity layout, e.g. by a pool of worker processes)."""
+    if len(parts) == 1:
+        return parts[0]
+    out = dict(parts[0])
+    ne = np.cumsum([0] + [len(p["events"]) for p in parts]); nr = np.cumsum([0] + [len(p["ranks"]) for p in parts])
+    nj = np.cumsum([0] + [len(p["jobs"]) for p in parts]); njr = np.cumsum([0] + [len(p["job_ranks"]) for p in parts])
+    out["n"] = sum(p["n"] for p in parts)
+    out["reads"] = [r for p in parts for r in p["reads"]]
+    out["ref_seqs"] = [r for p in parts for r in p["ref_seqs"]]
+    out["meta"] = [m for p in parts for m in p["meta"]]
+    for key in ("events", "ranks", "job_ranks", "kpos", "mom"):
+        out[key] = np.concatenate([p[key] for p in parts])
+    for key in ("reads_a", "reads_b"):
+        a = [p[key].copy() for p in parts]
+        for i, x in enumerate(a):
+            x["event_off"] += ne[i]; x["rank_off"] += nr[i]
+        out[key] = np.concatenate(a)
+    jb = [p["jobs"].copy() for p in parts]
+    nread = np.cumsum([0] + [p["n"] for p in parts])
+    for i, x in enumerate(jb):
+        x["read"] += np.uint32(nread[i]); x["rank_off"] += njr[i]
+    out["jobs"] = np.concatenate(jb)
+    out["event_off"] = np.concatenate([p["event_off"][:-1] + ne[i] for i, p in enumerate(parts)] + [[ne[-1]]]).astype(np.int64)
+    out["rank_off"] = np.concatenate([p["rank_off"][:-1] + nr[i] for i, p in enumerate(parts)] + [[nr[-1]]]).astype(np.int64)
+    out["job_off"] = np.concatenate([p["job_off"][:-1] + nj[i] for i, p in enumerate(parts)] + [[nj[-1]]]).astype(np.int64)
+    if "raw" in out:
+        ns = np.cumsum([0] + [len(p["raw"]) for p in parts])
+        out["raw"] = np.concatenate([p["raw"] for p in parts])
+        out["raw_off"] = np.concatenate([p["raw_off"][:-1] + ns[i] for i, p in enumerate(parts)] + [[ns[-1]]]).astype(np.int64)
+    return out
 
 
 def build_host_batch_records(models, records, contig, k=6, alphabet="cpg"):
@@ -209,6 +247,7 @@ class CallMethylationBatch:
         self.by_cigar = "cigar" in hb          # work items follow BAM CIGARs (build_host_batch_records)
         self.ctx = ctx
         self.hb = hb
+        self.stream = None         # raw hipStream_t the step is enqueued on (None: the context's own stream)
         self.n_reads = hb["n"]
         self.n_jobs = len(hb["jobs"])
         dev = torch.device(device)
@@ -295,42 +334,43 @@ class CallMethylationBatch:
     def step(self):
         L, h = self.ctx.L, self.ctx.h
         p = lambda t: C.c_void_p(t.data_ptr())
+        s = C.c_void_p(self.stream) if self.stream else None      # raw hipStream_t (0 / None: the context's own stream)
         ea = self.workload == "eventalign"
         n_jobs = 0 if ea else self.n_jobs
         if ea:
             pass
         elif self.jobs_on_device and self.by_cigar:
-            rc = L.np_cm_build_jobs_cigar_dev(h, None, self.n_reads, p(self.d_genome), p(self.d_ref_begin), p(self.d_ref_len), p(self.d_cigar),
+            rc = L.np_cm_build_jobs_cigar_dev(h, s, self.n_reads, p(self.d_genome), p(self.d_ref_begin), p(self.d_ref_len), p(self.d_cigar),
                                               p(self.d_cigar_off), self.n_cigar_ops, p(self.d_read_len), p(self.d_rc), api.alphabet_id(self.alphabet),
                                               self.cm[2], self.cm[0], self.cm[1], p(self.d_group_off), self.n_slots, p(self.d_jr_off),
                                               p(self.d_jobs), p(self.d_kpos), p(self.d_job_ranks), p(self.d_first), p(self.d_last),
                                               p(self.d_n_motif), p(self.d_n_groups), p(self.d_deg))
             self.ctx._chk(rc, "np_cm_build_jobs_cigar_dev")
         elif self.jobs_on_device:
-            rc = L.np_cm_build_jobs_identity_dev(h, None, self.n_reads, p(self.d_seq), p(self.d_seq_off), p(self.d_rc), api.alphabet_id("cpg"),
+            rc = L.np_cm_build_jobs_identity_dev(h, s, self.n_reads, p(self.d_seq), p(self.d_seq_off), p(self.d_rc), api.alphabet_id("cpg"),
                                                  self.cm[2], self.cm[0], self.cm[1], p(self.d_group_off), self.n_slots, p(self.d_jr_off),
                                                  p(self.d_jobs), p(self.d_kpos), p(self.d_job_ranks), p(self.d_first), p(self.d_last),
                                                  p(self.d_n_motif), p(self.d_n_groups))
             self.ctx._chk(rc, "np_cm_build_jobs_identity_dev")
         if self.from_raw:
-            rc = L.np_detect_events_dev(h, None, self.n_reads, p(self.d_raw), p(self.d_raw_off), self.max_samples, C.byref(self.prm),
+            rc = L.np_detect_events_dev(h, s, self.n_reads, p(self.d_raw), p(self.d_raw_off), self.max_samples, C.byref(self.prm),
                                         p(self.d_tstat), p(self.d_event_off), self.max_events, p(self.d_ev_start), p(self.d_ev_len),
                                         p(self.d_events), p(self.d_ev_stdv), p(self.d_n_events))
             self.ctx._chk(rc, "np_detect_events_dev")
-            rc = L.np_mom_fill_dev(h, None, self.n_reads, p(self.d_reads_a), p(self.d_reads_b), p(self.d_events), p(self.d_n_events),
+            rc = L.np_mom_fill_dev(h, s, self.n_reads, p(self.d_reads_a), p(self.d_reads_b), p(self.d_events), p(self.d_n_events),
                                    p(self.d_ranks), self.m_nuc)
             self.ctx._chk(rc, "np_mom_fill_dev")
-        rc = L.np_event_align_dev(h, None, self.n_reads, p(self.d_reads_a), p(self.d_events), p(self.d_ranks), self.m_nuc,
+        rc = L.np_event_align_dev(h, s, self.n_reads, p(self.d_reads_a), p(self.d_events), p(self.d_ranks), self.m_nuc,
                                   self.max_bands, p(self.d_pair_off), p(self.d_pairs), p(self.d_pair_begin), p(self.d_n_pairs))
         self.ctx._chk(rc, "np_event_align_dev")
         if self.calibrate:
-            rc = L.np_calibrate_resolve_dev(h, None, self.n_reads, p(self.d_reads_b), p(self.d_events), p(self.d_ranks),
+            rc = L.np_calibrate_resolve_dev(h, s, self.n_reads, p(self.d_reads_b), p(self.d_events), p(self.d_ranks),
                                             self.m_nuc, p(self.d_pair_off), p(self.d_pairs), p(self.d_pair_begin),
                                             p(self.d_n_pairs), p(self.d_map), p(self.d_map_stop), p(self.d_epb),
                                             p(self.d_calibrated), n_jobs, p(self.d_jobs), p(self.d_kpos))
             self.ctx._chk(rc, "np_calibrate_resolve_dev")
         else:
-            rc = L.np_resolve_jobs_dev(h, None, self.n_reads, p(self.d_reads_b), p(self.d_pair_off), p(self.d_pairs),
+            rc = L.np_resolve_jobs_dev(h, s, self.n_reads, p(self.d_reads_b), p(self.d_pair_off), p(self.d_pairs),
                                        p(self.d_pair_begin), p(self.d_n_pairs), p(self.d_map), p(self.d_epb), n_jobs,
                                        p(self.d_jobs), p(self.d_kpos))
             self.ctx._chk(rc, "np_resolve_jobs_dev")
@@ -338,9 +378,9 @@ class CallMethylationBatch:
             self.eventalign_enqueue()
             return
         if self.by_cigar:
-            rc = L.np_cm_discard_degenerate_dev(h, None, p(self.d_reads_b), p(self.d_map), p(self.d_deg), self.n_jobs, p(self.d_jobs))
+            rc = L.np_cm_discard_degenerate_dev(h, s, p(self.d_reads_b), p(self.d_map), p(self.d_deg), self.n_jobs, p(self.d_jobs))
             self.ctx._chk(rc, "np_cm_discard_degenerate_dev")
-        rc = L.np_hmm_score_dev(h, None, self.n_jobs, p(self.d_jobs), p(self.d_reads_b), p(self.d_events), p(self.d_job_ranks),
+        rc = L.np_hmm_score_dev(h, s, self.n_jobs, p(self.d_jobs), p(self.d_reads_b), p(self.d_events), p(self.d_job_ranks),
                                 self.m_cpg, p(self.d_scores))
         self.ctx._chk(rc, "np_hmm_score_dev")
 
@@ -356,6 +396,7 @@ class CallMethylationBatch:
         torch = self.torch
         L, h = self.ctx.L, self.ctx.h
         p = lambda t: C.c_void_p(t.data_ptr())
+        s = C.c_void_p(self.stream) if self.stream else None
         dev = self.d_events.device
         if not hasattr(self, "d_ea_off"):
             ecap = (self.hb["event_off"][1:] - self.hb["event_off"][:-1]) + 1
@@ -366,7 +407,8 @@ class CallMethylationBatch:
             self.d_ea_state = torch.zeros(tot, dtype=torch.uint8, device=dev)
             self.d_ea_n = torch.zeros(self.n_reads, dtype=torch.int32, device=dev); self.d_ea_status = torch.zeros(self.n_reads, dtype=torch.int32, device=dev)
             self.d_ea_calls = torch.zeros(self.n_reads, dtype=torch.int32, device=dev)
-        rc = L.np_eventalign_dev(h, None, self.n_reads, p(self.d_reads_b), p(self.d_events), p(self.d_map), p(self.d_n_pairs), p(self.d_epb),
+            torch.cuda.synchronize()       # the zero-fills ran on torch's stream; the kernels below run on the library's
+        rc = L.np_eventalign_dev(h, s, self.n_reads, p(self.d_reads_b), p(self.d_events), p(self.d_map), p(self.d_n_pairs), p(self.d_epb),
                                  p(self.d_calibrated) if self.calibrate else None, self.m_nuc, p(self.d_genome), p(self.d_ref_begin),
                                  p(self.d_ref_len), p(self.d_cigar), p(self.d_cigar_off), self.n_cigar_ops, p(self.d_read_len), p(self.d_rc),
                                  int(self.hb.get("k", 6)), p(self.d_ea_off), p(self.d_ea_ref), p(self.d_ea_event), p(self.d_ea_state),
@@ -385,7 +427,7 @@ class CallMethylationBatch:
         return out
 
     def sync(self):
-        self.ctx.sync()
+        self.ctx.sync(C.c_void_p(self.stream) if self.stream else None)
 
     # ---- results on the host (for checking) -------------------------------------------------------------
     def scores(self):
@@ -438,3 +480,96 @@ class CallMethylationBatch:
     def event_map(self):
         self.sync()
         return self.d_map.cpu().numpy(), (self.d_map_stop.cpu().numpy() if self.calibrate else None)
+
+    def groups_bulk(self, n):
+        """groups_of(r) for reads 0..n-1 with one transfer per array: list of (first, n_motif, unmeth, meth)."""
+        self.sync()
+        g1 = int(self.group_off[n])
+        ng = self.d_n_groups[:n].cpu().numpy()
+        first = self.d_first[:g1].cpu().numpy(); nm = self.d_n_motif[:g1].cpu().numpy()
+        sc = self.d_scores[:2 * g1].cpu().numpy()
+        out = []
+        for r in range(n):
+            g0 = int(self.group_off[r]); k = max(int(ng[r]), 0)
+            out.append((first[g0:g0 + k], nm[g0:g0 + k], sc[2 * g0:2 * (g0 + k):2], sc[2 * g0 + 1:2 * (g0 + k):2]))
+        return out
+
+
+class StreamedFeed:
+    """Host-fed operation of a CallMethylationBatch: every step's inputs arrive in pinned host memory, as BamProcessor's record
+    batches would deliver them (src/common/nanopolish_bam_processor.cpp:90-119), and are copied to the device while the
+    previous step computes; the results go back to pinned host memory the same way.  Two sets of input and output buffers
+    (double buffering), three HIP streams: host->device, compute (every *_dev entry point of the C ABI takes the stream),
+    device->host.  Scratch (alignments, event maps, work items) stays single: the compute stream runs one step at a time.
+
+    host -> device per step: event means (or raw samples), nucleotide k-mer ranks, the per-read records, and -- when work items
+    are generated on the device -- the reads' reference strands;  device -> host: the scores and the per-group site metadata.
+    """
+
+    def __init__(self, batch):
+        torch = batch.torch
+        self.b = b = batch
+        ins = ["d_ranks", "d_reads_a", "d_reads_b"] + (["d_raw"] if b.from_raw else ["d_events"])
+        if b.jobs_on_device and not b.by_cigar:
+            ins += ["d_seq", "d_rc"]
+        outs = ["d_scores"] + (["d_first", "d_n_motif", "d_n_groups"] if b.jobs_on_device else [])
+        b.sync(); torch.cuda.synchronize()
+        self.ins, self.outs = ins, outs
+        self.host_in = {n: getattr(b, n).cpu().pin_memory() for n in ins}
+        self.host_out = [{n: torch.empty_like(getattr(b, n), device="cpu").pin_memory() for n in outs} for _ in range(2)]
+        self.ref_out = {n: getattr(b, n).clone() for n in outs}            # the resident pass's results, for check_against
+        self.sets = [{n: getattr(b, n) for n in ins + outs}, {n: torch.zeros_like(getattr(b, n)) for n in ins + outs}]
+        self.h2d_bytes = sum(t.numel() * t.element_size() for t in self.host_in.values())
+        self.d2h_bytes = sum(t.numel() * t.element_size() for t in self.host_out[0].values())
+        self.s_h2d, self.s_cmp, self.s_d2h = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+        self.ev_h2d = [torch.cuda.Event(), torch.cuda.Event()]
+        self.ev_cmp = [None, None]
+        self.ev_d2h = [None, None]
+        self.k = 0
+        torch.cuda.synchronize()
+
+    def submit(self):
+        torch = self.b.torch
+        i = self.k & 1
+        st = self.sets[i]
+        with torch.cuda.stream(self.s_h2d):
+            if self.ev_cmp[i] is not None:
+                self.s_h2d.wait_event(self.ev_cmp[i])          # the step that last read this input set has finished
+            for n in self.ins:
+                st[n].copy_(self.host_in[n], non_blocking=True)
+            self.ev_h2d[i].record(self.s_h2d)
+        self.s_cmp.wait_event(self.ev_h2d[i])
+        if self.ev_d2h[i] is not None:
+            self.s_cmp.wait_event(self.ev_d2h[i])              # this output set has been read back
+        for n in self.ins + self.outs:
+            setattr(self.b, n, st[n])
+        self.b.stream = self.s_cmp.cuda_stream
+        self.b.step()
+        self.ev_cmp[i] = torch.cuda.Event(); self.ev_cmp[i].record(self.s_cmp)
+        with torch.cuda.stream(self.s_d2h):
+            self.s_d2h.wait_event(self.ev_cmp[i])
+            for n in self.outs:
+                self.host_out[i][n].copy_(st[n], non_blocking=True)
+            self.ev_d2h[i] = torch.cuda.Event(); self.ev_d2h[i].record(self.s_d2h)
+        self.k += 1
+
+    def drain(self):
+        for s in (self.s_h2d, self.s_cmp, self.s_d2h):
+            s.synchronize()
+        self.b.sync()
+
+    def check_against(self, batch=None):
+        """the results of the last two streamed steps, as they arrived on the host, against the resident pass (bit for bit)"""
+        self.drain()
+        ok = True
+        for i in range(min(self.k, 2)):
+            for n in self.outs:
+                a = self.host_out[i][n].numpy().view(np.uint8); r = self.ref_out[n].cpu().numpy().view(np.uint8)
+                ok = ok and bool(np.array_equal(a, r))
+        return ok
+
+    def close(self):
+        self.drain()
+        for n in self.ins + self.outs:
+            setattr(self.b, n, self.sets[0][n])
+        self.b.stream = None

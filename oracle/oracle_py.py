@@ -362,6 +362,17 @@ class RefOracle:
         self.L.npref_model_get(kit, alphabet.encode(), k, _p(lm, c_f64p), _p(ls, c_f64p), _p(ll, c_f64p))
         return dict(k=k, level_mean=lm, level_stdv=ls, level_log_stdv=ll)
 
+    def set_indel_bias(self, v):
+        """hmm_indel_bias_factor (src/hmm/nanopolish_profile_hmm_r9.cpp:19) for the *_many drivers (the single-call entry points
+        take it per call and reset it to 1.0)"""
+        self.L.npref_set_indel_bias.argtypes = [C.c_double]
+        self.L.npref_set_indel_bias(float(v))
+
+    def shift_model(self, alphabet, delta, k=6):
+        """test hook: add delta to every level_mean of the registered model, in place (same PoreModel address)"""
+        self.L.npref_shift_model.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_double]
+        self.L.npref_shift_model(self.KIT, alphabet.encode(), k, delta)
+
     def kmer_rank(self, alpha, kmer):
         return self.L.npref_kmer_rank(alpha.encode(), kmer.encode(), len(kmer))
 
@@ -416,6 +427,22 @@ class RefOracle:
                                                C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int] + [C.c_double] * 5 + [C.c_uint32]
         return self.L.npref_hmm_score_set(self.KIT, n, sa, aa, _p(events, c_f32p), len(events), e_start, e_stop,
                                           stride, int(rc), shift, scale, var, events_per_base, indel_bias, flags)
+
+    def hmm_score_vec(self, alphabet, seq, datas, indel_bias=1.0, flags=0):
+        """profile_hmm_score(sequence, std::vector<HMMInputData>, flags) (src/hmm/nanopolish_profile_hmm.cpp:14-21): one sequence
+        against several reads' windows.  datas: dicts(events, e_start, e_stop, stride, rc, shift, scale, var, events_per_base)."""
+        n = len(datas)
+        ev = np.concatenate([np.ascontiguousarray(d["events"], np.float32) for d in datas])
+        eo = np.zeros(n + 1, np.int64); eo[1:] = np.cumsum([len(d["events"]) for d in datas])
+        a = lambda k, t: np.ascontiguousarray([d[k] for d in datas], t)
+        e1, e2, st, rc = a("e_start", np.uint32), a("e_stop", np.uint32), a("stride", np.int32), a("rc", np.int32)
+        sh, sc, vr, epb = a("shift", np.float64), a("scale", np.float64), a("var", np.float64), a("events_per_base", np.float64)
+        f = self.L.npref_hmm_score_vec
+        f.restype = C.c_float
+        f.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, c_f32p, c_i64p, c_u32p, c_u32p, c_i32p, c_i32p, c_f64p, c_f64p,
+                      c_f64p, c_f64p, C.c_double, C.c_uint32]
+        return f(self.KIT, alphabet.encode(), seq.encode(), n, _p(ev, c_f32p), _p(eo, c_i64p), _p(e1, c_u32p), _p(e2, c_u32p),
+                 _p(st, c_i32p), _p(rc, c_i32p), _p(sh, c_f64p), _p(sc, c_f64p), _p(vr, c_f64p), _p(epb, c_f64p), indel_bias, flags)
 
     def hmm_align(self, alphabet, seq, rc_seq, events, e_start, e_stop, stride, rc, shift, scale, var,
                   events_per_base, indel_bias=1.0, flags=0):

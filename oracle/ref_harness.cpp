@@ -20,6 +20,7 @@
 #include <vector>
 #include <cmath>
 #include <omp.h>
+#include <malloc.h>
 #include "nanopolish_profile_hmm.h"
 #include "nanopolish_raw_loader.h"
 #include "nanopolish_pore_model_set.h"
@@ -124,6 +125,16 @@ int npref_model_get(const char* kit, const char* alphabet, int k,
 }
 
 // ---- alphabets ---------------------------------------------------------------
+void npref_set_indel_bias(double v) { hmm_indel_bias_factor = v; }
+
+// Test hook: change a registered model IN PLACE (same PoreModel address), which is what PoreModelSet::register_model does for
+// an existing key (src/pore_model/nanopolish_pore_model_set.cpp:70; methyltrain's add_model every training round).
+void npref_shift_model(const char* kit, const char* alphabet, int k, double delta)
+{
+    PoreModel* m = const_cast<PoreModel*>(PoreModelSet::get_model(kit, alphabet, "template", k));
+    for(size_t i = 0; i < m->states.size(); ++i) m->states[i].level_mean += delta;
+}
+
 int npref_kmer_rank(const char* alphabet, const char* kmer, int k)
 {
     const Alphabet* a = alphabet_by_name(alphabet);
@@ -224,6 +235,29 @@ void npref_hmm_score_many(const char* kit, const char* alphabet, int n_jobs,
     hmm_indel_bias_factor = 1.0;
 }
 
+// The vector overload (src/hmm/nanopolish_profile_hmm.cpp:14-21): ONE sequence against several reads' event windows,
+// the fp32 sum of the per-read scores in index order.  Read i: events event_mean[event_off[i] .. event_off[i+1]).
+float npref_hmm_score_vec(const char* kit, const char* alphabet, const char* seq, int n_data,
+                          const float* event_mean, const int64_t* event_off,
+                          const uint32_t* e_start, const uint32_t* e_stop, const int* stride, const int* rc,
+                          const double* shift, const double* scale, const double* var, const double* events_per_base,
+                          double indel_bias, uint32_t flags)
+{
+    std::vector<ReadHolder*> hs;
+    std::vector<HMMInputData> data;
+    for(int i = 0; i < n_data; ++i) {
+        hs.push_back(new ReadHolder(kit, event_mean + event_off[i], (int)(event_off[i+1] - event_off[i]), NULL,
+                                    shift[i], scale[i], 0.0, var[i], events_per_base[i]));
+        data.push_back(make_data(*hs.back(), kit, alphabet, e_start[i], e_stop[i], stride[i], rc[i]));
+    }
+    HMMInputSequence sq(seq, alphabet_by_name(alphabet));
+    hmm_indel_bias_factor = indel_bias;
+    float s = profile_hmm_score(sq, data, flags);
+    hmm_indel_bias_factor = 1.0;
+    for(size_t i = 0; i < hs.size(); ++i) delete hs[i];
+    return s;
+}
+
 // profile_hmm_score_set (src/hmm/nanopolish_profile_hmm.cpp:32-56): sequences[0] nucleotide, others by alphabet name
 float npref_hmm_score_set(const char* kit, int n_seqs, const char* const* seqs, const char* const* alphabets,
                           const float* event_mean, int n_events_total,
@@ -263,6 +297,19 @@ int npref_hmm_align(const char* kit, const char* alphabet, const char* seq, cons
         out_l_fm[i] = r[i].l_fm; out_state[i] = r[i].state;
     }
     return n;
+}
+
+// ---- allocator settings for the CPU baseline (process-wide, harness only; the reference code is untouched) ----
+// adaptive_banded_simple_event_align mallocs and frees ~6.5 MB of band + trace arrays per read
+// (src/nanopolish_raw_loader.cpp:123-138).  With glibc's defaults every one of them is an mmap/munmap pair plus a page
+// fault per 4 KB, and on a many-core host the OpenMP threads serialise on the process's address-space lock: 256 threads
+// then align 1.5 reads/s/core instead of ~30.  Keeping those blocks in the per-thread arenas (no mmap for them, no
+// trimming on free) removes the allocator from the measurement.
+void npref_tune_malloc(void)
+{
+    mallopt(M_MMAP_THRESHOLD, 32 << 20);       // DEFAULT_MMAP_THRESHOLD_MAX on 64-bit
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_TOP_PAD, 16 << 20);
 }
 
 // ---- CPU baseline driver: align + (2 x score per job) over many reads, OpenMP over reads ----

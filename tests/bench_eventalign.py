@@ -6,7 +6,8 @@ recalibration -> align_read_to_ref's segment chain (np_eventalign_dev), beside t
 This is a measurement tool for DESIGN.md / profiles/, not the driver's bench (bench.py keeps the call-methylation metric); it
 lives under tests/ because its CPU leg runs the oracle.
 
-    python tests/bench_eventalign.py [--pool 256] [--tile 32] [--read-len 5450] [--steps 3] [--cpu-sample 64]
+    python tests/bench_eventalign.py [--pool 1000] [--tile 50] [--read-len 5450] [--steps 3] [--cpu-sample 64]
+(also reachable as `python bench.py --workload eventalign`)
 """
 import argparse
 import json
@@ -22,8 +23,8 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--pool", type=int, default=256)
-    ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--pool", type=int, default=1000, help="distinct reads")
+    ap.add_argument("--tile", type=int, default=50, help="HBM copies of the pool: pool x tile = 50 000 reads per step (BASELINE.json configs[2])")
     ap.add_argument("--read-len", type=int, default=5450)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)

@@ -7,7 +7,9 @@ window's event bounds resolved on the device from the reads' event maps.  The ea
 (kernel benchmark).  Prints one JSON line; a sample of the scores is checked against the reference's own
 profile_hmm_score (oracle/_ref) -- which is why this tool lives under tests/.
 
-    python tests/bench_variants.py [--reads 64] [--tile 8] [--stride 2] [--steps 3] [--cpu-sample 20000]
+    python tests/bench_variants.py [--reads 250] [--tile 8] [--stride 1] [--indel-bias 0.9] [--steps 3] [--cpu-sample 20000]
+(defaults = BASELINE.json configs[3]: 10 kb window x 2 000 reads, every position, hmm_indel_bias_factor 0.9 as
+src/nanopolish_call_variants.cpp:1116 sets it for --consensus; also reachable as `python bench.py --workload variants`)
 """
 import argparse
 import ctypes as C
@@ -41,9 +43,10 @@ def haplotypes(ref, i):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--draft", type=int, default=10000)
-    ap.add_argument("--reads", type=int, default=64, help="distinct reads covering the draft")
+    ap.add_argument("--reads", type=int, default=250, help="distinct reads covering the draft")
     ap.add_argument("--tile", type=int, default=8, help="independent copies of the read set in HBM")
-    ap.add_argument("--stride", type=int, default=2, help="screen every stride-th draft position")
+    ap.add_argument("--stride", type=int, default=1, help="screen every stride-th draft position")
+    ap.add_argument("--indel-bias", type=float, default=0.9, help="hmm_indel_bias_factor (src/nanopolish_call_variants.cpp:1116)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=20000, help="work items for the CPU baseline / parity check (0: skip)")
@@ -56,7 +59,7 @@ def main():
     from nanopolish_amd.synth import synth_read_from_codes, BASES
     models = load_models()
     nuc = models["nucleotide"]
-    ctx = Context(0)
+    ctx = Context(0, indel_bias=args.indel_bias)
     m_nuc = ctx.register_model(nuc, "nucleotide")
     L_ = ctx.L
     rng = np.random.default_rng(4)
@@ -142,7 +145,7 @@ def main():
                steps=args.steps, ms_per_step=round(1e3 * dt / args.steps, 3), calls_per_step=scored, items_per_step=NJ,
                hmm_kernel_ms_per_step=round(ctx.kernel_time(1)[0] / args.steps, 3),
                config=dict(workload="variants --consensus screening shape (BASELINE.json configs[3]): 22-base windows, base + single-base edits",
-                           draft=Ld, reads=N, distinct_reads=n, positions=len(positions), haplotypes=n_seq, indel_bias=1.0))
+                           draft=Ld, reads=N, distinct_reads=n, positions=len(positions), haplotypes=n_seq, indel_bias=args.indel_bias))
     if args.cpu_sample > 0:
         try:
             from oracle import RefOracle, Oracle, have_ref
@@ -157,10 +160,12 @@ def main():
             rcs = [api.reverse_complement("nucleotide", q) for q in seqs]
             if have_ref():
                 refo = RefOracle()
+                refo.set_indel_bias(args.indel_bias)
                 got = refo.score_many_reads("nucleotide", events[:ne], event_off, [r["shift"] for r in reads], [r["scale"] for r in reads],
                                             [r["var"] for r in reads], epb[:n], job_off, seqs, rcs, jh["e_start"][pick], jh["e_stop"][pick],
                                             jh["stride"][pick], [int(reads[i]["rc"]) for i in rd_of], 3, threads)
                 t_cpu = refo.last_call_s
+                refo.set_indel_bias(1.0)
                 out["cpu_baseline"] = dict(value=round(len(pick) / t_cpu, 1), unit="calls/s", cores=threads, kind="reference",
                                            sample="%d of the same work items, OpenMP over reads" % len(pick),
                                            max_abs_diff=float(np.max(np.abs(got.astype(np.float64) - sc[pick].astype(np.float64)))))

@@ -61,3 +61,62 @@ def test_reference_harness_through_the_shim_reproduces_goldens(dropin, orc, mode
                   for sg in segs[:4]]                                                                   # profile_hmm_score_set
             assert np.array_equal(np.array(ss, np.float32), g[p + "score_set"])
     assert n_scores > 200
+
+
+def test_vector_overload_through_the_shim(dropin, orc, models):
+    """a8: profile_hmm_score(sequence, std::vector<HMMInputData>, flags) of np_dropin.cpp (one device batch over the reads, fp32
+    sum in index order) against the single-call goldens semantics pinned on the unmodified reference in
+    tests/test_oracle_vs_ref.py::test_vector_overload_is_the_fp32_sum_in_index_order."""
+    from cases import vector_overload_case
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_reads.npz"))
+    n = 0
+    for rid, L in zip(g["read_ids"], g["read_L"]):
+        p = "r%d_" % rid
+        if p + "score_meth" not in g.files:
+            continue
+        rd = synth_read(int(rid), models["nucleotide"], L=int(L))
+        epb, seq, rc_seq, datas = vector_overload_case(orc, rd, g[p + "pairs"])
+        if len(datas) < 3:
+            continue
+        mc = orc.model(models["cpg"])
+        for flags in (0, HAF_PRE | HAF_POST):
+            want = np.float32(0.0)
+            for d in datas:
+                ranks = orc.sequence_kmer_ranks("cpg", seq, rc_seq, K, d["rc"])
+                s = orc.hmm_score(mc, orc.scalings(d["shift"], d["scale"], d["var"]), d["events"], ranks, d["e_start"], d["e_stop"], d["stride"],
+                                  d["events_per_base"], 1.0, flags)
+                want = np.float32(want + np.float32(s))
+            got = dropin.hmm_score_vec("cpg", seq, datas, 1.0, flags)
+            assert np.float32(got) == want
+            n += 1
+    assert n >= 4
+
+
+def test_model_overwritten_in_place_is_refreshed_on_the_device(dropin, orc, models):
+    """The shim caches device models by PoreModel address; the reference overwrites registered models in place
+    (pore_model_set.cpp:70, methyltrain).  After such an overwrite the next call must score against the NEW parameters."""
+    rd = synth_read(102, models["nucleotide"], L=1000)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_reads.npz"))
+    pairs = g["r102_pairs"]
+    epb, jobs = methylation_jobs(orc, rd, pairs)
+    j = jobs[0]
+
+    def device_score():
+        return dropin.hmm_score("cpg", j["subseq"], j["rc_subseq"], rd["events"], j["e1"], j["e2"], j["stride"], j["rc"], rd["shift"],
+                                rd["scale"], rd["var"], epb, 1.0, HAF_PRE | HAF_POST)
+
+    def oracle_score():
+        mc = orc.model(dropin.model("cpg"))          # the parameters the reference-side PoreModel holds right now
+        ranks = orc.sequence_kmer_ranks("cpg", j["subseq"], j["rc_subseq"], K, j["rc"])
+        return orc.hmm_score(mc, orc.scalings(rd["shift"], rd["scale"], rd["var"]), rd["events"], ranks, j["e1"], j["e2"], j["stride"], epb,
+                             1.0, HAF_PRE | HAF_POST)
+
+    s0 = device_score()
+    assert s0 == oracle_score()
+    dropin.shift_model("cpg", 1.5)
+    try:
+        s1 = device_score()
+        assert s1 == oracle_score() and s1 != s0
+    finally:
+        dropin.shift_model("cpg", -1.5)
+    assert device_score() == oracle_score()

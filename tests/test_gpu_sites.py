@@ -1,0 +1,118 @@
+"""f4 on the device (np_site_table_dev) and profile_hmm_score_set's combination on the device (np_hmm_score_set_combine_dev),
+through the C ABI on the MI355X, against the text path (printf "%.2lf" + the frequency script's rules, nanopolish_amd/sites.py
+host mirror and nanopolish_amd/output.py) and against np_hmm_score_set_host / the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _scores_with_boundaries(rng, n):
+    """(unmethylated, methylated) float32 pairs whose differences sit on and around the text round trip's decision points:
+    x.xx5 ties (exactly representable eighths), the call threshold 2.0 * n_motif, sign changes, plus random values."""
+    u = rng.uniform(-400, -50, n).astype(np.float32)
+    d = rng.normal(0, 6, n)
+    special = np.array([0.125, -0.125, 0.375, 2.125, -2.125, 1.995, 2.0, -2.0, 2.005, 1.9949999, 3.995, 4.0, 4.005, -3.995, 5.995, 6.0,
+                        0.0, 0.004999, -0.004999, 0.005, 7.625, -7.625, 1.875, 2.375, 12.5, -12.5])
+    k = len(special)
+    d[:k] = special
+    d[k:2 * k] = special + rng.choice([-1, 1], k) * 2.0 ** -15         # one float ulp (at |score| in [64,128)) off the boundary
+    u[:2 * k] = -64.0 - rng.integers(0, 32, 2 * k)                      # exact in fp32, so that m - u == d exactly
+    m = (u.astype(np.float64) + d).astype(np.float32)
+    return u, m
+
+
+def test_site_table_on_the_device_equals_the_text_path(ctx):
+    import torch
+    from nanopolish_amd.sites import site_table, site_table_dev
+    rng = np.random.default_rng(11)
+    n, n_pos = 20000, 3000
+    u, m = _scores_with_boundaries(rng, n)
+    skip = rng.random(n) < 0.1
+    u[skip] = np.nan; m[skip] = np.nan
+    first = rng.integers(0, n_pos, n).astype(np.int32)
+    nm = rng.integers(1, 4, n).astype(np.int32)
+    sc = np.stack([u, m], 1).reshape(-1)
+    dev = torch.device("cuda:0")
+    t = site_table_dev(ctx, torch, torch.from_numpy(sc).to(dev), torch.from_numpy(first).to(dev), torch.from_numpy(nm).to(dev), n_pos)
+    ctx.sync()
+    llr = torch.from_numpy(m.astype(np.float64) - u.astype(np.float64))
+    want = site_table(torch, torch.from_numpy(first.astype(np.int64)), torch.from_numpy(nm.astype(np.int64)), llr, n_pos)
+    assert want[:, 0].sum() > 5000
+    assert np.array_equal(t.cpu().numpy(), want.numpy())
+    # the text path itself: TSV lines in the reference writer's format -> calculate_methylation_frequency.py's rules
+    from nanopolish_amd.output import methylation_tsv_header, format_methylation_tsv, calculate_methylation_frequency
+    keep = ~skip
+    lines = [methylation_tsv_header()]
+    for f, k, uu, mm in zip(first[keep], nm[keep], u[keep], m[keep]):
+        lines += format_methylation_tsv([dict(chromosome="c", start_position=int(f), end_position=int(f), n_motif=int(k), sequence="CG",
+                                              ll_methylated=[float(mm), 0.0], ll_unmethylated=[float(uu), 0.0], strands_scored=1)], "r", False)
+    freq = calculate_methylation_frequency(lines)[1:]
+    tt = t.cpu().numpy()
+    assert len(freq) == int((tt[:, 0] > 0).sum())
+    for ln in freq:
+        f = ln.split("\t")
+        assert tt[int(f[1]), 1] == int(f[4]) and tt[int(f[1]), 2] == int(f[5])
+
+
+def test_site_table_with_read_offsets(ctx):
+    import torch
+    from nanopolish_amd.pipeline import JOB_DT
+    from nanopolish_amd.sites import site_table_dev
+    dev = torch.device("cuda:0")
+    sc = np.array([-100, -90, -100, -99.5, np.nan, np.nan, -80, -90], np.float32)       # llr 10, 0.5 (ambiguous), skipped, -10
+    first = np.array([5, 5, 7, 5], np.int32); nm = np.array([1, 1, 1, 2], np.int32)
+    jobs = np.zeros(8, JOB_DT); jobs["read"] = [0, 0, 0, 0, 1, 1, 1, 1]
+    base = np.array([100, 200], np.int64)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+    t = site_table_dev(ctx, torch, up(sc).view(torch.float32), up(first).view(torch.int32), up(nm).view(torch.int32), 300,
+                       jobs=up(jobs), read_base=up(base).view(torch.int64))
+    ctx.sync()
+    t = t.cpu().numpy()
+    assert tuple(t[105]) == (1, 1, 1) and tuple(t[205]) == (1, 2, 0) and int(t.sum()) == 6
+
+
+def test_score_set_combination_on_the_device(ctx, orc, models):
+    """profile_hmm_score_set with members scored model by model on the device and combined by np_hmm_score_set_combine_dev ==
+    np_hmm_score_set_host == the oracle's combine_score_set."""
+    import torch
+    from cases import K, synth_read, eventalign_segments
+    rd = synth_read(7, models["nucleotide"], L=1500)
+    mn = orc.model(models["nucleotide"])
+    sh, sc_ = orc.estimate_scalings_mom(mn, rd["ranks"], rd["events"])
+    pairs = orc.event_align(mn, orc.scalings(sh, sc_, 1.0), rd["events"], rd["ranks"])
+    epb, segs = eventalign_segments(orc, rd, pairs)
+    sets, member_scores = [], []
+    for sg in segs[:12]:
+        seqs = [sg["seq"][:30], orc.methylate("cpg", sg["seq"][:30]), sg["seq"][1:31]]
+        alph = ["nucleotide", "cpg", "nucleotide"]
+        n_members = 2 + (len(sets) % 2)
+        jobs = []
+        for s, a in list(zip(seqs, alph))[:n_members]:
+            jobs.append(dict(events=rd["events"], ranks=orc.sequence_kmer_ranks(a, s, None, K, 0), e_start=sg["e1"], e_stop=sg["e1"] + 40, stride=1,
+                             model=ctx.models[a], scale=rd["scale"], shift=rd["shift"], var=rd["var"], events_per_base=epb, flags=0,
+                             indel_bias=0.9))
+        sets.append(jobs)
+    want = ctx.profile_hmm_score_set(sets)
+    flat = [j for s in sets for j in s]
+    singles = ctx.profile_hmm_score(flat) if len({j["model"] for j in flat}) == 1 else np.concatenate(
+        [ctx.profile_hmm_score([j]) for j in flat])
+    # members in a shuffled score array + an index, and in set order without one
+    off = np.zeros(len(sets) + 1, np.int64); off[1:] = np.cumsum([len(s) for s in sets])
+    perm = np.random.default_rng(3).permutation(len(flat))
+    shuffled = np.zeros(len(flat), np.float32); shuffled[perm] = singles
+    dev = torch.device("cuda:0")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    d_off = torch.from_numpy(off).to(dev)
+    for scores, idx in ((singles, None), (shuffled, perm.astype(np.int64))):
+        d_sc = torch.from_numpy(scores).to(dev); d_idx = torch.from_numpy(idx).to(dev) if idx is not None else None
+        d_out = torch.zeros(len(sets), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        ctx._chk(ctx.L.np_hmm_score_set_combine_dev(ctx.h, None, len(sets), p(d_off), p(d_idx) if d_idx is not None else None,
+                                                            p(d_sc), p(d_out)), "np_hmm_score_set_combine_dev")
+        ctx.sync()
+        assert np.array_equal(d_out.cpu().numpy(), want)
+    for q, s in enumerate(sets):
+        assert want[q] == np.float32(orc.combine_score_set(singles[off[q]:off[q + 1]]))

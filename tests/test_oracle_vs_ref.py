@@ -93,3 +93,23 @@ def test_event_detection_bit_equal(ref, orc, models):
             a, b = orc.detect_events(raw, **prm), ref.detect_events(raw, **prm)
             for k in a:
                 assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+def test_vector_overload_is_the_fp32_sum_in_index_order(ref, orc, models):
+    """a8: profile_hmm_score(sequence, vector<HMMInputData>) of the unmodified reference == its own single-read scores added
+    up in fp32, front to back (src/hmm/nanopolish_profile_hmm.cpp:14-21) -- what the GPU drop-in test then expects."""
+    from cases import vector_overload_case
+    for rid in (102, 103):
+        rd = synth_read(rid, models["nucleotide"], L=1000)
+        sh, sc = ref.estimate_scalings_mom(rd["seq"], rd["events"])
+        pairs = ref.event_align(rd["events"], rd["seq"], sh, sc)
+        epb, seq, rc_seq, datas = vector_overload_case(orc, rd, pairs)
+        assert len(datas) >= 3
+        for flags in (0, HAF_PRE | HAF_POST):
+            singles = [ref.hmm_score("cpg", seq, None, d["events"], d["e_start"], d["e_stop"], d["stride"], d["rc"], d["shift"], d["scale"],
+                                     d["var"], d["events_per_base"], 1.0, flags) for d in datas]
+            want = np.float32(0.0)
+            for s in singles:
+                want = np.float32(want + np.float32(s))
+            got = ref.hmm_score_vec("cpg", seq, datas, 1.0, flags)
+            assert np.isfinite(got) and np.float32(got) == want
