@@ -158,16 +158,37 @@ def cpu_pass(models, hb, idx, thread_list, calibrate, from_raw, repeats=2):
                 first=first, scores=sc, kind="reference" if ref else "port")
 
 
+def usable_cores():
+    """Hardware threads this process may actually run on: the affinity mask, capped by the cgroup CPU quota (a container that
+    SEES 256 cores but is throttled to a fraction of them is the usual reason an OpenMP run with 256 threads crawls)."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]               # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    eff = n if quota is None else max(1, min(n, int(quota + 0.5)))
+    return n, quota, eff
+
+
 def cpu_baseline(models, hb, calibrate, from_raw, budget_reads):
     """The CPU line: one thread first (t1), then the same reads-per-thread load (>= 32 reads per thread) on every available
     hardware thread and on half of them (SMT siblings share a core's FP units); the best multi-thread rate is `value`."""
-    cores = len(os.sched_getaffinity(0))
+    visible, quota, cores = usable_cores()
     pool = len(hb["reads"])
     n1 = min(pool, 24)
     c1 = cpu_pass(models, hb, list(range(n1)), [1], calibrate, from_raw, repeats=1)
     t1 = c1["timings"][1]
     out = dict(t1_value=round(n1 / t1["seconds"], 2), t1_reads=n1, unit="reads/s", kind=c1["kind"])
-    cands = sorted({c for c in (cores, cores // 2) if c >= 2}, reverse=True)
+    out.update(visible_cores=visible, cgroup_cpu_quota=quota)
+    cands = sorted({c for c in (cores, cores // 2, cores // 4) if c >= 2}, reverse=True)
     if not cands:
         out.update(value=out["t1_value"], cores=cores, threads=1, per_core=out["t1_value"], sample="%d reads on one thread" % n1)
         return out, c1
@@ -391,7 +412,7 @@ def main():
         streamed = dict(value=round(world * n_reads * args.steps / dts, 2), ms_per_step=round(dts / args.steps * 1e3, 3),
                         h2d_bytes_per_step=feed.h2d_bytes, d2h_bytes_per_step=feed.d2h_bytes,
                         pcie_GBps=round((feed.h2d_bytes + feed.d2h_bytes) * args.steps / dts / 1e9, 2),
-                        results_equal_resident=bool(same))
+                        results_equal_resident=bool(same), host_enqueue_ms_last_steps=feed.host_ms[-args.steps:])
         feed.close()
         batch.stream = None
 
@@ -474,7 +495,7 @@ def main():
                       read_len=dict(mean=round(float(lens.mean()), 1), p50=int(np.median(lens)), min=int(lens.min()), max=int(lens.max())),
                       mean_events=round(nev_r / rb.n_reads, 1),
                       events_per_s=round(world * nev_r * args.steps / dtr, 1),
-                      event_align_ms_per_step=round(a_ms / max(a_n - args.warmup, 1), 3) if a_n else None,
+                      event_align_ms_per_step=round(a_ms / a_n, 3) if a_n else None,
                       reads_aligned_ok=int((rb.d_n_pairs > 0).sum().item()))
         del rb
         torch.cuda.empty_cache()

@@ -65,7 +65,7 @@ struct np_ctx {
     std::vector<float> h_logsum;
     float* d_flank = nullptr;
     uint32_t* d_counters = nullptr;   // [0..6] class counts, [8..15] work-queue heads, [16] align queue head, [32] self-test, [1024..] bins
-    dev_buf order, trace, kparams;
+    dev_buf order, trace, kparams, align_order;
     // host-API staging
     dev_buf b_jobs, b_reads, b_events, b_ranks, b_out, b_pair_off, b_pairs, b_pair_begin, b_n_pairs,
             b_vm, b_bp, b_cell_off, b_state_off, b_states, b_n_states;
@@ -78,6 +78,7 @@ struct np_ctx {
     std::mutex lock;
     std::string err;
     int align_blocks_per_cu = 8, hmm_blocks_per_cu = 2;
+    int align_lpt = 1;                // issue the event aligner's reads longest first
     int ed_warmup = -1;               // parallel peak walk: samples of warm-up per segment (< 0: the kernel's default)
 };
 
@@ -184,6 +185,7 @@ int run_event_align(np_ctx* c, hipStream_t s, int n_reads, const np_read_dev* re
     if ((uint64_t)nb * per_block > budget) nb = (int)std::max<uint64_t>(1, budget / per_block);
     NP_HIP(c, c->trace.reserve((size_t)nb * waves_per_block * stride * sizeof(uint64_t)));
     NP_HIP(c, c->kparams.reserve((size_t)nb * waves_per_block * kp_stride * sizeof(float4)));
+    NP_HIP(c, c->align_order.reserve((size_t)(2048 + n_reads) * sizeof(uint32_t)));
     NP_HIP(c, hipMemsetAsync(c->d_counters + 16, 0, sizeof(uint32_t), s));
     np_align_args a{};
     a.reads = reads; a.event_mean = event_mean; a.ranks = ranks; a.model = c->models[model].d_states;
@@ -193,6 +195,10 @@ int run_event_align(np_ctx* c, hipStream_t s, int n_reads, const np_read_dev* re
     a.n_reads = n_reads; a.max_gap_threshold = c->params.max_gap_threshold;
     a.min_average_log_emission = c->params.min_average_log_emission;
     family_timer tm(c, 0, s);
+    if (c->align_lpt && n_reads > nb * waves_per_block) {       // more reads than resident waves: the issue order matters
+        NP_HIP(c, np_launch_align_order(n_reads, reads, c->align_order.as<uint32_t>(), s));
+        a.order = c->align_order.as<uint32_t>() + 2048;
+    }
     NP_HIP(c, np_launch_event_align(a, nb, s));
     return NP_OK;
 }
@@ -227,6 +233,7 @@ np_ctx* np_create(int device, const np_params* params)
     // tuning knobs (persistent-grid sizes); defaults fill the CU up to the kernels' register-limited occupancy
     if (const char* v = getenv("NP_ALIGN_BLOCKS_PER_CU")) c->align_blocks_per_cu = std::max(1, atoi(v));
     if (const char* v = getenv("NP_HMM_BLOCKS_PER_CU")) c->hmm_blocks_per_cu = std::max(1, atoi(v));
+    if (const char* v = getenv("NP_ALIGN_LPT")) c->align_lpt = atoi(v) != 0;
     if (const char* v = getenv("NP_EA_WAVES_PER_CU")) c->ea_waves_per_cu = std::max(1, atoi(v));
     if (params) c->params = *params; else np_default_params(&c->params);
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
@@ -276,7 +283,7 @@ void np_destroy(np_ctx* c)
     dev_buf* bufs[] = {&c->order, &c->trace, &c->kparams, &c->b_jobs, &c->b_reads, &c->b_events, &c->b_ranks, &c->b_out, &c->b_pair_off,
                        &c->b_pairs, &c->b_pair_begin, &c->b_n_pairs, &c->b_vm, &c->b_bp, &c->b_cell_off, &c->b_state_off,
                        &c->b_states, &c->b_n_states, &c->ed_status, &c->ed_tstat, &c->b_raw, &c->b_raw_off, &c->b_ev_off, &c->b_ev_start,
-                       &c->b_ev_len, &c->b_ev_mean, &c->b_ev_stdv, &c->b_n_events, &c->cm_group_rank_off, &c->cm_cigar_scratch, &c->ea_bp, &c->ea_path};
+                       &c->b_ev_len, &c->b_ev_mean, &c->b_ev_stdv, &c->b_n_events, &c->cm_group_rank_off, &c->cm_cigar_scratch, &c->ea_bp, &c->ea_path, &c->align_order};
     for (dev_buf* b : bufs) b->release();
     for (auto& t : c->timing) {
         for (auto& pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -796,6 +803,7 @@ int np_set_option(np_ctx* c, const char* name, int64_t value)
     const std::string k(name);
     if (k == "align_blocks_per_cu") c->align_blocks_per_cu = (int)std::max<int64_t>(1, value);
     else if (k == "hmm_blocks_per_cu") c->hmm_blocks_per_cu = (int)std::max<int64_t>(1, value);
+    else if (k == "align_lpt") c->align_lpt = value != 0;
     else if (k == "ed_warmup") c->ed_warmup = (int)value;
     else if (k == "ea_rows_cap") c->ea_rows_cap = (int)std::min<int64_t>(65535, std::max<int64_t>(16, value));
     else if (k == "ea_waves_per_cu") c->ea_waves_per_cu = (int)std::max<int64_t>(1, value);

@@ -81,6 +81,24 @@ __device__ __forceinline__ float np_div_exact(float n, float d, float r)
     return q;
 }
 
+// the same with the NEGATED divisor handed over (nd = -d): the two fused corrections then need no operand modifier, and a
+// caller that keeps -d instead of d (kernel A's per-k-mer records) never forms the negation
+__device__ __forceinline__ float np_div_exact_nd(float n, float nd, float r)
+{
+    float q = n * r;
+    float e = __builtin_fmaf(nd, q, n);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(nd, q, n);
+    q = __builtin_fmaf(e, r, q);
+    return q;
+}
+// log_probability_match_r9 with the record (mean, -stdv, log-constant, 1/stdv)
+__device__ __forceinline__ float np_emission_nd(float x, float mean, float nstdv, float cl, float rinv)
+{
+    const float a = np_div_exact_nd(x - mean, nstdv, rinv);
+    return cl + (-0.5f * a * a);
+}
+
 // log_probability_match_r9 (src/hmm/nanopolish_emissions.h:57-68) with drift == 0.
 __device__ __forceinline__ float np_emission(float x, const np_gauss& g)
 {

@@ -192,7 +192,10 @@ __global__ void __launch_bounds__(64) np_cm_groups_kernel(int n_reads, const cha
     n_groups[r] = overflow ? -1 : ng;
 }
 
-// pass 2, one block per read: every group's two work items and their k-mer ranks
+// pass 2, one block per read: every group's two work items and their k-mer ranks.
+// The k-mers of all groups of the read form one flat index space (group_rank_off is its prefix sum, two rank arrays per
+// group), so every thread of the block has a k-mer to rank in every iteration; the group of a flat index is found by a
+// binary search over the read's (L1-resident) offsets.  A k-mer and its methylated twin need the 8 bases around it once.
 __global__ void __launch_bounds__(256) np_cm_items_kernel(int n_reads, const char* __restrict__ seq, const int64_t* __restrict__ seq_off,
                                                           const int32_t* __restrict__ seq_len, const int32_t* __restrict__ group_kpos,
                                                           const uint8_t* __restrict__ read_rc, int alphabet, int k, int min_flank,
@@ -210,42 +213,67 @@ __global__ void __launch_bounds__(256) np_cm_items_kernel(int n_reads, const cha
     const int64_t g0 = group_off[r];
     const int cap = (int)(group_off[r + 1] - g0);
     const int ng = n_groups[r] > 0 ? n_groups[r] : 0;
-    // unused slots: items the scoring kernel drops (score NaN)
-    for (int g = ng + threadIdx.x; g < cap; g += 256) {
-        for (int v = 0; v < 2; ++v) {
-            np_hmm_job_dev jb; jb.rank_off = 0; jb.n_kmers = 0; jb.read = (uint32_t)r; jb.e_start = jb.e_stop = 0; jb.stride = 1; jb.flags = NP_JOB_SKIP;
-            jobs[2 * (g0 + g) + v] = jb;
-            kpos[2 * (2 * (g0 + g) + v)] = 0; kpos[2 * (2 * (g0 + g) + v) + 1] = 0;
+    // the work-item records: two per group slot; unused slots are items the scoring kernel drops (score NaN)
+    for (int g = threadIdx.x; g < cap; g += 256) {
+        np_hmm_job_dev jb; jb.rank_off = 0; jb.n_kmers = 0; jb.read = (uint32_t)r; jb.e_start = jb.e_stop = 0; jb.stride = 1; jb.flags = NP_JOB_SKIP;
+        int k0 = 0, k1 = 0, nk = 0;
+        if (g < ng) {
+            const int sub_start = first_site[g0 + g] - min_flank, sub_end = last_site[g0 + g] + min_flank;
+            nk = sub_end - sub_start + 1 - k + 1;
+            jb.rank_off = group_rank_off[g0 + g]; jb.n_kmers = (uint32_t)nk;
+            jb.flags = NP_HAF_ALLOW_PRE_CLIP | NP_HAF_ALLOW_POST_CLIP;                        // basemods.cpp:363
+            // read-strand k-mer positions of the window ends (flip_k_strand for reverse-strand reads, squiggle_read.h:229-233)
+            k0 = group_kpos ? group_kpos[2 * (g0 + g)] : (rc ? n - sub_start - k : sub_start);
+            k1 = group_kpos ? group_kpos[2 * (g0 + g) + 1] : (rc ? n - sub_end - k : sub_end);
         }
+        jobs[2 * (g0 + g)] = jb;                                       // unmethylated
+        jb.rank_off += nk;
+        jobs[2 * (g0 + g) + 1] = jb;                                   // methylated
+        int4 kp; kp.x = k0; kp.y = k1; kp.z = k0; kp.w = k1;
+        *(int4*)(kpos + 4 * (g0 + g)) = kp;
     }
-    for (int g = 0; g < ng; ++g) {
+    if (ng == 0) return;
+    const int64_t base = group_rank_off[g0];
+    const int nk_last = last_site[g0 + ng - 1] - first_site[g0 + ng - 1] + 2 * min_flank + 1 - k + 1;
+    const int total = (int)((group_rank_off[g0 + ng - 1] - base) >> 1) + nk_last;
+    for (int t = threadIdx.x; t < total; t += 256) {
+        int lo = 0, hi = ng - 1;                                       // the last group whose first k-mer is <= t
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if ((int)((group_rank_off[g0 + mid] - base) >> 1) <= t) lo = mid; else hi = mid - 1;
+        }
+        const int g = lo;
+        const int64_t ro = group_rank_off[g0 + g];
+        const int i = t - (int)((ro - base) >> 1);
         const int sub_start = first_site[g0 + g] - min_flank, sub_end = last_site[g0 + g] + min_flank;
         const int len = sub_end - sub_start + 1, nk = len - k + 1;
-        const int64_t ro = group_rank_off[g0 + g];
-        if (threadIdx.x < 2) {
-            const int v = threadIdx.x;                                 // 0: unmethylated, 1: methylated
-            np_hmm_job_dev jb;
-            jb.rank_off = ro + (int64_t)v * nk; jb.n_kmers = (uint32_t)nk; jb.read = (uint32_t)r; jb.e_start = jb.e_stop = 0; jb.stride = 1;
-            jb.flags = NP_HAF_ALLOW_PRE_CLIP | NP_HAF_ALLOW_POST_CLIP;                        // basemods.cpp:363
-            jobs[2 * (g0 + g) + v] = jb;
-            // read-strand k-mer positions of the window ends (flip_k_strand for reverse-strand reads, squiggle_read.h:229-233)
-            kpos[2 * (2 * (g0 + g) + v)] = group_kpos ? group_kpos[2 * (g0 + g)] : (rc ? n - sub_start - k : sub_start);
-            kpos[2 * (2 * (g0 + g) + v) + 1] = group_kpos ? group_kpos[2 * (g0 + g) + 1] : (rc ? n - sub_end - k : sub_end);
-        }
-        for (int i = threadIdx.x; i < nk; i += 256) {
-            // HMMInputSequence::get_kmer_rank(i, k, do_rc): the forward k-mer at i, or the reverse-complement string's k-mer at
-            // len - i - k
-            uint32_t ru = 0, rm = 0;
-            for (int t = 0; t < k; ++t) {
-                char cu, cm;
-                if (!rc) { cu = ref[sub_start + i + t]; cm = meth_char(ref, sub_start, len, i + t, s); }
-                else { const int j = len - i - k + t; cu = comp(ref[sub_start + len - 1 - j]); cm = rc_meth_char(ref, sub_start, len, j, s); }
-                ru = ru * 5u + (uint32_t)digit(cu);
+        // HMMInputSequence::get_kmer_rank(i, k, do_rc): the forward k-mer at i, or the reverse-complement string's k-mer at
+        // len - i - k, i.e. window characters i+k-1 down to i complemented.  Either way the characters are window positions
+        // i .. i+k-1, and methylation looks one position to each side INSIDE the window (Alphabet::methylate of the window).
+        uint32_t ru = 0, rm = 0;
+        char prev = i > 0 ? ref[sub_start + i - 1] : 0;
+        char cur = ref[sub_start + i];
+        if (!rc) {
+            for (int q = i; q < i + k; ++q) {
+                const char nxt = q + 1 < len ? ref[sub_start + q + 1] : 0;
+                const char cm = (cur == s.a && nxt == s.b) ? s.ma : ((cur == s.b && prev == s.a) ? s.mb : cur);
+                ru = ru * 5u + (uint32_t)digit(cur);
                 rm = rm * 5u + (uint32_t)digit(cm);
+                prev = cur; cur = nxt;
             }
-            job_ranks[ro + i] = (uint16_t)ru;
-            job_ranks[ro + nk + i] = (uint16_t)rm;
+        } else {
+            uint32_t pw = 1;                                           // window position q contributes digit * 5^(q - i)
+            for (int q = i; q < i + k; ++q) {
+                const char nxt = q + 1 < len ? ref[sub_start + q + 1] : 0;
+                const char cm = (cur == s.a && nxt == s.b) ? s.ca : ((cur == s.b && prev == s.a) ? s.cb : comp(cur));
+                ru += pw * (uint32_t)digit(comp(cur));
+                rm += pw * (uint32_t)digit(cm);
+                pw *= 5u;
+                prev = cur; cur = nxt;
+            }
         }
+        job_ranks[ro + i] = (uint16_t)ru;
+        job_ranks[ro + nk + i] = (uint16_t)rm;
     }
 }
 

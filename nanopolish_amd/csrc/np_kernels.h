@@ -73,6 +73,7 @@ struct np_align_args {
     float4* kparams;               // scratch: n_wave_slots * kp_stride records (scaled Gaussian per k-mer of the read in flight)
     uint64_t kp_stride;            // records per resident wave (>= max k-mers per read)
     uint32_t* counter;
+    const uint32_t* order;         // issue order of the read queue (longest first), or null: index order
     int32_t n_reads;
     int32_t max_gap_threshold;
     double min_average_log_emission;
@@ -87,6 +88,7 @@ hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, hi
 hipError_t np_launch_hmm_viterbi(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s);
 hipError_t np_launch_hmm_backtrack(const np_hmm_args& a, int64_t n_jobs, hipStream_t s);
 hipError_t np_launch_event_align(const np_align_args& a, int n_blocks, hipStream_t s);
+hipError_t np_launch_align_order(int n_reads, const np_read_dev* reads, uint32_t* scratch /* 2048 + n_reads */, hipStream_t s);
 int np_align_block_threads(void);
 int np_hmm_block_threads(int cls);
 int np_vit_block_threads(void);

@@ -526,18 +526,23 @@ class StreamedFeed:
         self.ev_cmp = [None, None]
         self.ev_d2h = [None, None]
         self.k = 0
+        self.read_back = 0           # steps whose read-back has been enqueued
+        self.host_ms = []            # host time of each submit: (enqueue H2D, enqueue compute, enqueue D2H) in ms
         torch.cuda.synchronize()
 
     def submit(self):
+        import time
         torch = self.b.torch
         i = self.k & 1
         st = self.sets[i]
+        t0 = time.perf_counter()
         with torch.cuda.stream(self.s_h2d):
             if self.ev_cmp[i] is not None:
                 self.s_h2d.wait_event(self.ev_cmp[i])          # the step that last read this input set has finished
             for n in self.ins:
                 st[n].copy_(self.host_in[n], non_blocking=True)
             self.ev_h2d[i].record(self.s_h2d)
+        t1 = time.perf_counter()
         self.s_cmp.wait_event(self.ev_h2d[i])
         if self.ev_d2h[i] is not None:
             self.s_cmp.wait_event(self.ev_d2h[i])              # this output set has been read back
@@ -545,15 +550,31 @@ class StreamedFeed:
             setattr(self.b, n, st[n])
         self.b.stream = self.s_cmp.cuda_stream
         self.b.step()
+        t2 = time.perf_counter()
         self.ev_cmp[i] = torch.cuda.Event(); self.ev_cmp[i].record(self.s_cmp)
+        # The read-back of step k is enqueued one submit LATER, behind the host->device copies of step k+1: HIP multiplexes
+        # streams onto a few in-order hardware queues, and when the two copy streams share one, a device->host copy that waits
+        # for the compute of step k would hold back the upload of step k+1 queued behind it -- the upload that is supposed to
+        # run WHILE step k computes (seen as a 20 ms bubble per step in profiles/r02: the upload started only after the
+        # previous step's kernels).
+        if self.read_back < self.k:
+            self._read_back(i ^ 1)                              # step k - 1
+            self.read_back = self.k
+        self.k += 1
+        self.host_ms.append((round((t1 - t0) * 1e3, 2), round((t2 - t1) * 1e3, 2), round((time.perf_counter() - t2) * 1e3, 2)))
+
+    def _read_back(self, i):
+        torch = self.b.torch
         with torch.cuda.stream(self.s_d2h):
             self.s_d2h.wait_event(self.ev_cmp[i])
             for n in self.outs:
-                self.host_out[i][n].copy_(st[n], non_blocking=True)
+                self.host_out[i][n].copy_(self.sets[i][n], non_blocking=True)
             self.ev_d2h[i] = torch.cuda.Event(); self.ev_d2h[i].record(self.s_d2h)
-        self.k += 1
 
     def drain(self):
+        if self.read_back < self.k:
+            self._read_back((self.k - 1) & 1)              # the last step's results
+            self.read_back = self.k
         for s in (self.s_h2d, self.s_cmp, self.s_d2h):
             s.synchronize()
         self.b.sync()

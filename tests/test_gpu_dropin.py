@@ -95,9 +95,9 @@ def test_vector_overload_through_the_shim(dropin, orc, models):
 def test_model_overwritten_in_place_is_refreshed_on_the_device(dropin, orc, models):
     """The shim caches device models by PoreModel address; the reference overwrites registered models in place
     (pore_model_set.cpp:70, methyltrain).  After such an overwrite the next call must score against the NEW parameters."""
-    rd = synth_read(102, models["nucleotide"], L=1000)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_reads.npz"))
-    pairs = g["r102_pairs"]
+    rd = synth_read(2, models["nucleotide"], L=900)
+    pairs = g["r2_pairs"]
     epb, jobs = methylation_jobs(orc, rd, pairs)
     j = jobs[0]
 

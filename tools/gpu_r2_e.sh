@@ -1,0 +1,17 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r02e; mkdir -p $O
+export TMPDIR=/tmp
+V=nanopolish_amd/variants
+( timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_edges.py tests/test_gpu_fullsize.py tests/test_gpu_reflevel.py -m gpu -q -x 2>&1 | tail -5 ) > $O/pytest.log 2>&1
+timeout 400 python tools/align_ab.py $V/libnp_hip_all.so $V/libnp_hip_bt4.so $V/libnp_hip_bt16.so $V/libnp_hip_noearly.so $V/libnp_hip_all.so > $O/align_ab.txt 2>&1
+timeout 200 python tools/align_ab.py --ragged 1 $V/libnp_hip_all.so >> $O/align_ab.txt 2>&1
+( time timeout 400 python bench.py --steps 3 --warmup 1 --cpu-sample 512 ) > $O/bench.log 2> $O/bench.err; echo "rc=$?" >> $O/bench.err
+cat $O/pytest.log $O/align_ab.txt
+python - <<'PY'
+import json
+for l in open("gpurun_out/r02e/bench.log"):
+    if l.startswith("{"):
+        d=json.loads(l); print(d["value"], d["ms_per_step"], d["value_streamed"], d["streamed"]["ms_per_step"], d["value_ragged"], d["roofline"]["kernel_ms_per_step"], d["cpu_baseline"]["value"], d["cpu_baseline"]["check"])
+PY
+tail -2 $O/bench.err
