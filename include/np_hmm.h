@@ -282,7 +282,7 @@ void np_restated_log_exp(const double* x, size_t n, double* out_log, double* out
 /* Device twin of np_cm_build_jobs_identity for a batch of identity-aligned reads: motif scan and grouping
  * (src/basemods/nanopolish_basemods.cpp:298-320), window and boundary rules (:328-345; src/alignment/nanopolish_alignment_db.cpp:
  * 65-71,697-708), methylated / unmethylated k-mer ranks of every window (Alphabet::methylate / reverse_complement,
- * HMMInputSequence::get_kmer_rank).  alphabet: cpg or gpc.  All pointers are device pointers.
+ * HMMInputSequence::get_kmer_rank).  alphabet: cpg, gpc, dam or dcm.  All pointers are device pointers.
  *   ref_seq / seq_off : the reference strand of every read (A/C/G/T bytes, concatenated), int64[n_reads+1]
  *   group_off         : int64[n_reads+1], per-read CAPACITY in groups (slots); total_group_slots = group_off[n_reads] (host value)
  *   rank_off          : int64[n_reads+1], per-read capacity in job k-mer ranks (both versions of all windows)
@@ -394,6 +394,15 @@ int np_mom_fill_dev(np_ctx* ctx, void* stream, int n_reads, np_read_dev* reads, 
 /* Device self-test: the emission's exact fast division (reciprocal + two fused corrections) against the IEEE fp32
  * divide on n_samples pseudo-random operand pairs; *n_mismatch must come back 0. */
 int np_selftest_division(np_ctx* ctx, uint64_t n_samples, uint64_t seed, uint64_t* n_mismatch);
+
+/* Device memory for bindings that are not HIP programs themselves (csrc/np_batch_dropin.cpp is plain C++ inside a nanopolish
+ * build): allocation on the context's device, and copies enqueued on `stream` (0 = the context's own).  Host buffers of the
+ * asynchronous copies must stay valid until np_sync; pageable host memory makes a copy synchronous, as in HIP. */
+void* np_dev_alloc(np_ctx* ctx, size_t bytes);
+void  np_dev_free(np_ctx* ctx, void* p);
+int   np_copy_to_device(np_ctx* ctx, void* stream, void* dst_dev, const void* src_host, size_t bytes);
+int   np_copy_to_host(np_ctx* ctx, void* stream, void* dst_host, const void* src_dev, size_t bytes);
+int   np_memset_dev(np_ctx* ctx, void* stream, void* dst_dev, int value, size_t bytes);
 
 /* Synchronise the context's stream (or the given one). */
 int np_sync(np_ctx* ctx, void* stream);

@@ -342,6 +342,52 @@ int np_selftest_division(np_ctx* c, uint64_t n_samples, uint64_t seed, uint64_t*
     return NP_OK;
 }
 
+void* np_dev_alloc(np_ctx* c, size_t bytes)
+{
+    if (!c) return nullptr;
+    std::lock_guard<std::mutex> g(c->lock);
+    void* p = nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    const hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) { c->err = std::string("np_dev_alloc: ") + hipGetErrorString(e); return nullptr; }
+    return p;
+}
+
+void np_dev_free(np_ctx* c, void* p)
+{
+    if (!c || !p) return;
+    std::lock_guard<std::mutex> g(c->lock);
+    (void)hipSetDevice(c->device);
+    (void)hipFree(p);
+}
+
+int np_copy_to_device(np_ctx* c, void* stream, void* dst, const void* src, size_t bytes)
+{
+    if (!c || (bytes && (!dst || !src))) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    if (bytes) NP_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, use_stream(c, stream)));
+    return NP_OK;
+}
+
+int np_copy_to_host(np_ctx* c, void* stream, void* dst, const void* src, size_t bytes)
+{
+    if (!c || (bytes && (!dst || !src))) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    if (bytes) NP_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, use_stream(c, stream)));
+    return NP_OK;
+}
+
+int np_memset_dev(np_ctx* c, void* stream, void* dst, int value, size_t bytes)
+{
+    if (!c || (bytes && !dst)) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    if (bytes) NP_HIP(c, hipMemsetAsync(dst, value, bytes, use_stream(c, stream)));
+    return NP_OK;
+}
+
 int np_sync(np_ctx* c, void* stream)
 {
     if (!c) return NP_ERR_INVALID;
@@ -697,7 +743,7 @@ int np_cm_build_jobs_identity_dev(np_ctx* c, void* stream, int n_reads, const ch
 {
     if (!c || n_reads < 0 || (n_reads > 0 && (!ref_seq || !seq_off || !read_rc || !group_off || !rank_off || !jobs || !kpos || !job_ranks ||
                                              !first_site || !last_site || !n_motif || !n_groups))) return NP_ERR_INVALID;
-    if (alphabet != 1 && alphabet != 2) { c->err = "np_cm_build_jobs_identity_dev: cpg or gpc only (dinucleotide sites)"; return NP_ERR_UNSUPPORTED; }
+    if (alphabet < 1 || alphabet > 4) { c->err = "np_cm_build_jobs_identity_dev: cpg, gpc, dam or dcm"; return NP_ERR_UNSUPPORTED; }
     if (k < 1 || k > 6) { c->err = "np_cm_build_jobs_identity_dev: k must be 1..6 (uint16 ranks over 5 letters)"; return NP_ERR_UNSUPPORTED; }
     if (n_reads == 0) return NP_OK;
     std::lock_guard<std::mutex> g(c->lock);
@@ -719,7 +765,7 @@ int np_cm_build_jobs_cigar_dev(np_ctx* c, void* stream, int n_reads, const char*
     if (!c || n_reads < 0 || total_cigar_ops < 0 ||
         (n_reads > 0 && (!genome || !ref_begin || !ref_len || !cigar || !cigar_off || !read_len || !read_rc || !group_off || !rank_off || !jobs ||
                          !kpos || !job_ranks || !first_site || !last_site || !n_motif || !n_groups || !deg_kpos))) return NP_ERR_INVALID;
-    if (alphabet != 1 && alphabet != 2) { c->err = "np_cm_build_jobs_cigar_dev: cpg or gpc only (dinucleotide sites)"; return NP_ERR_UNSUPPORTED; }
+    if (alphabet < 1 || alphabet > 4) { c->err = "np_cm_build_jobs_cigar_dev: cpg, gpc, dam or dcm"; return NP_ERR_UNSUPPORTED; }
     if (k < 1 || k > 6) { c->err = "np_cm_build_jobs_cigar_dev: k must be 1..6 (uint16 ranks over 5 letters)"; return NP_ERR_UNSUPPORTED; }
     if (n_reads == 0) return NP_OK;
     std::lock_guard<std::mutex> g(c->lock);

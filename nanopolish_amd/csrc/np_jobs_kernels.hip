@@ -7,7 +7,8 @@
 //   window rule / boundary rules     :328-345, EventAlignmentRecord bounds src/alignment/nanopolish_alignment_db.cpp:65-71,697-708
 //   methylated / unmethylated k-mers Alphabet::methylate / reverse_complement (src/common/nanopolish_alphabet.h:59-253) and
 //                                    HMMInputSequence::get_kmer_rank (src/hmm/nanopolish_hmm_input_sequence.h:76-91)
-// for the methylation alphabets whose recognition site is a dinucleotide (cpg: CG -> MG, gpc: GC -> GM).  It is the device
+// for the four methylation alphabets of the r9.4_450bps kit: cpg (CG -> MG), gpc (GC -> GM), dam (GATC -> GMTC) and dcm
+// (CCAGG / CCTGG -> CMAGG / CMTGG).  It is the device
 // twin of np_cm_build_jobs_identity / np_cm_build_jobs_cigar (np_host.cpp), against which tests/test_gpu_jobs.py compares it
 // item by item.
 // CIGAR mode never materialises the aligned pairs: a per-read exclusive scan of the operations' reference / read advances
@@ -24,8 +25,49 @@ __device__ __forceinline__ site2 site_of(int alphabet)
     // nanopolish_alphabet.cpp:67-125: cpg {"CG","MG","GM"}, gpc {"GC","GM","MG"}
     return alphabet == 2 ? site2{'G', 'C', 'G', 'M', 'M', 'G'} : site2{'C', 'G', 'M', 'G', 'G', 'M'};
 }
+
 __device__ __forceinline__ int digit(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'M' ? 3 : c == 'T' ? 4 : 0; }   // "ACGMT"
 __device__ __forceinline__ char comp(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'M' ? 'G' : c == 'T' ? 'A' : 'T'; }   // "TGCGA"
+
+// The general form (recognition sites of up to 5 bases, up to two of them): nanopolish_alphabet.cpp:127-190, dam
+// {"GATC","GMTC","CTMG"}, dcm {"CCAGG","CMAGG","GGTMC"} + {"CCTGG","CMTGG","GGAMC"}.  None of these sites can overlap another
+// occurrence (no proper suffix of a site is a prefix of a site), so Alphabet::methylate's left-to-right scan marks exactly the
+// FULL occurrences inside the string, and reverse_complement of the methylated string replaces exactly those by the
+// methylated complements (a site cut by the string's end stays as it is: match_to_site needs the full length).
+struct sites_t { int n, len; char s[2][5], m[2][5], mc[2][5]; };
+__device__ __forceinline__ sites_t sites_of(int alphabet)
+{
+    sites_t t{};
+    auto put = [&](int i, const char* a, const char* b, const char* c) { for (int q = 0; q < t.len; ++q) { t.s[i][q] = a[q]; t.m[i][q] = b[q]; t.mc[i][q] = c[q]; } };
+    switch (alphabet) {
+    case 2: t.n = 1; t.len = 2; put(0, "GC", "GM", "MG"); break;
+    case 3: t.n = 1; t.len = 4; put(0, "GATC", "GMTC", "CTMG"); break;
+    case 4: t.n = 2; t.len = 5; put(0, "CCAGG", "CMAGG", "GGTMC"); put(1, "CCTGG", "CMTGG", "GGAMC"); break;
+    default: t.n = 1; t.len = 2; put(0, "CG", "MG", "GM"); break;
+    }
+    return t;
+}
+// index of the site that starts at position p of the window [w0, w0 + len) of ref and lies fully inside it, else -1
+__device__ __forceinline__ int site_at(const char* __restrict__ ref, int w0, int len, int p, const sites_t& S)
+{
+    if (p < 0 || p + S.len > len) return -1;
+    for (int i = 0; i < S.n; ++i) {
+        bool ok = true;
+        for (int q = 0; q < S.len; ++q) ok = ok && ref[w0 + p + q] == S.s[i][q];
+        if (ok) return i;
+    }
+    return -1;
+}
+// character q of methylate(window), and character of reverse_complement(methylate(window)) that comes from window position q
+__device__ __forceinline__ void meth_chars_general(const char* __restrict__ ref, int w0, int len, int q, const sites_t& S, char& cm, char& crc)
+{
+    const char c = ref[w0 + q];
+    cm = c; crc = comp(c);
+    for (int d = 0; d < S.len; ++d) {
+        const int i = site_at(ref, w0, len, q - d, S);
+        if (i >= 0) { cm = S.m[i][d]; crc = S.mc[i][d]; return; }
+    }
+}
 
 // character q of the window [w0, w0 + len) of ref, after Alphabet::methylate of the WINDOW (a site cut by the window's
 // end stays unmethylated)
@@ -181,8 +223,9 @@ __global__ void __launch_bounds__(64) np_cm_groups_kernel(int n_reads, const cha
         }
         cnt = 0;
     };
+    const sites_t S = sites_of(alphabet);
     for (int i = 0; i + 1 < n; ++i) {
-        if (ref[i] == s.a && ref[i + 1] == s.b) {                                            // is_motif_match, whole site
+        if (S.len == 2 ? (ref[i] == s.a && ref[i + 1] == s.b) : site_at(ref, 0, n, i, S) >= 0) {   // is_motif_match, whole site
             if (cnt > 0 && i - last > min_separation) close_group();
             if (cnt == 0) first = i;
             last = i; cnt++;
@@ -253,7 +296,18 @@ __global__ void __launch_bounds__(256) np_cm_items_kernel(int n_reads, const cha
         uint32_t ru = 0, rm = 0;
         char prev = i > 0 ? ref[sub_start + i - 1] : 0;
         char cur = ref[sub_start + i];
-        if (!rc) {
+        if (alphabet > 2) {
+            // dam / dcm: sites of 4 and 5 bases (general form; rare alphabets, no fast path)
+            const sites_t S = sites_of(alphabet);
+            uint32_t pw = 1;
+            for (int q = i; q < i + k; ++q) {
+                char cm, crc;
+                meth_chars_general(ref, sub_start, len, q, S, cm, crc);
+                const char c = ref[sub_start + q];
+                if (!rc) { ru = ru * 5u + (uint32_t)digit(c); rm = rm * 5u + (uint32_t)digit(cm); }
+                else { ru += pw * (uint32_t)digit(comp(c)); rm += pw * (uint32_t)digit(crc); pw *= 5u; }
+            }
+        } else if (!rc) {
             for (int q = i; q < i + k; ++q) {
                 const char nxt = q + 1 < len ? ref[sub_start + q + 1] : 0;
                 const char cm = (cur == s.a && nxt == s.b) ? s.ma : ((cur == s.b && prev == s.a) ? s.mb : cur);

@@ -901,6 +901,13 @@ void npo_score_many(const npo_model* m, int64_t n_jobs, const int32_t* job_read,
  * solve is pinned against the reference's own recalibrate_model compiled in place (tests/test_oracle_vs_ref_full.py);
  * the solve itself is "parity unpinned" (the same restatement stands in for Eigen there).
  * ===================================================================================== */
+/* Which Eigen?  The reference's Makefile pins 3.3.7 (Makefile:59), its README still names 3.2.5.  The two differ on this path in
+ * ONE operation: `col(k).tail() /= pivot` is a true division in 3.3 and a multiplication by the rounded reciprocal in 3.2
+ * (DenseBase::operator/=(Scalar) multiplied by Scalar(1)/other for floating types until 3.3).  Default (0) = 3.3.7, what the
+ * device kernel implements; 1 = the 3.2 form, only so that tests/test_reflevel_golden.py can measure what the choice moves. */
+static int g_eigen32_scalar_div = 0;
+void npo_set_eigen32_scalar_div(int on) { g_eigen32_scalar_div = on; }
+
 static void eigen_fullpivlu_solve_2x2(const double Ain[4] /* row-major a00 a01 a10 a11 */, const double bin[2], double x[2])
 {
     double m[2][2] = {{Ain[0], Ain[1]}, {Ain[2], Ain[3]}};
@@ -913,7 +920,7 @@ static void eigen_fullpivlu_solve_2x2(const double Ain[4] /* row-major a00 a01 a
     if(big == 0.0) return;                                   /* zero matrix: rank 0, solution 0 */
     if(pr == 1) { double t; t = m[0][0]; m[0][0] = m[1][0]; m[1][0] = t; t = m[0][1]; m[0][1] = m[1][1]; m[1][1] = t; }
     if(pc == 1) { double t; t = m[0][0]; m[0][0] = m[0][1]; m[0][1] = t; t = m[1][0]; m[1][0] = m[1][1]; m[1][1] = t; }
-    m[1][0] /= m[0][0];
+    if(g_eigen32_scalar_div) m[1][0] *= (1.0 / m[0][0]); else m[1][0] /= m[0][0];
     m[1][1] -= m[1][0] * m[0][1];
     const double maxpivot = fabs(m[0][0]) > fabs(m[1][1]) ? fabs(m[0][0]) : fabs(m[1][1]);   /* m_maxpivot */
     const double thr = maxpivot * (2.220446049250313e-16 * 2);                                 /* epsilon * diagonalSize */

@@ -90,6 +90,7 @@ int  npo_get_closest_event_to(const int32_t* start, uint32_t n_kmers, int k_idx)
 
 /* f1: get_eventalignment_for_1d_basecalls (squiggle_read.cpp:339-389) + recalibrate_model (methyltrain.cpp:204-306,
  * scale_var, no drift).  Returns 1 if recalibrated.  The Eigen fullPivLu step is restated without Eigen (the only unpinned step). */
+void npo_set_eigen32_scalar_div(int on);   /* test switch, see np_oracle.c */
 int  npo_recalibrate(const npo_model* m, const float* event_mean, const uint32_t* kmer_ranks, uint32_t n_kmers,
                      const int32_t* map_start, const int32_t* map_stop, double* shift, double* scale, double* var);
 

@@ -188,3 +188,41 @@ class FullRef:
         r1, r2 = C.c_int(), C.c_int()
         ok = self.L.npfull_find_by_ref_bounds(_p(rp, _i32p), _p(qp, _i32p), len(rp), int(ref_start), int(ref_stop), C.byref(r1), C.byref(r2))
         return (r1.value, r2.value) if ok else None
+
+
+_BATCH = os.path.join(_HERE, "_ref", "libnp_ref_full_batch.so")
+
+
+def have_batch():
+    return os.path.exists(_BATCH)
+
+
+def call_methylation_batch(records, contig_seq, methylation_type="cpg", cap=65536):
+    """The reference build with the product's BATCHED binding linked in (`make -C oracle batch`: np_dropin.cpp +
+    np_batch_dropin.cpp in place of the hot-path translation units): all records through ONE call of
+    np_calculate_methylation_for_batch.  records: dicts(seq [the read's own sequence], raw, rc, pos, cigar, bam_seq).
+    Returns (list of per-record dicts of site arrays, status array)."""
+    L = C.CDLL(_BATCH)
+    n = len(records)
+    raw = np.concatenate([np.ascontiguousarray(r["raw"], np.float32) for r in records])
+    raw_off = np.zeros(n + 1, np.int64); raw_off[1:] = np.cumsum([len(r["raw"]) for r in records])
+    cig = np.concatenate([np.ascontiguousarray(r["cigar"], np.uint32) for r in records])
+    cig_off = np.zeros(n + 1, np.int64); cig_off[1:] = np.cumsum([len(r["cigar"]) for r in records])
+    is_rev = np.array([int(r["rc"]) for r in records], np.int32); pos = np.array([int(r["pos"]) for r in records], np.int32)
+    seqs = (C.c_char_p * n)(*[r["seq"].encode() for r in records])
+    bseqs = (C.c_char_p * n)(*[r["bam_seq"].encode() for r in records])
+    site_off = np.zeros(n + 1, np.int64); status = np.zeros(n, np.int32)
+    st, en, nm = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    lu, lm = np.zeros(cap, np.float64), np.zeros(cap, np.float64)
+    sq = C.create_string_buffer(cap * 256)
+    tot = L.npfull_call_methylation_batch(n, seqs, _p(raw, C.POINTER(C.c_float)), _p(raw_off, C.POINTER(C.c_int64)), _p(is_rev, _i32p),
+                                          _p(pos, _i32p), _p(cig, _u32p), _p(cig_off, C.POINTER(C.c_int64)), bseqs, contig_seq.encode(),
+                                          methylation_type.encode(), cap, _p(site_off, C.POINTER(C.c_int64)), _p(st, _i32p), _p(en, _i32p),
+                                          _p(nm, _i32p), _p(lu, _f64p), _p(lm, _f64p), sq, _p(status, _i32p))
+    assert tot <= cap
+    out = []
+    for i in range(n):
+        a, b = int(site_off[i]), int(site_off[i + 1])
+        out.append(dict(start=st[a:b].copy(), end=en[a:b].copy(), n_motif=nm[a:b].copy(), ll_unmeth=lu[a:b].copy(), ll_meth=lm[a:b].copy(),
+                        sequence=[sq.raw[j * 256:(j + 1) * 256].split(b"\0", 1)[0].decode() for j in range(a, b)]))
+    return out, status

@@ -236,6 +236,54 @@ int npfull_call_methylation(void* h, int is_rev, int pos, const uint32_t* cigar,
     return n;
 }
 
+#ifdef NP_WITH_BATCH
+}   // extern "C"
+#include "np_batch_dropin.h"
+extern "C" {
+// ---- the product's batched binding (nanopolish_amd/csrc/np_batch_dropin.cpp), `make -C oracle batch` only -------------
+// n records against one contig in ONE device batch; sites of record i come back at [site_off[i], site_off[i+1]) in
+// ascending start position (the std::map order), status[i] = NP_BATCH_*.  Returns the total number of sites.
+int npfull_call_methylation_batch(int n, const char* const* read_seqs, const float* raw, const int64_t* raw_off, const int32_t* is_rev,
+                                  const int32_t* pos, const uint32_t* cigar, const int64_t* cigar_off, const char* const* bam_seqs,
+                                  const char* contig_seq, const char* methylation_type, int cap, int64_t* site_off, int32_t* start,
+                                  int32_t* end, int32_t* n_motif, double* ll_unmeth, double* ll_meth, char* seq_out, int32_t* status)
+{
+    std::vector<Record*> recs(n);
+    std::vector<std::string> seqs(n);
+    std::vector<NpBatchRead> reads(n);
+    for(int i = 0; i < n; ++i) {
+        char name[32]; snprintf(name, sizeof(name), "read%d", i);
+        recs[i] = new Record(name, is_rev[i], pos[i], cigar + cigar_off[i], (int)(cigar_off[i + 1] - cigar_off[i]), bam_seqs[i], contig_seq);
+        seqs[i] = read_seqs[i];
+        reads[i].record = &recs[i]->b; reads[i].read_sequence = &seqs[i];
+        reads[i].raw_pa = raw + raw_off[i]; reads[i].n_raw = (size_t)(raw_off[i + 1] - raw_off[i]);
+    }
+    MethylationCallingResult result;
+    MethylationCallingParameters params;
+    params.methylation_type = methylation_type;
+    params.alphabet = get_alphabet_by_name(methylation_type);
+    np_calculate_methylation_for_batch(result, reads, params, "r9.4_450bps", &recs[0]->fai, &recs[0]->hdr, -1, -1);
+    int tot = 0;
+    for(int i = 0; i < n; ++i) {
+        site_off[i] = tot;
+        status[i] = reads[i].status;
+        const std::map<int, ScoredSite>& sites = result[&recs[i]->b];
+        for(std::map<int, ScoredSite>::const_iterator it = sites.begin(); it != sites.end(); ++it, ++tot) {
+            if(tot >= cap) continue;
+            const ScoredSite& s = it->second;
+            start[tot] = s.start_position; end[tot] = s.end_position; n_motif[tot] = s.n_motif;
+            ll_unmeth[tot] = s.ll_unmethylated[0] + s.ll_unmethylated[1];
+            ll_meth[tot] = s.ll_methylated[0] + s.ll_methylated[1];
+            strncpy(seq_out + (size_t)tot * 256, s.sequence.c_str(), 255);
+            seq_out[(size_t)tot * 256 + 255] = 0;
+        }
+    }
+    site_off[n] = tot;
+    for(int i = 0; i < n; ++i) delete recs[i];
+    return tot;
+}
+#endif
+
 // ---- align_read_to_ref (eventalign) ----------------------------------------------------------------------------------
 int npfull_eventalign(void* h, int is_rev, int pos, const uint32_t* cigar, int n_cigar, const char* seq, const char* contig_seq,
                       int cap, int32_t* ref_position, int32_t* event_idx, char* hmm_state, char* ref_kmer, char* model_kmer)

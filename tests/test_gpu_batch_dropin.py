@@ -1,0 +1,60 @@
+"""The batched reference-side binding on the GPU: nanopolish_amd/csrc/np_batch_dropin.cpp replaces the body of
+call-methylation's per-record loop -- calculate_methylation_for_read_from_bam (src/nanopolish_call_methylation.cpp:163-177)
+under BamProcessor's batch boundary (src/common/nanopolish_bam_processor.cpp:90-119) -- by one device pass over the whole batch.
+oracle/_ref/libnp_ref_full_batch.so (`make -C oracle batch`) is the reference's read-level build with that file (and the per-call
+shim np_dropin.cpp) linked in place of the hot-path translation units; it travels to the GPU box as a built artefact.
+The ScoredSite maps it fills must equal, field for field, what the UNMODIFIED reference produced for the same records
+(tests/golden/golden_reflevel.npz, tests/gen_golden_reflevel.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.ref_full import have_batch, call_methylation_batch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_batch(), reason="libnp_ref_full_batch.so not built")]
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_reflevel.npz")
+
+
+def _s(a):
+    return bytes(a).decode()
+
+
+def test_scored_site_maps_of_one_batch_equal_the_unmodified_reference():
+    import torch  # noqa: F401  (one HIP runtime per process: torch's)
+    g = np.load(GOLD)
+    recs = []
+    for i in range(int(g["n_reads"])):
+        p = "r%d_" % i
+        rc, pos = (int(v) for v in g[p + "rc_pos"])
+        recs.append(dict(seq=_s(g[p + "seq"]), raw=g[p + "raw"], rc=rc, pos=pos, cigar=g[p + "cigar"], bam_seq=_s(g[p + "bam_seq"])))
+    # the same batch twice (steady state of the cached models / scratch) and in reversed record order
+    for order in (list(range(len(recs))), list(range(len(recs)))[::-1]):
+        out, status = call_methylation_batch([recs[i] for i in order], _s(g["contig"]))
+        n_sites = 0
+        for q, i in enumerate(order):
+            p = "r%d_" % i
+            got = out[q]
+            assert status[q] in (0, 1), "record %d took the host path" % i
+            assert (status[q] == 1) == (int(g[p + "n_events"]) == 0)          # reads the reference cleared: empty maps
+            assert np.array_equal(got["start"], g[p + "site_start"]) and np.array_equal(got["end"], g[p + "site_end"])
+            assert np.array_equal(got["n_motif"], g[p + "site_n_motif"])
+            assert np.array_equal(got["ll_unmeth"], g[p + "site_ll_unmeth"]) and np.array_equal(got["ll_meth"], g[p + "site_ll_meth"])
+            assert got["sequence"] == [x.decode() for x in g[p + "site_sequence"]]
+            n_sites += len(got["start"])
+        assert n_sites > 150
+
+
+def test_gpc_batch_equals_the_unmodified_reference():
+    import torch  # noqa: F401
+    g = np.load(GOLD)
+    recs = []
+    for i in range(2):
+        p = "r%d_" % i
+        rc, pos = (int(v) for v in g[p + "rc_pos"])
+        recs.append(dict(seq=_s(g[p + "seq"]), raw=g[p + "raw"], rc=rc, pos=pos, cigar=g[p + "cigar"], bam_seq=_s(g[p + "bam_seq"])))
+    out, status = call_methylation_batch(recs, _s(g["contig"]), methylation_type="gpc")
+    for i in range(2):
+        p = "r%d_" % i
+        assert np.array_equal(out[i]["start"], g[p + "gpc_start"]) and np.array_equal(out[i]["n_motif"], g[p + "gpc_n_motif"])
+        assert np.array_equal(out[i]["ll_unmeth"], g[p + "gpc_ll_unmeth"]) and np.array_equal(out[i]["ll_meth"], g[p + "gpc_ll_meth"])

@@ -119,3 +119,31 @@ def test_pass_from_raw_signal_matches_oracle(ctx, orc, models):
             n_scored += 1
         g0 += len(firsts)
     assert n_scored > 300
+
+
+def adc_like_raw(n, seed, offset=10.0, raw_unit=1400.0 / 8192.0, zero_crossings=0):
+    """Raw signal as a sequencer delivers it: int16 ADC counts turned into pA by (count + offset) * range / digitisation in
+    fp32 (src/io/nanopolish_fast5_loader.cpp:96-103), levels changing every ~9 samples in the 60..130 pA band."""
+    rng = np.random.default_rng(seed)
+    dwell = 1 + rng.poisson(8, n // 8 + 2)
+    level = np.repeat(rng.uniform(350, 750, len(dwell)), dwell)[:n]
+    adc = np.rint(level + rng.normal(0, 9, n)).astype(np.int16)
+    if zero_crossings:
+        adc[rng.integers(0, n, zero_crossings)] = np.int16(1 - int(offset))          # (count + offset) == 1: 0.17 pA
+    return ((adc.astype(np.float32) + np.float32(offset)) * np.float32(raw_unit)).astype(np.float32)
+
+
+def test_exactness_bound_holds_for_sequencer_scale_signal(ctx, orc):
+    """the device detector refuses a read (NP_ED_INEXACT) when it cannot prove that the reference's
+    double-precision prefix sums are exact.  For signal at the scale a sequencer delivers -- pA values that are integer
+    multiples of range/digitisation in the 60..130 pA band, reads up to half a million samples -- the bound holds and the
+    events equal the reference's.  What trips it is a near-zero sample: the fp32 SQUARE of a 0.17 pA sample has an ulp of
+    2^-29, and the running sum of squares (~1e4 per sample) outgrows 2^53 of those within a thousand samples -- in the
+    reference too, whose serial sums then round.  Such a read is REPORTED, never approximated."""
+    raws = [adc_like_raw(n, 100 + i) for i, n in enumerate((4000, 60000, 250000, 500000))]
+    got = ctx.detect_events(raws)                       # raises on NP_ED_INEXACT
+    for raw, g in zip(raws[:3], got[:3]):
+        assert _same(g, orc.detect_events(raw, **ED_DEFAULTS))
+    assert len(got[3]["mean"]) > 20000
+    with pytest.raises(RuntimeError, match="INEXACT"):
+        ctx.detect_events([adc_like_raw(60000, 7, zero_crossings=3)])

@@ -41,7 +41,7 @@ def _device_jobs(ctx, refs, rcs, alphabet, k=6, min_separation=10, min_flank=10)
                 n_groups=d_ng.cpu().numpy())
 
 
-@pytest.mark.parametrize("alphabet", ["cpg", "gpc"])
+@pytest.mark.parametrize("alphabet", ["cpg", "gpc", "dam", "dcm"])
 def test_device_work_items_equal_host_builder(ctx, models, alphabet):
     rng = np.random.default_rng(4)
     reads = [synth_read(500 + i, models["nucleotide"], L=L) for i, L in enumerate((1500, 900, 5450, 64, 23, 300, 2500, 700))]
@@ -51,6 +51,11 @@ def test_device_work_items_equal_host_builder(ctx, models, alphabet):
     # motif-dense, motif-free and motif-at-the-edges references
     refs += ["CG" * 300, "ACGT" * 200, "A" * 400, "CG" + "A" * 200 + "GC" + "T" * 200 + "CG", "GCGCGCGC" + "ACGTTGCA" * 60 + "GCGC"]
     rcs += [False, True, False, True, False]
+    # 4- and 5-base sites (dam GATC, dcm CCAGG / CCTGG): dense, adjacent, cut by either end of the reference, near-misses
+    refs += ["GATC" * 120, "CCAGGCCTGG" * 60, "ATC" + "A" * 30 + "GATCGATC" + "T" * 40 + "CCAGGACCTGG" + "C" * 50 + "GAT",
+             "CCAGGT" * 3 + "ACGTTGCAAC" * 40 + "CCTGGATCCAGG" + "TTGACA" * 20 + "CCTG", "GATCCAGGATCCTGGATC" * 25,
+             "GTTC" * 50 + "CCGGG" * 30 + "GATC"]
+    rcs += [False, True, True, False, True, False]
     dv = _device_jobs(ctx, refs, rcs, alphabet)
     n_items = 0
     for i, (ref, rc) in enumerate(zip(refs, rcs)):

@@ -260,8 +260,8 @@ def test_gpc_chain_on_device_matches_reference(ctx, models, gold):
 
 @pytest.mark.parametrize("alpha", ["dam", "dcm"])
 def test_dam_and_dcm_chains_match_reference(ctx, models, gold, alpha):
-    """--methylation dam / dcm: work items from the host builder (the device builder covers the dinucleotide alphabets), everything
-    else on the device, against the reference's own output on a motif-rich contig"""
+    """--methylation dam / dcm (4- and 5-base sites, two sites for dcm): work items from the host builder and from the device
+    builder, everything else on the device, against the reference's own output on a motif-rich contig"""
     z = np.load(os.path.join(os.path.dirname(GOLD), "models_r9.4_450bps_%s.npz" % alpha))
     if alpha not in ctx.models:
         ctx.register_model(dict(k=6, level_mean=z["level_mean"], level_stdv=z["level_stdv"], level_log_stdv=z["level_log_stdv"]), alpha)
@@ -271,13 +271,19 @@ def test_dam_and_dcm_chains_match_reference(ctx, models, gold, alpha):
         rc, pos = (int(v) for v in gold[p + "rc_pos"])
         recs.append(dict(seq=_s(gold[p + "seq"]), raw=gold[p + "raw"], rc=rc, pos=pos, cigar=gold[p + "cigar"]))
     hb = build_host_batch_records(models, recs, _s(gold["m_contig"]), alphabet=alpha)
-    batch = CallMethylationBatch(ctx, hb, "cuda:0", calibrate=True, from_raw=True)
-    batch.step()
-    sc, jobs = batch.scores(), batch.jobs_host()
-    for i, rec in enumerate(recs):
-        p = "m%d_" % i
-        want = {int(s): (float(u), float(m)) for s, u, m in zip(gold[p + alpha + "_start"], gold[p + alpha + "_ll_unmeth"], gold[p + alpha + "_ll_meth"])}
-        lo = int(hb["job_off"][i])
-        got = {int(f) + rec["pos"]: (float(sc[lo + 2 * g]), float(sc[lo + 2 * g + 1])) for g, f in enumerate(hb["meta"][i]["first"])
-               if not (jobs[lo + 2 * g]["flags"] & 0x80000000)}
-        assert got == want and len(got) > 15, (alpha, i)
+    for on_dev in (False, True):
+        batch = CallMethylationBatch(ctx, hb, "cuda:0", calibrate=True, from_raw=True, jobs_on_device=on_dev)
+        batch.step()
+        sc, jobs = batch.scores(), batch.jobs_host()
+        for i, rec in enumerate(recs):
+            p = "m%d_" % i
+            want = {int(s): (float(u), float(m)) for s, u, m in zip(gold[p + alpha + "_start"], gold[p + alpha + "_ll_unmeth"], gold[p + alpha + "_ll_meth"])}
+            if on_dev:
+                first, nm, u, m = batch.groups_of(i)
+                got = {int(f) + rec["pos"]: (float(a), float(b)) for f, a, b in zip(first, u, m) if a == a}
+                assert np.array_equal(nm, hb["meta"][i]["n_motif"])
+            else:
+                lo = int(hb["job_off"][i])
+                got = {int(f) + rec["pos"]: (float(sc[lo + 2 * g]), float(sc[lo + 2 * g + 1])) for g, f in enumerate(hb["meta"][i]["first"])
+                       if not (jobs[lo + 2 * g]["flags"] & 0x80000000)}
+            assert got == want and len(got) > 15, (alpha, i, on_dev)
