@@ -33,6 +33,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The streamed variant runs three HIP streams (upload, compute, read-back) beside torch's and the library's own.  HIP maps
+# streams onto GPU_MAX_HW_QUEUES (default 4) in-order hardware queues; when the upload stream shares one with the compute
+# stream, the upload of step k+1 queues behind the kernels of step k and nothing overlaps (seen in the copy/kernel trace of
+# profiles/r02).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 CLOCK_HZ = 2.4e9          # MI355X engine clock (MI355X_MICROARCH.md); 256 CUs x 4 SIMDs
 N_SIMD = 1024
@@ -408,10 +413,14 @@ def main():
             feed.submit()
         feed.drain(); barrier()
         dts = max_over_ranks(time.perf_counter() - t0)
+        steady = feed.steady_ms_per_step(args.steps)
         same = feed.check_against(batch) if rank == 0 else True
         streamed = dict(value=round(world * n_reads * args.steps / dts, 2), ms_per_step=round(dts / args.steps * 1e3, 3),
                         h2d_bytes_per_step=feed.h2d_bytes, d2h_bytes_per_step=feed.d2h_bytes,
                         pcie_GBps=round((feed.h2d_bytes + feed.d2h_bytes) * args.steps / dts / 1e9, 2),
+                        steady_state_ms_per_step=round(steady, 3) if steady else None,
+                        note="value_streamed times K steps from a cold pipeline: the first step's upload is not overlapped; "
+                             "steady_state_ms_per_step is the interval between step completions after it",
                         results_equal_resident=bool(same), host_enqueue_ms_last_steps=feed.host_ms[-args.steps:])
         feed.close()
         batch.stream = None

@@ -527,6 +527,7 @@ class StreamedFeed:
         self.ev_d2h = [None, None]
         self.k = 0
         self.read_back = 0           # steps whose read-back has been enqueued
+        self.done_events = []        # one timed event per step, recorded when the step's kernels have finished
         self.host_ms = []            # host time of each submit: (enqueue H2D, enqueue compute, enqueue D2H) in ms
         torch.cuda.synchronize()
 
@@ -551,7 +552,8 @@ class StreamedFeed:
         self.b.stream = self.s_cmp.cuda_stream
         self.b.step()
         t2 = time.perf_counter()
-        self.ev_cmp[i] = torch.cuda.Event(); self.ev_cmp[i].record(self.s_cmp)
+        self.ev_cmp[i] = torch.cuda.Event(enable_timing=True); self.ev_cmp[i].record(self.s_cmp)
+        self.done_events.append(self.ev_cmp[i])
         # The read-back of step k is enqueued one submit LATER, behind the host->device copies of step k+1: HIP multiplexes
         # streams onto a few in-order hardware queues, and when the two copy streams share one, a device->host copy that waits
         # for the compute of step k would hold back the upload of step k+1 queued behind it -- the upload that is supposed to
@@ -578,6 +580,13 @@ class StreamedFeed:
         for s in (self.s_h2d, self.s_cmp, self.s_d2h):
             s.synchronize()
         self.b.sync()
+
+    def steady_ms_per_step(self, last):
+        """mean device time between the completions of consecutive steps over the last `last` steps (the first step of a
+        sequence also pays its own upload, which nothing overlaps)"""
+        self.drain()
+        ev = self.done_events[-last:]
+        return ev[0].elapsed_time(ev[-1]) / (len(ev) - 1) if len(ev) >= 2 else None
 
     def check_against(self, batch=None):
         """the results of the last two streamed steps, as they arrived on the host, against the resident pass (bit for bit)"""

@@ -76,7 +76,7 @@ def test_device_work_items_equal_host_builder(ctx, models, alphabet):
         # unused slots are marked skipped
         cap = int(dv["group_off"][i + 1]) - g0
         assert np.all(dv["jobs"][2 * (g0 + ng):2 * (g0 + cap)]["flags"] == 0x80000000)
-    assert n_items > 500
+    assert n_items > (500 if alphabet in ("cpg", "gpc") else 60)       # (4- and 5-base sites are rare in random sequence)
 
 
 def test_whole_chain_on_device_matches_oracle(ctx, orc, models):
