@@ -15,6 +15,9 @@
 #include "np_kernels.h"
 
 #define NP_HMM_BLOCK 512
+#ifndef NP_LSE_OOR
+#define NP_LSE_OOR 1        // forward kernel: log-sum lookups rely on the LDS out-of-range rule instead of clamping the index
+#endif
 
 namespace {
 
@@ -47,6 +50,12 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
     __shared__ float tbl[NP_LOGSUM_TBL];
     for (int i = threadIdx.x; i < NP_LOGSUM_TBL; i += BLK) tbl[i] = np_lse_table_entry(a.logsum, i);
     __syncthreads();
+#if NP_LSE_OOR
+    const __attribute__((address_space(3))) char* tbl3 = (const __attribute__((address_space(3))) char*)tbl;
+#define NP_LSE(x, y) np_lse_oor((x), (y), tbl3)
+#else
+#define NP_LSE(x, y) np_lse((x), (y), tbl)
+#endif
 
     constexpr int JPW = 64 / SEG;                 // jobs per wave
     const int lane = threadIdx.x & 63;
@@ -138,16 +147,16 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
                     const float em = np_emission(x, g[c]);
                     // PSR9_MATCH: HMT_FROM_SAME_M, PREV_M, SAME_B, PREV_B, PREV_K, SOFT (r9.inl:350-365)
                     float s = lp_mm_self + cur.M[c];
-                    s = np_lse(s, lp_mm_next + lM_p, tbl);
-                    s = np_lse(s, lp_bm_self + cur.B[c], tbl);
-                    s = np_lse(s, lp_bm_next + lB_p, tbl);
-                    s = np_lse(s, lp_km + lK_p, tbl);
-                    if (c == 0) s = np_lse(s, soft, tbl);   // HMT_FROM_SOFT: -inf except for the first k-mer
+                    s = NP_LSE(s, lp_mm_next + lM_p);
+                    s = NP_LSE(s, lp_bm_self + cur.B[c]);
+                    s = NP_LSE(s, lp_bm_next + lB_p);
+                    s = NP_LSE(s, lp_km + lK_p);
+                    if (c == 0) s = NP_LSE(s, soft);   // HMT_FROM_SOFT: -inf except for the first k-mer
                     const float newM = s + em;
                     // PSR9_BAD_EVENT (r9.inl:368-374): only SAME_M and SAME_B are finite; emission 0
-                    const float newB = np_lse(lp_mb + cur.M[c], lp_bb + cur.B[c], tbl);
+                    const float newB = NP_LSE(lp_mb + cur.M[c], lp_bb + cur.B[c]);
                     // PSR9_KMER_SKIP (r9.inl:377-383): PREV_M, PREV_B, PREV_K of the SAME row
-                    const float newK = np_lse(np_lse(lp_mk + lM_r, lp_bk + lB_r, tbl), lp_kk + lK_r, tbl);
+                    const float newK = NP_LSE(NP_LSE(lp_mk + lM_r, lp_bk + lB_r), lp_kk + lK_r);
 
                     lM_p = cur.M[c]; lB_p = cur.B[c]; lK_p = cur.K[c];
                     lM_r = newM; lB_r = newB; lK_r = newK;
@@ -155,9 +164,9 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
 
                     // end state (r9.inl:388-396): last k-mer, M then B then K
                     if (sl == last_lane && c == last_c && (post_clip || r == e)) {
-                        lp_end = np_lse(lp_end, newM + pf, tbl);
-                        lp_end = np_lse(lp_end, newB + pf, tbl);
-                        lp_end = np_lse(lp_end, newK + pf, tbl);
+                        lp_end = NP_LSE(lp_end, newM + pf);
+                        lp_end = NP_LSE(lp_end, newB + pf);
+                        lp_end = NP_LSE(lp_end, newK + pf);
                     }
                 }
             }
@@ -167,6 +176,7 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
     }
 }
 
+#undef NP_LSE
 // ---------------------------------------------------------------------------------------------------
 // Viterbi fill (ProfileHMMViterbiOutputR9, r9.inl:130-197): same sweep, max/arg-max with later-wins ties,
 // lattice + back-pointers streamed to HBM in row-major [row][3*n] (block 0 / terminal block omitted).

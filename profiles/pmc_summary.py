@@ -40,7 +40,17 @@ for key, c in tot.items():
                  fetch_size_correction=FETCH_CORR, write_size_correction=WRITE_CORR,
                  valu_insts_per_read=per_read("SQ_INSTS_VALU"), salu_insts_per_read=per_read("SQ_INSTS_SALU"),
                  vmem_rd_per_read=per_read("SQ_INSTS_VMEM_RD"), vmem_wr_per_read=per_read("SQ_INSTS_VMEM_WR"),
-                 valu_insts_per_band=per_read("SQ_INSTS_VALU") / bands, salu_insts_per_band=per_read("SQ_INSTS_SALU") / bands)
+                 valu_insts_per_band=per_read("SQ_INSTS_VALU") / bands, salu_insts_per_band=per_read("SQ_INSTS_SALU") / bands,
+                 valu_per_band=per_read("SQ_INSTS_VALU") / bands, salu_per_band=per_read("SQ_INSTS_SALU") / bands,
+                 branch_per_band=per_read("SQ_INSTS_BRANCH") / bands if "SQ_INSTS_BRANCH" in c else None)
+        if "SQ_WAVE_CYCLES" in c:
+            wc = c["SQ_WAVE_CYCLES"]
+            d.update(wait_inst_any_frac=c.get("SQ_WAIT_INST_ANY", 0.0) / wc, wait_any_frac=c.get("SQ_WAIT_ANY", 0.0) / wc,
+                     active_inst_any_frac=c.get("SQ_ACTIVE_INST_ANY", 0.0) / wc)
+        if "GRBM_GUI_ACTIVE" in c and "SQ_ACTIVE_INST_VALU" in c:
+            # rocprof's VALUBusy: 100 * SQ_ACTIVE_INST_VALU * 4 / SIMD_NUM / GRBM_GUI_ACTIVE with the per-XCD maximum of GUI_ACTIVE;
+            # the csv sums GUI_ACTIVE over the 8 XCDs, hence / 8
+            d["valu_busy_pct"] = 100.0 * c["SQ_ACTIVE_INST_VALU"] / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0)
     if "SQ_BUSY_CYCLES" in c and "SQ_ACTIVE_INST_VALU" in c:
         d["valu_active_over_busy"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_BUSY_CYCLES"]
     if "SQ_WAVE_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
