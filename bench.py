@@ -531,10 +531,12 @@ def main():
                              VALUBusy=pm.get("valu_busy_pct"), pmc_source="profiles/" + name,
                              pmc_reads_per_launch=pm.get("reads_per_launch"))
                 if valu and salu:
-                    # issue-slot model of tools/valu_rates.hip: this kernel's VALU mix averages ~3.2 cycles per wave-instruction
-                    # (fp32 2, fp64 / cvt / cmp / select / DPP 4), a scalar instruction ~4 per SIMD; frac = modelled issue cycles
-                    # of one band step / SIMD cycles one band step takes
-                    issue["frac"] = round((3.2 * valu + 4.0 * salu) / cyc_per_band, 3)
+                    # vector issue model: the band step's VALU mix (22 double-rate instructions and ~13
+                    # conversions / DPP / readlane at 4 cycles, the rest at 2; tools/valu_rates.hip) averages 2.8 cycles per
+                    # wave-instruction on a SIMD-32; frac = modelled VALU issue cycles of one band step / SIMD cycles it takes
+                    issue["instructions_per_band"] = round(valu + salu, 1)
+                    issue["cycles_per_instruction"] = round(cyc_per_band / (valu + salu), 2)
+                    issue["frac"] = round(2.8 * valu / cyc_per_band, 3)
                 break
             except Exception:
                 continue
