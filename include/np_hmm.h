@@ -277,6 +277,11 @@ int np_calibrate_resolve_dev(np_ctx* ctx, void* stream, int n_reads, np_read_dev
  * the restated functions themselves (out_log[i] = log(x[i]), out_exp[i] = exp(-x[i])); host-only, for verification. */
 void np_aligner_constants(uint32_t n_events, uint32_t n_kmers, double out[4]);
 void np_restated_log_exp(const double* x, size_t n, double* out_log, double* out_exp);
+/* Host-only: the restated log / exp / logf against THIS host's libm on n pseudo-random arguments of the ranges the path uses;
+ * *n_mismatch == 0 means the constants the device computes are bit-identical to what the reference computes on this host
+ * (glibc 2.35 x86-64 with FMA does; another libm may not -- the restatement then still matches the build this repository
+ * was verified against, tests/test_host_logic.py reports the difference). */
+int  np_selftest_libm(uint64_t n, uint64_t seed, uint64_t* n_mismatch);
 
 /* ---- f3: work-item generation on the device ------------------------------------------------ */
 /* Device twin of np_cm_build_jobs_identity for a batch of identity-aligned reads: motif scan and grouping

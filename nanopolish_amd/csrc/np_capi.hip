@@ -205,6 +205,21 @@ int run_event_align(np_ctx* c, hipStream_t s, int n_reads, const np_read_dev* re
 
 } // namespace
 
+// The emission's exact division (np_device.h:np_div_exact: reciprocal + two fused corrections, no range scaling) is verified
+// against the IEEE divide for divisors in [2^-5, 2^6) and numerators of magnitude < 2^15 (np_selftest_division): a model
+// whose scaled sigma can leave that range is refused here rather than scored with an unverified quotient.  (A read's `var`
+// multiplies sigma by 1 .. 2.5 before the calibration gate drops the read; levels are pA, |x - mean| < 2^15.)
+static bool model_in_range(np_ctx* c, int n_states, const double* level_mean, const double* level_stdv)
+{
+    for (int i = 0; i < n_states; ++i) {
+        if (!(level_stdv[i] >= 0.0625 && level_stdv[i] <= 16.0) || !(fabs(level_mean[i]) < 8192.0)) {
+            c->err = "np_register_model: level_stdv outside [1/16, 16] or |level_mean| >= 8192: outside the range the exact emission division is verified for";
+            return false;
+        }
+    }
+    return true;
+}
+
 extern "C" {
 
 const char* np_version(void) { return NP_VERSION_STR; }
@@ -300,6 +315,7 @@ int np_register_model(np_ctx* c, int k, int n_states, const double* level_mean, 
     if (!c || n_states <= 0 || n_states > 65536 || !level_mean || !level_stdv || !level_log_stdv) return NP_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
+    if (!model_in_range(c, n_states, level_mean, level_stdv)) return NP_ERR_UNSUPPORTED;
     std::vector<np_state_dev> st(n_states);
     for (int i = 0; i < n_states; ++i) { st[i].level_mean = level_mean[i]; st[i].level_stdv = level_stdv[i]; st[i].level_log_stdv = level_log_stdv[i]; st[i].pad = 0; }
     model_t m; m.k = k; m.n_states = n_states; m.level_mean.assign(level_mean, level_mean + n_states);
@@ -315,6 +331,7 @@ int np_update_model(np_ctx* c, int model, int n_states, const double* level_mean
     if (!c || !level_mean || !level_stdv || !level_log_stdv) return NP_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->lock);
     if (model < 0 || model >= (int)c->models.size() || n_states != c->models[model].n_states) { c->err = "np_update_model: bad model id or size"; return NP_ERR_INVALID; }
+    if (!model_in_range(c, n_states, level_mean, level_stdv)) return NP_ERR_UNSUPPORTED;
     NP_HIP(c, hipSetDevice(c->device));
     if (c->have_last_stream) NP_HIP(c, hipStreamSynchronize(c->last_stream));     // kernels in flight still read the old table
     NP_HIP(c, hipStreamSynchronize(c->stream));

@@ -80,7 +80,7 @@ __device__ __forceinline__ np_gauss np_scale_state(const np_state_dev* __restric
 // n / d, correctly rounded (== the IEEE fp32 quotient the reference computes), from a correctly rounded
 // reciprocal r = RN(1/d): q0 = RN(n r); two Markstein corrections q <- fma(fma(-d, q, n), r, q).  This is the
 // body of the hardware division expansion (v_div_scale/v_div_fmas/v_div_fixup only add range scaling, which
-// n = x - mean in [-1e3, 1e3] \ (0, 1e-6) and d = stdv in [0.05, 50] never need) with the reciprocal hoisted out
+// n = x - mean with |n| < 2^15 and d = stdv in [2^-5, 2^6) never need; np_register_model refuses models outside) with the reciprocal hoisted out
 // of the per-cell path: 5 VALU ops instead of ~11 incl. a quarter-rate v_rcp_f32.  Equality with `/` is checked
 // on the device by np_selftest_division (tests/test_gpu_parity.py) over 2^32 random operand pairs.
 __device__ __forceinline__ float np_div_exact(float n, float d, float r)

@@ -392,8 +392,8 @@ __global__ void __launch_bounds__(256) np_selftest_div_kernel(uint64_t n_per_thr
         // denominator: random mantissa, exponent in [2^-5, 2^6)  (stdv after scaling lives in ~[0.3, 12])
         const uint32_t dm = (uint32_t)u & 0x7fffffu, de = 122u + (uint32_t)((u >> 23) % 11u);
         const float d = __builtin_bit_cast(float, (de << 23) | dm);
-        // numerator: random sign/mantissa, exponent in [2^-20, 2^10) and exact zero now and then
-        const uint32_t nm = (uint32_t)(u >> 32) & 0x7fffffu, ne = 107u + (uint32_t)((u >> 55) % 30u);
+        // numerator: random sign/mantissa, exponent in [2^-40, 2^15) and exact zero now and then
+        const uint32_t nm = (uint32_t)(u >> 32) & 0x7fffffu, ne = 87u + (uint32_t)((u >> 55) % 55u);
         float n = __builtin_bit_cast(float, (ne << 23) | nm | ((uint32_t)(u >> 63) << 31));
         if ((u & 0xfff000000ull) == 0) n = 0.0f;
         const float r = (float)(1.0 / (double)d);

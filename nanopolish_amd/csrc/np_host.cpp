@@ -382,6 +382,29 @@ void np_aligner_constants(uint32_t n_events, uint32_t n_kmers, double out[4])
     out[2] = np_log_glibc(1.0 - np_exp_glibc(out[0]) - np_exp_glibc(out[1]));
     out[3] = np_log_glibc(0.01);
 }
+// The device computes the aligner's constants, set4's log(var) and calculate_transitions with restatements of glibc 2.35's
+// log / exp / logf (np_log.h, np_logf.h; the x86-64 FMA variants this image's libm selects).  A host whose libm is another
+// version or lacks FMA computes what the REFERENCE would compute there -- which may differ in the last bit from the
+// restatement.  This check compares them on `n` pseudo-random arguments in the ranges the path uses; 0 mismatches means
+// device-side constants are bit-identical to this host's libm.
+int np_selftest_libm(uint64_t n, uint64_t seed, uint64_t* n_mismatch)
+{
+    if (!n_mismatch) return NP_ERR_INVALID;
+    uint64_t bad = 0, s = seed ? seed : 1;
+    for (uint64_t i = 0; i < n; ++i) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const double u = (double)(s >> 11) * (1.0 / 9007199254740992.0);            // [0, 1)
+        const double x_log = ldexp(1.0 + u, (int)((s >> 3) % 24) - 12);              // log: 2^-12 .. 2^12 (probabilities, variances, ratios)
+        const double x_exp = 30.0 * u;                                               // exp(-x): 0 .. 30 nats
+        const float xf = (float)ldexp(1.0 + u, (int)((s >> 5) % 16) - 10);           // logf: transition probabilities
+        bad += np_log_glibc(x_log) != log(x_log);
+        bad += np_exp_glibc(-x_exp) != exp(-x_exp);
+        bad += np_logf_glibc(xf) != logf(xf);
+    }
+    *n_mismatch = bad;
+    return NP_OK;
+}
+
 void np_restated_log_exp(const double* x, size_t n, double* out_log, double* out_exp)
 {
     for (size_t i = 0; i < n; ++i) { out_log[i] = np_log_glibc(x[i]); out_exp[i] = np_exp_glibc(-x[i]); }

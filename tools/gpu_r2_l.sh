@@ -1,8 +1,8 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r02l; mkdir -p $O
+O=gpurun_out/r02m; mkdir -p $O
 V=nanopolish_amd/variants
-for t in hmm_onepass hmm_twopass hmm_onepass hmm_twopass; do
+for t in hmm_nospec hmm_spec hmm_nospec hmm_spec; do
   NP_HIP_LIB=$PWD/$V/libnp_hip_$t.so timeout 200 python bench.py --steps 3 --warmup 1 --pool 4000 --tile 5 --cpu-sample 0 --streamed 0 --ragged 0 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
