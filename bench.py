@@ -61,7 +61,7 @@ def ragged_lengths(read_ids, mean_len, sigma=0.5, lo=600, hi=40000):
 def _prep_chunk(a):
     from nanopolish_amd.pipeline import build_host_batch
     models, ids, lens, raw = a
-    return build_host_batch(models, ids, L=lens, raw=raw, with_jobs=False)
+    return build_host_batch(models, ids, L=lens, raw=raw, with_jobs=False, adc=raw)       # raw traces are int16 ADC counts
 
 
 def prep_host_batch(models, lo, hi, lens, raw, workers):

@@ -371,6 +371,13 @@ void np_event_detection_params(np_detector_param* p, int rna);
 #define NP_ED_INEXACT  (-2)   /* n_events[r]: the detector's double-precision sums are not provably exact for this read, */
                               /* so an order-independent evaluation could differ from the reference in the last bit      */
 
+/* The signal loaders' conversion of ADC counts to pA, in front of detect_events:
+ *     rawptr[i] = ((float)raw_signal[i] + offset) * raw_unit,   raw_unit = range / digitisation  (all fp32)
+ * (src/io/nanopolish_fast5_loader.cpp:96-103, src/io/nanopolish_fast5_io.cpp:163-165).  A host-fed batch then uploads int16
+ * samples, half the bytes.  adc: int16[total samples]; offset / raw_unit: float[n_reads]; raw_pa: float[total samples] out. */
+int np_adc_to_pa_dev(np_ctx* ctx, void* stream, int n_reads, const int16_t* adc, const int64_t* raw_off, int64_t max_samples,
+                     const float* offset, const float* raw_unit, float* raw_pa);
+
 /* detect_events (src/thirdparty/scrappie/event_detection.c:268-319) on the WHOLE raw table of every read, as
  * SquiggleRead::load_from_raw runs it (src/nanopolish_squiggle_read.cpp:229-236; the trim it computes is discarded there).
  *   raw / raw_off      : float[total samples] (pA), int64[n_reads+1]

@@ -454,6 +454,18 @@ int np_hmm_score_dev(np_ctx* c, void* stream, int64_t n_jobs, const np_hmm_job_d
     return run_hmm_forward(c, use_stream(c, stream), n_jobs, jobs, reads, event_mean, job_kmer_rank, model, out_scores);
 }
 
+int np_adc_to_pa_dev(np_ctx* c, void* stream, int n_reads, const int16_t* adc, const int64_t* raw_off, int64_t max_samples,
+                     const float* offset, const float* raw_unit, float* raw_pa)
+{
+    if (!c || n_reads < 0 || (n_reads > 0 && (!adc || !raw_off || !offset || !raw_unit || !raw_pa))) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = use_stream(c, stream);
+    family_timer tm(c, 4, s);
+    NP_HIP(c, np_launch_adc_to_pa(n_reads, adc, raw_off, max_samples, offset, raw_unit, raw_pa, s));
+    return NP_OK;
+}
+
 int np_site_table_dev(np_ctx* c, void* stream, int64_t n_groups, const float* scores, const int32_t* first_site,
                       const int32_t* n_motif, const np_hmm_job_dev* jobs, const int64_t* read_base, double call_threshold,
                       int64_t n_pos, int32_t* table)

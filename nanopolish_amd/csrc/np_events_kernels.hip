@@ -37,6 +37,27 @@ __device__ __forceinline__ double dbl_readlane(double v, int l)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// ADC counts -> pA, the conversion the signal loaders apply before SquiggleRead sees the raw table:
+//     float signal = rec->raw_signal[i]; rawptr[i] = (signal + offset) * raw_unit;     raw_unit = range / digitisation
+// (src/io/nanopolish_fast5_loader.cpp:96-103 for slow5, src/io/nanopolish_fast5_io.cpp:163-165 for fast5: the same fp32
+// expression).  Half the bytes of a host-fed batch: int16 up, fp32 on the device.  Block per (read, 1024-sample tile).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) np_adc_to_pa_kernel(int n_reads, const int16_t* __restrict__ adc, const int64_t* __restrict__ raw_off,
+                                                            const float* __restrict__ offset, const float* __restrict__ raw_unit,
+                                                            float* __restrict__ raw_pa)
+{
+    const int r = blockIdx.x;
+    if (r >= n_reads) return;
+    const int64_t n = raw_off[r + 1] - raw_off[r];
+    const int64_t base = (int64_t)blockIdx.y * 1024;
+    if (base >= n) return;
+    const float off = offset[r], unit = raw_unit[r];
+    const int16_t* in = adc + raw_off[r];
+    float* out = raw_pa + raw_off[r];
+    for (int64_t i = base + threadIdx.x; i < n && i < base + 1024; i += 256) out[i] = ((float)in[i] + off) * unit;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // exactness bound of the prefix sums, one block per read
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) np_ed_check_kernel(int n_reads, const float* __restrict__ raw, const int64_t* __restrict__ raw_off,
@@ -482,6 +503,15 @@ __global__ void __launch_bounds__(64) np_mom_fill_kernel(int n_reads, np_read_de
 }
 
 } // namespace
+
+hipError_t np_launch_adc_to_pa(int n_reads, const int16_t* adc, const int64_t* raw_off, int64_t max_samples, const float* offset,
+                               const float* raw_unit, float* raw_pa, hipStream_t s)
+{
+    if (n_reads <= 0 || max_samples <= 0) return hipSuccess;
+    hipLaunchKernelGGL(np_adc_to_pa_kernel, dim3(n_reads, (unsigned)((max_samples + 1023) / 1024)), dim3(256), 0, s, n_reads, adc, raw_off,
+                       offset, raw_unit, raw_pa);
+    return hipGetLastError();
+}
 
 hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t* raw_off, int64_t max_samples, const np_detector_param& p,
                                    float2* tstat, int32_t* status, const int64_t* event_off, int64_t max_events, uint32_t* event_start,

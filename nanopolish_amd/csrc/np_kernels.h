@@ -119,6 +119,8 @@ hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t*
                                    float2* tstat, int32_t* status, const int64_t* event_off, int64_t max_events, uint32_t* event_start,
                                    float* event_length, float* event_mean, float* event_stdv, int32_t* n_events, int warmup /* < 0: default */,
                                    hipStream_t s);
+hipError_t np_launch_adc_to_pa(int n_reads, const int16_t* adc, const int64_t* raw_off, int64_t max_samples, const float* offset,
+                               const float* raw_unit, float* raw_pa, hipStream_t s);
 hipError_t np_launch_mom_fill(int n_reads, np_read_dev* reads, np_read_dev* reads_b, const float* event_mean, const int32_t* n_events,
                               const uint16_t* ranks, const np_state_dev* model, hipStream_t s);
 

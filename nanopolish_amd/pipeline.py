@@ -31,16 +31,18 @@ assert READ_DT.itemsize == C.sizeof(_l.ReadDev) and JOB_DT.itemsize == C.sizeof(
 HAF = api.HAF_ALLOW_PRE_CLIP | api.HAF_ALLOW_POST_CLIP
 
 
-def build_host_batch(models, read_ids, L=5450, k=6, raw=False, with_jobs=True):
+def build_host_batch(models, read_ids, L=5450, k=6, raw=False, with_jobs=True, adc=False):
     """Host-side preparation of the distinct reads of a batch (numpy only).
     L: bases per read, one number or one per read (ragged batches).
     raw=True: reads carry synthetic raw signal (synth_raw); the event arrays are then sized as CAPACITY for the device
     detector (n_samples/2 + 2 per read) and hold no data, and the per-read records only carry offsets and n_kmers.
-    with_jobs=False: no host-built work items (the device builds them, jobs_on_device=True): hb["jobs"] stays empty."""
+    with_jobs=False: no host-built work items (the device builds them, jobs_on_device=True): hb["jobs"] stays empty.
+    adc=True (with raw): the traces are int16 ADC counts (hb["adc"], per-read offset / unit) and hb["raw"] holds the pA values
+    they convert to; a batch built this way uploads the counts and converts on the device (np_adc_to_pa_dev)."""
     L_ = _l.load_library()
     nuc = models["nucleotide"]
     Ls = np.broadcast_to(np.asarray(L, np.int64), (len(read_ids),))
-    reads = [(synth_raw if raw else synth_read)(r, nuc, L=int(l), k=k) for r, l in zip(read_ids, Ls)]
+    reads = [(synth_raw(r, nuc, L=int(l), k=k, adc=adc) if raw else synth_read(r, nuc, L=int(l), k=k)) for r, l in zip(read_ids, Ls)]
     n = len(reads)
     if raw:
         for r in reads:
@@ -85,6 +87,10 @@ def build_host_batch(models, read_ids, L=5450, k=6, raw=False, with_jobs=True):
     if raw:
         raw_off = np.zeros(n + 1, np.int64); raw_off[1:] = np.cumsum([len(r["raw"]) for r in reads])
         extra = dict(raw=np.concatenate([r["raw"] for r in reads]).astype(np.float32), raw_off=raw_off)
+        if adc:
+            from .synth import ADC_OFFSET, ADC_UNIT
+            extra.update(adc=np.concatenate([r["adc"] for r in reads]), adc_offset=np.full(n, ADC_OFFSET, np.float32),
+                         adc_unit=np.full(n, ADC_UNIT, np.float32))
     return dict(reads=reads, n=n, events=events, ranks=ranks, event_off=event_off, rank_off=rank_off,
                 reads_a=reads_a, reads_b=reads_b, mom=mom, ref_seqs=ref_seqs, k=k, **extra,
                 jobs=np.concatenate(jobs) if jobs else np.zeros(0, JOB_DT),
@@ -123,6 +129,9 @@ def concat_host_batches(parts):
         ns = np.cumsum([0] + [len(p["raw"]) for p in parts])
         out["raw"] = np.concatenate([p["raw"] for p in parts])
         out["raw_off"] = np.concatenate([p["raw_off"][:-1] + ns[i] for i, p in enumerate(parts)] + [[ns[-1]]]).astype(np.int64)
+    if "adc" in out:
+        for key in ("adc", "adc_offset", "adc_unit"):
+            out[key] = np.concatenate([p[key] for p in parts])
     return out
 
 
@@ -221,6 +230,8 @@ def tile_host_batch(hb, tile):
         ns = len(hb["raw"])
         out["raw"] = np.tile(hb["raw"], tile)
         out["raw_off"] = np.concatenate([hb["raw_off"][:-1] + t * ns for t in range(tile)] + [[ns * tile]]).astype(np.int64)
+        if "adc" in hb:
+            out["adc"] = np.tile(hb["adc"], tile); out["adc_offset"] = np.tile(hb["adc_offset"], tile); out["adc_unit"] = np.tile(hb["adc_unit"], tile)
     if "cigar" in hb:
         nc = len(hb["cigar"])
         out["cigar"] = np.tile(hb["cigar"], tile)
@@ -242,6 +253,7 @@ class CallMethylationBatch:
         self.torch = torch
         self.calibrate = bool(calibrate)
         self.from_raw = bool(from_raw)
+        self.from_adc = False
         self.jobs_on_device = bool(jobs_on_device)
         self.workload = workload       # "eventalign": a step ends with the segment chain instead of the methylation scoring
         self.by_cigar = "cigar" in hb          # work items follow BAM CIGARs (build_host_batch_records)
@@ -259,7 +271,13 @@ class CallMethylationBatch:
         self.d_events = up(hb["events"]); self.d_ranks = up(hb["ranks"])
         if self.from_raw:
             # raw signal in, events out: the detector writes event means into d_events at the capacity offsets
-            self.d_raw = up(hb["raw"]); self.d_raw_off = up(hb["raw_off"]); self.d_event_off = up(hb["event_off"])
+            self.from_adc = "adc" in hb          # int16 ADC counts in, converted to pA on the device at the head of the step
+            if self.from_adc:
+                self.d_adc = up(hb["adc"]); self.d_adc_offset = up(hb["adc_offset"]); self.d_adc_unit = up(hb["adc_unit"])
+                self.d_raw = torch.empty(len(hb["raw"]) * 4, dtype=torch.uint8, device=dev)
+            else:
+                self.d_raw = up(hb["raw"])
+            self.d_raw_off = up(hb["raw_off"]); self.d_event_off = up(hb["event_off"])
             ns = hb["raw_off"][1:] - hb["raw_off"][:-1]
             self.max_samples = int(ns.max()); self.total_samples = int(ns.sum())
             ecap = hb["event_off"][1:] - hb["event_off"][:-1]
@@ -353,6 +371,10 @@ class CallMethylationBatch:
                                                  p(self.d_n_motif), p(self.d_n_groups))
             self.ctx._chk(rc, "np_cm_build_jobs_identity_dev")
         if self.from_raw:
+            if self.from_adc:
+                rc = L.np_adc_to_pa_dev(h, s, self.n_reads, p(self.d_adc), p(self.d_raw_off), self.max_samples, p(self.d_adc_offset),
+                                        p(self.d_adc_unit), p(self.d_raw))
+                self.ctx._chk(rc, "np_adc_to_pa_dev")
             rc = L.np_detect_events_dev(h, s, self.n_reads, p(self.d_raw), p(self.d_raw_off), self.max_samples, C.byref(self.prm),
                                         p(self.d_tstat), p(self.d_event_off), self.max_events, p(self.d_ev_start), p(self.d_ev_len),
                                         p(self.d_events), p(self.d_ev_stdv), p(self.d_n_events))
@@ -509,7 +531,7 @@ class StreamedFeed:
     def __init__(self, batch):
         torch = batch.torch
         self.b = b = batch
-        ins = ["d_ranks", "d_reads_a", "d_reads_b"] + (["d_raw"] if b.from_raw else ["d_events"])
+        ins = ["d_ranks", "d_reads_a", "d_reads_b"] + ((["d_adc"] if b.from_adc else ["d_raw"]) if b.from_raw else ["d_events"])
         if b.jobs_on_device and not b.by_cigar:
             ins += ["d_seq", "d_rc"]
         outs = ["d_scores"] + (["d_first", "d_n_motif", "d_n_groups"] if b.jobs_on_device else [])

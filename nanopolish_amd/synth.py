@@ -79,12 +79,24 @@ def synth_read_from_codes(ref_codes, read_id, model, rc=False, k=6, seed0=SEED0)
                 shift=float(shift), scale=float(scale), var=float(var), rc=bool(rc))
 
 
-def synth_raw(read_id, model, L=5000, k=6, seed0=SEED0, samples_per_kmer=8.9, noise=1.0):
+ADC_OFFSET = np.float32(10.0)
+ADC_UNIT = np.float32(1400.0) / np.float32(8192.0)          # range / digitisation of a MinION channel, in fp32 as the loaders compute it
+
+
+def adc_quantise(raw):
+    """pA samples -> (int16 ADC counts, the pA values those counts convert back to): the signal loaders' conversion
+    rawptr[i] = ((float)count + offset) * raw_unit (src/io/nanopolish_fast5_loader.cpp:96-103), all in fp32."""
+    adc = np.clip(np.rint(np.asarray(raw, np.float32) / ADC_UNIT - ADC_OFFSET), -32768, 32767).astype(np.int16)
+    return adc, ((adc.astype(np.float32) + ADC_OFFSET) * ADC_UNIT).astype(np.float32)
+
+
+def synth_raw(read_id, model, L=5000, k=6, seed0=SEED0, samples_per_kmer=8.9, noise=1.0, adc=False):
     """Synthetic RAW current trace (pA, float32) of a read, for the event-detection stage:
     the read of synth_read(read_id) dwells on every k-mer for 1 + Poisson(samples_per_kmer - 1) samples (4 kHz sampling
     at 450 bases/s is ~8.9 samples per base) at its scaled model level, with white noise of the k-mer's scaled stdv.
     Values are kept >= 8 pA, like real open-channel-normalised signal (and comfortably inside the range where the
-    detector's double-precision prefix sums are exact)."""
+    detector's double-precision prefix sums are exact).  adc=True: also the int16 ADC counts (rd["adc"]), with rd["raw"]
+    the pA values they convert to."""
     rd = synth_read(read_id, model, L, k, seed0)
     rng = np.random.default_rng(seed0 + 104729 * (int(read_id) + 1))
     K = len(rd["ranks"])
@@ -94,6 +106,8 @@ def synth_raw(read_id, model, L=5000, k=6, seed0=SEED0, samples_per_kmer=8.9, no
     sd = noise * rd["var"] * model["level_stdv"][rk]
     raw = np.maximum(mu + sd * rng.standard_normal(len(rk)), 8.0).astype(np.float32)
     rd = dict(rd); rd["raw"] = raw; rd["dwell"] = dwell
+    if adc:          # the trace as a sequencer stores it: int16 counts; "raw" becomes exactly what those counts convert to
+        rd["adc"], rd["raw"] = adc_quantise(raw)
     return rd
 
 

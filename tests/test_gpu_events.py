@@ -147,3 +147,29 @@ def test_exactness_bound_holds_for_sequencer_scale_signal(ctx, orc):
     assert len(got[3]["mean"]) > 20000
     with pytest.raises(RuntimeError, match="INEXACT"):
         ctx.detect_events([adc_like_raw(60000, 7, zero_crossings=3)])
+
+
+def test_adc_counts_to_pa_on_the_device(ctx, orc, models):
+    """The loaders' conversion ((float)count + offset) * raw_unit (src/io/nanopolish_fast5_loader.cpp:96-103) on the device
+    (np_adc_to_pa_dev) equals the fp32 expression sample for sample, and a batch that uploads int16 counts detects exactly the
+    events of the same signal uploaded as pA."""
+    import ctypes as C
+    import torch
+    from nanopolish_amd.pipeline import build_host_batch, CallMethylationBatch
+    hb = build_host_batch(models, list(range(120, 124)), L=1500, raw=True, adc=True)
+    assert hb["adc"].dtype == np.int16
+    batch = CallMethylationBatch(ctx, hb, "cuda:0", calibrate=True, from_raw=True, jobs_on_device=True)
+    assert batch.from_adc
+    batch.step()
+    batch.sync()
+    assert np.array_equal(batch.d_raw.cpu().numpy().view(np.float32), hb["raw"])
+    # the same reads with the pA values uploaded directly
+    hb2 = {k: v for k, v in hb.items() if not k.startswith("adc")}
+    ref = CallMethylationBatch(ctx, hb2, "cuda:0", calibrate=True, from_raw=True, jobs_on_device=True)
+    ref.step()
+    for i, rd in enumerate(hb["reads"]):
+        a, b = batch.detected(i), ref.detected(i)
+        assert a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))
+        want = orc.detect_events(rd["raw"], **ED_DEFAULTS)
+        assert a[0] == len(want["mean"]) and np.array_equal(a[3], want["mean"])
+    assert np.array_equal(batch.scores(), ref.scores(), equal_nan=True)
