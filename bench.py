@@ -424,6 +424,7 @@ def main():
                         results_equal_resident=bool(same), host_enqueue_ms_last_steps=feed.host_ms[-args.steps:])
         feed.close()
         batch.stream = None
+        del feed                       # (it holds the second buffer set and clones of the outputs)
 
     # results of the resident batch on the host (rank 0), before it is released
     res = None
