@@ -39,6 +39,8 @@ sys.path.insert(0, ROOT)
 # profiles/r02).  Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
+from nanopolish_amd.hostinfo import usable_cores  # noqa: E402
+
 CLOCK_HZ = 2.4e9          # MI355X engine clock (MI355X_MICROARCH.md); 256 CUs x 4 SIMDs
 N_SIMD = 1024
 
@@ -161,26 +163,6 @@ def cpu_pass(models, hb, idx, thread_list, calibrate, from_raw, repeats=2):
         T[th]["seconds"] = T[th]["detect"] + T[th]["align"] + T[th]["calib"] + T[th]["score"]
     return dict(n=n, timings=T, n_events=[len(r["events"]) for r in rds], pairs=(pairs, pair_off, n_pairs),
                 first=first, scores=sc, kind="reference" if ref else "port")
-
-
-def usable_cores():
-    """Hardware threads this process may actually run on: the affinity mask, capped by the cgroup CPU quota (a container that
-    SEES 256 cores but is throttled to a fraction of them is the usual reason an OpenMP run with 256 threads crawls)."""
-    n = len(os.sched_getaffinity(0))
-    quota = None
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]               # cgroup v2
-        if q != "max":
-            quota = float(q) / float(per)
-    except Exception:
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                quota = q / per
-        except Exception:
-            pass
-    eff = n if quota is None else max(1, min(n, int(quota + 0.5)))
-    return n, quota, eff
 
 
 def cpu_baseline(models, hb, calibrate, from_raw, budget_reads):

@@ -65,13 +65,14 @@ def main():
                config=dict(workload="eventalign from raw signal, synthetic R9.4 reads (BASELINE.json configs[2] shape)", read_len=args.read_len,
                            distinct_reads=args.pool, tile=args.tile))
     # CPU: the reference itself, one read per thread (ctypes releases the GIL)
-    n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 2 * (os.cpu_count() or 1)
+    n_cpu = args.cpu_sample if args.cpu_sample >= 0 else 512
     n_cpu = min(n_cpu, args.pool)
     try:
         from oracle.ref_full import FullRef, have_full
         if n_cpu > 0 and have_full():
             F = FullRef()
-            threads = os.cpu_count() or 1
+            from nanopolish_amd.hostinfo import usable_cores
+            threads = usable_cores()[2]            # affinity mask capped by the cgroup CPU quota
             # timing: OpenMP over reads inside the reference-backed library; parity: the rows of a few reads, one by one
             rows_cpu, t_cpu = F.many_identity(0, [r["seq"] for r in recs[:n_cpu]], [r["raw"] for r in recs[:n_cpu]], [r["rc"] for r in recs[:n_cpu]], threads)
             ok = all(int(rows_cpu[i]) == len(res[i]["event_idx"]) for i in range(n_cpu))

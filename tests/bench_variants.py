@@ -152,7 +152,8 @@ def main():
             pick = np.flatnonzero((jh["flags"][:len(jobs)] & 0x80000000) == 0)
             pick = pick[np.linspace(0, len(pick) - 1, min(args.cpu_sample, len(pick))).astype(np.int64)]
             epb = d_epb.cpu().numpy()
-            threads = os.cpu_count() or 1
+            from nanopolish_amd.hostinfo import usable_cores
+            threads = usable_cores()[2]            # affinity mask capped by the cgroup CPU quota
             order = np.argsort(jh["read"][pick], kind="stable"); pick = pick[order]
             rd_of = jh["read"][pick].astype(np.int64)
             job_off = np.searchsorted(rd_of, np.arange(n + 1))
