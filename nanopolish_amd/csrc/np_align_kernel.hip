@@ -2,120 +2,75 @@
 //
 // One wavefront per read, ~E+K+2 sequential band steps.  Design (DESIGN.md section "Kernel A"):
 //   * The 100-cell band lives in registers, anchored by k-mer index instead of by band offset: cell (event e,
-//     k-mer k) of band b = e+k+2 sits in ring slot (k mod 128); lane l owns slots l and l+64.  With that
-//     anchoring the three DP sources never depend on the band's move history:
+//     k-mer k) of band b = e+k+2 sits in ring slot (k mod 128).  With that anchoring the three DP sources never
+//     depend on the band's move history:
 //         up   = band b-1, same slot        left = band b-1, slot-1        diag = band b-2, slot-1
-//     so one wave-rotate (2 DPP wave_ror:1 + 2 selects) of the previous band per step serves `left`, and the
-//     rotate kept from the step before serves `diag`.  A slot whose k-mer is outside the band window holds -inf,
-//     which is exactly the reference's is_offset_valid(...) ? BAND_ARRAY(...) : -INFINITY.
-//   * Suzuki's move rule reads the band's first and last cell (ll, ur) with v_readlane; all band geometry is
-//     wave-uniform scalar state.
+//     The ring is INTERLEAVED over the wave: lane l owns slots 2l (slot register 0) and 2l+1 (slot register 1).  The left
+//     neighbour of an odd slot is then the lane's own even slot (no data movement at all), that of an even slot the
+//     previous lane's odd slot: ONE DPP wave_ror:1 per band, whose wrap-around (lane 0 <- lane 63) is exactly slot 0's
+//     neighbour, slot 127.  A slot whose k-mer is outside the band window holds -inf, which is exactly the reference's
+//     is_offset_valid(...) ? BAND_ARRAY(...) : -INFINITY.  (A split layout -- slots l and l+64 -- needs two rotates plus two
+//     lane-0 selects, one more fp64 conversion and twice the v_readlane of Suzuki's rule: round 2, 284 -> ~200 SIMD cycles
+//     per band together with the two items below.)
+//   * Suzuki's move rule reads the band's first and last cell (ll, ur) with v_readlane: 100 is even, so the two ends always
+//     sit in DIFFERENT slot registers, one v_readlane each; all band geometry is wave-uniform scalar state.
 //   * Prologue per read: the scaled Gaussian of every k-mer (fp64 math of squiggle_read.h:217-226, plus the
 //     correctly rounded reciprocal of sigma) goes into a per-wave slab, 16 B per k-mer; the band loop then only
 //     does fp32 emissions and the reference's fp64 candidate sums.
 //   * The inner step is branch-free per lane: DP cells are computed by every lane and masked.  The band loop runs in
 //     three phases: a generic step (band geometry, trim column k = -1, end-cell search) for the first and last ~300
 //     bands, and a FAST step for the middle of the read, where every cell of the 100-wide window exists, so validity
-//     is a pair of wave-uniform lane masks that only change on a right move.
+//     is a pair of wave-uniform lane masks that only change on a right move -- by one bit rotation on the scalar unit.
 //   * Event means are prefetched one band ahead straight into the loop-carried register (the load is issued after
 //     the emission has consumed the old value), through a range-checked buffer descriptor: out-of-range events read
-//     as 0 and only feed masked cells, so there is no clamp.  A ring slot always holds the parameters of its next
-//     k-mer (k+128) in `n0/n1`, requested when the slot is re-targeted and consumed 128 right-moves later; the
-//     re-target itself is five v_mov under a one-lane exec mask.
-//   * Issue-cycle budget (tools/valu_rates.hip, measured on MI355X): fp32 add/fma/mov/int add issue in ~2 cycles per
-//     wave, fp64 ops, conversions, v_cmp, v_cndmask (VOP3), DPP, v_readlane and 3-operand integer ops in ~4, and the
-//     scalar unit also sustains one instruction per ~4 cycles per SIMD -- so scalar band bookkeeping is as expensive
-//     as vector work and is kept out of the FAST step.  Back-to-back VOP2 v_cndmask (implicit VCC) issue at ~20.
+//     as 0 and only feed masked cells, so there is no clamp.
+//   * The ring holds 128 k-mers for a window of 100: slots are re-targeted (k -> k + 128) EIGHT AT A TIME, whenever the
+//     window's first k-mer reaches a multiple of 8 -- the eight slots 9..16 k-mers below the window, i.e. both slots of four
+//     neighbouring lanes, which load their new parameter records themselves under a four-lane exec mask.  (An exec-mask
+//     region costs ~14 plain vector instructions of issue time on this chip, tools/valu_rates.hip: one region per right move,
+//     as in the first version of this kernel, was a tenth of the band.)  The new k-mers are 13+ right moves away from the
+//     window, so the wait for the records (inside the region: the compiler never sees a load in flight) is not on anyone's path.
+//   * Issue-cycle budget (tools/valu_rates.hip, measured on MI355X; v_add_f32 = 1): fp32 add/mul/fma, integer add/and/or with
+//     register or inline-constant operands 1; fp64 ops, conversions, v_cmp, v_cndmask (VOP3), v_max3, DPP moves, carry ops,
+//     anything with a scalar-register operand ~1.8; v_readlane with a scalar lane select 3.2; scalar ALU ops 2 (on their own
+//     port).  The kernel is bound by vector issue, so the band step is written against that table.
 //   * Candidates are evaluated as the reference does: fp32 cell + fp64 transition constant + fp32 emission in
 //     fp64, rounded to fp32, compared in fp32, later candidate wins ties (raw_loader.cpp:259-274).
-//   * The trace is 2 bits per cell: each lane packs the codes of its two slots, 4 bits per band, and stores one dword per
-//     8 bands (coalesced 256 B = 32 bytes per band, vs 100 bytes in the
-//     reference); unfilled cells read back as FROM_D exactly like the reference's zero-initialised trace.
-//   * Back-track: the walk state is scalar; the trace is pulled in 64-band chunks (lane i holds band hi-i, the
-//     next chunk is prefetched), each step is two v_readlane + bit tests.  Pairs are collected 64 at a time in a
-//     register pair and stored coalesced; their emissions are computed 64-wide at every flush and added to the QC
-//     sum in walk order (the reference's summation order, raw_loader.cpp:338-341).
+//   * The trace is 2 bits per cell (bit 1: the cell equals its `left` candidate, bit 0: its `up` candidate; left wins): each
+//     lane shifts the four bits of its two slots into one register per band -- the compare masks enter as the carry of
+//     v_addc(t, t) -- and stores one dword per 8 bands (coalesced 256 B = 32 bytes per band, vs 100 bytes in the reference);
+//     unfilled cells read back as FROM_D exactly like the reference's zero-initialised trace.
+//   * Back-track: the walk state is scalar; trace groups are prefetched NP_BT_DEPTH deep into registers, each step is one
+//     v_readlane + bit tests.  Pairs are collected 64 at a time and stored coalesced; their emissions are summed for the QC
+//     after the walk (the reference's summation order, raw_loader.cpp:338-341, when the decision is close).
 #include "np_kernels.h"
 
 #define NP_ALIGN_BLOCK 256
 #define NP_RING 128
-#define NP_MARGIN 14   // (128 - 100) / 2
-
-// Build-time switches of the band step (A/B builds, tools/align_variants.sh):
-#ifndef NP_A_INTCMP
-#define NP_A_INTCMP 1     // Suzuki's rule in the FAST phase as one scalar unsigned compare (reads whose cells are all <= 0)
-#endif
-#ifndef NP_A_ONEREC
-#define NP_A_ONEREC 1     // one pending k-mer record per lane (its two ring slots re-target alternately) instead of two
-#endif
-#ifndef NP_A_EARLYSUZ
-#define NP_A_EARLYSUZ 1   // FAST: read the band ends for Suzuki's rule before packing the trace codes
-#endif
-#ifndef NP_A_UNROLL8
-#define NP_A_UNROLL8 0    // FAST phase in blocks of 8 bands aligned with the trace groups: the trace store, the loop control and
-#endif                    // the event-mean offsets (instruction immediates) are paid once per block, not once per band.
-                          // Measured SLOWER than two bands per iteration (52.9 vs 51.6 ms per 32768 reads) although it issues
-                          // ~9 % fewer instructions per band: the fill is bound by its vector instructions (22 double-rate
-                          // ones per band), not by the scalar bookkeeping the blocks remove.  Needs NP_A_CMPX.
-#ifndef NP_A_TRACEASM
-#define NP_A_TRACEASM 1   // FAST: the four trace compares write four scalar pairs before the selects read them (no hazard s_nops)
-#endif
-#ifndef NP_A_CMPX
-#define NP_A_CMPX 1       // re-target: the one-lane exec masks come from v_cmpx on the slot index instead of scalar shifts
-#endif
 #ifndef NP_BT_DEPTH
 #define NP_BT_DEPTH 8     // back-track: trace groups (8 bands each) requested ahead of the walk
 #endif
-#ifndef NP_A_DDBL
-#define NP_A_DDBL 1       // the diagonal source is kept as the double the previous band converted for `left`
-#endif
-// ablations: timing experiments only, results are WRONG with any of these set
-#ifndef NP_ABL
-#define NP_ABL 0          // bit mask: 1 no trace, 2 fp32 candidate sums, 4 fixed move pattern (keeps the control flow of the
-#endif                    // other ablations comparable), 8 no event loads, 16 trivial emission, 32 no lane-0 wrap selects,
-                          // 64 no k-mer record loads, 128 no back-track
-#ifndef NP_PROBE_SALU
-#define NP_PROBE_SALU 0   // issue-cost probes: this many extra scalar / vector adds per FAST band (timing experiments)
-#endif
-#ifndef NP_PROBE_VALU
-#define NP_PROBE_VALU 0
-#endif
 #ifndef NP_A_WAVES
-#define NP_A_WAVES 7      // resident waves per SIMD the register budget is set for
+#define NP_A_WAVES 8      // resident waves per SIMD the register budget is set for
 #endif
-
+// timing experiments only (results are WRONG with any bit set): 1 no trace, 128 no back-track
+#ifndef NP_ABL
+#define NP_ABL 0
+#endif
 
 namespace {
 
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef int i4 __attribute__((ext_vector_type(4)));
+
+// The ring covers the k-mers [base, base + 127], base = 8 floor(llk / 8) - 8: at least 8 below the window [llk, llk + 99]
+// and at least 13 above it.  It moves up by 8 whenever llk reaches a multiple of 8 (retarget below).
+__device__ __forceinline__ int ring_base(int llk) { return (llk & ~7) - 8; }
+// k-mer that ring slot `slot` holds while the window starts at llk
 __device__ __forceinline__ int ring_kmer(int slot, int llk)
 {
-    const int base = llk - NP_MARGIN;
+    const int base = ring_base(llk);
     return base + ((slot - base) & (NP_RING - 1));
-}
-
-__device__ __forceinline__ float readlane_f(float v, int l)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-
-// value of ring slot s (uniform) of a band held as (r0 = slots 0..63, r1 = slots 64..127)
-__device__ __forceinline__ float ring_read(float r0, float r1, int s)
-{
-    const int a = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r0), s & 63);
-    const int b = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r1), s & 63);
-    return __builtin_bit_cast(float, (s & 64) ? b : a);      // both are SGPRs: a scalar select
-}
-
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-// parameter record of k-mer k from this wave's slab; the index is clamped (never a branch, never a default value:
-// a conditional load would make hipcc wait for it on the spot) -- records of k outside [0,K) are never used
-__device__ __forceinline__ float4 load_kp(const float4* __restrict__ kp, int k, int K) { return kp[clampi(k, 0, K - 1)]; }
-
-__device__ __forceinline__ np_gauss as_gauss(const float4 v)
-{
-    np_gauss g; g.mean = v.x; g.stdv = v.y; g.cl = v.z; g.rinv = v.w;
-    return g;
 }
 
 __device__ __forceinline__ double uniform_f64(double v)
@@ -132,48 +87,48 @@ template <class T> __device__ __forceinline__ T* uniform_ptr(T* p)
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
     return (T*)(((uint64_t)hi << 32) | lo);
 }
+__device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ float4 load_kp(const float4* __restrict__ kp, int k, int K) { return kp[clampi(k, 0, K - 1)]; }
+
 // Everything the fill carries from band to band.
 struct fill_t {
     int llk;                // band_lower_left[b].kmer_idx (wave-uniform)
-    int kb0, kb1;           // 4 * (k-mer mapped to this lane's two ring slots); inside the FAST blocks of 8 bands instead the
-                            // byte offset of the block's first event mean, 4 * (b0 - 1) - 4 k (band POS adds 4 * POS)
-    float g0m, g0s, g0c, g0r;   // scaled Gaussian of slot l: mean, -stdv, log-constant, 1/stdv (scalars, so that a
-    float g1m, g1s, g1c, g1r;   // re-target can update them in place) -- and of slot l + 64
-#if NP_A_ONEREC
-    float4 n0;              // the record this lane needs at its NEXT re-target.  A lane's two slots re-target alternately, 64
-    int nko;                // right moves apart, and the k-mers they take advance by 64 each time: one pending record
-                            // (byte offset nko in the slab) serves both slots
-#else
-    float4 n0, n1;          // the records of k0+128 / k1+128, requested when the slot was last re-targeted
-#endif
+    int eo0, eo1;           // byte offset, in the read's event means, of the event the NEXT band pairs with the k-mer of this
+                            // lane's slot 2l / 2l+1: on entry to band b it is 4 (b - 1 - k)
+    f4 g0, g1;              // scaled Gaussian of the two slots' k-mers: mean, -stdv, log-constant, 1/stdv (a register quad
+                            // each: a re-target loads it in place)
     float p0, p1;           // band b-1
-#if NP_A_DDBL
-    double d0, d1;          // band b-2 rotated by one slot, as the double the previous band made of its `left`
-#else
-    float d0, d1;           // band b-2 rotated by one slot
-#endif
+    double d0, d1;          // band b-2 moved on by one slot, as the doubles band b-1 made for its `left` candidates
     float best; int best_e; // end-cell search (:309-324): wave-uniform
-    uint32_t tacc;          // trace codes of the last (up to) 8 bands, 4 bits per band, newest in the top nibble
-    uint64_t vm0, vm1;      // FAST phase: lanes whose slot (l, l + 64) is inside the window (wave-uniform lane masks)
+    uint32_t tacc;          // trace bits of the last (up to) 8 bands, 4 bits per band, newest in the low nibble
+    uint64_t vm0, vm1;      // FAST phase: lanes whose slot (2l, 2l+1) is inside the window (wave-uniform lane masks)
+    int sel0, sel1, swp;    // FAST phase: the lanes of slot register 0 / 1 that hold a band end; swp: register 1 holds the FIRST cell
 };
 
 struct read_t {
-    int E, K, lane, end_slot;
+    int E, K, lane, lane4, end_slot;
     bool nonpos;                    // every emission constant of the read is <= 0, hence every DP cell is (see the prologue)
     __amdgpu_buffer_rsrc_t ev;      // event means of the read, E * 4 bytes
     __amdgpu_buffer_rsrc_t kp;      // this wave's k-mer parameter slab, K * 16 bytes
-    uint32_t* __restrict__ trace32;
+    i4 kpd;                         // the same descriptor as four scalars (for the loads written in assembly)
+    __amdgpu_buffer_rsrc_t tr;      // this wave's trace slab (a buffer store, not a flat one: a flat access in flight makes hipcc
+                                    // wait for EVERY outstanding load at the next use of any of them)
     double lp_skip, lp_stay, lp_step, lp_trim;
 };
 
-// bit pattern of ring slot s (uniform) of a band held as (r0 = slots 0..63, r1 = slots 64..127); all scalar
+// bit pattern of ring slot s (uniform) of a band held as (r0 = even slots, r1 = odd slots); all scalar
 __device__ __forceinline__ int ring_read_bits(float r0, float r1, int s)
 {
-    int a = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r0), s & 63);
-    int b = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r1), s & 63);
+    int a = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r0), (s >> 1) & 63);
+    int b = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r1), (s >> 1) & 63);
     asm("" : "+s"(a)); asm("" : "+s"(b));
-    return (s & 64) ? b : a;
+    return (s & 1) ? b : a;
 }
+__device__ __forceinline__ float ring_read(float r0, float r1, int s) { return __builtin_bit_cast(float, ring_read_bits(r0, r1, s)); }
 // keeps a wave-uniform value in a scalar register, so that what is computed from it is selected onto the scalar unit
 __device__ __forceinline__ int pin_s(int x) { asm("" : "+s"(x)); return x; }
 // wave_ror:1 where every lane has a source lane, so the destination's previous content needs no initialisation
@@ -188,87 +143,43 @@ __device__ __forceinline__ float sel_mask(uint64_t m, float t, float f)
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
     return r;
 }
-// lanes of slot register `half` (0: slots 0..63, 1: slots 64..127) whose slot is inside the window [llk, llk+99]
-__device__ __forceinline__ uint64_t window_mask(int lane, int half, int llk)
+// FAST-phase lane masks and band-end lanes for a window that starts at llk: 50 even and 50 odd slots, each a run of 50
+// lanes (mod 64) that starts at lane ceil(llk / 2) resp. floor(llk / 2)
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int n) { n &= 63; return n ? (x << n) | (x >> (64 - n)) : x; }
+__device__ __forceinline__ void window_state(fill_t& F)
 {
-    return __builtin_amdgcn_ballot_w64((uint32_t)((lane + 64 * half - llk) & (NP_RING - 1)) < (uint32_t)NP_ALN_BANDWIDTH);
+    const uint64_t m50 = (1ull << (NP_ALN_BANDWIDTH / 2)) - 1ull;
+    F.vm0 = rotl64(m50, (F.llk + 1) >> 1);
+    F.vm1 = rotl64(m50, F.llk >> 1);
+    const int la = (F.llk >> 1) & 63, ua = ((F.llk + NP_ALN_BANDWIDTH - 1) >> 1) & 63;       // lanes of slots llk, llk + 99
+    F.swp = F.llk & 1;
+    F.sel0 = F.swp ? ua : la;
+    F.sel1 = F.swp ? la : ua;
 }
 
-// The lane selected by m0 (slot register 0) or m1 (slot register 1) -- one of the two masks is empty -- takes over its
-// pending record and moves on by 128 k-mers.  Plain v_mov under a one-lane exec mask: straight-line code that updates
-// the registers in place (selects cost twice the issue cycles, and a branch per register costs the compiler's copies).
-// EO: kb0 / kb1 currently hold block-relative event offsets (FAST blocks), which DROP by 4 * 128 when the k-mer grows by 128.
-template <bool EO>
-__device__ __forceinline__ void retarget(fill_t& F, uint64_t m0, uint64_t m1, const int lane_id)
+// The window's first k-mer has just reached a multiple of 8 (F.llk): the eight slots that hold the k-mers llk-16 .. llk-9 --
+// both slots of the four lanes (slot >> 1) -- move on by 128 k-mers and load their new records.  kref16: 16 k = kref16 - 4 eo
+// for the eo values as they are at the call.
+__device__ __forceinline__ void retarget(fill_t& F, const read_t& R, const int kref16)
 {
-    uint64_t save;
-#if NP_A_ONEREC && NP_A_CMPX
-    // (this variant is called with m0 = the slot that falls out, 0..127, in its low word; the lane of slot register 0 that
-    //  holds slot `out` is lane == out, of slot register 1 lane == out - 64: two v_cmpx on the lane id select it)
-    const int out = (int)(uint32_t)m0, out1 = out - 64;
-    if (EO) {
+    const int grp = ((F.llk - 16) & (NP_RING - 1)) >> 3;
+    const int base = kref16 + 16 * NP_RING;
+    uint64_t save; int t0, t1;
     asm volatile("s_mov_b64 %[sv], exec\n\t"
-                 "v_cmpx_eq_u32_e32 %[o0], %[ln]\n\t"
-                 "v_mov_b32 %[a0], %[x0]\n\tv_mov_b32 %[a1], %[x1]\n\tv_mov_b32 %[a2], %[x2]\n\tv_mov_b32 %[a3], %[x3]\n\t"
-                 "v_subrev_u32 %[k0], 0x200, %[k0]\n\t"
-                 "v_add_u32 %[nk], 0x400, %[nk]\n\t"
-                 "s_mov_b64 exec, %[sv]\n\t"
-                 "v_cmpx_eq_u32_e32 %[o1], %[ln]\n\t"
-                 "v_mov_b32 %[b0], %[x0]\n\tv_mov_b32 %[b1], %[x1]\n\tv_mov_b32 %[b2], %[x2]\n\tv_mov_b32 %[b3], %[x3]\n\t"
-                 "v_subrev_u32 %[k1], 0x200, %[k1]\n\t"
-                 "v_add_u32 %[nk], 0x400, %[nk]\n\t"
+                 "v_cmpx_eq_u32_e32 %[grp], %[l4]\n\t"
+                 "v_lshlrev_b32 %[t0], 2, %[e0]\n\t"
+                 "v_lshlrev_b32 %[t1], 2, %[e1]\n\t"
+                 "v_sub_u32 %[t0], %[base], %[t0]\n\t"
+                 "v_sub_u32 %[t1], %[base], %[t1]\n\t"
+                 "v_subrev_u32 %[e0], 0x200, %[e0]\n\t"
+                 "v_subrev_u32 %[e1], 0x200, %[e1]\n\t"
+                 "buffer_load_dwordx4 %[g0], %[t0], %[rs], 0 offen\n\t"
+                 "buffer_load_dwordx4 %[g1], %[t1], %[rs], 0 offen\n\t"
+                 "s_waitcnt vmcnt(0)\n\t"
                  "s_mov_b64 exec, %[sv]"
-                 : [sv] "=&s"(save), [a0] "+v"(F.g0m), [a1] "+v"(F.g0s), [a2] "+v"(F.g0c), [a3] "+v"(F.g0r), [k0] "+v"(F.kb0),
-                   [b0] "+v"(F.g1m), [b1] "+v"(F.g1s), [b2] "+v"(F.g1c), [b3] "+v"(F.g1r), [k1] "+v"(F.kb1), [nk] "+v"(F.nko)
-                 : [o0] "s"(out), [o1] "s"(out1), [ln] "v"(lane_id), [x0] "v"(F.n0.x), [x1] "v"(F.n0.y), [x2] "v"(F.n0.z), [x3] "v"(F.n0.w)
-                 : "vcc");
-    } else {
-    asm volatile("s_mov_b64 %[sv], exec\n\t"
-                 "v_cmpx_eq_u32_e32 %[o0], %[ln]\n\t"
-                 "v_mov_b32 %[a0], %[x0]\n\tv_mov_b32 %[a1], %[x1]\n\tv_mov_b32 %[a2], %[x2]\n\tv_mov_b32 %[a3], %[x3]\n\t"
-                 "v_add_u32 %[k0], 0x200, %[k0]\n\t"
-                 "v_add_u32 %[nk], 0x400, %[nk]\n\t"
-                 "s_mov_b64 exec, %[sv]\n\t"
-                 "v_cmpx_eq_u32_e32 %[o1], %[ln]\n\t"
-                 "v_mov_b32 %[b0], %[x0]\n\tv_mov_b32 %[b1], %[x1]\n\tv_mov_b32 %[b2], %[x2]\n\tv_mov_b32 %[b3], %[x3]\n\t"
-                 "v_add_u32 %[k1], 0x200, %[k1]\n\t"
-                 "v_add_u32 %[nk], 0x400, %[nk]\n\t"
-                 "s_mov_b64 exec, %[sv]"
-                 : [sv] "=&s"(save), [a0] "+v"(F.g0m), [a1] "+v"(F.g0s), [a2] "+v"(F.g0c), [a3] "+v"(F.g0r), [k0] "+v"(F.kb0),
-                   [b0] "+v"(F.g1m), [b1] "+v"(F.g1s), [b2] "+v"(F.g1c), [b3] "+v"(F.g1r), [k1] "+v"(F.kb1), [nk] "+v"(F.nko)
-                 : [o0] "s"(out), [o1] "s"(out1), [ln] "v"(lane_id), [x0] "v"(F.n0.x), [x1] "v"(F.n0.y), [x2] "v"(F.n0.z), [x3] "v"(F.n0.w)
-                 : "vcc");
-    }
-    return;
-#elif NP_A_ONEREC
-    asm volatile("s_mov_b64 %[sv], exec\n\t"
-                 "s_mov_b64 exec, %[m0]\n\t"
-                 "v_mov_b32 %[a0], %[x0]\n\tv_mov_b32 %[a1], %[x1]\n\tv_mov_b32 %[a2], %[x2]\n\tv_mov_b32 %[a3], %[x3]\n\t"
-                 "v_add_u32 %[k0], 0x200, %[k0]\n\t"
-                 "v_add_u32 %[nk], 0x400, %[nk]\n\t"
-                 "s_mov_b64 exec, %[m1]\n\t"
-                 "v_mov_b32 %[b0], %[x0]\n\tv_mov_b32 %[b1], %[x1]\n\tv_mov_b32 %[b2], %[x2]\n\tv_mov_b32 %[b3], %[x3]\n\t"
-                 "v_add_u32 %[k1], 0x200, %[k1]\n\t"
-                 "v_add_u32 %[nk], 0x400, %[nk]\n\t"
-                 "s_mov_b64 exec, %[sv]"
-                 : [sv] "=&s"(save), [a0] "+v"(F.g0m), [a1] "+v"(F.g0s), [a2] "+v"(F.g0c), [a3] "+v"(F.g0r), [k0] "+v"(F.kb0),
-                   [b0] "+v"(F.g1m), [b1] "+v"(F.g1s), [b2] "+v"(F.g1c), [b3] "+v"(F.g1r), [k1] "+v"(F.kb1), [nk] "+v"(F.nko)
-                 : [m0] "s"(m0), [m1] "s"(m1), [x0] "v"(F.n0.x), [x1] "v"(F.n0.y), [x2] "v"(F.n0.z), [x3] "v"(F.n0.w));
-    return;
-#else
-    asm volatile("s_mov_b64 %[sv], exec\n\t"
-                 "s_mov_b64 exec, %[m0]\n\t"
-                 "v_mov_b32 %[a0], %[x0]\n\tv_mov_b32 %[a1], %[x1]\n\tv_mov_b32 %[a2], %[x2]\n\tv_mov_b32 %[a3], %[x3]\n\t"
-                 "v_add_u32 %[k0], 0x200, %[k0]\n\t"
-                 "s_mov_b64 exec, %[m1]\n\t"
-                 "v_mov_b32 %[b0], %[y0]\n\tv_mov_b32 %[b1], %[y1]\n\tv_mov_b32 %[b2], %[y2]\n\tv_mov_b32 %[b3], %[y3]\n\t"
-                 "v_add_u32 %[k1], 0x200, %[k1]\n\t"
-                 "s_mov_b64 exec, %[sv]"
-                 : [sv] "=&s"(save), [a0] "+v"(F.g0m), [a1] "+v"(F.g0s), [a2] "+v"(F.g0c), [a3] "+v"(F.g0r), [k0] "+v"(F.kb0),
-                   [b0] "+v"(F.g1m), [b1] "+v"(F.g1s), [b2] "+v"(F.g1c), [b3] "+v"(F.g1r), [k1] "+v"(F.kb1)
-                 : [m0] "s"(m0), [m1] "s"(m1), [x0] "v"(F.n0.x), [x1] "v"(F.n0.y), [x2] "v"(F.n0.z), [x3] "v"(F.n0.w),
-                   [y0] "v"(F.n1.x), [y1] "v"(F.n1.y), [y2] "v"(F.n1.z), [y3] "v"(F.n1.w));
-#endif
+                 : [sv] "=&s"(save), [t0] "=&v"(t0), [t1] "=&v"(t1), [e0] "+v"(F.eo0), [e1] "+v"(F.eo1), [g0] "+v"(F.g0), [g1] "+v"(F.g1)
+                 : [grp] "s"(grp), [l4] "v"(R.lane4), [base] "s"(base), [rs] "s"(R.kpd)
+                 : "vcc", "memory");
 }
 
 // One band.  (x0, x1): event means of this band's two cells on entry (loaded during the previous band), of the next
@@ -276,114 +187,92 @@ __device__ __forceinline__ void retarget(fill_t& F, uint64_t m0, uint64_t m1, co
 // FAST: the middle of the read -- every cell of the window [llk, llk+99] exists (0 <= llk, llk+99 < K-1, and the events
 // of the window's first and last k-mer are inside [0, E)), so a slot is valid iff it is inside the window, which only
 // changes on a right move: the lane masks F.vm0/F.vm1 replace the per-band geometry.
-// POS: b & 7 when the caller knows it (the FAST blocks), else -1.
+// POS: 0 / 1 = first / second band of the FAST loop's pair (b - POS is even; the event offsets advance once per pair and the
+// band's share is the load's immediate), -1 = stand-alone.
 template <bool TRIM, bool END, bool FAST, int POS = -1>
 __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int b, float& x0, float& x1)
 {
     const int lane = R.lane, E = R.E, K = R.K;
     const int llk = F.llk;
-    // left sources: band b-1 rotated by one slot
-    const float r0 = wave_ror1_all(F.p0), r1 = wave_ror1_all(F.p1);
-#if NP_ABL & 32
-    const float l0 = r0, l1 = r1;
-#else
-    const float l0 = lane == 0 ? r1 : r0;
-    const float l1 = lane == 0 ? r0 : r1;
-#endif
+    // left sources: an odd slot's is the lane's own even slot, an even slot's the previous lane's odd slot
+    const float l0 = wave_ror1_all(F.p1);
 
     // A slot holds a cell of this band iff its k-mer is inside the window and its event e = b-2-k exists, i.e. iff
-    // e is in [max(0, b-2-khi), min(E-1, b-2-klo)]: one unsigned range test on 4*(e+1), the byte offset of the NEXT
-    // band's event mean, which the prefetch needs anyway.
+    // e is in [max(0, b-2-khi), min(E-1, b-2-klo)]: one unsigned range test on eo = 4 (e + 1)
     const int klo = llk > 0 ? llk : 0;
     const int khi = (llk + NP_ALN_BANDWIDTH - 1) < (K - 1) ? (llk + NP_ALN_BANDWIDTH - 1) : (K - 1);
-    int off0 = 0, off1 = 0;
-    if (POS < 0) { off0 = 4 * (b - 1) - F.kb0; off1 = 4 * (b - 1) - F.kb1; }
+    const int eo1_in = F.eo1;
     bool v0 = false, v1 = false;
     if (!FAST) {
         const int elo = (b - 2 - khi) > 0 ? (b - 2 - khi) : 0;
         const int ehi = (b - 2 - klo) < (E - 1) ? (b - 2 - klo) : (E - 1);
         const int cnt = ehi - elo + 1 > 0 ? ehi - elo + 1 : 0;
-        const int tb = pin_s(4 * (b - 1) - 4 * (elo + 1));       // one scalar, so the test is one subtract + one compare
-        v0 = (uint32_t)(tb - F.kb0) < (uint32_t)(4 * cnt);
-        v1 = (uint32_t)(tb - F.kb1) < (uint32_t)(4 * cnt);
+        const int tb = pin_s(4 * (elo + 1));
+        v0 = (uint32_t)(F.eo0 - tb) < (uint32_t)(4 * cnt);
+        v1 = (uint32_t)(F.eo1 - tb) < (uint32_t)(4 * cnt);
     }
 
     // emissions of both cells: np_emission / np_div_exact, operation for operation (v_pk_*_f32 would halve the
     // instruction count but not the issue cycles -- tools/valu_rates.hip -- and forces the parameters into register pairs)
-#if NP_ABL & 16
-    const float emx = x0 * F.g0c, emy = x1 * F.g1c;
-#else
-    const float emx = np_emission_nd(x0, F.g0m, F.g0s, F.g0c, F.g0r);
-    const float emy = np_emission_nd(x1, F.g1m, F.g1s, F.g1c, F.g1r);
-#endif
+    const float emx = np_emission_nd(x0, F.g0.x, F.g0.y, F.g0.z, F.g0.w);
+    const float emy = np_emission_nd(x1, F.g1.x, F.g1.y, F.g1.z, F.g1.w);
     // the next band's event means (same k-mer, next event) go into the registers the emissions have just released: the
     // loop-carried value is the load's own destination, so nothing is copied (a copy would have to wait for the load)
-#if NP_ABL & 8
-    x0 = __builtin_bit_cast(float, off0 & 0x3f800000); x1 = __builtin_bit_cast(float, off1 & 0x3f800000);
-#else
     if (POS >= 0) {
-        // block-relative: the register part is the block's first offset (>= 4 for every in-window slot of a FAST band; a
-        // slot outside the window may see its sum misjudged by the range check -- it only feeds masked cells), the band's
-        // share is the instruction's immediate
-        x0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(R.ev, F.kb0 + 4 * POS, 0, 0));
-        x1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(R.ev, F.kb1 + 4 * POS, 0, 0));
+        // (the register part is >= 4 for every in-window slot of a FAST band; a slot outside the window may see its sum
+        //  misjudged by the range check -- it only feeds masked cells)
+        x0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(R.ev, F.eo0 + 4 * POS, 0, 0));
+        x1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(R.ev, F.eo1 + 4 * POS, 0, 0));
     } else {
-        x0 = buf_f32(R.ev, off0);
-        x1 = buf_f32(R.ev, off1);
+        x0 = buf_f32(R.ev, F.eo0); x1 = buf_f32(R.ev, F.eo1);
+        F.eo0 += 4; F.eo1 += 4;
     }
-#endif
 
     // DP cells (raw_loader.cpp:240-289), computed unconditionally and masked: fp32 cell + fp64 constant + fp32 emission
-    // in fp64, rounded to fp32; max, then FROM_U / FROM_L override on equality in that order (later candidate wins)
-#if NP_ABL & 2
-    const float sd0 = (float)F.d0 + (float)R.lp_step + emx, sd1 = (float)F.d1 + (float)R.lp_step + emy;
-    const float su0 = F.p0 + (float)R.lp_stay + emx, su1 = F.p1 + (float)R.lp_stay + emy;
-    const float sl0 = l0 + (float)R.lp_skip, sl1 = l1 + (float)R.lp_skip;
-    const double L0 = l0, L1 = l1;
-#else
+    // in fp64, rounded to fp32; max, then FROM_U / FROM_L override on equality in that order (later candidate wins).
+    // (double)p0 is `up` of the even slot AND `left` of the odd one; the two `left` doubles are the next band's diagonals.
     const double em0 = (double)emx, em1 = (double)emy;
-    const double L0 = (double)l0, L1 = (double)l1;           // `left` now, `diagonal` of the next band
-    const float sd0 = (float)((double)F.d0 + R.lp_step + em0), sd1 = (float)((double)F.d1 + R.lp_step + em1);
-    const float su0 = (float)((double)F.p0 + R.lp_stay + em0), su1 = (float)((double)F.p1 + R.lp_stay + em1);
-    const float sl0 = (float)(L0 + R.lp_skip), sl1 = (float)(L1 + R.lp_skip);
-#endif
-#if NP_PROBE_SALU || NP_PROBE_VALU
-    if (FAST) {
-        int ps = b, pv = lane;
-#pragma unroll
-        for (int i = 0; i < NP_PROBE_SALU; ++i) asm volatile("s_add_u32 %0, %0, 1" : "+s"(ps) : : "scc");
-#pragma unroll
-        for (int i = 0; i < NP_PROBE_VALU; ++i) asm volatile("v_add_u32 %0, 1, %0" : "+v"(pv));
-        asm volatile("" : : "s"(ps), "v"(pv));
-    }
-#endif
+    const double P0 = (double)F.p0, P1 = (double)F.p1, L0 = (double)l0;
+    const float sd0 = (float)(F.d0 + R.lp_step + em0), sd1 = (float)(F.d1 + R.lp_step + em1);
+    const float su0 = (float)(P0 + R.lp_stay + em0), su1 = (float)(P1 + R.lp_stay + em1);
+    const float sl0 = (float)(L0 + R.lp_skip), sl1 = (float)(P0 + R.lp_skip);
     const float m0 = __builtin_fmaxf(__builtin_fmaxf(sd0, su0), sl0);
     const float m1 = __builtin_fmaxf(__builtin_fmaxf(sd1, su1), sl1);
-    // the code of a slot outside the band is never read back: the walk only visits finite cells, whose best
-    // predecessor is finite, hence inside its band
-    uint32_t f0, f1;
-#if NP_A_TRACEASM
+
+    // FAST: the band ends of Suzuki's rule are read out (v_readlane -> scalar compares) BEFORE the trace bits are packed,
+    // so that the scalar chain of the move decision runs while the vector unit packs.  (The ends are inside the window:
+    // the unmasked maxima are the cells.)
+    int xs = 0, ys = 0;
     if (FAST) {
-        // f0 | f1 << 2 in one go.  A vector compare's mask cannot be used by the very next vector instructions (two wait states
-        // on gfx950; hipcc funnels all four compares through VCC and pads with s_nop): here the four compares write four
-        // scalar pairs, and by the time a select reads its mask three other instructions have issued.
-        uint64_t qa, qb, qc, qd;
-        uint32_t t1;
-        asm("v_cmp_eq_f32_e64 %[a], %[m0], %[u0]\n\t"
-            "v_cmp_neq_f32_e64 %[b], %[m0], %[l0]\n\t"
-            "v_cmp_eq_f32_e64 %[c], %[m1], %[u1]\n\t"
-            "v_cmp_neq_f32_e64 %[d], %[m1], %[l1]\n\t"
-            "v_cndmask_b32_e64 %[t0], 0, 1, %[a]\n\t"
-            "v_cndmask_b32_e64 %[t1], 0, 4, %[c]\n\t"
-            "v_cndmask_b32_e64 %[t0], 2, %[t0], %[b]\n\t"
-            "v_cndmask_b32_e64 %[t1], 8, %[t1], %[d]\n\t"
-            "v_or_b32_e32 %[t0], %[t0], %[t1]"
-            : [t0] "=&v"(f0), [t1] "=&v"(t1), [a] "=&s"(qa), [b] "=&s"(qb), [c] "=&s"(qc), [d] "=&s"(qd)
+        xs = __builtin_amdgcn_readlane(__builtin_bit_cast(int, m0), F.sel0);
+        ys = __builtin_amdgcn_readlane(__builtin_bit_cast(int, m1), F.sel1);
+        asm volatile("" : "+s"(xs), "+s"(ys));
+    }
+
+    // Trace: per slot bit 1 = "the cell is its left candidate", bit 0 = "the cell is its up candidate" (left wins: FROM_L = 2,
+    // FROM_U = 1, FROM_D = 0 in the reference's numbering, and the pattern 3 reads as FROM_L); odd slot in bits 3..2, even
+    // slot in bits 1..0 of the band's nibble.  The bits of a slot outside the band are never read back: the walk only
+    // visits finite cells, whose best predecessor is finite, hence inside its band.
+    if (FAST) {
+        // A vector compare's mask cannot be used by the very next vector instructions (hipcc funnels compares through VCC and
+        // pads with s_nop): the four compares write four scalar pairs, and by the time an add-with-carry shifts a mask into the
+        // accumulator three other instructions have issued.
+        uint64_t qa, qb, qc, qd, qj;
+#if !(NP_ABL & 1)
+        asm("v_cmp_eq_f32_e64 %[a], %[m1], %[l1]\n\t"
+            "v_cmp_eq_f32_e64 %[b], %[m1], %[u1]\n\t"
+            "v_cmp_eq_f32_e64 %[c], %[m0], %[l0]\n\t"
+            "v_cmp_eq_f32_e64 %[d], %[m0], %[u0]\n\t"
+            "v_addc_co_u32_e64 %[t], %[j], %[t], %[t], %[a]\n\t"
+            "v_addc_co_u32_e64 %[t], %[j], %[t], %[t], %[b]\n\t"
+            "v_addc_co_u32_e64 %[t], %[j], %[t], %[t], %[c]\n\t"
+            "v_addc_co_u32_e64 %[t], %[j], %[t], %[t], %[d]"
+            : [t] "+v"(F.tacc), [a] "=&s"(qa), [b] "=&s"(qb), [c] "=&s"(qc), [d] "=&s"(qd), [j] "=&s"(qj)
             : [m0] "v"(m0), [u0] "v"(su0), [l0] "v"(sl0), [m1] "v"(m1), [u1] "v"(su1), [l1] "v"(sl1));
-        f1 = 0u;
-    } else
 #endif
-    {
+    }
+    uint32_t f0 = 0u, f1 = 0u;
+    if (!FAST) {
         f0 = (m0 == sl0) ? 2u : ((m0 == su0) ? 1u : 0u);
         f1 = (m1 == sl1) ? 2u : ((m1 == su1) ? 1u : 0u);
     }
@@ -393,36 +282,23 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
 
     if (TRIM && llk <= -1) {
         // the window still contains k-mer -1: start cell of band 0 (:152-157) and the trim column (:216-225).
-        // k = -1 lives in ring slot 127 (lane 63, second register); its event is b - 1.
+        // k = -1 lives in ring slot 127 (lane 63, odd slot); its event is b - 1.
         const int et = b - 1;
-        if (lane == 63 && F.kb1 == -4) {
+        if (lane == 63 && eo1_in == 4 * b) {
             if (et == -1) { c1 = 0.0f; f1 = 0u; }
             else if (et >= 0 && et < E) { c1 = (float)(R.lp_trim * (double)(et + 1)); f1 = 1u; }
             else { c1 = NP_NEG_INF; f1 = 0u; }
         }
     }
 
-    // packed trace: every lane keeps the 2-bit codes of its two slots, 4 bits per band, and stores one dword per
-    // 8 bands (64 lanes x 4 B = 256 B coalesced = 32 B/band).  The back-track reads the word back into the SAME lane.
-    // (the word shifts down one nibble per band, so after 8 bands band b%8 == 0 sits in bits 0..3: no variable shift)
-    auto encode_trace = [&]() {
+    // packed trace: every lane keeps the bits of its two slots, 4 bits per band, and stores one dword per 8 bands
+    // (64 lanes x 4 B = 256 B coalesced = 32 B/band).  The back-track reads the word back into the SAME lane.
+    // (the word shifts up one nibble per band, so after 8 bands band b%8 == 0 sits in bits 31..28: no variable shift)
 #if !(NP_ABL & 1)
-        F.tacc = (F.tacc >> 4) | ((f0 | (f1 << 2)) << 28);
-        if (POS == 7 || (POS < 0 && (b & 7) == 7)) R.trace32[(size_t)(b >> 3) * 64 + lane] = F.tacc;
+    if (!FAST) F.tacc = (F.tacc << 4) | (f1 << 2) | f0;
+    if (POS == 1 ? (b & 7) == 7 : (POS < 0 && (b & 7) == 7))
+        __builtin_amdgcn_raw_buffer_store_b32((int)F.tacc, R.tr, 4 * lane, (b >> 3) * 256, 0);
 #endif
-    };
-#if NP_A_EARLYSUZ
-    // FAST: the band ends of Suzuki's rule are read out (v_readlane -> scalar compares) BEFORE the trace codes are packed,
-    // so that the scalar chain of the move decision runs while the vector unit packs -- in source order the wave would sit
-    // through the v_readlane -> s_cselect -> s_cmp latency with nothing else to issue
-    int ll_early = 0, ur_early = 0;
-    if (FAST) {
-        ll_early = ring_read_bits(c0, c1, llk & (NP_RING - 1));
-        ur_early = ring_read_bits(c0, c1, (llk + NP_ALN_BANDWIDTH - 1) & (NP_RING - 1));
-        asm volatile("" : "+s"(ll_early), "+s"(ur_early));
-    }
-#endif
-    encode_trace();
 
     if (END && khi == K - 1 && llk <= K - 1) {
         // end search: cell (e, K-1) while it is inside the window, any e in [0,E) (:309-324).  Wave-uniform: the cell's ring
@@ -435,76 +311,56 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
             if (sc > F.best) { F.best = sc; F.best_e = e; }
         }
     }
-#if NP_A_DDBL
-    F.d0 = L0; F.d1 = L1;
-#else
-    F.d0 = l0; F.d1 = l1;
-#endif
+    F.d0 = L0; F.d1 = P0;
     F.p0 = c0; F.p1 = c1;
 
-    // The event means requested above must have landed before the parameter request below is issued: loads return in
-    // order, and a wait placed after a conditional request would have to assume it was not made and drain everything.
-    // Here they have had the whole band to arrive; the parameter records then have the whole next band.
-    // (the band's results are operands too, which pins the statement -- and so the wait -- behind the band's arithmetic)
-    asm volatile("" : "+v"(x0), "+v"(x1), "+v"(c0), "+v"(c1));
-    F.p0 = c0; F.p1 = c1;
     if (FAST || b >= 1) {
-        // Suzuki's rule for band b+1, on this band (:179-195).
-#if NP_A_EARLYSUZ
-        const int ll = FAST ? ll_early : pin_s(ring_read_bits(c0, c1, llk & (NP_RING - 1)));
-        const int ur = FAST ? ur_early : pin_s(ring_read_bits(c0, c1, (llk + NP_ALN_BANDWIDTH - 1) & (NP_RING - 1)));
-#else
-        const int ll = pin_s(ring_read_bits(c0, c1, llk & (NP_RING - 1)));
-        const int ur = pin_s(ring_read_bits(c0, c1, (llk + NP_ALN_BANDWIDTH - 1) & (NP_RING - 1)));
-#endif
-        // both -inf (the AND of two non-NaN patterns is -inf's only then): alternate; else right iff ll < ur, where a
-        // single -inf compares as the reference's is_offset_valid ? value : -INFINITY does
-#if NP_ABL & 4
-        const bool right = (((b + 1) * 13) >> 5) != ((b * 13) >> 5);       // a fixed pattern with the same share of right moves
-#else
+        // Suzuki's rule for band b+1, on this band (:179-195): both ends -inf (the AND of two non-NaN patterns is -inf's only
+        // then): alternate; else right iff ll < ur, where a single -inf compares as the reference's
+        // is_offset_valid ? value : -INFINITY does
         bool right;
-        if (FAST && NP_A_INTCMP) {
+        if (FAST) {
             // FAST runs only for reads whose cells are all <= 0 (R.nonpos): for such floats (+0, negative, -inf) x < y is
             // bits(x) > bits(y) as unsigned integers -- scalar compares instead of a vector compare on two scalars
             // (spelled out for the scalar unit: hipcc lowers a select between wave-uniform conditions to vector code)
-            int r, t;
-            const int par = (b & 1) ^ 1;                                                          // both outside: alternate
-            asm("s_and_b32 %[t], %[ll], %[ur]\n\t"
-                "s_cmp_gt_u32 %[ll], %[ur]\n\t"
-                "s_cselect_b32 %[r], 1, 0\n\t"
-                "s_cmp_eq_u32 %[t], 0xff800000\n\t"
-                "s_cselect_b32 %[r], %[par], %[r]"
-                : [r] "=&s"(r), [t] "=&s"(t) : [ll] "s"(ll), [ur] "s"(ur), [par] "s"(par) : "scc");
+            int r, t, ll, ur;
+#define NP_SUZUKI(PAR_CONSTRAINT, PAR)                                                                                           \
+            asm("s_cmp_lg_u32 %[sw], 0\n\t"                                                                                       \
+                "s_cselect_b32 %[ll], %[y], %[x]\n\t"                                                                             \
+                "s_cselect_b32 %[ur], %[x], %[y]\n\t"                                                                             \
+                "s_and_b32 %[t], %[ll], %[ur]\n\t"                                                                                \
+                "s_cmp_gt_u32 %[ll], %[ur]\n\t"                                                                                   \
+                "s_cselect_b32 %[r], 1, 0\n\t"                                                                                    \
+                "s_cmp_eq_u32 %[t], 0xff800000\n\t"                                                                               \
+                "s_cselect_b32 %[r], %[par], %[r]"                                                                                \
+                : [r] "=&s"(r), [t] "=&s"(t), [ll] "=&s"(ll), [ur] "=&s"(ur)                                                      \
+                : [x] "s"(xs), [y] "s"(ys), [sw] "s"(F.swp), [par] PAR_CONSTRAINT(PAR) : "scc")
+            // both ends outside: alternate, starting with a right move on even bands (the band's parity is known in the pair loop)
+            if (POS == 0) NP_SUZUKI("n", 1);
+            else if (POS == 1) NP_SUZUKI("n", 0);
+            else { const int par = (b & 1) ^ 1; NP_SUZUKI("s", par); }
+#undef NP_SUZUKI
             right = r != 0;
         } else {
+            const int ll = pin_s(ring_read_bits(c0, c1, llk & (NP_RING - 1)));
+            const int ur = pin_s(ring_read_bits(c0, c1, (llk + NP_ALN_BANDWIDTH - 1) & (NP_RING - 1)));
             const bool both_ob = (ll & ur) == (int)0xff800000;
             right = both_ob ? ((b & 1) == 0) : (__builtin_bit_cast(float, ll) < __builtin_bit_cast(float, ur));
         }
-#endif
         if (right) {
             F.llk = llk + 1;
-            // Exactly one ring slot falls out per right move: slot (llk - 15) mod 128, one lane of one of the two slot
-            // registers.  It takes its next k-mer (k+128), whose record was requested the last time the slot moved
-            // (128 right-moves ago), and requests the one after that.  Every lane re-requests its `next` record (an L1
-            // hit for all but the re-targeted slot): no load sits inside a divergent branch, where hipcc would wait for
-            // it on the spot.
-            const int out = (F.llk - NP_MARGIN - 1) & (NP_RING - 1);
-#if NP_A_ONEREC && NP_A_CMPX
-            retarget<(POS >= 0)>(F, (uint64_t)(uint32_t)out, 0ull, lane);
-#else
-            const uint64_t bit = 1ull << (out & 63);
-            retarget<false>(F, (out & 64) ? 0ull : bit, (out & 64) ? bit : 0ull, lane);
-#endif
-            __builtin_amdgcn_sched_barrier(0);      // request after the moves have read the old records: same registers
-#if NP_ABL & 64
-            F.n0.x += 1.0f;
-#elif NP_A_ONEREC
-            F.n0 = buf_f32x4(R.kp, F.nko);
-#else
-            F.n0 = buf_f32x4(R.kp, F.kb0 * 4 + 16 * NP_RING);
-            F.n1 = buf_f32x4(R.kp, F.kb1 * 4 + 16 * NP_RING);
-#endif
-            if (FAST) { F.vm0 = window_mask(lane, 0, F.llk); F.vm1 = window_mask(lane, 1, F.llk); }
+            if (FAST) {
+                // the window moves up by one slot: the mask of the register that held its first slot rotates by one lane (llk even:
+                // the even register, whose mask then equals the odd register's rotated; llk odd: the odd register catches up);
+                // the band ends swap registers
+                const uint64_t rot = (F.vm0 << 1) | (F.vm0 >> 63);
+                const bool odd = (llk & 1) != 0;
+                F.vm1 = odd ? F.vm0 : F.vm1;
+                F.vm0 = odd ? F.vm0 : rot;
+                const int s0 = F.sel0;
+                F.sel0 = F.sel1 + 1; F.sel1 = s0; F.swp ^= 1;
+            }
+            if ((F.llk & 7) == 0) retarget(F, R, POS >= 0 ? 16 * (b - POS - 1) : 16 * b);
         }
     }
 }
@@ -560,9 +416,12 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
 
             // ---------------- fill ----------------
             read_t R;
-            R.E = E; R.K = K; R.lane = lane; R.end_slot = (K - 1) & (NP_RING - 1); R.nonpos = nonpos;
-            R.ev = make_rsrc(ev, (uint32_t)E * 4u); R.kp = make_rsrc(kp, (uint32_t)K * 16u); R.trace32 = 
- uniform_ptr((uint32_t*)trace);
+            R.E = E; R.K = K; R.lane = lane; R.lane4 = lane >> 2; R.end_slot = (K - 1) & (NP_RING - 1); R.nonpos = nonpos;
+            R.ev = make_rsrc(ev, (uint32_t)E * 4u); R.kp = make_rsrc(kp, (uint32_t)K * 16u); R.tr = make_rsrc(trace, (uint32_t)(a.trace_stride * 8u < 0xffffff00ull ? a.trace_stride * 8u : 0xffffff00ull));
+            {
+                const uint64_t u = (uint64_t)uniform_ptr(kp);
+                R.kpd = i4{(int)(uint32_t)u, (int)(uint32_t)(u >> 32), (int)((uint32_t)K * 16u), 0x00020000};      // == make_rsrc(kp, 16 K)
+            }
 
             // wave-uniform constants in scalar registers (a VALU fp64 add takes one SGPR-pair operand): 8 VGPRs saved
             R.lp_skip = uniform_f64(rd->lp_skip); R.lp_stay = uniform_f64(rd->lp_stay);
@@ -570,19 +429,14 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
             fill_t F;
             F.llk = -1 - NP_ALN_BANDWIDTH / 2;              // band_lower_left[0].kmer_idx, raw_loader.cpp:150-151
             {
-                const int k0 = ring_kmer(lane, F.llk), k1 = ring_kmer(lane + 64, F.llk);
-                F.kb0 = 4 * k0; F.kb1 = 4 * k1;
+                const int k0 = ring_kmer(2 * lane, F.llk), k1 = ring_kmer(2 * lane + 1, F.llk);
+                F.eo0 = 4 * (-1 - k0); F.eo1 = 4 * (-1 - k1);                    // band 0
                 const float4 g0 = buf_f32x4(R.kp, 16 * k0), g1 = buf_f32x4(R.kp, 16 * k1);
-                F.g0m = g0.x; F.g0s = g0.y; F.g0c = g0.z; F.g0r = g0.w; F.g1m = g1.x; F.g1s = g1.y; F.g1c = g1.z; F.g1r = g1.w;
-#if NP_A_ONEREC
-                F.nko = 16 * ((k0 < k1 ? k0 : k1) + NP_RING);        // the slot with the smaller k-mer re-targets first
-                F.n0 = buf_f32x4(R.kp, F.nko);
-#else
-                F.n0 = buf_f32x4(R.kp, 16 * (k0 + NP_RING)); F.n1 = buf_f32x4(R.kp, 16 * (k1 + NP_RING));
-#endif
+                F.g0 = f4{g0.x, g0.y, g0.z, g0.w}; F.g1 = f4{g1.x, g1.y, g1.z, g1.w};
             }
-            F.p0 = F.p1 = NP_NEG_INF; F.d0 = F.d1 = NP_NEG_INF;
+            F.p0 = F.p1 = NP_NEG_INF; F.d0 = F.d1 = (double)NP_NEG_INF;
             F.best = NP_NEG_INF; F.best_e = 0; F.tacc = 0u;
+            F.vm0 = F.vm1 = 0ull; F.sel0 = F.sel1 = F.swp = 0;
             float x0 = 0.0f, x1 = 0.0f;                     // event means of the current band's two cells
             int b = 0;
             // Three phases, so that the long middle of the read pays for no band geometry, trim column or end search.
@@ -593,33 +447,24 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
             // and while min(K-2 - (llk+99), E-1 - u) = s > 0 the next s bands are FAST whatever the moves are.
             for (; b < n_bands && !(F.llk >= 0 && b - 2 - F.llk >= NP_ALN_BANDWIDTH - 1); ++b)
                 band_step<true, true, false>(F, R, b, x0, x1);
-            F.vm0 = window_mask(lane, 0, F.llk); F.vm1 = window_mask(lane, 1, F.llk);
-            for (; !NP_A_INTCMP || R.nonpos;) {
+            window_state(F);
+            for (; R.nonpos;) {
                 const int ks = (K - 2) - (F.llk + NP_ALN_BANDWIDTH - 1), es = (E - 1) - (b - 2 - F.llk);
                 int stop = b + (ks < es ? ks : es);
                 stop = stop < n_bands ? stop : n_bands;
                 if (stop <= b) break;
-#if NP_A_UNROLL8
-                // blocks of 8 bands that coincide with the trace groups
-                for (; b < stop && (b & 7) != 0; ++b) band_step<false, false, true>(F, R, b, x0, x1);
-                // (inside the blocks kb0 / kb1 hold the block-relative event offsets: converted here and back below)
-                F.kb0 = 4 * (b - 1) - F.kb0; F.kb1 = 4 * (b - 1) - F.kb1;
-                for (; b + 7 < stop; b += 8) {
+                // two bands per iteration, the first one even: the doubles made of `left` become the next band's diagonal without
+                // a register copy, the event offsets advance once, the trace store and the parity of Suzuki's tie rule are
+                // compile-time properties of the position
+                if (b & 1) { band_step<false, false, true>(F, R, b, x0, x1); ++b; }
+                for (; b + 1 < stop; b += 2) {
                     band_step<false, false, true, 0>(F, R, b, x0, x1); band_step<false, false, true, 1>(F, R, b + 1, x0, x1);
-                    band_step<false, false, true, 2>(F, R, b + 2, x0, x1); band_step<false, false, true, 3>(F, R, b + 3, x0, x1);
-                    band_step<false, false, true, 4>(F, R, b + 4, x0, x1); band_step<false, false, true, 5>(F, R, b + 5, x0, x1);
-                    band_step<false, false, true, 6>(F, R, b + 6, x0, x1); band_step<false, false, true, 7>(F, R, b + 7, x0, x1);
-                    F.kb0 += 32; F.kb1 += 32;
+                    F.eo0 += 8; F.eo1 += 8;
                 }
-                F.kb0 = 4 * (b - 1) - F.kb0; F.kb1 = 4 * (b - 1) - F.kb1;
-#elif NP_A_DDBL
-                // two bands per iteration: the doubles made of `left` become the next band's diagonal without a register copy
-                for (; b + 1 < stop; b += 2) { band_step<false, false, true>(F, R, b, x0, x1); band_step<false, false, true>(F, R, b + 1, x0, x1); }
-#endif
                 for (; b < stop; ++b) band_step<false, false, true>(F, R, b, x0, x1);
             }
             for (; b < n_bands; ++b) band_step<true, true, false>(F, R, b, x0, x1);
-            if ((n_bands & 7) != 0) R.trace32[(size_t)((n_bands - 1) >> 3) * 64 + lane] = F.tacc >> (4 * (8 - (n_bands & 7)));   // last, partial group
+            if ((n_bands & 7) != 0) __builtin_amdgcn_raw_buffer_store_b32((int)(F.tacc << (4 * (8 - (n_bands & 7)))), R.tr, 4 * lane, ((n_bands - 1) >> 3) * 256, 0);   // last, partial group
 
             // ---------------- backtrack (:326-361) + QC sums (:338-341) ----------------
             const float best_u = F.best;
@@ -633,8 +478,8 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
             if (best_u != NP_NEG_INF && !(NP_ABL & 128)) {
                 // Scalar walk.  The kernel is instruction-issue bound (~2.3 cycles per wave-instruction of any kind, measured
                 // with tools/align_variants.sh probes), and a walk of ~0.63 steps per band is a fifth of its instructions, so
-                // the step is written out by hand: 19 instructions.
-                //   * A step reads the 2-bit code of its cell out of the lane that owns the k-mer's ring slot (v_readlane) and
+                // the step is written out by hand: 20 instructions.
+                //   * A step reads the 2 bits of its cell out of the lane that owns the k-mer's ring slot (v_readlane) and
                 //     parks it in lane j of a vector register (v_writelane): nothing else is recorded.  When 64 codes have
                 //     gathered, each lane rebuilds ITS pair from the chunk's start position and the population counts, below
                 //     its lane id, of the "k drops" / "e drops" ballots (two v_mbcnt pairs for 64 pairs); the longest run of
@@ -658,8 +503,8 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
                 // up to 64 pairs: stored at descending addresses (their emissions are added up after the walk)
                 auto flush = [&]() {
                     const bool valid = lane < j;
-                    const uint64_t mk = __builtin_amdgcn_ballot_w64(valid && vfrom != 1);          // FROM_D, FROM_L: k drops
-                    const uint64_t me = __builtin_amdgcn_ballot_w64(valid && vfrom != 2);          // FROM_D, FROM_U: e drops
+                    const uint64_t mk = __builtin_amdgcn_ballot_w64(valid && vfrom != 1);          // FROM_D, FROM_L (2, 3): k drops
+                    const uint64_t me = __builtin_amdgcn_ballot_w64(valid && vfrom < 2);           // FROM_D, FROM_U: e drops
                     if (valid) {
                         np_pair p;
                         p.ref_pos = k0 - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
@@ -684,9 +529,9 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
 #pragma unroll
                     for (int pos = 0; pos < NP_BT_DEPTH; ++pos) {
                         asm volatile("s_waitcnt vmcnt(%[n])" : [t] "+v"(tq[pos]) : [n] "n"(NP_BT_DEPTH - 1) : "memory");
-                        // steps inside trace group cg: band - 8 cg = (k + e) - lb is the nibble index, negative once the walk
-                        // has left the group
-                        const int lb = 8 * cg - 2;
+                        // steps inside trace group cg: 8 cg + 7 - band = lb7 - (k + e) is the nibble index counted from the top of
+                        // the word (band 8 cg in bits 31..28), above 7 once the walk has left the group
+                        const int lb7 = 8 * cg + 5;
                         for (;;) {
                         int t_, nib_, c_, w_;
                         // (the step counter j lives in M0 inside the loop: v_writelane takes its lane select from M0, because a
@@ -694,20 +539,21 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
                         asm volatile("s_mov_b32 m0, %[j]\n\t"
                                      "1:\n\t"
                                      "s_add_i32 %[t], %[k], %[e]\n\t"
-                                     "s_sub_i32 %[nib], %[t], %[lb]\n\t"
-                                     "s_cmp_lt_i32 %[nib], 0\n\t"
+                                     "s_sub_i32 %[nib], %[lb7], %[t]\n\t"
+                                     "s_cmp_gt_i32 %[nib], 7\n\t"
                                      "s_cbranch_scc1 2f\n\t"
-                                     "s_bfe_u32 %[c], %[k], 0x10006\n\t"              // second slot register: k bit 6
+                                     "s_and_b32 %[c], %[k], 1\n\t"                   // odd slot: bits 3..2 of the nibble
                                      "s_lshl1_add_u32 %[c], %[c], 0x20000\n\t"        // field width 2 | 2 * bit
                                      "s_lshl2_add_u32 %[c], %[nib], %[c]\n\t"         // + 4 * nibble
-                                     "v_readlane_b32 %[w], %[wreg], %[k]\n\t"        // (the lane select is taken modulo 64)
+                                     "s_lshr_b32 %[t], %[k], 1\n\t"                   // the slot's lane (the lane select is taken modulo 64)
+                                     "v_readlane_b32 %[w], %[wreg], %[t]\n\t"
                                      "s_bfe_u32 %[from], %[w], %[c]\n\t"
                                      "v_writelane_b32 %[vf], %[from], m0\n\t"
                                      "s_add_i32 m0, m0, 1\n\t"
                                      "s_cmp_lg_u32 %[from], 1\n\t"
                                      "s_subb_u32 %[k], %[k], 0\n\t"                   // k -= (from != FROM_U)
-                                     "s_cmp_lg_u32 %[from], 2\n\t"
-                                     "s_subb_u32 %[e], %[e], 0\n\t"                   // e -= (from != FROM_L)
+                                     "s_cmp_lt_u32 %[from], 2\n\t"
+                                     "s_subb_u32 %[e], %[e], 0\n\t"                   // e -= (from != FROM_L: patterns 2 and 3)
                                      "s_cmp_eq_u32 m0, 64\n\t"
                                      "s_cbranch_scc1 2f\n\t"
                                      "s_or_b32 %[t], %[k], %[e]\n\t"
@@ -717,11 +563,11 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
                                      "s_mov_b32 %[j], m0"
                                      : [k] "+s"(curr_k), [e] "+s"(curr_e), [j] "+s"(j), [vf] "+v"(vfrom), [from] "+s"(from),
                                        [t] "=&s"(t_), [nib] "=&s"(nib_), [c] "=&s"(c_), [w] "=&s"(w_)
-                                     : [wreg] "v"(tq[pos]), [lb] "s"(lb)
+                                     : [wreg] "v"(tq[pos]), [lb7] "s"(lb7)
                                      : "scc", "m0");
                         done = (curr_k | curr_e) >> 31;                                 // -1 once either index is negative
                         if (j == 64 || done) flush();
-                        if (done || curr_e + curr_k - lb < 0) break;                    // (else: a chunk boundary inside the group)
+                        if (done || lb7 - (curr_e + curr_k) > 7) break;                    // (else: a chunk boundary inside the group)
                         }
                         if (done) break;
                         NP_BT_LOAD(tq[pos], cg - NP_BT_DEPTH);

@@ -73,6 +73,32 @@ template <int OP> __global__ void k(unsigned long long* out, float* sink, int it
 #define LSHL(n) asm volatile("v_lshl_or_b32 %0, %1, 2, %1" : "=v"(a##n) : "v"(a##n));
 #define MUL64(n) asm volatile("v_mul_f64 %0, %1, %1" : "=v"(d##n) : "v"(d##n));
 #define CVTI(n) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(d##n) : "v"(a##n));
+// ---- round 2: candidates for the interleaved band layout / carry-chain trace packing ----
+#define SUBCO32(n) asm volatile("v_sub_co_u32_e32 %0, vcc, %1, %1" : "=v"(a##n) : "v"(a##n) : "vcc");
+#define SUBCO64(n) asm volatile("v_sub_co_u32_e64 %0, s[10:11], %1, %1" : "=v"(a##n) : "v"(a##n) : "s10", "s11");
+#define ADDC64(n) asm volatile("v_addc_co_u32_e64 %0, s[12:13], %1, %1, s[10:11]" : "=v"(a##n) : "v"(a##n) : "s12", "s13");
+#define TRACE8 asm volatile("v_sub_co_u32_e64 %1, s[10:11], %2, %3\n v_sub_co_u32_e64 %1, s[12:13], %2, %4\n v_sub_co_u32_e64 %1, s[14:15], %3, %4\n v_sub_co_u32_e64 %1, s[16:17], %4, %2\n" \
+                            "v_addc_co_u32_e64 %0, s[18:19], %0, %0, s[10:11]\n v_addc_co_u32_e64 %0, s[18:19], %0, %0, s[12:13]\n v_addc_co_u32_e64 %0, s[18:19], %0, %0, s[14:15]\n v_addc_co_u32_e64 %0, s[18:19], %0, %0, s[16:17]" \
+                            : "+v"(a0), "=&v"(a1) : "v"(a2), "v"(a3), "v"(a4) : "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19");
+#define RDLNS(n) asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(s0) : "v"(a##n), "s"(q##n));
+#define SLSHL64(n) asm volatile("s_lshl_b64 s[10:11], s[10:11], 1" ::: "s10", "s11", "scc");
+#define SOR64(n) asm volatile("s_or_b64 s[10:11], s[10:11], s[12:13]" ::: "s10", "s11", "scc");
+#define CMPX(n) asm volatile("s_mov_b64 s[12:13], exec\n v_cmpx_eq_u32_e32 %0, %1\n s_mov_b64 exec, s[12:13]" : : "s"(q##n), "v"(l##n) : "s12", "s13", "vcc");
+#define MIXSF(n) asm volatile("v_cvt_f64_f32 %0, %2\n v_add_f32 %1, %2, %2" : "=v"(d##n), "=v"(a##n) : "v"(a##n));
+#define ALIGNB(n) asm volatile("v_alignbit_b32 %0, %1, %1, 4" : "=v"(a##n) : "v"(a##n));
+#define ORB(n) asm volatile("v_or_b32 %0, %1, %1" : "=v"(a##n) : "v"(a##n));
+#define MAX64(n) asm volatile("v_max_f64 %0, %1, %1" : "=v"(d##n) : "v"(d##n));
+#define SCSEL64(n) asm volatile("s_cselect_b64 s[10:11], s[10:11], s[12:13]" ::: "s10", "s11");
+#define SBITC(n) asm volatile("s_bitcmp1_b32 %0, 0\n s_cselect_b32 %0, %0, 3" : "+s"(q##n) : : "scc");
+#define MOVS(n) asm volatile("v_mov_b32 %0, %1" : "=v"(a##n) : "s"(q##n));
+#define ADDFS(n) asm volatile("v_add_f32 %0, %1, %2" : "=v"(a##n) : "s"(q##n), "v"(a##n));
+#define SNOP(n) asm volatile("s_nop 0");
+#define SWAIT(n) asm volatile("s_waitcnt vmcnt(0)");
+#define SBR(n) asm volatile("s_cmp_eq_u32 %0, 77\n s_cbranch_scc1 1f\n 1:" : : "s"(q##n) : "scc");
+#define SBRT(n) asm volatile("s_branch 1f\n s_nop 0\n 1:");
+#define SUBCOADD(n) asm volatile("v_sub_co_u32_e32 %0, vcc, %1, %1\n v_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "=&v"(a##n) : "v"(a0) : "vcc");
+#define ADD64S(n) asm volatile("v_add_f64 %0, s[10:11], %1" : "=v"(d##n) : "v"(d##n));
+#define MAX3F(n) asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(a##n) : "v"(a##n), "v"(a0), "v"(a1));
         if (OP == 0) { REP8(CVT64) REP8(CVT64) }
         if (OP == 1) { REP8(CVT32) REP8(CVT32) }
         if (OP == 2) { REP8(ADD64) REP8(ADD64) }
@@ -113,6 +139,28 @@ template <int OP> __global__ void k(unsigned long long* out, float* sink, int it
         if (OP == 51) { REP8(SUBF) REP8(SUBF) }
         if (OP == 52) { REP8(ADDU) REP8(ADDU) }
         if (OP == 53) { REP8(LSHLADD) REP8(LSHLADD) }
+        if (OP == 60) { REP8(SUBCO32) REP8(SUBCO32) }
+        if (OP == 61) { REP8(SUBCO64) REP8(SUBCO64) }
+        if (OP == 62) { REP8(ADDC64) REP8(ADDC64) }
+        if (OP == 63) { TRACE8 TRACE8 }
+        if (OP == 64) { REP8(RDLNS) REP8(RDLNS) }
+        if (OP == 65) { REP8(SLSHL64) REP8(SLSHL64) }
+        if (OP == 66) { REP8(SOR64) REP8(SOR64) }
+        if (OP == 67) { REP8(CMPX) REP8(CMPX) }
+        if (OP == 68) { REP8(MIXSF) }
+        if (OP == 69) { REP8(ALIGNB) REP8(ALIGNB) }
+        if (OP == 70) { REP8(ORB) REP8(ORB) }
+        if (OP == 71) { REP8(MAX64) REP8(MAX64) }
+        if (OP == 73) { REP8(SCSEL64) REP8(SCSEL64) }
+        if (OP == 74) { REP8(SBITC) }
+        if (OP == 75) { REP8(MOVS) REP8(MOVS) }
+        if (OP == 76) { REP8(ADDFS) REP8(ADDFS) }
+        if (OP == 77) { REP8(SNOP) REP8(SNOP) }
+        if (OP == 78) { REP8(SWAIT) REP8(SWAIT) }
+        if (OP == 79) { REP8(SBR) }
+        if (OP == 80) { REP8(SBRT) }
+        if (OP == 81) { REP8(SUBCOADD) }
+        if (OP == 82) { REP8(ADD64S) REP8(ADD64S) }
         if (OP == 17) { REP8(CNDV2) REP8(CNDV2) }
         if (OP == 18) { REP8(SUBU) REP8(SUBU) }
         if (OP == 19) { REP8(MAXF) REP8(MAXF) }
@@ -154,9 +202,10 @@ template <int OP> double run(const char* name, int waves_per_simd)
     return ms;
 }
 
-int main()
+int main(int argc, char**)
 {
     for (int w : {8}) {
+        if (argc > 1) break;          // any argument: only the round-2 table
         run<12>("v_add_f32", w); run<3>("v_fma_f32", w); run<4>("v_pk_fma_f32", w); run<5>("v_pk_mul_f32", w);
         run<0>("v_cvt_f64_f32", w); run<1>("v_cvt_f32_f64", w); run<16>("v_cvt_f64_u32", w); run<2>("v_add_f64", w);
         run<15>("v_mul_f64", w); run<11>("v_fma_f64", w);
@@ -170,6 +219,16 @@ int main()
         run<45>("v_mul_f32 |abs|", w); run<46>("v_lshlrev_b32", w); run<47>("v_and_b32", w); run<48>("ds_read_b32", w); run<49>("v_med3_i32", w);
         run<50>("v_max_i32", w); run<51>("v_sub_f32", w); run<52>("v_add_u32", w); run<53>("v_lshl_add_u32", w);
         run<20>("v_pk_add_f32", w); run<21>("v_mov_b32", w); run<22>("v_fma_f32 3src", w); run<23>("v_max3 3src", w);
+    }
+    // round 2 table (per 16 instructions of the named kind; pairs / sequences are marked)
+    for (int w : {8}) {
+        run<60>("v_sub_co e32 vcc", w); run<61>("v_sub_co e64 sgpr", w); run<62>("v_addc_co e64 sgpr", w); run<63>("4 sub_co + 4 addc (16)", w);
+        run<81>("sub_co,addc vcc (x2)", w);
+        run<64>("v_readlane sgpr sel", w); run<9>("v_readlane const", w); run<65>("s_lshl_b64", w); run<66>("s_or_b64", w); run<73>("s_cselect_b64", w);
+        run<74>("s_bitcmp1+s_cselect (x2)", w); run<67>("s_mov,v_cmpx,s_mov (x3)", w); run<68>("cvt_f64 + add_f32 (x2)", w);
+        run<69>("v_alignbit_b32", w); run<70>("v_or_b32", w); run<71>("v_max_f64", w); run<75>("v_mov_b32 v,s", w); run<76>("v_add_f32 s,v", w);
+        run<82>("v_add_f64 s,v", w); run<77>("s_nop 0", w); run<78>("s_waitcnt (idle)", w); run<79>("s_cmp+cbranch nt (x2)", w); run<80>("s_branch taken (8)", w);
+        run<12>("v_add_f32", w); run<0>("v_cvt_f64_f32", w); run<35>("s_add_i32", w);
     }
     return 0;
 }
