@@ -53,7 +53,8 @@
 #ifndef NP_A_WAVES
 #define NP_A_WAVES 8      // resident waves per SIMD the register budget is set for
 #endif
-// timing experiments only (results are WRONG with any bit set): 1 no trace, 128 no back-track
+// timing experiments only (results are WRONG with any bit set): 1 no trace, 2 fp32 candidate sums, 4 fixed move pattern (no band-end
+// reads, no scalar decision chain), 16 trivial emission, 128 no back-track
 #ifndef NP_ABL
 #define NP_ABL 0
 #endif
@@ -157,6 +158,29 @@ __device__ __forceinline__ void window_state(fill_t& F)
     F.sel1 = F.swp ? la : ua;
 }
 
+// FAST phase, right move: the window moves up by one slot.  The mask of the register that held its first slot rotates by one lane
+// (llk even: the even register, whose mask then equals the odd register's rotated; llk odd: the odd register catches up), the
+// band ends swap registers.  Written out for the scalar unit, every register updated in place: left to the compiler, the
+// renamed values cost three s_mov on the path WITHOUT a right move and four more at the loop's back edge.
+__device__ __forceinline__ void right_move_fast(fill_t& F)
+{
+    uint64_t rot, tmp; int t;
+    asm("s_lshl_b64 %[rot], %[m0], 1\n\t"
+        "s_lshr_b64 %[tmp], %[m0], 63\n\t"
+        "s_or_b64 %[rot], %[rot], %[tmp]\n\t"
+        "s_bitcmp1_b32 %[llk], 0\n\t"
+        "s_cselect_b64 %[m1], %[m0], %[m1]\n\t"
+        "s_cselect_b64 %[m0], %[m0], %[rot]\n\t"
+        "s_add_i32 %[llk], %[llk], 1\n\t"
+        "s_add_i32 %[t], %[s1], 1\n\t"
+        "s_mov_b32 %[s1], %[s0]\n\t"
+        "s_mov_b32 %[s0], %[t]\n\t"
+        "s_xor_b32 %[sw], %[sw], 1"
+        : [rot] "=&s"(rot), [tmp] "=&s"(tmp), [t] "=&s"(t), [m0] "+s"(F.vm0), [m1] "+s"(F.vm1), [llk] "+s"(F.llk),
+          [s0] "+s"(F.sel0), [s1] "+s"(F.sel1), [sw] "+s"(F.swp)
+        : : "scc");
+}
+
 // The window's first k-mer has just reached a multiple of 8 (F.llk): the eight slots that hold the k-mers llk-16 .. llk-9 --
 // both slots of the four lanes (slot >> 1) -- move on by 128 k-mers and load their new records.  kref16: 16 k = kref16 - 4 eo
 // for the eo values as they are at the call.
@@ -190,10 +214,19 @@ __device__ __forceinline__ void retarget(fill_t& F, const read_t& R, const int k
 // POS: 0 / 1 = first / second band of the FAST loop's pair (b - POS is even; the event offsets advance once per pair and the
 // band's share is the load's immediate), -1 = stand-alone.
 template <bool TRIM, bool END, bool FAST, int POS = -1>
-__device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int b, float& x0, float& x1)
+__device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int b, float& x0, float& x1, float& n0, float& n1)
 {
     const int lane = R.lane, E = R.E, K = R.K;
     const int llk = F.llk;
+    if (POS >= 0) {
+        // pair loop: the next band's event means (same k-mer, next event) are requested first, into the other pair of registers,
+        // then ONE wait covers this band's two (requested a band ago; the new requests and a trace store may stay in flight).
+        // (the register part of the offset is >= 4 for every in-window slot of a FAST band; a slot outside the window may see its
+        //  sum misjudged by the range check -- it only feeds masked cells)
+        n0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(R.ev, F.eo0 + 4 * POS, 0, 0));
+        n1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(R.ev, F.eo1 + 4 * POS, 0, 0));
+        asm volatile("" : "+v"(x0), "+v"(x1));
+    }
     // left sources: an odd slot's is the lane's own even slot, an even slot's the previous lane's odd slot
     const float l0 = wave_ror1_all(F.p1);
 
@@ -214,28 +247,34 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
 
     // emissions of both cells: np_emission / np_div_exact, operation for operation (v_pk_*_f32 would halve the
     // instruction count but not the issue cycles -- tools/valu_rates.hip -- and forces the parameters into register pairs)
+#if NP_ABL & 16
+    const float emx = x0 * F.g0.z, emy = x1 * F.g1.z;
+#else
     const float emx = np_emission_nd(x0, F.g0.x, F.g0.y, F.g0.z, F.g0.w);
     const float emy = np_emission_nd(x1, F.g1.x, F.g1.y, F.g1.z, F.g1.w);
-    // the next band's event means (same k-mer, next event) go into the registers the emissions have just released: the
-    // loop-carried value is the load's own destination, so nothing is copied (a copy would have to wait for the load)
-    if (POS >= 0) {
-        // (the register part is >= 4 for every in-window slot of a FAST band; a slot outside the window may see its sum
-        //  misjudged by the range check -- it only feeds masked cells)
-        x0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(R.ev, F.eo0 + 4 * POS, 0, 0));
-        x1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(R.ev, F.eo1 + 4 * POS, 0, 0));
-    } else {
-        x0 = buf_f32(R.ev, F.eo0); x1 = buf_f32(R.ev, F.eo1);
+#endif
+    // stand-alone step: the next band's event means go into the registers the emissions have just released: the loop-carried
+    // value is the load's own destination, so nothing is copied (a copy would have to wait for the load)
+    if (POS < 0) {
+        n0 = buf_f32(R.ev, F.eo0); n1 = buf_f32(R.ev, F.eo1);
         F.eo0 += 4; F.eo1 += 4;
     }
 
     // DP cells (raw_loader.cpp:240-289), computed unconditionally and masked: fp32 cell + fp64 constant + fp32 emission
     // in fp64, rounded to fp32; max, then FROM_U / FROM_L override on equality in that order (later candidate wins).
     // (double)p0 is `up` of the even slot AND `left` of the odd one; the two `left` doubles are the next band's diagonals.
+#if NP_ABL & 2
+    const double P0 = (double)F.p0, L0 = (double)l0;
+    const float sd0 = (float)F.d0 + (float)R.lp_step + emx, sd1 = (float)F.d1 + (float)R.lp_step + emy;
+    const float su0 = F.p0 + (float)R.lp_stay + emx, su1 = F.p1 + (float)R.lp_stay + emy;
+    const float sl0 = l0 + (float)R.lp_skip, sl1 = F.p0 + (float)R.lp_skip;
+#else
     const double em0 = (double)emx, em1 = (double)emy;
     const double P0 = (double)F.p0, P1 = (double)F.p1, L0 = (double)l0;
     const float sd0 = (float)(F.d0 + R.lp_step + em0), sd1 = (float)(F.d1 + R.lp_step + em1);
     const float su0 = (float)(P0 + R.lp_stay + em0), su1 = (float)(P1 + R.lp_stay + em1);
     const float sl0 = (float)(L0 + R.lp_skip), sl1 = (float)(P0 + R.lp_skip);
+#endif
     const float m0 = __builtin_fmaxf(__builtin_fmaxf(sd0, su0), sl0);
     const float m1 = __builtin_fmaxf(__builtin_fmaxf(sd1, su1), sl1);
 
@@ -243,7 +282,7 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
     // so that the scalar chain of the move decision runs while the vector unit packs.  (The ends are inside the window:
     // the unmasked maxima are the cells.)
     int xs = 0, ys = 0;
-    if (FAST) {
+    if (FAST && !(NP_ABL & 4)) {
         xs = __builtin_amdgcn_readlane(__builtin_bit_cast(int, m0), F.sel0);
         ys = __builtin_amdgcn_readlane(__builtin_bit_cast(int, m1), F.sel1);
         asm volatile("" : "+s"(xs), "+s"(ys));
@@ -297,7 +336,7 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
 #if !(NP_ABL & 1)
     if (!FAST) F.tacc = (F.tacc << 4) | (f1 << 2) | f0;
     if (POS == 1 ? (b & 7) == 7 : (POS < 0 && (b & 7) == 7))
-        __builtin_amdgcn_raw_buffer_store_b32((int)F.tacc, R.tr, 4 * lane, (b >> 3) * 256, 0);
+        __builtin_amdgcn_raw_buffer_store_b32((int)F.tacc, R.tr, 4 * lane, (pin_s(b) >> 3) * 256, 0);    // (pin_s: no second induction variable)
 #endif
 
     if (END && khi == K - 1 && llk <= K - 1) {
@@ -314,12 +353,33 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
     F.d0 = L0; F.d1 = P0;
     F.p0 = c0; F.p1 = c1;
 
+    if (FAST && POS >= 0 && !(NP_ABL & 4)) {
+        // Suzuki's rule (see below) in the pair loop, where the band's parity is known.  ll < ur for floats that are +0, negative
+        // or -inf (R.nonpos) is bits(ll) > bits(ur) as unsigned integers; "both ends -inf: alternate, right on even bands" needs
+        // nothing on odd bands (equal patterns compare false) and on even bands is the same compare against min(ur, bits(-FLT_MAX)):
+        // -inf has the largest pattern, so ll > that is "ll is -inf" exactly when ur is -inf, and unchanged otherwise.
+        // The compare's SCC feeds the branch directly.
+        // (plain integer code on scalar values: hipcc emits s_cselect / s_min_u32 / s_cmp_gt_u32 + s_cbranch_scc -- the compare's SCC
+        //  feeds the branch directly.  `asm goto` is not an option: this compiler drops the statement.)
+        const uint32_t xu = (uint32_t)pin_s(xs), yu = (uint32_t)pin_s(ys);
+        const bool sw = F.swp != 0;
+        const uint32_t ll = sw ? yu : xu;
+        uint32_t ur = sw ? xu : yu;
+        if (POS == 0) ur = ur < 0xff7fffffu ? ur : 0xff7fffffu;
+        if (ll > ur) {
+            right_move_fast(F);
+            if ((F.llk & 7) == 0) retarget(F, R, 16 * (pin_s(b) - POS - 1));
+        }
+        return;
+    }
     if (FAST || b >= 1) {
         // Suzuki's rule for band b+1, on this band (:179-195): both ends -inf (the AND of two non-NaN patterns is -inf's only
         // then): alternate; else right iff ll < ur, where a single -inf compares as the reference's
         // is_offset_valid ? value : -INFINITY does
         bool right;
-        if (FAST) {
+        if (FAST && (NP_ABL & 4)) {
+            right = (((b + 1) * 13) >> 5) != ((b * 13) >> 5);       // a fixed pattern with the same share of right moves
+        } else if (FAST) {
             // FAST runs only for reads whose cells are all <= 0 (R.nonpos): for such floats (+0, negative, -inf) x < y is
             // bits(x) > bits(y) as unsigned integers -- scalar compares instead of a vector compare on two scalars
             // (spelled out for the scalar unit: hipcc lowers a select between wave-uniform conditions to vector code)
@@ -336,9 +396,7 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
                 : [r] "=&s"(r), [t] "=&s"(t), [ll] "=&s"(ll), [ur] "=&s"(ur)                                                      \
                 : [x] "s"(xs), [y] "s"(ys), [sw] "s"(F.swp), [par] PAR_CONSTRAINT(PAR) : "scc")
             // both ends outside: alternate, starting with a right move on even bands (the band's parity is known in the pair loop)
-            if (POS == 0) NP_SUZUKI("n", 1);
-            else if (POS == 1) NP_SUZUKI("n", 0);
-            else { const int par = (b & 1) ^ 1; NP_SUZUKI("s", par); }
+            { const int par = (b & 1) ^ 1; NP_SUZUKI("s", par); }
 #undef NP_SUZUKI
             right = r != 0;
         } else {
@@ -360,7 +418,7 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
                 const int s0 = F.sel0;
                 F.sel0 = F.sel1 + 1; F.sel1 = s0; F.swp ^= 1;
             }
-            if ((F.llk & 7) == 0) retarget(F, R, POS >= 0 ? 16 * (b - POS - 1) : 16 * b);
+            if ((F.llk & 7) == 0) retarget(F, R, 16 * b);
         }
     }
 }
@@ -393,7 +451,8 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
         const int cap = (int)(a.pair_off[ri + 1] - pbase);
         np_pair* __restrict__ pairs = a.pairs + pbase;
 
-        const bool ok = !(E <= 0 || K <= 0 || (uint64_t)((n_bands + 7) >> 3) * 32 > a.trace_stride || (uint64_t)K > a.kp_stride || cap < E + K + 2);
+        const int n_rows = (n_bands + 7) >> 3;
+        const bool ok = !(E <= 0 || K <= 0 || (uint64_t)n_rows * 32 > a.trace_stride || (uint64_t)K > a.kp_stride || cap < E + K + 2);
         int n_out = 0, max_gap = 0, last_k = -1;
         double sum_emission = 0.0;
         if (ok) {
@@ -417,7 +476,7 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
             // ---------------- fill ----------------
             read_t R;
             R.E = E; R.K = K; R.lane = lane; R.lane4 = lane >> 2; R.end_slot = (K - 1) & (NP_RING - 1); R.nonpos = nonpos;
-            R.ev = make_rsrc(ev, (uint32_t)E * 4u); R.kp = make_rsrc(kp, (uint32_t)K * 16u); R.tr = make_rsrc(trace, (uint32_t)(a.trace_stride * 8u < 0xffffff00ull ? a.trace_stride * 8u : 0xffffff00ull));
+            R.ev = make_rsrc(ev, (uint32_t)E * 4u); R.kp = make_rsrc(kp, (uint32_t)K * 16u); R.tr = make_rsrc(trace, (uint32_t)n_rows * 256u);
             {
                 const uint64_t u = (uint64_t)uniform_ptr(kp);
                 R.kpd = i4{(int)(uint32_t)u, (int)(uint32_t)(u >> 32), (int)((uint32_t)K * 16u), 0x00020000};      // == make_rsrc(kp, 16 K)
@@ -446,7 +505,7 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
             //   llk + 99 < K-1,  u <= E-1                                           -- become false once;
             // and while min(K-2 - (llk+99), E-1 - u) = s > 0 the next s bands are FAST whatever the moves are.
             for (; b < n_bands && !(F.llk >= 0 && b - 2 - F.llk >= NP_ALN_BANDWIDTH - 1); ++b)
-                band_step<true, true, false>(F, R, b, x0, x1);
+                band_step<true, true, false>(F, R, b, x0, x1, x0, x1);
             window_state(F);
             for (; R.nonpos;) {
                 const int ks = (K - 2) - (F.llk + NP_ALN_BANDWIDTH - 1), es = (E - 1) - (b - 2 - F.llk);
@@ -456,14 +515,15 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
                 // two bands per iteration, the first one even: the doubles made of `left` become the next band's diagonal without
                 // a register copy, the event offsets advance once, the trace store and the parity of Suzuki's tie rule are
                 // compile-time properties of the position
-                if (b & 1) { band_step<false, false, true>(F, R, b, x0, x1); ++b; }
+                if (b & 1) { band_step<false, false, true>(F, R, b, x0, x1, x0, x1); ++b; }
+                float y0, y1;
                 for (; b + 1 < stop; b += 2) {
-                    band_step<false, false, true, 0>(F, R, b, x0, x1); band_step<false, false, true, 1>(F, R, b + 1, x0, x1);
+                    band_step<false, false, true, 0>(F, R, b, x0, x1, y0, y1); band_step<false, false, true, 1>(F, R, b + 1, y0, y1, x0, x1);
                     F.eo0 += 8; F.eo1 += 8;
                 }
-                for (; b < stop; ++b) band_step<false, false, true>(F, R, b, x0, x1);
+                for (; b < stop; ++b) band_step<false, false, true>(F, R, b, x0, x1, x0, x1);
             }
-            for (; b < n_bands; ++b) band_step<true, true, false>(F, R, b, x0, x1);
+            for (; b < n_bands; ++b) band_step<true, true, false>(F, R, b, x0, x1, x0, x1);
             if ((n_bands & 7) != 0) __builtin_amdgcn_raw_buffer_store_b32((int)(F.tacc << (4 * (8 - (n_bands & 7)))), R.tr, 4 * lane, ((n_bands - 1) >> 3) * 256, 0);   // last, partial group
 
             // ---------------- backtrack (:326-361) + QC sums (:338-341) ----------------

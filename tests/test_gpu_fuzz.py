@@ -47,6 +47,46 @@ def test_event_align_fuzz(ctx, orc, models):
     assert n_ok > 80 and n_fail > 20           # both outcomes of the QC are exercised
 
 
+def test_event_align_more_reads_than_resident_waves(ctx, orc, models):
+    """A batch larger than the persistent grid: waves take reads from the queue one after the other, longest first
+    (align_lpt) or in index order -- same pairs either way, and the oracle's.  (The grid is shrunk to 1024 waves so that
+    1300 short reads are such a batch; two reads are far longer than the rest.)"""
+    nuc = models["nucleotide"]
+    mn = orc.model(nuc)
+    rng = np.random.default_rng(4242)
+    reads = []
+    while len(reads) < 1300:
+        L = 4000 if len(reads) in (7, 700) else int(rng.integers(12, 700))
+        rd = _random_read(rng, nuc, L, rate=float(rng.choice([0.8, 1.5, 2.5])), noise=float(rng.choice([0.5, 1.0, 1.0, 3.0, 8.0])))
+        if len(rd["events"]) >= 2:
+            reads.append(rd)
+    jobs = []
+    for rd in reads:
+        sh, sc = orc.estimate_scalings_mom(mn, rd["ranks"], rd["events"])
+        rd["mom"] = (sh, sc)
+        jobs.append(dict(events=rd["events"], ranks=rd["ranks"], model=ctx.models["nucleotide"], scale=sc, shift=sh, var=1.0))
+    try:
+        ctx.set_option("align_blocks_per_cu", 1)
+        ctx.set_option("align_lpt", 0)
+        in_order = ctx.adaptive_banded_simple_event_align(jobs)
+        ctx.set_option("align_lpt", 1)
+        longest_first = ctx.adaptive_banded_simple_event_align(jobs)
+    finally:
+        ctx.set_option("align_blocks_per_cu", 8); ctx.set_option("align_lpt", 1)
+    n_ok = 0
+    for i, (a, b) in enumerate(zip(in_order, longest_first)):
+        assert a.shape == b.shape and np.array_equal(a, b), i
+        n_ok += len(a) > 0
+    assert 300 < n_ok < 1300
+    for i in list(range(0, 1300, 9)) + [7, 700]:
+        rd = reads[i]
+        want = orc.event_align(mn, orc.scalings(rd["mom"][0], rd["mom"][1], 1.0), rd["events"], rd["ranks"])
+        if want is None:
+            assert len(longest_first[i]) == 0
+            continue
+        assert longest_first[i].shape == want.shape and np.array_equal(longest_first[i], want), i
+
+
 def test_hmm_score_and_align_fuzz(ctx, orc, models):
     nuc, cpg = models["nucleotide"], models["cpg"]
     mn, mc = orc.model(nuc), orc.model(cpg)
