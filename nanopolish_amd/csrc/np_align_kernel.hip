@@ -700,10 +700,16 @@ __device__ __forceinline__ int order_bucket(const np_read_dev& r)
     const uint32_t b = (r.n_events + r.n_kmers + 2u) >> 7;
     return (int)(b < NP_ORDER_BUCKETS - 1 ? b : NP_ORDER_BUCKETS - 1);
 }
+// (workgroup-private counts in LDS first: a batch of equally long reads hits ONE bucket, and 100 000 atomics on one address
+//  take most of a millisecond)
 __global__ void __launch_bounds__(256) np_align_hist_kernel(int n_reads, const np_read_dev* __restrict__ reads, uint32_t* __restrict__ hist)
 {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r < n_reads) atomicAdd(&hist[order_bucket(reads[r])], 1u);
+    __shared__ uint32_t h[NP_ORDER_BUCKETS];
+    for (int i = threadIdx.x; i < NP_ORDER_BUCKETS; i += 256) h[i] = 0;
+    __syncthreads();
+    for (int r = blockIdx.x * 1024 + threadIdx.x; r < n_reads && r < (blockIdx.x + 1) * 1024; r += 256) atomicAdd(&h[order_bucket(reads[r])], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < NP_ORDER_BUCKETS; i += 256) if (h[i]) atomicAdd(&hist[i], h[i]);
 }
 // one block: cursor[b] = number of reads in longer buckets (exclusive scan from the top)
 __global__ void __launch_bounds__(NP_ORDER_BUCKETS) np_align_scan_kernel(const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor)
@@ -724,8 +730,22 @@ __global__ void __launch_bounds__(NP_ORDER_BUCKETS) np_align_scan_kernel(const u
 __global__ void __launch_bounds__(256) np_align_scatter_kernel(int n_reads, const np_read_dev* __restrict__ reads, uint32_t* __restrict__ cursor,
                                                                uint32_t* __restrict__ order)
 {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r < n_reads) order[atomicAdd(&cursor[order_bucket(reads[r])], 1u)] = (uint32_t)r;
+    __shared__ uint32_t h[NP_ORDER_BUCKETS];       // workgroup-private counts, then the workgroup's base in every bucket
+    for (int i = threadIdx.x; i < NP_ORDER_BUCKETS; i += 256) h[i] = 0;
+    __syncthreads();
+    int bk[4]; uint32_t local[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int r = blockIdx.x * 1024 + t * 256 + threadIdx.x;
+        bk[t] = -1; local[t] = 0;
+        if (r < n_reads) { bk[t] = order_bucket(reads[r]); local[t] = atomicAdd(&h[bk[t]], 1u); }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NP_ORDER_BUCKETS; i += 256) { const uint32_t n = h[i]; if (n) h[i] = atomicAdd(&cursor[i], n); }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (bk[t] >= 0) order[h[bk[t]] + local[t]] = (uint32_t)(blockIdx.x * 1024 + t * 256 + threadIdx.x);
 }
 
 } // namespace
@@ -738,7 +758,7 @@ hipError_t np_launch_align_order(int n_reads, const np_read_dev* reads, uint32_t
     uint32_t* hist = scratch; uint32_t* cursor = scratch + NP_ORDER_BUCKETS; uint32_t* order = scratch + 2 * NP_ORDER_BUCKETS;
     hipError_t e = hipMemsetAsync(hist, 0, NP_ORDER_BUCKETS * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    const int nb = (n_reads + 255) / 256;
+    const int nb = (n_reads + 1023) / 1024;
     hipLaunchKernelGGL(np_align_hist_kernel, dim3(nb), dim3(256), 0, s, n_reads, reads, hist);
     hipLaunchKernelGGL(np_align_scan_kernel, dim3(1), dim3(NP_ORDER_BUCKETS), 0, s, hist, cursor);
     hipLaunchKernelGGL(np_align_scatter_kernel, dim3(nb), dim3(256), 0, s, n_reads, reads, cursor, order);

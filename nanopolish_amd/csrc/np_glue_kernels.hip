@@ -40,20 +40,33 @@ __global__ void __launch_bounds__(64) np_build_map_kernel(int n_reads, np_read_d
     // k-mer); every later pair of that k-mer advanced the event.  Hence
     //   start[k] = event of the k-mer's first pair if that records, else of its second pair (if it has one);
     //   stop[k]  = event of the k-mer's last pair, unless that pair is also its first and does not record.
-    for (int i = lane; i < np_; i += 64) {
-        const np_pair c = p[i];
-        const np_pair a = i > 0 ? p[i - 1] : np_pair{-1, -1};      // prev_event_idx = -1 initially (:281)
-        const bool first_of_k = a.ref_pos != c.ref_pos;
-        const bool records = c.read_pos != a.read_pos;
-        bool is_start = first_of_k && records;
-        if (!first_of_k) {                                          // second pair of k: start if the first did not record
-            const np_pair b = i > 1 ? p[i - 2] : np_pair{-1, -1};
-            is_start = b.ref_pos != c.ref_pos && a.read_pos == b.read_pos;
+    // (four chunks of 64 pairs per round, all their loads requested before the first store: one wave per read, bound by the
+    //  memory round trips)
+    for (int i0 = 0; i0 < np_; i0 += 256) {
+        np_pair c_[4], a_[4], b_[4]; int nxt_[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 64 * u + lane;
+            const bool in = i < np_;
+            c_[u] = in ? p[i] : np_pair{-1, -1};
+            a_[u] = in && i > 0 ? p[i - 1] : np_pair{-1, -1};      // prev_event_idx = -1 initially (:281)
+            b_[u] = in && i > 1 ? p[i - 2] : np_pair{-1, -1};
+            nxt_[u] = in && i + 1 < np_ ? p[i + 1].ref_pos : -2;
         }
-        if (is_start) ms[c.ref_pos] = c.read_pos;
-        if (mp) {
-            const bool last_of_k = i + 1 >= np_ || p[i + 1].ref_pos != c.ref_pos;
-            if (last_of_k && (records || !first_of_k)) mp[c.ref_pos] = c.read_pos;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 64 * u + lane;
+            if (i >= np_) continue;
+            const np_pair c = c_[u], a = a_[u], b = b_[u];
+            const bool first_of_k = a.ref_pos != c.ref_pos;
+            const bool records = c.read_pos != a.read_pos;
+            bool is_start = first_of_k && records;
+            if (!first_of_k) is_start = b.ref_pos != c.ref_pos && a.read_pos == b.read_pos;   // second pair of k: start if the first did not record
+            if (is_start) ms[c.ref_pos] = c.read_pos;
+            if (mp) {
+                const bool last_of_k = nxt_[u] != c.ref_pos;
+                if (last_of_k && (records || !first_of_k)) mp[c.ref_pos] = c.read_pos;
+            }
         }
     }
     if (lane == 0) {
@@ -129,44 +142,68 @@ __global__ void __launch_bounds__(64) np_recalibrate_kernel(int n_reads, np_read
     long long n = 0;
     for (int pass = 0; pass < 2; ++pass) {
         int carry_rank = -1;                                     // prev_kmer_rank = -1 (squiggle_read.cpp:351)
-        for (int base = 0; base < K; base += 64) {
-            const int ki = base + lane;
-            const int st = ki < K ? ms[ki] : -1;
-            const bool has = st != -1;
-            const int rank = has ? (int)rk[ki] : -1;
-            const unsigned long long hm = __ballot(has);
-            const unsigned long long before = hm & ((1ull << lane) - 1ull);
-            const int src = before ? 63 - __clzll((long long)before) : 0;
-            const int prev = __shfl(rank, src, 64);
-            const bool isM = has && rank != (before ? prev : carry_rank);
-            double t0 = 0., t1 = 0., t2 = 0., t3 = 0., t4 = 0.;
-            if (isM) {
-                const double ls = model[rank].level_stdv, mu = model[rank].level_mean;
-                const double e = (double)ev[st];                 // raw_events: get_unscaled_level of the run's first event
-                if (pass == 0) {
-                    const double inv_var = 1. / (ls * ls);
-                    t0 = inv_var; t1 = mu * inv_var; t2 = mu * mu * inv_var; t3 = e * inv_var; t4 = mu * e * inv_var;
-                } else {
-                    const double yi = (e - shift - scale * mu);
-                    t0 = yi * yi / (ls * ls);
-                }
+        // NP_RC_U chunks of 64 k-mers per round: their map entries and ranks are requested together, then the model states and
+        // event means they point at (for every k-mer that has events: a superset of the 'M' entries), then the chunks are
+        // consumed in order -- two dependent memory round trips per round instead of per chunk (the kernel is one wave per read
+        // and bound by exactly those round trips).
+#define NP_RC_U 4
+        for (int base0 = 0; base0 < K; base0 += 64 * NP_RC_U) {
+            int st_[NP_RC_U], rank_[NP_RC_U];
+            double ls_[NP_RC_U], mu_[NP_RC_U]; float e_[NP_RC_U];
+#pragma unroll
+            for (int u = 0; u < NP_RC_U; ++u) {
+                const int ki = base0 + 64 * u + lane;
+                st_[u] = ki < K ? ms[ki] : -1;
+                rank_[u] = ki < K ? (int)rk[ki] : 0;
             }
-            // ordered accumulation: the terms go through LDS, lane c (0..4) owns sum c and adds its 64 terms in k-mer order
-            // (a zero term leaves a non-negative-zero sum unchanged, so lanes that are not 'M' entries need no masking)
-            if (__ballot(isM)) {
-                __syncthreads();
-                terms[0][lane] = t0;
-                if (pass == 0) { terms[1][lane] = t1; terms[2][lane] = t2; terms[3][lane] = t3; terms[4][lane] = t4; }
-                __syncthreads();
-                if (lane < (pass == 0 ? 5 : 1)) {
-                    const double* row = terms[lane];
+#pragma unroll
+            for (int u = 0; u < NP_RC_U; ++u) {
+                const bool has = st_[u] != -1;
+                ls_[u] = has ? model[rank_[u]].level_stdv : 1.0;
+                mu_[u] = has ? model[rank_[u]].level_mean : 0.0;
+                e_[u] = has ? ev[st_[u]] : 0.0f;                 // raw_events: get_unscaled_level of the run's first event
+            }
+#pragma unroll
+            for (int u = 0; u < NP_RC_U; ++u) {
+                if (base0 + 64 * u >= K) break;                   // wave-uniform
+                const int st = st_[u];
+                const bool has = st != -1;
+                const int rank = has ? rank_[u] : -1;
+                const unsigned long long hm = __ballot(has);
+                const unsigned long long before = hm & ((1ull << lane) - 1ull);
+                const int src = before ? 63 - __clzll((long long)before) : 0;
+                const int prev = __shfl(rank, src, 64);
+                const bool isM = has && rank != (before ? prev : carry_rank);
+                double t0 = 0., t1 = 0., t2 = 0., t3 = 0., t4 = 0.;
+                if (isM) {
+                    const double ls = ls_[u], mu = mu_[u];
+                    const double e = (double)e_[u];
+                    if (pass == 0) {
+                        const double inv_var = 1. / (ls * ls);
+                        t0 = inv_var; t1 = mu * inv_var; t2 = mu * mu * inv_var; t3 = e * inv_var; t4 = mu * e * inv_var;
+                    } else {
+                        const double yi = (e - shift - scale * mu);
+                        t0 = yi * yi / (ls * ls);
+                    }
+                }
+                // ordered accumulation: the terms go through LDS, lane c (0..4) owns sum c and adds its 64 terms in k-mer order
+                // (a zero term leaves a non-negative-zero sum unchanged, so lanes that are not 'M' entries need no masking)
+                if (__ballot(isM)) {
+                    __syncthreads();
+                    terms[0][lane] = t0;
+                    if (pass == 0) { terms[1][lane] = t1; terms[2][lane] = t2; terms[3][lane] = t3; terms[4][lane] = t4; }
+                    __syncthreads();
+                    if (lane < (pass == 0 ? 5 : 1)) {
+                        const double* row = terms[lane];
 #pragma unroll 16
-                    for (int q = 0; q < 64; ++q) acc += row[q];
+                        for (int q = 0; q < 64; ++q) acc += row[q];
+                    }
+                    n += __popcll(__ballot(isM));
                 }
-                n += __popcll(__ballot(isM));
+                if (hm) carry_rank = __shfl(rank, 63 - __clzll((long long)hm), 64);
             }
-            if (hm) carry_rank = __shfl(rank, 63 - __clzll((long long)hm), 64);
         }
+#undef NP_RC_U
         if (pass == 0) {
             if (n < 200) { if (lane == 0) calibrated[ri] = 0; return; }      // minNumEventsToRescale: not recalibrated
             const double a00 = readlane_f64(acc, 0), a01 = readlane_f64(acc, 1), a11 = readlane_f64(acc, 2);
@@ -255,17 +292,24 @@ __device__ __forceinline__ int job_bin(const np_hmm_job_dev& jb, uint32_t flank_
     return (cls * NP_CPL + (NP_CPL - cg)) * NP_EBUCKETS + (NP_EBUCKETS - 1 - (int)bucket);
 }
 
+// NP_BIN_ITEMS work items per workgroup: the workgroup's histogram (7 KB of LDS) is cleared and flushed once per 4096 items,
+// and the global counters -- a few hot bins take nearly all items -- see one atomic per bin and workgroup instead of sixteen.
+#define NP_BIN_ITEMS 4096
 __global__ void __launch_bounds__(256) np_bin_count_kernel(const np_hmm_job_dev* jobs, int64_t n_jobs, uint32_t* hist,
                                                            float* out_scores, uint32_t flank_len)
 {
     __shared__ uint32_t h[NP_NBINS];
     for (int i = threadIdx.x; i < NP_NBINS; i += 256) h[i] = 0;
     __syncthreads();
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j < n_jobs) {
-        const int bin = job_bin(jobs[j], flank_len);
-        if (bin >= 0) atomicAdd(&h[bin], 1u);
-        else if (out_scores) out_scores[j] = __builtin_nanf("");          // skipped / unsupported item
+    const int64_t base = (int64_t)blockIdx.x * NP_BIN_ITEMS;
+#pragma unroll 4
+    for (int t = 0; t < NP_BIN_ITEMS / 256; ++t) {
+        const int64_t j = base + t * 256 + threadIdx.x;
+        if (j < n_jobs) {
+            const int bin = job_bin(jobs[j], flank_len);
+            if (bin >= 0) atomicAdd(&h[bin], 1u);
+            else if (out_scores) out_scores[j] = __builtin_nanf("");          // skipped / unsupported item
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < NP_NBINS; i += 256) if (h[i]) atomicAdd(&hist[i], h[i]);
@@ -287,17 +331,25 @@ __global__ void __launch_bounds__(256) np_bin_scatter_kernel(const np_hmm_job_de
     __shared__ uint32_t h[NP_NBINS];       // per-block counts, then per-block base offsets
     for (int i = threadIdx.x; i < NP_NBINS; i += 256) h[i] = 0;
     __syncthreads();
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    int bin = -1;
-    uint32_t local = 0;
-    if (j < n_jobs) {
-        bin = job_bin(jobs[j], flank_len);
-        if (bin >= 0) local = atomicAdd(&h[bin], 1u);
+    const int64_t base = (int64_t)blockIdx.x * NP_BIN_ITEMS;
+    int bin[NP_BIN_ITEMS / 256];
+    uint32_t local[NP_BIN_ITEMS / 256];
+#pragma unroll
+    for (int t = 0; t < NP_BIN_ITEMS / 256; ++t) {
+        const int64_t j = base + t * 256 + threadIdx.x;
+        bin[t] = -1; local[t] = 0;
+        if (j < n_jobs) {
+            bin[t] = job_bin(jobs[j], flank_len);
+            if (bin[t] >= 0) local[t] = atomicAdd(&h[bin[t]], 1u);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < NP_NBINS; i += 256) { const uint32_t n = h[i]; if (n) h[i] = atomicAdd(&cursor[i], n); }
     __syncthreads();
-    if (bin >= 0) order[(size_t)(bin / (NP_CPL * NP_EBUCKETS)) * (size_t)n_jobs + h[bin] + local] = (uint32_t)j;
+#pragma unroll
+    for (int t = 0; t < NP_BIN_ITEMS / 256; ++t)
+        if (bin[t] >= 0)
+            order[(size_t)(bin[t] / (NP_CPL * NP_EBUCKETS)) * (size_t)n_jobs + h[bin[t]] + local[t]] = (uint32_t)(base + t * 256 + threadIdx.x);
 }
 
 } // namespace
@@ -311,7 +363,7 @@ hipError_t np_launch_classify(const np_hmm_job_dev* jobs, int64_t n_jobs, uint32
     uint32_t* cursor = bins + NP_NBINS;
     hipError_t e = hipMemsetAsync(bins, 0, 2 * NP_NBINS * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    const unsigned nb = (unsigned)((n_jobs + 255) / 256);
+    const unsigned nb = (unsigned)((n_jobs + NP_BIN_ITEMS - 1) / NP_BIN_ITEMS);
     hipLaunchKernelGGL(np_bin_count_kernel, dim3(nb), dim3(256), 0, s, jobs, n_jobs, hist, out_scores, flank_len);
     hipLaunchKernelGGL(np_bin_scan_kernel, dim3(1), dim3(64), 0, s, hist, cursor, class_count);
     hipLaunchKernelGGL(np_bin_scatter_kernel, dim3(nb), dim3(256), 0, s, jobs, n_jobs, cursor, order, flank_len);

@@ -160,7 +160,10 @@ __global__ void __launch_bounds__(64) np_cigar_index_kernel(int n_reads, const u
     }
 }
 
-// pass 1, one lane per read: sequential motif scan and grouping, the skip rules, slot and k-mer offsets
+// pass 1, one wavefront per read: the motif test runs on 64 positions at a time (coalesced byte loads, one ballot), the
+// sequential grouping only visits the matches (wave-uniform state, every lane computes the same values; lane 0 stores): the
+// skip rules, slot and k-mer offsets.  (One LANE per read, a byte at a time, took 5.8 ms per 100 000 reads -- as long as the
+// slowest lane's 5000 dependent iterations whatever the batch size.)
 __global__ void __launch_bounds__(64) np_cm_groups_kernel(int n_reads, const char* __restrict__ seq, const int64_t* __restrict__ seq_off,
                                                            const int32_t* __restrict__ seq_len, const uint8_t* __restrict__ read_rc,
                                                            const uint32_t* __restrict__ cigar, const int64_t* __restrict__ cigar_off,
@@ -173,8 +176,9 @@ __global__ void __launch_bounds__(64) np_cm_groups_kernel(int n_reads, const cha
                                                            int32_t* __restrict__ n_motif, int64_t* __restrict__ group_rank_off,
                                                            int32_t* __restrict__ n_groups)
 {
-    const int r = blockIdx.x * 64 + threadIdx.x;
+    const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= n_reads) return;
+    const bool writer = lane == 0;
     const char* ref = seq + seq_off[r];
     const int n = seq_len ? seq_len[r] : (int)(seq_off[r + 1] - seq_off[r]);
     const site2 s = site_of(alphabet);
@@ -192,8 +196,10 @@ __global__ void __launch_bounds__(64) np_cm_groups_kernel(int n_reads, const cha
         cv.op_ref = op_ref + cigar_off[r] + r; cv.op_read = op_read + cigar_off[r] + r;
         cr = cig_reads[r]; rc = read_rc[r] != 0; rl = read_len[r];
         // flip_k_strand for reverse-strand reads (squiggle_read.h:229-233); the degenerate-record test needs these two
-        deg_kpos[2 * r] = cr.first_q < 0 ? -1 : (rc ? rl - cr.first_q - k : cr.first_q);
-        deg_kpos[2 * r + 1] = cr.first_q < 0 ? -1 : (rc ? rl - cr.last_q - k : cr.last_q);
+        if (writer) {
+            deg_kpos[2 * r] = cr.first_q < 0 ? -1 : (rc ? rl - cr.first_q - k : cr.first_q);
+            deg_kpos[2 * r + 1] = cr.first_q < 0 ? -1 : (rc ? rl - cr.last_q - k : cr.last_q);
+        }
     }
     int ng = 0, first = -1, last = -1, cnt = 0;
     int64_t w = 0;
@@ -211,11 +217,13 @@ __global__ void __launch_bounds__(64) np_cm_groups_kernel(int n_reads, const cha
             const int nk = sub_end - sub_start + 1 - k + 1;
             if (ng >= cap || w + 2 * (int64_t)nk > rank_cap) { overflow = true; }
             else {
-                first_site[g0 + ng] = first; last_site[g0 + ng] = last; n_motif[g0 + ng] = cnt;
-                group_rank_off[g0 + ng] = rank_off_cap[r] + w;
-                if (by_cigar) {
-                    group_kpos[2 * (g0 + ng)] = rc ? rl - q1 - k : q1;
-                    group_kpos[2 * (g0 + ng) + 1] = rc ? rl - q2 - k : q2;
+                if (writer) {
+                    first_site[g0 + ng] = first; last_site[g0 + ng] = last; n_motif[g0 + ng] = cnt;
+                    group_rank_off[g0 + ng] = rank_off_cap[r] + w;
+                    if (by_cigar) {
+                        group_kpos[2 * (g0 + ng)] = rc ? rl - q1 - k : q1;
+                        group_kpos[2 * (g0 + ng) + 1] = rc ? rl - q2 - k : q2;
+                    }
                 }
                 w += 2 * (int64_t)nk;
                 ng++;
@@ -224,15 +232,19 @@ __global__ void __launch_bounds__(64) np_cm_groups_kernel(int n_reads, const cha
         cnt = 0;
     };
     const sites_t S = sites_of(alphabet);
-    for (int i = 0; i + 1 < n; ++i) {
-        if (S.len == 2 ? (ref[i] == s.a && ref[i + 1] == s.b) : site_at(ref, 0, n, i, S) >= 0) {   // is_motif_match, whole site
+    for (int base = 0; base + 1 < n; base += 64) {
+        const int pos = base + lane;
+        const bool hit = pos + 1 < n &&
+                         (S.len == 2 ? (ref[pos] == s.a && ref[pos + 1] == s.b) : site_at(ref, 0, n, pos, S) >= 0);   // is_motif_match, whole site
+        for (unsigned long long bits = __ballot(hit); bits; bits &= bits - 1) {
+            const int i = base + __builtin_ctzll(bits);
             if (cnt > 0 && i - last > min_separation) close_group();
             if (cnt == 0) first = i;
             last = i; cnt++;
         }
     }
     close_group();
-    n_groups[r] = overflow ? -1 : ng;
+    if (writer) n_groups[r] = overflow ? -1 : ng;
 }
 
 // pass 2, one block per read: every group's two work items and their k-mer ranks.
@@ -276,20 +288,32 @@ __global__ void __launch_bounds__(256) np_cm_items_kernel(int n_reads, const cha
         *(int4*)(kpos + 4 * (g0 + g)) = kp;
     }
     if (ng == 0) return;
-    const int64_t base = group_rank_off[g0];
-    const int nk_last = last_site[g0 + ng - 1] - first_site[g0 + ng - 1] + 2 * min_flank + 1 - k + 1;
-    const int total = (int)((group_rank_off[g0 + ng - 1] - base) >> 1) + nk_last;
+    // Groups in tiles of NP_ITEM_TILE: the tile's offsets and windows go to LDS, so the binary search and the three per-group
+    // values of every k-mer are LDS reads instead of dependent global loads (the kernel was bound by those round trips).
+#define NP_ITEM_TILE 512
+    __shared__ int t_first[NP_ITEM_TILE + 1], t_sub[NP_ITEM_TILE], t_len[NP_ITEM_TILE];
+    for (int tile = 0; tile < ng; tile += NP_ITEM_TILE) {
+    const int tn = ng - tile < NP_ITEM_TILE ? ng - tile : NP_ITEM_TILE;
+    const int64_t base = group_rank_off[g0 + tile];
+    __syncthreads();
+    for (int g = threadIdx.x; g < tn; g += 256) {
+        const int sub_start = first_site[g0 + tile + g] - min_flank, sub_end = last_site[g0 + tile + g] + min_flank;
+        t_first[g] = (int)((group_rank_off[g0 + tile + g] - base) >> 1);   // flat index of the group's first k-mer (two rank arrays per group)
+        t_sub[g] = sub_start; t_len[g] = sub_end - sub_start + 1;
+    }
+    __syncthreads();
+    const int total = t_first[tn - 1] + (t_len[tn - 1] - k + 1);
     for (int t = threadIdx.x; t < total; t += 256) {
-        int lo = 0, hi = ng - 1;                                       // the last group whose first k-mer is <= t
+        int lo = 0, hi = tn - 1;                                       // the last group whose first k-mer is <= t
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if ((int)((group_rank_off[g0 + mid] - base) >> 1) <= t) lo = mid; else hi = mid - 1;
+            if (t_first[mid] <= t) lo = mid; else hi = mid - 1;
         }
         const int g = lo;
-        const int64_t ro = group_rank_off[g0 + g];
-        const int i = t - (int)((ro - base) >> 1);
-        const int sub_start = first_site[g0 + g] - min_flank, sub_end = last_site[g0 + g] + min_flank;
-        const int len = sub_end - sub_start + 1, nk = len - k + 1;
+        const int i = t - t_first[g];
+        const int64_t ro = base + 2 * (int64_t)t_first[g];
+        const int sub_start = t_sub[g];
+        const int len = t_len[g], nk = len - k + 1;
         // HMMInputSequence::get_kmer_rank(i, k, do_rc): the forward k-mer at i, or the reverse-complement string's k-mer at
         // len - i - k, i.e. window characters i+k-1 down to i complemented.  Either way the characters are window positions
         // i .. i+k-1, and methylation looks one position to each side INSIDE the window (Alphabet::methylate of the window).
@@ -329,6 +353,8 @@ __global__ void __launch_bounds__(256) np_cm_items_kernel(int n_reads, const cha
         job_ranks[ro + i] = (uint16_t)ru;
         job_ranks[ro + nk + i] = (uint16_t)rm;
     }
+    }
+#undef NP_ITEM_TILE
 }
 
 } // namespace
@@ -339,7 +365,7 @@ hipError_t np_launch_cm_build_jobs(int n_reads, const char* seq, const int64_t* 
                                    int32_t* n_motif, int64_t* group_rank_off, int32_t* n_groups, hipStream_t s)
 {
     if (n_reads <= 0) return hipSuccess;
-    hipLaunchKernelGGL(np_cm_groups_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, seq, seq_off, nullptr, read_rc, nullptr, nullptr,
+    hipLaunchKernelGGL(np_cm_groups_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, seq, seq_off, nullptr, read_rc, nullptr, nullptr,
                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, alphabet, k, min_separation,
                        min_flank, group_off, rank_off_cap, first_site, last_site, n_motif, group_rank_off, n_groups);
     hipLaunchKernelGGL(np_cm_items_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, seq, seq_off, nullptr, nullptr, read_rc, alphabet, k, min_flank,
@@ -361,7 +387,7 @@ hipError_t np_launch_cm_build_jobs_cigar(int n_reads, const char* genome, const 
     if (n_reads <= 0) return hipSuccess;
     hipLaunchKernelGGL(np_cigar_index_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, cigar, cigar_off, read_len, k, op_ref, op_read,
                        (cig_read_t*)cig_reads);
-    hipLaunchKernelGGL(np_cm_groups_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, genome, ref_begin, ref_len, read_rc, cigar,
+    hipLaunchKernelGGL(np_cm_groups_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, genome, ref_begin, ref_len, read_rc, cigar,
                        cigar_off, read_len, op_ref, op_read, (const cig_read_t*)cig_reads, group_kpos, deg_kpos, alphabet, k, min_separation,
                        min_flank, group_off, rank_off_cap, first_site, last_site, n_motif, group_rank_off, n_groups);
     hipLaunchKernelGGL(np_cm_items_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, genome, ref_begin, ref_len, group_kpos, read_rc, alphabet, k,
