@@ -58,6 +58,12 @@
 #ifndef NP_ABL
 #define NP_ABL 0
 #endif
+#ifndef NP_A_WALK_PRIO
+#define NP_A_WALK_PRIO 3  // wave priority during the back-track (s_setprio): a dependent scalar chain that needs few issue slots but holds a
+#endif                    // wave slot for as long as it takes; 45.6 -> 43.2 ms per 32768 reads
+#ifndef NP_A_FILL_PRIO
+#define NP_A_FILL_PRIO 1  // ... and, lower, while a band's move decision (v_readlane -> scalar compare -> branch) is in flight: the wave cannot
+#endif                    // issue the next band before it resolves; 43.8 -> 42.6 ms
 
 namespace {
 
@@ -226,6 +232,9 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
         n0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(R.ev, F.eo0 + 4 * POS, 0, 0));
         n1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(R.ev, F.eo1 + 4 * POS, 0, 0));
         asm volatile("" : "+v"(x0), "+v"(x1));
+#if NP_A_FILL_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
     // left sources: an odd slot's is the lane's own even slot, an even slot's the previous lane's odd slot
     const float l0 = wave_ror1_all(F.p1);
@@ -283,6 +292,9 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
     // the unmasked maxima are the cells.)
     int xs = 0, ys = 0;
     if (FAST && !(NP_ABL & 4)) {
+#if NP_A_FILL_PRIO
+        if (POS >= 0) __builtin_amdgcn_s_setprio(NP_A_FILL_PRIO);
+#endif
         xs = __builtin_amdgcn_readlane(__builtin_bit_cast(int, m0), F.sel0);
         ys = __builtin_amdgcn_readlane(__builtin_bit_cast(int, m1), F.sel1);
         asm volatile("" : "+s"(xs), "+s"(ys));
@@ -536,6 +548,9 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
             __builtin_amdgcn_s_waitcnt(0);
 
             if (best_u != NP_NEG_INF && !(NP_ABL & 128)) {
+#if NP_A_WALK_PRIO
+                __builtin_amdgcn_s_setprio(NP_A_WALK_PRIO);
+#endif
                 // Scalar walk.  The kernel is instruction-issue bound (~2.3 cycles per wave-instruction of any kind, measured
                 // with tools/align_variants.sh probes), and a walk of ~0.63 steps per band is a fifth of its instructions, so
                 // the step is written out by hand: 20 instructions.
@@ -672,6 +687,9 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
                     }
                 }
                 sum_emission = tot;
+#if NP_A_WALK_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
         }
         {
