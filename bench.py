@@ -499,9 +499,10 @@ def main():
         a_avg_s = a_ms / max(a_n, 1) * 1e-3
         algo = res["algo"]
         achieved = algo / a_avg_s / 1e9 if a_avg_s > 0 else 0.0
-        # HBM traffic and instruction counts per launch from the PMC passes (profiles/collect_pmc.sh + profiles/pmc_summary.py ->
-        # profiles/r02_pmc.json): FETCH_SIZE + WRITE_SIZE per read of this kernel and SQ_INSTS_VALU / SQ_INSTS_SALU per band step,
-        # measured on this workload shape at this batch size in separate rocprofv3 --pmc runs
+        # HBM traffic per launch and the issue model of the kernel (profiles/r02_pmc.json): FETCH_SIZE + WRITE_SIZE per read from
+        # rocprofv3 --pmc passes over this kernel; instructions per band step counted in the generated assembly
+        # (tools/count_isa.py); vector-issue cycles per band from the occupancy scan (per-wave band time 370 + 157 w cycles at
+        # w resident waves per SIMD: 157 cycles of issue time, the rest latency that eight waves do not hide)
         traffic, issue = None, None
         n_bands = res["band_cells"] // 100
         cyc_per_band = a_avg_s * CLOCK_HZ * N_SIMD / max(n_bands, 1)
@@ -511,14 +512,14 @@ def main():
                 traffic = int((pm["fetch_bytes_per_read"] + pm["write_bytes_per_read"]) * n_reads)
                 valu, salu = pm.get("valu_per_band"), pm.get("salu_per_band")
                 issue = dict(valu_per_band=valu, salu_per_band=salu, simd_cycles_per_band=round(cyc_per_band, 1),
-                             VALUBusy=pm.get("valu_busy_pct"), pmc_source="profiles/" + name,
-                             pmc_reads_per_launch=pm.get("reads_per_launch"))
-                if valu and salu:
-                    # vector issue model: the band step's VALU mix (22 double-rate instructions and ~13
-                    # conversions / DPP / readlane at 4 cycles, the rest at 2; tools/valu_rates.hip) averages 2.8 cycles per
-                    # wave-instruction on a SIMD-32; frac = modelled VALU issue cycles of one band step / SIMD cycles it takes
-                    issue["instructions_per_band"] = round(valu + salu, 1)
-                    issue["cycles_per_instruction"] = round(cyc_per_band / (valu + salu), 2)
+                             source="profiles/" + name, instruction_source=pm.get("instruction_source", "rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU"))
+                port = (pm.get("occupancy_scan") or {}).get("port_cycles_per_band")
+                if port:
+                    # frac: vector-issue cycles one band step needs / SIMD cycles it takes (fill and back-track together)
+                    issue["port_cycles_per_band"] = port
+                    issue["latency_cycles_per_band_at_8_waves"] = round((pm["occupancy_scan"]["latency_cycles_per_band"]) / 8.0, 1)
+                    issue["frac"] = round(port / cyc_per_band, 3)
+                elif valu and salu:
                     issue["frac"] = round(2.8 * valu / cyc_per_band, 3)
                 break
             except Exception:

@@ -1,15 +1,14 @@
 #!/usr/bin/env python3
-"""Assembles profiles/r02_round_end.md from the outputs of `bash profiles/collect_r02_final.sh r02z` and
-`bash tools/gpu_r2_m.sh r02z2` (gpurun_out/r02z, gpurun_out/r02z2).   usage: make_r02_summary.py > profiles/r02_round_end.md"""
+"""Assembles profiles/r02_round_end.md from the outputs of `bash profiles/collect_r02_final.sh <tag>` (gpurun_out/<tag>).
+usage: make_r02_summary.py [tag] > profiles/r02_round_end.md"""
 import csv, glob, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-A = os.path.join(ROOT, "gpurun_out", "r02z"); B = os.path.join(ROOT, "gpurun_out", "r02z2")
+A = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r02f"); B = A
 line = lambda d, f: open(os.path.join(d, f)).read().strip().splitlines()[-1]
 o = []
 o.append("# Round 2 -- end-of-round measurement set (MI355X, 1 GPU)\n")
-o.append("Collected through gpurun with `bash profiles/collect_r02_final.sh r02z` (tests, default bench, configs[0], kernel trace, HBM counters of "
-         "kernel A) and `bash tools/gpu_r2_m.sh r02z2` (from-raw bench, configs[2], configs[3]); raw outputs under `gpurun_out/` (scratch), "
-         "summarised here by `profiles/make_r02_summary.py`.\n")
+o.append("Collected through gpurun with `bash profiles/collect_r02_final.sh` (tests, the bench lines of all four configs, kernel trace, counter passes "
+         "over kernel A alone); raw outputs under `gpurun_out/` (scratch), summarised here by `profiles/make_r02_summary.py`.\n")
 o.append("GPU tests on the same box: `" + [l for l in open(os.path.join(A, "pytest.log")).read().splitlines() if " passed" in l][-1].strip() + "`\n")
 o.append("## Bench lines\n")
 o.append("Default (`python bench.py --steps 5 --warmup 1`): BASELINE.json configs[1] -- 100 000 reads per step (20 000 distinct x 5), ~8k events each, "
@@ -30,21 +29,27 @@ o.append("`rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmu
          "summarised with `profiles/summarize_rocpd.py`; the average duration of `np_event_align_kernel` agrees with `roofline.avg_launch_ms` of the "
          "bench line (HIP events inside bench.py):\n")
 o.append(open(os.path.join(A, "trace.md")).read())
-o.append("\n## HBM traffic of kernel A (PMC)\n")
-o.append("`rocprofv3 --kernel-trace --pmc <counter> -- python tools/align_ab.py --child --pool 1024 --tile 8 --reps 2` -- one counter per pass, a process "
-         "that launches kernel A alone, 8192 reads per launch (counter collection on the full bench command does not finish inside its time limit at "
-         "16 384 or 100 000 reads per launch: only the instruction/wait pass of `profiles/r02_pmc.json` comes from the bench command).  Sums over "
-         "all instances of the counter, per launch of `np_event_align_kernel`:\n")
-o.append("| counter | launches | raw per launch (KB) | correction | bytes per read |\n|---|---|---|---|---|")
-for c, corr in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+PMC_READS = 16384 if os.path.exists(os.path.join(A, "pmc1.log")) else 8192
+o.append("\n## Counters of kernel A (PMC)\n")
+o.append("`rocprofv3 --kernel-trace --pmc <counters> -- python tools/align_ab.py --child --pool 2048 --tile 8 --reps 2` -- one counter set per pass, a "
+         "process that launches kernel A alone, 8192 reads per launch.  Passes that did not finish inside their 150 s limit are listed as such "
+         "(counter collection over these kernels is unpredictable on this pool; the mid-round passes are in `r02_pmc.json`).\n")
+o.append("| pass | counters | outcome |\n|---|---|---|")
+names = {1: "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY",
+         2: "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH", 3: "FETCH_SIZE", 4: "WRITE_SIZE"}
+PMC_DONE = [k for k in (1, 2, 3, 4) if os.path.exists(os.path.join(A, 'pmc%d.log' % k))]
+for k in PMC_DONE:
+    log = os.path.join(A, "pmc%d.log" % k)
+    rc = open(log).read().strip().splitlines()[-1] if os.path.exists(log) else "not run"
     per = {}
-    for f in glob.glob(os.path.join(A, "pmc_" + c, "**", "*counter_collection.csv"), recursive=True):
+    for f in glob.glob(os.path.join(A, "pmc%d" % k, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "np_event_align_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
-                per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
-    if per:
-        v = sum(per.values()) / len(per)
-        o.append("| %s | %d | %.1f | x%g | %.0f |" % (c, len(per), v, corr, v * 1024 * corr / 8192))
-o.append("\n(corrections calibrated in round 1 with `tools/hbm_counter_calib.hip`; the algorithmic figure of SURVEY 8d is 1.45 MB per read -- the kernel moves "
-         "less than that because its trace is 32 B per band instead of the reference's 100 B.)\n")
+            if "np_event_align_kernel" in r["Kernel_Name"]:
+                per.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+                per[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    res = "; ".join("%s = %.1f per launch (%d launches)" % (c, sum(v.values()) / len(v), len(v)) for c, v in sorted(per.items()))
+    o.append("| %d | %s | %s%s |" % (k, names[k], rc, (": " + res) if res else (" (timed out)" if rc == "rc=124" else "")))
+o.append("\nFETCH_SIZE / WRITE_SIZE are in KB: x1024 / reads per launch = bytes per read (corrections x2 / x1, calibrated in round 1 with `tools/hbm_counter_calib.hip`); the "
+         "algorithmic figure of SURVEY 8d is 1.45 MB per read moved in total -- the kernel moves less because its trace is 32 B per band instead of the "
+         "reference's 100 B.\n")
 print("\n".join(o))
