@@ -1,5 +1,4 @@
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r02z6}; mkdir -p $O; cd $R
-( timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -3 ) > $O/pytest.log 2>&1
-cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python $R/bench.py --steps 3 --warmup 1 --pool 8000 --tile 5 --cpu-sample 0 --streamed 0 --ragged 0 > $O/trace.log 2>&1
-cd $R; f=$(find $O/trace -name "*results.db" | head -1); [ -n "$f" ] && python3 profiles/summarize_rocpd.py $f > $O/trace.md
-tail -2 $O/pytest.log; grep "np_cm_\|recalib\|build_map\|resolve" $O/trace.md | cut -c1-150; tail -1 $O/trace.log | cut -c1-300
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r02z8}; mkdir -p $O; cd $R
+V=nanopolish_amd/variants
+timeout 300 python tools/align_ab.py --pool 2048 --tile 16 --reps 4 $V/libnp_hip_strace_nobt.so $V/libnp_hip_nobt.so $V/libnp_hip_strace_nobt.so $V/libnp_hip_nobt.so >> $O/ab.jsonl 2>&1
+cat $O/ab.jsonl
