@@ -1,4 +1,9 @@
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r02z8}; mkdir -p $O; cd $R
-V=nanopolish_amd/variants
-timeout 300 python tools/align_ab.py --pool 2048 --tile 16 --reps 4 $V/libnp_hip_strace_nobt.so $V/libnp_hip_nobt.so $V/libnp_hip_strace_nobt.so $V/libnp_hip_nobt.so >> $O/ab.jsonl 2>&1
-cat $O/ab.jsonl
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r02za}; mkdir -p $O; cd $R
+( timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -5 ) > $O/pytest.log 2>&1
+timeout 300 python bench.py --steps 3 --warmup 1 --pool 8000 --tile 5 --cpu-sample 64 --streamed 0 --ragged 0 > $O/bench.json 2> $O/bench.err
+python - <<PY
+import json
+d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"], d["roofline"]["kernel_ms_per_step"], d["cpu_baseline"].get("check"))
+PY
+tail -4 $O/pytest.log; tail -2 $O/bench.err
