@@ -292,6 +292,11 @@ __global__ void __launch_bounds__(256) np_cm_items_kernel(int n_reads, const cha
     // values of every k-mer are LDS reads instead of dependent global loads (the kernel was bound by those round trips).
 #define NP_ITEM_TILE 512
     __shared__ int t_first[NP_ITEM_TILE + 1], t_sub[NP_ITEM_TILE], t_len[NP_ITEM_TILE];
+    // digit(c) and digit(comp(c)) of every byte value: one LDS read instead of two chains of ten compares and selects per base
+    // (the kernel was bound by those: ~250 vector instructions per k-mer)
+    __shared__ uint8_t t_dig[256], t_dcomp[256];
+    t_dig[threadIdx.x] = (uint8_t)digit((char)threadIdx.x); t_dcomp[threadIdx.x] = (uint8_t)digit(comp((char)threadIdx.x));
+    const uint32_t dma = (uint32_t)digit(s.ma), dmb = (uint32_t)digit(s.mb), dca = (uint32_t)digit(s.ca), dcb = (uint32_t)digit(s.cb);
     for (int tile = 0; tile < ng; tile += NP_ITEM_TILE) {
     const int tn = ng - tile < NP_ITEM_TILE ? ng - tile : NP_ITEM_TILE;
     const int64_t base = group_rank_off[g0 + tile];
@@ -331,23 +336,26 @@ __global__ void __launch_bounds__(256) np_cm_items_kernel(int n_reads, const cha
                 if (!rc) { ru = ru * 5u + (uint32_t)digit(c); rm = rm * 5u + (uint32_t)digit(cm); }
                 else { ru += pw * (uint32_t)digit(comp(c)); rm += pw * (uint32_t)digit(crc); pw *= 5u; }
             }
-        } else if (!rc) {
-            for (int q = i; q < i + k; ++q) {
-                const char nxt = q + 1 < len ? ref[sub_start + q + 1] : 0;
-                const char cm = (cur == s.a && nxt == s.b) ? s.ma : ((cur == s.b && prev == s.a) ? s.mb : cur);
-                ru = ru * 5u + (uint32_t)digit(cur);
-                rm = rm * 5u + (uint32_t)digit(cm);
-                prev = cur; cur = nxt;
-            }
         } else {
-            uint32_t pw = 1;                                           // window position q contributes digit * 5^(q - i)
+            // the k-mer's digits and its methylated twin's: a base is replaced when it is the first base of a whole site (next base
+            // is the site's second) or the second base of one (previous base is its first), inside the window
+            bool pa = prev == s.a, ca_ = cur == s.a, cb_ = cur == s.b;
+            uint32_t pw = 1;                                           // reverse strand: window position q contributes digit * 5^(q - i)
             for (int q = i; q < i + k; ++q) {
                 const char nxt = q + 1 < len ? ref[sub_start + q + 1] : 0;
-                const char cm = (cur == s.a && nxt == s.b) ? s.ca : ((cur == s.b && prev == s.a) ? s.cb : comp(cur));
-                ru += pw * (uint32_t)digit(comp(cur));
-                rm += pw * (uint32_t)digit(cm);
-                pw *= 5u;
-                prev = cur; cur = nxt;
+                const bool na = nxt == s.a, nb = nxt == s.b;
+                const bool site1 = ca_ && nb, site2 = cb_ && pa;
+                if (!rc) {
+                    const uint32_t d = t_dig[(uint8_t)cur];
+                    ru = ru * 5u + d;
+                    rm = rm * 5u + (site1 ? dma : (site2 ? dmb : d));
+                } else {
+                    const uint32_t d = t_dcomp[(uint8_t)cur];
+                    ru += pw * d;
+                    rm += pw * (site1 ? dca : (site2 ? dcb : d));
+                    pw *= 5u;
+                }
+                pa = ca_; ca_ = na; cb_ = nb; cur = nxt;
             }
         }
         job_ranks[ro + i] = (uint16_t)ru;
