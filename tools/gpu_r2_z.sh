@@ -1,9 +1,13 @@
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r02zc}; mkdir -p $O; cd $R
-( timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -5 ) > $O/pytest.log 2>&1
-timeout 300 python bench.py --steps 3 --warmup 1 --pool 8000 --tile 5 --cpu-sample 64 --streamed 0 --ragged 0 > $O/bench.json 2> $O/bench.err
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r02ze}; mkdir -p $O; cd $R
+timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
+NP_BENCH_BACKEND=gloo timeout 400 python bench.py --gpus 2 --steps 2 --warmup 1 --pool 4000 --tile 2 --cpu-sample 0 --streamed 0 --ragged 0 > $O/bench_2rank.json 2> $O/bench_2rank.err
+timeout 300 python bench.py --gpus 1 --steps 2 --warmup 1 --pool 4000 --tile 2 --cpu-sample 0 --streamed 0 --ragged 0 > $O/bench_1rank.json 2> $O/bench_1rank.err
 python - <<PY
 import json
-d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1])
-print(d["value"], d["ms_per_step"], d["roofline"]["kernel_ms_per_step"], d["cpu_baseline"].get("check"))
+for f in ("bench_2rank","bench_1rank"):
+    try:
+        d=json.loads(open("$O/%s.json"%f).read().strip().splitlines()[-1])
+        print(f, d["n_gpus"], d["value"], d["ms_per_step"], d.get("site_table"))
+    except Exception as e:
+        print(f, "FAILED", e, open("$O/%s.err"%f).read()[-600:])
 PY
-tail -3 $O/pytest.log
