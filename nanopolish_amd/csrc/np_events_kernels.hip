@@ -25,6 +25,9 @@
 #define NP_ED_HALO 16          // >= the largest window (event_detection_rna: 14)
 #define NP_ED_WARMUP 256       // samples a segment of the parallel peak walk starts early (see np_ed_peaks_par_kernel)
 #define NP_ED_PAR_MIN 2048     // reads shorter than this take the lane-per-read walk
+#ifndef NP_ED_FUSED
+#define NP_ED_FUSED 1          // long reads: t-statistics computed inside the peak walk (DNA windows), no t-statistic array
+#endif
 
 namespace {
 
@@ -147,11 +150,13 @@ __device__ __forceinline__ float tstat_from_sums(double sum1, double sumsq1, dou
 }
 
 __global__ void __launch_bounds__(NP_ED_TILE) np_ed_tstat_kernel(int n_reads, const float* __restrict__ raw, const int64_t* __restrict__ raw_off,
-                                                                 const int32_t* __restrict__ status, int w1, int w2, float2* __restrict__ tstat)
+                                                                 const int32_t* __restrict__ status, int w1, int w2, float2* __restrict__ tstat,
+                                                                 int64_t skip_from)
 {
     const int r = blockIdx.x;                               // (reads on x: the y extent of a grid stops at 65535)
     if (r >= n_reads || status[r] != 0) return;
     const int64_t n = raw_off[r + 1] - raw_off[r];
+    if (n >= skip_from) return;                             // served by the fused walk (np_ed_peaks_par_kernel<true>)
     const int64_t base = (int64_t)blockIdx.y * NP_ED_TILE;
     if (base >= n) return;
     const float* x = raw + raw_off[r];
@@ -340,7 +345,77 @@ __device__ __forceinline__ void walk_segment(const float2* __restrict__ ts_all, 
     }
 }
 
-__global__ void __launch_bounds__(64) np_ed_peaks_par_kernel(int n_reads, const int64_t* __restrict__ raw_off, const float2* __restrict__ tstat,
+// The same walk with the t-statistics computed on the fly from the raw samples (windows 3 and 6, the DNA defaults): no
+// t-statistic array is written or read for these reads (8 bytes per sample each way, 115 GB per 100 000 reads).  Each lane
+// streams ITS segment of the read in blocks of 8 samples through a range-checked descriptor over the read (samples before the
+// first or after the last read as 0, which is what compute_tstat's window sums see there), keeps three blocks in registers
+// and slides the eight window sums -- sample and fp32-square sums of the 3- and 6-sample windows left and right of the
+// position -- by one sample per step: np_ed_check_kernel has proved every such addition exact, so the slid sums ARE the
+// window sums, and tstat_from_sums is the arithmetic of np_ed_tstat_kernel.
+template <bool RECORD>
+__device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int n, int begin, int end, int trip, bool lane_active,
+                                                 walk_state& st, const np_detector_param& p, uint32_t* tmp, int tmp_cap, int& cnt)
+{
+    constexpr int WA = 3, WB = 6;
+    int blk = begin >> 3;                                     // this lane's first block of 8 samples (read-relative)
+    const int n_blk = (trip + 7) / 8 + 1;                     // a misaligned range of `trip` samples touches at most this many
+    float W[24];                                              // blocks blk-1, blk, blk+1
+    auto load_block = [&](int b, float* dst) {
+        const bool need = lane_active && b >= 0 && b * 8 < n;
+        const float4 lo = need ? buf_f32x4(xr, 32 * b) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 hi = need ? buf_f32x4(xr, 32 * b + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dst[0] = lo.x; dst[1] = lo.y; dst[2] = lo.z; dst[3] = lo.w; dst[4] = hi.x; dst[5] = hi.y; dst[6] = hi.z; dst[7] = hi.w;
+    };
+    load_block(blk - 1, W); load_block(blk, W + 8); load_block(blk + 1, W + 16);
+    // window sums at the block's first sample i = 8 blk: left [i - w, i), right [i, i + w)
+    double s3l = 0, q3l = 0, s6l = 0, q6l = 0, s3r = 0, q3r = 0, s6r = 0, q6r = 0;
+#pragma unroll
+    for (int j = 1; j <= WB; ++j) {
+        const float a = W[8 - j], b = W[7 + j];
+        const double ad = (double)a, aq = (double)(a * a), bd = (double)b, bq = (double)(b * b);
+        s6l += ad; q6l += aq; s6r += bd; q6r += bq;
+        if (j <= WA) { s3l += ad; q3l += aq; s3r += bd; q3r += bq; }
+    }
+    const int w1 = (int)p.window_length1, w2 = (int)p.window_length2;       // (3, 6) or (6, 3): which statistic feeds which detector
+    float nxt[8];
+    for (int t = 0; t < n_blk; ++t) {
+        load_block(blk + 2, nxt);                             // one block ahead of the window
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = blk * 8 + q;
+            const bool in = lane_active && i >= begin && i < end;
+            const float ta = tstat_from_sums(s3l, q3l, s3r, q3r, i, n, WA);
+            const float tb = tstat_from_sums(s6l, q6l, s6r, q6r, i, n, WB);
+            const float t1 = w1 < w2 ? ta : tb, t2 = w1 < w2 ? tb : ta;
+            int pos;
+            if (detector_step<0>(st.d0, st.d1, in ? i : -1, t1, p.peak_height, p.threshold1, w1, pos) && RECORD) {
+                if (cnt < tmp_cap) tmp[cnt] = (uint32_t)pos;
+                cnt++;
+            }
+            if (detector_step<1>(st.d1, st.d0, in ? i : -1, t2, p.peak_height, p.threshold2, w2, pos) && RECORD) {
+                if (cnt < tmp_cap) tmp[cnt] = (uint32_t)pos;
+                cnt++;
+            }
+            // slide to i + 1: the sample at i moves from the right windows to the left ones
+            const int c = 8 + q;
+            const float x0 = W[c], l3 = W[c - WA], l6 = W[c - WB], r3 = W[c + WA], r6 = W[c + WB];
+            const double x0d = (double)x0, x0q = (double)(x0 * x0);
+            s3l += x0d - (double)l3; q3l += x0q - (double)(l3 * l3);
+            s6l += x0d - (double)l6; q6l += x0q - (double)(l6 * l6);
+            s3r += (double)r3 - x0d; q3r += (double)(r3 * r3) - x0q;
+            s6r += (double)r6 - x0d; q6r += (double)(r6 * r6) - x0q;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) W[j] = W[j + 8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) W[16 + j] = nxt[j];
+        blk += 1;
+    }
+}
+
+template <bool FUSED>
+__global__ void __launch_bounds__(64, 3) np_ed_peaks_par_kernel(int n_reads, const int64_t* __restrict__ raw_off, const float2* __restrict__ tstat,
+                                                              const float* __restrict__ raw,
                                                               const int32_t* __restrict__ status, np_detector_param p,
                                                               const int64_t* __restrict__ event_off, uint32_t* __restrict__ event_start,
                                                               uint32_t* __restrict__ scratch_a, uint32_t* __restrict__ scratch_b,
@@ -368,9 +443,12 @@ __global__ void __launch_bounds__(64) np_ed_peaks_par_kernel(int n_reads, const 
     const detector fresh = {0, -1, 3.40282347e+38f, 0};            // DEF_PEAK_POS, DEF_PEAK_VAL = FLT_MAX
     walk_state st = {fresh, fresh};
     int cnt = 0;
-    walk_segment<false>(tstat, base, begin, start, warmup, start < end, st, p, tmp, tmp_cap, cnt);   // warm-up, nothing recorded
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(raw + base, (uint32_t)n * 4u);
+    if (FUSED) walk_segment_raw<false>(xr, n, begin, start, warmup, start < end, st, p, tmp, tmp_cap, cnt);
+    else walk_segment<false>(tstat, base, begin, start, warmup, start < end, st, p, tmp, tmp_cap, cnt);   // warm-up, nothing recorded
     walk_state entry = st;                                                                           // state at the segment's first sample
-    walk_segment<true>(tstat, base, start, end, S, start < end, st, p, tmp, tmp_cap, cnt);
+    if (FUSED) walk_segment_raw<true>(xr, n, start, end, S, start < end, st, p, tmp, tmp_cap, cnt);
+    else walk_segment<true>(tstat, base, start, end, S, start < end, st, p, tmp, tmp_cap, cnt);
 
     // verification / repair rounds
     for (int round = 0; round < 64; ++round) {
@@ -382,7 +460,8 @@ __global__ void __launch_bounds__(64) np_ed_peaks_par_kernel(int n_reads, const 
         if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;
         walk_state redo = left;
         int c2 = 0;
-        walk_segment<true>(tstat, base, start, end, S, bad, redo, p, tmp, tmp_cap, c2);
+        if (FUSED) walk_segment_raw<true>(xr, n, start, end, S, bad, redo, p, tmp, tmp_cap, c2);
+        else walk_segment<true>(tstat, base, start, end, S, bad, redo, p, tmp, tmp_cap, c2);
         if (bad) { st = redo; entry = left; cnt = c2; }
     }
 
@@ -520,14 +599,22 @@ hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t*
     if (n_reads <= 0) return hipSuccess;
     hipLaunchKernelGGL(np_ed_check_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, raw, raw_off, status);
     const unsigned tiles = (unsigned)((max_samples + NP_ED_TILE - 1) / NP_ED_TILE);
+    // reads of NP_ED_PAR_MIN samples and more compute their t-statistics inside the peak walk when the windows are the DNA
+    // defaults (3 and 6 samples); other window lengths (RNA: 7 and 14) and short reads go through the t-statistic array
+    const bool fused = NP_ED_FUSED && ((p.window_length1 == 3 && p.window_length2 == 6) || (p.window_length1 == 6 && p.window_length2 == 3));
     if (tiles > 0)
         hipLaunchKernelGGL(np_ed_tstat_kernel, dim3(n_reads, tiles), dim3(NP_ED_TILE), 0, s, n_reads, raw, raw_off, status,
-                           (int)p.window_length1, (int)p.window_length2, tstat);
+                           (int)p.window_length1, (int)p.window_length2, tstat, fused ? (int64_t)NP_ED_PAR_MIN : INT64_MAX);
     hipLaunchKernelGGL(np_ed_peaks_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, raw_off, tstat, status, p, event_off,
                        event_start, n_events);
-    if (max_samples >= NP_ED_PAR_MIN)
-        hipLaunchKernelGGL(np_ed_peaks_par_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, raw_off, tstat, status, p, event_off, event_start,
-                           (uint32_t*)event_length, (uint32_t*)event_mean, (uint32_t*)event_stdv, n_events, warmup < 0 ? NP_ED_WARMUP : warmup);
+    if (max_samples >= NP_ED_PAR_MIN) {
+        if (fused)
+            hipLaunchKernelGGL(np_ed_peaks_par_kernel<true>, dim3(n_reads), dim3(64), 0, s, n_reads, raw_off, tstat, raw, status, p, event_off, event_start,
+                               (uint32_t*)event_length, (uint32_t*)event_mean, (uint32_t*)event_stdv, n_events, warmup < 0 ? NP_ED_WARMUP : warmup);
+        else
+            hipLaunchKernelGGL(np_ed_peaks_par_kernel<false>, dim3(n_reads), dim3(64), 0, s, n_reads, raw_off, tstat, raw, status, p, event_off, event_start,
+                               (uint32_t*)event_length, (uint32_t*)event_mean, (uint32_t*)event_stdv, n_events, warmup < 0 ? NP_ED_WARMUP : warmup);
+    }
     (void)max_events;
     hipLaunchKernelGGL(np_ed_events_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, raw, raw_off, event_off, event_start,
                        n_events, event_length, event_mean, event_stdv);
