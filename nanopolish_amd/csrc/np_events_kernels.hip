@@ -23,7 +23,9 @@
 
 #define NP_ED_TILE 256
 #define NP_ED_HALO 16          // >= the largest window (event_detection_rna: 14)
-#define NP_ED_WARMUP 256       // samples a segment of the parallel peak walk starts early (see np_ed_peaks_par_kernel)
+#define NP_ED_WARMUP 64        // samples a segment of the parallel peak walk starts early (see np_ed_peaks_par_kernel): results never depend on
+                               // it; with the t-statistics computed inside the walk a warm-up sample costs as much as a real one, and the rare
+                               // repair rounds of a short warm-up cost less than a long one (256 / 128 / 64 / 32: 17.2 / 16.3 / 15.8 / 15.6 ms)
 #define NP_ED_PAR_MIN 2048     // reads shorter than this take the lane-per-read walk
 #ifndef NP_ED_FUSED
 #define NP_ED_FUSED 1          // long reads: t-statistics computed inside the peak walk (DNA windows), no t-statistic array
