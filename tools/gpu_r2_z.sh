@@ -1,9 +1,6 @@
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r02zj}; mkdir -p $O; cd $R
-for w in 256 128 64 32; do
-NP_ED_WARMUP=$w timeout 400 python bench.py --steps 2 --warmup 1 --pool 4000 --tile 5 --from-raw 1 --cpu-sample 32 --streamed 0 --ragged 0 > $O/bench_$w.json 2> $O/bench_$w.err
-python - <<PY
-import json
-d=json.loads(open("$O/bench_$w.json").read().strip().splitlines()[-1])
-print("warmup $w", d["ms_per_step"], d["roofline"]["kernel_ms_per_step"]["event_detect"], d["cpu_baseline"]["check"]["pairs_bit_exact"], d["cpu_baseline"]["check"]["max_abs_dLLR"])
-PY
-done
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r02fin}; mkdir -p $O; cd $R
+( time timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -6 ) > $O/pytest.log 2>&1
+timeout 500 python bench.py --steps 5 --warmup 1 > $O/bench_default.json 2> $O/bench_default.err
+timeout 500 python bench.py --steps 3 --warmup 1 --from-raw 1 --cpu-sample 256 > $O/bench_from_raw.json 2> $O/bench_from_raw.err
+timeout 400 python bench.py --workload eventalign --steps 3 --warmup 1 > $O/bench_eventalign.json 2> $O/bench_eventalign.err
+tail -4 $O/pytest.log; for f in default from_raw eventalign; do tail -c 200 $O/bench_$f.json; echo; done
