@@ -18,6 +18,7 @@
 // The t-statistics are embarrassingly parallel (one thread per sample, neighbours through LDS).  The short/long peak
 // picker is a sequential state machine per read: one lane per read, 64 reads per wave, t-statistics streamed with
 // a four-sample register prefetch.  Event means/stdv are one thread per event.
+#include <algorithm>
 #include "np_kernels.h"
 #include "np_log.h"
 
@@ -604,8 +605,11 @@ hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t*
     // reads of NP_ED_PAR_MIN samples and more compute their t-statistics inside the peak walk when the windows are the DNA
     // defaults (3 and 6 samples); other window lengths (RNA: 7 and 14) and short reads go through the t-statistic array
     const bool fused = NP_ED_FUSED && ((p.window_length1 == 3 && p.window_length2 == 6) || (p.window_length1 == 6 && p.window_length2 == 3));
-    if (tiles > 0)
-        hipLaunchKernelGGL(np_ed_tstat_kernel, dim3(n_reads, tiles), dim3(NP_ED_TILE), 0, s, n_reads, raw, raw_off, status,
+    // (fused: only reads shorter than NP_ED_PAR_MIN still need the array -- a grid of eight tiles per read instead of one per 256
+    //  samples of the longest read)
+    const unsigned t_tiles = fused ? std::min<unsigned>(tiles, (NP_ED_PAR_MIN + NP_ED_TILE - 1) / NP_ED_TILE) : tiles;
+    if (t_tiles > 0)
+        hipLaunchKernelGGL(np_ed_tstat_kernel, dim3(n_reads, t_tiles), dim3(NP_ED_TILE), 0, s, n_reads, raw, raw_off, status,
                            (int)p.window_length1, (int)p.window_length2, tstat, fused ? (int64_t)NP_ED_PAR_MIN : INT64_MAX);
     hipLaunchKernelGGL(np_ed_peaks_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, raw_off, tstat, status, p, event_off,
                        event_start, n_events);
