@@ -177,3 +177,46 @@ def test_restated_libm_matches_this_hosts_libm():
     bad = C.c_uint64(1)
     assert _l.load_library().np_selftest_libm(2000000, 20260924, C.byref(bad)) == 0
     assert bad.value == 0, "%d of 6M restated log/exp/logf values differ from this host's libm" % bad.value
+
+
+def test_host_batches_concatenate_and_tile_like_one_build(models):
+    """bench.py prepares its reads in chunks on a pool of processes and tiles the pool: joining chunks (concat_host_batches)
+    must give what one build over the whole id range gives, and a tiled batch must be its copies back to back with every
+    offset shifted (tile_host_batch)."""
+    from nanopolish_amd.pipeline import build_host_batch, concat_host_batches, tile_host_batch
+    ids = np.arange(6)
+    whole = build_host_batch(models, ids, L=400, raw=True, adc=True)
+    parts = concat_host_batches([build_host_batch(models, ids[:2], L=400, raw=True, adc=True),
+                                 build_host_batch(models, ids[2:5], L=400, raw=True, adc=True),
+                                 build_host_batch(models, ids[5:], L=400, raw=True, adc=True)])
+    assert parts["n"] == whole["n"] == 6
+    for key in ("events", "ranks", "job_ranks", "kpos", "event_off", "rank_off", "job_off", "raw", "raw_off", "adc", "adc_offset", "adc_unit"):
+        assert np.array_equal(parts[key], whole[key]), key
+    for key in ("reads_a", "reads_b", "jobs"):
+        assert parts[key].tobytes() == whole[key].tobytes(), key
+    assert parts["ref_seqs"] == whole["ref_seqs"]
+
+    t = tile_host_batch(whole, 3)
+    assert t["n"] == 18 and len(t["events"]) == 3 * len(whole["events"]) and len(t["jobs"]) == 3 * len(whole["jobs"])
+    ne, nr = len(whole["events"]), len(whole["ranks"])
+    for c in range(3):
+        a = t["reads_a"][6 * c:6 * (c + 1)]
+        assert np.array_equal(a["event_off"], whole["reads_a"]["event_off"] + c * ne)
+        assert np.array_equal(a["rank_off"], whole["reads_a"]["rank_off"] + c * nr)
+        assert np.array_equal(t["events"][c * ne:(c + 1) * ne], whole["events"])
+        j = t["jobs"][len(whole["jobs"]) * c:len(whole["jobs"]) * (c + 1)]
+        assert np.array_equal(j["read"], whole["jobs"]["read"] + 6 * c)
+    assert np.array_equal(t["event_off"], np.concatenate([whole["event_off"][:-1] + c * ne for c in range(3)] + [[3 * ne]]))
+
+
+def test_bench_host_helpers():
+    """the bench's read-length distribution (deterministic in the read id, clipped, the requested mean) and the CPU count it
+    sizes the reference's OpenMP run with (affinity mask capped by the cgroup quota)"""
+    import bench
+    from nanopolish_amd.hostinfo import usable_cores
+    ids = np.arange(20000)
+    a = bench.ragged_lengths(ids, 5500)
+    assert np.array_equal(a, bench.ragged_lengths(ids, 5500)) and np.array_equal(a[100:200], bench.ragged_lengths(ids[100:200], 5500))
+    assert a.min() >= 600 and a.max() <= 40000 and abs(a.mean() - 5500) < 120 and a.std() > 2000
+    visible, quota, eff = usable_cores()
+    assert visible >= 1 and 1 <= eff <= visible and (quota is None or eff <= max(1, int(quota + 0.5)))
