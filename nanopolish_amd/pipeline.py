@@ -349,12 +349,17 @@ class CallMethylationBatch:
         self.band_cells = int((100 * bands).sum())
         self.total_events = int(ne.sum())
 
-    def step(self):
+    def step(self, stage=0):
+        """One pass.  stage 1: work items + (event detection +) event alignment only; stage 2: calibration, window bounds and
+        scoring only (a caller that pipelines two batches puts the stages on two streams: the aligner is bound by vector issue
+        and uses no LDS, the scorer by LDS lookup latency); 0: both."""
         L, h = self.ctx.L, self.ctx.h
         p = lambda t: C.c_void_p(t.data_ptr())
         s = C.c_void_p(self.stream) if self.stream else None      # raw hipStream_t (0 / None: the context's own stream)
         ea = self.workload == "eventalign"
         n_jobs = 0 if ea else self.n_jobs
+        if stage == 2:
+            return self._step_score(L, h, p, s, ea, n_jobs)
         if ea:
             pass
         elif self.jobs_on_device and self.by_cigar:
@@ -385,6 +390,11 @@ class CallMethylationBatch:
         rc = L.np_event_align_dev(h, s, self.n_reads, p(self.d_reads_a), p(self.d_events), p(self.d_ranks), self.m_nuc,
                                   self.max_bands, p(self.d_pair_off), p(self.d_pairs), p(self.d_pair_begin), p(self.d_n_pairs))
         self.ctx._chk(rc, "np_event_align_dev")
+        if stage == 1:
+            return
+        return self._step_score(L, h, p, s, ea, n_jobs)
+
+    def _step_score(self, L, h, p, s, ea, n_jobs):
         if self.calibrate:
             rc = L.np_calibrate_resolve_dev(h, s, self.n_reads, p(self.d_reads_b), p(self.d_events), p(self.d_ranks),
                                             self.m_nuc, p(self.d_pair_off), p(self.d_pairs), p(self.d_pair_begin),

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--workers", type=int, default=14)
     ap.add_argument("--parts", type=str, default="1,2,4")
+    ap.add_argument("--stages", type=int, default=1)
     args = ap.parse_args()
     import bench
     import torch
@@ -62,7 +63,24 @@ def main():
             return dict(parts=P, mode=mode, prio=prio, skew_ms=skew_ms, reads_per_round=n_reads, ms_per_round=round(1e3 * dt / args.steps, 2),
                         reads_per_s=round(n_reads * args.steps / dt, 1))
 
+        def run_stages(wa, wb):
+            """stage 1 of every part on one stream, stage 2 on another: one aligner and one scorer in flight at any time"""
+            sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+            def enqueue():
+                for b in batches:
+                    b.stream = sa.cuda_stream; b.step(stage=1)
+                    b.stream = sb.cuda_stream; b.step(stage=2)
+            enqueue(); sync_all()
+            t = time.perf_counter()
+            for _ in range(args.steps):
+                enqueue()
+            sync_all()
+            dt = time.perf_counter() - t
+            return dict(parts=P, mode="stages", reads_per_round=n_reads, ms_per_round=round(1e3 * dt / args.steps, 2), reads_per_s=round(n_reads * args.steps / dt, 1))
+
         print(json.dumps(run("one")), flush=True)
+        if P > 1 and args.stages:
+            print(json.dumps(run_stages(0, 0)), flush=True)
         if P > 1:
             step_ms = 255.0 * n_reads / 100000.0
             print(json.dumps(run("streams")), flush=True)
