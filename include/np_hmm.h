@@ -64,7 +64,9 @@ const char* np_last_error(const np_ctx* ctx);
 const char* np_version(void);
 
 /* Tuning / test knobs (defaults are what bench.py measures): "align_blocks_per_cu", "hmm_blocks_per_cu" (persistent grid
- * sizes), "align_lpt" (1: the event aligner takes the batch's reads longest first; 0: in index order), "ed_warmup" (samples each segment of the parallel peak walk starts early; 0 forces every segment through the
+ * sizes), "align_lpt" (1: the event aligner takes the batch's reads longest first; 0: in index order),
+ * "stream_switch_wait" (1: a call on another stream than the context's previous call waits for that stream's tail; 0: the caller orders
+ * the streams it uses with one context by its own events), "ed_warmup" (samples each segment of the parallel peak walk starts early; 0 forces every segment through the
  * repair path -- results never depend on it), "ea_rows_cap" (events per eventalign segment the chain kernel's scratch holds;
  * a longer segment ends its read with NP_EA_OVERFLOW), "ea_waves_per_cu" (persistent grid of the chain kernel). */
 int np_set_option(np_ctx* ctx, const char* name, int64_t value);

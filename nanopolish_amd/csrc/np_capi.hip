@@ -79,6 +79,7 @@ struct np_ctx {
     std::string err;
     int align_blocks_per_cu = 8, hmm_blocks_per_cu = 2;
     int align_lpt = 1;                // issue the event aligner's reads longest first
+    int stream_switch_wait = 1;       // a call on a new stream waits for the tail of the stream the context used before (0: the caller orders its streams itself)
     int ed_warmup = -1;               // parallel peak walk: samples of warm-up per segment (< 0: the kernel's default)
 };
 
@@ -128,7 +129,7 @@ hipStream_t pick_stream(np_ctx* c, void* s) { return s ? (hipStream_t)s : c->str
 hipStream_t use_stream(np_ctx* c, void* s)
 {
     hipStream_t st = pick_stream(c, s);
-    if (c->have_last_stream && st != c->last_stream && c->switch_ev) {
+    if (c->stream_switch_wait && c->have_last_stream && st != c->last_stream && c->switch_ev) {
         if (hipEventRecord(c->switch_ev, c->last_stream) == hipSuccess) (void)hipStreamWaitEvent(st, c->switch_ev, 0);
         else (void)hipStreamSynchronize(c->last_stream);
     }
@@ -880,6 +881,7 @@ int np_set_option(np_ctx* c, const char* name, int64_t value)
     if (k == "align_blocks_per_cu") c->align_blocks_per_cu = (int)std::max<int64_t>(1, value);
     else if (k == "hmm_blocks_per_cu") c->hmm_blocks_per_cu = (int)std::max<int64_t>(1, value);
     else if (k == "align_lpt") c->align_lpt = value != 0;
+    else if (k == "stream_switch_wait") c->stream_switch_wait = value != 0;
     else if (k == "ed_warmup") c->ed_warmup = (int)value;
     else if (k == "ea_rows_cap") c->ea_rows_cap = (int)std::min<int64_t>(65535, std::max<int64_t>(16, value));
     else if (k == "ea_waves_per_cu") c->ea_waves_per_cu = (int)std::max<int64_t>(1, value);

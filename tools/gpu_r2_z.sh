@@ -1,5 +1,6 @@
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r02zn}; mkdir -p $O; cd $R
-( timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -3 ) > $O/pytest.log 2>&1
-timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
-timeout 200 python bench.py --steps 2 --warmup 1 --pool 4000 --tile 5 --cpu-sample 32 --ragged 0 > $O/bench.json 2> $O/bench.err
-tail -2 $O/pytest.log; tail -1 $O/smoke.log; tail -c 400 $O/bench.json
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r02zo}; mkdir -p $O; cd $R
+for cfg in "4 1" "8 2"; do set -- $cfg
+echo "== kernel A $1 blocks/CU, kernel B $2 blocks/CU" >> $O/overlap.txt
+NP_ALIGN_BLOCKS_PER_CU=$1 NP_HMM_BLOCKS_PER_CU=$2 timeout 100 python tools/overlap_ab.py --parts 2 --steps 4 2>&1 | grep "\"one\"\|stages\|equal\|Error\|error" >> $O/overlap.txt
+done
+cut -c1-170 $O/overlap.txt

@@ -64,18 +64,30 @@ def main():
                         reads_per_s=round(n_reads * args.steps / dt, 1))
 
         def run_stages(wa, wb):
-            """stage 1 of every part on one stream, stage 2 on another: one aligner and one scorer in flight at any time"""
+            """stage 1 (work items + aligner) of every part on one stream, stage 2 (calibration + scoring) on another: one aligner
+            and one scorer in flight at any time.  The parts' contexts leave the ordering to the events recorded here: scoring of a
+            part after its alignment, the next alignment of a part after its scoring."""
             sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+            for c in ctxs:
+                c.set_option("stream_switch_wait", 0)
+            e1 = [torch.cuda.Event() for _ in batches]; e2 = [torch.cuda.Event() for _ in batches]
+            started = [False] * len(batches)
             def enqueue():
-                for b in batches:
-                    b.stream = sa.cuda_stream; b.step(stage=1)
-                    b.stream = sb.cuda_stream; b.step(stage=2)
+                for i, b in enumerate(batches):
+                    if started[i]:
+                        sa.wait_event(e2[i])
+                    b.stream = sa.cuda_stream; b.step(stage=1); e1[i].record(sa)
+                    sb.wait_event(e1[i])
+                    b.stream = sb.cuda_stream; b.step(stage=2); e2[i].record(sb)
+                    started[i] = True
             enqueue(); sync_all()
             t = time.perf_counter()
             for _ in range(args.steps):
                 enqueue()
             sync_all()
             dt = time.perf_counter() - t
+            for c in ctxs:
+                c.set_option("stream_switch_wait", 1)
             return dict(parts=P, mode="stages", reads_per_round=n_reads, ms_per_round=round(1e3 * dt / args.steps, 2), reads_per_s=round(n_reads * args.steps / dt, 1))
 
         print(json.dumps(run("one")), flush=True)
