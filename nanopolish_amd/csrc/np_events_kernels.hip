@@ -15,9 +15,12 @@
 // (samples below ~4 pA in a 130k-sample read would do it) reports NP_ED_INEXACT instead of a result that might differ
 // in the last bit; there is no approximate path.
 //
-// The t-statistics are embarrassingly parallel (one thread per sample, neighbours through LDS).  The short/long peak
-// picker is a sequential state machine per read: one lane per read, 64 reads per wave, t-statistics streamed with
-// a four-sample register prefetch.  Event means/stdv are one thread per event.
+// The t-statistics are embarrassingly parallel (np_ed_tstat_kernel: one thread per sample, neighbours through LDS).  The
+// short/long peak picker is a sequential state machine per read: short reads take one lane per read (64 reads per wave,
+// t-statistics streamed with a four-sample register prefetch); reads of NP_ED_PAR_MIN samples and more are walked as 64
+// segments per read, one per lane, with a checked warm-up (np_ed_peaks_par_kernel) -- and with the DNA windows (3 and 6
+// samples) each lane computes the t-statistics of its segment on the fly from the raw samples, so that no t-statistic array
+// is written or read for them (round 2).  Event means/stdv are one thread per event.
 #include <algorithm>
 #include "np_kernels.h"
 #include "np_log.h"
