@@ -9,7 +9,7 @@ o = []
 o.append("# Round 2 -- end-of-round measurement set (MI355X, 1 GPU)\n")
 o.append("Collected through gpurun with `bash profiles/collect_r02_final.sh` (tests, the bench lines of all four configs, kernel trace, counter passes "
          "over kernel A alone); raw outputs under `gpurun_out/` (scratch), summarised here by `profiles/make_r02_summary.py`.  The tests and the default, "
-         "from-raw and eventalign lines are those of the round's last GPU call (`tools/gpu_r2_z.sh r02fin`, after the event detector's fusion); the variants and "
+         "from-raw and eventalign lines are those of the round's last GPU call (`tools/runs_r02/gpu_r2_z.sh r02fin`, after the event detector's fusion); the variants and "
          "cpu-t1 lines, the kernel trace and the counters are from the collection just before it (r02end: the kernels of the default step did not change in between).\n")
 o.append("GPU tests on the same box: `" + [l for l in open(os.path.join(A, "pytest.log")).read().splitlines() if " passed" in l][-1].strip() + "`\n")
 o.append("## Bench lines\n")
