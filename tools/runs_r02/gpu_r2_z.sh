@@ -1,6 +1,9 @@
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r02zo}; mkdir -p $O; cd $R
-for cfg in "4 1" "8 2"; do set -- $cfg
-echo "== kernel A $1 blocks/CU, kernel B $2 blocks/CU" >> $O/overlap.txt
-NP_ALIGN_BLOCKS_PER_CU=$1 NP_HMM_BLOCKS_PER_CU=$2 timeout 100 python tools/overlap_ab.py --parts 2 --steps 4 2>&1 | grep "\"one\"\|stages\|equal\|Error\|error" >> $O/overlap.txt
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r02zp}; mkdir -p $O; cd $R
+V=nanopolish_amd/variants
+( timeout 300 python -m pytest tests -m gpu -q -k "eventalign or reflevel" 2>&1 | tail -2 ) > $O/pytest.log 2>&1
+for l in eaprio0 cur eaprio0 cur; do
+  NP_HIP_LIB=$R/$V/libnp_hip_$l.so timeout 200 python bench.py --workload eventalign --steps 2 --warmup 1 --cpu-sample 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$l', d['value'], d['ms_per_step'], d['kernel_ms_per_step']['eventalign_chain'])"
 done
-cut -c1-170 $O/overlap.txt
+tail -1 $O/pytest.log
