@@ -62,13 +62,21 @@ np_ctx* np_create(int device, const np_params* params);
 void    np_destroy(np_ctx* ctx);
 const char* np_last_error(const np_ctx* ctx);
 const char* np_version(void);
+/* What np_create's hardware probe found, one line: the clamp-free fast paths rest on two hardware rules -- an LDS read past the
+ * workgroup's allocation returns 0 (the forward kernel's log-sum lookup), a range-checked buffer access outside its descriptor
+ * reads 0 / is dropped (the event aligner's and the chain kernel's prefetches) -- and on every forward kernel owning exactly
+ * one LDS object.  If the LDS rule or the size check fails the context scores with the clamped lookup (same results, ~5 %
+ * slower); if the buffer rule fails np_create fails.  NP_VERBOSE=1 prints the line at np_create; NP_LSE_CLAMP=1 forces the
+ * clamped lookup. */
+const char* np_ctx_info(const np_ctx* ctx);
 
 /* Tuning / test knobs (defaults are what bench.py measures): "align_blocks_per_cu", "hmm_blocks_per_cu" (persistent grid
  * sizes), "align_lpt" (1: the event aligner takes the batch's reads longest first; 0: in index order),
  * "stream_switch_wait" (1: a call on another stream than the context's previous call waits for that stream's tail; 0: the caller orders
  * the streams it uses with one context by its own events), "ed_warmup" (samples each segment of the parallel peak walk starts early; 0 forces every segment through the
  * repair path -- results never depend on it), "ea_rows_cap" (events per eventalign segment the chain kernel's scratch holds;
- * a longer segment ends its read with NP_EA_OVERFLOW), "ea_waves_per_cu" (persistent grid of the chain kernel). */
+ * a longer segment ends its read with NP_EA_OVERFLOW), "ea_waves_per_cu" (persistent grid of the chain kernel), "lse_oor" (0: the forward kernel clamps its log-sum table index;
+ * 1: it relies on the LDS out-of-range rule, the default when np_create's probe passes -- scores never depend on it). */
 int np_set_option(np_ctx* ctx, const char* name, int64_t value);
 
 /* Upload a pore model (PoreModel::states, src/pore_model/nanopolish_poremodel.h:20-67,107): the three
@@ -409,14 +417,26 @@ int np_mom_fill_dev(np_ctx* ctx, void* stream, int n_reads, np_read_dev* reads, 
  * divide on n_samples pseudo-random operand pairs; *n_mismatch must come back 0. */
 int np_selftest_division(np_ctx* ctx, uint64_t n_samples, uint64_t seed, uint64_t* n_mismatch);
 
-/* Device memory for bindings that are not HIP programs themselves (csrc/np_batch_dropin.cpp is plain C++ inside a nanopolish
- * build): allocation on the context's device, and copies enqueued on `stream` (0 = the context's own).  Host buffers of the
- * asynchronous copies must stay valid until np_sync; pageable host memory makes a copy synchronous, as in HIP. */
+/* Device memory, pinned host memory, streams and events for bindings that are not HIP programs themselves
+ * (csrc/np_batch_dropin.cpp is plain C++ inside a nanopolish build).  Copies and fills are plain stream operations enqueued on
+ * `stream` (0 = the context's own): they take no part in the one-stream-at-a-time rule of the compute entry points, so an upload
+ * on one stream can run beside the context's kernels on another -- ordered by the caller's events (np_event_record on the
+ * producing stream, np_stream_wait_event on the consuming one).  Host buffers of asynchronous copies must stay valid until the
+ * copy has completed; pageable host memory makes a copy synchronous, as in HIP: use np_host_alloc (pinned) for staging. */
 void* np_dev_alloc(np_ctx* ctx, size_t bytes);
 void  np_dev_free(np_ctx* ctx, void* p);
+void* np_host_alloc(np_ctx* ctx, size_t bytes);
+void  np_host_free(np_ctx* ctx, void* p);
 int   np_copy_to_device(np_ctx* ctx, void* stream, void* dst_dev, const void* src_host, size_t bytes);
 int   np_copy_to_host(np_ctx* ctx, void* stream, void* dst_host, const void* src_dev, size_t bytes);
 int   np_memset_dev(np_ctx* ctx, void* stream, void* dst_dev, int value, size_t bytes);
+void* np_stream_create(np_ctx* ctx);                 /* a hipStream_t (non-blocking), NULL on failure */
+void  np_stream_destroy(np_ctx* ctx, void* stream);  /* waits for the stream's work first */
+void* np_event_create(np_ctx* ctx);                  /* a hipEvent_t without timing */
+void  np_event_destroy(np_ctx* ctx, void* event);
+int   np_event_record(np_ctx* ctx, void* event, void* stream);
+int   np_stream_wait_event(np_ctx* ctx, void* stream, void* event);
+int   np_event_sync(np_ctx* ctx, void* event);       /* blocks the calling host thread */
 
 /* Synchronise the context's stream (or the given one). */
 int np_sync(np_ctx* ctx, void* stream);

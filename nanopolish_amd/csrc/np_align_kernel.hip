@@ -608,10 +608,13 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
                         // the word (band 8 cg in bits 31..28), above 7 once the walk has left the group
                         const int lb7 = 8 * cg + 5;
                         for (;;) {
-                        int t_, nib_, c_, w_;
+                        int t_, nib_, c_, w_, m0s_;
                         // (the step counter j lives in M0 inside the loop: v_writelane takes its lane select from M0, because a
-                        //  second scalar register next to the data operand would exceed the constant-bus limit)
-                        asm volatile("s_mov_b32 m0, %[j]\n\t"
+                        //  second scalar register next to the data operand would exceed the constant-bus limit.  M0 is saved and
+                        //  restored around the block -- two scalar moves per trace group -- instead of being declared clobbered:
+                        //  the compiler treats it as reserved and makes no promise about a clobbered reserved register)
+                        asm volatile("s_mov_b32 %[m0s], m0\n\t"
+                                     "s_mov_b32 m0, %[j]\n\t"
                                      "1:\n\t"
                                      "s_add_i32 %[t], %[k], %[e]\n\t"
                                      "s_sub_i32 %[nib], %[lb7], %[t]\n\t"
@@ -635,11 +638,12 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
                                      "s_cmp_ge_i32 %[t], 0\n\t"
                                      "s_cbranch_scc1 1b\n\t"
                                      "2:\n\t"
-                                     "s_mov_b32 %[j], m0"
+                                     "s_mov_b32 %[j], m0\n\t"
+                                     "s_mov_b32 m0, %[m0s]"
                                      : [k] "+s"(curr_k), [e] "+s"(curr_e), [j] "+s"(j), [vf] "+v"(vfrom), [from] "+s"(from),
-                                       [t] "=&s"(t_), [nib] "=&s"(nib_), [c] "=&s"(c_), [w] "=&s"(w_)
+                                       [t] "=&s"(t_), [nib] "=&s"(nib_), [c] "=&s"(c_), [w] "=&s"(w_), [m0s] "=&s"(m0s_)
                                      : [wreg] "v"(tq[pos]), [lb7] "s"(lb7)
-                                     : "scc", "m0");
+                                     : "scc");
                         done = (curr_k | curr_e) >> 31;                                 // -1 once either index is negative
                         if (j == 64 || done) flush();
                         if (done || lb7 - (curr_e + curr_k) > 7) break;                    // (else: a chunk boundary inside the group)

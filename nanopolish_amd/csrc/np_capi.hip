@@ -57,9 +57,12 @@ struct np_ctx {
     int n_cu = 256;
     np_params params;
     hipStream_t stream = nullptr;
-    hipStream_t last_stream = nullptr;   // the stream of the most recent compute call (use_stream)
-    bool have_last_stream = false;
+    hipStream_t last_stream = nullptr;   // identity of the stream of the most recent call (use_stream); never dereferenced later:
+                                         // the caller may have destroyed it (torch stream pools, short-lived streams)
+    bool tail_recorded = false;          // switch_ev marks the tail of the most recent call's work
     hipEvent_t switch_ev = nullptr;
+    bool lse_oor = true;                 // forward kernel: clamp-free log-sum lookups (cleared when probe_hardware fails)
+    std::string info;                    // np_ctx_info(): the probe's findings
     std::vector<model_t> models;
     float* d_logsum = nullptr;
     std::vector<float> h_logsum;
@@ -123,18 +126,25 @@ void drain_timing(np_ctx* c)
 
 hipStream_t pick_stream(np_ctx* c, void* s) { return s ? (hipStream_t)s : c->stream; }
 
-// The stream a compute entry point enqueues on.  A context's work queues, counters and scratch are shared by all of its
-// calls, so work on a new stream must not overtake what was enqueued on the previous one (include/np_hmm.h, "ONE stream at
-// a time per context"): on a switch the new stream waits for an event recorded at the old stream's tail.
-hipStream_t use_stream(np_ctx* c, void* s)
+// The stream an entry point enqueues on.  A context's work queues, counters and scratch are shared by all of its calls, so
+// work on a new stream must not overtake what was enqueued on the previous one (include/np_hmm.h, "ONE stream at a time per
+// context").  Every call records the context's switch event at the tail of what it enqueued -- on its own stream, while that
+// stream is certainly alive -- and a call that arrives on a different stream makes its stream wait for that event.  The previous
+// stream's handle is only compared, never used: the caller may have destroyed it in the meantime.
+struct stream_scope {
+    np_ctx* c; hipStream_t s;
+    stream_scope(np_ctx* ctx, hipStream_t st) : c(ctx), s(st) {}
+    stream_scope(const stream_scope&) = delete;
+    stream_scope& operator=(const stream_scope&) = delete;
+    operator hipStream_t() const { return s; }
+    ~stream_scope() { c->tail_recorded = c->switch_ev && hipEventRecord(c->switch_ev, s) == hipSuccess; }
+};
+stream_scope use_stream(np_ctx* c, void* s)
 {
     hipStream_t st = pick_stream(c, s);
-    if (c->stream_switch_wait && c->have_last_stream && st != c->last_stream && c->switch_ev) {
-        if (hipEventRecord(c->switch_ev, c->last_stream) == hipSuccess) (void)hipStreamWaitEvent(st, c->switch_ev, 0);
-        else (void)hipStreamSynchronize(c->last_stream);
-    }
-    c->last_stream = st; c->have_last_stream = true;
-    return st;
+    if (c->stream_switch_wait && c->tail_recorded && st != c->last_stream) (void)hipStreamWaitEvent(st, c->switch_ev, 0);
+    c->last_stream = st;
+    return stream_scope(c, st);
 }
 
 int persistent_blocks(np_ctx* c, int64_t work_items, int per_block, int blocks_per_cu)
@@ -163,7 +173,7 @@ int run_hmm_forward(np_ctx* c, hipStream_t s, int64_t n_jobs, const np_hmm_job_d
         a.logsum = c->d_logsum; a.flank = c->d_flank; a.counter = c->d_counters + 8 + cls; a.out = out;
         const int jobs_per_block = (np_hmm_block_threads(cls) / 64) * (64 / NP_CLASS_SEG[cls]);
         const int nb = persistent_blocks(c, n_jobs, jobs_per_block, c->hmm_blocks_per_cu);
-        NP_HIP(c, np_launch_hmm_forward(cls, a, nb, s));
+        NP_HIP(c, np_launch_hmm_forward(cls, a, nb, c->lse_oor, s));
     }
     return NP_OK;
 }
@@ -221,9 +231,61 @@ static bool model_in_range(np_ctx* c, int n_states, const double* level_mean, co
     return true;
 }
 
+
+// Hardware / toolchain assumptions the clamp-free fast paths rest on, checked once per context (np_hmm_kernels.hip, "Hardware
+// probes").  (a) every forward kernel's static LDS is exactly the log-sum table, (b) LDS reads past the allocation return 0 and
+// np_lse_oor agrees with np_lse bit for bit, (c) range-checked buffer loads return 0 / stores are dropped outside the descriptor.
+// (a) or (b) failing selects the clamped log-sum (slower, same results); (c) failing is fatal: the event aligner and the
+// eventalign chain have no other form.
+static bool probe_hardware(np_ctx* c)
+{
+    char line[512];
+    bool lds_size_ok = true;
+    size_t lds_seen = 0;
+    for (int cls = 0; cls < NP_NUM_CLASSES; ++cls) {
+        size_t b = 0;
+        if (np_hmm_forward_lds_bytes(cls, &b) != hipSuccess || b != NP_LOGSUM_TBL * sizeof(float)) lds_size_ok = false;
+        lds_seen = std::max(lds_seen, b);
+    }
+    float* d_buf = nullptr; uint16_t* d_sbuf = nullptr; uint32_t* d_out = c->d_counters + 64;     // 8 words, zeroed at np_create
+    std::vector<float> ones(32, 1.0f);
+    std::vector<uint16_t> pat(32, (uint16_t)0xa5a5u);
+    uint32_t out[8] = {0};
+    bool ran = hipMalloc((void**)&d_buf, ones.size() * sizeof(float)) == hipSuccess && hipMalloc((void**)&d_sbuf, pat.size() * sizeof(uint16_t)) == hipSuccess;
+    ran = ran && hipMemcpy(d_buf, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    ran = ran && hipMemcpy(d_sbuf, pat.data(), pat.size() * sizeof(uint16_t), hipMemcpyHostToDevice) == hipSuccess;
+    ran = ran && hipMemset(d_out, 0, sizeof(out)) == hipSuccess;
+    ran = ran && np_launch_probe(c->d_logsum, d_buf, d_sbuf, d_out, 4 * c->n_cu, c->stream) == hipSuccess;
+    ran = ran && hipStreamSynchronize(c->stream) == hipSuccess;
+    ran = ran && hipMemcpy(out, d_out, sizeof(out), hipMemcpyDeviceToHost) == hipSuccess;
+    ran = ran && hipMemcpy(pat.data(), d_sbuf, pat.size() * sizeof(uint16_t), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipMemset(d_out, 0, sizeof(out));
+    if (d_buf) (void)hipFree(d_buf);
+    if (d_sbuf) (void)hipFree(d_sbuf);
+    (void)hipGetLastError();
+    bool store_ok = ran;
+    for (int i = 0; i < 16 && store_ok; ++i) store_ok = pat[i] == 0x1234u && pat[16 + i] == 0xa5a5u;
+    const bool ran_all = ran && out[3] == (uint32_t)(4 * c->n_cu);
+    const bool lds_ok = ran_all && lds_size_ok && out[0] == 0 && out[1] == 0;
+    const bool buf_ok = ran_all && out[2] == 0 && store_ok;
+    const char* forced = getenv("NP_LSE_CLAMP");
+    c->lse_oor = lds_ok && !(forced && atoi(forced) != 0);
+    snprintf(line, sizeof(line), "probe: forward-kernel LDS %zu B (%s), reads past the LDS allocation %s (%u non-zero words, %u log-sum mismatches), "
+             "range-checked buffer access %s (%u bad loads, stores %s); log-sum lookup: %s",
+             lds_seen, lds_size_ok ? "the table only" : "NOT the table only", ran_all && out[1] == 0 ? "return 0" : "DO NOT return 0", out[1], out[0],
+             buf_ok ? "ok" : "BROKEN", out[2], store_ok ? "dropped out of range" : "NOT dropped out of range",
+             c->lse_oor ? "clamp-free (np_lse_oor)" : (lds_ok ? "clamped (NP_LSE_CLAMP)" : "clamped (probe failed)"));
+    c->info = line;
+    if (const char* v = getenv("NP_VERBOSE")) if (atoi(v) != 0) fprintf(stderr, "nanopolish_amd: %s\n", line);
+    if (!buf_ok) { g_create_err = std::string("np_create: hardware probe failed: ") + line; return false; }
+    return true;
+}
+
 extern "C" {
 
 const char* np_version(void) { return NP_VERSION_STR; }
+
+const char* np_ctx_info(const np_ctx* ctx) { return ctx ? ctx->info.c_str() : ""; }
 
 const char* np_last_error(const np_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -285,6 +347,7 @@ np_ctx* np_create(int device, const np_params* params)
         return nullptr;
     }
     g_create_err.clear();
+    if (!probe_hardware(c)) { np_destroy(c); return nullptr; }
     return c;
 }
 
@@ -335,7 +398,7 @@ int np_update_model(np_ctx* c, int model, int n_states, const double* level_mean
     if (model < 0 || model >= (int)c->models.size() || n_states != c->models[model].n_states) { c->err = "np_update_model: bad model id or size"; return NP_ERR_INVALID; }
     if (!model_in_range(c, n_states, level_mean, level_stdv)) return NP_ERR_UNSUPPORTED;
     NP_HIP(c, hipSetDevice(c->device));
-    if (c->have_last_stream) NP_HIP(c, hipStreamSynchronize(c->last_stream));     // kernels in flight still read the old table
+    if (c->tail_recorded) NP_HIP(c, hipEventSynchronize(c->switch_ev));           // kernels in flight still read the old table
     NP_HIP(c, hipStreamSynchronize(c->stream));
     std::vector<np_state_dev> st(n_states);
     for (int i = 0; i < n_states; ++i) { st[i].level_mean = level_mean[i]; st[i].level_stdv = level_stdv[i]; st[i].level_log_stdv = level_log_stdv[i]; st[i].pad = 0; }
@@ -351,7 +414,7 @@ int np_selftest_division(np_ctx* c, uint64_t n_samples, uint64_t seed, uint64_t*
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
     unsigned long long* d = (unsigned long long*)(c->d_counters + 32);
-    (void)use_stream(c, nullptr);
+    stream_scope scope = use_stream(c, nullptr);
     NP_HIP(c, hipMemsetAsync(d, 0, sizeof(unsigned long long), c->stream));
     NP_HIP(c, np_launch_selftest_div(n_samples, seed, d, c->stream));
     unsigned long long h = 0;
@@ -380,12 +443,15 @@ void np_dev_free(np_ctx* c, void* p)
     (void)hipFree(p);
 }
 
+// Copies and fills are plain stream operations: they touch none of the context's shared scratch, so they take no part in the
+// one-stream-at-a-time rule (no switch wait, no tail event) -- a caller that uploads on one stream while the context computes on
+// another orders the two with its own events (np_event_record / np_stream_wait_event), as NpBatchPipeline does.
 int np_copy_to_device(np_ctx* c, void* stream, void* dst, const void* src, size_t bytes)
 {
     if (!c || (bytes && (!dst || !src))) return NP_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    if (bytes) NP_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, use_stream(c, stream)));
+    if (bytes) NP_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, pick_stream(c, stream)));
     return NP_OK;
 }
 
@@ -394,7 +460,7 @@ int np_copy_to_host(np_ctx* c, void* stream, void* dst, const void* src, size_t 
     if (!c || (bytes && (!dst || !src))) return NP_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    if (bytes) NP_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, use_stream(c, stream)));
+    if (bytes) NP_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, pick_stream(c, stream)));
     return NP_OK;
 }
 
@@ -403,7 +469,92 @@ int np_memset_dev(np_ctx* c, void* stream, void* dst, int value, size_t bytes)
     if (!c || (bytes && !dst)) return NP_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    if (bytes) NP_HIP(c, hipMemsetAsync(dst, value, bytes, use_stream(c, stream)));
+    if (bytes) NP_HIP(c, hipMemsetAsync(dst, value, bytes, pick_stream(c, stream)));
+    return NP_OK;
+}
+
+// ---- streams, events and pinned host memory for bindings that are not HIP programs themselves ------------------------------
+void* np_host_alloc(np_ctx* c, size_t bytes)
+{
+    if (!c) return nullptr;
+    std::lock_guard<std::mutex> g(c->lock);
+    void* p = nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { c->err = std::string("np_host_alloc: ") + hipGetErrorString(e); return nullptr; }
+    return p;
+}
+
+void np_host_free(np_ctx* c, void* p)
+{
+    if (!c || !p) return;
+    std::lock_guard<std::mutex> g(c->lock);
+    (void)hipSetDevice(c->device);
+    (void)hipHostFree(p);
+}
+
+void* np_stream_create(np_ctx* c)
+{
+    if (!c) return nullptr;
+    std::lock_guard<std::mutex> g(c->lock);
+    hipStream_t s = nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) { c->err = std::string("np_stream_create: ") + hipGetErrorString(e); return nullptr; }
+    return (void*)s;
+}
+
+void np_stream_destroy(np_ctx* c, void* stream)
+{
+    if (!c || !stream) return;
+    std::lock_guard<std::mutex> g(c->lock);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    if (c->last_stream == (hipStream_t)stream) { c->last_stream = nullptr; }      // (its tail event stays valid: events outlive streams)
+    (void)hipStreamDestroy((hipStream_t)stream);
+}
+
+void* np_event_create(np_ctx* c)
+{
+    if (!c) return nullptr;
+    std::lock_guard<std::mutex> g(c->lock);
+    hipEvent_t e = nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (rc != hipSuccess) { c->err = std::string("np_event_create: ") + hipGetErrorString(rc); return nullptr; }
+    return (void*)e;
+}
+
+void np_event_destroy(np_ctx* c, void* ev)
+{
+    if (!c || !ev) return;
+    std::lock_guard<std::mutex> g(c->lock);
+    (void)hipSetDevice(c->device);
+    (void)hipEventDestroy((hipEvent_t)ev);
+}
+
+int np_event_record(np_ctx* c, void* ev, void* stream)
+{
+    if (!c || !ev) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    NP_HIP(c, hipEventRecord((hipEvent_t)ev, pick_stream(c, stream)));
+    return NP_OK;
+}
+
+int np_stream_wait_event(np_ctx* c, void* stream, void* ev)
+{
+    if (!c || !ev) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    NP_HIP(c, hipStreamWaitEvent(pick_stream(c, stream), (hipEvent_t)ev, 0));
+    return NP_OK;
+}
+
+int np_event_sync(np_ctx* c, void* ev)
+{
+    if (!c || !ev) return NP_ERR_INVALID;
+    NP_HIP(c, hipEventSynchronize((hipEvent_t)ev));       // (no lock: other threads keep enqueueing while this one waits)
     return NP_OK;
 }
 
@@ -411,6 +562,7 @@ int np_sync(np_ctx* c, void* stream)
 {
     if (!c) return NP_ERR_INVALID;
     NP_HIP(c, hipStreamSynchronize(pick_stream(c, stream)));
+    std::lock_guard<std::mutex> g(c->lock);          // (other threads may be enqueueing: the timers' event lists are shared)
     drain_timing(c);
     return NP_OK;
 }
@@ -418,6 +570,7 @@ int np_sync(np_ctx* c, void* stream)
 int np_kernel_time(np_ctx* c, int which, double* total_ms, int64_t* launches, int reset)
 {
     if (!c || which < 0 || which >= NP_NUM_FAMILIES) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
     drain_timing(c);
     if (total_ms) *total_ms = c->timing[which].total_ms;
     if (launches) *launches = c->timing[which].launches;
@@ -428,6 +581,7 @@ int np_kernel_time(np_ctx* c, int which, double* total_ms, int64_t* launches, in
 int np_last_kernel_ms(np_ctx* c, int which, float* ms)
 {
     if (!c || which < 0 || which >= NP_NUM_FAMILIES || !ms) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
     drain_timing(c);
     *ms = c->timing[which].last_ms;
     return NP_OK;
@@ -462,7 +616,7 @@ int np_adc_to_pa_dev(np_ctx* c, void* stream, int n_reads, const int16_t* adc, c
     if (!c || n_reads < 0 || (n_reads > 0 && (!adc || !raw_off || !offset || !raw_unit || !raw_pa))) return NP_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = use_stream(c, stream);
+    stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
     family_timer tm(c, 4, s);
     NP_HIP(c, np_launch_adc_to_pa(n_reads, adc, raw_off, max_samples, offset, raw_unit, raw_pa, s));
     return NP_OK;
@@ -475,7 +629,7 @@ int np_site_table_dev(np_ctx* c, void* stream, int64_t n_groups, const float* sc
     if (!c || n_groups < 0 || n_pos < 0 || (n_groups > 0 && (!scores || !first_site || !n_motif || !table)) || (read_base && !jobs)) return NP_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = use_stream(c, stream);
+    stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
     family_timer tm(c, 2, s);
     NP_HIP(c, np_launch_site_table(n_groups, scores, first_site, n_motif, jobs, read_base, call_threshold, n_pos, table, s));
     return NP_OK;
@@ -487,7 +641,7 @@ int np_hmm_score_set_combine_dev(np_ctx* c, void* stream, int64_t n_sets, const 
     if (!c || n_sets < 0 || (n_sets > 0 && (!set_off || !member_scores || !out_scores))) return NP_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = use_stream(c, stream);
+    stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
     family_timer tm(c, 1, s);
     NP_HIP(c, np_launch_score_set_combine(n_sets, set_off, member_idx, member_scores, c->d_logsum, out_scores, s));
     return NP_OK;
@@ -500,7 +654,7 @@ int np_resolve_jobs_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* reads
     if (!c) return NP_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = use_stream(c, stream);
+    stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
     family_timer tm(c, 2, s);
     NP_HIP(c, np_launch_build_map(n_reads, reads, pair_off, pairs, pair_begin, n_pairs, map_start, nullptr, events_per_base,
                                   c->params.hmm_indel_bias_factor, s));
@@ -523,7 +677,7 @@ int np_calibrate_resolve_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* 
     if (model < 0 || model >= (int)c->models.size()) { c->err = "bad model id"; return NP_ERR_INVALID; }
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = use_stream(c, stream);
+    stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
     family_timer tm(c, 2, s);
     NP_HIP(c, np_launch_build_map(n_reads, reads, pair_off, pairs, pair_begin, n_pairs, map_start, map_stop, events_per_base,
                                   c->params.hmm_indel_bias_factor, s));
@@ -598,7 +752,7 @@ int np_hmm_score_host(np_ctx* c, int n_jobs, const np_hmm_job* jobs, float* out_
     int model = -1;
     int rc = pack_hmm_jobs(c, n_jobs, jobs, dj, dr, ev, rk, &model);
     if (rc != NP_OK) return rc;
-    hipStream_t s = use_stream(c, nullptr);
+    stream_scope scope = use_stream(c, nullptr); hipStream_t s = scope.s;
     NP_HIP(c, c->b_jobs.reserve(dj.size() * sizeof(np_hmm_job_dev)));
     NP_HIP(c, c->b_reads.reserve(dr.size() * sizeof(np_read_dev)));
     NP_HIP(c, c->b_events.reserve(ev.size() * sizeof(float)));
@@ -660,7 +814,7 @@ int np_hmm_align_host(np_ctx* c, int n_jobs, const np_hmm_job* jobs, np_hmm_stat
         cell_off[j + 1] = cell_off[j] + e * 3 * (int64_t)dj[j].n_kmers;
         state_off[j + 1] = state_off[j] + e + (int64_t)dj[j].n_kmers + 1;     // path length bound: e rows + n silent K hops
     }
-    hipStream_t s = use_stream(c, nullptr);
+    stream_scope scope = use_stream(c, nullptr); hipStream_t s = scope.s;
     NP_HIP(c, c->b_jobs.reserve(dj.size() * sizeof(np_hmm_job_dev)));
     NP_HIP(c, c->b_reads.reserve(dr.size() * sizeof(np_read_dev)));
     NP_HIP(c, c->b_events.reserve(ev.size() * sizeof(float)));
@@ -732,7 +886,7 @@ int np_event_align_host(np_ctx* c, int n_jobs, const np_align_job* jobs, np_pair
         pair_off[j + 1] = pair_off[j] + nb;
         max_bands = std::max(max_bands, nb);
     }
-    hipStream_t s = use_stream(c, nullptr);
+    stream_scope scope = use_stream(c, nullptr); hipStream_t s = scope.s;
     NP_HIP(c, c->b_reads.reserve(dr.size() * sizeof(np_read_dev)));
     NP_HIP(c, c->b_events.reserve(ev.size() * sizeof(float)));
     NP_HIP(c, c->b_ranks.reserve(rk.size() * sizeof(uint16_t)));
@@ -779,7 +933,7 @@ int np_cm_build_jobs_identity_dev(np_ctx* c, void* stream, int n_reads, const ch
     if (n_reads == 0) return NP_OK;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = use_stream(c, stream);
+    stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
     NP_HIP(c, c->cm_group_rank_off.reserve((size_t)total_group_slots * sizeof(int64_t)));
     family_timer tm(c, 2, s);
     NP_HIP(c, np_launch_cm_build_jobs(n_reads, ref_seq, seq_off, read_rc, alphabet, (int)k, min_separation, min_flank, group_off, rank_off, jobs,
@@ -801,7 +955,7 @@ int np_cm_build_jobs_cigar_dev(np_ctx* c, void* stream, int n_reads, const char*
     if (n_reads == 0) return NP_OK;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = use_stream(c, stream);
+    stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
     const size_t n_idx = (size_t)total_cigar_ops + (size_t)n_reads;
     NP_HIP(c, c->cm_group_rank_off.reserve((size_t)total_group_slots * sizeof(int64_t)));
     NP_HIP(c, c->cm_cigar_scratch.reserve(2 * n_idx * sizeof(int32_t) + (size_t)n_reads * 16 + 2 * (size_t)total_group_slots * sizeof(int32_t)));
@@ -822,7 +976,7 @@ int np_cm_discard_degenerate_dev(np_ctx* c, void* stream, const np_read_dev* rea
     if (!c || n_jobs < 0 || (n_jobs > 0 && (!reads || !map_start || !deg_kpos || !jobs))) return NP_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = use_stream(c, stream);
+    stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
     family_timer tm(c, 2, s);
     NP_HIP(c, np_launch_discard_degenerate(n_jobs, jobs, reads, map_start, deg_kpos, s));
     return NP_OK;
@@ -844,7 +998,7 @@ int np_eventalign_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* r
     if (n_reads == 0) return NP_OK;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = use_stream(c, stream);
+    stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
     const size_t n_idx = (size_t)total_cigar_ops + (size_t)n_reads;
     NP_HIP(c, c->cm_cigar_scratch.reserve(2 * n_idx * sizeof(int32_t) + (size_t)n_reads * 16));
     int32_t* op_ref = c->cm_cigar_scratch.as<int32_t>();
@@ -884,6 +1038,7 @@ int np_set_option(np_ctx* c, const char* name, int64_t value)
     else if (k == "stream_switch_wait") c->stream_switch_wait = value != 0;
     else if (k == "ed_warmup") c->ed_warmup = (int)value;
     else if (k == "ea_rows_cap") c->ea_rows_cap = (int)std::min<int64_t>(65535, std::max<int64_t>(16, value));
+    else if (k == "lse_oor") c->lse_oor = value != 0;          // tests: both log-sum lookups must give the same scores
     else if (k == "ea_waves_per_cu") c->ea_waves_per_cu = (int)std::max<int64_t>(1, value);
     else { c->err = "np_set_option: unknown option " + k; return NP_ERR_INVALID; }
     return NP_OK;
@@ -947,7 +1102,7 @@ int np_detect_events_host(np_ctx* c, int n_reads, const float* const* raw, const
         ev_off[r + 1] = ev_off[r] + ecap;
         max_samples = std::max<int64_t>(max_samples, n_samples[r]); max_events = std::max(max_events, ecap);
     }
-    hipStream_t s = use_stream(c, nullptr);
+    stream_scope scope = use_stream(c, nullptr); hipStream_t s = scope.s;
     const size_t ns = (size_t)raw_off[n_reads], ne = (size_t)ev_off[n_reads];
     NP_HIP(c, c->b_raw.reserve(ns * sizeof(float) + 16));
     NP_HIP(c, c->b_raw_off.reserve(raw_off.size() * sizeof(int64_t)));
@@ -996,7 +1151,7 @@ int np_mom_fill_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* reads, np
     if (n_reads == 0) return NP_OK;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = use_stream(c, stream);
+    stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
     family_timer tm(c, 5, s);
     NP_HIP(c, np_launch_mom_fill(n_reads, reads, reads_b, event_mean, n_events, kmer_rank, c->models[model].d_states, s));
     return NP_OK;

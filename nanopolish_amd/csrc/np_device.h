@@ -30,13 +30,20 @@ struct __attribute__((aligned(32))) np_state_dev {
 // read the same last entry (one broadcast access).  What bounds the kernel is the gather of the remaining third: PMC
 // shows the LDS pipe busy for the whole kernel at 4.2 cycles per ds_read, half of them bank-conflict cycles.
 #define NP_LOGSUM_CUT 15700
+// float -> unsigned as the hardware instruction defines it: truncation, saturation (+inf -> 0xffffffff), NaN -> 0
+__device__ __forceinline__ uint32_t np_cvt_u32_sat(float v)
+{
+    uint32_t r;
+    asm("v_cvt_u32_f32_e32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
 __device__ __forceinline__ float np_lse(float a, float b, const float* __restrict__ tbl)
 {
     const float mx = __builtin_fmaxf(a, b);            // inputs are never NaN (finite or -inf): v_max is exact
     const float d = __builtin_fabsf(a - b);
     // byte offset of the entry without a shift: RN(d * 4000.f) == 4 * RN(d * 1000.f) (scaling by 4 is exact) and
     // trunc(4y) & ~3 == 4 * trunc(y); v_cvt_u32_f32 truncates, saturates (+inf -> 0xffffffff) and maps NaN to 0
-    uint32_t off = (uint32_t)(d * 4000.f) & ~3u;
+    uint32_t off = np_cvt_u32_sat(d * 4000.f) & ~3u;
     off = off < 4u * (NP_LOGSUM_TBL - 1) ? off : 4u * (NP_LOGSUM_TBL - 1);
     return mx + *(const float*)((const char*)tbl + off);
 }
@@ -45,12 +52,20 @@ __device__ __forceinline__ float np_lse(float a, float b, const float* __restric
 // out-of-range rule for DS instructions.  So every offset past the table -- |a-b| >= 16 nats, or +inf when one operand is -inf
 // (the conversion saturates to 0xffffffff) -- reads as the zero the saturated form fetched from the table's zeroed tail.
 // One vector instruction less per log-sum (6 instead of 7); tbl_lds: the table's LDS address.
+// Nothing here is left to the language's undefined corners: the float -> unsigned conversion is the hardware instruction itself
+// (v_cvt_u32_f32 truncates, saturates and maps NaN to 0; a C cast of an out-of-range float is undefined), and the address is
+// formed as an integer (no in-bounds pointer arithmetic the compiler could reason from).  The hardware side -- one LDS object of
+// exactly NP_LOGSUM_TBL * 4 bytes per workgroup, reads past it returning 0 -- is checked at np_create (np_capi.hip:probe_hardware:
+// hipFuncGetAttributes on every forward kernel and a probe kernel over dirtied LDS); if either check fails the context scores
+// with the clamped np_lse instead.
+static_assert((NP_LOGSUM_TBL * 4) % 1280 == 0 && (NP_LOGSUM_TBL * 4) % 512 == 0, "the log-sum table must be a whole number of LDS allocation granules");
 __device__ __forceinline__ float np_lse_oor(float a, float b, const __attribute__((address_space(3))) char* tbl_lds)
 {
     const float mx = __builtin_fmaxf(a, b);
     const float d = __builtin_fabsf(a - b);
-    const uint32_t off = (uint32_t)(d * 4000.f) & ~3u;
-    return mx + *(const __attribute__((address_space(3))) float*)(tbl_lds + off);
+    const uint32_t off = np_cvt_u32_sat(d * 4000.f) & ~3u;
+    const uint32_t addr = (uint32_t)(uintptr_t)tbl_lds + off;
+    return mx + *(const __attribute__((address_space(3))) float*)(uintptr_t)addr;
 }
 __device__ __forceinline__ float np_lse_table_entry(const float* __restrict__ logsum, int i) { return i < NP_LOGSUM_CUT ? logsum[i] : 0.0f; }
 

@@ -20,66 +20,15 @@
 #include "nanopolish_profile_hmm_r7.h"
 #include "nanopolish_raw_loader.h"
 #include "np_hmm.h"
+#include "np_shim_common.h"
 
 extern double hmm_indel_bias_factor;   // src/hmm/nanopolish_profile_hmm_r9.cpp:19 (still the caller-visible knob)
 
+using np_shim::shim;
+
+extern "C" void np_dropin_invalidate_models(void) { shim().invalidate(); }
+
 namespace {
-
-// FNV-1a over the bit patterns of the three per-state doubles the device table holds
-uint64_t model_hash(const PoreModel* m)
-{
-    uint64_t h = 1469598103934665603ull ^ (uint64_t)m->states.size();
-    for (size_t i = 0; i < m->states.size(); ++i) {
-        const double v[3] = {m->states[i].level_mean, m->states[i].level_stdv, m->states[i].level_log_stdv};
-        for (int q = 0; q < 3; ++q) { uint64_t u; memcpy(&u, &v[q], 8); h = (h ^ u) * 1099511628211ull; }
-    }
-    return h;
-}
-
-struct Shim {
-    np_ctx* ctx = nullptr;
-    struct Entry { int id; uint64_t hash; size_t n; };
-    std::map<const PoreModel*, Entry> models;
-    std::mutex lock;
-
-    np_ctx* get()
-    {
-        std::lock_guard<std::mutex> g(lock);
-        if (!ctx) {
-            const char* dev = getenv("NP_DEVICE");
-            ctx = np_create(dev ? atoi(dev) : 0, NULL);
-            if (!ctx) { fprintf(stderr, "nanopolish_amd: %s\n", np_last_error(NULL)); exit(EXIT_FAILURE); }
-        }
-        return ctx;
-    }
-
-    int model_id(const PoreModel* m)
-    {
-        np_ctx* c = get();
-        std::lock_guard<std::mutex> g(lock);
-        // The cache is keyed by address, and the reference overwrites registered models in place
-        // (PoreModelSet::register_model, pore_model_set.cpp:70 -- methyltrain's add_model every round): the entry is only
-        // valid while the content hash matches; otherwise the device copy is refreshed (or re-registered if the size changed).
-        const uint64_t h = model_hash(m);
-        const size_t n = m->states.size();
-        auto it = models.find(m);
-        if (it != models.end() && it->second.hash == h && it->second.n == n) return it->second.id;
-        std::vector<double> lm(n), ls(n), ll(n);
-        for (size_t i = 0; i < n; ++i) { lm[i] = m->states[i].level_mean; ls[i] = m->states[i].level_stdv; ll[i] = m->states[i].level_log_stdv; }
-        if (it != models.end() && it->second.n == n) {
-            const int rc = np_update_model(c, it->second.id, (int)n, lm.data(), ls.data(), ll.data());
-            if (rc != NP_OK) { fprintf(stderr, "nanopolish_amd: np_update_model: %s\n", np_last_error(c)); exit(EXIT_FAILURE); }
-            it->second.hash = h;
-            return it->second.id;
-        }
-        const int id = np_register_model(c, (int)m->k, (int)n, lm.data(), ls.data(), ll.data());
-        if (id < 0) { fprintf(stderr, "nanopolish_amd: np_register_model: %s\n", np_last_error(c)); exit(EXIT_FAILURE); }
-        models[m] = Entry{id, h, n};
-        return id;
-    }
-};
-
-Shim& shim() { static Shim s; return s; }
 
 void fail(const char* what, int rc)
 {

@@ -15,9 +15,6 @@
 #include "np_kernels.h"
 
 #define NP_HMM_BLOCK 512
-#ifndef NP_LSE_OOR
-#define NP_LSE_OOR 1        // forward kernel: log-sum lookups rely on the LDS out-of-range rule instead of clamping the index
-#endif
 
 namespace {
 
@@ -44,18 +41,19 @@ __device__ __forceinline__ int wave_max_i32(int v)
 #ifndef NP_HMM_FWD_BLOCK
 #define NP_HMM_FWD_BLOCK 512
 #endif
-template <int SEG, int C, int BLK>
+// OOR: the log-sum lookups rely on the LDS out-of-range rule (np_lse_oor) instead of clamping the index; np_create selects the
+// clamped instantiation when its hardware probe fails (np_capi.hip:probe_hardware).
+template <int SEG, int C, int BLK, bool OOR>
 __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_args a)
 {
-    __shared__ float tbl[NP_LOGSUM_TBL];
+    __shared__ float tbl[NP_LOGSUM_TBL];          // the kernel's ONLY LDS object (np_lse_oor; checked at np_create)
     for (int i = threadIdx.x; i < NP_LOGSUM_TBL; i += BLK) tbl[i] = np_lse_table_entry(a.logsum, i);
     __syncthreads();
-#if NP_LSE_OOR
     const __attribute__((address_space(3))) char* tbl3 = (const __attribute__((address_space(3))) char*)tbl;
-#define NP_LSE(x, y) np_lse_oor((x), (y), tbl3)
-#else
-#define NP_LSE(x, y) np_lse((x), (y), tbl)
-#endif
+    auto NP_LSE = [&](float x, float y) -> float {
+        if constexpr (OOR) return np_lse_oor(x, y, tbl3);
+        else return np_lse(x, y, tbl);
+    };
 
     constexpr int JPW = 64 / SEG;                 // jobs per wave
     const int lane = threadIdx.x & 63;
@@ -176,7 +174,6 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
     }
 }
 
-#undef NP_LSE
 // ---------------------------------------------------------------------------------------------------
 // Viterbi fill (ProfileHMMViterbiOutputR9, r9.inl:130-197): same sweep, max/arg-max with later-wins ties,
 // lattice + back-pointers streamed to HBM in row-major [row][3*n] (block 0 / terminal block omitted).
@@ -346,12 +343,88 @@ __global__ void np_hmm_backtrack_kernel(np_hmm_args a, int64_t n_jobs_total)
     a.n_states[j] = cnt;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Hardware probes run once per context (np_capi.hip:probe_hardware).  The forward kernel's clamp-free log-sum and the event
+// aligner's / chain kernel's clamp-free prefetches rest on two hardware rules; a device, driver or compiler that breaks one
+// must not produce silently wrong scores:
+//   (1) an LDS read at or beyond the workgroup's allocation returns 0                      (np_lse_oor)
+//   (2) a raw-buffer load outside [0, num_records) returns 0, a store there is dropped      (np_device.h: buf_f32, buf_store_u16)
+// np_probe_dirty_kernel first fills every CU's whole LDS with non-zero words, so that (1) is not satisfied by leftovers.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) np_probe_dirty_kernel(int n_dwords, uint32_t* sink)
+{
+    extern __shared__ uint32_t dyn_lds[];
+    for (int i = threadIdx.x; i < n_dwords; i += 1024) dyn_lds[i] = 0xdeadbeefu ^ (uint32_t)i;
+    __syncthreads();
+    if (dyn_lds[(threadIdx.x * 97) % n_dwords] == 0u) atomicAdd(sink, 1u);        // (keeps the stores alive)
+}
+
+// out[0]: np_lse_oor != np_lse on the probe pairs; out[1]: non-zero words read past the allocation; out[2]: buffer loads that
+// broke rule (2); out[3]: workgroups that ran
+__global__ void __launch_bounds__(NP_HMM_FWD_BLOCK) np_probe_kernel(const float* logsum, const float* buf, uint16_t* sbuf, uint32_t* out)
+{
+    __shared__ float tbl[NP_LOGSUM_TBL];          // the same single LDS object as np_hmm_forward_kernel
+    for (int i = threadIdx.x; i < NP_LOGSUM_TBL; i += NP_HMM_FWD_BLOCK) tbl[i] = np_lse_table_entry(logsum, i);
+    __syncthreads();
+    const __attribute__((address_space(3))) char* tbl3 = (const __attribute__((address_space(3))) char*)tbl;
+    const uint32_t base = (uint32_t)(uintptr_t)tbl3;
+    uint32_t bad_lds = 0, bad_lse = 0, bad_buf = 0;
+    // (1) every word from the end of the allocation to past the end of the CU's LDS (160 KB), and the far offsets the
+    //     saturated conversion produces
+    for (uint32_t o = NP_LOGSUM_TBL * 4u + 4u * threadIdx.x; o < 168u * 1024u; o += 4u * NP_HMM_FWD_BLOCK)
+        bad_lds += *(const volatile __attribute__((address_space(3))) uint32_t*)(uintptr_t)(base + o) != 0u;
+    {
+        const uint32_t far[6] = {0x00100000u, 0x01000000u, 0x7ffffffcu, 0x80000000u, 0xfffffff0u, 0xfffffffcu};
+        for (int i = 0; i < 6; ++i) bad_lds += *(const volatile __attribute__((address_space(3))) uint32_t*)(uintptr_t)(base + far[i]) != 0u;
+    }
+    // the two lookups must agree bit for bit wherever the forward pass can take them
+    {
+        const float inf = __builtin_inff();
+        const float d[16] = {0.0f, 0.00099f, 0.001f, 7.3f, 15.69f, 15.6995f, 15.7f, 15.9999f, 16.0f, 16.0001f, 17.5f, 100.0f, 1.0e6f, 4.0e9f, 1.0e30f, inf};
+        const float x = -1.0f - 0.37f * (float)threadIdx.x;
+        for (int i = 0; i < 16; ++i) {
+            const float y = x - d[i];
+            bad_lse += __builtin_bit_cast(uint32_t, np_lse_oor(x, y, tbl3)) != __builtin_bit_cast(uint32_t, np_lse(x, y, tbl));
+            bad_lse += __builtin_bit_cast(uint32_t, np_lse_oor(y, x, tbl3)) != __builtin_bit_cast(uint32_t, np_lse(y, x, tbl));
+        }
+        bad_lse += np_lse_oor(-inf, -inf, tbl3) != -inf;
+        bad_lse += np_lse_oor(-inf, x, tbl3) != x;
+    }
+    // (2) a descriptor over the first 64 bytes of buf (sixteen 1.0f): in range reads 1, everything else 0
+    if (threadIdx.x < 64) {
+        const __amdgpu_buffer_rsrc_t r = make_rsrc(buf, 64u);
+        const int oob[8] = {-4, -64, 64, 68, 1 << 20, 0x7ffffff0, (int)0x80000000u, (int)0xc0000000u};
+        for (int i = 0; i < 8; ++i) bad_buf += buf_f32(r, oob[i]) != 0.0f;
+        bad_buf += buf_f32(r, 4 * (threadIdx.x & 15)) != 1.0f;
+        // stores: the descriptor covers the first 32 bytes of sbuf; the host checks that the 32 bytes after them kept their pattern
+        const __amdgpu_buffer_rsrc_t w = make_rsrc(sbuf, 32u);
+        buf_store_u16(w, 32 + 2 * (threadIdx.x & 15), 0xffffu);
+        buf_store_u16(w, -2 - 2 * (int)(threadIdx.x & 15), 0xffffu);
+        if (blockIdx.x == 0 && threadIdx.x < 16) buf_store_u16(w, 2 * threadIdx.x, 0x1234u);      // in range: must land
+    }
+    if (bad_lse) atomicAdd(out + 0, bad_lse);
+    if (bad_lds) atomicAdd(out + 1, bad_lds);
+    if (bad_buf) atomicAdd(out + 2, bad_buf);
+    if (threadIdx.x == 0) atomicAdd(out + 3, 1u);
+}
+
 template <int SEG, int C>
-hipError_t launch_fwd(const np_hmm_args& a, int n_blocks, hipStream_t s)
+hipError_t launch_fwd(const np_hmm_args& a, int n_blocks, bool oor, hipStream_t s)
 {
     constexpr int BLK = NP_HMM_FWD_BLOCK;
-    hipLaunchKernelGGL((np_hmm_forward_kernel<SEG, C, BLK>), dim3(n_blocks), dim3(BLK), 0, s, a);
+    if (oor) hipLaunchKernelGGL((np_hmm_forward_kernel<SEG, C, BLK, true>), dim3(n_blocks), dim3(BLK), 0, s, a);
+    else hipLaunchKernelGGL((np_hmm_forward_kernel<SEG, C, BLK, false>), dim3(n_blocks), dim3(BLK), 0, s, a);
     return hipGetLastError();
+}
+// static LDS bytes of the OOR instantiation of a size class: must be exactly the table (np_lse_oor's precondition)
+template <int SEG, int C>
+hipError_t fwd_lds_bytes(size_t* bytes)
+{
+    hipFuncAttributes at;
+    const hipError_t e = hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&np_hmm_forward_kernel<SEG, C, NP_HMM_FWD_BLOCK, true>));
+    if (e == hipSuccess) *bytes = at.sharedSizeBytes;
+    return e;
 }
 template <int SEG, int C>
 hipError_t launch_vit(const np_hmm_args& a, int n_blocks, hipStream_t s)
@@ -365,16 +438,46 @@ hipError_t launch_vit(const np_hmm_args& a, int n_blocks, hipStream_t s)
 int np_hmm_block_threads(int cls) { (void)cls; return NP_HMM_FWD_BLOCK; }
 int np_vit_block_threads(void) { return NP_HMM_BLOCK; }
 
-hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s)
+hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, bool lse_oor, hipStream_t s)
 {
     switch (cls) {
-        case 0: return launch_fwd<2, 8>(a, n_blocks, s);
-        case 1: return launch_fwd<4, 8>(a, n_blocks, s);
-        case 2: return launch_fwd<8, 8>(a, n_blocks, s);
-        case 3: return launch_fwd<16, 8>(a, n_blocks, s);
-        case 4: return launch_fwd<32, 8>(a, n_blocks, s);
-        case 5: return launch_fwd<64, 8>(a, n_blocks, s);
-        case 6: return launch_fwd<64, 16>(a, n_blocks, s);
+        case 0: return launch_fwd<2, 8>(a, n_blocks, lse_oor, s);
+        case 1: return launch_fwd<4, 8>(a, n_blocks, lse_oor, s);
+        case 2: return launch_fwd<8, 8>(a, n_blocks, lse_oor, s);
+        case 3: return launch_fwd<16, 8>(a, n_blocks, lse_oor, s);
+        case 4: return launch_fwd<32, 8>(a, n_blocks, lse_oor, s);
+        case 5: return launch_fwd<64, 8>(a, n_blocks, lse_oor, s);
+        case 6: return launch_fwd<64, 16>(a, n_blocks, lse_oor, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t np_launch_probe(const float* logsum, const float* buf, uint16_t* sbuf, uint32_t* out, int n_blocks, hipStream_t s)
+{
+    // best effort: dirty the whole LDS of every CU first (a launch that cannot get 160 KB of dynamic LDS is simply skipped)
+    const int lds_bytes = 160 * 1024;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&np_probe_dirty_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess) {
+        hipLaunchKernelGGL(np_probe_dirty_kernel, dim3(n_blocks), dim3(1024), lds_bytes, s, lds_bytes / 4, out + 4);
+        (void)hipGetLastError();
+    }
+    hipFuncAttributes at;
+    hipError_t e = hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&np_probe_kernel));
+    if (e != hipSuccess) return e;
+    if (at.sharedSizeBytes != NP_LOGSUM_TBL * sizeof(float)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(np_probe_kernel, dim3(n_blocks), dim3(NP_HMM_FWD_BLOCK), 0, s, logsum, buf, sbuf, out);
+    return hipGetLastError();
+}
+
+hipError_t np_hmm_forward_lds_bytes(int cls, size_t* bytes)
+{
+    switch (cls) {
+        case 0: return fwd_lds_bytes<2, 8>(bytes);
+        case 1: return fwd_lds_bytes<4, 8>(bytes);
+        case 2: return fwd_lds_bytes<8, 8>(bytes);
+        case 3: return fwd_lds_bytes<16, 8>(bytes);
+        case 4: return fwd_lds_bytes<32, 8>(bytes);
+        case 5: return fwd_lds_bytes<64, 8>(bytes);
+        case 6: return fwd_lds_bytes<64, 16>(bytes);
     }
     return hipErrorInvalidValue;
 }

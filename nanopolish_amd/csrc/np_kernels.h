@@ -84,7 +84,10 @@ struct np_align_args {
 static const int NP_CLASS_SEG[NP_NUM_CLASSES] = {2, 4, 8, 16, 32, 64, 64};
 static const int NP_CLASS_C[NP_NUM_CLASSES] = {8, 8, 8, 8, 8, 8, 16};
 
-hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s);
+hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, bool lse_oor, hipStream_t s);
+hipError_t np_hmm_forward_lds_bytes(int cls, size_t* bytes);      // static LDS of the class's clamp-free instantiation
+// hardware probes (np_hmm_kernels.hip): out = 8 x uint32 (zeroed), buf = 16 floats of 1.0f, sbuf = 32 x uint16
+hipError_t np_launch_probe(const float* logsum, const float* buf, uint16_t* sbuf, uint32_t* out, int n_blocks, hipStream_t s);
 hipError_t np_launch_hmm_viterbi(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s);
 hipError_t np_launch_hmm_backtrack(const np_hmm_args& a, int64_t n_jobs, hipStream_t s);
 hipError_t np_launch_event_align(const np_align_args& a, int n_blocks, hipStream_t s);

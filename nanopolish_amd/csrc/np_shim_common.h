@@ -1,0 +1,100 @@
+// np_shim_common.h -- what the two reference-side bindings (np_dropin.cpp: the six per-call entry points; np_batch_dropin.cpp:
+// the batched callers) share: ONE library context per process and ONE cache of the pore models registered on the device.
+// Compiled inside a nanopolish build (C++11), like the files that include it.
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+#include "nanopolish_poremodel.h"
+#include "np_hmm.h"
+
+namespace np_shim {
+
+// FNV-1a over the bit patterns of the three per-state doubles the device table holds, every `step`-th state
+inline uint64_t model_hash(const PoreModel* m, size_t step)
+{
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)m->states.size();
+    for (size_t i = 0; i < m->states.size(); i += step) {
+        const double v[3] = {m->states[i].level_mean, m->states[i].level_stdv, m->states[i].level_log_stdv};
+        for (int q = 0; q < 3; ++q) { uint64_t u; memcpy(&u, &v[q], 8); h = (h ^ u) * 1099511628211ull; }
+    }
+    return h;
+}
+
+struct Shim {
+    np_ctx* ctx;
+    // The cache is keyed by address, and the reference overwrites registered models in place (PoreModelSet::register_model,
+    // src/pore_model/nanopolish_pore_model_set.cpp:70 -- methyltrain's add_model every training round): an entry is only valid
+    // while the model's content matches what was uploaded.  Per call that is checked with a FINGERPRINT (size + 64 evenly spaced
+    // states: a few hundred bytes, so the OpenMP callers of the per-call shim do not serialise on a 100-370 KB hash); the FULL
+    // hash runs when the fingerprint differs or after np_dropin_invalidate_models(), which a caller that edits single states in
+    // place (a training round) calls once per round.
+    struct Entry { int id; uint64_t fingerprint, hash; size_t n; bool check_full; };
+    std::map<const PoreModel*, Entry> models;
+    std::mutex lock;
+    Shim() : ctx(NULL) {}
+
+    np_ctx* get()
+    {
+        std::lock_guard<std::mutex> g(lock);
+        if (!ctx) {
+            const char* dev = getenv("NP_DEVICE");
+            ctx = np_create(dev ? atoi(dev) : 0, NULL);
+            if (!ctx) { fprintf(stderr, "nanopolish_amd: %s\n", np_last_error(NULL)); exit(EXIT_FAILURE); }
+        }
+        return ctx;
+    }
+
+    int model_id(const PoreModel* m)
+    {
+        np_ctx* c = get();
+        std::lock_guard<std::mutex> g(lock);
+        const size_t n = m->states.size();
+        const size_t step = n > 64 ? n / 64 : 1;
+        const uint64_t fp = model_hash(m, step);
+        std::map<const PoreModel*, Entry>::iterator it = models.find(m);
+        if (it != models.end() && it->second.n == n && it->second.fingerprint == fp && !it->second.check_full) return it->second.id;
+        const uint64_t h = model_hash(m, 1);
+        if (it != models.end() && it->second.n == n && it->second.hash == h) {          // invalidated, but unchanged
+            it->second.fingerprint = fp; it->second.check_full = false;
+            return it->second.id;
+        }
+        std::vector<double> lm(n), ls(n), ll(n);
+        for (size_t i = 0; i < n; ++i) { lm[i] = m->states[i].level_mean; ls[i] = m->states[i].level_stdv; ll[i] = m->states[i].level_log_stdv; }
+        if (it != models.end() && it->second.n == n) {
+            const int rc = np_update_model(c, it->second.id, (int)n, lm.data(), ls.data(), ll.data());
+            if (rc != NP_OK) { fprintf(stderr, "nanopolish_amd: np_update_model: %s\n", np_last_error(c)); exit(EXIT_FAILURE); }
+            it->second.fingerprint = fp; it->second.hash = h; it->second.check_full = false;
+            return it->second.id;
+        }
+        const int id = np_register_model(c, (int)m->k, (int)n, lm.data(), ls.data(), ll.data());
+        if (id < 0) { fprintf(stderr, "nanopolish_amd: np_register_model: %s\n", np_last_error(c)); exit(EXIT_FAILURE); }
+        Entry e; e.id = id; e.fingerprint = fp; e.hash = h; e.n = n; e.check_full = false;
+        models[m] = e;
+        return id;
+    }
+
+    void invalidate()
+    {
+        std::lock_guard<std::mutex> g(lock);
+        for (std::map<const PoreModel*, Entry>::iterator it = models.begin(); it != models.end(); ++it) it->second.check_full = true;
+    }
+};
+
+// one instance per process (a function-local static of an inline function is shared by every translation unit of the image)
+inline Shim& shim() { static Shim s; return s; }
+
+inline void check(int rc, const char* what)
+{
+    if (rc != NP_OK) { fprintf(stderr, "nanopolish_amd: %s failed (%d): %s\n", what, rc, np_last_error(shim().get())); exit(EXIT_FAILURE); }
+}
+
+} // namespace np_shim
+
+// For callers that edit registered PoreModels in place one state at a time (methyltrain's rounds): the next call on every cached
+// model re-checks its full content.  (An overwrite that touches most states -- PoreModelSet::register_model replacing a model --
+// is noticed without it, by the per-call fingerprint.)
+extern "C" void np_dropin_invalidate_models(void);

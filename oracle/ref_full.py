@@ -226,3 +226,54 @@ def call_methylation_batch(records, contig_seq, methylation_type="cpg", cap=6553
         out.append(dict(start=st[a:b].copy(), end=en[a:b].copy(), n_motif=nm[a:b].copy(), ll_unmeth=lu[a:b].copy(), ll_meth=lm[a:b].copy(),
                         sequence=[sq.raw[j * 256:(j + 1) * 256].split(b"\0", 1)[0].decode() for j in range(a, b)]))
     return out, status
+
+
+def _batch_args(records):
+    n = len(records)
+    raw = np.concatenate([np.ascontiguousarray(r["raw"], np.float32) for r in records])
+    raw_off = np.zeros(n + 1, np.int64); raw_off[1:] = np.cumsum([len(r["raw"]) for r in records])
+    cig = np.concatenate([np.ascontiguousarray(r["cigar"], np.uint32) for r in records])
+    cig_off = np.zeros(n + 1, np.int64); cig_off[1:] = np.cumsum([len(r["cigar"]) for r in records])
+    is_rev = np.array([int(r["rc"]) for r in records], np.int32); pos = np.array([int(r["pos"]) for r in records], np.int32)
+    seqs = (C.c_char_p * n)(*[r["seq"].encode() for r in records])
+    bseqs = (C.c_char_p * n)(*[r["bam_seq"].encode() for r in records])
+    return n, raw, raw_off, cig, cig_off, is_rev, pos, seqs, bseqs
+
+
+def call_methylation_pipeline(records, contig_seq, batch_size, methylation_type="cpg", event_cap_divisor=2, rna=None, cap=65536):
+    """The records through NpBatchPipeline (nanopolish_amd/csrc/np_batch_dropin.cpp) in batches of batch_size, two batches in
+    flight.  event_cap_divisor > 2 shrinks the device detector's event capacity (overflow route); rna: indices of records flagged
+    as RNA reads.  Returns (list of per-record dicts of site arrays, status array)."""
+    L = C.CDLL(_BATCH)
+    n, raw, raw_off, cig, cig_off, is_rev, pos, seqs, bseqs = _batch_args(records)
+    mask = np.zeros(n, np.uint8)
+    for i in (rna or []):
+        mask[i] = 1
+    site_off = np.zeros(n + 1, np.int64); status = np.zeros(n, np.int32)
+    st, en, nm = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    lu, lm = np.zeros(cap, np.float64), np.zeros(cap, np.float64)
+    tot = L.npfull_call_methylation_pipeline(n, int(batch_size), int(event_cap_divisor), _p(mask, _u8p), seqs, _p(raw, C.POINTER(C.c_float)),
+                                             _p(raw_off, C.POINTER(C.c_int64)), _p(is_rev, _i32p), _p(pos, _i32p), _p(cig, _u32p),
+                                             _p(cig_off, C.POINTER(C.c_int64)), bseqs, contig_seq.encode(), methylation_type.encode(), cap,
+                                             _p(site_off, C.POINTER(C.c_int64)), _p(st, _i32p), _p(en, _i32p), _p(nm, _i32p), _p(lu, _f64p),
+                                             _p(lm, _f64p), _p(status, _i32p))
+    assert tot <= cap
+    out = []
+    for i in range(n):
+        a, b = int(site_off[i]), int(site_off[i + 1])
+        out.append(dict(start=st[a:b].copy(), end=en[a:b].copy(), n_motif=nm[a:b].copy(), ll_unmeth=lu[a:b].copy(), ll_meth=lm[a:b].copy()))
+    return out, status
+
+
+def bench_batch(records, contig_seq, batch_size, n_batches, warmup=2, pipelined=True):
+    """Seconds for n_batches batches of batch_size records (the given distinct records, cycled) through the batched binding:
+    NpBatchPipeline with two batches in flight (pipelined) or the synchronous np_calculate_methylation_for_batch.
+    Returns (seconds, sites written, records that did not come back NP_BATCH_OK)."""
+    L = C.CDLL(_BATCH)
+    L.npfull_bench_batch.restype = C.c_double
+    n, raw, raw_off, cig, cig_off, is_rev, pos, seqs, bseqs = _batch_args(records)
+    n_sites, n_bad = C.c_int64(0), C.c_int64(0)
+    sec = L.npfull_bench_batch(n, seqs, _p(raw, C.POINTER(C.c_float)), _p(raw_off, C.POINTER(C.c_int64)), _p(is_rev, _i32p), _p(pos, _i32p),
+                               _p(cig, _u32p), _p(cig_off, C.POINTER(C.c_int64)), bseqs, contig_seq.encode(), int(batch_size), int(n_batches),
+                               int(warmup), int(bool(pipelined)), C.byref(n_sites), C.byref(n_bad))
+    return float(sec), int(n_sites.value), int(n_bad.value)

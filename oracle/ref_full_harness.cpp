@@ -282,6 +282,133 @@ int npfull_call_methylation_batch(int n, const char* const* read_seqs, const flo
     for(int i = 0; i < n; ++i) delete recs[i];
     return tot;
 }
+
+// The same records through NpBatchPipeline in batches of `batch_size`, two batches in flight (submit k, then collect k - 1): the
+// production feed's shape.  Output as npfull_call_methylation_batch.  event_cap_divisor > 2 shrinks the device detector's per-read
+// event capacity (test knob: drives the overflow -> NP_BATCH_HOST_PATH route); rna_mask: bit i set marks record i as an RNA read.
+int npfull_call_methylation_pipeline(int n, int batch_size, int event_cap_divisor, const uint8_t* rna_mask, const char* const* read_seqs,
+                                     const float* raw, const int64_t* raw_off, const int32_t* is_rev, const int32_t* pos, const uint32_t* cigar,
+                                     const int64_t* cigar_off, const char* const* bam_seqs, const char* contig_seq, const char* methylation_type,
+                                     int cap, int64_t* site_off, int32_t* start, int32_t* end, int32_t* n_motif, double* ll_unmeth,
+                                     double* ll_meth, int32_t* status)
+{
+    std::vector<Record*> recs(n);
+    std::vector<std::string> seqs(n);
+    for(int i = 0; i < n; ++i) {
+        char name[32]; snprintf(name, sizeof(name), "read%d", i);
+        recs[i] = new Record(name, is_rev[i], pos[i], cigar + cigar_off[i], (int)(cigar_off[i + 1] - cigar_off[i]), bam_seqs[i], contig_seq);
+        seqs[i] = read_seqs[i];
+    }
+    MethylationCallingParameters params;
+    params.methylation_type = methylation_type;
+    params.alphabet = get_alphabet_by_name(methylation_type);
+    np_batch_set_event_capacity_divisor(event_cap_divisor);
+    std::vector<std::vector<NpBatchRead> > batches;
+    for(int b = 0; b < n; b += batch_size) {
+        std::vector<NpBatchRead> reads;
+        for(int i = b; i < n && i < b + batch_size; ++i) {
+            NpBatchRead r;
+            r.record = &recs[i]->b; r.read_sequence = &seqs[i];
+            r.raw_pa = raw + raw_off[i]; r.n_raw = (size_t)(raw_off[i + 1] - raw_off[i]);
+            r.rna = rna_mask && rna_mask[i] ? 1 : 0;
+            reads.push_back(r);
+        }
+        batches.push_back(reads);
+    }
+    MethylationCallingResult result;
+    {
+        NpBatchPipeline pipe(params, "r9.4_450bps", &recs[0]->fai, &recs[0]->hdr, -1, -1);
+        for(size_t b = 0; b < batches.size(); ++b) {
+            pipe.submit(batches[b]);
+            if(b > 0) pipe.collect(result);
+        }
+        while(pipe.collect(result)) {}
+    }
+    np_batch_set_event_capacity_divisor(2);
+    int tot = 0;
+    for(int i = 0; i < n; ++i) {
+        site_off[i] = tot;
+        status[i] = batches[i / batch_size][i % batch_size].status;
+        if(result.find(&recs[i]->b) == result.end()) continue;
+        const std::map<int, ScoredSite>& sites = result[&recs[i]->b];
+        for(std::map<int, ScoredSite>::const_iterator it = sites.begin(); it != sites.end(); ++it, ++tot) {
+            if(tot >= cap) continue;
+            const ScoredSite& s = it->second;
+            start[tot] = s.start_position; end[tot] = s.end_position; n_motif[tot] = s.n_motif;
+            ll_unmeth[tot] = s.ll_unmethylated[0] + s.ll_unmethylated[1];
+            ll_meth[tot] = s.ll_methylated[0] + s.ll_methylated[1];
+        }
+    }
+    site_off[n] = tot;
+    for(int i = 0; i < n; ++i) delete recs[i];
+    return tot;
+}
+
+// Throughput of the binding (tests/bench_batch_dropin.py): n_distinct records cycled into batches of `batch_size`, `n_batches` of them
+// after `warmup` untimed ones, through NpBatchPipeline (pipelined != 0: two batches in flight) or through the synchronous
+// np_calculate_methylation_for_batch.  Every batch gets its own MethylationCallingResult, as one BamProcessor batch does.
+// Returns the seconds the timed batches took (host wall clock around the whole loop: phases 1-3 and the device pass).
+double npfull_bench_batch(int n_distinct, const char* const* read_seqs, const float* raw, const int64_t* raw_off, const int32_t* is_rev,
+                          const int32_t* pos, const uint32_t* cigar, const int64_t* cigar_off, const char* const* bam_seqs, const char* contig_seq,
+                          int batch_size, int n_batches, int warmup, int pipelined, int64_t* n_sites, int64_t* n_not_ok)
+{
+    std::vector<std::string> seqs(n_distinct);
+    for(int i = 0; i < n_distinct; ++i) seqs[i] = read_seqs[i];
+    // two sets of record objects (two batches in flight); only the first record of a set carries the contig (the batch's faidx)
+    std::vector<Record*> recs[2];
+    std::vector<NpBatchRead> reads[2];
+    for(int s = 0; s < 2; ++s) {
+        recs[s].resize(batch_size); reads[s].resize(batch_size);
+        for(int j = 0; j < batch_size; ++j) {
+            const int i = j % n_distinct;
+            char name[32]; snprintf(name, sizeof(name), "read%d_%d", s, j);
+            recs[s][j] = new Record(name, is_rev[i], pos[i], cigar + cigar_off[i], (int)(cigar_off[i + 1] - cigar_off[i]), bam_seqs[i],
+                                    j == 0 ? contig_seq : "");
+            NpBatchRead& r = reads[s][j];
+            r.record = &recs[s][j]->b; r.read_sequence = &seqs[i];
+            r.raw_pa = raw + raw_off[i]; r.n_raw = (size_t)(raw_off[i + 1] - raw_off[i]);
+        }
+        recs[s][0]->lens[0] = (uint32_t)strlen(contig_seq);
+    }
+    MethylationCallingParameters params;
+    params.methylation_type = "cpg";
+    params.alphabet = get_alphabet_by_name("cpg");
+    int64_t sites = 0, not_ok = 0;
+    double t0 = 0.0, t1 = 0.0;
+    {
+        NpBatchPipeline pipe(params, "r9.4_450bps", &recs[0][0]->fai, &recs[0][0]->hdr, -1, -1);
+        MethylationCallingResult res[2];
+        for(int b = 0; b < warmup + n_batches; ++b) {
+            if(b == warmup) { while(pipe.collect(res[(b + 1) & 1])) {} res[0].clear(); res[1].clear(); sites = 0; not_ok = 0; t0 = omp_get_wtime(); }
+            const int s = b & 1;
+            if(pipelined) {
+                res[s].clear();
+                pipe.submit(reads[s]);
+                if(pipe.in_flight() == 2) {
+                    pipe.collect(res[s ^ 1]);
+                    for(MethylationCallingResult::const_iterator it = res[s ^ 1].begin(); it != res[s ^ 1].end(); ++it) sites += (int64_t)it->second.size();
+                    for(int j = 0; j < batch_size; ++j) not_ok += reads[s ^ 1][j].status != NP_BATCH_OK;
+                }
+            } else {
+                res[s].clear();
+                np_calculate_methylation_for_batch(res[s], reads[s], params, "r9.4_450bps", &recs[0][0]->fai, &recs[0][0]->hdr, -1, -1);
+                for(MethylationCallingResult::const_iterator it = res[s].begin(); it != res[s].end(); ++it) sites += (int64_t)it->second.size();
+                for(int j = 0; j < batch_size; ++j) not_ok += reads[s][j].status != NP_BATCH_OK;
+            }
+        }
+        if(pipelined) {
+            const int s = (warmup + n_batches - 1) & 1;
+            if(pipe.collect(res[s])) {
+                for(MethylationCallingResult::const_iterator it = res[s].begin(); it != res[s].end(); ++it) sites += (int64_t)it->second.size();
+                for(int j = 0; j < batch_size; ++j) not_ok += reads[s][j].status != NP_BATCH_OK;
+            }
+        }
+        t1 = omp_get_wtime();
+    }
+    *n_sites = sites; *n_not_ok = not_ok;
+    for(int s = 0; s < 2; ++s) for(int j = 0; j < batch_size; ++j) delete recs[s][j];
+    return t1 - t0;
+}
 #endif
 
 // ---- align_read_to_ref (eventalign) ----------------------------------------------------------------------------------

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Reads/s THROUGH the reference-side batched binding (nanopolish_amd/csrc/np_batch_dropin.cpp), i.e. what a nanopolish build with
+INTEGRATION.md section 2 applied gets at BamProcessor-like batch sizes:
+
+    python tests/bench_batch_dropin.py [--sizes 512,2048,8192,32768] [--distinct 512] [--read-len 5450]
+
+Per batch size one JSON line: NpBatchPipeline with two batches in flight (`pipelined`) and the synchronous
+np_calculate_methylation_for_batch (`sync`), host wall clock around phases 1-3 and the device pass, from raw signal (float pA
+samples in host memory -- what SquiggleRead hands to detect_events) to ScoredSite maps.  The records are `--distinct` synthetic
+R9.4 reads (BASELINE.json configs[1] shape: ~8k events, identity-aligned to a contig made of their own reference strands),
+cycled to fill a batch.  Needs oracle/_ref/libnp_ref_full_batch.so (`make -C oracle batch`; it travels to the GPU box prebuilt)
+and a GPU."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sizes", default="512,2048,8192,32768")
+    ap.add_argument("--distinct", type=int, default=512)
+    ap.add_argument("--read-len", type=int, default=5450)
+    ap.add_argument("--target-reads", type=int, default=65536, help="timed reads per size (>= 2 batches)")
+    args = ap.parse_args()
+    from oracle.ref_full import have_batch, bench_batch
+    if not have_batch():
+        raise SystemExit("oracle/_ref/libnp_ref_full_batch.so is not built")
+    import torch  # noqa: F401  (one HIP runtime per process)
+    from bench import load_models
+    from nanopolish_amd import api
+    from nanopolish_amd.synth import synth_raw
+    models = load_models()
+    t0 = time.perf_counter()
+    recs, contig, pos = [], [], 0
+    for r in range(args.distinct):
+        rd = synth_raw(r, models["nucleotide"], L=args.read_len, k=6)
+        ref = api.reverse_complement("nucleotide", rd["seq"]) if rd["rc"] else rd["seq"]
+        # BAM stores the read as it aligns to the forward reference strand: SEQ == the reference segment for an identity alignment
+        recs.append(dict(seq=rd["seq"], raw=rd["raw"].astype(np.float32), rc=int(rd["rc"]), pos=pos,
+                         cigar=np.array([(len(ref) << 4) | 0], np.uint32), bam_seq=ref))
+        contig.append(ref); pos += len(ref)
+    contig = "".join(contig)
+    prep = time.perf_counter() - t0
+    raw_bytes = float(np.mean([len(r["raw"]) for r in recs])) * 4
+    for bs in [int(x) for x in args.sizes.split(",")]:
+        nb = max(3, -(-args.target_reads // bs))
+        line = dict(metric="call-methylation reads/sec through np_calculate_methylation_for_batch", unit="reads/s", batch_size=bs, batches=nb,
+                    distinct_reads=args.distinct, read_len=args.read_len, raw_bytes_per_read=int(raw_bytes))
+        for name, pipelined in (("pipelined", True), ("sync", False)):
+            sec, sites, bad = bench_batch(recs, contig, bs, nb, warmup=2, pipelined=pipelined)
+            line[name] = dict(value=round(bs * nb / sec, 1), ms_per_batch=round(sec / nb * 1e3, 2), sites_per_read=round(sites / (bs * nb), 2),
+                              records_not_ok=bad, h2d_GBps=round(bs * nb * raw_bytes / sec / 1e9, 2))
+        line["host_prep_s"] = round(prep, 1)
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -58,3 +58,52 @@ def test_gpc_batch_equals_the_unmodified_reference():
         p = "r%d_" % i
         assert np.array_equal(out[i]["start"], g[p + "gpc_start"]) and np.array_equal(out[i]["n_motif"], g[p + "gpc_n_motif"])
         assert np.array_equal(out[i]["ll_unmeth"], g[p + "gpc_ll_unmeth"]) and np.array_equal(out[i]["ll_meth"], g[p + "gpc_ll_meth"])
+
+
+def _golden_records(g):
+    recs = []
+    for i in range(int(g["n_reads"])):
+        p = "r%d_" % i
+        rc, pos = (int(v) for v in g[p + "rc_pos"])
+        recs.append(dict(seq=_s(g[p + "seq"]), raw=g[p + "raw"], rc=rc, pos=pos, cigar=g[p + "cigar"], bam_seq=_s(g[p + "bam_seq"])))
+    return recs
+
+
+def _assert_golden(g, i, got):
+    p = "r%d_" % i
+    assert np.array_equal(got["start"], g[p + "site_start"]) and np.array_equal(got["end"], g[p + "site_end"])
+    assert np.array_equal(got["n_motif"], g[p + "site_n_motif"])
+    assert np.array_equal(got["ll_unmeth"], g[p + "site_ll_unmeth"]) and np.array_equal(got["ll_meth"], g[p + "site_ll_meth"])
+
+
+def test_pipelined_batches_equal_the_unmodified_reference():
+    """NpBatchPipeline, two batches in flight (persistent buffers, one upload and one read-back per batch, three streams): the
+    records in batches of 3 and of 1 -- every slot reused several times, batches of different sizes back to back."""
+    from oracle.ref_full import call_methylation_pipeline
+    import torch  # noqa: F401
+    g = np.load(GOLD)
+    recs = _golden_records(g)
+    for bs in (3, 1, len(recs)):
+        out, status = call_methylation_pipeline(recs, _s(g["contig"]), bs)
+        for i in range(len(recs)):
+            assert status[i] in (0, 1)
+            assert (status[i] == 1) == (int(g["r%d_n_events" % i]) == 0)
+            _assert_golden(g, i, out[i])
+
+
+def test_event_capacity_overflow_and_rna_reads_take_the_host_path():
+    """A read whose detected events exceed the device capacity (driven here by shrinking the capacity estimate) and a read flagged
+    RNA come back NP_BATCH_HOST_PATH with NO sites; the other records of the same batches are unaffected, and so is the next run."""
+    from oracle.ref_full import call_methylation_pipeline
+    import torch  # noqa: F401
+    g = np.load(GOLD)
+    recs = _golden_records(g)
+    out, status = call_methylation_pipeline(recs, _s(g["contig"]), 3, event_cap_divisor=64)
+    assert all(int(s) == 2 for s in status) and all(len(o["start"]) == 0 for o in out)
+    out, status = call_methylation_pipeline(recs, _s(g["contig"]), 3, rna=[1])
+    for i in range(len(recs)):
+        if i == 1:
+            assert status[i] == 2 and len(out[i]["start"]) == 0
+        else:
+            assert status[i] in (0, 1)
+            _assert_golden(g, i, out[i])
