@@ -193,6 +193,37 @@ def cpu_baseline(models, hb, calibrate, from_raw, budget_reads):
     return out, cb
 
 
+def ragged_parity(models, hb, batch, calibrate, from_raw, n_sample=48):
+    """Pairs and LLRs of a sample of the RAGGED batch against the CPU pass (the ragged leg was only checked for
+    `reads_aligned_ok`): the longest and the shortest reads of the batch and a spread between them."""
+    lens = np.array([len(q) for q in hb["ref_seqs"]])
+    order = np.argsort(lens)
+    pick = sorted(set(order[-4:].tolist() + order[:4].tolist() + order[np.linspace(0, len(order) - 1, n_sample).astype(int)].tolist()))
+    _, _, cores = usable_cores()
+    cb = cpu_pass(models, hb, pick, [max(1, min(cores, len(pick)))], calibrate, from_raw, repeats=1)
+    pairs, pair_off, n_pairs = cb["pairs"]
+    ok = True
+    if from_raw:
+        ok &= np.array_equal(batch.d_n_events.cpu().numpy()[pick], np.array(cb["n_events"]))
+    for q, i in enumerate(pick):
+        ok &= np.array_equal(batch.pairs_of(i), pairs[pair_off[q]:pair_off[q] + n_pairs[q]])
+    gmap = {}
+    for q, i in enumerate(pick):
+        f, nm, su, sm = batch.groups_of(i)
+        for j in range(len(f)):
+            gmap[(q, int(f[j]))] = (float(su[j]), float(sm[j]))
+    want = cb["scores"]
+    d, missing = [], 0
+    for j, key in enumerate(cb["first"]):
+        g = gmap.get(key)
+        if g is None or not np.isfinite(g[0]):
+            missing += 1
+            continue
+        d.append((g[1] - g[0]) - (float(want[2 * j + 1]) - float(want[2 * j])))
+    return dict(reads=len(pick), read_len_min=int(lens[pick].min()), read_len_max=int(lens[pick].max()), pairs_bit_exact=bool(ok),
+                groups=len(cb["first"]), groups_missing_on_gpu=missing, max_abs_dLLR=float(np.max(np.abs(d))) if d else None)
+
+
 # ---- N > 1 without a launcher ---------------------------------------------------------------------------------------------
 def launch_ranks(n, argv):
     """Start the n ranks of `bench.py --gpus n` ourselves (the driver's N = 1 command shape with --gpus > 1): one process per
@@ -245,6 +276,10 @@ def main():
     ap.add_argument("--ragged-pool", type=int, default=-1, help="distinct reads of the ragged batch (-1: pool / 2, tile x 2)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="cap on the reads of the CPU baseline (-1: 32 per thread, 0: skip)")
     ap.add_argument("--workers", type=int, default=-1, help="host-preparation worker processes (-1: min(32, cores))")
+    ap.add_argument("--legs", type=int, default=1,
+                    help="1: rank 0 of a one-GPU run also measures BASELINE.json configs[2] (eventalign, 50 000 reads per step) and configs[3] "
+                         "(variants, 10 kb x 2 000 reads) and folds them into the line as value_eventalign / value_variants, each with its "
+                         "parity fields and its own roofline")
     args, extra = ap.parse_known_args()
 
     if args.workload in ("eventalign", "variants"):
@@ -365,12 +400,18 @@ def main():
     for _ in range(args.steps):
         batch.step()
     ctx.sync()
+    t_steps = time.perf_counter() - t0          # this rank's K steps alone (N > 1: what the per-rank diagnostics report)
     table = None
+    t_reduce = 0.0
     if world > 1:
+        t1 = time.perf_counter()
         table = device_table(batch)
         all_reduce(table, dist.ReduceOp.SUM)        # RCCL all-reduce(sum): the job's only collective (final site-level reduction)
+        torch.cuda.synchronize()
+        t_reduce = time.perf_counter() - t1         # table kernel + all-reduce, incl. waiting for the slowest rank
     barrier()
     dt = time.perf_counter() - t0
+    dt_rank = dt
 
     def max_over_ranks(x):
         t = torch.tensor([x], dtype=torch.float64, device="cuda")
@@ -394,10 +435,11 @@ def main():
         for k in range(args.steps):
             feed.submit()
         feed.drain(); barrier()
-        dts = max_over_ranks(time.perf_counter() - t0)
+        dts_rank = time.perf_counter() - t0
+        dts = max_over_ranks(dts_rank)
         steady = feed.steady_ms_per_step(args.steps)
         same = feed.check_against(batch) if rank == 0 else True
-        streamed = dict(value=round(world * n_reads * args.steps / dts, 2), ms_per_step=round(dts / args.steps * 1e3, 3),
+        streamed = dict(value=round(world * n_reads * args.steps / dts, 2), value_rank=round(n_reads * args.steps / dts_rank, 2), ms_per_step=round(dts / args.steps * 1e3, 3),
                         h2d_bytes_per_step=feed.h2d_bytes, d2h_bytes_per_step=feed.d2h_bytes,
                         pcie_GBps=round((feed.h2d_bytes + feed.d2h_bytes) * args.steps / dts / 1e9, 2),
                         steady_state_ms_per_step=round(steady, 3) if steady else None,
@@ -435,7 +477,7 @@ def main():
         ok = True
         if args.from_raw:
             ok &= np.array_equal(batch.d_n_events[:cb["n"]].cpu().numpy(), np.array(cb["n_events"]))
-        for i in range(min(cb["n"], 256)):
+        for i in range(cb["n"]):                      # every sampled read, pair for pair
             ok &= np.array_equal(batch.pairs_of(i), pairs[pair_off[i]:pair_off[i] + n_pairs[i]])
         gmap = {}
         for i, (f, nm, su, sm) in enumerate(batch.groups_bulk(cb["n"])):
@@ -452,8 +494,8 @@ def main():
             d.append((g[1] - g[0]) - (float(want[2 * q + 1]) - float(want[2 * q])))
         max_dllr = float(np.max(np.abs(d))) if d else None
         n_gpu_groups = sum(1 for v in gmap.values() if np.isfinite(v[0]))
-        cpu["check"] = dict(reads=cb["n"], groups=len(cb["first"]), groups_scored_on_gpu=n_gpu_groups, groups_missing_on_gpu=missing,
-                            pairs_bit_exact=bool(ok), max_abs_dLLR=max_dllr)
+        cpu["check"] = dict(reads=cb["n"], reads_pairs_compared=cb["n"], groups=len(cb["first"]), groups_scored_on_gpu=n_gpu_groups,
+                            groups_missing_on_gpu=missing, pairs_bit_exact=bool(ok), max_abs_dLLR=max_dllr)
         if args.from_raw and args.calibrate:
             # the same sample through the reference's WHOLE per-read function: SquiggleRead(sequence, Fast5Data) -> load_from_raw
             # -> calculate_methylation_for_read, compiled in place (oracle/_ref/libnp_ref_full.so), OpenMP over reads
@@ -482,7 +524,10 @@ def main():
         a_ms, a_n = ctx.kernel_time(0)
         lens = np.array([len(q) for q in hb_rag["ref_seqs"]])
         nev_r = rb.total_events if not args.from_raw else int(rb.d_n_events.clamp(min=0).sum().item())
-        ragged = dict(value=round(world * rb.n_reads * args.steps / dtr, 2), ms_per_step=round(dtr / args.steps * 1e3, 3),
+        rag_check = None
+        if rank == 0 and args.cpu_sample != 0 and world == 1:
+            rag_check = ragged_parity(models, hb_rag, rb, bool(args.calibrate), bool(args.from_raw))
+        ragged = dict(value=round(world * rb.n_reads * args.steps / dtr, 2), ms_per_step=round(dtr / args.steps * 1e3, 3), check=rag_check,
                       reads_per_step_per_gpu=rb.n_reads, distinct_reads_per_gpu=hb_rag["n"],
                       read_len=dict(mean=round(float(lens.mean()), 1), p50=int(np.median(lens)), min=int(lens.min()), max=int(lens.max())),
                       mean_events=round(nev_r / rb.n_reads, 1),
@@ -492,6 +537,43 @@ def main():
         del rb
         torch.cuda.empty_cache()
 
+    # per-rank diagnostics: with N > 1 a scaling efficiency below 0.9 must be attributable -- this rank's own
+    # K steps, its host-fed rate, its host preparation time and what the final table + all-reduce cost it
+    mine = [float(rank), n_reads * args.steps / t_steps, (streamed or {}).get("value_rank", 0.0), t_prep, t_reduce * 1e3, dt_rank * 1e3,
+            k_ms["event_align"][0] / max(args.steps, 1), k_ms["hmm_score"][0] / max(args.steps, 1)]
+    gathered = [mine]
+    if world > 1:
+        t = torch.tensor(mine, dtype=torch.float64, device="cuda")
+        lst = [torch.zeros_like(t) for _ in range(world)]
+        if backend == "nccl":
+            dist.all_gather(lst, t)
+        else:
+            hl = [x.cpu() for x in lst]; dist.all_gather(hl, t.cpu()); lst = hl
+        gathered = [x.cpu().tolist() for x in lst]
+    per_rank = [dict(rank=int(g[0]), value=round(g[1], 1), value_streamed=round(g[2], 1) if g[2] else None, host_prep_s=round(g[3], 1),
+                     table_and_allreduce_ms=round(g[4], 3), timed_region_ms=round(g[5], 3), event_align_ms_per_step=round(g[6], 3),
+                     hmm_score_ms_per_step=round(g[7], 3)) for g in gathered]
+
+    # ---------------- BASELINE.json configs[2] and configs[3], folded into the line (one GPU, rank 0) ----------------
+    legs = None
+    if rank == 0 and world == 1 and args.legs:
+        legs = {}
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        try:
+            import bench_eventalign
+            ea = bench_eventalign.run(steps=args.steps, warmup=args.warmup, cpu_sample=0 if args.cpu_sample == 0 else -1, ctx=ctx)
+            legs["value_eventalign"] = ea["value"]; legs["eventalign"] = ea
+        except Exception as e:  # noqa: BLE001
+            legs["eventalign"] = dict(error=repr(e))
+        torch.cuda.empty_cache()
+        try:
+            import bench_variants
+            va = bench_variants.run(steps=args.steps, warmup=args.warmup, cpu_sample=0 if args.cpu_sample == 0 else 20000)
+            legs["value_variants"] = va["value"]; legs["variants"] = va
+        except Exception as e:  # noqa: BLE001
+            legs["variants"] = dict(error=repr(e))
+        torch.cuda.empty_cache()
+
     if rank == 0:
         # dominant kernel + HBM roofline (algorithmic bytes)
         dom = max(k_ms, key=lambda k: k_ms[k][0])
@@ -499,33 +581,38 @@ def main():
         a_avg_s = a_ms / max(a_n, 1) * 1e-3
         algo = res["algo"]
         achieved = algo / a_avg_s / 1e9 if a_avg_s > 0 else 0.0
-        # HBM traffic per launch and the issue model of the kernel (profiles/r02_pmc.json): FETCH_SIZE + WRITE_SIZE per read from
-        # rocprofv3 --pmc passes over this kernel; instructions per band step counted in the generated assembly
-        # (tools/count_isa.py); vector-issue cycles per band from the occupancy scan (per-wave band time 370 + 157 w cycles at
-        # w resident waves per SIMD: 157 cycles of issue time, the rest latency that eight waves do not hide)
-        traffic, issue = None, None
+        # HBM traffic of THIS run's launch: bytes per BAND from the counter passes over the shipped kernel (profiles/r03_pmc.json:
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE at a launch size the passes finish at, profiles/collect_r03_pmc.sh; round 2's file
+        # as a fallback) x the bands this run's reads have -- a from-raw run (more events per read) reports its own figure.
+        # `issue` is a MODEL (static instruction count of the generated band loop, tools/count_isa.py, and the round-2 occupancy scan:
+        # per-wave band time 370 + 157 w cycles at w resident waves per SIMD) and says so; `counters` beside it are measured.
+        traffic, issue, counters = None, None, None
         n_bands = res["band_cells"] // 100
         cyc_per_band = a_avg_s * CLOCK_HZ * N_SIMD / max(n_bands, 1)
-        for name in ("r02_pmc.json", "r01_pmc.json"):
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", name)))["event_align"]
-                traffic = int((pm["fetch_bytes_per_read"] + pm["write_bytes_per_read"]) * n_reads)
-                valu, salu = pm.get("valu_per_band"), pm.get("salu_per_band")
-                issue = dict(valu_per_band=valu, salu_per_band=salu, simd_cycles_per_band=round(cyc_per_band, 1),
-                             source="profiles/" + name, instruction_source=pm.get("instruction_source", "rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU"))
-                port = (pm.get("occupancy_scan") or {}).get("port_cycles_per_band")
-                if port:
-                    # frac: vector-issue cycles one band step needs / SIMD cycles it takes (fill and back-track together)
-                    issue["port_cycles_per_band"] = port
-                    issue["latency_cycles_per_band_at_8_waves"] = round((pm["occupancy_scan"]["latency_cycles_per_band"]) / 8.0, 1)
-                    issue["frac"] = round(port / cyc_per_band, 3)
-                elif valu and salu:
-                    issue["frac"] = round(2.8 * valu / cyc_per_band, 3)
-                break
-            except Exception:
-                continue
-        if issue is None:
-            issue = dict(simd_cycles_per_band=round(cyc_per_band, 1))
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))["event_align"]
+            if pm.get("fetch_bytes_per_band") is not None and pm.get("write_bytes_per_band") is not None:
+                traffic = int((pm["fetch_bytes_per_band"] + pm["write_bytes_per_band"]) * n_bands)
+            counters = {k: pm[k] for k in ("valu_per_band", "salu_per_band", "valu_busy_pct", "salu_busy_pct", "reads_per_launch",
+                                           "fetch_bytes_per_band", "write_bytes_per_band", "simd_cycles_per_band") if k in pm}
+            counters["source"] = "profiles/r03_pmc.json (rocprofv3 --pmc over the shipped kernel, profiles/collect_r03_pmc.sh)"
+        except Exception:
+            pass
+        try:
+            pm2 = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))["event_align"]
+            if traffic is None:
+                per_band = (pm2["fetch_bytes_per_read"] + pm2["write_bytes_per_read"]) / 13463.2      # the profiled reads' bands
+                traffic = int(per_band * n_bands)
+            port = pm2["occupancy_scan"]["port_cycles_per_band"]
+            issue = dict(kind="model", valu_per_band=pm2.get("valu_per_band"), salu_per_band=pm2.get("salu_per_band"),
+                         simd_cycles_per_band=round(cyc_per_band, 1), port_cycles_per_band=port,
+                         latency_cycles_per_band_at_8_waves=round(pm2["occupancy_scan"]["latency_cycles_per_band"] / 8.0, 1),
+                         frac=round(port / cyc_per_band, 3),
+                         source="static count of the band loop in the generated assembly (tools/count_isa.py) + round-2 occupancy scan "
+                                "(profiles/r02_pmc.json); a model, not a measurement of this run")
+        except Exception:
+            issue = dict(kind="model", simd_cycles_per_band=round(cyc_per_band, 1))
+        issue["counters"] = counters
         roof = dict(bound="hbm", kernel="np_event_align_kernel", achieved=round(achieved, 2), peak=8000.0, unit="GB/s",
                     frac=round(achieved / 8000.0, 5), traffic=traffic,
                     algo_bytes_per_launch=algo, avg_launch_ms=round(a_ms / max(a_n, 1), 3),
@@ -549,6 +636,9 @@ def main():
                    value_streamed=streamed["value"] if streamed else None, streamed=streamed,
                    value_ragged=ragged["value"] if ragged else None, ragged=ragged,
                    max_abs_dLLR_vs_cpu=max_dllr, roofline=roof, cpu_baseline=cpu, host_prep_s=round(t_prep, 1))
+        out["per_rank"] = per_rank
+        if legs:
+            out.update(legs)
         if table is not None:
             out["site_table"] = dict(sites=int((table[:, 0] > 0).sum().item()), num_reads=int(table[:, 0].sum().item()),
                                      called_sites=int(table[:, 1].sum().item()), called_sites_methylated=int(table[:, 2].sum().item()))

@@ -78,6 +78,12 @@ const char* np_ctx_info(const np_ctx* ctx);
  * a longer segment ends its read with NP_EA_OVERFLOW), "ea_waves_per_cu" (persistent grid of the chain kernel), "lse_oor" (0: the forward kernel clamps its log-sum table index;
  * 1: it relies on the LDS out-of-range rule, the default when np_create's probe passes -- scores never depend on it). */
 int np_set_option(np_ctx* ctx, const char* name, int64_t value);
+/* Read-only facts about the context (-1: unknown name): "align_blocks" / "align_scratch_bytes" (persistent grid and per-wave scratch
+ * of the most recent event-align launch: the grid shrinks under a 48 GB scratch budget when a batch holds ultra-long reads),
+ * "align_blocks_max", "lse_oor" (1: the clamp-free log-sum lookup is in use, see np_ctx_info), "n_cu", "ea_lattice_cells" /
+ * "ea_lattice_rows" / "ea_lattice_kmers" (sum over the segments of the most recent np_eventalign_dev call of the reference's
+ * lattice size (e + 1) x 3 (n + 2), of e and of n; waits for the call). */
+int64_t np_get_stat(np_ctx* ctx, const char* name);
 
 /* Upload a pore model (PoreModel::states, src/pore_model/nanopolish_poremodel.h:20-67,107): the three
  * per-state doubles the path reads.  Returns a model id >= 0, or a negative error. */

@@ -184,6 +184,13 @@ class Context:
     def set_option(self, name, value):
         self._chk(self.L.np_set_option(self.h, name.encode(), int(value)), "np_set_option")
 
+    def get_stat(self, name):
+        return int(self.L.np_get_stat(self.h, name.encode()))
+
+    def info(self):
+        """what np_create's hardware probe found (np_ctx_info)"""
+        return self.L.np_ctx_info(self.h).decode()
+
     def register_model(self, model, name=None):
         lm = np.ascontiguousarray(model["level_mean"], np.float64)
         ls = np.ascontiguousarray(model["level_stdv"], np.float64)

@@ -84,6 +84,7 @@ struct np_ctx {
     int align_lpt = 1;                // issue the event aligner's reads longest first
     int stream_switch_wait = 1;       // a call on a new stream waits for the tail of the stream the context used before (0: the caller orders its streams itself)
     int ed_warmup = -1;               // parallel peak walk: samples of warm-up per segment (< 0: the kernel's default)
+    int64_t last_align_blocks = 0, last_align_scratch = 0;      // np_get_stat: grid and scratch of the most recent event-align launch
 };
 
 namespace {
@@ -194,6 +195,7 @@ int run_event_align(np_ctx* c, hipStream_t s, int n_reads, const np_read_dev* re
     const uint64_t per_block = (uint64_t)waves_per_block * (stride * sizeof(uint64_t) + kp_stride * sizeof(float4));
     const uint64_t budget = 48ull << 30;
     if ((uint64_t)nb * per_block > budget) nb = (int)std::max<uint64_t>(1, budget / per_block);
+    c->last_align_blocks = nb; c->last_align_scratch = (int64_t)((uint64_t)nb * per_block);
     NP_HIP(c, c->trace.reserve((size_t)nb * waves_per_block * stride * sizeof(uint64_t)));
     NP_HIP(c, c->kparams.reserve((size_t)nb * waves_per_block * kp_stride * sizeof(float4)));
     NP_HIP(c, c->align_order.reserve((size_t)(2048 + n_reads) * sizeof(uint32_t)));
@@ -1012,7 +1014,9 @@ int np_eventalign_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* r
     family_timer tm(c, 6, s);
     NP_HIP(c, np_launch_cigar_index(n_reads, cigar, cigar_off, read_len, (int)k, op_ref, op_read, cig_reads, s));
     NP_HIP(c, hipMemsetAsync(c->d_counters + 17, 0, sizeof(uint32_t), s));
+    NP_HIP(c, hipMemsetAsync(c->d_counters + 40, 0, 3 * sizeof(unsigned long long), s));
     np_ea_args a{};
+    a.stats = (unsigned long long*)(c->d_counters + 40);
     a.n_reads = n_reads; a.reads = reads; a.event_mean = event_mean; a.map_start = map_start; a.n_pairs = n_pairs;
     a.events_per_base = events_per_base; a.calibrated = calibrated;
     a.model = c->models[model].d_states; a.flank = c->d_flank; a.genome = genome; a.ref_begin = ref_begin; a.ref_len = ref_len;
@@ -1024,6 +1028,26 @@ int np_eventalign_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* r
     a.n_calls = n_calls; a.counter = c->d_counters + 17;
     NP_HIP(c, np_launch_eventalign_chain(a, nb, s));
     return NP_OK;
+}
+
+int64_t np_get_stat(np_ctx* c, const char* name)
+{
+    if (!c || !name) return -1;
+    std::lock_guard<std::mutex> g(c->lock);
+    const std::string k(name);
+    if (k == "align_blocks") return c->last_align_blocks;
+    if (k == "align_scratch_bytes") return c->last_align_scratch;
+    if (k == "align_blocks_max") return (int64_t)c->n_cu * c->align_blocks_per_cu;
+    if (k == "lse_oor") return c->lse_oor ? 1 : 0;
+    if (k == "n_cu") return c->n_cu;
+    if (k == "ea_lattice_cells" || k == "ea_lattice_rows" || k == "ea_lattice_kmers") {        // of the most recent np_eventalign_dev call (waits for it)
+        unsigned long long h[3] = {0, 0, 0};
+        if (hipSetDevice(c->device) != hipSuccess) return -1;
+        if (c->tail_recorded && hipEventSynchronize(c->switch_ev) != hipSuccess) return -1;
+        if (hipMemcpy(h, c->d_counters + 40, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        return (int64_t)h[k == "ea_lattice_cells" ? 0 : k == "ea_lattice_rows" ? 1 : 2];
+    }
+    return -1;
 }
 
 // tuning / test knobs

@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(64, 5) np_eventalign_chain_kernel(np_ea_args a
         const int64_t o0 = a.out_off[ri];
         const int out_cap = (int)(a.out_off[ri + 1] - o0);
         int n_out = 0, n_calls = 0, status = NP_EA_OK;
+        unsigned long long cells = 0ull, rows = 0ull, kmers = 0ull;          // lattice cells / rows of the read's segments (statistics for the roofline)
 
         // aligned pairs trimmed to read_pos <= max_kmer_idx (trim_aligned_pairs_to_kmer, :167-177)
         const int max_kmer_idx = rl - k;
@@ -184,6 +185,7 @@ __global__ void __launch_bounds__(64, 5) np_eventalign_chain_kernel(np_ea_args a
             const int e = span + 1, n = __builtin_amdgcn_readfirstlane(l - k + 1);
             if (n > NP_EA_MAX_KMERS || e > a.rows_cap) { status = NP_EA_OVERFLOW; break; }
             n_calls++;
+            cells += (unsigned long long)(e + 1) * (unsigned long long)(3 * (n + 2)); rows += (unsigned long long)e; kmers += (unsigned long long)n;
 
             // ---- Viterbi fill (ProfileHMMViterbiOutputR9, r9.inl:130-197): lane owns blocks 2*lane, 2*lane + 1 ----
             np_gauss g[2];
@@ -281,7 +283,10 @@ __global__ void __launch_bounds__(64, 5) np_eventalign_chain_kernel(np_ea_args a
             curr_start_ref = __builtin_amdgcn_readfirstlane(last_ref_kmer_output);
             if (num_output == 0) break;
         }
-        if (lane == 0) { a.n_out[ri] = n_out < out_cap ? n_out : out_cap; a.status[ri] = status; a.n_calls[ri] = n_calls; }
+        if (lane == 0) {
+            a.n_out[ri] = n_out < out_cap ? n_out : out_cap; a.status[ri] = status; a.n_calls[ri] = n_calls;
+            if (a.stats && n_calls > 0) { atomicAdd(a.stats, cells); atomicAdd(a.stats + 1, rows); atomicAdd(a.stats + 2, kmers); }
+        }
     }
 }
 

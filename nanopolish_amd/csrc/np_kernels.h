@@ -57,6 +57,7 @@ struct np_ea_args {
     int32_t* status;
     int32_t* n_calls;
     uint32_t* counter;
+    unsigned long long* stats;     // [0] += lattice cells (e + 1) x 3 (n + 2) of every segment, [1] += lattice rows e, [2] += k-mers n (nullable)
 };
 
 struct np_align_args {

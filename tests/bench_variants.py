@@ -40,17 +40,11 @@ def haplotypes(ref, i):
     return cs, ce, seqs
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--draft", type=int, default=10000)
-    ap.add_argument("--reads", type=int, default=250, help="distinct reads covering the draft")
-    ap.add_argument("--tile", type=int, default=8, help="independent copies of the read set in HBM")
-    ap.add_argument("--stride", type=int, default=1, help="screen every stride-th draft position")
-    ap.add_argument("--indel-bias", type=float, default=0.9, help="hmm_indel_bias_factor (src/nanopolish_call_variants.cpp:1116)")
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cpu-sample", type=int, default=20000, help="work items for the CPU baseline / parity check (0: skip)")
-    args = ap.parse_args()
+def run(draft=10000, reads=250, tile=8, stride=1, indel_bias=0.9, steps=3, warmup=1, cpu_sample=20000):
+    """One variants-screening measurement (BASELINE.json configs[3]); returns the JSON-able dict."""
+    import types
+    args = types.SimpleNamespace(draft=draft, reads=reads, tile=tile, stride=stride, indel_bias=indel_bias, steps=steps, warmup=warmup,
+                                 cpu_sample=cpu_sample)
     import torch
     from oracle import load_models
     from nanopolish_amd import api, lib as _l
@@ -141,9 +135,20 @@ def main():
     sc = d_scores.cpu().numpy()
     jh = d_jobs.cpu().numpy().view(JOB_DT)
     scored = int(np.sum((jh["flags"] & 0x80000000) == 0))
-    out = dict(metric="variants screening profile_hmm_score calls/sec", value=round(scored * args.steps / dt, 1), unit="calls/s", n_gpus=1,
+    # HBM roofline of the forward kernel: algorithmic bytes per call 4 e + 2 n + 12 n + 4 (event means, k-mer ranks, the
+    # three scaled-Gaussian floats per k-mer, the score), summed over the scored items of one launch; the lattice never leaves the chip
+    live = (jh["flags"] & 0x80000000) == 0
+    e_len = np.abs(jh["e_stop"].astype(np.int64) - jh["e_start"].astype(np.int64)) + 1
+    algo = int((4 * e_len[live] + 14 * jh["n_kmers"][live].astype(np.int64) + 4).sum())
+    cells = int((3 * e_len[live] * jh["n_kmers"][live].astype(np.int64)).sum())
+    hmm_ms = ctx.kernel_time(1)[0] / args.steps
+    roof = dict(bound="hbm", kernel="np_hmm_forward_kernel", achieved=round(algo / (hmm_ms * 1e-3) / 1e9, 2) if hmm_ms > 0 else 0.0, peak=8000.0,
+                unit="GB/s", frac=round(algo / (hmm_ms * 1e-3) / 1e9 / 8000.0, 5) if hmm_ms > 0 else 0.0, traffic=None, algo_bytes_per_launch=algo,
+                avg_launch_ms=round(hmm_ms, 3), cell_states_per_s=round(cells / (hmm_ms * 1e-3) / 1e9, 2) if hmm_ms > 0 else 0.0,
+                limiter="LDS gather of the log-sum table (p7_FLogsum, bit-exact): ~6 look-ups per cell-state, nothing but events, ranks and scores touches HBM")
+    out = dict(metric="variants screening profile_hmm_score calls/sec", roofline=roof, value=round(scored * args.steps / dt, 1), unit="calls/s", n_gpus=1,
                steps=args.steps, ms_per_step=round(1e3 * dt / args.steps, 3), calls_per_step=scored, items_per_step=NJ,
-               hmm_kernel_ms_per_step=round(ctx.kernel_time(1)[0] / args.steps, 3),
+               hmm_kernel_ms_per_step=round(hmm_ms, 3),
                config=dict(workload="variants --consensus screening shape (BASELINE.json configs[3]): 22-base windows, base + single-base edits",
                            draft=Ld, reads=N, distinct_reads=n, positions=len(positions), haplotypes=n_seq, indel_bias=args.indel_bias))
     if args.cpu_sample > 0:
@@ -172,7 +177,22 @@ def main():
                                            max_abs_diff=float(np.max(np.abs(got.astype(np.float64) - sc[pick].astype(np.float64)))))
         except Exception as e:  # noqa: BLE001
             out["cpu_baseline"] = dict(error=repr(e))
-    print(json.dumps(out))
+    ctx.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--draft", type=int, default=10000)
+    ap.add_argument("--reads", type=int, default=250, help="distinct reads covering the draft")
+    ap.add_argument("--tile", type=int, default=8, help="independent copies of the read set in HBM")
+    ap.add_argument("--stride", type=int, default=1, help="screen every stride-th draft position")
+    ap.add_argument("--indel-bias", type=float, default=0.9, help="hmm_indel_bias_factor (src/nanopolish_call_variants.cpp:1116)")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-sample", type=int, default=20000, help="work items for the CPU baseline / parity check (0: skip)")
+    a = ap.parse_args()
+    print(json.dumps(run(a.draft, a.reads, a.tile, a.stride, a.indel_bias, a.steps, a.warmup, a.cpu_sample)))
 
 
 if __name__ == "__main__":
