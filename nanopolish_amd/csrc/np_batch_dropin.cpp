@@ -26,6 +26,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <omp.h>
 #include "np_batch_dropin.h"
 #include "nanopolish_alphabet.h"
 #include "nanopolish_eventalign.h"          // get_reference_region_ts
@@ -35,45 +36,39 @@
 
 using np_shim::shim;
 using np_shim::check;
+using np_shim::die;
+using np_shim::Layout;
+using np_shim::Blob;
 
 namespace {
 
 int g_event_cap_divisor = 2;
 
-void die(const char* what)
+// 0..3 for A, C, G, T (DNAAlphabet's ranks), 4 for anything else
+inline int base_code(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; }
+
+bool is_plain_acgt(const std::string& s)
 {
-    fprintf(stderr, "nanopolish_amd: %s\n", what);
-    exit(EXIT_FAILURE);
+    for (size_t i = 0; i < s.size(); ++i) if (base_code(s[i]) > 3) return false;
+    return true;
 }
 
-// arrays laid out back to back in one allocation, each aligned to 256 bytes
-struct Layout {
-    size_t size;
-    Layout() : size(0) {}
-    size_t add(size_t bytes) { const size_t o = size; size = (size + bytes + 255) & ~(size_t)255; return o; }
-};
-
-// a device allocation, optionally with a pinned host mirror of the same layout; grows, never shrinks
-struct Blob {
-    char* d; char* h; size_t cap; bool mirrored;
-    explicit Blob(bool with_host) : d(NULL), h(NULL), cap(0), mirrored(with_host) {}
-    void reserve(np_ctx* c, size_t bytes)
-    {
-        if (bytes <= cap) return;
-        release(c);
-        const size_t want = bytes + bytes / 4 + 4096;
-        d = (char*)np_dev_alloc(c, want);
-        if (!d) die(np_last_error(c));
-        if (mirrored) { h = (char*)np_host_alloc(c, want); if (!h) die(np_last_error(c)); }
-        cap = want;
+// gDNAAlphabet.kmer_rank(seq + j, k) for every k-mer of the read (Alphabet::kmer_rank, nanopolish_alphabet.h: the base-4 number of the
+// k-mer's base ranks), as one rolling pass; a read with a character outside ACGT goes through the reference's own function
+void nucleotide_kmer_ranks(const std::string& seq, uint32_t k, uint16_t* out)
+{
+    const size_t n = seq.size() >= k ? seq.size() - k + 1 : 0;
+    if (!is_plain_acgt(seq)) {
+        for (size_t j = 0; j < n; ++j) out[j] = (uint16_t)gDNAAlphabet.kmer_rank(seq.c_str() + j, k);
+        return;
     }
-    void release(np_ctx* c)
-    {
-        if (d) np_dev_free(c, d);
-        if (h) np_host_free(c, h);
-        d = h = NULL; cap = 0;
+    const uint32_t mask = (1u << (2 * k)) - 1u;
+    uint32_t r = 0;
+    for (size_t i = 0; i < seq.size(); ++i) {
+        r = ((r << 2) | (uint32_t)base_code(seq[i])) & mask;
+        if (i + 1 >= k) out[i + 1 - k] = (uint16_t)r;
     }
-};
+}
 
 // what one batch in flight needs on the host until it is collected
 struct Slot {
@@ -102,7 +97,8 @@ struct NpBatchPipeline::Impl {
     Blob scratch;
     void *s_h2d, *s_d2h;
     long n_submitted, n_collected;
-    Impl() : c(NULL), fai(NULL), hdr(NULL), region_start(-1), region_end(-1), scratch(false), s_h2d(NULL), s_d2h(NULL), n_submitted(0), n_collected(0) {}
+    double t[6];
+    Impl() : c(NULL), fai(NULL), hdr(NULL), region_start(-1), region_end(-1), scratch(false), s_h2d(NULL), s_d2h(NULL), n_submitted(0), n_collected(0) { for (int i = 0; i < 6; ++i) t[i] = 0.0; }
 };
 
 NpBatchPipeline::NpBatchPipeline(const MethylationCallingParameters& calling_parameters, const std::string& kit, const faidx_t* fai,
@@ -141,6 +137,7 @@ void NpBatchPipeline::configure(const MethylationCallingParameters& calling_para
 }
 
 int NpBatchPipeline::in_flight() const { return (int)(p->n_submitted - p->n_collected); }
+void NpBatchPipeline::host_seconds(double out[6]) const { for (int i = 0; i < 6; ++i) out[i] = p->t[i]; }
 
 void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
 {
@@ -166,6 +163,7 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
     const int MINSEP = p->params.min_separation, FLANK = p->params.min_flank;
 
     // ---- phase 1a: which records go to the device, their reference segments and sizes ---------------------------------------
+    double tm = omp_get_wtime();
     std::vector<int> idx;                         // device order -> batch index
     for (int i = 0; i < n_all; ++i) {
         reads[i].status = NP_BATCH_OK;
@@ -185,7 +183,10 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
         const std::string contig = p->hdr->target_name[record->core.tid];
         S.ref_start[i] = record->core.pos;
         int fetched_len = 0;
-        S.ref_seqs[i] = gDNAAlphabet.disambiguate(get_reference_region_ts(p->fai, contig.c_str(), S.ref_start[i], bam_endpos(record), &fetched_len));   // :258-270
+        S.ref_seqs[i] = get_reference_region_ts(p->fai, contig.c_str(), S.ref_start[i], bam_endpos(record), &fetched_len);   // :258-270
+        // Alphabet::disambiguate (upper-casing + IUPAC codes -> their first base) is the identity on an upper-case ACGT string, and
+        // it builds one std::string per character: 0.3 ms of a host core per 5 kb read.  Only a segment that needs it gets it.
+        if (!is_plain_acgt(S.ref_seqs[i])) S.ref_seqs[i] = gDNAAlphabet.disambiguate(S.ref_seqs[i]);
     }
     std::vector<int64_t> raw_off(n + 1, 0), event_off(n + 1, 0), rank_off(n + 1, 0), cigar_off(n + 1, 0), jr_off(n + 1, 0),
                          pair_off(n + 1, 0), genome_off(n + 1, 0);
@@ -234,11 +235,13 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
                  s_ev_stdv = ls.add((size_t)n_ev * 4), s_ev_start = ls.add((size_t)n_ev * 4), s_map_start = ls.add((size_t)n_rk * 4),
                  s_map_stop = ls.add((size_t)n_rk * 4), s_pairs = ls.add((size_t)pair_off[n] * sizeof(np_pair)),
                  s_job_ranks = ls.add((size_t)jr_off[n] * sizeof(uint16_t));
+    p->t[0] += omp_get_wtime() - tm; tm = omp_get_wtime();
     S.in.reserve(c, li.size + 256); S.out.reserve(c, lo.size + 256);
     if (ls.size + 256 > p->scratch.cap) {
         check(np_sync(c, NULL), "np_sync");                  // the batch in flight still computes in the scratch that is about to be replaced
         p->scratch.reserve(c, ls.size + 256);
     }
+    p->t[5] += omp_get_wtime() - tm; tm = omp_get_wtime();
 
     // ---- phase 1b: pack the pinned input blob -----------------------------------------------------------------------------
     char* H = S.in.h;
@@ -255,8 +258,7 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
             np_fill_read_host(t ? &h_reads_b[q] : &h_reads_a[q], 0.0, 1.0, 1.0, event_off[q], (uint32_t)(event_off[q + 1] - event_off[q]), rank_off[q],
                               (uint32_t)(rank_off[q + 1] - rank_off[q]));
         memcpy(h_raw + raw_off[q], reads[i].raw_pa, reads[i].n_raw * sizeof(float));
-        for (int64_t j = 0; j < rank_off[q + 1] - rank_off[q]; ++j)
-            h_ranks[rank_off[q] + j] = (uint16_t)gDNAAlphabet.kmer_rank(seq.c_str() + j, k);
+        nucleotide_kmer_ranks(seq, k, h_ranks + rank_off[q]);
         memcpy(h_genome + genome_off[q], S.ref_seqs[i].data(), S.ref_seqs[i].size());
         h_ref_begin[q] = genome_off[q]; h_ref_len[q] = (int32_t)S.ref_seqs[i].size();
         memcpy(h_cigar + cigar_off[q], bam_get_cigar(record), 4 * (size_t)record->core.n_cigar);
@@ -267,6 +269,7 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
     memcpy(H + i_cigar_off, cigar_off.data(), (size_t)(n + 1) * 8); memcpy(H + i_group_off, group_off.data(), (size_t)(n + 1) * 8);
     memcpy(H + i_jr_off, jr_off.data(), (size_t)(n + 1) * 8); memcpy(H + i_pair_off, pair_off.data(), (size_t)(n + 1) * 8);
 
+    p->t[1] += omp_get_wtime() - tm; tm = omp_get_wtime();
     // ---- phase 2: one upload, the batch on the device, one read-back -----------------------------------------------------------
     const int m_nuc = shim().model_id(pm_nuc);
     const int m_meth = shim().model_id(PoreModelSet::get_model(p->kit, p->params.methylation_type, strand_name, k));
@@ -314,6 +317,7 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
     check(np_stream_wait_event(c, p->s_d2h, S.ev_cmp), "np_stream_wait_event");
     check(np_copy_to_host(c, p->s_d2h, S.out.h, S.out.d, lo.size), "np_copy_to_host");
     check(np_event_record(c, S.ev_d2h, p->s_d2h), "np_event_record");
+    p->t[2] += omp_get_wtime() - tm;
 }
 
 bool NpBatchPipeline::collect(MethylationCallingResult& result)
@@ -325,7 +329,9 @@ bool NpBatchPipeline::collect(MethylationCallingResult& result)
     std::vector<NpBatchRead>& reads = *S.reads;
     const int n = (int)reads.size();
     if (n == 0) return true;
+    double tm = omp_get_wtime();
     if (S.n_dev > 0) check(np_event_sync(c, S.ev_d2h), "np_event_sync");
+    p->t[3] += omp_get_wtime() - tm; tm = omp_get_wtime();
     const char* O = S.out.h;
     const float* scores = (const float*)(O + S.o_scores);
     const int32_t *first = (const int32_t*)(O + S.o_first), *last = (const int32_t*)(O + S.o_last), *n_motif = (const int32_t*)(O + S.o_n_motif),
@@ -334,10 +340,17 @@ bool NpBatchPipeline::collect(MethylationCallingResult& result)
     const uint32_t k = 6;
 
     // ---- phase 3: ScoredSite maps (basemods.cpp:384-413) ------------------------------------------------------------------
+    // the per-record maps are created serially (result is one std::map), then filled in parallel: records are independent
+    std::vector<std::map<int, ScoredSite>*> maps(n, (std::map<int, ScoredSite>*)NULL);
+    for (int i = 0; i < n; ++i) {
+        if (reads[i].status == NP_BATCH_HOST_PATH) continue;            // decided in phase 1: the caller's per-record function fills its map
+        maps[i] = &result[reads[i].record];                              // the (possibly empty) map of the record, basemods.cpp:253-256
+    }
+    #pragma omp parallel for schedule(dynamic, 16)
     for (int i = 0; i < n; ++i) {
         const bam1_t* record = reads[i].record;
-        if (reads[i].status == NP_BATCH_HOST_PATH) continue;            // decided in phase 1: the caller's per-record function fills its map
-        std::map<int, ScoredSite>& site_score_map = result[record];      // the (possibly empty) map of the record, basemods.cpp:253-256
+        if (!maps[i]) continue;
+        std::map<int, ScoredSite>& site_score_map = *maps[i];
         const int q = S.dev_index[i];
         if (q < 0) continue;                                             // no motif model for the kit: the map stays empty
         if (n_events[q] < 0 || n_groups[q] < 0) { reads[i].status = NP_BATCH_HOST_PATH; continue; }   // NP_ED_INEXACT / NP_ED_OVERFLOW / capacity
@@ -368,6 +381,7 @@ bool NpBatchPipeline::collect(MethylationCallingResult& result)
             iter->second.strands_scored += 1;
         }
     }
+    p->t[4] += omp_get_wtime() - tm;
     return true;
 }
 

@@ -50,6 +50,10 @@ public:
     void submit(std::vector<NpBatchRead>& reads);              // at most two batches in flight (exits with a message otherwise)
     bool collect(MethylationCallingResult& result);           // the oldest batch in flight; false if there is none
     int in_flight() const;
+    // host wall-clock seconds spent in the phases since construction (diagnostics; tests/bench_batch_dropin.py prints them):
+    // [0] phase 1a reference fetch + sizes, [1] phase 1b packing the pinned blob, [2] enqueueing copies and kernels,
+    // [3] collect: waiting for the device, [4] phase 3 ScoredSite maps, [5] buffer growth (allocation)
+    void host_seconds(double out[6]) const;
     struct Impl;
 private:
     Impl* p;

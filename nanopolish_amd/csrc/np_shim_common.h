@@ -92,6 +92,41 @@ inline void check(int rc, const char* what)
     if (rc != NP_OK) { fprintf(stderr, "nanopolish_amd: %s failed (%d): %s\n", what, rc, np_last_error(shim().get())); exit(EXIT_FAILURE); }
 }
 
+inline void die(const char* what)
+{
+    fprintf(stderr, "nanopolish_amd: %s\n", what);
+    exit(EXIT_FAILURE);
+}
+
+// arrays laid out back to back in one allocation, each aligned to 256 bytes
+struct Layout {
+    size_t size;
+    Layout() : size(0) {}
+    size_t add(size_t bytes) { const size_t o = size; size = (size + bytes + 255) & ~(size_t)255; return o; }
+};
+
+// a device allocation, optionally with a pinned host mirror of the same layout; grows, never shrinks
+struct Blob {
+    char* d; char* h; size_t cap; bool mirrored;
+    explicit Blob(bool with_host) : d(NULL), h(NULL), cap(0), mirrored(with_host) {}
+    void reserve(np_ctx* c, size_t bytes)
+    {
+        if (bytes <= cap) return;
+        release(c);
+        const size_t want = bytes + bytes / 4 + 4096;
+        d = (char*)np_dev_alloc(c, want);
+        if (!d) die(np_last_error(c));
+        if (mirrored) { h = (char*)np_host_alloc(c, want); if (!h) die(np_last_error(c)); }
+        cap = want;
+    }
+    void release(np_ctx* c)
+    {
+        if (d) np_dev_free(c, d);
+        if (h) np_host_free(c, h);
+        d = h = NULL; cap = 0;
+    }
+};
+
 } // namespace np_shim
 
 // For callers that edit registered PoreModels in place one state at a time (methyltrain's rounds): the next call on every cached

@@ -268,12 +268,14 @@ def call_methylation_pipeline(records, contig_seq, batch_size, methylation_type=
 def bench_batch(records, contig_seq, batch_size, n_batches, warmup=2, pipelined=True):
     """Seconds for n_batches batches of batch_size records (the given distinct records, cycled) through the batched binding:
     NpBatchPipeline with two batches in flight (pipelined) or the synchronous np_calculate_methylation_for_batch.
-    Returns (seconds, sites written, records that did not come back NP_BATCH_OK)."""
+    Returns (seconds, sites written, records that did not come back NP_BATCH_OK, host seconds per phase of the timed batches)."""
     L = C.CDLL(_BATCH)
     L.npfull_bench_batch.restype = C.c_double
     n, raw, raw_off, cig, cig_off, is_rev, pos, seqs, bseqs = _batch_args(records)
     n_sites, n_bad = C.c_int64(0), C.c_int64(0)
+    hs = np.zeros(7, np.float64)
     sec = L.npfull_bench_batch(n, seqs, _p(raw, C.POINTER(C.c_float)), _p(raw_off, C.POINTER(C.c_int64)), _p(is_rev, _i32p), _p(pos, _i32p),
                                _p(cig, _u32p), _p(cig_off, C.POINTER(C.c_int64)), bseqs, contig_seq.encode(), int(batch_size), int(n_batches),
-                               int(warmup), int(bool(pipelined)), C.byref(n_sites), C.byref(n_bad))
-    return float(sec), int(n_sites.value), int(n_bad.value)
+                               int(warmup), int(bool(pipelined)), C.byref(n_sites), C.byref(n_bad), _p(hs, _f64p))
+    names = ("phase1a_fetch_sizes", "phase1b_pack", "enqueue", "wait_device", "phase3_maps", "buffer_growth", "inside_binding")
+    return float(sec), int(n_sites.value), int(n_bad.value), {k: round(float(v), 4) for k, v in zip(names, hs)}

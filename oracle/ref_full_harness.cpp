@@ -347,10 +347,12 @@ int npfull_call_methylation_pipeline(int n, int batch_size, int event_cap_diviso
 // Throughput of the binding (tests/bench_batch_dropin.py): n_distinct records cycled into batches of `batch_size`, `n_batches` of them
 // after `warmup` untimed ones, through NpBatchPipeline (pipelined != 0: two batches in flight) or through the synchronous
 // np_calculate_methylation_for_batch.  Every batch gets its own MethylationCallingResult, as one BamProcessor batch does.
-// Returns the seconds the timed batches took (host wall clock around the whole loop: phases 1-3 and the device pass).
+// Returns the seconds the timed batches took (host wall clock around the whole loop: phases 1-3, the device pass, and this
+// harness's own share -- counting the sites and destroying the result maps, which stands in for the caller's writer);
+// host_seconds[0..5]: NpBatchPipeline::host_seconds of the timed batches, [6]: seconds inside submit() + collect().
 double npfull_bench_batch(int n_distinct, const char* const* read_seqs, const float* raw, const int64_t* raw_off, const int32_t* is_rev,
                           const int32_t* pos, const uint32_t* cigar, const int64_t* cigar_off, const char* const* bam_seqs, const char* contig_seq,
-                          int batch_size, int n_batches, int warmup, int pipelined, int64_t* n_sites, int64_t* n_not_ok)
+                          int batch_size, int n_batches, int warmup, int pipelined, int64_t* n_sites, int64_t* n_not_ok, double* host_seconds /* [7] */)
 {
     std::vector<std::string> seqs(n_distinct);
     for(int i = 0; i < n_distinct; ++i) seqs[i] = read_seqs[i];
@@ -374,36 +376,50 @@ double npfull_bench_batch(int n_distinct, const char* const* read_seqs, const fl
     params.methylation_type = "cpg";
     params.alphabet = get_alphabet_by_name("cpg");
     int64_t sites = 0, not_ok = 0;
-    double t0 = 0.0, t1 = 0.0;
+    double t0 = 0.0, t1 = 0.0, t_in = 0.0, tq = 0.0;
     {
         NpBatchPipeline pipe(params, "r9.4_450bps", &recs[0][0]->fai, &recs[0][0]->hdr, -1, -1);
         MethylationCallingResult res[2];
         for(int b = 0; b < warmup + n_batches; ++b) {
-            if(b == warmup) { while(pipe.collect(res[(b + 1) & 1])) {} res[0].clear(); res[1].clear(); sites = 0; not_ok = 0; t0 = omp_get_wtime(); }
+            if(b == warmup) {
+                while(pipe.collect(res[(b + 1) & 1])) {}
+                res[0].clear(); res[1].clear(); sites = 0; not_ok = 0;
+                pipe.host_seconds(host_seconds);          // (the warm-up's share is subtracted below)
+                t_in = 0.0;
+                t0 = omp_get_wtime();
+            }
             const int s = b & 1;
             if(pipelined) {
                 res[s].clear();
-                pipe.submit(reads[s]);
+                tq = omp_get_wtime(); pipe.submit(reads[s]); t_in += omp_get_wtime() - tq;
                 if(pipe.in_flight() == 2) {
-                    pipe.collect(res[s ^ 1]);
+                    tq = omp_get_wtime(); pipe.collect(res[s ^ 1]); t_in += omp_get_wtime() - tq;
                     for(MethylationCallingResult::const_iterator it = res[s ^ 1].begin(); it != res[s ^ 1].end(); ++it) sites += (int64_t)it->second.size();
                     for(int j = 0; j < batch_size; ++j) not_ok += reads[s ^ 1][j].status != NP_BATCH_OK;
                 }
             } else {
                 res[s].clear();
+                tq = omp_get_wtime();
                 np_calculate_methylation_for_batch(res[s], reads[s], params, "r9.4_450bps", &recs[0][0]->fai, &recs[0][0]->hdr, -1, -1);
+                t_in += omp_get_wtime() - tq;
                 for(MethylationCallingResult::const_iterator it = res[s].begin(); it != res[s].end(); ++it) sites += (int64_t)it->second.size();
                 for(int j = 0; j < batch_size; ++j) not_ok += reads[s][j].status != NP_BATCH_OK;
             }
         }
         if(pipelined) {
             const int s = (warmup + n_batches - 1) & 1;
-            if(pipe.collect(res[s])) {
+            tq = omp_get_wtime();
+            const bool more = pipe.collect(res[s]);
+            t_in += omp_get_wtime() - tq;
+            if(more) {
                 for(MethylationCallingResult::const_iterator it = res[s].begin(); it != res[s].end(); ++it) sites += (int64_t)it->second.size();
                 for(int j = 0; j < batch_size; ++j) not_ok += reads[s][j].status != NP_BATCH_OK;
             }
         }
         t1 = omp_get_wtime();
+        double hs[6]; pipe.host_seconds(hs);
+        for(int i = 0; i < 6; ++i) host_seconds[i] = pipelined ? hs[i] - host_seconds[i] : 0.0;
+        host_seconds[6] = t_in;
     }
     *n_sites = sites; *n_not_ok = not_ok;
     for(int s = 0; s < 2; ++s) for(int j = 0; j < batch_size; ++j) delete recs[s][j];

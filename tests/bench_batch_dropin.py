@@ -20,6 +20,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# OpenMP inside the binding (and inside the reference objects it is linked with) sizes its team from the VISIBLE CPUs; a container
+# with a CPU quota below that (the GPU box: 256 visible, 16 granted) would run 256 threads on 16 CPUs.  Must be set before libgomp
+# starts its first team.
+from nanopolish_amd.hostinfo import usable_cores  # noqa: E402
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores()[2])))
 
 
 def main():
@@ -54,9 +59,13 @@ def main():
         line = dict(metric="call-methylation reads/sec through np_calculate_methylation_for_batch", unit="reads/s", batch_size=bs, batches=nb,
                     distinct_reads=args.distinct, read_len=args.read_len, raw_bytes_per_read=int(raw_bytes))
         for name, pipelined in (("pipelined", True), ("sync", False)):
-            sec, sites, bad = bench_batch(recs, contig, bs, nb, warmup=2, pipelined=pipelined)
+            sec, sites, bad, hs = bench_batch(recs, contig, bs, nb, warmup=2, pipelined=pipelined)
             line[name] = dict(value=round(bs * nb / sec, 1), ms_per_batch=round(sec / nb * 1e3, 2), sites_per_read=round(sites / (bs * nb), 2),
                               records_not_ok=bad, h2d_GBps=round(bs * nb * raw_bytes / sec / 1e9, 2))
+            line[name]["value_binding_only"] = round(bs * nb / hs["inside_binding"], 1) if hs["inside_binding"] > 0 else None
+            if pipelined:
+                line[name]["host_ms_per_batch"] = {k: round(v / nb * 1e3, 2) for k, v in hs.items()}
+        line["omp_threads"] = int(os.environ["OMP_NUM_THREADS"])
         line["host_prep_s"] = round(prep, 1)
         print(json.dumps(line), flush=True)
 
