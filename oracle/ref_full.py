@@ -133,10 +133,13 @@ class FullRead:
 
 
 class FullRef:
-    def __init__(self):
+    def __init__(self, batch=False):
+        """batch=False: the unmodified reference (libnp_ref_full.so, CPU).  batch=True: the reference with the product's bindings linked
+        in place of its hot-path translation units (libnp_ref_full_batch.so, needs a GPU): the same entry points then run through
+        np_dropin.cpp, and the np_* batched bindings are reachable (mode=1 of score_variants / score_variant_group)."""
         if not have_full():
             raise RuntimeError("oracle/_ref/libnp_ref_full.so is not built (needs /root/reference; `make -C oracle full`)")
-        L = C.CDLL(_FULL)
+        L = C.CDLL(os.path.join(_HERE, "_ref", "libnp_ref_full_batch.so") if batch else _FULL)
         L.npfull_read_create.restype = C.c_void_p
         L.npfull_read_create.argtypes = [C.c_char_p, C.c_char_p, _f32p, C.c_size_t, C.c_double]
         L.npfull_read_destroy.argtypes = [C.c_void_p]
@@ -157,6 +160,46 @@ class FullRef:
         L.npfull_many_identity.argtypes = [C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int64), _f32p, C.POINTER(C.c_int64), _u8p, C.c_double,
                                            C.c_int, _i32p]
         self.L = L
+
+    def _variant_args(self, reads, records):
+        n = len(reads)
+        hs = (C.c_void_p * n)(*[r.h for r in reads])
+        cig = np.concatenate([np.ascontiguousarray(r["cigar"], np.uint32) for r in records])
+        cig_off = np.zeros(n + 1, np.int64); cig_off[1:] = np.cumsum([len(r["cigar"]) for r in records])
+        is_rev = np.array([int(r["rc"]) for r in records], np.int32); pos = np.array([int(r["pos"]) for r in records], np.int32)
+        bseqs = (C.c_char_p * n)(*[r["bam_seq"].encode() for r in records])
+        return n, hs, is_rev, pos, cig, cig_off, bseqs
+
+    def score_variants(self, mode, reads, records, contig_seq, positions, flank=10, score_threshold=1000000, methylation_types="",
+                       indel_bias=0.9, cap=1 << 16):
+        """The screening loop of generate_candidate_single_base_edits over `positions` (npfull_score_variants): mode 0 = the
+        reference's score_variant_thresholded per candidate (one OpenMP thread), mode 1 = np_score_variants_thresholded, all windows
+        in one device batch (batch=True only).  reads: FullRead objects of THIS library; records: dicts(rc, pos, cigar, bam_seq).
+        Returns (quality per candidate, window index per candidate, number of profile_hmm_score_set evaluations)."""
+        n, hs, is_rev, pos, cig, cig_off, bseqs = self._variant_args(reads, records)
+        P = np.ascontiguousarray(positions, np.int32)
+        q = np.zeros(cap, np.float64); w = np.zeros(cap, np.int32); sets = C.c_int64(0)
+        self.L.npfull_score_variants.restype = C.c_int
+        m = self.L.npfull_score_variants(int(mode), n, hs, _p(is_rev, _i32p), _p(pos, _i32p), _p(cig, _u32p), _p(cig_off, C.POINTER(C.c_int64)),
+                                         bseqs, contig_seq.encode(), len(P), _p(P, _i32p), int(flank), int(score_threshold),
+                                         methylation_types.encode(), C.c_double(indel_bias), cap, _p(q, _f64p), _p(w, _i32p), C.byref(sets))
+        assert 0 <= m <= cap
+        return q[:m].copy(), w[:m].copy(), int(sets.value)
+
+    def score_variant_group(self, mode, reads, records, contig_seq, positions, flank=10, max_haplotypes=1000, methylation_types="",
+                            indel_bias=0.8, cap=1 << 20):
+        """score_variant_group for one group of substitutions at `positions`: array [combination, input read] of
+        get_combination_read_score (mode as score_variants)."""
+        n, hs, is_rev, pos, cig, cig_off, bseqs = self._variant_args(reads, records)
+        P = np.ascontiguousarray(positions, np.int32)
+        sc = np.zeros(cap, np.float64); ni = C.c_int(0)
+        self.L.npfull_score_variant_group.restype = C.c_int
+        nc = self.L.npfull_score_variant_group(int(mode), n, hs, _p(is_rev, _i32p), _p(pos, _i32p), _p(cig, _u32p),
+                                               _p(cig_off, C.POINTER(C.c_int64)), bseqs, contig_seq.encode(), len(P), _p(P, _i32p), int(flank),
+                                               int(max_haplotypes), methylation_types.encode(), C.c_double(indel_bias), cap, _p(sc, _f64p),
+                                               C.byref(ni))
+        assert nc >= 0 and nc * ni.value <= cap
+        return sc[:nc * ni.value].reshape(nc, ni.value).copy()
 
     def many_identity(self, mode, seqs, raws, rcs, n_threads=0, sample_rate=4000.0):
         """OpenMP-over-reads timing driver (see npfull_many_identity): mode 0 eventalign, 1 call-methylation.
@@ -279,3 +322,41 @@ def bench_batch(records, contig_seq, batch_size, n_batches, warmup=2, pipelined=
                                int(warmup), int(bool(pipelined)), C.byref(n_sites), C.byref(n_bad), _p(hs, _f64p))
     names = ("phase1a_fetch_sizes", "phase1b_pack", "enqueue", "wait_device", "phase3_maps", "buffer_growth", "inside_binding")
     return float(sec), int(n_sites.value), int(n_bad.value), {k: round(float(v), 4) for k, v in zip(names, hs)}
+
+
+def realign_batch(records, contig_seq, sample_rate=4000.0):
+    """The records through ONE np_realign_reads_batch (nanopolish_amd/csrc/np_eventalign_dropin.cpp; libnp_ref_full_batch.so): list of
+    per-record dicts with the rebuilt SquiggleRead's fields (n_events, shift, scale, var, events_per_base, event mean / stdv / duration /
+    start_time, event map), the EventAlignment rows and the TSV text the reference's own writer prints from them; and the status array."""
+    L = C.CDLL(_BATCH)
+    n, raw, raw_off, cig, cig_off, is_rev, pos, seqs, bseqs = _batch_args(records)
+    ecap = np.array([len(r["raw"]) // 2 + 2 for r in records], np.int64)
+    ev_off = np.zeros(n + 1, np.int64); ev_off[1:] = np.cumsum(ecap)
+    mcap = np.array([len(r["seq"]) for r in records], np.int64)
+    map_off = np.zeros(n + 1, np.int64); map_off[1:] = np.cumsum(mcap)
+    status = np.zeros(n, np.int32); n_events = np.zeros(n, np.int32)
+    sh, sc, va, epb = (np.zeros(n, np.float64) for _ in range(4))
+    evm, evs, evd = (np.zeros(int(ev_off[-1]), np.float32) for _ in range(3)); evt = np.zeros(int(ev_off[-1]), np.float64)
+    ms, me = np.full(int(map_off[-1]), -2, np.int32), np.full(int(map_off[-1]), -2, np.int32)
+    row_cap = int(ev_off[-1]) + n
+    row_off = np.zeros(n + 1, np.int64); rp = np.zeros(row_cap, np.int32); ei = np.zeros(row_cap, np.int32); st = C.create_string_buffer(row_cap)
+    tsv_cap = 160 * row_cap
+    tsv = C.create_string_buffer(tsv_cap); tsv_off = np.zeros(n + 1, np.int64)
+    i64 = C.POINTER(C.c_int64)
+    L.npfull_realign_batch(n, seqs, _p(raw, C.POINTER(C.c_float)), _p(raw_off, i64), _p(is_rev, _i32p), _p(pos, _i32p), _p(cig, _u32p), _p(cig_off, i64),
+                           bseqs, contig_seq.encode(), C.c_double(sample_rate), _p(status, _i32p), _p(n_events, _i32p), _p(sh, _f64p), _p(sc, _f64p),
+                           _p(va, _f64p), _p(epb, _f64p), _p(ev_off, i64), _p(evm, _f32p), _p(evs, _f32p), _p(evd, _f32p), _p(evt, _f64p),
+                           _p(map_off, i64), _p(ms, _i32p), _p(me, _i32p), C.c_int64(row_cap), _p(row_off, i64), _p(rp, _i32p), _p(ei, _i32p), st,
+                           tsv, C.c_int64(tsv_cap), _p(tsv_off, i64))
+    assert tsv_off[-1] < tsv_cap and row_off[-1] <= row_cap
+    out = []
+    for i in range(n):
+        a, b = int(ev_off[i]), int(ev_off[i]) + int(n_events[i])
+        k_n = len(records[i]["seq"]) - 5
+        out.append(dict(n_events=int(n_events[i]), shift=float(sh[i]), scale=float(sc[i]), var=float(va[i]), events_per_base=float(epb[i]),
+                        mean=evm[a:b].copy(), stdv=evs[a:b].copy(), duration=evd[a:b].copy(), start_time=evt[a:b].copy(),
+                        map_start=ms[int(map_off[i]):int(map_off[i]) + k_n].copy(), map_stop=me[int(map_off[i]):int(map_off[i]) + k_n].copy(),
+                        ref_position=rp[int(row_off[i]):int(row_off[i + 1])].copy(), event_idx=ei[int(row_off[i]):int(row_off[i + 1])].copy(),
+                        hmm_state=np.frombuffer(st.raw[int(row_off[i]):int(row_off[i + 1])], np.uint8).copy(),
+                        tsv=tsv.raw[int(tsv_off[i]):int(tsv_off[i + 1])].decode()))
+    return out, status

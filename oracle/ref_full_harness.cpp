@@ -20,6 +20,9 @@
 #include <cstring>
 #include <cstdlib>
 #include <string>
+#include <sstream>
+#include <algorithm>
+#include <cmath>
 #include <vector>
 #include <map>
 #include <omp.h>
@@ -30,6 +33,15 @@
 #include "nanopolish_basemods.h"
 #include "nanopolish_eventalign.h"
 #include "nanopolish_alphabet.h"
+#include "nanopolish_profile_hmm.h"
+#include "nanopolish_haplotype.h"
+#include "nanopolish_variant.h"
+#include "nanopolish_variant_db.h"
+#ifdef NP_WITH_BATCH
+#include "np_variants_dropin.h"
+#include "np_eventalign_dropin.h"
+#endif
+extern double hmm_indel_bias_factor;
 
 // ---- htslib stand-ins that execute -------------------------------------------------------------------------------
 struct faidx_t { std::string name; std::string seq; };
@@ -427,6 +439,170 @@ double npfull_bench_batch(int n_distinct, const char* const* read_seqs, const fl
 }
 #endif
 
+
+// ---- variants: score_variant_thresholded / score_variant_group ------------------------------------------------------------------
+namespace {
+// the HMMInputData of AlignmentDB::get_event_subsequences (src/alignment/nanopolish_alignment_db.cpp:172-221) for the reads given
+// as (SquiggleRead handle, BAM record): the event range of [start, stop] on every read that spans it
+std::vector<HMMInputData> window_input(const std::vector<EventAlignmentRecord>& ears, int start, int stop)
+{
+    std::vector<HMMInputData> out;
+    for(size_t i = 0; i < ears.size(); ++i) {
+        const EventAlignmentRecord& record = ears[i];
+        if(record.aligned_events.empty() || !record.sr->has_events_for_strand(record.strand)) continue;
+        HMMInputData data;
+        data.read = record.sr; data.pore_model = record.sr->get_base_model(record.strand); data.strand = record.strand;
+        data.rc = record.rc; data.event_stride = record.stride;
+        int e1, e2;
+        if(AlignmentDB::_find_by_ref_bounds(record.aligned_events, start, stop, e1, e2)) {
+            const double ratio = fabs(e1 - e2) / fabs(stop - start);
+            if(ratio < MAX_EVENT_TO_BP_RATIO) { data.event_start_idx = e1; data.event_stop_idx = e2; out.push_back(data); }
+        }
+    }
+    return out;
+}
+std::vector<std::string> split_csv(const char* s)
+{
+    std::vector<std::string> out; std::string cur;
+    for(const char* p = s; *p; ++p) { if(*p == ',') { if(!cur.empty()) out.push_back(cur); cur.clear(); } else cur += *p; }
+    if(!cur.empty()) out.push_back(cur);
+    return out;
+}
+// candidate single-base edits at position i (src/nanopolish_call_variants.cpp:306-338)
+std::vector<Variant> candidate_edits(const std::string& contig, int i)
+{
+    std::vector<Variant> out;
+    for(size_t j = 0; j < 4; ++j) {
+        Variant v; v.ref_name = "contig"; v.ref_position = i; v.ref_seq = contig.substr(i, 1); v.alt_seq = "ACGT"[j];
+        if(v.ref_seq != v.alt_seq) out.push_back(v);
+        v.alt_seq = v.ref_seq + "ACGT"[j];
+        if(v.alt_seq[1] != v.ref_seq[0]) out.push_back(v);
+    }
+    Variant del; del.ref_name = "contig"; del.ref_position = i - 1; del.ref_seq = contig.substr(i - 1, 2); del.alt_seq = del.ref_seq[0];
+    if(del.alt_seq[0] != del.ref_seq[1]) out.push_back(del);
+    return out;
+}
+}
+
+// The screening loop of generate_candidate_single_base_edits (src/nanopolish_call_variants.cpp:288-352) over the given positions.
+//   mode 0: the reference's score_variant_thresholded, variant by variant, ONE OpenMP thread (its accumulation is order-dependent
+//           otherwise); in the `batch` build this runs through the per-call shim
+//   mode 1: np_score_variants_thresholded (nanopolish_amd/csrc/np_variants_dropin.cpp), every window in ONE device batch
+// quality[v], win[v] (index into positions) per candidate, in generation order.  Returns the number of candidates (or -1).
+int npfull_score_variants(int mode, int n_reads, void** handles, const int32_t* is_rev, const int32_t* pos, const uint32_t* cigar,
+                          const int64_t* cigar_off, const char* const* bam_seqs, const char* contig_seq, int n_windows, const int32_t* positions,
+                          int flank, int score_threshold, const char* methylation_types, double indel_bias, int cap, double* quality, int32_t* win,
+                          int64_t* n_forward_sets)
+{
+    const std::string contig(contig_seq);
+    std::vector<Record*> recs(n_reads);
+    std::vector<EventAlignmentRecord> ears;
+    for(int i = 0; i < n_reads; ++i) {
+        recs[i] = new Record("read", is_rev[i], pos[i], cigar + cigar_off[i], (int)(cigar_off[i + 1] - cigar_off[i]), bam_seqs[i], "A");
+        SequenceAlignmentRecord sar(&recs[i]->b);
+        ears.push_back(EventAlignmentRecord((SquiggleRead*)handles[i], 0, sar));
+    }
+    const std::vector<std::string> mt = split_csv(methylation_types);
+    const uint32_t flags = HAF_ALLOW_PRE_CLIP | HAF_ALLOW_POST_CLIP;
+    const double saved_bias = hmm_indel_bias_factor;
+    hmm_indel_bias_factor = indel_bias;
+    int n = 0; int64_t sets = 0;
+#ifdef NP_WITH_BATCH
+    std::vector<NpVariantWindow> windows;
+#endif
+    const int saved_threads = omp_get_max_threads();
+    if(mode == 0) omp_set_num_threads(1);
+    for(int w = 0; w < n_windows; ++w) {
+        const int i = positions[w], calling_start = i - flank, calling_end = i + 1 + flank;
+        Haplotype test_haplotype("contig", calling_start, contig.substr(calling_start, calling_end - calling_start + 1));
+        const std::vector<Variant> cands = candidate_edits(contig, i);
+        const std::vector<HMMInputData> input = window_input(ears, calling_start, calling_end);
+        sets += (int64_t)(cands.size() + 1) * (int64_t)input.size();
+        if(mode == 0) {
+            for(size_t v = 0; v < cands.size(); ++v, ++n) {
+                const Variant scored = score_variant_thresholded(cands[v], test_haplotype, input, flags, score_threshold, mt);
+                if(n < cap) { quality[n] = scored.quality; win[n] = w; }
+            }
+        } else {
+#ifdef NP_WITH_BATCH
+            NpVariantWindow W(test_haplotype); W.variants = cands; W.input = input;
+            windows.push_back(W);
+#else
+            n = -1; break;
+#endif
+        }
+    }
+#ifdef NP_WITH_BATCH
+    if(mode == 1) {
+        const std::vector<std::vector<Variant> > out = np_score_variants_thresholded(windows, flags, score_threshold, mt);
+        for(size_t w = 0; w < out.size(); ++w)
+            for(size_t v = 0; v < out[w].size(); ++v, ++n)
+                if(n < cap) { quality[n] = out[w][v].quality; win[n] = (int32_t)w; }
+    }
+#endif
+    omp_set_num_threads(saved_threads);
+    hmm_indel_bias_factor = saved_bias;
+    *n_forward_sets = sets;
+    for(int i = 0; i < n_reads; ++i) delete recs[i];
+    return n;
+}
+
+// score_variant_group (src/common/nanopolish_variant.cpp:182-262) for one group of substitutions at the given positions (alt = the
+// base after the reference base in ACGT order): scores[combination * n_inputs + input] = get_combination_read_score.
+// mode 0: the reference's function; mode 1: np_score_variant_group.  Returns the number of combinations (or -1); *n_inputs out.
+int npfull_score_variant_group(int mode, int n_reads, void** handles, const int32_t* is_rev, const int32_t* pos, const uint32_t* cigar,
+                               const int64_t* cigar_off, const char* const* bam_seqs, const char* contig_seq, int n_variants,
+                               const int32_t* positions, int flank, int max_haplotypes, const char* methylation_types, double indel_bias,
+                               int cap, double* scores, int* n_inputs)
+{
+    const std::string contig(contig_seq);
+    std::vector<Record*> recs(n_reads);
+    std::vector<EventAlignmentRecord> ears;
+    for(int i = 0; i < n_reads; ++i) {
+        recs[i] = new Record("read", is_rev[i], pos[i], cigar + cigar_off[i], (int)(cigar_off[i + 1] - cigar_off[i]), bam_seqs[i], "A");
+        SequenceAlignmentRecord sar(&recs[i]->b);
+        ears.push_back(EventAlignmentRecord((SquiggleRead*)handles[i], 0, sar));
+        ((SquiggleRead*)handles[i])->read_name = std::string("read") + std::to_string(i);      // read ids key the group's score maps
+    }
+    std::vector<Variant> variants;
+    int lo = positions[0], hi = positions[0];
+    for(int v = 0; v < n_variants; ++v) {
+        Variant x; x.ref_name = "contig"; x.ref_position = positions[v]; x.ref_seq = contig.substr(positions[v], 1);
+        const char* acgt = "ACGT"; const char* at = strchr(acgt, x.ref_seq[0]);
+        x.alt_seq = std::string(1, acgt[((at ? at - acgt : 0) + 1) & 3]);
+        variants.push_back(x);
+        lo = std::min(lo, positions[v]); hi = std::max(hi, positions[v]);
+    }
+    const int calling_start = lo - flank, calling_end = hi + 1 + flank;
+    Haplotype base("contig", calling_start, contig.substr(calling_start, calling_end - calling_start + 1));
+    const std::vector<HMMInputData> input = window_input(ears, calling_start, calling_end);
+    const std::vector<std::string> mt = split_csv(methylation_types);
+    const uint32_t flags = HAF_ALLOW_PRE_CLIP | HAF_ALLOW_POST_CLIP;
+    const double saved_bias = hmm_indel_bias_factor;
+    hmm_indel_bias_factor = indel_bias;
+    VariantGroup group(0, variants);
+    int rc = 0;
+    if(mode == 0) score_variant_group(group, base, input, max_haplotypes, 1, false, flags, mt);
+    else {
+#ifdef NP_WITH_BATCH
+        np_score_variant_group(group, base, input, max_haplotypes, 1, false, flags, mt);
+#else
+        rc = -1;
+#endif
+    }
+    hmm_indel_bias_factor = saved_bias;
+    *n_inputs = (int)input.size();
+    const int nc = (int)group.get_num_combinations();
+    for(int c = 0; c < nc && rc == 0; ++c)
+        for(size_t j = 0; j < input.size(); ++j) {
+            std::stringstream ss; ss << input[j].read->read_name << ":" << input[j].strand;      // (as variant.cpp:236: the strand streams as a character)
+            const size_t o = (size_t)c * input.size() + j;
+            if((int)o < cap) scores[o] = group.get_combination_read_score(c, ss.str());
+        }
+    for(int i = 0; i < n_reads; ++i) delete recs[i];
+    return rc == 0 ? nc : -1;
+}
+
 // ---- align_read_to_ref (eventalign) ----------------------------------------------------------------------------------
 int npfull_eventalign(void* h, int is_rev, int pos, const uint32_t* cigar, int n_cigar, const char* seq, const char* contig_seq,
                       int cap, int32_t* ref_position, int32_t* event_idx, char* hmm_state, char* ref_kmer, char* model_kmer)
@@ -464,6 +640,73 @@ int npfull_eventalign_tsv(void* h, int is_rev, int pos, const uint32_t* cigar, i
     free(buf);
     return n;
 }
+
+
+#ifdef NP_WITH_BATCH
+// ---- the product's batched eventalign binding (nanopolish_amd/csrc/np_eventalign_dropin.cpp) -------------------------------------
+// n records against one contig through ONE np_realign_reads_batch; per read the rebuilt SquiggleRead's summary (as npfull_read_summary),
+// its events' means / stdvs / durations / start times and event map at [ev_off[i], ..) / [map_off[i], ..), the EventAlignment rows at
+// [row_off[i], row_off[i+1]) and the text the reference's own emit_event_alignment_tsv prints from (sr, alignment), concatenated.
+// Returns the total text length (text truncated to tsv_cap - 1).
+int npfull_realign_batch(int n, const char* const* read_seqs, const float* raw, const int64_t* raw_off, const int32_t* is_rev, const int32_t* pos,
+                         const uint32_t* cigar, const int64_t* cigar_off, const char* const* bam_seqs, const char* contig_seq, double sample_rate,
+                         int32_t* status, int32_t* n_events, double* shift, double* scale, double* var, double* epb,
+                         const int64_t* ev_off, float* ev_mean, float* ev_stdv, float* ev_duration, double* ev_start_time,
+                         const int64_t* map_off, int32_t* map_start, int32_t* map_stop,
+                         int64_t row_cap, int64_t* row_off, int32_t* ref_position, int32_t* event_idx, char* hmm_state,
+                         char* tsv, int64_t tsv_cap, int64_t* tsv_off)
+{
+    std::vector<Record*> recs(n);
+    std::vector<std::string> seqs(n);
+    std::vector<NpRealignRead> reads(n);
+    for(int i = 0; i < n; ++i) {
+        char name[32]; snprintf(name, sizeof(name), "read%d", i);
+        recs[i] = new Record(name, is_rev[i], pos[i], cigar + cigar_off[i], (int)(cigar_off[i + 1] - cigar_off[i]), bam_seqs[i], contig_seq);
+        seqs[i] = read_seqs[i];
+        reads[i].record = &recs[i]->b; reads[i].read_name = name; reads[i].read_sequence = &seqs[i];
+        reads[i].raw_pa = raw + raw_off[i]; reads[i].n_raw = (size_t)(raw_off[i + 1] - raw_off[i]);
+        reads[i].sample_rate = sample_rate; reads[i].read_idx = i;
+    }
+    np_realign_reads_batch(reads, &recs[0]->fai, &recs[0]->hdr, -1, -1);
+    int64_t rows = 0, text = 0;
+    for(int i = 0; i < n; ++i) {
+        row_off[i] = rows; tsv_off[i] = text;
+        status[i] = reads[i].status;
+        n_events[i] = 0; shift[i] = scale[i] = var[i] = epb[i] = 0.0;
+        if(!reads[i].sr) continue;
+        const SquiggleRead& sr = *reads[i].sr;
+        n_events[i] = (int)sr.events[0].size();
+        shift[i] = sr.scalings[0].shift; scale[i] = sr.scalings[0].scale; var[i] = sr.scalings[0].var; epb[i] = sr.events_per_base[0];
+        for(size_t e = 0; e < sr.events[0].size(); ++e) {
+            ev_mean[ev_off[i] + e] = sr.events[0][e].mean; ev_stdv[ev_off[i] + e] = sr.events[0][e].stdv;
+            ev_duration[ev_off[i] + e] = sr.events[0][e].duration; ev_start_time[ev_off[i] + e] = sr.events[0][e].start_time;
+        }
+        for(size_t j = 0; j < sr.base_to_event_map.size() && (int64_t)j < map_off[i + 1] - map_off[i]; ++j) {
+            map_start[map_off[i] + j] = sr.base_to_event_map[j].indices[0].start; map_stop[map_off[i] + j] = sr.base_to_event_map[j].indices[0].stop;
+        }
+        for(size_t t = 0; t < reads[i].alignment.size(); ++t, ++rows) {
+            if(rows >= row_cap) continue;
+            const EventAlignment& ea = reads[i].alignment[t];
+            ref_position[rows] = ea.ref_position; event_idx[rows] = ea.event_idx; hmm_state[rows] = ea.hmm_state;
+        }
+        if(!reads[i].alignment.empty()) {
+            EventAlignmentParameters params;
+            params.sr = reads[i].sr.get(); params.fai = &recs[0]->fai; params.hdr = &recs[0]->hdr; params.record = &recs[i]->b;
+            params.strand_idx = 0; params.read_idx = i;
+            char* buf = NULL; size_t len = 0;
+            FILE* fp = open_memstream(&buf, &len);
+            emit_event_alignment_tsv(fp, sr, 0, params, reads[i].alignment);
+            fclose(fp);
+            for(size_t q = 0; q < len; ++q, ++text) if(text < tsv_cap - 1) tsv[text] = buf[q];
+            free(buf);
+        }
+    }
+    row_off[n] = rows; tsv_off[n] = text;
+    if(tsv_cap > 0) tsv[text < tsv_cap - 1 ? text : tsv_cap - 1] = 0;
+    for(int i = 0; i < n; ++i) delete recs[i];
+    return (int)text;
+}
+#endif
 
 // ---- timing drivers: OpenMP over reads, like BamProcessor::parallel_run (src/common/nanopolish_bam_processor.cpp:99) ----------
 // identity-aligned reads (CIGAR = <len>M at pos 0 of their own contig); mode 0: SquiggleRead from raw + align_read_to_ref,

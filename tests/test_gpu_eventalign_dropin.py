@@ -1,0 +1,59 @@
+"""The batched eventalign binding (nanopolish_amd/csrc/np_eventalign_dropin.cpp): realign_read's per-record work
+(src/alignment/nanopolish_eventalign.cpp:539-610) for a whole batch in one device pass, against the UNMODIFIED reference on the
+same records (goldens' reads: substitutions, indels, clips, both strands, QC failures):
+  * the SquiggleRead the binding rebuilds equals the one SquiggleRead(sequence, Fast5Data) builds through load_from_raw -- event
+    count, every event's mean / stdv / duration / start time, scalings, events_per_base, the base-to-event map;
+  * the EventAlignment rows equal align_read_to_ref's;
+  * the text the reference's own emit_event_alignment_tsv prints from the binding's (SquiggleRead, rows) equals, byte for byte, what
+    it prints in the unmodified reference."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.ref_full import FullRef, have_full, have_batch, realign_batch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not (have_full() and have_batch()), reason="reference-backed libraries not built")]
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_reflevel.npz")
+
+
+def _s(a):
+    return bytes(a).decode()
+
+
+def test_batch_realignment_equals_the_unmodified_reference():
+    import torch  # noqa: F401
+    g = np.load(GOLD)
+    contig = _s(g["contig"])
+    recs = []
+    for i in range(int(g["n_reads"])):
+        p = "r%d_" % i
+        rc, pos = (int(v) for v in g[p + "rc_pos"])
+        recs.append(dict(seq=_s(g[p + "seq"]), raw=g[p + "raw"], rc=rc, pos=pos, cigar=g[p + "cigar"], bam_seq=_s(g[p + "bam_seq"])))
+    F = FullRef()
+    for order in (list(range(len(recs))), list(range(len(recs)))[::-1]):
+        got, status = realign_batch([recs[i] for i in order], contig)
+        n_rows = 0
+        for q, i in enumerate(order):
+            r = recs[i]
+            fr = F.read("read%d" % q, r["seq"], r["raw"])
+            o = got[q]
+            assert status[q] in (0, 1), "record %d took the host path" % i
+            assert (status[q] == 1) == (fr.n_events == 0)
+            assert o["n_events"] == fr.n_events
+            s, e = fr.event_map()
+            if fr.map_size:
+                assert np.array_equal(o["map_start"], s) and np.array_equal(o["map_stop"], e)
+                assert o["events_per_base"] == fr.events_per_base
+            if fr.n_events == 0:
+                assert len(o["event_idx"]) == 0
+                continue
+            assert (o["shift"], o["scale"], o["var"]) == (fr.shift, fr.scale, fr.var)
+            assert np.array_equal(o["mean"], fr.events())
+            ea = fr.eventalign(r["rc"], r["pos"], r["cigar"], r["bam_seq"], contig)
+            assert np.array_equal(o["ref_position"], ea["ref_position"]) and np.array_equal(o["event_idx"], ea["event_idx"])
+            assert np.array_equal(o["hmm_state"], ea["hmm_state"])
+            assert o["tsv"] == fr.eventalign_tsv(r["rc"], r["pos"], r["cigar"], r["bam_seq"], contig, read_idx=q)
+            n_rows += len(ea["event_idx"])
+            fr.close()
+        assert n_rows > 3000
