@@ -168,7 +168,7 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
     for (int i = 0; i < n_all; ++i) {
         reads[i].status = NP_BATCH_OK;
         const bool fits = device_ok && !reads[i].rna && reads[i].record && reads[i].read_sequence && reads[i].read_sequence->size() >= k &&
-                          reads[i].raw_pa && reads[i].n_raw >= 64;
+                          (reads[i].raw_pa || reads[i].raw_adc) && reads[i].n_raw >= 64;
         if (!fits) { reads[i].status = NP_BATCH_HOST_PATH; continue; }
         if (!have_meth) continue;                                            // an empty map (basemods.cpp:280-287)
         S.dev_index[i] = (int)idx.size(); idx.push_back(i);
@@ -176,14 +176,45 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
     const int n = (int)idx.size();
     S.n_dev = n;
     if (n == 0) return;
-    #pragma omp parallel for schedule(dynamic)
+    // The reference fetches every record's segment on its own, under a critical section (get_reference_region_ts,
+    // src/alignment/nanopolish_eventalign.cpp:207-221: faidx_fetch_seq is not thread-safe) -- serial work per record.  The records
+    // of a BamProcessor batch come from a sorted BAM: when the batch's records on one contig cover a compact stretch, ONE fetch of
+    // their union serves them all (faidx clips a range to the contig, so a slice of the clipped union is what the clipped
+    // per-record fetch returns); a scattered batch keeps the per-record fetches.
+    std::map<int, std::pair<int, int> > span;           // tid -> [lowest pos, highest end] of the batch's records
+    std::map<int, int64_t> covered;
+    bool all_adc = true;
+    for (int q = 0; q < n; ++q) {
+        const bam1_t* record = reads[idx[q]].record;
+        const int lo = record->core.pos, hi = bam_endpos(record);
+        S.ref_start[idx[q]] = lo;
+        std::map<int, std::pair<int, int> >::iterator it = span.find(record->core.tid);
+        if (it == span.end()) span[record->core.tid] = std::make_pair(lo, hi);
+        else { it->second.first = std::min(it->second.first, lo); it->second.second = std::max(it->second.second, hi); }
+        covered[record->core.tid] += hi - lo + 1;
+        all_adc = all_adc && reads[idx[q]].raw_adc != NULL;
+    }
+    std::map<int, std::string> union_seq;
+    for (std::map<int, std::pair<int, int> >::const_iterator it = span.begin(); it != span.end(); ++it) {
+        const int64_t len = (int64_t)it->second.second - it->second.first + 1;
+        if (len <= (64 << 20) && len <= 4 * covered[it->first] + (1 << 20)) {
+            int fetched_len = 0;
+            union_seq[it->first] = get_reference_region_ts(p->fai, p->hdr->target_name[it->first], it->second.first, it->second.second, &fetched_len);
+        }
+    }
+    #pragma omp parallel for schedule(dynamic, 16)
     for (int q = 0; q < n; ++q) {
         const int i = idx[q];
         const bam1_t* record = reads[i].record;
-        const std::string contig = p->hdr->target_name[record->core.tid];
-        S.ref_start[i] = record->core.pos;
-        int fetched_len = 0;
-        S.ref_seqs[i] = get_reference_region_ts(p->fai, contig.c_str(), S.ref_start[i], bam_endpos(record), &fetched_len);   // :258-270
+        std::map<int, std::string>::const_iterator u = union_seq.find(record->core.tid);
+        if (u != union_seq.end()) {
+            const int64_t off = (int64_t)record->core.pos - span[record->core.tid].first, want = (int64_t)bam_endpos(record) - record->core.pos + 1;
+            const int64_t have = (int64_t)u->second.size() - off;
+            S.ref_seqs[i] = have > 0 ? u->second.substr((size_t)off, (size_t)std::min(want, have)) : std::string();
+        } else {
+            int fetched_len = 0;
+            S.ref_seqs[i] = get_reference_region_ts(p->fai, p->hdr->target_name[record->core.tid], record->core.pos, bam_endpos(record), &fetched_len);   // :258-270
+        }
         // Alphabet::disambiguate (upper-casing + IUPAC codes -> their first base) is the identity on an upper-case ACGT string, and
         // it builds one std::string per character: 0.3 ms of a host core per 5 kb read.  Only a segment that needs it gets it.
         if (!is_plain_acgt(S.ref_seqs[i])) S.ref_seqs[i] = gDNAAlphabet.disambiguate(S.ref_seqs[i]);
@@ -216,7 +247,8 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
 
     // ---- layouts ----------------------------------------------------------------------------------------------------------
     Layout li;
-    const size_t i_raw = li.add((size_t)raw_off[n] * sizeof(float)), i_ranks = li.add((size_t)n_rk * sizeof(uint16_t)),
+    const size_t i_raw = li.add((size_t)raw_off[n] * (all_adc ? sizeof(int16_t) : sizeof(float))), i_adc_offset = li.add((size_t)n * 4),
+                 i_adc_unit = li.add((size_t)n * 4), i_ranks = li.add((size_t)n_rk * sizeof(uint16_t)),
                  i_reads_a = li.add((size_t)n * sizeof(np_read_dev)), i_reads_b = li.add((size_t)n * sizeof(np_read_dev)),
                  i_genome = li.add((size_t)genome_off[n]), i_raw_off = li.add((size_t)(n + 1) * 8), i_event_off = li.add((size_t)(n + 1) * 8),
                  i_cigar_off = li.add((size_t)(n + 1) * 8), i_group_off = li.add((size_t)(n + 1) * 8), i_jr_off = li.add((size_t)(n + 1) * 8),
@@ -231,6 +263,7 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
     const size_t s_pair_begin = ls.add((size_t)n * 4), s_deg = ls.add((size_t)n * 8), s_kpos = ls.add((size_t)n_jobs * 8),
                  s_epb = ls.add((size_t)n * 8), s_jobs = ls.add((size_t)n_jobs * sizeof(np_hmm_job_dev));
     const size_t zero_bytes = ls.size;
+    const size_t s_raw_pa = ls.add(all_adc ? (size_t)raw_off[n] * sizeof(float) : 0);
     const size_t s_tstat = ls.add((size_t)(2 * raw_off[n] + 16) * sizeof(float)), s_ev_len = ls.add((size_t)n_ev * 4), s_ev_mean = ls.add((size_t)n_ev * 4),
                  s_ev_stdv = ls.add((size_t)n_ev * 4), s_ev_start = ls.add((size_t)n_ev * 4), s_map_start = ls.add((size_t)n_rk * 4),
                  s_map_stop = ls.add((size_t)n_rk * 4), s_pairs = ls.add((size_t)pair_off[n] * sizeof(np_pair)),
@@ -257,7 +290,11 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
         for (int t = 0; t < 2; ++t)
             np_fill_read_host(t ? &h_reads_b[q] : &h_reads_a[q], 0.0, 1.0, 1.0, event_off[q], (uint32_t)(event_off[q + 1] - event_off[q]), rank_off[q],
                               (uint32_t)(rank_off[q + 1] - rank_off[q]));
-        memcpy(h_raw + raw_off[q], reads[i].raw_pa, reads[i].n_raw * sizeof(float));
+        ((float*)(H + i_adc_offset))[q] = reads[i].adc_offset; ((float*)(H + i_adc_unit))[q] = reads[i].adc_raw_unit;
+        if (all_adc) memcpy((int16_t*)(H + i_raw) + raw_off[q], reads[i].raw_adc, reads[i].n_raw * sizeof(int16_t));
+        else if (reads[i].raw_pa) memcpy(h_raw + raw_off[q], reads[i].raw_pa, reads[i].n_raw * sizeof(float));
+        else for (size_t t = 0; t < reads[i].n_raw; ++t)            // the loader's conversion, fp32 (fast5_loader.cpp:96-103)
+            h_raw[raw_off[q] + t] = ((float)reads[i].raw_adc[t] + reads[i].adc_offset) * reads[i].adc_raw_unit;
         nucleotide_kmer_ranks(seq, k, h_ranks + rank_off[q]);
         memcpy(h_genome + genome_off[q], S.ref_seqs[i].data(), S.ref_seqs[i].size());
         h_ref_begin[q] = genome_off[q]; h_ref_len[q] = (int32_t)S.ref_seqs[i].size();
@@ -280,7 +317,7 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
     check(np_memset_dev(c, NULL, p->scratch.d, 0, zero_bytes), "np_memset_dev");
     {
         char* D = S.in.d; char* O = S.out.d; char* X = p->scratch.d;
-        float* raw = (float*)(D + i_raw); uint16_t* ranks = (uint16_t*)(D + i_ranks);
+        float* raw = all_adc ? (float*)(p->scratch.d + s_raw_pa) : (float*)(D + i_raw); uint16_t* ranks = (uint16_t*)(D + i_ranks);
         np_read_dev* reads_a = (np_read_dev*)(D + i_reads_a); np_read_dev* reads_b = (np_read_dev*)(D + i_reads_b);
         int64_t *d_raw_off = (int64_t*)(D + i_raw_off), *d_event_off = (int64_t*)(D + i_event_off), *d_cigar_off = (int64_t*)(D + i_cigar_off),
                 *d_group_off = (int64_t*)(D + i_group_off), *d_jr_off = (int64_t*)(D + i_jr_off), *d_pair_off = (int64_t*)(D + i_pair_off),
@@ -304,6 +341,9 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
         check(np_cm_build_jobs_cigar_dev(c, NULL, n, genome, ref_begin, ref_len, cigar, d_cigar_off, cigar_off[n], read_len, rc, alphabet, k, MINSEP,
                                          FLANK, d_group_off, n_slots, d_jr_off, jobs, kpos, job_ranks, first, last, n_motif, n_groups, deg),
               "np_cm_build_jobs_cigar_dev");
+        if (all_adc)
+            check(np_adc_to_pa_dev(c, NULL, n, (const int16_t*)(D + i_raw), d_raw_off, max_samples, (const float*)(D + i_adc_offset),
+                                   (const float*)(D + i_adc_unit), raw), "np_adc_to_pa_dev");
         check(np_detect_events_dev(c, NULL, n, raw, d_raw_off, max_samples, &prm, tstat, d_event_off, max_events, ev_start, ev_len, ev_mean,
                                    ev_stdv, n_events), "np_detect_events_dev");
         check(np_mom_fill_dev(c, NULL, n, reads_a, reads_b, ev_mean, n_events, ranks, m_nuc), "np_mom_fill_dev");

@@ -14,6 +14,12 @@ struct NpBatchRead {
     const std::string* read_sequence = NULL;   // SquiggleRead::read_sequence (ReadDB::get_read_sequence)
     const float* raw_pa = NULL;                // the read's raw table in pA, as load_from_raw hands it to detect_events
     size_t n_raw = 0;
+    // alternatively the samples as the sequencer stored them, with the channel's conversion (src/io/nanopolish_fast5_loader.cpp:96-103:
+    // pA = ((float)adc + offset) * raw_unit, raw_unit = range / digitisation, all in fp32): half the bytes to pack and to upload.
+    // A batch whose records ALL carry raw_adc is converted on the device (np_adc_to_pa_dev, the same fp32 expression); otherwise a
+    // record without raw_pa is converted on the host while packing.
+    const int16_t* raw_adc = NULL;
+    float adc_offset = 0.0f, adc_raw_unit = 1.0f;
     int rna = 0;                               // SquiggleRead::nucleotide_type == SRNT_RNA (squiggle_read.cpp:195): such a read uses the
                                                // r9.4_70bps 5-mer models and the RNA detector; the device pass is built for what
                                                // load_from_raw hard-codes for DNA (kit r9.4_450bps, "template", k = 6, :197-202), so an

@@ -298,7 +298,8 @@ int npfull_call_methylation_batch(int n, const char* const* read_seqs, const flo
 // The same records through NpBatchPipeline in batches of `batch_size`, two batches in flight (submit k, then collect k - 1): the
 // production feed's shape.  Output as npfull_call_methylation_batch.  event_cap_divisor > 2 shrinks the device detector's per-read
 // event capacity (test knob: drives the overflow -> NP_BATCH_HOST_PATH route); rna_mask: bit i set marks record i as an RNA read.
-int npfull_call_methylation_pipeline(int n, int batch_size, int event_cap_divisor, const uint8_t* rna_mask, const char* const* read_seqs,
+int npfull_call_methylation_pipeline(int n, int batch_size, int event_cap_divisor, const uint8_t* rna_mask, const int16_t* adc /* nullable: the
+                                     samples as ADC counts, raw then unused */, float adc_offset, float adc_raw_unit, const char* const* read_seqs,
                                      const float* raw, const int64_t* raw_off, const int32_t* is_rev, const int32_t* pos, const uint32_t* cigar,
                                      const int64_t* cigar_off, const char* const* bam_seqs, const char* contig_seq, const char* methylation_type,
                                      int cap, int64_t* site_off, int32_t* start, int32_t* end, int32_t* n_motif, double* ll_unmeth,
@@ -321,7 +322,8 @@ int npfull_call_methylation_pipeline(int n, int batch_size, int event_cap_diviso
         for(int i = b; i < n && i < b + batch_size; ++i) {
             NpBatchRead r;
             r.record = &recs[i]->b; r.read_sequence = &seqs[i];
-            r.raw_pa = raw + raw_off[i]; r.n_raw = (size_t)(raw_off[i + 1] - raw_off[i]);
+            r.raw_pa = adc ? NULL : raw + raw_off[i]; r.n_raw = (size_t)(raw_off[i + 1] - raw_off[i]);
+            if(adc) { r.raw_adc = adc + raw_off[i]; r.adc_offset = adc_offset; r.adc_raw_unit = adc_raw_unit; }
             r.rna = rna_mask && rna_mask[i] ? 1 : 0;
             reads.push_back(r);
         }
@@ -364,7 +366,8 @@ int npfull_call_methylation_pipeline(int n, int batch_size, int event_cap_diviso
 // host_seconds[0..5]: NpBatchPipeline::host_seconds of the timed batches, [6]: seconds inside submit() + collect().
 double npfull_bench_batch(int n_distinct, const char* const* read_seqs, const float* raw, const int64_t* raw_off, const int32_t* is_rev,
                           const int32_t* pos, const uint32_t* cigar, const int64_t* cigar_off, const char* const* bam_seqs, const char* contig_seq,
-                          int batch_size, int n_batches, int warmup, int pipelined, int64_t* n_sites, int64_t* n_not_ok, double* host_seconds /* [7] */)
+                          int batch_size, int n_batches, int warmup, int pipelined, const int16_t* adc /* nullable: records carry ADC counts */,
+                          float adc_offset, float adc_raw_unit, int64_t* n_sites, int64_t* n_not_ok, double* host_seconds /* [7] */)
 {
     std::vector<std::string> seqs(n_distinct);
     for(int i = 0; i < n_distinct; ++i) seqs[i] = read_seqs[i];
@@ -380,7 +383,8 @@ double npfull_bench_batch(int n_distinct, const char* const* read_seqs, const fl
                                     j == 0 ? contig_seq : "");
             NpBatchRead& r = reads[s][j];
             r.record = &recs[s][j]->b; r.read_sequence = &seqs[i];
-            r.raw_pa = raw + raw_off[i]; r.n_raw = (size_t)(raw_off[i + 1] - raw_off[i]);
+            r.raw_pa = adc ? NULL : raw + raw_off[i]; r.n_raw = (size_t)(raw_off[i + 1] - raw_off[i]);
+            if(adc) { r.raw_adc = adc + raw_off[i]; r.adc_offset = adc_offset; r.adc_raw_unit = adc_raw_unit; }
         }
         recs[s][0]->lens[0] = (uint32_t)strlen(contig_seq);
     }

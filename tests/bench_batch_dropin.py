@@ -5,7 +5,7 @@ INTEGRATION.md section 2 applied gets at BamProcessor-like batch sizes:
     python tests/bench_batch_dropin.py [--sizes 512,2048,8192,32768] [--distinct 512] [--read-len 5450]
 
 Per batch size one JSON line: NpBatchPipeline with two batches in flight (`pipelined`) and the synchronous
-np_calculate_methylation_for_batch (`sync`), host wall clock around phases 1-3 and the device pass, from raw signal (float pA
+np_calculate_methylation_for_batch (`sync`), and the pipeline fed int16 ADC counts (`pipelined_adc`), host wall clock around phases 1-3 and the device pass, from raw signal (float pA
 samples in host memory -- what SquiggleRead hands to detect_events) to ScoredSite maps.  The records are `--distinct` synthetic
 R9.4 reads (BASELINE.json configs[1] shape: ~8k events, identity-aligned to a contig made of their own reference strands),
 cycled to fill a batch.  Needs oracle/_ref/libnp_ref_full_batch.so (`make -C oracle batch`; it travels to the GPU box prebuilt)
@@ -45,10 +45,10 @@ def main():
     t0 = time.perf_counter()
     recs, contig, pos = [], [], 0
     for r in range(args.distinct):
-        rd = synth_raw(r, models["nucleotide"], L=args.read_len, k=6)
+        rd = synth_raw(r, models["nucleotide"], L=args.read_len, k=6, adc=True)       # raw = the pA values the int16 counts convert to
         ref = api.reverse_complement("nucleotide", rd["seq"]) if rd["rc"] else rd["seq"]
         # BAM stores the read as it aligns to the forward reference strand: SEQ == the reference segment for an identity alignment
-        recs.append(dict(seq=rd["seq"], raw=rd["raw"].astype(np.float32), rc=int(rd["rc"]), pos=pos,
+        recs.append(dict(seq=rd["seq"], raw=rd["raw"].astype(np.float32), adc=rd["adc"], rc=int(rd["rc"]), pos=pos,
                          cigar=np.array([(len(ref) << 4) | 0], np.uint32), bam_seq=ref))
         contig.append(ref); pos += len(ref)
     contig = "".join(contig)
@@ -58,10 +58,11 @@ def main():
         nb = max(3, -(-args.target_reads // bs))
         line = dict(metric="call-methylation reads/sec through np_calculate_methylation_for_batch", unit="reads/s", batch_size=bs, batches=nb,
                     distinct_reads=args.distinct, read_len=args.read_len, raw_bytes_per_read=int(raw_bytes))
-        for name, pipelined in (("pipelined", True), ("sync", False)):
-            sec, sites, bad, hs = bench_batch(recs, contig, bs, nb, warmup=2, pipelined=pipelined)
+        from nanopolish_amd.synth import ADC_OFFSET, ADC_UNIT
+        for name, pipelined, adc in (("pipelined", True, None), ("pipelined_adc", True, (float(ADC_OFFSET), float(ADC_UNIT))), ("sync", False, None)):
+            sec, sites, bad, hs = bench_batch(recs, contig, bs, nb, warmup=2, pipelined=pipelined, adc=adc)
             line[name] = dict(value=round(bs * nb / sec, 1), ms_per_batch=round(sec / nb * 1e3, 2), sites_per_read=round(sites / (bs * nb), 2),
-                              records_not_ok=bad, h2d_GBps=round(bs * nb * raw_bytes / sec / 1e9, 2))
+                              records_not_ok=bad, h2d_GBps=round(bs * nb * raw_bytes * (0.5 if adc else 1.0) / sec / 1e9, 2))
             line[name]["value_binding_only"] = round(bs * nb / hs["inside_binding"], 1) if hs["inside_binding"] > 0 else None
             if pipelined:
                 line[name]["host_ms_per_batch"] = {k: round(v / nb * 1e3, 2) for k, v in hs.items()}

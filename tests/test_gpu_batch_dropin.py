@@ -107,3 +107,25 @@ def test_event_capacity_overflow_and_rna_reads_take_the_host_path():
         else:
             assert status[i] in (0, 1)
             _assert_golden(g, i, out[i])
+
+
+def test_adc_input_gives_the_results_of_the_converted_samples():
+    """Records handed over as int16 ADC counts + the channel's conversion (half the bytes to pack and upload; converted on the device
+    with the loader's fp32 expression, src/io/nanopolish_fast5_loader.cpp:96-103) against the same records handed over as the pA
+    values those counts convert to."""
+    from oracle.ref_full import call_methylation_pipeline
+    from nanopolish_amd.synth import adc_quantise, ADC_OFFSET, ADC_UNIT
+    import torch  # noqa: F401
+    g = np.load(GOLD)
+    recs = _golden_records(g)
+    for r in recs:
+        r["adc"], r["raw"] = adc_quantise(r["raw"])
+    want, s0 = call_methylation_pipeline(recs, _s(g["contig"]), 4)
+    got, s1 = call_methylation_pipeline(recs, _s(g["contig"]), 4, adc=(float(ADC_OFFSET), float(ADC_UNIT)))
+    assert np.array_equal(s0, s1)
+    n = 0
+    for a, b in zip(want, got):
+        for k in ("start", "end", "n_motif", "ll_unmeth", "ll_meth"):
+            assert np.array_equal(a[k], b[k])
+        n += len(a["start"])
+    assert n > 150
