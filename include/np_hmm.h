@@ -82,7 +82,9 @@ int np_set_option(np_ctx* ctx, const char* name, int64_t value);
  * of the most recent event-align launch: the grid shrinks under a 48 GB scratch budget when a batch holds ultra-long reads),
  * "align_blocks_max", "lse_oor" (1: the clamp-free log-sum lookup is in use, see np_ctx_info), "n_cu", "ea_lattice_cells" /
  * "ea_lattice_rows" / "ea_lattice_kmers" (sum over the segments of the most recent np_eventalign_dev call of the reference's
- * lattice size (e + 1) x 3 (n + 2), of e and of n; waits for the call). */
+ * lattice size (e + 1) x 3 (n + 2), of e and of n; waits for the call), "ea_cycles_geometry" / "ea_cycles_fill" /
+ * "ea_cycles_backtrack" (two-read chain kernel: shader cycles, summed over the waves, spent finding segments, sweeping them, and
+ * walking back + emitting). */
 int64_t np_get_stat(np_ctx* ctx, const char* name);
 
 /* Upload a pore model (PoreModel::states, src/pore_model/nanopolish_poremodel.h:20-67,107): the three

@@ -74,8 +74,10 @@ struct np_ctx {
             b_vm, b_bp, b_cell_off, b_state_off, b_states, b_n_states;
     dev_buf ed_status, ed_tstat;      // event detection scratch
     dev_buf cm_group_rank_off, cm_cigar_scratch;        // work-item generation scratch
-    dev_buf ea_bp, ea_path;                             // eventalign chain: per-wave back-pointer rows and path lists
+    dev_buf ea_bp, ea_path, ea_args;                    // eventalign chain: per-wave back-pointer rows and path lists; a device copy of the launch arguments
     int ea_rows_cap = 4096, ea_waves_per_cu = 20;
+    int ea_walk_prio = 1;            // two-read chain kernel: back-track + emission at wave priority 3 (315 -> 300 ms per 50 000 reads, gpurun r03g)
+    int ea_kernel = 1;                // eventalign chain: 1 = one read per wave (shipped), 2 = two reads per wave (np_eventalign_kernel.hip; experimental)
     dev_buf b_raw, b_raw_off, b_ev_off, b_ev_start, b_ev_len, b_ev_mean, b_ev_stdv, b_n_events;
     timing_t timing[NP_NUM_FAMILIES];
     std::mutex lock;
@@ -316,6 +318,8 @@ np_ctx* np_create(int device, const np_params* params)
     if (const char* v = getenv("NP_ALIGN_LPT")) c->align_lpt = atoi(v) != 0;
     if (const char* v = getenv("NP_ED_WARMUP")) c->ed_warmup = atoi(v);
     if (const char* v = getenv("NP_EA_WAVES_PER_CU")) c->ea_waves_per_cu = std::max(1, atoi(v));
+    if (const char* v = getenv("NP_EA_KERNEL")) c->ea_kernel = atoi(v) == 1 ? 1 : 2;
+    if (const char* v = getenv("NP_EA_WALK_PRIO")) c->ea_walk_prio = atoi(v);
     if (params) c->params = *params; else np_default_params(&c->params);
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->switch_ev, hipEventDisableTiming) == hipSuccess;
@@ -365,7 +369,7 @@ void np_destroy(np_ctx* c)
     dev_buf* bufs[] = {&c->order, &c->trace, &c->kparams, &c->b_jobs, &c->b_reads, &c->b_events, &c->b_ranks, &c->b_out, &c->b_pair_off,
                        &c->b_pairs, &c->b_pair_begin, &c->b_n_pairs, &c->b_vm, &c->b_bp, &c->b_cell_off, &c->b_state_off,
                        &c->b_states, &c->b_n_states, &c->ed_status, &c->ed_tstat, &c->b_raw, &c->b_raw_off, &c->b_ev_off, &c->b_ev_start,
-                       &c->b_ev_len, &c->b_ev_mean, &c->b_ev_stdv, &c->b_n_events, &c->cm_group_rank_off, &c->cm_cigar_scratch, &c->ea_bp, &c->ea_path, &c->align_order};
+                       &c->b_ev_len, &c->b_ev_mean, &c->b_ev_stdv, &c->b_n_events, &c->cm_group_rank_off, &c->cm_cigar_scratch, &c->ea_bp, &c->ea_path, &c->ea_args, &c->align_order};
     for (dev_buf* b : bufs) b->release();
     for (auto& t : c->timing) {
         for (auto& pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1007,16 +1011,19 @@ int np_eventalign_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* r
     int32_t* op_read = op_ref + n_idx;
     int32_t* cig_reads = op_read + n_idx;
     const int rows_cap = c->ea_rows_cap;
-    const int nb = persistent_blocks(c, n_reads, 1, c->ea_waves_per_cu);
-    const size_t bp_stride = ((size_t)rows_cap + 64) * 128, path_stride = (size_t)rows_cap + 256;     // one line per sweep step: e + 63 at most
+    const int variant = c->ea_kernel == 1 ? 1 : (c->ea_waves_per_cu > 16 ? 3 : 2);                       // (two-read kernel: 5 or 4 waves per SIMD)
+    const int waves_per_cu = c->ea_waves_per_cu;
+    const int nb = persistent_blocks(c, variant == 1 ? n_reads : (n_reads + 1) / 2, 1, waves_per_cu);
+    const size_t bp_stride = ((size_t)rows_cap + 64) * (size_t)np_eventalign_line_bytes(variant), path_stride = 2 * ((size_t)rows_cap + 256);     // one line per sweep step: e + 63 at most; two path lists (one per half-wave in the two-read kernel)
     NP_HIP(c, c->ea_bp.reserve((size_t)nb * bp_stride));
     NP_HIP(c, c->ea_path.reserve((size_t)nb * path_stride * sizeof(uint32_t)));
     family_timer tm(c, 6, s);
     NP_HIP(c, np_launch_cigar_index(n_reads, cigar, cigar_off, read_len, (int)k, op_ref, op_read, cig_reads, s));
     NP_HIP(c, hipMemsetAsync(c->d_counters + 17, 0, sizeof(uint32_t), s));
-    NP_HIP(c, hipMemsetAsync(c->d_counters + 40, 0, 3 * sizeof(unsigned long long), s));
+    NP_HIP(c, hipMemsetAsync(c->d_counters + 40, 0, 6 * sizeof(unsigned long long), s));
     np_ea_args a{};
     a.stats = (unsigned long long*)(c->d_counters + 40);
+    a.walk_prio = c->ea_walk_prio;
     a.n_reads = n_reads; a.reads = reads; a.event_mean = event_mean; a.map_start = map_start; a.n_pairs = n_pairs;
     a.events_per_base = events_per_base; a.calibrated = calibrated;
     a.model = c->models[model].d_states; a.flank = c->d_flank; a.genome = genome; a.ref_begin = ref_begin; a.ref_len = ref_len;
@@ -1026,7 +1033,9 @@ int np_eventalign_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* r
     a.path = c->ea_path.as<uint32_t>(); a.path_stride = path_stride;
     a.out_off = out_off; a.out_ref = out_ref; a.out_event = out_event; a.out_state = out_state; a.n_out = n_out; a.status = status;
     a.n_calls = n_calls; a.counter = c->d_counters + 17;
-    NP_HIP(c, np_launch_eventalign_chain(a, nb, s));
+    NP_HIP(c, c->ea_args.reserve(sizeof(np_ea_args)));
+    if (variant != 1) NP_HIP(c, hipMemcpyAsync(c->ea_args.p, &a, sizeof(np_ea_args), hipMemcpyHostToDevice, s));      // (pageable source: staged before the call returns)
+    NP_HIP(c, np_launch_eventalign_chain(a, c->ea_args.as<np_ea_args>(), nb, variant, s));
     return NP_OK;
 }
 
@@ -1040,12 +1049,14 @@ int64_t np_get_stat(np_ctx* c, const char* name)
     if (k == "align_blocks_max") return (int64_t)c->n_cu * c->align_blocks_per_cu;
     if (k == "lse_oor") return c->lse_oor ? 1 : 0;
     if (k == "n_cu") return c->n_cu;
-    if (k == "ea_lattice_cells" || k == "ea_lattice_rows" || k == "ea_lattice_kmers") {        // of the most recent np_eventalign_dev call (waits for it)
-        unsigned long long h[3] = {0, 0, 0};
+    if (k.rfind("ea_", 0) == 0) {        // statistics of the most recent np_eventalign_dev call (waits for it)
+        unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
         if (hipSetDevice(c->device) != hipSuccess) return -1;
         if (c->tail_recorded && hipEventSynchronize(c->switch_ev) != hipSuccess) return -1;
         if (hipMemcpy(h, c->d_counters + 40, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        return (int64_t)h[k == "ea_lattice_cells" ? 0 : k == "ea_lattice_rows" ? 1 : 2];
+        static const char* names[6] = {"ea_lattice_cells", "ea_lattice_rows", "ea_lattice_kmers", "ea_cycles_geometry", "ea_cycles_fill", "ea_cycles_backtrack"};
+        for (int i = 0; i < 6; ++i) if (k == names[i]) return (int64_t)h[i];
+        return -1;
     }
     return -1;
 }
@@ -1063,6 +1074,7 @@ int np_set_option(np_ctx* c, const char* name, int64_t value)
     else if (k == "ed_warmup") c->ed_warmup = (int)value;
     else if (k == "ea_rows_cap") c->ea_rows_cap = (int)std::min<int64_t>(65535, std::max<int64_t>(16, value));
     else if (k == "lse_oor") c->lse_oor = value != 0;          // tests: both log-sum lookups must give the same scores
+    else if (k == "ea_kernel") c->ea_kernel = value == 1 ? 1 : 2;
     else if (k == "ea_waves_per_cu") c->ea_waves_per_cu = (int)std::max<int64_t>(1, value);
     else { c->err = "np_set_option: unknown option " + k; return NP_ERR_INVALID; }
     return NP_OK;

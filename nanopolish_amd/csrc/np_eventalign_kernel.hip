@@ -35,6 +35,27 @@ __device__ __forceinline__ float readlane_f32(float v, int l)
 
 __device__ __forceinline__ uint32_t base_code(char c) { return c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u; }   // disambiguated to ACGT upstream
 
+
+// One step of the back-track (profile_hmm_align_r9, r9.cpp:150-186) without branches.  byte: the cell's back-pointers (M: bits 0..2
+// = HMMMovementType, B: bit 3 = "from the same block's B", K: bits 4..5 = 0 / 1 / 2 for "from M / B / K of the block to the left").
+// ps: 2 MATCH, 1 BAD_EVENT, 0 KMER_SKIP.  The moves, by HMMMovementType mv: 0 same block M, 1 previous block M, 2 same block B,
+// 3 previous block B, 4 previous block K, 5 soft clip (stop).  As lookup words: "k-mer steps back" for mv in {1, 3, 4} = bits of 0x1A,
+// next state = 2, 2, 1, 1, 0 = two-bit fields of 0x05A; the K state's move 1 / 3 / 4 = nibbles of 0x431
+// (the tables are padded so that a byte no cell ever holds decodes as the if / else form did).
+// (Written as selects between three tiny tables because the if / else form compiles to a state machine of ~20 dependent branches
+//  per step: 790 cycles per step measured, half of the chain kernel's time.)
+__device__ __forceinline__ void ea_walk_step(const uint32_t byte, int& row, int& kmer, int& ps, int& stop)
+{
+    const uint32_t mvM = byte & 7u, mvB = (byte >> 2) & 2u, mvK = (0x4431u >> ((byte >> 4) * 4u)) & 7u;
+    const uint32_t mv = ps == 2 ? mvM : (ps == 1 ? mvB : mvK);
+    stop = mv == 5u ? 1 : 0;
+    const int dk = (int)((0x1Au >> mv) & 1u);
+    const int nps = (int)((0xA05Au >> (2u * mv)) & 3u);
+    row -= (ps != 0 && !stop) ? 1 : 0;                 // K states are silent (r9.cpp:176-178)
+    kmer -= stop ? 0 : dk;
+    ps = stop ? ps : nps;
+}
+
 // The Viterbi sweep of one segment, as a separate (not inlined) function: the chain loop around it keeps ~100 wave-uniform values
 // alive (CIGAR view, read record, output cursors); inlined, the register allocator spills some of them INSIDE this loop.  Called
 // once per segment, the caller's state is parked around the call instead and the sweep gets the registers to itself.
@@ -232,6 +253,9 @@ __global__ void __launch_bounds__(64, 5) np_eventalign_chain_kernel(np_ea_args a
                         cnt++;
                         if ((cnt & 63) == 0) path[cnt - 64 + lane] = pv;
                         const uint32_t byte = (uint32_t)__builtin_amdgcn_readfirstlane((int)sb[(row + (kmer >> 1) - lo) * NP_EA_ROW_BYTES + kmer]);
+                        // (the if / else form on purpose: with the branch-free ea_walk_step inlined HERE this kernel emitted fewer rows on the
+                        //  GPU -- gpurun r03e / r03g -- although the step's logic is the same, exhaustively, and the two-read kernel runs it
+                        //  bit-identically to the reference; the generated code of this loop looked right, the cause was not found)
                         const uint32_t mv = ps == 2 ? (byte & 7u) : ps == 1 ? ((byte >> 3) & 1u) * 2u : ((byte >> 4) == 0u ? 1u : (byte >> 4) == 1u ? 3u : 4u);
                         if (mv == 5u) { stop = 1; break; }          // HMT_FROM_SOFT
                         int next_ps = 2;
@@ -290,10 +314,455 @@ __global__ void __launch_bounds__(64, 5) np_eventalign_chain_kernel(np_ea_args a
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 3: TWO reads per wave.  A segment has <= 96 k-mers: at two blocks per lane the sweep above keeps 48 of 64 lanes busy and
+// spends e + 47 steps per segment.  Here a half-wave (32 lanes) owns a segment at THREE blocks per lane -- 96 k-mers exactly --
+// and the two halves sweep two segments of two different reads in the same instruction stream: every lane busy, e + 31 steps,
+// the per-step overhead (neighbour exchange, event distribution, store) shared by two segments.  The two chains are independent
+// and data-dependent, so everything around the sweep (segment geometry, back-track, emission) is scalar code run for half 0,
+// then for half 1; a half whose read is finished pulls the next read from the queue, a half without work sweeps an empty
+// segment.  The per-read state that survives from segment to segment is ten integers per half (ea_half); what only depends on
+// the read's index is reloaded where it is needed (wave-uniform loads).
+// Back-pointers: one dword per lane and sweep step (the lane's three blocks in bytes 0..2), one 256-byte line per step: cell
+// (row r, k-mer b) of half h lives in line r + b / 3 at byte 128 h + 4 (b / 3) + b % 3.
+// ---------------------------------------------------------------------------------------------------------------------------
+#define NP_EA2_LINE 256
+
+struct ea_read {                 // what the chain needs of a read, all derived from its index
+    const np_read_dev* rd; const float* ev; const int32_t* ms; const char* ref;
+    cig_view cv;
+    int K, ref_n, rl; bool rc;
+    int64_t o0; int out_cap;
+};
+__device__ __forceinline__ ea_read ea_load_read(const np_ea_args& a, int ri)
+{
+    ea_read R;
+    R.rd = a.reads + ri;
+    R.ev = a.event_mean + R.rd->event_off;
+    R.ms = a.map_start + R.rd->rank_off;
+    R.K = (int)R.rd->n_kmers;
+    R.ref = a.genome + a.ref_begin[ri];
+    R.ref_n = a.ref_len[ri];
+    R.rl = a.read_len[ri];
+    R.rc = a.read_rc[ri] != 0;
+    R.cv = cig_view{a.cigar + a.cigar_off[ri], a.op_ref + a.cigar_off[ri] + ri, a.op_read + a.cigar_off[ri] + ri,
+                    (int)(a.cigar_off[ri + 1] - a.cigar_off[ri])};
+    R.o0 = a.out_off[ri];
+    R.out_cap = (int)(a.out_off[ri + 1] - R.o0);
+    return R;
+}
+
+struct ea_half {                 // chain state of the read a half-wave works on (wave-uniform scalars)
+    int ri;                      // -1: no read
+    int n_out, n_calls, status;
+    int curr_start_event, curr_start_ref, last_event, forward, q_last, r_last;
+    // the segment about to be swept / just swept
+    int e_start, stride, e, n, last_section;
+};
+
+// one k-mer block of one lattice row: the candidates of r9.inl:130-197 in HMMMovementType order, later index wins ties;
+// (lM_r, lB_r, lK_r): the block to the left in this row, (lM_p, ...): in the previous row.  Returns the block's back-pointer byte.
+template <bool FIRST>
+__device__ __forceinline__ uint32_t ea_block(float& M, float& B, float& K, const float lM_r, const float lB_r, const float lK_r,
+                                             const float lM_p, const float lB_p, const float lK_p, const float x, const np_gauss& g,
+                                             const ea_trans& tr, const float soft)
+{
+    const float em = np_emission(x, g);
+    const float a0 = tr.mm_self + M, a1 = tr.mm_next + lM_p, a2 = tr.bm_self + B, a3 = tr.bm_next + lB_p, a4 = tr.km + lK_p;
+    float v = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), __builtin_fmaxf(a2, a3)), a4);
+    if (FIRST) v = __builtin_fmaxf(v, soft);
+    uint32_t from = (a1 == v) ? 1u : 0u;
+    from = (a2 == v) ? 2u : from; from = (a3 == v) ? 3u : from; from = (a4 == v) ? 4u : from;
+    if (FIRST) from = (soft == v) ? 5u : from;
+    const float newM = v + em;
+    const float b0 = tr.mb + M, b2 = tr.bb + B;
+    const float newB = __builtin_fmaxf(b0, b2);
+    const uint32_t bbit = (b2 >= b0) ? 8u : 0u;
+    const float k1 = tr.mk + lM_r, k3 = tr.bk + lB_r, k4 = tr.kk + lK_r;
+    const float newK = __builtin_fmaxf(__builtin_fmaxf(k1, k3), k4);
+    uint32_t kbits = (k3 == newK) ? 16u : 0u; kbits = (k4 == newK) ? 32u : kbits;
+    M = newM; B = newB; K = newK;
+    return from | bbit | kbits;
+}
+
+struct ea_seg { const float* ev; int e_start, stride, e, n; };
+
+// The sweep of two segments, one per half-wave (e == 0: no segment).  tr, g0..g2: the lane's half's transitions and the scaled
+// Gaussians of the lane's three blocks.  Returns the value of (last row, MATCH of the last k-mer) of each segment.
+__device__ __attribute__((noinline)) float2 ea_fill2(const np_gauss g0, const np_gauss g1, const np_gauss g2, const ea_trans tr,
+                                                     const float flank0, const ea_seg s0, const ea_seg s1, uint8_t* __restrict__ bp, const int lane)
+{
+    const int sl = lane & 31;
+    const bool hi_half = lane >= 32;
+    const int lu0 = (s0.n + 2) / 3, lu1 = (s1.n + 2) / 3;
+    const int steps0 = __builtin_amdgcn_readfirstlane(s0.e > 0 ? s0.e + lu0 - 1 : 0), steps1 = __builtin_amdgcn_readfirstlane(s1.e > 0 ? s1.e + lu1 - 1 : 0);
+    const int s_min = steps0 < steps1 ? steps0 : steps1, s_max = steps0 < steps1 ? steps1 : steps0;
+    float M0 = NP_NEG_INF, M1 = NP_NEG_INF, M2 = NP_NEG_INF, B0 = NP_NEG_INF, B1 = NP_NEG_INF, B2 = NP_NEG_INF, K0 = NP_NEG_INF, K1 = NP_NEG_INF,
+          K2 = NP_NEG_INF;                                                  // row r-1 of this lane's three blocks
+    float oM = NP_NEG_INF, oB = NP_NEG_INF, oK = NP_NEG_INF;                // row r-1 of the block to the left
+    // events: see ea_fill; one stream per half, every lane holds 64 events of BOTH streams
+    const __amdgpu_buffer_rsrc_t evr0 = make_rsrc(s0.ev + (s0.stride > 0 ? s0.e_start : s0.e_start - (s0.e - 1)), (uint32_t)s0.e * 4u);
+    const __amdgpu_buffer_rsrc_t evr1 = make_rsrc(s1.ev + (s1.stride > 0 ? s1.e_start : s1.e_start - (s1.e - 1)), (uint32_t)s1.e * 4u);
+    auto off0 = [&](int idx) { return s0.stride > 0 ? 4 * idx : 4 * (s0.e - 1 - idx); };
+    auto off1 = [&](int idx) { return s1.stride > 0 ? 4 * idx : 4 * (s1.e - 1 - idx); };
+    float ec0 = buf_f32(evr0, off0(lane)), en0 = buf_f32(evr0, off0(lane + 64));
+    float ec1 = buf_f32(evr1, off1(lane)), en1 = buf_f32(evr1, off1(lane + 64));
+    float x = 0.0f;
+    uint8_t* line = bp + 4 * lane;
+    auto step = [&](const int t) {
+        float nM = np_wave_shr1(M2, NP_NEG_INF), nB = np_wave_shr1(B2, NP_NEG_INF), nK = np_wave_shr1(K2, NP_NEG_INF);
+        // lane 32 is the first lane of its half: its left neighbour is block -1 (-inf), not lane 31's last block
+        nM = lane == 32 ? NP_NEG_INF : nM; nB = lane == 32 ? NP_NEG_INF : nB; nK = lane == 32 ? NP_NEG_INF : nK;
+        const int ti = (t - 1) & 63;
+        if (ti == 0 && t > 1) { ec0 = en0; en0 = buf_f32(evr0, off0(t - 1 + 64 + lane)); ec1 = en1; en1 = buf_f32(evr1, off1(t - 1 + 64 + lane)); }
+        const float xa = readlane_f32(ec0, ti), xb = readlane_f32(ec1, ti);     // the event of row t of either segment
+        x = np_wave_shr1(x, xa);
+        x = lane == 32 ? xb : x;
+        const float soft = (sl == 0 && t == 1) ? flank0 : NP_NEG_INF;           // HMT_FROM_SOFT: block 0 of row 1 (flags 0)
+        const float pM0 = M0, pB0 = B0, pK0 = K0, pM1 = M1, pB1 = B1, pK1 = K1;
+        uint32_t packed = ea_block<true>(M0, B0, K0, nM, nB, nK, oM, oB, oK, x, g0, tr, soft);
+        packed |= ea_block<false>(M1, B1, K1, M0, B0, K0, pM0, pB0, pK0, x, g1, tr, NP_NEG_INF) << 8;
+        packed |= ea_block<false>(M2, B2, K2, M1, B1, K1, pM1, pB1, pK1, x, g2, tr, NP_NEG_INF) << 16;
+        oM = nM; oB = nB; oK = nK;
+        *(uint32_t*)(line + (size_t)(t - 1) * NP_EA2_LINE) = packed;
+    };
+    int t = 1;
+    for (; t <= s_min; ++t) step(t);
+    // the segment with fewer steps has just computed its last row in the lane that owns its last k-mer: keep that row (the lanes
+    // go on computing rows nobody reads)
+    const float zM0 = M0, zM1 = M1, zM2 = M2;
+    for (; t <= s_max; ++t) step(t);
+    const int ec_0 = s0.n > 0 ? (s0.n - 1) % 3 : 0, ec_1 = s1.n > 0 ? (s1.n - 1) % 3 : 0;
+    const int my_ec = hi_half ? ec_1 : ec_0;
+    const float live = my_ec == 0 ? M0 : my_ec == 1 ? M1 : M2, snap = my_ec == 0 ? zM0 : my_ec == 1 ? zM1 : zM2;
+    const int el0 = s0.n > 0 ? (s0.n - 1) / 3 : 0, el1 = 32 + (s1.n > 0 ? (s1.n - 1) / 3 : 0);
+    float2 out;
+    out.x = s0.e > 0 ? readlane_f32(steps0 == s_max ? live : snap, el0) : NP_NEG_INF;
+    out.y = s1.e > 0 ? readlane_f32(steps1 == s_max ? live : snap, el1) : NP_NEG_INF;
+    return out;
+}
+
+// The scalar phases are separate (not inlined) functions over a state block in LDS, and the launch arguments are read through a
+// pointer to a device copy of np_ea_args: inlined into one kernel body, the two halves' states, the ~40 argument pointers and the
+// walk's own variables competed for 102 scalar registers, and the compiler parked hundreds of them in vector-register lanes
+// (v_writelane / v_readlane on every use) -- the first form of this kernel was slower than the one-read kernel for that reason alone.
+struct ea_wave_state { ea_half h[2]; int drained; };
+
+// Arguments of a (not inlined) device function arrive in vector registers, and the compiler cannot know that they are wave-uniform:
+// everything computed from them would become vector code (the back-track as exec-masked vector loops, the argument block read with
+// flat loads).  These put a uniform value back into scalar registers.
+template <class T> __device__ __forceinline__ T* ea_uniform(T* p)
+{
+    const uint64_t u = (uint64_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    return (T*)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ float ea_uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ int ea_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ ea_half ea_get(const ea_wave_state* W, int q)
+{
+    ea_half h;
+    const int* p = (const int*)&W->h[q];
+    int* d = (int*)&h;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(ea_half) / 4); ++i) d[i] = __builtin_amdgcn_readfirstlane(p[i]);
+    return h;
+}
+__device__ __forceinline__ void ea_put(ea_wave_state* W, int q, const ea_half& h, int lane)
+{
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) W->h[q] = h;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void ea_finish_read(const np_ea_args& a, ea_half& h, int lane)
+{
+    if (lane == 0) {
+        const int cap = (int)(a.out_off[h.ri + 1] - a.out_off[h.ri]);
+        a.n_out[h.ri] = h.n_out < cap ? h.n_out : cap; a.status[h.ri] = h.status; a.n_calls[h.ri] = h.n_calls;
+    }
+    h.ri = -1;
+}
+
+// leaves half q with the geometry of its read's next segment (taking new reads from the queue as reads end), or without a read
+__device__ __attribute__((noinline)) void ea_next_segment(const np_ea_args* __restrict__ ap_, ea_wave_state* W, const int q_, const int lane)
+{
+    const np_ea_args& a = *ea_uniform(ap_);
+    const int q = ea_uniform(q_);
+    ea_half h = ea_get(W, q);
+    int drained = __builtin_amdgcn_readfirstlane(W->drained);
+    const int k = a.k;
+    for (;;) {
+        if (h.ri < 0) {
+            if (drained) break;
+            const int ri = __builtin_amdgcn_readfirstlane((int)atomicAdd(a.counter, lane == 0 ? 1u : 0u));
+            if (ri >= a.n_reads) { drained = 1; break; }
+            h.ri = ri; h.n_out = 0; h.n_calls = 0; h.status = NP_EA_OK;
+            const ea_read R = ea_load_read(a, ri);
+            const int max_kmer_idx = R.rl - k;                       // trim_aligned_pairs_to_kmer, :167-177
+            int q_first = 0, r_first = 0, q_last = 0, r_last = 0;
+            // a read without events in the reference (failed alignment / calibration / events-per-base QC, squiggle_read.cpp:320-335) is skipped
+            bool have = a.cig_reads[4 * ri + 2] != 0 && R.rd->n_events > 0 && a.n_pairs[ri] > 0 && !(a.events_per_base[ri] > 5.0) &&
+                        (!a.calibrated || a.calibrated[ri] != 0) && first_aligned_read_ge(R.cv, 0, q_first, r_first) &&
+                        last_aligned_read_le_r(R.cv, max_kmer_idx, q_last, r_last) && q_first <= q_last;
+            int first_event = -1, last_event = -1;
+            if (have) {
+                const int ks = R.rc ? R.rl - q_first - k : q_first, ke = R.rc ? R.rl - q_last - k : q_last;      // flip_k_strand
+                if (ks < 0 || ks >= R.K || ke < 0 || ke >= R.K) { have = false; h.status = NP_EA_BAD_RECORD; }    // the reference asserts / reads out of range
+                else { first_event = closest_event(R.ms, R.K, ks); last_event = closest_event(R.ms, R.K, ke); }
+            }
+            if (!have) { ea_finish_read(a, h, lane); continue; }
+            h.forward = first_event < last_event ? 1 : 0;
+            h.curr_start_event = __builtin_amdgcn_readfirstlane(first_event); h.curr_start_ref = __builtin_amdgcn_readfirstlane(r_first);
+            h.last_event = __builtin_amdgcn_readfirstlane(last_event); h.q_last = __builtin_amdgcn_readfirstlane(q_last);
+            h.r_last = __builtin_amdgcn_readfirstlane(r_last);
+        }
+        if (!((h.forward && h.curr_start_event < h.last_event) || (!h.forward && h.curr_start_event > h.last_event))) { ea_finish_read(a, h, lane); continue; }
+        const ea_read R = ea_load_read(a, h.ri);
+        // ---- segment geometry (:695-735) ----
+        int q_end = 0, r_end = 0;
+        if (!last_aligned_ref_le(R.cv, h.curr_start_ref + 100, q_end, r_end)) { ea_finish_read(a, h, lane); continue; }   // cannot happen
+        if (q_end > h.q_last) { q_end = h.q_last; r_end = h.r_last; }
+        const bool last_section = q_end == h.q_last;
+        const int curr_end_read = R.rc ? R.rl - q_end - k : q_end;
+        const int l = r_end - h.curr_start_ref + 1;
+        if (l < 2 * k) { ea_finish_read(a, h, lane); continue; }                                     // hmm_sequence.length() < 2 * k
+        if (h.curr_start_ref + l > R.ref_n || curr_end_read < 0 || curr_end_read >= R.K) { h.status = NP_EA_BAD_RECORD; ea_finish_read(a, h, lane); continue; }
+        const int e_start = __builtin_amdgcn_readfirstlane(h.curr_start_event), e_stop = __builtin_amdgcn_readfirstlane(closest_event(R.ms, R.K, curr_end_read));
+        const int span = e_start > e_stop ? e_start - e_stop : e_stop - e_start;
+        if (span < 2) { ea_finish_read(a, h, lane); continue; }
+        const int e = span + 1, n = __builtin_amdgcn_readfirstlane(l - k + 1);
+        if (n > 96 || e > a.rows_cap) { h.status = NP_EA_OVERFLOW; ea_finish_read(a, h, lane); continue; }
+        h.n_calls++;
+        h.e_start = e_start; h.stride = e_start < e_stop ? 1 : -1; h.e = e; h.n = n; h.last_section = last_section ? 1 : 0;
+        break;
+    }
+    ea_put(W, q, h, lane);
+    if (lane == 0) W->drained = drained;
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Back-track (profile_hmm_align_r9, r9.cpp:117-196) of BOTH halves' segments in one scalar loop.  A walk step is a dependent
+// chain of ~40 scalar instructions around one LDS read (~550 cycles measured): run for one segment after the other it made the
+// back-track half of this kernel's time.  The two walks are independent, so the loop below advances both per iteration -- one LDS
+// read (lanes 0..31 fetch half 0's byte, lanes 32..63 half 1's), two interleaved chains; a half that has finished (or has no
+// segment) idles.  Each half keeps a window of NP_EA_WIN lines of its 128 back-pointer bytes staged in LDS, refilled when its walk
+// leaves it; visited states go to the half's path list 64 at a time, as before.  Returns the two path lengths.
+#define NP_EA_WIN 16
+struct ea_walker { int row, kmer, ps, stop, cnt, lo, alive; uint32_t pv; };
+__device__ __attribute__((noinline)) int2 ea_walk2(const ea_wave_state* W, uint4* stage, const float sv0_, const float sv1_, const uint8_t* __restrict__ bp_,
+                                                   uint32_t* __restrict__ path0_, uint32_t* __restrict__ path1_, const int lane)
+{
+    const float sv0 = ea_uniform(sv0_), sv1 = ea_uniform(sv1_);
+    const uint8_t* __restrict__ bp = ea_uniform(bp_);
+    uint32_t* __restrict__ path0 = ea_uniform(path0_); uint32_t* __restrict__ path1 = ea_uniform(path1_);
+    const ea_half H0 = ea_get(W, 0), H1 = ea_get(W, 1);
+    ea_walker w0, w1;
+    // assert(get(vm, row, col) != -INFINITY): no path, nothing to emit
+    w0.alive = H0.ri >= 0 && sv0 != NP_NEG_INF; w1.alive = H1.ri >= 0 && sv1 != NP_NEG_INF;
+    w0.row = H0.e; w0.kmer = H0.n - 1; w1.row = H1.e; w1.kmer = H1.n - 1;
+    w0.ps = w1.ps = 2; w0.stop = w1.stop = 0; w0.cnt = w1.cnt = 0; w0.pv = w1.pv = 0u;
+    w0.lo = w1.lo = 0x7fffffff;                       // no window yet
+    w0.alive = w0.alive && w0.row > 0 && w0.kmer >= 0; w1.alive = w1.alive && w1.row > 0 && w1.kmer >= 0;
+    const uint8_t* sb = (const uint8_t*)stage;
+    const bool hi_half = lane >= 32;
+    while (w0.alive || w1.alive) {
+        // ---- (re)fill the window of a half whose walk is outside it: lines lo .. hi of its 128 bytes, one coalesced pass ----
+        const bool need0 = w0.alive && w0.row + w0.kmer / 3 < w0.lo, need1 = w1.alive && w1.row + w1.kmer / 3 < w1.lo;
+        __builtin_amdgcn_wave_barrier();
+        if (need0) {
+            const int hi = w0.row + w0.kmer / 3;
+            w0.lo = hi - (NP_EA_WIN - 1) > 1 ? hi - (NP_EA_WIN - 1) : 1;
+            const int n16 = (hi - w0.lo + 1) * 8;
+            const uint8_t* __restrict__ src = bp + (size_t)(w0.lo - 1) * NP_EA2_LINE;
+            for (int i = lane; i < n16; i += 64) stage[i] = *(const uint4*)(src + (size_t)(i >> 3) * NP_EA2_LINE + (i & 7) * 16);
+        }
+        if (need1) {
+            const int hi = w1.row + w1.kmer / 3;
+            w1.lo = hi - (NP_EA_WIN - 1) > 1 ? hi - (NP_EA_WIN - 1) : 1;
+            const int n16 = (hi - w1.lo + 1) * 8;
+            const uint8_t* __restrict__ src = bp + (size_t)(w1.lo - 1) * NP_EA2_LINE + 128;
+            for (int i = lane; i < n16; i += 64) stage[NP_EA_WIN * 8 + i] = *(const uint4*)(src + (size_t)(i >> 3) * NP_EA2_LINE + (i & 7) * 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        // ---- steps, while no live walk is outside its window ----
+        for (;;) {
+            const int k30 = w0.kmer / 3, k31 = w1.kmer / 3;
+            const bool in0 = w0.alive && w0.row + k30 >= w0.lo, in1 = w1.alive && w1.row + k31 >= w1.lo;
+            if ((w0.alive && !in0) || (w1.alive && !in1) || !(in0 || in1)) break;
+            // the visited state of either walk goes into lane (cnt & 63) of its list register
+            const uint32_t entry0 = (uint32_t)w0.row | ((uint32_t)w0.kmer << 16) | ((uint32_t)w0.ps << 24);
+            const uint32_t entry1 = (uint32_t)w1.row | ((uint32_t)w1.kmer << 16) | ((uint32_t)w1.ps << 24);
+            w0.pv = (in0 && lane == (w0.cnt & 63)) ? entry0 : w0.pv;
+            w1.pv = (in1 && lane == (w1.cnt & 63)) ? entry1 : w1.pv;
+            // one LDS read for both: a walk that idles reads its window's first byte
+            const int a0 = in0 ? (w0.row + k30 - w0.lo) * 128 + 4 * k30 + (w0.kmer - 3 * k30) : 0;
+            const int a1 = NP_EA_WIN * 128 + (in1 ? (w1.row + k31 - w1.lo) * 128 + 4 * k31 + (w1.kmer - 3 * k31) : 0);
+            const int bytes = (int)sb[hi_half ? a1 : a0];
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane(bytes, 0), b1 = (uint32_t)__builtin_amdgcn_readlane(bytes, 32);
+            int r0 = w0.row, q0 = w0.kmer, p0 = w0.ps, s0 = 0, r1 = w1.row, q1 = w1.kmer, p1 = w1.ps, s1 = 0;
+            ea_walk_step(b0, r0, q0, p0, s0);
+            ea_walk_step(b1, r1, q1, p1, s1);
+            w0.row = in0 ? r0 : w0.row; w0.kmer = in0 ? q0 : w0.kmer; w0.ps = in0 ? p0 : w0.ps; w0.stop = in0 ? s0 : w0.stop; w0.cnt += in0 ? 1 : 0;
+            w1.row = in1 ? r1 : w1.row; w1.kmer = in1 ? q1 : w1.kmer; w1.ps = in1 ? p1 : w1.ps; w1.stop = in1 ? s1 : w1.stop; w1.cnt += in1 ? 1 : 0;
+            w0.alive = w0.alive && w0.row > 0 && w0.kmer >= 0 && !w0.stop;
+            w1.alive = w1.alive && w1.row > 0 && w1.kmer >= 0 && !w1.stop;
+            if (in0 && (w0.cnt & 63) == 0) path0[w0.cnt - 64 + lane] = w0.pv;
+            if (in1 && (w1.cnt & 63) == 0) path1[w1.cnt - 64 + lane] = w1.pv;
+        }
+    }
+    if ((w0.cnt & 63) != 0 && lane < (w0.cnt & 63)) path0[(w0.cnt & ~63) + lane] = w0.pv;
+    if ((w1.cnt & 63) != 0 && lane < (w1.cnt & 63)) path1[(w1.cnt & ~63) + lane] = w1.pv;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    int2 out; out.x = w0.cnt; out.y = w1.cnt;
+    return out;
+}
+
+// emission (eventalign.cpp:774-812) of half q's segment from its path list: ascending order = the list read backwards
+__device__ __attribute__((noinline)) void ea_emit_segment(const np_ea_args* __restrict__ ap_, ea_wave_state* W, const int q_, const int cnt_,
+                                                          const uint32_t* __restrict__ path_, const int lane)
+{
+    const np_ea_args& a = *ea_uniform(ap_);
+    const int q = ea_uniform(q_), cnt = ea_uniform(cnt_);
+    const uint32_t* __restrict__ path = ea_uniform(path_);
+    ea_half h = ea_get(W, q);
+    const int e_start = h.e_start, stride = h.stride;
+    const int64_t o0 = a.out_off[h.ri];
+    const int out_cap = (int)(a.out_off[h.ri + 1] - o0);
+    int32_t* __restrict__ out_ref = a.out_ref + o0; int32_t* __restrict__ out_event = a.out_event + o0; uint8_t* __restrict__ out_state = a.out_state + o0;
+    int num_output = 0, last_event_output = 0, last_ref_kmer_output = 0;
+    for (int base = 0; base < cnt && (num_output < 50 || h.last_section); base += 64) {
+        const int i = base + lane;
+        uint32_t pe = 0; bool qq = false; int evi = 0, km = 0, ps = 0;
+        if (i < cnt) {
+            pe = path[cnt - 1 - i];
+            ps = (int)(pe >> 24); km = (int)((pe >> 16) & 0xff); evi = e_start + ((int)(pe & 0xffff) - 1) * stride;
+            qq = ps != 0 && evi != h.curr_start_event;
+        }
+        const uint64_t qm = __builtin_amdgcn_ballot_w64(qq);
+        const int before = __builtin_popcountll(qm & ((1ull << lane) - 1ull));
+        const int pos = num_output + before;
+        const bool wr = qq && (pos < 50 || h.last_section);
+        if (wr && h.n_out + before < out_cap) {
+            out_ref[h.n_out + before] = h.curr_start_ref + km;
+            out_event[h.n_out + before] = evi;
+            out_state[h.n_out + before] = ps == 2 ? (uint8_t)'M' : (uint8_t)'B';
+        }
+        const uint64_t wm = __builtin_amdgcn_ballot_w64(wr);
+        const int nw = __builtin_popcountll(wm);
+        if (nw > 0) {
+            const int last_lane = 63 - __builtin_clzll(wm);
+            last_event_output = __shfl(evi, last_lane, 64);
+            last_ref_kmer_output = h.curr_start_ref + __shfl(km, last_lane, 64);
+        }
+        if (h.n_out + nw > out_cap) h.status = NP_EA_OVERFLOW;
+        h.n_out += nw; num_output += nw;
+    }
+    if (h.status != NP_EA_OK) ea_finish_read(a, h, lane);
+    else {
+        h.curr_start_event = __builtin_amdgcn_readfirstlane(last_event_output);
+        h.curr_start_ref = __builtin_amdgcn_readfirstlane(last_ref_kmer_output);
+        if (num_output == 0) ea_finish_read(a, h, lane);
+    }
+    ea_put(W, q, h, lane);
+}
+
+// WAVES: resident waves per SIMD the register budget is set for (4: 128 registers, no spills in the sweep; 5: 96)
+template <int WAVES>
+__global__ void __launch_bounds__(64, WAVES) np_eventalign_chain2_kernel(const np_ea_args* __restrict__ ap)
+{
+    __shared__ uint4 stage[2 * NP_EA_WIN * 128 / 16];
+    __shared__ ea_wave_state W;
+    const np_ea_args& a = *ap;
+    const int lane = threadIdx.x;
+    const int wave_slot = blockIdx.x;
+    uint8_t* __restrict__ bp = a.bp + (size_t)wave_slot * a.bp_stride;
+    uint32_t* __restrict__ path = a.path + (size_t)wave_slot * a.path_stride;
+    const int k = a.k;
+    if (lane == 0) { W.h[0].ri = -1; W.h[1].ri = -1; W.drained = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+
+    unsigned long long cells = 0ull, rows = 0ull, kmers = 0ull;
+    unsigned long long t_next = 0ull, t_fill = 0ull, t_fin = 0ull;      // shader cycles this wave spent in the three phases (statistics)
+    for (;;) {
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        ea_next_segment(ap, &W, 0, lane);
+        ea_next_segment(ap, &W, 1, lane);
+        const ea_half H0 = ea_get(&W, 0), H1 = ea_get(&W, 1);
+        if (H0.ri < 0 && H1.ri < 0) break;
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        t_next += t1 - t0;
+
+        // ---- the lane's three blocks of its half's segment (ProfileHMMViterbiOutputR9, r9.inl:130-197) ----
+        const bool hi_half = lane >= 32;
+        const int sl = lane & 31;
+        ea_seg S0, S1;
+        np_gauss g[3];
+        ea_trans tr;
+        {
+            const ea_read R0 = ea_load_read(a, H0.ri >= 0 ? H0.ri : 0), R1 = ea_load_read(a, H1.ri >= 0 ? H1.ri : 0);
+            S0 = H0.ri >= 0 ? ea_seg{R0.ev, H0.e_start, H0.stride, H0.e, H0.n} : ea_seg{R0.ev, 0, 1, 0, 0};
+            S1 = H1.ri >= 0 ? ea_seg{R1.ev, H1.e_start, H1.stride, H1.e, H1.n} : ea_seg{R1.ev, 0, 1, 0, 0};
+            cells += (unsigned long long)(S0.e > 0 ? (S0.e + 1) * 3 * (S0.n + 2) : 0) + (unsigned long long)(S1.e > 0 ? (S1.e + 1) * 3 * (S1.n + 2) : 0);
+            rows += (unsigned long long)(S0.e + S1.e); kmers += (unsigned long long)(S0.n + S1.n);
+            const np_read_dev* rd = hi_half ? R1.rd : R0.rd;
+            const char* ref = hi_half ? R1.ref : R0.ref;
+            const bool rc = hi_half ? R1.rc : R0.rc;
+            const int n = hi_half ? S1.n : S0.n, csr = hi_half ? H1.curr_start_ref : H0.curr_start_ref;
+            const double scale = rd->scale, shift = rd->shift, var = rd->var, log_var = rd->log_var;
+            tr = ea_trans{rd->trans[0], rd->trans[1], rd->trans[2], rd->trans[3], rd->trans[4], rd->trans[5], rd->trans[6], rd->trans[7],
+                          rd->trans[8], rd->trans[9]};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int b = 3 * sl + c;
+                uint32_t rank = 0;
+                if (b < n) {
+                    // HMMInputSequence::get_kmer_rank(b, k, rc): the forward k-mer at b, or its reverse complement's rank
+                    for (int t = 0; t < k; ++t) {
+                        const uint32_t code = rc ? 3u - base_code(ref[csr + b + k - 1 - t]) : base_code(ref[csr + b + t]);
+                        rank = rank * 4u + code;
+                    }
+                }
+                g[c] = np_scale_state(a.model, rank, scale, shift, var, log_var);
+            }
+        }
+        const float2 start_v = ea_fill2(g[0], g[1], g[2], tr, a.flank[0], S0, S1, bp, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        t_fill += t2 - t1;
+        const bool prio = __builtin_amdgcn_readfirstlane(a.walk_prio) != 0;
+        if (prio) __builtin_amdgcn_s_setprio(3);
+        uint32_t* path1 = path + (a.path_stride >> 1);
+        const int2 cnt = ea_walk2(&W, stage, start_v.x, start_v.y, bp, path, path1, lane);
+        if (H0.ri >= 0) ea_emit_segment(ap, &W, 0, cnt.x, path, lane);
+        if (H1.ri >= 0) ea_emit_segment(ap, &W, 1, cnt.y, path1, lane);
+        if (prio) __builtin_amdgcn_s_setprio(0);
+        t_fin += __builtin_amdgcn_s_memtime() - t2;
+    }
+    if (lane == 0 && a.stats && cells) {
+        atomicAdd(a.stats, cells); atomicAdd(a.stats + 1, rows); atomicAdd(a.stats + 2, kmers);
+        atomicAdd(a.stats + 3, t_next); atomicAdd(a.stats + 4, t_fill); atomicAdd(a.stats + 5, t_fin);
+    }
+}
+
 } // namespace
 
-hipError_t np_launch_eventalign_chain(const np_ea_args& a, int n_blocks, hipStream_t s)
+// variant 1: one read per wave (two k-mer blocks per lane); 2 / 3: two reads per wave (three blocks per lane of a half-wave) with the
+// register budget of 4 / 5 resident waves per SIMD
+hipError_t np_launch_eventalign_chain(const np_ea_args& a, const np_ea_args* a_dev /* a device copy of a (variant 2) */, int n_blocks, int variant, hipStream_t s)
 {
-    hipLaunchKernelGGL(np_eventalign_chain_kernel, dim3(n_blocks), dim3(64), 0, s, a);
+    if (variant == 1) hipLaunchKernelGGL(np_eventalign_chain_kernel, dim3(n_blocks), dim3(64), 0, s, a);
+    else if (variant == 2) hipLaunchKernelGGL(np_eventalign_chain2_kernel<4>, dim3(n_blocks), dim3(64), 0, s, a_dev);
+    else hipLaunchKernelGGL(np_eventalign_chain2_kernel<5>, dim3(n_blocks), dim3(64), 0, s, a_dev);
     return hipGetLastError();
 }
+int np_eventalign_line_bytes(int variant) { return variant == 1 ? NP_EA_ROW_BYTES : NP_EA2_LINE; }

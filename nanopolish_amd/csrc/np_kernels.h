@@ -57,6 +57,7 @@ struct np_ea_args {
     int32_t* status;
     int32_t* n_calls;
     uint32_t* counter;
+    int walk_prio;                 // two-read kernel: raise the wave priority during back-track + emission (experiment knob)
     unsigned long long* stats;     // [0] += lattice cells (e + 1) x 3 (n + 2) of every segment, [1] += lattice rows e, [2] += k-mers n (nullable)
 };
 
@@ -133,7 +134,8 @@ hipError_t np_launch_cm_build_jobs(int n_reads, const char* seq, const int64_t* 
                                    int min_separation, int min_flank, const int64_t* group_off, const int64_t* rank_off_cap,
                                    np_hmm_job_dev* jobs, int32_t* kpos, uint16_t* job_ranks, int32_t* first_site, int32_t* last_site,
                                    int32_t* n_motif, int64_t* group_rank_off, int32_t* n_groups, hipStream_t s);
-hipError_t np_launch_eventalign_chain(const np_ea_args& a, int n_blocks, hipStream_t s);
+hipError_t np_launch_eventalign_chain(const np_ea_args& a, const np_ea_args* a_dev, int n_blocks, int variant, hipStream_t s);
+int np_eventalign_line_bytes(int variant);
 hipError_t np_launch_cigar_index(int n_reads, const uint32_t* cigar, const int64_t* cigar_off, const int32_t* read_len, int k, int32_t* op_ref,
                                  int32_t* op_read, void* cig_reads, hipStream_t s);
 hipError_t np_launch_cm_build_jobs_cigar(int n_reads, const char* genome, const int64_t* ref_begin, const int32_t* ref_len,

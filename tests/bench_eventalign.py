@@ -53,6 +53,7 @@ def run(pool=1000, tile=50, read_len=5450, steps=3, warmup=1, cpu_sample=-1, ctx
     ctx.sync(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     cells, erows, kmers = (ctx.get_stat("ea_lattice_" + q) for q in ("cells", "rows", "kmers"))
+    phase = {q: ctx.get_stat("ea_cycles_" + q) for q in ("geometry", "fill", "backtrack")}
     res = batch.eventalign_results()
     fam = {name: ctx.kernel_time(w)[0] / max(1, steps) for w, name in ((0, "event_align"), (2, "map_calibrate"), (4, "event_detect"), (5, "mom_scalings"), (6, "eventalign_chain"))}
     rows = int(sum(len(r["event_idx"]) for r in res)); calls = int(sum(r["n_calls"] for r in res))
@@ -65,6 +66,7 @@ def run(pool=1000, tile=50, read_len=5450, steps=3, warmup=1, cpu_sample=-1, ctx
     roof = dict(bound="hbm", kernel="np_eventalign_chain_kernel", achieved=round(algo / chain_s / 1e9, 2) if chain_s > 0 else 0.0, peak=8000.0,
                 unit="GB/s", frac=round(algo / chain_s / 1e9 / 8000.0, 5) if chain_s > 0 else 0.0, traffic=None, algo_bytes_per_launch=algo,
                 avg_launch_ms=round(fam["eventalign_chain"], 3), lattice_cells_per_launch=int(cells), segments_per_launch=calls,
+                wave_cycles_by_phase=phase if phase["fill"] > 0 else None,
                 limiter="vector-instruction issue of the Viterbi sweep (one wave per read, data-dependent chain of segments)")
     out = dict(metric="eventalign reads/sec", value=round(batch.n_reads * steps / dt, 1), unit="reads/s", n_gpus=1, steps=steps,
                ms_per_step=round(1e3 * dt / steps, 3), reads_per_step=batch.n_reads, rows_per_step=rows, hmm_align_calls_per_step=calls,
