@@ -76,8 +76,8 @@ struct np_ctx {
     dev_buf cm_group_rank_off, cm_cigar_scratch;        // work-item generation scratch
     dev_buf ea_bp, ea_path, ea_args;                    // eventalign chain: per-wave back-pointer rows and path lists; a device copy of the launch arguments
     int ea_rows_cap = 4096, ea_waves_per_cu = 20;
-    int ea_walk_prio = 1;            // two-read chain kernel: back-track + emission at wave priority 3 (315 -> 300 ms per 50 000 reads, gpurun r03g)
-    int ea_kernel = 1;                // eventalign chain: 1 = one read per wave (shipped), 2 = two reads per wave (np_eventalign_kernel.hip; experimental)
+    int ea_walk_prio = 0;            // two-read chain kernel: wave priority 3 during back-track + emission (helped the scalar walks, not the vector walk)
+    int ea_kernel = 2;                // eventalign chain: 1 = one read per wave (rounds 1-2), 2 = two reads per wave (np_eventalign_kernel.hip)
     dev_buf b_raw, b_raw_off, b_ev_off, b_ev_start, b_ev_len, b_ev_mean, b_ev_stdv, b_n_events;
     timing_t timing[NP_NUM_FAMILIES];
     std::mutex lock;

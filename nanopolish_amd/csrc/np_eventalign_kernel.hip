@@ -324,8 +324,8 @@ __global__ void __launch_bounds__(64, 5) np_eventalign_chain_kernel(np_ea_args a
 // then for half 1; a half whose read is finished pulls the next read from the queue, a half without work sweeps an empty
 // segment.  The per-read state that survives from segment to segment is ten integers per half (ea_half); what only depends on
 // the read's index is reloaded where it is needed (wave-uniform loads).
-// Back-pointers: one dword per lane and sweep step (the lane's three blocks in bytes 0..2), one 256-byte line per step: cell
-// (row r, k-mer b) of half h lives in line r + b / 3 at byte 128 h + 4 (b / 3) + b % 3.
+// Back-pointers: one dword per lane and sweep step (nine bits per block, see ea_block), one 256-byte line per step: cell
+// (row r, k-mer b) of half h lives in line r + b / 3, dword 32 h + b / 3, bits 9 (b % 3) .. 9 (b % 3) + 8.
 // ---------------------------------------------------------------------------------------------------------------------------
 #define NP_EA2_LINE 256
 
@@ -362,7 +362,10 @@ struct ea_half {                 // chain state of the read a half-wave works on
 };
 
 // one k-mer block of one lattice row: the candidates of r9.inl:130-197 in HMMMovementType order, later index wins ties;
-// (lM_r, lB_r, lK_r): the block to the left in this row, (lM_p, ...): in the previous row.  Returns the block's back-pointer byte.
+// (lM_r, lB_r, lK_r): the block to the left in this row, (lM_p, ...): in the previous row.
+// Returns the block's back-pointers as NINE bits, three per state (K in bits 0..2, B in 3..5, M in 6..8), each already the
+// back-track's move: bit 2 = "the k-mer steps back", bits 1..0 = the state walked to (2 MATCH, 1 BAD_EVENT, 0 KMER_SKIP), 7 = soft
+// clip (stop).  I.e. HMT_FROM_SAME_M 2, PREV_M 6, SAME_B 1, PREV_B 5, PREV_K 4, SOFT 7 (r9.cpp:150-186): the walk needs no decoding.
 template <bool FIRST>
 __device__ __forceinline__ uint32_t ea_block(float& M, float& B, float& K, const float lM_r, const float lB_r, const float lK_r,
                                              const float lM_p, const float lB_p, const float lK_p, const float x, const np_gauss& g,
@@ -370,20 +373,25 @@ __device__ __forceinline__ uint32_t ea_block(float& M, float& B, float& K, const
 {
     const float em = np_emission(x, g);
     const float a0 = tr.mm_self + M, a1 = tr.mm_next + lM_p, a2 = tr.bm_self + B, a3 = tr.bm_next + lB_p, a4 = tr.km + lK_p;
-    float v = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), __builtin_fmaxf(a2, a3)), a4);
-    if (FIRST) v = __builtin_fmaxf(v, soft);
-    uint32_t from = (a1 == v) ? 1u : 0u;
-    from = (a2 == v) ? 2u : from; from = (a3 == v) ? 3u : from; from = (a4 == v) ? 4u : from;
-    if (FIRST) from = (soft == v) ? 5u : from;
+    // maximum and "the largest index whose candidate equals it" (r9.inl:138-143) as a tournament in which a tie goes to the later
+    // candidate at every node: 4 max + 4 compares + 4 selects instead of 4 max + 5 compares + 5 selects
+    const float m01 = __builtin_fmaxf(a0, a1), m23 = __builtin_fmaxf(a2, a3);
+    const uint32_t c01 = (a1 >= a0) ? 6u : 2u, c23 = (a3 >= a2) ? 5u : 1u;
+    const float m03 = __builtin_fmaxf(m01, m23);
+    uint32_t cm = (m23 >= m01) ? c23 : c01;
+    float v = __builtin_fmaxf(m03, a4);
+    cm = (a4 >= m03) ? 4u : cm;
+    if (FIRST) { cm = (soft >= v) ? 7u : cm; v = __builtin_fmaxf(v, soft); }
     const float newM = v + em;
+    // (the B and K states emit 0: the reference's `+ lp_emission` leaves every value it can meet here unchanged)
     const float b0 = tr.mb + M, b2 = tr.bb + B;
     const float newB = __builtin_fmaxf(b0, b2);
-    const uint32_t bbit = (b2 >= b0) ? 8u : 0u;
+    const uint32_t cb = (b2 >= b0) ? 1u : 2u;         // from the block's own B, else from its own M
     const float k1 = tr.mk + lM_r, k3 = tr.bk + lB_r, k4 = tr.kk + lK_r;
     const float newK = __builtin_fmaxf(__builtin_fmaxf(k1, k3), k4);
-    uint32_t kbits = (k3 == newK) ? 16u : 0u; kbits = (k4 == newK) ? 32u : kbits;
+    uint32_t ck = (k3 == newK) ? 5u : 6u; ck = (k4 == newK) ? 4u : ck;
     M = newM; B = newB; K = newK;
-    return from | bbit | kbits;
+    return ck | (cb << 3) | (cm << 6);
 }
 
 struct ea_seg { const float* ev; int e_start, stride, e, n; };
@@ -422,8 +430,8 @@ __device__ __attribute__((noinline)) float2 ea_fill2(const np_gauss g0, const np
         const float soft = (sl == 0 && t == 1) ? flank0 : NP_NEG_INF;           // HMT_FROM_SOFT: block 0 of row 1 (flags 0)
         const float pM0 = M0, pB0 = B0, pK0 = K0, pM1 = M1, pB1 = B1, pK1 = K1;
         uint32_t packed = ea_block<true>(M0, B0, K0, nM, nB, nK, oM, oB, oK, x, g0, tr, soft);
-        packed |= ea_block<false>(M1, B1, K1, M0, B0, K0, pM0, pB0, pK0, x, g1, tr, NP_NEG_INF) << 8;
-        packed |= ea_block<false>(M2, B2, K2, M1, B1, K1, pM1, pB1, pK1, x, g2, tr, NP_NEG_INF) << 16;
+        packed |= ea_block<false>(M1, B1, K1, M0, B0, K0, pM0, pB0, pK0, x, g1, tr, NP_NEG_INF) << 9;
+        packed |= ea_block<false>(M2, B2, K2, M1, B1, K1, pM1, pB1, pK1, x, g2, tr, NP_NEG_INF) << 18;
         oM = nM; oB = nB; oK = nK;
         *(uint32_t*)(line + (size_t)(t - 1) * NP_EA2_LINE) = packed;
     };
@@ -545,103 +553,121 @@ __device__ __attribute__((noinline)) void ea_next_segment(const np_ea_args* __re
     __builtin_amdgcn_wave_barrier();
 }
 
-// Back-track (profile_hmm_align_r9, r9.cpp:117-196) of BOTH halves' segments in one scalar loop.  A walk step is a dependent
-// chain of ~40 scalar instructions around one LDS read (~550 cycles measured): run for one segment after the other it made the
-// back-track half of this kernel's time.  The two walks are independent, so the loop below advances both per iteration -- one LDS
-// read (lanes 0..31 fetch half 0's byte, lanes 32..63 half 1's), two interleaved chains; a half that has finished (or has no
-// segment) idles.  Each half keeps a window of NP_EA_WIN lines of its 128 back-pointer bytes staged in LDS, refilled when its walk
-// leaves it; visited states go to the half's path list 64 at a time, as before.  Returns the two path lengths.
+// Back-track (profile_hmm_align_r9, r9.cpp:117-196) of BOTH halves' segments as vector code: lanes 0..31 walk half 0's path, lanes
+// 32..63 half 1's (every lane of a half computes the same).  A walk step is one dependent chain around an LDS read; as scalar
+// code, one segment after the other, it took ~550-790 cycles per step and half of this kernel's time (the scalar unit's latency
+// per dependent instruction, ~40-55 of them per step), and two scalar chains interleaved in one loop were no faster.  As vector
+// code the chain is ~25 instructions for BOTH segments, and the back-pointer word is already the move (ea_block).
+// Per half: a window of NP_EA_WIN lines of its 32 dwords staged in LDS (refilled when the walk leaves it) and the list of visited
+// states in LDS (NP_EA_PCAP entries; a longer path spills the full buffer to the half's global list and goes on).
 #define NP_EA_WIN 16
-struct ea_walker { int row, kmer, ps, stop, cnt, lo, alive; uint32_t pv; };
-__device__ __attribute__((noinline)) int2 ea_walk2(const ea_wave_state* W, uint4* stage, const float sv0_, const float sv1_, const uint8_t* __restrict__ bp_,
-                                                   uint32_t* __restrict__ path0_, uint32_t* __restrict__ path1_, const int lane)
+#define NP_EA_PCAP 384
+struct ea_lds {
+    uint32_t stage[2][NP_EA_WIN * 32];     // back-pointer windows
+    uint32_t pbuf[2][NP_EA_PCAP];          // visited states, oldest first: row | kmer << 16 | state << 24
+    uint32_t dump[64];                     // where the lanes that record nothing write
+    ea_wave_state W;
+};
+struct ea_walk_result { int cnt0, cnt1, spilled0, spilled1; };
+
+__device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const float sv0_, const float sv1_, const uint8_t* __restrict__ bp_,
+                                                             uint32_t* __restrict__ path0_, uint32_t* __restrict__ path1_, const int lane)
 {
     const float sv0 = ea_uniform(sv0_), sv1 = ea_uniform(sv1_);
     const uint8_t* __restrict__ bp = ea_uniform(bp_);
     uint32_t* __restrict__ path0 = ea_uniform(path0_); uint32_t* __restrict__ path1 = ea_uniform(path1_);
-    const ea_half H0 = ea_get(W, 0), H1 = ea_get(W, 1);
-    ea_walker w0, w1;
-    // assert(get(vm, row, col) != -INFINITY): no path, nothing to emit
-    w0.alive = H0.ri >= 0 && sv0 != NP_NEG_INF; w1.alive = H1.ri >= 0 && sv1 != NP_NEG_INF;
-    w0.row = H0.e; w0.kmer = H0.n - 1; w1.row = H1.e; w1.kmer = H1.n - 1;
-    w0.ps = w1.ps = 2; w0.stop = w1.stop = 0; w0.cnt = w1.cnt = 0; w0.pv = w1.pv = 0u;
-    w0.lo = w1.lo = 0x7fffffff;                       // no window yet
-    w0.alive = w0.alive && w0.row > 0 && w0.kmer >= 0; w1.alive = w1.alive && w1.row > 0 && w1.kmer >= 0;
-    const uint8_t* sb = (const uint8_t*)stage;
+    const ea_half H0 = ea_get(&L->W, 0), H1 = ea_get(&L->W, 1);
     const bool hi_half = lane >= 32;
-    while (w0.alive || w1.alive) {
-        // ---- (re)fill the window of a half whose walk is outside it: lines lo .. hi of its 128 bytes, one coalesced pass ----
-        const bool need0 = w0.alive && w0.row + w0.kmer / 3 < w0.lo, need1 = w1.alive && w1.row + w1.kmer / 3 < w1.lo;
+    const int sl = lane & 31;
+    // per-lane state, uniform within a half
+    const int e = hi_half ? H1.e : H0.e, n = hi_half ? H1.n : H0.n;
+    int row = e, k3 = n > 0 ? (n - 1) / 3 : 0, kr = n > 0 ? (n - 1) % 3 : 0, ps = 2, cnt = 0, spilled = 0;
+    int lo = 0x7fffffff;                                  // no window yet
+    // assert(get(vm, row, col) != -INFINITY): no path, nothing to emit
+    bool alive = (hi_half ? (H1.ri >= 0 && sv1 != NP_NEG_INF) : (H0.ri >= 0 && sv0 != NP_NEG_INF)) && e > 0 && n > 0;
+    const uint32_t* st = &L->stage[hi_half ? 1 : 0][0];
+    uint32_t* pb = &L->pbuf[hi_half ? 1 : 0][0];
+    uint32_t* dump = &L->dump[lane];
+    while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
+        // ---- per half, by scalar control: refill the window of a walk that is outside it; spill a full list ----
+        const bool need = alive && row + k3 < lo, full = alive && cnt - spilled >= NP_EA_PCAP;
+        const uint64_t need_m = __builtin_amdgcn_ballot_w64(need), full_m = __builtin_amdgcn_ballot_w64(full);
         __builtin_amdgcn_wave_barrier();
-        if (need0) {
-            const int hi = w0.row + w0.kmer / 3;
-            w0.lo = hi - (NP_EA_WIN - 1) > 1 ? hi - (NP_EA_WIN - 1) : 1;
-            const int n16 = (hi - w0.lo + 1) * 8;
-            const uint8_t* __restrict__ src = bp + (size_t)(w0.lo - 1) * NP_EA2_LINE;
-            for (int i = lane; i < n16; i += 64) stage[i] = *(const uint4*)(src + (size_t)(i >> 3) * NP_EA2_LINE + (i & 7) * 16);
-        }
-        if (need1) {
-            const int hi = w1.row + w1.kmer / 3;
-            w1.lo = hi - (NP_EA_WIN - 1) > 1 ? hi - (NP_EA_WIN - 1) : 1;
-            const int n16 = (hi - w1.lo + 1) * 8;
-            const uint8_t* __restrict__ src = bp + (size_t)(w1.lo - 1) * NP_EA2_LINE + 128;
-            for (int i = lane; i < n16; i += 64) stage[NP_EA_WIN * 8 + i] = *(const uint4*)(src + (size_t)(i >> 3) * NP_EA2_LINE + (i & 7) * 16);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if ((need_m >> (32 * h)) & 1ull) {
+                const int hi = __builtin_amdgcn_readlane(row + k3, 32 * h);
+                const int nlo = hi - (NP_EA_WIN - 1) > 1 ? hi - (NP_EA_WIN - 1) : 1;
+                const int n16 = (hi - nlo + 1) * 8;
+                const uint8_t* __restrict__ src = bp + (size_t)(nlo - 1) * NP_EA2_LINE + 128 * h;
+                uint4* dst = (uint4*)&L->stage[h][0];
+                for (int i = lane; i < n16; i += 64) dst[i] = *(const uint4*)(src + (size_t)(i >> 3) * NP_EA2_LINE + (i & 7) * 16);
+                lo = (hi_half == (h == 1)) ? nlo : lo;
+            }
+            if ((full_m >> (32 * h)) & 1ull) {
+                const int sp = __builtin_amdgcn_readlane(spilled, 32 * h);
+                uint32_t* __restrict__ dstp = (h ? path1 : path0) + sp;
+                for (int i = lane; i < NP_EA_PCAP; i += 64) dstp[i] = L->pbuf[h][i];
+                spilled = (hi_half == (h == 1)) ? spilled + NP_EA_PCAP : spilled;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
-        // ---- steps, while no live walk is outside its window ----
+        // ---- steps, while no live walk is outside its window or out of list space ----
         for (;;) {
-            const int k30 = w0.kmer / 3, k31 = w1.kmer / 3;
-            const bool in0 = w0.alive && w0.row + k30 >= w0.lo, in1 = w1.alive && w1.row + k31 >= w1.lo;
-            if ((w0.alive && !in0) || (w1.alive && !in1) || !(in0 || in1)) break;
-            // the visited state of either walk goes into lane (cnt & 63) of its list register
-            const uint32_t entry0 = (uint32_t)w0.row | ((uint32_t)w0.kmer << 16) | ((uint32_t)w0.ps << 24);
-            const uint32_t entry1 = (uint32_t)w1.row | ((uint32_t)w1.kmer << 16) | ((uint32_t)w1.ps << 24);
-            w0.pv = (in0 && lane == (w0.cnt & 63)) ? entry0 : w0.pv;
-            w1.pv = (in1 && lane == (w1.cnt & 63)) ? entry1 : w1.pv;
-            // one LDS read for both: a walk that idles reads its window's first byte
-            const int a0 = in0 ? (w0.row + k30 - w0.lo) * 128 + 4 * k30 + (w0.kmer - 3 * k30) : 0;
-            const int a1 = NP_EA_WIN * 128 + (in1 ? (w1.row + k31 - w1.lo) * 128 + 4 * k31 + (w1.kmer - 3 * k31) : 0);
-            const int bytes = (int)sb[hi_half ? a1 : a0];
-            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane(bytes, 0), b1 = (uint32_t)__builtin_amdgcn_readlane(bytes, 32);
-            int r0 = w0.row, q0 = w0.kmer, p0 = w0.ps, s0 = 0, r1 = w1.row, q1 = w1.kmer, p1 = w1.ps, s1 = 0;
-            ea_walk_step(b0, r0, q0, p0, s0);
-            ea_walk_step(b1, r1, q1, p1, s1);
-            w0.row = in0 ? r0 : w0.row; w0.kmer = in0 ? q0 : w0.kmer; w0.ps = in0 ? p0 : w0.ps; w0.stop = in0 ? s0 : w0.stop; w0.cnt += in0 ? 1 : 0;
-            w1.row = in1 ? r1 : w1.row; w1.kmer = in1 ? q1 : w1.kmer; w1.ps = in1 ? p1 : w1.ps; w1.stop = in1 ? s1 : w1.stop; w1.cnt += in1 ? 1 : 0;
-            w0.alive = w0.alive && w0.row > 0 && w0.kmer >= 0 && !w0.stop;
-            w1.alive = w1.alive && w1.row > 0 && w1.kmer >= 0 && !w1.stop;
-            if (in0 && (w0.cnt & 63) == 0) path0[w0.cnt - 64 + lane] = w0.pv;
-            if (in1 && (w1.cnt & 63) == 0) path1[w1.cnt - 64 + lane] = w1.pv;
+            const int line = row + k3;
+            const bool in = alive && line >= lo && cnt - spilled < NP_EA_PCAP;
+            if (__builtin_amdgcn_ballot_w64(alive && !in) != 0ull || __builtin_amdgcn_ballot_w64(in) == 0ull) break;
+            // the visited state goes to the half's list (lane 0 of the half writes it, the others write their dump slots)
+            const uint32_t entry = (uint32_t)row | ((uint32_t)(3 * k3 + kr) << 16) | ((uint32_t)ps << 24);
+            uint32_t* wp = (in && sl == 0) ? pb + (cnt - spilled) : dump;
+            *wp = entry;
+            // the move out of this cell
+            const uint32_t w = st[in ? (line - lo) * 32 + k3 : 0];
+            const uint32_t c = (w >> (9 * kr + 3 * ps)) & 7u;
+            const bool stop = c == 7u;                                  // HMT_FROM_SOFT
+            const bool stepped = in && !stop;
+            const int nrow = row - (ps != 0 ? 1 : 0);                   // K states are silent (r9.cpp:176-178)
+            const int dk = (int)(c >> 2);
+            const int t = kr - dk;
+            const int nkr = t < 0 ? 2 : t, nk3 = t < 0 ? k3 - 1 : k3;
+            cnt += in ? 1 : 0;
+            row = stepped ? nrow : row; k3 = stepped ? nk3 : k3; kr = stepped ? nkr : kr; ps = stepped ? (int)(c & 3u) : ps;
+            alive = alive && !(in && stop) && row > 0 && k3 >= 0;
         }
     }
-    if ((w0.cnt & 63) != 0 && lane < (w0.cnt & 63)) path0[(w0.cnt & ~63) + lane] = w0.pv;
-    if ((w1.cnt & 63) != 0 && lane < (w1.cnt & 63)) path1[(w1.cnt & ~63) + lane] = w1.pv;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
-    int2 out; out.x = w0.cnt; out.y = w1.cnt;
-    return out;
+    __builtin_amdgcn_wave_barrier();
+    ea_walk_result r;
+    r.cnt0 = __builtin_amdgcn_readlane(cnt, 0); r.cnt1 = __builtin_amdgcn_readlane(cnt, 32);
+    r.spilled0 = __builtin_amdgcn_readlane(spilled, 0); r.spilled1 = __builtin_amdgcn_readlane(spilled, 32);
+    return r;
 }
 
-// emission (eventalign.cpp:774-812) of half q's segment from its path list: ascending order = the list read backwards
-__device__ __attribute__((noinline)) void ea_emit_segment(const np_ea_args* __restrict__ ap_, ea_wave_state* W, const int q_, const int cnt_,
+// emission (eventalign.cpp:774-812) of half q's segment from its list of visited states (entries [spilled, cnt) in LDS, older ones in
+// the half's global list): ascending order = the list read backwards
+__device__ __attribute__((noinline)) void ea_emit_segment(const np_ea_args* __restrict__ ap_, ea_lds* L, const int q_, const int cnt_, const int spilled_,
                                                           const uint32_t* __restrict__ path_, const int lane)
 {
     const np_ea_args& a = *ea_uniform(ap_);
-    const int q = ea_uniform(q_), cnt = ea_uniform(cnt_);
+    const int q = ea_uniform(q_), cnt = ea_uniform(cnt_), spilled = ea_uniform(spilled_);
     const uint32_t* __restrict__ path = ea_uniform(path_);
+    ea_wave_state* W = &L->W;
     ea_half h = ea_get(W, q);
     const int e_start = h.e_start, stride = h.stride;
     const int64_t o0 = a.out_off[h.ri];
     const int out_cap = (int)(a.out_off[h.ri + 1] - o0);
     int32_t* __restrict__ out_ref = a.out_ref + o0; int32_t* __restrict__ out_event = a.out_event + o0; uint8_t* __restrict__ out_state = a.out_state + o0;
+    const uint32_t* pb = &L->pbuf[q][0];
     int num_output = 0, last_event_output = 0, last_ref_kmer_output = 0;
     for (int base = 0; base < cnt && (num_output < 50 || h.last_section); base += 64) {
         const int i = base + lane;
         uint32_t pe = 0; bool qq = false; int evi = 0, km = 0, ps = 0;
         if (i < cnt) {
-            pe = path[cnt - 1 - i];
+            const int j = cnt - 1 - i;
+            pe = j >= spilled ? pb[j - spilled] : path[j];
             ps = (int)(pe >> 24); km = (int)((pe >> 16) & 0xff); evi = e_start + ((int)(pe & 0xffff) - 1) * stride;
             qq = ps != 0 && evi != h.curr_start_event;
         }
@@ -677,8 +703,8 @@ __device__ __attribute__((noinline)) void ea_emit_segment(const np_ea_args* __re
 template <int WAVES>
 __global__ void __launch_bounds__(64, WAVES) np_eventalign_chain2_kernel(const np_ea_args* __restrict__ ap)
 {
-    __shared__ uint4 stage[2 * NP_EA_WIN * 128 / 16];
-    __shared__ ea_wave_state W;
+    __shared__ ea_lds lds;
+    ea_wave_state& W = lds.W;
     const np_ea_args& a = *ap;
     const int lane = threadIdx.x;
     const int wave_slot = blockIdx.x;
@@ -742,9 +768,9 @@ __global__ void __launch_bounds__(64, WAVES) np_eventalign_chain2_kernel(const n
         const bool prio = __builtin_amdgcn_readfirstlane(a.walk_prio) != 0;
         if (prio) __builtin_amdgcn_s_setprio(3);
         uint32_t* path1 = path + (a.path_stride >> 1);
-        const int2 cnt = ea_walk2(&W, stage, start_v.x, start_v.y, bp, path, path1, lane);
-        if (H0.ri >= 0) ea_emit_segment(ap, &W, 0, cnt.x, path, lane);
-        if (H1.ri >= 0) ea_emit_segment(ap, &W, 1, cnt.y, path1, lane);
+        const ea_walk_result wr = ea_walk2(&lds, start_v.x, start_v.y, bp, path, path1, lane);
+        if (H0.ri >= 0) ea_emit_segment(ap, &lds, 0, wr.cnt0, wr.spilled0, path, lane);
+        if (H1.ri >= 0) ea_emit_segment(ap, &lds, 1, wr.cnt1, wr.spilled1, path1, lane);
         if (prio) __builtin_amdgcn_s_setprio(0);
         t_fin += __builtin_amdgcn_s_memtime() - t2;
     }

@@ -57,3 +57,46 @@ def test_batch_realignment_equals_the_unmodified_reference():
             n_rows += len(ea["event_idx"])
             fr.close()
         assert n_rows > 3000
+
+
+def test_oversegmented_reads_long_segments(ctx, models):
+    """Reads with ~3.7 events per base (every k-mer's dwell split into two sub-levels): a 100-base segment then spans 370+ events, its
+    back-track visits more states than the two-read chain kernel's LDS list holds (NP_EA_PCAP), so the list spills to memory on the
+    way -- and the one-read kernel needs several LDS window refills per segment.  Both chain kernels against the reference's own
+    SquiggleRead + align_read_to_ref on the same raw signal."""
+    from nanopolish_amd import api
+    from nanopolish_amd.pipeline import build_host_batch_records, CallMethylationBatch
+    from nanopolish_amd.synth import BASES, nucleotide_kmer_ranks
+    nuc = models["nucleotide"]
+    F = FullRef()
+    recs, want = [], []
+    for rid in range(3):
+        rng = np.random.default_rng(4200 + rid)
+        codes = rng.integers(0, 4, 1400)
+        seq = BASES[codes].tobytes().decode()
+        ranks = nucleotide_kmer_ranks(codes, 6)
+        shift, scale, var = rng.uniform(-3, 3), rng.uniform(0.95, 1.05), 1.1
+        sub = np.tile(np.array([-1.8, 1.8]), len(ranks))                      # two sub-levels per k-mer, 10 samples each
+        rk = np.repeat(np.repeat(ranks, 2), 10)
+        mu = scale * nuc["level_mean"][rk] + shift + np.repeat(sub, 10) * nuc["level_stdv"][rk]
+        raw = np.maximum(mu + 0.4 * var * nuc["level_stdv"][rk] * rng.standard_normal(len(rk)), 8.0).astype(np.float32)
+        rc = rid & 1
+        ref = api.reverse_complement("nucleotide", seq) if rc else seq
+        recs.append(dict(seq=seq, raw=raw, rc=rc, pos=0, cigar=api.cigar_words([("M", len(seq))]), contig=ref))
+        fr = F.read("o%d" % rid, seq, raw)
+        assert fr.n_events > 0 and fr.events_per_base > 3.3, (fr.n_events, fr.events_per_base)
+        want.append(fr.eventalign(rc, 0, recs[-1]["cigar"], ref, ref))
+        fr.close()
+    hb = build_host_batch_records(models, recs, "")
+    try:
+        for kernel in (2, 1):
+            ctx.set_option("ea_kernel", kernel)
+            batch = CallMethylationBatch(ctx, hb, "cuda:0", calibrate=True, from_raw=True)
+            batch.step()
+            got = batch.eventalign()
+            for g, w in zip(got, want):
+                assert g["status"] == 0 and len(w["event_idx"]) > 3000
+                assert np.array_equal(g["ref_position"], w["ref_position"]) and np.array_equal(g["event_idx"], w["event_idx"]), kernel
+                assert np.array_equal(g["hmm_state"], w["hmm_state"]), kernel
+    finally:
+        ctx.set_option("ea_kernel", 2)
