@@ -80,7 +80,8 @@ const char* np_ctx_info(const np_ctx* ctx);
 int np_set_option(np_ctx* ctx, const char* name, int64_t value);
 /* Read-only facts about the context (-1: unknown name): "align_blocks" / "align_scratch_bytes" (persistent grid and per-wave scratch
  * of the most recent event-align launch: the grid shrinks under a 48 GB scratch budget when a batch holds ultra-long reads),
- * "align_blocks_max", "lse_oor" (1: the clamp-free log-sum lookup is in use, see np_ctx_info), "n_cu", "ea_lattice_cells" /
+ * "align_blocks_max", "lse_oor" (1: the clamp-free log-sum lookup is in use, see np_ctx_info), "n_cu", "ed_serial_reads" / "ed_refused_reads" (most recent event-detection
+ * call: reads that took the serial prefix-sum path, reads refused with NP_ED_INEXACT; waits for the call), "ea_lattice_cells" /
  * "ea_lattice_rows" / "ea_lattice_kmers" (sum over the segments of the most recent np_eventalign_dev call of the reference's
  * lattice size (e + 1) x 3 (n + 2), of e and of n; waits for the call), "ea_cycles_geometry" / "ea_cycles_fill" /
  * "ea_cycles_backtrack" (two-read chain kernel: shader cycles, summed over the waves, spent finding segments, sweeping them, and
@@ -386,8 +387,10 @@ typedef struct np_detector_param {
 void np_event_detection_params(np_detector_param* p, int rna);
 
 #define NP_ED_OVERFLOW (-1)   /* n_events[r]: more events than the caller's capacity for the read                      */
-#define NP_ED_INEXACT  (-2)   /* n_events[r]: the detector's double-precision sums are not provably exact for this read, */
-                              /* so an order-independent evaluation could differ from the reference in the last bit      */
+#define NP_ED_INEXACT  (-2)   /* n_events[r]: the read holds a non-finite sample (inf / nan): the reference's own result is     */
+                              /* undefined.                 (A read whose double-precision prefix sums are merely not       */
+                              /* PROVABLY exact -- a near-zero sample does that -- is not refused any more: its sums are      */
+                              /* accumulated serially, as the reference does; np_get_stat "ed_serial_reads" counts them.)     */
 
 /* The signal loaders' conversion of ADC counts to pA, in front of detect_events:
  *     rawptr[i] = ((float)raw_signal[i] + offset) * raw_unit,   raw_unit = range / digitisation  (all fp32)

@@ -28,7 +28,7 @@ struct NpBatchRead {
 };
 #define NP_BATCH_OK 0
 #define NP_BATCH_NO_EVENTS 1     // the read has no usable event alignment (failed QC / calibration): an empty site map, as the reference
-#define NP_BATCH_HOST_PATH 2     // not processed on the device (RNA read, event detection not provably exact for this signal, or a
+#define NP_BATCH_HOST_PATH 2     // not processed on the device (RNA read, a non-finite sample in the signal, or a
                                  // per-read capacity estimate was exceeded): the caller runs its per-record function on it
 
 // Fills result[record] (one map per record, created even when empty, like basemods.cpp:253-256) for every read whose

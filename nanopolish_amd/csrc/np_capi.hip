@@ -86,7 +86,8 @@ struct np_ctx {
     int align_lpt = 1;                // issue the event aligner's reads longest first
     int stream_switch_wait = 1;       // a call on a new stream waits for the tail of the stream the context used before (0: the caller orders its streams itself)
     int ed_warmup = -1;               // parallel peak walk: samples of warm-up per segment (< 0: the kernel's default)
-    int64_t last_align_blocks = 0, last_align_scratch = 0;      // np_get_stat: grid and scratch of the most recent event-align launch
+    int64_t last_align_blocks = 0, last_align_scratch = 0;
+    int ed_last_reads = 0;            // np_get_stat("ed_serial_reads"): reads of the most recent event-detection call      // np_get_stat: grid and scratch of the most recent event-align launch
 };
 
 namespace {
@@ -1049,6 +1050,17 @@ int64_t np_get_stat(np_ctx* c, const char* name)
     if (k == "align_blocks_max") return (int64_t)c->n_cu * c->align_blocks_per_cu;
     if (k == "lse_oor") return c->lse_oor ? 1 : 0;
     if (k == "n_cu") return c->n_cu;
+    if (k == "ed_serial_reads" || k == "ed_refused_reads") {     // of the most recent np_detect_events_* call (waits for it): reads whose
+        // prefix sums were accumulated serially (exactness bound not provable), resp. refused (NP_ED_INEXACT: non-finite samples)
+        if (c->ed_last_reads <= 0 || !c->ed_status.p) return 0;
+        std::vector<int32_t> st((size_t)c->ed_last_reads);
+        if (hipSetDevice(c->device) != hipSuccess) return -1;
+        if (c->tail_recorded && hipEventSynchronize(c->switch_ev) != hipSuccess) return -1;
+        if (hipMemcpy(st.data(), c->ed_status.p, st.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        int64_t n = 0;
+        for (int32_t v : st) n += k == "ed_serial_reads" ? v == 1 : v == NP_ED_INEXACT;
+        return n;
+    }
     if (k.rfind("ea_", 0) == 0) {        // statistics of the most recent np_eventalign_dev call (waits for it)
         unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
         if (hipSetDevice(c->device) != hipSuccess) return -1;
@@ -1098,6 +1110,7 @@ static int detect_events_locked(np_ctx* c, hipStream_t s, int n_reads, const flo
     if (p.window_length1 > 16 || p.window_length2 > 16) { c->err = "np_detect_events: window length > 16"; return NP_ERR_UNSUPPORTED; }
     if (tstat && ((uintptr_t)tstat & 63u)) { c->err = "np_detect_events: tstat scratch must be 64-byte aligned"; return NP_ERR_INVALID; }
     NP_HIP(c, c->ed_status.reserve((size_t)n_reads * sizeof(int32_t)));
+    c->ed_last_reads = n_reads;
     if (!tstat) {
         NP_HIP(c, c->ed_tstat.reserve((size_t)total_samples_hint * sizeof(float2) + 64));
         tstat = c->ed_tstat.as<float>();
@@ -1167,7 +1180,7 @@ int np_detect_events_host(np_ctx* c, int n_reads, const float* const* raw, const
     int64_t w = 0;
     for (int r = 0; r < n_reads; ++r) {
         out_off[r] = w;
-        if (hn[r] == NP_ED_INEXACT) { c->err = "np_detect_events_host: a read's prefix sums are not provably exact (NP_ED_INEXACT)"; return NP_ERR_UNSUPPORTED; }
+        if (hn[r] == NP_ED_INEXACT) { c->err = "np_detect_events_host: a read holds a non-finite sample (NP_ED_INEXACT)"; return NP_ERR_UNSUPPORTED; }
         if (hn[r] < 0) { c->err = "np_detect_events_host: event capacity exceeded"; return NP_ERR_NOMEM; }
         if (w + hn[r] > cap) { c->err = "np_detect_events_host: output capacity too small"; return NP_ERR_NOMEM; }
         const size_t o = (size_t)ev_off[r];

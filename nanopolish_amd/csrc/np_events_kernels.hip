@@ -12,8 +12,10 @@
 // two prefix values IS the exact sum of the samples in between -- in any order.  np_ed_check_kernel proves that bound
 // per read (for the samples and for their squares); reads that pass are segmented from window sums computed directly
 // (no prefix arrays, no serial scan), and the result is bit-identical to the reference.  A read that fails the bound
-// (samples below ~4 pA in a 130k-sample read would do it) reports NP_ED_INEXACT instead of a result that might differ
-// in the last bit; there is no approximate path.
+// (samples below ~4 pA in a 130k-sample read would do it) takes the SERIAL path (round 3): its prefix sums are accumulated
+// front to back by one lane, exactly the reference's additions with the reference's roundings (np_ed_serial_tstat_kernel,
+// np_ed_serial_events_kernel) -- slower, but a fallback for the odd read, bit-identical like the rest.  Only a read with a
+// non-finite sample still reports NP_ED_INEXACT; there is no approximate path.
 //
 // The t-statistics are embarrassingly parallel (np_ed_tstat_kernel: one thread per sample, neighbours through LDS).  The
 // short/long peak picker is a sequential state machine per read: short reads take one lane per read (64 reads per wave,
@@ -31,6 +33,7 @@
                                // it; with the t-statistics computed inside the walk a warm-up sample costs as much as a real one, and the rare
                                // repair rounds of a short warm-up cost less than a long one (256 / 128 / 64 / 32: 17.2 / 16.3 / 15.8 / 15.6 ms)
 #define NP_ED_PAR_MIN 2048     // reads shorter than this take the lane-per-read walk
+#define NP_ED_SERIAL 1         // status of a read whose prefix sums are not provably exact: serial path
 #ifndef NP_ED_FUSED
 #define NP_ED_FUSED 1          // long reads: t-statistics computed inside the peak walk (DNA windows), no t-statistic array
 #endif
@@ -99,17 +102,19 @@ __global__ void __launch_bounds__(256) np_ed_check_kernel(int n_reads, const flo
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        bool ok = true;
+        bool ok = true, bad = false;
         for (int w = 0; w < 2; ++w) {
             const uint32_t mx = red[2 * w][0], mn = red[2 * w + 1][0];
-            if (mx >= 0x7f800000u) { ok = false; continue; }               // inf / nan
+            if (mx >= 0x7f800000u) { bad = true; continue; }               // inf / nan
             if (mn == 0xffffffffu) continue;                                // all zero
             if ((mn >> 23) == 0u) { ok = false; continue; }                 // a denormal term: no bound attempted
             const int g = (int)(mn >> 23) - 127 - 23;                       // every term is a multiple of 2^g
             const double bound = (double)n * (double)__builtin_bit_cast(float, mx);
             ok = ok && bound < ldexp(1.0, 53 + g);
         }
-        status[r] = ok ? 0 : NP_ED_INEXACT;
+        // 0: every addition of the reference is exact (the parallel path); NP_ED_SERIAL: not provably -- the serial path repeats
+        // the reference's additions one by one; NP_ED_INEXACT: a non-finite sample (the reference's own result is undefined)
+        status[r] = bad ? NP_ED_INEXACT : (ok ? 0 : NP_ED_SERIAL);
     }
 }
 
@@ -186,6 +191,59 @@ __global__ void __launch_bounds__(NP_ED_TILE) np_ed_tstat_kernel(int n_reads, co
     tstat[raw_off[r] + i] = w1 < w2 ? make_float2(ta, tb) : make_float2(tb, ta);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The serial path of a read that failed the exactness bound: compute_sum_sumsq (event_detection.c:35-49) as the reference runs
+// it -- sum[i + 1] = sum[i] + data[i], sumsq[i + 1] = sumsq[i] + data[i] * data[i], front to back in double -- by lane 0, 64
+// samples at a time into an LDS ring, and compute_tstat (:63-119) from DIFFERENCES of those prefix values by all 64 lanes.
+// One wave per read.  The t-statistics go to the batch's t-statistic array; the peak walk then reads them like any other read's.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) np_ed_serial_tstat_kernel(int n_reads, const float* __restrict__ raw, const int64_t* __restrict__ raw_off,
+                                                                const int32_t* __restrict__ status, int w1, int w2, float2* __restrict__ tstat)
+{
+    const int r = blockIdx.x;
+    if (r >= n_reads || status[r] != NP_ED_SERIAL) return;
+    const int lane = threadIdx.x;
+    const float* x = raw + raw_off[r];
+    const int64_t n = raw_off[r + 1] - raw_off[r];
+    __shared__ double S[256], Q[256];                 // prefix values sum[j], sumsq[j] at ring slot j & 255
+    double s = 0.0, q = 0.0;                          // (lane 0) the running prefix values
+    int64_t have = 0;                                 // prefix values sum[0 .. have] are in the ring
+    if (lane == 0) { S[0] = 0.0; Q[0] = 0.0; }
+    const int wa = w1 < w2 ? w1 : w2, wb = w1 < w2 ? w2 : w1;
+    for (int64_t base = 0; base < n; base += 64) {
+        // extend the prefix to sum[min(n, base + 64 + wb)]: at most 64 + NP_ED_HALO new values, while sum[base - wb ..] stay in the ring
+        const int64_t want = base + 64 + wb < n ? base + 64 + wb : n;
+        __syncthreads();
+        if (lane == 0) {
+            for (int64_t j = have; j < want; ++j) {
+                const float v = x[j];
+                s = s + (double)v; q = q + (double)(v * v);
+                S[(j + 1) & 255] = s; Q[(j + 1) & 255] = q;
+            }
+        }
+        have = want;
+        __syncthreads();
+        const int64_t i = base + lane;
+        if (i < n) {
+            float t[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int w = k ? wb : wa;
+                float tv = 0.0f;
+                if (!(w < 2 || n < 2 * (int64_t)w || i < w || i > n - w)) {
+                    double sum1 = S[i & 255], sumsq1 = Q[i & 255];
+                    if (i > w) { sum1 -= S[(i - w) & 255]; sumsq1 -= Q[(i - w) & 255]; }
+                    const double sum2d = S[(i + w) & 255] - S[i & 255], sumsq2d = Q[(i + w) & 255] - Q[i & 255];
+                    tv = tstat_from_sums(sum1, sumsq1, sum2d, sumsq2d, i, n, w);
+                }
+                t[k] = tv;
+            }
+            tstat[raw_off[r] + i] = w1 < w2 ? make_float2(t[0], t[1]) : make_float2(t[1], t[0]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // short_long_peak_detector (event_detection.c:126-207), one lane per read
 // ---------------------------------------------------------------------------------------------------------------
@@ -234,7 +292,7 @@ __global__ void __launch_bounds__(64) np_ed_peaks_kernel(int n_reads, const int6
 {
     const int r = blockIdx.x * 64 + threadIdx.x;
     const bool mine = r < n_reads && (raw_off[r + 1] - raw_off[r] < NP_ED_PAR_MIN || status[r] != 0);   // long reads: np_ed_peaks_par_kernel
-    const bool live = mine && status[r] == 0;
+    const bool live = mine && status[r] >= 0;                   // (NP_ED_SERIAL: t-statistics from the serial kernel)
     const int n = live ? (int)(raw_off[r + 1] - raw_off[r]) : 0;
     const float2* ts = tstat + (live ? raw_off[r] : 0);
     uint32_t* es = event_start + (live ? event_off[r] : 0);
@@ -489,11 +547,11 @@ __global__ void __launch_bounds__(64, 3) np_ed_peaks_par_kernel(int n_reads, con
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) np_ed_events_kernel(int n_reads, const float* __restrict__ raw, const int64_t* __restrict__ raw_off,
                                                             const int64_t* __restrict__ event_off, const uint32_t* __restrict__ event_start,
-                                                            const int32_t* __restrict__ n_events, float* __restrict__ event_length,
-                                                            float* __restrict__ event_mean, float* __restrict__ event_stdv)
+                                                            const int32_t* __restrict__ n_events, const int32_t* __restrict__ status,
+                                                            float* __restrict__ event_length, float* __restrict__ event_mean, float* __restrict__ event_stdv)
 {
     const int r = blockIdx.x;
-    if (r >= n_reads) return;
+    if (r >= n_reads || status[r] != 0) return;              // (serial reads: np_ed_serial_events_kernel)
     const int n_ev = n_events[r];
     const float* x = raw + raw_off[r];
     const int64_t n = raw_off[r + 1] - raw_off[r];
@@ -514,6 +572,45 @@ __global__ void __launch_bounds__(256) np_ed_events_kernel(int n_reads, const fl
     event_length[eo + e] = length;
     event_mean[eo + e] = mean;
     event_stdv[eo + e] = sqrtf(fmaxf(var, 0.0f));
+    }
+}
+
+
+// create_event for a read on the serial path: the prefix sums are accumulated front to back as the reference does, and every
+// event takes the difference of the prefix values at its two ends (event_detection.c:223-241).  One lane per read; the events'
+// start positions are visited in order, and the scan restarts from the first sample should a start lie before its predecessor
+// (the two detectors emit in time order, so that is a corner of a corner).
+__global__ void __launch_bounds__(64) np_ed_serial_events_kernel(int n_reads, const float* __restrict__ raw, const int64_t* __restrict__ raw_off,
+                                                                 const int64_t* __restrict__ event_off, const uint32_t* __restrict__ event_start,
+                                                                 const int32_t* __restrict__ n_events, const int32_t* __restrict__ status,
+                                                                 float* __restrict__ event_length, float* __restrict__ event_mean, float* __restrict__ event_stdv)
+{
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= n_reads || status[r] != NP_ED_SERIAL) return;
+    const int n_ev = n_events[r];
+    const float* x = raw + raw_off[r];
+    const int64_t n = raw_off[r + 1] - raw_off[r];
+    const int64_t eo = event_off[r];
+    double s = 0.0, q = 0.0;          // sum[pos], sumsq[pos]
+    int64_t pos = 0;
+    auto seek = [&](int64_t to) {     // the prefix values at `to`
+        if (to < pos) { s = 0.0; q = 0.0; pos = 0; }
+        for (; pos < to; ++pos) { const float v = x[pos]; s = s + (double)v; q = q + (double)(v * v); }
+    };
+    for (int e = 0; e < n_ev; ++e) {
+        const int64_t start = event_start[eo + e];
+        const int64_t end = e + 1 < n_ev ? (int64_t)event_start[eo + e + 1] : n;
+        seek(start);
+        const double s0 = s, q0 = q;
+        seek(end);
+        const double ds = s - s0, dq = q - q0;
+        const float length = (float)((uint64_t)end - (uint64_t)start);
+        const float mean = (float)ds / length;
+        const float deltasqr = (float)dq;
+        const float var = deltasqr / length - mean * mean;
+        event_length[eo + e] = length;
+        event_mean[eo + e] = mean;
+        event_stdv[eo + e] = sqrtf(fmaxf(var, 0.0f));
     }
 }
 
@@ -614,6 +711,9 @@ hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t*
     if (t_tiles > 0)
         hipLaunchKernelGGL(np_ed_tstat_kernel, dim3(n_reads, t_tiles), dim3(NP_ED_TILE), 0, s, n_reads, raw, raw_off, status,
                            (int)p.window_length1, (int)p.window_length2, tstat, fused ? (int64_t)NP_ED_PAR_MIN : INT64_MAX);
+    // reads on the serial path (rare): their t-statistics, whatever their length, into the same array
+    hipLaunchKernelGGL(np_ed_serial_tstat_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, raw, raw_off, status, (int)p.window_length1,
+                       (int)p.window_length2, tstat);
     hipLaunchKernelGGL(np_ed_peaks_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, raw_off, tstat, status, p, event_off,
                        event_start, n_events);
     if (max_samples >= NP_ED_PAR_MIN) {
@@ -626,7 +726,9 @@ hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t*
     }
     (void)max_events;
     hipLaunchKernelGGL(np_ed_events_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, raw, raw_off, event_off, event_start,
-                       n_events, event_length, event_mean, event_stdv);
+                       n_events, status, event_length, event_mean, event_stdv);
+    hipLaunchKernelGGL(np_ed_serial_events_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, raw, raw_off, event_off, event_start,
+                       n_events, status, event_length, event_mean, event_stdv);
     return hipGetLastError();
 }
 

@@ -79,13 +79,21 @@ def test_parallel_peak_walk_repairs_unconverged_segments(ctx, orc, models):
     assert not np.any((want["start"] > lo) & (want["start"] < lo + 2500))
 
 
-def test_detector_declines_reads_whose_sums_are_not_provably_exact(ctx, models):
-    """A 50k-sample read with one sample of 1e-3 pA: the reference's double prefix sums of squares round, so an
-    order-independent evaluation is no longer guaranteed identical -- the library says so instead of approximating."""
-    raw = synth_raw(8, models["nucleotide"], L=5450)["raw"].copy()
-    raw[1234] = 1e-3
-    with pytest.raises(RuntimeError):
-        ctx.detect_events([raw])
+def test_reads_whose_sums_are_not_provably_exact_take_the_serial_path(ctx, orc, models):
+    """A 50k-sample read with one sample of 1e-3 pA: the reference's double prefix sums of squares round from there on, so an
+    order-independent evaluation is no longer guaranteed identical.  Rounds 1-2 refused such a read (NP_ED_INEXACT); since round 3 it
+    is segmented by the serial path -- the reference's additions in the reference's order -- beside parallel-path reads in one
+    batch, and every read equals the oracle.  A denormal sample (whose fp32 square flushes to zero or not, as the host's does) goes
+    the same way."""
+    raws = [synth_raw(8 + i, models["nucleotide"], L=5450)["raw"].copy() for i in range(4)]
+    raws[1][1234] = 1e-3
+    raws[3][77] = 1e-41
+    got = ctx.detect_events(raws)
+    assert ctx.get_stat("ed_serial_reads") == 2 and ctx.get_stat("ed_refused_reads") == 0
+    for raw, g in zip(raws, got):
+        assert _same(g, orc.detect_events(raw, **ED_DEFAULTS))
+    for raw, g in zip(raws, ctx.detect_events(raws, rna=True)):       # the RNA detector's windows (7 and 14 samples)
+        assert _same(g, orc.detect_events(raw, **ED_RNA))
 
 
 def test_pass_from_raw_signal_matches_oracle(ctx, orc, models):
@@ -134,19 +142,52 @@ def adc_like_raw(n, seed, offset=10.0, raw_unit=1400.0 / 8192.0, zero_crossings=
 
 
 def test_exactness_bound_holds_for_sequencer_scale_signal(ctx, orc):
-    """the device detector refuses a read (NP_ED_INEXACT) when it cannot prove that the reference's
-    double-precision prefix sums are exact.  For signal at the scale a sequencer delivers -- pA values that are integer
-    multiples of range/digitisation in the 60..130 pA band, reads up to half a million samples -- the bound holds and the
-    events equal the reference's.  What trips it is a near-zero sample: the fp32 SQUARE of a 0.17 pA sample has an ulp of
-    2^-29, and the running sum of squares (~1e4 per sample) outgrows 2^53 of those within a thousand samples -- in the
-    reference too, whose serial sums then round.  Such a read is REPORTED, never approximated."""
+    """The parallel detector needs every addition of the reference's double-precision prefix sums to be exact.  For signal at the
+    scale a sequencer delivers -- pA values that are integer multiples of range/digitisation in the 60..130 pA band, reads up to half
+    a million samples -- the bound holds (no read takes the serial path) and the events equal the reference's.  What trips it is a
+    near-zero sample: the fp32 SQUARE of a 0.17 pA sample has an ulp of 2^-29, and the running sum of squares (~1e4 per sample)
+    outgrows 2^53 of those within a thousand samples -- in the reference too, whose serial sums then round.  Such a read takes the
+    SERIAL path (round 3: the reference's additions, one by one) and still equals the reference bit for bit; only a non-finite
+    sample is refused (NP_ED_INEXACT)."""
     raws = [adc_like_raw(n, 100 + i) for i, n in enumerate((4000, 60000, 250000, 500000))]
     got = ctx.detect_events(raws)                       # raises on NP_ED_INEXACT
+    assert ctx.get_stat("ed_serial_reads") == 0
     for raw, g in zip(raws[:3], got[:3]):
         assert _same(g, orc.detect_events(raw, **ED_DEFAULTS))
     assert len(got[3]["mean"]) > 20000
+    near_zero = [adc_like_raw(60000, 7, zero_crossings=3), adc_like_raw(1500, 8, zero_crossings=2), adc_like_raw(260000, 9, zero_crossings=40)]
+    got = ctx.detect_events(near_zero)
+    assert ctx.get_stat("ed_serial_reads") == 3
+    for raw, g in zip(near_zero, got):
+        assert _same(g, orc.detect_events(raw, **ED_DEFAULTS)), len(raw)
+    bad = adc_like_raw(5000, 11); bad[1234] = np.inf
     with pytest.raises(RuntimeError, match="INEXACT"):
-        ctx.detect_events([adc_like_raw(60000, 7, zero_crossings=3)])
+        ctx.detect_events([bad])
+
+
+def test_serial_path_rate_on_adc_signal_with_spikes_and_dropouts(ctx, orc):
+    """ADC-derived signal with what real traces carry besides levels -- current spikes (hundreds of pA for a sample
+    or two) and drop-outs towards 0 pA (a blocked pore) -- in a batch of 96 reads, a third of them with drop-outs: every read's events
+    equal the reference's, and only the reads with near-zero samples pay for the serial path."""
+    rng = np.random.default_rng(5)
+    raws, has_dropout = [], []
+    for i in range(96):
+        n = int(rng.integers(3000, 40000))
+        x = adc_like_raw(n, 900 + i, zero_crossings=0)
+        for p in rng.integers(0, n, int(rng.integers(0, 6))):              # spikes: +300 .. +900 pA
+            x[p:p + int(rng.integers(1, 3))] += np.float32(rng.uniform(300, 900))
+        drop = i % 3 == 0
+        if drop:                                                           # drop-outs: 5-40 samples within 0.2 .. 3 pA of zero
+            for p in rng.integers(0, n - 50, int(rng.integers(1, 4))):
+                m = int(rng.integers(5, 40))
+                x[p:p + m] = (np.rint(rng.uniform(1, 18, m)).astype(np.float32)) * np.float32(1400.0 / 8192.0)
+        raws.append(x.astype(np.float32)); has_dropout.append(drop)
+    got = ctx.detect_events(raws)
+    serial = ctx.get_stat("ed_serial_reads")
+    for x, g in zip(raws, got):
+        assert _same(g, orc.detect_events(x, **ED_DEFAULTS)), len(x)
+    assert 0 < serial <= sum(has_dropout), (serial, sum(has_dropout))
+    print("serial-path reads: %d of %d (%d with drop-outs)" % (serial, len(raws), sum(has_dropout)))
 
 
 def test_adc_counts_to_pa_on_the_device(ctx, orc, models):
