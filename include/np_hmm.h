@@ -235,6 +235,18 @@ int np_event_align_dev(np_ctx* ctx, void* stream, int n_reads, const np_read_dev
                        const float* event_mean, const uint16_t* kmer_rank, int model, int64_t max_bands,
                        const int64_t* pair_off, np_pair* pairs_out, int32_t* pair_begin, int32_t* n_pairs);
 
+/* The same alignment as two launches (round 3): phase 1 = the banded fill, phase 2 = the back-track + QC, 3 = both in this call.
+ * Between the two the packed trace of EVERY read of the batch stays in HBM (32 B per pair slot: total_pairs >= pair_off[n_reads] of
+ * them, 43 GB for 100 000 reads of 8 000 events -- the context keeps the buffer and only grows it), where np_event_align_dev keeps
+ * one trace per resident wave.  What it buys: the fill is bound by vector-instruction issue, the back-track is a dependent scalar
+ * chain that occupies a wave slot and little else; as its own launch it can run on ANOTHER stream beside the scoring kernels of the
+ * previous batch (pass different streams and order them with np_event_record / np_stream_wait_event; phase 2 must follow phase 1 of
+ * the same batch, and the next phase 1 must follow it).  Results are identical to np_event_align_dev's.
+ * Kernel time of phase 2 is family 7 of np_kernel_time. */
+int np_event_align_split_dev(np_ctx* ctx, void* stream, int phase, int n_reads, const np_read_dev* reads,
+                             const float* event_mean, const uint16_t* kmer_rank, int model, int64_t max_bands, int64_t total_pairs,
+                             const int64_t* pair_off, np_pair* pairs_out, int32_t* pair_begin, int32_t* n_pairs);
+
 /* Forward scores of a batch of HMM work items (kernel B).
  *   order (host pointer, may be NULL): nothing to provide; the library bins jobs by size on the device. */
 int np_hmm_score_dev(np_ctx* ctx, void* stream, int64_t n_jobs, const np_hmm_job_dev* jobs,
@@ -454,7 +466,8 @@ int np_sync(np_ctx* ctx, void* stream);
 
 /* Time (ms) spent in the most recent launch of each kernel family on the device, measured with HIP events
  * on the launching stream.  which: 0 = event align, 1 = hmm score, 2 = resolve / calibrate / work items, 3 = hmm viterbi,
- * 4 = event detection, 5 = MoM scalings, 6 = eventalign chain. */
+ * 4 = event detection, 5 = MoM scalings, 6 = eventalign chain, 7 = the event aligner's back-track as its own launch
+ * (np_event_align_split_dev phase 2; then family 0 is the fill alone). */
 int np_last_kernel_ms(np_ctx* ctx, int which, float* ms);
 /* Accumulated device time (ms) and launch count of a kernel family since the last reset (call after np_sync). */
 int np_kernel_time(np_ctx* ctx, int which, double* total_ms, int64_t* launches, int reset);

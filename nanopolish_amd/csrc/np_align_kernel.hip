@@ -435,13 +435,19 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
     }
 }
 
+// MODE 0: fill and back-track of a read by the same wave (trace scratch per resident wave).  MODE 1 / MODE 2: the two halves as
+// separate launches (round 3) -- the fill keeps the packed trace of EVERY read of the batch (a.trace_all, 32 B per band: 43 GB for
+// 100 000 reads of 13.5k bands, what 288 GB of HBM are for) and each read's end cell (a.fill_state); the back-track kernel, a
+// dependent scalar chain that needs a wave slot and few issue slots, then runs wherever the caller's stream puts it -- beside the
+// scoring kernels of another batch instead of inside the issue-bound fill.
+template <int MODE>
 __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_kernel(np_align_args a)
 {
     const int lane = threadIdx.x & 63;
     // readfirstlane: tells the compiler the value is wave-uniform, so pointers derived from it stay in SGPRs (buffer
     // descriptors must be scalar; a VGPR descriptor costs a waterfall loop per load)
     const int wave_slot = __builtin_amdgcn_readfirstlane(blockIdx.x * (NP_ALIGN_BLOCK / 64) + (threadIdx.x >> 6));
-    uint64_t* __restrict__ trace = a.trace + (size_t)wave_slot * a.trace_stride;
+    uint64_t* __restrict__ trace = MODE == 0 ? a.trace + (size_t)wave_slot * a.trace_stride : nullptr;
     float4* __restrict__ kp = a.kparams + (size_t)wave_slot * a.kp_stride;     // per-wave slab of scaled k-mer parameters
 
     for (;;) {
@@ -464,9 +470,13 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
         np_pair* __restrict__ pairs = a.pairs + pbase;
 
         const int n_rows = (n_bands + 7) >> 3;
-        const bool ok = !(E <= 0 || K <= 0 || (uint64_t)n_rows * 32 > a.trace_stride || (uint64_t)K > a.kp_stride || cap < E + K + 2);
+        // kept trace: read ri's rows start at row (pair_off[ri] >> 3) + ri -- successive starts are at least (cap >> 3) + 1 >= n_rows apart
+        if (MODE != 0) trace = a.trace_all + (size_t)((pbase >> 3) + ri) * 32;
+        const bool ok = !(E <= 0 || K <= 0 || (MODE == 0 && (uint64_t)n_rows * 32 > a.trace_stride) || (uint64_t)K > a.kp_stride || cap < E + K + 2);
         int n_out = 0, max_gap = 0, last_k = -1;
         double sum_emission = 0.0;
+        float best_u = NP_NEG_INF;
+        int curr_e = 0;
         if (ok) {
             // ---------------- prologue: per-k-mer scaled Gaussians ----------------
             float cl_max = NP_NEG_INF;
@@ -485,72 +495,82 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_s_waitcnt(0);
 
-            // ---------------- fill ----------------
-            read_t R;
-            R.E = E; R.K = K; R.lane = lane; R.lane4 = lane >> 2; R.end_slot = (K - 1) & (NP_RING - 1); R.nonpos = nonpos;
-            R.ev = make_rsrc(ev, (uint32_t)E * 4u); R.kp = make_rsrc(kp, (uint32_t)K * 16u); R.tr = make_rsrc(trace, (uint32_t)n_rows * 256u);
-            {
-                const uint64_t u = (uint64_t)uniform_ptr(kp);
-                R.kpd = i4{(int)(uint32_t)u, (int)(uint32_t)(u >> 32), (int)((uint32_t)K * 16u), 0x00020000};      // == make_rsrc(kp, 16 K)
-            }
-
-            // wave-uniform constants in scalar registers (a VALU fp64 add takes one SGPR-pair operand): 8 VGPRs saved
-            R.lp_skip = uniform_f64(rd->lp_skip); R.lp_stay = uniform_f64(rd->lp_stay);
-            R.lp_step = uniform_f64(rd->lp_step); R.lp_trim = uniform_f64(rd->lp_trim);
-            fill_t F;
-            F.llk = -1 - NP_ALN_BANDWIDTH / 2;              // band_lower_left[0].kmer_idx, raw_loader.cpp:150-151
-            {
-                const int k0 = ring_kmer(2 * lane, F.llk), k1 = ring_kmer(2 * lane + 1, F.llk);
-                F.eo0 = 4 * (-1 - k0); F.eo1 = 4 * (-1 - k1);                    // band 0
-                const float4 g0 = buf_f32x4(R.kp, 16 * k0), g1 = buf_f32x4(R.kp, 16 * k1);
-                F.g0 = f4{g0.x, g0.y, g0.z, g0.w}; F.g1 = f4{g1.x, g1.y, g1.z, g1.w};
-            }
-            F.p0 = F.p1 = NP_NEG_INF; F.d0 = F.d1 = (double)NP_NEG_INF;
-            F.best = NP_NEG_INF; F.best_e = 0; F.tacc = 0u;
-            F.vm0 = F.vm1 = 0ull; F.sel0 = F.sel1 = F.swp = 0;
-            float x0 = 0.0f, x1 = 0.0f;                     // event means of the current band's two cells
-            int b = 0;
-            // Three phases, so that the long middle of the read pays for no band geometry, trim column or end search.
-            // llk and u = b-2-llk (the event of the window's first k-mer) never decrease and exactly one of them grows
-            // per band, so the FAST conditions
-            //   llk >= 0,  u >= 99  (the window's last k-mer has event u-99 >= 0)  -- become true once, and
-            //   llk + 99 < K-1,  u <= E-1                                           -- become false once;
-            // and while min(K-2 - (llk+99), E-1 - u) = s > 0 the next s bands are FAST whatever the moves are.
-            for (; b < n_bands && !(F.llk >= 0 && b - 2 - F.llk >= NP_ALN_BANDWIDTH - 1); ++b)
-                band_step<true, true, false>(F, R, b, x0, x1, x0, x1);
-            window_state(F);
-            for (; R.nonpos;) {
-                const int ks = (K - 2) - (F.llk + NP_ALN_BANDWIDTH - 1), es = (E - 1) - (b - 2 - F.llk);
-                int stop = b + (ks < es ? ks : es);
-                stop = stop < n_bands ? stop : n_bands;
-                if (stop <= b) break;
-                // two bands per iteration, the first one even: the doubles made of `left` become the next band's diagonal without
-                // a register copy, the event offsets advance once, the trace store and the parity of Suzuki's tie rule are
-                // compile-time properties of the position
-                if (b & 1) { band_step<false, false, true>(F, R, b, x0, x1, x0, x1); ++b; }
-                float y0, y1;
-                for (; b + 1 < stop; b += 2) {
-                    band_step<false, false, true, 0>(F, R, b, x0, x1, y0, y1); band_step<false, false, true, 1>(F, R, b + 1, y0, y1, x0, x1);
-                    F.eo0 += 8; F.eo1 += 8;
+            if (MODE != 2) {
+                // ---------------- fill ----------------
+                read_t R;
+                R.E = E; R.K = K; R.lane = lane; R.lane4 = lane >> 2; R.end_slot = (K - 1) & (NP_RING - 1); R.nonpos = nonpos;
+                R.ev = make_rsrc(ev, (uint32_t)E * 4u); R.kp = make_rsrc(kp, (uint32_t)K * 16u); R.tr = make_rsrc(trace, (uint32_t)n_rows * 256u);
+                {
+                    const uint64_t u = (uint64_t)uniform_ptr(kp);
+                    R.kpd = i4{(int)(uint32_t)u, (int)(uint32_t)(u >> 32), (int)((uint32_t)K * 16u), 0x00020000};      // == make_rsrc(kp, 16 K)
                 }
-                for (; b < stop; ++b) band_step<false, false, true>(F, R, b, x0, x1, x0, x1);
+
+                // wave-uniform constants in scalar registers (a VALU fp64 add takes one SGPR-pair operand): 8 VGPRs saved
+                R.lp_skip = uniform_f64(rd->lp_skip); R.lp_stay = uniform_f64(rd->lp_stay);
+                R.lp_step = uniform_f64(rd->lp_step); R.lp_trim = uniform_f64(rd->lp_trim);
+                fill_t F;
+                F.llk = -1 - NP_ALN_BANDWIDTH / 2;              // band_lower_left[0].kmer_idx, raw_loader.cpp:150-151
+                {
+                    const int k0 = ring_kmer(2 * lane, F.llk), k1 = ring_kmer(2 * lane + 1, F.llk);
+                    F.eo0 = 4 * (-1 - k0); F.eo1 = 4 * (-1 - k1);                    // band 0
+                    const float4 g0 = buf_f32x4(R.kp, 16 * k0), g1 = buf_f32x4(R.kp, 16 * k1);
+                    F.g0 = f4{g0.x, g0.y, g0.z, g0.w}; F.g1 = f4{g1.x, g1.y, g1.z, g1.w};
+                }
+                F.p0 = F.p1 = NP_NEG_INF; F.d0 = F.d1 = (double)NP_NEG_INF;
+                F.best = NP_NEG_INF; F.best_e = 0; F.tacc = 0u;
+                F.vm0 = F.vm1 = 0ull; F.sel0 = F.sel1 = F.swp = 0;
+                float x0 = 0.0f, x1 = 0.0f;                     // event means of the current band's two cells
+                int b = 0;
+                // Three phases, so that the long middle of the read pays for no band geometry, trim column or end search.
+                // llk and u = b-2-llk (the event of the window's first k-mer) never decrease and exactly one of them grows
+                // per band, so the FAST conditions
+                //   llk >= 0,  u >= 99  (the window's last k-mer has event u-99 >= 0)  -- become true once, and
+                //   llk + 99 < K-1,  u <= E-1                                           -- become false once;
+                // and while min(K-2 - (llk+99), E-1 - u) = s > 0 the next s bands are FAST whatever the moves are.
+                for (; b < n_bands && !(F.llk >= 0 && b - 2 - F.llk >= NP_ALN_BANDWIDTH - 1); ++b)
+                    band_step<true, true, false>(F, R, b, x0, x1, x0, x1);
+                window_state(F);
+                for (; R.nonpos;) {
+                    const int ks = (K - 2) - (F.llk + NP_ALN_BANDWIDTH - 1), es = (E - 1) - (b - 2 - F.llk);
+                    int stop = b + (ks < es ? ks : es);
+                    stop = stop < n_bands ? stop : n_bands;
+                    if (stop <= b) break;
+                    // two bands per iteration, the first one even: the doubles made of `left` become the next band's diagonal without
+                    // a register copy, the event offsets advance once, the trace store and the parity of Suzuki's tie rule are
+                    // compile-time properties of the position
+                    if (b & 1) { band_step<false, false, true>(F, R, b, x0, x1, x0, x1); ++b; }
+                    float y0, y1;
+                    for (; b + 1 < stop; b += 2) {
+                        band_step<false, false, true, 0>(F, R, b, x0, x1, y0, y1); band_step<false, false, true, 1>(F, R, b + 1, y0, y1, x0, x1);
+                        F.eo0 += 8; F.eo1 += 8;
+                    }
+                    for (; b < stop; ++b) band_step<false, false, true>(F, R, b, x0, x1, x0, x1);
+                }
+                for (; b < n_bands; ++b) band_step<true, true, false>(F, R, b, x0, x1, x0, x1);
+                if ((n_bands & 7) != 0) __builtin_amdgcn_raw_buffer_store_b32((int)(F.tacc << (4 * (8 - (n_bands & 7)))), R.tr, 4 * lane, ((n_bands - 1) >> 3) * 256, 0);   // last, partial group
+
+                best_u = F.best; curr_e = F.best_e;
+            } else {
+                best_u = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(a.fill_state[2 * ri]));
+                curr_e = __builtin_amdgcn_readfirstlane(a.fill_state[2 * ri + 1]);
             }
-            for (; b < n_bands; ++b) band_step<true, true, false>(F, R, b, x0, x1, x0, x1);
-            if ((n_bands & 7) != 0) __builtin_amdgcn_raw_buffer_store_b32((int)(F.tacc << (4 * (8 - (n_bands & 7)))), R.tr, 4 * lane, ((n_bands - 1) >> 3) * 256, 0);   // last, partial group
 
             // ---------------- backtrack (:326-361) + QC sums (:338-341) ----------------
-            const float best_u = F.best;
-            int curr_e = F.best_e;
             int curr_k = K - 1;
 
             // the trace was written by lanes 0..3 of this wave: complete the stores before other lanes read them back
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_s_waitcnt(0);
 
-            if (best_u != NP_NEG_INF && !(NP_ABL & 128)) {
+            if (MODE != 1 && best_u != NP_NEG_INF && !(NP_ABL & 128)) {
 #if NP_A_WALK_PRIO
-                __builtin_amdgcn_s_setprio(NP_A_WALK_PRIO);
+                if (MODE == 0) __builtin_amdgcn_s_setprio(NP_A_WALK_PRIO);
 #endif
+                if (MODE == 2) {            // on its own the walk competes with whatever the caller runs beside it: the caller's choice
+                    if (a.bt_prio >= 3) __builtin_amdgcn_s_setprio(3);
+                    else if (a.bt_prio == 2) __builtin_amdgcn_s_setprio(2);
+                    else if (a.bt_prio == 1) __builtin_amdgcn_s_setprio(1);
+                }
                 // Scalar walk.  The kernel is instruction-issue bound (~2.3 cycles per wave-instruction of any kind, measured
                 // with tools/align_variants.sh probes), and a walk of ~0.63 steps per band is a fifth of its instructions, so
                 // the step is written out by hand: 20 instructions.
@@ -691,12 +711,15 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
                     }
                 }
                 sum_emission = tot;
-#if NP_A_WALK_PRIO
                 __builtin_amdgcn_s_setprio(0);
-#endif
             }
         }
-        {
+        if (MODE == 1) {
+            // the read's end cell for the back-track launch (two lanes, two words; a read that was refused leaves -inf)
+            int32_t* dst = a.fill_state + 2 * ri + lane;
+            const int32_t val = lane == 0 ? __builtin_bit_cast(int32_t, best_u) : curr_e;
+            if (lane < 2) *dst = val;
+        } else {
             // QC (:365-372); out.back() is always k-mer K-1, so `spanned` reduces to "the walk ended on k-mer 0"
             bool failed = true;
             if (n_out > 0) {
@@ -787,8 +810,11 @@ hipError_t np_launch_align_order(int n_reads, const np_read_dev* reads, uint32_t
     return hipGetLastError();
 }
 
-hipError_t np_launch_event_align(const np_align_args& a, int n_blocks, hipStream_t s)
+// mode 0: fill + back-track; 1: fill only (a.trace_all, a.fill_state written); 2: back-track only (a.trace_all, a.fill_state read)
+hipError_t np_launch_event_align(const np_align_args& a, int n_blocks, int mode, hipStream_t s)
 {
-    hipLaunchKernelGGL(np_event_align_kernel, dim3(n_blocks), dim3(NP_ALIGN_BLOCK), 0, s, a);
+    if (mode == 0) hipLaunchKernelGGL(np_event_align_kernel<0>, dim3(n_blocks), dim3(NP_ALIGN_BLOCK), 0, s, a);
+    else if (mode == 1) hipLaunchKernelGGL(np_event_align_kernel<1>, dim3(n_blocks), dim3(NP_ALIGN_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL(np_event_align_kernel<2>, dim3(n_blocks), dim3(NP_ALIGN_BLOCK), 0, s, a);
     return hipGetLastError();
 }

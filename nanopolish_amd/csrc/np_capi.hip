@@ -15,7 +15,8 @@
 
 #define NP_VERSION_STR "nanopolish_amd 0.1 (gfx950)"
 #define NP_FLANK_LEN (1u << 20)
-#define NP_NUM_FAMILIES 7      // 0 event align, 1 forward HMM, 2 glue, 3 Viterbi, 4 event detection, 5 MoM scalings, 6 eventalign chain
+#define NP_NUM_FAMILIES 8      // 0 event align, 1 forward HMM, 2 glue, 3 Viterbi, 4 event detection, 5 MoM scalings, 6 eventalign chain,
+                               // 7 the event aligner's back-track when launched on its own (np_event_align_split_dev)
 
 namespace {
 
@@ -67,8 +68,9 @@ struct np_ctx {
     float* d_logsum = nullptr;
     std::vector<float> h_logsum;
     float* d_flank = nullptr;
-    uint32_t* d_counters = nullptr;   // [0..6] class counts, [8..15] work-queue heads, [16] align queue head, [32] self-test, [1024..] bins
+    uint32_t* d_counters = nullptr;   // [0..6] class counts, [8..15] work-queue heads, [16] align queue head, [17] chain queue head, [18] back-track queue head, [32] self-test, [1024..] bins
     dev_buf order, trace, kparams, align_order;
+    dev_buf trace_all, fill_state, kparams_bt, align_order_bt;    // np_event_align_split_dev: every read's trace and end cell; the back-track launch's own slab and order
     // host-API staging
     dev_buf b_jobs, b_reads, b_events, b_ranks, b_out, b_pair_off, b_pairs, b_pair_begin, b_n_pairs,
             b_vm, b_bp, b_cell_off, b_state_off, b_states, b_n_states;
@@ -83,6 +85,8 @@ struct np_ctx {
     std::mutex lock;
     std::string err;
     int align_blocks_per_cu = 8, hmm_blocks_per_cu = 2;
+    int align_bt_prio = 3, hmm_prio = 0;   // wave priorities of the back-track launch and of the forward kernels (co-scheduling experiments)
+    int align_bt_blocks_per_cu = 8;   // the back-track launch of np_event_align_split_dev (256-thread workgroups per CU)
     int align_lpt = 1;                // issue the event aligner's reads longest first
     int stream_switch_wait = 1;       // a call on a new stream waits for the tail of the stream the context used before (0: the caller orders its streams itself)
     int ed_warmup = -1;               // parallel peak walk: samples of warm-up per segment (< 0: the kernel's default)
@@ -174,7 +178,7 @@ int run_hmm_forward(np_ctx* c, hipStream_t s, int64_t n_jobs, const np_hmm_job_d
         np_hmm_args a{};
         a.jobs = jobs; a.order = c->order.as<uint32_t>() + (size_t)cls * (size_t)n_jobs; a.n_class_jobs = c->d_counters + cls;
         a.reads = reads; a.event_mean = event_mean; a.ranks = ranks; a.model = c->models[model].d_states;
-        a.logsum = c->d_logsum; a.flank = c->d_flank; a.counter = c->d_counters + 8 + cls; a.out = out;
+        a.logsum = c->d_logsum; a.flank = c->d_flank; a.counter = c->d_counters + 8 + cls; a.out = out; a.prio = c->hmm_prio;
         const int jobs_per_block = (np_hmm_block_threads(cls) / 64) * (64 / NP_CLASS_SEG[cls]);
         const int nb = persistent_blocks(c, n_jobs, jobs_per_block, c->hmm_blocks_per_cu);
         NP_HIP(c, np_launch_hmm_forward(cls, a, nb, c->lse_oor, s));
@@ -182,40 +186,56 @@ int run_hmm_forward(np_ctx* c, hipStream_t s, int64_t n_jobs, const np_hmm_job_d
     return NP_OK;
 }
 
+// phase 0: fill and back-track of a read in one kernel (trace scratch per resident wave).  phase 1 / 2: the fill / the back-track as
+// launches of their own, the packed trace of every read kept in between (total_pairs >= pair_off[n_reads]: 32 B per pair slot).
 int run_event_align(np_ctx* c, hipStream_t s, int n_reads, const np_read_dev* reads, const float* event_mean,
                     const uint16_t* ranks, int model, int64_t max_bands, const int64_t* pair_off, np_pair* pairs,
-                    int32_t* pair_begin, int32_t* n_pairs)
+                    int32_t* pair_begin, int32_t* n_pairs, int phase = 0, int64_t total_pairs = 0)
 {
     if (n_reads <= 0) return NP_OK;
     if (model < 0 || model >= (int)c->models.size()) { c->err = "bad model id"; return NP_ERR_INVALID; }
     const int waves_per_block = np_align_block_threads() / 64;
-    int nb = persistent_blocks(c, n_reads, waves_per_block, c->align_blocks_per_cu);
+    int nb = persistent_blocks(c, n_reads, waves_per_block, phase == 2 ? c->align_bt_blocks_per_cu : c->align_blocks_per_cu);
     // per-resident-wave scratch: packed trace (32 B per band) and the k-mer parameter slab (16 B per k-mer).
     // Ultra-long reads make the slabs large, so the persistent grid shrinks to keep the scratch under a budget
     // (a 1M-event read needs ~56 MB per wave: 48 GB would hold ~850 resident waves instead of 5120).
-    const uint64_t stride = (((uint64_t)max_bands + 7) / 8) * 32;        // u64 units: one 256-byte row per 8 bands
+    const uint64_t stride = phase == 0 ? (((uint64_t)max_bands + 7) / 8) * 32 : 0;        // u64 units: one 256-byte row per 8 bands
     const uint64_t kp_stride = ((uint64_t)max_bands + 63) & ~63ull;      // k-mers per read < bands per read
     const uint64_t per_block = (uint64_t)waves_per_block * (stride * sizeof(uint64_t) + kp_stride * sizeof(float4));
     const uint64_t budget = 48ull << 30;
     if ((uint64_t)nb * per_block > budget) nb = (int)std::max<uint64_t>(1, budget / per_block);
     c->last_align_blocks = nb; c->last_align_scratch = (int64_t)((uint64_t)nb * per_block);
-    NP_HIP(c, c->trace.reserve((size_t)nb * waves_per_block * stride * sizeof(uint64_t)));
-    NP_HIP(c, c->kparams.reserve((size_t)nb * waves_per_block * kp_stride * sizeof(float4)));
-    NP_HIP(c, c->align_order.reserve((size_t)(2048 + n_reads) * sizeof(uint32_t)));
-    NP_HIP(c, hipMemsetAsync(c->d_counters + 16, 0, sizeof(uint32_t), s));
+    if (phase == 0) NP_HIP(c, c->trace.reserve((size_t)nb * waves_per_block * stride * sizeof(uint64_t)));
+    else {
+        // every read's trace: read r starts at row (pair_off[r] >> 3) + r of 256 bytes
+        const size_t all = ((size_t)(total_pairs >> 3) + (size_t)n_reads + 1) * 256;
+        c->last_align_scratch += (int64_t)all;
+        if (phase == 2 && (c->trace_all.cap < all || c->fill_state.cap < (size_t)n_reads * 8)) { c->err = "np_event_align_split_dev: back-track phase without the fill phase of the same batch"; return NP_ERR_INVALID; }
+        NP_HIP(c, c->trace_all.reserve(all));
+        NP_HIP(c, c->fill_state.reserve((size_t)n_reads * 8));
+    }
+    // the fill and the back-track of a split call use separate slabs, queues and orders: the back-track of one batch may run beside
+    // the fill of the next one (another stream)
+    dev_buf& kparams = phase == 2 ? c->kparams_bt : c->kparams;
+    dev_buf& align_order = phase == 2 ? c->align_order_bt : c->align_order;
+    uint32_t* counter = c->d_counters + (phase == 2 ? 18 : 16);
+    NP_HIP(c, kparams.reserve((size_t)nb * waves_per_block * kp_stride * sizeof(float4)));
+    NP_HIP(c, align_order.reserve((size_t)(2048 + n_reads) * sizeof(uint32_t)));
+    NP_HIP(c, hipMemsetAsync(counter, 0, sizeof(uint32_t), s));
     np_align_args a{};
     a.reads = reads; a.event_mean = event_mean; a.ranks = ranks; a.model = c->models[model].d_states;
     a.pair_off = pair_off; a.pairs = pairs; a.pair_begin = pair_begin; a.n_pairs = n_pairs;
-    a.trace = c->trace.as<uint64_t>(); a.trace_stride = stride; a.kparams = c->kparams.as<float4>(); a.kp_stride = kp_stride;
-    a.counter = c->d_counters + 16;
+    a.trace = c->trace.as<uint64_t>(); a.trace_stride = stride; a.kparams = kparams.as<float4>(); a.kp_stride = kp_stride;
+    a.trace_all = c->trace_all.as<uint64_t>(); a.fill_state = c->fill_state.as<int32_t>(); a.bt_prio = c->align_bt_prio;
+    a.counter = counter;
     a.n_reads = n_reads; a.max_gap_threshold = c->params.max_gap_threshold;
     a.min_average_log_emission = c->params.min_average_log_emission;
-    family_timer tm(c, 0, s);
+    family_timer tm(c, phase == 2 ? 7 : 0, s);
     if (c->align_lpt && n_reads > nb * waves_per_block) {       // more reads than resident waves: the issue order matters
-        NP_HIP(c, np_launch_align_order(n_reads, reads, c->align_order.as<uint32_t>(), s));
-        a.order = c->align_order.as<uint32_t>() + 2048;
+        NP_HIP(c, np_launch_align_order(n_reads, reads, align_order.as<uint32_t>(), s));
+        a.order = align_order.as<uint32_t>() + 2048;
     }
-    NP_HIP(c, np_launch_event_align(a, nb, s));
+    NP_HIP(c, np_launch_event_align(a, nb, phase, s));
     return NP_OK;
 }
 
@@ -367,7 +387,7 @@ void np_destroy(np_ctx* c)
     if (c->d_logsum) (void)hipFree(c->d_logsum);
     if (c->d_flank) (void)hipFree(c->d_flank);
     if (c->d_counters) (void)hipFree(c->d_counters);
-    dev_buf* bufs[] = {&c->order, &c->trace, &c->kparams, &c->b_jobs, &c->b_reads, &c->b_events, &c->b_ranks, &c->b_out, &c->b_pair_off,
+    dev_buf* bufs[] = {&c->order, &c->trace, &c->kparams, &c->trace_all, &c->fill_state, &c->kparams_bt, &c->align_order_bt, &c->b_jobs, &c->b_reads, &c->b_events, &c->b_ranks, &c->b_out, &c->b_pair_off,
                        &c->b_pairs, &c->b_pair_begin, &c->b_n_pairs, &c->b_vm, &c->b_bp, &c->b_cell_off, &c->b_state_off,
                        &c->b_states, &c->b_n_states, &c->ed_status, &c->ed_tstat, &c->b_raw, &c->b_raw_off, &c->b_ev_off, &c->b_ev_start,
                        &c->b_ev_len, &c->b_ev_mean, &c->b_ev_stdv, &c->b_n_events, &c->cm_group_rank_off, &c->cm_cigar_scratch, &c->ea_bp, &c->ea_path, &c->ea_args, &c->align_order};
@@ -606,6 +626,23 @@ int np_event_align_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* 
     NP_HIP(c, hipSetDevice(c->device));
     return run_event_align(c, use_stream(c, stream), n_reads, reads, event_mean, kmer_rank, model, max_bands,
                            pair_off, pairs_out, pair_begin, n_pairs);
+}
+
+int np_event_align_split_dev(np_ctx* c, void* stream, int phase, int n_reads, const np_read_dev* reads, const float* event_mean,
+                             const uint16_t* kmer_rank, int model, int64_t max_bands, int64_t total_pairs, const int64_t* pair_off,
+                             np_pair* pairs_out, int32_t* pair_begin, int32_t* n_pairs)
+{
+    if (!c) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    if (phase < 1 || phase > 3 || total_pairs < 0) { c->err = "np_event_align_split_dev: phase is 1 (fill), 2 (back-track) or 3 (both)"; return NP_ERR_INVALID; }
+    NP_HIP(c, hipSetDevice(c->device));
+    stream_scope scope = use_stream(c, stream);
+    for (int ph = 1; ph <= 2; ++ph) {
+        if (!(phase & ph)) continue;
+        const int rc = run_event_align(c, scope.s, n_reads, reads, event_mean, kmer_rank, model, max_bands, pair_off, pairs_out, pair_begin, n_pairs, ph, total_pairs);
+        if (rc != NP_OK) return rc;
+    }
+    return NP_OK;
 }
 
 int np_hmm_score_dev(np_ctx* c, void* stream, int64_t n_jobs, const np_hmm_job_dev* jobs, const np_read_dev* reads,
@@ -1080,6 +1117,9 @@ int np_set_option(np_ctx* c, const char* name, int64_t value)
     std::lock_guard<std::mutex> g(c->lock);
     const std::string k(name);
     if (k == "align_blocks_per_cu") c->align_blocks_per_cu = (int)std::max<int64_t>(1, value);
+    else if (k == "align_bt_blocks_per_cu") c->align_bt_blocks_per_cu = (int)std::max<int64_t>(1, value);
+    else if (k == "align_bt_prio") c->align_bt_prio = (int)std::min<int64_t>(3, std::max<int64_t>(0, value));
+    else if (k == "hmm_prio") c->hmm_prio = (int)std::min<int64_t>(2, std::max<int64_t>(0, value));
     else if (k == "hmm_blocks_per_cu") c->hmm_blocks_per_cu = (int)std::max<int64_t>(1, value);
     else if (k == "align_lpt") c->align_lpt = value != 0;
     else if (k == "stream_switch_wait") c->stream_switch_wait = value != 0;

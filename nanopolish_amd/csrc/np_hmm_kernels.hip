@@ -47,6 +47,8 @@ template <int SEG, int C, int BLK, bool OOR>
 __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_args a)
 {
     __shared__ float tbl[NP_LOGSUM_TBL];          // the kernel's ONLY LDS object (np_lse_oor; checked at np_create)
+    if (a.prio >= 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
     for (int i = threadIdx.x; i < NP_LOGSUM_TBL; i += BLK) tbl[i] = np_lse_table_entry(a.logsum, i);
     __syncthreads();
     const __attribute__((address_space(3))) char* tbl3 = (const __attribute__((address_space(3))) char*)tbl;

@@ -21,6 +21,8 @@ struct np_hmm_args {
     np_hmm_state* states;          // output
     const int64_t* state_off;
     int32_t* n_states;
+    int prio;                      // forward kernel: wave priority (s_setprio 0..3) -- above 0 only when the caller co-schedules it with
+                                   // the event aligner's back-track launch, whose scalar chain would otherwise starve it
 };
 
 struct np_ea_args {
@@ -79,6 +81,9 @@ struct np_align_args {
     int32_t n_reads;
     int32_t max_gap_threshold;
     double min_average_log_emission;
+    uint64_t* trace_all;           // split launches (mode 1 / 2): the trace of EVERY read, read r from row (pair_off[r] >> 3) + r (256 B rows)
+    int32_t* fill_state;           // split launches: 2 words per read (bits of the best end-cell score, its event index)
+    int bt_prio;                   // back-track launch (mode 2): wave priority of the walk (the fused kernel's is NP_A_WALK_PRIO)
 };
 
 #define NP_NUM_CLASSES 7
@@ -92,7 +97,7 @@ hipError_t np_hmm_forward_lds_bytes(int cls, size_t* bytes);      // static LDS 
 hipError_t np_launch_probe(const float* logsum, const float* buf, uint16_t* sbuf, uint32_t* out, int n_blocks, hipStream_t s);
 hipError_t np_launch_hmm_viterbi(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s);
 hipError_t np_launch_hmm_backtrack(const np_hmm_args& a, int64_t n_jobs, hipStream_t s);
-hipError_t np_launch_event_align(const np_align_args& a, int n_blocks, hipStream_t s);
+hipError_t np_launch_event_align(const np_align_args& a, int n_blocks, int mode, hipStream_t s);
 hipError_t np_launch_align_order(int n_reads, const np_read_dev* reads, uint32_t* scratch /* 2048 + n_reads */, hipStream_t s);
 int np_align_block_threads(void);
 int np_hmm_block_threads(int cls);

@@ -318,3 +318,34 @@ def test_variant_screening_scores_match_oracle(ctx, orc, models):
             vg, vw = got[i + v * nr:i + (v + 1) * nr].astype(np.float64), want[i + v * nr:i + (v + 1) * nr].astype(np.float64)
             assert np.sum(vg - base_g) == np.sum(vw - base_w)
         i += nr * len(it["seqs"])
+
+
+def test_split_aligner_equals_the_fused_kernel(ctx, orc, models):
+    """np_event_align_split_dev (round 3): the banded fill and the back-track as two launches, every read's trace kept in HBM in
+    between, against np_event_align_dev on the same ragged batch (130 .. 6000 bases, more reads than resident waves would need for
+    the queue order to matter is covered by the bench's CRC; here: every read's pairs, pair_begin / n_pairs words, calibrations and
+    scores bit for bit, and three reads against the oracle).  Run twice: the kept trace of the previous pass must not leak."""
+    from nanopolish_amd.pipeline import build_host_batch, tile_host_batch, CallMethylationBatch
+    mn = orc.model(models["nucleotide"])
+    rng = np.random.default_rng(11)
+    Ls = [130, 150, 6000, 700] + [int(x) for x in rng.integers(200, 4000, 36)]
+    hb = build_host_batch(models, list(range(300, 300 + len(Ls))), L=Ls)
+    got = {}
+    for split in (False, True):
+        batch = CallMethylationBatch(ctx, tile_host_batch(hb, 3), "cuda:0", calibrate=True)
+        batch.split_align = split
+        batch.step(); batch.step()
+        batch.sync()
+        got[split] = dict(pairs=[batch.pairs_of(r) for r in range(batch.n_reads)], begin=batch.d_pair_begin.cpu().numpy().copy(),
+                          n=batch.d_n_pairs.cpu().numpy().copy(), scores=batch.scores().copy(), cal=batch.calibrated().copy())
+        del batch
+    a, b = got[False], got[True]
+    assert np.array_equal(a["begin"], b["begin"]) and np.array_equal(a["n"], b["n"]) and np.array_equal(a["cal"], b["cal"])
+    assert all(np.array_equal(x, y) for x, y in zip(a["pairs"], b["pairs"]))
+    assert np.array_equal(a["scores"], b["scores"], equal_nan=True)
+    assert (a["n"] > 0).sum() >= len(Ls)          # (not vacuous)
+    for i in (0, 2, 7):
+        rd = hb["reads"][i]
+        sh, sc = orc.estimate_scalings_mom(mn, rd["ranks"], rd["events"])
+        want = orc.event_align(mn, orc.scalings(sh, sc, 1.0), rd["events"], rd["ranks"])
+        assert np.array_equal(b["pairs"][i], want) and np.array_equal(b["pairs"][i + 2 * len(Ls)], want)
