@@ -123,12 +123,16 @@ void drain_timing(np_ctx* c)
 {
     for (int w = 0; w < NP_NUM_FAMILIES; ++w) {
         timing_t& t = c->timing[w];
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> later;
         for (auto& pr : t.pending) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { t.total_ms += ms; t.launches += 1; t.last_ms = ms; }
+            const hipError_t e = hipEventElapsedTime(&ms, pr.first, pr.second);
+            if (e == hipErrorNotReady) { later.push_back(pr); continue; }      // enqueued on a stream the caller has not synchronised: next time
+            if (e == hipSuccess) { t.total_ms += ms; t.launches += 1; t.last_ms = ms; }
             t.pool.push_back(pr.first); t.pool.push_back(pr.second);
         }
-        t.pending.clear();
+        if (!later.empty()) (void)hipGetLastError();
+        t.pending.swap(later);
     }
 }
 

@@ -16,6 +16,12 @@
 
 #define NP_HMM_BLOCK 512
 
+// timing experiments only (results WRONG with any bit set): 1 = emissions for free (the upper bound of what scoring a group's
+// methylated and unmethylated sequence in one pass could share), 2 = log-sums without the table look-up (max only)
+#ifndef NP_HMM_ABL
+#define NP_HMM_ABL 0
+#endif
+
 namespace {
 
 template <int C>
@@ -53,6 +59,9 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
     __syncthreads();
     const __attribute__((address_space(3))) char* tbl3 = (const __attribute__((address_space(3))) char*)tbl;
     auto NP_LSE = [&](float x, float y) -> float {
+#if NP_HMM_ABL & 2
+        return __builtin_fmaxf(x, y);
+#endif
         if constexpr (OOR) return np_lse_oor(x, y, tbl3);
         else return np_lse(x, y, tbl);
     };
@@ -144,7 +153,11 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     if (c >= cw) continue;                     // wave-uniform
+#if NP_HMM_ABL & 1
+                    const float em = x * g[c].cl;              // timing experiment only (scores WRONG): emissions for free
+#else
                     const float em = np_emission(x, g[c]);
+#endif
                     // PSR9_MATCH: HMT_FROM_SAME_M, PREV_M, SAME_B, PREV_B, PREV_K, SOFT (r9.inl:350-365)
                     float s = lp_mm_self + cur.M[c];
                     s = NP_LSE(s, lp_mm_next + lM_p);
