@@ -592,43 +592,51 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
                              asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p_) : "memory"); }
 #pragma unroll
                 for (int i = 0; i < NP_BT_DEPTH; ++i) NP_BT_LOAD(tq[i], cg - i);
-                int j = 0, from = 0, gap = 0;
+                int j = 0, gap = 0;
                 int k0 = curr_k, e0 = curr_e;          // position of the chunk's first step
                 int vfrom = 0;                         // lane j: the code of step j of the chunk
+                // Round 3: the step loop only leaves at the end of a trace group -- it tests neither "chunk full" nor "an index went
+                // negative" per step (14 scalar instructions per step instead of 21, one branch instead of three: the walk is bound
+                // by the CU's scalar-instruction throughput, profiles/r03_kernel_a_split.md).  A group is 8 bands and a step leaves at
+                // least one, so a chunk that enters a group with at most 56 codes cannot overflow its 64 lanes; and a walk that runs
+                // off the lattice inside a group (k or e below 0) only gathers a few garbage codes until the group ends: the flush
+                // keeps the steps whose position is on the lattice -- a prefix, both indices only decrease.
                 // up to 64 pairs: stored at descending addresses (their emissions are added up after the walk)
                 auto flush = [&]() {
-                    const bool valid = lane < j;
-                    const uint64_t mk = __builtin_amdgcn_ballot_w64(valid && vfrom != 1);          // FROM_D, FROM_L (2, 3): k drops
-                    const uint64_t me = __builtin_amdgcn_ballot_w64(valid && vfrom < 2);           // FROM_D, FROM_U: e drops
-                    if (valid) {
-                        np_pair p;
-                        p.ref_pos = k0 - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                        p.read_pos = e0 - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(me >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)me, 0u));
-                        pairs[cap - 1 - (n_out + lane)] = p;
+                    const bool in = lane < j;
+                    const uint64_t mk = __builtin_amdgcn_ballot_w64(in && vfrom != 1);          // FROM_D, FROM_L (2, 3): k drops
+                    const uint64_t me = __builtin_amdgcn_ballot_w64(in && vfrom < 2);           // FROM_D, FROM_U: e drops
+                    np_pair p;
+                    p.ref_pos = k0 - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                    p.read_pos = e0 - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(me >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)me, 0u));
+                    const bool valid = in && (p.ref_pos | p.read_pos) >= 0;
+                    const int jv = __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid));     // (the valid steps are steps 0 .. jv-1)
+                    if (valid) pairs[cap - 1 - (n_out + lane)] = p;
+                    if (jv > 0) {
+                        last_k = __builtin_amdgcn_readlane(p.ref_pos, jv - 1);                                   // the last recorded pair's k-mer
+                        // runs of FROM_L steps: ml has bit i set iff step i is FROM_L (the steps of the chunk are bits 0 .. jv-1)
+                        const uint64_t all = jv >= 64 ? ~0ull : ((1ull << jv) - 1ull);
+                        const uint64_t ml = all & ~me;
+                        const int lead = ml == all ? jv : __builtin_ctzll(~ml);                     // run that continues the previous chunk's
+                        int longest = 0;
+                        for (uint64_t m = ml; m != 0; m &= m << 1) longest++;                      // longest run inside the chunk
+                        longest = longest > gap + lead ? longest : gap + lead;
+                        max_gap = longest > max_gap ? longest : max_gap;
+                        // run still open at the chunk's end
+                        if (ml == all) gap += jv;
+                        else gap = __builtin_clzll(~(ml << (64 - jv)));                              // (bits below 64 - jv are set in the operand)
                     }
-                    // runs of FROM_L steps: ml has bit i set iff step i is FROM_L (the steps of the chunk are bits 0 .. j-1)
-                    const uint64_t all = j >= 64 ? ~0ull : ((1ull << j) - 1ull);
-                    const uint64_t ml = all & ~me;
-                    const int lead = ml == all ? j : __builtin_ctzll(~ml);                         // run that continues the previous chunk's
-                    int longest = 0;
-                    for (uint64_t m = ml; m != 0; m &= m << 1) longest++;                         // longest run inside the chunk
-                    longest = longest > gap + lead ? longest : gap + lead;
-                    max_gap = longest > max_gap ? longest : max_gap;
-                    // run still open at the chunk's end
-                    if (ml == all) gap += j;
-                    else gap = __builtin_clzll(~(ml << (64 - j)));                                 // (bits below 64 - j are set in the operand)
-                    n_out += j; j = 0; k0 = curr_k; e0 = curr_e;
+                    n_out += jv; j = 0; k0 = curr_k; e0 = curr_e;
                 };
                 int done = 0;
+                int nib = 8 * cg + 5 - (curr_k + curr_e);        // nibble of the current band inside its group's words, counted from the top
                 while (!done) {
 #pragma unroll
                     for (int pos = 0; pos < NP_BT_DEPTH; ++pos) {
                         asm volatile("s_waitcnt vmcnt(%[n])" : [t] "+v"(tq[pos]) : [n] "n"(NP_BT_DEPTH - 1) : "memory");
-                        // steps inside trace group cg: 8 cg + 7 - band = lb7 - (k + e) is the nibble index counted from the top of
-                        // the word (band 8 cg in bits 31..28), above 7 once the walk has left the group
-                        const int lb7 = 8 * cg + 5;
-                        for (;;) {
-                        int t_, nib_, c_, w_, m0s_;
+                        // steps inside trace group cg (band 8 cg in bits 31..28 of the lanes' words: nibble 7); the loop is entered with
+                        // nib 0 or 1 (the step that left the group above crossed one or two bands) and runs while nib <= 7
+                        int t_, c_, w_, m0s_, from_;
                         // (the step counter j lives in M0 inside the loop: v_writelane takes its lane select from M0, because a
                         //  second scalar register next to the data operand would exceed the constant-bus limit.  M0 is saved and
                         //  restored around the block -- two scalar moves per trace group -- instead of being declared clobbered:
@@ -636,10 +644,6 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
                         asm volatile("s_mov_b32 %[m0s], m0\n\t"
                                      "s_mov_b32 m0, %[j]\n\t"
                                      "1:\n\t"
-                                     "s_add_i32 %[t], %[k], %[e]\n\t"
-                                     "s_sub_i32 %[nib], %[lb7], %[t]\n\t"
-                                     "s_cmp_gt_i32 %[nib], 7\n\t"
-                                     "s_cbranch_scc1 2f\n\t"
                                      "s_and_b32 %[c], %[k], 1\n\t"                   // odd slot: bits 3..2 of the nibble
                                      "s_lshl1_add_u32 %[c], %[c], 0x20000\n\t"        // field width 2 | 2 * bit
                                      "s_lshl2_add_u32 %[c], %[nib], %[c]\n\t"         // + 4 * nibble
@@ -650,31 +654,25 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
                                      "s_add_i32 m0, m0, 1\n\t"
                                      "s_cmp_lg_u32 %[from], 1\n\t"
                                      "s_subb_u32 %[k], %[k], 0\n\t"                   // k -= (from != FROM_U)
-                                     "s_cmp_lt_u32 %[from], 2\n\t"
-                                     "s_subb_u32 %[e], %[e], 0\n\t"                   // e -= (from != FROM_L: patterns 2 and 3)
-                                     "s_cmp_eq_u32 m0, 64\n\t"
-                                     "s_cbranch_scc1 2f\n\t"
-                                     "s_or_b32 %[t], %[k], %[e]\n\t"
-                                     "s_cmp_ge_i32 %[t], 0\n\t"
+                                     "s_cmp_eq_u32 %[from], 0\n\t"
+                                     "s_addc_u32 %[nib], %[nib], 1\n\t"               // one band down, two on FROM_D (the only code that moves k AND e)
+                                     "s_cmp_le_i32 %[nib], 7\n\t"
                                      "s_cbranch_scc1 1b\n\t"
-                                     "2:\n\t"
                                      "s_mov_b32 %[j], m0\n\t"
                                      "s_mov_b32 m0, %[m0s]"
-                                     : [k] "+s"(curr_k), [e] "+s"(curr_e), [j] "+s"(j), [vf] "+v"(vfrom), [from] "+s"(from),
-                                       [t] "=&s"(t_), [nib] "=&s"(nib_), [c] "=&s"(c_), [w] "=&s"(w_), [m0s] "=&s"(m0s_)
-                                     : [wreg] "v"(tq[pos]), [lb7] "s"(lb7)
+                                     : [k] "+s"(curr_k), [nib] "+s"(nib), [j] "+s"(j), [vf] "+v"(vfrom),
+                                       [from] "=&s"(from_), [t] "=&s"(t_), [c] "=&s"(c_), [w] "=&s"(w_), [m0s] "=&s"(m0s_)
+                                     : [wreg] "v"(tq[pos])
                                      : "scc");
+                        curr_e = 8 * cg + 5 - nib - curr_k;                                // band = k + e + 2
                         done = (curr_k | curr_e) >> 31;                                 // -1 once either index is negative
-                        if (j == 64 || done) flush();
-                        if (done || lb7 - (curr_e + curr_k) > 7) break;                    // (else: a chunk boundary inside the group)
-                        }
+                        if (j > 56 || done) flush();
                         if (done) break;
+                        nib -= 8;
                         NP_BT_LOAD(tq[pos], cg - NP_BT_DEPTH);
                         cg -= 1;
                     }
                 }
-                // the last recorded pair's k-mer: the position before the last step
-                last_k = curr_k + (from != 1 ? 1 : 0);
 #undef NP_BT_LOAD
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
