@@ -72,6 +72,10 @@ const char* np_ctx_info(const np_ctx* ctx);
 
 /* Tuning / test knobs (defaults are what bench.py measures): "align_blocks_per_cu", "hmm_blocks_per_cu" (persistent grid
  * sizes), "align_lpt" (1: the event aligner takes the batch's reads longest first; 0: in index order),
+ * "cm_async" (1: np_cm_build_jobs_*_dev launch their kernels on a side stream of the context, ordered after what the caller's stream
+ * holds at the time of the call; np_event_align*_dev / np_detect_events_dev / np_mom_fill_dev / np_adc_to_pa_dev that follow run BESIDE
+ * them -- work items do not depend on the alignment -- and the first other entry point, or np_sync, waits for them.  A caller's OWN
+ * kernels on its stream do not: leave it 0 unless the library's entry points are the only consumers of the work items),
  * "stream_switch_wait" (1: a call on another stream than the context's previous call waits for that stream's tail; 0: the caller orders
  * the streams it uses with one context by its own events), "ed_warmup" (samples each segment of the parallel peak walk starts early; 0 forces every segment through the
  * repair path -- results never depend on it), "ea_rows_cap" (events per eventalign segment the chain kernel's scratch holds;
@@ -467,7 +471,8 @@ int np_sync(np_ctx* ctx, void* stream);
 /* Time (ms) spent in the most recent launch of each kernel family on the device, measured with HIP events
  * on the launching stream.  which: 0 = event align, 1 = hmm score, 2 = resolve / calibrate / work items, 3 = hmm viterbi,
  * 4 = event detection, 5 = MoM scalings, 6 = eventalign chain, 7 = the event aligner's back-track as its own launch
- * (np_event_align_split_dev phase 2; then family 0 is the fill alone). */
+ * (np_event_align_split_dev phase 2; then family 0 is the fill alone), 8 = work items built on the side stream (option "cm_async":
+ * the interval overlaps the event aligner's; without the option they are part of family 2). */
 int np_last_kernel_ms(np_ctx* ctx, int which, float* ms);
 /* Accumulated device time (ms) and launch count of a kernel family since the last reset (call after np_sync). */
 int np_kernel_time(np_ctx* ctx, int which, double* total_ms, int64_t* launches, int reset);

@@ -15,8 +15,9 @@
 
 #define NP_VERSION_STR "nanopolish_amd 0.1 (gfx950)"
 #define NP_FLANK_LEN (1u << 20)
-#define NP_NUM_FAMILIES 8      // 0 event align, 1 forward HMM, 2 glue, 3 Viterbi, 4 event detection, 5 MoM scalings, 6 eventalign chain,
-                               // 7 the event aligner's back-track when launched on its own (np_event_align_split_dev)
+#define NP_NUM_FAMILIES 9      // 0 event align, 1 forward HMM, 2 glue, 3 Viterbi, 4 event detection, 5 MoM scalings, 6 eventalign chain,
+                               // 7 the event aligner's back-track when launched on its own (np_event_align_split_dev), 8 work items built on the side
+                               // stream (cm_async: the interval runs beside the event aligner; in order, they are part of family 2)
 
 namespace {
 
@@ -85,6 +86,11 @@ struct np_ctx {
     std::mutex lock;
     std::string err;
     int align_blocks_per_cu = 8, hmm_blocks_per_cu = 2;
+    // work items built beside the event aligner (option "cm_async"): np_cm_build_jobs_*_dev launch on the context's side stream, forked
+    // from the caller's stream and joined by the next entry point that is not one of the aligner-side calls (np_event_align*_dev,
+    // np_detect_events_dev, np_mom_fill_dev, np_adc_to_pa_dev), or by np_sync
+    hipStream_t side = nullptr; hipEvent_t side_fork = nullptr, side_join = nullptr;
+    bool cm_async = false, side_pending = false;
     int align_bt_prio = 3, hmm_prio = 0;   // wave priorities of the back-track launch and of the forward kernels (co-scheduling experiments)
     int align_bt_blocks_per_cu = 8;   // the back-track launch of np_event_align_split_dev (256-thread workgroups per CU)
     int align_lpt = 1;                // issue the event aligner's reads longest first
@@ -151,12 +157,35 @@ struct stream_scope {
     operator hipStream_t() const { return s; }
     ~stream_scope() { c->tail_recorded = c->switch_ev && hipEventRecord(c->switch_ev, s) == hipSuccess; }
 };
-stream_scope use_stream(np_ctx* c, void* s)
+stream_scope use_stream(np_ctx* c, void* s, bool join_side = true)
 {
     hipStream_t st = pick_stream(c, s);
+    if (join_side && c->side_pending) { (void)hipStreamWaitEvent(st, c->side_join, 0); c->side_pending = false; }
     if (c->stream_switch_wait && c->tail_recorded && st != c->last_stream) (void)hipStreamWaitEvent(st, c->switch_ev, 0);
     c->last_stream = st;
     return stream_scope(c, st);
+}
+
+// the stream the work-item builders launch on: the caller's, or (cm_async) the side stream, ordered after what the caller's stream holds
+hipStream_t fork_side(np_ctx* c, hipStream_t s)
+{
+    if (!c->cm_async) return s;
+    if (!c->side) {
+        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->side = nullptr; (void)hipGetLastError(); return s; }
+        if (hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->side_join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipStreamDestroy(c->side); c->side = nullptr; (void)hipGetLastError(); return s;
+        }
+    }
+    if (c->side_pending) { (void)hipStreamWaitEvent(s, c->side_join, 0); c->side_pending = false; }   // (a second build before any consumer)
+    (void)hipEventRecord(c->side_fork, s);
+    (void)hipStreamWaitEvent(c->side, c->side_fork, 0);
+    return c->side;
+}
+void join_side_later(np_ctx* c, hipStream_t launched_on, hipStream_t s)
+{
+    if (launched_on == s) return;
+    c->side_pending = hipEventRecord(c->side_join, launched_on) == hipSuccess;
+    if (!c->side_pending) (void)hipStreamSynchronize(launched_on);
 }
 
 int persistent_blocks(np_ctx* c, int64_t work_items, int per_block, int blocks_per_cu)
@@ -391,6 +420,7 @@ void np_destroy(np_ctx* c)
     if (c->d_logsum) (void)hipFree(c->d_logsum);
     if (c->d_flank) (void)hipFree(c->d_flank);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->side_fork); (void)hipEventDestroy(c->side_join); }
     dev_buf* bufs[] = {&c->order, &c->trace, &c->kparams, &c->trace_all, &c->fill_state, &c->kparams_bt, &c->align_order_bt, &c->b_jobs, &c->b_reads, &c->b_events, &c->b_ranks, &c->b_out, &c->b_pair_off,
                        &c->b_pairs, &c->b_pair_begin, &c->b_n_pairs, &c->b_vm, &c->b_bp, &c->b_cell_off, &c->b_state_off,
                        &c->b_states, &c->b_n_states, &c->ed_status, &c->ed_tstat, &c->b_raw, &c->b_raw_off, &c->b_ev_off, &c->b_ev_start,
@@ -594,6 +624,7 @@ int np_sync(np_ctx* c, void* stream)
     if (!c) return NP_ERR_INVALID;
     NP_HIP(c, hipStreamSynchronize(pick_stream(c, stream)));
     std::lock_guard<std::mutex> g(c->lock);          // (other threads may be enqueueing: the timers' event lists are shared)
+    if (c->side_pending) { NP_HIP(c, hipEventSynchronize(c->side_join)); c->side_pending = false; }   // work items built on the side stream
     drain_timing(c);
     return NP_OK;
 }
@@ -628,7 +659,7 @@ int np_event_align_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* 
     if (!c) return NP_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    return run_event_align(c, use_stream(c, stream), n_reads, reads, event_mean, kmer_rank, model, max_bands,
+    return run_event_align(c, use_stream(c, stream, false), n_reads, reads, event_mean, kmer_rank, model, max_bands,
                            pair_off, pairs_out, pair_begin, n_pairs);
 }
 
@@ -640,7 +671,7 @@ int np_event_align_split_dev(np_ctx* c, void* stream, int phase, int n_reads, co
     std::lock_guard<std::mutex> g(c->lock);
     if (phase < 1 || phase > 3 || total_pairs < 0) { c->err = "np_event_align_split_dev: phase is 1 (fill), 2 (back-track) or 3 (both)"; return NP_ERR_INVALID; }
     NP_HIP(c, hipSetDevice(c->device));
-    stream_scope scope = use_stream(c, stream);
+    stream_scope scope = use_stream(c, stream, false);
     for (int ph = 1; ph <= 2; ++ph) {
         if (!(phase & ph)) continue;
         const int rc = run_event_align(c, scope.s, n_reads, reads, event_mean, kmer_rank, model, max_bands, pair_off, pairs_out, pair_begin, n_pairs, ph, total_pairs);
@@ -664,7 +695,7 @@ int np_adc_to_pa_dev(np_ctx* c, void* stream, int n_reads, const int16_t* adc, c
     if (!c || n_reads < 0 || (n_reads > 0 && (!adc || !raw_off || !offset || !raw_unit || !raw_pa))) return NP_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
+    stream_scope scope = use_stream(c, stream, false); hipStream_t s = scope.s;
     family_timer tm(c, 4, s);
     NP_HIP(c, np_launch_adc_to_pa(n_reads, adc, raw_off, max_samples, offset, raw_unit, raw_pa, s));
     return NP_OK;
@@ -983,9 +1014,13 @@ int np_cm_build_jobs_identity_dev(np_ctx* c, void* stream, int n_reads, const ch
     NP_HIP(c, hipSetDevice(c->device));
     stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
     NP_HIP(c, c->cm_group_rank_off.reserve((size_t)total_group_slots * sizeof(int64_t)));
-    family_timer tm(c, 2, s);
-    NP_HIP(c, np_launch_cm_build_jobs(n_reads, ref_seq, seq_off, read_rc, alphabet, (int)k, min_separation, min_flank, group_off, rank_off, jobs,
-                                      kpos, job_ranks, first_site, last_site, n_motif, c->cm_group_rank_off.as<int64_t>(), n_groups, s));
+    const hipStream_t ls = fork_side(c, s);
+    {
+        family_timer tm(c, ls == s ? 2 : 8, ls);
+        NP_HIP(c, np_launch_cm_build_jobs(n_reads, ref_seq, seq_off, read_rc, alphabet, (int)k, min_separation, min_flank, group_off, rank_off, jobs,
+                                          kpos, job_ranks, first_site, last_site, n_motif, c->cm_group_rank_off.as<int64_t>(), n_groups, ls));
+    }
+    join_side_later(c, ls, s);
     return NP_OK;
 }
 
@@ -1011,10 +1046,14 @@ int np_cm_build_jobs_cigar_dev(np_ctx* c, void* stream, int n_reads, const char*
     int32_t* op_read = op_ref + n_idx;
     int32_t* cig_reads = op_read + n_idx;                      // 16 B per read
     int32_t* group_kpos = cig_reads + 4 * (size_t)n_reads;
-    family_timer tm(c, 2, s);
-    NP_HIP(c, np_launch_cm_build_jobs_cigar(n_reads, genome, ref_begin, ref_len, cigar, cigar_off, read_len, read_rc, alphabet, (int)k,
-                                            min_separation, min_flank, group_off, rank_off, jobs, kpos, job_ranks, first_site, last_site, n_motif,
-                                            c->cm_group_rank_off.as<int64_t>(), n_groups, deg_kpos, op_ref, op_read, cig_reads, group_kpos, s));
+    const hipStream_t ls = fork_side(c, s);
+    {
+        family_timer tm(c, ls == s ? 2 : 8, ls);
+        NP_HIP(c, np_launch_cm_build_jobs_cigar(n_reads, genome, ref_begin, ref_len, cigar, cigar_off, read_len, read_rc, alphabet, (int)k,
+                                                min_separation, min_flank, group_off, rank_off, jobs, kpos, job_ranks, first_site, last_site, n_motif,
+                                                c->cm_group_rank_off.as<int64_t>(), n_groups, deg_kpos, op_ref, op_read, cig_reads, group_kpos, ls));
+    }
+    join_side_later(c, ls, s);
     return NP_OK;
 }
 
@@ -1122,6 +1161,7 @@ int np_set_option(np_ctx* c, const char* name, int64_t value)
     const std::string k(name);
     if (k == "align_blocks_per_cu") c->align_blocks_per_cu = (int)std::max<int64_t>(1, value);
     else if (k == "align_bt_blocks_per_cu") c->align_bt_blocks_per_cu = (int)std::max<int64_t>(1, value);
+    else if (k == "cm_async") c->cm_async = value != 0;
     else if (k == "align_bt_prio") c->align_bt_prio = (int)std::min<int64_t>(3, std::max<int64_t>(0, value));
     else if (k == "hmm_prio") c->hmm_prio = (int)std::min<int64_t>(2, std::max<int64_t>(0, value));
     else if (k == "hmm_blocks_per_cu") c->hmm_blocks_per_cu = (int)std::max<int64_t>(1, value);
@@ -1174,7 +1214,7 @@ int np_detect_events_dev(np_ctx* c, void* stream, int n_reads, const float* raw,
     if (n_reads == 0) return NP_OK;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    return detect_events_locked(c, use_stream(c, stream), n_reads, raw, raw_off, max_samples, params, tstat, 0, event_off, max_events,
+    return detect_events_locked(c, use_stream(c, stream, false), n_reads, raw, raw_off, max_samples, params, tstat, 0, event_off, max_events,
                                 event_start, event_length, event_mean, event_stdv, n_events);
 }
 
@@ -1244,7 +1284,7 @@ int np_mom_fill_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* reads, np
     if (n_reads == 0) return NP_OK;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
+    stream_scope scope = use_stream(c, stream, false); hipStream_t s = scope.s;
     family_timer tm(c, 5, s);
     NP_HIP(c, np_launch_mom_fill(n_reads, reads, reads_b, event_mean, n_events, kmer_rank, c->models[model].d_states, s));
     return NP_OK;

@@ -45,7 +45,7 @@ def run(pool=1000, tile=50, read_len=5450, steps=3, warmup=1, cpu_sample=-1, ctx
     for _ in range(warmup):
         batch.step()
     ctx.sync(); torch.cuda.synchronize()
-    for w in range(7):
+    for w in range(9):
         ctx.kernel_time(w, reset=True)
     t0 = time.perf_counter()
     for _ in range(steps):
