@@ -4,7 +4,7 @@
     pmc_summary_r03.py gpurun_out/<tag>
 
 Per kernel family (event_align = np_event_align_kernel, hmm_forward = every size class of np_hmm_forward_kernel, chain =
-np_eventalign_chain_kernel): counter totals per launch, instructions per unit of work (band / HMM call and cell-state / segment and
+np_eventalign_chain2_kernel, or np_eventalign_chain_kernel with ea_kernel = 1): counter totals per launch, instructions per unit of work (band / HMM call and cell-state / segment and
 lattice cell; the units come from tools/pmc_workload.py's own JSON line), VALUBusy, and HBM bytes per unit.
 Units of the counters (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (x4 = cycles);
 SQ_BUSY_CYCLES is summed over the shader engines; GRBM_GUI_ACTIVE is summed over the 8 XCDs in the csv.
@@ -20,7 +20,7 @@ from collections import defaultdict
 
 root = sys.argv[1]
 FETCH_CORR, WRITE_CORR, N_SIMD = 2.0, 1.0, 1024
-FAM = (("event_align", "np_event_align_kernel"), ("hmm_forward", "np_hmm_forward_kernel"), ("chain", "np_eventalign_chain_kernel"),
+FAM = (("event_align", "np_event_align_kernel"), ("hmm_forward", "np_hmm_forward_kernel"), ("chain", "np_eventalign_chain"),
        ("recalibrate", "np_recalibrate_kernel"), ("build_map", "np_build_map_kernel"), ("cm_items", "np_cm_items_kernel"))
 units = {}
 try:
