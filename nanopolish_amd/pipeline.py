@@ -353,7 +353,7 @@ class CallMethylationBatch:
     def step(self, stage=0):
         """One pass.  stage 0: everything.  Stages for callers that pipeline batches over streams (set self.stream before each):
         1: work items + (event detection +) event alignment;  2: calibration, window bounds and scoring (the aligner is bound by
-        vector issue and uses no LDS, the scorer by LDS lookup latency);
+        vector issue and uses no LDS, the scorer by vector issue too, its LDS look-ups the largest part);
         11 / 12 / 13 (round 3, PipelinedPass): 11 = (event detection +) the aligner's FILL only (np_event_align_split_dev phase 1),
         12 = work items + the aligner's back-track + calibration and window bounds, 13 = scoring only."""
         L, h = self.ctx.L, self.ctx.h
@@ -554,7 +554,7 @@ class PipelinedPass:
     """The call-methylation pass software-pipelined over two HIP streams (round 3).
 
     The event aligner's fill is bound by vector-instruction issue and keeps every wave slot busy; its back-track is a dependent scalar
-    chain that holds a wave slot and issues little; the scoring kernels are bound by LDS look-ups at 4 waves per SIMD.  Run one after
+    chain that holds a wave slot and issues scalar instructions only; the scoring kernels run at 4 waves per SIMD around their LDS look-ups.  Run one after
     the other (CallMethylationBatch.step) each leaves the others' resource idle.  Here the aligner's two halves are separate launches
     (np_event_align_split_dev, the trace of every read kept in HBM) and a step is spread over two streams:
 
