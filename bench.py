@@ -331,8 +331,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    cores = len(os.sched_getaffinity(0))
-    workers = args.workers if args.workers > 0 else max(1, min(32, cores // max(1, world)))
+    from nanopolish_amd.hostinfo import usable_cores
+    cores = usable_cores()[2]                  # affinity mask capped by the cgroup CPU quota (16 on the pool's boxes, whatever nproc says)
+    workers = args.workers if args.workers > 0 else max(1, min(32, (2 * cores) // max(1, world)))
 
     # ---- host preparation (before the HIP runtime is initialised: the pool forks) ----
     from nanopolish_amd.shard import shard_read_ids
