@@ -233,4 +233,13 @@ PY
 done
 }
 
+# call 25: soak against the reference itself -- indel / clipped records through the whole chain, both chain kernels
+call_u() {
+O=$R/gpurun_out/r03u; mkdir -p $O; cd $R
+for cfg in "1 2" "2 2" "3 1"; do set -- $cfg
+timeout 900 python tests/gpu_soak.py --reads 1500 --seed $1 --ea-kernel $2 >> $O/soak.jsonl 2>> $O/soak.err; echo "rc=$?"
+done
+cat $O/soak.jsonl; tail -3 $O/soak.err
+}
+
 "call_$1"
