@@ -349,3 +349,34 @@ def test_split_aligner_equals_the_fused_kernel(ctx, orc, models):
         sh, sc = orc.estimate_scalings_mom(mn, rd["ranks"], rd["events"])
         want = orc.event_align(mn, orc.scalings(sh, sc, 1.0), rd["events"], rd["ranks"])
         assert np.array_equal(b["pairs"][i], want) and np.array_equal(b["pairs"][i + 2 * len(Ls)], want)
+
+
+def test_pipelined_pass_over_two_streams_equals_the_in_order_pass(orc, models):
+    """PipelinedPass (round 3): the aligner's fill on one stream, its back-track + work items + calibration behind it, the scoring of the
+    previous step on a second stream, two batch objects on two contexts ordered by events.  Slower than the in-order pass on every
+    schedule measured (profiles/r03_kernel_a_split.md) and kept as a tested option: five steps through the pipeline must leave both
+    batch objects with exactly the in-order pass's pairs and scores."""
+    from nanopolish_amd.api import Context
+    from nanopolish_amd.pipeline import build_host_batch, tile_host_batch, CallMethylationBatch, PipelinedPass
+    hb = build_host_batch(models, list(range(600, 640)), L=[700 + 90 * i for i in range(40)], with_jobs=False)
+    thb = tile_host_batch(hb, 2)
+    ctxs = []
+    try:
+        for _ in range(3):
+            c = Context(0); c.register_model(models["nucleotide"], "nucleotide"); c.register_model(models["cpg"], "cpg")
+            ctxs.append(c)
+        ref = CallMethylationBatch(ctxs[2], thb, "cuda:0", calibrate=True, jobs_on_device=True)
+        ref.step(); ref.step()
+        want_scores = ref.scores().copy(); want_pairs = [ref.pairs_of(r) for r in range(ref.n_reads)]
+        pp = PipelinedPass(lambda i: CallMethylationBatch(ctxs[i], thb, "cuda:0", calibrate=True, jobs_on_device=True))
+        for _ in range(5):
+            pp.step()
+        pp.flush()
+        for b in pp.batches:
+            assert np.array_equal(b.scores(), want_scores, equal_nan=True)
+            assert all(np.array_equal(b.pairs_of(r), want_pairs[r]) for r in range(b.n_reads))
+        assert np.isfinite(want_scores).sum() > 2000
+        del pp, ref
+    finally:
+        for c in ctxs:
+            c.close()
