@@ -572,8 +572,8 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
                     else if (a.bt_prio == 1) __builtin_amdgcn_s_setprio(1);
                 }
                 // Scalar walk.  The kernel is instruction-issue bound (~2.3 cycles per wave-instruction of any kind, measured
-                // with tools/align_variants.sh probes), and a walk of ~0.63 steps per band is a fifth of its instructions, so
-                // the step is written out by hand: 20 instructions.
+                // with tools/align_variants.sh probes), and a walk of ~0.63 steps per band was a fifth of its instructions, so
+                // the step is written out by hand: 14 instructions since round 3 (12 scalar + v_readlane + v_writelane; 21 before).
                 //   * A step reads the 2 bits of its cell out of the lane that owns the k-mer's ring slot (v_readlane) and
                 //     parks it in lane j of a vector register (v_writelane): nothing else is recorded.  When 64 codes have
                 //     gathered, each lane rebuilds ITS pair from the chunk's start position and the population counts, below
