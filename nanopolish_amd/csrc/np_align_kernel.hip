@@ -48,7 +48,11 @@
 #define NP_ALIGN_BLOCK 256
 #define NP_RING 128
 #ifndef NP_BT_DEPTH
-#define NP_BT_DEPTH 8     // back-track: trace groups (8 bands each) requested ahead of the walk
+#define NP_BT_DEPTH 8     // back-track: trace groups (8 bands each) requested ahead of the walk.  Re-measured with round 3's shorter step:
+                          // 4 -> 41.2 ms, 8 -> 40.8 ms per 32768 reads.  NOT more than the register budget holds: the queue's loads are
+                          // issued and awaited by hand (asm), which is only sound while every queue entry stays in the register the asm
+                          // wrote -- at 12 the compiler spills queue entries (it may copy an asm output right away: the load has not
+                          // landed) and the kernel faults
 #endif
 #ifndef NP_A_WAVES
 #define NP_A_WAVES 8      // resident waves per SIMD the register budget is set for
