@@ -26,8 +26,10 @@ o.append("# Round 3 -- end-of-round measurement set (MI355X, 1 GPU)\n")
 o.append("Collected through gpurun with `bash profiles/collect_r03_final.sh %s` (GPU tests, the default bench line with its folded eventalign and "
          "variants legs, the from-raw line, the CPU plumbing line, the 2-rank gloo rehearsal, the reference-side batched binding, kernel traces); "
          "counters from `bash profiles/collect_r03_pmc.sh` (`r03_pmc.json`).  Raw outputs live under `gpurun_out/` (scratch); this file is "
-         "`profiles/make_r03_summary.py %s`.  Experiments of the round: `r03_kernel_a_split.md` (kernel A's back-track as its own launch, the "
-         "pipelined pass), the chain-kernel log and the kernel-B ablations at the end of this file.\n" % (TAG, TAG))
+         "`profiles/make_r03_summary.py %s`.  Beside it: `r03_kernel_a_split.md` (kernel A's back-track as its own launch, the pipelined pass, the "
+         "14-instruction walk step), `r03_soak.md` (4 500 indel records against the reference itself), `r03_rccl_probe.md`, `r03_pmc.json` "
+         "(+ `r03_pmc_mid_round.json`, before the walk's trim and with the one-read chain kernel); the chain-kernel log, the kernel-B ablations and the "
+         "dropped experiments are at the end of this file.\n" % (TAG, TAG))
 pl = os.path.join(A, "pytest.log")
 if os.path.exists(pl):
     ps = [l for l in open(pl).read().splitlines() if " passed" in l or " failed" in l]
