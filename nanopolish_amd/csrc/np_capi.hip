@@ -69,7 +69,7 @@ struct np_ctx {
     float* d_logsum = nullptr;
     std::vector<float> h_logsum;
     float* d_flank = nullptr;
-    uint32_t* d_counters = nullptr;   // [0..6] class counts, [8..15] work-queue heads, [16] align queue head, [17] chain queue head, [18] back-track queue head, [32] self-test, [1024..] bins
+    uint32_t* d_counters = nullptr;   // [0..7] class counts, [8..15] work-queue heads, [16] align queue head, [17] chain queue head, [18] back-track queue head, [32] self-test, [1024..] bins
     dev_buf order, trace, kparams, align_order;
     dev_buf trace_all, fill_state, kparams_bt, align_order_bt;    // np_event_align_split_dev: every read's trace and end cell; the back-track launch's own slab and order
     // host-API staging

@@ -260,12 +260,13 @@ __device__ __forceinline__ int size_class(uint32_t n)
 {
     if (n == 0) return -1;
     if (n <= 16) return 0;
-    if (n <= 32) return 1;
-    if (n <= 64) return 2;
-    if (n <= 128) return 3;
-    if (n <= 256) return 4;
-    if (n <= 512) return 5;
-    if (n <= 1024) return 6;
+    if (n <= 24) return 1;
+    if (n <= 32) return 2;
+    if (n <= 64) return 3;
+    if (n <= 128) return 4;
+    if (n <= 256) return 5;
+    if (n <= 512) return 6;
+    if (n <= 1024) return 7;
     return -1;
 }
 
@@ -282,10 +283,10 @@ __device__ __forceinline__ int job_bin(const np_hmm_job_dev& jb, uint32_t flank_
     const uint32_t e = (jb.e_stop > jb.e_start ? jb.e_stop - jb.e_start : jb.e_start - jb.e_stop) + 1u;
     const int cls = (e <= flank_len && !(jb.flags & NP_JOB_SKIP)) ? size_class(jb.n_kmers) : -1;
     if (cls < 0) return -1;
-    const uint32_t shift = 2u + (uint32_t)(cls < 3 ? cls : 3);            // bucket width 4, 8, 16, 32 events
+    const uint32_t shift = cls < 2 ? 2u : (cls < 5 ? (uint32_t)(cls + 1) : 5u);   // bucket width 4, 4, 8, 16, 32, 32 ... events
     const uint32_t bucket = (e >> shift) < (NP_EBUCKETS - 1) ? (e >> shift) : (NP_EBUCKETS - 1);
     // blocks per lane the item needs: ceil(n / SEG), in units of the class' C / 8 (C = 8: 1..8; C = 16: pairs)
-    const int seg = (2 << cls) < 64 ? (2 << cls) : 64, cu = (cls == NP_NUM_CLASSES - 1 ? 16 : 8) / NP_CPL;   // NP_CLASS_SEG / NP_CLASS_C
+    const int seg = cls == 0 ? 2 : (cls == 1 ? 3 : ((1 << cls) < 64 ? (1 << cls) : 64)), cu = (cls == NP_NUM_CLASSES - 1 ? 16 : 8) / NP_CPL;   // NP_CLASS_SEG / NP_CLASS_C
     const int cpl = ((int)jb.n_kmers + seg - 1) / seg;
     const int cg = (cpl + cu - 1) / cu;                                     // 1..8
     // descending blocks per lane, then descending event count, inside a class

@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
         if (pack >= n_packs) break;
 
         const uint32_t slot = pack * JPW + seg;
-        const bool has = slot < n_jobs;
+        const bool has = seg < JPW && slot < n_jobs;          // (SEG = 3: lane 63 belongs to no segment)
         const uint32_t jidx = has ? a.order[slot] : 0u;
         const np_hmm_job_dev job = a.jobs[jidx];
         const np_read_dev* rd = a.reads + job.read;
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(NP_HMM_BLOCK) np_hmm_viterbi_kernel(np_hmm_arg
         if (pack >= n_packs) break;
 
         const uint32_t slot = pack * JPW + seg;
-        const bool has = slot < n_jobs;
+        const bool has = seg < JPW && slot < n_jobs;          // (SEG = 3: lane 63 belongs to no segment)
         const uint32_t jidx = has ? a.order[slot] : 0u;
         const np_hmm_job_dev job = a.jobs[jidx];
         const np_read_dev* rd = a.reads + job.read;
@@ -457,12 +457,13 @@ hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, bo
 {
     switch (cls) {
         case 0: return launch_fwd<2, 8>(a, n_blocks, lse_oor, s);
-        case 1: return launch_fwd<4, 8>(a, n_blocks, lse_oor, s);
-        case 2: return launch_fwd<8, 8>(a, n_blocks, lse_oor, s);
-        case 3: return launch_fwd<16, 8>(a, n_blocks, lse_oor, s);
-        case 4: return launch_fwd<32, 8>(a, n_blocks, lse_oor, s);
-        case 5: return launch_fwd<64, 8>(a, n_blocks, lse_oor, s);
-        case 6: return launch_fwd<64, 16>(a, n_blocks, lse_oor, s);
+        case 1: return launch_fwd<3, 8>(a, n_blocks, lse_oor, s);
+        case 2: return launch_fwd<4, 8>(a, n_blocks, lse_oor, s);
+        case 3: return launch_fwd<8, 8>(a, n_blocks, lse_oor, s);
+        case 4: return launch_fwd<16, 8>(a, n_blocks, lse_oor, s);
+        case 5: return launch_fwd<32, 8>(a, n_blocks, lse_oor, s);
+        case 6: return launch_fwd<64, 8>(a, n_blocks, lse_oor, s);
+        case 7: return launch_fwd<64, 16>(a, n_blocks, lse_oor, s);
     }
     return hipErrorInvalidValue;
 }
@@ -487,12 +488,13 @@ hipError_t np_hmm_forward_lds_bytes(int cls, size_t* bytes)
 {
     switch (cls) {
         case 0: return fwd_lds_bytes<2, 8>(bytes);
-        case 1: return fwd_lds_bytes<4, 8>(bytes);
-        case 2: return fwd_lds_bytes<8, 8>(bytes);
-        case 3: return fwd_lds_bytes<16, 8>(bytes);
-        case 4: return fwd_lds_bytes<32, 8>(bytes);
-        case 5: return fwd_lds_bytes<64, 8>(bytes);
-        case 6: return fwd_lds_bytes<64, 16>(bytes);
+        case 1: return fwd_lds_bytes<3, 8>(bytes);
+        case 2: return fwd_lds_bytes<4, 8>(bytes);
+        case 3: return fwd_lds_bytes<8, 8>(bytes);
+        case 4: return fwd_lds_bytes<16, 8>(bytes);
+        case 5: return fwd_lds_bytes<32, 8>(bytes);
+        case 6: return fwd_lds_bytes<64, 8>(bytes);
+        case 7: return fwd_lds_bytes<64, 16>(bytes);
     }
     return hipErrorInvalidValue;
 }
@@ -501,12 +503,13 @@ hipError_t np_launch_hmm_viterbi(int cls, const np_hmm_args& a, int n_blocks, hi
 {
     switch (cls) {
         case 0: return launch_vit<2, 8>(a, n_blocks, s);
-        case 1: return launch_vit<4, 8>(a, n_blocks, s);
-        case 2: return launch_vit<8, 8>(a, n_blocks, s);
-        case 3: return launch_vit<16, 8>(a, n_blocks, s);
-        case 4: return launch_vit<32, 8>(a, n_blocks, s);
-        case 5: return launch_vit<64, 8>(a, n_blocks, s);
-        case 6: return launch_vit<64, 16>(a, n_blocks, s);
+        case 1: return launch_vit<3, 8>(a, n_blocks, s);
+        case 2: return launch_vit<4, 8>(a, n_blocks, s);
+        case 3: return launch_vit<8, 8>(a, n_blocks, s);
+        case 4: return launch_vit<16, 8>(a, n_blocks, s);
+        case 5: return launch_vit<32, 8>(a, n_blocks, s);
+        case 6: return launch_vit<64, 8>(a, n_blocks, s);
+        case 7: return launch_vit<64, 16>(a, n_blocks, s);
     }
     return hipErrorInvalidValue;
 }

@@ -86,10 +86,12 @@ struct np_align_args {
     int bt_prio;                   // back-track launch (mode 2): wave priority of the walk (the fused kernel's is NP_A_WALK_PRIO)
 };
 
-#define NP_NUM_CLASSES 7
-// size classes of the HMM kernels: (lanes per job, k-mer blocks per lane)
-static const int NP_CLASS_SEG[NP_NUM_CLASSES] = {2, 4, 8, 16, 32, 64, 64};
-static const int NP_CLASS_C[NP_NUM_CLASSES] = {8, 8, 8, 8, 8, 8, 16};
+#define NP_NUM_CLASSES 8
+// size classes of the HMM kernels: (lanes per job, k-mer blocks per lane), by the item's k-mers: <= 16, 24, 32, 64, 128, 256, 512, 1024.
+// The three-lane class (round 3) is for 17..24 k-mers -- the variants shape (17) and the two-site methylation windows: 21 items per
+// wave on 63 lanes, 6..8 blocks per lane and a skew of two steps, where four lanes carry 5..6 blocks (20..24 slots) and three steps.
+static const int NP_CLASS_SEG[NP_NUM_CLASSES] = {2, 3, 4, 8, 16, 32, 64, 64};
+static const int NP_CLASS_C[NP_NUM_CLASSES] = {8, 8, 8, 8, 8, 8, 8, 16};
 
 hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, bool lse_oor, hipStream_t s);
 hipError_t np_hmm_forward_lds_bytes(int cls, size_t* bytes);      // static LDS of the class's clamp-free instantiation

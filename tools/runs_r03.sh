@@ -242,4 +242,18 @@ done
 cat $O/soak.jsonl; tail -3 $O/soak.err
 }
 
+# call 31: three-lane size class of the forward kernel -- all GPU tests, then the default line with its legs
+call_v() {
+O=$R/gpurun_out/r03v; mkdir -p $O; cd $R
+timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -4 > $O/pytest.log; cat $O/pytest.log
+timeout 900 python bench.py --steps 4 --warmup 1 --cpu-sample 64 --streamed 0 --ragged 0 --legs 1 > $O/bench.json 2> $O/bench.err
+python3 - <<PY
+import json
+d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"], d["roofline"]["kernel_ms_per_step"], d["max_abs_dLLR_vs_cpu"])
+print("ea", d["value_eventalign"], "var", d["value_variants"], d["variants"]["ms_per_step"], d["variants"]["cpu_baseline"])
+PY
+tail -2 $O/bench.err
+}
+
 "call_$1"
