@@ -69,7 +69,7 @@ struct np_ctx {
     float* d_logsum = nullptr;
     std::vector<float> h_logsum;
     float* d_flank = nullptr;
-    uint32_t* d_counters = nullptr;   // [0..7] class counts, [8..15] work-queue heads, [16] align queue head, [17] chain queue head, [18] back-track queue head, [32] self-test, [1024..] bins
+    uint32_t* d_counters = nullptr;   // [0..7] class counts, [8..15] work-queue heads, [16] align queue head, [17] chain queue head, [18] back-track queue head, [32] self-test, [1024 .. 1024 + 2 * 4096) work-item bins (np_launch_classify)
     dev_buf order, trace, kparams, align_order;
     dev_buf trace_all, fill_state, kparams_bt, align_order_bt;    // np_event_align_split_dev: every read's trace and end cell; the back-track launch's own slab and order
     // host-API staging
@@ -397,10 +397,10 @@ np_ctx* np_create(int device, const np_params* params)
     c->h_logsum = tbl;
     ok = ok && hipMalloc((void**)&c->d_logsum, tbl.size() * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_flank, flank.size() * sizeof(float)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&c->d_counters, 8192 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_counters, 16384 * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemcpy(c->d_logsum, tbl.data(), tbl.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(c->d_flank, flank.data(), flank.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemset(c->d_counters, 0, 8192 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(c->d_counters, 0, 16384 * sizeof(uint32_t)) == hipSuccess;
     if (!ok) {
         if (g_create_err.empty()) g_create_err = "np_create: device allocation failed";
         np_destroy(c);

@@ -274,7 +274,7 @@ __device__ __forceinline__ int size_class(uint32_t n)
 // then need the same number of blocks per lane (the forward kernel runs every lane for the wave's maximum) and have
 // nearly the same number of rows (no padding steps); inside a class the widest and longest packs are issued first.
 // Counting sort in three small kernels: histogram -> exclusive scan -> scatter.
-#define NP_EBUCKETS 32
+#define NP_EBUCKETS 64
 #define NP_CPL 8                 // blocks-per-lane groups inside a class (ceil(n / SEG) scaled to 1..8)
 #define NP_NBINS (NP_NUM_CLASSES * NP_CPL * NP_EBUCKETS)
 
@@ -283,7 +283,10 @@ __device__ __forceinline__ int job_bin(const np_hmm_job_dev& jb, uint32_t flank_
     const uint32_t e = (jb.e_stop > jb.e_start ? jb.e_stop - jb.e_start : jb.e_start - jb.e_stop) + 1u;
     const int cls = (e <= flank_len && !(jb.flags & NP_JOB_SKIP)) ? size_class(jb.n_kmers) : -1;
     if (cls < 0) return -1;
-    const uint32_t shift = cls < 2 ? 2u : (cls < 5 ? (uint32_t)(cls + 1) : 5u);   // bucket width 4, 4, 8, 16, 32, 32 ... events
+    // bucket width 1, 1, 2, 4, 8, 16, 16, 16 events (round 3: the two smallest classes -- three quarters of the methylation items and all of
+    // the variants shape -- are sorted by their EXACT event count: a pack runs for its longest item, and buckets of four events cost
+    // those classes 5 % of their steps)
+    const uint32_t shift = cls < 2 ? 0u : (cls < 6 ? (uint32_t)(cls - 1) : 4u);
     const uint32_t bucket = (e >> shift) < (NP_EBUCKETS - 1) ? (e >> shift) : (NP_EBUCKETS - 1);
     // blocks per lane the item needs: ceil(n / SEG), in units of the class' C / 8 (C = 8: 1..8; C = 16: pairs)
     const int seg = cls == 0 ? 2 : (cls == 1 ? 3 : ((1 << cls) < 64 ? (1 << cls) : 64)), cu = (cls == NP_NUM_CLASSES - 1 ? 16 : 8) / NP_CPL;   // NP_CLASS_SEG / NP_CLASS_C

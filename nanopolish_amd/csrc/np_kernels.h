@@ -107,7 +107,7 @@ int np_vit_block_threads(void);
 
 // glue kernels
 hipError_t np_launch_classify(const np_hmm_job_dev* jobs, int64_t n_jobs, uint32_t* class_count /*[7]*/,
-                              uint32_t* order /*[7][n_jobs]*/, float* out_scores, uint32_t flank_len, uint32_t* bins /*[2*7*64]*/, hipStream_t s);
+                              uint32_t* order /*[NP_NUM_CLASSES][n_jobs]*/, float* out_scores, uint32_t flank_len, uint32_t* bins /*[2 * 8 * 8 * 64]*/, hipStream_t s);
 hipError_t np_launch_build_map(int n_reads, np_read_dev* reads, const int64_t* pair_off, const np_pair* pairs,
                                const int32_t* pair_begin, const int32_t* n_pairs, int32_t* map_start, int32_t* map_stop,
                                double* events_per_base, double indel_bias, hipStream_t s);
