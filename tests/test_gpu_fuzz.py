@@ -96,7 +96,7 @@ def test_hmm_score_and_align_fuzz(ctx, orc, models):
     S = orc.scalings(rd["shift"], rd["scale"], rd["var"])
     jobs, want, vjobs, vwant = [], [], [], []
     for t in range(600):
-        n = int(rng.choice([6, 7, 15, 16, 17, 31, 33, 64, 65, 129, 300])) if t % 3 == 0 else int(rng.integers(6, 120))
+        n = int(rng.choice([6, 7, 15, 16, 17, 18, 23, 24, 25, 31, 32, 33, 64, 65, 129, 300])) if t % 3 == 0 else int(rng.integers(6, 120))
         e = int(rng.integers(2, 600)) if t % 5 == 0 else int(rng.integers(2, 3 * n + 12))
         e = min(e, E - 2)
         e1 = int(rng.integers(0, E - e))
