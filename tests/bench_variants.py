@@ -145,7 +145,7 @@ def run(draft=10000, reads=250, tile=8, stride=1, indel_bias=0.9, steps=3, warmu
     roof = dict(bound="hbm", kernel="np_hmm_forward_kernel", achieved=round(algo / (hmm_ms * 1e-3) / 1e9, 2) if hmm_ms > 0 else 0.0, peak=8000.0,
                 unit="GB/s", frac=round(algo / (hmm_ms * 1e-3) / 1e9 / 8000.0, 5) if hmm_ms > 0 else 0.0, traffic=None, algo_bytes_per_launch=algo,
                 avg_launch_ms=round(hmm_ms, 3), cell_states_per_s=round(cells / (hmm_ms * 1e-3) / 1e9, 2) if hmm_ms > 0 else 0.0,
-                limiter="vector-instruction issue; the bit-exact p7_FLogsum look-ups (6 vector instructions + one LDS gather each, ~8 per cell) are half of the kernel; nothing but events, ranks and scores touches HBM")
+                limiter="at 4 waves per SIMD the step is balanced between vector-instruction issue and the latency of its dependent p7_FLogsum look-up chains (bit-exact: 6 vector instructions + one LDS gather each, ~8 per cell); nothing but events, ranks and scores touches HBM")
     out = dict(metric="variants screening profile_hmm_score calls/sec", roofline=roof, value=round(scored * args.steps / dt, 1), unit="calls/s", n_gpus=1,
                steps=args.steps, ms_per_step=round(1e3 * dt / args.steps, 3), calls_per_step=scored, items_per_step=NJ,
                hmm_kernel_ms_per_step=round(hmm_ms, 3),
