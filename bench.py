@@ -210,23 +210,24 @@ def cpu_baseline(models, hb, calibrate, from_raw, budget_reads):
     return out, cb
 
 
-def ragged_parity(models, hb, batch, calibrate, from_raw, n_sample=48):
-    """Pairs and LLRs of a sample of the RAGGED batch against the CPU pass (VERDICT r2: the ragged leg was only checked for
-    `reads_aligned_ok`): the longest and the shortest reads of the batch and a spread between them."""
-    lens = np.array([len(q) for q in hb["ref_seqs"]])
-    order = np.argsort(lens)
-    pick = sorted(set(order[-4:].tolist() + order[:4].tolist() + order[np.linspace(0, len(order) - 1, n_sample).astype(int)].tolist()))
-    _, _, cores = usable_cores()
-    cb = cpu_pass(models, hb, pick, [max(1, min(cores, len(pick)))], calibrate, from_raw, repeats=1)
+def compare_with_cpu(batch, cb, idx, from_raw):
+    """GPU results of reads `idx` of `batch` against the CPU pass `cb` over the same reads (cpu_pass keeps idx's order): detected
+    event counts (from raw), aligned pairs bit for bit, and the LLR of every group the CPU scored."""
     pairs, pair_off, n_pairs = cb["pairs"]
     ok = True
     if from_raw:
-        ok &= np.array_equal(batch.d_n_events.cpu().numpy()[pick], np.array(cb["n_events"]))
-    for q, i in enumerate(pick):
-        ok &= np.array_equal(batch.pairs_of(i), pairs[pair_off[q]:pair_off[q] + n_pairs[q]])
+        ok &= np.array_equal(batch.d_n_events.cpu().numpy()[idx], np.array(cb["n_events"]))
+    bad_reads = 0
+    for q, i in enumerate(idx):
+        same = np.array_equal(batch.pairs_of(i), pairs[pair_off[q]:pair_off[q] + n_pairs[q]])
+        bad_reads += 0 if same else 1
+    ok &= bad_reads == 0
     gmap = {}
-    for q, i in enumerate(pick):
-        f, nm, su, sm = batch.groups_of(i)
+    if list(idx) == list(range(len(idx))):
+        per_read = batch.groups_bulk(len(idx))
+    else:
+        per_read = (batch.groups_of(i) for i in idx)
+    for q, (f, nm, su, sm) in enumerate(per_read):
         for j in range(len(f)):
             gmap[(q, int(f[j]))] = (float(su[j]), float(sm[j]))
     want = cb["scores"]
@@ -237,8 +238,33 @@ def ragged_parity(models, hb, batch, calibrate, from_raw, n_sample=48):
             missing += 1
             continue
         d.append((g[1] - g[0]) - (float(want[2 * j + 1]) - float(want[2 * j])))
-    return dict(reads=len(pick), read_len_min=int(lens[pick].min()), read_len_max=int(lens[pick].max()), pairs_bit_exact=bool(ok),
-                groups=len(cb["first"]), groups_missing_on_gpu=missing, max_abs_dLLR=float(np.max(np.abs(d))) if d else None)
+    return dict(reads=len(idx), reads_pairs_compared=len(idx), reads_pairs_differ=bad_reads, groups=len(cb["first"]),
+                groups_scored_on_gpu=sum(1 for v in gmap.values() if np.isfinite(v[0])), groups_missing_on_gpu=missing,
+                pairs_bit_exact=bool(ok), max_abs_dLLR=float(np.max(np.abs(d))) if d else None)
+
+
+def ragged_parity(models, hb, batch, calibrate, from_raw, n_sample=48):
+    """Pairs and LLRs of a sample of the RAGGED batch against the CPU pass (VERDICT r2: the ragged leg was only checked for
+    `reads_aligned_ok`): the longest and the shortest reads of the batch and a spread between them."""
+    lens = np.array([len(q) for q in hb["ref_seqs"]])
+    order = np.argsort(lens)
+    pick = sorted(set(order[-4:].tolist() + order[:4].tolist() + order[np.linspace(0, len(order) - 1, n_sample).astype(int)].tolist()))
+    _, _, cores = usable_cores()
+    cb = cpu_pass(models, hb, pick, [max(1, min(cores, len(pick)))], calibrate, from_raw, repeats=1)
+    out = compare_with_cpu(batch, cb, pick, from_raw)
+    out.update(read_len_min=int(lens[pick].min()), read_len_max=int(lens[pick].max()))
+    return out
+
+
+def rank_sample_parity(models, hb, batch, calibrate, from_raw, rank, threads, n_sample=32):
+    """N > 1: every rank checks a sample of ITS OWN shard against the CPU pass (a rank that computed garbage must not hide behind
+    rank 0's check): n_sample reads spread over the shard, on this rank's share of the host cores."""
+    n = len(hb["reads"])
+    pick = sorted(set(np.linspace(0, n - 1, min(n, n_sample)).astype(int).tolist()))
+    cb = cpu_pass(models, hb, pick, [max(1, threads)], calibrate, from_raw, repeats=1)
+    out = compare_with_cpu(batch, cb, pick, from_raw)
+    out["rank"] = rank
+    return out
 
 
 # ---- N > 1 without a launcher ---------------------------------------------------------------------------------------------
@@ -360,11 +386,21 @@ def main():
         raise SystemExit("--gpus %d but only %d device(s) visible (NP_BENCH_BACKEND=gloo rehearses the N>1 path on fewer)" % (world, ndev))
     local = local % ndev
     torch.cuda.set_device(local)
+    class stdout_to_stderr:
+        """gloo announces every new process group on STDOUT ("[Gloo] Rank 0 is connected to ..."); the line rank 0 prints must stay the
+        only thing there: file descriptor 1 points at stderr while a group is being created"""
+        def __enter__(self):
+            sys.stdout.flush(); self.saved = os.dup(1); os.dup2(2, 1)
+        def __exit__(self, *a):
+            sys.stdout.flush(); os.dup2(self.saved, 1); os.close(self.saved)
+
     if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
+        with stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(backend)
+                dist.barrier()                     # (gloo connects lazily: make it talk now)
 
     from nanopolish_amd.api import Context
     from nanopolish_amd.pipeline import tile_host_batch, CallMethylationBatch, StreamedFeed
@@ -489,35 +525,34 @@ def main():
             batch.band_cells = int((100 * bands).sum()); batch.total_events = int(nev.sum())
         res.update(algo=batch.algo_bytes_align, band_cells=batch.band_cells, total_events=batch.total_events)
 
+    # ---------------- parity + CPU baseline (outside every timed region) ----------------
+    # N = 1: rank 0 times the CPU pass and compares its reads with the GPU's.  N > 1: EVERY rank first checks a
+    # 32-read sample of its own shard against the CPU pass on its share of the host cores; the mismatch counts are summed over the
+    # ranks and each rank's verdict lands in per_rank.  Then rank 0 runs the same cpu_baseline + pairs / LLR check as at N = 1 while
+    # the other ranks wait on a SOCKET barrier (a gloo group: an RCCL barrier would keep N - 1 host threads spinning on the very
+    # cores the baseline is timed on).
     cpu = None
     max_dllr = None
-    if rank == 0 and args.cpu_sample != 0 and world == 1:
+    rank_check = None
+    host_group = None
+    if world > 1:
+        with stdout_to_stderr():
+            host_group = dist.new_group(backend="gloo") if backend == "nccl" else dist.group.WORLD
+            dist.barrier(group=host_group)
+
+    def host_barrier():
+        if world > 1:
+            dist.barrier(group=host_group)
+
+    if world > 1 and args.cpu_sample != 0:
+        rank_check = rank_sample_parity(models, hb, batch, bool(args.calibrate), bool(args.from_raw), rank, max(1, cores // world))
+        host_barrier()
+    if rank == 0 and args.cpu_sample != 0:
         budget = args.cpu_sample if args.cpu_sample > 0 else 1 << 30
         cpu, cb = cpu_baseline(models, hb, bool(args.calibrate), bool(args.from_raw), budget)
         # parity of the GPU results with the CPU pass on that sample: pairs bit-exact, LLR within 1e-4
-        pairs, pair_off, n_pairs = cb["pairs"]
-        ok = True
-        if args.from_raw:
-            ok &= np.array_equal(batch.d_n_events[:cb["n"]].cpu().numpy(), np.array(cb["n_events"]))
-        for i in range(cb["n"]):                      # every sampled read, pair for pair
-            ok &= np.array_equal(batch.pairs_of(i), pairs[pair_off[i]:pair_off[i] + n_pairs[i]])
-        gmap = {}
-        for i, (f, nm, su, sm) in enumerate(batch.groups_bulk(cb["n"])):
-            for q in range(len(f)):
-                gmap[(i, int(f[q]))] = (float(su[q]), float(sm[q]))
-        want = cb["scores"]
-        d = []
-        missing = 0
-        for q, key in enumerate(cb["first"]):
-            g = gmap.get(key)
-            if g is None or not np.isfinite(g[0]):
-                missing += 1
-                continue
-            d.append((g[1] - g[0]) - (float(want[2 * q + 1]) - float(want[2 * q])))
-        max_dllr = float(np.max(np.abs(d))) if d else None
-        n_gpu_groups = sum(1 for v in gmap.values() if np.isfinite(v[0]))
-        cpu["check"] = dict(reads=cb["n"], reads_pairs_compared=cb["n"], groups=len(cb["first"]), groups_scored_on_gpu=n_gpu_groups,
-                            groups_missing_on_gpu=missing, pairs_bit_exact=bool(ok), max_abs_dLLR=max_dllr)
+        cpu["check"] = compare_with_cpu(batch, cb, list(range(cb["n"])), bool(args.from_raw))
+        max_dllr = cpu["check"]["max_abs_dLLR"]
         if args.from_raw and args.calibrate:
             # the same sample through the reference's WHOLE per-read function: SquiggleRead(sequence, Fast5Data) -> load_from_raw
             # -> calculate_methylation_for_read, compiled in place (oracle/_ref/libnp_ref_full.so), OpenMP over reads
@@ -532,6 +567,7 @@ def main():
                                                  sites_per_read_match_gpu=bool(np.array_equal(sites, np.array(n_gpu))))
             except Exception as e:  # noqa: BLE001
                 cpu["whole_function"] = dict(error=repr(e))
+    host_barrier()
 
     # ---------------- ragged read lengths (resident) ----------------
     ragged = None
@@ -547,8 +583,9 @@ def main():
         lens = np.array([len(q) for q in hb_rag["ref_seqs"]])
         nev_r = rb.total_events if not args.from_raw else int(rb.d_n_events.clamp(min=0).sum().item())
         rag_check = None
-        if rank == 0 and args.cpu_sample != 0 and world == 1:
+        if rank == 0 and args.cpu_sample != 0:
             rag_check = ragged_parity(models, hb_rag, rb, bool(args.calibrate), bool(args.from_raw))
+        host_barrier()
         ragged = dict(value=round(world * rb.n_reads * args.steps / dtr, 2), ms_per_step=round(dtr / args.steps * 1e3, 3), check=rag_check,
                       reads_per_step_per_gpu=rb.n_reads, distinct_reads_per_gpu=hb_rag["n"],
                       read_len=dict(mean=round(float(lens.mean()), 1), p50=int(np.median(lens)), min=int(lens.min()), max=int(lens.max())),
@@ -563,6 +600,10 @@ def main():
     # K steps, its host-fed rate, its host preparation time and what the final table + all-reduce cost it
     mine = [float(rank), n_reads * args.steps / t_steps, (streamed or {}).get("value_rank", 0.0), t_prep, t_reduce * 1e3, dt_rank * 1e3,
             k_ms["event_align"][0] / max(args.steps, 1), k_ms["hmm_score"][0] / max(args.steps, 1)]
+    rc_ = rank_check or {}
+    dl = rc_.get("max_abs_dLLR")
+    mine += [float(rc_.get("reads", 0)), float(rc_.get("reads_pairs_differ", 0)), float(rc_.get("groups", 0)),
+             float(rc_.get("groups_missing_on_gpu", 0)), float(dl) if dl is not None else -1.0]
     gathered = [mine]
     if world > 1:
         t = torch.tensor(mine, dtype=torch.float64, device="cuda")
@@ -574,7 +615,17 @@ def main():
         gathered = [x.cpu().tolist() for x in lst]
     per_rank = [dict(rank=int(g[0]), value=round(g[1], 1), value_streamed=round(g[2], 1) if g[2] else None, host_prep_s=round(g[3], 1),
                      table_and_allreduce_ms=round(g[4], 3), timed_region_ms=round(g[5], 3), event_align_ms_per_step=round(g[6], 3),
-                     hmm_score_ms_per_step=round(g[7], 3)) for g in gathered]
+                     hmm_score_ms_per_step=round(g[7], 3),
+                     check=dict(reads=int(g[8]), reads_pairs_differ=int(g[9]), groups=int(g[10]), groups_missing_on_gpu=int(g[11]),
+                                max_abs_dLLR=(g[12] if g[12] >= 0 else None)) if g[8] else None) for g in gathered]
+    shard_check = None
+    if world > 1 and any(pr["check"] for pr in per_rank):
+        cks = [pr["check"] for pr in per_rank if pr["check"]]
+        dls = [c["max_abs_dLLR"] for c in cks if c["max_abs_dLLR"] is not None]
+        shard_check = dict(ranks_checked=len(cks), reads=sum(c["reads"] for c in cks), reads_pairs_differ=sum(c["reads_pairs_differ"] for c in cks),
+                           groups=sum(c["groups"] for c in cks), groups_missing_on_gpu=sum(c["groups_missing_on_gpu"] for c in cks),
+                           max_abs_dLLR=max(dls) if dls else None,
+                           what="every rank: 32 reads of its own shard, GPU pairs and LLRs against the CPU pass")
 
     # ---------------- BASELINE.json configs[2] and configs[3], folded into the line (one GPU, rank 0) ----------------
     legs = None
@@ -659,6 +710,8 @@ def main():
                    value_ragged=ragged["value"] if ragged else None, ragged=ragged,
                    max_abs_dLLR_vs_cpu=max_dllr, roofline=roof, cpu_baseline=cpu, host_prep_s=round(t_prep, 1))
         out["per_rank"] = per_rank
+        if shard_check:
+            out["shard_check"] = shard_check
         if legs:
             out.update(legs)
         if table is not None:

@@ -80,7 +80,9 @@ const char* np_ctx_info(const np_ctx* ctx);
  * the streams it uses with one context by its own events), "ed_warmup" (samples each segment of the parallel peak walk starts early; 0 forces every segment through the
  * repair path -- results never depend on it), "ea_rows_cap" (events per eventalign segment the chain kernel's scratch holds;
  * a longer segment ends its read with NP_EA_OVERFLOW), "ea_waves_per_cu" (persistent grid of the chain kernel), "lse_oor" (0: the forward kernel clamps its log-sum table index;
- * 1: it relies on the LDS out-of-range rule, the default when np_create's probe passes -- scores never depend on it). */
+ * 1: it relies on the LDS out-of-range rule, the default when np_create's probe passes -- scores never depend on it),
+ * "hmm_kernel" (forward kernel of the four smallest size classes: 1 = a lane's k-mer blocks one after the other, the default; 2 = the
+ * log-sums of a step issued stage by stage across the blocks, round 4's experiment -- scores never depend on it). */
 int np_set_option(np_ctx* ctx, const char* name, int64_t value);
 /* Read-only facts about the context (-1: unknown name): "align_blocks" / "align_scratch_bytes" (persistent grid and per-wave scratch
  * of the most recent event-align launch: the grid shrinks under a 48 GB scratch budget when a batch holds ultra-long reads),

@@ -71,6 +71,10 @@ struct np_ctx {
     float* d_flank = nullptr;
     uint32_t* d_counters = nullptr;   // [0..7] class counts, [8..15] work-queue heads, [16] align queue head, [17] chain queue head, [18] back-track queue head, [32] self-test, [1024 .. 1024 + 2 * 4096) work-item bins (np_launch_classify)
     dev_buf order, trace, kparams, align_order;
+    dev_buf gslab;                    // staged forward kernel: the resident waves' scaled Gaussians (8 KB per wave)
+    int hmm_kernel = 1;               // forward kernel: 1 = block-major step (the default), 2 = stage-major step (np_hmm_forward2_kernel, round 4's
+                                      // experiment: six look-ups in flight per wave, same scores, measured 13 % slower -- np_hmm_kernels.hip;
+                                      // the clamp-free log-sum only: a context whose probe failed scores with kernel 1)
     dev_buf trace_all, fill_state, kparams_bt, align_order_bt;    // np_event_align_split_dev: every read's trace and end cell; the back-track launch's own slab and order
     // host-API staging
     dev_buf b_jobs, b_reads, b_events, b_ranks, b_out, b_pair_off, b_pairs, b_pair_begin, b_n_pairs,
@@ -212,9 +216,16 @@ int run_hmm_forward(np_ctx* c, hipStream_t s, int64_t n_jobs, const np_hmm_job_d
         a.jobs = jobs; a.order = c->order.as<uint32_t>() + (size_t)cls * (size_t)n_jobs; a.n_class_jobs = c->d_counters + cls;
         a.reads = reads; a.event_mean = event_mean; a.ranks = ranks; a.model = c->models[model].d_states;
         a.logsum = c->d_logsum; a.flank = c->d_flank; a.counter = c->d_counters + 8 + cls; a.out = out; a.prio = c->hmm_prio;
-        const int jobs_per_block = (np_hmm_block_threads(cls) / 64) * (64 / NP_CLASS_SEG[cls]);
+        const bool staged = c->hmm_kernel == 2 && c->lse_oor && np_hmm_forward2_has(cls);
+        const int threads = staged ? np_hmm_forward2_block_threads() : np_hmm_block_threads(cls);
+        const int jobs_per_block = (threads / 64) * (64 / NP_CLASS_SEG[cls]);
         const int nb = persistent_blocks(c, n_jobs, jobs_per_block, c->hmm_blocks_per_cu);
-        NP_HIP(c, np_launch_hmm_forward(cls, a, nb, c->lse_oor, s));
+        if (staged) {
+            NP_HIP(c, c->gslab.reserve((size_t)c->n_cu * c->hmm_blocks_per_cu * (threads / 64) * 8 * 64 * sizeof(float4)));
+            a.gslab = c->gslab.as<float4>();
+            NP_HIP(c, np_launch_hmm_forward2(cls, a, nb, s));
+        } else
+            NP_HIP(c, np_launch_hmm_forward(cls, a, nb, c->lse_oor, s));
     }
     return NP_OK;
 }
@@ -303,6 +314,7 @@ static bool probe_hardware(np_ctx* c)
     for (int cls = 0; cls < NP_NUM_CLASSES; ++cls) {
         size_t b = 0;
         if (np_hmm_forward_lds_bytes(cls, &b) != hipSuccess || b != NP_LOGSUM_TBL * sizeof(float)) lds_size_ok = false;
+        if (np_hmm_forward2_has(cls) && (np_hmm_forward2_lds_bytes(cls, &b) != hipSuccess || b != NP_LOGSUM_TBL * sizeof(float))) lds_size_ok = false;
         lds_seen = std::max(lds_seen, b);
     }
     float* d_buf = nullptr; uint16_t* d_sbuf = nullptr; uint32_t* d_out = c->d_counters + 64;     // 8 words, zeroed at np_create
@@ -369,6 +381,7 @@ np_ctx* np_create(int device, const np_params* params)
     // tuning knobs (persistent-grid sizes); defaults fill the CU up to the kernels' register-limited occupancy
     if (const char* v = getenv("NP_ALIGN_BLOCKS_PER_CU")) c->align_blocks_per_cu = std::max(1, atoi(v));
     if (const char* v = getenv("NP_HMM_BLOCKS_PER_CU")) c->hmm_blocks_per_cu = std::max(1, atoi(v));
+    if (const char* v = getenv("NP_HMM_KERNEL")) c->hmm_kernel = atoi(v) == 2 ? 2 : 1;
     if (const char* v = getenv("NP_ALIGN_LPT")) c->align_lpt = atoi(v) != 0;
     if (const char* v = getenv("NP_ED_WARMUP")) c->ed_warmup = atoi(v);
     if (const char* v = getenv("NP_EA_WAVES_PER_CU")) c->ea_waves_per_cu = std::max(1, atoi(v));
@@ -424,7 +437,7 @@ void np_destroy(np_ctx* c)
     dev_buf* bufs[] = {&c->order, &c->trace, &c->kparams, &c->trace_all, &c->fill_state, &c->kparams_bt, &c->align_order_bt, &c->b_jobs, &c->b_reads, &c->b_events, &c->b_ranks, &c->b_out, &c->b_pair_off,
                        &c->b_pairs, &c->b_pair_begin, &c->b_n_pairs, &c->b_vm, &c->b_bp, &c->b_cell_off, &c->b_state_off,
                        &c->b_states, &c->b_n_states, &c->ed_status, &c->ed_tstat, &c->b_raw, &c->b_raw_off, &c->b_ev_off, &c->b_ev_start,
-                       &c->b_ev_len, &c->b_ev_mean, &c->b_ev_stdv, &c->b_n_events, &c->cm_group_rank_off, &c->cm_cigar_scratch, &c->ea_bp, &c->ea_path, &c->ea_args, &c->align_order};
+                       &c->b_ev_len, &c->b_ev_mean, &c->b_ev_stdv, &c->b_n_events, &c->cm_group_rank_off, &c->cm_cigar_scratch, &c->ea_bp, &c->ea_path, &c->ea_args, &c->align_order, &c->gslab};
     for (dev_buf* b : bufs) b->release();
     for (auto& t : c->timing) {
         for (auto& pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1129,6 +1142,7 @@ int64_t np_get_stat(np_ctx* c, const char* name)
     if (k == "align_scratch_bytes") return c->last_align_scratch;
     if (k == "align_blocks_max") return (int64_t)c->n_cu * c->align_blocks_per_cu;
     if (k == "lse_oor") return c->lse_oor ? 1 : 0;
+    if (k == "hmm_kernel") return c->hmm_kernel;
     if (k == "n_cu") return c->n_cu;
     if (k == "ed_serial_reads" || k == "ed_refused_reads") {     // of the most recent np_detect_events_* call (waits for it): reads whose
         // prefix sums were accumulated serially (exactness bound not provable), resp. refused (NP_ED_INEXACT: non-finite samples)
@@ -1165,6 +1179,7 @@ int np_set_option(np_ctx* c, const char* name, int64_t value)
     else if (k == "align_bt_prio") c->align_bt_prio = (int)std::min<int64_t>(3, std::max<int64_t>(0, value));
     else if (k == "hmm_prio") c->hmm_prio = (int)std::min<int64_t>(2, std::max<int64_t>(0, value));
     else if (k == "hmm_blocks_per_cu") c->hmm_blocks_per_cu = (int)std::max<int64_t>(1, value);
+    else if (k == "hmm_kernel") c->hmm_kernel = value == 2 ? 2 : 1;
     else if (k == "align_lpt") c->align_lpt = value != 0;
     else if (k == "stream_switch_wait") c->stream_switch_wait = value != 0;
     else if (k == "ed_warmup") c->ed_warmup = (int)value;

@@ -21,6 +21,7 @@ struct np_hmm_args {
     np_hmm_state* states;          // output
     const int64_t* state_off;
     int32_t* n_states;
+    float4* gslab;                 // staged forward kernel (np_hmm_forward2_kernel): 8 x 64 records per resident wave
     int prio;                      // forward kernel: wave priority (s_setprio 0..3) -- above 0 only when the caller co-schedules it with
                                    // the event aligner's back-track launch, whose scalar chain would otherwise starve it
 };
@@ -94,7 +95,10 @@ static const int NP_CLASS_SEG[NP_NUM_CLASSES] = {2, 3, 4, 8, 16, 32, 64, 64};
 static const int NP_CLASS_C[NP_NUM_CLASSES] = {8, 8, 8, 8, 8, 8, 8, 16};
 
 hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, bool lse_oor, hipStream_t s);
-hipError_t np_hmm_forward_lds_bytes(int cls, size_t* bytes);      // static LDS of the class's clamp-free instantiation
+hipError_t np_hmm_forward_lds_bytes(int cls, size_t* bytes);
+bool np_hmm_forward2_has(int cls);                                  // the staged forward kernel covers this size class
+hipError_t np_launch_hmm_forward2(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s);      // needs a.gslab: n_blocks x (threads / 64) x 8 KB
+hipError_t np_hmm_forward2_lds_bytes(int cls, size_t* bytes);      // static LDS of the class's clamp-free instantiation
 // hardware probes (np_hmm_kernels.hip): out = 8 x uint32 (zeroed), buf = 16 floats of 1.0f, sbuf = 32 x uint16
 hipError_t np_launch_probe(const float* logsum, const float* buf, uint16_t* sbuf, uint32_t* out, int n_blocks, hipStream_t s);
 hipError_t np_launch_hmm_viterbi(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s);
@@ -103,6 +107,7 @@ hipError_t np_launch_event_align(const np_align_args& a, int n_blocks, int mode,
 hipError_t np_launch_align_order(int n_reads, const np_read_dev* reads, uint32_t* scratch /* 2048 + n_reads */, hipStream_t s);
 int np_align_block_threads(void);
 int np_hmm_block_threads(int cls);
+int np_hmm_forward2_block_threads(void);
 int np_vit_block_threads(void);
 
 // glue kernels

@@ -83,6 +83,34 @@ def test_hmm_score_flags_and_long_windows(ctx, orc, models):
     assert np.array_equal(got, np.array(want, np.float32))
 
 
+def test_staged_forward_kernel_gives_the_same_scores(ctx, orc, models):
+    """option hmm_kernel = 2 (the stage-major forward kernel, round 4's experiment): bit-equal to the oracle and to the default kernel,
+    on the methylation windows and on windows of every size class with all clip-flag combinations."""
+    jobs, want = _score_jobs(ctx, orc, models, _reads(models, range(20, 26), 1200))
+    mn = orc.model(models["nucleotide"])
+    rd = synth_read(30, models["nucleotide"], L=1500)
+    S = orc.scalings(rd["shift"], rd["scale"], rd["var"])
+    jobs2, want2 = [], []
+    for n_k, e0 in ((3, 20), (8, 40), (11, 50), (16, 80), (17, 100), (22, 120), (24, 130), (31, 140), (33, 150), (64, 300), (65, 320), (129, 500)):
+        ranks = rd["ranks"][e0 // 2: e0 // 2 + n_k]
+        for flags in (0, HAF_PRE, HAF_POST, HAF_PRE | HAF_POST):
+            for ne in (1, 2, int(1.5 * n_k)):
+                e1, e2 = e0, e0 + ne - 1
+                jobs2.append(dict(events=rd["events"], ranks=ranks, e_start=e1, e_stop=e2, stride=1, model=ctx.models["nucleotide"],
+                                  scale=rd["scale"], shift=rd["shift"], var=rd["var"], events_per_base=1.6, flags=flags))
+                want2.append(orc.hmm_score(mn, S, rd["events"], ranks.astype(np.uint32), e1, e2, 1, 1.6, 1.0, flags))
+    try:
+        ctx.set_option("hmm_kernel", 2)
+        assert ctx.get_stat("hmm_kernel") == 2
+        got = ctx.profile_hmm_score(jobs)
+        got2 = ctx.profile_hmm_score(jobs2)
+    finally:
+        ctx.set_option("hmm_kernel", 1)
+    assert np.array_equal(got, want)
+    assert np.array_equal(got2, np.array(want2, np.float32))
+    assert np.array_equal(ctx.profile_hmm_score(jobs2), got2)
+
+
 def test_hmm_align_matches_oracle(ctx, orc, models):
     mn = orc.model(models["nucleotide"])
     jobs, want = [], []

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B timing of kernel B builds on the GPU box: for every library given, the whole call-methylation step over the same batch of
 synthetic reads; prints the forward-kernel family time (the library's own HIP events) and a checksum of the scores.  Each library
-runs in its own process (NP_HIP_LIB).  Usage: python tools/hmm_ab.py [--pool 4000 --tile 10] lib1.so lib2.so ..."""
+runs in its own process (NP_HIP_LIB).  Usage: python tools/hmm_ab.py [--pool 4000 --tile 10] lib1.so lib2.so@NP_HMM_KERNEL=1 ...
+(`@NAME=VALUE[,NAME=VALUE]` after a library sets environment variables for that run; an empty library name means the default one)"""
 import argparse
 import json
 import os
@@ -30,7 +31,8 @@ def child(args):
         b.step()
     ctx.sync(); torch.cuda.synchronize()
     ms = {n: round(ctx.kernel_time(w)[0] / args.reps, 3) for w, n in ((0, "event_align"), (1, "hmm_forward"), (2, "glue"))}
-    print(json.dumps(dict(lib=os.path.basename(os.environ.get("NP_HIP_LIB", "default")), reads=b.n_reads, ms=ms,
+    print(json.dumps(dict(lib=os.path.basename(os.environ.get("NP_HIP_LIB", "default")), env=os.environ.get("NP_AB_ENV", ""), reads=b.n_reads, ms=ms,
+                          hmm_kernel=ctx.get_stat("hmm_kernel"),
                           scores_crc="%08x" % zlib.crc32(b.scores().tobytes()))))
 
 
@@ -47,6 +49,11 @@ def main():
         return child(args)
     for lib in args.libs or [""]:
         env = dict(os.environ)
+        lib, _, extra = lib.partition("@")
+        for kv in filter(None, extra.split(",")):
+            k, _, v = kv.partition("=")
+            env[k] = v
+        env["NP_AB_ENV"] = extra
         if lib:
             env["NP_HIP_LIB"] = os.path.abspath(lib)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--pool", str(args.pool), "--tile", str(args.tile),

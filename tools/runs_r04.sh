@@ -1,0 +1,69 @@
+#!/bin/bash
+# Round-4 GPU calls, one function per call (provenance of the gpurun tags the files under profiles/ cite: r04a ...).
+#   usage on the GPU box (through gpurun):  bash tools/runs_r04.sh <letter>        e.g.  gpurun -- 'bash tools/runs_r04.sh a'
+export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; export GRAFT_REPO_ROOT=$R
+
+# first pass: parity of the staged forward kernel (all GPU tests, then the scoring tests under the old kernel), A/B of its variants,
+# the VALU counter calibration (tools/valu_rates under --pmc), the 8-rank rehearsal of the N>1 bench line on one device
+call_a() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04a; mkdir -p $O
+( time timeout 600 python -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+( NP_HMM_KERNEL=1 timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -x -q ) > $O/pytest_k1.log 2>&1; echo "k1 pytest rc=$?" >> $O/pytest_k1.log
+V=nanopolish_amd/variants
+( timeout 900 python tools/hmm_ab.py --pool 4000 --tile 10 "@NP_HMM_KERNEL=1" "@NP_HMM_KERNEL=2" $V/libnp_hip_f2s.so $V/libnp_hip_f2w5.so $V/libnp_hip_f2w5s.so "@NP_HMM_KERNEL=2" "@NP_HMM_KERNEL=1" ) > $O/hmm_ab.log 2>&1
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $R/$O/valu_pmc -o v -- $R/tools/valu_rates > $R/$O/valu_rates_pmc.log 2>&1 )
+$R/tools/valu_rates > $O/valu_rates.log 2>&1
+find $O/valu_pmc -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} $O/valu_counters.csv; find $O/valu_pmc -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} $O/valu_kernel_trace.csv
+( time NP_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 --pool 1000 --tile 5 --steps 2 --warmup 1 --legs 0 ) > $O/bench_8rank_gloo.json 2> $O/bench_8rank_gloo.err; echo "rc=$?" >> $O/bench_8rank_gloo.err
+tail -4 $O/pytest.log; tail -3 $O/pytest_k1.log; cat $O/hmm_ab.log; head -c 600 $O/valu_counters.csv; tail -c 1800 $O/bench_8rank_gloo.json; tail -5 $O/bench_8rank_gloo.err
+}
+
+# kernel B, staged: where do the Gaussians come from (slab loads in two halves / all first / none = ablation), scheduling strategy
+call_b() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04b; mkdir -p $O
+V=nanopolish_amd/variants
+( timeout 900 python tools/hmm_ab.py --pool 4000 --tile 10 "@NP_HMM_KERNEL=1" "@NP_HMM_KERNEL=2" $V/libnp_hip_g1.so $V/libnp_hip_g2.so $V/libnp_hip_g2s.so $V/libnp_hip_g1ilp.so "@NP_HMM_KERNEL=1" ) > $O/hmm_ab.log 2>&1
+cat $O/hmm_ab.log
+}
+
+# kernel B, staged, emissions one step ahead (Gaussian requests behind the K chain): against kernel 1, with free emissions, 5 waves, stage barriers
+call_c() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04c; mkdir -p $O
+V=nanopolish_amd/variants
+( timeout 900 python tools/hmm_ab.py --pool 4000 --tile 10 "@NP_HMM_KERNEL=1" "@NP_HMM_KERNEL=2" $V/libnp_hip_e1.so $V/libnp_hip_e1.so@NP_HMM_KERNEL=1 $V/libnp_hip_e_w5.so $V/libnp_hip_e_s.so "@NP_HMM_KERNEL=2" "@NP_HMM_KERNEL=1" ) > $O/hmm_ab.log 2>&1
+cat $O/hmm_ab.log
+( timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_sites.py -m gpu -x -q ) 2>&1 | tail -3
+}
+
+# counters of the forward kernels, block-major (1) against stage-major (2), same workload (8192 reads, call-methylation step only)
+call_d() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=$GRAFT_REPO_ROOT/gpurun_out/r04d; mkdir -p $O
+for k in 1 2; do
+  W="python $GRAFT_REPO_ROOT/tools/pmc_workload.py --reads 8192 --ea-reads 0 --reps 2"
+  ( cd /tmp && NP_HMM_KERNEL=$k timeout 120 $W > $O/units_k$k.json 2> $O/units_k$k.err ); echo "units k$k rc=$?"
+  pass() { local name=$1; shift
+    ( cd /tmp && NP_HMM_KERNEL=$k timeout 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/k${k}_$name -o $name -- $W > $O/k${k}_$name.log 2>&1 ); echo "k$k $name rc=$?" | tee -a $O/passes.log; }
+  pass sq1 SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE
+  pass sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
+  pass sq3 SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_IFETCH GRBM_GUI_ACTIVE
+done
+python3 - <<'PY'
+import csv, glob, os
+from collections import defaultdict
+O = os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/r04d"
+for k in (1, 2):
+    tot = defaultdict(float); n = defaultdict(int)
+    for f in glob.glob(O + "/k%d_*/**/*counter_collection.csv" % k, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "np_hmm_forward" in r["Kernel_Name"]:
+                tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+    print("kernel", k, {c: (round(v / 2), n[c] // 2) for c, v in sorted(tot.items())})
+PY
+cat $O/units_k1.json | tail -1 | cut -c1-400; cat $O/units_k2.json | tail -1 | cut -c1-400
+}
+
+"call_$1"
