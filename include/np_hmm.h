@@ -41,6 +41,7 @@ extern "C" {
 #define NP_JOB_SKIP 0x80000000u
 
 #define NP_MAX_KMERS 1024      /* k-mers per profile_hmm_* call (reference callers stay <= 260) */
+#define NP_MAX_WINDOW_EVENTS (1u << 20)  /* events per profile_hmm_* call: the length of the universal clip-flank table (np_create) */
 #define NP_ALN_BANDWIDTH 100   /* ALN_BANDWIDTH, src/nanopolish_raw_loader.cpp:72 */
 
 typedef struct np_ctx np_ctx;
@@ -461,11 +462,14 @@ int   np_copy_to_host(np_ctx* ctx, void* stream, void* dst_host, const void* src
 int   np_memset_dev(np_ctx* ctx, void* stream, void* dst_dev, int value, size_t bytes);
 void* np_stream_create(np_ctx* ctx);                 /* a hipStream_t (non-blocking), NULL on failure */
 void  np_stream_destroy(np_ctx* ctx, void* stream);  /* waits for the stream's work first */
-void* np_event_create(np_ctx* ctx);                  /* a hipEvent_t without timing */
+void* np_event_create(np_ctx* ctx);                  /* a hipEvent_t without timing; a host thread that waits on it (np_event_sync) SLEEPS
+                                                        (hipEventBlockingSync): the bindings' waiting threads must not spin on a core the
+                                                        packing and result-building workers need */
 void  np_event_destroy(np_ctx* ctx, void* event);
 int   np_event_record(np_ctx* ctx, void* event, void* stream);
 int   np_stream_wait_event(np_ctx* ctx, void* stream, void* event);
 int   np_event_sync(np_ctx* ctx, void* event);       /* blocks the calling host thread */
+int   np_event_query(np_ctx* ctx, void* event);      /* NP_OK: the work before the event's last record has finished; 1: not yet; < 0: error */
 
 /* Synchronise the context's stream (or the given one). */
 int np_sync(np_ctx* ctx, void* stream);

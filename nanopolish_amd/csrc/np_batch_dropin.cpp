@@ -1,37 +1,48 @@
 // np_batch_dropin.cpp -- the throughput binding on the reference side: call-methylation's per-record work for whole
-// BamProcessor batches, on the device, double-buffered.
+// BamProcessor batches, on the device, as a three-stage pipeline with its own host threads, over one or several GPUs.
 //
 // In the reference every record of a batch runs, under `#pragma omp parallel for` (src/common/nanopolish_bam_processor.cpp:99-106),
 //     calculate_methylation_for_read_from_bam            src/nanopolish_call_methylation.cpp:163-177
 //       SquiggleRead sr(read_name, read_db)               load_from_raw: detect_events, MoM scalings, event alignment, event map,
 //                                                         recalibrate_model, QC gates (src/nanopolish_squiggle_read.cpp:141-336)
 //       calculate_methylation_for_read(..., sr, ...)      src/basemods/nanopolish_basemods.cpp:238-419
-// This file is compiled INSIDE a nanopolish build (it includes nanopolish's headers) and splits that loop in three:
-//   phase 1 (host, OpenMP over the records): what only the host can do -- the read's sequence and raw samples (ReadDB / slow5 /
-//            fast5: the caller's NpBatchRead), the reference segment (faidx), the CIGAR -- packed into ONE pinned blob;
+// and the batch's writer then walks the result maps and clears them (write_methylation_results_for_batch, call_methylation.cpp:552-588).
+// This file is compiled INSIDE a nanopolish build (it includes nanopolish's headers) and splits that loop in three stages:
+//   phase 1 (host, the pipeline's PACKER thread + worker pool): what only the host can do -- the read's sequence and raw samples
+//            (ReadDB / slow5 / fast5: the caller's NpBatchRead), the reference segment (faidx), the CIGAR -- packed into ONE pinned blob;
 //   phase 2 (device): ONE upload of that blob, then the whole batch in seven enqueues through the C ABI (include/np_hmm.h)
 //            np_cm_build_jobs_cigar_dev -> np_detect_events_dev -> np_mom_fill_dev -> np_event_align_dev ->
 //            np_calibrate_resolve_dev -> np_cm_discard_degenerate_dev -> np_hmm_score_dev, then ONE read-back of the output blob;
-//   phase 3 (host): one ScoredSite map per record from the scores, exactly the fields basemods.cpp:384-413 fills.
-// NpBatchPipeline keeps two input and two output blobs (device + pinned host, persistent, growing on demand) and three streams --
-// upload, compute (the context's own), read-back -- ordered by events, so the upload and phase 1 of batch k+1 and the read-back and
-// phase 3 of batch k-1 run beside the kernels of batch k.  Scratch (events, alignments, event maps, work items) is single: the
-// compute stream runs one batch at a time.
+//   phase 3 (host, the FINISHER thread + worker pool): one ScoredSite map per record from the scores, exactly the fields
+//            basemods.cpp:384-413 fills.
+// Round 3's form ran phases 1 and 3 on the CALLER's OpenMP team, one after the other around the wait for the device: at 8 192
+// records the binding took 37 ms of the caller's time per batch and the harness's stand-in for the writer (count the sites, clear the
+// maps: 1.5 M ScoredSites, two heap blocks each, serially) 79 ms more -- 70 k reads/s against 340 k for the device pass alone.  Now
+// the three stages of three consecutive batches run at the same time on threads of the pipeline's own (np_pool.h), submit() only
+// queues, collect() swaps finished maps into the caller's result, and recycle() takes written-out maps back to destroy them on the
+// workers.  With several devices the batches are dealt round-robin to one context per GPU; results come back in submission order.
 // oracle/Makefile builds the reference with this file in (`make -C oracle batch`), tests/test_gpu_batch_dropin.py feeds it
-// the records of tests/golden/golden_reflevel.npz and expects the maps the unmodified reference produced;
-// tests/bench_batch_dropin.py times it at BamProcessor-like batch sizes.  INTEGRATION.md section 2 shows the call site.
+// the records of tests/golden/golden_reflevel.npz and expects the maps the unmodified reference produced (one context, and two
+// contexts on one device); tests/bench_batch_dropin.py times it at BamProcessor-like batch sizes.  INTEGRATION.md section 2 shows the call site.
+#include <malloc.h>
+#include <sched.h>
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <map>
+#include <memory>
 #include <mutex>
-#include <omp.h>
+#include <thread>
 #include "np_batch_dropin.h"
 #include "nanopolish_alphabet.h"
 #include "nanopolish_eventalign.h"          // get_reference_region_ts
 #include "nanopolish_pore_model_set.h"
 #include "np_hmm.h"
+#include "np_pool.h"
 #include "np_shim_common.h"
 
 using np_shim::shim;
@@ -39,10 +50,33 @@ using np_shim::check;
 using np_shim::die;
 using np_shim::Layout;
 using np_shim::Blob;
+using np_shim::Pool;
 
 namespace {
 
 int g_event_cap_divisor = 2;
+
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// CPUs this process may use: the affinity mask, capped by the cgroup CPU quota (a container that SEES 256 hardware threads may be
+// granted 16: a pool sized by the former would run 256 threads on 16 CPUs)
+int usable_cpus()
+{
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    {
+        std::ifstream f("/sys/fs/cgroup/cpu.max");                       // cgroup v2: "<quota> <period>" or "max <period>"
+        std::string q; double period = 0.0;
+        if (f >> q >> period && q != "max" && period > 0.0) n = std::min(n, std::max(1, (int)(atof(q.c_str()) / period + 0.5)));
+    }
+    {
+        std::ifstream fq("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), fp("/sys/fs/cgroup/cpu/cpu.cfs_period_us");      // cgroup v1
+        double q = 0.0, per = 0.0;
+        if (fq >> q && fp >> per && q > 0.0 && per > 0.0) n = std::min(n, std::max(1, (int)(q / per + 0.5)));
+    }
+    return std::max(1, n);
+}
 
 // 0..3 for A, C, G, T (DNAAlphabet's ranks), 4 for anything else
 inline int base_code(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; }
@@ -70,62 +104,138 @@ void nucleotide_kmer_ranks(const std::string& seq, uint32_t k, uint16_t* out)
     }
 }
 
+struct RefView { const char* p; size_t n; RefView() : p(NULL), n(0) {} };
+
 // what one batch in flight needs on the host until it is collected
 struct Slot {
+    int dev;                                // index into Impl::devs
     Blob in, out;
     void *ev_h2d, *ev_cmp, *ev_d2h;
-    std::vector<NpBatchRead>* reads;
-    std::vector<std::string> ref_seqs;
-    std::vector<int> ref_start;
+    std::vector<NpBatchRead>* caller;       // the caller's vector: statuses go back into it at collect()
+    std::vector<NpBatchRead> rec;           // its entries as they were at submit() (the buffers they point to stay the caller's)
+    std::map<int, std::string> union_seq;   // tid -> the reference stretch the batch's records on that contig cover
+    std::map<int, int> union_lo;
+    std::vector<std::string> own_seq;       // a record's own segment when no union serves it, or when it needed disambiguation
+    std::vector<RefView> ref;               // every record's reference segment (a view into union_seq / own_seq)
+    std::vector<int> ref_start, dev_index, status;
     std::vector<int64_t> group_off;
-    std::vector<int> dev_index;             // batch index -> position among the records that went to the device, or -1
+    std::vector<std::map<int, ScoredSite> > built;      // phase 3's output, swapped into the caller's result by collect()
+    std::vector<int> builder;               // the pool worker that built (allocated) each record's map
     int n_dev;
-    // offsets into `out`
-    size_t o_scores, o_first, o_last, o_n_motif, o_n_groups, o_n_events, o_n_pairs, o_calibrated, out_bytes;
-    Slot() : in(true), out(true), ev_h2d(NULL), ev_cmp(NULL), ev_d2h(NULL), reads(NULL), n_dev(0) {}
+    bool finished;                          // phase 3 done, not collected yet (under Impl::m)
+    size_t o_scores, o_first, o_last, o_n_motif, o_n_groups, o_n_events, o_n_pairs, o_calibrated, out_bytes;   // offsets into `out`
+    Slot() : dev(0), in(true), out(true), ev_h2d(NULL), ev_cmp(NULL), ev_d2h(NULL), caller(NULL), n_dev(0), finished(false), out_bytes(0) {}
+};
+
+struct DevState {
+    int slot_key;                           // context slot of the process-wide shim
+    np_ctx* c;
+    Blob scratch;                           // single per context: its compute stream runs one batch at a time
+    void *s_h2d, *s_d2h;
+    DevState() : slot_key(0), c(NULL), scratch(false), s_h2d(NULL), s_d2h(NULL) {}
 };
 
 } // namespace
 
 struct NpBatchPipeline::Impl {
-    np_ctx* c;
     MethylationCallingParameters params;
     std::string kit;
     const faidx_t* fai; const bam_hdr_t* hdr;
     int region_start, region_end;
-    Slot slot[2];
-    Blob scratch;
-    void *s_h2d, *s_d2h;
-    long n_submitted, n_collected;
-    double t[6];
-    Impl() : c(NULL), fai(NULL), hdr(NULL), region_start(-1), region_end(-1), scratch(false), s_h2d(NULL), s_d2h(NULL), n_submitted(0), n_collected(0) { for (int i = 0; i < 6; ++i) t[i] = 0.0; }
+    std::vector<DevState*> devs;
+    std::vector<Slot*> slots;               // 3 per device; batch b uses slot b % slots.size() on device b % devs.size()
+    Pool* pool;
+    std::thread packer, finisher[2];        // two finishers: one waits for batch k+1's read-back while the other builds batch k's maps
+    std::mutex m; std::condition_variable cv;
+    long n_submitted, n_packed, n_claimed, n_finished, n_collected;      // batches that have passed each stage (under m); n_claimed: taken by a finisher
+    bool stop;
+    std::mutex tm; double t[8];
+    // which pool worker allocated the map of a record handed out by collect(): recycle() sends every map back to ITS worker, so that a
+    // heap block is freed by the thread that allocated it (glibc keeps an arena per thread: a free from another thread takes that
+    // arena's lock -- sixteen workers freeing each other's blocks while sixteen build the next batch spent 147 ms on a batch whose
+    // maps take 9 ms to build).  collect() and recycle() are the caller's: one thread.
+    std::map<const bam1_t*, int> builder_of;
+    Impl() : fai(NULL), hdr(NULL), region_start(-1), region_end(-1), pool(NULL), n_submitted(0), n_packed(0), n_claimed(0), n_finished(0), n_collected(0), stop(false) { for (int i = 0; i < 8; ++i) t[i] = 0.0; }
+    void add_time(int i, double s) { std::lock_guard<std::mutex> g(tm); t[i] += s; }
+    void open(const std::vector<int>& devices, bool shared_default, int host_threads);
+    void pack(Slot& S);
+    void finish(Slot& S);
+    void packer_loop();
+    void finisher_loop();
 };
+
+void NpBatchPipeline::Impl::open(const std::vector<int>& devices, bool shared_default, int host_threads)
+{
+    for (size_t d = 0; d < devices.size(); ++d) {
+        DevState* D = new DevState();
+        D->slot_key = shared_default ? 0 : shim().take_slot(devices[d]);
+        D->c = shim().ctx(D->slot_key);
+        D->s_h2d = np_stream_create(D->c); D->s_d2h = np_stream_create(D->c);
+        if (!D->s_h2d || !D->s_d2h) die(np_last_error(D->c));
+        devs.push_back(D);
+    }
+    for (size_t i = 0; i < 3 * devs.size(); ++i) {
+        Slot* S = new Slot();
+        S->dev = (int)(i % devs.size());
+        np_ctx* c = devs[S->dev]->c;
+        S->ev_h2d = np_event_create(c); S->ev_cmp = np_event_create(c); S->ev_d2h = np_event_create(c);
+        if (!S->ev_h2d || !S->ev_cmp || !S->ev_d2h) die(np_last_error(c));
+        slots.push_back(S);
+    }
+    // Freed map memory goes back to the allocator, not to the kernel: with glibc's default trim threshold (128 KB) every batch's
+    // 300 MB of released nodes is unmapped page by page and faulted in again by the next batch (seen as system time, and as a 7 ms
+    // packing loop taking 58).  NP_KEEP_MALLOC_DEFAULTS=1 leaves the process's settings alone.
+    if (!getenv("NP_KEEP_MALLOC_DEFAULTS")) { (void)mallopt(M_TRIM_THRESHOLD, 1 << 30); (void)mallopt(M_TOP_PAD, 64 << 20); }
+    int nt = host_threads;
+    if (nt <= 0) { const char* v = getenv("NP_HOST_THREADS"); nt = v ? atoi(v) : 0; }
+    if (nt <= 0) { const int cpus = usable_cpus(); nt = cpus + cpus / 4; }      // (the workers stall on memory and on the allocator: 20 threads on 16 CPUs
+                                                                                //  measured 7 % over 16, 24 no better -- profiles/r04_batch_binding.md)
+    pool = new Pool(std::min(nt, 256));
+    packer = std::thread(&Impl::packer_loop, this);
+    for (int i = 0; i < 2; ++i) finisher[i] = std::thread(&Impl::finisher_loop, this);
+}
 
 NpBatchPipeline::NpBatchPipeline(const MethylationCallingParameters& calling_parameters, const std::string& kit, const faidx_t* fai,
                                  const bam_hdr_t* hdr, int region_start, int region_end) : p(new Impl())
 {
-    p->c = shim().get();
-    p->s_h2d = np_stream_create(p->c); p->s_d2h = np_stream_create(p->c);
-    if (!p->s_h2d || !p->s_d2h) die(np_last_error(p->c));
-    for (int i = 0; i < 2; ++i) {
-        Slot& s = p->slot[i];
-        s.ev_h2d = np_event_create(p->c); s.ev_cmp = np_event_create(p->c); s.ev_d2h = np_event_create(p->c);
-        if (!s.ev_h2d || !s.ev_cmp || !s.ev_d2h) die(np_last_error(p->c));
-    }
+    p->open(std::vector<int>(1, 0), true, 0);
+    configure(calling_parameters, kit, fai, hdr, region_start, region_end);
+}
+
+NpBatchPipeline::NpBatchPipeline(const MethylationCallingParameters& calling_parameters, const std::string& kit, const faidx_t* fai,
+                                 const bam_hdr_t* hdr, int region_start, int region_end, const std::vector<int>& devices, int host_threads) : p(new Impl())
+{
+    if (devices.empty()) die("NpBatchPipeline: an empty device list");
+    p->open(devices, false, host_threads);
     configure(calling_parameters, kit, fai, hdr, region_start, region_end);
 }
 
 NpBatchPipeline::~NpBatchPipeline()
 {
-    np_ctx* c = p->c;
-    (void)np_sync(c, p->s_h2d); (void)np_sync(c, NULL); (void)np_sync(c, p->s_d2h);
-    for (int i = 0; i < 2; ++i) {
-        Slot& s = p->slot[i];
-        s.in.release(c); s.out.release(c);
-        np_event_destroy(c, s.ev_h2d); np_event_destroy(c, s.ev_cmp); np_event_destroy(c, s.ev_d2h);
+    {
+        std::unique_lock<std::mutex> g(p->m);
+        while (p->n_finished < p->n_submitted) p->cv.wait(g);          // batches nobody collected still run to their end
+        p->stop = true;
     }
-    p->scratch.release(c);
-    np_stream_destroy(c, p->s_h2d); np_stream_destroy(c, p->s_d2h);
+    p->cv.notify_all();
+    p->packer.join(); p->finisher[0].join(); p->finisher[1].join();
+    p->pool->drain();
+    delete p->pool;
+    for (size_t i = 0; i < p->slots.size(); ++i) {
+        Slot* S = p->slots[i];
+        np_ctx* c = p->devs[S->dev]->c;
+        (void)np_sync(c, p->devs[S->dev]->s_h2d); (void)np_sync(c, NULL); (void)np_sync(c, p->devs[S->dev]->s_d2h);
+        S->in.release(c); S->out.release(c);
+        np_event_destroy(c, S->ev_h2d); np_event_destroy(c, S->ev_cmp); np_event_destroy(c, S->ev_d2h);
+        delete S;
+    }
+    for (size_t d = 0; d < p->devs.size(); ++d) {
+        DevState* D = p->devs[d];
+        D->scratch.release(D->c);
+        np_stream_destroy(D->c, D->s_h2d); np_stream_destroy(D->c, D->s_d2h);
+        shim().release_slot(D->slot_key);
+        delete D;
+    }
     delete p;
 }
 
@@ -136,18 +246,69 @@ void NpBatchPipeline::configure(const MethylationCallingParameters& calling_para
     p->params = calling_parameters; p->kit = kit; p->fai = fai; p->hdr = hdr; p->region_start = region_start; p->region_end = region_end;
 }
 
-int NpBatchPipeline::in_flight() const { return (int)(p->n_submitted - p->n_collected); }
-void NpBatchPipeline::host_seconds(double out[6]) const { for (int i = 0; i < 6; ++i) out[i] = p->t[i]; }
+int NpBatchPipeline::in_flight() const { std::lock_guard<std::mutex> g(p->m); return (int)(p->n_submitted - p->n_collected); }
+int NpBatchPipeline::max_in_flight() const { return (int)p->slots.size(); }
+int NpBatchPipeline::devices() const { return (int)p->devs.size(); }
+void NpBatchPipeline::host_seconds(double out[8]) const { std::lock_guard<std::mutex> g(p->tm); for (int i = 0; i < 8; ++i) out[i] = p->t[i]; }
 
 void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
 {
-    if (in_flight() >= 2) die("NpBatchPipeline::submit: two batches are in flight already (collect one first)");
-    np_ctx* c = p->c;
-    Slot& S = p->slot[p->n_submitted & 1];
-    p->n_submitted += 1;
-    S.reads = &reads;
+    const double t0 = now();
+    {
+        std::lock_guard<std::mutex> g(p->m);
+        if (p->n_submitted - p->n_collected >= (long)p->slots.size()) die("NpBatchPipeline::submit: max_in_flight() batches are in flight already (collect one first)");
+        Slot& S = *p->slots[p->n_submitted % (long)p->slots.size()];
+        S.caller = &reads;
+        S.rec = reads;                     // (the records, sequences and samples they point to stay the caller's until collect())
+        p->n_submitted += 1;
+    }
+    p->cv.notify_all();
+    p->add_time(7, now() - t0);
+}
+
+void NpBatchPipeline::Impl::packer_loop()
+{
+    for (;;) {
+        Slot* S;
+        {
+            std::unique_lock<std::mutex> g(m);
+            while (!stop && n_packed >= n_submitted) cv.wait(g);
+            if (stop) return;
+            S = slots[n_packed % (long)slots.size()];
+        }
+        pack(*S);
+        { std::lock_guard<std::mutex> g(m); n_packed += 1; }
+        cv.notify_all();
+    }
+}
+
+void NpBatchPipeline::Impl::finisher_loop()
+{
+    for (;;) {
+        Slot* S;
+        {
+            std::unique_lock<std::mutex> g(m);
+            while (!stop && n_claimed >= n_packed) cv.wait(g);
+            if (stop) return;
+            S = slots[n_claimed % (long)slots.size()];
+            n_claimed += 1;
+        }
+        finish(*S);
+        { std::lock_guard<std::mutex> g(m); S->finished = true; n_finished += 1; }
+        cv.notify_all();
+    }
+}
+
+// ---- phases 1 and 2 of one batch (the packer thread) ---------------------------------------------------------------------------------
+void NpBatchPipeline::Impl::pack(Slot& S)
+{
+    DevState& D = *devs[S.dev];
+    np_ctx* c = D.c;
+    std::vector<NpBatchRead>& reads = S.rec;
     const int n_all = (int)reads.size();
-    S.ref_seqs.assign(n_all, std::string()); S.ref_start.assign(n_all, 0); S.dev_index.assign(n_all, -1);
+    S.union_seq.clear(); S.union_lo.clear();
+    S.own_seq.assign(n_all, std::string()); S.ref.assign(n_all, RefView()); S.ref_start.assign(n_all, 0); S.dev_index.assign(n_all, -1);
+    S.status.assign(n_all, NP_BATCH_OK);
     S.group_off.assign(1, 0); S.out_bytes = 0; S.n_dev = 0;
     if (n_all == 0) return;
 
@@ -156,20 +317,19 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
     // k = 5, another detector) take the caller's host path; a kit without a motif model leaves every map empty, as the reference.
     const char* strand_name = "template";
     const uint32_t k = 6;
-    const PoreModel* pm_nuc = PoreModelSet::has_model(p->kit, "nucleotide", strand_name, k) ? PoreModelSet::get_model(p->kit, "nucleotide", strand_name, k) : NULL;
-    const bool have_meth = pm_nuc && PoreModelSet::has_model(p->kit, p->params.methylation_type, strand_name, k);
-    const int alphabet = np_alphabet_id(p->params.methylation_type.c_str());
+    const PoreModel* pm_nuc = PoreModelSet::has_model(kit, "nucleotide", strand_name, k) ? PoreModelSet::get_model(kit, "nucleotide", strand_name, k) : NULL;
+    const bool have_meth = pm_nuc && PoreModelSet::has_model(kit, params.methylation_type, strand_name, k);
+    const int alphabet = np_alphabet_id(params.methylation_type.c_str());
     const bool device_ok = pm_nuc && pm_nuc->k == k && alphabet >= 1 && alphabet <= 4;
-    const int MINSEP = p->params.min_separation, FLANK = p->params.min_flank;
+    const int MINSEP = params.min_separation, FLANK = params.min_flank;
 
     // ---- phase 1a: which records go to the device, their reference segments and sizes ---------------------------------------
-    double tm = omp_get_wtime();
+    double tm0 = now();
     std::vector<int> idx;                         // device order -> batch index
     for (int i = 0; i < n_all; ++i) {
-        reads[i].status = NP_BATCH_OK;
         const bool fits = device_ok && !reads[i].rna && reads[i].record && reads[i].read_sequence && reads[i].read_sequence->size() >= k &&
                           (reads[i].raw_pa || reads[i].raw_adc) && reads[i].n_raw >= 64;
-        if (!fits) { reads[i].status = NP_BATCH_HOST_PATH; continue; }
+        if (!fits) { S.status[i] = NP_BATCH_HOST_PATH; continue; }
         if (!have_meth) continue;                                            // an empty map (basemods.cpp:280-287)
         S.dev_index[i] = (int)idx.size(); idx.push_back(i);
     }
@@ -180,7 +340,8 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
     // src/alignment/nanopolish_eventalign.cpp:207-221: faidx_fetch_seq is not thread-safe) -- serial work per record.  The records
     // of a BamProcessor batch come from a sorted BAM: when the batch's records on one contig cover a compact stretch, ONE fetch of
     // their union serves them all (faidx clips a range to the contig, so a slice of the clipped union is what the clipped
-    // per-record fetch returns); a scattered batch keeps the per-record fetches.
+    // per-record fetch returns) and every record's segment is a VIEW into it -- nothing is copied per record; a scattered batch
+    // keeps the per-record fetches.
     std::map<int, std::pair<int, int> > span;           // tid -> [lowest pos, highest end] of the batch's records
     std::map<int, int64_t> covered;
     bool all_adc = true;
@@ -194,31 +355,41 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
         covered[record->core.tid] += hi - lo + 1;
         all_adc = all_adc && reads[idx[q]].raw_adc != NULL;
     }
-    std::map<int, std::string> union_seq;
     for (std::map<int, std::pair<int, int> >::const_iterator it = span.begin(); it != span.end(); ++it) {
         const int64_t len = (int64_t)it->second.second - it->second.first + 1;
         if (len <= (64 << 20) && len <= 4 * covered[it->first] + (1 << 20)) {
             int fetched_len = 0;
-            union_seq[it->first] = get_reference_region_ts(p->fai, p->hdr->target_name[it->first], it->second.first, it->second.second, &fetched_len);
+            S.union_seq[it->first] = get_reference_region_ts(fai, hdr->target_name[it->first], it->second.first, it->second.second, &fetched_len);
+            S.union_lo[it->first] = it->second.first;
         }
     }
-    #pragma omp parallel for schedule(dynamic, 16)
-    for (int q = 0; q < n; ++q) {
+    for (int q = 0; q < n; ++q) {                          // records no union serves: the reference's own per-record fetch (serial: faidx)
         const int i = idx[q];
         const bam1_t* record = reads[i].record;
-        std::map<int, std::string>::const_iterator u = union_seq.find(record->core.tid);
-        if (u != union_seq.end()) {
-            const int64_t off = (int64_t)record->core.pos - span[record->core.tid].first, want = (int64_t)bam_endpos(record) - record->core.pos + 1;
-            const int64_t have = (int64_t)u->second.size() - off;
-            S.ref_seqs[i] = have > 0 ? u->second.substr((size_t)off, (size_t)std::min(want, have)) : std::string();
-        } else {
-            int fetched_len = 0;
-            S.ref_seqs[i] = get_reference_region_ts(p->fai, p->hdr->target_name[record->core.tid], record->core.pos, bam_endpos(record), &fetched_len);   // :258-270
-        }
-        // Alphabet::disambiguate (upper-casing + IUPAC codes -> their first base) is the identity on an upper-case ACGT string, and
-        // it builds one std::string per character: 0.3 ms of a host core per 5 kb read.  Only a segment that needs it gets it.
-        if (!is_plain_acgt(S.ref_seqs[i])) S.ref_seqs[i] = gDNAAlphabet.disambiguate(S.ref_seqs[i]);
+        if (S.union_seq.find(record->core.tid) != S.union_seq.end()) continue;
+        int fetched_len = 0;
+        S.own_seq[i] = get_reference_region_ts(fai, hdr->target_name[record->core.tid], record->core.pos, bam_endpos(record), &fetched_len);   // :258-270
     }
+    // Alphabet::disambiguate (upper-casing + IUPAC codes -> their first base) is the identity on an upper-case ACGT string, and it
+    // builds one std::string per character: 0.3 ms of a host core per 5 kb read.  Only a segment that needs it gets it (as its own copy).
+    pool->run(n, 32, [&](int q) {
+        const int i = idx[q];
+        const bam1_t* record = reads[i].record;
+        std::map<int, std::string>::const_iterator u = S.union_seq.find(record->core.tid);
+        RefView v;
+        if (u != S.union_seq.end()) {
+            const int64_t off = (int64_t)record->core.pos - S.union_lo.find(record->core.tid)->second, want = (int64_t)bam_endpos(record) - record->core.pos + 1;
+            const int64_t have = (int64_t)u->second.size() - off;
+            if (have > 0) { v.p = u->second.data() + off; v.n = (size_t)std::min(want, have); }
+        } else { v.p = S.own_seq[i].data(); v.n = S.own_seq[i].size(); }
+        bool plain = true;
+        for (size_t t = 0; t < v.n; ++t) if (base_code(v.p[t]) > 3) { plain = false; break; }
+        if (!plain) {
+            S.own_seq[i] = gDNAAlphabet.disambiguate(std::string(v.p, v.n));
+            v.p = S.own_seq[i].data(); v.n = S.own_seq[i].size();
+        }
+        S.ref[i] = v;
+    });
     std::vector<int64_t> raw_off(n + 1, 0), event_off(n + 1, 0), rank_off(n + 1, 0), cigar_off(n + 1, 0), jr_off(n + 1, 0),
                          pair_off(n + 1, 0), genome_off(n + 1, 0);
     std::vector<int64_t>& group_off = S.group_off;
@@ -226,7 +397,7 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
     for (int q = 0; q < n; ++q) {
         const int i = idx[q];
         const bam1_t* record = reads[i].record;
-        const int64_t n_raw = (int64_t)reads[i].n_raw, L = (int64_t)reads[i].read_sequence->size(), ln = (int64_t)S.ref_seqs[i].size();
+        const int64_t n_raw = (int64_t)reads[i].n_raw, L = (int64_t)reads[i].read_sequence->size(), ln = (int64_t)S.ref[i].n;
         const int64_t ecap = n_raw / g_event_cap_divisor + 2, nk = L - k + 1, gcap = ln / (MINSEP + 1) + 2;
         raw_off[q + 1] = raw_off[q] + n_raw;
         event_off[q + 1] = event_off[q] + ecap;
@@ -268,13 +439,13 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
                  s_ev_stdv = ls.add((size_t)n_ev * 4), s_ev_start = ls.add((size_t)n_ev * 4), s_map_start = ls.add((size_t)n_rk * 4),
                  s_map_stop = ls.add((size_t)n_rk * 4), s_pairs = ls.add((size_t)pair_off[n] * sizeof(np_pair)),
                  s_job_ranks = ls.add((size_t)jr_off[n] * sizeof(uint16_t));
-    p->t[0] += omp_get_wtime() - tm; tm = omp_get_wtime();
+    add_time(0, now() - tm0); tm0 = now();
     S.in.reserve(c, li.size + 256); S.out.reserve(c, lo.size + 256);
-    if (ls.size + 256 > p->scratch.cap) {
-        check(np_sync(c, NULL), "np_sync");                  // the batch in flight still computes in the scratch that is about to be replaced
-        p->scratch.reserve(c, ls.size + 256);
+    if (ls.size + 256 > D.scratch.cap) {
+        check(np_sync(c, NULL), "np_sync");                  // the batch in flight on this device still computes in the scratch that is about to be replaced
+        D.scratch.reserve(c, ls.size + 256);
     }
-    p->t[5] += omp_get_wtime() - tm; tm = omp_get_wtime();
+    add_time(5, now() - tm0); tm0 = now();
 
     // ---- phase 1b: pack the pinned input blob -----------------------------------------------------------------------------
     char* H = S.in.h;
@@ -282,8 +453,7 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
     np_read_dev* h_reads_a = (np_read_dev*)(H + i_reads_a); np_read_dev* h_reads_b = (np_read_dev*)(H + i_reads_b);
     char* h_genome = H + i_genome; int64_t* h_ref_begin = (int64_t*)(H + i_ref_begin); int32_t* h_ref_len = (int32_t*)(H + i_ref_len);
     int32_t* h_read_len = (int32_t*)(H + i_read_len); uint32_t* h_cigar = (uint32_t*)(H + i_cigar); uint8_t* h_rc = (uint8_t*)(H + i_rc);
-    #pragma omp parallel for schedule(dynamic)
-    for (int q = 0; q < n; ++q) {
+    pool->run(n, 4, [&](int q) {
         const int i = idx[q];
         const bam1_t* record = reads[i].record;
         const std::string& seq = *reads[i].read_sequence;
@@ -296,34 +466,34 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
         else for (size_t t = 0; t < reads[i].n_raw; ++t)            // the loader's conversion, fp32 (fast5_loader.cpp:96-103)
             h_raw[raw_off[q] + t] = ((float)reads[i].raw_adc[t] + reads[i].adc_offset) * reads[i].adc_raw_unit;
         nucleotide_kmer_ranks(seq, k, h_ranks + rank_off[q]);
-        memcpy(h_genome + genome_off[q], S.ref_seqs[i].data(), S.ref_seqs[i].size());
-        h_ref_begin[q] = genome_off[q]; h_ref_len[q] = (int32_t)S.ref_seqs[i].size();
+        memcpy(h_genome + genome_off[q], S.ref[i].p, S.ref[i].n);
+        h_ref_begin[q] = genome_off[q]; h_ref_len[q] = (int32_t)S.ref[i].n;
         memcpy(h_cigar + cigar_off[q], bam_get_cigar(record), 4 * (size_t)record->core.n_cigar);
         h_read_len[q] = (int32_t)seq.size();
         h_rc[q] = bam_is_rev(record) ? 1 : 0;
-    }
+    });
     memcpy(H + i_raw_off, raw_off.data(), (size_t)(n + 1) * 8); memcpy(H + i_event_off, event_off.data(), (size_t)(n + 1) * 8);
     memcpy(H + i_cigar_off, cigar_off.data(), (size_t)(n + 1) * 8); memcpy(H + i_group_off, group_off.data(), (size_t)(n + 1) * 8);
     memcpy(H + i_jr_off, jr_off.data(), (size_t)(n + 1) * 8); memcpy(H + i_pair_off, pair_off.data(), (size_t)(n + 1) * 8);
 
-    p->t[1] += omp_get_wtime() - tm; tm = omp_get_wtime();
+    add_time(1, now() - tm0); tm0 = now();
     // ---- phase 2: one upload, the batch on the device, one read-back -----------------------------------------------------------
-    const int m_nuc = shim().model_id(pm_nuc);
-    const int m_meth = shim().model_id(PoreModelSet::get_model(p->kit, p->params.methylation_type, strand_name, k));
-    check(np_copy_to_device(c, p->s_h2d, S.in.d, S.in.h, li.size), "np_copy_to_device");
-    check(np_event_record(c, S.ev_h2d, p->s_h2d), "np_event_record");
+    const int m_nuc = shim().model_id(pm_nuc, D.slot_key);
+    const int m_meth = shim().model_id(PoreModelSet::get_model(kit, params.methylation_type, strand_name, k), D.slot_key);
+    check(np_copy_to_device(c, D.s_h2d, S.in.d, S.in.h, li.size), "np_copy_to_device");
+    check(np_event_record(c, S.ev_h2d, D.s_h2d), "np_event_record");
     check(np_stream_wait_event(c, NULL, S.ev_h2d), "np_stream_wait_event");
     check(np_memset_dev(c, NULL, S.out.d, 0, lo.size), "np_memset_dev");
-    check(np_memset_dev(c, NULL, p->scratch.d, 0, zero_bytes), "np_memset_dev");
+    check(np_memset_dev(c, NULL, D.scratch.d, 0, zero_bytes), "np_memset_dev");
     {
-        char* D = S.in.d; char* O = S.out.d; char* X = p->scratch.d;
-        float* raw = all_adc ? (float*)(p->scratch.d + s_raw_pa) : (float*)(D + i_raw); uint16_t* ranks = (uint16_t*)(D + i_ranks);
-        np_read_dev* reads_a = (np_read_dev*)(D + i_reads_a); np_read_dev* reads_b = (np_read_dev*)(D + i_reads_b);
-        int64_t *d_raw_off = (int64_t*)(D + i_raw_off), *d_event_off = (int64_t*)(D + i_event_off), *d_cigar_off = (int64_t*)(D + i_cigar_off),
-                *d_group_off = (int64_t*)(D + i_group_off), *d_jr_off = (int64_t*)(D + i_jr_off), *d_pair_off = (int64_t*)(D + i_pair_off),
-                *ref_begin = (int64_t*)(D + i_ref_begin);
-        int32_t *ref_len = (int32_t*)(D + i_ref_len), *read_len = (int32_t*)(D + i_read_len);
-        uint32_t* cigar = (uint32_t*)(D + i_cigar); uint8_t* rc = (uint8_t*)(D + i_rc); char* genome = D + i_genome;
+        char* Dv = S.in.d; char* O = S.out.d; char* X = D.scratch.d;
+        float* raw = all_adc ? (float*)(X + s_raw_pa) : (float*)(Dv + i_raw); uint16_t* ranks = (uint16_t*)(Dv + i_ranks);
+        np_read_dev* reads_a = (np_read_dev*)(Dv + i_reads_a); np_read_dev* reads_b = (np_read_dev*)(Dv + i_reads_b);
+        int64_t *d_raw_off = (int64_t*)(Dv + i_raw_off), *d_event_off = (int64_t*)(Dv + i_event_off), *d_cigar_off = (int64_t*)(Dv + i_cigar_off),
+                *d_group_off = (int64_t*)(Dv + i_group_off), *d_jr_off = (int64_t*)(Dv + i_jr_off), *d_pair_off = (int64_t*)(Dv + i_pair_off),
+                *ref_begin = (int64_t*)(Dv + i_ref_begin);
+        int32_t *ref_len = (int32_t*)(Dv + i_ref_len), *read_len = (int32_t*)(Dv + i_read_len);
+        uint32_t* cigar = (uint32_t*)(Dv + i_cigar); uint8_t* rc = (uint8_t*)(Dv + i_rc); char* genome = Dv + i_genome;
         float* scores = (float*)(O + S.o_scores);
         int32_t *first = (int32_t*)(O + S.o_first), *last = (int32_t*)(O + S.o_last), *n_motif = (int32_t*)(O + S.o_n_motif),
                 *n_groups = (int32_t*)(O + S.o_n_groups), *n_events = (int32_t*)(O + S.o_n_events), *n_pairs = (int32_t*)(O + S.o_n_pairs),
@@ -342,8 +512,8 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
                                          FLANK, d_group_off, n_slots, d_jr_off, jobs, kpos, job_ranks, first, last, n_motif, n_groups, deg),
               "np_cm_build_jobs_cigar_dev");
         if (all_adc)
-            check(np_adc_to_pa_dev(c, NULL, n, (const int16_t*)(D + i_raw), d_raw_off, max_samples, (const float*)(D + i_adc_offset),
-                                   (const float*)(D + i_adc_unit), raw), "np_adc_to_pa_dev");
+            check(np_adc_to_pa_dev(c, NULL, n, (const int16_t*)(Dv + i_raw), d_raw_off, max_samples, (const float*)(Dv + i_adc_offset),
+                                   (const float*)(Dv + i_adc_unit), raw), "np_adc_to_pa_dev");
         check(np_detect_events_dev(c, NULL, n, raw, d_raw_off, max_samples, &prm, tstat, d_event_off, max_events, ev_start, ev_len, ev_mean,
                                    ev_stdv, n_events), "np_detect_events_dev");
         check(np_mom_fill_dev(c, NULL, n, reads_a, reads_b, ev_mean, n_events, ranks, m_nuc), "np_mom_fill_dev");
@@ -354,49 +524,41 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
         check(np_hmm_score_dev(c, NULL, n_jobs, jobs, reads_b, ev_mean, job_ranks, m_meth, scores), "np_hmm_score_dev");
     }
     check(np_event_record(c, S.ev_cmp, NULL), "np_event_record");
-    check(np_stream_wait_event(c, p->s_d2h, S.ev_cmp), "np_stream_wait_event");
-    check(np_copy_to_host(c, p->s_d2h, S.out.h, S.out.d, lo.size), "np_copy_to_host");
-    check(np_event_record(c, S.ev_d2h, p->s_d2h), "np_event_record");
-    p->t[2] += omp_get_wtime() - tm;
+    check(np_stream_wait_event(c, D.s_d2h, S.ev_cmp), "np_stream_wait_event");
+    check(np_copy_to_host(c, D.s_d2h, S.out.h, S.out.d, lo.size), "np_copy_to_host");
+    check(np_event_record(c, S.ev_d2h, D.s_d2h), "np_event_record");
+    add_time(2, now() - tm0);
 }
 
-bool NpBatchPipeline::collect(MethylationCallingResult& result)
+// ---- phase 3 of one batch (the finisher thread): wait for the read-back, build the ScoredSite maps (basemods.cpp:384-413) -----------
+void NpBatchPipeline::Impl::finish(Slot& S)
 {
-    if (in_flight() <= 0) return false;
-    np_ctx* c = p->c;
-    Slot& S = p->slot[p->n_collected & 1];
-    p->n_collected += 1;
-    std::vector<NpBatchRead>& reads = *S.reads;
+    np_ctx* c = devs[S.dev]->c;
+    std::vector<NpBatchRead>& reads = S.rec;
     const int n = (int)reads.size();
-    if (n == 0) return true;
-    double tm = omp_get_wtime();
+    S.built.clear(); S.built.resize(n); S.builder.assign(n, -1);
+    if (n == 0) return;
+    double tm0 = now();
     if (S.n_dev > 0) check(np_event_sync(c, S.ev_d2h), "np_event_sync");
-    p->t[3] += omp_get_wtime() - tm; tm = omp_get_wtime();
+    add_time(3, now() - tm0); tm0 = now();
+    if (S.n_dev == 0) return;
     const char* O = S.out.h;
     const float* scores = (const float*)(O + S.o_scores);
     const int32_t *first = (const int32_t*)(O + S.o_first), *last = (const int32_t*)(O + S.o_last), *n_motif = (const int32_t*)(O + S.o_n_motif),
                   *n_groups = (const int32_t*)(O + S.o_n_groups), *n_events = (const int32_t*)(O + S.o_n_events),
                   *n_pairs = (const int32_t*)(O + S.o_n_pairs), *calibrated = (const int32_t*)(O + S.o_calibrated);
     const uint32_t k = 6;
-
-    // ---- phase 3: ScoredSite maps (basemods.cpp:384-413) ------------------------------------------------------------------
-    // the per-record maps are created serially (result is one std::map), then filled in parallel: records are independent
-    std::vector<std::map<int, ScoredSite>*> maps(n, (std::map<int, ScoredSite>*)NULL);
-    for (int i = 0; i < n; ++i) {
-        if (reads[i].status == NP_BATCH_HOST_PATH) continue;            // decided in phase 1: the caller's per-record function fills its map
-        maps[i] = &result[reads[i].record];                              // the (possibly empty) map of the record, basemods.cpp:253-256
-    }
-    #pragma omp parallel for schedule(dynamic, 16)
-    for (int i = 0; i < n; ++i) {
+    pool->run(n, 8, [&](int i) {
         const bam1_t* record = reads[i].record;
-        if (!maps[i]) continue;
-        std::map<int, ScoredSite>& site_score_map = *maps[i];
+        S.builder[i] = Pool::current_worker();
+        if (S.status[i] == NP_BATCH_HOST_PATH) return;                    // decided in phase 1: the caller's per-record function fills its map
+        std::map<int, ScoredSite>& site_score_map = S.built[i];
         const int q = S.dev_index[i];
-        if (q < 0) continue;                                             // no motif model for the kit: the map stays empty
-        if (n_events[q] < 0 || n_groups[q] < 0) { reads[i].status = NP_BATCH_HOST_PATH; continue; }   // NP_ED_INEXACT / NP_ED_OVERFLOW / capacity
-        if (n_pairs[q] <= 0 || !calibrated[q]) { reads[i].status = NP_BATCH_NO_EVENTS; continue; }
-        const std::string contig = p->hdr->target_name[record->core.tid];
-        const std::string& ref_seq = S.ref_seqs[i];
+        if (q < 0) return;                                                // no motif model for the kit: the map stays empty
+        if (n_events[q] < 0 || n_groups[q] < 0) { S.status[i] = NP_BATCH_HOST_PATH; return; }   // NP_ED_INEXACT / NP_ED_OVERFLOW / capacity
+        if (n_pairs[q] <= 0 || !calibrated[q]) { S.status[i] = NP_BATCH_NO_EVENTS; return; }
+        const std::string contig = hdr->target_name[record->core.tid];
+        const RefView ref_seq = S.ref[i];
         const int strand_idx = 0;
         for (int g = 0; g < n_groups[q]; ++g) {
             const int64_t slot = S.group_off[q] + g;
@@ -404,25 +566,84 @@ bool NpBatchPipeline::collect(MethylationCallingResult& result)
             if (unmethylated_score != unmethylated_score || methylated_score != methylated_score) continue;   // a group the caller rules skip
             const int start_position = first[slot] + S.ref_start[i];
             const int end_position = last[slot] + S.ref_start[i];
-            if ((p->region_start != -1 && start_position < p->region_start) || (p->region_end != -1 && end_position >= p->region_end)) continue;
-            std::map<int, ScoredSite>::iterator iter = site_score_map.find(start_position);
-            if (iter == site_score_map.end()) {
-                ScoredSite ss;
+            if ((region_start != -1 && start_position < region_start) || (region_end != -1 && end_position >= region_end)) continue;
+            // groups come in ascending reference order: a new site goes to the END of the map, constructed in place (the reference's
+            // find + copy-insert costs two tree descents, a temporary ScoredSite and a second copy of its strings); a position that
+            // is already there -- the second strand of a 2D read in the reference's loop, never on this path -- takes the general route
+            std::map<int, ScoredSite>::iterator iter;
+            if (site_score_map.empty() || site_score_map.rbegin()->first < start_position) {
+                iter = site_score_map.emplace_hint(site_score_map.end(), std::piecewise_construct, std::forward_as_tuple(start_position), std::forward_as_tuple());
+                ScoredSite& ss = iter->second;
                 ss.chromosome = contig;
                 ss.start_position = start_position;
                 ss.end_position = end_position;
                 ss.n_motif = n_motif[slot];
                 const size_t site_output_start = first[slot] - k + 1, site_output_end = last[slot] + k;
-                ss.sequence = ref_seq.substr(site_output_start, site_output_end - site_output_start);
-                iter = site_score_map.insert(std::make_pair(start_position, ss)).first;
+                if (site_output_start < ref_seq.n) ss.sequence.assign(ref_seq.p + site_output_start, std::min(site_output_end - site_output_start, ref_seq.n - site_output_start));
+            } else {
+                iter = site_score_map.find(start_position);
+                if (iter == site_score_map.end()) {
+                    ScoredSite ss;
+                    ss.chromosome = contig;
+                    ss.start_position = start_position;
+                    ss.end_position = end_position;
+                    ss.n_motif = n_motif[slot];
+                    const size_t site_output_start = first[slot] - k + 1, site_output_end = last[slot] + k;
+                    if (site_output_start < ref_seq.n) ss.sequence.assign(ref_seq.p + site_output_start, std::min(site_output_end - site_output_start, ref_seq.n - site_output_start));
+                    iter = site_score_map.insert(std::make_pair(start_position, ss)).first;
+                }
             }
             iter->second.ll_unmethylated[strand_idx] = unmethylated_score;
             iter->second.ll_methylated[strand_idx] = methylated_score;
             iter->second.strands_scored += 1;
         }
+    }, false /* on the workers only: see Impl::builder_of */);
+    add_time(4, now() - tm0);
+}
+
+bool NpBatchPipeline::collect(MethylationCallingResult& result)
+{
+    Slot* Sp;
+    const double t0 = now();
+    {
+        std::unique_lock<std::mutex> g(p->m);
+        if (p->n_collected >= p->n_submitted) return false;
+        Sp = p->slots[p->n_collected % (long)p->slots.size()];
+        while (!Sp->finished) p->cv.wait(g);                    // (the two finishers may end out of order: collect() keeps submission order)
     }
-    p->t[4] += omp_get_wtime() - tm;
+    p->add_time(6, now() - t0);
+    Slot& S = *Sp;
+    std::vector<NpBatchRead>& reads = *S.caller;
+    const int n = (int)S.rec.size();
+    for (int i = 0; i < n; ++i) {
+        reads[i].status = S.status[i];
+        if (S.status[i] == NP_BATCH_HOST_PATH) continue;                 // the caller's per-record function fills (and creates) its map
+        result[S.rec[i].record].swap(S.built[i]);                         // the (possibly empty) map of the record, basemods.cpp:253-256
+        p->builder_of[S.rec[i].record] = S.builder[i];
+    }
+    S.built.clear();
+    { std::lock_guard<std::mutex> g(p->m); S.finished = false; p->n_collected += 1; }
+    p->cv.notify_all();
     return true;
+}
+
+void NpBatchPipeline::recycle(MethylationCallingResult& result)
+{
+    typedef std::vector<std::map<int, ScoredSite> > Maps;
+    const int W = p->pool->threads();
+    std::vector<std::shared_ptr<Maps> > mine(W + 1);
+    for (MethylationCallingResult::iterator it = result.begin(); it != result.end(); ++it) {
+        if (it->second.empty()) continue;
+        std::map<const bam1_t*, int>::iterator b = p->builder_of.find(it->first);
+        const int w = b != p->builder_of.end() && b->second >= 0 && b->second < W ? b->second : W;       // W: built elsewhere (the caller's host path)
+        if (b != p->builder_of.end()) p->builder_of.erase(b);
+        if (!mine[w]) mine[w] = std::make_shared<Maps>();
+        mine[w]->push_back(std::map<int, ScoredSite>());
+        mine[w]->back().swap(it->second);
+    }
+    for (int w = 0; w < W; ++w)
+        if (mine[w]) { std::shared_ptr<Maps> g = mine[w]; p->pool->post_to(w, [g]() { g->clear(); }); }
+    if (mine[W]) { std::shared_ptr<Maps> g = mine[W]; p->pool->post((int)g->size(), 32, [g](int i) { std::map<int, ScoredSite>().swap((*g)[i]); }, [g]() {}); }
 }
 
 extern "C" void np_batch_set_event_capacity_divisor(int divisor) { g_event_cap_divisor = divisor >= 2 ? divisor : 2; }

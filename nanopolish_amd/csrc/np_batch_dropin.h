@@ -1,5 +1,5 @@
 // np_batch_dropin.h -- the batched reference-side bindings (see np_batch_dropin.cpp): call-methylation's per-record work for whole
-// BamProcessor batches, as a synchronous call and as a double-buffered pipeline.
+// BamProcessor batches, as a synchronous call and as a pipeline with its own host worker threads over one or several GPUs.
 #pragma once
 #include <string>
 #include <vector>
@@ -38,28 +38,46 @@ void np_calculate_methylation_for_batch(MethylationCallingResult& result, std::v
                                         const MethylationCallingParameters& calling_parameters, const std::string& kit,
                                         const faidx_t* fai, const bam_hdr_t* hdr, int region_start, int region_end);
 
-// The production feed: the same pass, double-buffered.  Two batches can be in flight: while the device works on batch k (one
-// upload, the kernels, one read-back, on three HIP streams ordered by events) the caller reads batch k+1 from the BAM / signal
-// files and submits it; collect() returns batches in submission order.  All device and pinned-host buffers persist and only
-// grow.  BamProcessor's loop (bam_processor.cpp:90-119) becomes
-//     while (read a batch into recs[k & 1]) { pipe.submit(recs[k & 1]); if (k > 0) pipe.collect(result_of(k - 1)); ++k; }
-//     pipe.collect(result_of(k - 1));
-// (INTEGRATION.md section 2).  The read vector, the records and the buffers its entries point to must stay alive and unchanged
-// until the batch has been collected.
+// The production feed: the same pass as a three-stage pipeline that does not borrow the caller's threads.
+//
+//     submit(batch k+1)  -> [pack: reference segments, k-mer ranks, samples into one pinned blob]      the pipeline's packer thread
+//                        -> [device: one upload, the kernels, one read-back; three HIP streams]        + its worker pool
+//                        -> [results: one std::map<int, ScoredSite> per record]                       the finisher thread + the pool
+//     collect(batch k-1)    hands the finished maps over (a swap per record)
+//
+// submit() returns as soon as the batch is queued; collect() returns batches in submission order and blocks until the oldest one
+// is finished.  With `devices` = {0, 1, ..., N-1} the pipeline owns one library context per listed GPU and deals batches to them
+// round-robin (the same device may be listed twice: two contexts on one GPU).  `max_in_flight()` batches may be in flight (three per
+// device: one in each stage); submit() with that many already in flight is an error.  BamProcessor's loop
+// (bam_processor.cpp:90-119) becomes
+//     while (read a batch into recs[k % n]) { pipe.submit(recs[k % n]); if (pipe.in_flight() == pipe.max_in_flight()) { pipe.collect(res); write(res); pipe.recycle(res); } ++k; }
+//     while (pipe.collect(res)) { write(res); pipe.recycle(res); }
+// (INTEGRATION.md section 2).  LIFETIME: the read vector, the records and every buffer its entries point to (sequence, samples) must
+// stay alive and unchanged from submit() until the batch has been collected -- packing runs after submit() has returned.
 class NpBatchPipeline {
 public:
     NpBatchPipeline(const MethylationCallingParameters& calling_parameters, const std::string& kit, const faidx_t* fai,
-                    const bam_hdr_t* hdr, int region_start, int region_end);
+                    const bam_hdr_t* hdr, int region_start, int region_end);                     // one GPU: the process-wide context (NP_DEVICE)
+    NpBatchPipeline(const MethylationCallingParameters& calling_parameters, const std::string& kit, const faidx_t* fai,
+                    const bam_hdr_t* hdr, int region_start, int region_end, const std::vector<int>& devices,
+                    int host_threads = 0 /* worker threads; 0: the CPUs this process may use (affinity mask, cgroup quota), NP_HOST_THREADS */);
     ~NpBatchPipeline();
     void configure(const MethylationCallingParameters& calling_parameters, const std::string& kit, const faidx_t* fai,
                    const bam_hdr_t* hdr, int region_start, int region_end);        // only with nothing in flight
-    void submit(std::vector<NpBatchRead>& reads);              // at most two batches in flight (exits with a message otherwise)
+    void submit(std::vector<NpBatchRead>& reads);
     bool collect(MethylationCallingResult& result);           // the oldest batch in flight; false if there is none
+    // Takes the site maps of a batch the caller has written out back and destroys them on the pipeline's workers, off the caller's
+    // thread (a batch of 8 192 reads holds 1.5 M ScoredSites, two heap blocks each: `results.clear()` on the writer's thread,
+    // src/nanopolish_call_methylation.cpp:587, costs more than the device pass).  The outer map keeps its (now empty) entries.
+    void recycle(MethylationCallingResult& result);
     int in_flight() const;
+    int max_in_flight() const;
+    int devices() const;
     // host wall-clock seconds spent in the phases since construction (diagnostics; tests/bench_batch_dropin.py prints them):
     // [0] phase 1a reference fetch + sizes, [1] phase 1b packing the pinned blob, [2] enqueueing copies and kernels,
-    // [3] collect: waiting for the device, [4] phase 3 ScoredSite maps, [5] buffer growth (allocation)
-    void host_seconds(double out[6]) const;
+    // [3] finisher waiting for the device, [4] phase 3 ScoredSite maps, [5] buffer growth (allocation), [6] collect() waiting for a
+    // finished batch (the caller's thread), [7] submit() (the caller's thread)
+    void host_seconds(double out[8]) const;
     struct Impl;
 private:
     Impl* p;

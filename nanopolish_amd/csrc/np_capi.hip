@@ -14,7 +14,7 @@
 #include "np_logf.h"
 
 #define NP_VERSION_STR "nanopolish_amd 0.1 (gfx950)"
-#define NP_FLANK_LEN (1u << 20)
+#define NP_FLANK_LEN NP_MAX_WINDOW_EVENTS
 #define NP_NUM_FAMILIES 9      // 0 event align, 1 forward HMM, 2 glue, 3 Viterbi, 4 event detection, 5 MoM scalings, 6 eventalign chain,
                                // 7 the event aligner's back-track when launched on its own (np_event_align_split_dev), 8 work items built on the side
                                // stream (cm_async: the interval runs beside the event aligner; in order, they are part of family 2)
@@ -594,7 +594,7 @@ void* np_event_create(np_ctx* c)
     std::lock_guard<std::mutex> g(c->lock);
     hipEvent_t e = nullptr;
     if (hipSetDevice(c->device) != hipSuccess) return nullptr;
-    const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync);
     if (rc != hipSuccess) { c->err = std::string("np_event_create: ") + hipGetErrorString(rc); return nullptr; }
     return (void*)e;
 }
@@ -630,6 +630,16 @@ int np_event_sync(np_ctx* c, void* ev)
     if (!c || !ev) return NP_ERR_INVALID;
     NP_HIP(c, hipEventSynchronize((hipEvent_t)ev));       // (no lock: other threads keep enqueueing while this one waits)
     return NP_OK;
+}
+
+int np_event_query(np_ctx* c, void* ev)
+{
+    if (!c || !ev) return NP_ERR_INVALID;
+    const hipError_t e = hipEventQuery((hipEvent_t)ev);
+    if (e == hipSuccess) return NP_OK;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 1; }
+    c->err = std::string("np_event_query: ") + hipGetErrorString(e);
+    return NP_ERR_DEVICE;
 }
 
 int np_sync(np_ctx* c, void* stream)

@@ -25,40 +25,71 @@ inline uint64_t model_hash(const PoreModel* m, size_t step)
 }
 
 struct Shim {
-    np_ctx* ctx;
     // The cache is keyed by address, and the reference overwrites registered models in place (PoreModelSet::register_model,
     // src/pore_model/nanopolish_pore_model_set.cpp:70 -- methyltrain's add_model every training round): an entry is only valid
     // while the model's content matches what was uploaded.  Per call that is checked with a FINGERPRINT (size + 64 evenly spaced
     // states: a few hundred bytes, so the OpenMP callers of the per-call shim do not serialise on a 100-370 KB hash); the FULL
-    // hash runs when the fingerprint differs or after np_dropin_invalidate_models(), which a caller that edits single states in
-    // place (a training round) calls once per round.
-    struct Entry { int id; uint64_t fingerprint, hash; size_t n; bool check_full; };
-    std::map<const PoreModel*, Entry> models;
+    // hash runs when the fingerprint differs, after np_dropin_invalidate_models() -- which a caller that edits single states in
+    // place (a training round) calls once per round -- and, as a backstop for callers that never call it, on every
+    // 256th use of an entry.
+    struct Entry { int id; uint64_t fingerprint, hash; size_t n; bool check_full; unsigned uses; };
+    // One library context per (process, slot).  Slot 0 is the process-wide default (device NP_DEVICE, or 0): the per-call shim and
+    // the synchronous bindings use it.  NpBatchPipeline's multi-device form opens one more slot per listed device -- the same
+    // device may be listed twice (two contexts on one GPU: tests) -- and keeps them for the life of the process.
+    struct Dev { np_ctx* ctx; int device; bool in_use; std::map<const PoreModel*, Entry> models; Dev() : ctx(NULL), device(0), in_use(false) {} };
+    std::vector<Dev*> devs;
     std::mutex lock;
-    Shim() : ctx(NULL) {}
+    Shim() {}
 
-    np_ctx* get()
+    np_ctx* get() { return ctx(0); }
+
+    np_ctx* ctx(int slot)
     {
         std::lock_guard<std::mutex> g(lock);
-        if (!ctx) {
-            const char* dev = getenv("NP_DEVICE");
-            ctx = np_create(dev ? atoi(dev) : 0, NULL);
-            if (!ctx) { fprintf(stderr, "nanopolish_amd: %s\n", np_last_error(NULL)); exit(EXIT_FAILURE); }
+        if (devs.empty()) devs.push_back(new Dev());
+        if (slot < 0 || slot >= (int)devs.size()) { fprintf(stderr, "nanopolish_amd: no context slot %d\n", slot); exit(EXIT_FAILURE); }
+        Dev& d = *devs[slot];
+        if (!d.ctx) {
+            if (slot == 0) { const char* dev = getenv("NP_DEVICE"); d.device = dev ? atoi(dev) : 0; }
+            d.ctx = np_create(d.device, NULL);
+            if (!d.ctx) { fprintf(stderr, "nanopolish_amd: %s\n", np_last_error(NULL)); exit(EXIT_FAILURE); }
         }
-        return ctx;
+        return d.ctx;
     }
 
-    int model_id(const PoreModel* m)
+    // a context slot of its own on `device` for the caller (released with release_slot; the context and its model cache stay for the next taker)
+    int take_slot(int device)
     {
-        np_ctx* c = get();
+        {
+            std::lock_guard<std::mutex> g(lock);
+            if (devs.empty()) devs.push_back(new Dev());
+            for (size_t i = 1; i < devs.size(); ++i)
+                if (!devs[i]->in_use && devs[i]->device == device) { devs[i]->in_use = true; return (int)i; }
+            Dev* d = new Dev(); d->device = device; d->in_use = true;
+            devs.push_back(d);
+        }
+        const int slot = (int)devs.size() - 1;
+        (void)ctx(slot);
+        return slot;
+    }
+    void release_slot(int slot)
+    {
         std::lock_guard<std::mutex> g(lock);
+        if (slot > 0 && slot < (int)devs.size()) devs[slot]->in_use = false;
+    }
+
+    int model_id(const PoreModel* m, int slot = 0)
+    {
+        np_ctx* c = ctx(slot);
+        std::lock_guard<std::mutex> g(lock);
+        std::map<const PoreModel*, Entry>& models = devs[slot]->models;
         const size_t n = m->states.size();
         const size_t step = n > 64 ? n / 64 : 1;
         const uint64_t fp = model_hash(m, step);
         std::map<const PoreModel*, Entry>::iterator it = models.find(m);
-        if (it != models.end() && it->second.n == n && it->second.fingerprint == fp && !it->second.check_full) return it->second.id;
+        if (it != models.end() && it->second.n == n && it->second.fingerprint == fp && !it->second.check_full && (++it->second.uses & 255u) != 0) return it->second.id;
         const uint64_t h = model_hash(m, 1);
-        if (it != models.end() && it->second.n == n && it->second.hash == h) {          // invalidated, but unchanged
+        if (it != models.end() && it->second.n == n && it->second.hash == h) {          // invalidated (or the periodic full check), but unchanged
             it->second.fingerprint = fp; it->second.check_full = false;
             return it->second.id;
         }
@@ -72,7 +103,7 @@ struct Shim {
         }
         const int id = np_register_model(c, (int)m->k, (int)n, lm.data(), ls.data(), ll.data());
         if (id < 0) { fprintf(stderr, "nanopolish_amd: np_register_model: %s\n", np_last_error(c)); exit(EXIT_FAILURE); }
-        Entry e; e.id = id; e.fingerprint = fp; e.hash = h; e.n = n; e.check_full = false;
+        Entry e; e.id = id; e.fingerprint = fp; e.hash = h; e.n = n; e.check_full = false; e.uses = 0;
         models[m] = e;
         return id;
     }
@@ -80,7 +111,8 @@ struct Shim {
     void invalidate()
     {
         std::lock_guard<std::mutex> g(lock);
-        for (std::map<const PoreModel*, Entry>::iterator it = models.begin(); it != models.end(); ++it) it->second.check_full = true;
+        for (size_t d = 0; d < devs.size(); ++d)
+            for (std::map<const PoreModel*, Entry>::iterator it = devs[d]->models.begin(); it != devs[d]->models.end(); ++it) it->second.check_full = true;
     }
 };
 

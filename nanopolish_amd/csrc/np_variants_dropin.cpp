@@ -28,6 +28,7 @@ extern double hmm_indel_bias_factor;   // src/hmm/nanopolish_profile_hmm_r9.cpp:
 
 using np_shim::shim;
 using np_shim::check;
+using np_shim::die;
 using np_shim::Layout;
 using np_shim::Blob;
 
@@ -57,10 +58,14 @@ std::vector<double> np_profile_hmm_score_sets(const std::vector<const std::vecto
     std::map<std::pair<const SquiggleRead*, int>, int> read_index;
     std::vector<std::pair<const SquiggleRead*, int> > read_list;
     std::vector<int> set_read(n_sets);
+    // Preconditions are checked at run time (the reference's own are asserts, gone under NDEBUG): a set the device pass does not cover
+    // must not come back as a silent NaN (np_hmm_score_dev marks such work items with a NaN score).
+    std::vector<char> on_host(n_sets, 0);            // sets scored by the reference's per-call path instead (see below)
     for (size_t i = 0; i < n_sets; ++i) {
         const HMMInputData& d = *data[i];
-        assert(d.read->pore_type == PORETYPE_R9);
-        assert((d.rc && d.event_stride == -1) || (!d.rc && d.event_stride == 1));      // r9.inl:275
+        if (d.read->pore_type != PORETYPE_R9) die("np_profile_hmm_score_sets: only R9 reads are supported (profile_hmm.cpp:16-28 would take the R7 path)");
+        if (!((d.rc && d.event_stride == -1) || (!d.rc && d.event_stride == 1)))      // r9.inl:275
+            die("np_profile_hmm_score_sets: event stride does not match the strand (nanopolish_profile_hmm_r9.inl:275)");
         const std::pair<const SquiggleRead*, int> key(d.read, (int)d.strand);
         std::map<std::pair<const SquiggleRead*, int>, int>::iterator it = read_index.find(key);
         if (it == read_index.end()) { it = read_index.insert(std::make_pair(key, (int)read_list.size())).first; read_list.push_back(key); }
@@ -79,13 +84,22 @@ std::vector<double> np_profile_hmm_score_sets(const std::vector<const std::vecto
     for (size_t i = 0; i < n_sets; ++i) {
         const std::vector<HMMInputSequence>& seqs = *sets[i];
         const HMMInputData& d = *data[i];
-        assert(!seqs.empty());
-        assert(std::string(seqs[0].get_alphabet()->get_name()) == "nucleotide");
-        assert(std::string(d.pore_model->pmalphabet->get_name()) == "nucleotide");
+        if (seqs.empty()) die("np_profile_hmm_score_sets: an empty sequence set (profile_hmm.cpp:36)");
+        if (std::string(seqs[0].get_alphabet()->get_name()) != "nucleotide" || std::string(d.pore_model->pmalphabet->get_name()) != "nucleotide")
+            die("np_profile_hmm_score_sets: the first sequence of a set and the data's pore model must be over the nucleotide alphabet (profile_hmm.cpp:34-35)");
+        // what the kernels do not cover goes to the reference's per-call function for the WHOLE set: more than NP_MAX_KMERS k-mers, a
+        // sequence shorter than k, an event window longer than the clip-flank table
+        const uint64_t window = (uint64_t)(d.event_stop_idx > d.event_start_idx ? d.event_stop_idx - d.event_start_idx : d.event_start_idx - d.event_stop_idx) + 1;
         for (size_t s = 0; s < seqs.size(); ++s) {
             const PoreModel* pm = s == 0 ? d.pore_model : d.read->get_model(d.strand, seqs[s].get_alphabet()->get_name());
-            assert(pm != NULL);
-            assert(pm->states.size() == seqs[s].get_num_kmer_ranks(pm->k));          // r9.inl:305
+            if (pm == NULL) die("np_profile_hmm_score_sets: the read has no pore model for a sequence's alphabet");
+            if (seqs[s].length() < pm->k || seqs[s].length() - pm->k + 1 > NP_MAX_KMERS || window > NP_MAX_WINDOW_EVENTS) on_host[i] = 1;
+        }
+        if (on_host[i]) continue;
+        for (size_t s = 0; s < seqs.size(); ++s) {
+            const PoreModel* pm = s == 0 ? d.pore_model : d.read->get_model(d.strand, seqs[s].get_alphabet()->get_name());
+            if (pm->states.size() != seqs[s].get_num_kmer_ranks(pm->k))               // r9.inl:305
+                die("np_profile_hmm_score_sets: pore model and sequence alphabet disagree on the number of k-mers (nanopolish_profile_hmm_r9.inl:305)");
             k = pm->k;
             const std::pair<const HMMInputSequence*, int> key(&seqs[s], d.rc ? 1 : 0);
             if (rank_index.find(key) == rank_index.end()) {
@@ -111,7 +125,7 @@ std::vector<double> np_profile_hmm_score_sets(const std::vector<const std::vecto
     for (int r = 0; r < n_reads; ++r) {
         const SquiggleRead* sr = read_list[r].first; const int strand = read_list[r].second;
         const SquiggleScalings& sc = sr->scalings[strand];
-        assert(sc.drift == 0.0);                 // always 0 on the R9 path (squiggle_read.cpp:310, raw_loader.cpp:52)
+        if (sc.drift != 0.0) die("np_profile_hmm_score_sets: a read with a drift term (always 0 on the R9 path, squiggle_read.cpp:310)");   // (exit inside the parallel region: a precondition, not a device error)
         const size_t ne = sr->events[strand].size();
         for (size_t e = 0; e < ne; ++e) h_events[event_off[r] + e] = sr->events[strand][e].mean;
         np_fill_read_host(&h_reads[r], sc.shift, sc.scale, sc.var, event_off[r], (uint32_t)ne, 0, 1);
@@ -139,20 +153,28 @@ std::vector<double> np_profile_hmm_score_sets(const std::vector<const std::vecto
     (void)k;
 
     // ---- the batch on the device: one forward launch set per pore model -------------------------------------------------------------
-    check(np_copy_to_device(c, NULL, B.in.d, B.in.h, li.size), "np_copy_to_device");
+    if (n_jobs > 0) check(np_copy_to_device(c, NULL, B.in.d, B.in.h, li.size), "np_copy_to_device");
     for (size_t l = 0; l < launches.size(); ++l) {
         const int model = shim().model_id(launches[l].second.first);
         const int64_t j0 = launches[l].first, nj = launches[l].second.second;
         check(np_hmm_score_dev(c, NULL, nj, (const np_hmm_job_dev*)(B.in.d + i_jobs) + j0, (const np_read_dev*)(B.in.d + i_reads),
                                (const float*)(B.in.d + i_events), (const uint16_t*)(B.in.d + i_ranks), model, (float*)B.out.d + j0), "np_hmm_score_dev");
     }
-    check(np_copy_to_host(c, NULL, B.out.h, B.out.d, (size_t)n_jobs * sizeof(float)), "np_copy_to_host");
+    if (n_jobs > 0) check(np_copy_to_host(c, NULL, B.out.h, B.out.d, (size_t)n_jobs * sizeof(float)), "np_copy_to_host");
     check(np_sync(c, NULL), "np_sync");
     const float* sc = (const float*)B.out.h;
 
     // ---- profile_hmm_score_set's combination (profile_hmm.cpp:38-54), the reference's own add_logs ------------------------------------
     for (size_t i = 0; i < n_sets; ++i) {
+        if (on_host[i]) {
+            // the reference's own per-call function (in a drop-in build that is np_dropin.cpp's, which refuses sizes the library does
+            // not cover with NP_ERR_UNSUPPORTED and a message -- loudly, never a NaN)
+            result[i] = profile_hmm_score_set(*sets[i], *data[i], flags);
+            continue;
+        }
         const size_t num_models = sets[i]->size();
+        for (size_t s = 0; s < num_models; ++s)
+            if (sc[job_of[i][s]] != sc[job_of[i][s]]) die("np_profile_hmm_score_sets: the device returned no score for a work item (NaN)");
         const double num_model_penalty = log(num_models);
         double score = sc[job_of[i][0]] - num_model_penalty;
         for (size_t s = 1; s < num_models; ++s) {

@@ -283,9 +283,10 @@ def _batch_args(records):
     return n, raw, raw_off, cig, cig_off, is_rev, pos, seqs, bseqs
 
 
-def call_methylation_pipeline(records, contig_seq, batch_size, methylation_type="cpg", event_cap_divisor=2, rna=None, cap=65536, adc=None):
-    """The records through NpBatchPipeline (nanopolish_amd/csrc/np_batch_dropin.cpp) in batches of batch_size, two batches in
-    flight.  adc = (offset, raw_unit): the records carry int16 ADC counts in r["adc"] instead of pA samples (converted on the device).
+def call_methylation_pipeline(records, contig_seq, batch_size, methylation_type="cpg", event_cap_divisor=2, rna=None, cap=65536, adc=None, contexts=0):
+    """The records through NpBatchPipeline (nanopolish_amd/csrc/np_batch_dropin.cpp) in batches of batch_size, as many in flight as the
+    pipeline takes.  contexts = 0: the process-wide context; contexts = N >= 1: N contexts of the pipeline's own on device 0 (the
+    multi-GPU form on one device), batches dealt round-robin.  adc = (offset, raw_unit): the records carry int16 ADC counts in r["adc"] instead of pA samples (converted on the device).
     event_cap_divisor > 2 shrinks the device detector's event capacity (overflow route); rna: indices of records flagged
     as RNA reads.  Returns (list of per-record dicts of site arrays, status array)."""
     L = C.CDLL(_BATCH)
@@ -297,7 +298,7 @@ def call_methylation_pipeline(records, contig_seq, batch_size, methylation_type=
     st, en, nm = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
     lu, lm = np.zeros(cap, np.float64), np.zeros(cap, np.float64)
     counts = np.concatenate([np.ascontiguousarray(r["adc"], np.int16) for r in records]) if adc else None
-    tot = L.npfull_call_methylation_pipeline(n, int(batch_size), int(event_cap_divisor), _p(mask, _u8p),
+    tot = L.npfull_call_methylation_pipeline(n, int(batch_size), int(contexts), int(event_cap_divisor), _p(mask, _u8p),
                                              _p(counts, C.POINTER(C.c_int16)) if adc else None, C.c_float(adc[0] if adc else 0.0),
                                              C.c_float(adc[1] if adc else 1.0), seqs, _p(raw, C.POINTER(C.c_float)),
                                              _p(raw_off, C.POINTER(C.c_int64)), _p(is_rev, _i32p), _p(pos, _i32p), _p(cig, _u32p),
@@ -312,21 +313,24 @@ def call_methylation_pipeline(records, contig_seq, batch_size, methylation_type=
     return out, status
 
 
-def bench_batch(records, contig_seq, batch_size, n_batches, warmup=2, pipelined=True, adc=None):
+def bench_batch(records, contig_seq, batch_size, n_batches, warmup=2, pipelined=True, adc=None, contexts=0, consumer=1):
     """Seconds for n_batches batches of batch_size records (the given distinct records, cycled) through the batched binding:
-    NpBatchPipeline with two batches in flight (pipelined) or the synchronous np_calculate_methylation_for_batch.
+    NpBatchPipeline (pipelined; contexts as call_methylation_pipeline) or the synchronous np_calculate_methylation_for_batch.  consumer:
+    the harness's stand-in for the batch writer -- 0: count the sites and results.clear() on the calling thread (the reference's
+    write_methylation_results_for_batch), 1: count the sites and hand the maps back with NpBatchPipeline::recycle.
     Returns (seconds, sites written, records that did not come back NP_BATCH_OK, host seconds per phase of the timed batches)."""
     L = C.CDLL(_BATCH)
     L.npfull_bench_batch.restype = C.c_double
     n, raw, raw_off, cig, cig_off, is_rev, pos, seqs, bseqs = _batch_args(records)
     n_sites, n_bad = C.c_int64(0), C.c_int64(0)
-    hs = np.zeros(7, np.float64)
+    hs = np.zeros(10, np.float64)
     counts = np.concatenate([np.ascontiguousarray(r["adc"], np.int16) for r in records]) if adc else None
     sec = L.npfull_bench_batch(n, seqs, _p(raw, C.POINTER(C.c_float)), _p(raw_off, C.POINTER(C.c_int64)), _p(is_rev, _i32p), _p(pos, _i32p),
                                _p(cig, _u32p), _p(cig_off, C.POINTER(C.c_int64)), bseqs, contig_seq.encode(), int(batch_size), int(n_batches),
-                               int(warmup), int(bool(pipelined)), _p(counts, C.POINTER(C.c_int16)) if adc else None,
+                               int(warmup), int(bool(pipelined)), int(contexts), int(consumer), _p(counts, C.POINTER(C.c_int16)) if adc else None,
                                C.c_float(adc[0] if adc else 0.0), C.c_float(adc[1] if adc else 1.0), C.byref(n_sites), C.byref(n_bad), _p(hs, _f64p))
-    names = ("phase1a_fetch_sizes", "phase1b_pack", "enqueue", "wait_device", "phase3_maps", "buffer_growth", "inside_binding")
+    names = ("phase1a_fetch_sizes", "phase1b_pack", "enqueue", "finisher_wait_device", "phase3_maps", "buffer_growth", "collect_wait", "submit",
+             "caller_inside_binding", "caller_writer_stand_in")
     return float(sec), int(n_sites.value), int(n_bad.value), {k: round(float(v), 4) for k, v in zip(names, hs)}
 
 

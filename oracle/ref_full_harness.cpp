@@ -295,10 +295,12 @@ int npfull_call_methylation_batch(int n, const char* const* read_seqs, const flo
     return tot;
 }
 
-// The same records through NpBatchPipeline in batches of `batch_size`, two batches in flight (submit k, then collect k - 1): the
-// production feed's shape.  Output as npfull_call_methylation_batch.  event_cap_divisor > 2 shrinks the device detector's per-read
+// The same records through NpBatchPipeline in batches of `batch_size`, as many batches in flight as the pipeline takes (submit; collect
+// when full): the production feed's shape.  n_contexts <= 0: the process-wide context; n_contexts >= 1: that many contexts of the
+// pipeline's own, all on device 0 (the multi-GPU form, rehearsed on one device), batches dealt round-robin.  Output as
+// npfull_call_methylation_batch.  event_cap_divisor > 2 shrinks the device detector's per-read
 // event capacity (test knob: drives the overflow -> NP_BATCH_HOST_PATH route); rna_mask: bit i set marks record i as an RNA read.
-int npfull_call_methylation_pipeline(int n, int batch_size, int event_cap_divisor, const uint8_t* rna_mask, const int16_t* adc /* nullable: the
+int npfull_call_methylation_pipeline(int n, int batch_size, int n_contexts, int event_cap_divisor, const uint8_t* rna_mask, const int16_t* adc /* nullable: the
                                      samples as ADC counts, raw then unused */, float adc_offset, float adc_raw_unit, const char* const* read_seqs,
                                      const float* raw, const int64_t* raw_off, const int32_t* is_rev, const int32_t* pos, const uint32_t* cigar,
                                      const int64_t* cigar_off, const char* const* bam_seqs, const char* contig_seq, const char* methylation_type,
@@ -331,12 +333,14 @@ int npfull_call_methylation_pipeline(int n, int batch_size, int event_cap_diviso
     }
     MethylationCallingResult result;
     {
-        NpBatchPipeline pipe(params, "r9.4_450bps", &recs[0]->fai, &recs[0]->hdr, -1, -1);
+        NpBatchPipeline* pipe = n_contexts <= 0 ? new NpBatchPipeline(params, "r9.4_450bps", &recs[0]->fai, &recs[0]->hdr, -1, -1)
+                                                : new NpBatchPipeline(params, "r9.4_450bps", &recs[0]->fai, &recs[0]->hdr, -1, -1, std::vector<int>(n_contexts, 0), 0);
         for(size_t b = 0; b < batches.size(); ++b) {
-            pipe.submit(batches[b]);
-            if(b > 0) pipe.collect(result);
+            if(pipe->in_flight() == pipe->max_in_flight()) pipe->collect(result);
+            pipe->submit(batches[b]);
         }
-        while(pipe.collect(result)) {}
+        while(pipe->collect(result)) {}
+        delete pipe;
     }
     np_batch_set_event_capacity_divisor(2);
     int tot = 0;
@@ -359,86 +363,99 @@ int npfull_call_methylation_pipeline(int n, int batch_size, int event_cap_diviso
 }
 
 // Throughput of the binding (tests/bench_batch_dropin.py): n_distinct records cycled into batches of `batch_size`, `n_batches` of them
-// after `warmup` untimed ones, through NpBatchPipeline (pipelined != 0: two batches in flight) or through the synchronous
-// np_calculate_methylation_for_batch.  Every batch gets its own MethylationCallingResult, as one BamProcessor batch does.
-// Returns the seconds the timed batches took (host wall clock around the whole loop: phases 1-3, the device pass, and this
-// harness's own share -- counting the sites and destroying the result maps, which stands in for the caller's writer);
-// host_seconds[0..5]: NpBatchPipeline::host_seconds of the timed batches, [6]: seconds inside submit() + collect().
+// after `warmup` untimed ones, through NpBatchPipeline (pipelined != 0) or through the synchronous np_calculate_methylation_for_batch.
+// n_contexts as npfull_call_methylation_pipeline.  Every batch gets its own MethylationCallingResult, as one BamProcessor batch does.
+// consumer: what stands in for the batch's writer (write_methylation_results_for_batch, src/nanopolish_call_methylation.cpp:552-588, walks
+// the maps and then clears them): 0 = count the sites, then results.clear() on this thread, as the reference does; 1 = count the sites,
+// then hand the maps back with NpBatchPipeline::recycle (INTEGRATION.md section 2's one-line change to the writer).
+// Returns the seconds the timed batches took (host wall clock around the whole loop: the pipeline's three stages and this harness's
+// writer stand-in); host_seconds[0..7]: NpBatchPipeline::host_seconds of the timed batches, [8]: seconds of this thread inside
+// submit() + collect() + recycle(), [9]: seconds of this thread in the writer stand-in.
 double npfull_bench_batch(int n_distinct, const char* const* read_seqs, const float* raw, const int64_t* raw_off, const int32_t* is_rev,
                           const int32_t* pos, const uint32_t* cigar, const int64_t* cigar_off, const char* const* bam_seqs, const char* contig_seq,
-                          int batch_size, int n_batches, int warmup, int pipelined, const int16_t* adc /* nullable: records carry ADC counts */,
-                          float adc_offset, float adc_raw_unit, int64_t* n_sites, int64_t* n_not_ok, double* host_seconds /* [7] */)
+                          int batch_size, int n_batches, int warmup, int pipelined, int n_contexts, int consumer,
+                          const int16_t* adc /* nullable: records carry ADC counts */,
+                          float adc_offset, float adc_raw_unit, int64_t* n_sites, int64_t* n_not_ok, double* host_seconds /* [10] */)
 {
     std::vector<std::string> seqs(n_distinct);
     for(int i = 0; i < n_distinct; ++i) seqs[i] = read_seqs[i];
-    // two sets of record objects (two batches in flight); only the first record of a set carries the contig (the batch's faidx)
-    std::vector<Record*> recs[2];
-    std::vector<NpBatchRead> reads[2];
-    for(int s = 0; s < 2; ++s) {
+    NpBatchPipeline* pipe = (NpBatchPipeline*)0;
+    MethylationCallingParameters params;
+    params.methylation_type = "cpg";
+    params.alphabet = get_alphabet_by_name("cpg");
+    // as many sets of record objects as batches can be in flight; only the first record of a set carries the contig (the batch's faidx)
+    Record* first = new Record("first", is_rev[0], pos[0], cigar + cigar_off[0], (int)(cigar_off[1] - cigar_off[0]), bam_seqs[0], contig_seq);
+    first->lens[0] = (uint32_t)strlen(contig_seq);
+    pipe = n_contexts <= 0 ? new NpBatchPipeline(params, "r9.4_450bps", &first->fai, &first->hdr, -1, -1)
+                           : new NpBatchPipeline(params, "r9.4_450bps", &first->fai, &first->hdr, -1, -1, std::vector<int>(n_contexts, 0), 0);
+    const int n_sets = pipelined ? pipe->max_in_flight() : 1;
+    std::vector<std::vector<Record*> > recs(n_sets);
+    std::vector<std::vector<NpBatchRead> > reads(n_sets);
+    for(int s = 0; s < n_sets; ++s) {
         recs[s].resize(batch_size); reads[s].resize(batch_size);
         for(int j = 0; j < batch_size; ++j) {
             const int i = j % n_distinct;
             char name[32]; snprintf(name, sizeof(name), "read%d_%d", s, j);
-            recs[s][j] = new Record(name, is_rev[i], pos[i], cigar + cigar_off[i], (int)(cigar_off[i + 1] - cigar_off[i]), bam_seqs[i],
-                                    j == 0 ? contig_seq : "");
+            recs[s][j] = new Record(name, is_rev[i], pos[i], cigar + cigar_off[i], (int)(cigar_off[i + 1] - cigar_off[i]), bam_seqs[i], "");
             NpBatchRead& r = reads[s][j];
             r.record = &recs[s][j]->b; r.read_sequence = &seqs[i];
             r.raw_pa = adc ? NULL : raw + raw_off[i]; r.n_raw = (size_t)(raw_off[i + 1] - raw_off[i]);
             if(adc) { r.raw_adc = adc + raw_off[i]; r.adc_offset = adc_offset; r.adc_raw_unit = adc_raw_unit; }
         }
-        recs[s][0]->lens[0] = (uint32_t)strlen(contig_seq);
     }
-    MethylationCallingParameters params;
-    params.methylation_type = "cpg";
-    params.alphabet = get_alphabet_by_name("cpg");
     int64_t sites = 0, not_ok = 0;
-    double t0 = 0.0, t1 = 0.0, t_in = 0.0, tq = 0.0;
+    double t0 = 0.0, t1 = 0.0, t_in = 0.0, t_writer = 0.0, tq = 0.0;
+    double hs0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     {
-        NpBatchPipeline pipe(params, "r9.4_450bps", &recs[0][0]->fai, &recs[0][0]->hdr, -1, -1);
-        MethylationCallingResult res[2];
+        std::vector<MethylationCallingResult> res(n_sets);
+        long next_collect = 0;
+        // the writer stand-in for the batch whose results sit in res[s]
+        #define NPH_WRITE(s) do { \
+            tq = omp_get_wtime(); \
+            for(MethylationCallingResult::const_iterator it = res[s].begin(); it != res[s].end(); ++it) sites += (int64_t)it->second.size(); \
+            for(int j = 0; j < batch_size; ++j) not_ok += reads[s][j].status != NP_BATCH_OK; \
+            if(consumer == 0) { res[s].clear(); t_writer += omp_get_wtime() - tq; } \
+            else { t_writer += omp_get_wtime() - tq; tq = omp_get_wtime(); pipe->recycle(res[s]); t_in += omp_get_wtime() - tq; tq = omp_get_wtime(); res[s].clear(); t_writer += omp_get_wtime() - tq; } \
+        } while(0)
         for(int b = 0; b < warmup + n_batches; ++b) {
             if(b == warmup) {
-                while(pipe.collect(res[(b + 1) & 1])) {}
-                res[0].clear(); res[1].clear(); sites = 0; not_ok = 0;
-                pipe.host_seconds(host_seconds);          // (the warm-up's share is subtracted below)
-                t_in = 0.0;
+                while(pipe->in_flight() > 0) { const int s = (int)(next_collect++ % n_sets); pipe->collect(res[s]); NPH_WRITE(s); }
+                sites = 0; not_ok = 0; t_in = 0.0; t_writer = 0.0;
+                pipe->host_seconds(hs0);          // (the warm-up's share is subtracted below)
                 t0 = omp_get_wtime();
             }
-            const int s = b & 1;
             if(pipelined) {
-                res[s].clear();
-                tq = omp_get_wtime(); pipe.submit(reads[s]); t_in += omp_get_wtime() - tq;
-                if(pipe.in_flight() == 2) {
-                    tq = omp_get_wtime(); pipe.collect(res[s ^ 1]); t_in += omp_get_wtime() - tq;
-                    for(MethylationCallingResult::const_iterator it = res[s ^ 1].begin(); it != res[s ^ 1].end(); ++it) sites += (int64_t)it->second.size();
-                    for(int j = 0; j < batch_size; ++j) not_ok += reads[s ^ 1][j].status != NP_BATCH_OK;
+                if(pipe->in_flight() == pipe->max_in_flight()) {
+                    const int s = (int)(next_collect++ % n_sets);
+                    tq = omp_get_wtime(); pipe->collect(res[s]); t_in += omp_get_wtime() - tq;
+                    NPH_WRITE(s);
                 }
+                const int s = b % n_sets;
+                tq = omp_get_wtime(); pipe->submit(reads[s]); t_in += omp_get_wtime() - tq;
             } else {
-                res[s].clear();
                 tq = omp_get_wtime();
-                np_calculate_methylation_for_batch(res[s], reads[s], params, "r9.4_450bps", &recs[0][0]->fai, &recs[0][0]->hdr, -1, -1);
+                np_calculate_methylation_for_batch(res[0], reads[0], params, "r9.4_450bps", &first->fai, &first->hdr, -1, -1);
                 t_in += omp_get_wtime() - tq;
-                for(MethylationCallingResult::const_iterator it = res[s].begin(); it != res[s].end(); ++it) sites += (int64_t)it->second.size();
-                for(int j = 0; j < batch_size; ++j) not_ok += reads[s][j].status != NP_BATCH_OK;
+                for(MethylationCallingResult::const_iterator it = res[0].begin(); it != res[0].end(); ++it) sites += (int64_t)it->second.size();
+                for(int j = 0; j < batch_size; ++j) not_ok += reads[0][j].status != NP_BATCH_OK;
+                tq = omp_get_wtime(); res[0].clear(); t_writer += omp_get_wtime() - tq;
             }
         }
-        if(pipelined) {
-            const int s = (warmup + n_batches - 1) & 1;
-            tq = omp_get_wtime();
-            const bool more = pipe.collect(res[s]);
-            t_in += omp_get_wtime() - tq;
-            if(more) {
-                for(MethylationCallingResult::const_iterator it = res[s].begin(); it != res[s].end(); ++it) sites += (int64_t)it->second.size();
-                for(int j = 0; j < batch_size; ++j) not_ok += reads[s][j].status != NP_BATCH_OK;
-            }
+        while(pipelined && pipe->in_flight() > 0) {
+            const int s = (int)(next_collect++ % n_sets);
+            tq = omp_get_wtime(); pipe->collect(res[s]); t_in += omp_get_wtime() - tq;
+            NPH_WRITE(s);
         }
+        #undef NPH_WRITE
         t1 = omp_get_wtime();
-        double hs[6]; pipe.host_seconds(hs);
-        for(int i = 0; i < 6; ++i) host_seconds[i] = pipelined ? hs[i] - host_seconds[i] : 0.0;
-        host_seconds[6] = t_in;
+        double hs[8]; pipe->host_seconds(hs);
+        for(int i = 0; i < 8; ++i) host_seconds[i] = pipelined ? hs[i] - hs0[i] : 0.0;
+        host_seconds[8] = t_in; host_seconds[9] = t_writer;
     }
+    delete pipe;
     *n_sites = sites; *n_not_ok = not_ok;
-    for(int s = 0; s < 2; ++s) for(int j = 0; j < batch_size; ++j) delete recs[s][j];
+    for(int s = 0; s < n_sets; ++s) for(int j = 0; j < batch_size; ++j) delete recs[s][j];
+    delete first;
     return t1 - t0;
 }
 #endif

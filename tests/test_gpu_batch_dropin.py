@@ -91,6 +91,22 @@ def test_pipelined_batches_equal_the_unmodified_reference():
             _assert_golden(g, i, out[i])
 
 
+def test_two_contexts_on_one_device_deal_batches_round_robin():
+    """The multi-GPU form of NpBatchPipeline (devices = {0, 0}: two library contexts of the pipeline's own, here on one GPU; batches dealt
+    round-robin, three slots per context, results in submission order): batches of 1, 2 and 3 records, i.e. up to 12 batches through 6
+    slots, every result equal to the unmodified reference's; then three contexts; then the process-wide context again."""
+    from oracle.ref_full import call_methylation_pipeline
+    import torch  # noqa: F401
+    g = np.load(GOLD)
+    recs = _golden_records(g)
+    for contexts, bs in ((2, 1), (2, 2), (2, 3), (3, 1), (0, 2)):
+        out, status = call_methylation_pipeline(recs, _s(g["contig"]), bs, contexts=contexts)
+        for i in range(len(recs)):
+            assert status[i] in (0, 1)
+            assert (status[i] == 1) == (int(g["r%d_n_events" % i]) == 0)
+            _assert_golden(g, i, out[i])
+
+
 def test_event_capacity_overflow_and_rna_reads_take_the_host_path():
     """A read whose detected events exceed the device capacity (driven here by shrinking the capacity estimate) and a read flagged
     RNA come back NP_BATCH_HOST_PATH with NO sites; the other records of the same batches are unaffected, and so is the next run."""

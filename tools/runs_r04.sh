@@ -66,4 +66,25 @@ PY
 cat $O/units_k1.json | tail -1 | cut -c1-400; cat $O/units_k2.json | tail -1 | cut -c1-400
 }
 
+# the threaded batch binding: parity (one context, two and three contexts on one device), throughput at 512 / 8192 records
+call_e() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04e; mkdir -p $O
+( time timeout 600 python -m pytest tests/test_gpu_batch_dropin.py tests/test_gpu_variants_dropin.py tests/test_gpu_eventalign_dropin.py tests/test_gpu_dropin.py tests/test_gpu_parity.py -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+( time timeout 900 python tests/bench_batch_dropin.py --sizes ${SIZES:-512,8192} ) > $O/batch_dropin.json 2> $O/batch_dropin.err; echo "rc=$?" >> $O/batch_dropin.err
+tail -6 $O/pytest.log; cat $O/batch_dropin.json | cut -c1-3000; tail -4 $O/batch_dropin.err
+}
+
+# the threaded batch binding: worker-pool size and batch size
+call_f() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04f; mkdir -p $O
+for t in 12 14 16 20 24; do
+  ( NP_HOST_THREADS=$t timeout 600 python tests/bench_batch_dropin.py --sizes 8192 --skip sync,pipelined_adc_ref_writer,pipelined_adc_4ctx,pipelined_adc_2ctx ) > $O/threads_$t.json 2> $O/threads_$t.err
+  echo "threads $t: $(grep -o '"pipelined_adc": {"value": [0-9.]*\|"pipelined": {"value": [0-9.]*' $O/threads_$t.json | tr '\n' ' ')"
+done
+( timeout 600 python tests/bench_batch_dropin.py --sizes 2048,32768 --skip sync,pipelined_adc_ref_writer,pipelined_adc_4ctx ) > $O/sizes.json 2> $O/sizes.err
+grep -o '"batch_size": [0-9]*\|"pipelined[a-z_0-9]*": {"value": [0-9.]*' $O/sizes.json | tr '\n' ' '
+}
+
 "call_$1"
