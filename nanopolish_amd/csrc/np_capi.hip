@@ -201,8 +201,11 @@ int persistent_blocks(np_ctx* c, int64_t work_items, int per_block, int blocks_p
 }
 
 // ---- kernel B driver: classify + one persistent launch per non-empty size class ----------------------
+// class_mask: bit cls set = the size class may hold work items (the *_dev callers do not know: all eight; the host entry points
+// see the items and launch only the classes that occur -- a per-call round is launch-bound, and six empty persistent launches each
+// still load their 64 KB table)
 int run_hmm_forward(np_ctx* c, hipStream_t s, int64_t n_jobs, const np_hmm_job_dev* jobs, const np_read_dev* reads,
-                    const float* event_mean, const uint16_t* ranks, int model, float* out)
+                    const float* event_mean, const uint16_t* ranks, int model, float* out, unsigned class_mask = 0xffu)
 {
     if (n_jobs <= 0) return NP_OK;
     if (model < 0 || model >= (int)c->models.size()) { c->err = "bad model id"; return NP_ERR_INVALID; }
@@ -212,6 +215,7 @@ int run_hmm_forward(np_ctx* c, hipStream_t s, int64_t n_jobs, const np_hmm_job_d
     family_timer tm(c, 1, s);
     NP_HIP(c, np_launch_classify(jobs, n_jobs, c->d_counters, c->order.as<uint32_t>(), out, NP_FLANK_LEN, c->d_counters + 1024, s));
     for (int cls = 0; cls < NP_NUM_CLASSES; ++cls) {
+        if (!(class_mask >> cls & 1u)) continue;
         np_hmm_args a{};
         a.jobs = jobs; a.order = c->order.as<uint32_t>() + (size_t)cls * (size_t)n_jobs; a.n_class_jobs = c->d_counters + cls;
         a.reads = reads; a.event_mean = event_mean; a.ranks = ranks; a.model = c->models[model].d_states;
@@ -864,8 +868,13 @@ int np_hmm_score_host(np_ctx* c, int n_jobs, const np_hmm_job* jobs, float* out_
     NP_HIP(c, hipMemcpyAsync(c->b_reads.p, dr.data(), dr.size() * sizeof(np_read_dev), hipMemcpyHostToDevice, s));
     NP_HIP(c, hipMemcpyAsync(c->b_events.p, ev.data(), ev.size() * sizeof(float), hipMemcpyHostToDevice, s));
     NP_HIP(c, hipMemcpyAsync(c->b_ranks.p, rk.data(), rk.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+    unsigned class_mask = 0;
+    for (int j = 0; j < n_jobs; ++j) {           // np_glue_kernels.hip:size_class
+        const uint32_t n = jobs[j].n_kmers;
+        class_mask |= 1u << (n <= 16 ? 0 : n <= 24 ? 1 : n <= 32 ? 2 : n <= 64 ? 3 : n <= 128 ? 4 : n <= 256 ? 5 : n <= 512 ? 6 : 7);
+    }
     rc = run_hmm_forward(c, s, n_jobs, c->b_jobs.as<np_hmm_job_dev>(), c->b_reads.as<np_read_dev>(),
-                         c->b_events.as<float>(), c->b_ranks.as<uint16_t>(), model, c->b_out.as<float>());
+                         c->b_events.as<float>(), c->b_ranks.as<uint16_t>(), model, c->b_out.as<float>(), class_mask);
     if (rc != NP_OK) return rc;
     NP_HIP(c, hipMemcpyAsync(out_scores, c->b_out.p, (size_t)n_jobs * sizeof(float), hipMemcpyDeviceToHost, s));
     NP_HIP(c, hipStreamSynchronize(s));

@@ -7,14 +7,27 @@
 // nanopolish_squiggle_read.cpp:270 -- links unchanged.  See INTEGRATION.md.  oracle/Makefile builds exactly this
 // configuration (`make -C oracle dropin`) and tests/test_gpu_dropin.py runs the reference's harness through it.
 //
-// One call = one tiny batch: correct, but launch-bound.  The throughput path is the *_dev batch API fed at the
-// BamProcessor batch boundary; this file is the drop-in for parity and for the minor callers.
+// One call = one tiny batch: correct, but launch-bound -- and the reference calls these functions from inside OpenMP loops
+// (src/nanopolish_scorereads.cpp:164,388, src/nanopolish_phase_reads.cpp:289-292, basemods.cpp:374,382 under bam_processor.cpp:99):
+// sixteen threads each paying an upload, a launch, a read-back and a synchronisation, one after the other on the context's lock.
+// The scoring entry points therefore COMBINE concurrent callers (flat combining): a caller queues its work items; whoever finds
+// no flush in progress becomes the combiner, takes everything queued so far -- what arrived while the previous flush was on the
+// device -- and scores it with ONE np_hmm_score_host; the others sleep until their scores are there.  One thread still costs one
+// launch per call; sixteen threads cost one launch per round (tests/bench_percall_dropin.py, profiles/r04_percall_dropin.md).
+// Errors do not exit() from inside the caller's parallel region any more: a failed call reports on stderr (once per message),
+// counts in np_dropin_error_count(), and returns the reference's in-band "no result" (-INFINITY / an empty vector); the caller's
+// serial code checks the count after its loop.  NP_DROPIN_ABORT_ON_ERROR=1 restores the immediate exit.
+// The throughput path remains the *_dev batch API fed at the BamProcessor batch boundary (np_batch_dropin.cpp).
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
 #include <map>
 #include <mutex>
+#include <set>
+#include <string>
 #include "nanopolish_profile_hmm.h"
 #include "nanopolish_profile_hmm_r9.h"
 #include "nanopolish_profile_hmm_r7.h"
@@ -30,11 +43,79 @@ extern "C" void np_dropin_invalidate_models(void) { shim().invalidate(); }
 
 namespace {
 
+std::atomic<long> g_errors(0);
+
+// a failed device call: message (once per distinct text), count, and -- unless NP_DROPIN_ABORT_ON_ERROR is set -- back to the caller,
+// who returns the entry point's in-band failure value
 void fail(const char* what, int rc)
 {
-    fprintf(stderr, "nanopolish_amd: %s failed (%d): %s\n", what, rc, np_last_error(shim().get()));
-    exit(EXIT_FAILURE);
+    static std::mutex m;
+    static std::set<std::string> seen;
+    const std::string msg = std::string(what) + " failed (" + std::to_string(rc) + "): " + np_last_error(shim().get());
+    g_errors.fetch_add(1);
+    {
+        std::lock_guard<std::mutex> g(m);
+        if (seen.insert(msg).second) fprintf(stderr, "nanopolish_amd: %s\n", msg.c_str());
+    }
+    const char* fatal = getenv("NP_DROPIN_ABORT_ON_ERROR");
+    if (fatal && atoi(fatal) != 0) exit(EXIT_FAILURE);
 }
+
+// Flat combining of concurrent scoring calls (see the header).  A request is a run of np_hmm_job with room for their scores.
+class ScoreCombiner {
+public:
+    ScoreCombiner() : flushing_(false) {}
+    // scores of jobs[0..n) into out[0..n); NP_OK or the library's error for THIS request
+    int score(const np_hmm_job* jobs, int n, float* out)
+    {
+        if (n <= 0) return NP_OK;
+        Req r; r.jobs = jobs; r.n = n; r.out = out; r.rc = NP_OK; r.done = false;
+        std::unique_lock<std::mutex> g(m_);
+        queue_.push_back(&r);
+        while (!r.done) {
+            if (flushing_) { cv_.wait(g); continue; }
+            flushing_ = true;                                   // this thread combines
+            std::vector<Req*> batch; batch.swap(queue_);
+            g.unlock();
+            flush(batch);
+            g.lock();
+            for (size_t i = 0; i < batch.size(); ++i) batch[i]->done = true;
+            flushing_ = false;
+            cv_.notify_all();
+        }
+        return r.rc;
+    }
+    long rounds() const { return rounds_.load(); }
+    long requests() const { return requests_.load(); }
+private:
+    struct Req { const np_hmm_job* jobs; int n; float* out; int rc; bool done; };
+    void flush(std::vector<Req*>& batch)
+    {
+        rounds_.fetch_add(1); requests_.fetch_add((long)batch.size());
+        np_ctx* c = shim().get();
+        if (batch.size() == 1) { batch[0]->rc = np_hmm_score_host(c, batch[0]->n, batch[0]->jobs, batch[0]->out); return; }
+        size_t total = 0;
+        for (size_t i = 0; i < batch.size(); ++i) total += (size_t)batch[i]->n;
+        all_.resize(total); sc_.resize(total);
+        size_t at = 0;
+        for (size_t i = 0; i < batch.size(); ++i) { memcpy(&all_[at], batch[i]->jobs, (size_t)batch[i]->n * sizeof(np_hmm_job)); at += (size_t)batch[i]->n; }
+        const int rc = np_hmm_score_host(c, (int)total, all_.data(), sc_.data());
+        if (rc == NP_OK) {
+            at = 0;
+            for (size_t i = 0; i < batch.size(); ++i) { memcpy(batch[i]->out, &sc_[at], (size_t)batch[i]->n * sizeof(float)); batch[i]->rc = NP_OK; at += (size_t)batch[i]->n; }
+            return;
+        }
+        // one request of the round is outside what the library covers (NP_ERR_UNSUPPORTED: more than NP_MAX_KMERS k-mers, ...): the
+        // others must not fail with it -- every request again, on its own
+        for (size_t i = 0; i < batch.size(); ++i) batch[i]->rc = np_hmm_score_host(c, batch[i]->n, batch[i]->jobs, batch[i]->out);
+    }
+    std::mutex m_; std::condition_variable cv_;
+    std::vector<Req*> queue_;
+    bool flushing_;
+    std::vector<np_hmm_job> all_; std::vector<float> sc_;      // the combiner's buffers (one combiner at a time)
+    std::atomic<long> rounds_{0}, requests_{0};
+};
+ScoreCombiner& combiner() { static ScoreCombiner c; return c; }
 
 // (HMMInputSequence, HMMInputData) -> np_hmm_job.  `ev` and `ranks` own the flattened buffers.
 struct FlatJob {
@@ -79,8 +160,8 @@ float profile_hmm_score(const HMMInputSequence& sequence, const HMMInputData& da
     FlatJob f;
     flatten(sequence, data, flags, f);
     float out = 0.0f;
-    const int rc = np_hmm_score_host(shim().get(), 1, &f.job, &out);
-    if (rc != NP_OK) fail("np_hmm_score_host", rc);
+    const int rc = combiner().score(&f.job, 1, &out);
+    if (rc != NP_OK) { fail("profile_hmm_score: np_hmm_score_host", rc); return -INFINITY; }
     return out;
 }
 
@@ -95,8 +176,8 @@ float profile_hmm_score(const HMMInputSequence& sequence, const std::vector<HMMI
         jobs[i] = f[i].job;
     }
     std::vector<float> sc(data.size());
-    const int rc = np_hmm_score_host(shim().get(), (int)jobs.size(), jobs.data(), sc.data());
-    if (rc != NP_OK) fail("np_hmm_score_host", rc);
+    const int rc = combiner().score(jobs.data(), (int)jobs.size(), sc.data());
+    if (rc != NP_OK) { fail("profile_hmm_score (vector): np_hmm_score_host", rc); return -INFINITY; }
     float score = 0.0f;
     for (size_t i = 0; i < sc.size(); ++i) score += sc[i];
     return score;
@@ -119,11 +200,18 @@ float profile_hmm_score_set(const std::vector<HMMInputSequence>& sequences, cons
         flatten(sequences[s], s == 0 ? data : alt, flags, f[s]);
         jobs[s] = f[s].job;
     }
-    const int32_t off[2] = {0, (int32_t)jobs.size()};
-    float out = 0.0f;
-    const int rc = np_hmm_score_set_host(shim().get(), 1, off, jobs.data(), &out);
-    if (rc != NP_OK) fail("np_hmm_score_set_host", rc);
-    return out;
+    // the members' forward scores through the combiner, then profile_hmm.cpp:38-54's own combination (the reference's add_logs)
+    std::vector<float> sc(jobs.size());
+    const int rc = combiner().score(jobs.data(), (int)jobs.size(), sc.data());
+    if (rc != NP_OK) { fail("profile_hmm_score_set: np_hmm_score_host", rc); return -INFINITY; }
+    const size_t num_models = sequences.size();
+    const double num_model_penalty = log(num_models);
+    double score = sc[0] - num_model_penalty;
+    for (size_t q = 1; q < num_models; ++q) {
+        const double alt_score = sc[q] - num_model_penalty;
+        score = add_logs(score, alt_score);
+    }
+    return score;
 }
 
 // src/hmm/nanopolish_profile_hmm.cpp:58-65
@@ -136,7 +224,7 @@ std::vector<HMMAlignmentState> profile_hmm_align(const HMMInputSequence& sequenc
     std::vector<np_hmm_state> st(cap);
     int64_t off[2] = {0, 0};
     const int rc = np_hmm_align_host(shim().get(), 1, &f.job, st.data(), cap, off);
-    if (rc != NP_OK) fail("np_hmm_align_host", rc);
+    if (rc != NP_OK) { fail("profile_hmm_align: np_hmm_align_host", rc); return std::vector<HMMAlignmentState>(); }
     std::vector<HMMAlignmentState> out(off[1]);
     for (int64_t i = 0; i < off[1]; ++i) {
         out[i].event_idx = st[i].event_idx; out[i].kmer_idx = st[i].kmer_idx;
@@ -181,8 +269,14 @@ std::vector<AlignedPair> adaptive_banded_simple_event_align(SquiggleRead& read, 
     std::vector<np_pair> pairs(cap);
     int64_t off[2] = {0, 0};
     const int rc = np_event_align_host(shim().get(), 1, &j, pairs.data(), cap, off);
-    if (rc != NP_OK) fail("np_event_align_host", rc);
+    if (rc != NP_OK) { fail("adaptive_banded_simple_event_align: np_event_align_host", rc); return std::vector<AlignedPair>(); }
     std::vector<AlignedPair> out(off[1]);
     for (int64_t i = 0; i < off[1]; ++i) { out[i].ref_pos = pairs[i].ref_pos; out[i].read_pos = pairs[i].read_pos; }
     return out;
 }
+
+// Failed device calls since the process started (each reported on stderr once per distinct message): the caller's serial code checks
+// this after a parallel region whose calls returned -INFINITY / empty vectors.
+extern "C" long np_dropin_error_count(void) { return g_errors.load(); }
+// diagnostics of the combiner: device rounds and the scoring calls they carried (calls / rounds = callers combined per launch)
+extern "C" void np_dropin_combiner_stats(long* rounds, long* calls) { if (rounds) *rounds = combiner().rounds(); if (calls) *calls = combiner().requests(); }

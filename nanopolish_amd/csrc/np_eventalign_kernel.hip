@@ -328,6 +328,9 @@ __global__ void __launch_bounds__(64, 5) np_eventalign_chain_kernel(np_ea_args a
 // (row r, k-mer b) of half h lives in line r + b / 3, dword 32 h + b / 3, bits 9 (b % 3) .. 9 (b % 3) + 8.
 // ---------------------------------------------------------------------------------------------------------------------------
 #define NP_EA2_LINE 256
+#ifndef NP_EA_ARGMAX
+#define NP_EA_ARGMAX 1           // the M cell's arg-max: 0 = tournament (round 3), 1 = three-input maxima + equality chain (round 4)
+#endif
 
 struct ea_read {                 // what the chain needs of a read, all derived from its index
     const np_read_dev* rd; const float* ev; const int32_t* ms; const char* ref;
@@ -366,32 +369,45 @@ struct ea_half {                 // chain state of the read a half-wave works on
 // Returns the block's back-pointers as NINE bits, three per state (K in bits 0..2, B in 3..5, M in 6..8), each already the
 // back-track's move: bit 2 = "the k-mer steps back", bits 1..0 = the state walked to (2 MATCH, 1 BAD_EVENT, 0 KMER_SKIP), 7 = soft
 // clip (stop).  I.e. HMT_FROM_SAME_M 2, PREV_M 6, SAME_B 1, PREV_B 5, PREV_K 4, SOFT 7 (r9.cpp:150-186): the walk needs no decoding.
-template <bool FIRST>
+// Round 4 (issue-cost driven: a select, a compare, a maximum and a shift each cost 6.3 cycles of a SIMD's issue time, an add 3.7 --
+// profiles/r04_valu_calibration.json): the codes are selected already SHIFTED to the block's position in the step's dword (SHIFT = 0,
+// 9, 18: no shift instructions), and the M cell's maximum is two three-input maxima with the arg-max as an equality chain ("the
+// largest index whose candidate equals the maximum", r9.inl:138-143, literally) -- ten slow-class instructions where round 3's
+// tournament (NP_EA_ARGMAX = 0) has twelve.
+template <bool FIRST, int SHIFT>
 __device__ __forceinline__ uint32_t ea_block(float& M, float& B, float& K, const float lM_r, const float lB_r, const float lK_r,
                                              const float lM_p, const float lB_p, const float lK_p, const float x, const np_gauss& g,
                                              const ea_trans& tr, const float soft)
 {
+    constexpr uint32_t SM = 6 + SHIFT, SB = 3 + SHIFT, SK = SHIFT;
     const float em = np_emission(x, g);
     const float a0 = tr.mm_self + M, a1 = tr.mm_next + lM_p, a2 = tr.bm_self + B, a3 = tr.bm_next + lB_p, a4 = tr.km + lK_p;
-    // maximum and "the largest index whose candidate equals it" (r9.inl:138-143) as a tournament in which a tie goes to the later
-    // candidate at every node: 4 max + 4 compares + 4 selects instead of 4 max + 5 compares + 5 selects
+#if NP_EA_ARGMAX == 1
+    float v = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), __builtin_fmaxf(a3, a4));
+    if (FIRST) v = __builtin_fmaxf(v, soft);
+    uint32_t cm = 2u << SM;
+    cm = (a1 == v) ? 6u << SM : cm; cm = (a2 == v) ? 1u << SM : cm; cm = (a3 == v) ? 5u << SM : cm; cm = (a4 == v) ? 4u << SM : cm;
+    if (FIRST) cm = (soft == v) ? 7u << SM : cm;
+#else
+    // maximum and arg-max as a tournament in which a tie goes to the later candidate at every node: 4 max + 4 compares + 4 selects
     const float m01 = __builtin_fmaxf(a0, a1), m23 = __builtin_fmaxf(a2, a3);
-    const uint32_t c01 = (a1 >= a0) ? 6u : 2u, c23 = (a3 >= a2) ? 5u : 1u;
+    const uint32_t c01 = (a1 >= a0) ? 6u << SM : 2u << SM, c23 = (a3 >= a2) ? 5u << SM : 1u << SM;
     const float m03 = __builtin_fmaxf(m01, m23);
     uint32_t cm = (m23 >= m01) ? c23 : c01;
     float v = __builtin_fmaxf(m03, a4);
-    cm = (a4 >= m03) ? 4u : cm;
-    if (FIRST) { cm = (soft >= v) ? 7u : cm; v = __builtin_fmaxf(v, soft); }
+    cm = (a4 >= m03) ? 4u << SM : cm;
+    if (FIRST) { cm = (soft >= v) ? 7u << SM : cm; v = __builtin_fmaxf(v, soft); }
+#endif
     const float newM = v + em;
     // (the B and K states emit 0: the reference's `+ lp_emission` leaves every value it can meet here unchanged)
     const float b0 = tr.mb + M, b2 = tr.bb + B;
     const float newB = __builtin_fmaxf(b0, b2);
-    const uint32_t cb = (b2 >= b0) ? 1u : 2u;         // from the block's own B, else from its own M
+    const uint32_t cb = (b2 >= b0) ? 1u << SB : 2u << SB;         // from the block's own B, else from its own M
     const float k1 = tr.mk + lM_r, k3 = tr.bk + lB_r, k4 = tr.kk + lK_r;
     const float newK = __builtin_fmaxf(__builtin_fmaxf(k1, k3), k4);
-    uint32_t ck = (k3 == newK) ? 5u : 6u; ck = (k4 == newK) ? 4u : ck;
+    uint32_t ck = (k3 == newK) ? 5u << SK : 6u << SK; ck = (k4 == newK) ? 4u << SK : ck;
     M = newM; B = newB; K = newK;
-    return ck | (cb << 3) | (cm << 6);
+    return ck | cb | cm;
 }
 
 struct ea_seg { const float* ev; int e_start, stride, e, n; };
@@ -418,21 +434,29 @@ __device__ __attribute__((noinline)) float2 ea_fill2(const np_gauss g0, const np
     float ec1 = buf_f32(evr1, off1(lane)), en1 = buf_f32(evr1, off1(lane + 64));
     float x = 0.0f;
     uint8_t* line = bp + 4 * lane;
+    // the first lane of a half has no left neighbour (block -1 = -inf): instead of a select after the lane shift, the shift ADDS a
+    // per-lane constant -- -inf in lanes 0 and 32, else 0 (v + 0 == v for every value the lattice holds, v + -inf == -inf) -- in the
+    // same DPP instruction (bound_ctrl: lane 0's missing source reads as 0)
+    const float head = sl == 0 ? NP_NEG_INF : 0.0f;
+    auto shr_add = [&](const float v) {
+        float r;
+        asm("v_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(v), "v"(head));
+        return r;
+    };
+    float soft = sl == 0 ? flank0 : NP_NEG_INF;                                  // HMT_FROM_SOFT: block 0 of row 1 only (flags 0)
     auto step = [&](const int t) {
-        float nM = np_wave_shr1(M2, NP_NEG_INF), nB = np_wave_shr1(B2, NP_NEG_INF), nK = np_wave_shr1(K2, NP_NEG_INF);
-        // lane 32 is the first lane of its half: its left neighbour is block -1 (-inf), not lane 31's last block
-        nM = lane == 32 ? NP_NEG_INF : nM; nB = lane == 32 ? NP_NEG_INF : nB; nK = lane == 32 ? NP_NEG_INF : nK;
+        const float nM = shr_add(M2), nB = shr_add(B2), nK = shr_add(K2);
         const int ti = (t - 1) & 63;
         if (ti == 0 && t > 1) { ec0 = en0; en0 = buf_f32(evr0, off0(t - 1 + 64 + lane)); ec1 = en1; en1 = buf_f32(evr1, off1(t - 1 + 64 + lane)); }
         const float xa = readlane_f32(ec0, ti), xb = readlane_f32(ec1, ti);     // the event of row t of either segment
         x = np_wave_shr1(x, xa);
         x = lane == 32 ? xb : x;
-        const float soft = (sl == 0 && t == 1) ? flank0 : NP_NEG_INF;           // HMT_FROM_SOFT: block 0 of row 1 (flags 0)
         const float pM0 = M0, pB0 = B0, pK0 = K0, pM1 = M1, pB1 = B1, pK1 = K1;
-        uint32_t packed = ea_block<true>(M0, B0, K0, nM, nB, nK, oM, oB, oK, x, g0, tr, soft);
-        packed |= ea_block<false>(M1, B1, K1, M0, B0, K0, pM0, pB0, pK0, x, g1, tr, NP_NEG_INF) << 9;
-        packed |= ea_block<false>(M2, B2, K2, M1, B1, K1, pM1, pB1, pK1, x, g2, tr, NP_NEG_INF) << 18;
+        uint32_t packed = ea_block<true, 0>(M0, B0, K0, nM, nB, nK, oM, oB, oK, x, g0, tr, soft);
+        packed |= ea_block<false, 9>(M1, B1, K1, M0, B0, K0, pM0, pB0, pK0, x, g1, tr, NP_NEG_INF);
+        packed |= ea_block<false, 18>(M2, B2, K2, M1, B1, K1, pM1, pB1, pK1, x, g2, tr, NP_NEG_INF);
         oM = nM; oB = nB; oK = nK;
+        soft = NP_NEG_INF;
         *(uint32_t*)(line + (size_t)(t - 1) * NP_EA2_LINE) = packed;
     };
     int t = 1;

@@ -120,3 +120,33 @@ def test_model_overwritten_in_place_is_refreshed_on_the_device(dropin, orc, mode
     finally:
         dropin.shift_model("cpg", -1.5)
     assert device_score() == oracle_score()
+
+
+def test_concurrent_callers_are_combined_and_score_the_same(dropin, orc, models):
+    """profile_hmm_score called per work item from an OpenMP loop over reads (the reference's calling pattern, scorereads.cpp:388,
+    bam_processor.cpp:99) through the shim: concurrent callers share device rounds (flat combining, np_dropin.cpp), and every score
+    equals the single-thread run's and the oracle's."""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from bench_percall_dropin import jobs_of
+    J = jobs_of(orc, models, range(300, 316), 900)
+    args = ("cpg", J["events"], J["event_off"], J["shift"], J["scale"], J["var"], J["epb"], J["job_off"], J["seqs"], J["rc_seqs"],
+            J["e_start"], J["e_stop"], J["stride"], J["rc"], 3)
+    one = dropin.score_many_reads(*args, 1)
+    r0, c0 = C.c_long(0), C.c_long(0)
+    dropin.L.np_dropin_combiner_stats(C.byref(r0), C.byref(c0))
+    many = dropin.score_many_reads(*args, 8)
+    r1, c1 = C.c_long(0), C.c_long(0)
+    dropin.L.np_dropin_combiner_stats(C.byref(r1), C.byref(c1))
+    assert len(one) > 500 and np.array_equal(one, many)
+    assert c1.value - c0.value == len(one) and r1.value - r0.value < c1.value - c0.value        # fewer device rounds than calls
+    mc = orc.model(models["cpg"])
+    from cases import synth_read
+    rd = synth_read(300, models["nucleotide"], L=900)
+    S = orc.scalings(rd["shift"], rd["scale"], rd["var"])
+    for j in range(J["job_off"][0], min(J["job_off"][1], 12)):
+        ranks = orc.sequence_kmer_ranks("cpg", J["seqs"][j], J["rc_seqs"][j], K, J["rc"][j])
+        assert one[j] == orc.hmm_score(mc, S, rd["events"], ranks, J["e_start"][j], J["e_stop"][j], J["stride"][j], J["epb"][0], 1.0, 3)
+    dropin.L.np_dropin_error_count.restype = C.c_long
+    assert dropin.L.np_dropin_error_count() == 0

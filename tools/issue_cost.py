@@ -68,7 +68,7 @@ def main():
     L = open(sys.argv[1]).read().splitlines()
     pat = sys.argv[2]
     start = next(i for i, l in enumerate(L) if l.startswith("_Z") and pat in l.split(":")[0])
-    end = next(i for i in range(start, len(L)) if "s_endpgm" in L[i])
+    end = next(i for i in range(start, len(L)) if "s_endpgm" in L[i] or "s_setpc_b64" in L[i] or L[i].startswith(".Lfunc_end"))
     K = L[start:end]
     print("class costs (cycles per wave-instruction and SIMD): fast %.2f  fma %.2f  slow %.2f  packed %.2f  lane %.2f" % (FAST, FMA, SLOW, PK, LANE))
     if len(sys.argv) >= 5:
@@ -82,6 +82,8 @@ def main():
         n, o, cyc, ops = price(K[a:b])
         if sum(n.values()) >= 40:
             print("%6d %6d  valu %4d %-58s other %-36s cycles %6.0f" % (a, b, sum(n.values()), dict(n), dict(o), cyc))
+            if os.environ.get("NP_ISSUE_OPS"):
+                print("        ", ops.most_common(18))
 
 
 main()

@@ -87,4 +87,26 @@ done
 grep -o '"batch_size": [0-9]*\|"pipelined[a-z_0-9]*": {"value": [0-9.]*' $O/sizes.json | tr '\n' ' '
 }
 
+# per-call drop-in under OpenMP (flat combining) beside the reference's own function; its tests
+call_g() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04g; mkdir -p $O
+( timeout 600 python -m pytest tests/test_gpu_dropin.py tests/test_gpu_variants_dropin.py -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+( timeout 600 python tests/bench_percall_dropin.py ) > $O/percall.json 2> $O/percall.err; echo "rc=$?" >> $O/percall.err
+tail -5 $O/pytest.log; cat $O/percall.json; tail -3 $O/percall.err
+}
+
+# chain kernel: round-4 sweep (pre-shifted codes, max3 + equality-chain arg-max, DPP-add neighbour exchange): parity + timing; per-call drop-in again
+call_h() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04h; mkdir -p $O
+( timeout 600 python -m pytest tests/test_gpu_reflevel.py tests/test_gpu_eventalign_dropin.py tests/test_gpu_parity.py -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+( timeout 600 python tests/bench_eventalign.py --steps 3 --warmup 1 --cpu-sample 64 ) > $O/ea.json 2> $O/ea.err
+( NP_HIP_LIB=$GRAFT_REPO_ROOT/nanopolish_amd/variants/libnp_hip_ea_r3.so timeout 600 python tests/bench_eventalign.py --steps 3 --warmup 1 --cpu-sample 0 ) > $O/ea_r3.json 2> $O/ea_r3.err
+( timeout 600 python tests/bench_percall_dropin.py ) > $O/percall.json 2> $O/percall.err
+tail -3 $O/pytest.log
+for f in ea ea_r3; do echo "$f: $(grep -o '"value": [0-9.]*\|"eventalign_chain": [0-9.]*\|"rows_match": [a-z]*\|"copies_identical": [a-z]*' $O/$f.json | tr '\n' ' ')"; done
+cat $O/percall.json
+}
+
 "call_$1"
