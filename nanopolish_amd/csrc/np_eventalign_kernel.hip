@@ -327,10 +327,37 @@ __global__ void __launch_bounds__(64, 5) np_eventalign_chain_kernel(np_ea_args a
 // Back-pointers: one dword per lane and sweep step (nine bits per block, see ea_block), one 256-byte line per step: cell
 // (row r, k-mer b) of half h lives in line r + b / 3, dword 32 h + b / 3, bits 9 (b % 3) .. 9 (b % 3) + 8.
 // ---------------------------------------------------------------------------------------------------------------------------
+// Round 4: the back-pointers of a sweep step leave the wave as eighteen 64-bit LANE MASKS (bit planes), written by SCALAR stores,
+// instead of one packed dword per lane (NP_EA_PLANES = 0: round 3's form).  Why: a step's vector instructions were 40 % selects and
+// shifts that only turn compare results -- lane masks in scalar registers already -- into per-lane codes (23 v_cndmask + 4 v_or3 of
+// ~122 instructions, all in the slow issue class).  The masks ARE the information: per block the M cell's code (3 bits: planes 0-2,
+// combined from the four equality masks by scalar logic, which has an issue port of its own), the B cell's bit (plane 3), the K cell's
+// two (planes 4-5: PREV_K, and PREV_B without PREV_K).  A line is 18 x 8 = 144 bytes instead of 256; bit l of a plane is lane l's block,
+// so half h's walk reads dword h of a plane.  The walk gathers a cell's six planes with six lanes and one ballot.
+#ifndef NP_EA_PLANES
+#define NP_EA_PLANES 1
+#endif
+#if NP_EA_PLANES
+#define NP_EA2_LINE 144
+#define NP_EA2_PLANES 18
+#else
 #define NP_EA2_LINE 256
+#endif
 #ifndef NP_EA_ARGMAX
 #define NP_EA_ARGMAX 1           // the M cell's arg-max: 0 = tournament (round 3), 1 = three-input maxima + equality chain (round 4)
 #endif
+
+// Arguments of a (not inlined) device function arrive in vector registers, and the compiler cannot know that they are wave-uniform:
+// everything computed from them would become vector code (the back-track as exec-masked vector loops, the argument block read with
+// flat loads).  These put a uniform value back into scalar registers.
+template <class T> __device__ __forceinline__ T* ea_uniform(T* p)
+{
+    const uint64_t u = (uint64_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    return (T*)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ float ea_uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ int ea_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 struct ea_read {                 // what the chain needs of a read, all derived from its index
     const np_read_dev* rd; const float* ev; const int32_t* ms; const char* ref;
@@ -410,6 +437,39 @@ __device__ __forceinline__ uint32_t ea_block(float& M, float& B, float& K, const
     return ck | cb | cm;
 }
 
+#if NP_EA_PLANES
+// The same cell update with the back-pointers as lane masks: p[0..2] the M cell's move code bit by bit (HMT_FROM_SAME_M 2, PREV_M 6,
+// SAME_B 1, PREV_B 5, PREV_K 4, SOFT 7 as in ea_block), p[3] "B comes from the block's own B", p[4] "K comes from PREV_K", p[5] "K
+// comes from PREV_B and not from PREV_K" (the walk: B 2 - p3, K 6 - p5 - 2 p4).  The masks are the compares' own result registers;
+// the priority of the equality chain ("the largest index whose candidate equals the maximum", r9.inl:138-143) is scalar logic:
+//   e4 -> 100, e3 & ~e4 -> 101, e2 & ~e3 & ~e4 -> 001, e1 & ~(e2 | e3 | e4) -> 110, none -> 010
+//   bit0 = (e3 | e2) & ~e4,   bit1 = ~(e4 | e3 | e2),   bit2 = e4 | e3 | (e1 & bit1);   soft (block 0 of row 1): all three set
+template <bool FIRST>
+__device__ __forceinline__ void ea_block_p(float& M, float& B, float& K, const float lM_r, const float lB_r, const float lK_r,
+                                           const float lM_p, const float lB_p, const float lK_p, const float x, const np_gauss& g,
+                                           const ea_trans& tr, const float soft, uint64_t* __restrict__ p)
+{
+    const float em = np_emission(x, g);
+    const float a0 = tr.mm_self + M, a1 = tr.mm_next + lM_p, a2 = tr.bm_self + B, a3 = tr.bm_next + lB_p, a4 = tr.km + lK_p;
+    float v = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), a3), a4);      // two three-input maxima
+    if (FIRST) v = __builtin_fmaxf(v, soft);
+    const uint64_t e1 = __builtin_amdgcn_ballot_w64(a1 == v), e2 = __builtin_amdgcn_ballot_w64(a2 == v), e3 = __builtin_amdgcn_ballot_w64(a3 == v),
+                   e4 = __builtin_amdgcn_ballot_w64(a4 == v);
+    const uint64_t t23 = e3 | e2, t234 = e4 | t23;
+    uint64_t c0 = t23 & ~e4, c1 = ~t234, c2 = (e4 | e3) | (e1 & c1);
+    if (FIRST) { const uint64_t es = __builtin_amdgcn_ballot_w64(soft == v); c0 |= es; c1 |= es; c2 |= es; }
+    const float newM = v + em;
+    const float b0 = tr.mb + M, b2 = tr.bb + B;
+    const float newB = __builtin_fmaxf(b0, b2);
+    const uint64_t pb = __builtin_amdgcn_ballot_w64(b2 >= b0);
+    const float k1 = tr.mk + lM_r, k3 = tr.bk + lB_r, k4 = tr.kk + lK_r;
+    const float newK = __builtin_fmaxf(__builtin_fmaxf(k1, k3), k4);
+    const uint64_t q4 = __builtin_amdgcn_ballot_w64(k4 == newK), q3 = __builtin_amdgcn_ballot_w64(k3 == newK) & ~q4;
+    M = newM; B = newB; K = newK;
+    p[0] = c0; p[1] = c1; p[2] = c2; p[3] = pb; p[4] = q4; p[5] = q3;
+}
+#endif
+
 struct ea_seg { const float* ev; int e_start, stride, e, n; };
 
 // The sweep of two segments, one per half-wave (e == 0: no segment).  tr, g0..g2: the lane's half's transitions and the scaled
@@ -433,7 +493,11 @@ __device__ __attribute__((noinline)) float2 ea_fill2(const np_gauss g0, const np
     float ec0 = buf_f32(evr0, off0(lane)), en0 = buf_f32(evr0, off0(lane + 64));
     float ec1 = buf_f32(evr1, off1(lane)), en1 = buf_f32(evr1, off1(lane + 64));
     float x = 0.0f;
+#if NP_EA_PLANES
+    const uint8_t* sline = ea_uniform(bp);                // (wave-uniform: the scalar stores' base)
+#else
     uint8_t* line = bp + 4 * lane;
+#endif
     // the first lane of a half has no left neighbour (block -1 = -inf): instead of a select after the lane shift, the shift ADDS a
     // per-lane constant -- -inf in lanes 0 and 32, else 0 (v + 0 == v for every value the lattice holds, v + -inf == -inf) -- in the
     // same DPP instruction (bound_ctrl: lane 0's missing source reads as 0)
@@ -445,6 +509,11 @@ __device__ __attribute__((noinline)) float2 ea_fill2(const np_gauss g0, const np
     };
     float soft = sl == 0 ? flank0 : NP_NEG_INF;                                  // HMT_FROM_SOFT: block 0 of row 1 only (flags 0)
     auto step = [&](const int t) {
+#if NP_EA_PLANES && !defined(NP_EA_NOWAIT)
+        // the previous step's eighteen scalar stores have had a whole step to finish: their data registers are free again from here on
+        // (NP_EA_NOWAIT: timing experiment -- what the wait costs)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
         const float nM = shr_add(M2), nB = shr_add(B2), nK = shr_add(K2);
         const int ti = (t - 1) & 63;
         if (ti == 0 && t > 1) { ec0 = en0; en0 = buf_f32(evr0, off0(t - 1 + 64 + lane)); ec1 = en1; en1 = buf_f32(evr1, off1(t - 1 + 64 + lane)); }
@@ -452,12 +521,30 @@ __device__ __attribute__((noinline)) float2 ea_fill2(const np_gauss g0, const np
         x = np_wave_shr1(x, xa);
         x = lane == 32 ? xb : x;
         const float pM0 = M0, pB0 = B0, pK0 = K0, pM1 = M1, pB1 = B1, pK1 = K1;
+#if NP_EA_PLANES
+        uint64_t pl[NP_EA2_PLANES];
+        ea_block_p<true>(M0, B0, K0, nM, nB, nK, oM, oB, oK, x, g0, tr, soft, pl);
+        ea_block_p<false>(M1, B1, K1, M0, B0, K0, pM0, pB0, pK0, x, g1, tr, NP_NEG_INF, pl + 6);
+        ea_block_p<false>(M2, B2, K2, M1, B1, K1, pM1, pB1, pK1, x, g2, tr, NP_NEG_INF, pl + 12);
+        oM = nM; oB = nB; oK = nK;
+        soft = NP_NEG_INF;
+        // ONE asm block issues the line's stores: every plane stays in its own scalar registers until all eighteen are on their way
+        const uint8_t* lp = sline + (size_t)(t - 1) * NP_EA2_LINE;
+        asm volatile("s_store_dwordx2 %1, %0, 0x0\n\ts_store_dwordx2 %2, %0, 0x8\n\ts_store_dwordx2 %3, %0, 0x10\n\ts_store_dwordx2 %4, %0, 0x18\n\t"
+                     "s_store_dwordx2 %5, %0, 0x20\n\ts_store_dwordx2 %6, %0, 0x28\n\ts_store_dwordx2 %7, %0, 0x30\n\ts_store_dwordx2 %8, %0, 0x38\n\t"
+                     "s_store_dwordx2 %9, %0, 0x40\n\ts_store_dwordx2 %10, %0, 0x48\n\ts_store_dwordx2 %11, %0, 0x50\n\ts_store_dwordx2 %12, %0, 0x58\n\t"
+                     "s_store_dwordx2 %13, %0, 0x60\n\ts_store_dwordx2 %14, %0, 0x68\n\ts_store_dwordx2 %15, %0, 0x70\n\ts_store_dwordx2 %16, %0, 0x78\n\t"
+                     "s_store_dwordx2 %17, %0, 0x80\n\ts_store_dwordx2 %18, %0, 0x88"
+                     :: "s"(lp), "s"(pl[0]), "s"(pl[1]), "s"(pl[2]), "s"(pl[3]), "s"(pl[4]), "s"(pl[5]), "s"(pl[6]), "s"(pl[7]), "s"(pl[8]), "s"(pl[9]),
+                        "s"(pl[10]), "s"(pl[11]), "s"(pl[12]), "s"(pl[13]), "s"(pl[14]), "s"(pl[15]), "s"(pl[16]), "s"(pl[17]) : "memory");
+#else
         uint32_t packed = ea_block<true, 0>(M0, B0, K0, nM, nB, nK, oM, oB, oK, x, g0, tr, soft);
         packed |= ea_block<false, 9>(M1, B1, K1, M0, B0, K0, pM0, pB0, pK0, x, g1, tr, NP_NEG_INF);
         packed |= ea_block<false, 18>(M2, B2, K2, M1, B1, K1, pM1, pB1, pK1, x, g2, tr, NP_NEG_INF);
         oM = nM; oB = nB; oK = nK;
         soft = NP_NEG_INF;
         *(uint32_t*)(line + (size_t)(t - 1) * NP_EA2_LINE) = packed;
+#endif
     };
     int t = 1;
     for (; t <= s_min; ++t) step(t);
@@ -465,6 +552,11 @@ __device__ __attribute__((noinline)) float2 ea_fill2(const np_gauss g0, const np
     // go on computing rows nobody reads)
     const float zM0 = M0, zM1 = M1, zM2 = M2;
     for (; t <= s_max; ++t) step(t);
+#if NP_EA_PLANES
+    // the lines sit in the scalar data cache: write them back to L2, where the walk's vector loads find them (ea_walk2 invalidates
+    // the vector L1 first: the scratch is reused segment after segment)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     const int ec_0 = s0.n > 0 ? (s0.n - 1) % 3 : 0, ec_1 = s1.n > 0 ? (s1.n - 1) % 3 : 0;
     const int my_ec = hi_half ? ec_1 : ec_0;
     const float live = my_ec == 0 ? M0 : my_ec == 1 ? M1 : M2, snap = my_ec == 0 ? zM0 : my_ec == 1 ? zM1 : zM2;
@@ -480,18 +572,6 @@ __device__ __attribute__((noinline)) float2 ea_fill2(const np_gauss g0, const np
 // walk's own variables competed for 102 scalar registers, and the compiler parked hundreds of them in vector-register lanes
 // (v_writelane / v_readlane on every use) -- the first form of this kernel was slower than the one-read kernel for that reason alone.
 struct ea_wave_state { ea_half h[2]; int drained; };
-
-// Arguments of a (not inlined) device function arrive in vector registers, and the compiler cannot know that they are wave-uniform:
-// everything computed from them would become vector code (the back-track as exec-masked vector loops, the argument block read with
-// flat loads).  These put a uniform value back into scalar registers.
-template <class T> __device__ __forceinline__ T* ea_uniform(T* p)
-{
-    const uint64_t u = (uint64_t)p;
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
-    return (T*)(((uint64_t)hi << 32) | lo);
-}
-__device__ __forceinline__ float ea_uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
-__device__ __forceinline__ int ea_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ ea_half ea_get(const ea_wave_state* W, int q)
 {
@@ -584,6 +664,7 @@ __device__ __attribute__((noinline)) void ea_next_segment(const np_ea_args* __re
 // code the chain is ~25 instructions for BOTH segments, and the back-pointer word is already the move (ea_block).
 // Per half: a window of NP_EA_WIN lines of its 32 dwords staged in LDS (refilled when the walk leaves it) and the list of visited
 // states in LDS (NP_EA_PCAP entries; a longer path spills the full buffer to the half's global list and goes on).
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 #define NP_EA_WIN 16
 #define NP_EA_PCAP 384
 struct ea_lds {
@@ -599,6 +680,7 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
 {
     const float sv0 = ea_uniform(sv0_), sv1 = ea_uniform(sv1_);
     const uint8_t* __restrict__ bp = ea_uniform(bp_);
+
     uint32_t* __restrict__ path0 = ea_uniform(path0_); uint32_t* __restrict__ path1 = ea_uniform(path1_);
     const ea_half H0 = ea_get(&L->W, 0), H1 = ea_get(&L->W, 1);
     const bool hi_half = lane >= 32;
@@ -609,9 +691,11 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
     int lo = 0x7fffffff;                                  // no window yet
     // assert(get(vm, row, col) != -INFINITY): no path, nothing to emit
     bool alive = (hi_half ? (H1.ri >= 0 && sv1 != NP_NEG_INF) : (H0.ri >= 0 && sv0 != NP_NEG_INF)) && e > 0 && n > 0;
-    const uint32_t* st = &L->stage[hi_half ? 1 : 0][0];
-    uint32_t* pb = &L->pbuf[hi_half ? 1 : 0][0];
-    uint32_t* dump = &L->dump[lane];
+    // (L arrives as a generic pointer -- a not-inlined function's argument; without the address space the compiler reads the staged
+    //  lines with flat loads behind null checks and 64-bit address arithmetic, in the middle of the walk's dependent chain)
+    const lds_u32* st = (const lds_u32*)&L->stage[hi_half ? 1 : 0][0];
+    lds_u32* pb = (lds_u32*)&L->pbuf[hi_half ? 1 : 0][0];
+    lds_u32* dump = (lds_u32*)&L->dump[lane];
     while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
         // ---- per half, by scalar control: refill the window of a walk that is outside it; spill a full list ----
         const bool need = alive && row + k3 < lo, full = alive && cnt - spilled >= NP_EA_PCAP;
@@ -622,10 +706,31 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
             if ((need_m >> (32 * h)) & 1ull) {
                 const int hi = __builtin_amdgcn_readlane(row + k3, 32 * h);
                 const int nlo = hi - (NP_EA_WIN - 1) > 1 ? hi - (NP_EA_WIN - 1) : 1;
+#if NP_EA_PLANES
+                // dword h of the eighteen planes of every line of the window: stage[h][line * 18 + plane].  Nine 16-byte requests per
+                // line (two planes each), all of a refill in flight at once (three rounds of 64 lanes cover 16 lines), at agent scope:
+                // they bypass the vector L1, which may still hold the previous segment's lines at these addresses (the sweep wrote the
+                // new ones through the scalar cache)
+                const int n16 = (hi - nlo + 1) * 9;
+                const __amdgpu_buffer_rsrc_t lr = make_rsrc(bp + (size_t)(nlo - 1) * NP_EA2_LINE, (uint32_t)(hi - nlo + 1) * NP_EA2_LINE);
+                lds_u32* dst = (lds_u32*)&L->stage[h][0];
+                uint4 v[3];
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {
+                    const int i = lane + 64 * it, ln = (i * 7282) >> 16;                       // i / 9 for i < 192
+                    v[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(lr, whole_offset(i < n16 ? ln * NP_EA2_LINE + (i - 9 * ln) * 16 : -16), 0, 16 /* sc1 */));
+                }
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {
+                    const int i = lane + 64 * it, ln = (i * 7282) >> 16, q = i - 9 * ln;
+                    if (i < n16) { dst[ln * NP_EA2_PLANES + 2 * q] = h ? v[it].y : v[it].x; dst[ln * NP_EA2_PLANES + 2 * q + 1] = h ? v[it].w : v[it].z; }
+                }
+#else
                 const int n16 = (hi - nlo + 1) * 8;
                 const uint8_t* __restrict__ src = bp + (size_t)(nlo - 1) * NP_EA2_LINE + 128 * h;
                 uint4* dst = (uint4*)&L->stage[h][0];
                 for (int i = lane; i < n16; i += 64) dst[i] = *(const uint4*)(src + (size_t)(i >> 3) * NP_EA2_LINE + (i & 7) * 16);
+#endif
                 lo = (hi_half == (h == 1)) ? nlo : lo;
             }
             if ((full_m >> (32 * h)) & 1ull) {
@@ -645,11 +750,24 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
             if (__builtin_amdgcn_ballot_w64(alive && !in) != 0ull || __builtin_amdgcn_ballot_w64(in) == 0ull) break;
             // the visited state goes to the half's list (lane 0 of the half writes it, the others write their dump slots)
             const uint32_t entry = (uint32_t)row | ((uint32_t)(3 * k3 + kr) << 16) | ((uint32_t)ps << 24);
-            uint32_t* wp = (in && sl == 0) ? pb + (cnt - spilled) : dump;
+            lds_u32* wp = (in && sl == 0) ? pb + (cnt - spilled) : dump;
             *wp = entry;
             // the move out of this cell
+#if NP_EA_PLANES
+            // every lane reads the six planes of the cell's block itself (the address does not depend on the state walked in) and takes
+            // the bit of the lane that owns the k-mer out of each; the three states' codes are cheap, the state picks one
+            const lds_u32* pw = st + (in ? (line - lo) * NP_EA2_PLANES + kr * 6 : 0);
+            const uint32_t x0 = (pw[0] >> k3) & 1u, x1 = (pw[1] >> k3) & 1u, x2 = (pw[2] >> k3) & 1u, x3 = (pw[3] >> k3) & 1u, x4 = (pw[4] >> k3) & 1u,
+                           x5 = (pw[5] >> k3) & 1u;
+            const uint32_t cM = x0 | (x1 << 1) | (x2 << 2), cB = 2u - x3, cK = 6u - x5 - 2u * x4;
+            // (masks, not selects: the two halves walk different states, and a select lets the compiler sink the loads into divergent
+            //  branches -- each half then waits for its own LDS round trip)
+            const uint32_t m2 = 0u - (uint32_t)(ps == 2), m1 = 0u - (uint32_t)(ps == 1);
+            const uint32_t c = (cM & m2) | (cB & m1) | (cK & ~(m2 | m1));
+#else
             const uint32_t w = st[in ? (line - lo) * 32 + k3 : 0];
             const uint32_t c = (w >> (9 * kr + 3 * ps)) & 7u;
+#endif
             const bool stop = c == 7u;                                  // HMT_FROM_SOFT
             const bool stepped = in && !stop;
             const int nrow = row - (ps != 0 ? 1 : 0);                   // K states are silent (r9.cpp:176-178)

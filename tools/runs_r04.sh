@@ -103,9 +103,9 @@ O=gpurun_out/r04h; mkdir -p $O
 ( timeout 600 python -m pytest tests/test_gpu_reflevel.py tests/test_gpu_eventalign_dropin.py tests/test_gpu_parity.py -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
 ( timeout 600 python tests/bench_eventalign.py --steps 3 --warmup 1 --cpu-sample 64 ) > $O/ea.json 2> $O/ea.err
 ( NP_HIP_LIB=$GRAFT_REPO_ROOT/nanopolish_amd/variants/libnp_hip_ea_r3.so timeout 600 python tests/bench_eventalign.py --steps 3 --warmup 1 --cpu-sample 0 ) > $O/ea_r3.json 2> $O/ea_r3.err
-( timeout 600 python tests/bench_percall_dropin.py ) > $O/percall.json 2> $O/percall.err
+for v in $EA_VARIANTS; do ( NP_HIP_LIB=$GRAFT_REPO_ROOT/nanopolish_amd/variants/libnp_hip_$v.so timeout 600 python tests/bench_eventalign.py --steps 3 --warmup 1 --cpu-sample 64 ) > $O/$v.json 2> $O/$v.err; done
 tail -3 $O/pytest.log
-for f in ea ea_r3; do echo "$f: $(grep -o '"value": [0-9.]*\|"eventalign_chain": [0-9.]*\|"rows_match": [a-z]*\|"copies_identical": [a-z]*' $O/$f.json | tr '\n' ' ')"; done
+for f in ea ea_r3 $EA_VARIANTS; do echo "$f: $(grep -o '"value": [0-9.]*\|"eventalign_chain": [0-9.]*\|"rows_match": [a-z]*\|"copies_identical": [a-z]*' $O/$f.json | tr '\n' ' ')"; done
 cat $O/percall.json
 }
 
