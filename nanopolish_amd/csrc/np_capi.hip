@@ -84,7 +84,6 @@ struct np_ctx {
     dev_buf ea_bp, ea_path, ea_args;                    // eventalign chain: per-wave back-pointer rows and path lists; a device copy of the launch arguments
     int ea_rows_cap = 4096, ea_waves_per_cu = 20;
     int ea_walk_prio = 0;            // two-read chain kernel: wave priority 3 during back-track + emission (helped the scalar walks, not the vector walk)
-    int ea_kernel = 2;                // eventalign chain: 1 = one read per wave (rounds 1-2), 2 = two reads per wave (np_eventalign_kernel.hip)
     dev_buf b_raw, b_raw_off, b_ev_off, b_ev_start, b_ev_len, b_ev_mean, b_ev_stdv, b_n_events;
     timing_t timing[NP_NUM_FAMILIES];
     std::mutex lock;
@@ -389,7 +388,6 @@ np_ctx* np_create(int device, const np_params* params)
     if (const char* v = getenv("NP_ALIGN_LPT")) c->align_lpt = atoi(v) != 0;
     if (const char* v = getenv("NP_ED_WARMUP")) c->ed_warmup = atoi(v);
     if (const char* v = getenv("NP_EA_WAVES_PER_CU")) c->ea_waves_per_cu = std::max(1, atoi(v));
-    if (const char* v = getenv("NP_EA_KERNEL")) c->ea_kernel = atoi(v) == 1 ? 1 : 2;
     if (const char* v = getenv("NP_EA_WALK_PRIO")) c->ea_walk_prio = atoi(v);
     if (params) c->params = *params; else np_default_params(&c->params);
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
@@ -1124,9 +1122,9 @@ int np_eventalign_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* r
     int32_t* op_read = op_ref + n_idx;
     int32_t* cig_reads = op_read + n_idx;
     const int rows_cap = c->ea_rows_cap;
-    const int variant = c->ea_kernel == 1 ? 1 : (c->ea_waves_per_cu > 16 ? 3 : 2);                       // (two-read kernel: 5 or 4 waves per SIMD)
+    const int variant = c->ea_waves_per_cu > 16 ? 3 : 2;                       // (the register budget of 5 or 4 waves per SIMD)
     const int waves_per_cu = c->ea_waves_per_cu;
-    const int nb = persistent_blocks(c, variant == 1 ? n_reads : (n_reads + 1) / 2, 1, waves_per_cu);
+    const int nb = persistent_blocks(c, (n_reads + 1) / 2, 1, waves_per_cu);
     const size_t bp_stride = ((size_t)rows_cap + 64) * (size_t)np_eventalign_line_bytes(variant), path_stride = 2 * ((size_t)rows_cap + 256);     // one line per sweep step: e + 63 at most; two path lists (one per half-wave in the two-read kernel)
     NP_HIP(c, c->ea_bp.reserve((size_t)nb * bp_stride));
     NP_HIP(c, c->ea_path.reserve((size_t)nb * path_stride * sizeof(uint32_t)));
@@ -1147,7 +1145,7 @@ int np_eventalign_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* r
     a.out_off = out_off; a.out_ref = out_ref; a.out_event = out_event; a.out_state = out_state; a.n_out = n_out; a.status = status;
     a.n_calls = n_calls; a.counter = c->d_counters + 17;
     NP_HIP(c, c->ea_args.reserve(sizeof(np_ea_args)));
-    if (variant != 1) NP_HIP(c, hipMemcpyAsync(c->ea_args.p, &a, sizeof(np_ea_args), hipMemcpyHostToDevice, s));      // (pageable source: staged before the call returns)
+    NP_HIP(c, hipMemcpyAsync(c->ea_args.p, &a, sizeof(np_ea_args), hipMemcpyHostToDevice, s));      // (pageable source: staged before the call returns)
     NP_HIP(c, np_launch_eventalign_chain(a, c->ea_args.as<np_ea_args>(), nb, variant, s));
     return NP_OK;
 }
@@ -1204,7 +1202,7 @@ int np_set_option(np_ctx* c, const char* name, int64_t value)
     else if (k == "ed_warmup") c->ed_warmup = (int)value;
     else if (k == "ea_rows_cap") c->ea_rows_cap = (int)std::min<int64_t>(65535, std::max<int64_t>(16, value));
     else if (k == "lse_oor") c->lse_oor = value != 0;          // tests: both log-sum lookups must give the same scores
-    else if (k == "ea_kernel") c->ea_kernel = value == 1 ? 1 : 2;
+    else if (k == "ea_kernel") { if (value != 2) { c->err = "ea_kernel: the one-read chain kernel was removed in round 4"; return NP_ERR_INVALID; } }
     else if (k == "ea_waves_per_cu") c->ea_waves_per_cu = (int)std::max<int64_t>(1, value);
     else { c->err = "np_set_option: unknown option " + k; return NP_ERR_INVALID; }
     return NP_OK;

@@ -16,7 +16,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=1500)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--ea-kernel", type=int, default=2)
     args = ap.parse_args()
     from oracle import load_models
     from oracle.ref_full import FullRef
@@ -40,7 +39,6 @@ def main():
         recs.append(dict(seq=rd["seq"], raw=rd["raw"], rc=rd["rc"], pos=rd["pos"], cigar=api.cigar_words(rd["cigar_ops"]), bam_seq=rd["bam_seq"]))
     t_synth = time.time() - t0
     ctx = Context(0); ctx.register_model(nuc, "nucleotide"); ctx.register_model(models["cpg"], "cpg")
-    ctx.set_option("ea_kernel", args.ea_kernel)
     hb = build_host_batch_records(models, recs, contig)
     batch = CallMethylationBatch(ctx, hb, "cuda:0", calibrate=True, from_raw=True, jobs_on_device=True)
     t0 = time.time()
@@ -78,7 +76,7 @@ def main():
         res = list(ex.map(check, range(len(recs))))
     t_cpu = time.time() - t0
     bs, br = sum(r[0] for r in res), sum(r[1] for r in res)
-    out = dict(reads=len(recs), seed=args.seed, ea_kernel=args.ea_kernel, sites_checked=sum(r[2] for r in res), rows_checked=sum(r[3] for r in res),
+    out = dict(reads=len(recs), seed=args.seed, sites_checked=sum(r[2] for r in res), rows_checked=sum(r[3] for r in res),
                reads_with_site_mismatch=bs, reads_with_row_mismatch=br, reads_without_events=sum(1 for r in res if r[2] == 0 and r[3] == 0),
                serial_path_reads=int(ctx.get_stat("ed_serial_reads")), seconds=dict(synth=round(t_synth, 1), gpu=round(t_gpu, 2), reference=round(t_cpu, 1)))
     print(json.dumps(out), flush=True)

@@ -88,15 +88,10 @@ def test_oversegmented_reads_long_segments(ctx, models):
         want.append(fr.eventalign(rc, 0, recs[-1]["cigar"], ref, ref))
         fr.close()
     hb = build_host_batch_records(models, recs, "")
-    try:
-        for kernel in (2, 1):
-            ctx.set_option("ea_kernel", kernel)
-            batch = CallMethylationBatch(ctx, hb, "cuda:0", calibrate=True, from_raw=True)
-            batch.step()
-            got = batch.eventalign()
-            for g, w in zip(got, want):
-                assert g["status"] == 0 and len(w["event_idx"]) > 3000
-                assert np.array_equal(g["ref_position"], w["ref_position"]) and np.array_equal(g["event_idx"], w["event_idx"]), kernel
-                assert np.array_equal(g["hmm_state"], w["hmm_state"]), kernel
-    finally:
-        ctx.set_option("ea_kernel", 2)
+    batch = CallMethylationBatch(ctx, hb, "cuda:0", calibrate=True, from_raw=True)
+    batch.step()
+    got = batch.eventalign()
+    for g, w in zip(got, want):
+        assert g["status"] == 0 and len(w["event_idx"]) > 3000
+        assert np.array_equal(g["ref_position"], w["ref_position"]) and np.array_equal(g["event_idx"], w["event_idx"])
+        assert np.array_equal(g["hmm_state"], w["hmm_state"])

@@ -2,6 +2,7 @@
 declares, refuses to run without a GPU (no CPU fallback), and its host helpers agree with the oracle / goldens."""
 import ctypes as C
 import os
+import sys
 import re
 
 import numpy as np
@@ -220,3 +221,24 @@ def test_bench_host_helpers():
     assert a.min() >= 600 and a.max() <= 40000 and abs(a.mean() - 5500) < 120 and a.std() > 2000
     visible, quota, eff = usable_cores()
     assert visible >= 1 and 1 <= eff <= visible and (quota is None or eff <= max(1, int(quota + 0.5)))
+
+
+def test_align_kernel_isa_guard_accepts_the_shipped_build_and_rejects_a_spilling_queue(tmp_path):
+    """tools/check_align_isa.py (run by the Makefile on every build of np_align_kernel.hip): the shipped kernel passes; the build with a
+    trace prefetch queue deeper than the register budget holds (NP_BT_DEPTH = 12: the compiler copies a queue entry right after the
+    inline-asm load that fills it -- the configuration that once walked garbage on the GPU) is rejected."""
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "nanopolish_amd", "csrc", "np_align_kernel.hip")
+    flags = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-S", "--cuda-device-only"]
+    for extra, want_ok in (([], True), (["-DNP_BT_DEPTH=12"], False)):
+        out = str(tmp_path / ("a%d.s" % len(extra)))
+        subprocess.run([hipcc] + flags + extra + [src, "-o", out], check=True, capture_output=True)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_align_isa.py"), out], capture_output=True, text=True)
+        assert (r.returncode == 0) == want_ok, r.stderr[-600:]
+        if not want_ok:
+            assert "may still be in flight" in r.stderr
