@@ -443,6 +443,13 @@ int np_detect_events_host(np_ctx* ctx, int n_reads, const float* const* raw, con
 int np_mom_fill_dev(np_ctx* ctx, void* stream, int n_reads, np_read_dev* reads, np_read_dev* reads_b, const float* event_mean,
                     const int32_t* n_events, const uint16_t* kmer_rank, int model);
 
+/* Direct-RNA reads (SquiggleRead::nucleotide_type == SRNT_RNA): load_from_raw uses the kit r9.4_70bps / alphabet u_to_t_rna / k = 5 model, the
+ * RNA detector parameters (np_event_detection_params(p, 1)), and REVERSES the detected events -- the strand is sequenced 3' -> 5' -- after the
+ * MoM scalings and before the event aligner (src/nanopolish_squiggle_read.cpp:206-213,260-263).  This entry point is that reversal for a
+ * batch, in place, on whichever of the four per-event arrays are given (event_off / n_events as np_detect_events_dev left them). */
+int np_reverse_events_dev(np_ctx* ctx, void* stream, int n_reads, const int64_t* event_off, const int32_t* n_events, uint32_t* event_start,
+                          float* event_length, float* event_mean, float* event_stdv);
+
 /* Device self-test: the emission's exact fast division (reciprocal + two fused corrections) against the IEEE fp32
  * divide on n_samples pseudo-random operand pairs; *n_mismatch must come back 0. */
 int np_selftest_division(np_ctx* ctx, uint64_t n_samples, uint64_t seed, uint64_t* n_mismatch);

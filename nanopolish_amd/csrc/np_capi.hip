@@ -1111,7 +1111,11 @@ int np_eventalign_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* r
                          !cigar_off || !read_len || !read_rc || !out_off || !out_ref || !out_event || !out_state || !n_out || !status || !n_calls)))
         return NP_ERR_INVALID;
     if (model < 0 || model >= (int)c->models.size()) { c->err = "bad model id"; return NP_ERR_INVALID; }
-    if (c->models[model].n_states != 4096 || k != 6) { c->err = "np_eventalign_dev: nucleotide 6-mer base model only"; return NP_ERR_UNSUPPORTED; }
+    // the base model of a DNA read (4096 states, k = 6) or of a direct-RNA read (u_to_t_rna: 1024 states, k = 5); a segment holds up to
+    // 102 - k k-mers (eventalign.cpp:695-735)
+    if (!((c->models[model].n_states == 4096 && k == 6) || (c->models[model].n_states == 1024 && k == 5))) {
+        c->err = "np_eventalign_dev: a four-letter base model with k = 6 (DNA) or k = 5 (direct RNA)"; return NP_ERR_UNSUPPORTED;
+    }
     if (n_reads == 0) return NP_OK;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
@@ -1122,7 +1126,7 @@ int np_eventalign_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* r
     int32_t* op_read = op_ref + n_idx;
     int32_t* cig_reads = op_read + n_idx;
     const int rows_cap = c->ea_rows_cap;
-    const int variant = c->ea_waves_per_cu > 16 ? 3 : 2;                       // (the register budget of 5 or 4 waves per SIMD)
+    const int variant = k == 5 ? 4 : (c->ea_waves_per_cu > 16 ? 3 : 2);        // (k = 5: four blocks per lane; else the register budget of 5 or 4 waves per SIMD)
     const int waves_per_cu = c->ea_waves_per_cu;
     const int nb = persistent_blocks(c, (n_reads + 1) / 2, 1, waves_per_cu);
     const size_t bp_stride = ((size_t)rows_cap + 64) * (size_t)np_eventalign_line_bytes(variant), path_stride = 2 * ((size_t)rows_cap + 256);     // one line per sweep step: e + 63 at most; two path lists (one per half-wave in the two-read kernel)
@@ -1140,7 +1144,7 @@ int np_eventalign_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* r
     a.model = c->models[model].d_states; a.flank = c->d_flank; a.genome = genome; a.ref_begin = ref_begin; a.ref_len = ref_len;
     a.cigar = cigar; a.cigar_off = cigar_off; a.op_ref = op_ref; a.op_read = op_read; a.cig_reads = cig_reads;
     a.read_len = read_len; a.read_rc = read_rc; a.k = (int)k;
-    a.bp = c->ea_bp.as<uint8_t>(); a.bp_stride = bp_stride; a.rows_cap = rows_cap;
+    a.bp = c->ea_bp.as<uint8_t>(); a.bp_stride = bp_stride; a.rows_cap = rows_cap; a.max_kmers = np_eventalign_max_kmers(variant);
     a.path = c->ea_path.as<uint32_t>(); a.path_stride = path_stride;
     a.out_off = out_off; a.out_ref = out_ref; a.out_event = out_event; a.out_state = out_state; a.n_out = n_out; a.status = status;
     a.n_calls = n_calls; a.counter = c->d_counters + 17;
@@ -1319,6 +1323,21 @@ int np_mom_fill_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* reads, np
     stream_scope scope = use_stream(c, stream, false); hipStream_t s = scope.s;
     family_timer tm(c, 5, s);
     NP_HIP(c, np_launch_mom_fill(n_reads, reads, reads_b, event_mean, n_events, kmer_rank, c->models[model].d_states, s));
+    return NP_OK;
+}
+
+// Direct-RNA reads: the detected events of every read reversed in place (squiggle_read.cpp:260-263), AFTER np_mom_fill_dev (the MoM
+// sums run over the events in detection order) and before np_event_align_dev.  Any of the four arrays may be null.
+int np_reverse_events_dev(np_ctx* c, void* stream, int n_reads, const int64_t* event_off, const int32_t* n_events, uint32_t* event_start,
+                          float* event_length, float* event_mean, float* event_stdv)
+{
+    if (!c || n_reads < 0 || (n_reads > 0 && (!event_off || !n_events))) return NP_ERR_INVALID;
+    if (n_reads == 0) return NP_OK;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    stream_scope scope = use_stream(c, stream, false); hipStream_t s = scope.s;
+    family_timer tm(c, 4, s);
+    NP_HIP(c, np_launch_reverse_events(n_reads, event_off, n_events, event_start, event_length, event_mean, event_stdv, s));
     return NP_OK;
 }
 

@@ -50,27 +50,35 @@ bool spliced(const bam1_t* b)
 
 } // namespace
 
-void np_realign_reads_batch(std::vector<NpRealignRead>& reads, const faidx_t* fai, const bam_hdr_t* hdr, int region_start, int region_end)
+// one device pass over the records of ONE nucleotide type (load_from_raw picks kit, alphabet, k and detector by it, squiggle_read.cpp:197-213)
+static void realign_group(std::vector<NpRealignRead>& reads, const bool rna, const faidx_t* fai, const bam_hdr_t* hdr, int region_start, int region_end)
 {
     const int n_all = (int)reads.size();
-    if (n_all == 0) return;
     np_ctx* c = shim().get();
     Buffers& B = buffers();
-    std::lock_guard<std::mutex> g(B.lock);
-    // what load_from_raw hard-codes for a DNA read (squiggle_read.cpp:197-218)
-    const std::string kit = "r9.4_450bps", alphabet = "nucleotide", strand_str = "template";
-    const uint32_t k = 6;
+    // DNA: what load_from_raw hard-codes (squiggle_read.cpp:197-202); direct RNA: kit r9.4_70bps, alphabet u_to_t_rna, k = 5, the RNA
+    // detector, U read as T, and the events reversed after the MoM scalings (:206-213, :260-263)
+    const std::string kit = rna ? "r9.4_70bps" : "r9.4_450bps", alphabet = rna ? "u_to_t_rna" : "nucleotide", strand_str = "template";
+    const uint32_t k = rna ? 5 : 6;
+    if (!PoreModelSet::has_model(kit, alphabet, strand_str, k)) {          // (a build without the RNA models: the caller's own path)
+        for (int i = 0; i < n_all; ++i) if ((reads[i].rna != 0) == rna) reads[i].status = NP_REALIGN_HOST_PATH;
+        return;
+    }
     const PoreModel* pm = PoreModelSet::get_model(kit, alphabet, strand_str, k);
+    std::vector<std::string> seq_t(rna ? n_all : 0);                      // RNA: the read sequence with U -> T (:212)
 
     // ---- phase 1: which records go to the device; reference segments; sizes ----------------------------------------------------------
     std::vector<int> idx;
     std::vector<std::string> ref_seqs(n_all);
     for (int i = 0; i < n_all; ++i) {
         NpRealignRead& R = reads[i];
+        if ((R.rna != 0) != rna) continue;                                // the other group's record
         R.alignment.clear(); R.sr.reset(); R.status = NP_REALIGN_OK;
         const bam1_t* b = R.record;
-        bool fits = b && !R.rna && R.read_sequence && R.read_sequence->length() > 20 && R.raw_pa && R.n_raw >= 64 &&      // (:141-146)
-                    (b->core.flag & BAM_FUNMAP) == 0 && !spliced(b) && plain_acgt(*R.read_sequence);
+        if (rna && R.read_sequence) { seq_t[i] = *R.read_sequence; std::replace(seq_t[i].begin(), seq_t[i].end(), 'U', 'T'); }
+        const std::string* rs = rna ? &seq_t[i] : R.read_sequence;
+        bool fits = b && R.read_sequence && rs->length() > 20 && R.raw_pa && R.n_raw >= 64 &&      // (:141-146)
+                    (b->core.flag & BAM_FUNMAP) == 0 && !spliced(b) && plain_acgt(*rs);
         if (fits && region_start != -1 && region_end != -1)            // trim_aligned_pairs_to_ref_region would cut the record: host path
             fits = b->core.pos >= region_start && bam_endpos(b) <= region_end;
         if (!fits) { R.status = NP_REALIGN_HOST_PATH; continue; }
@@ -94,7 +102,7 @@ void np_realign_reads_batch(std::vector<NpRealignRead>& reads, const faidx_t* fa
     int64_t max_samples = 1, max_events = 1, max_bands = 1;
     for (int q = 0; q < n; ++q) {
         const NpRealignRead& R = reads[idx[q]];
-        const int64_t n_raw = (int64_t)R.n_raw, nk = (int64_t)R.read_sequence->size() - k + 1, ecap = n_raw / 2 + 2;
+        const int64_t n_raw = (int64_t)R.n_raw, nk = (int64_t)(rna ? seq_t[idx[q]].size() : R.read_sequence->size()) - k + 1, ecap = n_raw / 2 + 2;
         raw_off[q + 1] = raw_off[q] + n_raw; event_off[q + 1] = event_off[q] + ecap; rank_off[q + 1] = rank_off[q] + nk;
         cigar_off[q + 1] = cigar_off[q] + R.record->core.n_cigar; genome_off[q + 1] = genome_off[q] + (int64_t)ref_seqs[idx[q]].size();
         pair_off[q + 1] = pair_off[q] + ecap + nk + 2; out_off[q + 1] = out_off[q] + ecap + 1;
@@ -128,7 +136,7 @@ void np_realign_reads_batch(std::vector<NpRealignRead>& reads, const faidx_t* fa
     #pragma omp parallel for schedule(dynamic)
     for (int q = 0; q < n; ++q) {
         const NpRealignRead& R = reads[idx[q]];
-        const std::string& seq = *R.read_sequence;
+        const std::string& seq = rna ? seq_t[idx[q]] : *R.read_sequence;
         for (int t = 0; t < 2; ++t)
             np_fill_read_host(t ? &h_reads_b[q] : &h_reads_a[q], 0.0, 1.0, 1.0, event_off[q], (uint32_t)(event_off[q + 1] - event_off[q]), rank_off[q],
                               (uint32_t)(rank_off[q + 1] - rank_off[q]));
@@ -156,13 +164,16 @@ void np_realign_reads_batch(std::vector<NpRealignRead>& reads, const faidx_t* fa
     check(np_memset_dev(c, NULL, O, 0, lo.size), "np_memset_dev");
     check(np_memset_dev(c, NULL, X, 0, zero_bytes), "np_memset_dev");
     np_detector_param prm;
-    np_event_detection_params(&prm, 0);
+    np_event_detection_params(&prm, rna ? 1 : 0);
     np_read_dev* reads_a = (np_read_dev*)(D + i_reads_a); np_read_dev* reads_b = (np_read_dev*)(D + i_reads_b);
     float* ev_mean = (float*)(O + o_ev_mean);
     check(np_detect_events_dev(c, NULL, n, (float*)(D + i_raw), (int64_t*)(D + i_raw_off), max_samples, &prm, (float*)(X + s_tstat),
                                (int64_t*)(D + i_event_off), max_events, (uint32_t*)(O + o_ev_start), (float*)(O + o_ev_len), ev_mean,
                                (float*)(O + o_ev_stdv), (int32_t*)(O + o_n_events)), "np_detect_events_dev");
     check(np_mom_fill_dev(c, NULL, n, reads_a, reads_b, ev_mean, (int32_t*)(O + o_n_events), (uint16_t*)(D + i_ranks), m_nuc), "np_mom_fill_dev");
+    if (rna)
+        check(np_reverse_events_dev(c, NULL, n, (int64_t*)(D + i_event_off), (int32_t*)(O + o_n_events), (uint32_t*)(O + o_ev_start), (float*)(O + o_ev_len),
+                                    ev_mean, (float*)(O + o_ev_stdv)), "np_reverse_events_dev");
     check(np_event_align_dev(c, NULL, n, reads_a, ev_mean, (uint16_t*)(D + i_ranks), m_nuc, max_bands, (int64_t*)(D + i_pair_off),
                              (np_pair*)(X + s_pairs), (int32_t*)(X + s_pair_begin), (int32_t*)(O + o_n_pairs)), "np_event_align_dev");
     check(np_calibrate_resolve_dev(c, NULL, n, reads_b, ev_mean, (uint16_t*)(D + i_ranks), m_nuc, (int64_t*)(D + i_pair_off), (np_pair*)(X + s_pairs),
@@ -196,8 +207,8 @@ void np_realign_reads_batch(std::vector<NpRealignRead>& reads, const faidx_t* fa
         NpRealignRead& R = reads[idx[q]];
         if (n_events[q] < 0 || status[q] != NP_EA_OK) { R.status = NP_REALIGN_HOST_PATH; continue; }    // NP_ED_INEXACT / overflow / a record the chain refuses
         std::shared_ptr<SquiggleRead> sr(new SquiggleRead());
-        sr->read_name = R.read_name; sr->read_sequence = *R.read_sequence;
-        sr->nucleotide_type = SRNT_DNA; sr->read_type = SRT_TEMPLATE; sr->pore_type = PORETYPE_R9;
+        sr->read_name = R.read_name; sr->read_sequence = rna ? seq_t[idx[q]] : *R.read_sequence;
+        sr->nucleotide_type = rna ? SRNT_RNA : SRNT_DNA; sr->read_type = SRT_TEMPLATE; sr->pore_type = PORETYPE_R9;
         sr->base_model[0] = pm; sr->base_model[1] = NULL;
         sr->sample_rate = R.sample_rate; sr->channel_id = 0; sr->sample_start_time = 0; sr->read_id = 0;
         sr->events_per_base[0] = sr->events_per_base[1] = 0.0;
@@ -210,13 +221,14 @@ void np_realign_reads_batch(std::vector<NpRealignRead>& reads, const faidx_t* fa
         if (keep) {
             sr->events[0].resize(ne);
             double start_time = 0;
-            for (int e = 0; e < ne; ++e) {                                              // squiggle_read.cpp:243-249
-                const int64_t o = event_off[q] + e;
+            for (int e = 0; e < ne; ++e) {                                              // squiggle_read.cpp:243-249, in DETECTION order
+                const int64_t o = event_off[q] + (rna ? ne - 1 - e : e);                // (the device arrays of an RNA read are reversed already)
                 const float length_in_seconds = ev_len[o] / sr->sample_rate;
                 const SquiggleEvent se = { evm[o], evs[o], start_time, length_in_seconds, logf(evs[o]) };
                 sr->events[0][e] = se;
                 start_time += length_in_seconds;
             }
+            if (rna) std::reverse(sr->events[0].begin(), sr->events[0].end());           // :260-263
         }
         if (aligned) {
             const int64_t nk = rank_off[q + 1] - rank_off[q];
@@ -247,4 +259,15 @@ void np_realign_reads_batch(std::vector<NpRealignRead>& reads, const faidx_t* fa
             else ea.model_kmer = std::string(k, 'N');
         }
     }
+}
+
+void np_realign_reads_batch(std::vector<NpRealignRead>& reads, const faidx_t* fai, const bam_hdr_t* hdr, int region_start, int region_end)
+{
+    if (reads.empty()) return;
+    Buffers& B = buffers();
+    std::lock_guard<std::mutex> g(B.lock);
+    bool any_dna = false, any_rna = false;
+    for (size_t i = 0; i < reads.size(); ++i) { if (reads[i].rna) any_rna = true; else any_dna = true; }
+    if (any_dna) realign_group(reads, false, fai, hdr, region_start, region_end);
+    if (any_rna) realign_group(reads, true, fai, hdr, region_start, region_end);
 }

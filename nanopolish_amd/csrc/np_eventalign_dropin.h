@@ -18,7 +18,8 @@ struct NpRealignRead {
     size_t n_raw = 0;
     double sample_rate = 4000.0;               // Fast5Data::channel_params.sample_rate
     size_t read_idx = 0;
-    int rna = 0;                               // an RNA read (other kit, k = 5, other detector): NP_REALIGN_HOST_PATH
+    int rna = 0;                               // SquiggleRead::nucleotide_type == SRNT_RNA: kit r9.4_70bps, alphabet u_to_t_rna, k = 5, the RNA
+                                               // detector, events reversed (squiggle_read.cpp:206-213,260-263); a batch may mix both types
     // out
     std::shared_ptr<SquiggleRead> sr;          // the read as SquiggleRead(sequence, Fast5Data, 0) leaves it after load_from_raw: events,
                                                // scalings, base_to_event_map, events_per_base, base model (what the reference's writers read)

@@ -48,22 +48,17 @@ struct ea_trans { float mm_self, mb, mk, mm_next, bb, bk, bm_next, bm_self, kk, 
 // Back-pointers: one dword per lane and sweep step (nine bits per block, see ea_block), one 256-byte line per step: cell
 // (row r, k-mer b) of half h lives in line r + b / 3, dword 32 h + b / 3, bits 9 (b % 3) .. 9 (b % 3) + 8.
 // ---------------------------------------------------------------------------------------------------------------------------
-// Round 4: the back-pointers of a sweep step leave the wave as eighteen 64-bit LANE MASKS (bit planes), written by SCALAR stores,
-// instead of one packed dword per lane (NP_EA_PLANES = 0: round 3's form).  Why: a step's vector instructions were 40 % selects and
-// shifts that only turn compare results -- lane masks in scalar registers already -- into per-lane codes (23 v_cndmask + 4 v_or3 of
-// ~122 instructions, all in the slow issue class).  The masks ARE the information: per block the M cell's code (3 bits: planes 0-2,
+// Round 4: the back-pointers of a sweep step leave the wave as 64-bit LANE MASKS (bit planes), six per k-mer block of a lane, written
+// by SCALAR stores, instead of one packed dword per lane (round 3).  Why: a step's vector instructions were 40 % selects and shifts
+// that only turn compare results -- lane masks in scalar registers already -- into per-lane codes (23 v_cndmask + 4 v_or3 of ~122
+// instructions, all in the slow issue class).  The masks ARE the information: per block the M cell's code (3 bits: planes 0-2,
 // combined from the four equality masks by scalar logic, which has an issue port of its own), the B cell's bit (plane 3), the K cell's
-// two (planes 4-5: PREV_K, and PREV_B without PREV_K).  A line is 18 x 8 = 144 bytes instead of 256; bit l of a plane is lane l's block,
-// so half h's walk reads dword h of a plane.  The walk gathers a cell's six planes with six lanes and one ballot.
-#ifndef NP_EA_PLANES
-#define NP_EA_PLANES 1
-#endif
-#if NP_EA_PLANES
-#define NP_EA2_LINE 144
-#define NP_EA2_PLANES 18
-#else
-#define NP_EA2_LINE 256
-#endif
+// two (planes 4-5: PREV_K, and PREV_B without PREV_K).  A line is 6 x BPL x 8 bytes (144 at three blocks per lane, round 3: 256); bit
+// l of a plane is lane l's block, so half h's walk reads dword h of a plane.
+// BPL, the k-mer blocks per lane: a segment spans up to 101 reference bases (eventalign.cpp:695-735), i.e. 102 - k k-mers: 96 for the
+// DNA models (k = 6: three blocks on each of a half-wave's 32 lanes), 97 for the direct-RNA model (k = 5): that one k-mer more takes a
+// fourth block per lane (np_eventalign_chain2_kernel<WAVES, 4>: the same code, 24 planes per line).
+#define NP_EA2_LINE_BYTES(BPL) (48 * (BPL))
 #ifndef NP_EA_ARGMAX
 #define NP_EA_ARGMAX 1           // the M cell's arg-max: 0 = tournament (round 3), 1 = three-input maxima + equality chain (round 4)
 #endif
@@ -117,50 +112,10 @@ struct ea_half {                 // chain state of the read a half-wave works on
 // Returns the block's back-pointers as NINE bits, three per state (K in bits 0..2, B in 3..5, M in 6..8), each already the
 // back-track's move: bit 2 = "the k-mer steps back", bits 1..0 = the state walked to (2 MATCH, 1 BAD_EVENT, 0 KMER_SKIP), 7 = soft
 // clip (stop).  I.e. HMT_FROM_SAME_M 2, PREV_M 6, SAME_B 1, PREV_B 5, PREV_K 4, SOFT 7 (r9.cpp:150-186): the walk needs no decoding.
-// Round 4 (issue-cost driven: a select, a compare, a maximum and a shift each cost 6.3 cycles of a SIMD's issue time, an add 3.7 --
-// profiles/r04_valu_calibration.json): the codes are selected already SHIFTED to the block's position in the step's dword (SHIFT = 0,
-// 9, 18: no shift instructions), and the M cell's maximum is two three-input maxima with the arg-max as an equality chain ("the
-// largest index whose candidate equals the maximum", r9.inl:138-143, literally) -- ten slow-class instructions where round 3's
-// tournament (NP_EA_ARGMAX = 0) has twelve.
-template <bool FIRST, int SHIFT>
-__device__ __forceinline__ uint32_t ea_block(float& M, float& B, float& K, const float lM_r, const float lB_r, const float lK_r,
-                                             const float lM_p, const float lB_p, const float lK_p, const float x, const np_gauss& g,
-                                             const ea_trans& tr, const float soft)
-{
-    constexpr uint32_t SM = 6 + SHIFT, SB = 3 + SHIFT, SK = SHIFT;
-    const float em = np_emission(x, g);
-    const float a0 = tr.mm_self + M, a1 = tr.mm_next + lM_p, a2 = tr.bm_self + B, a3 = tr.bm_next + lB_p, a4 = tr.km + lK_p;
-#if NP_EA_ARGMAX == 1
-    float v = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), __builtin_fmaxf(a3, a4));
-    if (FIRST) v = __builtin_fmaxf(v, soft);
-    uint32_t cm = 2u << SM;
-    cm = (a1 == v) ? 6u << SM : cm; cm = (a2 == v) ? 1u << SM : cm; cm = (a3 == v) ? 5u << SM : cm; cm = (a4 == v) ? 4u << SM : cm;
-    if (FIRST) cm = (soft == v) ? 7u << SM : cm;
-#else
-    // maximum and arg-max as a tournament in which a tie goes to the later candidate at every node: 4 max + 4 compares + 4 selects
-    const float m01 = __builtin_fmaxf(a0, a1), m23 = __builtin_fmaxf(a2, a3);
-    const uint32_t c01 = (a1 >= a0) ? 6u << SM : 2u << SM, c23 = (a3 >= a2) ? 5u << SM : 1u << SM;
-    const float m03 = __builtin_fmaxf(m01, m23);
-    uint32_t cm = (m23 >= m01) ? c23 : c01;
-    float v = __builtin_fmaxf(m03, a4);
-    cm = (a4 >= m03) ? 4u << SM : cm;
-    if (FIRST) { cm = (soft >= v) ? 7u << SM : cm; v = __builtin_fmaxf(v, soft); }
-#endif
-    const float newM = v + em;
-    // (the B and K states emit 0: the reference's `+ lp_emission` leaves every value it can meet here unchanged)
-    const float b0 = tr.mb + M, b2 = tr.bb + B;
-    const float newB = __builtin_fmaxf(b0, b2);
-    const uint32_t cb = (b2 >= b0) ? 1u << SB : 2u << SB;         // from the block's own B, else from its own M
-    const float k1 = tr.mk + lM_r, k3 = tr.bk + lB_r, k4 = tr.kk + lK_r;
-    const float newK = __builtin_fmaxf(__builtin_fmaxf(k1, k3), k4);
-    uint32_t ck = (k3 == newK) ? 5u << SK : 6u << SK; ck = (k4 == newK) ? 4u << SK : ck;
-    M = newM; B = newB; K = newK;
-    return ck | cb | cm;
-}
-
-#if NP_EA_PLANES
-// The same cell update with the back-pointers as lane masks: p[0..2] the M cell's move code bit by bit (HMT_FROM_SAME_M 2, PREV_M 6,
-// SAME_B 1, PREV_B 5, PREV_K 4, SOFT 7 as in ea_block), p[3] "B comes from the block's own B", p[4] "K comes from PREV_K", p[5] "K
+// One k-mer block of one lattice row (the candidates of r9.inl:130-197 in HMMMovementType order, later index wins ties; (lM_r, lB_r,
+// lK_r): the block to the left in this row, (lM_p, ...): in the previous row) with the back-pointers as lane masks: p[0..2] the M cell's move code bit by bit (HMT_FROM_SAME_M 2, PREV_M 6,
+// SAME_B 1, PREV_B 5, PREV_K 4, SOFT 7: bit 2 = "the k-mer steps back", bits 1..0 = the state walked to, 2 MATCH, 1 BAD_EVENT, 0
+// KMER_SKIP; 7 = soft clip, stop -- r9.cpp:150-186), p[3] "B comes from the block's own B", p[4] "K comes from PREV_K", p[5] "K
 // comes from PREV_B and not from PREV_K" (the walk: B 2 - p3, K 6 - p5 - 2 p4).  The masks are the compares' own result registers;
 // the priority of the equality chain ("the largest index whose candidate equals the maximum", r9.inl:138-143) is scalar logic:
 //   e4 -> 100, e3 & ~e4 -> 101, e2 & ~e3 & ~e4 -> 001, e1 & ~(e2 | e3 | e4) -> 110, none -> 010
@@ -189,24 +144,29 @@ __device__ __forceinline__ void ea_block_p(float& M, float& B, float& K, const f
     M = newM; B = newB; K = newK;
     p[0] = c0; p[1] = c1; p[2] = c2; p[3] = pb; p[4] = q4; p[5] = q3;
 }
-#endif
 
 struct ea_seg { const float* ev; int e_start, stride, e, n; };
 
-// The sweep of two segments, one per half-wave (e == 0: no segment).  tr, g0..g2: the lane's half's transitions and the scaled
-// Gaussians of the lane's three blocks.  Returns the value of (last row, MATCH of the last k-mer) of each segment.
-__device__ __attribute__((noinline)) float2 ea_fill2(const np_gauss g0, const np_gauss g1, const np_gauss g2, const ea_trans tr,
-                                                     const float flank0, const ea_seg s0, const ea_seg s1, uint8_t* __restrict__ bp, const int lane)
+// The sweep of two segments, one per half-wave (e == 0: no segment).  tr, g[]: the lane's half's transitions and the scaled Gaussians
+// of the lane's BPL blocks.  Returns the value of (last row, MATCH of the last k-mer) of each segment.
+template <int BPL> struct ea_gauss { np_gauss g[BPL]; };
+template <int BPL>
+__device__ __attribute__((noinline)) float2 ea_fill2(const ea_gauss<BPL> G, const ea_trans tr, const float flank0, const ea_seg s0, const ea_seg s1,
+                                                     uint8_t* __restrict__ bp, const int lane)
 {
+    constexpr int LINE = NP_EA2_LINE_BYTES(BPL);
     const int sl = lane & 31;
     const bool hi_half = lane >= 32;
-    const int lu0 = (s0.n + 2) / 3, lu1 = (s1.n + 2) / 3;
+    const int lu0 = (s0.n + BPL - 1) / BPL, lu1 = (s1.n + BPL - 1) / BPL;
     const int steps0 = __builtin_amdgcn_readfirstlane(s0.e > 0 ? s0.e + lu0 - 1 : 0), steps1 = __builtin_amdgcn_readfirstlane(s1.e > 0 ? s1.e + lu1 - 1 : 0);
     const int s_min = steps0 < steps1 ? steps0 : steps1, s_max = steps0 < steps1 ? steps1 : steps0;
-    float M0 = NP_NEG_INF, M1 = NP_NEG_INF, M2 = NP_NEG_INF, B0 = NP_NEG_INF, B1 = NP_NEG_INF, B2 = NP_NEG_INF, K0 = NP_NEG_INF, K1 = NP_NEG_INF,
-          K2 = NP_NEG_INF;                                                  // row r-1 of this lane's three blocks
+    float M[BPL], B[BPL], K[BPL];                                           // row r-1 of this lane's blocks
+#pragma unroll
+    for (int c = 0; c < BPL; ++c) M[c] = B[c] = K[c] = NP_NEG_INF;
     float oM = NP_NEG_INF, oB = NP_NEG_INF, oK = NP_NEG_INF;                // row r-1 of the block to the left
-    // events: see ea_fill; one stream per half, every lane holds 64 events of BOTH streams
+    // events: one stream per half, every lane holds 64 events of BOTH streams: every lane walks its half's event sequence one step
+    // behind its left neighbour, so the wave fetches 64 events with one coalesced load (a block ahead), the half's first lane takes
+    // its event with v_readlane and the others by one DPP shift
     const __amdgpu_buffer_rsrc_t evr0 = make_rsrc(s0.ev + (s0.stride > 0 ? s0.e_start : s0.e_start - (s0.e - 1)), (uint32_t)s0.e * 4u);
     const __amdgpu_buffer_rsrc_t evr1 = make_rsrc(s1.ev + (s1.stride > 0 ? s1.e_start : s1.e_start - (s1.e - 1)), (uint32_t)s1.e * 4u);
     auto off0 = [&](int idx) { return s0.stride > 0 ? 4 * idx : 4 * (s0.e - 1 - idx); };
@@ -214,11 +174,7 @@ __device__ __attribute__((noinline)) float2 ea_fill2(const np_gauss g0, const np
     float ec0 = buf_f32(evr0, off0(lane)), en0 = buf_f32(evr0, off0(lane + 64));
     float ec1 = buf_f32(evr1, off1(lane)), en1 = buf_f32(evr1, off1(lane + 64));
     float x = 0.0f;
-#if NP_EA_PLANES
     const uint8_t* sline = ea_uniform(bp);                // (wave-uniform: the scalar stores' base)
-#else
-    uint8_t* line = bp + 4 * lane;
-#endif
     // the first lane of a half has no left neighbour (block -1 = -inf): instead of a select after the lane shift, the shift ADDS a
     // per-lane constant -- -inf in lanes 0 and 32, else 0 (v + 0 == v for every value the lattice holds, v + -inf == -inf) -- in the
     // same DPP instruction (bound_ctrl: lane 0's missing source reads as 0)
@@ -230,27 +186,28 @@ __device__ __attribute__((noinline)) float2 ea_fill2(const np_gauss g0, const np
     };
     float soft = sl == 0 ? flank0 : NP_NEG_INF;                                  // HMT_FROM_SOFT: block 0 of row 1 only (flags 0)
     auto step = [&](const int t) {
-#if NP_EA_PLANES && !defined(NP_EA_NOWAIT)
-        // the previous step's eighteen scalar stores have had a whole step to finish: their data registers are free again from here on
-        // (NP_EA_NOWAIT: timing experiment -- what the wait costs)
+#ifndef NP_EA_NOWAIT
+        // the previous step's scalar stores have had a whole step to finish: their data registers are free again from here on
+        // (NP_EA_NOWAIT: timing experiment -- the wait costs nothing measurable)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-        const float nM = shr_add(M2), nB = shr_add(B2), nK = shr_add(K2);
+        const float nM = shr_add(M[BPL - 1]), nB = shr_add(B[BPL - 1]), nK = shr_add(K[BPL - 1]);
         const int ti = (t - 1) & 63;
         if (ti == 0 && t > 1) { ec0 = en0; en0 = buf_f32(evr0, off0(t - 1 + 64 + lane)); ec1 = en1; en1 = buf_f32(evr1, off1(t - 1 + 64 + lane)); }
         const float xa = readlane_f32(ec0, ti), xb = readlane_f32(ec1, ti);     // the event of row t of either segment
         x = np_wave_shr1(x, xa);
         x = lane == 32 ? xb : x;
-        const float pM0 = M0, pB0 = B0, pK0 = K0, pM1 = M1, pB1 = B1, pK1 = K1;
-#if NP_EA_PLANES
-        uint64_t pl[NP_EA2_PLANES];
-        ea_block_p<true>(M0, B0, K0, nM, nB, nK, oM, oB, oK, x, g0, tr, soft, pl);
-        ea_block_p<false>(M1, B1, K1, M0, B0, K0, pM0, pB0, pK0, x, g1, tr, NP_NEG_INF, pl + 6);
-        ea_block_p<false>(M2, B2, K2, M1, B1, K1, pM1, pB1, pK1, x, g2, tr, NP_NEG_INF, pl + 12);
+        float pM[BPL], pB[BPL], pK[BPL];
+#pragma unroll
+        for (int c = 0; c < BPL; ++c) { pM[c] = M[c]; pB[c] = B[c]; pK[c] = K[c]; }
+        uint64_t pl[6 * BPL];
+        ea_block_p<true>(M[0], B[0], K[0], nM, nB, nK, oM, oB, oK, x, G.g[0], tr, soft, pl);
+#pragma unroll
+        for (int c = 1; c < BPL; ++c) ea_block_p<false>(M[c], B[c], K[c], M[c - 1], B[c - 1], K[c - 1], pM[c - 1], pB[c - 1], pK[c - 1], x, G.g[c], tr, NP_NEG_INF, pl + 6 * c);
         oM = nM; oB = nB; oK = nK;
         soft = NP_NEG_INF;
-        // ONE asm block issues the line's stores: every plane stays in its own scalar registers until all eighteen are on their way
-        const uint8_t* lp = sline + (size_t)(t - 1) * NP_EA2_LINE;
+        // ONE asm block issues the line's stores: every plane stays in its own scalar registers until all of them are on their way
+        const uint8_t* lp = sline + (size_t)(t - 1) * LINE;
         asm volatile("s_store_dwordx2 %1, %0, 0x0\n\ts_store_dwordx2 %2, %0, 0x8\n\ts_store_dwordx2 %3, %0, 0x10\n\ts_store_dwordx2 %4, %0, 0x18\n\t"
                      "s_store_dwordx2 %5, %0, 0x20\n\ts_store_dwordx2 %6, %0, 0x28\n\ts_store_dwordx2 %7, %0, 0x30\n\ts_store_dwordx2 %8, %0, 0x38\n\t"
                      "s_store_dwordx2 %9, %0, 0x40\n\ts_store_dwordx2 %10, %0, 0x48\n\ts_store_dwordx2 %11, %0, 0x50\n\ts_store_dwordx2 %12, %0, 0x58\n\t"
@@ -258,30 +215,27 @@ __device__ __attribute__((noinline)) float2 ea_fill2(const np_gauss g0, const np
                      "s_store_dwordx2 %17, %0, 0x80\n\ts_store_dwordx2 %18, %0, 0x88"
                      :: "s"(lp), "s"(pl[0]), "s"(pl[1]), "s"(pl[2]), "s"(pl[3]), "s"(pl[4]), "s"(pl[5]), "s"(pl[6]), "s"(pl[7]), "s"(pl[8]), "s"(pl[9]),
                         "s"(pl[10]), "s"(pl[11]), "s"(pl[12]), "s"(pl[13]), "s"(pl[14]), "s"(pl[15]), "s"(pl[16]), "s"(pl[17]) : "memory");
-#else
-        uint32_t packed = ea_block<true, 0>(M0, B0, K0, nM, nB, nK, oM, oB, oK, x, g0, tr, soft);
-        packed |= ea_block<false, 9>(M1, B1, K1, M0, B0, K0, pM0, pB0, pK0, x, g1, tr, NP_NEG_INF);
-        packed |= ea_block<false, 18>(M2, B2, K2, M1, B1, K1, pM1, pB1, pK1, x, g2, tr, NP_NEG_INF);
-        oM = nM; oB = nB; oK = nK;
-        soft = NP_NEG_INF;
-        *(uint32_t*)(line + (size_t)(t - 1) * NP_EA2_LINE) = packed;
-#endif
+        if constexpr (BPL == 4)
+            asm volatile("s_store_dwordx2 %1, %0, 0x90\n\ts_store_dwordx2 %2, %0, 0x98\n\ts_store_dwordx2 %3, %0, 0xa0\n\ts_store_dwordx2 %4, %0, 0xa8\n\t"
+                         "s_store_dwordx2 %5, %0, 0xb0\n\ts_store_dwordx2 %6, %0, 0xb8"
+                         :: "s"(lp), "s"(pl[6 * BPL - 6]), "s"(pl[6 * BPL - 5]), "s"(pl[6 * BPL - 4]), "s"(pl[6 * BPL - 3]), "s"(pl[6 * BPL - 2]), "s"(pl[6 * BPL - 1]) : "memory");
     };
     int t = 1;
     for (; t <= s_min; ++t) step(t);
     // the segment with fewer steps has just computed its last row in the lane that owns its last k-mer: keep that row (the lanes
     // go on computing rows nobody reads)
-    const float zM0 = M0, zM1 = M1, zM2 = M2;
+    float zM[BPL];
+#pragma unroll
+    for (int c = 0; c < BPL; ++c) zM[c] = M[c];
     for (; t <= s_max; ++t) step(t);
-#if NP_EA_PLANES
-    // the lines sit in the scalar data cache: write them back to L2, where the walk's vector loads find them (ea_walk2 invalidates
-    // the vector L1 first: the scratch is reused segment after segment)
+    // the lines sit in the scalar data cache: write them back to L2, where the walk's loads (at agent scope: past the vector L1) find them
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-    const int ec_0 = s0.n > 0 ? (s0.n - 1) % 3 : 0, ec_1 = s1.n > 0 ? (s1.n - 1) % 3 : 0;
+    const int ec_0 = s0.n > 0 ? (s0.n - 1) % BPL : 0, ec_1 = s1.n > 0 ? (s1.n - 1) % BPL : 0;
     const int my_ec = hi_half ? ec_1 : ec_0;
-    const float live = my_ec == 0 ? M0 : my_ec == 1 ? M1 : M2, snap = my_ec == 0 ? zM0 : my_ec == 1 ? zM1 : zM2;
-    const int el0 = s0.n > 0 ? (s0.n - 1) / 3 : 0, el1 = 32 + (s1.n > 0 ? (s1.n - 1) / 3 : 0);
+    float live = M[0], snap = zM[0];
+#pragma unroll
+    for (int c = 1; c < BPL; ++c) { live = my_ec == c ? M[c] : live; snap = my_ec == c ? zM[c] : snap; }
+    const int el0 = s0.n > 0 ? (s0.n - 1) / BPL : 0, el1 = 32 + (s1.n > 0 ? (s1.n - 1) / BPL : 0);
     float2 out;
     out.x = s0.e > 0 ? readlane_f32(steps0 == s_max ? live : snap, el0) : NP_NEG_INF;
     out.y = s1.e > 0 ? readlane_f32(steps1 == s_max ? live : snap, el1) : NP_NEG_INF;
@@ -368,7 +322,7 @@ __device__ __attribute__((noinline)) void ea_next_segment(const np_ea_args* __re
         const int span = e_start > e_stop ? e_start - e_stop : e_stop - e_start;
         if (span < 2) { ea_finish_read(a, h, lane); continue; }
         const int e = span + 1, n = __builtin_amdgcn_readfirstlane(l - k + 1);
-        if (n > 96 || e > a.rows_cap) { h.status = NP_EA_OVERFLOW; ea_finish_read(a, h, lane); continue; }
+        if (n > a.max_kmers || e > a.rows_cap) { h.status = NP_EA_OVERFLOW; ea_finish_read(a, h, lane); continue; }
         h.n_calls++;
         h.e_start = e_start; h.stride = e_start < e_stop ? 1 : -1; h.e = e; h.n = n; h.last_section = last_section ? 1 : 0;
         break;
@@ -396,9 +350,12 @@ struct ea_lds {
 };
 struct ea_walk_result { int cnt0, cnt1, spilled0, spilled1; };
 
+template <int BPL>
 __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const float sv0_, const float sv1_, const uint8_t* __restrict__ bp_,
                                                              uint32_t* __restrict__ path0_, uint32_t* __restrict__ path1_, const int lane)
 {
+    constexpr int LINE = NP_EA2_LINE_BYTES(BPL), PLANES = 6 * BPL, PER_LINE = 3 * BPL;     // PER_LINE: 16-byte pieces (two planes) of a line
+    static_assert(NP_EA_WIN * PER_LINE <= 192 && NP_EA_WIN * PLANES <= NP_EA_WIN * 32, "window staging: three rounds of 64 lanes, 512 dwords per half");
     const float sv0 = ea_uniform(sv0_), sv1 = ea_uniform(sv1_);
     const uint8_t* __restrict__ bp = ea_uniform(bp_);
 
@@ -408,7 +365,7 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
     const int sl = lane & 31;
     // per-lane state, uniform within a half
     const int e = hi_half ? H1.e : H0.e, n = hi_half ? H1.n : H0.n;
-    int row = e, k3 = n > 0 ? (n - 1) / 3 : 0, kr = n > 0 ? (n - 1) % 3 : 0, ps = 2, cnt = 0, spilled = 0;
+    int row = e, k3 = n > 0 ? (n - 1) / BPL : 0, kr = n > 0 ? (n - 1) % BPL : 0, ps = 2, cnt = 0, spilled = 0;      // k3: the lane (of the half) that owns the k-mer, kr: its block
     int lo = 0x7fffffff;                                  // no window yet
     // assert(get(vm, row, col) != -INFINITY): no path, nothing to emit
     bool alive = (hi_half ? (H1.ri >= 0 && sv1 != NP_NEG_INF) : (H0.ri >= 0 && sv0 != NP_NEG_INF)) && e > 0 && n > 0;
@@ -427,31 +384,24 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
             if ((need_m >> (32 * h)) & 1ull) {
                 const int hi = __builtin_amdgcn_readlane(row + k3, 32 * h);
                 const int nlo = hi - (NP_EA_WIN - 1) > 1 ? hi - (NP_EA_WIN - 1) : 1;
-#if NP_EA_PLANES
-                // dword h of the eighteen planes of every line of the window: stage[h][line * 18 + plane].  Nine 16-byte requests per
-                // line (two planes each), all of a refill in flight at once (three rounds of 64 lanes cover 16 lines), at agent scope:
-                // they bypass the vector L1, which may still hold the previous segment's lines at these addresses (the sweep wrote the
-                // new ones through the scalar cache)
-                const int n16 = (hi - nlo + 1) * 9;
-                const __amdgpu_buffer_rsrc_t lr = make_rsrc(bp + (size_t)(nlo - 1) * NP_EA2_LINE, (uint32_t)(hi - nlo + 1) * NP_EA2_LINE);
+                // dword h of every plane of every line of the window: stage[h][line * PLANES + plane].  PER_LINE 16-byte requests per line
+                // (two planes each), all of a refill in flight at once (three rounds of 64 lanes cover 16 lines), at agent scope: they
+                // bypass the vector L1, which may still hold the previous segment's lines at these addresses (the sweep wrote the new
+                // ones through the scalar cache)
+                const int n16 = (hi - nlo + 1) * PER_LINE;
+                const __amdgpu_buffer_rsrc_t lr = make_rsrc(bp + (size_t)(nlo - 1) * LINE, (uint32_t)(hi - nlo + 1) * LINE);
                 lds_u32* dst = (lds_u32*)&L->stage[h][0];
                 uint4 v[3];
 #pragma unroll
                 for (int it = 0; it < 3; ++it) {
-                    const int i = lane + 64 * it, ln = (i * 7282) >> 16;                       // i / 9 for i < 192
-                    v[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(lr, whole_offset(i < n16 ? ln * NP_EA2_LINE + (i - 9 * ln) * 16 : -16), 0, 16 /* sc1 */));
+                    const int i = lane + 64 * it, ln = i / PER_LINE;
+                    v[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(lr, whole_offset(i < n16 ? ln * LINE + (i - PER_LINE * ln) * 16 : -16), 0, 16 /* sc1 */));
                 }
 #pragma unroll
                 for (int it = 0; it < 3; ++it) {
-                    const int i = lane + 64 * it, ln = (i * 7282) >> 16, q = i - 9 * ln;
-                    if (i < n16) { dst[ln * NP_EA2_PLANES + 2 * q] = h ? v[it].y : v[it].x; dst[ln * NP_EA2_PLANES + 2 * q + 1] = h ? v[it].w : v[it].z; }
+                    const int i = lane + 64 * it, ln = i / PER_LINE, q = i - PER_LINE * ln;
+                    if (i < n16) { dst[ln * PLANES + 2 * q] = h ? v[it].y : v[it].x; dst[ln * PLANES + 2 * q + 1] = h ? v[it].w : v[it].z; }
                 }
-#else
-                const int n16 = (hi - nlo + 1) * 8;
-                const uint8_t* __restrict__ src = bp + (size_t)(nlo - 1) * NP_EA2_LINE + 128 * h;
-                uint4* dst = (uint4*)&L->stage[h][0];
-                for (int i = lane; i < n16; i += 64) dst[i] = *(const uint4*)(src + (size_t)(i >> 3) * NP_EA2_LINE + (i & 7) * 16);
-#endif
                 lo = (hi_half == (h == 1)) ? nlo : lo;
             }
             if ((full_m >> (32 * h)) & 1ull) {
@@ -470,14 +420,13 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
             const bool in = alive && line >= lo && cnt - spilled < NP_EA_PCAP;
             if (__builtin_amdgcn_ballot_w64(alive && !in) != 0ull || __builtin_amdgcn_ballot_w64(in) == 0ull) break;
             // the visited state goes to the half's list (lane 0 of the half writes it, the others write their dump slots)
-            const uint32_t entry = (uint32_t)row | ((uint32_t)(3 * k3 + kr) << 16) | ((uint32_t)ps << 24);
+            const uint32_t entry = (uint32_t)row | ((uint32_t)(BPL * k3 + kr) << 16) | ((uint32_t)ps << 24);
             lds_u32* wp = (in && sl == 0) ? pb + (cnt - spilled) : dump;
             *wp = entry;
             // the move out of this cell
-#if NP_EA_PLANES
             // every lane reads the six planes of the cell's block itself (the address does not depend on the state walked in) and takes
             // the bit of the lane that owns the k-mer out of each; the three states' codes are cheap, the state picks one
-            const lds_u32* pw = st + (in ? (line - lo) * NP_EA2_PLANES + kr * 6 : 0);
+            const lds_u32* pw = st + (in ? (line - lo) * PLANES + kr * 6 : 0);
             const uint32_t x0 = (pw[0] >> k3) & 1u, x1 = (pw[1] >> k3) & 1u, x2 = (pw[2] >> k3) & 1u, x3 = (pw[3] >> k3) & 1u, x4 = (pw[4] >> k3) & 1u,
                            x5 = (pw[5] >> k3) & 1u;
             const uint32_t cM = x0 | (x1 << 1) | (x2 << 2), cB = 2u - x3, cK = 6u - x5 - 2u * x4;
@@ -485,16 +434,12 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
             //  branches -- each half then waits for its own LDS round trip)
             const uint32_t m2 = 0u - (uint32_t)(ps == 2), m1 = 0u - (uint32_t)(ps == 1);
             const uint32_t c = (cM & m2) | (cB & m1) | (cK & ~(m2 | m1));
-#else
-            const uint32_t w = st[in ? (line - lo) * 32 + k3 : 0];
-            const uint32_t c = (w >> (9 * kr + 3 * ps)) & 7u;
-#endif
             const bool stop = c == 7u;                                  // HMT_FROM_SOFT
             const bool stepped = in && !stop;
             const int nrow = row - (ps != 0 ? 1 : 0);                   // K states are silent (r9.cpp:176-178)
             const int dk = (int)(c >> 2);
             const int t = kr - dk;
-            const int nkr = t < 0 ? 2 : t, nk3 = t < 0 ? k3 - 1 : k3;
+            const int nkr = t < 0 ? BPL - 1 : t, nk3 = t < 0 ? k3 - 1 : k3;
             cnt += in ? 1 : 0;
             row = stepped ? nrow : row; k3 = stepped ? nk3 : k3; kr = stepped ? nkr : kr; ps = stepped ? (int)(c & 3u) : ps;
             alive = alive && !(in && stop) && row > 0 && k3 >= 0;
@@ -563,7 +508,7 @@ __device__ __attribute__((noinline)) void ea_emit_segment(const np_ea_args* __re
 }
 
 // WAVES: resident waves per SIMD the register budget is set for (4: 128 registers, no spills in the sweep; 5: 96)
-template <int WAVES>
+template <int WAVES, int BPL>
 __global__ void __launch_bounds__(64, WAVES) np_eventalign_chain2_kernel(const np_ea_args* __restrict__ ap)
 {
     __shared__ ea_lds lds;
@@ -590,11 +535,11 @@ __global__ void __launch_bounds__(64, WAVES) np_eventalign_chain2_kernel(const n
         unsigned long long t1 = __builtin_amdgcn_s_memtime();
         t_next += t1 - t0;
 
-        // ---- the lane's three blocks of its half's segment (ProfileHMMViterbiOutputR9, r9.inl:130-197) ----
+        // ---- the lane's BPL blocks of its half's segment (ProfileHMMViterbiOutputR9, r9.inl:130-197) ----
         const bool hi_half = lane >= 32;
         const int sl = lane & 31;
         ea_seg S0, S1;
-        np_gauss g[3];
+        ea_gauss<BPL> G;
         ea_trans tr;
         {
             const ea_read R0 = ea_load_read(a, H0.ri >= 0 ? H0.ri : 0), R1 = ea_load_read(a, H1.ri >= 0 ? H1.ri : 0);
@@ -610,8 +555,8 @@ __global__ void __launch_bounds__(64, WAVES) np_eventalign_chain2_kernel(const n
             tr = ea_trans{rd->trans[0], rd->trans[1], rd->trans[2], rd->trans[3], rd->trans[4], rd->trans[5], rd->trans[6], rd->trans[7],
                           rd->trans[8], rd->trans[9]};
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int b = 3 * sl + c;
+            for (int c = 0; c < BPL; ++c) {
+                const int b = BPL * sl + c;
                 uint32_t rank = 0;
                 if (b < n) {
                     // HMMInputSequence::get_kmer_rank(b, k, rc): the forward k-mer at b, or its reverse complement's rank
@@ -620,10 +565,10 @@ __global__ void __launch_bounds__(64, WAVES) np_eventalign_chain2_kernel(const n
                         rank = rank * 4u + code;
                     }
                 }
-                g[c] = np_scale_state(a.model, rank, scale, shift, var, log_var);
+                G.g[c] = np_scale_state(a.model, rank, scale, shift, var, log_var);
             }
         }
-        const float2 start_v = ea_fill2(g[0], g[1], g[2], tr, a.flank[0], S0, S1, bp, lane);
+        const float2 start_v = ea_fill2<BPL>(G, tr, a.flank[0], S0, S1, bp, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
         unsigned long long t2 = __builtin_amdgcn_s_memtime();
@@ -631,7 +576,7 @@ __global__ void __launch_bounds__(64, WAVES) np_eventalign_chain2_kernel(const n
         const bool prio = __builtin_amdgcn_readfirstlane(a.walk_prio) != 0;
         if (prio) __builtin_amdgcn_s_setprio(3);
         uint32_t* path1 = path + (a.path_stride >> 1);
-        const ea_walk_result wr = ea_walk2(&lds, start_v.x, start_v.y, bp, path, path1, lane);
+        const ea_walk_result wr = ea_walk2<BPL>(&lds, start_v.x, start_v.y, bp, path, path1, lane);
         if (H0.ri >= 0) ea_emit_segment(ap, &lds, 0, wr.cnt0, wr.spilled0, path, lane);
         if (H1.ri >= 0) ea_emit_segment(ap, &lds, 1, wr.cnt1, wr.spilled1, path1, lane);
         if (prio) __builtin_amdgcn_s_setprio(0);
@@ -645,14 +590,18 @@ __global__ void __launch_bounds__(64, WAVES) np_eventalign_chain2_kernel(const n
 
 } // namespace
 
-// variant 2 / 3: the register budget of 4 / 5 resident waves per SIMD.  (Rounds 1-3 also carried a one-read-per-wave kernel, variant 1;
-// round 4 removed it: the two-read kernel is the faster one on every input measured, both were pinned by the same tests, and a
-// divergence seen once while refactoring the old kernel's walk was never explained -- VERDICT r3, Weak 9.)
+// variant 2 / 3: the register budget of 4 / 5 resident waves per SIMD (three k-mer blocks per lane: segments of up to 96 k-mers, k >= 6);
+// variant 4: four blocks per lane at 4 waves per SIMD (up to 128 k-mers: the direct-RNA model, k = 5, whose segments reach 97).
+// (Rounds 1-3 also carried a one-read-per-wave kernel; round 4 removed it: the two-read kernel is the faster one on every input
+// measured, both were pinned by the same tests, and a divergence seen once while refactoring the old kernel's walk was never
+// explained -- VERDICT r3, Weak 9.)
 hipError_t np_launch_eventalign_chain(const np_ea_args& a, const np_ea_args* a_dev /* a device copy of a */, int n_blocks, int variant, hipStream_t s)
 {
     (void)a;
-    if (variant == 2) hipLaunchKernelGGL(np_eventalign_chain2_kernel<4>, dim3(n_blocks), dim3(64), 0, s, a_dev);
-    else hipLaunchKernelGGL(np_eventalign_chain2_kernel<5>, dim3(n_blocks), dim3(64), 0, s, a_dev);
+    if (variant == 2) hipLaunchKernelGGL((np_eventalign_chain2_kernel<4, 3>), dim3(n_blocks), dim3(64), 0, s, a_dev);
+    else if (variant == 3) hipLaunchKernelGGL((np_eventalign_chain2_kernel<5, 3>), dim3(n_blocks), dim3(64), 0, s, a_dev);
+    else hipLaunchKernelGGL((np_eventalign_chain2_kernel<4, 4>), dim3(n_blocks), dim3(64), 0, s, a_dev);
     return hipGetLastError();
 }
-int np_eventalign_line_bytes(int variant) { (void)variant; return NP_EA2_LINE; }
+int np_eventalign_line_bytes(int variant) { return variant == 4 ? NP_EA2_LINE_BYTES(4) : NP_EA2_LINE_BYTES(3); }
+int np_eventalign_max_kmers(int variant) { return variant == 4 ? 128 : 96; }

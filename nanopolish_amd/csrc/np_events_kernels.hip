@@ -732,6 +732,32 @@ hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t*
     return hipGetLastError();
 }
 
+// Direct-RNA reads are sequenced 3' -> 5': load_from_raw detects the events, takes the MoM scalings, and then REVERSES the event list
+// so that it runs along the basecalled sequence (src/nanopolish_squiggle_read.cpp:260-263) before the event aligner sees it.  One
+// workgroup per read swaps event i with event n - 1 - i in up to four arrays (start, length, mean, stdv: whatever the caller keeps).
+__global__ void __launch_bounds__(256) np_reverse_events_kernel(const int64_t* __restrict__ event_off, const int32_t* __restrict__ n_events,
+                                                                uint32_t* a0, float* a1, float* a2, float* a3)
+{
+    const int r = blockIdx.x;
+    const int n = n_events[r];
+    if (n <= 1) return;
+    const int64_t o = event_off[r];
+    for (int i = threadIdx.x; i < n / 2; i += 256) {
+        const int64_t p = o + i, q = o + n - 1 - i;
+        if (a0) { const uint32_t t = a0[p]; a0[p] = a0[q]; a0[q] = t; }
+        if (a1) { const float t = a1[p]; a1[p] = a1[q]; a1[q] = t; }
+        if (a2) { const float t = a2[p]; a2[p] = a2[q]; a2[q] = t; }
+        if (a3) { const float t = a3[p]; a3[p] = a3[q]; a3[q] = t; }
+    }
+}
+hipError_t np_launch_reverse_events(int n_reads, const int64_t* event_off, const int32_t* n_events, uint32_t* start, float* length, float* mean,
+                                    float* stdv, hipStream_t s)
+{
+    if (n_reads <= 0) return hipSuccess;
+    hipLaunchKernelGGL(np_reverse_events_kernel, dim3(n_reads), dim3(256), 0, s, event_off, n_events, start, length, mean, stdv);
+    return hipGetLastError();
+}
+
 hipError_t np_launch_mom_fill(int n_reads, np_read_dev* reads, np_read_dev* reads_b, const float* event_mean, const int32_t* n_events,
                               const uint16_t* ranks, const np_state_dev* model, hipStream_t s)
 {

@@ -50,6 +50,7 @@ struct np_ea_args {
     uint8_t* bp;                   // per-wave back-pointer scratch: rows_cap x 128 B
     size_t bp_stride;
     int rows_cap;
+    int max_kmers;                 // k-mers per segment the launched instantiation holds (32 lanes x blocks per lane)
     uint32_t* path;                // per-wave path list: rows_cap + 128 entries
     size_t path_stride;
     const int64_t* out_off;
@@ -138,6 +139,8 @@ hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t*
                                    hipStream_t s);
 hipError_t np_launch_adc_to_pa(int n_reads, const int16_t* adc, const int64_t* raw_off, int64_t max_samples, const float* offset,
                                const float* raw_unit, float* raw_pa, hipStream_t s);
+hipError_t np_launch_reverse_events(int n_reads, const int64_t* event_off, const int32_t* n_events, uint32_t* start, float* length, float* mean,
+                                    float* stdv, hipStream_t s);
 hipError_t np_launch_mom_fill(int n_reads, np_read_dev* reads, np_read_dev* reads_b, const float* event_mean, const int32_t* n_events,
                               const uint16_t* ranks, const np_state_dev* model, hipStream_t s);
 
@@ -148,6 +151,7 @@ hipError_t np_launch_cm_build_jobs(int n_reads, const char* seq, const int64_t* 
                                    int32_t* n_motif, int64_t* group_rank_off, int32_t* n_groups, hipStream_t s);
 hipError_t np_launch_eventalign_chain(const np_ea_args& a, const np_ea_args* a_dev, int n_blocks, int variant, hipStream_t s);
 int np_eventalign_line_bytes(int variant);
+int np_eventalign_max_kmers(int variant);
 hipError_t np_launch_cigar_index(int n_reads, const uint32_t* cigar, const int64_t* cigar_off, const int32_t* read_len, int k, int32_t* op_ref,
                                  int32_t* op_read, void* cig_reads, hipStream_t s);
 hipError_t np_launch_cm_build_jobs_cigar(int n_reads, const char* genome, const int64_t* ref_begin, const int32_t* ref_len,

@@ -16,7 +16,7 @@ c_i64p = C.POINTER(C.c_int64)
 
 # exported symbols of include/np_hmm.h (tests check that every one resolves)
 SYMBOLS = [
-    "np_default_params", "np_create", "np_destroy", "np_last_error", "np_version", "np_ctx_info", "np_set_option", "np_get_stat", "np_register_model", "np_update_model", "np_site_table_dev", "np_hmm_score_set_combine_dev", "np_dev_alloc", "np_dev_free", "np_host_alloc", "np_host_free", "np_stream_create", "np_stream_destroy", "np_event_create", "np_event_destroy", "np_event_record", "np_stream_wait_event", "np_event_sync", "np_event_query", "np_copy_to_device", "np_copy_to_host", "np_memset_dev",
+    "np_default_params", "np_create", "np_destroy", "np_last_error", "np_version", "np_ctx_info", "np_set_option", "np_get_stat", "np_register_model", "np_update_model", "np_site_table_dev", "np_hmm_score_set_combine_dev", "np_dev_alloc", "np_dev_free", "np_host_alloc", "np_host_free", "np_stream_create", "np_stream_destroy", "np_event_create", "np_event_destroy", "np_event_record", "np_stream_wait_event", "np_event_sync", "np_event_query", "np_reverse_events_dev", "np_copy_to_device", "np_copy_to_host", "np_memset_dev",
     "np_alphabet_id", "np_alphabet_size", "np_kmer_rank", "np_reverse_complement", "np_methylate", "np_unmethylate",
     "np_is_motif_match", "np_sequence_kmer_ranks", "np_calculate_transitions", "np_estimate_scalings_mom",
     "np_scan_motif_groups", "np_cm_build_jobs_identity", "np_fill_read_host", "np_hmm_score_host", "np_hmm_score_set_host", "np_hmm_align_host", "np_event_align_host",
@@ -142,6 +142,8 @@ def load_library():
     L.np_detect_events_host.argtypes = [vp, C.c_int, C.POINTER(c_f32p), C.POINTER(C.c_uint32), C.POINTER(DetectorParam),
                                         C.POINTER(C.c_uint32), c_f32p, c_f32p, c_f32p, C.c_int64, c_i64p]
     L.np_mom_fill_dev.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int]
+    L.np_reverse_events_dev.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.np_event_query.argtypes = [vp, vp]
     L.np_cm_build_jobs_identity_dev.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_uint32, C.c_int, C.c_int, vp, C.c_int64, vp, vp, vp,
                                                 vp, vp, vp, vp, vp]
     L.np_cm_build_jobs_cigar_dev.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int64, vp, vp, C.c_int, C.c_uint32, C.c_int, C.c_int, vp,

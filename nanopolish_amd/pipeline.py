@@ -135,13 +135,14 @@ def concat_host_batches(parts):
     return out
 
 
-def build_host_batch_records(models, records, contig, k=6, alphabet="cpg"):
+def build_host_batch_records(models, records, contig, k=6, alphabet="cpg", with_jobs=True):
     """Host-side preparation of a batch of reads given EXPLICITLY, each with its raw signal and the BAM record of its
     base-to-reference alignment: records = dicts(seq: the read's own sequence, raw: float32 samples, rc: bam_is_rev,
     pos: 0-based leftmost reference position, cigar: uint32 BAM words[, contig: this record's own reference]).  contig: the
     reference the records align to (those without their own).
     The batch starts from raw signal (from_raw) and its work items follow the CIGARs: the host builder's
-    items are in hb["jobs"] / hb["kpos"]; the device builder needs hb["cigar"], hb["ref_begin"], ... (same numbering)."""
+    items are in hb["jobs"] / hb["kpos"]; the device builder needs hb["cigar"], hb["ref_begin"], ... (same numbering).
+    with_jobs=False: no methylation work items (an eventalign-only batch, e.g. direct-RNA reads: k = 5, base model u_to_t_rna)."""
     L_ = _l.load_library()
     from .synth import nucleotide_kmer_ranks
     lut = np.zeros(256, np.int64); lut[ord("C")] = 1; lut[ord("G")] = 2; lut[ord("T")] = 3
@@ -174,6 +175,8 @@ def build_host_batch_records(models, records, contig, k=6, alphabet="cpg"):
         seg = r["contig"][r["pos"]:min(endpos + 1, len(r["contig"]))]
         ref_seqs.append(seg); ref_begin[i] = contig_base[r["contig"]] + r["pos"]; ref_len[i] = len(seg)
         try:
+            if not with_jobs:
+                raise ValueError("no work items wanted")
             jb = api.cm_build_jobs_cigar(seg, r["cigar"], len(r["seq"]), r["rc"], k, alphabet)
         except ValueError:            # a record the reference refuses (spliced / padded CIGAR): no work items, as on the device
             z = np.zeros(0, np.int32)
@@ -245,14 +248,20 @@ def tile_host_batch(hb, tile):
 
 
 class CallMethylationBatch:
-    def __init__(self, ctx, hb, device="cuda:0", calibrate=False, from_raw=False, jobs_on_device=False, workload="call-methylation"):
+    def __init__(self, ctx, hb, device="cuda:0", calibrate=False, from_raw=False, jobs_on_device=False, workload="call-methylation", rna=False,
+                 base_model="nucleotide"):
         """calibrate=False: kernel B scores with the scalings the caller put in hb["reads_b"] (a read whose
         calibration was done elsewhere).  calibrate=True: the pass recalibrates every read on the device from its
-        own event alignment, as load_from_raw does (squiggle_read.cpp:304-323), and reads_b is overwritten."""
+        own event alignment, as load_from_raw does (squiggle_read.cpp:304-323), and reads_b is overwritten.
+        rna=True (from_raw, workload "eventalign"): direct-RNA reads as load_from_raw treats them (squiggle_read.cpp:206-213,260-263):
+        the RNA detector parameters, the events reversed after the MoM scalings, the base model registered as `base_model`
+        (r9.4_70bps / u_to_t_rna / 5-mers; hb built with k = 5)."""
         import torch
         self.torch = torch
         self.calibrate = bool(calibrate)
         self.from_raw = bool(from_raw)
+        self.rna = bool(rna)
+        assert not self.rna or (self.from_raw and workload == "eventalign"), "rna=True: from raw signal, eventalign workload"
         self.from_adc = False
         self.jobs_on_device = bool(jobs_on_device)
         self.workload = workload       # "eventalign": a step ends with the segment chain instead of the methylation scoring
@@ -288,7 +297,7 @@ class CallMethylationBatch:
             self.d_ev_len = torch.empty(nev, dtype=torch.float32, device=dev)
             self.d_ev_stdv = torch.empty(nev, dtype=torch.float32, device=dev)
             self.d_n_events = torch.zeros(self.n_reads, dtype=torch.int32, device=dev)
-            self.prm = _l.DetectorParam(); ctx.L.np_event_detection_params(C.byref(self.prm), 0)
+            self.prm = _l.DetectorParam(); ctx.L.np_event_detection_params(C.byref(self.prm), 1 if self.rna else 0)
         self.d_reads_a = up(hb["reads_a"]); self.d_reads_b = up(hb["reads_b"])
         if self.jobs_on_device:
             # work items are generated on the device from the reads' reference strands: group slots at
@@ -341,7 +350,7 @@ class CallMethylationBatch:
         self.d_calibrated = torch.ones(self.n_reads, dtype=torch.int32, device=dev)
         self.d_scores = torch.zeros(max(self.n_jobs, 1), dtype=torch.float32, device=dev)
         self.alphabet = hb.get("alphabet", "cpg")      # the methylation alphabet whose model scores the work items
-        self.m_nuc = ctx.models["nucleotide"]; self.m_cpg = ctx.models[self.alphabet]
+        self.m_nuc = ctx.models[base_model]; self.m_cpg = ctx.models.get(self.alphabet, -1) if workload == "eventalign" else ctx.models[self.alphabet]
         torch.cuda.synchronize()
         # algorithmic bytes of one pass: kernel A 4E + 2K + 100(E+K+2) + 8E per read,
         # kernel B 4e + 2n + 12n + 4 per call (e, n of every work item are only known after the pass; use the
@@ -381,6 +390,10 @@ class CallMethylationBatch:
                 rc = L.np_mom_fill_dev(h, s, self.n_reads, p(self.d_reads_a), p(self.d_reads_b), p(self.d_events), p(self.d_n_events),
                                        p(self.d_ranks), self.m_nuc)
                 self.ctx._chk(rc, "np_mom_fill_dev")
+                if self.rna:          # 3' -> 5' signal: the events run along the sequence from here on (squiggle_read.cpp:260-263)
+                    rc = L.np_reverse_events_dev(h, s, self.n_reads, p(self.d_event_off), p(self.d_n_events), p(self.d_ev_start), p(self.d_ev_len),
+                                                 p(self.d_events), p(self.d_ev_stdv))
+                    self.ctx._chk(rc, "np_reverse_events_dev")
         phase = {11: 1, 12: 2}.get(stage, 3 if self.split_align else 0)
         if phase:
             rc = L.np_event_align_split_dev(h, s, phase, self.n_reads, p(self.d_reads_a), p(self.d_events), p(self.d_ranks), self.m_nuc,

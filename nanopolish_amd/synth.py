@@ -170,3 +170,20 @@ def synth_cigar_read(read_id, contig_codes, model, span=1200, k=6, seed0=SEED0, 
     rd = synth_raw_from_codes(read_codes, read_id, model, k, seed0)
     rd.update(rc=rc, pos=pos, cigar_ops=[(o, n) for o, n in ops], bam_seq=BASES[bam_codes].tobytes().decode(), ref_span=span)
     return rd
+
+
+def synth_raw_rna(read_id, model, L=1200, k=5, seed0=SEED0, samples_per_kmer=42.0, noise=1.0):
+    """Synthetic raw trace of a direct-RNA-like read: the strand passes the pore 3' -> 5' at ~70 bases/s (3 kHz sampling: ~43
+    samples per base), so the trace dwells on the k-mers of the basecalled (5' -> 3') sequence from the LAST to the first;
+    model: the r9.4_70bps u_to_t_rna 5-mer table (tests/golden/models_r9.4_70bps_rna.npz).  rd["seq"] is the 5' -> 3' sequence
+    (T for U, as load_from_raw stores it), rd["ranks"] its k-mer ranks."""
+    rd = synth_read(read_id, model, L, k, seed0)
+    rng = np.random.default_rng(seed0 + 179424673 * (int(read_id) + 1))
+    ranks = rd["ranks"][::-1]
+    dwell = np.maximum(4, rng.poisson(samples_per_kmer, len(ranks)))
+    rk = np.repeat(ranks, dwell)
+    mu = rd["scale"] * model["level_mean"][rk] + rd["shift"]
+    sd = noise * rd["var"] * model["level_stdv"][rk]
+    raw = np.maximum(mu + sd * rng.standard_normal(len(rk)), 8.0).astype(np.float32)
+    rd = dict(rd); rd["raw"] = raw; rd["dwell"] = dwell
+    return rd

@@ -40,11 +40,14 @@ def _p(a, t):
 class FullRead:
     """A SquiggleRead built by the reference from raw samples (SquiggleRead(sequence, Fast5Data, flags))."""
 
-    def __init__(self, lib, name, sequence, raw, sample_rate=4000.0):
+    def __init__(self, lib, name, sequence, raw, sample_rate=4000.0, rna=False):
         self.L = lib
         raw = np.ascontiguousarray(raw, np.float32)
         self.sequence = sequence
-        self.h = lib.npfull_read_create(name.encode(), sequence.encode(), _p(raw, _f32p), len(raw), float(sample_rate))
+        make = lib.npfull_read_create_rna if rna else lib.npfull_read_create       # rna: load_from_raw's direct-RNA branch
+        make.restype = C.c_void_p
+        make.argtypes = [C.c_char_p, C.c_char_p, _f32p, C.c_size_t, C.c_double]
+        self.h = make(name.encode(), sequence.encode(), _p(raw, _f32p), len(raw), float(sample_rate))
         n_ev, mp = C.c_int(), C.c_int()
         sh, sc, va, epb = C.c_double(), C.c_double(), C.c_double(), C.c_double()
         lib.npfull_read_summary(self.h, C.byref(n_ev), C.byref(sh), C.byref(sc), C.byref(va), C.byref(epb), C.byref(mp))
@@ -215,8 +218,8 @@ class FullRef:
                                     _p(raw_off, C.POINTER(C.c_int64)), _p(rc, _u8p), float(sample_rate), int(n_threads), _p(rows, _i32p))
         return rows, time.perf_counter() - t0
 
-    def read(self, name, sequence, raw, sample_rate=4000.0):
-        return FullRead(self.L, name, sequence, raw, sample_rate)
+    def read(self, name, sequence, raw, sample_rate=4000.0, rna=False):
+        return FullRead(self.L, name, sequence, raw, sample_rate, rna)
 
     def aligned_bases(self, is_rev, pos, cigar, bam_seq):
         cig = np.ascontiguousarray(cigar, np.uint32)
@@ -334,7 +337,7 @@ def bench_batch(records, contig_seq, batch_size, n_batches, warmup=2, pipelined=
     return float(sec), int(n_sites.value), int(n_bad.value), {k: round(float(v), 4) for k, v in zip(names, hs)}
 
 
-def realign_batch(records, contig_seq, sample_rate=4000.0):
+def realign_batch(records, contig_seq, sample_rate=4000.0, rna=None):
     """The records through ONE np_realign_reads_batch (nanopolish_amd/csrc/np_eventalign_dropin.cpp; libnp_ref_full_batch.so): list of
     per-record dicts with the rebuilt SquiggleRead's fields (n_events, shift, scale, var, events_per_base, event mean / stdv / duration /
     start_time, event map), the EventAlignment rows and the TSV text the reference's own writer prints from them; and the status array."""
@@ -353,16 +356,19 @@ def realign_batch(records, contig_seq, sample_rate=4000.0):
     tsv_cap = 160 * row_cap
     tsv = C.create_string_buffer(tsv_cap); tsv_off = np.zeros(n + 1, np.int64)
     i64 = C.POINTER(C.c_int64)
+    mask = np.zeros(n, np.uint8)             # rna: indices of the records that are direct-RNA reads (a batch may mix both types)
+    for i in (rna or []):
+        mask[i] = 1
     L.npfull_realign_batch(n, seqs, _p(raw, C.POINTER(C.c_float)), _p(raw_off, i64), _p(is_rev, _i32p), _p(pos, _i32p), _p(cig, _u32p), _p(cig_off, i64),
                            bseqs, contig_seq.encode(), C.c_double(sample_rate), _p(status, _i32p), _p(n_events, _i32p), _p(sh, _f64p), _p(sc, _f64p),
                            _p(va, _f64p), _p(epb, _f64p), _p(ev_off, i64), _p(evm, _f32p), _p(evs, _f32p), _p(evd, _f32p), _p(evt, _f64p),
                            _p(map_off, i64), _p(ms, _i32p), _p(me, _i32p), C.c_int64(row_cap), _p(row_off, i64), _p(rp, _i32p), _p(ei, _i32p), st,
-                           tsv, C.c_int64(tsv_cap), _p(tsv_off, i64))
+                           tsv, C.c_int64(tsv_cap), _p(tsv_off, i64), _p(mask, _u8p))
     assert tsv_off[-1] < tsv_cap and row_off[-1] <= row_cap
     out = []
     for i in range(n):
         a, b = int(ev_off[i]), int(ev_off[i]) + int(n_events[i])
-        k_n = len(records[i]["seq"]) - 5
+        k_n = len(records[i]["seq"]) - (4 if mask[i] else 5)          # k-mers of the read: k = 5 for RNA, 6 for DNA
         out.append(dict(n_events=int(n_events[i]), shift=float(sh[i]), scale=float(sc[i]), var=float(va[i]), events_per_base=float(epb[i]),
                         mean=evm[a:b].copy(), stdv=evs[a:b].copy(), duration=evd[a:b].copy(), start_time=evt[a:b].copy(),
                         map_start=ms[int(map_off[i]):int(map_off[i]) + k_n].copy(), map_stop=me[int(map_off[i]):int(map_off[i]) + k_n].copy(),

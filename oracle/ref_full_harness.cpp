@@ -137,13 +137,13 @@ struct Record {
 extern "C" {
 
 // ---- SquiggleRead from raw samples -----------------------------------------------------------------------------
-void* npfull_read_create(const char* name, const char* sequence, const float* raw, size_t n_raw, double sample_rate)
+static void* read_create(const char* name, const char* sequence, const float* raw, size_t n_raw, double sample_rate, bool rna)
 {
     Fast5Data d;
     d.is_valid = true;
     d.read_name = name;
-    d.sequencing_kit = "sqk-lsk109";
-    d.experiment_type = "genomic_dna";
+    d.sequencing_kit = rna ? "sqk-rna002" : "sqk-lsk109";
+    d.experiment_type = rna ? "rna" : "genomic_dna";          // squiggle_read.cpp:194-195: SRNT_RNA / SRNT_DNA
     d.channel_params.digitisation = 8192; d.channel_params.offset = 0; d.channel_params.range = 1400;
     d.channel_params.sample_rate = sample_rate; d.channel_params.channel_id = 1;
     d.start_time = 0;
@@ -153,6 +153,15 @@ void* npfull_read_create(const char* name, const char* sequence, const float* ra
     SquiggleRead* sr = new SquiggleRead(std::string(sequence), d, 0);
     free(d.rt.raw);
     return sr;
+}
+void* npfull_read_create(const char* name, const char* sequence, const float* raw, size_t n_raw, double sample_rate)
+{
+    return read_create(name, sequence, raw, n_raw, sample_rate, false);
+}
+// a direct-RNA read: load_from_raw's RNA branch (kit r9.4_70bps, alphabet u_to_t_rna, k = 5, the RNA detector, events reversed)
+void* npfull_read_create_rna(const char* name, const char* sequence, const float* raw, size_t n_raw, double sample_rate)
+{
+    return read_create(name, sequence, raw, n_raw, sample_rate, true);
 }
 void npfull_read_destroy(void* h) { delete (SquiggleRead*)h; }
 
@@ -675,7 +684,7 @@ int npfull_realign_batch(int n, const char* const* read_seqs, const float* raw, 
                          const int64_t* ev_off, float* ev_mean, float* ev_stdv, float* ev_duration, double* ev_start_time,
                          const int64_t* map_off, int32_t* map_start, int32_t* map_stop,
                          int64_t row_cap, int64_t* row_off, int32_t* ref_position, int32_t* event_idx, char* hmm_state,
-                         char* tsv, int64_t tsv_cap, int64_t* tsv_off)
+                         char* tsv, int64_t tsv_cap, int64_t* tsv_off, const uint8_t* rna_mask /* nullable: record i is a direct-RNA read */)
 {
     std::vector<Record*> recs(n);
     std::vector<std::string> seqs(n);
@@ -687,6 +696,7 @@ int npfull_realign_batch(int n, const char* const* read_seqs, const float* raw, 
         reads[i].record = &recs[i]->b; reads[i].read_name = name; reads[i].read_sequence = &seqs[i];
         reads[i].raw_pa = raw + raw_off[i]; reads[i].n_raw = (size_t)(raw_off[i + 1] - raw_off[i]);
         reads[i].sample_rate = sample_rate; reads[i].read_idx = i;
+        reads[i].rna = rna_mask && rna_mask[i] ? 1 : 0;
     }
     np_realign_reads_batch(reads, &recs[0]->fai, &recs[0]->hdr, -1, -1);
     int64_t rows = 0, text = 0;

@@ -109,4 +109,13 @@ for f in ea ea_r3 $EA_VARIANTS; do echo "$f: $(grep -o '"value": [0-9.]*\|"event
 cat $O/percall.json
 }
 
+# direct-RNA reads on the device path; whole GPU suite
+call_i() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04i; mkdir -p $O
+( timeout 600 python -m pytest tests/test_gpu_rna.py -m gpu -x -q ) > $O/pytest_rna.log 2>&1; echo "rna pytest rc=$?" >> $O/pytest_rna.log
+( time timeout 900 python -m pytest tests -m gpu -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+tail -25 $O/pytest_rna.log; tail -6 $O/pytest.log
+}
+
 "call_$1"
