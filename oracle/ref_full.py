@@ -6,6 +6,7 @@ generates tests/golden/golden_reflevel.npz (tests/gen_golden_reflevel.py)."""
 import ctypes as C
 import os
 import subprocess
+import time
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -218,6 +219,27 @@ class FullRef:
                                     _p(raw_off, C.POINTER(C.c_int64)), _p(rc, _u8p), float(sample_rate), int(n_threads), _p(rows, _i32p))
         return rows, time.perf_counter() - t0
 
+    def many_records(self, recs, contig_seq, n_threads, sample_rate=4000.0):
+        """SquiggleRead from raw + align_read_to_ref for every record (dicts: seq, raw, rc, pos, cigar, bam_seq) against one contig, OpenMP
+        over records: (row counts, hashes of every record's rows -- see rows_hash, seconds)."""
+        n = len(recs)
+        seq_off = np.zeros(n + 1, np.int64); seq_off[1:] = np.cumsum([len(r["seq"]) for r in recs])
+        bam_off = np.zeros(n + 1, np.int64); bam_off[1:] = np.cumsum([len(r["bam_seq"]) for r in recs])
+        raw_off = np.zeros(n + 1, np.int64); raw_off[1:] = np.cumsum([len(r["raw"]) for r in recs])
+        cig_off = np.zeros(n + 1, np.int64); cig_off[1:] = np.cumsum([len(r["cigar"]) for r in recs])
+        raw = np.concatenate([np.ascontiguousarray(r["raw"], np.float32) for r in recs])
+        cig = np.concatenate([np.ascontiguousarray(r["cigar"], np.uint32) for r in recs])
+        is_rev = np.array([int(r["rc"]) for r in recs], np.int32); pos = np.array([int(r["pos"]) for r in recs], np.int32)
+        rows = np.zeros(n, np.int32); hsh = np.zeros(n, np.uint64)
+        i64 = C.POINTER(C.c_int64)
+        self.L.npfull_many_records.argtypes = [C.c_int, C.c_char_p, i64, _f32p, i64, _i32p, _i32p, _u32p, i64, C.c_char_p, i64, C.c_char_p, C.c_double,
+                                               C.c_int, _i32p, C.POINTER(C.c_uint64)]
+        t0 = time.perf_counter()
+        self.L.npfull_many_records(n, "".join(r["seq"] for r in recs).encode(), _p(seq_off, i64), _p(raw, _f32p), _p(raw_off, i64), _p(is_rev, _i32p),
+                                   _p(pos, _i32p), _p(cig, _u32p), _p(cig_off, i64), "".join(r["bam_seq"] for r in recs).encode(), _p(bam_off, i64),
+                                   contig_seq.encode(), float(sample_rate), int(n_threads), _p(rows, _i32p), _p(hsh, C.POINTER(C.c_uint64)))
+        return rows, hsh, time.perf_counter() - t0
+
     def read(self, name, sequence, raw, sample_rate=4000.0, rna=False):
         return FullRead(self.L, name, sequence, raw, sample_rate, rna)
 
@@ -376,3 +398,17 @@ def realign_batch(records, contig_seq, sample_rate=4000.0, rna=None):
                         hmm_state=np.frombuffer(st.raw[int(row_off[i]):int(row_off[i + 1])], np.uint8).copy(),
                         tsv=tsv.raw[int(tsv_off[i]):int(tsv_off[i + 1])].decode()))
     return out, status
+
+
+def rows_hash(ref_position, event_idx, hmm_state):
+    """The hash npfull_many_records takes of a record's rows: h <- h * P + word + 1 (mod 2^64) over (ref_position, event_idx, hmm_state)
+    row by row -- here as one dot product with the powers of P (numpy's uint64 arithmetic wraps the same way)."""
+    a = np.stack([np.asarray(ref_position).astype(np.uint32), np.asarray(event_idx).astype(np.uint32), np.asarray(hmm_state).astype(np.uint32)], 1)
+    a = a.reshape(-1).astype(np.uint64) + np.uint64(1)
+    m = len(a)
+    if m == 0:
+        return 0
+    with np.errstate(over="ignore"):
+        pw = np.cumprod(np.full(m, 0x9E3779B97F4A7C15, np.uint64))          # P^1 .. P^m
+        w = np.concatenate([np.ones(1, np.uint64), pw[:-1]])[::-1]            # P^(m-1) .. P^0
+        return int((a * w).sum(dtype=np.uint64))

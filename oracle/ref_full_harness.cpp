@@ -772,4 +772,36 @@ void npfull_many_identity(int mode, int n_reads, const char* seqs, const int64_t
     }
 }
 
+// records with their own BAM alignment against one contig (BASELINE.json configs[2]: reads drawn from a genome, CIGARs with indels and
+// clips): SquiggleRead from raw + align_read_to_ref per record, OpenMP over records.  rows_out[i]: rows of record i; hash_out[i]: a polynomial hash
+// over its rows' (ref_position, event_idx, hmm_state) -- the caller hashes the device's rows the same way, so that EVERY row of every
+// sampled record is compared.  (hash: h <- h * 0x9E3779B97F4A7C15 + word + 1 over the rows' three 32-bit words, mod 2^64)
+void npfull_many_records(int n, const char* seqs, const int64_t* seq_off, const float* raw, const int64_t* raw_off, const int32_t* is_rev,
+                         const int32_t* pos, const uint32_t* cigar, const int64_t* cigar_off, const char* bam_seqs, const int64_t* bam_off,
+                         const char* contig_seq, double sample_rate, int n_threads, int32_t* rows_out, uint64_t* hash_out)
+{
+    if(n_threads > 0) omp_set_num_threads(n_threads);
+    #pragma omp parallel for schedule(dynamic)
+    for(int i = 0; i < n; ++i) {
+        std::string seq(seqs + seq_off[i], seqs + seq_off[i + 1]), bam_seq(bam_seqs + bam_off[i], bam_seqs + bam_off[i + 1]);
+        void* h = npfull_read_create("r", seq.c_str(), raw + raw_off[i], (size_t)(raw_off[i + 1] - raw_off[i]), sample_rate);
+        SquiggleRead* sr = (SquiggleRead*)h;
+        int rows = 0;
+        uint64_t hsh = 0;
+        if(!sr->events[0].empty()) {
+            Record r("r", is_rev[i], pos[i], cigar + cigar_off[i], (int)(cigar_off[i + 1] - cigar_off[i]), bam_seq.c_str(), contig_seq);
+            EventAlignmentParameters params;
+            params.sr = sr; params.fai = &r.fai; params.hdr = &r.hdr; params.record = &r.b; params.strand_idx = 0; params.read_idx = i;
+            std::vector<EventAlignment> al = align_read_to_ref(params);
+            rows = (int)al.size();
+            for(size_t t = 0; t < al.size(); ++t) {
+                const uint32_t w[3] = {(uint32_t)al[t].ref_position, (uint32_t)al[t].event_idx, (uint32_t)(unsigned char)al[t].hmm_state};
+                for(int q = 0; q < 3; ++q) hsh = hsh * 0x9E3779B97F4A7C15ull + (uint64_t)w[q] + 1ull;       // (Horner, mod 2^64: order-sensitive)
+            }
+        }
+        rows_out[i] = rows; hash_out[i] = hsh;
+        npfull_read_destroy(h);
+    }
+}
+
 } // extern "C"

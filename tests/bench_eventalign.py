@@ -6,7 +6,7 @@ recalibration -> align_read_to_ref's segment chain (np_eventalign_dev), beside t
 This is a measurement tool for DESIGN.md / profiles/, not the driver's bench (bench.py keeps the call-methylation metric); it
 lives under tests/ because its CPU leg runs the oracle.
 
-    python tests/bench_eventalign.py [--pool 1000] [--tile 50] [--read-len 5450] [--steps 3] [--cpu-sample 64]
+    python tests/bench_eventalign.py [--pool 5000] [--tile 10] [--read-len 5450] [--steps 3] [--cpu-sample 512]
 (also reachable as `python bench.py --workload eventalign`)
 """
 import argparse
@@ -21,26 +21,40 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ ->
 sys.path.insert(0, ROOT)
 
 
-def run(pool=1000, tile=50, read_len=5450, steps=3, warmup=1, cpu_sample=-1, ctx=None):
-    """One eventalign measurement (BASELINE.json configs[2]); returns the JSON-able dict.  ctx: a Context with the nucleotide and cpg
-    models registered (bench.py's), else one is created."""
+GENOME = 5_000_000            # BASELINE.json configs[2]: "50k synthetic reads against 5 Mb reference"
+CIGAR_MIX = dict(p_sub=0.02, p_ins=0.015, p_del=0.015, max_indel=4, soft_clip=(0, 12))      # synth_cigar_read's defaults, spelled out
+
+
+def run(pool=5000, tile=10, read_len=5450, steps=3, warmup=1, cpu_sample=-1, ctx=None):
+    """One eventalign measurement (BASELINE.json configs[2], literally since round 4): `pool` distinct reads drawn at uniform origins from
+    a seeded 5 Mb genome (resident in HBM once), on both strands, each with substitutions, insertions, deletions and soft clips and the
+    BAM record an aligner would report for it (nanopolish_amd/synth.py:synth_cigar_read); pool x tile = 50 000 reads per step.  Returns
+    the JSON-able dict.  ctx: a Context with the nucleotide and cpg models registered (bench.py's), else one is created."""
     import torch
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import load_models
     from nanopolish_amd import api
     from nanopolish_amd.api import Context
+    from nanopolish_amd.hostinfo import usable_cores
     from nanopolish_amd.pipeline import build_host_batch_records, tile_host_batch, CallMethylationBatch
-    from nanopolish_amd.synth import synth_raw
+    from nanopolish_amd.synth import synth_cigar_read, BASES
     models = load_models()
     own = ctx is None
     if own:
         ctx = Context(0)
         ctx.register_model(models["nucleotide"], "nucleotide"); ctx.register_model(models["cpg"], "cpg")
-    recs = []
-    for rid in range(pool):
-        rd = synth_raw(rid, models["nucleotide"], L=read_len)
-        ref = api.reverse_complement("nucleotide", rd["seq"]) if rd["rc"] else rd["seq"]
-        recs.append(dict(seq=rd["seq"], raw=rd["raw"], rc=rd["rc"], pos=0, cigar=api.cigar_words([("M", len(rd["seq"]))]), contig=ref))
-    hb = build_host_batch_records(models, recs, "")
+    t_prep = time.perf_counter()
+    genome = np.random.default_rng(0x5EED5).integers(0, 4, GENOME)
+    contig = BASES[genome].tobytes().decode()
+
+    def make(rid):
+        r = synth_cigar_read(rid, genome, models["nucleotide"], span=read_len, **CIGAR_MIX)
+        return dict(seq=r["seq"], raw=r["raw"], rc=int(r["rc"]), pos=int(r["pos"]), cigar=api.cigar_words(r["cigar_ops"]), bam_seq=r["bam_seq"])
+    with ThreadPoolExecutor(max(1, usable_cores()[2])) as ex:          # (threads: the HIP runtime is up, a forked pool is not an option)
+        recs = list(ex.map(make, range(pool)))
+    n_ops = np.array([len(r["cigar"]) for r in recs])
+    t_prep = time.perf_counter() - t_prep
+    hb = build_host_batch_records(models, recs, contig, with_jobs=False)
     batch = CallMethylationBatch(ctx, tile_host_batch(hb, tile), "cuda:0", calibrate=True, from_raw=True, workload="eventalign")
     for _ in range(warmup):
         batch.step()
@@ -71,8 +85,10 @@ def run(pool=1000, tile=50, read_len=5450, steps=3, warmup=1, cpu_sample=-1, ctx
     out = dict(metric="eventalign reads/sec", value=round(batch.n_reads * steps / dt, 1), unit="reads/s", n_gpus=1, steps=steps,
                ms_per_step=round(1e3 * dt / steps, 3), reads_per_step=batch.n_reads, rows_per_step=rows, hmm_align_calls_per_step=calls,
                statuses=sorted(set(r["status"] for r in res)), kernel_ms_per_step={k: round(v, 3) for k, v in fam.items()}, roofline=roof,
-               config=dict(workload="eventalign from raw signal, synthetic R9.4 reads (BASELINE.json configs[2] shape)", read_len=read_len,
-                           distinct_reads=pool, tile=tile))
+               config=dict(workload="eventalign from raw signal, 50k synthetic R9.4 reads against a 5 Mb reference (BASELINE.json configs[2])",
+                           genome_bases=GENOME, read_span=read_len, distinct_reads=pool, tile=tile, strands="both (odd read ids reverse)",
+                           cigar_mix=dict(CIGAR_MIX, soft_clip=list(CIGAR_MIX["soft_clip"])), mean_cigar_ops=round(float(n_ops.mean()), 1),
+                           host_prep_s=round(t_prep, 1)))
     # every HBM copy of a read must give the same rows (replication invariance over the whole step: a size-independent property)
     same = True
     for t in range(1, tile):
@@ -89,22 +105,18 @@ def run(pool=1000, tile=50, read_len=5450, steps=3, warmup=1, cpu_sample=-1, ctx
             F = FullRef()
             from nanopolish_amd.hostinfo import usable_cores
             threads = usable_cores()[2]            # affinity mask capped by the cgroup CPU quota
-            # timing: OpenMP over reads inside the reference-backed library; parity: the row COUNT of every sampled read, and the rows
-            # themselves of a spread of them, one by one
-            rows_cpu, t_cpu = F.many_identity(0, [r["seq"] for r in recs[:n_cpu]], [r["raw"] for r in recs[:n_cpu]], [r["rc"] for r in recs[:n_cpu]], threads)
-            ok = all(int(rows_cpu[i]) == len(res[i]["event_idx"]) for i in range(n_cpu))
-            checked = 0
-            for i in sorted(set(np.linspace(0, n_cpu - 1, min(16, n_cpu)).astype(int).tolist())):
-                r = recs[i]
-                fr = F.read("r%d" % i, r["seq"], r["raw"])
-                ea = fr.eventalign(r["rc"], 0, r["cigar"], r["contig"], r["contig"]) if fr.n_events else None
-                ok = ok and ((ea is None and len(res[i]["event_idx"]) == 0) or
-                             (ea is not None and np.array_equal(ea["ref_position"], res[i]["ref_position"]) and
-                              np.array_equal(ea["event_idx"], res[i]["event_idx"]) and np.array_equal(ea["hmm_state"], res[i]["hmm_state"])))
-                checked += 1
+            # OpenMP over records inside the reference-backed library; parity: the row count AND a hash of every row (ref_position,
+            # event_idx, hmm_state) of every sampled record against the same hash of the device's rows
+            from oracle.ref_full import rows_hash
+            rows_cpu, hash_cpu, t_cpu = F.many_records(recs[:n_cpu], contig, threads)
+            bad = 0
+            for i in range(n_cpu):
+                g = res[i]
+                bad += int(int(rows_cpu[i]) != len(g["event_idx"]) or int(hash_cpu[i]) != rows_hash(g["ref_position"], g["event_idx"], g["hmm_state"]))
             out["cpu_baseline"] = dict(value=round(n_cpu / t_cpu, 2), unit="reads/s", cores=threads, kind="reference",
-                                       sample="%d of the same reads: SquiggleRead from raw + align_read_to_ref, OpenMP over reads" % n_cpu,
-                                       rows_match=bool(ok), reads_row_counts_checked=n_cpu, reads_rows_checked=checked)
+                                       sample="%d of the same records: SquiggleRead from raw + align_read_to_ref, OpenMP over records" % n_cpu,
+                                       rows_match=bool(bad == 0), reads_rows_checked=n_cpu, reads_differing=bad,
+                                       rows_checked=int(sum(int(x) for x in rows_cpu)))
     except Exception as e:  # noqa: BLE001
         out["cpu_baseline"] = dict(error=str(e))
     del batch
@@ -116,8 +128,8 @@ def run(pool=1000, tile=50, read_len=5450, steps=3, warmup=1, cpu_sample=-1, ctx
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--pool", type=int, default=1000, help="distinct reads")
-    ap.add_argument("--tile", type=int, default=50, help="HBM copies of the pool: pool x tile = 50 000 reads per step (BASELINE.json configs[2])")
+    ap.add_argument("--pool", type=int, default=5000, help="distinct reads")
+    ap.add_argument("--tile", type=int, default=10, help="HBM copies of the pool: pool x tile = 50 000 reads per step (BASELINE.json configs[2])")
     ap.add_argument("--read-len", type=int, default=5450)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)

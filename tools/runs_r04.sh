@@ -118,4 +118,12 @@ O=gpurun_out/r04i; mkdir -p $O
 tail -25 $O/pytest_rna.log; tail -6 $O/pytest.log
 }
 
+# configs[2] literally: reads from a 5 Mb genome with indel / clip CIGARs, every row of 512 records against the reference
+call_j() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04j; mkdir -p $O
+( time timeout 900 python tests/bench_eventalign.py --steps 3 --warmup 1 ) > $O/ea.json 2> $O/ea.err; echo "rc=$?" >> $O/ea.err
+cut -c1-2500 $O/ea.json; tail -5 $O/ea.err
+}
+
 "call_$1"
