@@ -654,43 +654,22 @@ def main():
         a_avg_s = a_ms / max(a_n, 1) * 1e-3
         algo = res["algo"]
         achieved = algo / a_avg_s / 1e9 if a_avg_s > 0 else 0.0
-        # HBM traffic of THIS run's launch: bytes per BAND from the counter passes over the shipped kernel (profiles/r03_pmc.json:
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE at a launch size the passes finish at, profiles/collect_r03_pmc.sh; round 2's file
-        # as a fallback) x the bands this run's reads have -- a from-raw run (more events per read) reports its own figure.
-        # `issue` is a MODEL (static instruction count of the generated band loop, tools/count_isa.py, and the round-2 occupancy scan:
-        # per-wave band time 370 + 157 w cycles at w resident waves per SIMD) and says so; `counters` beside it are measured.
-        traffic, issue, counters = None, None, None
+        # HBM traffic of THIS run's launch: bytes per BAND from the counter passes over the shipped kernel (profiles/r04_pmc.json:
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE at a launch size the passes finish at, profiles/collect_r04_pmc.sh) x the bands this
+        # run's reads have -- a from-raw run (more events per read) reports its own figure.  `issue`: vector instructions per band from
+        # the same passes, priced at the calibrated issue cycles per class (profiles/r04_valu_calibration.json), over this run's
+        # SIMD-cycles per band: floor = every instruction at the fastest class's cost, priced = by the class mix of the band loop.
         n_bands = res["band_cells"] // 100
         cyc_per_band = a_avg_s * CLOCK_HZ * N_SIMD / max(n_bands, 1)
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))["event_align"]
-            if pm.get("fetch_bytes_per_band") is not None and pm.get("write_bytes_per_band") is not None:
-                traffic = int((pm["fetch_bytes_per_band"] + pm["write_bytes_per_band"]) * n_bands)
-            counters = {k: pm[k] for k in ("valu_per_band", "salu_per_band", "valu_busy_pct", "salu_busy_pct", "reads_per_launch",
-                                           "fetch_bytes_per_band", "write_bytes_per_band", "simd_cycles_per_band") if k in pm}
-            counters["source"] = "profiles/r03_pmc.json (rocprofv3 --pmc over the shipped kernel, profiles/collect_r03_pmc.sh)"
-        except Exception:
-            pass
-        try:
-            pm2 = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))["event_align"]
-            if traffic is None:
-                per_band = (pm2["fetch_bytes_per_read"] + pm2["write_bytes_per_read"]) / 13463.2      # the profiled reads' bands
-                traffic = int(per_band * n_bands)
-            port = pm2["occupancy_scan"]["port_cycles_per_band"]
-            issue = dict(kind="model", valu_per_band=pm2.get("valu_per_band"), salu_per_band=pm2.get("salu_per_band"),
-                         simd_cycles_per_band=round(cyc_per_band, 1), port_cycles_per_band=port,
-                         latency_cycles_per_band_at_8_waves=round(pm2["occupancy_scan"]["latency_cycles_per_band"] / 8.0, 1),
-                         frac=round(port / cyc_per_band, 3),
-                         source="static count of the band loop in the generated assembly (tools/count_isa.py) + round-2 occupancy scan "
-                                "(profiles/r02_pmc.json); a model, not a measurement of this run")
-        except Exception:
-            issue = dict(kind="model", simd_cycles_per_band=round(cyc_per_band, 1))
-        issue["counters"] = counters
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_lookup
+        traffic = pmc_lookup.traffic("event_align", "band", n_bands)
+        issue = pmc_lookup.issue("event_align", "band", cyc_per_band) or dict(kind="unavailable", simd_cycles_per_band=round(cyc_per_band, 1))
         roof = dict(bound="hbm", kernel="np_event_align_kernel", achieved=round(achieved, 2), peak=8000.0, unit="GB/s",
                     frac=round(achieved / 8000.0, 5), traffic=traffic,
                     algo_bytes_per_launch=algo, avg_launch_ms=round(a_ms / max(a_n, 1), 3),
                     band_cells_per_s=round(res["band_cells"] / a_avg_s / 1e9, 3) if a_avg_s > 0 else 0.0,
-                    limiter="instruction issue (one wave per read, ~13.5k dependent band steps): see issue",
+                    limiter="vector-instruction issue (one wave per read, ~13.5k dependent band steps; HBM traffic ~0.9 x the algorithmic bytes): see issue",
                     issue=issue, dominant_kernel_by_time=dom,
                     kernel_ms_per_step={k: round(v[0] / max(args.steps, 1), 3) for k, v in k_ms.items()})
 

@@ -35,7 +35,10 @@ def klass(op, line):
     if base.startswith(("v_fma_f32", "v_fmac_f32", "v_mad_f32")):
         return "fma"
     if base in FAST_OPS or base.startswith("v_accvgpr"):
-        # a fast opcode in its VOP3 form with a scalar-register or literal operand was measured in the slow class (v_add_f32 s,v)
+        # a fast opcode with a scalar-register source was measured in the slow class (v_add_f32 s,v / v_mov_b32 v,s: 4.3 cycles against 2.5)
+        srcs = line.split(None, 1)[1].split(",")[1:] if len(line.split(None, 1)) > 1 else []
+        if any(re.match(r"\s*(s\d+|s\[|vcc|exec|ttmp)", x) for x in srcs):
+            return "slow"
         return "fast"
     return "slow"
 
@@ -64,6 +67,25 @@ def price(lines):
     return n, other, cyc, ops
 
 
+def loop_mix(sfile, pat):
+    """Class mix of the VALU instructions inside the loops of the kernel / function whose mangled name contains `pat` (blocks annotated
+    "in Loop" / "Loop Header" by the assembler listing), unweighted: {"n": {class: count}, "mean_cycles": cycles per wave-instruction}."""
+    L = open(sfile).read().splitlines()
+    start = next(i for i, l in enumerate(L) if l.startswith("_Z") and pat in l.split(":")[0])
+    end = next(i for i in range(start, len(L)) if "s_endpgm" in L[i] or "s_setpc_b64" in L[i] or L[i].startswith(".Lfunc_end"))
+    K = L[start:end]
+    labs = [i for i, l in enumerate(K) if l.startswith(".LBB") or l.startswith("; %bb.")] + [len(K)]
+    tot = Counter()
+    for a, b in zip(labs, labs[1:]):
+        head = " ".join(K[a:a + 3])
+        if "Loop" not in head:
+            continue
+        n, o, cyc, ops = price(K[a:b])
+        tot.update(n)
+    nv = sum(tot.values())
+    return dict(n=dict(tot), mean_cycles=round(sum(tot[k] * COST[k] for k in tot) / max(nv, 1), 3), class_cycles={k: round(v, 2) for k, v in COST.items()})
+
+
 def main():
     L = open(sys.argv[1]).read().splitlines()
     pat = sys.argv[2]
@@ -86,4 +108,5 @@ def main():
                 print("        ", ops.most_common(18))
 
 
-main()
+if __name__ == "__main__":
+    main()

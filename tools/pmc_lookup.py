@@ -1,0 +1,43 @@
+"""Per-unit counter figures of the shipped kernels for the bench lines' `roofline.traffic` / `issue` fields, read from the committed
+summary of this round's counter passes (profiles/r04_pmc.json <- profiles/collect_r04_pmc.sh + profiles/pmc_summary_r04.py).  The passes
+run at a launch size they finish at (8 192 reads); a bench line scales the PER-UNIT figures (bytes per band / call / segment) by the
+units its own launch processed, and says so in `source`."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FILE = os.path.join("profiles", "r04_pmc.json")
+
+
+def family(name):
+    """dict of the family's per-unit figures (without the raw per-step totals), or {} when the summary is missing."""
+    try:
+        d = json.load(open(os.path.join(ROOT, FILE)))[name]
+    except Exception:  # noqa: BLE001
+        return {}
+    out = {k: v for k, v in d.items() if not k.endswith("_per_step") and k != "loop_class_mix"}
+    out["source"] = FILE + " (rocprofv3 --pmc over the shipped kernel at 8 192 reads per launch, profiles/collect_r04_pmc.sh; per-unit figures x this launch's units)"
+    return out
+
+
+def traffic(name, unit, n_units):
+    """HBM bytes of a launch of `n_units` units (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950 corrections of tools/hbm_counter_calib.hip), or None."""
+    d = family(name)
+    f, w = d.get("fetch_bytes_per_" + unit), d.get("write_bytes_per_" + unit)
+    return None if f is None or w is None else int((f + w) * n_units)
+
+
+def issue(name, unit, simd_cycles_per_unit):
+    """Vector-issue figures of a launch that took `simd_cycles_per_unit` (launch time x 2.4 GHz x 1024 SIMDs / units): instructions per unit from
+    the counters, priced at the calibrated issue cycles (profiles/r04_valu_calibration.json).  floor: every instruction at the fastest
+    class's cost (a lower bound of the vector port's busy fraction); priced: by the class mix of the kernel's loops (an estimate)."""
+    d = family(name)
+    v = d.get("valu_per_" + unit)
+    if v is None or simd_cycles_per_unit <= 0:
+        return None
+    fast = json.load(open(os.path.join(ROOT, FILE))).get("fast_class_cycles_per_instruction", 2.49)
+    out = dict(kind="counters x calibrated issue cycles", valu_per_unit=v, salu_per_unit=d.get("salu_per_" + unit), lds_per_unit=d.get("lds_per_" + unit),
+               unit=unit, simd_cycles_per_unit=round(simd_cycles_per_unit, 1), valu_issue_floor=round(v * fast / simd_cycles_per_unit, 3), source=d["source"])
+    if d.get("valu_issue_priced") and d.get("valu_issue_floor"):
+        out["valu_issue_priced"] = round(out["valu_issue_floor"] * d["valu_issue_priced"] / d["valu_issue_floor"], 3)
+    return out

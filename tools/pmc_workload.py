@@ -25,7 +25,16 @@ def main():
     ap.add_argument("--distinct", type=int, default=256)
     ap.add_argument("--read-len", type=int, default=5450)
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--var-tile", type=int, default=0, help="> 0: ONLY the variants screening step (tests/bench_variants.py at this tile; configs[3] shape)")
     args = ap.parse_args()
+    if args.var_tile > 0:
+        # configs[3]'s forward launches alone (their own process: the kernel names are the call-methylation step's)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import bench_variants
+        va = bench_variants.run(tile=args.var_tile, steps=args.reps, warmup=0, cpu_sample=0)
+        print(json.dumps(dict(reps=args.reps, variants=dict(calls=va["calls_per_step"], algo_bytes=va["roofline"]["algo_bytes_per_launch"],
+                                                            unprofiled_ms=va["hmm_kernel_ms_per_step"]))), flush=True)
+        return
     import torch
     import bench
     from nanopolish_amd import api

@@ -126,4 +126,20 @@ O=gpurun_out/r04j; mkdir -p $O
 cut -c1-2500 $O/ea.json; tail -5 $O/ea.err
 }
 
+# counter passes over the shipped kernels (A, B in the call-methylation mix and in the variants shape, the chain)
+call_k() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+PASS_TIMEOUT=240 bash profiles/collect_r04_pmc.sh r04pmc 8192 2>&1 | tail -14
+}
+
+# VALU calibration again: tools/valu_rates with 2 KB of LDS per wave (the first calibration's 16 KB capped a CU at 10 waves, not 32) at 8/4/2/1 waves per SIMD
+call_l() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04l; mkdir -p $O
+$R/tools/valu_rates > $O/valu_rates.log 2>&1
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE -d $R/$O/valu_pmc -o v -- $R/tools/valu_rates > $R/$O/valu_rates_pmc.log 2>&1 )
+find $O/valu_pmc -name "*.db" | head -1 | xargs -I{} cp {} $O/valu.db
+head -70 $O/valu_rates.log
+}
+
 "call_$1"

@@ -15,7 +15,7 @@ template <int OP> __global__ void k(unsigned long long* out, float* sink, int it
     double d0 = 1.0, d1 = 2.0, d2 = 3.0, d3 = 4.0, d4 = 5.0, d5 = 6.0, d6 = 7.0, d7 = 8.0;
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 p0 = {1.f, 2.f}, p1 = p0, p2 = p0, p3 = p0, p4 = p0, p5 = p0, p6 = p0, p7 = p0;
-    __shared__ float lds[4096]; lds[threadIdx.x] = 1.0f; __syncthreads();
+    __shared__ float lds[512]; lds[threadIdx.x] = 1.0f; __syncthreads();   // 2 KB: 32 waves per CU co-reside (16 KB here capped a CU at 10 waves: the first r04 calibration)
     int l0 = threadIdx.x * 4, l1 = l0 + 256, l2 = l0 + 512, l3 = l0 + 768, l4 = l0 + 1024, l5 = l0 + 1280, l6 = l0 + 1536, l7 = l0 + 1792;
     int s0 = 0; int q0 = 0, q1 = 1, q2 = 2, q3 = 3, q4 = 4, q5 = 5, q6 = 6, q7 = 7;
     asm volatile("v_cmp_gt_f32 vcc, 1.0, %0\n s_mov_b64 s[10:11], vcc" : : "v"(a0) : "vcc", "s10", "s11");
@@ -182,7 +182,7 @@ template <int OP> __global__ void k(unsigned long long* out, float* sink, int it
 
 template <int OP> double run(const char* name, int waves_per_simd)
 {
-    const int blocks = 1024 * waves_per_simd, iters = 4000;
+    const int blocks = 1024 * waves_per_simd, iters = 16000;
     unsigned long long* d; float* s;
     hipMalloc(&d, blocks * 8); hipMalloc(&s, blocks * 64 * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -204,7 +204,7 @@ template <int OP> double run(const char* name, int waves_per_simd)
 
 int main(int argc, char**)
 {
-    for (int w : {8}) {
+    for (int w : {8, 4, 2, 1}) {
         if (argc > 1) break;          // any argument: only the round-2 table
         run<12>("v_add_f32", w); run<3>("v_fma_f32", w); run<4>("v_pk_fma_f32", w); run<5>("v_pk_mul_f32", w);
         run<0>("v_cvt_f64_f32", w); run<1>("v_cvt_f32_f64", w); run<16>("v_cvt_f64_u32", w); run<2>("v_add_f64", w);
