@@ -30,6 +30,9 @@ struct __attribute__((aligned(32))) np_state_dev {
 // read the same last entry (one broadcast access).  What bounds the kernel is the gather of the remaining third: PMC
 // shows the LDS pipe busy for the whole kernel at 4.2 cycles per ds_read, half of them bank-conflict cycles.
 #define NP_LOGSUM_CUT 15700
+#ifndef NP_LSE_FORM
+#define NP_LSE_FORM 1
+#endif
 // float -> unsigned as the hardware instruction defines it: truncation, saturation (+inf -> 0xffffffff), NaN -> 0
 __device__ __forceinline__ uint32_t np_cvt_u32_sat(float v)
 {
@@ -59,12 +62,33 @@ __device__ __forceinline__ float np_lse(float a, float b, const float* __restric
 // hipFuncGetAttributes on every forward kernel and a probe kernel over dirtied LDS); if either check fails the context scores
 // with the clamped np_lse instead.
 static_assert((NP_LOGSUM_TBL * 4) % 1280 == 0 && (NP_LOGSUM_TBL * 4) % 512 == 0, "the log-sum table must be a whole number of LDS allocation granules");
+// byte offset of the table entry of a log-sum: 4 * trunc(|a - b| * 1000.f) (see np_lse)
+__device__ __forceinline__ uint32_t np_lse_offset(float a, float b)
+{
+#if NP_LSE_FORM == 0
+    const float d = __builtin_fabsf(a - b);
+    return np_cvt_u32_sat(d * 4000.f) & ~3u;
+#else
+    // |a - b| * 4000 == |(a - b) * 4000| (rounding to nearest is symmetric), and the conversion takes the absolute value as an operand
+    // modifier: the multiplication is then a plain two-operand instruction with the constant as a literal (form 1) or in a vector
+    // register (form 2).  With the modifier on the multiplication the compiler has to use the three-operand encoding, which takes no
+    // literal on gfx9: it parks 4000.f in a SCALAR register, and a vector instruction with a scalar-register source issues in the slow
+    // class (4.6 cycles against 2.6, tools/valu_rates l: "v_mul_f32 |v|, s" / "v_mul_f32 literal") -- once per log-sum, ~8 times per cell.
+#if NP_LSE_FORM == 2
+    float c4000; asm("v_mov_b32 %0, 0x457a0000" : "=v"(c4000));
+    const float t = (a - b) * c4000;
+#else
+    const float t = (a - b) * 4000.f;
+#endif
+    uint32_t off;
+    asm("v_cvt_u32_f32_e64 %0, |%1|" : "=v"(off) : "v"(t));
+    return off & ~3u;
+#endif
+}
 __device__ __forceinline__ float np_lse_oor(float a, float b, const __attribute__((address_space(3))) char* tbl_lds)
 {
     const float mx = __builtin_fmaxf(a, b);
-    const float d = __builtin_fabsf(a - b);
-    const uint32_t off = np_cvt_u32_sat(d * 4000.f) & ~3u;
-    const uint32_t addr = (uint32_t)(uintptr_t)tbl_lds + off;
+    const uint32_t addr = (uint32_t)(uintptr_t)tbl_lds + np_lse_offset(a, b);
     return mx + *(const __attribute__((address_space(3))) float*)(uintptr_t)addr;
 }
 __device__ __forceinline__ float np_lse_table_entry(const float* __restrict__ logsum, int i) { return i < NP_LOGSUM_CUT ? logsum[i] : 0.0f; }

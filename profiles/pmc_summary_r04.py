@@ -85,7 +85,7 @@ try:
                        ("np_hmm_kernels", {"hmm_forward": "np_hmm_forward_kernelILi2ELi8ELi512ELb1", "hmm_forward_variants": "np_hmm_forward_kernelILi3ELi8ELi512ELb1"}),
                        ("np_eventalign_kernel", {"chain": "ea_fill2ILi3"})):
         sfile = os.path.join(tmp, unit + ".s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-S", "--cuda-device-only",
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "--offload-arch=gfx950", "-S", "--cuda-device-only",
                         os.path.join(ROOT, "nanopolish_amd", "csrc", unit + ".hip"), "-o", sfile], check=True, capture_output=True)
         for key, pat in pats.items():
             mix[key] = issue_cost.loop_mix(sfile, pat)

@@ -142,4 +142,38 @@ find $O/valu_pmc -name "*.db" | head -1 | xargs -I{} cp {} $O/valu.db
 head -70 $O/valu_rates.log
 }
 
+# kernel B's log-sum with the constant out of the scalar register (NP_LSE_FORM 1: literal, 2: vector register): issue cost of the forms, A/B, parity
+call_m() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04m; mkdir -p $O
+$R/tools/valu_rates l > $O/valu_rates_forms.log 2>&1; cat $O/valu_rates_forms.log
+V=nanopolish_amd/variants
+( timeout 900 python tools/hmm_ab.py --pool 4000 --tile 10 "" $V/libnp_hip_lse1.so $V/libnp_hip_lse2.so "" $V/libnp_hip_lse1.so $V/libnp_hip_lse2.so ) > $O/hmm_ab.log 2>&1; cat $O/hmm_ab.log
+for l in lse1 lse2; do ( NP_HIP_LIB=$R/$V/libnp_hip_$l.so timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_sites.py -m gpu -x -q ) 2>&1 | tail -2; done
+}
+
+# kernel B with two blocks' log-sum chains in lock step (NP_HMM_PAIR, the tree's default from here on) against the block-major step, with and
+# without SLP vectorisation; parity of the new default (scoring tests + whole GPU suite), variants leg
+call_n() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04n; mkdir -p $O
+V=nanopolish_amd/variants
+( timeout 900 python tools/hmm_ab.py --pool 4000 --tile 10 "" $V/libnp_hip_old.so $V/libnp_hip_pairslp.so $V/libnp_hip_nopair.so $V/libnp_hip_oldnoslp.so "" $V/libnp_hip_old.so ) > $O/hmm_ab.log 2>&1; cat $O/hmm_ab.log
+( time timeout 900 python -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1; tail -4 $O/pytest.log
+( timeout 600 python tests/bench_variants.py --steps 3 --warmup 1 ) > $O/variants.json 2> $O/variants.err; cut -c1-900 $O/variants.json; tail -3 $O/variants.err
+}
+
+# kernel B's new default (block-major, literal constant, no SLP) against the shipped build; the chain kernel without SLP vectorisation
+call_o() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04o; mkdir -p $O
+V=nanopolish_amd/variants
+( timeout 900 python tools/hmm_ab.py --pool 4000 --tile 10 "" $V/libnp_hip_old.so "" $V/libnp_hip_old.so ) > $O/hmm_ab.log 2>&1; cat $O/hmm_ab.log
+for l in "" $R/$V/libnp_hip_eanoslp.so "" $R/$V/libnp_hip_eanoslp.so; do
+  ( NP_HIP_LIB=$l timeout 600 python tests/bench_eventalign.py --pool 1000 --tile 20 --steps 3 --cpu-sample 0 ) 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$l', d['value'], d['kernel_ms_per_step'])"
+done 2>&1 | tee $O/ea_ab.log
+( NP_HIP_LIB=$R/$V/libnp_hip_eanoslp.so timeout 600 python -m pytest tests/test_gpu_reflevel.py tests/test_gpu_eventalign_dropin.py tests/test_gpu_rna.py -m gpu -x -q ) 2>&1 | tail -2
+( timeout 900 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -2
+}
+
 "call_$1"

@@ -98,6 +98,12 @@ template <int OP> __global__ void k(unsigned long long* out, float* sink, int it
 #define SBRT(n) asm volatile("s_branch 1f\n s_nop 0\n 1:");
 #define SUBCOADD(n) asm volatile("v_sub_co_u32_e32 %0, vcc, %1, %1\n v_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "=&v"(a##n) : "v"(a0) : "vcc");
 #define ADD64S(n) asm volatile("v_add_f64 %0, s[10:11], %1" : "=v"(d##n) : "v"(d##n));
+#define MULLIT(n) asm volatile("v_mul_f32_e32 %0, 0x457a0000, %1" : "=v"(a##n) : "v"(a##n));
+#define MULSABS(n) asm volatile("v_mul_f32_e64 %0, |%1|, s10" : "=v"(a##n) : "v"(a##n) : "s10");
+#define CVTUABS(n) asm volatile("v_cvt_u32_f32_e64 %0, |%1|" : "=v"(a##n) : "v"(a##n));
+#define ADDLIT(n) asm volatile("v_add_f32_e32 %0, 0x457a0000, %1" : "=v"(a##n) : "v"(a##n));
+#define ANDLIT(n) asm volatile("v_and_b32_e32 %0, 0xfffffffc, %1" : "=v"(a##n) : "v"(a##n));
+#define ANDINL(n) asm volatile("v_and_b32_e32 %0, -4, %1" : "=v"(a##n) : "v"(a##n));
 #define MAX3F(n) asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(a##n) : "v"(a##n), "v"(a0), "v"(a1));
         if (OP == 0) { REP8(CVT64) REP8(CVT64) }
         if (OP == 1) { REP8(CVT32) REP8(CVT32) }
@@ -172,6 +178,12 @@ template <int OP> __global__ void k(unsigned long long* out, float* sink, int it
         if (OP == 25) { REP8(CMPU) REP8(CMPU) }
         if (OP == 14) { REP8(LSHL) REP8(LSHL) }
         if (OP == 15) { REP8(MUL64) REP8(MUL64) }
+        if (OP == 90) { REP8(MULLIT) REP8(MULLIT) }
+        if (OP == 91) { REP8(MULSABS) REP8(MULSABS) }
+        if (OP == 92) { REP8(CVTUABS) REP8(CVTUABS) }
+        if (OP == 93) { REP8(ADDLIT) REP8(ADDLIT) }
+        if (OP == 94) { REP8(ANDLIT) REP8(ANDLIT) }
+        if (OP == 95) { REP8(ANDINL) REP8(ANDINL) }
         if (OP == 16) { REP8(CVTI) REP8(CVTI) }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -202,8 +214,14 @@ template <int OP> double run(const char* name, int waves_per_simd)
     return ms;
 }
 
-int main(int argc, char**)
+int main(int argc, char** argv)
 {
+    if (argc > 1 && argv[1][0] == 'l') {          // "l": the literal / modifier forms of round 4 only
+        const int w = 8;
+        run<44>("v_mul_f32", w); run<90>("v_mul_f32 literal", w); run<91>("v_mul_f32 |v|, s", w); run<40>("v_cvt_u32_f32", w); run<92>("v_cvt_u32_f32 |v| e64", w);
+        run<93>("v_add_f32 literal", w); run<47>("v_and_b32", w); run<94>("v_and_b32 literal", w); run<95>("v_and_b32 inline -4", w);
+        return 0;
+    }
     for (int w : {8, 4, 2, 1}) {
         if (argc > 1) break;          // any argument: only the round-2 table
         run<12>("v_add_f32", w); run<3>("v_fma_f32", w); run<4>("v_pk_fma_f32", w); run<5>("v_pk_mul_f32", w);
