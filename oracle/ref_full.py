@@ -11,6 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _FULL = os.path.join(_HERE, "_ref", "libnp_ref_full.so")
+# NP_REF_BATCH_LIB: another build of the batch configuration (the sanitizer build of the shims, tests/test_gpu_sanitizers.py)
+_BATCH = os.environ.get("NP_REF_BATCH_LIB") or os.path.join(_HERE, "_ref", "libnp_ref_full_batch.so")
 
 _i32p = C.POINTER(C.c_int32)
 _u32p = C.POINTER(C.c_uint32)
@@ -143,7 +145,7 @@ class FullRef:
         np_dropin.cpp, and the np_* batched bindings are reachable (mode=1 of score_variants / score_variant_group)."""
         if not have_full():
             raise RuntimeError("oracle/_ref/libnp_ref_full.so is not built (needs /root/reference; `make -C oracle full`)")
-        L = C.CDLL(os.path.join(_HERE, "_ref", "libnp_ref_full_batch.so") if batch else _FULL)
+        L = C.CDLL(_BATCH if batch else _FULL)
         L.npfull_read_create.restype = C.c_void_p
         L.npfull_read_create.argtypes = [C.c_char_p, C.c_char_p, _f32p, C.c_size_t, C.c_double]
         L.npfull_read_destroy.argtypes = [C.c_void_p]
@@ -258,7 +260,6 @@ class FullRef:
         return (r1.value, r2.value) if ok else None
 
 
-_BATCH = os.path.join(_HERE, "_ref", "libnp_ref_full_batch.so")
 
 
 def have_batch():

@@ -10,7 +10,7 @@ import pytest
 
 from cases import K, HAF_PRE, HAF_POST, methylation_jobs, eventalign_segments, synth_read
 
-DROPIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libnp_ref_dropin.so")
+DROPIN = os.environ.get("NP_REF_DROPIN_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libnp_ref_dropin.so")
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(DROPIN), reason="libnp_ref_dropin.so not built")]
 
 

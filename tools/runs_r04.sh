@@ -176,4 +176,10 @@ done 2>&1 | tee $O/ea_ab.log
 ( timeout 900 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -2
 }
 
+# the drop-in tests under ASan + UBSan (shims) and UBSan-trap (library host code)
+call_p() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+( time timeout 1500 python -m pytest tests/test_gpu_sanitizers.py -m gpu -x -q ) 2>&1 | tail -40
+}
+
 "call_$1"
