@@ -476,7 +476,8 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
         const int n_rows = (n_bands + 7) >> 3;
         // kept trace: read ri's rows start at row (pair_off[ri] >> 3) + ri -- successive starts are at least (cap >> 3) + 1 >= n_rows apart
         if (MODE != 0) trace = a.trace_all + (size_t)((pbase >> 3) + ri) * 32;
-        const bool ok = !(E <= 0 || K <= 0 || (MODE == 0 && (uint64_t)n_rows * 32 > a.trace_stride) || (uint64_t)K > a.kp_stride || cap < E + K + 2);
+        const bool ok = !(E <= 0 || K <= 0 || (MODE == 0 && (uint64_t)n_rows * 32 > a.trace_stride) || (uint64_t)K > a.kp_stride || cap < E + K + 2 ||
+                          (MODE != 0 && (uint64_t)(pbase >> 3) + (uint64_t)ri + (uint64_t)n_rows > a.trace_all_rows));
         int n_out = 0, max_gap = 0, last_k = -1;
         double sum_emission = 0.0;
         float best_u = NP_NEG_INF;

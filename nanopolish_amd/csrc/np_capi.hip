@@ -72,6 +72,7 @@ struct np_ctx {
     uint32_t* d_counters = nullptr;   // [0..7] class counts, [8..15] work-queue heads, [16] align queue head, [17] chain queue head, [18] back-track queue head, [32] self-test, [1024 .. 1024 + 2 * 4096) work-item bins (np_launch_classify)
     dev_buf order, trace, kparams, align_order;
     dev_buf gslab;                    // staged forward kernel: the resident waves' scaled Gaussians (8 KB per wave)
+    int split_n_reads = -1; int64_t split_total_pairs = 0; const int64_t* split_pair_off = nullptr;   // the batch np_event_align_split_dev's fill phase last ran for
     int hmm_kernel = 1;               // forward kernel: 1 = block-major step (the default), 2 = stage-major step (np_hmm_forward2_kernel, round 4's
                                       // experiment: six look-ups in flight per wave, same scores, measured 13 % slower -- np_hmm_kernels.hip;
                                       // the clamp-free log-sum only: a context whose probe failed scores with kernel 1)
@@ -257,7 +258,15 @@ int run_event_align(np_ctx* c, hipStream_t s, int n_reads, const np_read_dev* re
         // every read's trace: read r starts at row (pair_off[r] >> 3) + r of 256 bytes
         const size_t all = ((size_t)(total_pairs >> 3) + (size_t)n_reads + 1) * 256;
         c->last_align_scratch += (int64_t)all;
-        if (phase == 2 && (c->trace_all.cap < all || c->fill_state.cap < (size_t)n_reads * 8)) { c->err = "np_event_align_split_dev: back-track phase without the fill phase of the same batch"; return NP_ERR_INVALID; }
+        // the back-track walks what the fill of the SAME batch left: same read count, same pair slots, same offsets array (a stale trace
+        // of an earlier, larger batch would pass a capacity check and be walked without complaint)
+        if (phase == 1) { c->split_n_reads = n_reads; c->split_total_pairs = total_pairs; c->split_pair_off = pair_off; }
+        else if (c->split_n_reads != n_reads || c->split_total_pairs != total_pairs || c->split_pair_off != pair_off ||
+                 c->trace_all.cap < all || c->fill_state.cap < (size_t)n_reads * 8) {
+            c->err = "np_event_align_split_dev: back-track phase without the fill phase of the same batch (read count, pair slots and offsets must match)";
+            return NP_ERR_INVALID;
+        }
+        if (phase == 2) c->split_n_reads = -1;                     // a fill's trace is walked once
         NP_HIP(c, c->trace_all.reserve(all));
         NP_HIP(c, c->fill_state.reserve((size_t)n_reads * 8));
     }
@@ -273,7 +282,7 @@ int run_event_align(np_ctx* c, hipStream_t s, int n_reads, const np_read_dev* re
     a.reads = reads; a.event_mean = event_mean; a.ranks = ranks; a.model = c->models[model].d_states;
     a.pair_off = pair_off; a.pairs = pairs; a.pair_begin = pair_begin; a.n_pairs = n_pairs;
     a.trace = c->trace.as<uint64_t>(); a.trace_stride = stride; a.kparams = kparams.as<float4>(); a.kp_stride = kp_stride;
-    a.trace_all = c->trace_all.as<uint64_t>(); a.fill_state = c->fill_state.as<int32_t>(); a.bt_prio = c->align_bt_prio;
+    a.trace_all = c->trace_all.as<uint64_t>(); a.trace_all_rows = phase == 0 ? 0 : (uint64_t)(total_pairs >> 3) + (uint64_t)n_reads + 1; a.fill_state = c->fill_state.as<int32_t>(); a.bt_prio = c->align_bt_prio;
     a.counter = counter;
     a.n_reads = n_reads; a.max_gap_threshold = c->params.max_gap_threshold;
     a.min_average_log_emission = c->params.min_average_log_emission;

@@ -84,6 +84,7 @@ struct np_align_args {
     int32_t max_gap_threshold;
     double min_average_log_emission;
     uint64_t* trace_all;           // split launches (mode 1 / 2): the trace of EVERY read, read r from row (pair_off[r] >> 3) + r (256 B rows)
+    uint64_t trace_all_rows;       // rows allocated behind trace_all: a read whose rows would end past them is refused (as a read that does not fit)
     int32_t* fill_state;           // split launches: 2 words per read (bits of the best end-cell score, its event index)
     int bt_prio;                   // back-track launch (mode 2): wave priority of the walk (the fused kernel's is NP_A_WALK_PRIO)
 };

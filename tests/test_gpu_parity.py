@@ -379,6 +379,21 @@ def test_split_aligner_equals_the_fused_kernel(ctx, orc, models):
         assert np.array_equal(b["pairs"][i], want) and np.array_equal(b["pairs"][i + 2 * len(Ls)], want)
 
 
+def test_split_aligner_refuses_a_back_track_without_its_fill(ctx, models):
+    """np_event_align_split_dev phase 2 walks the trace phase 1 left for the SAME batch (read count, pair slots, offsets array): without a
+    fill, after the fill of another batch, or a second time, it returns an error instead of walking a stale trace."""
+    from nanopolish_amd.pipeline import build_host_batch, CallMethylationBatch
+    big = CallMethylationBatch(ctx, build_host_batch(models, list(range(40, 52)), L=900), "cuda:0", calibrate=True)
+    small = CallMethylationBatch(ctx, build_host_batch(models, list(range(60, 64)), L=400), "cuda:0", calibrate=True)
+    big.step(stage=11); big.sync()                    # fill of the larger batch: capacities alone would now admit `small`
+    with pytest.raises(Exception, match="back-track phase without the fill phase"):
+        small.step(stage=12)
+    big.step(stage=12); big.sync()                    # its own back-track: fine
+    assert (big.d_n_pairs.cpu().numpy() > 0).all()
+    with pytest.raises(Exception, match="back-track phase without the fill phase"):
+        big.step(stage=12)                            # a fill's trace is walked once
+
+
 def test_pipelined_pass_over_two_streams_equals_the_in_order_pass(orc, models):
     """PipelinedPass (round 3): the aligner's fill on one stream, its back-track + work items + calibration behind it, the scoring of the
     previous step on a second stream, two batch objects on two contexts ordered by events.  Slower than the in-order pass on every
