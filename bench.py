@@ -641,7 +641,7 @@ def main():
         torch.cuda.empty_cache()
         try:
             import bench_variants
-            va = bench_variants.run(steps=args.steps, warmup=args.warmup, cpu_sample=0 if args.cpu_sample == 0 else 20000)
+            va = bench_variants.run(steps=args.steps, warmup=args.warmup, cpu_sample=0 if args.cpu_sample == 0 else 400000)
             legs["value_variants"] = va["value"]; legs["variants"] = va
         except Exception as e:  # noqa: BLE001
             legs["variants"] = dict(error=repr(e))

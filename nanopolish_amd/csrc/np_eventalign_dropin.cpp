@@ -216,7 +216,11 @@ static void realign_group(std::vector<NpRealignRead>& reads, const bool rna, con
         const bool aligned = n_pairs[q] > 0;
         // scalings: MoM (set4(shift, scale, 0, 1), raw_loader.cpp:52-58), replaced by recalibrate_model's set4 when it ran
         sr->scalings[0].set4(ra[q].shift, ra[q].scale, 0.0, 1.0);
-        if (aligned && calibrated[q]) sr->scalings[0].set4(rb[q].shift, rb[q].scale, 0.0, rb[q].var);
+        // (also when it ran and the result failed the MIN_CALIBRATION_VAR gate: the reference leaves those scalings in place and clears the
+        //  events, squiggle_read.cpp:316-323.  The device writes a read's recalibrated scalings whenever the fit ran and reports the gate in
+        //  calibrated[]; "ran and failed" is therefore calibrated == 0 with var > 2.5 -- the method-of-moments input carries var = 1.)
+        const bool recal_ran = aligned && (calibrated[q] || rb[q].var > 2.5);
+        if (recal_ran) sr->scalings[0].set4(rb[q].shift, rb[q].scale, 0.0, rb[q].var);
         const bool keep = aligned && calibrated[q] && !(epb[q] > 5.0);
         if (keep) {
             sr->events[0].resize(ne);

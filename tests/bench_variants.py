@@ -40,7 +40,7 @@ def haplotypes(ref, i):
     return cs, ce, seqs
 
 
-def run(draft=10000, reads=250, tile=8, stride=1, indel_bias=0.9, steps=3, warmup=1, cpu_sample=20000):
+def run(draft=10000, reads=250, tile=8, stride=1, indel_bias=0.9, steps=3, warmup=1, cpu_sample=400000):
     """One variants-screening measurement (BASELINE.json configs[3]); returns the JSON-able dict."""
     import types
     args = types.SimpleNamespace(draft=draft, reads=reads, tile=tile, stride=stride, indel_bias=indel_bias, steps=steps, warmup=warmup,
@@ -193,7 +193,7 @@ def main():
     ap.add_argument("--indel-bias", type=float, default=0.9, help="hmm_indel_bias_factor (src/nanopolish_call_variants.cpp:1116)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cpu-sample", type=int, default=20000, help="work items for the CPU baseline / parity check (0: skip)")
+    ap.add_argument("--cpu-sample", type=int, default=400000, help="work items for the CPU baseline / parity check (0: skip)")
     a = ap.parse_args()
     print(json.dumps(run(a.draft, a.reads, a.tile, a.stride, a.indel_bias, a.steps, a.warmup, a.cpu_sample)))
 

@@ -182,4 +182,14 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 ( time timeout 1500 python -m pytest tests/test_gpu_sanitizers.py -m gpu -x -q ) 2>&1 | tail -40
 }
 
+# kernel B at five / six waves per SIMD (640- / 768-thread workgroups, 96 / 80 registers with a few spills); the split-phase guard test; shims after the scalings fix
+call_q() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04q; mkdir -p $O
+V=nanopolish_amd/variants
+( timeout 900 python tools/hmm_ab.py --pool 4000 --tile 10 "" $V/libnp_hip_w5.so $V/libnp_hip_w6.so "" $V/libnp_hip_w5.so $V/libnp_hip_w6.so ) > $O/hmm_ab.log 2>&1; cat $O/hmm_ab.log
+for l in w5 w6; do ( NP_HIP_LIB=$R/$V/libnp_hip_$l.so timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_sites.py -m gpu -x -q ) 2>&1 | tail -2; done
+( timeout 900 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -3
+}
+
 "call_$1"
