@@ -192,4 +192,21 @@ for l in w5 w6; do ( NP_HIP_LIB=$R/$V/libnp_hip_$l.so timeout 300 python -m pyte
 ( timeout 900 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -3
 }
 
+# the one-wave-per-read glue kernels (event map, recalibration, work-item groups) at four waves per workgroup against one
+call_r() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04r; mkdir -p $O
+V=nanopolish_amd/variants
+( timeout 900 python tools/hmm_ab.py --pool 4000 --tile 10 "" $V/libnp_hip_gluew1.so "" $V/libnp_hip_gluew1.so ) > $O/hmm_ab.log 2>&1; cat $O/hmm_ab.log
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/tr -o t -- python $R/tools/hmm_ab.py --pool 4000 --tile 10 "" > $R/$O/tr.log 2>&1 ); f=$(find $O/tr -name "*results.db" | head -1); [ -n "$f" ] && python3 profiles/summarize_rocpd.py $f | cut -c1-150 | head -24; rm -rf $O/tr
+( timeout 900 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -3
+}
+
+# glue of step i-1 beside the aligner of step i (two streams, the aligner's grid at 8 / 7 / 6 waves per SIMD)
+call_s() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04s; mkdir -p $O
+( timeout 600 python tools/overlap_probe.py ) > $O/overlap.log 2>&1; tail -8 $O/overlap.log
+}
+
 "call_$1"
