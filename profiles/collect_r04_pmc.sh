@@ -7,8 +7,8 @@
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; TAG=${1:-r04pmc}; N=${2:-8192}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 W="python $R/tools/pmc_workload.py --reads $N --ea-reads $N --reps 2"
 V="python $R/tools/pmc_workload.py --var-tile 1 --reps 2"
-( cd /tmp && timeout 120 $W > $O/units.json 2> $O/units.err ); echo "units rc=$?"
-( cd /tmp && timeout 120 $V > $O/units_variants.json 2> $O/units_variants.err ); echo "units variants rc=$?"
+( cd /tmp && timeout 200 $W --timing-reps 5 > $O/units.json 2> $O/units.err ); echo "units rc=$?"        # the run WITHOUT counters: a warm-up step, five timed ones
+( cd /tmp && timeout 200 $V --timing-reps 5 > $O/units_variants.json 2> $O/units_variants.err ); echo "units variants rc=$?"
 pass() {   # name, workload, counters...
   local name=$1; local wl=$2; shift; shift
   ( cd /tmp && timeout ${PASS_TIMEOUT:-200} rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$name -o $name -- $wl > $O/$name.log 2>&1 ); echo "$name rc=$?" | tee -a $O/passes.log

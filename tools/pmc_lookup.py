@@ -40,4 +40,7 @@ def issue(name, unit, simd_cycles_per_unit):
                unit=unit, simd_cycles_per_unit=round(simd_cycles_per_unit, 1), valu_issue_floor=round(v * fast / simd_cycles_per_unit, 3), source=d["source"])
     if d.get("valu_issue_priced") and d.get("valu_issue_floor"):
         out["valu_issue_priced"] = round(out["valu_issue_floor"] * d["valu_issue_priced"] / d["valu_issue_floor"], 3)
+        out["note"] = ("the vector port's busy fraction lies between valu_issue_floor and 1; valu_issue_priced charges every instruction its class's cost in an "
+                       "ISOLATED stream (profiles/r04_valu_calibration.json) -- mixed streams overlap by ~10 % (cmp + cndmask alternating: 3.8 cycles against "
+                       "4.4), so a value at or above 1 reads: this launch runs at the issue bound of its instruction mix")
     return out
