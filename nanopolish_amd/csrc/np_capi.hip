@@ -72,7 +72,9 @@ struct np_ctx {
     uint32_t* d_counters = nullptr;   // [0..7] class counts, [8..15] work-queue heads, [16] align queue head, [17] chain queue head, [18] back-track queue head, [32] self-test, [1024 .. 1024 + 2 * 4096) work-item bins (np_launch_classify)
     dev_buf order, trace, kparams, align_order;
     dev_buf gslab;                    // staged forward kernel: the resident waves' scaled Gaussians (8 KB per wave)
+    void* small_h = nullptr; size_t small_h_cap = 0; dev_buf small_d;     // np_hmm_score_host's small-batch path: one pinned blob, its device twin
     int split_n_reads = -1; int64_t split_total_pairs = 0; const int64_t* split_pair_off = nullptr;   // the batch np_event_align_split_dev's fill phase last ran for
+    int small_batch_path = 1;         // np_hmm_score_host: batches of <= NP_SMALL_BATCH items as one pinned blob (0: the general path; tests compare the two)
     int hmm_kernel = 1;               // forward kernel: 1 = block-major step (the default), 2 = stage-major step (np_hmm_forward2_kernel, round 4's
                                       // experiment: six look-ups in flight per wave, same scores, measured 13 % slower -- np_hmm_kernels.hip;
                                       // the clamp-free log-sum only: a context whose probe failed scores with kernel 1)
@@ -450,6 +452,8 @@ void np_destroy(np_ctx* c)
                        &c->b_states, &c->b_n_states, &c->ed_status, &c->ed_tstat, &c->b_raw, &c->b_raw_off, &c->b_ev_off, &c->b_ev_start,
                        &c->b_ev_len, &c->b_ev_mean, &c->b_ev_stdv, &c->b_n_events, &c->cm_group_rank_off, &c->cm_cigar_scratch, &c->ea_bp, &c->ea_path, &c->ea_args, &c->align_order, &c->gslab};
     for (dev_buf* b : bufs) b->release();
+    c->small_d.release();
+    if (c->small_h) (void)hipHostFree(c->small_h);
     for (auto& t : c->timing) {
         for (auto& pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         for (auto& ev : t.pool) (void)hipEventDestroy(ev);
@@ -836,6 +840,77 @@ static int pack_hmm_jobs(np_ctx* c, int n_jobs, const np_hmm_job* jobs, std::vec
     return NP_OK;
 }
 
+// A SMALL batch through the host entry point (the per-call shim: one work item, or one round of the callers it combined) is bound by
+// API calls, not by the device: four pageable uploads, a memset, the three binning kernels, the forward launch, a pageable read-back
+// and two timer events cost ~230 us a round.  Here the packed arrays, the per-class order the binning kernels would have produced
+// (np_job_bin, sorted on the host) and the zeroed tickets travel as ONE pinned blob (one upload), only the size classes that occur
+// are launched, and the scores come back into the blob's pinned tail: two copies, the launches, one synchronisation.
+#define NP_SMALL_BATCH 4096
+static int score_small(np_ctx* c, hipStream_t s, int n_jobs, const std::vector<np_hmm_job_dev>& dj, const std::vector<np_read_dev>& dr,
+                       const std::vector<float>& ev, const std::vector<uint16_t>& rk, int model, float* out_scores)
+{
+    if (model < 0 || model >= (int)c->models.size()) { c->err = "bad model id"; return NP_ERR_INVALID; }
+    size_t off = 0;
+    auto add = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t n = (size_t)n_jobs;
+    const size_t o_cnt = add(16 * sizeof(uint32_t)), o_order = add((size_t)NP_NUM_CLASSES * n * sizeof(uint32_t)), o_jobs = add(n * sizeof(np_hmm_job_dev)),
+                 o_reads = add(dr.size() * sizeof(np_read_dev)), o_ev = add(ev.size() * sizeof(float)), o_rk = add(rk.size() * sizeof(uint16_t));
+    const size_t up = off;
+    const size_t o_out = add(n * sizeof(float));
+    if (off > c->small_h_cap) {
+        if (c->small_h) (void)hipHostFree(c->small_h);
+        c->small_h = nullptr; c->small_h_cap = 0;
+        const size_t want = off + off / 2 + 65536;
+        NP_HIP(c, hipHostMalloc(&c->small_h, want, hipHostMallocDefault));
+        c->small_h_cap = want;
+    }
+    NP_HIP(c, c->small_d.reserve(c->small_h_cap));
+    char* H = (char*)c->small_h; char* D = (char*)c->small_d.p;
+    uint32_t* cnt = (uint32_t*)(H + o_cnt);
+    memset(cnt, 0, 16 * sizeof(uint32_t));                      // [0..8): items per class, [8..16): the kernels' tickets
+    uint32_t* order = (uint32_t*)(H + o_order);
+    float* out_h = (float*)(H + o_out);
+    std::vector<std::pair<int, uint32_t>> key(n);
+    for (size_t j = 0; j < n; ++j) key[j] = std::make_pair(np_job_bin(dj[j], NP_FLANK_LEN), (uint32_t)j);
+    std::sort(key.begin(), key.end());
+    // A round of a few items (the per-call shim: up to one per calling thread) is one wave's worth of work per class, and the classes'
+    // launches run one after the other: three classes, three times the latency.  A size class is a CAPACITY (lanes x blocks per lane
+    // >= the item's k-mers; blocks per lane and lanes used follow the item at run time), so such a round goes to the largest class any
+    // of its items needs, in ONE launch (same arithmetic per cell: tests/test_gpu_parity.py::test_host_scoring_...).
+    int one_class = -1;
+    if (n <= 64) for (size_t q = 0; q < n; ++q) if (key[q].first >= 0) one_class = std::max(one_class, key[q].first / (NP_CPL * NP_EBUCKETS));
+    bool skipped = false;
+    for (size_t q = 0; q < n; ++q) {
+        if (key[q].first < 0) { skipped = true; continue; }
+        const int cls = one_class >= 0 ? one_class : key[q].first / (NP_CPL * NP_EBUCKETS);
+        order[(size_t)cls * n + cnt[cls]++] = key[q].second;
+    }
+    memcpy(H + o_jobs, dj.data(), n * sizeof(np_hmm_job_dev));
+    memcpy(H + o_reads, dr.data(), dr.size() * sizeof(np_read_dev));
+    memcpy(H + o_ev, ev.data(), ev.size() * sizeof(float));
+    memcpy(H + o_rk, rk.data(), rk.size() * sizeof(uint16_t));
+    NP_HIP(c, hipMemcpyAsync(D, H, up, hipMemcpyHostToDevice, s));
+    {
+        family_timer tm(c, 1, s);
+        for (int cls = 0; cls < NP_NUM_CLASSES; ++cls) {
+            if (!cnt[cls]) continue;
+            np_hmm_args a{};
+            a.jobs = (const np_hmm_job_dev*)(D + o_jobs); a.order = (const uint32_t*)(D + o_order) + (size_t)cls * n; a.n_class_jobs = (const uint32_t*)(D + o_cnt) + cls;
+            a.reads = (const np_read_dev*)(D + o_reads); a.event_mean = (const float*)(D + o_ev); a.ranks = (const uint16_t*)(D + o_rk);
+            a.model = c->models[model].d_states; a.logsum = c->d_logsum; a.flank = c->d_flank; a.counter = (uint32_t*)(D + o_cnt) + 8 + cls;
+            a.out = (float*)(D + o_out); a.prio = c->hmm_prio;
+            const int jobs_per_block = (np_hmm_block_threads(cls) / 64) * (64 / NP_CLASS_SEG[cls]);
+            NP_HIP(c, np_launch_hmm_forward(cls, a, persistent_blocks(c, cnt[cls], jobs_per_block, c->hmm_blocks_per_cu), c->lse_oor, s));
+        }
+    }
+    NP_HIP(c, hipMemcpyAsync(out_h, D + o_out, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    NP_HIP(c, hipStreamSynchronize(s));
+    memcpy(out_scores, out_h, n * sizeof(float));
+    if (skipped) for (size_t q = 0; q < n && key[q].first < 0; ++q) out_scores[key[q].second] = __builtin_nanf("");      // (classify's rule for an item no class takes)
+    drain_timing(c);
+    return NP_OK;
+}
+
 int np_hmm_score_host(np_ctx* c, int n_jobs, const np_hmm_job* jobs, float* out_scores)
 {
     if (!c || n_jobs < 0 || (n_jobs > 0 && (!jobs || !out_scores))) return NP_ERR_INVALID;
@@ -866,6 +941,7 @@ int np_hmm_score_host(np_ctx* c, int n_jobs, const np_hmm_job* jobs, float* out_
     int rc = pack_hmm_jobs(c, n_jobs, jobs, dj, dr, ev, rk, &model);
     if (rc != NP_OK) return rc;
     stream_scope scope = use_stream(c, nullptr); hipStream_t s = scope.s;
+    if (n_jobs <= NP_SMALL_BATCH && c->small_batch_path) return score_small(c, s, n_jobs, dj, dr, ev, rk, model, out_scores);
     NP_HIP(c, c->b_jobs.reserve(dj.size() * sizeof(np_hmm_job_dev)));
     NP_HIP(c, c->b_reads.reserve(dr.size() * sizeof(np_read_dev)));
     NP_HIP(c, c->b_events.reserve(ev.size() * sizeof(float)));
@@ -1212,6 +1288,7 @@ int np_set_option(np_ctx* c, const char* name, int64_t value)
     else if (k == "hmm_kernel") c->hmm_kernel = value == 2 ? 2 : 1;
     else if (k == "align_lpt") c->align_lpt = value != 0;
     else if (k == "stream_switch_wait") c->stream_switch_wait = value != 0;
+    else if (k == "small_batch_path") c->small_batch_path = value != 0;
     else if (k == "ed_warmup") c->ed_warmup = (int)value;
     else if (k == "ea_rows_cap") c->ea_rows_cap = (int)std::min<int64_t>(65535, std::max<int64_t>(16, value));
     else if (k == "lse_oor") c->lse_oor = value != 0;          // tests: both log-sum lookups must give the same scores

@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <map>
 #include <mutex>
@@ -62,6 +63,13 @@ void fail(const char* what, int rc)
 }
 
 // Flat combining of concurrent scoring calls (see the header).  A request is a run of np_hmm_job with room for their scores.
+static inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
+
 class ScoreCombiner {
 public:
     ScoreCombiner() : flushing_(false) {}
@@ -72,10 +80,31 @@ public:
         Req r; r.jobs = jobs; r.n = n; r.out = out; r.rc = NP_OK; r.done = false;
         std::unique_lock<std::mutex> g(m_);
         queue_.push_back(&r);
+        queued_.store(queue_.size(), std::memory_order_release);
         while (!r.done) {
-            if (flushing_) { cv_.wait(g); continue; }
+            if (flushing_) {
+                // a round is ~100 us: spin for the hand-over first (a futex sleep and wake-up costs as much as the round itself), sleep
+                // only when the device keeps the combiner for long
+                g.unlock();
+                for (int spin = 0; spin < 20000 && flushing_.load(std::memory_order_acquire) && !r.done.load(std::memory_order_acquire); ++spin) cpu_relax();
+                g.lock();
+                if (flushing_ && !r.done) cv_.wait_for(g, std::chrono::microseconds(200));
+                continue;
+            }
             flushing_ = true;                                   // this thread combines
+            // The callers a round has just released need a few microseconds to come back with their next item; a combiner that collects
+            // at once only ever sees the other half of the threads (two groups taking turns: 8 calls per round from 16 threads).  With
+            // company in the last round it holds the door for up to ~12 us, or until as many items wait as the last two rounds carried.
+            if (last_round_ >= 2) {
+                const size_t target = last_round_ + prev_round_;
+                g.unlock();
+                const std::chrono::steady_clock::time_point until = std::chrono::steady_clock::now() + std::chrono::microseconds(12);
+                while (queued_.load(std::memory_order_acquire) < target && std::chrono::steady_clock::now() < until) cpu_relax();
+                g.lock();
+            }
             std::vector<Req*> batch; batch.swap(queue_);
+            queued_.store(0, std::memory_order_release);
+            prev_round_ = last_round_; last_round_ = batch.size();
             g.unlock();
             flush(batch);
             g.lock();
@@ -87,10 +116,13 @@ public:
     }
     long rounds() const { return rounds_.load(); }
     long requests() const { return requests_.load(); }
+    long flush_ns() const { return flush_ns_.load(); }
 private:
-    struct Req { const np_hmm_job* jobs; int n; float* out; int rc; bool done; };
+    struct Req { const np_hmm_job* jobs; int n; float* out; int rc; std::atomic<bool> done; };
     void flush(std::vector<Req*>& batch)
     {
+        struct Clock { std::atomic<long>& acc; std::chrono::steady_clock::time_point t0; Clock(std::atomic<long>& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+                       ~Clock() { acc.fetch_add((long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count()); } } clk(flush_ns_);
         rounds_.fetch_add(1); requests_.fetch_add((long)batch.size());
         np_ctx* c = shim().get();
         if (batch.size() == 1) { batch[0]->rc = np_hmm_score_host(c, batch[0]->n, batch[0]->jobs, batch[0]->out); return; }
@@ -111,9 +143,11 @@ private:
     }
     std::mutex m_; std::condition_variable cv_;
     std::vector<Req*> queue_;
-    bool flushing_;
+    std::atomic<bool> flushing_;
+    std::atomic<size_t> queued_{0};
+    size_t last_round_ = 0, prev_round_ = 0;       // (under m_)
     std::vector<np_hmm_job> all_; std::vector<float> sc_;      // the combiner's buffers (one combiner at a time)
-    std::atomic<long> rounds_{0}, requests_{0};
+    std::atomic<long> rounds_{0}, requests_{0}, flush_ns_{0};
 };
 ScoreCombiner& combiner() { static ScoreCombiner c; return c; }
 
@@ -280,3 +314,4 @@ std::vector<AlignedPair> adaptive_banded_simple_event_align(SquiggleRead& read, 
 extern "C" long np_dropin_error_count(void) { return g_errors.load(); }
 // diagnostics of the combiner: device rounds and the scoring calls they carried (calls / rounds = callers combined per launch)
 extern "C" void np_dropin_combiner_stats(long* rounds, long* calls) { if (rounds) *rounds = combiner().rounds(); if (calls) *calls = combiner().requests(); }
+extern "C" long np_dropin_combiner_flush_ns(void) { return combiner().flush_ns(); }        // wall time inside the rounds' np_hmm_score_host calls

@@ -256,45 +256,7 @@ __global__ void __launch_bounds__(256) np_resolve_kernel(int64_t n_jobs, np_hmm_
     jobs[j] = job;
 }
 
-__device__ __forceinline__ int size_class(uint32_t n)
-{
-    if (n == 0) return -1;
-    if (n <= 16) return 0;
-    if (n <= 24) return 1;
-    if (n <= 32) return 2;
-    if (n <= 64) return 3;
-    if (n <= 128) return 4;
-    if (n <= 256) return 5;
-    if (n <= 512) return 6;
-    if (n <= 1024) return 7;
-    return -1;
-}
-
-// Work-item binning.  A bin is (size class, k-mer blocks per lane, event-count bucket): the items that share a wave
-// then need the same number of blocks per lane (the forward kernel runs every lane for the wave's maximum) and have
-// nearly the same number of rows (no padding steps); inside a class the widest and longest packs are issued first.
-// Counting sort in three small kernels: histogram -> exclusive scan -> scatter.
-#define NP_EBUCKETS 64
-#define NP_CPL 8                 // blocks-per-lane groups inside a class (ceil(n / SEG) scaled to 1..8)
-#define NP_NBINS (NP_NUM_CLASSES * NP_CPL * NP_EBUCKETS)
-
-__device__ __forceinline__ int job_bin(const np_hmm_job_dev& jb, uint32_t flank_len)
-{
-    const uint32_t e = (jb.e_stop > jb.e_start ? jb.e_stop - jb.e_start : jb.e_start - jb.e_stop) + 1u;
-    const int cls = (e <= flank_len && !(jb.flags & NP_JOB_SKIP)) ? size_class(jb.n_kmers) : -1;
-    if (cls < 0) return -1;
-    // bucket width 1, 1, 2, 4, 8, 16, 16, 16 events (round 3: the two smallest classes -- three quarters of the methylation items and all of
-    // the variants shape -- are sorted by their EXACT event count: a pack runs for its longest item, and buckets of four events cost
-    // those classes 5 % of their steps)
-    const uint32_t shift = cls < 2 ? 0u : (cls < 6 ? (uint32_t)(cls - 1) : 4u);
-    const uint32_t bucket = (e >> shift) < (NP_EBUCKETS - 1) ? (e >> shift) : (NP_EBUCKETS - 1);
-    // blocks per lane the item needs: ceil(n / SEG), in units of the class' C / 8 (C = 8: 1..8; C = 16: pairs)
-    const int seg = cls == 0 ? 2 : (cls == 1 ? 3 : ((1 << cls) < 64 ? (1 << cls) : 64)), cu = (cls == NP_NUM_CLASSES - 1 ? 16 : 8) / NP_CPL;   // NP_CLASS_SEG / NP_CLASS_C
-    const int cpl = ((int)jb.n_kmers + seg - 1) / seg;
-    const int cg = (cpl + cu - 1) / cu;                                     // 1..8
-    // descending blocks per lane, then descending event count, inside a class
-    return (cls * NP_CPL + (NP_CPL - cg)) * NP_EBUCKETS + (NP_EBUCKETS - 1 - (int)bucket);
-}
+// (size_class / job_bin: np_kernels.h -- the host entry points bin small batches themselves)
 
 // NP_BIN_ITEMS work items per workgroup: the workgroup's histogram (7 KB of LDS) is cleared and flushed once per 4096 items,
 // and the global counters -- a few hot bins take nearly all items -- see one atomic per bin and workgroup instead of sixteen.
@@ -310,7 +272,7 @@ __global__ void __launch_bounds__(256) np_bin_count_kernel(const np_hmm_job_dev*
     for (int t = 0; t < NP_BIN_ITEMS / 256; ++t) {
         const int64_t j = base + t * 256 + threadIdx.x;
         if (j < n_jobs) {
-            const int bin = job_bin(jobs[j], flank_len);
+            const int bin = np_job_bin(jobs[j], flank_len);
             if (bin >= 0) atomicAdd(&h[bin], 1u);
             else if (out_scores) out_scores[j] = __builtin_nanf("");          // skipped / unsupported item
         }
@@ -343,7 +305,7 @@ __global__ void __launch_bounds__(256) np_bin_scatter_kernel(const np_hmm_job_de
         const int64_t j = base + t * 256 + threadIdx.x;
         bin[t] = -1; local[t] = 0;
         if (j < n_jobs) {
-            bin[t] = job_bin(jobs[j], flank_len);
+            bin[t] = np_job_bin(jobs[j], flank_len);
             if (bin[t] >= 0) local[t] = atomicAdd(&h[bin[t]], 1u);
         }
     }

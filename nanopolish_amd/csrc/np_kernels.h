@@ -96,6 +96,47 @@ struct np_align_args {
 static const int NP_CLASS_SEG[NP_NUM_CLASSES] = {2, 3, 4, 8, 16, 32, 64, 64};
 static const int NP_CLASS_C[NP_NUM_CLASSES] = {8, 8, 8, 8, 8, 8, 8, 16};
 
+__host__ __device__ inline int np_size_class(uint32_t n)
+{
+    if (n == 0) return -1;
+    if (n <= 16) return 0;
+    if (n <= 24) return 1;
+    if (n <= 32) return 2;
+    if (n <= 64) return 3;
+    if (n <= 128) return 4;
+    if (n <= 256) return 5;
+    if (n <= 512) return 6;
+    if (n <= 1024) return 7;
+    return -1;
+}
+
+// Work-item binning.  A bin is (size class, k-mer blocks per lane, event-count bucket): the items that share a wave
+// then need the same number of blocks per lane (the forward kernel runs every lane for the wave's maximum) and have
+// nearly the same number of rows (no padding steps); inside a class the widest and longest packs are issued first.
+// Counting sort in three small kernels: histogram -> exclusive scan -> scatter.
+#define NP_EBUCKETS 64
+#define NP_CPL 8                 // blocks-per-lane groups inside a class (ceil(n / SEG) scaled to 1..8)
+#define NP_NBINS (NP_NUM_CLASSES * NP_CPL * NP_EBUCKETS)
+
+__host__ __device__ inline int np_job_bin(const np_hmm_job_dev& jb, uint32_t flank_len)
+{
+    const uint32_t e = (jb.e_stop > jb.e_start ? jb.e_stop - jb.e_start : jb.e_start - jb.e_stop) + 1u;
+    const int cls = (e <= flank_len && !(jb.flags & NP_JOB_SKIP)) ? np_size_class(jb.n_kmers) : -1;
+    if (cls < 0) return -1;
+    // bucket width 1, 1, 2, 4, 8, 16, 16, 16 events (round 3: the two smallest classes -- three quarters of the methylation items and all of
+    // the variants shape -- are sorted by their EXACT event count: a pack runs for its longest item, and buckets of four events cost
+    // those classes 5 % of their steps)
+    const uint32_t shift = cls < 2 ? 0u : (cls < 6 ? (uint32_t)(cls - 1) : 4u);
+    const uint32_t bucket = (e >> shift) < (NP_EBUCKETS - 1) ? (e >> shift) : (NP_EBUCKETS - 1);
+    // blocks per lane the item needs: ceil(n / SEG), in units of the class' C / 8 (C = 8: 1..8; C = 16: pairs)
+    const int seg = cls == 0 ? 2 : (cls == 1 ? 3 : ((1 << cls) < 64 ? (1 << cls) : 64)), cu = (cls == NP_NUM_CLASSES - 1 ? 16 : 8) / NP_CPL;   // NP_CLASS_SEG / NP_CLASS_C
+    const int cpl = ((int)jb.n_kmers + seg - 1) / seg;
+    const int cg = (cpl + cu - 1) / cu;                                     // 1..8
+    // descending blocks per lane, then descending event count, inside a class
+    return (cls * NP_CPL + (NP_CPL - cg)) * NP_EBUCKETS + (NP_EBUCKETS - 1 - (int)bucket);
+}
+
+
 hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, bool lse_oor, hipStream_t s);
 hipError_t np_hmm_forward_lds_bytes(int cls, size_t* bytes);
 bool np_hmm_forward2_has(int cls);                                  // the staged forward kernel covers this size class

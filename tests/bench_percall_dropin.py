@@ -10,6 +10,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import time
 import sys
 
 import numpy as np
@@ -56,13 +57,27 @@ def main():
     out = dict(metric="profile_hmm_score calls/sec, called per work item from an OpenMP loop over reads", unit="calls/s", calls=n_calls,
                reads=args.reads, read_len=args.read_len, cores=cores)
     want = None
+    Ld = C.CDLL(dropin_path)
+    Ld.np_dropin_combiner_flush_ns.restype = C.c_long
+
+    def stats():
+        r, c = C.c_long(0), C.c_long(0)
+        Ld.np_dropin_combiner_stats(C.byref(r), C.byref(c))
+        return r.value, c.value, int(Ld.np_dropin_combiner_flush_ns())
+    rounds = {}
     for name, lib in libs:
         for th in (1, cores):
             best = 0.0
+            s0, t0 = stats(), time.perf_counter()
             for _ in range(3 if name == "dropin" else 1):
                 sc = lib.score_many_reads("cpg", J["events"], J["event_off"], J["shift"], J["scale"], J["var"], J["epb"], J["job_off"], J["seqs"],
                                           J["rc_seqs"], J["e_start"], J["e_stop"], J["stride"], J["rc"], 3, th)
                 best = max(best, n_calls / lib.last_call_s)
+            if name == "dropin":
+                s1, wall = stats(), time.perf_counter() - t0
+                nr = max(1, s1[0] - s0[0])
+                rounds["t%d" % th] = dict(device_rounds=nr, calls_per_round=round((s1[1] - s0[1]) / nr, 2), us_per_round_inside_the_library=round((s1[2] - s0[2]) / nr / 1e3, 1),
+                                          us_per_round_wall=round(wall / nr * 1e6, 1))
             if want is None:
                 want = sc
             out["%s_t%d" % (name, th)] = round(best, 1)
@@ -71,7 +86,7 @@ def main():
     r, c = C.c_long(0), C.c_long(0)
     L.np_dropin_combiner_stats(C.byref(r), C.byref(c))
     L.np_dropin_error_count.restype = C.c_long
-    out["combiner"] = dict(device_rounds=r.value, calls=c.value, calls_per_round=round(c.value / max(1, r.value), 2), errors=int(L.np_dropin_error_count()))
+    out["combiner"] = dict(device_rounds=r.value, calls=c.value, errors=int(L.np_dropin_error_count()), **rounds)
     out["dropin_over_reference_t%d" % cores] = round(out["dropin_t%d" % cores] / out["reference_t%d" % cores], 3)
     print(json.dumps(out), flush=True)
 

@@ -83,6 +83,30 @@ def test_hmm_score_flags_and_long_windows(ctx, orc, models):
     assert np.array_equal(got, np.array(want, np.float32))
 
 
+def test_host_scoring_general_path_equals_the_small_batch_path(ctx, orc, models):
+    """np_hmm_score_host sends batches of <= 4096 items as one pinned blob with the order the binning kernels would have produced made on
+    the host (round 4: the per-call shim's rounds are bound by API calls); option small_batch_path = 0 forces the general path (separate
+    uploads, binning on the device).  Same scores either way, every size class, one item and many."""
+    jobs, want = _score_jobs(ctx, orc, models, _reads(models, range(20, 24), 1200))
+    mn = orc.model(models["nucleotide"])
+    rd = synth_read(30, models["nucleotide"], L=1500)
+    jobs2 = []
+    for n_k, e0 in ((3, 20), (16, 80), (17, 100), (24, 130), (33, 150), (65, 320), (129, 500), (260, 700), (600, 200)):
+        jobs2.append(dict(events=rd["events"], ranks=rd["ranks"][e0 // 2: e0 // 2 + n_k], e_start=e0, e_stop=e0 + int(1.4 * n_k), stride=1, model=ctx.models["nucleotide"],
+                          scale=rd["scale"], shift=rd["shift"], var=rd["var"], events_per_base=1.6, flags=HAF_PRE | HAF_POST))
+    # (a round of <= 64 items runs in ONE launch of the largest size class any item needs: jobs2 mixes all classes, jobs[:40] two)
+    sets = [jobs, jobs2, jobs2[:1], jobs2[:4], jobs[:40], jobs[5:6] + jobs2[3:5]]
+    small = [ctx.profile_hmm_score(q) for q in sets]
+    try:
+        ctx.set_option("small_batch_path", 0)
+        general = [ctx.profile_hmm_score(q) for q in sets]
+    finally:
+        ctx.set_option("small_batch_path", 1)
+    assert np.array_equal(small[0], want)
+    for a, b in zip(small, general):
+        assert np.array_equal(a, b) and np.all(np.isfinite(a))
+
+
 def test_staged_forward_kernel_gives_the_same_scores(ctx, orc, models):
     """option hmm_kernel = 2 (the stage-major forward kernel, round 4's experiment): bit-equal to the oracle and to the default kernel,
     on the methylation windows and on windows of every size class with all clip-flag combinations."""

@@ -209,4 +209,12 @@ O=gpurun_out/r04s; mkdir -p $O
 ( timeout 600 python tools/overlap_probe.py ) > $O/overlap.log 2>&1; tail -8 $O/overlap.log
 }
 
+# np_hmm_score_host's small-batch path + the combiner's spin hand-over: parity, per-call calls/s
+call_t() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04t; mkdir -p $O
+( timeout 900 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -3
+( timeout 600 python tests/bench_percall_dropin.py ) > $O/percall.json 2> $O/percall.err; cat $O/percall.json; tail -2 $O/percall.err
+}
+
 "call_$1"
