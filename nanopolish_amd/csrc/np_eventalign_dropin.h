@@ -34,6 +34,7 @@ struct NpRealignRead {
 // detect_events -> MoM scalings -> adaptive banded event alignment -> event map + recalibrate_model -> the segment chain of
 // profile_hmm_align calls.  Fills sr / alignment / status of every read; the caller then runs its writer
 // (emit_event_alignment_tsv / _sam, summarize_alignment) on them exactly as realign_read does.
-// A record that only partly overlaps [region_start, region_end] (the reference trims its aligned pairs, :661-663), a spliced record,
-// an RNA read or a read whose signal the exact detector refuses come back NP_REALIGN_HOST_PATH.
+// A record that only partly overlaps [region_start, region_end] (the reference trims its aligned pairs, :661-663), a spliced record
+// or a read whose signal holds a non-finite sample come back NP_REALIGN_HOST_PATH.  Direct-RNA reads (rna = 1) run on the device like
+// DNA reads, as a group of their own (k = 5 models, the RNA detector, reversed events): a batch may mix both.
 void np_realign_reads_batch(std::vector<NpRealignRead>& reads, const faidx_t* fai, const bam_hdr_t* hdr, int region_start, int region_end);
