@@ -217,4 +217,12 @@ O=gpurun_out/r04t; mkdir -p $O
 ( timeout 600 python tests/bench_percall_dropin.py ) > $O/percall.json 2> $O/percall.err; cat $O/percall.json; tail -2 $O/percall.err
 }
 
+# soak against the reference itself with the round's final kernels: indel / clipped records through the whole chain (seeds 8-10)
+call_u() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04u; mkdir -p $O; rm -f $O/soak.jsonl
+for seed in 8 9 10; do timeout 900 python tests/gpu_soak.py --reads 1500 --seed $seed >> $O/soak.jsonl 2>> $O/soak.err; echo "rc=$?"; done
+cat $O/soak.jsonl | cut -c1-400; tail -2 $O/soak.err
+}
+
 "call_$1"
