@@ -225,4 +225,17 @@ for seed in 8 9 10; do timeout 900 python tests/gpu_soak.py --reads 1500 --seed 
 cat $O/soak.jsonl | cut -c1-400; tail -2 $O/soak.err
 }
 
+# the t-statistic's final quotient by a checked approximation (np_tstat_quotient): parity of the default build and of the two extremes
+# (the reference's arithmetic everywhere / for every sample whose approximation is checked... never: margin 2^29), detection time from raw
+call_v() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04v; mkdir -p $O
+V=$R/nanopolish_amd/variants
+for l in "" $V/libnp_hip_tsexact.so $V/libnp_hip_tsalways.so; do
+  ( NP_HIP_LIB=$l timeout 600 python -m pytest tests/test_gpu_events.py tests/test_gpu_reflevel.py tests/test_gpu_rna.py -m gpu -x -q ) 2>&1 | tail -1
+  ( NP_HIP_LIB=$l timeout 600 python bench.py --steps 3 --warmup 1 --from-raw 1 --cpu-sample 0 --legs 0 --streamed 0 --ragged 0 ) 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$l', d['value'], d['roofline']['kernel_ms_per_step'])"
+done 2>&1 | tee $O/ts_ab.log
+for seed in 11; do NP_HIP_LIB= timeout 900 python tests/gpu_soak.py --reads 1500 --seed $seed | cut -c1-300; done
+}
+
 "call_$1"
