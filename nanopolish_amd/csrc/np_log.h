@@ -8,6 +8,9 @@
 // against the host's log() on a multi-million point sweep in tests/test_host_logic.py.  x86-64 libm selects its
 // FMA build (__log_fma) on every CPU with FMA3, which forms r with one fused multiply-add; that is the variant
 // restated here (NP_LOG_NO_FMA selects the table-compensated form of CPUs without FMA).
+// PROVENANCE: third-party algorithm and constants, NOT part of the nanopolish reference: glibc 2.35 (sysdeps/ieee754/dbl-64/e_log.c, e_exp.c), itself the ARM
+// optimized-routines implementation (Szabolcs Nagy, MIT licence; glibc's copy LGPL-2.1-or-later).  Restated here, not copied: the control flow is
+// this file's own, the coefficients and the table are the published ones (they ARE the function).
 #pragma once
 #include <stdint.h>
 #include <string.h>

@@ -8,6 +8,9 @@
 // libm's result exactly: table and coefficients were read out of this image's libm.so.6 and the function is
 // checked against host logf on a 7M-point sweep in tests/test_host_logic.py (CPU) -- both the FMA and non-FMA
 // evaluation orders give identical floats on that sweep, we use the non-fused one (-ffp-contract=off).
+// PROVENANCE: third-party algorithm and constants, NOT part of the nanopolish reference: glibc 2.35 (sysdeps/ieee754/flt-32/e_logf.c), itself the ARM
+// optimized-routines implementation (Szabolcs Nagy, MIT licence; glibc's copy LGPL-2.1-or-later).  Restated here, not copied: the control flow is
+// this file's own, the coefficients and the table are the published ones (they ARE the function).
 #pragma once
 #include <stdint.h>
 #include <string.h>
