@@ -238,4 +238,16 @@ done 2>&1 | tee $O/ts_ab.log
 for seed in 11; do NP_HIP_LIB= timeout 900 python tests/gpu_soak.py --reads 1500 --seed $seed | cut -c1-300; done
 }
 
+# v_readlane's lane select through M0 (kernel A's two band-end reads, the chain kernel's two event reads) against the scalar-register form
+call_w() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04w; mkdir -p $O
+V=$R/nanopolish_amd/variants
+( timeout 900 python tools/hmm_ab.py --pool 10000 --tile 10 "" $V/libnp_hip_rlold.so "" $V/libnp_hip_rlold.so ) > $O/hmm_ab.log 2>&1; cut -c1-220 $O/hmm_ab.log
+for l in "" $V/libnp_hip_rlold.so "" $V/libnp_hip_rlold.so; do
+  ( NP_HIP_LIB=$l timeout 600 python tests/bench_eventalign.py --pool 1000 --tile 20 --steps 3 --cpu-sample 0 ) 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$l', d['value'], d['kernel_ms_per_step'])"
+done 2>&1 | tee $O/ea_ab.log
+( timeout 900 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -2
+}
+
 "call_$1"

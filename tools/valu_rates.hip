@@ -104,6 +104,9 @@ template <int OP> __global__ void k(unsigned long long* out, float* sink, int it
 #define ADDLIT(n) asm volatile("v_add_f32_e32 %0, 0x457a0000, %1" : "=v"(a##n) : "v"(a##n));
 #define ANDLIT(n) asm volatile("v_and_b32_e32 %0, 0xfffffffc, %1" : "=v"(a##n) : "v"(a##n));
 #define ANDINL(n) asm volatile("v_and_b32_e32 %0, -4, %1" : "=v"(a##n) : "v"(a##n));
+#define RDLNM0(n) asm volatile("v_readlane_b32 %0, %1, m0" : "=s"(s0) : "v"(a##n) : "m0");
+#define RDLNM0S(n) asm volatile("s_mov_b32 m0, %2\n v_readlane_b32 %0, %1, m0" : "=s"(s0) : "v"(a##n), "s"(q##n) : "m0");
+#define RDFIRST(n) asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(s0) : "v"(a##n));
 #define MAX3F(n) asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(a##n) : "v"(a##n), "v"(a0), "v"(a1));
         if (OP == 0) { REP8(CVT64) REP8(CVT64) }
         if (OP == 1) { REP8(CVT32) REP8(CVT32) }
@@ -184,6 +187,9 @@ template <int OP> __global__ void k(unsigned long long* out, float* sink, int it
         if (OP == 93) { REP8(ADDLIT) REP8(ADDLIT) }
         if (OP == 94) { REP8(ANDLIT) REP8(ANDLIT) }
         if (OP == 95) { REP8(ANDINL) REP8(ANDINL) }
+        if (OP == 96) { REP8(RDLNM0) REP8(RDLNM0) }
+        if (OP == 97) { REP8(RDLNM0S) REP8(RDLNM0S) }
+        if (OP == 98) { REP8(RDFIRST) REP8(RDFIRST) }
         if (OP == 16) { REP8(CVTI) REP8(CVTI) }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -219,6 +225,7 @@ int main(int argc, char** argv)
     if (argc > 1 && argv[1][0] == 'l') {          // "l": the literal / modifier forms of round 4 only
         const int w = 8;
         run<44>("v_mul_f32", w); run<90>("v_mul_f32 literal", w); run<91>("v_mul_f32 |v|, s", w); run<40>("v_cvt_u32_f32", w); run<92>("v_cvt_u32_f32 |v| e64", w);
+        run<9>("v_readlane const", w); run<64>("v_readlane sgpr sel", w); run<96>("v_readlane m0", w); run<97>("s_mov m0 + v_readlane m0", w); run<98>("v_readfirstlane", w);
         run<93>("v_add_f32 literal", w); run<47>("v_and_b32", w); run<94>("v_and_b32 literal", w); run<95>("v_and_b32 inline -4", w);
         return 0;
     }
