@@ -72,6 +72,7 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
         else return np_lse(x, y, tbl);
     };
 
+#if NP_HMM_PAIR
     // a log-sum in two halves: the request (maximum, table offset) and the look-up + addition -- so that a step can have several
     // look-ups in flight (NP_HMM_PAIR); GET(REQ(x, y)) is NP_LSE(x, y) operation for operation
     auto NP_LSE_REQ = [&](float x, float y) -> lse_req {
@@ -87,6 +88,8 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
 #endif
         return q.mx + *(const __attribute__((address_space(3))) float*)(uintptr_t)((uint32_t)(uintptr_t)tbl3 + q.off);
     };
+#endif
+
     constexpr int JPW = 64 / SEG;                 // jobs per wave
     const int lane = threadIdx.x & 63;
     const int seg = lane / SEG, sl = lane % SEG;
