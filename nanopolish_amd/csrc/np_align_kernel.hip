@@ -286,7 +286,11 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
     const double P0 = (double)F.p0, P1 = (double)F.p1, L0 = (double)l0;
     const float sd0 = (float)(F.d0 + R.lp_step + em0), sd1 = (float)(F.d1 + R.lp_step + em1);
     const float su0 = (float)(P0 + R.lp_stay + em0), su1 = (float)(P1 + R.lp_stay + em1);
+#if NP_ABL & 32
+    const float sl0 = NP_NEG_INF, sl1 = NP_NEG_INF;      // timing experiment only (results WRONG): the left (k-mer skip) candidates for free
+#else
     const float sl0 = (float)(L0 + R.lp_skip), sl1 = (float)(P0 + R.lp_skip);
+#endif
 #endif
     const float m0 = __builtin_fmaxf(__builtin_fmaxf(sd0, su0), sl0);
     const float m1 = __builtin_fmaxf(__builtin_fmaxf(sd1, su1), sl1);
