@@ -25,11 +25,6 @@
 
 namespace {
 
-#ifndef NP_HMM_PAIR
-#define NP_HMM_PAIR 0      // 1: two blocks' log-sum chains in lock step (round-4 experiment: fewer instructions, two look-ups in flight, 6 % SLOWER)
-#endif
-struct lse_req { float mx; uint32_t off; };
-
 template <int C>
 struct lane_state {
     float M[C], B[C], K[C];
@@ -71,24 +66,6 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
         if constexpr (OOR) return np_lse_oor(x, y, tbl3);
         else return np_lse(x, y, tbl);
     };
-
-#if NP_HMM_PAIR
-    // a log-sum in two halves: the request (maximum, table offset) and the look-up + addition -- so that a step can have several
-    // look-ups in flight (NP_HMM_PAIR); GET(REQ(x, y)) is NP_LSE(x, y) operation for operation
-    auto NP_LSE_REQ = [&](float x, float y) -> lse_req {
-        lse_req q;
-        q.mx = __builtin_fmaxf(x, y);
-        if constexpr (OOR) q.off = np_lse_offset(x, y);
-        else { const uint32_t o = np_lse_offset(x, y); q.off = o < 4u * (NP_LOGSUM_TBL - 1) ? o : 4u * (NP_LOGSUM_TBL - 1); }
-        return q;
-    };
-    auto NP_LSE_GET = [&](const lse_req& q) -> float {
-#if NP_HMM_ABL & 2
-        return q.mx;
-#endif
-        return q.mx + *(const __attribute__((address_space(3))) float*)(uintptr_t)((uint32_t)(uintptr_t)tbl3 + q.off);
-    };
-#endif
 
     constexpr int JPW = 64 / SEG;                 // jobs per wave
     const int lane = threadIdx.x & 63;
@@ -141,6 +118,7 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
         for (int c = 0; c < C; ++c) cur.M[c] = cur.B[c] = cur.K[c] = NP_NEG_INF;   // row 0 (r9.cpp:21-33)
         float oM = NP_NEG_INF, oB = NP_NEG_INF, oK = NP_NEG_INF;   // left neighbour, row r-1
         float lp_end = NP_NEG_INF;
+        float tM = NP_NEG_INF, tB = NP_NEG_INF, tK = NP_NEG_INF;   // the lane's last block, as of the row it computed last (row 0: -inf)
         const int last_lane = n > 0 ? (n - 1) / cw : 0, last_c = n > 0 ? (n - 1) % cw : 0;
 
         const int steps = wave_max_i32(has ? e + lanes_used - 1 : 0);
@@ -153,9 +131,9 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
         for (int t = 1; t <= steps; ++t) {
             // left neighbour's row r (what lane j-1 computed in step t-1 for its last block, cw-1: a wave-uniform index);
             // segment heads see block 0 = -inf
-            float tM = cur.M[0], tB = cur.B[0], tK = cur.K[0];
-#pragma unroll
-            for (int c = 1; c < C; ++c) if (c == cw - 1) { tM = cur.M[c]; tB = cur.B[c]; tK = cur.K[c]; }
+            // (tM, tB, tK: the lane's LAST block, row r - 1 of the neighbour's next row.  Its index cw - 1 is wave-uniform but not a
+            //  constant: picking it out of the eight candidates cost 21 selects per step; the block loop below leaves it in lM_r /
+            //  lB_r / lK_r anyway, so the three values are carried from step to step instead -- round 4)
             float nM = np_wave_shr1(tM, NP_NEG_INF);
             float nB = np_wave_shr1(tB, NP_NEG_INF);
             float nK = np_wave_shr1(tK, NP_NEG_INF);
@@ -171,73 +149,6 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
                 softn = (actn && sl == 0 && (rn == 1 || pre_clip)) ? a.flank[rn - 1] : NP_NEG_INF;     // r9.inl:361-363
                 pfn = (actn && is_last && (post_clip || rn == e)) ? a.flank[e - rn] : 0.0f;           // r9.inl:388
             }
-#if NP_HMM_PAIR
-            if (act) {
-                // Two blocks at a time, their log-sum chains in LOCK STEP (round 4).  The block-major step below waits for every table
-                // look-up before it issues the next instruction (one s_waitcnt lgkmcnt(0) per log-sum: ~9 exposed LDS round trips per
-                // block, and a wave issues in order) -- at four waves per SIMD that exposed latency, not vector issue, is what a step
-                // costs.  The M chains of two neighbouring blocks are independent (both read row r-1), so are the two B cells and the
-                // first K log-sum of the left block: 8 waits per PAIR instead of 18, every cell's own sequence of operations unchanged.
-                float lM_r = nM, lB_r = nB, lK_r = nK;     // block to the left, row r
-                float lM_p = oM, lB_p = oB, lK_p = oK;     // block to the left, row r-1
-#pragma unroll
-                for (int p = 0; p < (C + 1) / 2; ++p) {
-                    const int c0 = 2 * p, c1 = 2 * p + 1;
-                    if (c0 >= cw) continue;                    // wave-uniform
-                    if (c1 < C && c1 < cw) {
-                        const float m0 = cur.M[c0], b0 = cur.B[c0], k0 = cur.K[c0];
-                        const float m1 = cur.M[c1], b1 = cur.B[c1], k1 = cur.K[c1];
-                        const float em0 = np_emission(x, g[c0]), em1 = np_emission(x, g[c1]);
-                        float sA = lp_mm_self + m0, sB = lp_mm_self + m1;
-                        lse_req qa, qb, qc;
-                        qa = NP_LSE_REQ(sA, lp_mm_next + lM_p); qb = NP_LSE_REQ(sB, lp_mm_next + m0); sA = NP_LSE_GET(qa); sB = NP_LSE_GET(qb);
-                        qa = NP_LSE_REQ(sA, lp_bm_self + b0);   qb = NP_LSE_REQ(sB, lp_bm_self + b1); sA = NP_LSE_GET(qa); sB = NP_LSE_GET(qb);
-                        qa = NP_LSE_REQ(sA, lp_bm_next + lB_p); qb = NP_LSE_REQ(sB, lp_bm_next + b0); sA = NP_LSE_GET(qa); sB = NP_LSE_GET(qb);
-                        qa = NP_LSE_REQ(sA, lp_km + lK_p);      qb = NP_LSE_REQ(sB, lp_km + k0);      sA = NP_LSE_GET(qa); sB = NP_LSE_GET(qb);
-                        if (c0 == 0) sA = NP_LSE(sA, soft);    // HMT_FROM_SOFT: -inf except for the first k-mer
-                        const float newM0 = sA + em0, newM1 = sB + em1;
-                        // B of both blocks and the first K log-sum of the left one (PREV_M, PREV_B of the SAME row: the block before the pair)
-                        qa = NP_LSE_REQ(lp_mb + m0, lp_bb + b0); qb = NP_LSE_REQ(lp_mb + m1, lp_bb + b1); qc = NP_LSE_REQ(lp_mk + lM_r, lp_bk + lB_r);
-                        const float newB0 = NP_LSE_GET(qa), newB1 = NP_LSE_GET(qb); const float t0 = NP_LSE_GET(qc);
-                        // the K chain: K(c0) <- K(c0 - 1), beside the first K log-sum of the right block
-                        qa = NP_LSE_REQ(t0, lp_kk + lK_r); qb = NP_LSE_REQ(lp_mk + newM0, lp_bk + newB0);
-                        const float newK0 = NP_LSE_GET(qa); const float t1 = NP_LSE_GET(qb);
-                        const float newK1 = NP_LSE(t1, lp_kk + newK0);
-                        lM_p = m1; lB_p = b1; lK_p = k1;
-                        lM_r = newM1; lB_r = newB1; lK_r = newK1;
-                        cur.M[c0] = newM0; cur.B[c0] = newB0; cur.K[c0] = newK0;
-                        cur.M[c1] = newM1; cur.B[c1] = newB1; cur.K[c1] = newK1;
-                        if (sl == last_lane && (post_clip || r == e) && (c0 == last_c || c1 == last_c)) {
-                            const bool first = c0 == last_c;
-                            lp_end = NP_LSE(lp_end, (first ? newM0 : newM1) + pf);
-                            lp_end = NP_LSE(lp_end, (first ? newB0 : newB1) + pf);
-                            lp_end = NP_LSE(lp_end, (first ? newK0 : newK1) + pf);
-                        }
-                    } else {
-                        const int c = c0;
-                        const float em = np_emission(x, g[c]);
-                        float s = lp_mm_self + cur.M[c];
-                        s = NP_LSE(s, lp_mm_next + lM_p);
-                        s = NP_LSE(s, lp_bm_self + cur.B[c]);
-                        s = NP_LSE(s, lp_bm_next + lB_p);
-                        s = NP_LSE(s, lp_km + lK_p);
-                        if (c == 0) s = NP_LSE(s, soft);
-                        const float newM = s + em;
-                        lse_req qa = NP_LSE_REQ(lp_mb + cur.M[c], lp_bb + cur.B[c]), qb = NP_LSE_REQ(lp_mk + lM_r, lp_bk + lB_r);
-                        const float newB = NP_LSE_GET(qa); const float t0 = NP_LSE_GET(qb);
-                        const float newK = NP_LSE(t0, lp_kk + lK_r);
-                        lM_p = cur.M[c]; lB_p = cur.B[c]; lK_p = cur.K[c];
-                        lM_r = newM; lB_r = newB; lK_r = newK;
-                        cur.M[c] = newM; cur.B[c] = newB; cur.K[c] = newK;
-                        if (sl == last_lane && c == last_c && (post_clip || r == e)) {
-                            lp_end = NP_LSE(lp_end, newM + pf);
-                            lp_end = NP_LSE(lp_end, newB + pf);
-                            lp_end = NP_LSE(lp_end, newK + pf);
-                        }
-                    }
-                }
-            }
-#else
             if (act) {
                 float lM_r = nM, lB_r = nB, lK_r = nK;     // block to the left, row r
                 float lM_p = oM, lB_p = oB, lK_p = oK;     // block to the left, row r-1
@@ -273,8 +184,8 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
                         lp_end = NP_LSE(lp_end, newK + pf);
                     }
                 }
+                tM = lM_r; tB = lB_r; tK = lK_r;               // what the last block of the loop left: row r of block cw - 1
             }
-#endif
             oM = nM; oB = nB; oK = nK;
         }
         if (has && sl == last_lane) a.out[jidx] = lp_end;
@@ -300,9 +211,8 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
 // (35.7 / 30.7 / 46.8 ms for the first three forms: Gaussians loaded at the top of the step, in two halves, all early with
 // spills).  With every emission free BOTH take 22.3 ms.  Counters over the same launch: this kernel waits 18 % less on data
 // (SQ_WAIT_ANY) and 58 % MORE for an issue slot (SQ_WAIT_INST_ANY), with 10 % fewer vector instructions of a costlier mix (64-bit
-// address arithmetic, packed moves).  So the look-up latency is not what bounds kernel B: the vector-issue port is -- at the
-// calibrated costs (profiles/r04_valu_calibration.json: add / mul / and 3.7 cycles per wave-instruction, conversion / max /
-// compare / select / DPP 6.3) a log-sum is 27 issue cycles and a cell 295 -- and both forms execute the same arithmetic.
+// address arithmetic, packed moves).  So more look-ups in flight alone buy nothing; what a step costs is in profiles/r04_kernel_b_issue.md (the
+// instruction-class costs quoted in the first write-up of this experiment came from a mis-sized calibration and were 1.5 x too high).
 // ---------------------------------------------------------------------------------------------------
 // experiment knobs of the staged kernel: workgroup size (640 threads = 5 waves per SIMD at two workgroups per CU: needs <= 96 VGPRs) and
 // scheduling barriers between the stages (1: the compiler may not move instructions across a stage boundary)
