@@ -119,6 +119,12 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
         float oM = NP_NEG_INF, oB = NP_NEG_INF, oK = NP_NEG_INF;   // left neighbour, row r-1
         float lp_end = NP_NEG_INF;
         float tM = NP_NEG_INF, tB = NP_NEG_INF, tK = NP_NEG_INF;   // the lane's last block, as of the row it computed last (row 0: -inf)
+        const float head = sl == 0 ? NP_NEG_INF : 0.0f;
+        auto shr_add = [&](const float v) {
+            float r;
+            asm("v_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(v), "v"(head));
+            return r;
+        };
         const int last_lane = n > 0 ? (n - 1) / cw : 0, last_c = n > 0 ? (n - 1) % cw : 0;
 
         const int steps = wave_max_i32(has ? e + lanes_used - 1 : 0);
@@ -134,10 +140,9 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
             // (tM, tB, tK: the lane's LAST block, row r - 1 of the neighbour's next row.  Its index cw - 1 is wave-uniform but not a
             //  constant: picking it out of the eight candidates cost 21 selects per step; the block loop below leaves it in lM_r /
             //  lB_r / lK_r anyway, so the three values are carried from step to step instead -- round 4)
-            float nM = np_wave_shr1(tM, NP_NEG_INF);
-            float nB = np_wave_shr1(tB, NP_NEG_INF);
-            float nK = np_wave_shr1(tK, NP_NEG_INF);
-            if (sl == 0) { nM = NP_NEG_INF; nB = NP_NEG_INF; nK = NP_NEG_INF; }
+            // one instruction per state: the lane shift ADDS a per-lane constant -- -inf in a segment's first lane (block -1 = -inf), else
+            // 0 (v + 0 == v for every value the lattice holds, v + -inf == -inf); bound_ctrl: lane 0's missing source reads as 0
+            const float nM = shr_add(tM), nB = shr_add(tB), nK = shr_add(tK);
 
             const int r = t - sl;
             const bool act = lane_on && r >= 1 && r <= e;
