@@ -120,10 +120,14 @@ struct ea_half {                 // chain state of the read a half-wave works on
 // the priority of the equality chain ("the largest index whose candidate equals the maximum", r9.inl:138-143) is scalar logic:
 //   e4 -> 100, e3 & ~e4 -> 101, e2 & ~e3 & ~e4 -> 001, e1 & ~(e2 | e3 | e4) -> 110, none -> 010
 //   bit0 = (e3 | e2) & ~e4,   bit1 = ~(e4 | e3 | e2),   bit2 = e4 | e3 | (e1 & bit1);   soft (block 0 of row 1): all three set
+// Round 4, second pass: the block in two halves so that a step needs no copy of the previous row.  The M and B cells of row r read row
+// r-1 of their own block and of the block to the left; K reads row r of the block to the left.  Sweeping M and B over the lane's blocks
+// in DESCENDING order, in place, every block still finds its left neighbour's row r-1 untouched; K then runs ASCENDING, in place, behind
+// the new M and B (and M has already used the old K).  The one-piece form kept a copy of each block's previous row for its right
+// neighbour: 9 of the step's 17 register moves.  Every cell's own operations and their order are unchanged.
 template <bool FIRST>
-__device__ __forceinline__ void ea_block_p(float& M, float& B, float& K, const float lM_r, const float lB_r, const float lK_r,
-                                           const float lM_p, const float lB_p, const float lK_p, const float x, const np_gauss& g,
-                                           const ea_trans& tr, const float soft, uint64_t* __restrict__ p)
+__device__ __forceinline__ void ea_block_mb(float& M, float& B, const float lM_p, const float lB_p, const float lK_p, const float x, const np_gauss& g,
+                                            const ea_trans& tr, const float soft, uint64_t* __restrict__ p)
 {
     const float em = np_emission(x, g);
     const float a0 = tr.mm_self + M, a1 = tr.mm_next + lM_p, a2 = tr.bm_self + B, a3 = tr.bm_next + lB_p, a4 = tr.km + lK_p;
@@ -138,11 +142,16 @@ __device__ __forceinline__ void ea_block_p(float& M, float& B, float& K, const f
     const float b0 = tr.mb + M, b2 = tr.bb + B;
     const float newB = __builtin_fmaxf(b0, b2);
     const uint64_t pb = __builtin_amdgcn_ballot_w64(b2 >= b0);
+    M = newM; B = newB;
+    p[0] = c0; p[1] = c1; p[2] = c2; p[3] = pb;
+}
+__device__ __forceinline__ void ea_block_k(float& K, const float lM_r, const float lB_r, const float lK_r, const ea_trans& tr, uint64_t* __restrict__ p)
+{
     const float k1 = tr.mk + lM_r, k3 = tr.bk + lB_r, k4 = tr.kk + lK_r;
     const float newK = __builtin_fmaxf(__builtin_fmaxf(k1, k3), k4);
     const uint64_t q4 = __builtin_amdgcn_ballot_w64(k4 == newK), q3 = __builtin_amdgcn_ballot_w64(k3 == newK) & ~q4;
-    M = newM; B = newB; K = newK;
-    p[0] = c0; p[1] = c1; p[2] = c2; p[3] = pb; p[4] = q4; p[5] = q3;
+    K = newK;
+    p[4] = q4; p[5] = q3;
 }
 
 struct ea_seg { const float* ev; int e_start, stride, e, n; };
@@ -197,13 +206,13 @@ __device__ __attribute__((noinline)) float2 ea_fill2(const ea_gauss<BPL> G, cons
         const float xa = readlane_f32(ec0, ti), xb = readlane_f32(ec1, ti);     // the event of row t of either segment
         x = np_wave_shr1(x, xa);
         x = lane == 32 ? xb : x;
-        float pM[BPL], pB[BPL], pK[BPL];
-#pragma unroll
-        for (int c = 0; c < BPL; ++c) { pM[c] = M[c]; pB[c] = B[c]; pK[c] = K[c]; }
         uint64_t pl[6 * BPL];
-        ea_block_p<true>(M[0], B[0], K[0], nM, nB, nK, oM, oB, oK, x, G.g[0], tr, soft, pl);
 #pragma unroll
-        for (int c = 1; c < BPL; ++c) ea_block_p<false>(M[c], B[c], K[c], M[c - 1], B[c - 1], K[c - 1], pM[c - 1], pB[c - 1], pK[c - 1], x, G.g[c], tr, NP_NEG_INF, pl + 6 * c);
+        for (int c = BPL - 1; c >= 1; --c) ea_block_mb<false>(M[c], B[c], M[c - 1], B[c - 1], K[c - 1], x, G.g[c], tr, NP_NEG_INF, pl + 6 * c);
+        ea_block_mb<true>(M[0], B[0], oM, oB, oK, x, G.g[0], tr, soft, pl);
+        ea_block_k(K[0], nM, nB, nK, tr, pl);
+#pragma unroll
+        for (int c = 1; c < BPL; ++c) ea_block_k(K[c], M[c - 1], B[c - 1], K[c - 1], tr, pl + 6 * c);
         oM = nM; oB = nB; oK = nK;
         soft = NP_NEG_INF;
         // ONE asm block issues the line's stores: every plane stays in its own scalar registers until all of them are on their way
