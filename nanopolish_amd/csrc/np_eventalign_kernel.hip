@@ -230,12 +230,14 @@ __device__ __attribute__((noinline)) float2 ea_fill2(const ea_gauss<BPL> G, cons
                          :: "s"(lp), "s"(pl[6 * BPL - 6]), "s"(pl[6 * BPL - 5]), "s"(pl[6 * BPL - 4]), "s"(pl[6 * BPL - 3]), "s"(pl[6 * BPL - 2]), "s"(pl[6 * BPL - 1]) : "memory");
     };
     int t = 1;
+    for (; t + 1 <= s_min; t += 2) { step(t); step(t + 1); }      // two steps per iteration: the values a step hands to the next need no move back to fixed registers
     for (; t <= s_min; ++t) step(t);
     // the segment with fewer steps has just computed its last row in the lane that owns its last k-mer: keep that row (the lanes
     // go on computing rows nobody reads)
     float zM[BPL];
 #pragma unroll
     for (int c = 0; c < BPL; ++c) zM[c] = M[c];
+    for (; t + 1 <= s_max; t += 2) { step(t); step(t + 1); }
     for (; t <= s_max; ++t) step(t);
     // the lines sit in the scalar data cache: write them back to L2, where the walk's loads (at agent scope: past the vector L1) find them
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
