@@ -127,14 +127,14 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
         };
         const int last_lane = n > 0 ? (n - 1) / cw : 0, last_c = n > 0 ? (n - 1) % cw : 0;
 
-        const int steps = wave_max_i32(has ? e + lanes_used - 1 : 0);
+        const int steps = __builtin_amdgcn_readfirstlane(wave_max_i32(has ? e + lanes_used - 1 : 0));      // (scalar: a uniform loop, not an exec-masked one)
         const bool is_last = lane_on && sl == last_lane;
         // software prefetch, one step ahead: event mean of the row this lane computes next, and the two clip-flank
         // values only the first / last k-mer's lane needs (pre_flank[r-1], post_flank[r-1] == flank[e-r])
         float xn = 0.0f, softn = NP_NEG_INF, pfn = 0.0f;
         if (lane_on && sl == 0) { xn = ev[job.e_start]; softn = a.flank[0]; }      // row 1: event_idx == e_start (r9.inl:361)
         if (is_last && sl == 0 && (post_clip || e == 1)) pfn = a.flank[e - 1];
-        for (int t = 1; t <= steps; ++t) {
+        auto step = [&](const int t) __attribute__((always_inline)) {
             // left neighbour's row r (what lane j-1 computed in step t-1 for its last block, cw-1: a wave-uniform index);
             // segment heads see block 0 = -inf
             // (tM, tB, tK: the lane's LAST block, row r - 1 of the neighbour's next row.  Its index cw - 1 is wave-uniform but not a
@@ -192,7 +192,12 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
                 tM = lM_r; tB = lB_r; tK = lK_r;               // what the last block of the loop left: row r of block cw - 1
             }
             oM = nM; oB = nB; oK = nK;
-        }
+        };
+        // two steps per iteration: what a step hands to the next (the rows, the neighbour's rows, the prefetched values) needs no move back
+        // to fixed registers at the loop's back edge (27 moves per step in the one-step loop)
+        int t = 1;
+        for (; t + 1 <= steps; t += 2) { step(t); step(t + 1); }
+        if (t <= steps) step(t);
         if (has && sl == last_lane) a.out[jidx] = lp_end;
     }
 }
