@@ -173,16 +173,20 @@ __device__ __attribute__((noinline)) float2 ea_fill2(const ea_gauss<BPL> G, cons
 #pragma unroll
     for (int c = 0; c < BPL; ++c) M[c] = B[c] = K[c] = NP_NEG_INF;
     float oM = NP_NEG_INF, oB = NP_NEG_INF, oK = NP_NEG_INF;                // row r-1 of the block to the left
-    // events: one stream per half, every lane holds 64 events of BOTH streams: every lane walks its half's event sequence one step
-    // behind its left neighbour, so the wave fetches 64 events with one coalesced load (a block ahead), the half's first lane takes
-    // its event with v_readlane and the others by one DPP shift
+    // events: lane sl of a half computes row t - sl at step t, i.e. needs event t - 1 - sl of ITS segment: every lane loads its own event
+    // of the next step through its half's range-checked descriptor (an index before the segment's first or past its last event reads as
+    // 0 and only feeds rows nobody reads), one step ahead.  Both descriptors are scalar, so every lane requests from both and keeps its
+    // half's: two loads, two offset additions and one select per step.  (Until round 4 a wave fetched 64 events per 64 steps with one
+    // coalesced load, the half's first lane took its event with v_readlane and the others by a DPP shift: two lane reads with a scalar
+    // lane select, two scalar-to-vector moves, a shift and a select per step -- 35 issue cycles of the step's ~350; the loads are not
+    // vector-ALU instructions.)
     const __amdgpu_buffer_rsrc_t evr0 = make_rsrc(s0.ev + (s0.stride > 0 ? s0.e_start : s0.e_start - (s0.e - 1)), (uint32_t)s0.e * 4u);
     const __amdgpu_buffer_rsrc_t evr1 = make_rsrc(s1.ev + (s1.stride > 0 ? s1.e_start : s1.e_start - (s1.e - 1)), (uint32_t)s1.e * 4u);
-    auto off0 = [&](int idx) { return s0.stride > 0 ? 4 * idx : 4 * (s0.e - 1 - idx); };
-    auto off1 = [&](int idx) { return s1.stride > 0 ? 4 * idx : 4 * (s1.e - 1 - idx); };
-    float ec0 = buf_f32(evr0, off0(lane)), en0 = buf_f32(evr0, off0(lane + 64));
-    float ec1 = buf_f32(evr1, off1(lane)), en1 = buf_f32(evr1, off1(lane + 64));
-    float x = 0.0f;
+    int off0 = s0.stride > 0 ? -4 * sl : 4 * (s0.e - 1 + sl), off1 = s1.stride > 0 ? -4 * sl : 4 * (s1.e - 1 + sl);        // byte offset of event t - 1 - sl at t = 1
+    int d0 = s0.stride > 0 ? 4 : -4, d1 = s1.stride > 0 ? 4 : -4;
+    asm("" : "+v"(d0), "+v"(d1));                          // (vector registers: an addition with a scalar-register source issues in the slow class)
+    float xn;                                             // the lane's event of the NEXT step
+    { const float xa = buf_f32(evr0, off0), xb = buf_f32(evr1, off1); xn = hi_half ? xb : xa; }
     const uint8_t* sline = ea_uniform(bp);                // (wave-uniform: the scalar stores' base)
     // the first lane of a half has no left neighbour (block -1 = -inf): instead of a select after the lane shift, the shift ADDS a
     // per-lane constant -- -inf in lanes 0 and 32, else 0 (v + 0 == v for every value the lattice holds, v + -inf == -inf) -- in the
@@ -201,11 +205,9 @@ __device__ __attribute__((noinline)) float2 ea_fill2(const ea_gauss<BPL> G, cons
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
         const float nM = shr_add(M[BPL - 1]), nB = shr_add(B[BPL - 1]), nK = shr_add(K[BPL - 1]);
-        const int ti = (t - 1) & 63;
-        if (ti == 0 && t > 1) { ec0 = en0; en0 = buf_f32(evr0, off0(t - 1 + 64 + lane)); ec1 = en1; en1 = buf_f32(evr1, off1(t - 1 + 64 + lane)); }
-        const float xa = readlane_f32(ec0, ti), xb = readlane_f32(ec1, ti);     // the event of row t of either segment
-        x = np_wave_shr1(x, xa);
-        x = lane == 32 ? xb : x;
+        const float x = xn;
+        off0 += d0; off1 += d1;
+        { const float xa = buf_f32(evr0, off0), xb = buf_f32(evr1, off1); xn = hi_half ? xb : xa; }
         uint64_t pl[6 * BPL];
 #pragma unroll
         for (int c = BPL - 1; c >= 1; --c) ea_block_mb<false>(M[c], B[c], M[c - 1], B[c - 1], K[c - 1], x, G.g[c], tr, NP_NEG_INF, pl + 6 * c);
