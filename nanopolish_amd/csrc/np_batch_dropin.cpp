@@ -168,7 +168,7 @@ void NpBatchPipeline::Impl::open(const std::vector<int>& devices, bool shared_de
 {
     for (size_t d = 0; d < devices.size(); ++d) {
         DevState* D = new DevState();
-        D->slot_key = shared_default ? 0 : shim().take_slot(devices[d]);
+        D->slot_key = (shared_default && d == 0) ? 0 : shim().take_slot(devices[d]);      // (shared_default: the first entry is the process-wide context)
         D->c = shim().ctx(D->slot_key);
         D->s_h2d = np_stream_create(D->c); D->s_d2h = np_stream_create(D->c);
         if (!D->s_h2d || !D->s_d2h) die(np_last_error(D->c));
@@ -198,7 +198,13 @@ void NpBatchPipeline::Impl::open(const std::vector<int>& devices, bool shared_de
 NpBatchPipeline::NpBatchPipeline(const MethylationCallingParameters& calling_parameters, const std::string& kit, const faidx_t* fai,
                                  const bam_hdr_t* hdr, int region_start, int region_end) : p(new Impl())
 {
-    p->open(std::vector<int>(1, 0), true, 0);
+    // One GPU: the process-wide context (NP_DEVICE) and, beside it, a second context on the same device -- two device passes in flight hide
+    // the per-batch latencies (copies, ~12 launches, stream waits) that a 512-record batch (BamProcessor's default) cannot amortise:
+    // 65 k -> 95 k reads/s at 512 records, 186 k -> 225 k at 2 048, the same at 8 192; four contexts are no better (profiles/r04_batch_binding.md).
+    // NP_BATCH_CONTEXTS=1 keeps it to one (half the device scratch).
+    const char* dev = getenv("NP_DEVICE"); const int device = dev ? atoi(dev) : 0;
+    const char* nc = getenv("NP_BATCH_CONTEXTS"); const int contexts = nc ? std::max(1, std::min(4, atoi(nc))) : 2;
+    p->open(std::vector<int>((size_t)contexts, device), true, 0);
     configure(calling_parameters, kit, fai, hdr, region_start, region_end);
 }
 
