@@ -304,8 +304,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="call-methylation", choices=["call-methylation", "eventalign", "variants", "cpu-t1"])
-    ap.add_argument("--pool", type=int, default=20000, help="distinct synthetic reads per rank")
-    ap.add_argument("--tile", type=int, default=5, help="independent HBM copies of the pool per batch (pool x tile = 100 000 reads/step)")
+    ap.add_argument("--pool", type=int, default=-1,
+                    help="distinct synthetic reads per rank (-1: 20 000 at --gpus 1 -- BASELINE.json configs[1], 100 000 reads per step -- and "
+                         "50 000 at --gpus N > 1 -- configs[4], 250 000 reads per rank per step, 2 M over 8 GPUs)")
+    ap.add_argument("--tile", type=int, default=5, help="independent HBM copies of the pool per batch (pool x tile reads per rank and step)")
     ap.add_argument("--read-len", type=int, default=5450, help="bases per read (5450 -> ~8k events)")
     ap.add_argument("--calibrate", type=int, default=1,
                     help="1: recalibrate each read on the device between the two kernels, as load_from_raw does (SURVEY 8 f1); "
@@ -314,7 +316,9 @@ def main():
                     help="1: a step starts from raw current samples (scrappie event detection + MoM scalings on the device, "
                          "SURVEY 8 f2); 0: from pre-detected events")
     ap.add_argument("--jobs-on-device", type=int, default=1, help="1: work items are generated on the device inside the step (SURVEY 8 f3)")
-    ap.add_argument("--streamed", type=int, default=1, help="1: also time the host-fed (pinned, double-buffered) variant")
+    ap.add_argument("--streamed", type=int, default=-1,
+                    help="1: also time the host-fed (pinned, double-buffered) variant (-1: on at --gpus 1; off at N > 1, where every rank "
+                         "would pin 12 GB of host memory for its 250 000 reads)")
     ap.add_argument("--ragged", type=int, default=1, help="1: also time a batch with log-normal read lengths of the same mean")
     ap.add_argument("--ragged-pool", type=int, default=-1, help="distinct reads of the ragged batch (-1: pool / 2, tile x 2)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="cap on the reads of the CPU baseline (-1: 32 per thread, 0: skip)")
@@ -334,10 +338,14 @@ def main():
         return
     if extra:
         ap.error("unknown arguments: %s" % " ".join(extra))
+    if args.pool < 0:
+        args.pool = 20000 if args.gpus == 1 else 50000
+    if args.streamed < 0:
+        args.streamed = 1 if args.gpus == 1 else 0
     models = load_models()
     if args.workload == "cpu-t1":
         # BASELINE.json configs[0]: the CPU plumbing line (-t 1), the reference's own code on one host thread, no GPU
-        n = min(args.pool, 1000) if args.pool != 20000 else 1000
+        n = min(args.pool, 1000)
         n = args.cpu_sample if args.cpu_sample > 0 else n
         hb = prep_host_batch(models, 0, n, args.read_len, False, 1)
         cb = cpu_pass(models, hb, list(range(n)), [1], bool(args.calibrate), False, repeats=1)
@@ -407,9 +415,6 @@ def main():
     from nanopolish_amd.sites import site_table_dev
 
     ctx = Context(local)
-    # NP_CM_ASYNC=1: work items built on the context's side stream, beside the event aligner.  Measured on one box (gpurun r03s): the step
-    # 200.5 -> 199.9 ms, but the aligner's own launch 115.8 -> 120.4 ms (the work-item kernels need the vector port too) -- off by default
-    ctx.set_option("cm_async", int(os.environ.get("NP_CM_ASYNC", "0")))
     ctx.register_model(models["nucleotide"], "nucleotide"); ctx.register_model(models["cpg"], "cpg")
     dev = "cuda:%d" % local
 
@@ -478,8 +483,7 @@ def main():
     if table is None:
         table = device_table(batch)                 # one rank: the same table, outside the timed region
     k_ms = {}
-    for name, w in (("event_align", 0), ("hmm_score", 1), ("glue_and_work_items", 2), ("event_detect", 4), ("mom_scalings", 5),
-                    ("work_items_beside_the_aligner", 8)):
+    for name, w in (("event_align", 0), ("hmm_score", 1), ("glue_and_work_items", 2), ("event_detect", 4), ("mom_scalings", 5)):
         k_ms[name] = ctx.kernel_time(w)
 
     # ---------------- streamed: the same batch, host-fed ----------------
@@ -649,7 +653,7 @@ def main():
 
     if rank == 0:
         # dominant kernel + HBM roofline (algorithmic bytes)
-        dom = max((k for k in k_ms if k != "work_items_beside_the_aligner"), key=lambda k: k_ms[k][0])
+        dom = max(k_ms, key=lambda k: k_ms[k][0])
         a_ms, a_n = k_ms["event_align"]
         a_avg_s = a_ms / max(a_n, 1) * 1e-3
         algo = res["algo"]
@@ -671,15 +675,39 @@ def main():
                     band_cells_per_s=round(res["band_cells"] / a_avg_s / 1e9, 3) if a_avg_s > 0 else 0.0,
                     limiter="vector-instruction issue (one wave per read, ~13.5k dependent band steps; HBM traffic ~0.9 x the algorithmic bytes): see issue",
                     issue=issue, dominant_kernel_by_time=dom,
+                    roofline_issue=pmc_lookup.roofline_issue("event_align", "band", cyc_per_band, "np_event_align_kernel"),
                     kernel_ms_per_step={k: round(v[0] / max(args.steps, 1), 3) for k, v in k_ms.items()})
 
         value = world * n_reads * args.steps / dt
+        # kernel B of the same step: HBM roofline on the algorithmic bytes (4 e + 2 n + 12 n + 4 per call, from the counter
+        # passes' calls) and the vector-issue roofline it actually sits under
+        h_ms, h_n = k_ms["hmm_score"]
+        calls = 2 * res["n_groups"]
+        roof_b = None
+        if h_n and calls:
+            h_s = h_ms / h_n * 1e-3
+            fb = pmc_lookup.family("hmm_forward")
+            ab = fb.get("algo_bytes_per_call")
+            roof_b = dict(kernel="np_hmm_forward_kernel", avg_launch_family_ms=round(h_ms / h_n, 3), calls_per_launch=calls,
+                          hbm=dict(bound="hbm", achieved=round(ab * calls / h_s / 1e9, 2), peak=8000.0, unit="GB/s", frac=round(ab * calls / h_s / 1e9 / 8000.0, 5),
+                                   algo_bytes_per_call=ab, traffic=pmc_lookup.traffic("hmm_forward", "call", calls)) if ab else None,
+                          roofline_issue=pmc_lookup.roofline_issue("hmm_forward", "call", h_s * CLOCK_HZ * N_SIMD / calls, "np_hmm_forward_kernel"))
+        # the configuration this line is quoted on (BASELINE.json): one GPU = configs[1] (100 000 reads per step); N GPUs = configs[4]
+        # (250 000 reads per rank and step: "2M synthetic R9.4 reads sharded across 8 x MI355X", one all-reduce of the per-site table)
+        if world == 1 and n_reads == 100000:
+            workload_name = "call-methylation, 100k synthetic R9.4 reads (~8k events each), r9.4_450bps CpG model (BASELINE.json configs[1])"
+        elif world > 1 and n_reads == 250000:
+            workload_name = ("call-methylation, %s synthetic R9.4 reads sharded across %dxMI355X (250 000 per rank and step), RCCL reduction of the "
+                             "per-site table (BASELINE.json configs[4]%s)" % ("2M" if world == 8 else "%dk" % (world * 250), world,
+                                                                              "" if world == 8 else ": its per-GPU shape on %d GPUs" % world))
+        else:
+            workload_name = ("call-methylation, %d synthetic R9.4 reads per rank and step on %d GPU(s), r9.4_450bps CpG model (a non-default --pool / --tile: "
+                             "neither BASELINE.json configs[1] nor configs[4])" % (n_reads, world))
         out = dict(metric="call-methylation reads/sec", value=round(value, 2), unit="reads/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload="call-methylation, 100k synthetic R9.4 reads (~8k events each), r9.4_450bps CpG model "
-                                        "(BASELINE.json configs[1])",
-                               reads_per_step_per_gpu=n_reads, distinct_reads_per_gpu=args.pool, tile=args.tile,
+                   config=dict(workload=workload_name,
+                               reads_per_step_per_gpu=n_reads, reads_total=world * n_reads, distinct_reads_per_gpu=args.pool, tile=args.tile,
                                read_len=args.read_len, mean_events=round(mean_events, 1), jobs_on_device=bool(args.jobs_on_device),
                                groups_per_step_per_gpu=res["n_groups"], reads_aligned_ok=res["n_ok"],
                                calibrate_on_device=bool(args.calibrate), from_raw_signal=bool(args.from_raw),
@@ -687,7 +715,7 @@ def main():
                    cpg_site_groups_per_s=round(world * res["n_groups"] * args.steps / dt, 1),
                    value_streamed=streamed["value"] if streamed else None, streamed=streamed,
                    value_ragged=ragged["value"] if ragged else None, ragged=ragged,
-                   max_abs_dLLR_vs_cpu=max_dllr, roofline=roof, cpu_baseline=cpu, host_prep_s=round(t_prep, 1))
+                   max_abs_dLLR_vs_cpu=max_dllr, roofline=roof, roofline_hmm_forward=roof_b, cpu_baseline=cpu, host_prep_s=round(t_prep, 1))
         out["per_rank"] = per_rank
         if shard_check:
             out["shard_check"] = shard_check

@@ -73,21 +73,16 @@ const char* np_ctx_info(const np_ctx* ctx);
 
 /* Tuning / test knobs (defaults are what bench.py measures): "align_blocks_per_cu", "hmm_blocks_per_cu" (persistent grid
  * sizes), "align_lpt" (1: the event aligner takes the batch's reads longest first; 0: in index order),
- * "cm_async" (1: np_cm_build_jobs_*_dev launch their kernels on a side stream of the context, ordered after what the caller's stream
- * holds at the time of the call; np_event_align*_dev / np_detect_events_dev / np_mom_fill_dev / np_adc_to_pa_dev that follow run BESIDE
- * them -- work items do not depend on the alignment -- and the first other entry point, or np_sync, waits for them.  A caller's OWN
- * kernels on its stream do not: leave it 0 unless the library's entry points are the only consumers of the work items),
  * "stream_switch_wait" (1: a call on another stream than the context's previous call waits for that stream's tail; 0: the caller orders
  * the streams it uses with one context by its own events), "ed_warmup" (samples each segment of the parallel peak walk starts early; 0 forces every segment through the
  * repair path -- results never depend on it), "ea_rows_cap" (events per eventalign segment the chain kernel's scratch holds;
  * a longer segment ends its read with NP_EA_OVERFLOW), "ea_waves_per_cu" (persistent grid of the chain kernel), "lse_oor" (0: the forward kernel clamps its log-sum table index;
- * 1: it relies on the LDS out-of-range rule, the default when np_create's probe passes -- scores never depend on it),
- * "hmm_kernel" (forward kernel of the four smallest size classes: 1 = a lane's k-mer blocks one after the other, the default; 2 = the
- * log-sums of a step issued stage by stage across the blocks, round 4's experiment -- scores never depend on it). */
+ * 1: it relies on the LDS out-of-range rule, the default when np_create's probe passes and refused (NP_ERR_UNSUPPORTED) when it did not --
+ * scores never depend on it). */
 int np_set_option(np_ctx* ctx, const char* name, int64_t value);
 /* Read-only facts about the context (-1: unknown name): "align_blocks" / "align_scratch_bytes" (persistent grid and per-wave scratch
  * of the most recent event-align launch: the grid shrinks under a 48 GB scratch budget when a batch holds ultra-long reads),
- * "align_blocks_max", "lse_oor" (1: the clamp-free log-sum lookup is in use, see np_ctx_info), "n_cu", "ed_serial_reads" / "ed_refused_reads" (most recent event-detection
+ * "align_blocks_max", "lse_oor" (1: the clamp-free log-sum lookup is in use, see np_ctx_info), "lse_probe_ok" (1: np_create's probe found the LDS rule to hold), "n_cu", "ed_serial_reads" / "ed_refused_reads" (most recent event-detection
  * call: reads that took the serial prefix-sum path, reads refused with NP_ED_INEXACT; waits for the call), "ea_lattice_cells" /
  * "ea_lattice_rows" / "ea_lattice_kmers" (sum over the segments of the most recent np_eventalign_dev call of the reference's
  * lattice size (e + 1) x 3 (n + 2), of e and of n; waits for the call), "ea_cycles_geometry" / "ea_cycles_fill" /
@@ -241,18 +236,6 @@ typedef struct np_hmm_job_dev {
 int np_event_align_dev(np_ctx* ctx, void* stream, int n_reads, const np_read_dev* reads,
                        const float* event_mean, const uint16_t* kmer_rank, int model, int64_t max_bands,
                        const int64_t* pair_off, np_pair* pairs_out, int32_t* pair_begin, int32_t* n_pairs);
-
-/* The same alignment as two launches (round 3): phase 1 = the banded fill, phase 2 = the back-track + QC, 3 = both in this call.
- * Between the two the packed trace of EVERY read of the batch stays in HBM (32 B per pair slot: total_pairs >= pair_off[n_reads] of
- * them, 43 GB for 100 000 reads of 8 000 events -- the context keeps the buffer and only grows it), where np_event_align_dev keeps
- * one trace per resident wave.  What it buys: the fill is bound by vector-instruction issue, the back-track is a dependent scalar
- * chain that occupies a wave slot and little else; as its own launch it can run on ANOTHER stream beside the scoring kernels of the
- * previous batch (pass different streams and order them with np_event_record / np_stream_wait_event; phase 2 must follow phase 1 of
- * the same batch, and the next phase 1 must follow it).  Results are identical to np_event_align_dev's.
- * Kernel time of phase 2 is family 7 of np_kernel_time. */
-int np_event_align_split_dev(np_ctx* ctx, void* stream, int phase, int n_reads, const np_read_dev* reads,
-                             const float* event_mean, const uint16_t* kmer_rank, int model, int64_t max_bands, int64_t total_pairs,
-                             const int64_t* pair_off, np_pair* pairs_out, int32_t* pair_begin, int32_t* n_pairs);
 
 /* Forward scores of a batch of HMM work items (kernel B).
  *   order (host pointer, may be NULL): nothing to provide; the library bins jobs by size on the device. */
@@ -483,9 +466,8 @@ int np_sync(np_ctx* ctx, void* stream);
 
 /* Time (ms) spent in the most recent launch of each kernel family on the device, measured with HIP events
  * on the launching stream.  which: 0 = event align, 1 = hmm score, 2 = resolve / calibrate / work items, 3 = hmm viterbi,
- * 4 = event detection, 5 = MoM scalings, 6 = eventalign chain, 7 = the event aligner's back-track as its own launch
- * (np_event_align_split_dev phase 2; then family 0 is the fill alone), 8 = work items built on the side stream (option "cm_async":
- * the interval overlaps the event aligner's; without the option they are part of family 2). */
+ * 4 = event detection, 5 = MoM scalings, 6 = eventalign chain (7 and 8 are unused: they belonged to round 3's split-aligner and
+ * side-stream experiments, removed in round 5; their write-ups are profiles/r03_kernel_a_split.md and profiles/r03_experiments_tail.md). */
 int np_last_kernel_ms(np_ctx* ctx, int which, float* ms);
 /* Accumulated device time (ms) and launch count of a kernel family since the last reset (call after np_sync). */
 int np_kernel_time(np_ctx* ctx, int which, double* total_ms, int64_t* launches, int reset);

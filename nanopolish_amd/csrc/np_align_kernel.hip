@@ -443,19 +443,14 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
     }
 }
 
-// MODE 0: fill and back-track of a read by the same wave (trace scratch per resident wave).  MODE 1 / MODE 2: the two halves as
-// separate launches (round 3) -- the fill keeps the packed trace of EVERY read of the batch (a.trace_all, 32 B per band: 43 GB for
-// 100 000 reads of 13.5k bands, what 288 GB of HBM are for) and each read's end cell (a.fill_state); the back-track kernel, a
-// dependent scalar chain that needs a wave slot and few issue slots, then runs wherever the caller's stream puts it -- beside the
-// scoring kernels of another batch instead of inside the issue-bound fill.
-template <int MODE>
+// fill and back-track of a read by the same wave (trace scratch per resident wave)
 __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_kernel(np_align_args a)
 {
     const int lane = threadIdx.x & 63;
     // readfirstlane: tells the compiler the value is wave-uniform, so pointers derived from it stay in SGPRs (buffer
     // descriptors must be scalar; a VGPR descriptor costs a waterfall loop per load)
     const int wave_slot = __builtin_amdgcn_readfirstlane(blockIdx.x * (NP_ALIGN_BLOCK / 64) + (threadIdx.x >> 6));
-    uint64_t* __restrict__ trace = MODE == 0 ? a.trace + (size_t)wave_slot * a.trace_stride : nullptr;
+    uint64_t* __restrict__ trace = a.trace + (size_t)wave_slot * a.trace_stride;
     float4* __restrict__ kp = a.kparams + (size_t)wave_slot * a.kp_stride;     // per-wave slab of scaled k-mer parameters
 
     for (;;) {
@@ -478,10 +473,7 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
         np_pair* __restrict__ pairs = a.pairs + pbase;
 
         const int n_rows = (n_bands + 7) >> 3;
-        // kept trace: read ri's rows start at row (pair_off[ri] >> 3) + ri -- successive starts are at least (cap >> 3) + 1 >= n_rows apart
-        if (MODE != 0) trace = a.trace_all + (size_t)((pbase >> 3) + ri) * 32;
-        const bool ok = !(E <= 0 || K <= 0 || (MODE == 0 && (uint64_t)n_rows * 32 > a.trace_stride) || (uint64_t)K > a.kp_stride || cap < E + K + 2 ||
-                          (MODE != 0 && (uint64_t)(pbase >> 3) + (uint64_t)ri + (uint64_t)n_rows > a.trace_all_rows));
+        const bool ok = !(E <= 0 || K <= 0 || (uint64_t)n_rows * 32 > a.trace_stride || (uint64_t)K > a.kp_stride || cap < E + K + 2);
         int n_out = 0, max_gap = 0, last_k = -1;
         double sum_emission = 0.0;
         float best_u = NP_NEG_INF;
@@ -504,7 +496,7 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_s_waitcnt(0);
 
-            if (MODE != 2) {
+            {
                 // ---------------- fill ----------------
                 read_t R;
                 R.E = E; R.K = K; R.lane = lane; R.lane4 = lane >> 2; R.end_slot = (K - 1) & (NP_RING - 1); R.nonpos = nonpos;
@@ -559,9 +551,6 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
                 if ((n_bands & 7) != 0) __builtin_amdgcn_raw_buffer_store_b32((int)(F.tacc << (4 * (8 - (n_bands & 7)))), R.tr, 4 * lane, ((n_bands - 1) >> 3) * 256, 0);   // last, partial group
 
                 best_u = F.best; curr_e = F.best_e;
-            } else {
-                best_u = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(a.fill_state[2 * ri]));
-                curr_e = __builtin_amdgcn_readfirstlane(a.fill_state[2 * ri + 1]);
             }
 
             // ---------------- backtrack (:326-361) + QC sums (:338-341) ----------------
@@ -571,15 +560,10 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_s_waitcnt(0);
 
-            if (MODE != 1 && best_u != NP_NEG_INF && !(NP_ABL & 128)) {
+            if (best_u != NP_NEG_INF && !(NP_ABL & 128)) {
 #if NP_A_WALK_PRIO
-                if (MODE == 0) __builtin_amdgcn_s_setprio(NP_A_WALK_PRIO);
+                __builtin_amdgcn_s_setprio(NP_A_WALK_PRIO);
 #endif
-                if (MODE == 2) {            // on its own the walk competes with whatever the caller runs beside it: the caller's choice
-                    if (a.bt_prio >= 3) __builtin_amdgcn_s_setprio(3);
-                    else if (a.bt_prio == 2) __builtin_amdgcn_s_setprio(2);
-                    else if (a.bt_prio == 1) __builtin_amdgcn_s_setprio(1);
-                }
                 // Scalar walk.  The kernel is instruction-issue bound (~2.3 cycles per wave-instruction of any kind, measured
                 // with tools/align_variants.sh probes), and a walk of ~0.63 steps per band was a fifth of its instructions, so
                 // the step is written out by hand: 14 instructions since round 3 (12 scalar + v_readlane + v_writelane; 21 before).
@@ -721,12 +705,7 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
                 __builtin_amdgcn_s_setprio(0);
             }
         }
-        if (MODE == 1) {
-            // the read's end cell for the back-track launch (two lanes, two words; a read that was refused leaves -inf)
-            int32_t* dst = a.fill_state + 2 * ri + lane;
-            const int32_t val = lane == 0 ? __builtin_bit_cast(int32_t, best_u) : curr_e;
-            if (lane < 2) *dst = val;
-        } else {
+        {
             // QC (:365-372); out.back() is always k-mer K-1, so `spanned` reduces to "the walk ended on k-mer 0"
             bool failed = true;
             if (n_out > 0) {
@@ -817,11 +796,8 @@ hipError_t np_launch_align_order(int n_reads, const np_read_dev* reads, uint32_t
     return hipGetLastError();
 }
 
-// mode 0: fill + back-track; 1: fill only (a.trace_all, a.fill_state written); 2: back-track only (a.trace_all, a.fill_state read)
-hipError_t np_launch_event_align(const np_align_args& a, int n_blocks, int mode, hipStream_t s)
+hipError_t np_launch_event_align(const np_align_args& a, int n_blocks, hipStream_t s)
 {
-    if (mode == 0) hipLaunchKernelGGL(np_event_align_kernel<0>, dim3(n_blocks), dim3(NP_ALIGN_BLOCK), 0, s, a);
-    else if (mode == 1) hipLaunchKernelGGL(np_event_align_kernel<1>, dim3(n_blocks), dim3(NP_ALIGN_BLOCK), 0, s, a);
-    else hipLaunchKernelGGL(np_event_align_kernel<2>, dim3(n_blocks), dim3(NP_ALIGN_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(np_event_align_kernel, dim3(n_blocks), dim3(NP_ALIGN_BLOCK), 0, s, a);
     return hipGetLastError();
 }

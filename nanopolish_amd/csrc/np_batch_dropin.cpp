@@ -155,7 +155,8 @@ struct NpBatchPipeline::Impl {
     // arena's lock -- sixteen workers freeing each other's blocks while sixteen build the next batch spent 147 ms on a batch whose
     // maps take 9 ms to build).  collect() and recycle() are the caller's: one thread.
     std::map<const bam1_t*, int> builder_of;
-    Impl() : fai(NULL), hdr(NULL), region_start(-1), region_end(-1), pool(NULL), n_submitted(0), n_packed(0), n_claimed(0), n_finished(0), n_collected(0), stop(false) { for (int i = 0; i < 8; ++i) t[i] = 0.0; }
+    bool track_builders;          // false: the synchronous pipeline (nobody recycles: nothing to remember)
+    Impl() : fai(NULL), hdr(NULL), region_start(-1), region_end(-1), pool(NULL), n_submitted(0), n_packed(0), n_claimed(0), n_finished(0), n_collected(0), stop(false) { track_builders = true; for (int i = 0; i < 8; ++i) t[i] = 0.0; }
     void add_time(int i, double s) { std::lock_guard<std::mutex> g(tm); t[i] += s; }
     void open(const std::vector<int>& devices, bool shared_default, int host_threads);
     void pack(Slot& S);
@@ -205,6 +206,15 @@ NpBatchPipeline::NpBatchPipeline(const MethylationCallingParameters& calling_par
     const char* dev = getenv("NP_DEVICE"); const int device = dev ? atoi(dev) : 0;
     const char* nc = getenv("NP_BATCH_CONTEXTS"); const int contexts = nc ? std::max(1, std::min(4, atoi(nc))) : 2;
     p->open(std::vector<int>((size_t)contexts, device), true, 0);
+    configure(calling_parameters, kit, fai, hdr, region_start, region_end);
+}
+
+NpBatchPipeline::NpBatchPipeline(synchronous_t, const MethylationCallingParameters& calling_parameters, const std::string& kit, const faidx_t* fai,
+                                 const bam_hdr_t* hdr, int region_start, int region_end) : p(new Impl())
+{
+    const char* dev = getenv("NP_DEVICE"); const int device = dev ? atoi(dev) : 0;
+    p->track_builders = false;
+    p->open(std::vector<int>(1, device), true, 0);
     configure(calling_parameters, kit, fai, hdr, region_start, region_end);
 }
 
@@ -556,7 +566,7 @@ void NpBatchPipeline::Impl::finish(Slot& S)
     const uint32_t k = 6;
     pool->run(n, 8, [&](int i) {
         const bam1_t* record = reads[i].record;
-        S.builder[i] = Pool::current_worker();
+        S.builder[i] = pool->current_worker();
         if (S.status[i] == NP_BATCH_HOST_PATH) return;                    // decided in phase 1: the caller's per-record function fills its map
         std::map<int, ScoredSite>& site_score_map = S.built[i];
         const int q = S.dev_index[i];
@@ -625,7 +635,7 @@ bool NpBatchPipeline::collect(MethylationCallingResult& result)
         reads[i].status = S.status[i];
         if (S.status[i] == NP_BATCH_HOST_PATH) continue;                 // the caller's per-record function fills (and creates) its map
         result[S.rec[i].record].swap(S.built[i]);                         // the (possibly empty) map of the record, basemods.cpp:253-256
-        p->builder_of[S.rec[i].record] = S.builder[i];
+        if (p->track_builders) p->builder_of[S.rec[i].record] = S.builder[i];
     }
     S.built.clear();
     { std::lock_guard<std::mutex> g(p->m); S.finished = false; p->n_collected += 1; }
@@ -639,10 +649,11 @@ void NpBatchPipeline::recycle(MethylationCallingResult& result)
     const int W = p->pool->threads();
     std::vector<std::shared_ptr<Maps> > mine(W + 1);
     for (MethylationCallingResult::iterator it = result.begin(); it != result.end(); ++it) {
-        if (it->second.empty()) continue;
+        // (the entry goes whether or not the map is empty: a stale one would route a later host-path map of a reused bam1_t* to the wrong worker)
         std::map<const bam1_t*, int>::iterator b = p->builder_of.find(it->first);
         const int w = b != p->builder_of.end() && b->second >= 0 && b->second < W ? b->second : W;       // W: built elsewhere (the caller's host path)
         if (b != p->builder_of.end()) p->builder_of.erase(b);
+        if (it->second.empty()) continue;
         if (!mine[w]) mine[w] = std::make_shared<Maps>();
         mine[w]->push_back(std::map<int, ScoredSite>());
         mine[w]->back().swap(it->second);
@@ -663,7 +674,7 @@ void np_calculate_methylation_for_batch(MethylationCallingResult& result, std::v
     static std::mutex lock;
     static NpBatchPipeline* pipe = NULL;
     std::lock_guard<std::mutex> g(lock);
-    if (!pipe) pipe = new NpBatchPipeline(params, kit, fai, hdr, region_start, region_end);
+    if (!pipe) pipe = new NpBatchPipeline(NpBatchPipeline::synchronous_t(), params, kit, fai, hdr, region_start, region_end);
     else pipe->configure(params, kit, fai, hdr, region_start, region_end);
     pipe->submit(reads);
     pipe->collect(result);

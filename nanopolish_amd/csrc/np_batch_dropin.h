@@ -79,6 +79,11 @@ public:
     // finished batch (the caller's thread), [7] submit() (the caller's thread)
     void host_seconds(double out[8]) const;
     struct Impl;
+    // the pipeline behind np_calculate_methylation_for_batch: one batch in flight at a time, so ONE context (the process-wide one) and no
+    // bookkeeping of which worker built which map (the caller of the synchronous form never recycles)
+    struct synchronous_t {};
+    NpBatchPipeline(synchronous_t, const MethylationCallingParameters& calling_parameters, const std::string& kit, const faidx_t* fai,
+                    const bam_hdr_t* hdr, int region_start, int region_end);
 private:
     Impl* p;
     NpBatchPipeline(const NpBatchPipeline&);

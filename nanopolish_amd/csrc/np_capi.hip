@@ -15,9 +15,9 @@
 
 #define NP_VERSION_STR "nanopolish_amd 0.1 (gfx950)"
 #define NP_FLANK_LEN NP_MAX_WINDOW_EVENTS
-#define NP_NUM_FAMILIES 9      // 0 event align, 1 forward HMM, 2 glue, 3 Viterbi, 4 event detection, 5 MoM scalings, 6 eventalign chain,
-                               // 7 the event aligner's back-track when launched on its own (np_event_align_split_dev), 8 work items built on the side
-                               // stream (cm_async: the interval runs beside the event aligner; in order, they are part of family 2)
+#define NP_NUM_FAMILIES 9      // 0 event align, 1 forward HMM, 2 glue, 3 Viterbi, 4 event detection, 5 MoM scalings, 6 eventalign chain
+                               // (7 and 8 belonged to round 3's split-aligner / side-stream experiments: kept as empty slots so that np_kernel_time's
+                               // family numbers do not move)
 
 namespace {
 
@@ -64,6 +64,7 @@ struct np_ctx {
     bool tail_recorded = false;          // switch_ev marks the tail of the most recent call's work
     hipEvent_t switch_ev = nullptr;
     bool lse_oor = true;                 // forward kernel: clamp-free log-sum lookups (cleared when probe_hardware fails)
+    bool lse_probe_ok = false;           // probe_hardware found the LDS out-of-range rule to hold: only then may option "lse_oor" select the clamp-free kernel
     std::string info;                    // np_ctx_info(): the probe's findings
     std::vector<model_t> models;
     float* d_logsum = nullptr;
@@ -71,14 +72,8 @@ struct np_ctx {
     float* d_flank = nullptr;
     uint32_t* d_counters = nullptr;   // [0..7] class counts, [8..15] work-queue heads, [16] align queue head, [17] chain queue head, [18] back-track queue head, [32] self-test, [1024 .. 1024 + 2 * 4096) work-item bins (np_launch_classify)
     dev_buf order, trace, kparams, align_order;
-    dev_buf gslab;                    // staged forward kernel: the resident waves' scaled Gaussians (8 KB per wave)
     void* small_h = nullptr; size_t small_h_cap = 0; dev_buf small_d;     // np_hmm_score_host's small-batch path: one pinned blob, its device twin
-    int split_n_reads = -1; int64_t split_total_pairs = 0; const int64_t* split_pair_off = nullptr;   // the batch np_event_align_split_dev's fill phase last ran for
     int small_batch_path = 1;         // np_hmm_score_host: batches of <= NP_SMALL_BATCH items as one pinned blob (0: the general path; tests compare the two)
-    int hmm_kernel = 1;               // forward kernel: 1 = block-major step (the default), 2 = stage-major step (np_hmm_forward2_kernel, round 4's
-                                      // experiment: six look-ups in flight per wave, same scores, measured 13 % slower -- np_hmm_kernels.hip;
-                                      // the clamp-free log-sum only: a context whose probe failed scores with kernel 1)
-    dev_buf trace_all, fill_state, kparams_bt, align_order_bt;    // np_event_align_split_dev: every read's trace and end cell; the back-track launch's own slab and order
     // host-API staging
     dev_buf b_jobs, b_reads, b_events, b_ranks, b_out, b_pair_off, b_pairs, b_pair_begin, b_n_pairs,
             b_vm, b_bp, b_cell_off, b_state_off, b_states, b_n_states;
@@ -92,13 +87,7 @@ struct np_ctx {
     std::mutex lock;
     std::string err;
     int align_blocks_per_cu = 8, hmm_blocks_per_cu = 2;
-    // work items built beside the event aligner (option "cm_async"): np_cm_build_jobs_*_dev launch on the context's side stream, forked
-    // from the caller's stream and joined by the next entry point that is not one of the aligner-side calls (np_event_align*_dev,
-    // np_detect_events_dev, np_mom_fill_dev, np_adc_to_pa_dev), or by np_sync
-    hipStream_t side = nullptr; hipEvent_t side_fork = nullptr, side_join = nullptr;
-    bool cm_async = false, side_pending = false;
-    int align_bt_prio = 3, hmm_prio = 0;   // wave priorities of the back-track launch and of the forward kernels (co-scheduling experiments)
-    int align_bt_blocks_per_cu = 8;   // the back-track launch of np_event_align_split_dev (256-thread workgroups per CU)
+    int hmm_prio = 0;                 // wave priority of the forward kernels
     int align_lpt = 1;                // issue the event aligner's reads longest first
     int stream_switch_wait = 1;       // a call on a new stream waits for the tail of the stream the context used before (0: the caller orders its streams itself)
     int ed_warmup = -1;               // parallel peak walk: samples of warm-up per segment (< 0: the kernel's default)
@@ -163,35 +152,12 @@ struct stream_scope {
     operator hipStream_t() const { return s; }
     ~stream_scope() { c->tail_recorded = c->switch_ev && hipEventRecord(c->switch_ev, s) == hipSuccess; }
 };
-stream_scope use_stream(np_ctx* c, void* s, bool join_side = true)
+stream_scope use_stream(np_ctx* c, void* s)
 {
     hipStream_t st = pick_stream(c, s);
-    if (join_side && c->side_pending) { (void)hipStreamWaitEvent(st, c->side_join, 0); c->side_pending = false; }
     if (c->stream_switch_wait && c->tail_recorded && st != c->last_stream) (void)hipStreamWaitEvent(st, c->switch_ev, 0);
     c->last_stream = st;
     return stream_scope(c, st);
-}
-
-// the stream the work-item builders launch on: the caller's, or (cm_async) the side stream, ordered after what the caller's stream holds
-hipStream_t fork_side(np_ctx* c, hipStream_t s)
-{
-    if (!c->cm_async) return s;
-    if (!c->side) {
-        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->side = nullptr; (void)hipGetLastError(); return s; }
-        if (hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->side_join, hipEventDisableTiming) != hipSuccess) {
-            (void)hipStreamDestroy(c->side); c->side = nullptr; (void)hipGetLastError(); return s;
-        }
-    }
-    if (c->side_pending) { (void)hipStreamWaitEvent(s, c->side_join, 0); c->side_pending = false; }   // (a second build before any consumer)
-    (void)hipEventRecord(c->side_fork, s);
-    (void)hipStreamWaitEvent(c->side, c->side_fork, 0);
-    return c->side;
-}
-void join_side_later(np_ctx* c, hipStream_t launched_on, hipStream_t s)
-{
-    if (launched_on == s) return;
-    c->side_pending = hipEventRecord(c->side_join, launched_on) == hipSuccess;
-    if (!c->side_pending) (void)hipStreamSynchronize(launched_on);
 }
 
 int persistent_blocks(np_ctx* c, int64_t work_items, int per_block, int blocks_per_cu)
@@ -222,78 +188,50 @@ int run_hmm_forward(np_ctx* c, hipStream_t s, int64_t n_jobs, const np_hmm_job_d
         a.jobs = jobs; a.order = c->order.as<uint32_t>() + (size_t)cls * (size_t)n_jobs; a.n_class_jobs = c->d_counters + cls;
         a.reads = reads; a.event_mean = event_mean; a.ranks = ranks; a.model = c->models[model].d_states;
         a.logsum = c->d_logsum; a.flank = c->d_flank; a.counter = c->d_counters + 8 + cls; a.out = out; a.prio = c->hmm_prio;
-        const bool staged = c->hmm_kernel == 2 && c->lse_oor && np_hmm_forward2_has(cls);
-        const int threads = staged ? np_hmm_forward2_block_threads() : np_hmm_block_threads(cls);
+        const int threads = np_hmm_block_threads(cls);
         const int jobs_per_block = (threads / 64) * (64 / NP_CLASS_SEG[cls]);
         const int nb = persistent_blocks(c, n_jobs, jobs_per_block, c->hmm_blocks_per_cu);
-        if (staged) {
-            NP_HIP(c, c->gslab.reserve((size_t)c->n_cu * c->hmm_blocks_per_cu * (threads / 64) * 8 * 64 * sizeof(float4)));
-            a.gslab = c->gslab.as<float4>();
-            NP_HIP(c, np_launch_hmm_forward2(cls, a, nb, s));
-        } else
-            NP_HIP(c, np_launch_hmm_forward(cls, a, nb, c->lse_oor, s));
+        NP_HIP(c, np_launch_hmm_forward(cls, a, nb, c->lse_oor, s));
     }
     return NP_OK;
 }
 
-// phase 0: fill and back-track of a read in one kernel (trace scratch per resident wave).  phase 1 / 2: the fill / the back-track as
-// launches of their own, the packed trace of every read kept in between (total_pairs >= pair_off[n_reads]: 32 B per pair slot).
+// fill and back-track of a read in one kernel (trace scratch per resident wave)
 int run_event_align(np_ctx* c, hipStream_t s, int n_reads, const np_read_dev* reads, const float* event_mean,
                     const uint16_t* ranks, int model, int64_t max_bands, const int64_t* pair_off, np_pair* pairs,
-                    int32_t* pair_begin, int32_t* n_pairs, int phase = 0, int64_t total_pairs = 0)
+                    int32_t* pair_begin, int32_t* n_pairs)
 {
     if (n_reads <= 0) return NP_OK;
     if (model < 0 || model >= (int)c->models.size()) { c->err = "bad model id"; return NP_ERR_INVALID; }
     const int waves_per_block = np_align_block_threads() / 64;
-    int nb = persistent_blocks(c, n_reads, waves_per_block, phase == 2 ? c->align_bt_blocks_per_cu : c->align_blocks_per_cu);
+    int nb = persistent_blocks(c, n_reads, waves_per_block, c->align_blocks_per_cu);
     // per-resident-wave scratch: packed trace (32 B per band) and the k-mer parameter slab (16 B per k-mer).
     // Ultra-long reads make the slabs large, so the persistent grid shrinks to keep the scratch under a budget
     // (a 1M-event read needs ~56 MB per wave: 48 GB would hold ~850 resident waves instead of 5120).
-    const uint64_t stride = phase == 0 ? (((uint64_t)max_bands + 7) / 8) * 32 : 0;        // u64 units: one 256-byte row per 8 bands
+    const uint64_t stride = (((uint64_t)max_bands + 7) / 8) * 32;        // u64 units: one 256-byte row per 8 bands
     const uint64_t kp_stride = ((uint64_t)max_bands + 63) & ~63ull;      // k-mers per read < bands per read
     const uint64_t per_block = (uint64_t)waves_per_block * (stride * sizeof(uint64_t) + kp_stride * sizeof(float4));
     const uint64_t budget = 48ull << 30;
     if ((uint64_t)nb * per_block > budget) nb = (int)std::max<uint64_t>(1, budget / per_block);
     c->last_align_blocks = nb; c->last_align_scratch = (int64_t)((uint64_t)nb * per_block);
-    if (phase == 0) NP_HIP(c, c->trace.reserve((size_t)nb * waves_per_block * stride * sizeof(uint64_t)));
-    else {
-        // every read's trace: read r starts at row (pair_off[r] >> 3) + r of 256 bytes
-        const size_t all = ((size_t)(total_pairs >> 3) + (size_t)n_reads + 1) * 256;
-        c->last_align_scratch += (int64_t)all;
-        // the back-track walks what the fill of the SAME batch left: same read count, same pair slots, same offsets array (a stale trace
-        // of an earlier, larger batch would pass a capacity check and be walked without complaint)
-        if (phase == 1) { c->split_n_reads = n_reads; c->split_total_pairs = total_pairs; c->split_pair_off = pair_off; }
-        else if (c->split_n_reads != n_reads || c->split_total_pairs != total_pairs || c->split_pair_off != pair_off ||
-                 c->trace_all.cap < all || c->fill_state.cap < (size_t)n_reads * 8) {
-            c->err = "np_event_align_split_dev: back-track phase without the fill phase of the same batch (read count, pair slots and offsets must match)";
-            return NP_ERR_INVALID;
-        }
-        if (phase == 2) c->split_n_reads = -1;                     // a fill's trace is walked once
-        NP_HIP(c, c->trace_all.reserve(all));
-        NP_HIP(c, c->fill_state.reserve((size_t)n_reads * 8));
-    }
-    // the fill and the back-track of a split call use separate slabs, queues and orders: the back-track of one batch may run beside
-    // the fill of the next one (another stream)
-    dev_buf& kparams = phase == 2 ? c->kparams_bt : c->kparams;
-    dev_buf& align_order = phase == 2 ? c->align_order_bt : c->align_order;
-    uint32_t* counter = c->d_counters + (phase == 2 ? 18 : 16);
-    NP_HIP(c, kparams.reserve((size_t)nb * waves_per_block * kp_stride * sizeof(float4)));
-    NP_HIP(c, align_order.reserve((size_t)(2048 + n_reads) * sizeof(uint32_t)));
+    NP_HIP(c, c->trace.reserve((size_t)nb * waves_per_block * stride * sizeof(uint64_t)));
+    uint32_t* counter = c->d_counters + 16;
+    NP_HIP(c, c->kparams.reserve((size_t)nb * waves_per_block * kp_stride * sizeof(float4)));
+    NP_HIP(c, c->align_order.reserve((size_t)(2048 + n_reads) * sizeof(uint32_t)));
     NP_HIP(c, hipMemsetAsync(counter, 0, sizeof(uint32_t), s));
     np_align_args a{};
     a.reads = reads; a.event_mean = event_mean; a.ranks = ranks; a.model = c->models[model].d_states;
     a.pair_off = pair_off; a.pairs = pairs; a.pair_begin = pair_begin; a.n_pairs = n_pairs;
-    a.trace = c->trace.as<uint64_t>(); a.trace_stride = stride; a.kparams = kparams.as<float4>(); a.kp_stride = kp_stride;
-    a.trace_all = c->trace_all.as<uint64_t>(); a.trace_all_rows = phase == 0 ? 0 : (uint64_t)(total_pairs >> 3) + (uint64_t)n_reads + 1; a.fill_state = c->fill_state.as<int32_t>(); a.bt_prio = c->align_bt_prio;
+    a.trace = c->trace.as<uint64_t>(); a.trace_stride = stride; a.kparams = c->kparams.as<float4>(); a.kp_stride = kp_stride;
     a.counter = counter;
     a.n_reads = n_reads; a.max_gap_threshold = c->params.max_gap_threshold;
     a.min_average_log_emission = c->params.min_average_log_emission;
-    family_timer tm(c, phase == 2 ? 7 : 0, s);
+    family_timer tm(c, 0, s);
     if (c->align_lpt && n_reads > nb * waves_per_block) {       // more reads than resident waves: the issue order matters
-        NP_HIP(c, np_launch_align_order(n_reads, reads, align_order.as<uint32_t>(), s));
-        a.order = align_order.as<uint32_t>() + 2048;
+        NP_HIP(c, np_launch_align_order(n_reads, reads, c->align_order.as<uint32_t>(), s));
+        a.order = c->align_order.as<uint32_t>() + 2048;
     }
-    NP_HIP(c, np_launch_event_align(a, nb, phase, s));
+    NP_HIP(c, np_launch_event_align(a, nb, s));
     return NP_OK;
 }
 
@@ -328,7 +266,6 @@ static bool probe_hardware(np_ctx* c)
     for (int cls = 0; cls < NP_NUM_CLASSES; ++cls) {
         size_t b = 0;
         if (np_hmm_forward_lds_bytes(cls, &b) != hipSuccess || b != NP_LOGSUM_TBL * sizeof(float)) lds_size_ok = false;
-        if (np_hmm_forward2_has(cls) && (np_hmm_forward2_lds_bytes(cls, &b) != hipSuccess || b != NP_LOGSUM_TBL * sizeof(float))) lds_size_ok = false;
         lds_seen = std::max(lds_seen, b);
     }
     float* d_buf = nullptr; uint16_t* d_sbuf = nullptr; uint32_t* d_out = c->d_counters + 64;     // 8 words, zeroed at np_create
@@ -353,6 +290,7 @@ static bool probe_hardware(np_ctx* c)
     const bool lds_ok = ran_all && lds_size_ok && out[0] == 0 && out[1] == 0;
     const bool buf_ok = ran_all && out[2] == 0 && store_ok;
     const char* forced = getenv("NP_LSE_CLAMP");
+    c->lse_probe_ok = lds_ok;
     c->lse_oor = lds_ok && !(forced && atoi(forced) != 0);
     snprintf(line, sizeof(line), "probe: forward-kernel LDS %zu B (%s), reads past the LDS allocation %s (%u non-zero words, %u log-sum mismatches), "
              "range-checked buffer access %s (%u bad loads, stores %s); log-sum lookup: %s",
@@ -395,7 +333,6 @@ np_ctx* np_create(int device, const np_params* params)
     // tuning knobs (persistent-grid sizes); defaults fill the CU up to the kernels' register-limited occupancy
     if (const char* v = getenv("NP_ALIGN_BLOCKS_PER_CU")) c->align_blocks_per_cu = std::max(1, atoi(v));
     if (const char* v = getenv("NP_HMM_BLOCKS_PER_CU")) c->hmm_blocks_per_cu = std::max(1, atoi(v));
-    if (const char* v = getenv("NP_HMM_KERNEL")) c->hmm_kernel = atoi(v) == 2 ? 2 : 1;
     if (const char* v = getenv("NP_ALIGN_LPT")) c->align_lpt = atoi(v) != 0;
     if (const char* v = getenv("NP_ED_WARMUP")) c->ed_warmup = atoi(v);
     if (const char* v = getenv("NP_EA_WAVES_PER_CU")) c->ea_waves_per_cu = std::max(1, atoi(v));
@@ -446,11 +383,10 @@ void np_destroy(np_ctx* c)
     if (c->d_logsum) (void)hipFree(c->d_logsum);
     if (c->d_flank) (void)hipFree(c->d_flank);
     if (c->d_counters) (void)hipFree(c->d_counters);
-    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->side_fork); (void)hipEventDestroy(c->side_join); }
-    dev_buf* bufs[] = {&c->order, &c->trace, &c->kparams, &c->trace_all, &c->fill_state, &c->kparams_bt, &c->align_order_bt, &c->b_jobs, &c->b_reads, &c->b_events, &c->b_ranks, &c->b_out, &c->b_pair_off,
+    dev_buf* bufs[] = {&c->order, &c->trace, &c->kparams, &c->b_jobs, &c->b_reads, &c->b_events, &c->b_ranks, &c->b_out, &c->b_pair_off,
                        &c->b_pairs, &c->b_pair_begin, &c->b_n_pairs, &c->b_vm, &c->b_bp, &c->b_cell_off, &c->b_state_off,
                        &c->b_states, &c->b_n_states, &c->ed_status, &c->ed_tstat, &c->b_raw, &c->b_raw_off, &c->b_ev_off, &c->b_ev_start,
-                       &c->b_ev_len, &c->b_ev_mean, &c->b_ev_stdv, &c->b_n_events, &c->cm_group_rank_off, &c->cm_cigar_scratch, &c->ea_bp, &c->ea_path, &c->ea_args, &c->align_order, &c->gslab};
+                       &c->b_ev_len, &c->b_ev_mean, &c->b_ev_stdv, &c->b_n_events, &c->cm_group_rank_off, &c->cm_cigar_scratch, &c->ea_bp, &c->ea_path, &c->ea_args, &c->align_order};
     for (dev_buf* b : bufs) b->release();
     c->small_d.release();
     if (c->small_h) (void)hipHostFree(c->small_h);
@@ -662,7 +598,6 @@ int np_sync(np_ctx* c, void* stream)
     if (!c) return NP_ERR_INVALID;
     NP_HIP(c, hipStreamSynchronize(pick_stream(c, stream)));
     std::lock_guard<std::mutex> g(c->lock);          // (other threads may be enqueueing: the timers' event lists are shared)
-    if (c->side_pending) { NP_HIP(c, hipEventSynchronize(c->side_join)); c->side_pending = false; }   // work items built on the side stream
     drain_timing(c);
     return NP_OK;
 }
@@ -697,25 +632,8 @@ int np_event_align_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* 
     if (!c) return NP_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    return run_event_align(c, use_stream(c, stream, false), n_reads, reads, event_mean, kmer_rank, model, max_bands,
+    return run_event_align(c, use_stream(c, stream), n_reads, reads, event_mean, kmer_rank, model, max_bands,
                            pair_off, pairs_out, pair_begin, n_pairs);
-}
-
-int np_event_align_split_dev(np_ctx* c, void* stream, int phase, int n_reads, const np_read_dev* reads, const float* event_mean,
-                             const uint16_t* kmer_rank, int model, int64_t max_bands, int64_t total_pairs, const int64_t* pair_off,
-                             np_pair* pairs_out, int32_t* pair_begin, int32_t* n_pairs)
-{
-    if (!c) return NP_ERR_INVALID;
-    std::lock_guard<std::mutex> g(c->lock);
-    if (phase < 1 || phase > 3 || total_pairs < 0) { c->err = "np_event_align_split_dev: phase is 1 (fill), 2 (back-track) or 3 (both)"; return NP_ERR_INVALID; }
-    NP_HIP(c, hipSetDevice(c->device));
-    stream_scope scope = use_stream(c, stream, false);
-    for (int ph = 1; ph <= 2; ++ph) {
-        if (!(phase & ph)) continue;
-        const int rc = run_event_align(c, scope.s, n_reads, reads, event_mean, kmer_rank, model, max_bands, pair_off, pairs_out, pair_begin, n_pairs, ph, total_pairs);
-        if (rc != NP_OK) return rc;
-    }
-    return NP_OK;
 }
 
 int np_hmm_score_dev(np_ctx* c, void* stream, int64_t n_jobs, const np_hmm_job_dev* jobs, const np_read_dev* reads,
@@ -733,7 +651,7 @@ int np_adc_to_pa_dev(np_ctx* c, void* stream, int n_reads, const int16_t* adc, c
     if (!c || n_reads < 0 || (n_reads > 0 && (!adc || !raw_off || !offset || !raw_unit || !raw_pa))) return NP_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    stream_scope scope = use_stream(c, stream, false); hipStream_t s = scope.s;
+    stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
     family_timer tm(c, 4, s);
     NP_HIP(c, np_launch_adc_to_pa(n_reads, adc, raw_off, max_samples, offset, raw_unit, raw_pa, s));
     return NP_OK;
@@ -889,22 +807,30 @@ static int score_small(np_ctx* c, hipStream_t s, int n_jobs, const std::vector<n
     memcpy(H + o_reads, dr.data(), dr.size() * sizeof(np_read_dev));
     memcpy(H + o_ev, ev.data(), ev.size() * sizeof(float));
     memcpy(H + o_rk, rk.data(), rk.size() * sizeof(uint16_t));
-    NP_HIP(c, hipMemcpyAsync(D, H, up, hipMemcpyHostToDevice, s));
-    {
-        family_timer tm(c, 1, s);
-        for (int cls = 0; cls < NP_NUM_CLASSES; ++cls) {
-            if (!cnt[cls]) continue;
-            np_hmm_args a{};
-            a.jobs = (const np_hmm_job_dev*)(D + o_jobs); a.order = (const uint32_t*)(D + o_order) + (size_t)cls * n; a.n_class_jobs = (const uint32_t*)(D + o_cnt) + cls;
-            a.reads = (const np_read_dev*)(D + o_reads); a.event_mean = (const float*)(D + o_ev); a.ranks = (const uint16_t*)(D + o_rk);
-            a.model = c->models[model].d_states; a.logsum = c->d_logsum; a.flank = c->d_flank; a.counter = (uint32_t*)(D + o_cnt) + 8 + cls;
-            a.out = (float*)(D + o_out); a.prio = c->hmm_prio;
-            const int jobs_per_block = (np_hmm_block_threads(cls) / 64) * (64 / NP_CLASS_SEG[cls]);
-            NP_HIP(c, np_launch_hmm_forward(cls, a, persistent_blocks(c, cnt[cls], jobs_per_block, c->hmm_blocks_per_cu), c->lse_oor, s));
+    // From here on the stream holds copies out of / into the shared pinned blob: whatever fails, the stream is drained before this call
+    // returns -- the combiner retries the requests of a failed round one by one straight away, and the next call rewrites (or frees and
+    // re-allocates) small_h.
+    auto enqueue = [&]() -> int {
+        NP_HIP(c, hipMemcpyAsync(D, H, up, hipMemcpyHostToDevice, s));
+        {
+            family_timer tm(c, 1, s);
+            for (int cls = 0; cls < NP_NUM_CLASSES; ++cls) {
+                if (!cnt[cls]) continue;
+                np_hmm_args a{};
+                a.jobs = (const np_hmm_job_dev*)(D + o_jobs); a.order = (const uint32_t*)(D + o_order) + (size_t)cls * n; a.n_class_jobs = (const uint32_t*)(D + o_cnt) + cls;
+                a.reads = (const np_read_dev*)(D + o_reads); a.event_mean = (const float*)(D + o_ev); a.ranks = (const uint16_t*)(D + o_rk);
+                a.model = c->models[model].d_states; a.logsum = c->d_logsum; a.flank = c->d_flank; a.counter = (uint32_t*)(D + o_cnt) + 8 + cls;
+                a.out = (float*)(D + o_out); a.prio = c->hmm_prio;
+                const int jobs_per_block = (np_hmm_block_threads(cls) / 64) * (64 / NP_CLASS_SEG[cls]);
+                NP_HIP(c, np_launch_hmm_forward(cls, a, persistent_blocks(c, cnt[cls], jobs_per_block, c->hmm_blocks_per_cu), c->lse_oor, s));
+            }
         }
-    }
-    NP_HIP(c, hipMemcpyAsync(out_h, D + o_out, n * sizeof(float), hipMemcpyDeviceToHost, s));
-    NP_HIP(c, hipStreamSynchronize(s));
+        NP_HIP(c, hipMemcpyAsync(out_h, D + o_out, n * sizeof(float), hipMemcpyDeviceToHost, s));
+        NP_HIP(c, hipStreamSynchronize(s));
+        return NP_OK;
+    };
+    const int erc = enqueue();
+    if (erc != NP_OK) { (void)hipStreamSynchronize(s); (void)hipGetLastError(); return erc; }
     memcpy(out_scores, out_h, n * sizeof(float));
     if (skipped) for (size_t q = 0; q < n && key[q].first < 0; ++q) out_scores[key[q].second] = __builtin_nanf("");      // (classify's rule for an item no class takes)
     drain_timing(c);
@@ -1129,13 +1055,11 @@ int np_cm_build_jobs_identity_dev(np_ctx* c, void* stream, int n_reads, const ch
     NP_HIP(c, hipSetDevice(c->device));
     stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
     NP_HIP(c, c->cm_group_rank_off.reserve((size_t)total_group_slots * sizeof(int64_t)));
-    const hipStream_t ls = fork_side(c, s);
     {
-        family_timer tm(c, ls == s ? 2 : 8, ls);
+        family_timer tm(c, 2, s);
         NP_HIP(c, np_launch_cm_build_jobs(n_reads, ref_seq, seq_off, read_rc, alphabet, (int)k, min_separation, min_flank, group_off, rank_off, jobs,
-                                          kpos, job_ranks, first_site, last_site, n_motif, c->cm_group_rank_off.as<int64_t>(), n_groups, ls));
+                                          kpos, job_ranks, first_site, last_site, n_motif, c->cm_group_rank_off.as<int64_t>(), n_groups, s));
     }
-    join_side_later(c, ls, s);
     return NP_OK;
 }
 
@@ -1161,14 +1085,12 @@ int np_cm_build_jobs_cigar_dev(np_ctx* c, void* stream, int n_reads, const char*
     int32_t* op_read = op_ref + n_idx;
     int32_t* cig_reads = op_read + n_idx;                      // 16 B per read
     int32_t* group_kpos = cig_reads + 4 * (size_t)n_reads;
-    const hipStream_t ls = fork_side(c, s);
     {
-        family_timer tm(c, ls == s ? 2 : 8, ls);
+        family_timer tm(c, 2, s);
         NP_HIP(c, np_launch_cm_build_jobs_cigar(n_reads, genome, ref_begin, ref_len, cigar, cigar_off, read_len, read_rc, alphabet, (int)k,
                                                 min_separation, min_flank, group_off, rank_off, jobs, kpos, job_ranks, first_site, last_site, n_motif,
-                                                c->cm_group_rank_off.as<int64_t>(), n_groups, deg_kpos, op_ref, op_read, cig_reads, group_kpos, ls));
+                                                c->cm_group_rank_off.as<int64_t>(), n_groups, deg_kpos, op_ref, op_read, cig_reads, group_kpos, s));
     }
-    join_side_later(c, ls, s);
     return NP_OK;
 }
 
@@ -1248,7 +1170,7 @@ int64_t np_get_stat(np_ctx* c, const char* name)
     if (k == "align_scratch_bytes") return c->last_align_scratch;
     if (k == "align_blocks_max") return (int64_t)c->n_cu * c->align_blocks_per_cu;
     if (k == "lse_oor") return c->lse_oor ? 1 : 0;
-    if (k == "hmm_kernel") return c->hmm_kernel;
+    if (k == "lse_probe_ok") return c->lse_probe_ok ? 1 : 0;
     if (k == "n_cu") return c->n_cu;
     if (k == "ed_serial_reads" || k == "ed_refused_reads") {     // of the most recent np_detect_events_* call (waits for it): reads whose
         // prefix sums were accumulated serially (exactness bound not provable), resp. refused (NP_ED_INEXACT: non-finite samples)
@@ -1280,18 +1202,17 @@ int np_set_option(np_ctx* c, const char* name, int64_t value)
     std::lock_guard<std::mutex> g(c->lock);
     const std::string k(name);
     if (k == "align_blocks_per_cu") c->align_blocks_per_cu = (int)std::max<int64_t>(1, value);
-    else if (k == "align_bt_blocks_per_cu") c->align_bt_blocks_per_cu = (int)std::max<int64_t>(1, value);
-    else if (k == "cm_async") c->cm_async = value != 0;
-    else if (k == "align_bt_prio") c->align_bt_prio = (int)std::min<int64_t>(3, std::max<int64_t>(0, value));
     else if (k == "hmm_prio") c->hmm_prio = (int)std::min<int64_t>(2, std::max<int64_t>(0, value));
     else if (k == "hmm_blocks_per_cu") c->hmm_blocks_per_cu = (int)std::max<int64_t>(1, value);
-    else if (k == "hmm_kernel") c->hmm_kernel = value == 2 ? 2 : 1;
     else if (k == "align_lpt") c->align_lpt = value != 0;
     else if (k == "stream_switch_wait") c->stream_switch_wait = value != 0;
     else if (k == "small_batch_path") c->small_batch_path = value != 0;
     else if (k == "ed_warmup") c->ed_warmup = (int)value;
     else if (k == "ea_rows_cap") c->ea_rows_cap = (int)std::min<int64_t>(65535, std::max<int64_t>(16, value));
-    else if (k == "lse_oor") c->lse_oor = value != 0;          // tests: both log-sum lookups must give the same scores
+    else if (k == "lse_oor") {                                   // tests: both log-sum lookups must give the same scores
+        if (value != 0 && !c->lse_probe_ok) { c->err = "lse_oor: the hardware probe of this context failed; the clamp-free log-sum is not available"; return NP_ERR_UNSUPPORTED; }
+        c->lse_oor = value != 0;
+    }
     else if (k == "ea_kernel") { if (value != 2) { c->err = "ea_kernel: the one-read chain kernel was removed in round 4"; return NP_ERR_INVALID; } }
     else if (k == "ea_waves_per_cu") c->ea_waves_per_cu = (int)std::max<int64_t>(1, value);
     else { c->err = "np_set_option: unknown option " + k; return NP_ERR_INVALID; }
@@ -1336,7 +1257,7 @@ int np_detect_events_dev(np_ctx* c, void* stream, int n_reads, const float* raw,
     if (n_reads == 0) return NP_OK;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    return detect_events_locked(c, use_stream(c, stream, false), n_reads, raw, raw_off, max_samples, params, tstat, 0, event_off, max_events,
+    return detect_events_locked(c, use_stream(c, stream), n_reads, raw, raw_off, max_samples, params, tstat, 0, event_off, max_events,
                                 event_start, event_length, event_mean, event_stdv, n_events);
 }
 
@@ -1406,7 +1327,7 @@ int np_mom_fill_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* reads, np
     if (n_reads == 0) return NP_OK;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    stream_scope scope = use_stream(c, stream, false); hipStream_t s = scope.s;
+    stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
     family_timer tm(c, 5, s);
     NP_HIP(c, np_launch_mom_fill(n_reads, reads, reads_b, event_mean, n_events, kmer_rank, c->models[model].d_states, s));
     return NP_OK;
@@ -1421,7 +1342,7 @@ int np_reverse_events_dev(np_ctx* c, void* stream, int n_reads, const int64_t* e
     if (n_reads == 0) return NP_OK;
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
-    stream_scope scope = use_stream(c, stream, false); hipStream_t s = scope.s;
+    stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
     family_timer tm(c, 4, s);
     NP_HIP(c, np_launch_reverse_events(n_reads, event_off, n_events, event_start, event_length, event_mean, event_stdv, s));
     return NP_OK;

@@ -14,11 +14,15 @@
 // no flush in progress becomes the combiner, takes everything queued so far -- what arrived while the previous flush was on the
 // device -- and scores it with ONE np_hmm_score_host; the others sleep until their scores are there.  One thread still costs one
 // launch per call; sixteen threads cost one launch per round (tests/bench_percall_dropin.py, profiles/r04_percall_dropin.md).
-// Errors do not exit() from inside the caller's parallel region any more: a failed call reports on stderr (once per message),
-// counts in np_dropin_error_count(), and returns the reference's in-band "no result" (-INFINITY / an empty vector); the caller's
-// serial code checks the count after its loop.  NP_DROPIN_ABORT_ON_ERROR=1 restores the immediate exit.
+// Errors: the reference's callers link UNCHANGED, so none of them reads an error count -- a failed device call therefore ends the
+// process (message on stderr, exit status 1: what the reference itself does when its own allocation fails, raw_loader.cpp:124-131),
+// as it must not be possible to write NaN / -inf log-likelihoods into a TSV and exit 0.  A caller that HAS been adapted to check
+// np_dropin_error_count() after its loop sets NP_DROPIN_ERRORS_IN_BAND=1: the call then reports (once per message), counts, and
+// returns the reference's in-band "no result" (-INFINITY / an empty vector); even then an atexit handler turns the exit status of a
+// process that ends with a non-zero count into 1.
 // The throughput path remains the *_dev batch API fed at the BamProcessor batch boundary (np_batch_dropin.cpp).
 #include <algorithm>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,20 +50,54 @@ namespace {
 
 std::atomic<long> g_errors(0);
 
-// a failed device call: message (once per distinct text), count, and -- unless NP_DROPIN_ABORT_ON_ERROR is set -- back to the caller,
-// who returns the entry point's in-band failure value
+bool errors_in_band()
+{
+    static const bool v = [] { const char* e = getenv("NP_DROPIN_ERRORS_IN_BAND"); return e && atoi(e) != 0; }();
+    return v;
+}
+
+// process exit with failed calls on the books (in-band mode): an unmodified caller would exit 0 with corrupt output
+void exit_status_guard()
+{
+    const long n = g_errors.load();
+    if (n > 0) {
+        fprintf(stderr, "nanopolish_amd: %ld device call(s) failed during this run; results are incomplete (exit status 1)\n", n);
+        fflush(stderr);
+        _exit(EXIT_FAILURE);
+    }
+}
+
+// a failed device call: message, count, and the end of the process -- or, with NP_DROPIN_ERRORS_IN_BAND=1, back to the caller, who
+// returns the entry point's in-band failure value (message once per distinct text)
 void fail(const char* what, int rc)
 {
     static std::mutex m;
     static std::set<std::string> seen;
+    static std::once_flag guard;
     const std::string msg = std::string(what) + " failed (" + std::to_string(rc) + "): " + np_last_error(shim().get());
     g_errors.fetch_add(1);
     {
         std::lock_guard<std::mutex> g(m);
         if (seen.insert(msg).second) fprintf(stderr, "nanopolish_amd: %s\n", msg.c_str());
     }
-    const char* fatal = getenv("NP_DROPIN_ABORT_ON_ERROR");
-    if (fatal && atoi(fatal) != 0) exit(EXIT_FAILURE);
+    if (!errors_in_band()) { fflush(stderr); _exit(EXIT_FAILURE); }       // (_exit: no static destructors under the caller's running OpenMP team)
+    std::call_once(guard, [] { atexit(exit_status_guard); });
+}
+
+// Per-item callers (scorereads, phase-reads: SURVEY section 2 OUT OF SCOPE, no batched binding) get SLOWER through this shim -- a
+// synchronous device round trip per item, ~12 x the CPU function from sixteen threads (profiles/r04_percall_dropin.md).  Say so once,
+// after enough calls that it is a throughput caller and not a test; NP_DROPIN_QUIET=1 silences it.
+void note_per_call_use()
+{
+    static std::atomic<long> calls(0);
+    if (calls.fetch_add(1, std::memory_order_relaxed) + 1 != 4096) return;
+    const char* q = getenv("NP_DROPIN_QUIET");
+    if (q && atoi(q) != 0) return;
+    fprintf(stderr, "nanopolish_amd: note: profile_hmm_score* has been called 4096 times one item at a time.  Each call is a synchronous device round\n"
+                    "  trip (~35 us of dependent work against ~20 us for the CPU function): per-item callers (scorereads, phase-reads) run slower\n"
+                    "  through this shim than on the host.  Throughput callers use the batched bindings: np_calculate_methylation_for_batch /\n"
+                    "  NpBatchPipeline (call-methylation), np_score_variants_thresholded (variants), np_realign_reads_batch (eventalign);\n"
+                    "  INTEGRATION.md section 1.  NP_DROPIN_QUIET=1 silences this note.\n");
 }
 
 // Flat combining of concurrent scoring calls (see the header).  A request is a run of np_hmm_job with room for their scores.
@@ -194,6 +232,7 @@ float profile_hmm_score(const HMMInputSequence& sequence, const HMMInputData& da
     FlatJob f;
     flatten(sequence, data, flags, f);
     float out = 0.0f;
+    note_per_call_use();
     const int rc = combiner().score(&f.job, 1, &out);
     if (rc != NP_OK) { fail("profile_hmm_score: np_hmm_score_host", rc); return -INFINITY; }
     return out;
@@ -236,6 +275,7 @@ float profile_hmm_score_set(const std::vector<HMMInputSequence>& sequences, cons
     }
     // the members' forward scores through the combiner, then profile_hmm.cpp:38-54's own combination (the reference's add_logs)
     std::vector<float> sc(jobs.size());
+    note_per_call_use();
     const int rc = combiner().score(jobs.data(), (int)jobs.size(), sc.data());
     if (rc != NP_OK) { fail("profile_hmm_score_set: np_hmm_score_host", rc); return -INFINITY; }
     const size_t num_models = sequences.size();

@@ -203,217 +203,6 @@ __global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward_kernel(np_hmm_a
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Forward, round 4 (EXPERIMENT, option hmm_kernel = 2; the kernel above stays the default): the same sweep with the log-sums of a
-// step issued STAGE by stage across the lane's blocks.
-//
-// Round 3 read the kernel above as balanced between vector issue and the latency of its dependent look-up chains at 4 waves per
-// SIMD.  The chains are fixed per CELL by the reference's order of log-sums -- but the M and B cells of a lane's blocks do not
-// depend on each other within a row (only K(r, b) <- K(r, b-1) does), so a step can issue the first log-sum of all its blocks,
-// then the second of all, ...: 5-7 table look-ups in flight per wave instead of one (tools/lds_schedule.py prints the order the
-// compiler kept).  Round 2 tried this and spilled: beside 24 state and 32 Gaussian-parameter registers the stage arrays do not
-// fit 128 VGPRs.  Here the scaled Gaussians leave the register file: the prologue writes them to a per-wave slab in global
-// memory (16 B per block and lane, 8 KB per resident wave, L2-resident), the emissions are computed one ROW AHEAD, and the
-// slab is re-read where the step holds the fewest values, the requests landing behind the K chain (eight log-sums in series).
-// The blocks per lane are a compile-time constant (a switch over instantiations; packs are binned by it).
-// Same arithmetic, same order per cell: scores bit-identical (tests/test_gpu_parity.py::test_staged_forward_kernel...).
-//
-// Measured (profiles/r04_kernel_b_staged.md; 40 000 reads, forward family): 25.3 ms for the kernel above, 28.6 ms for this one
-// (35.7 / 30.7 / 46.8 ms for the first three forms: Gaussians loaded at the top of the step, in two halves, all early with
-// spills).  With every emission free BOTH take 22.3 ms.  Counters over the same launch: this kernel waits 18 % less on data
-// (SQ_WAIT_ANY) and 58 % MORE for an issue slot (SQ_WAIT_INST_ANY), with 10 % fewer vector instructions of a costlier mix (64-bit
-// address arithmetic, packed moves).  So more look-ups in flight alone buy nothing; what a step costs is in profiles/r04_kernel_b_issue.md (the
-// instruction-class costs quoted in the first write-up of this experiment came from a mis-sized calibration and were 1.5 x too high).
-// ---------------------------------------------------------------------------------------------------
-// experiment knobs of the staged kernel: workgroup size (640 threads = 5 waves per SIMD at two workgroups per CU: needs <= 96 VGPRs) and
-// scheduling barriers between the stages (1: the compiler may not move instructions across a stage boundary)
-#ifndef NP_HMM_FWD2_BLOCK
-#define NP_HMM_FWD2_BLOCK 512
-#endif
-#ifndef NP_F2_SCHED
-#define NP_F2_SCHED 0
-#endif
-
-#if NP_F2_SCHED
-#define NP_F2_STAGE_END() __builtin_amdgcn_sched_barrier(0)
-#else
-#define NP_F2_STAGE_END() ((void)0)
-#endif
-template <int SEG, int BLK>
-__global__ void __launch_bounds__(BLK, BLK / 128) np_hmm_forward2_kernel(np_hmm_args a)
-{
-    __shared__ float tbl[NP_LOGSUM_TBL];          // the kernel's ONLY LDS object (np_lse_oor; checked at np_create)
-    if (a.prio >= 2) __builtin_amdgcn_s_setprio(2);
-    else if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
-    for (int i = threadIdx.x; i < NP_LOGSUM_TBL; i += BLK) tbl[i] = np_lse_table_entry(a.logsum, i);
-    __syncthreads();
-    const __attribute__((address_space(3))) char* tbl3 = (const __attribute__((address_space(3))) char*)tbl;
-#define NP_LSE2(x, y) np_lse_oor((x), (y), tbl3)
-
-    constexpr int C = 8;
-    constexpr int JPW = 64 / SEG;                 // jobs per wave
-    const int lane = threadIdx.x & 63;
-    const int seg = lane / SEG, sl = lane % SEG;
-    const uint32_t n_jobs = *a.n_class_jobs;
-    const uint32_t n_packs = (n_jobs + JPW - 1) / JPW;
-    // this wave's Gaussian slab: block c of lane l at gs[c * 64] (one coalesced 1 KB line per block)
-    float4* const gs = a.gslab + ((size_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6)) * (size_t)(C * 64) + lane;
-
-    for (;;) {
-        const uint32_t pack = __builtin_amdgcn_readfirstlane(atomicAdd(a.counter, lane == 0 ? 1u : 0u));
-        if (pack >= n_packs) break;
-
-        const uint32_t slot = pack * JPW + seg;
-        const bool has = seg < JPW && slot < n_jobs;
-        const uint32_t jidx = has ? a.order[slot] : 0u;
-        const np_hmm_job_dev job = a.jobs[jidx];
-        const np_read_dev* rd = a.reads + job.read;
-        const int n = has ? (int)job.n_kmers : 0;
-        const int e = has ? (int)(job.e_stop > job.e_start ? job.e_stop - job.e_start : job.e_start - job.e_stop) + 1 : 0;
-        const int stride = job.stride;
-        const int cw = __builtin_amdgcn_readfirstlane(wave_max_i32(has ? (n + SEG - 1) / SEG : 1));
-        const float* ev = a.event_mean + rd->event_off;
-        const bool pre_clip = (job.flags & NP_HAF_ALLOW_PRE_CLIP) != 0;
-        const bool post_clip = (job.flags & NP_HAF_ALLOW_POST_CLIP) != 0;
-        const float lp_mm_self = rd->trans[0], lp_mb = rd->trans[1], lp_mk = rd->trans[2], lp_mm_next = rd->trans[3],
-                    lp_bb = rd->trans[4], lp_bk = rd->trans[5], lp_bm_next = rd->trans[6], lp_bm_self = rd->trans[7],
-                    lp_kk = rd->trans[8], lp_km = rd->trans[9];
-
-        auto sweep = [&](auto cw_tag) __attribute__((always_inline)) {
-            constexpr int CW = decltype(cw_tag)::value;
-            const int lanes_used = (n + CW - 1) / CW;
-            const bool lane_on = has && sl < lanes_used;
-            float xn = 0.0f, softn = NP_NEG_INF, pfn = 0.0f;
-            const int last_lane = n > 0 ? (n - 1) / CW : 0, last_c = n > 0 ? (n - 1) % CW : 0;
-            const bool is_last = lane_on && sl == last_lane;
-            if (lane_on && sl == 0) { xn = ev[job.e_start]; softn = a.flank[0]; }      // row 1: event_idx == e_start (r9.inl:361)
-            if (is_last && sl == 0 && (post_clip || e == 1)) pfn = a.flank[e - 1];
-            // em[c]: the emission of the row this lane computes NEXT, always one step ahead (see the step's tail).  The prologue
-            // has the Gaussians in registers anyway: segment heads (row 1 in step 1) take theirs from here, the other lanes of a
-            // segment when their first row comes up.
-            float em[CW];
-            {
-                const double scale = rd->scale, shift = rd->shift, var = rd->var, log_var = rd->log_var;
-#pragma unroll
-                for (int c = 0; c < CW; ++c) {
-                    const int b = sl * CW + c;
-                    const uint32_t rank = (lane_on && b < n) ? a.ranks[job.rank_off + b] : 0u;
-                    const np_gauss g = np_scale_state(a.model, rank, scale, shift, var, log_var);
-                    gs[c * 64] = make_float4(g.mean, g.stdv, g.cl, g.rinv);
-                    em[c] = np_emission(xn, g);
-                }
-            }
-            float M[CW], B[CW], K[CW];
-#pragma unroll
-            for (int c = 0; c < CW; ++c) M[c] = B[c] = K[c] = NP_NEG_INF;   // row 0 (r9.cpp:21-33)
-            float oM = NP_NEG_INF, oB = NP_NEG_INF, oK = NP_NEG_INF;   // left neighbour, row r-1
-            float lp_end = NP_NEG_INF;
-            const int steps = wave_max_i32(has ? e + lanes_used - 1 : 0);
-            for (int t = 1; t <= steps; ++t) {
-                float nM = np_wave_shr1(M[CW - 1], NP_NEG_INF);
-                float nB = np_wave_shr1(B[CW - 1], NP_NEG_INF);
-                float nK = np_wave_shr1(K[CW - 1], NP_NEG_INF);
-                if (sl == 0) { nM = NP_NEG_INF; nB = NP_NEG_INF; nK = NP_NEG_INF; }
-                const int r = t - sl;
-                const bool act = lane_on && r >= 1 && r <= e;
-                const float soft = softn, pf = pfn;
-                {
-                    const int rn = r + 1;
-                    const bool actn = lane_on && rn >= 1 && rn <= e;
-                    xn = actn ? ev[job.e_start + (uint32_t)((rn - 1) * stride)] : 0.0f;                    // r9.inl:342
-                    softn = (actn && sl == 0 && (rn == 1 || pre_clip)) ? a.flank[rn - 1] : NP_NEG_INF;     // r9.inl:361-363
-                    pfn = (actn && is_last && (post_clip || rn == e)) ? a.flank[e - rn] : 0.0f;           // r9.inl:388
-                }
-                // the slab offset is re-made opaque every step: the loads below are loop-invariant to the compiler otherwise and
-                // would be hoisted back into 32 registers
-                int goff = 0;
-                asm volatile("" : "+v"(goff));
-                if (act) {
-                    float s[CW], nb[CW], tk[CW];
-                    // PSR9_MATCH, term by term across the blocks (r9.inl:350-365): SAME_M + PREV_M
-#pragma unroll
-                    for (int c = 0; c < CW; ++c) s[c] = NP_LSE2(lp_mm_self + M[c], lp_mm_next + (c ? M[c - 1] : oM));
-                    NP_F2_STAGE_END();
-#pragma unroll
-                    for (int c = 0; c < CW; ++c) s[c] = NP_LSE2(s[c], lp_bm_self + B[c]);                       // SAME_B
-                    NP_F2_STAGE_END();
-#pragma unroll
-                    for (int c = 0; c < CW; ++c) s[c] = NP_LSE2(s[c], lp_bm_next + (c ? B[c - 1] : oB));        // PREV_B
-                    NP_F2_STAGE_END();
-#pragma unroll
-                    for (int c = 0; c < CW; ++c) s[c] = NP_LSE2(s[c], lp_km + (c ? K[c - 1] : oK));             // PREV_K
-                    NP_F2_STAGE_END();
-                    s[0] = NP_LSE2(s[0], soft);                                                                  // SOFT: first k-mer only
-#pragma unroll
-                    for (int c = 0; c < CW; ++c) s[c] = s[c] + em[c];                                            // new M
-                    // PSR9_BAD_EVENT (r9.inl:368-374)
-#pragma unroll
-                    for (int c = 0; c < CW; ++c) nb[c] = NP_LSE2(lp_mb + M[c], lp_bb + B[c]);
-                    NP_F2_STAGE_END();
-                    // PSR9_KMER_SKIP (r9.inl:377-383): PREV_M + PREV_B of the SAME row, then the chain through PREV_K
-#pragma unroll
-                    for (int c = 0; c < CW; ++c) tk[c] = NP_LSE2(lp_mk + (c ? s[c - 1] : nM), lp_bk + (c ? nb[c - 1] : nB));
-                    // The NEXT row's emissions.  The Gaussians are requested here, where the step holds the fewest values, and the
-                    // requests (L2 hits, ~1 us) land behind the K chain -- eight log-sums in series, the one part of a step that
-                    // cannot keep look-ups in flight.  The scheduling barriers keep the requests above the chain and the uses below.
-                    float4 q[CW]; (void)q;
-                    __builtin_amdgcn_sched_barrier(0);
-#if !(NP_HMM_ABL & 1)
-#pragma unroll
-                    for (int c = 0; c < CW; ++c) q[c] = gs[c * 64 + goff];
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                    float kprev = nK;
-#pragma unroll
-                    for (int c = 0; c < CW; ++c) { K[c] = NP_LSE2(tk[c], lp_kk + kprev); kprev = K[c]; }
-#pragma unroll
-                    for (int c = 0; c < CW; ++c) { M[c] = s[c]; B[c] = nb[c]; }
-                    // end state (r9.inl:388-396): last k-mer, M then B then K
-                    if (sl == last_lane && (post_clip || r == e)) {
-                        float eM = M[0], eB = B[0], eK = K[0];
-#pragma unroll
-                        for (int c = 1; c < CW; ++c) if (c == last_c) { eM = M[c]; eB = B[c]; eK = K[c]; }
-                        lp_end = NP_LSE2(lp_end, eM + pf);
-                        lp_end = NP_LSE2(lp_end, eB + pf);
-                        lp_end = NP_LSE2(lp_end, eK + pf);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int c = 0; c < CW; ++c) {
-#if NP_HMM_ABL & 1
-                        em[c] = xn * 0.001f - (float)c;               // timing experiment only (scores WRONG): emissions for free
-#else
-                        np_gauss g; g.mean = q[c].x; g.stdv = q[c].y; g.cl = q[c].z; g.rinv = q[c].w;
-                        em[c] = np_emission(xn, g);
-#endif
-                    }
-                } else if (r == 0 && lane_on) {
-                    // a lane whose FIRST row comes next (steps 1 .. lanes - 1 of a pack only): its emissions from the slab, unhidden
-#pragma unroll
-                    for (int c = 0; c < CW; ++c) {
-                        const float4 q = gs[c * 64 + goff];
-                        np_gauss g; g.mean = q.x; g.stdv = q.y; g.cl = q.z; g.rinv = q.w;
-                        em[c] = np_emission(xn, g);
-                    }
-                }
-                oM = nM; oB = nB; oK = nK;
-            }
-            if (has && sl == last_lane) a.out[jidx] = lp_end;
-        };
-        switch (cw) {
-            case 1: sweep(std::integral_constant<int, 1>{}); break;
-            case 2: sweep(std::integral_constant<int, 2>{}); break;
-            case 3: sweep(std::integral_constant<int, 3>{}); break;
-            case 4: sweep(std::integral_constant<int, 4>{}); break;
-            case 5: sweep(std::integral_constant<int, 5>{}); break;
-            case 6: sweep(std::integral_constant<int, 6>{}); break;
-            case 7: sweep(std::integral_constant<int, 7>{}); break;
-            default: sweep(std::integral_constant<int, 8>{}); break;
-        }
-    }
-#undef NP_LSE2
-}
-
-// ---------------------------------------------------------------------------------------------------
 // Viterbi fill (ProfileHMMViterbiOutputR9, r9.inl:130-197): same sweep, max/arg-max with later-wins ties,
 // lattice + back-pointers streamed to HBM in row-major [row][3*n] (block 0 / terminal block omitted).
 // ---------------------------------------------------------------------------------------------------
@@ -656,20 +445,6 @@ hipError_t launch_fwd(const np_hmm_args& a, int n_blocks, bool oor, hipStream_t 
     else hipLaunchKernelGGL((np_hmm_forward_kernel<SEG, C, BLK, false>), dim3(n_blocks), dim3(BLK), 0, s, a);
     return hipGetLastError();
 }
-template <int SEG>
-hipError_t launch_fwd2(const np_hmm_args& a, int n_blocks, hipStream_t s)
-{
-    hipLaunchKernelGGL((np_hmm_forward2_kernel<SEG, NP_HMM_FWD2_BLOCK>), dim3(n_blocks), dim3(NP_HMM_FWD2_BLOCK), 0, s, a);
-    return hipGetLastError();
-}
-template <int SEG>
-hipError_t fwd2_lds_bytes(size_t* bytes)
-{
-    hipFuncAttributes at;
-    const hipError_t e = hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&np_hmm_forward2_kernel<SEG, NP_HMM_FWD2_BLOCK>));
-    if (e == hipSuccess) *bytes = at.sharedSizeBytes;
-    return e;
-}
 // static LDS bytes of the OOR instantiation of a size class: must be exactly the table (np_lse_oor's precondition)
 template <int SEG, int C>
 hipError_t fwd_lds_bytes(size_t* bytes)
@@ -689,7 +464,6 @@ hipError_t launch_vit(const np_hmm_args& a, int n_blocks, hipStream_t s)
 } // namespace
 
 int np_hmm_block_threads(int cls) { (void)cls; return NP_HMM_FWD_BLOCK; }
-int np_hmm_forward2_block_threads(void) { return NP_HMM_FWD2_BLOCK; }
 int np_vit_block_threads(void) { return NP_HMM_BLOCK; }
 
 hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, bool lse_oor, hipStream_t s)
@@ -703,29 +477,6 @@ hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, bo
         case 5: return launch_fwd<32, 8>(a, n_blocks, lse_oor, s);
         case 6: return launch_fwd<64, 8>(a, n_blocks, lse_oor, s);
         case 7: return launch_fwd<64, 16>(a, n_blocks, lse_oor, s);
-    }
-    return hipErrorInvalidValue;
-}
-
-// the staged kernel exists for the classes whose lanes own up to 8 blocks and whose items are many (2, 3, 4 and 8 lanes per item)
-bool np_hmm_forward2_has(int cls) { return cls >= 0 && cls <= 3; }
-hipError_t np_launch_hmm_forward2(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s)
-{
-    switch (cls) {
-        case 0: return launch_fwd2<2>(a, n_blocks, s);
-        case 1: return launch_fwd2<3>(a, n_blocks, s);
-        case 2: return launch_fwd2<4>(a, n_blocks, s);
-        case 3: return launch_fwd2<8>(a, n_blocks, s);
-    }
-    return hipErrorInvalidValue;
-}
-hipError_t np_hmm_forward2_lds_bytes(int cls, size_t* bytes)
-{
-    switch (cls) {
-        case 0: return fwd2_lds_bytes<2>(bytes);
-        case 1: return fwd2_lds_bytes<3>(bytes);
-        case 2: return fwd2_lds_bytes<4>(bytes);
-        case 3: return fwd2_lds_bytes<8>(bytes);
     }
     return hipErrorInvalidValue;
 }

@@ -21,7 +21,6 @@ struct np_hmm_args {
     np_hmm_state* states;          // output
     const int64_t* state_off;
     int32_t* n_states;
-    float4* gslab;                 // staged forward kernel (np_hmm_forward2_kernel): 8 x 64 records per resident wave
     int prio;                      // forward kernel: wave priority (s_setprio 0..3) -- above 0 only when the caller co-schedules it with
                                    // the event aligner's back-track launch, whose scalar chain would otherwise starve it
 };
@@ -83,10 +82,6 @@ struct np_align_args {
     int32_t n_reads;
     int32_t max_gap_threshold;
     double min_average_log_emission;
-    uint64_t* trace_all;           // split launches (mode 1 / 2): the trace of EVERY read, read r from row (pair_off[r] >> 3) + r (256 B rows)
-    uint64_t trace_all_rows;       // rows allocated behind trace_all: a read whose rows would end past them is refused (as a read that does not fit)
-    int32_t* fill_state;           // split launches: 2 words per read (bits of the best end-cell score, its event index)
-    int bt_prio;                   // back-track launch (mode 2): wave priority of the walk (the fused kernel's is NP_A_WALK_PRIO)
 };
 
 #define NP_NUM_CLASSES 8
@@ -139,18 +134,14 @@ __host__ __device__ inline int np_job_bin(const np_hmm_job_dev& jb, uint32_t fla
 
 hipError_t np_launch_hmm_forward(int cls, const np_hmm_args& a, int n_blocks, bool lse_oor, hipStream_t s);
 hipError_t np_hmm_forward_lds_bytes(int cls, size_t* bytes);
-bool np_hmm_forward2_has(int cls);                                  // the staged forward kernel covers this size class
-hipError_t np_launch_hmm_forward2(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s);      // needs a.gslab: n_blocks x (threads / 64) x 8 KB
-hipError_t np_hmm_forward2_lds_bytes(int cls, size_t* bytes);      // static LDS of the class's clamp-free instantiation
 // hardware probes (np_hmm_kernels.hip): out = 8 x uint32 (zeroed), buf = 16 floats of 1.0f, sbuf = 32 x uint16
 hipError_t np_launch_probe(const float* logsum, const float* buf, uint16_t* sbuf, uint32_t* out, int n_blocks, hipStream_t s);
 hipError_t np_launch_hmm_viterbi(int cls, const np_hmm_args& a, int n_blocks, hipStream_t s);
 hipError_t np_launch_hmm_backtrack(const np_hmm_args& a, int64_t n_jobs, hipStream_t s);
-hipError_t np_launch_event_align(const np_align_args& a, int n_blocks, int mode, hipStream_t s);
+hipError_t np_launch_event_align(const np_align_args& a, int n_blocks, hipStream_t s);
 hipError_t np_launch_align_order(int n_reads, const np_read_dev* reads, uint32_t* scratch /* 2048 + n_reads */, hipStream_t s);
 int np_align_block_threads(void);
 int np_hmm_block_threads(int cls);
-int np_hmm_forward2_block_threads(void);
 int np_vit_block_threads(void);
 
 // glue kernels

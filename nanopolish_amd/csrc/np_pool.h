@@ -34,8 +34,8 @@ public:
         for (size_t i = 0; i < workers_.size(); ++i) workers_[i].join();
     }
     int threads() const { return (int)workers_.size(); }
-    // index of the calling thread among this process's pool workers (0 .. threads() - 1), -1 for any other thread
-    static int current_worker() { return worker_index(); }
+    // index of the calling thread among THIS pool's workers (0 .. threads() - 1), -1 for any other thread -- a worker of another pool included
+    int current_worker() const { const Who& w = who(); return w.pool == this ? w.idx : -1; }
 
     // fn(i) for every i in [0, n), in chunks of `chunk` consecutive indices; returns when all of them have run.  The calling thread
     // takes chunks too.  Loops submitted concurrently from several threads share the workers, oldest first.
@@ -124,11 +124,12 @@ private:
         }
     }
 
-    static int& worker_index() { static thread_local int idx = -1; return idx; }
+    struct Who { const Pool* pool; int idx; };
+    static Who& who() { static thread_local Who w = {nullptr, -1}; return w; }
 
     void worker(int idx)
     {
-        worker_index() = idx;
+        who().pool = this; who().idx = idx;
         for (;;) {
             std::shared_ptr<Job> j;
             std::function<void()> mine;

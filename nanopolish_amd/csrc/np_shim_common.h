@@ -60,15 +60,18 @@ struct Shim {
     // a context slot of its own on `device` for the caller (released with release_slot; the context and its model cache stay for the next taker)
     int take_slot(int device)
     {
+        int slot = -1;
         {
             std::lock_guard<std::mutex> g(lock);
             if (devs.empty()) devs.push_back(new Dev());
-            for (size_t i = 1; i < devs.size(); ++i)
-                if (!devs[i]->in_use && devs[i]->device == device) { devs[i]->in_use = true; return (int)i; }
-            Dev* d = new Dev(); d->device = device; d->in_use = true;
-            devs.push_back(d);
+            for (size_t i = 1; i < devs.size() && slot < 0; ++i)
+                if (!devs[i]->in_use && devs[i]->device == device) { devs[i]->in_use = true; slot = (int)i; }
+            if (slot < 0) {
+                Dev* d = new Dev(); d->device = device; d->in_use = true;
+                devs.push_back(d);
+                slot = (int)devs.size() - 1;          // taken under the lock: two pipelines constructed at once get two slots
+            }
         }
-        const int slot = (int)devs.size() - 1;
         (void)ctx(slot);
         return slot;
     }

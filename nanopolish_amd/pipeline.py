@@ -337,7 +337,6 @@ class CallMethylationBatch:
         ne = (hb["event_off"][1:] - hb["event_off"][:-1]); nk = (hb["rank_off"][1:] - hb["rank_off"][:-1])
         bands = ne + nk + 2
         self.max_bands = int(bands.max())
-        self.split_align = False       # True: the aligner's fill and back-track as two launches (np_event_align_split_dev)
         pair_off = np.zeros(self.n_reads + 1, np.int64); pair_off[1:] = np.cumsum(bands)
         self.pair_off = pair_off
         self.d_pair_off = up(pair_off)
@@ -362,9 +361,7 @@ class CallMethylationBatch:
     def step(self, stage=0):
         """One pass.  stage 0: everything.  Stages for callers that pipeline batches over streams (set self.stream before each):
         1: work items + (event detection +) event alignment;  2: calibration, window bounds and scoring (the aligner is bound by
-        vector issue and uses no LDS, the scorer by vector issue too, its LDS look-ups the largest part);
-        11 / 12 / 13 (round 3, PipelinedPass): 11 = (event detection +) the aligner's FILL only (np_event_align_split_dev phase 1),
-        12 = work items + the aligner's back-track + calibration and window bounds, 13 = scoring only."""
+        vector issue and uses no LDS, the scorer by vector issue too, its LDS look-ups the largest part)."""
         L, h = self.ctx.L, self.ctx.h
         p = lambda t: C.c_void_p(t.data_ptr())
         s = C.c_void_p(self.stream) if self.stream else None      # raw hipStream_t (0 / None: the context's own stream)
@@ -373,42 +370,29 @@ class CallMethylationBatch:
         if stage == 2:
             self._step_glue(L, h, p, s, ea, n_jobs)
             return self._step_hmm(L, h, p, s, ea)
-        if stage == 13:
-            return self._step_hmm(L, h, p, s, ea)
-        if stage != 11:
-            self._step_work_items(L, h, p, s, ea)
-        if stage != 12:
-            if self.from_raw:
-                if self.from_adc:
-                    rc = L.np_adc_to_pa_dev(h, s, self.n_reads, p(self.d_adc), p(self.d_raw_off), self.max_samples, p(self.d_adc_offset),
-                                            p(self.d_adc_unit), p(self.d_raw))
-                    self.ctx._chk(rc, "np_adc_to_pa_dev")
-                rc = L.np_detect_events_dev(h, s, self.n_reads, p(self.d_raw), p(self.d_raw_off), self.max_samples, C.byref(self.prm),
-                                            p(self.d_tstat), p(self.d_event_off), self.max_events, p(self.d_ev_start), p(self.d_ev_len),
-                                            p(self.d_events), p(self.d_ev_stdv), p(self.d_n_events))
-                self.ctx._chk(rc, "np_detect_events_dev")
-                rc = L.np_mom_fill_dev(h, s, self.n_reads, p(self.d_reads_a), p(self.d_reads_b), p(self.d_events), p(self.d_n_events),
-                                       p(self.d_ranks), self.m_nuc)
-                self.ctx._chk(rc, "np_mom_fill_dev")
-                if self.rna:          # 3' -> 5' signal: the events run along the sequence from here on (squiggle_read.cpp:260-263)
-                    rc = L.np_reverse_events_dev(h, s, self.n_reads, p(self.d_event_off), p(self.d_n_events), p(self.d_ev_start), p(self.d_ev_len),
-                                                 p(self.d_events), p(self.d_ev_stdv))
-                    self.ctx._chk(rc, "np_reverse_events_dev")
-        phase = {11: 1, 12: 2}.get(stage, 3 if self.split_align else 0)
-        if phase:
-            rc = L.np_event_align_split_dev(h, s, phase, self.n_reads, p(self.d_reads_a), p(self.d_events), p(self.d_ranks), self.m_nuc,
-                                            self.max_bands, int(self.pair_off[-1]), p(self.d_pair_off), p(self.d_pairs), p(self.d_pair_begin),
-                                            p(self.d_n_pairs))
-            self.ctx._chk(rc, "np_event_align_split_dev")
-        else:
-            rc = L.np_event_align_dev(h, s, self.n_reads, p(self.d_reads_a), p(self.d_events), p(self.d_ranks), self.m_nuc,
-                                      self.max_bands, p(self.d_pair_off), p(self.d_pairs), p(self.d_pair_begin), p(self.d_n_pairs))
-            self.ctx._chk(rc, "np_event_align_dev")
-        if stage in (1, 11):
+        self._step_work_items(L, h, p, s, ea)
+        if self.from_raw:
+            if self.from_adc:
+                rc = L.np_adc_to_pa_dev(h, s, self.n_reads, p(self.d_adc), p(self.d_raw_off), self.max_samples, p(self.d_adc_offset),
+                                        p(self.d_adc_unit), p(self.d_raw))
+                self.ctx._chk(rc, "np_adc_to_pa_dev")
+            rc = L.np_detect_events_dev(h, s, self.n_reads, p(self.d_raw), p(self.d_raw_off), self.max_samples, C.byref(self.prm),
+                                        p(self.d_tstat), p(self.d_event_off), self.max_events, p(self.d_ev_start), p(self.d_ev_len),
+                                        p(self.d_events), p(self.d_ev_stdv), p(self.d_n_events))
+            self.ctx._chk(rc, "np_detect_events_dev")
+            rc = L.np_mom_fill_dev(h, s, self.n_reads, p(self.d_reads_a), p(self.d_reads_b), p(self.d_events), p(self.d_n_events),
+                                   p(self.d_ranks), self.m_nuc)
+            self.ctx._chk(rc, "np_mom_fill_dev")
+            if self.rna:          # 3' -> 5' signal: the events run along the sequence from here on (squiggle_read.cpp:260-263)
+                rc = L.np_reverse_events_dev(h, s, self.n_reads, p(self.d_event_off), p(self.d_n_events), p(self.d_ev_start), p(self.d_ev_len),
+                                             p(self.d_events), p(self.d_ev_stdv))
+                self.ctx._chk(rc, "np_reverse_events_dev")
+        rc = L.np_event_align_dev(h, s, self.n_reads, p(self.d_reads_a), p(self.d_events), p(self.d_ranks), self.m_nuc,
+                                  self.max_bands, p(self.d_pair_off), p(self.d_pairs), p(self.d_pair_begin), p(self.d_n_pairs))
+        self.ctx._chk(rc, "np_event_align_dev")
+        if stage == 1:
             return
         self._step_glue(L, h, p, s, ea, n_jobs)
-        if stage == 12:
-            return
         return self._step_hmm(L, h, p, s, ea)
 
     def _step_work_items(self, L, h, p, s, ea):
@@ -562,76 +546,6 @@ class CallMethylationBatch:
             out.append((first[g0:g0 + k], nm[g0:g0 + k], sc[2 * g0:2 * (g0 + k):2], sc[2 * g0 + 1:2 * (g0 + k):2]))
         return out
 
-
-class PipelinedPass:
-    """The call-methylation pass software-pipelined over two HIP streams (round 3).
-
-    The event aligner's fill is bound by vector-instruction issue and keeps every wave slot busy; its back-track is a dependent scalar
-    chain that holds a wave slot and issues scalar instructions only; the scoring kernels run at 4 waves per SIMD around their LDS look-ups.  Run one after
-    the other (CallMethylationBatch.step) each leaves the others' resource idle.  Here the aligner's two halves are separate launches
-    (np_event_align_split_dev, the trace of every read kept in HBM) and a step is spread over two streams:
-
-        stream A:  fill(i+1)   work items, back-track, calibration + window bounds (i+1)   fill(i+2)   ...
-        stream B:              [ score(i) ............................................. ]              [ score(i+1) ...
-
-    score(i) waits for fill(i+1): it shares the chip with the back-track and the glue kernels of the next step, not with a fill.  Two
-    batch objects on two contexts alternate (scratch, work items and results of step i are still in use while step i+1 is aligned),
-    each context's calls ordered by the events recorded here (stream_switch_wait = 0).  The scoring of step i is enqueued by the call
-    that submits step i+1; flush() enqueues the last one and drains the pipeline.
-    Every step's results are bit-identical to CallMethylationBatch.step's (tests/test_gpu_parity.py)."""
-
-    def __init__(self, make_batch, n=2):
-        """make_batch(ctx_index) -> CallMethylationBatch on a context of its own (the caller registers the models)."""
-        import torch
-        self.torch = torch
-        self.batches = [make_batch(i) for i in range(n)]
-        for b in self.batches:
-            b.ctx.set_option("stream_switch_wait", 0)
-        self.sa, self.sb = torch.cuda.Stream(), torch.cuda.Stream()
-        self.e_fill = [torch.cuda.Event() for _ in self.batches]
-        self.e_glue = [torch.cuda.Event() for _ in self.batches]
-        self.e_score = [None for _ in self.batches]
-        self.k = 0                    # steps submitted
-        self.pending = None           # index of the batch whose scoring has not been enqueued yet
-        self.n_reads = self.batches[0].n_reads
-        torch.cuda.synchronize()
-
-    def _score(self, i, after_fill_of=None):
-        b = self.batches[i]
-        self.sb.wait_event(self.e_glue[i])
-        if after_fill_of is not None:
-            self.sb.wait_event(self.e_fill[after_fill_of])
-        b.stream = self.sb.cuda_stream
-        b.step(stage=13)
-        ev = self.torch.cuda.Event(); ev.record(self.sb)
-        self.e_score[i] = ev
-
-    def step(self):
-        i = self.k % len(self.batches)
-        b = self.batches[i]
-        b.stream = self.sa.cuda_stream
-        if b.from_raw and self.e_score[i] is not None:
-            self.sa.wait_event(self.e_score[i])            # (the detector rewrites the event table score(k-n) reads)
-        b.step(stage=11)                                   # fill(k): overwrites pairs / trace of step k - n (long consumed)
-        self.e_fill[i].record(self.sa)
-        if self.pending is not None:
-            self._score(self.pending, after_fill_of=i)     # score(k-1) beside back-track(k) + glue(k)
-        if self.e_score[i] is not None:
-            self.sa.wait_event(self.e_score[i])            # glue(k) rewrites the work items and scalings score(k-n) reads
-        b.stream = self.sa.cuda_stream
-        b.step(stage=12)
-        self.e_glue[i].record(self.sa)
-        self.pending = i
-        self.k += 1
-
-    def flush(self):
-        if self.pending is not None:
-            self._score(self.pending)
-            self.pending = None
-        self.sa.synchronize(); self.sb.synchronize()
-
-    def sync(self):
-        self.flush()
 
 class StreamedFeed:
     """Host-fed operation of a CallMethylationBatch: every step's inputs arrive in pinned host memory, as BamProcessor's record

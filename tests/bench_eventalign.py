@@ -82,6 +82,7 @@ def run(pool=5000, tile=10, read_len=5450, steps=3, warmup=1, cpu_sample=-1, ctx
     roof = dict(bound="hbm", kernel="np_eventalign_chain2_kernel" if ctx.get_stat("ea_cycles_fill") > 0 else "np_eventalign_chain_kernel", achieved=round(algo / chain_s / 1e9, 2) if chain_s > 0 else 0.0, peak=8000.0,
                 unit="GB/s", frac=round(algo / chain_s / 1e9 / 8000.0, 5) if chain_s > 0 else 0.0, traffic=pmc_lookup.traffic("chain", "segment", calls), algo_bytes_per_launch=algo,
                 issue=pmc_lookup.issue("chain", "segment", chain_s * 2.4e9 * 1024 / max(calls, 1)),
+                roofline_issue=pmc_lookup.roofline_issue("chain", "segment", chain_s * 2.4e9 * 1024 / max(calls, 1), "np_eventalign_chain2_kernel"),
                 avg_launch_ms=round(fam["eventalign_chain"], 3), lattice_cells_per_launch=int(cells), segments_per_launch=calls,
                 wave_cycles_by_phase=phase if phase["fill"] > 0 else None,
                 limiter="vector-instruction issue of the Viterbi sweep (one wave per read, data-dependent chain of segments)")

@@ -147,6 +147,7 @@ def run(draft=10000, reads=250, tile=8, stride=1, indel_bias=0.9, steps=3, warmu
     roof = dict(bound="hbm", kernel="np_hmm_forward_kernel", achieved=round(algo / (hmm_ms * 1e-3) / 1e9, 2) if hmm_ms > 0 else 0.0, peak=8000.0,
                 unit="GB/s", frac=round(algo / (hmm_ms * 1e-3) / 1e9 / 8000.0, 5) if hmm_ms > 0 else 0.0, traffic=pmc_lookup.traffic("hmm_forward_variants", "call", scored), algo_bytes_per_launch=algo,
                 issue=pmc_lookup.issue("hmm_forward_variants", "call", hmm_ms * 1e-3 * 2.4e9 * 1024 / max(scored, 1)),
+                roofline_issue=pmc_lookup.roofline_issue("hmm_forward_variants", "call", hmm_ms * 1e-3 * 2.4e9 * 1024 / max(scored, 1), "np_hmm_forward_kernel"),
                 avg_launch_ms=round(hmm_ms, 3), cell_states_per_s=round(cells / (hmm_ms * 1e-3) / 1e9, 2) if hmm_ms > 0 else 0.0,
                 limiter="vector-instruction issue (see issue: the p7_FLogsum look-ups are 6 vector instructions + one LDS gather each, ~8 per cell, bit-exact); nothing but events, ranks and scores touches HBM")
     out = dict(metric="variants screening profile_hmm_score calls/sec", roofline=roof, value=round(scored * args.steps / dt, 1), unit="calls/s", n_gpus=1,

@@ -34,18 +34,27 @@ int main()
         // (5) loops the submitter does not take part in run on workers only; per-worker tasks run on the worker they name
         if (nt > 0) {
             std::vector<int> who(4000, -2);
-            pool.run(4000, 16, [&](int i) { who[i] = Pool::current_worker(); }, false);
+            pool.run(4000, 16, [&](int i) { who[i] = pool.current_worker(); }, false);
             bool all_workers = true;
             for (int i = 0; i < 4000; ++i) all_workers = all_workers && who[i] >= 0 && who[i] < nt;
             bad += check(all_workers, "run(participate = false) stays on the workers");
             std::vector<int> ran(nt, -1);
-            for (int w = 0; w < nt; ++w) pool.post_to(w, [&, w]() { ran[w] = Pool::current_worker(); });
+            for (int w = 0; w < nt; ++w) pool.post_to(w, [&, w]() { ran[w] = pool.current_worker(); });
             pool.drain();
             bool own = true;
             for (int w = 0; w < nt; ++w) own = own && ran[w] == w;
             bad += check(own, "post_to runs on the named worker");
         }
-        bad += check(Pool::current_worker() == -1, "the submitting thread is no worker");
+        bad += check(pool.current_worker() == -1, "the submitting thread is no worker");
+        // (6) worker indices belong to a pool: a worker of ANOTHER pool is no worker of this one (two pipelines in one process)
+        if (nt > 0) {
+            Pool other(2);
+            std::vector<int> seen_by_pool(8, 0), seen_by_other(8, 0);
+            other.run(8, 1, [&](int i) { seen_by_pool[i] = pool.current_worker(); seen_by_other[i] = other.current_worker(); }, false);
+            bool ok = true;
+            for (int i = 0; i < 8; ++i) ok = ok && seen_by_pool[i] == -1 && seen_by_other[i] >= 0 && seen_by_other[i] < 2;
+            bad += check(ok, "a worker of another pool is not a worker of this pool");
+        }
         // (4) empty loops
         pool.run(0, 8, [&](int) { bad += 1; });
         int called = 0;

@@ -99,32 +99,3 @@ def test_whole_chain_on_device_matches_oracle(ctx, orc, models):
             assert got == {int(f): (float(a), float(b)) for f, a, b in zip(want["first"], want["unmeth"], want["meth"])}
             n_scored += len(got)
     assert n_scored > 400
-
-
-def test_work_items_built_beside_the_aligner_give_the_same_pass(orc, models):
-    """Option "cm_async" (round 3): the work-item kernels run on the context's side stream beside the event aligner (they do not depend
-    on the alignment; the aligner is bound by instruction issue, they by memory latency) and are joined by the first consumer.  The
-    whole pass -- identity and CIGAR work items, from events and from raw signal -- must give the results of the in-order pass bit
-    for bit, run after run on the same buffers, and the work items must be complete after np_sync."""
-    from nanopolish_amd.api import Context
-    from nanopolish_amd.pipeline import build_host_batch, tile_host_batch, CallMethylationBatch
-    c = Context(0)
-    c.register_model(models["nucleotide"], "nucleotide"); c.register_model(models["cpg"], "cpg")
-    try:
-        for raw in (False, True):
-            hb = build_host_batch(models, list(range(400, 424)), L=[900 + 130 * i for i in range(24)], raw=raw, with_jobs=False)
-            res = {}
-            for on in (0, 1, 0, 1):
-                c.set_option("cm_async", on)
-                batch = CallMethylationBatch(c, tile_host_batch(hb, 3), "cuda:0", calibrate=True, from_raw=raw, jobs_on_device=True)
-                batch.step(); batch.step(); batch.step()
-                jobs = batch.jobs_host().copy()                    # (np_sync joins the side stream)
-                got = (jobs.tobytes(), batch.scores().tobytes(), batch.d_first.cpu().numpy().tobytes(), batch.d_n_groups.cpu().numpy().tobytes())
-                if on in res:
-                    assert res[on] == got
-                res[on] = got
-                del batch
-            assert res[0] == res[1]
-            assert len(res[0][1]) > 4000
-    finally:
-        c.close()

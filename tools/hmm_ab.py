@@ -32,7 +32,6 @@ def child(args):
     ctx.sync(); torch.cuda.synchronize()
     ms = {n: round(ctx.kernel_time(w)[0] / args.reps, 3) for w, n in ((0, "event_align"), (1, "hmm_forward"), (2, "glue"))}
     print(json.dumps(dict(lib=os.path.basename(os.environ.get("NP_HIP_LIB", "default")), env=os.environ.get("NP_AB_ENV", ""), reads=b.n_reads, ms=ms,
-                          hmm_kernel=ctx.get_stat("hmm_kernel"),
                           scores_crc="%08x" % zlib.crc32(b.scores().tobytes()))))
 
 

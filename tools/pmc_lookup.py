@@ -44,3 +44,21 @@ def issue(name, unit, simd_cycles_per_unit):
                        "ISOLATED stream (profiles/r04_valu_calibration.json) -- mixed streams overlap by ~10 % (cmp + cndmask alternating: 3.8 cycles against "
                        "4.4), so a value at or above 1 reads: this launch runs at the issue bound of its instruction mix")
     return out
+
+
+def roofline_issue(name, unit, simd_cycles_per_unit, kernel=None):
+    """The roofline these kernels actually sit under: vector-instruction ISSUE.  peak = one wave64 VALU instruction
+    per 2 cycles and SIMD (MI355X_MICROARCH.md; the calibration of profiles/r04_valu_calibration.json measures 2.49 for the fastest
+    class and 4.4 for fp64 / compares / selects / conversions, so a kernel of mixed classes saturates the port well below frac 1);
+    achieved = the counters' vector instructions per unit x 2 cycles / the SIMD-cycles this launch spent per unit."""
+    d = family(name)
+    v = d.get("valu_per_" + unit)
+    if v is None or simd_cycles_per_unit <= 0:
+        return None
+    frac = v * 2.0 / simd_cycles_per_unit
+    out = dict(bound="valu_issue", achieved=round(frac, 4), peak=1.0, unit="fraction of the vector port's issue slots (2 cycles per wave64 VALU instruction)",
+               frac=round(frac, 4), peak_cycles_per_inst=2, valu_per_unit=v, per=unit, simd_cycles_per_unit=round(simd_cycles_per_unit, 1),
+               source=d["source"])
+    if kernel:
+        out["kernel"] = kernel
+    return out
