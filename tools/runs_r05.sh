@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round-5 GPU calls, one function per call (provenance of the gpurun tags the files under profiles/ cite: r05a ...).
+#   usage on the GPU box (through gpurun):  bash tools/runs_r05.sh <letter>        e.g.  gpurun -- 'bash tools/runs_r05.sh a'
+export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; export GRAFT_REPO_ROOT=$R
+
+# first pass: the whole GPU suite after the pruning (with the new lse_oor / all-generic fallback tests), then configs[4]'s per-rank shape
+# rehearsed on the one GPU of the lease (250 000 reads per step) against configs[1] (100 000) on the same box
+call_a() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r05a; mkdir -p $O
+( time timeout 900 python -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+( time timeout 600 python bench.py --gpus 1 --pool 50000 --tile 5 --steps 5 --warmup 2 --legs 0 --streamed 0 ) > $O/bench_250k.json 2> $O/bench_250k.err; echo "rc=$?" >> $O/bench_250k.err
+( time timeout 600 python bench.py --gpus 1 --steps 5 --warmup 2 --legs 0 --streamed 0 --ragged 0 ) > $O/bench_100k.json 2> $O/bench_100k.err; echo "rc=$?" >> $O/bench_100k.err
+tail -6 $O/pytest.log; tail -c 1500 $O/bench_250k.json; tail -4 $O/bench_250k.err; head -c 700 $O/bench_100k.json; tail -4 $O/bench_100k.err
+}
+
+"call_$1"
