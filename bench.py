@@ -425,8 +425,10 @@ def main():
         ctx.sync(stream); torch.cuda.synchronize()
 
     def make_batch(h, tile):
+        # (map_stop=False: call-methylation never reads base_to_event_map[].stop -- get_closest_event_to and the recalibration walk .start,
+        #  squiggle_read.cpp:161-186,339-389; the eventalign leg, whose binding hands the map back to the reference, builds both)
         return CallMethylationBatch(ctx, tile_host_batch(h, tile), dev, calibrate=bool(args.calibrate), from_raw=bool(args.from_raw),
-                                    jobs_on_device=bool(args.jobs_on_device))
+                                    jobs_on_device=bool(args.jobs_on_device), map_stop=False)
 
     def all_reduce(t, op):
         """all-reduce of a device tensor; the gloo rehearsal backend reduces a host copy"""

@@ -282,7 +282,9 @@ int np_resolve_jobs_dev(np_ctx* ctx, void* stream, int n_reads, np_read_dev* rea
                         int64_t n_jobs, np_hmm_job_dev* jobs, const int32_t* kpos);
 
 /* The same glue with load_from_raw's calibration step in between:
- *   event map (start AND stop) -> recalibrate_model(scale_var, no drift; src/nanopolish_methyltrain.cpp:204-306) on the
+ *   event map (start, and stop when map_stop is not NULL: recalibration and the window bounds read .start only; callers that rebuild
+ *   the reference's base_to_event_map -- the eventalign binding -- want both) -> recalibrate_model(scale_var, no drift;
+ *   src/nanopolish_methyltrain.cpp:204-306) on the
  *   'M' entries of get_eventalignment_for_1d_basecalls (src/nanopolish_squiggle_read.cpp:339-389) -> work-item bounds.
  * reads[r] leaves with the calibrated shift/scale/var/log_var (and the HMM transitions); calibrated[r] = 0 marks reads
  * with < 200 'M' events or var > 2.5 (events cleared in the reference, squiggle_read.cpp:320-323): their items are

@@ -453,7 +453,7 @@ void NpBatchPipeline::Impl::pack(Slot& S)
     const size_t s_raw_pa = ls.add(all_adc ? (size_t)raw_off[n] * sizeof(float) : 0);
     const size_t s_tstat = ls.add((size_t)(2 * raw_off[n] + 16) * sizeof(float)), s_ev_len = ls.add((size_t)n_ev * 4), s_ev_mean = ls.add((size_t)n_ev * 4),
                  s_ev_stdv = ls.add((size_t)n_ev * 4), s_ev_start = ls.add((size_t)n_ev * 4), s_map_start = ls.add((size_t)n_rk * 4),
-                 s_map_stop = ls.add((size_t)n_rk * 4), s_pairs = ls.add((size_t)pair_off[n] * sizeof(np_pair)),
+                 s_pairs = ls.add((size_t)pair_off[n] * sizeof(np_pair)),
                  s_job_ranks = ls.add((size_t)jr_off[n] * sizeof(uint16_t));
     add_time(0, now() - tm0); tm0 = now();
     S.in.reserve(c, li.size + 256); S.out.reserve(c, lo.size + 256);
@@ -515,7 +515,7 @@ void NpBatchPipeline::Impl::pack(Slot& S)
                 *n_groups = (int32_t*)(O + S.o_n_groups), *n_events = (int32_t*)(O + S.o_n_events), *n_pairs = (int32_t*)(O + S.o_n_pairs),
                 *calibrated = (int32_t*)(O + S.o_calibrated);
         int32_t *pair_begin = (int32_t*)(X + s_pair_begin), *deg = (int32_t*)(X + s_deg), *kpos = (int32_t*)(X + s_kpos),
-                *map_start = (int32_t*)(X + s_map_start), *map_stop = (int32_t*)(X + s_map_stop);
+                *map_start = (int32_t*)(X + s_map_start);
         double* epb = (double*)(X + s_epb);
         np_hmm_job_dev* jobs = (np_hmm_job_dev*)(X + s_jobs);
         float *tstat = (float*)(X + s_tstat), *ev_len = (float*)(X + s_ev_len), *ev_mean = (float*)(X + s_ev_mean), *ev_stdv = (float*)(X + s_ev_stdv);
@@ -534,7 +534,7 @@ void NpBatchPipeline::Impl::pack(Slot& S)
                                    ev_stdv, n_events), "np_detect_events_dev");
         check(np_mom_fill_dev(c, NULL, n, reads_a, reads_b, ev_mean, n_events, ranks, m_nuc), "np_mom_fill_dev");
         check(np_event_align_dev(c, NULL, n, reads_a, ev_mean, ranks, m_nuc, max_bands, d_pair_off, pairs, pair_begin, n_pairs), "np_event_align_dev");
-        check(np_calibrate_resolve_dev(c, NULL, n, reads_b, ev_mean, ranks, m_nuc, d_pair_off, pairs, pair_begin, n_pairs, map_start, map_stop, epb,
+        check(np_calibrate_resolve_dev(c, NULL, n, reads_b, ev_mean, ranks, m_nuc, d_pair_off, pairs, pair_begin, n_pairs, map_start, NULL /* .stop: not read on this path */, epb,
                                        calibrated, n_jobs, jobs, kpos), "np_calibrate_resolve_dev");
         check(np_cm_discard_degenerate_dev(c, NULL, reads_b, map_start, deg, n_jobs, jobs), "np_cm_discard_degenerate_dev");
         check(np_hmm_score_dev(c, NULL, n_jobs, jobs, reads_b, ev_mean, job_ranks, m_meth, scores), "np_hmm_score_dev");

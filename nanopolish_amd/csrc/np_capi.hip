@@ -708,7 +708,7 @@ int np_calibrate_resolve_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* 
                              double* events_per_base, int32_t* calibrated, int64_t n_jobs, np_hmm_job_dev* jobs,
                              const int32_t* kpos)
 {
-    if (!c || !calibrated || !map_stop) return NP_ERR_INVALID;
+    if (!c || !calibrated) return NP_ERR_INVALID;
     if (model < 0 || model >= (int)c->models.size()) { c->err = "bad model id"; return NP_ERR_INVALID; }
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
@@ -716,8 +716,15 @@ int np_calibrate_resolve_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* 
     family_timer tm(c, 2, s);
     NP_HIP(c, np_launch_build_map(n_reads, reads, pair_off, pairs, pair_begin, n_pairs, map_start, map_stop, events_per_base,
                                   c->params.hmm_indel_bias_factor, s));
+    // the calibration kernel takes several reads per wave and runs for the longest of them: groups of similar length (the aligner's order)
+    const uint32_t* order = nullptr;
+    if (n_reads > 64) {
+        NP_HIP(c, c->align_order.reserve((size_t)(2048 + n_reads) * sizeof(uint32_t)));
+        NP_HIP(c, np_launch_align_order(n_reads, reads, c->align_order.as<uint32_t>(), s));
+        order = c->align_order.as<uint32_t>() + 2048;
+    }
     NP_HIP(c, np_launch_recalibrate(n_reads, reads, event_mean, kmer_rank, c->models[model].d_states, n_pairs, map_start,
-                                    calibrated, s));
+                                    calibrated, order, s));
     NP_HIP(c, np_launch_resolve(n_jobs, jobs, reads, n_pairs, events_per_base, calibrated, map_start, kpos, s));
     return NP_OK;
 }

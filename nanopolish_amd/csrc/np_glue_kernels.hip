@@ -13,6 +13,21 @@
 
 namespace {
 
+// wave_shr:1 / wave_shl:1 of a 32-bit value (lane j <- lane j-1 / j+1; the lane without a source keeps `fill`)
+__device__ __forceinline__ int wave_shr1_i(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int wave_shl1_i(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
+
+// One wave per read, lanes = pairs.  The path kernel A emits is monotone and moves one k-mer and/or one event per step, so
+//   * every k-mer between the path's first and last has a FIRST pair and a LAST pair, and those two lanes are the only writers of
+//     start[k] / stop[k] -- no atomics, and (round 5) no initialisation pass either: the first-pair lane writes -1 itself when the
+//     k-mer has no recording pair; only k-mers outside the path's range (none, for an alignment that passed QC) are filled with -1;
+//   * a pair "records" when its event differs from the previous pair's (:283).  Of the pairs of one k-mer only the first can fail to
+//     record (it shares its event with the previous k-mer); every later pair of that k-mer advanced the event.  Hence
+//       start[k] = event of the k-mer's first pair if that records, else of its second pair if it has one, else -1;
+//       stop[k]  = event of the k-mer's last pair, unless that pair is also its first and does not record (then -1).
+// A lane's neighbours p[i-1], p[i+1] come from the neighbouring lanes (DPP), the chunk's edges from the previous chunk's last lane
+// and one extra load: 4 + 1 loads per 256 pairs (round 4: 16, plus two stores per k-mer of -1).
+template <bool STOP>
 __global__ void __launch_bounds__(64) np_build_map_kernel(int n_reads, np_read_dev* reads, const int64_t* pair_off,
                                                           const np_pair* pairs, const int32_t* pair_begin,
                                                           const int32_t* n_pairs, int32_t* map_start, int32_t* map_stop,
@@ -24,53 +39,57 @@ __global__ void __launch_bounds__(64) np_build_map_kernel(int n_reads, np_read_d
     np_read_dev* rd = reads + ri;
     const int K = (int)rd->n_kmers;
     int32_t* ms = map_start + rd->rank_off;
-    int32_t* mp = map_stop ? map_stop + rd->rank_off : nullptr;
-    for (int k = lane; k < K; k += 64) { ms[k] = -1; if (mp) mp[k] = -1; }      // IndexPair(): start = stop = -1
+    int32_t* mp = STOP ? map_stop + rd->rank_off : nullptr;
     const int np_ = n_pairs[ri];
     if (np_ <= 0) {
-        // failed alignment: events cleared, events_per_base = 0 (squiggle_read.cpp:324-329)
+        // failed alignment: events cleared, events_per_base = 0 (squiggle_read.cpp:324-329); IndexPair(): start = stop = -1
+        for (int k = lane; k < K; k += 64) { ms[k] = -1; if (STOP) mp[k] = -1; }
         if (lane == 0) { events_per_base[ri] = 0.0; np_transitions(0.0, indel_bias, rd->trans); }
         return;
     }
-    __syncthreads();
     const np_pair* p = pairs + pair_off[ri] + pair_begin[ri];
-    // The path kernel A emits is monotone and moves one k-mer and/or one event per step, so every k-mer's start/stop has
-    // exactly one writer and no atomics are needed.  A pair "records" when its event differs from the previous pair's
-    // (:283).  Of the pairs of one k-mer only the first can fail to record (it shares its event with the previous
-    // k-mer); every later pair of that k-mer advanced the event.  Hence
-    //   start[k] = event of the k-mer's first pair if that records, else of its second pair (if it has one);
-    //   stop[k]  = event of the k-mer's last pair, unless that pair is also its first and does not record.
-    // (four chunks of 64 pairs per round, all their loads requested before the first store: one wave per read, bound by the
-    //  memory round trips)
+    const np_pair first = p[0], last = p[np_ - 1];
+    // k-mers the path does not reach (the aligner's QC demands k-mer 0 ... K-1, so these loops are empty for a read that aligned)
+    for (int k = lane; k < first.ref_pos && k < K; k += 64) { ms[k] = -1; if (STOP) mp[k] = -1; }
+    for (int k = last.ref_pos + 1 + lane; k < K; k += 64) { ms[k] = -1; if (STOP) mp[k] = -1; }
+    int carry_ref = -1, carry_read = -1;                       // p[i0 - 1]; prev_event_idx = -1 initially (:281)
+    np_pair c_[4]; np_pair peek;
+    auto load = [&](int i0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u + lane; c_[u] = i < np_ ? p[i] : np_pair{-2, -2}; }
+        peek = i0 + 256 < np_ ? p[i0 + 256] : np_pair{-2, -2};   // (uniform address: one request)
+    };
+    load(0);
     for (int i0 = 0; i0 < np_; i0 += 256) {
-        np_pair c_[4], a_[4], b_[4]; int nxt_[4];
+        np_pair c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = c_[u];
+        const np_pair pk = peek;
+        if (i0 + 256 < np_) load(i0 + 256);                      // the next chunk's loads fly while this one is scattered
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            if (i0 + 64 * u >= np_) break;                        // wave-uniform
+            // previous pair: lane - 1, lane 0 from the previous sub-chunk's lane 63 (or the carry)
+            const int pr_ref = u == 0 ? carry_ref : __builtin_amdgcn_readlane(c[u == 0 ? 0 : u - 1].ref_pos, 63);
+            const int pr_read = u == 0 ? carry_read : __builtin_amdgcn_readlane(c[u == 0 ? 0 : u - 1].read_pos, 63);
+            const int a_ref = wave_shr1_i(c[u].ref_pos, pr_ref), a_read = wave_shr1_i(c[u].read_pos, pr_read);
+            // next pair: lane + 1, lane 63 from the next sub-chunk's lane 0 (or the peeked pair); -2 past the end
+            const int nx_ref0 = u == 3 ? pk.ref_pos : __builtin_amdgcn_readlane(c[u == 3 ? 3 : u + 1].ref_pos, 0);
+            const int nx_read0 = u == 3 ? pk.read_pos : __builtin_amdgcn_readlane(c[u == 3 ? 3 : u + 1].read_pos, 0);
+            const int n_ref = wave_shl1_i(c[u].ref_pos, nx_ref0), n_read = wave_shl1_i(c[u].read_pos, nx_read0);
             const int i = i0 + 64 * u + lane;
-            const bool in = i < np_;
-            c_[u] = in ? p[i] : np_pair{-1, -1};
-            a_[u] = in && i > 0 ? p[i - 1] : np_pair{-1, -1};      // prev_event_idx = -1 initially (:281)
-            b_[u] = in && i > 1 ? p[i - 2] : np_pair{-1, -1};
-            nxt_[u] = in && i + 1 < np_ ? p[i + 1].ref_pos : -2;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + 64 * u + lane;
-            if (i >= np_) continue;
-            const np_pair c = c_[u], a = a_[u], b = b_[u];
-            const bool first_of_k = a.ref_pos != c.ref_pos;
-            const bool records = c.read_pos != a.read_pos;
-            bool is_start = first_of_k && records;
-            if (!first_of_k) is_start = b.ref_pos != c.ref_pos && a.read_pos == b.read_pos;   // second pair of k: start if the first did not record
-            if (is_start) ms[c.ref_pos] = c.read_pos;
-            if (mp) {
-                const bool last_of_k = nxt_[u] != c.ref_pos;
-                if (last_of_k && (records || !first_of_k)) mp[c.ref_pos] = c.read_pos;
+            if (i < np_) {
+                const int k = c[u].ref_pos, e = c[u].read_pos;
+                const bool first_of_k = a_ref != k, last_of_k = n_ref != k;
+                const bool records = e != a_read;
+                if (first_of_k) ms[k] = records ? e : (last_of_k ? -1 : n_read);
+                if (STOP && last_of_k) mp[k] = (records || !first_of_k) ? e : -1;
             }
         }
+        carry_ref = __builtin_amdgcn_readlane(c[3].ref_pos, 63); carry_read = __builtin_amdgcn_readlane(c[3].read_pos, 63);
     }
     if (lane == 0) {
-        const size_t min_event = (size_t)p[0].read_pos, max_event = (size_t)p[np_ - 1].read_pos;  // path is monotone
+        const size_t min_event = (size_t)first.read_pos, max_event = (size_t)last.read_pos;        // path is monotone
         const double epb = (double)(max_event - min_event) / (double)(size_t)K;                    // :301
         events_per_base[ri] = epb;
         np_transitions(epb, indel_bias, rd->trans);
@@ -94,6 +113,13 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l);
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ int64_t uniform_i64(int64_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
 __device__ __forceinline__ void fullpivlu_solve_2x2(double a00, double a01, double a10, double a11, double b0, double b1,
@@ -121,139 +147,188 @@ __device__ __forceinline__ void fullpivlu_solve_2x2(double a00, double a01, doub
     if (pc == 1) { x0 = y1; x1 = y0; } else { x0 = y0; x1 = y1; }
 }
 
+// Round 5: NP_RC_R reads per wave.  The ordered sums are serial chains -- one fp64 addition per term and sum, in k-mer order, whatever
+// the hardware -- but a chain needs ONE LANE: with one read per wave (round 4) the 64-step serial phase of every chunk ran with 5 of 64
+// lanes busy and was two thirds of the kernel's instructions (7.7 ms per 100 000 reads, 76 % of its wave-cycles waiting).  Here the
+// wave forms the terms of a 64-k-mer chunk of EACH of its reads (lanes = k-mers, one LDS tile per read), then lane (r, c) adds the 64
+// terms of sum c of read r: one serial phase per NP_RC_R reads, and NP_RC_R reads' loads in flight per round trip.  What bounds
+// NP_RC_R is the LDS: a tile is 5 x 65 doubles (2.6 KB; the row stride keeps the 5 NP_RC_R readers on distinct banks).
+// A read shorter than its group's longest contributes zero terms past its end (a zero term leaves a non-negative-zero sum unchanged),
+// so the groups are made of reads of similar length (the aligner's longest-first order) only for efficiency.
+#define NP_RC_R 4
 __global__ void __launch_bounds__(64) np_recalibrate_kernel(int n_reads, np_read_dev* reads, const float* event_mean,
                                                             const uint16_t* ranks, const np_state_dev* model,
                                                             const int32_t* n_pairs, const int32_t* map_start,
-                                                            int32_t* calibrated)
+                                                            int32_t* calibrated, const uint32_t* order)
 {
-    const int ri = blockIdx.x;
-    if (ri >= n_reads) return;
+    constexpr int R = NP_RC_R;
     const int lane = threadIdx.x;
-    np_read_dev* rd = reads + ri;
-    if (n_pairs[ri] <= 0) { if (lane == 0) calibrated[ri] = 0; return; }
-    const int K = (int)rd->n_kmers;
-    const int32_t* ms = map_start + rd->rank_off;
-    const uint16_t* rk = ranks + rd->rank_off;
-    const float* ev = event_mean + rd->event_off;
-
-    __shared__ double terms[5][66];                              // row stride 66: the five readers hit distinct banks
-    double shift = 0.0, scale = 0.0;
-    double acc = 0.0;                                            // lane 0..4: a00, a01, a11, b0, b1; then lane 0: var
-    long long n = 0;
+    __shared__ double terms[R][5][65];
+    int ri[R], K[R]; bool live[R];
+    const int32_t* ms[R]; const uint16_t* rk[R]; const float* ev[R];
+    int maxK = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int slot = blockIdx.x * R + r;
+        // (readfirstlane: the per-read values are wave-uniform; told so, the compiler keeps them and the loop control in scalar registers)
+        ri[r] = slot < n_reads ? __builtin_amdgcn_readfirstlane(order ? (int)order[slot] : slot) : -1;
+        live[r] = false; K[r] = 0; ms[r] = nullptr; rk[r] = nullptr; ev[r] = nullptr;
+        if (ri[r] >= 0) {
+            if (__builtin_amdgcn_readfirstlane(n_pairs[ri[r]]) <= 0) { if (lane == 0) calibrated[ri[r]] = 0; }
+            else {
+                const np_read_dev* rd = reads + ri[r];
+                live[r] = true; K[r] = __builtin_amdgcn_readfirstlane((int)rd->n_kmers);
+                const int64_t ro = uniform_i64(rd->rank_off), eo = uniform_i64(rd->event_off);
+                ms[r] = map_start + ro; rk[r] = ranks + ro; ev[r] = event_mean + eo;
+                maxK = K[r] > maxK ? K[r] : maxK;
+            }
+        }
+    }
+    double shift[R], scale[R];
+    long long n[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { shift[r] = 0.0; scale[r] = 0.0; n[r] = 0; }
+    // serial-phase role of this lane: pass 0 lane 5 r + c owns sum c of read r; pass 1 lane r owns read r's residual sum
+    const int sr0 = lane / 5, sc0 = lane - 5 * sr0;
+    double acc = 0.0;
     for (int pass = 0; pass < 2; ++pass) {
-        int carry_rank = -1;                                     // prev_kmer_rank = -1 (squiggle_read.cpp:351)
-        // NP_RC_U chunks of 64 k-mers per round: their map entries and ranks are requested together, then the model states and
-        // event means they point at (for every k-mer that has events: a superset of the 'M' entries), then the chunks are
-        // consumed in order -- two dependent memory round trips per round instead of per chunk (the kernel is one wave per read
-        // and bound by exactly those round trips).
-#define NP_RC_U 4
-        for (int base0 = 0; base0 < K; base0 += 64 * NP_RC_U) {
-            int st_[NP_RC_U], rank_[NP_RC_U];
-            double ls_[NP_RC_U], mu_[NP_RC_U]; float e_[NP_RC_U];
+        int carry_rank[R];                                       // prev_kmer_rank = -1 (squiggle_read.cpp:351)
 #pragma unroll
-            for (int u = 0; u < NP_RC_U; ++u) {
-                const int ki = base0 + 64 * u + lane;
-                st_[u] = ki < K ? ms[ki] : -1;
-                rank_[u] = ki < K ? (int)rk[ki] : 0;
+        for (int r = 0; r < R; ++r) carry_rank[r] = -1;
+        const double* row = pass == 0 ? &terms[sr0 < R ? sr0 : 0][sc0][0] : &terms[lane < R ? lane : 0][0][0];
+        const bool adder = pass == 0 ? lane < 5 * R : lane < R;
+        for (int base0 = 0; base0 < maxK; base0 += 64) {
+            int st_[R], rank_[R];
+            double ls_[R], mu_[R]; float e_[R];
+            const int ki = base0 + lane;
+            // the R reads' map entries and ranks are requested together, then the model states and event means they point at (for
+            // every k-mer that has events: a superset of the 'M' entries): two dependent round trips per chunk for all R reads
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const bool in = live[r] && ki < K[r];
+                st_[r] = in ? ms[r][ki] : -1;
+                rank_[r] = in ? (int)rk[r][ki] : 0;
             }
 #pragma unroll
-            for (int u = 0; u < NP_RC_U; ++u) {
-                const bool has = st_[u] != -1;
-                ls_[u] = has ? model[rank_[u]].level_stdv : 1.0;
-                mu_[u] = has ? model[rank_[u]].level_mean : 0.0;
-                e_[u] = has ? ev[st_[u]] : 0.0f;                 // raw_events: get_unscaled_level of the run's first event
+            for (int r = 0; r < R; ++r) {
+                const bool has = st_[r] != -1;
+                ls_[r] = has ? model[rank_[r]].level_stdv : 1.0;
+                mu_[r] = has ? model[rank_[r]].level_mean : 0.0;
+                e_[r] = has ? ev[r][st_[r]] : 0.0f;              // raw_events: get_unscaled_level of the run's first event
             }
+            unsigned long long any = 0ull;
 #pragma unroll
-            for (int u = 0; u < NP_RC_U; ++u) {
-                if (base0 + 64 * u >= K) break;                   // wave-uniform
-                const int st = st_[u];
+            for (int r = 0; r < R; ++r) {
+                const int st = st_[r];
                 const bool has = st != -1;
-                const int rank = has ? rank_[u] : -1;
+                const int rank = has ? rank_[r] : -1;
                 const unsigned long long hm = __ballot(has);
                 const unsigned long long before = hm & ((1ull << lane) - 1ull);
                 const int src = before ? 63 - __clzll((long long)before) : 0;
                 const int prev = __shfl(rank, src, 64);
-                const bool isM = has && rank != (before ? prev : carry_rank);
+                const bool isM = has && rank != (before ? prev : carry_rank[r]);
                 double t0 = 0., t1 = 0., t2 = 0., t3 = 0., t4 = 0.;
                 if (isM) {
-                    const double ls = ls_[u], mu = mu_[u];
-                    const double e = (double)e_[u];
+                    const double ls = ls_[r], mu = mu_[r];
+                    const double e = (double)e_[r];
                     if (pass == 0) {
                         const double inv_var = 1. / (ls * ls);
                         t0 = inv_var; t1 = mu * inv_var; t2 = mu * mu * inv_var; t3 = e * inv_var; t4 = mu * e * inv_var;
                     } else {
-                        const double yi = (e - shift - scale * mu);
+                        const double yi = (e - shift[r] - scale[r] * mu);
                         t0 = yi * yi / (ls * ls);
                     }
                 }
-                // ordered accumulation: the terms go through LDS, lane c (0..4) owns sum c and adds its 64 terms in k-mer order
-                // (a zero term leaves a non-negative-zero sum unchanged, so lanes that are not 'M' entries need no masking)
-                if (__ballot(isM)) {
-                    __syncthreads();
-                    terms[0][lane] = t0;
-                    if (pass == 0) { terms[1][lane] = t1; terms[2][lane] = t2; terms[3][lane] = t3; terms[4][lane] = t4; }
-                    __syncthreads();
-                    if (lane < (pass == 0 ? 5 : 1)) {
-                        const double* row = terms[lane];
-#pragma unroll 16
-                        for (int q = 0; q < 64; ++q) acc += row[q];
-                    }
-                    n += __popcll(__ballot(isM));
-                }
-                if (hm) carry_rank = __shfl(rank, 63 - __clzll((long long)hm), 64);
+                terms[r][0][lane] = t0;
+                if (pass == 0) { terms[r][1][lane] = t1; terms[r][2][lane] = t2; terms[r][3][lane] = t3; terms[r][4][lane] = t4; }
+                const unsigned long long mm = __ballot(isM);
+                n[r] += __popcll(mm);
+                any |= mm;
+                if (hm) carry_rank[r] = __shfl(rank, 63 - __clzll((long long)hm), 64);
             }
+            // ordered accumulation: lane (r, c) adds its 64 terms in k-mer order (a zero term leaves a non-negative-zero sum unchanged,
+            // so lanes that are not 'M' entries, and reads that have ended, need no masking)
+            __syncthreads();
+            if (any && adder) {
+#pragma unroll 16
+                for (int q = 0; q < 64; ++q) acc += row[q];
+            }
+            __syncthreads();
         }
-#undef NP_RC_U
         if (pass == 0) {
-            if (n < 200) { if (lane == 0) calibrated[ri] = 0; return; }      // minNumEventsToRescale: not recalibrated
-            const double a00 = readlane_f64(acc, 0), a01 = readlane_f64(acc, 1), a11 = readlane_f64(acc, 2);
-            const double b0 = readlane_f64(acc, 3), b1 = readlane_f64(acc, 4);
-            fullpivlu_solve_2x2(a00, a01, a01, a11, b0, b1, shift, scale);
-            n = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (!live[r]) continue;
+                if (n[r] < 200) { if (lane == 0) calibrated[ri[r]] = 0; live[r] = false; continue; }      // minNumEventsToRescale: not recalibrated
+                const double a00 = readlane_f64(acc, 5 * r), a01 = readlane_f64(acc, 5 * r + 1), a11 = readlane_f64(acc, 5 * r + 2);
+                const double b0 = readlane_f64(acc, 5 * r + 3), b1 = readlane_f64(acc, 5 * r + 4);
+                fullpivlu_solve_2x2(a00, a01, a01, a11, b0, b1, shift[r], scale[r]);
+                n[r] = 0;
+            }
             acc = 0.0;
+            maxK = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) if (live[r] && K[r] > maxK) maxK = K[r];
         }
     }
-    double var = readlane_f64(acc, 0);
-    var /= (double)(unsigned long long)n;
-    var = sqrt(var);
-    if (lane == 0) {
-        rd->shift = shift; rd->scale = scale; rd->var = var; rd->log_var = np_log_glibc(var);   // set4 (squiggle_read.cpp:38-65), glibc's log restated
-        calibrated[ri] = var > 2.5 ? 0 : 1;                                            // MIN_CALIBRATION_VAR (:320)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (!live[r]) continue;
+        double var = readlane_f64(acc, r);
+        var /= (double)(unsigned long long)n[r];
+        var = sqrt(var);
+        if (lane == 0) {
+            np_read_dev* rd = reads + ri[r];
+            rd->shift = shift[r]; rd->scale = scale[r]; rd->var = var; rd->log_var = np_log_glibc(var);   // set4 (squiggle_read.cpp:38-65), glibc's log restated
+            calibrated[ri[r]] = var > 2.5 ? 0 : 1;                                          // MIN_CALIBRATION_VAR (:320)
+        }
     }
 }
 
+// Thread per PAIR of consecutive work items: the two sequences of a methylation group (unmethylated, methylated) sit side by side
+// and share their window bounds, so one pair of closest-event searches (two dependent gathers into the map) serves both -- checked,
+// not assumed: items of different reads or bounds each get their own.
+__device__ __forceinline__ bool resolve_bounds(const np_read_dev* rd, const int32_t* map_start, int k1, int k2, int& e1, int& e2)
+{
+    const int32_t* ms = map_start + rd->rank_off;
+    const int K = (int)rd->n_kmers;
+    if (k1 < 0 || k1 >= K || k2 < 0 || k2 >= K) return false;
+    e1 = closest_event(ms, K, k1);
+    e2 = closest_event(ms, K, k2);
+    const int d = e2 - e1;
+    return !(e1 < 0 || e2 < 0 || (d < 0 ? -d : d) <= 10);                        // basemods.cpp:356
+}
+__device__ __forceinline__ void resolve_store(np_hmm_job_dev* dst, np_hmm_job_dev job, bool ok, int e1, int e2)
+{
+    if (ok) {
+        job.e_start = (uint32_t)e1; job.e_stop = (uint32_t)e2;
+        job.stride = e1 <= e2 ? 1 : -1;                                          // basemods.cpp:370
+        job.flags &= ~NP_JOB_SKIP;
+    } else {
+        job.e_start = 0; job.e_stop = 0; job.stride = 1;
+        job.flags |= NP_JOB_SKIP;                                                // classify drops it, score = NaN
+    }
+    *dst = job;
+}
 __global__ void __launch_bounds__(256) np_resolve_kernel(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads,
                                                          const int32_t* n_pairs, const double* events_per_base,
                                                          const int32_t* calibrated, const int32_t* map_start, const int32_t* kpos)
 {
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t j = 2 * ((int64_t)blockIdx.x * 256 + threadIdx.x);
     if (j >= n_jobs) return;
-    np_hmm_job_dev job = jobs[j];
-    const np_read_dev* rd = reads + job.read;
+    const bool two = j + 1 < n_jobs;
+    const np_hmm_job_dev ja = jobs[j], jb = two ? jobs[j + 1] : ja;
+    const int ka1 = kpos[2 * j], ka2 = kpos[2 * j + 1];
+    const int kb1 = two ? kpos[2 * j + 2] : ka1, kb2 = two ? kpos[2 * j + 3] : ka2;
     // failed alignment, failed calibration (squiggle_read.cpp:320-323) or events-per-base QC (:332): no events, no scoring
-    bool ok = n_pairs[job.read] > 0 && !(events_per_base[job.read] > 5.0) && (!calibrated || calibrated[job.read] != 0);
+    auto read_ok = [&](uint32_t r) { return n_pairs[r] > 0 && !(events_per_base[r] > 5.0) && (!calibrated || calibrated[r] != 0); };
     int e1 = -1, e2 = -1;
-    if (ok) {
-        const int32_t* ms = map_start + rd->rank_off;
-        const int K = (int)rd->n_kmers;
-        const int k1 = kpos[2 * j], k2 = kpos[2 * j + 1];
-        if (k1 < 0 || k1 >= K || k2 < 0 || k2 >= K) ok = false;
-        else {
-            e1 = closest_event(ms, K, k1);
-            e2 = closest_event(ms, K, k2);
-            const int d = e2 - e1;
-            if (e1 < 0 || e2 < 0 || (d < 0 ? -d : d) <= 10) ok = false;     // basemods.cpp:356
-        }
-    }
-    if (ok) {
-        job.e_start = (uint32_t)e1; job.e_stop = (uint32_t)e2;
-        job.stride = e1 <= e2 ? 1 : -1;                                      // basemods.cpp:370
-        job.flags &= ~NP_JOB_SKIP;
-    } else {
-        job.e_start = 0; job.e_stop = 0; job.stride = 1;
-        job.flags |= NP_JOB_SKIP;                                            // classify drops it, score = NaN
-    }
-    jobs[j] = job;
+    const bool oka = read_ok(ja.read) && resolve_bounds(reads + ja.read, map_start, ka1, ka2, e1, e2);
+    resolve_store(jobs + j, ja, oka, e1, e2);
+    if (!two) return;
+    bool okb = oka;
+    if (jb.read != ja.read || kb1 != ka1 || kb2 != ka2) { e1 = -1; e2 = -1; okb = read_ok(jb.read) && resolve_bounds(reads + jb.read, map_start, kb1, kb2, e1, e2); }
+    resolve_store(jobs + j + 1, jb, okb, e1, e2);
 }
 
 // (size_class / job_bin: np_kernels.h -- the host entry points bin small batches themselves)
@@ -341,8 +416,10 @@ hipError_t np_launch_build_map(int n_reads, np_read_dev* reads, const int64_t* p
                                double* events_per_base, double indel_bias, hipStream_t s)
 {
     if (n_reads <= 0) return hipSuccess;
-    hipLaunchKernelGGL(np_build_map_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, reads, pair_off, pairs,
-                       pair_begin, n_pairs, map_start, map_stop, events_per_base, indel_bias);
+    if (map_stop) hipLaunchKernelGGL(np_build_map_kernel<true>, dim3(n_reads), dim3(64), 0, s, n_reads, reads, pair_off, pairs,
+                                     pair_begin, n_pairs, map_start, map_stop, events_per_base, indel_bias);
+    else hipLaunchKernelGGL(np_build_map_kernel<false>, dim3(n_reads), dim3(64), 0, s, n_reads, reads, pair_off, pairs,
+                            pair_begin, n_pairs, map_start, map_stop, events_per_base, indel_bias);
     return hipGetLastError();
 }
 
@@ -383,7 +460,7 @@ hipError_t np_launch_resolve(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read
                              const int32_t* kpos, hipStream_t s)
 {
     if (n_jobs <= 0) return hipSuccess;
-    hipLaunchKernelGGL(np_resolve_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(np_resolve_kernel, dim3((unsigned)(((n_jobs + 1) / 2 + 255) / 256)), dim3(256), 0, s,
                        n_jobs, jobs, reads, n_pairs, events_per_base, calibrated, map_start, kpos);
     return hipGetLastError();
 }
@@ -506,10 +583,10 @@ hipError_t np_launch_selftest_div(uint64_t n_samples, uint64_t seed, unsigned lo
 
 hipError_t np_launch_recalibrate(int n_reads, np_read_dev* reads, const float* event_mean, const uint16_t* ranks,
                                  const np_state_dev* model, const int32_t* n_pairs, const int32_t* map_start,
-                                 int32_t* calibrated, hipStream_t s)
+                                 int32_t* calibrated, const uint32_t* order, hipStream_t s)
 {
     if (n_reads <= 0) return hipSuccess;
-    hipLaunchKernelGGL(np_recalibrate_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, reads, event_mean, ranks, model,
-                       n_pairs, map_start, calibrated);
+    hipLaunchKernelGGL(np_recalibrate_kernel, dim3((n_reads + NP_RC_R - 1) / NP_RC_R), dim3(64), 0, s, n_reads, reads, event_mean, ranks, model,
+                       n_pairs, map_start, calibrated, order);
     return hipGetLastError();
 }

@@ -249,13 +249,15 @@ def tile_host_batch(hb, tile):
 
 class CallMethylationBatch:
     def __init__(self, ctx, hb, device="cuda:0", calibrate=False, from_raw=False, jobs_on_device=False, workload="call-methylation", rna=False,
-                 base_model="nucleotide"):
+                 base_model="nucleotide", map_stop=True):
         """calibrate=False: kernel B scores with the scalings the caller put in hb["reads_b"] (a read whose
         calibration was done elsewhere).  calibrate=True: the pass recalibrates every read on the device from its
         own event alignment, as load_from_raw does (squiggle_read.cpp:304-323), and reads_b is overwritten.
         rna=True (from_raw, workload "eventalign"): direct-RNA reads as load_from_raw treats them (squiggle_read.cpp:206-213,260-263):
         the RNA detector parameters, the events reversed after the MoM scalings, the base model registered as `base_model`
-        (r9.4_70bps / u_to_t_rna / 5-mers; hb built with k = 5)."""
+        (r9.4_70bps / u_to_t_rna / 5-mers; hb built with k = 5).
+        map_stop=False (calibrate=True): base_to_event_map[].stop is not built -- recalibration and the window bounds read .start only
+        (squiggle_read.cpp:161-186,339-389); the eventalign workload, which hands the map back to the reference, always builds it."""
         import torch
         self.torch = torch
         self.calibrate = bool(calibrate)
@@ -345,7 +347,8 @@ class CallMethylationBatch:
         self.d_n_pairs = torch.zeros(self.n_reads, dtype=torch.int32, device=dev)
         self.d_map = torch.empty(len(hb["ranks"]), dtype=torch.int32, device=dev)
         self.d_epb = torch.zeros(self.n_reads, dtype=torch.float64, device=dev)
-        self.d_map_stop = torch.empty(len(hb["ranks"]) if self.calibrate else 1, dtype=torch.int32, device=dev)
+        self.want_map_stop = self.calibrate and (bool(map_stop) or workload == "eventalign")
+        self.d_map_stop = torch.empty(len(hb["ranks"]) if self.want_map_stop else 1, dtype=torch.int32, device=dev)
         self.d_calibrated = torch.ones(self.n_reads, dtype=torch.int32, device=dev)
         self.d_scores = torch.zeros(max(self.n_jobs, 1), dtype=torch.float32, device=dev)
         self.alphabet = hb.get("alphabet", "cpg")      # the methylation alphabet whose model scores the work items
@@ -416,7 +419,7 @@ class CallMethylationBatch:
         if self.calibrate:
             rc = L.np_calibrate_resolve_dev(h, s, self.n_reads, p(self.d_reads_b), p(self.d_events), p(self.d_ranks),
                                             self.m_nuc, p(self.d_pair_off), p(self.d_pairs), p(self.d_pair_begin),
-                                            p(self.d_n_pairs), p(self.d_map), p(self.d_map_stop), p(self.d_epb),
+                                            p(self.d_n_pairs), p(self.d_map), p(self.d_map_stop) if self.want_map_stop else None, p(self.d_epb),
                                             p(self.d_calibrated), n_jobs, p(self.d_jobs), p(self.d_kpos))
             self.ctx._chk(rc, "np_calibrate_resolve_dev")
         else:
@@ -531,7 +534,7 @@ class CallMethylationBatch:
 
     def event_map(self):
         self.sync()
-        return self.d_map.cpu().numpy(), (self.d_map_stop.cpu().numpy() if self.calibrate else None)
+        return self.d_map.cpu().numpy(), (self.d_map_stop.cpu().numpy() if self.want_map_stop else None)
 
     def groups_bulk(self, n):
         """groups_of(r) for reads 0..n-1 with one transfer per array: list of (first, n_motif, unmeth, meth)."""

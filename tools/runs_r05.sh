@@ -14,4 +14,17 @@ O=gpurun_out/r05a; mkdir -p $O
 tail -6 $O/pytest.log; tail -c 1500 $O/bench_250k.json; tail -4 $O/bench_250k.err; head -c 700 $O/bench_100k.json; tail -4 $O/bench_100k.err
 }
 
+# glue rewrite (multi-read recalibration, map without an init pass, bounds per pair of work items): parity suite, then the step's kernels by name
+call_b() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r05${TAG:-b}; mkdir -p $O
+( time timeout 900 python -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o p -- python $R/bench.py --steps 3 --warmup 1 --legs 0 --streamed 0 --ragged 0 --cpu-sample 0 > $R/$O/bench.json 2> $R/$O/bench.err )
+python profiles/summarize_rocpd.py $(find $O/prof -name "*_results.db" | head -1) > $O/kernels.txt 2>&1
+tail -5 $O/pytest.log; head -40 $O/kernels.txt; head -c 400 $O/bench.json; python - <<EOF
+import json
+d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"], d["roofline"]["kernel_ms_per_step"])
+EOF
+}
+
 "call_$1"
