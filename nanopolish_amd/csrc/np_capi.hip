@@ -88,6 +88,7 @@ struct np_ctx {
     std::string err;
     int align_blocks_per_cu = 8, hmm_blocks_per_cu = 2;
     int hmm_prio = 0;                 // wave priority of the forward kernels
+    int recal_shape = 0;              // np_recalibrate_kernel's workgroup shape (0: default; 1, 2: A/B alternatives, same results)
     int align_lpt = 1;                // issue the event aligner's reads longest first
     int stream_switch_wait = 1;       // a call on a new stream waits for the tail of the stream the context used before (0: the caller orders its streams itself)
     int ed_warmup = -1;               // parallel peak walk: samples of warm-up per segment (< 0: the kernel's default)
@@ -334,6 +335,7 @@ np_ctx* np_create(int device, const np_params* params)
     if (const char* v = getenv("NP_ALIGN_BLOCKS_PER_CU")) c->align_blocks_per_cu = std::max(1, atoi(v));
     if (const char* v = getenv("NP_HMM_BLOCKS_PER_CU")) c->hmm_blocks_per_cu = std::max(1, atoi(v));
     if (const char* v = getenv("NP_ALIGN_LPT")) c->align_lpt = atoi(v) != 0;
+    if (const char* v = getenv("NP_RECAL_SHAPE")) c->recal_shape = std::max(0, std::min(2, atoi(v)));
     if (const char* v = getenv("NP_ED_WARMUP")) c->ed_warmup = atoi(v);
     if (const char* v = getenv("NP_EA_WAVES_PER_CU")) c->ea_waves_per_cu = std::max(1, atoi(v));
     if (const char* v = getenv("NP_EA_WALK_PRIO")) c->ea_walk_prio = atoi(v);
@@ -723,8 +725,8 @@ int np_calibrate_resolve_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* 
         NP_HIP(c, np_launch_align_order(n_reads, reads, c->align_order.as<uint32_t>(), s));
         order = c->align_order.as<uint32_t>() + 2048;
     }
-    NP_HIP(c, np_launch_recalibrate(n_reads, reads, event_mean, kmer_rank, c->models[model].d_states, n_pairs, map_start,
-                                    calibrated, order, s));
+    NP_HIP(c, np_launch_recalibrate(n_reads, reads, event_mean, kmer_rank, c->models[model].d_states, c->models[model].n_states, n_pairs, map_start,
+                                    calibrated, order, c->recal_shape, s));
     NP_HIP(c, np_launch_resolve(n_jobs, jobs, reads, n_pairs, events_per_base, calibrated, map_start, kpos, s));
     return NP_OK;
 }
@@ -1212,6 +1214,7 @@ int np_set_option(np_ctx* c, const char* name, int64_t value)
     else if (k == "hmm_prio") c->hmm_prio = (int)std::min<int64_t>(2, std::max<int64_t>(0, value));
     else if (k == "hmm_blocks_per_cu") c->hmm_blocks_per_cu = (int)std::max<int64_t>(1, value);
     else if (k == "align_lpt") c->align_lpt = value != 0;
+    else if (k == "recal_shape") c->recal_shape = (int)std::min<int64_t>(2, std::max<int64_t>(0, value));
     else if (k == "stream_switch_wait") c->stream_switch_wait = value != 0;
     else if (k == "small_batch_path") c->small_batch_path = value != 0;
     else if (k == "ed_warmup") c->ed_warmup = (int)value;

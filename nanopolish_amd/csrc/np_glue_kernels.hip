@@ -147,29 +147,35 @@ __device__ __forceinline__ void fullpivlu_solve_2x2(double a00, double a01, doub
     if (pc == 1) { x0 = y1; x1 = y0; } else { x0 = y0; x1 = y1; }
 }
 
-// Round 5: NP_RC_R reads per wave.  The ordered sums are serial chains -- one fp64 addition per term and sum, in k-mer order, whatever
-// the hardware -- but a chain needs ONE LANE: with one read per wave (round 4) the 64-step serial phase of every chunk ran with 5 of 64
-// lanes busy and was two thirds of the kernel's instructions (7.7 ms per 100 000 reads, 76 % of its wave-cycles waiting).  Here the
-// wave forms the terms of a 64-k-mer chunk of EACH of its reads (lanes = k-mers, one LDS tile per read), then lane (r, c) adds the 64
-// terms of sum c of read r: one serial phase per NP_RC_R reads, and NP_RC_R reads' loads in flight per round trip.  What bounds
-// NP_RC_R is the LDS: a tile is 5 x 65 doubles (2.6 KB; the row stride keeps the 5 NP_RC_R readers on distinct banks).
+// Round 5.  Two things bounded round 4's kernel (one read per 64-thread workgroup, 7.7 ms per 100 000 reads, 76 % of its wave-cycles
+// waiting): (1) the model look-ups -- two doubles out of a 32-byte state per k-mer, 64 random 128-byte lines per wave instruction from a
+// table that does not fit the L1: ~170 GB of L2 -> L1 traffic per pass over the batch; (2) the ordered sums -- one fp64 addition per
+// term and sum, in k-mer order, whatever the hardware: a serial phase of 64 steps per chunk with 5 of 64 lanes busy.
+// Now a workgroup of W waves keeps the model in LDS -- (level_mean, 1 / level_stdv^2) for the first pass, (level_mean, level_stdv^2)
+// for the second, 64 KB for the 4 096 states of a 6-mer base model, the division done once per state and workgroup instead of once per
+// term -- and a wave carries R reads: it forms the terms of a 64-k-mer chunk of EACH of its reads (lanes = k-mers, one LDS tile of
+// 5 x 65 doubles per read; the row stride keeps the serial readers on distinct banks), then lane (r, c) adds the 64 terms of sum c of
+// read r -- one serial phase per R reads.  The next chunk's map entries and ranks are requested before the current chunk is consumed.
 // A read shorter than its group's longest contributes zero terms past its end (a zero term leaves a non-negative-zero sum unchanged),
-// so the groups are made of reads of similar length (the aligner's longest-first order) only for efficiency.
-#define NP_RC_R 4
-__global__ void __launch_bounds__(64) np_recalibrate_kernel(int n_reads, np_read_dev* reads, const float* event_mean,
-                                                            const uint16_t* ranks, const np_state_dev* model,
-                                                            const int32_t* n_pairs, const int32_t* map_start,
-                                                            int32_t* calibrated, const uint32_t* order)
+// so the groups are made of reads of similar length (the aligner's longest-first order) only for efficiency.  Same terms, same order,
+// same roundings as before: shift / scale / var / log_var bit-identical (tests/test_gpu_parity.py::test_calibrated_pass...).
+// TABLE = false: a base model of more than NP_RC_STATES states (none of the kits') reads the states from memory as round 4 did.
+#define NP_RC_STATES 4096
+template <int W, int R, bool TABLE>
+__global__ void __launch_bounds__(64 * W) np_recalibrate_kernel(int n_reads, np_read_dev* reads, const float* event_mean,
+                                                                const uint16_t* ranks, const np_state_dev* model, int n_states,
+                                                                const int32_t* n_pairs, const int32_t* map_start,
+                                                                int32_t* calibrated, const uint32_t* order)
 {
-    constexpr int R = NP_RC_R;
-    const int lane = threadIdx.x;
-    __shared__ double terms[R][5][65];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    __shared__ double terms[W][R][5][65];
+    __shared__ double2 table[TABLE ? NP_RC_STATES : 1];         // .x = level_mean, .y = 1 / level_stdv^2 (pass 0) or level_stdv^2 (pass 1)
     int ri[R], K[R]; bool live[R];
     const int32_t* ms[R]; const uint16_t* rk[R]; const float* ev[R];
     int maxK = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int slot = blockIdx.x * R + r;
+        const int slot = (blockIdx.x * W + wave) * R + r;
         // (readfirstlane: the per-read values are wave-uniform; told so, the compiler keeps them and the loop control in scalar registers)
         ri[r] = slot < n_reads ? __builtin_amdgcn_readfirstlane(order ? (int)order[slot] : slot) : -1;
         live[r] = false; K[r] = 0; ms[r] = nullptr; rk[r] = nullptr; ev[r] = nullptr;
@@ -192,29 +198,46 @@ __global__ void __launch_bounds__(64) np_recalibrate_kernel(int n_reads, np_read
     const int sr0 = lane / 5, sc0 = lane - 5 * sr0;
     double acc = 0.0;
     for (int pass = 0; pass < 2; ++pass) {
+        if (TABLE) {
+            if (pass == 1) __syncthreads();                      // every wave is done with the first pass's table
+            for (int q = threadIdx.x; q < n_states; q += 64 * W) {
+                const double ls = model[q].level_stdv, v = ls * ls;
+                table[q] = double2{model[q].level_mean, pass == 0 ? 1. / v : v};
+            }
+            __syncthreads();
+        }
         int carry_rank[R];                                       // prev_kmer_rank = -1 (squiggle_read.cpp:351)
 #pragma unroll
         for (int r = 0; r < R; ++r) carry_rank[r] = -1;
-        const double* row = pass == 0 ? &terms[sr0 < R ? sr0 : 0][sc0][0] : &terms[lane < R ? lane : 0][0][0];
+        const double* row = pass == 0 ? &terms[wave][sr0 < R ? sr0 : 0][sc0][0] : &terms[wave][lane < R ? lane : 0][0][0];
         const bool adder = pass == 0 ? lane < 5 * R : lane < R;
-        for (int base0 = 0; base0 < maxK; base0 += 64) {
-            int st_[R], rank_[R];
-            double ls_[R], mu_[R]; float e_[R];
+        int st_n[R], rank_n[R];                                  // the NEXT chunk's map entries and ranks (requested a chunk ahead)
+        auto request = [&](int base0) {
             const int ki = base0 + lane;
-            // the R reads' map entries and ranks are requested together, then the model states and event means they point at (for
-            // every k-mer that has events: a superset of the 'M' entries): two dependent round trips per chunk for all R reads
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const bool in = live[r] && ki < K[r];
-                st_[r] = in ? ms[r][ki] : -1;
-                rank_[r] = in ? (int)rk[r][ki] : 0;
+                st_n[r] = in ? ms[r][ki] : -1;
+                rank_n[r] = in ? (int)rk[r][ki] : 0;
             }
+        };
+        request(0);
+        for (int base0 = 0; base0 < maxK; base0 += 64) {
+            int st_[R], rank_[R];
+            double mu_[R], x_[R]; float e_[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) { st_[r] = st_n[r]; rank_[r] = rank_n[r]; }
+            if (base0 + 64 < maxK) request(base0 + 64);
+            // the event means the map entries point at (for every k-mer that has events: a superset of the 'M' entries) and the states
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const bool has = st_[r] != -1;
-                ls_[r] = has ? model[rank_[r]].level_stdv : 1.0;
-                mu_[r] = has ? model[rank_[r]].level_mean : 0.0;
                 e_[r] = has ? ev[r][st_[r]] : 0.0f;              // raw_events: get_unscaled_level of the run's first event
+                if (TABLE) { const double2 t = table[rank_[r]]; mu_[r] = t.x; x_[r] = t.y; }
+                else {
+                    const double ls = has ? model[rank_[r]].level_stdv : 1.0, v = ls * ls;
+                    mu_[r] = has ? model[rank_[r]].level_mean : 0.0; x_[r] = pass == 0 ? 1. / v : v;
+                }
             }
             unsigned long long any = 0ull;
 #pragma unroll
@@ -229,31 +252,32 @@ __global__ void __launch_bounds__(64) np_recalibrate_kernel(int n_reads, np_read
                 const bool isM = has && rank != (before ? prev : carry_rank[r]);
                 double t0 = 0., t1 = 0., t2 = 0., t3 = 0., t4 = 0.;
                 if (isM) {
-                    const double ls = ls_[r], mu = mu_[r];
+                    const double mu = mu_[r];
                     const double e = (double)e_[r];
                     if (pass == 0) {
-                        const double inv_var = 1. / (ls * ls);
+                        const double inv_var = x_[r];            // 1. / (ls * ls)
                         t0 = inv_var; t1 = mu * inv_var; t2 = mu * mu * inv_var; t3 = e * inv_var; t4 = mu * e * inv_var;
                     } else {
                         const double yi = (e - shift[r] - scale[r] * mu);
-                        t0 = yi * yi / (ls * ls);
+                        t0 = yi * yi / x_[r];                     // / (ls * ls)
                     }
                 }
-                terms[r][0][lane] = t0;
-                if (pass == 0) { terms[r][1][lane] = t1; terms[r][2][lane] = t2; terms[r][3][lane] = t3; terms[r][4][lane] = t4; }
+                terms[wave][r][0][lane] = t0;
+                if (pass == 0) { terms[wave][r][1][lane] = t1; terms[wave][r][2][lane] = t2; terms[wave][r][3][lane] = t3; terms[wave][r][4][lane] = t4; }
                 const unsigned long long mm = __ballot(isM);
                 n[r] += __popcll(mm);
                 any |= mm;
                 if (hm) carry_rank[r] = __shfl(rank, 63 - __clzll((long long)hm), 64);
             }
             // ordered accumulation: lane (r, c) adds its 64 terms in k-mer order (a zero term leaves a non-negative-zero sum unchanged,
-            // so lanes that are not 'M' entries, and reads that have ended, need no masking)
-            __syncthreads();
+            // so lanes that are not 'M' entries, and reads that have ended, need no masking).  The tiles are this wave's own: LDS
+            // operations of one wave complete in order, the fences only keep the compiler from moving them across each other.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (any && adder) {
 #pragma unroll 16
                 for (int q = 0; q < 64; ++q) acc += row[q];
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         if (pass == 0) {
 #pragma unroll
@@ -285,50 +309,55 @@ __global__ void __launch_bounds__(64) np_recalibrate_kernel(int n_reads, np_read
     }
 }
 
-// Thread per PAIR of consecutive work items: the two sequences of a methylation group (unmethylated, methylated) sit side by side
-// and share their window bounds, so one pair of closest-event searches (two dependent gathers into the map) serves both -- checked,
-// not assumed: items of different reads or bounds each get their own.
-__device__ __forceinline__ bool resolve_bounds(const np_read_dev* rd, const int32_t* map_start, int k1, int k2, int& e1, int& e2)
-{
-    const int32_t* ms = map_start + rd->rank_off;
-    const int K = (int)rd->n_kmers;
-    if (k1 < 0 || k1 >= K || k2 < 0 || k2 >= K) return false;
-    e1 = closest_event(ms, K, k1);
-    e2 = closest_event(ms, K, k2);
-    const int d = e2 - e1;
-    return !(e1 < 0 || e2 < 0 || (d < 0 ? -d : d) <= 10);                        // basemods.cpp:356
-}
-__device__ __forceinline__ void resolve_store(np_hmm_job_dev* dst, np_hmm_job_dev job, bool ok, int e1, int e2)
-{
-    if (ok) {
-        job.e_start = (uint32_t)e1; job.e_stop = (uint32_t)e2;
-        job.stride = e1 <= e2 ? 1 : -1;                                          // basemods.cpp:370
-        job.flags &= ~NP_JOB_SKIP;
-    } else {
-        job.e_start = 0; job.e_stop = 0; job.stride = 1;
-        job.flags |= NP_JOB_SKIP;                                                // classify drops it, score = NaN
-    }
-    *dst = job;
-}
+// Thread per work item.  The two sequences of a methylation group (unmethylated, methylated) sit side by side and share their window
+// bounds: the odd lane takes the even lane's result (DPP) instead of repeating the two closest-event searches -- checked per pair, not
+// assumed: neighbours of different reads or bounds each search for themselves.  Only the item's second half (e_start, e_stop, stride,
+// flags: 16 of its 32 bytes) is read and written.
 __global__ void __launch_bounds__(256) np_resolve_kernel(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads,
                                                          const int32_t* n_pairs, const double* events_per_base,
                                                          const int32_t* calibrated, const int32_t* map_start, const int32_t* kpos)
 {
-    const int64_t j = 2 * ((int64_t)blockIdx.x * 256 + threadIdx.x);
-    if (j >= n_jobs) return;
-    const bool two = j + 1 < n_jobs;
-    const np_hmm_job_dev ja = jobs[j], jb = two ? jobs[j + 1] : ja;
-    const int ka1 = kpos[2 * j], ka2 = kpos[2 * j + 1];
-    const int kb1 = two ? kpos[2 * j + 2] : ka1, kb2 = two ? kpos[2 * j + 3] : ka2;
-    // failed alignment, failed calibration (squiggle_read.cpp:320-323) or events-per-base QC (:332): no events, no scoring
-    auto read_ok = [&](uint32_t r) { return n_pairs[r] > 0 && !(events_per_base[r] > 5.0) && (!calibrated || calibrated[r] != 0); };
-    int e1 = -1, e2 = -1;
-    const bool oka = read_ok(ja.read) && resolve_bounds(reads + ja.read, map_start, ka1, ka2, e1, e2);
-    resolve_store(jobs + j, ja, oka, e1, e2);
-    if (!two) return;
-    bool okb = oka;
-    if (jb.read != ja.read || kb1 != ka1 || kb2 != ka2) { e1 = -1; e2 = -1; okb = read_ok(jb.read) && resolve_bounds(reads + jb.read, map_start, kb1, kb2, e1, e2); }
-    resolve_store(jobs + j + 1, jb, okb, e1, e2);
+    static_assert(sizeof(np_hmm_job_dev) == 32 && offsetof(np_hmm_job_dev, e_start) == 16 && offsetof(np_hmm_job_dev, read) == 12, "np_hmm_job_dev layout");
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = j < n_jobs;
+    const int64_t jj = valid ? j : n_jobs - 1;
+    const int read = (int)jobs[jj].read;
+    uint4* tail = reinterpret_cast<uint4*>(reinterpret_cast<char*>(jobs + jj) + 16);
+    uint4 t = *tail;                                                             // e_start, e_stop, stride, flags
+    const int2 kp = *reinterpret_cast<const int2*>(kpos + 2 * jj);
+    const int k1 = kp.x, k2 = kp.y;
+    // the even neighbour's item (lane - 1; lane 0 is even, an odd lane always has its partner in the wave)
+    const int p_read = wave_shr1_i(read, -1), p_k1 = wave_shr1_i(k1, -1), p_k2 = wave_shr1_i(k2, -2);
+    const bool share = (threadIdx.x & 1) && p_read == read && p_k1 == k1 && p_k2 == k2;
+    int e1 = -1, e2 = -1; int ok = 0;
+    if (!share) {
+        // failed alignment, failed calibration (squiggle_read.cpp:320-323) or events-per-base QC (:332): no events, no scoring
+        bool o = n_pairs[read] > 0 && !(events_per_base[read] > 5.0) && (!calibrated || calibrated[read] != 0);
+        if (o) {
+            const np_read_dev* rd = reads + read;
+            const int32_t* ms = map_start + rd->rank_off;
+            const int K = (int)rd->n_kmers;
+            if (k1 < 0 || k1 >= K || k2 < 0 || k2 >= K) o = false;
+            else {
+                e1 = closest_event(ms, K, k1);
+                e2 = closest_event(ms, K, k2);
+                const int d = e2 - e1;
+                if (e1 < 0 || e2 < 0 || (d < 0 ? -d : d) <= 10) o = false;      // basemods.cpp:356
+            }
+        }
+        ok = o ? 1 : 0;
+    }
+    const int q1 = wave_shr1_i(e1, -1), q2 = wave_shr1_i(e2, -1), qok = wave_shr1_i(ok, 0);
+    if (share) { e1 = q1; e2 = q2; ok = qok; }
+    if (ok) {
+        t.x = (uint32_t)e1; t.y = (uint32_t)e2;
+        t.z = (uint32_t)(e1 <= e2 ? 1 : -1);                                     // basemods.cpp:370
+        t.w &= ~(uint32_t)NP_JOB_SKIP;
+    } else {
+        t.x = 0; t.y = 0; t.z = 1;
+        t.w |= (uint32_t)NP_JOB_SKIP;                                            // classify drops it, score = NaN
+    }
+    if (valid) *tail = t;
 }
 
 // (size_class / job_bin: np_kernels.h -- the host entry points bin small batches themselves)
@@ -460,7 +489,7 @@ hipError_t np_launch_resolve(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read
                              const int32_t* kpos, hipStream_t s)
 {
     if (n_jobs <= 0) return hipSuccess;
-    hipLaunchKernelGGL(np_resolve_kernel, dim3((unsigned)(((n_jobs + 1) / 2 + 255) / 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(np_resolve_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, s,
                        n_jobs, jobs, reads, n_pairs, events_per_base, calibrated, map_start, kpos);
     return hipGetLastError();
 }
@@ -581,12 +610,30 @@ hipError_t np_launch_selftest_div(uint64_t n_samples, uint64_t seed, unsigned lo
     return hipGetLastError();
 }
 
+// shape: 0 = the default (NP_RC_W waves x NP_RC_R reads), 1 / 2 = alternatives kept for A/B runs (option "recal_shape")
+#ifndef NP_RC_W
+#define NP_RC_W 16
+#endif
+#ifndef NP_RC_R
+#define NP_RC_R 2
+#endif
+template <int W, int R>
+static hipError_t launch_recal(int n_reads, np_read_dev* reads, const float* event_mean, const uint16_t* ranks, const np_state_dev* model, int n_states,
+                               const int32_t* n_pairs, const int32_t* map_start, int32_t* calibrated, const uint32_t* order, hipStream_t s)
+{
+    const int nb = (n_reads + W * R - 1) / (W * R);
+    if (n_states <= NP_RC_STATES)
+        hipLaunchKernelGGL((np_recalibrate_kernel<W, R, true>), dim3(nb), dim3(64 * W), 0, s, n_reads, reads, event_mean, ranks, model, n_states, n_pairs, map_start, calibrated, order);
+    else
+        hipLaunchKernelGGL((np_recalibrate_kernel<W, R, false>), dim3(nb), dim3(64 * W), 0, s, n_reads, reads, event_mean, ranks, model, n_states, n_pairs, map_start, calibrated, order);
+    return hipGetLastError();
+}
 hipError_t np_launch_recalibrate(int n_reads, np_read_dev* reads, const float* event_mean, const uint16_t* ranks,
-                                 const np_state_dev* model, const int32_t* n_pairs, const int32_t* map_start,
-                                 int32_t* calibrated, const uint32_t* order, hipStream_t s)
+                                 const np_state_dev* model, int n_states, const int32_t* n_pairs, const int32_t* map_start,
+                                 int32_t* calibrated, const uint32_t* order, int shape, hipStream_t s)
 {
     if (n_reads <= 0) return hipSuccess;
-    hipLaunchKernelGGL(np_recalibrate_kernel, dim3((n_reads + NP_RC_R - 1) / NP_RC_R), dim3(64), 0, s, n_reads, reads, event_mean, ranks, model,
-                       n_pairs, map_start, calibrated, order);
-    return hipGetLastError();
+    if (shape == 1) return launch_recal<8, 4>(n_reads, reads, event_mean, ranks, model, n_states, n_pairs, map_start, calibrated, order, s);
+    if (shape == 2) return launch_recal<12, 3>(n_reads, reads, event_mean, ranks, model, n_states, n_pairs, map_start, calibrated, order, s);
+    return launch_recal<NP_RC_W, NP_RC_R>(n_reads, reads, event_mean, ranks, model, n_states, n_pairs, map_start, calibrated, order, s);
 }

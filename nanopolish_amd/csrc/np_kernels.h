@@ -151,8 +151,9 @@ hipError_t np_launch_build_map(int n_reads, np_read_dev* reads, const int64_t* p
                                const int32_t* pair_begin, const int32_t* n_pairs, int32_t* map_start, int32_t* map_stop,
                                double* events_per_base, double indel_bias, hipStream_t s);
 hipError_t np_launch_recalibrate(int n_reads, np_read_dev* reads, const float* event_mean, const uint16_t* ranks,
-                                 const np_state_dev* model, const int32_t* n_pairs, const int32_t* map_start,
-                                 int32_t* calibrated, const uint32_t* order /* read order of the groups (np_launch_align_order) or null */, hipStream_t s);
+                                 const np_state_dev* model, int n_states, const int32_t* n_pairs, const int32_t* map_start,
+                                 int32_t* calibrated, const uint32_t* order /* read order of the groups (np_launch_align_order) or null */,
+                                 int shape /* 0: the default workgroup shape; 1, 2: A/B alternatives */, hipStream_t s);
 hipError_t np_launch_discard_degenerate(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads, const int32_t* map_start,
                                         const int32_t* deg_kpos, hipStream_t s);
 hipError_t np_launch_resolve(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads, const int32_t* n_pairs,

@@ -27,4 +27,18 @@ d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1]); print(d["va
 EOF
 }
 
+# recalibration with the model in LDS: workgroup shapes A/B (16 waves x 2 reads, 8 x 4, 12 x 3), then the step's kernels by name
+call_c() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r05${TAG:-c}; mkdir -p $O
+( time timeout 900 python -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+( timeout 600 python tools/hmm_ab.py --pool 4000 --tile 10 "@NP_RECAL_SHAPE=0" "@NP_RECAL_SHAPE=1" "@NP_RECAL_SHAPE=2" "@NP_RECAL_SHAPE=0" ) > $O/recal_ab.log 2>&1
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o p -- python $R/bench.py --steps 3 --warmup 1 --legs 0 --streamed 0 --ragged 0 --cpu-sample 0 > $R/$O/bench.json 2> $R/$O/bench.err )
+python profiles/summarize_rocpd.py $(find $O/prof -name "*_results.db" | head -1) > $O/kernels.txt 2>&1
+tail -5 $O/pytest.log; cat $O/recal_ab.log; grep -v "at::native\|rocclr\|probe\|np_align_\|hmm_forward" $O/kernels.txt | head -16; python - <<EOF
+import json
+d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"], d["roofline"]["kernel_ms_per_step"])
+EOF
+}
+
 "call_$1"
