@@ -211,28 +211,40 @@ __global__ void __launch_bounds__(64 * W) np_recalibrate_kernel(int n_reads, np_
         for (int r = 0; r < R; ++r) carry_rank[r] = -1;
         const double* row = pass == 0 ? &terms[wave][sr0 < R ? sr0 : 0][sc0][0] : &terms[wave][lane < R ? lane : 0][0][0];
         const bool adder = pass == 0 ? lane < 5 * R : lane < R;
-        int st_n[R], rank_n[R];                                  // the NEXT chunk's map entries and ranks (requested a chunk ahead)
+        // Two chunks in flight ahead of the one being consumed: chunk c + 2's map entries and ranks (coalesced) and chunk c + 1's event
+        // means (a gather through the map entries that arrived during chunk c - 1) are requested before chunk c's terms are formed, so
+        // every request has a whole chunk -- the serial phase included -- to land
+        int st_a[R], rank_a[R];                                  // map entries and ranks of the chunk after next
+        int st_c[R], rank_c[R]; float e_c[R];                    // the next chunk: map entries, ranks, event means
         auto request = [&](int base0) {
             const int ki = base0 + lane;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const bool in = live[r] && ki < K[r];
-                st_n[r] = in ? ms[r][ki] : -1;
-                rank_n[r] = in ? (int)rk[r][ki] : 0;
+                st_a[r] = in ? ms[r][ki] : -1;
+                rank_a[r] = in ? (int)rk[r][ki] : 0;
+            }
+        };
+        auto gather = [&]() {                                    // (st_a, rank_a) -> (st_c, rank_c), and the event means they point at
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                st_c[r] = st_a[r]; rank_c[r] = rank_a[r];
+                e_c[r] = st_c[r] != -1 ? ev[r][st_c[r]] : 0.0f; // raw_events: get_unscaled_level of the run's first event
             }
         };
         request(0);
+        gather();
+        request(64);
         for (int base0 = 0; base0 < maxK; base0 += 64) {
             int st_[R], rank_[R];
             double mu_[R], x_[R]; float e_[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) { st_[r] = st_n[r]; rank_[r] = rank_n[r]; }
-            if (base0 + 64 < maxK) request(base0 + 64);
-            // the event means the map entries point at (for every k-mer that has events: a superset of the 'M' entries) and the states
+            for (int r = 0; r < R; ++r) { st_[r] = st_c[r]; rank_[r] = rank_c[r]; e_[r] = e_c[r]; }
+            if (base0 + 64 < maxK) { gather(); request(base0 + 128); }
+            // the states of the k-mers that have events (a superset of the 'M' entries)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const bool has = st_[r] != -1;
-                e_[r] = has ? ev[r][st_[r]] : 0.0f;              // raw_events: get_unscaled_level of the run's first event
                 if (TABLE) { const double2 t = table[rank_[r]]; mu_[r] = t.x; x_[r] = t.y; }
                 else {
                     const double ls = has ? model[rank_[r]].level_stdv : 1.0, v = ls * ls;
