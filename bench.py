@@ -267,6 +267,91 @@ def rank_sample_parity(models, hb, batch, calibrate, from_raw, rank, threads, n_
     return out
 
 
+# ---- the legs VERDICT r4 item 3 asked to see in the driver-timed line --------------------------------------------------------
+def from_raw_leg(ctx, torch, models, hb_raw, tile, steps, warmup, calibrate, cpu_check):
+    """The step from RAW SIGNAL (SURVEY 8 f2 in front: int16 ADC counts -> pA -> scrappie event detection -> MoM scalings -> the resident
+    step), inputs resident, `steps` timed steps.  Parity: the sites per read of a sample against the reference's WHOLE per-read function
+    (SquiggleRead::load_from_raw + calculate_methylation_for_read, compiled in place)."""
+    from nanopolish_amd.pipeline import tile_host_batch, CallMethylationBatch
+    b = CallMethylationBatch(ctx, tile_host_batch(hb_raw, tile), "cuda:%d" % torch.cuda.current_device(), calibrate=calibrate, from_raw=True,
+                             jobs_on_device=True, map_stop=False)
+    for _ in range(warmup):
+        b.step()
+    ctx.sync(); torch.cuda.synchronize()
+    for w in (0, 1, 2, 4, 5):
+        ctx.kernel_time(w, reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.step()
+    ctx.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fam = {n: round(ctx.kernel_time(w)[0] / max(1, steps), 3) for w, n in ((4, "event_detect"), (5, "mom_scalings"), (0, "event_align"), (2, "glue_and_work_items"), (1, "hmm_score"))}
+    nev = b.d_n_events.clamp(min=0).to(torch.int64)
+    out = dict(value=round(b.n_reads * steps / dt, 2), unit="reads/s", ms_per_step=round(dt / steps * 1e3, 3), reads_per_step=b.n_reads,
+               distinct_reads=hb_raw["n"], mean_events_detected=round(float(nev.sum().item()) / b.n_reads, 1), kernel_ms_per_step=fam,
+               reads_aligned_ok=int((b.d_n_pairs > 0).sum().item()), input="int16 ADC counts resident in HBM")
+    if cpu_check:
+        try:
+            from oracle.ref_full import FullRef, have_full
+            if have_full():
+                n = min(64, hb_raw["n"])
+                rds = hb_raw["reads"][:n]
+                _, _, cores = usable_cores()
+                sites, t_full = FullRef().many_identity(1, [r["seq"] for r in rds], [r["raw"] for r in rds], [r["rc"] for r in rds], max(1, cores))
+                n_gpu = [int(np.isfinite(b.groups_of(i)[2]).sum()) for i in range(n)]
+                out["check"] = dict(reads=n, what="sites per read against load_from_raw + calculate_methylation_for_read, reference code",
+                                    sites_per_read_match_reference=bool(np.array_equal(sites, np.array(n_gpu))), sites=int(np.sum(n_gpu)),
+                                    cpu_whole_function_reads_per_s=round(n / t_full, 2))
+        except Exception as e:  # noqa: BLE001
+            out["check"] = dict(error=repr(e))
+    del b
+    torch.cuda.empty_cache()
+    return out
+
+
+def binding_legs(models, sizes=(512, 8192), distinct=512, read_len=5450, target_reads=65536, cpu_check=True):
+    """Reads/s THROUGH the reference-side batched binding (nanopolish_amd/csrc/np_batch_dropin.cpp: NpBatchPipeline linked into the
+    reference's read-level build in place of call-methylation's per-record loop, src/common/nanopolish_bam_processor.cpp:90-119,
+    INTEGRATION.md section 2): BAM records + int16 raw signal in HOST memory in, the reference's ScoredSite maps out, host wall clock
+    around the whole loop, at BamProcessor's default batch size (512 records) and at 8 192.  The harness that plays the caller
+    (oracle/ref_full_harness.cpp) and the reference objects live under oracle/_ref; what is timed is the product's binding + library.
+    Parity: the sites written must equal, in number, what the reference's whole per-read function finds for the same records."""
+    from oracle.ref_full import have_batch, bench_batch
+    if not have_batch():
+        return dict(error="oracle/_ref/libnp_ref_full_batch.so did not travel with the repository")
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores()[2])))
+    from nanopolish_amd import api
+    from nanopolish_amd.synth import synth_raw, ADC_OFFSET, ADC_UNIT
+    recs, contig, pos = [], [], 0
+    for r in range(distinct):
+        rd = synth_raw(r, models["nucleotide"], L=read_len, k=6, adc=True)
+        ref = api.reverse_complement("nucleotide", rd["seq"]) if rd["rc"] else rd["seq"]
+        recs.append(dict(seq=rd["seq"], raw=rd["raw"].astype(np.float32), adc=rd["adc"], rc=int(rd["rc"]), pos=pos,
+                         cigar=np.array([(len(ref) << 4) | 0], np.uint32), bam_seq=ref))
+        contig.append(ref); pos += len(ref)
+    contig = "".join(contig)
+    want_sites = None
+    if cpu_check:
+        try:
+            from oracle.ref_full import FullRef, have_full
+            if have_full():
+                sites, _ = FullRef().many_identity(1, [r["seq"] for r in recs], [r["raw"] for r in recs], [r["rc"] for r in recs], max(1, usable_cores()[2]))
+                want_sites = int(np.sum(sites))
+        except Exception:  # noqa: BLE001
+            want_sites = None
+    out = dict(distinct_reads=distinct, read_len=read_len, what="NpBatchPipeline (default construction: two contexts on the device), int16 samples from host memory, "
+                                                              "ScoredSite maps handed over and recycled; host wall clock")
+    for bs in sizes:
+        nb = max(8, -(-target_reads // bs))
+        sec, sites, bad, hs = bench_batch(recs, contig, bs, nb, warmup=7, pipelined=True, adc=(float(ADC_OFFSET), float(ADC_UNIT)), contexts=0, consumer=1)
+        d = dict(value=round(bs * nb / sec, 1), unit="reads/s", records_per_batch=bs, batches=nb, ms_per_batch=round(sec / nb * 1e3, 2),
+                 records_not_ok=bad, sites_written=sites, host_ms_per_batch={k: round(v / nb * 1e3, 2) for k, v in hs.items()})
+        if want_sites is not None and bs % distinct == 0:
+            d["sites_match_reference"] = bool(sites == want_sites * (bs // distinct) * nb)
+        out["records_%d" % bs] = d
+    return out
+
+
 # ---- N > 1 without a launcher ---------------------------------------------------------------------------------------------
 def launch_ranks(n, argv):
     """Start the n ranks of `bench.py --gpus n` ourselves (the driver's N = 1 command shape with --gpus > 1): one process per
@@ -381,6 +466,10 @@ def main():
         rlo, rhi = shard_read_ids(world * rp, rank, world)
         ids = np.arange(rlo, rhi) + (1 << 24)                          # its own id range
         hb_rag = prep_host_batch(models, int(ids[0]), int(ids[-1]) + 1, ragged_lengths(ids, args.read_len), bool(args.from_raw), workers)
+    hb_raw = None
+    if world == 1 and args.legs and not args.from_raw:
+        # the from-raw leg's pool (int16 traces): 4 000 distinct reads, 25 copies in HBM = the same 100 000 reads per step
+        hb_raw = prep_host_batch(models, (1 << 25), (1 << 25) + min(4000, args.pool), args.read_len, True, workers)
     t_prep = time.perf_counter() - t_prep
 
     import torch
@@ -638,6 +727,14 @@ def main():
     if rank == 0 and world == 1 and args.legs:
         legs = {}
         sys.path.insert(0, os.path.join(ROOT, "tests"))
+        if hb_raw is not None:
+            try:
+                fr = from_raw_leg(ctx, torch, models, hb_raw, max(1, n_reads // hb_raw["n"]), args.steps, args.warmup, bool(args.calibrate), args.cpu_sample != 0)
+                legs["value_from_raw"] = fr["value"]; legs["from_raw"] = fr
+            except Exception as e:  # noqa: BLE001
+                legs["from_raw"] = dict(error=repr(e))
+            hb_raw = None
+            torch.cuda.empty_cache()
         try:
             import bench_eventalign
             ea = bench_eventalign.run(steps=args.steps, warmup=args.warmup, cpu_sample=0 if args.cpu_sample == 0 else -1, ctx=ctx)
@@ -652,6 +749,14 @@ def main():
         except Exception as e:  # noqa: BLE001
             legs["variants"] = dict(error=repr(e))
         torch.cuda.empty_cache()
+        try:
+            bl = binding_legs(models, cpu_check=args.cpu_sample != 0)
+            legs["binding"] = bl
+            for bs in (512, 8192):
+                if "records_%d" % bs in bl:
+                    legs["value_binding_%d" % bs] = bl["records_%d" % bs]["value"]
+        except Exception as e:  # noqa: BLE001
+            legs["binding"] = dict(error=repr(e))
 
     if rank == 0:
         # dominant kernel + HBM roofline (algorithmic bytes)

@@ -106,25 +106,35 @@ void nucleotide_kmer_ranks(const std::string& seq, uint32_t k, uint16_t* out)
 
 struct RefView { const char* p; size_t n; RefView() : p(NULL), n(0) {} };
 
-// what one batch in flight needs on the host until it is collected
-struct Slot {
+// One DEVICE PASS: the records of one or several consecutive batches (round 5: a batch of BamProcessor's default 512 records is a 2.5 ms
+// pass behind ~8 ms of latencies -- one wave per read walks 13 000 dependent band steps whatever the batch holds -- so the packer merges
+// the batches that are already waiting, up to NP_BATCH_COALESCE records, into one upload, one run of the kernels and one read-back;
+// results stay per batch, in submission order).  Three per device: one being packed, one on the device, one being turned into maps.
+struct Pass {
     int dev;                                // index into Impl::devs
     Blob in, out;
     void *ev_h2d, *ev_cmp, *ev_d2h;
+    std::map<int, std::string> union_seq;   // tid -> the reference stretch the pass's records on that contig cover
+    std::map<int, int> union_lo;
+    std::vector<int64_t> group_off;         // group slots of the pass's device records
+    size_t o_scores, o_first, o_last, o_n_motif, o_n_groups, o_n_events, o_n_pairs, o_calibrated, out_bytes;   // offsets into `out`
+    int unfinished;                         // member batches whose maps are not built yet (under Impl::m): 0 = free for the packer
+    Pass() : dev(0), in(true), out(true), ev_h2d(NULL), ev_cmp(NULL), ev_d2h(NULL), out_bytes(0), unfinished(0) {}
+};
+
+// what one batch in flight needs on the host until it is collected
+struct Slot {
+    Pass* pass;                             // the device pass its records went into (NULL: none of them goes to the device)
     std::vector<NpBatchRead>* caller;       // the caller's vector: statuses go back into it at collect()
     std::vector<NpBatchRead> rec;           // its entries as they were at submit() (the buffers they point to stay the caller's)
-    std::map<int, std::string> union_seq;   // tid -> the reference stretch the batch's records on that contig cover
-    std::map<int, int> union_lo;
     std::vector<std::string> own_seq;       // a record's own segment when no union serves it, or when it needed disambiguation
-    std::vector<RefView> ref;               // every record's reference segment (a view into union_seq / own_seq)
-    std::vector<int> ref_start, dev_index, status;
-    std::vector<int64_t> group_off;
+    std::vector<RefView> ref;               // every record's reference segment (a view into the pass's union_seq / own_seq)
+    std::vector<int> ref_start, dev_index, status;     // dev_index: the record's index among the PASS's device records
     std::vector<std::map<int, ScoredSite> > built;      // phase 3's output, swapped into the caller's result by collect()
     std::vector<int> builder;               // the pool worker that built (allocated) each record's map
     int n_dev;
     bool finished;                          // phase 3 done, not collected yet (under Impl::m)
-    size_t o_scores, o_first, o_last, o_n_motif, o_n_groups, o_n_events, o_n_pairs, o_calibrated, out_bytes;   // offsets into `out`
-    Slot() : dev(0), in(true), out(true), ev_h2d(NULL), ev_cmp(NULL), ev_d2h(NULL), caller(NULL), n_dev(0), finished(false), out_bytes(0) {}
+    Slot() : pass(NULL), caller(NULL), n_dev(0), finished(false) {}
 };
 
 struct DevState {
@@ -143,7 +153,11 @@ struct NpBatchPipeline::Impl {
     const faidx_t* fai; const bam_hdr_t* hdr;
     int region_start, region_end;
     std::vector<DevState*> devs;
-    std::vector<Slot*> slots;               // 3 per device; batch b uses slot b % slots.size() on device b % devs.size()
+    std::vector<Slot*> slots;               // NP_BATCH_SLOTS (16) per device; batch b uses slot b % slots.size()
+    std::vector<Pass*> passes;              // 3 per device; pass k runs on device k % devs.size() in buffers (k / devs.size()) % 3 of that device
+    long n_passes;                          // device passes started so far (packer thread only)
+    long coalesce_records;                  // a pass takes waiting batches while it holds fewer records than this (NP_BATCH_COALESCE, default 4096)
+    long last_batch_records;                // size of the most recently submitted batch (under m): max_in_flight() scales with it
     Pool* pool;
     std::thread packer, finisher[2];        // two finishers: one waits for batch k+1's read-back while the other builds batch k's maps
     std::mutex m; std::condition_variable cv;
@@ -156,10 +170,10 @@ struct NpBatchPipeline::Impl {
     // maps take 9 ms to build).  collect() and recycle() are the caller's: one thread.
     std::map<const bam1_t*, int> builder_of;
     bool track_builders;          // false: the synchronous pipeline (nobody recycles: nothing to remember)
-    Impl() : fai(NULL), hdr(NULL), region_start(-1), region_end(-1), pool(NULL), n_submitted(0), n_packed(0), n_claimed(0), n_finished(0), n_collected(0), stop(false) { track_builders = true; for (int i = 0; i < 8; ++i) t[i] = 0.0; }
+    Impl() : fai(NULL), hdr(NULL), region_start(-1), region_end(-1), pool(NULL), n_submitted(0), n_packed(0), n_claimed(0), n_finished(0), n_collected(0), stop(false) { n_passes = 0; coalesce_records = 4096; last_batch_records = 0; track_builders = true; for (int i = 0; i < 8; ++i) t[i] = 0.0; }
     void add_time(int i, double s) { std::lock_guard<std::mutex> g(tm); t[i] += s; }
     void open(const std::vector<int>& devices, bool shared_default, int host_threads);
-    void pack(Slot& S);
+    void pack(const std::vector<Slot*>& group);
     void finish(Slot& S);
     void packer_loop();
     void finisher_loop();
@@ -176,13 +190,20 @@ void NpBatchPipeline::Impl::open(const std::vector<int>& devices, bool shared_de
         devs.push_back(D);
     }
     for (size_t i = 0; i < 3 * devs.size(); ++i) {
-        Slot* S = new Slot();
-        S->dev = (int)(i % devs.size());
-        np_ctx* c = devs[S->dev]->c;
-        S->ev_h2d = np_event_create(c); S->ev_cmp = np_event_create(c); S->ev_d2h = np_event_create(c);
-        if (!S->ev_h2d || !S->ev_cmp || !S->ev_d2h) die(np_last_error(c));
-        slots.push_back(S);
+        Pass* P = new Pass();
+        P->dev = (int)(i % devs.size());
+        np_ctx* c = devs[P->dev]->c;
+        P->ev_h2d = np_event_create(c); P->ev_cmp = np_event_create(c); P->ev_d2h = np_event_create(c);
+        if (!P->ev_h2d || !P->ev_cmp || !P->ev_d2h) die(np_last_error(c));
+        passes.push_back(P);
     }
+    // batches in flight: enough small ones to fill three passes per device (max_in_flight() scales the number handed to the caller with
+    // the batch size: large batches stay at three per device, as before)
+    int per_dev = 16;
+    if (const char* v = getenv("NP_BATCH_SLOTS")) per_dev = std::max(3, std::min(64, atoi(v)));
+    if (const char* v = getenv("NP_BATCH_COALESCE")) coalesce_records = std::max(1L, atol(v));
+    if (!track_builders) per_dev = 3;                  // the synchronous pipeline: one batch at a time
+    for (size_t i = 0; i < (size_t)per_dev * devs.size(); ++i) slots.push_back(new Slot());
     // Freed map memory goes back to the allocator, not to the kernel: with glibc's default trim threshold (128 KB) every batch's
     // 300 MB of released nodes is unmapped page by page and faulted in again by the next batch (seen as system time, and as a 7 ms
     // packing loop taking 58).  NP_KEEP_MALLOC_DEFAULTS=1 leaves the process's settings alone.
@@ -237,14 +258,15 @@ NpBatchPipeline::~NpBatchPipeline()
     p->packer.join(); p->finisher[0].join(); p->finisher[1].join();
     p->pool->drain();
     delete p->pool;
-    for (size_t i = 0; i < p->slots.size(); ++i) {
-        Slot* S = p->slots[i];
-        np_ctx* c = p->devs[S->dev]->c;
-        (void)np_sync(c, p->devs[S->dev]->s_h2d); (void)np_sync(c, NULL); (void)np_sync(c, p->devs[S->dev]->s_d2h);
-        S->in.release(c); S->out.release(c);
-        np_event_destroy(c, S->ev_h2d); np_event_destroy(c, S->ev_cmp); np_event_destroy(c, S->ev_d2h);
-        delete S;
+    for (size_t i = 0; i < p->passes.size(); ++i) {
+        Pass* P = p->passes[i];
+        np_ctx* c = p->devs[P->dev]->c;
+        (void)np_sync(c, p->devs[P->dev]->s_h2d); (void)np_sync(c, NULL); (void)np_sync(c, p->devs[P->dev]->s_d2h);
+        P->in.release(c); P->out.release(c);
+        np_event_destroy(c, P->ev_h2d); np_event_destroy(c, P->ev_cmp); np_event_destroy(c, P->ev_d2h);
+        delete P;
     }
+    for (size_t i = 0; i < p->slots.size(); ++i) delete p->slots[i];
     for (size_t d = 0; d < p->devs.size(); ++d) {
         DevState* D = p->devs[d];
         D->scratch.release(D->c);
@@ -263,7 +285,16 @@ void NpBatchPipeline::configure(const MethylationCallingParameters& calling_para
 }
 
 int NpBatchPipeline::in_flight() const { std::lock_guard<std::mutex> g(p->m); return (int)(p->n_submitted - p->n_collected); }
-int NpBatchPipeline::max_in_flight() const { return (int)p->slots.size(); }
+// Batches the caller may keep in flight: three device passes per device, each of up to NP_BATCH_COALESCE records -- three batches per device
+// when a batch fills a pass on its own, more (up to the slots there are) when batches are small.  Before the first submit(): the upper bound.
+int NpBatchPipeline::max_in_flight() const
+{
+    std::lock_guard<std::mutex> g(p->m);
+    const long n_dev = (long)p->devs.size(), last = p->last_batch_records;
+    if (last <= 0) return (int)p->slots.size();
+    const long per_dev = std::max(3L, (3 * p->coalesce_records + last - 1) / last);
+    return (int)std::min((long)p->slots.size(), per_dev * n_dev);
+}
 int NpBatchPipeline::devices() const { return (int)p->devs.size(); }
 void NpBatchPipeline::host_seconds(double out[8]) const { std::lock_guard<std::mutex> g(p->tm); for (int i = 0; i < 8; ++i) out[i] = p->t[i]; }
 
@@ -276,6 +307,7 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
         Slot& S = *p->slots[p->n_submitted % (long)p->slots.size()];
         S.caller = &reads;
         S.rec = reads;                     // (the records, sequences and samples they point to stay the caller's until collect())
+        p->last_batch_records = (long)reads.size();
         p->n_submitted += 1;
     }
     p->cv.notify_all();
@@ -285,15 +317,22 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
 void NpBatchPipeline::Impl::packer_loop()
 {
     for (;;) {
-        Slot* S;
+        std::vector<Slot*> group;
         {
             std::unique_lock<std::mutex> g(m);
             while (!stop && n_packed >= n_submitted) cv.wait(g);
             if (stop) return;
-            S = slots[n_packed % (long)slots.size()];
+            // the oldest waiting batch, and the batches waiting behind it while the pass holds fewer than coalesce_records records: what
+            // is already submitted only -- a caller that submits slowly is never made to wait for company
+            long records = 0;
+            for (long b = n_packed; b < n_submitted && (group.empty() || records < coalesce_records); ++b) {
+                Slot* S = slots[b % (long)slots.size()];
+                if (!group.empty() && records + (long)S->rec.size() > coalesce_records) break;
+                group.push_back(S); records += (long)S->rec.size();
+            }
         }
-        pack(*S);
-        { std::lock_guard<std::mutex> g(m); n_packed += 1; }
+        pack(group);
+        { std::lock_guard<std::mutex> g(m); n_packed += (long)group.size(); }
         cv.notify_all();
     }
 }
@@ -310,22 +349,24 @@ void NpBatchPipeline::Impl::finisher_loop()
             n_claimed += 1;
         }
         finish(*S);
-        { std::lock_guard<std::mutex> g(m); S->finished = true; n_finished += 1; }
+        { std::lock_guard<std::mutex> g(m); S->finished = true; n_finished += 1; if (S->pass) S->pass->unfinished -= 1; }
         cv.notify_all();
     }
 }
 
-// ---- phases 1 and 2 of one batch (the packer thread) ---------------------------------------------------------------------------------
-void NpBatchPipeline::Impl::pack(Slot& S)
+// ---- phases 1 and 2 of one device pass over the records of `group` (consecutive batches; the packer thread) ---------------------------
+void NpBatchPipeline::Impl::pack(const std::vector<Slot*>& group)
 {
-    DevState& D = *devs[S.dev];
-    np_ctx* c = D.c;
-    std::vector<NpBatchRead>& reads = S.rec;
-    const int n_all = (int)reads.size();
-    S.union_seq.clear(); S.union_lo.clear();
-    S.own_seq.assign(n_all, std::string()); S.ref.assign(n_all, RefView()); S.ref_start.assign(n_all, 0); S.dev_index.assign(n_all, -1);
-    S.status.assign(n_all, NP_BATCH_OK);
-    S.group_off.assign(1, 0); S.out_bytes = 0; S.n_dev = 0;
+    int n_all = 0;
+    for (size_t gi = 0; gi < group.size(); ++gi) {
+        Slot& S = *group[gi];
+        const int nb = (int)S.rec.size();
+        S.pass = NULL;
+        S.own_seq.assign(nb, std::string()); S.ref.assign(nb, RefView()); S.ref_start.assign(nb, 0); S.dev_index.assign(nb, -1);
+        S.status.assign(nb, NP_BATCH_OK);
+        S.n_dev = 0;
+        n_all += nb;
+    }
     if (n_all == 0) return;
 
     // the strand's models as load_from_raw and calculate_methylation_for_read choose them for a DNA read (squiggle_read.cpp:197-218,
@@ -341,17 +382,33 @@ void NpBatchPipeline::Impl::pack(Slot& S)
 
     // ---- phase 1a: which records go to the device, their reference segments and sizes ---------------------------------------
     double tm0 = now();
-    std::vector<int> idx;                         // device order -> batch index
-    for (int i = 0; i < n_all; ++i) {
-        const bool fits = device_ok && !reads[i].rna && reads[i].record && reads[i].read_sequence && reads[i].read_sequence->size() >= k &&
-                          (reads[i].raw_pa || reads[i].raw_adc) && reads[i].n_raw >= 64;
-        if (!fits) { S.status[i] = NP_BATCH_HOST_PATH; continue; }
-        if (!have_meth) continue;                                            // an empty map (basemods.cpp:280-287)
-        S.dev_index[i] = (int)idx.size(); idx.push_back(i);
+    struct Rec { Slot* S; int i; };
+    std::vector<Rec> idx;                         // device order -> (batch, index in the batch)
+    for (size_t gi = 0; gi < group.size(); ++gi) {
+        Slot& S = *group[gi];
+        const std::vector<NpBatchRead>& reads = S.rec;
+        for (int i = 0; i < (int)reads.size(); ++i) {
+            const bool fits = device_ok && !reads[i].rna && reads[i].record && reads[i].read_sequence && reads[i].read_sequence->size() >= k &&
+                              (reads[i].raw_pa || reads[i].raw_adc) && reads[i].n_raw >= 64;
+            if (!fits) { S.status[i] = NP_BATCH_HOST_PATH; continue; }
+            if (!have_meth) continue;                                            // an empty map (basemods.cpp:280-287)
+            S.dev_index[i] = (int)idx.size(); idx.push_back(Rec{&S, i}); S.n_dev += 1;
+        }
     }
     const int n = (int)idx.size();
-    S.n_dev = n;
     if (n == 0) return;
+    // the pass's buffers: three per device in rotation; the one whose turn it is must have handed all its batches' maps over
+    Pass& P = *passes[n_passes % (long)passes.size()];
+    n_passes += 1;
+    {
+        std::unique_lock<std::mutex> g(m);
+        while (P.unfinished > 0) cv.wait(g);
+        for (size_t gi = 0; gi < group.size(); ++gi) if (group[gi]->n_dev > 0) { group[gi]->pass = &P; P.unfinished += 1; }
+    }
+    DevState& D = *devs[P.dev];
+    np_ctx* c = D.c;
+    P.union_seq.clear(); P.union_lo.clear();
+    auto rd = [&](int q) -> const NpBatchRead& { return idx[q].S->rec[idx[q].i]; };
     // The reference fetches every record's segment on its own, under a critical section (get_reference_region_ts,
     // src/alignment/nanopolish_eventalign.cpp:207-221: faidx_fetch_seq is not thread-safe) -- serial work per record.  The records
     // of a BamProcessor batch come from a sorted BAM: when the batch's records on one contig cover a compact stretch, ONE fetch of
@@ -362,39 +419,39 @@ void NpBatchPipeline::Impl::pack(Slot& S)
     std::map<int, int64_t> covered;
     bool all_adc = true;
     for (int q = 0; q < n; ++q) {
-        const bam1_t* record = reads[idx[q]].record;
+        const bam1_t* record = rd(q).record;
         const int lo = record->core.pos, hi = bam_endpos(record);
-        S.ref_start[idx[q]] = lo;
+        idx[q].S->ref_start[idx[q].i] = lo;
         std::map<int, std::pair<int, int> >::iterator it = span.find(record->core.tid);
         if (it == span.end()) span[record->core.tid] = std::make_pair(lo, hi);
         else { it->second.first = std::min(it->second.first, lo); it->second.second = std::max(it->second.second, hi); }
         covered[record->core.tid] += hi - lo + 1;
-        all_adc = all_adc && reads[idx[q]].raw_adc != NULL;
+        all_adc = all_adc && rd(q).raw_adc != NULL;
     }
     for (std::map<int, std::pair<int, int> >::const_iterator it = span.begin(); it != span.end(); ++it) {
         const int64_t len = (int64_t)it->second.second - it->second.first + 1;
         if (len <= (64 << 20) && len <= 4 * covered[it->first] + (1 << 20)) {
             int fetched_len = 0;
-            S.union_seq[it->first] = get_reference_region_ts(fai, hdr->target_name[it->first], it->second.first, it->second.second, &fetched_len);
-            S.union_lo[it->first] = it->second.first;
+            P.union_seq[it->first] = get_reference_region_ts(fai, hdr->target_name[it->first], it->second.first, it->second.second, &fetched_len);
+            P.union_lo[it->first] = it->second.first;
         }
     }
     for (int q = 0; q < n; ++q) {                          // records no union serves: the reference's own per-record fetch (serial: faidx)
-        const int i = idx[q];
-        const bam1_t* record = reads[i].record;
-        if (S.union_seq.find(record->core.tid) != S.union_seq.end()) continue;
+        Slot& S = *idx[q].S; const int i = idx[q].i;
+        const bam1_t* record = rd(q).record;
+        if (P.union_seq.find(record->core.tid) != P.union_seq.end()) continue;
         int fetched_len = 0;
         S.own_seq[i] = get_reference_region_ts(fai, hdr->target_name[record->core.tid], record->core.pos, bam_endpos(record), &fetched_len);   // :258-270
     }
     // Alphabet::disambiguate (upper-casing + IUPAC codes -> their first base) is the identity on an upper-case ACGT string, and it
     // builds one std::string per character: 0.3 ms of a host core per 5 kb read.  Only a segment that needs it gets it (as its own copy).
     pool->run(n, 32, [&](int q) {
-        const int i = idx[q];
-        const bam1_t* record = reads[i].record;
-        std::map<int, std::string>::const_iterator u = S.union_seq.find(record->core.tid);
+        Slot& S = *idx[q].S; const int i = idx[q].i;
+        const bam1_t* record = rd(q).record;
+        std::map<int, std::string>::const_iterator u = P.union_seq.find(record->core.tid);
         RefView v;
-        if (u != S.union_seq.end()) {
-            const int64_t off = (int64_t)record->core.pos - S.union_lo.find(record->core.tid)->second, want = (int64_t)bam_endpos(record) - record->core.pos + 1;
+        if (u != P.union_seq.end()) {
+            const int64_t off = (int64_t)record->core.pos - P.union_lo.find(record->core.tid)->second, want = (int64_t)bam_endpos(record) - record->core.pos + 1;
             const int64_t have = (int64_t)u->second.size() - off;
             if (have > 0) { v.p = u->second.data() + off; v.n = (size_t)std::min(want, have); }
         } else { v.p = S.own_seq[i].data(); v.n = S.own_seq[i].size(); }
@@ -408,12 +465,11 @@ void NpBatchPipeline::Impl::pack(Slot& S)
     });
     std::vector<int64_t> raw_off(n + 1, 0), event_off(n + 1, 0), rank_off(n + 1, 0), cigar_off(n + 1, 0), jr_off(n + 1, 0),
                          pair_off(n + 1, 0), genome_off(n + 1, 0);
-    std::vector<int64_t>& group_off = S.group_off;
+    std::vector<int64_t>& group_off = P.group_off;
     group_off.assign(n + 1, 0);
     for (int q = 0; q < n; ++q) {
-        const int i = idx[q];
-        const bam1_t* record = reads[i].record;
-        const int64_t n_raw = (int64_t)reads[i].n_raw, L = (int64_t)reads[i].read_sequence->size(), ln = (int64_t)S.ref[i].n;
+        const bam1_t* record = rd(q).record;
+        const int64_t n_raw = (int64_t)rd(q).n_raw, L = (int64_t)rd(q).read_sequence->size(), ln = (int64_t)idx[q].S->ref[idx[q].i].n;
         const int64_t ecap = n_raw / g_event_cap_divisor + 2, nk = L - k + 1, gcap = ln / (MINSEP + 1) + 2;
         raw_off[q + 1] = raw_off[q] + n_raw;
         event_off[q + 1] = event_off[q] + ecap;
@@ -442,10 +498,10 @@ void NpBatchPipeline::Impl::pack(Slot& S)
                  i_pair_off = li.add((size_t)(n + 1) * 8), i_ref_begin = li.add((size_t)n * 8), i_ref_len = li.add((size_t)n * 4),
                  i_read_len = li.add((size_t)n * 4), i_cigar = li.add((size_t)cigar_off[n] * 4), i_rc = li.add((size_t)n);
     Layout lo;
-    S.o_scores = lo.add((size_t)n_jobs * sizeof(float)); S.o_first = lo.add((size_t)n_slots * 4); S.o_last = lo.add((size_t)n_slots * 4);
-    S.o_n_motif = lo.add((size_t)n_slots * 4); S.o_n_groups = lo.add((size_t)n * 4); S.o_n_events = lo.add((size_t)n * 4);
-    S.o_n_pairs = lo.add((size_t)n * 4); S.o_calibrated = lo.add((size_t)n * 4);
-    S.out_bytes = lo.size;
+    P.o_scores = lo.add((size_t)n_jobs * sizeof(float)); P.o_first = lo.add((size_t)n_slots * 4); P.o_last = lo.add((size_t)n_slots * 4);
+    P.o_n_motif = lo.add((size_t)n_slots * 4); P.o_n_groups = lo.add((size_t)n * 4); P.o_n_events = lo.add((size_t)n * 4);
+    P.o_n_pairs = lo.add((size_t)n * 4); P.o_calibrated = lo.add((size_t)n * 4);
+    P.out_bytes = lo.size;
     Layout ls;       // the part of the scratch that must start a batch zeroed comes first
     const size_t s_pair_begin = ls.add((size_t)n * 4), s_deg = ls.add((size_t)n * 8), s_kpos = ls.add((size_t)n_jobs * 8),
                  s_epb = ls.add((size_t)n * 8), s_jobs = ls.add((size_t)n_jobs * sizeof(np_hmm_job_dev));
@@ -456,7 +512,7 @@ void NpBatchPipeline::Impl::pack(Slot& S)
                  s_pairs = ls.add((size_t)pair_off[n] * sizeof(np_pair)),
                  s_job_ranks = ls.add((size_t)jr_off[n] * sizeof(uint16_t));
     add_time(0, now() - tm0); tm0 = now();
-    S.in.reserve(c, li.size + 256); S.out.reserve(c, lo.size + 256);
+    P.in.reserve(c, li.size + 256); P.out.reserve(c, lo.size + 256);
     if (ls.size + 256 > D.scratch.cap) {
         check(np_sync(c, NULL), "np_sync");                  // the batch in flight on this device still computes in the scratch that is about to be replaced
         D.scratch.reserve(c, ls.size + 256);
@@ -464,26 +520,27 @@ void NpBatchPipeline::Impl::pack(Slot& S)
     add_time(5, now() - tm0); tm0 = now();
 
     // ---- phase 1b: pack the pinned input blob -----------------------------------------------------------------------------
-    char* H = S.in.h;
+    char* H = P.in.h;
     float* h_raw = (float*)(H + i_raw); uint16_t* h_ranks = (uint16_t*)(H + i_ranks);
     np_read_dev* h_reads_a = (np_read_dev*)(H + i_reads_a); np_read_dev* h_reads_b = (np_read_dev*)(H + i_reads_b);
     char* h_genome = H + i_genome; int64_t* h_ref_begin = (int64_t*)(H + i_ref_begin); int32_t* h_ref_len = (int32_t*)(H + i_ref_len);
     int32_t* h_read_len = (int32_t*)(H + i_read_len); uint32_t* h_cigar = (uint32_t*)(H + i_cigar); uint8_t* h_rc = (uint8_t*)(H + i_rc);
     pool->run(n, 4, [&](int q) {
-        const int i = idx[q];
-        const bam1_t* record = reads[i].record;
-        const std::string& seq = *reads[i].read_sequence;
+        const NpBatchRead& R = rd(q);
+        const RefView& ref = idx[q].S->ref[idx[q].i];
+        const bam1_t* record = R.record;
+        const std::string& seq = *R.read_sequence;
         for (int t = 0; t < 2; ++t)
             np_fill_read_host(t ? &h_reads_b[q] : &h_reads_a[q], 0.0, 1.0, 1.0, event_off[q], (uint32_t)(event_off[q + 1] - event_off[q]), rank_off[q],
                               (uint32_t)(rank_off[q + 1] - rank_off[q]));
-        ((float*)(H + i_adc_offset))[q] = reads[i].adc_offset; ((float*)(H + i_adc_unit))[q] = reads[i].adc_raw_unit;
-        if (all_adc) memcpy((int16_t*)(H + i_raw) + raw_off[q], reads[i].raw_adc, reads[i].n_raw * sizeof(int16_t));
-        else if (reads[i].raw_pa) memcpy(h_raw + raw_off[q], reads[i].raw_pa, reads[i].n_raw * sizeof(float));
-        else for (size_t t = 0; t < reads[i].n_raw; ++t)            // the loader's conversion, fp32 (fast5_loader.cpp:96-103)
-            h_raw[raw_off[q] + t] = ((float)reads[i].raw_adc[t] + reads[i].adc_offset) * reads[i].adc_raw_unit;
+        ((float*)(H + i_adc_offset))[q] = R.adc_offset; ((float*)(H + i_adc_unit))[q] = R.adc_raw_unit;
+        if (all_adc) memcpy((int16_t*)(H + i_raw) + raw_off[q], R.raw_adc, R.n_raw * sizeof(int16_t));
+        else if (R.raw_pa) memcpy(h_raw + raw_off[q], R.raw_pa, R.n_raw * sizeof(float));
+        else for (size_t t = 0; t < R.n_raw; ++t)            // the loader's conversion, fp32 (fast5_loader.cpp:96-103)
+            h_raw[raw_off[q] + t] = ((float)R.raw_adc[t] + R.adc_offset) * R.adc_raw_unit;
         nucleotide_kmer_ranks(seq, k, h_ranks + rank_off[q]);
-        memcpy(h_genome + genome_off[q], S.ref[i].p, S.ref[i].n);
-        h_ref_begin[q] = genome_off[q]; h_ref_len[q] = (int32_t)S.ref[i].n;
+        memcpy(h_genome + genome_off[q], ref.p, ref.n);
+        h_ref_begin[q] = genome_off[q]; h_ref_len[q] = (int32_t)ref.n;
         memcpy(h_cigar + cigar_off[q], bam_get_cigar(record), 4 * (size_t)record->core.n_cigar);
         h_read_len[q] = (int32_t)seq.size();
         h_rc[q] = bam_is_rev(record) ? 1 : 0;
@@ -496,13 +553,13 @@ void NpBatchPipeline::Impl::pack(Slot& S)
     // ---- phase 2: one upload, the batch on the device, one read-back -----------------------------------------------------------
     const int m_nuc = shim().model_id(pm_nuc, D.slot_key);
     const int m_meth = shim().model_id(PoreModelSet::get_model(kit, params.methylation_type, strand_name, k), D.slot_key);
-    check(np_copy_to_device(c, D.s_h2d, S.in.d, S.in.h, li.size), "np_copy_to_device");
-    check(np_event_record(c, S.ev_h2d, D.s_h2d), "np_event_record");
-    check(np_stream_wait_event(c, NULL, S.ev_h2d), "np_stream_wait_event");
-    check(np_memset_dev(c, NULL, S.out.d, 0, lo.size), "np_memset_dev");
+    check(np_copy_to_device(c, D.s_h2d, P.in.d, P.in.h, li.size), "np_copy_to_device");
+    check(np_event_record(c, P.ev_h2d, D.s_h2d), "np_event_record");
+    check(np_stream_wait_event(c, NULL, P.ev_h2d), "np_stream_wait_event");
+    check(np_memset_dev(c, NULL, P.out.d, 0, lo.size), "np_memset_dev");
     check(np_memset_dev(c, NULL, D.scratch.d, 0, zero_bytes), "np_memset_dev");
     {
-        char* Dv = S.in.d; char* O = S.out.d; char* X = D.scratch.d;
+        char* Dv = P.in.d; char* O = P.out.d; char* X = D.scratch.d;
         float* raw = all_adc ? (float*)(X + s_raw_pa) : (float*)(Dv + i_raw); uint16_t* ranks = (uint16_t*)(Dv + i_ranks);
         np_read_dev* reads_a = (np_read_dev*)(Dv + i_reads_a); np_read_dev* reads_b = (np_read_dev*)(Dv + i_reads_b);
         int64_t *d_raw_off = (int64_t*)(Dv + i_raw_off), *d_event_off = (int64_t*)(Dv + i_event_off), *d_cigar_off = (int64_t*)(Dv + i_cigar_off),
@@ -510,10 +567,10 @@ void NpBatchPipeline::Impl::pack(Slot& S)
                 *ref_begin = (int64_t*)(Dv + i_ref_begin);
         int32_t *ref_len = (int32_t*)(Dv + i_ref_len), *read_len = (int32_t*)(Dv + i_read_len);
         uint32_t* cigar = (uint32_t*)(Dv + i_cigar); uint8_t* rc = (uint8_t*)(Dv + i_rc); char* genome = Dv + i_genome;
-        float* scores = (float*)(O + S.o_scores);
-        int32_t *first = (int32_t*)(O + S.o_first), *last = (int32_t*)(O + S.o_last), *n_motif = (int32_t*)(O + S.o_n_motif),
-                *n_groups = (int32_t*)(O + S.o_n_groups), *n_events = (int32_t*)(O + S.o_n_events), *n_pairs = (int32_t*)(O + S.o_n_pairs),
-                *calibrated = (int32_t*)(O + S.o_calibrated);
+        float* scores = (float*)(O + P.o_scores);
+        int32_t *first = (int32_t*)(O + P.o_first), *last = (int32_t*)(O + P.o_last), *n_motif = (int32_t*)(O + P.o_n_motif),
+                *n_groups = (int32_t*)(O + P.o_n_groups), *n_events = (int32_t*)(O + P.o_n_events), *n_pairs = (int32_t*)(O + P.o_n_pairs),
+                *calibrated = (int32_t*)(O + P.o_calibrated);
         int32_t *pair_begin = (int32_t*)(X + s_pair_begin), *deg = (int32_t*)(X + s_deg), *kpos = (int32_t*)(X + s_kpos),
                 *map_start = (int32_t*)(X + s_map_start);
         double* epb = (double*)(X + s_epb);
@@ -539,30 +596,30 @@ void NpBatchPipeline::Impl::pack(Slot& S)
         check(np_cm_discard_degenerate_dev(c, NULL, reads_b, map_start, deg, n_jobs, jobs), "np_cm_discard_degenerate_dev");
         check(np_hmm_score_dev(c, NULL, n_jobs, jobs, reads_b, ev_mean, job_ranks, m_meth, scores), "np_hmm_score_dev");
     }
-    check(np_event_record(c, S.ev_cmp, NULL), "np_event_record");
-    check(np_stream_wait_event(c, D.s_d2h, S.ev_cmp), "np_stream_wait_event");
-    check(np_copy_to_host(c, D.s_d2h, S.out.h, S.out.d, lo.size), "np_copy_to_host");
-    check(np_event_record(c, S.ev_d2h, D.s_d2h), "np_event_record");
+    check(np_event_record(c, P.ev_cmp, NULL), "np_event_record");
+    check(np_stream_wait_event(c, D.s_d2h, P.ev_cmp), "np_stream_wait_event");
+    check(np_copy_to_host(c, D.s_d2h, P.out.h, P.out.d, lo.size), "np_copy_to_host");
+    check(np_event_record(c, P.ev_d2h, D.s_d2h), "np_event_record");
     add_time(2, now() - tm0);
 }
 
 // ---- phase 3 of one batch (the finisher thread): wait for the read-back, build the ScoredSite maps (basemods.cpp:384-413) -----------
 void NpBatchPipeline::Impl::finish(Slot& S)
 {
-    np_ctx* c = devs[S.dev]->c;
     std::vector<NpBatchRead>& reads = S.rec;
     const int n = (int)reads.size();
     S.built.clear(); S.built.resize(n); S.builder.assign(n, -1);
     if (n == 0) return;
     double tm0 = now();
-    if (S.n_dev > 0) check(np_event_sync(c, S.ev_d2h), "np_event_sync");
+    if (S.pass) check(np_event_sync(devs[S.pass->dev]->c, S.pass->ev_d2h), "np_event_sync");      // (the pass's other batches wait on the same event)
     add_time(3, now() - tm0); tm0 = now();
-    if (S.n_dev == 0) return;
-    const char* O = S.out.h;
-    const float* scores = (const float*)(O + S.o_scores);
-    const int32_t *first = (const int32_t*)(O + S.o_first), *last = (const int32_t*)(O + S.o_last), *n_motif = (const int32_t*)(O + S.o_n_motif),
-                  *n_groups = (const int32_t*)(O + S.o_n_groups), *n_events = (const int32_t*)(O + S.o_n_events),
-                  *n_pairs = (const int32_t*)(O + S.o_n_pairs), *calibrated = (const int32_t*)(O + S.o_calibrated);
+    if (!S.pass) return;
+    const Pass& P = *S.pass;
+    const char* O = P.out.h;
+    const float* scores = (const float*)(O + P.o_scores);
+    const int32_t *first = (const int32_t*)(O + P.o_first), *last = (const int32_t*)(O + P.o_last), *n_motif = (const int32_t*)(O + P.o_n_motif),
+                  *n_groups = (const int32_t*)(O + P.o_n_groups), *n_events = (const int32_t*)(O + P.o_n_events),
+                  *n_pairs = (const int32_t*)(O + P.o_n_pairs), *calibrated = (const int32_t*)(O + P.o_calibrated);
     const uint32_t k = 6;
     pool->run(n, 8, [&](int i) {
         const bam1_t* record = reads[i].record;
@@ -577,7 +634,7 @@ void NpBatchPipeline::Impl::finish(Slot& S)
         const RefView ref_seq = S.ref[i];
         const int strand_idx = 0;
         for (int g = 0; g < n_groups[q]; ++g) {
-            const int64_t slot = S.group_off[q] + g;
+            const int64_t slot = P.group_off[q] + g;
             const float unmethylated_score = scores[2 * slot], methylated_score = scores[2 * slot + 1];
             if (unmethylated_score != unmethylated_score || methylated_score != methylated_score) continue;   // a group the caller rules skip
             const int start_position = first[slot] + S.ref_start[i];

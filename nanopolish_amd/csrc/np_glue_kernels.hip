@@ -196,6 +196,7 @@ __global__ void __launch_bounds__(64 * W) np_recalibrate_kernel(int n_reads, np_
     for (int r = 0; r < R; ++r) { shift[r] = 0.0; scale[r] = 0.0; n[r] = 0; }
     // serial-phase role of this lane: pass 0 lane 5 r + c owns sum c of read r; pass 1 lane r owns read r's residual sum
     const int sr0 = lane / 5, sc0 = lane - 5 * sr0;
+    const unsigned long long below = (1ull << lane) - 1ull;
     double acc = 0.0;
     for (int pass = 0; pass < 2; ++pass) {
         if (TABLE) {
@@ -254,32 +255,30 @@ __global__ void __launch_bounds__(64 * W) np_recalibrate_kernel(int n_reads, np_
             unsigned long long any = 0ull;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int st = st_[r];
-                const bool has = st != -1;
+                const bool has = st_[r] != -1;
                 const int rank = has ? rank_[r] : -1;
                 const unsigned long long hm = __ballot(has);
-                const unsigned long long before = hm & ((1ull << lane) - 1ull);
+                const unsigned long long before = hm & below;
                 const int src = before ? 63 - __clzll((long long)before) : 0;
                 const int prev = __shfl(rank, src, 64);
                 const bool isM = has && rank != (before ? prev : carry_rank[r]);
-                double t0 = 0., t1 = 0., t2 = 0., t3 = 0., t4 = 0.;
-                if (isM) {
-                    const double mu = mu_[r];
-                    const double e = (double)e_[r];
-                    if (pass == 0) {
-                        const double inv_var = x_[r];            // 1. / (ls * ls)
-                        t0 = inv_var; t1 = mu * inv_var; t2 = mu * mu * inv_var; t3 = e * inv_var; t4 = mu * e * inv_var;
-                    } else {
-                        const double yi = (e - shift[r] - scale[r] * mu);
-                        t0 = yi * yi / x_[r];                     // / (ls * ls)
-                    }
+                // branch-free: a lane that is not an 'M' entry forms its terms with a zero factor (mu and e are finite; a -0.0 term
+                // leaves every sum unchanged, like +0.0)
+                const double mu = mu_[r], e = (double)e_[r];
+                double t0, t1 = 0., t2 = 0., t3 = 0., t4 = 0.;
+                if (pass == 0) {
+                    const double inv_var = isM ? x_[r] : 0.0;    // 1. / (ls * ls)
+                    t0 = inv_var; t1 = mu * inv_var; t2 = mu * mu * inv_var; t3 = e * inv_var; t4 = mu * e * inv_var;
+                } else {
+                    const double yi = (e - shift[r] - scale[r] * mu);
+                    t0 = (isM ? yi * yi : 0.0) / x_[r];           // / (ls * ls)
                 }
                 terms[wave][r][0][lane] = t0;
                 if (pass == 0) { terms[wave][r][1][lane] = t1; terms[wave][r][2][lane] = t2; terms[wave][r][3][lane] = t3; terms[wave][r][4][lane] = t4; }
                 const unsigned long long mm = __ballot(isM);
                 n[r] += __popcll(mm);
                 any |= mm;
-                if (hm) carry_rank[r] = __shfl(rank, 63 - __clzll((long long)hm), 64);
+                if (hm) carry_rank[r] = __builtin_amdgcn_readlane(rank, 63 - __clzll((long long)hm));      // (a wave-uniform lane index)
             }
             // ordered accumulation: lane (r, c) adds its 64 terms in k-mer order (a zero term leaves a non-negative-zero sum unchanged,
             // so lanes that are not 'M' entries, and reads that have ended, need no masking).  The tiles are this wave's own: LDS
@@ -622,12 +621,13 @@ hipError_t np_launch_selftest_div(uint64_t n_samples, uint64_t seed, unsigned lo
     return hipGetLastError();
 }
 
-// shape: 0 = the default (NP_RC_W waves x NP_RC_R reads), 1 / 2 = alternatives kept for A/B runs (option "recal_shape")
+// shape: 0 = the default (NP_RC_W waves x NP_RC_R reads: 8 x 4), 1 / 2 = 16 x 2 and 12 x 3, kept for A/B runs (option "recal_shape");
+// gpurun r05d, 40 000 reads, glue family: 5.997 ms for 8 x 4, 6.19 for 12 x 3, 6.45-6.49 for 16 x 2
 #ifndef NP_RC_W
-#define NP_RC_W 16
+#define NP_RC_W 8
 #endif
 #ifndef NP_RC_R
-#define NP_RC_R 2
+#define NP_RC_R 4
 #endif
 template <int W, int R>
 static hipError_t launch_recal(int n_reads, np_read_dev* reads, const float* event_mean, const uint16_t* ranks, const np_state_dev* model, int n_states,
@@ -645,7 +645,7 @@ hipError_t np_launch_recalibrate(int n_reads, np_read_dev* reads, const float* e
                                  int32_t* calibrated, const uint32_t* order, int shape, hipStream_t s)
 {
     if (n_reads <= 0) return hipSuccess;
-    if (shape == 1) return launch_recal<8, 4>(n_reads, reads, event_mean, ranks, model, n_states, n_pairs, map_start, calibrated, order, s);
+    if (shape == 1) return launch_recal<16, 2>(n_reads, reads, event_mean, ranks, model, n_states, n_pairs, map_start, calibrated, order, s);
     if (shape == 2) return launch_recal<12, 3>(n_reads, reads, event_mean, ranks, model, n_states, n_pairs, map_start, calibrated, order, s);
     return launch_recal<NP_RC_W, NP_RC_R>(n_reads, reads, event_mean, ranks, model, n_states, n_pairs, map_start, calibrated, order, s);
 }

@@ -41,4 +41,19 @@ d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1]); print(d["va
 EOF
 }
 
+# coalesced device passes in the batched binding; the driver's bench command with the from-raw and binding legs folded in
+call_e() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r05${TAG:-e}; mkdir -p $O
+( time timeout 900 python -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+( time timeout 1200 python bench.py --steps ${STEPS:-10} --warmup 3 ) > $O/bench.json 2> $O/bench.err; echo "rc=$?" >> $O/bench.err
+tail -5 $O/pytest.log; tail -5 $O/bench.err; python - <<EOF
+import json
+d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"], d["roofline"]["kernel_ms_per_step"], d["roofline"]["frac"])
+for k in ("value_streamed","value_ragged","value_from_raw","value_eventalign","value_variants","value_binding_512","value_binding_8192"): print(k, d.get(k))
+print(json.dumps(d.get("from_raw"))[:900]); print(json.dumps(d.get("binding"))[:2500])
+EOF
+}
+
 "call_$1"
