@@ -343,7 +343,8 @@ def binding_legs(models, sizes=(512, 8192), distinct=512, read_len=5450, target_
                                                               "ScoredSite maps handed over and recycled; host wall clock")
     for bs in sizes:
         nb = max(8, -(-target_reads // bs))
-        sec, sites, bad, hs = bench_batch(recs, contig, bs, nb, warmup=7, pipelined=True, adc=(float(ADC_OFFSET), float(ADC_UNIT)), contexts=0, consumer=1)
+        # (warm-up: every slot of the pipeline used once and the passes' buffers grown to their steady size)
+        sec, sites, bad, hs = bench_batch(recs, contig, bs, nb, warmup=48 if bs <= 1024 else 7, pipelined=True, adc=(float(ADC_OFFSET), float(ADC_UNIT)), contexts=0, consumer=1)
         d = dict(value=round(bs * nb / sec, 1), unit="reads/s", records_per_batch=bs, batches=nb, ms_per_batch=round(sec / nb * 1e3, 2),
                  records_not_ok=bad, sites_written=sites, host_ms_per_batch={k: round(v / nb * 1e3, 2) for k, v in hs.items()})
         if want_sites is not None and bs % distinct == 0:

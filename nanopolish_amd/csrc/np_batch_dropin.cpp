@@ -119,7 +119,8 @@ struct Pass {
     std::vector<int64_t> group_off;         // group slots of the pass's device records
     size_t o_scores, o_first, o_last, o_n_motif, o_n_groups, o_n_events, o_n_pairs, o_calibrated, out_bytes;   // offsets into `out`
     int unfinished;                         // member batches whose maps are not built yet (under Impl::m): 0 = free for the packer
-    Pass() : dev(0), in(true), out(true), ev_h2d(NULL), ev_cmp(NULL), ev_d2h(NULL), out_bytes(0), unfinished(0) {}
+    bool on_device;                         // enqueued and its read-back not seen complete yet (packer thread only)
+    Pass() : dev(0), in(true), out(true), ev_h2d(NULL), ev_cmp(NULL), ev_d2h(NULL), out_bytes(0), unfinished(0), on_device(false) {}
 };
 
 // what one batch in flight needs on the host until it is collected
@@ -138,11 +139,12 @@ struct Slot {
 };
 
 struct DevState {
+    int ordinal;                            // the HIP device the context lives on (two contexts may share one)
     int slot_key;                           // context slot of the process-wide shim
     np_ctx* c;
     Blob scratch;                           // single per context: its compute stream runs one batch at a time
     void *s_h2d, *s_d2h;
-    DevState() : slot_key(0), c(NULL), scratch(false), s_h2d(NULL), s_d2h(NULL) {}
+    DevState() : ordinal(0), slot_key(0), c(NULL), scratch(false), s_h2d(NULL), s_d2h(NULL) {}
 };
 
 } // namespace
@@ -154,7 +156,7 @@ struct NpBatchPipeline::Impl {
     int region_start, region_end;
     std::vector<DevState*> devs;
     std::vector<Slot*> slots;               // NP_BATCH_SLOTS (16) per device; batch b uses slot b % slots.size()
-    std::vector<Pass*> passes;              // 3 per device; pass k runs on device k % devs.size() in buffers (k / devs.size()) % 3 of that device
+    std::vector<Pass*> passes;              // 3 per context: passes[3 * d + j] belongs to devs[d]
     long n_passes;                          // device passes started so far (packer thread only)
     long coalesce_records;                  // a pass takes waiting batches while it holds fewer records than this (NP_BATCH_COALESCE, default 4096)
     long last_batch_records;                // size of the most recently submitted batch (under m): max_in_flight() scales with it
@@ -173,7 +175,8 @@ struct NpBatchPipeline::Impl {
     Impl() : fai(NULL), hdr(NULL), region_start(-1), region_end(-1), pool(NULL), n_submitted(0), n_packed(0), n_claimed(0), n_finished(0), n_collected(0), stop(false) { n_passes = 0; coalesce_records = 4096; last_batch_records = 0; track_builders = true; for (int i = 0; i < 8; ++i) t[i] = 0.0; }
     void add_time(int i, double s) { std::lock_guard<std::mutex> g(tm); t[i] += s; }
     void open(const std::vector<int>& devices, bool shared_default, int host_threads);
-    void pack(const std::vector<Slot*>& group);
+    void pack(const std::vector<Slot*>& group, int dev);
+    int device_passes(int ordinal);
     void finish(Slot& S);
     void packer_loop();
     void finisher_loop();
@@ -183,6 +186,7 @@ void NpBatchPipeline::Impl::open(const std::vector<int>& devices, bool shared_de
 {
     for (size_t d = 0; d < devices.size(); ++d) {
         DevState* D = new DevState();
+        D->ordinal = devices[d];
         D->slot_key = (shared_default && d == 0) ? 0 : shim().take_slot(devices[d]);      // (shared_default: the first entry is the process-wide context)
         D->c = shim().ctx(D->slot_key);
         D->s_h2d = np_stream_create(D->c); D->s_d2h = np_stream_create(D->c);
@@ -191,7 +195,7 @@ void NpBatchPipeline::Impl::open(const std::vector<int>& devices, bool shared_de
     }
     for (size_t i = 0; i < 3 * devs.size(); ++i) {
         Pass* P = new Pass();
-        P->dev = (int)(i % devs.size());
+        P->dev = (int)(i / 3);
         np_ctx* c = devs[P->dev]->c;
         P->ev_h2d = np_event_create(c); P->ev_cmp = np_event_create(c); P->ev_d2h = np_event_create(c);
         if (!P->ev_h2d || !P->ev_cmp || !P->ev_d2h) die(np_last_error(c));
@@ -314,16 +318,49 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
     p->add_time(7, now() - t0);
 }
 
+// passes enqueued on the HIP device `ordinal` (any of its contexts) whose read-back has not completed (packer thread; polls the events)
+int NpBatchPipeline::Impl::device_passes(int ordinal)
+{
+    int busy = 0;
+    for (size_t i = 0; i < passes.size(); ++i) {
+        Pass& P = *passes[i];
+        if (!P.on_device || devs[P.dev]->ordinal != ordinal) continue;
+        if (np_event_query(devs[P.dev]->c, P.ev_d2h) == NP_OK) P.on_device = false; else busy += 1;
+    }
+    return busy;
+}
+
+// When does a pass start?  A wave walks one read's 13 000 dependent band steps whatever the batch holds: a pass of 512 records keeps a
+// twentieth of the device busy for as long as a pass of 5 000.  So the packer lets waiting batches gather -- up to coalesce_records
+// records per pass -- for as long as the GPU has a pass to work on, and takes whatever waits the moment a GPU has none (a caller that
+// submits slowly is never made to wait for company; a caller that has stopped submitting because max_in_flight() batches are in flight
+// is waiting for batches that are on a device already).  The context: the least loaded one of the least loaded GPU.
 void NpBatchPipeline::Impl::packer_loop()
 {
     for (;;) {
         std::vector<Slot*> group;
+        int dev = 0;
         {
             std::unique_lock<std::mutex> g(m);
-            while (!stop && n_packed >= n_submitted) cv.wait(g);
-            if (stop) return;
-            // the oldest waiting batch, and the batches waiting behind it while the pass holds fewer than coalesce_records records: what
-            // is already submitted only -- a caller that submits slowly is never made to wait for company
+            for (;;) {
+                if (stop) return;
+                if (n_packed < n_submitted) {
+                    long records = 0;
+                    for (long b = n_packed; b < n_submitted; ++b) records += (long)slots[b % (long)slots.size()]->rec.size();
+                    // least loaded GPU, then least loaded context on it
+                    int best_gpu = -1, best_gpu_busy = 1 << 30, best_ctx_busy = 1 << 30;
+                    for (size_t d = 0; d < devs.size(); ++d) {
+                        const int gb = device_passes(devs[d]->ordinal);
+                        int cb = 0;
+                        for (int q = 0; q < 3; ++q) cb += passes[3 * d + q]->on_device ? 1 : 0;
+                        if (gb < best_gpu_busy || (gb == best_gpu_busy && cb < best_ctx_busy)) { best_gpu = (int)d; best_gpu_busy = gb; best_ctx_busy = cb; }
+                    }
+                    if ((records >= coalesce_records || best_gpu_busy == 0) && best_ctx_busy < 3) { dev = best_gpu; break; }
+                    cv.wait_for(g, std::chrono::microseconds(200));            // (a pass finishing on the device signals no condition variable: poll)
+                    continue;
+                }
+                cv.wait(g);
+            }
             long records = 0;
             for (long b = n_packed; b < n_submitted && (group.empty() || records < coalesce_records); ++b) {
                 Slot* S = slots[b % (long)slots.size()];
@@ -331,7 +368,7 @@ void NpBatchPipeline::Impl::packer_loop()
                 group.push_back(S); records += (long)S->rec.size();
             }
         }
-        pack(group);
+        pack(group, dev);
         { std::lock_guard<std::mutex> g(m); n_packed += (long)group.size(); }
         cv.notify_all();
     }
@@ -355,7 +392,7 @@ void NpBatchPipeline::Impl::finisher_loop()
 }
 
 // ---- phases 1 and 2 of one device pass over the records of `group` (consecutive batches; the packer thread) ---------------------------
-void NpBatchPipeline::Impl::pack(const std::vector<Slot*>& group)
+void NpBatchPipeline::Impl::pack(const std::vector<Slot*>& group, int dev)
 {
     int n_all = 0;
     for (size_t gi = 0; gi < group.size(); ++gi) {
@@ -397,14 +434,20 @@ void NpBatchPipeline::Impl::pack(const std::vector<Slot*>& group)
     }
     const int n = (int)idx.size();
     if (n == 0) return;
-    // the pass's buffers: three per device in rotation; the one whose turn it is must have handed all its batches' maps over
-    Pass& P = *passes[n_passes % (long)passes.size()];
-    n_passes += 1;
+    // the pass's buffers: one of the context's three that is off the device and has handed all its batches' maps over
+    Pass* Pp = NULL;
     {
         std::unique_lock<std::mutex> g(m);
-        while (P.unfinished > 0) cv.wait(g);
-        for (size_t gi = 0; gi < group.size(); ++gi) if (group[gi]->n_dev > 0) { group[gi]->pass = &P; P.unfinished += 1; }
+        for (;;) {
+            for (int q = 0; q < 3 && !Pp; ++q) { Pass* C = passes[3 * dev + (int)((n_passes + q) % 3)]; if (!C->on_device && C->unfinished == 0) Pp = C; }
+            if (Pp) break;
+            (void)device_passes(devs[dev]->ordinal);
+            cv.wait_for(g, std::chrono::microseconds(200));
+        }
+        for (size_t gi = 0; gi < group.size(); ++gi) if (group[gi]->n_dev > 0) { group[gi]->pass = Pp; Pp->unfinished += 1; }
     }
+    Pass& P = *Pp;
+    n_passes += 1;
     DevState& D = *devs[P.dev];
     np_ctx* c = D.c;
     P.union_seq.clear(); P.union_lo.clear();
@@ -600,6 +643,7 @@ void NpBatchPipeline::Impl::pack(const std::vector<Slot*>& group)
     check(np_stream_wait_event(c, D.s_d2h, P.ev_cmp), "np_stream_wait_event");
     check(np_copy_to_host(c, D.s_d2h, P.out.h, P.out.d, lo.size), "np_copy_to_host");
     check(np_event_record(c, P.ev_d2h, D.s_d2h), "np_event_record");
+    P.on_device = true;
     add_time(2, now() - tm0);
 }
 

@@ -56,4 +56,24 @@ print(json.dumps(d.get("from_raw"))[:900]); print(json.dumps(d.get("binding"))[:
 EOF
 }
 
+# the binding's packer policy (gather waiting batches while the GPU is busy): binding tests, then reads/s at 512 / 2 048 / 8 192 records
+# with the default policy and with NP_BATCH_COALESCE=1 (every batch a pass of its own: round 4's behaviour)
+call_f() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r05${TAG:-f}; mkdir -p $O
+( time timeout 900 python -m pytest tests/test_gpu_batch_dropin.py tests/test_gpu_sanitizers.py tests/test_gpu_dropin.py -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+SKIP=pipelined,pipelined_adc_ref_writer,pipelined_adc_4ctx,sync,pipelined_adc_2ctx
+( timeout 600 python tests/bench_batch_dropin.py --sizes 512,2048,8192 --skip $SKIP ) > $O/binding.json 2> $O/binding.err
+( NP_BATCH_COALESCE=1 timeout 600 python tests/bench_batch_dropin.py --sizes 512,2048 --skip $SKIP ) > $O/binding_nocoalesce.json 2>> $O/binding.err
+( NP_BATCH_CONTEXTS=1 timeout 600 python tests/bench_batch_dropin.py --sizes 512,2048 --skip $SKIP ) > $O/binding_1ctx.json 2>> $O/binding.err
+tail -5 $O/pytest.log; tail -3 $O/binding.err
+python - <<EOF
+import json
+for f in ("binding","binding_nocoalesce","binding_1ctx"):
+    for l in open("$O/%s.json" % f):
+        if l.startswith("{"):
+            d=json.loads(l); print(f, d["batch_size"], d["pipelined_adc"]["value"], d["pipelined_adc"]["ms_per_batch"], d["pipelined_adc"]["host_ms_per_batch"])
+EOF
+}
+
 "call_$1"
