@@ -158,7 +158,7 @@ struct NpBatchPipeline::Impl {
     std::vector<Slot*> slots;               // NP_BATCH_SLOTS (16) per device; batch b uses slot b % slots.size()
     std::vector<Pass*> passes;              // 3 per context: passes[3 * d + j] belongs to devs[d]
     long n_passes;                          // device passes started so far (packer thread only)
-    long coalesce_records;                  // a pass takes waiting batches while it holds fewer records than this (NP_BATCH_COALESCE, default 4096)
+    long coalesce_records;                  // a pass takes waiting batches while it holds fewer records than this (NP_BATCH_COALESCE, default 8192)
     long last_batch_records;                // size of the most recently submitted batch (under m): max_in_flight() scales with it
     Pool* pool;
     std::thread packer, finisher[2];        // two finishers: one waits for batch k+1's read-back while the other builds batch k's maps
@@ -172,7 +172,7 @@ struct NpBatchPipeline::Impl {
     // maps take 9 ms to build).  collect() and recycle() are the caller's: one thread.
     std::map<const bam1_t*, int> builder_of;
     bool track_builders;          // false: the synchronous pipeline (nobody recycles: nothing to remember)
-    Impl() : fai(NULL), hdr(NULL), region_start(-1), region_end(-1), pool(NULL), n_submitted(0), n_packed(0), n_claimed(0), n_finished(0), n_collected(0), stop(false) { n_passes = 0; coalesce_records = 4096; last_batch_records = 0; track_builders = true; for (int i = 0; i < 8; ++i) t[i] = 0.0; }
+    Impl() : fai(NULL), hdr(NULL), region_start(-1), region_end(-1), pool(NULL), n_submitted(0), n_packed(0), n_claimed(0), n_finished(0), n_collected(0), stop(false) { n_passes = 0; coalesce_records = 8192; last_batch_records = 0; track_builders = true; for (int i = 0; i < 8; ++i) t[i] = 0.0; }
     void add_time(int i, double s) { std::lock_guard<std::mutex> g(tm); t[i] += s; }
     void open(const std::vector<int>& devices, bool shared_default, int host_threads);
     void pack(const std::vector<Slot*>& group, int dev);
@@ -203,7 +203,7 @@ void NpBatchPipeline::Impl::open(const std::vector<int>& devices, bool shared_de
     }
     // batches in flight: enough small ones to fill three passes per device (max_in_flight() scales the number handed to the caller with
     // the batch size: large batches stay at three per device, as before)
-    int per_dev = 16;
+    int per_dev = 24;
     if (const char* v = getenv("NP_BATCH_SLOTS")) per_dev = std::max(3, std::min(64, atoi(v)));
     if (const char* v = getenv("NP_BATCH_COALESCE")) coalesce_records = std::max(1L, atol(v));
     if (!track_builders) per_dev = 3;                  // the synchronous pipeline: one batch at a time
@@ -555,10 +555,14 @@ void NpBatchPipeline::Impl::pack(const std::vector<Slot*>& group, int dev)
                  s_pairs = ls.add((size_t)pair_off[n] * sizeof(np_pair)),
                  s_job_ranks = ls.add((size_t)jr_off[n] * sizeof(uint16_t));
     add_time(0, now() - tm0); tm0 = now();
-    P.in.reserve(c, li.size + 256); P.out.reserve(c, lo.size + 256);
+    // A buffer that must grow for a MERGED pass grows to what a full pass (coalesce_records records like these) needs: the groups the
+    // packer forms vary in size, and growing a pinned / device allocation step by step costs more than the passes themselves.
+    const double full = group.size() > 1 && n_all < coalesce_records ? std::min(32.0, (double)coalesce_records / (double)n_all) : 1.0;
+    if (li.size + 256 > P.in.cap) P.in.reserve(c, (size_t)((double)li.size * full) + 256);
+    if (lo.size + 256 > P.out.cap) P.out.reserve(c, (size_t)((double)lo.size * full) + 256);
     if (ls.size + 256 > D.scratch.cap) {
         check(np_sync(c, NULL), "np_sync");                  // the batch in flight on this device still computes in the scratch that is about to be replaced
-        D.scratch.reserve(c, ls.size + 256);
+        D.scratch.reserve(c, (size_t)((double)ls.size * full) + 256);
     }
     add_time(5, now() - tm0); tm0 = now();
 

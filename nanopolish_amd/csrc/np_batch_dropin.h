@@ -46,11 +46,16 @@ void np_calculate_methylation_for_batch(MethylationCallingResult& result, std::v
 //     collect(batch k-1)    hands the finished maps over (a swap per record)
 //
 // submit() returns as soon as the batch is queued; collect() returns batches in submission order and blocks until the oldest one
-// is finished.  With `devices` = {0, 1, ..., N-1} the pipeline owns one library context per listed GPU and deals batches to them
-// round-robin (the same device may be listed twice: two contexts on one GPU).  `max_in_flight()` batches may be in flight (three per
-// device: one in each stage); submit() with that many already in flight is an error.  BamProcessor's loop
-// (bam_processor.cpp:90-119) becomes
-//     while (read a batch into recs[k % n]) { pipe.submit(recs[k % n]); if (pipe.in_flight() == pipe.max_in_flight()) { pipe.collect(res); write(res); pipe.recycle(res); } ++k; }
+// is finished.  With `devices` = {0, 1, ..., N-1} the pipeline owns one library context per listed GPU (the same device may be listed
+// twice: two contexts on one GPU) and sends every device pass to the least loaded one.  A DEVICE PASS is one batch or -- round 5 --
+// several consecutive ones: a pass costs the device the time of its longest read whatever it holds, so batches of BamProcessor's default
+// 512 records that are already waiting are merged, up to NP_BATCH_COALESCE records (default 8 192) per pass; a pass starts as soon as
+// that many records wait or a GPU has nothing to do, so a slow caller is never made to wait for company.  Results are per batch.
+// `max_in_flight()` batches may be in flight: three per device when a batch fills a pass on its own, more when batches are small (up to
+// NP_BATCH_SLOTS, default 24, per device); it can change after a submit() with the size of the batches -- ask again, as the loop below
+// does; before the first submit() it returns the upper bound (the number of record / result vectors to rotate).  submit() with that
+// many in flight is an error.  BamProcessor's loop (bam_processor.cpp:90-119) becomes
+//     while (read a batch into recs[k % n]) { pipe.submit(recs[k % n]); if (pipe.in_flight() >= pipe.max_in_flight()) { pipe.collect(res); write(res); pipe.recycle(res); } ++k; }
 //     while (pipe.collect(res)) { write(res); pipe.recycle(res); }
 // (INTEGRATION.md section 2).  LIFETIME: the read vector, the records and every buffer its entries point to (sequence, samples) must
 // stay alive and unchanged from submit() until the batch has been collected -- packing runs after submit() has returned.

@@ -345,7 +345,7 @@ int npfull_call_methylation_pipeline(int n, int batch_size, int n_contexts, int 
         NpBatchPipeline* pipe = n_contexts <= 0 ? new NpBatchPipeline(params, "r9.4_450bps", &recs[0]->fai, &recs[0]->hdr, -1, -1)
                                                 : new NpBatchPipeline(params, "r9.4_450bps", &recs[0]->fai, &recs[0]->hdr, -1, -1, std::vector<int>(n_contexts, 0), 0);
         for(size_t b = 0; b < batches.size(); ++b) {
-            if(pipe->in_flight() == pipe->max_in_flight()) pipe->collect(result);
+            if(pipe->in_flight() >= pipe->max_in_flight()) pipe->collect(result);
             pipe->submit(batches[b]);
         }
         while(pipe->collect(result)) {}
@@ -434,7 +434,7 @@ double npfull_bench_batch(int n_distinct, const char* const* read_seqs, const fl
                 t0 = omp_get_wtime();
             }
             if(pipelined) {
-                if(pipe->in_flight() == pipe->max_in_flight()) {
+                if(pipe->in_flight() >= pipe->max_in_flight()) {
                     const int s = (int)(next_collect++ % n_sets);
                     tq = omp_get_wtime(); pipe->collect(res[s]); t_in += omp_get_wtime() - tq;
                     NPH_WRITE(s);

@@ -76,11 +76,11 @@ def _assert_golden(g, i, got):
     assert np.array_equal(got["ll_unmeth"], g[p + "site_ll_unmeth"]) and np.array_equal(got["ll_meth"], g[p + "site_ll_meth"])
 
 
-@pytest.mark.parametrize("coalesce", ["4096", "1", "5"])
+@pytest.mark.parametrize("coalesce", ["8192", "1", "5"])
 def test_pipelined_batches_equal_the_unmodified_reference(coalesce, monkeypatch):
     """NpBatchPipeline, batches in flight (persistent buffers, one upload and one read-back per device pass, three streams): the
     records in batches of 3 and of 1 -- every slot reused several times, batches of different sizes back to back.  Round 5: the packer
-    merges the batches that are already waiting into one device pass of up to NP_BATCH_COALESCE records (default 4 096: here everything
+    merges the batches that are already waiting into one device pass of up to NP_BATCH_COALESCE records (default 8 192: here everything
     that waits goes into one pass; 1: every batch is a pass of its own, the round-4 behaviour; 5: passes of one to five records, groups
     that end in the middle of the queue) -- results per batch, in submission order, whatever was merged."""
     from oracle.ref_full import call_methylation_pipeline
