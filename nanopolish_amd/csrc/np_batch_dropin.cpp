@@ -160,6 +160,7 @@ struct NpBatchPipeline::Impl {
     long n_passes;                          // device passes started so far (packer thread only)
     long coalesce_records;                  // a pass takes waiting batches while it holds fewer records than this (NP_BATCH_COALESCE, default 8192)
     long last_batch_records;                // size of the most recently submitted batch (under m): max_in_flight() scales with it
+    bool presized;                          // the buffers have been sized for a full merged pass (packer thread only)
     Pool* pool;
     std::thread packer, finisher[2];        // two finishers: one waits for batch k+1's read-back while the other builds batch k's maps
     std::mutex m; std::condition_variable cv;
@@ -172,7 +173,7 @@ struct NpBatchPipeline::Impl {
     // maps take 9 ms to build).  collect() and recycle() are the caller's: one thread.
     std::map<const bam1_t*, int> builder_of;
     bool track_builders;          // false: the synchronous pipeline (nobody recycles: nothing to remember)
-    Impl() : fai(NULL), hdr(NULL), region_start(-1), region_end(-1), pool(NULL), n_submitted(0), n_packed(0), n_claimed(0), n_finished(0), n_collected(0), stop(false) { n_passes = 0; coalesce_records = 8192; last_batch_records = 0; track_builders = true; for (int i = 0; i < 8; ++i) t[i] = 0.0; }
+    Impl() : fai(NULL), hdr(NULL), region_start(-1), region_end(-1), pool(NULL), n_submitted(0), n_packed(0), n_claimed(0), n_finished(0), n_collected(0), stop(false) { n_passes = 0; coalesce_records = 8192; last_batch_records = 0; presized = false; track_builders = true; for (int i = 0; i < 8; ++i) t[i] = 0.0; }
     void add_time(int i, double s) { std::lock_guard<std::mutex> g(tm); t[i] += s; }
     void open(const std::vector<int>& devices, bool shared_default, int host_threads);
     void pack(const std::vector<Slot*>& group, int dev);
@@ -555,14 +556,28 @@ void NpBatchPipeline::Impl::pack(const std::vector<Slot*>& group, int dev)
                  s_pairs = ls.add((size_t)pair_off[n] * sizeof(np_pair)),
                  s_job_ranks = ls.add((size_t)jr_off[n] * sizeof(uint16_t));
     add_time(0, now() - tm0); tm0 = now();
-    // A buffer that must grow for a MERGED pass grows to what a full pass (coalesce_records records like these) needs: the groups the
-    // packer forms vary in size, and growing a pinned / device allocation step by step costs more than the passes themselves.
-    const double full = group.size() > 1 && n_all < coalesce_records ? std::min(32.0, (double)coalesce_records / (double)n_all) : 1.0;
-    if (li.size + 256 > P.in.cap) P.in.reserve(c, (size_t)((double)li.size * full) + 256);
-    if (lo.size + 256 > P.out.cap) P.out.reserve(c, (size_t)((double)lo.size * full) + 256);
+    // The first MERGED pass sizes every buffer of the pipeline -- all passes, every context's scratch -- for a full pass (coalesce_records
+    // records like these): the groups the packer forms vary in size, and growing pinned / device allocations step by step, pass buffer by
+    // pass buffer, costs more than the passes themselves (seconds of hipHostMalloc spread over the first hundred batches).
+    if (group.size() > 1 && !presized) {
+        presized = true;
+        const double full = n_all < coalesce_records ? std::min(32.0, (double)coalesce_records / (double)n_all) : 1.0;
+        for (size_t i = 0; i < passes.size(); ++i) {
+            Pass& Q = *passes[i];
+            if (Q.on_device || Q.unfinished > 0) continue;     // (in use: it grows when its turn comes)
+            np_ctx* qc = devs[Q.dev]->c;
+            Q.in.reserve(qc, (size_t)((double)li.size * full) + 256); Q.out.reserve(qc, (size_t)((double)lo.size * full) + 256);
+        }
+        for (size_t d = 0; d < devs.size(); ++d) {
+            if ((size_t)((double)ls.size * full) + 256 <= devs[d]->scratch.cap) continue;
+            check(np_sync(devs[d]->c, NULL), "np_sync");
+            devs[d]->scratch.reserve(devs[d]->c, (size_t)((double)ls.size * full) + 256);
+        }
+    }
+    P.in.reserve(c, li.size + 256); P.out.reserve(c, lo.size + 256);
     if (ls.size + 256 > D.scratch.cap) {
         check(np_sync(c, NULL), "np_sync");                  // the batch in flight on this device still computes in the scratch that is about to be replaced
-        D.scratch.reserve(c, (size_t)((double)ls.size * full) + 256);
+        D.scratch.reserve(c, ls.size + 256);
     }
     add_time(5, now() - tm0); tm0 = now();
 

@@ -575,13 +575,14 @@ __global__ void __launch_bounds__(256) np_site_table_kernel(int64_t n_groups, co
 // profile_hmm_score_set's combination (src/hmm/nanopolish_profile_hmm.cpp:41-55): score = (+)_j (score_j - log n) with
 // add_logs -> p7_FLogsum on (float) casts of the doubles (nanopolish_common.h:97-104), thread per set.
 __global__ void __launch_bounds__(256) np_score_set_combine_kernel(int64_t n_sets, const int64_t* set_off, const int64_t* member_idx,
-                                                                   const float* member_scores, const float* logsum, float* out)
+                                                                   const float* member_scores, const float* logsum, const double* log_n, float* out)
 {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= n_sets) return;
     const int64_t b = set_off[q], n = set_off[q + 1] - b;
     if (n <= 0) { out[q] = NP_NEG_INF; return; }
-    const double pen = np_log_glibc((double)(uint64_t)n);                     // glibc's log, restated (csrc/np_log.h)
+    // glibc's log, restated (csrc/np_log.h) -- or, in host-constants mode, log(n) as the process's own libm computed it (n <= 64)
+    const double pen = log_n && n <= 64 ? log_n[n] : np_log_glibc((double)(uint64_t)n);
     auto sc = [&](int64_t t) { return (double)member_scores[member_idx ? member_idx[b + t] : b + t]; };
     double score = sc(0) - pen;
     for (int64_t t = 1; t < n; ++t) {
@@ -605,11 +606,11 @@ hipError_t np_launch_site_table(int64_t n_groups, const float* scores, const int
 }
 
 hipError_t np_launch_score_set_combine(int64_t n_sets, const int64_t* set_off, const int64_t* member_idx, const float* member_scores,
-                                       const float* logsum, float* out, hipStream_t s)
+                                       const float* logsum, const double* log_n, float* out, hipStream_t s)
 {
     if (n_sets <= 0) return hipSuccess;
     hipLaunchKernelGGL(np_score_set_combine_kernel, dim3((unsigned)((n_sets + 255) / 256)), dim3(256), 0, s, n_sets, set_off, member_idx,
-                       member_scores, logsum, out);
+                       member_scores, logsum, log_n, out);
     return hipGetLastError();
 }
 

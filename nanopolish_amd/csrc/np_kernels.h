@@ -163,7 +163,7 @@ hipError_t np_launch_site_table(int64_t n_groups, const float* scores, const int
                                 const np_hmm_job_dev* jobs, const int64_t* read_base, double call_threshold, int64_t n_pos,
                                 int32_t* table, hipStream_t s);
 hipError_t np_launch_score_set_combine(int64_t n_sets, const int64_t* set_off, const int64_t* member_idx, const float* member_scores,
-                                       const float* logsum, float* out, hipStream_t s);
+                                       const float* logsum, const double* log_n /* host-constants mode: log(0 .. 64) by the process's libm; else null */, float* out, hipStream_t s);
 hipError_t np_launch_selftest_div(uint64_t n_samples, uint64_t seed, unsigned long long* d_mismatches, hipStream_t s);
 
 // ---- f2: event detection + method-of-moments scalings (np_events_kernels.hip) ------------------------------------

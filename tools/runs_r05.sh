@@ -76,4 +76,23 @@ for f in ("binding","binding_nocoalesce","binding_1ctx"):
 EOF
 }
 
+# host-constants mode (the libm repair) + the binding with all buffers sized at the first merged pass: the whole suite, then the binding's rates
+call_h() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r05${TAG:-h}; mkdir -p $O
+( time timeout 1200 python -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+SKIP=pipelined,pipelined_adc_ref_writer,pipelined_adc_4ctx,sync,pipelined_adc_2ctx
+( timeout 600 python tests/bench_batch_dropin.py --sizes 512,2048,8192 --skip $SKIP ) > $O/binding.json 2> $O/binding.err
+( NP_BATCH_COALESCE=1 timeout 600 python tests/bench_batch_dropin.py --sizes 512,8192 --skip $SKIP ) > $O/binding_nocoalesce.json 2>> $O/binding.err
+( timeout 600 python tests/bench_batch_dropin.py --sizes 512 --target-reads 524288 --skip $SKIP ) > $O/binding_long.json 2>> $O/binding.err
+tail -7 $O/pytest.log; tail -3 $O/binding.err
+python - <<EOF
+import json
+for f in ("binding","binding_nocoalesce","binding_long"):
+    for l in open("$O/%s.json" % f):
+        if l.startswith("{"):
+            d=json.loads(l); print(f, d["batch_size"], d["batches"], d["pipelined_adc"]["value"], d["pipelined_adc"]["ms_per_batch"], d["pipelined_adc"]["host_ms_per_batch"])
+EOF
+}
+
 "call_$1"
