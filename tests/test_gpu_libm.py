@@ -27,7 +27,8 @@ CHAIN = ["tests/test_gpu_events.py::test_pass_from_raw_signal_matches_oracle",
 
 def _run(env_extra, tests):
     env = dict(os.environ, **env_extra)
-    return subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + tests, cwd=ROOT, env=env,
+    # (-s: np_create's NP_VERBOSE line goes to stderr, which pytest would swallow for a passing test)
+    return subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider"] + tests, cwd=ROOT, env=env,
                           capture_output=True, text=True, timeout=900)
 
 

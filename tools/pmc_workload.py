@@ -90,7 +90,9 @@ def main():
         res = b.eventalign_results()
         out["eventalign"] = dict(reads=b.n_reads, segments=int(sum(r["n_calls"] for r in res)), lattice_cells=int(cells), lattice_rows=int(erows),
                                  lattice_kmers=int(kmers), rows_out=int(sum(len(r["event_idx"]) for r in res)),
-                                 unprofiled_chain_ms=round(ctx.kernel_time(6)[0] / n_t, 3))
+                                 raw_samples=int(b.d_raw_off[-1].item()) if hasattr(b, "d_raw_off") else None,
+                                 unprofiled_chain_ms=round(ctx.kernel_time(6)[0] / n_t, 3),
+                                 unprofiled_ms=dict(event_detect_family=round(ctx.kernel_time(4)[0] / n_t, 3), mom_fill=round(ctx.kernel_time(5)[0] / n_t, 3)))
     print(json.dumps(out), flush=True)
     ctx.close()
 

@@ -95,4 +95,13 @@ for f in ("binding","binding_nocoalesce","binding_long"):
 EOF
 }
 
+# the libm tests again (stderr of the child visible), then the round's counter passes (kernels A, B, chain, glue, detector) at 8 192 reads
+call_i() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r05${TAG:-i}; mkdir -p $O
+( time timeout 900 python -m pytest tests/test_gpu_libm.py tests/test_gpu_batch_dropin.py -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+tail -6 $O/pytest.log
+PASS_TIMEOUT=240 bash profiles/collect_r05_pmc.sh r05pmc 8192 2>&1 | tail -14
+}
+
 "call_$1"
