@@ -342,6 +342,20 @@ int np_cm_build_jobs_cigar_dev(np_ctx* ctx, void* stream, int n_reads, const cha
                                int min_flank, const int64_t* group_off, int64_t total_group_slots, const int64_t* rank_off,
                                np_hmm_job_dev* jobs, int32_t* kpos, uint16_t* job_ranks,
                                int32_t* first_site, int32_t* last_site, int32_t* n_motif, int32_t* n_groups, int32_t* deg_kpos);
+/* Declares the SLOT LAYOUT of the work-item array the calls that follow operate on (round 5): read r owns the items
+ * [2 group_off[r], 2 group_off[r + 1]) -- the group slots np_cm_build_jobs_*_dev was given -- of which only the first 2 n_groups[r] are
+ * live (n_groups is what the builder writes; a negative count reads as 0).  The slot ranges are sized for the worst case (one group per
+ * min_separation + 1 bases, 2.7 x the groups a read has on average), and a kernel that visits "all n_jobs items" spends most of its
+ * memory traffic on empty slots.  With the layout declared
+ *     np_cm_build_jobs_*_dev (called with these group_off / n_groups), np_resolve_jobs_dev, np_calibrate_resolve_dev,
+ *     np_cm_discard_degenerate_dev and np_hmm_score_dev
+ * touch live items only: unused slots are neither written nor read, and their scores are NaN (one fill).  group_off and n_groups
+ * (device arrays) must stay valid until the layout is cleared or replaced; n_jobs of those calls must be 2 * total_slots (anything else
+ * is refused).  n_reads = 0 clears the layout: every kernel visits all n_jobs items again, as a caller with work items of its own needs
+ * (the default).  Results never depend on it.  Reference: the per-read group lists of calculate_methylation_for_read,
+ * src/basemods/nanopolish_basemods.cpp:289-336 -- the reference has no slots to skip. */
+int np_set_job_layout(np_ctx* ctx, int n_reads, const int64_t* group_off, const int32_t* n_groups, int64_t total_slots);
+
 /* After np_resolve_jobs_dev / np_calibrate_resolve_dev: drops every work item of a read whose first and last aligned event
  * coincide (the "degenerate alignment" rule of EventAlignmentRecord, alignment_db.cpp:83-86). */
 int np_cm_discard_degenerate_dev(np_ctx* ctx, void* stream, const np_read_dev* reads, const int32_t* map_start,

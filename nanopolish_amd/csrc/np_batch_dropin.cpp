@@ -643,6 +643,8 @@ void NpBatchPipeline::Impl::pack(const std::vector<Slot*>& group, int dev)
         uint16_t* job_ranks = (uint16_t*)(X + s_job_ranks);
         np_detector_param prm;
         np_event_detection_params(&prm, 0);
+        // the slot layout of this pass's work items: the kernels from the builder to the scorer visit live items only (np_set_job_layout)
+        check(np_set_job_layout(c, n, d_group_off, n_groups, n_slots), "np_set_job_layout");
         check(np_cm_build_jobs_cigar_dev(c, NULL, n, genome, ref_begin, ref_len, cigar, d_cigar_off, cigar_off[n], read_len, rc, alphabet, k, MINSEP,
                                          FLANK, d_group_off, n_slots, d_jr_off, jobs, kpos, job_ranks, first, last, n_motif, n_groups, deg),
               "np_cm_build_jobs_cigar_dev");
@@ -657,6 +659,7 @@ void NpBatchPipeline::Impl::pack(const std::vector<Slot*>& group, int dev)
                                        calibrated, n_jobs, jobs, kpos), "np_calibrate_resolve_dev");
         check(np_cm_discard_degenerate_dev(c, NULL, reads_b, map_start, deg, n_jobs, jobs), "np_cm_discard_degenerate_dev");
         check(np_hmm_score_dev(c, NULL, n_jobs, jobs, reads_b, ev_mean, job_ranks, m_meth, scores), "np_hmm_score_dev");
+        check(np_set_job_layout(c, 0, NULL, NULL, 0), "np_set_job_layout");
     }
     check(np_event_record(c, P.ev_cmp, NULL), "np_event_record");
     check(np_stream_wait_event(c, D.s_d2h, P.ev_cmp), "np_stream_wait_event");

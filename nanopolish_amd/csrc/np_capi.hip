@@ -90,6 +90,7 @@ struct np_ctx {
     int hmm_prio = 0;                 // wave priority of the forward kernels
     bool host_constants = false;      // the per-read constants that go through libm are computed on the HOST with the process's own log / exp / logf (np_create)
     double* d_log_n = nullptr;        // host_constants: log(1 .. 64) for profile_hmm_score_set's penalty
+    np_slots lay = {nullptr, nullptr, 0}; int64_t lay_total = 0;   // np_set_job_layout: the slot layout of the work-item arrays of the calls that follow
     int recal_shape = 0;              // np_recalibrate_kernel's workgroup shape (0: default; 1, 2: A/B alternatives, same results)
     int align_lpt = 1;                // issue the event aligner's reads longest first
     int stream_switch_wait = 1;       // a call on a new stream waits for the tail of the stream the context used before (0: the caller orders its streams itself)
@@ -226,6 +227,17 @@ int host_constants_fix(np_ctx* c, hipStream_t s, int n_reads, np_read_dev* reads
     return NP_OK;
 }
 
+// the slot layout a consumer of `n_jobs` work items may use: the declared one when it describes exactly this array, none otherwise
+// (a declared layout with another item count is the caller's mistake: refused, not guessed at)
+int layout_for(np_ctx* c, int64_t n_jobs, np_slots* out)
+{
+    *out = np_slots{nullptr, nullptr, 0};
+    if (c->lay.n_reads <= 0 || n_jobs <= 0) return NP_OK;
+    if (n_jobs != 2 * c->lay_total) { c->err = "np_set_job_layout describes another work-item array (2 x total_slots != n_jobs): clear it with n_reads = 0"; return NP_ERR_INVALID; }
+    *out = c->lay;
+    return NP_OK;
+}
+
 // ---- kernel B driver: classify + one persistent launch per non-empty size class ----------------------
 // class_mask: bit cls set = the size class may hold work items (the *_dev callers do not know: all eight; the host entry points
 // see the items and launch only the classes that occur -- a per-call round is launch-bound, and six empty persistent launches each
@@ -239,7 +251,9 @@ int run_hmm_forward(np_ctx* c, hipStream_t s, int64_t n_jobs, const np_hmm_job_d
     NP_HIP(c, c->order.reserve((size_t)NP_NUM_CLASSES * (size_t)n_jobs * sizeof(uint32_t)));
     NP_HIP(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint32_t), s));
     family_timer tm(c, 1, s);
-    NP_HIP(c, np_launch_classify(jobs, n_jobs, c->d_counters, c->order.as<uint32_t>(), out, NP_FLANK_LEN, c->d_counters + 1024, s));
+    np_slots lay;
+    { const int rc = layout_for(c, n_jobs, &lay); if (rc != NP_OK) return rc; }
+    NP_HIP(c, np_launch_classify(jobs, n_jobs, c->d_counters, c->order.as<uint32_t>(), out, NP_FLANK_LEN, c->d_counters + 1024, lay, s));
     for (int cls = 0; cls < NP_NUM_CLASSES; ++cls) {
         if (!(class_mask >> cls & 1u)) continue;
         np_hmm_args a{};
@@ -772,7 +786,9 @@ int np_resolve_jobs_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* reads
     NP_HIP(c, np_launch_build_map(n_reads, reads, pair_off, pairs, pair_begin, n_pairs, map_start, nullptr, events_per_base,
                                   c->params.hmm_indel_bias_factor, s));
     if (c->host_constants) { const int rc = host_constants_fix(c, s, n_reads, reads, events_per_base, 2); if (rc != NP_OK) return rc; }
-    NP_HIP(c, np_launch_resolve(n_jobs, jobs, reads, n_pairs, events_per_base, nullptr, map_start, kpos, s));
+    np_slots lay;
+    { const int rc = layout_for(c, n_jobs, &lay); if (rc != NP_OK) return rc; }
+    NP_HIP(c, np_launch_resolve(n_jobs, jobs, reads, n_pairs, events_per_base, nullptr, map_start, kpos, lay, s));
     return NP_OK;
 }
 
@@ -805,7 +821,9 @@ int np_calibrate_resolve_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* 
     NP_HIP(c, np_launch_recalibrate(n_reads, reads, event_mean, kmer_rank, c->models[model].d_states, c->models[model].n_states, n_pairs, map_start,
                                     calibrated, order, c->recal_shape, s));
     if (c->host_constants) { const int rc = host_constants_fix(c, s, n_reads, reads, events_per_base, 2 | 4); if (rc != NP_OK) return rc; }
-    NP_HIP(c, np_launch_resolve(n_jobs, jobs, reads, n_pairs, events_per_base, calibrated, map_start, kpos, s));
+    np_slots lay;
+    { const int rc = layout_for(c, n_jobs, &lay); if (rc != NP_OK) return rc; }
+    NP_HIP(c, np_launch_resolve(n_jobs, jobs, reads, n_pairs, events_per_base, calibrated, map_start, kpos, lay, s));
     return NP_OK;
 }
 
@@ -1043,7 +1061,7 @@ int np_hmm_align_host(np_ctx* c, int n_jobs, const np_hmm_job* jobs, np_hmm_stat
     NP_HIP(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint32_t), s));
     {
         family_timer tm(c, 3, s);
-        NP_HIP(c, np_launch_classify(c->b_jobs.as<np_hmm_job_dev>(), n_jobs, c->d_counters, c->order.as<uint32_t>(), nullptr, NP_FLANK_LEN, c->d_counters + 1024, s));
+        NP_HIP(c, np_launch_classify(c->b_jobs.as<np_hmm_job_dev>(), n_jobs, c->d_counters, c->order.as<uint32_t>(), nullptr, NP_FLANK_LEN, c->d_counters + 1024, np_slots{nullptr, nullptr, 0}, s));
         np_hmm_args a{};
         a.jobs = c->b_jobs.as<np_hmm_job_dev>(); a.reads = c->b_reads.as<np_read_dev>(); a.event_mean = c->b_events.as<float>();
         a.ranks = c->b_ranks.as<uint16_t>(); a.model = c->models[model].d_states; a.logsum = c->d_logsum; a.flank = c->d_flank;
@@ -1146,7 +1164,8 @@ int np_cm_build_jobs_identity_dev(np_ctx* c, void* stream, int n_reads, const ch
     {
         family_timer tm(c, 2, s);
         NP_HIP(c, np_launch_cm_build_jobs(n_reads, ref_seq, seq_off, read_rc, alphabet, (int)k, min_separation, min_flank, group_off, rank_off, jobs,
-                                          kpos, job_ranks, first_site, last_site, n_motif, c->cm_group_rank_off.as<int64_t>(), n_groups, s));
+                                          kpos, job_ranks, first_site, last_site, n_motif, c->cm_group_rank_off.as<int64_t>(), n_groups,
+                                          !(c->lay.n_reads == n_reads && c->lay.group_off == group_off && c->lay.n_groups == n_groups), s));
     }
     return NP_OK;
 }
@@ -1177,8 +1196,18 @@ int np_cm_build_jobs_cigar_dev(np_ctx* c, void* stream, int n_reads, const char*
         family_timer tm(c, 2, s);
         NP_HIP(c, np_launch_cm_build_jobs_cigar(n_reads, genome, ref_begin, ref_len, cigar, cigar_off, read_len, read_rc, alphabet, (int)k,
                                                 min_separation, min_flank, group_off, rank_off, jobs, kpos, job_ranks, first_site, last_site, n_motif,
-                                                c->cm_group_rank_off.as<int64_t>(), n_groups, deg_kpos, op_ref, op_read, cig_reads, group_kpos, s));
+                                                c->cm_group_rank_off.as<int64_t>(), n_groups, deg_kpos, op_ref, op_read, cig_reads, group_kpos,
+                                                !(c->lay.n_reads == n_reads && c->lay.group_off == group_off && c->lay.n_groups == n_groups), s));
     }
+    return NP_OK;
+}
+
+int np_set_job_layout(np_ctx* c, int n_reads, const int64_t* group_off, const int32_t* n_groups, int64_t total_slots)
+{
+    if (!c || n_reads < 0 || (n_reads > 0 && (!group_off || !n_groups || total_slots < 0))) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    if (n_reads == 0) { c->lay = np_slots{nullptr, nullptr, 0}; c->lay_total = 0; }
+    else { c->lay = np_slots{group_off, n_groups, n_reads}; c->lay_total = total_slots; }
     return NP_OK;
 }
 
@@ -1190,7 +1219,9 @@ int np_cm_discard_degenerate_dev(np_ctx* c, void* stream, const np_read_dev* rea
     NP_HIP(c, hipSetDevice(c->device));
     stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
     family_timer tm(c, 2, s);
-    NP_HIP(c, np_launch_discard_degenerate(n_jobs, jobs, reads, map_start, deg_kpos, s));
+    np_slots lay;
+    { const int rc = layout_for(c, n_jobs, &lay); if (rc != NP_OK) return rc; }
+    NP_HIP(c, np_launch_discard_degenerate(n_jobs, jobs, reads, map_start, deg_kpos, lay, s));
     return NP_OK;
 }
 

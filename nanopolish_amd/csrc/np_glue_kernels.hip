@@ -324,14 +324,10 @@ __global__ void __launch_bounds__(64 * W) np_recalibrate_kernel(int n_reads, np_
 // bounds: the odd lane takes the even lane's result (DPP) instead of repeating the two closest-event searches -- checked per pair, not
 // assumed: neighbours of different reads or bounds each search for themselves.  Only the item's second half (e_start, e_stop, stride,
 // flags: 16 of its 32 bytes) is read and written.
-__global__ void __launch_bounds__(256) np_resolve_kernel(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads,
-                                                         const int32_t* n_pairs, const double* events_per_base,
-                                                         const int32_t* calibrated, const int32_t* map_start, const int32_t* kpos)
+__device__ __forceinline__ void resolve_item(bool valid, int64_t jj, np_hmm_job_dev* jobs, const np_read_dev* reads, const int32_t* n_pairs,
+                                             const double* events_per_base, const int32_t* calibrated, const int32_t* map_start, const int32_t* kpos)
 {
     static_assert(sizeof(np_hmm_job_dev) == 32 && offsetof(np_hmm_job_dev, e_start) == 16 && offsetof(np_hmm_job_dev, read) == 12, "np_hmm_job_dev layout");
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool valid = j < n_jobs;
-    const int64_t jj = valid ? j : n_jobs - 1;
     const int read = (int)jobs[jj].read;
     uint4* tail = reinterpret_cast<uint4*>(reinterpret_cast<char*>(jobs + jj) + 16);
     uint4 t = *tail;                                                             // e_start, e_stop, stride, flags
@@ -369,6 +365,62 @@ __global__ void __launch_bounds__(256) np_resolve_kernel(int64_t n_jobs, np_hmm_
         t.w |= (uint32_t)NP_JOB_SKIP;                                            // classify drops it, score = NaN
     }
     if (valid) *tail = t;
+}
+
+__global__ void __launch_bounds__(256) np_resolve_kernel(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads,
+                                                         const int32_t* n_pairs, const double* events_per_base,
+                                                         const int32_t* calibrated, const int32_t* map_start, const int32_t* kpos)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    resolve_item(j < n_jobs, j < n_jobs ? j : n_jobs - 1, jobs, reads, n_pairs, events_per_base, calibrated, map_start, kpos);
+}
+
+// ---- the same kernels over a SLOT LAYOUT (np_set_job_layout, round 5) ---------------------------------------------------------------
+// The device builder lays work items out in per-read slot ranges sized for the worst case (one group per min_separation + 1 bases:
+// 497 slots for a 5 450-base read that has 182 groups), and every kernel that walked "all n_jobs items" spent 63 % of its memory traffic
+// on slots that hold nothing -- a 32-byte sector per slot whether 4 or 32 bytes of it are wanted (profiles/r05_pmc.json: np_resolve_kernel
+// 62 KB fetched + 32 KB written per read).  With the layout a workgroup takes NP_SLOT_RPB consecutive reads and visits their LIVE items
+// only; unused slots are neither read nor written (their scores are NaN from one fill).
+#define NP_SLOT_RPB 12
+struct slot_block {
+    int64_t base[NP_SLOT_RPB];
+    int pre[NP_SLOT_RPB + 1];
+};
+__device__ __forceinline__ int slot_block_init(slot_block& B, np_slots L)
+{
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int q = 0; q < NP_SLOT_RPB; ++q) {
+            const int r = blockIdx.x * NP_SLOT_RPB + q;
+            const int ng = r < L.n_reads ? L.n_groups[r] : 0;
+            B.base[q] = r < L.n_reads ? 2 * L.group_off[r] : 0;
+            B.pre[q] = acc;
+            acc += 2 * (ng > 0 ? ng : 0);
+        }
+        B.pre[NP_SLOT_RPB] = acc;
+    }
+    __syncthreads();
+    return B.pre[NP_SLOT_RPB];
+}
+__device__ __forceinline__ int64_t slot_item(const slot_block& B, int idx)       // idx < B.pre[NP_SLOT_RPB]
+{
+    int q = 0;
+#pragma unroll
+    for (int t = 1; t < NP_SLOT_RPB; ++t) q += idx >= B.pre[t] ? 1 : 0;
+    return B.base[q] + (idx - B.pre[q]);
+}
+
+__global__ void __launch_bounds__(256) np_resolve_slots_kernel(np_slots L, np_hmm_job_dev* jobs, const np_read_dev* reads, const int32_t* n_pairs,
+                                                               const double* events_per_base, const int32_t* calibrated, const int32_t* map_start,
+                                                               const int32_t* kpos)
+{
+    __shared__ slot_block B;
+    const int total = slot_block_init(B, L);
+    // (a read's live items are an even number, so an item's parity is its thread's: the odd lane's partner is lane - 1 here too)
+    for (int i0 = 0; i0 < total; i0 += 256) {
+        const int idx = i0 + threadIdx.x;
+        resolve_item(idx < total, slot_item(B, idx < total ? idx : total - 1), jobs, reads, n_pairs, events_per_base, calibrated, map_start, kpos);
+    }
 }
 
 // (size_class / job_bin: np_kernels.h -- the host entry points bin small batches themselves)
@@ -433,17 +485,73 @@ __global__ void __launch_bounds__(256) np_bin_scatter_kernel(const np_hmm_job_de
             order[(size_t)(bin[t] / (NP_CPL * NP_EBUCKETS)) * (size_t)n_jobs + h[bin[t]] + local[t]] = (uint32_t)(base + t * 256 + threadIdx.x);
 }
 
+// the two binning passes over a slot layout: a workgroup's reads hold ~4 400 live items (12 x 2 x 182), the scatter takes them 4 096 at a time
+__global__ void __launch_bounds__(256) np_bin_count_slots_kernel(np_slots L, const np_hmm_job_dev* jobs, uint32_t* hist, uint32_t flank_len)
+{
+    __shared__ slot_block B;
+    __shared__ uint32_t h[NP_NBINS];
+    for (int i = threadIdx.x; i < NP_NBINS; i += 256) h[i] = 0;
+    const int total = slot_block_init(B, L);
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        const int bin = np_job_bin(jobs[slot_item(B, idx)], flank_len);
+        if (bin >= 0) atomicAdd(&h[bin], 1u);                             // (a skipped item's score is NaN already: the launcher's fill)
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NP_NBINS; i += 256) if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+__global__ void __launch_bounds__(256) np_bin_scatter_slots_kernel(np_slots L, const np_hmm_job_dev* jobs, int64_t n_jobs, uint32_t* cursor,
+                                                                   uint32_t* order, uint32_t flank_len)
+{
+    __shared__ slot_block B;
+    __shared__ uint32_t h[NP_NBINS];
+    const int total = slot_block_init(B, L);
+    for (int c0 = 0; c0 < total; c0 += NP_BIN_ITEMS) {
+        for (int i = threadIdx.x; i < NP_NBINS; i += 256) h[i] = 0;
+        __syncthreads();
+        int bin[NP_BIN_ITEMS / 256]; uint32_t local[NP_BIN_ITEMS / 256]; uint32_t item[NP_BIN_ITEMS / 256];
+#pragma unroll
+        for (int t = 0; t < NP_BIN_ITEMS / 256; ++t) {
+            const int idx = c0 + t * 256 + threadIdx.x;
+            bin[t] = -1; local[t] = 0; item[t] = 0;
+            if (idx < total) {
+                const int64_t j = slot_item(B, idx);
+                item[t] = (uint32_t)j;
+                bin[t] = np_job_bin(jobs[j], flank_len);
+                if (bin[t] >= 0) local[t] = atomicAdd(&h[bin[t]], 1u);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < NP_NBINS; i += 256) { const uint32_t n = h[i]; if (n) h[i] = atomicAdd(&cursor[i], n); }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NP_BIN_ITEMS / 256; ++t)
+            if (bin[t] >= 0)
+                order[(size_t)(bin[t] / (NP_CPL * NP_EBUCKETS)) * (size_t)n_jobs + h[bin[t]] + local[t]] = item[t];
+        __syncthreads();
+    }
+}
+
 } // namespace
 
 // bins: device scratch of 2 * NP_NBINS uint32 (histogram, cursors)
 hipError_t np_launch_classify(const np_hmm_job_dev* jobs, int64_t n_jobs, uint32_t* class_count, uint32_t* order,
-                              float* out_scores, uint32_t flank_len, uint32_t* bins, hipStream_t s)
+                              float* out_scores, uint32_t flank_len, uint32_t* bins, np_slots lay, hipStream_t s)
 {
     if (n_jobs <= 0) return hipSuccess;
     uint32_t* hist = bins;
     uint32_t* cursor = bins + NP_NBINS;
     hipError_t e = hipMemsetAsync(bins, 0, 2 * NP_NBINS * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
+    if (lay.n_reads > 0) {
+        // every item's score starts as NaN (what a skipped item and an unused slot end with); the kernels visit live items only
+        if (out_scores) { e = hipMemsetD32Async((hipDeviceptr_t)out_scores, 0x7fc00000, (size_t)n_jobs, s); if (e != hipSuccess) return e; }
+        const unsigned nbs = (unsigned)((lay.n_reads + NP_SLOT_RPB - 1) / NP_SLOT_RPB);
+        hipLaunchKernelGGL(np_bin_count_slots_kernel, dim3(nbs), dim3(256), 0, s, lay, jobs, hist, flank_len);
+        hipLaunchKernelGGL(np_bin_scan_kernel, dim3(1), dim3(64), 0, s, hist, cursor, class_count);
+        hipLaunchKernelGGL(np_bin_scatter_slots_kernel, dim3(nbs), dim3(256), 0, s, lay, jobs, n_jobs, cursor, order, flank_len);
+        return hipGetLastError();
+    }
     const unsigned nb = (unsigned)((n_jobs + NP_BIN_ITEMS - 1) / NP_BIN_ITEMS);
     hipLaunchKernelGGL(np_bin_count_kernel, dim3(nb), dim3(256), 0, s, jobs, n_jobs, hist, out_scores, flank_len);
     hipLaunchKernelGGL(np_bin_scan_kernel, dim3(1), dim3(64), 0, s, hist, cursor, class_count);
@@ -467,11 +575,8 @@ namespace {
 // EventAlignmentRecord discards a record whose first and last aligned event coincide (alignment_db.cpp:83-86): every
 // work item of such a read is unbounded.  deg_kpos holds, per read, the read-strand k-mer positions of the first and last
 // aligned base that pass the record's filter (-1: none).  Thread per work item, after np_resolve_kernel.
-__global__ void __launch_bounds__(256) np_discard_degenerate_kernel(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads,
-                                                                    const int32_t* map_start, const int32_t* deg_kpos)
+__device__ __forceinline__ void discard_item(int64_t j, np_hmm_job_dev* jobs, const np_read_dev* reads, const int32_t* map_start, const int32_t* deg_kpos)
 {
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= n_jobs) return;
     np_hmm_job_dev job = jobs[j];
     if (job.flags & NP_JOB_SKIP) return;
     const np_read_dev* rd = reads + job.read;
@@ -484,12 +589,30 @@ __global__ void __launch_bounds__(256) np_discard_degenerate_kernel(int64_t n_jo
     }
     if (drop) { job.e_start = 0; job.e_stop = 0; job.stride = 1; job.flags |= NP_JOB_SKIP; jobs[j] = job; }
 }
+__global__ void __launch_bounds__(256) np_discard_degenerate_kernel(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads,
+                                                                    const int32_t* map_start, const int32_t* deg_kpos)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < n_jobs) discard_item(j, jobs, reads, map_start, deg_kpos);
+}
+__global__ void __launch_bounds__(256) np_discard_degenerate_slots_kernel(np_slots L, np_hmm_job_dev* jobs, const np_read_dev* reads,
+                                                                          const int32_t* map_start, const int32_t* deg_kpos)
+{
+    __shared__ slot_block B;
+    const int total = slot_block_init(B, L);
+    for (int idx = threadIdx.x; idx < total; idx += 256) discard_item(slot_item(B, idx), jobs, reads, map_start, deg_kpos);
+}
 } // namespace
 
 hipError_t np_launch_discard_degenerate(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads, const int32_t* map_start,
-                                        const int32_t* deg_kpos, hipStream_t s)
+                                        const int32_t* deg_kpos, np_slots lay, hipStream_t s)
 {
     if (n_jobs <= 0) return hipSuccess;
+    if (lay.n_reads > 0) {
+        hipLaunchKernelGGL(np_discard_degenerate_slots_kernel, dim3((unsigned)((lay.n_reads + NP_SLOT_RPB - 1) / NP_SLOT_RPB)), dim3(256), 0, s, lay, jobs, reads,
+                           map_start, deg_kpos);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(np_discard_degenerate_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, s, n_jobs, jobs, reads,
                        map_start, deg_kpos);
     return hipGetLastError();
@@ -497,9 +620,14 @@ hipError_t np_launch_discard_degenerate(int64_t n_jobs, np_hmm_job_dev* jobs, co
 
 hipError_t np_launch_resolve(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads, const int32_t* n_pairs,
                              const double* events_per_base, const int32_t* calibrated, const int32_t* map_start,
-                             const int32_t* kpos, hipStream_t s)
+                             const int32_t* kpos, np_slots lay, hipStream_t s)
 {
     if (n_jobs <= 0) return hipSuccess;
+    if (lay.n_reads > 0) {
+        hipLaunchKernelGGL(np_resolve_slots_kernel, dim3((unsigned)((lay.n_reads + NP_SLOT_RPB - 1) / NP_SLOT_RPB)), dim3(256), 0, s, lay, jobs, reads, n_pairs,
+                           events_per_base, calibrated, map_start, kpos);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(np_resolve_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, s,
                        n_jobs, jobs, reads, n_pairs, events_per_base, calibrated, map_start, kpos);
     return hipGetLastError();

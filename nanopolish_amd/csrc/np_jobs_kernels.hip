@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256) np_cm_items_kernel(int n_reads, const cha
                                                           const int64_t* __restrict__ group_off, const int32_t* __restrict__ first_site,
                                                           const int32_t* __restrict__ last_site, const int64_t* __restrict__ group_rank_off,
                                                           const int32_t* __restrict__ n_groups, np_hmm_job_dev* __restrict__ jobs,
-                                                          int32_t* __restrict__ kpos, uint16_t* __restrict__ job_ranks)
+                                                          int32_t* __restrict__ kpos, uint16_t* __restrict__ job_ranks, int write_unused)
 {
     const int r = blockIdx.x;
     if (r >= n_reads) return;
@@ -268,8 +268,9 @@ __global__ void __launch_bounds__(256) np_cm_items_kernel(int n_reads, const cha
     const int64_t g0 = group_off[r];
     const int cap = (int)(group_off[r + 1] - g0);
     const int ng = n_groups[r] > 0 ? n_groups[r] : 0;
-    // the work-item records: two per group slot; unused slots are items the scoring kernel drops (score NaN)
-    for (int g = threadIdx.x; g < cap; g += 256) {
+    // the work-item records: two per group slot; unused slots are items the scoring kernel drops (score NaN) -- or, when the caller has
+    // declared the slot layout (np_set_job_layout: every consumer then visits live items only), are not touched at all
+    for (int g = threadIdx.x; g < (write_unused ? cap : ng); g += 256) {
         np_hmm_job_dev jb; jb.rank_off = 0; jb.n_kmers = 0; jb.read = (uint32_t)r; jb.e_start = jb.e_stop = 0; jb.stride = 1; jb.flags = NP_JOB_SKIP;
         int k0 = 0, k1 = 0, nk = 0;
         if (g < ng) {
@@ -370,14 +371,14 @@ __global__ void __launch_bounds__(256) np_cm_items_kernel(int n_reads, const cha
 hipError_t np_launch_cm_build_jobs(int n_reads, const char* seq, const int64_t* seq_off, const uint8_t* read_rc, int alphabet, int k,
                                    int min_separation, int min_flank, const int64_t* group_off, const int64_t* rank_off_cap,
                                    np_hmm_job_dev* jobs, int32_t* kpos, uint16_t* job_ranks, int32_t* first_site, int32_t* last_site,
-                                   int32_t* n_motif, int64_t* group_rank_off, int32_t* n_groups, hipStream_t s)
+                                   int32_t* n_motif, int64_t* group_rank_off, int32_t* n_groups, int write_unused, hipStream_t s)
 {
     if (n_reads <= 0) return hipSuccess;
     hipLaunchKernelGGL(np_cm_groups_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, seq, seq_off, nullptr, read_rc, nullptr, nullptr,
                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, alphabet, k, min_separation,
                        min_flank, group_off, rank_off_cap, first_site, last_site, n_motif, group_rank_off, n_groups);
     hipLaunchKernelGGL(np_cm_items_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, seq, seq_off, nullptr, nullptr, read_rc, alphabet, k, min_flank,
-                       group_off, first_site, last_site, group_rank_off, n_groups, jobs, kpos, job_ranks);
+                       group_off, first_site, last_site, group_rank_off, n_groups, jobs, kpos, job_ranks, write_unused);
     return hipGetLastError();
 }
 
@@ -390,7 +391,7 @@ hipError_t np_launch_cm_build_jobs_cigar(int n_reads, const char* genome, const 
                                          const int64_t* rank_off_cap, np_hmm_job_dev* jobs, int32_t* kpos, uint16_t* job_ranks,
                                          int32_t* first_site, int32_t* last_site, int32_t* n_motif, int64_t* group_rank_off,
                                          int32_t* n_groups, int32_t* deg_kpos, int32_t* op_ref, int32_t* op_read, void* cig_reads,
-                                         int32_t* group_kpos, hipStream_t s)
+                                         int32_t* group_kpos, int write_unused, hipStream_t s)
 {
     if (n_reads <= 0) return hipSuccess;
     hipLaunchKernelGGL(np_cigar_index_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, cigar, cigar_off, read_len, k, op_ref, op_read,
@@ -399,7 +400,7 @@ hipError_t np_launch_cm_build_jobs_cigar(int n_reads, const char* genome, const 
                        cigar_off, read_len, op_ref, op_read, (const cig_read_t*)cig_reads, group_kpos, deg_kpos, alphabet, k, min_separation,
                        min_flank, group_off, rank_off_cap, first_site, last_site, n_motif, group_rank_off, n_groups);
     hipLaunchKernelGGL(np_cm_items_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, genome, ref_begin, ref_len, group_kpos, read_rc, alphabet, k,
-                       min_flank, group_off, first_site, last_site, group_rank_off, n_groups, jobs, kpos, job_ranks);
+                       min_flank, group_off, first_site, last_site, group_rank_off, n_groups, jobs, kpos, job_ranks, write_unused);
     return hipGetLastError();
 }
 

@@ -145,8 +145,11 @@ int np_hmm_block_threads(int cls);
 int np_vit_block_threads(void);
 
 // glue kernels
+// The slot layout of a work-item array (np_set_job_layout): read r owns items [2 group_off[r], 2 group_off[r + 1]), of which the first
+// 2 max(n_groups[r], 0) are live; n_reads == 0: no layout, every kernel visits all n_jobs items.
+struct np_slots { const int64_t* group_off; const int32_t* n_groups; int n_reads; };
 hipError_t np_launch_classify(const np_hmm_job_dev* jobs, int64_t n_jobs, uint32_t* class_count /*[7]*/,
-                              uint32_t* order /*[NP_NUM_CLASSES][n_jobs]*/, float* out_scores, uint32_t flank_len, uint32_t* bins /*[2 * 8 * 8 * 64]*/, hipStream_t s);
+                              uint32_t* order /*[NP_NUM_CLASSES][n_jobs]*/, float* out_scores, uint32_t flank_len, uint32_t* bins /*[2 * 8 * 8 * 64]*/, np_slots lay, hipStream_t s);
 hipError_t np_launch_build_map(int n_reads, np_read_dev* reads, const int64_t* pair_off, const np_pair* pairs,
                                const int32_t* pair_begin, const int32_t* n_pairs, int32_t* map_start, int32_t* map_stop,
                                double* events_per_base, double indel_bias, hipStream_t s);
@@ -155,10 +158,10 @@ hipError_t np_launch_recalibrate(int n_reads, np_read_dev* reads, const float* e
                                  int32_t* calibrated, const uint32_t* order /* read order of the groups (np_launch_align_order) or null */,
                                  int shape /* 0: the default workgroup shape; 1, 2: A/B alternatives */, hipStream_t s);
 hipError_t np_launch_discard_degenerate(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads, const int32_t* map_start,
-                                        const int32_t* deg_kpos, hipStream_t s);
+                                        const int32_t* deg_kpos, np_slots lay, hipStream_t s);
 hipError_t np_launch_resolve(int64_t n_jobs, np_hmm_job_dev* jobs, const np_read_dev* reads, const int32_t* n_pairs,
                              const double* events_per_base, const int32_t* calibrated, const int32_t* map_start,
-                             const int32_t* kpos, hipStream_t s);
+                             const int32_t* kpos, np_slots lay, hipStream_t s);
 hipError_t np_launch_site_table(int64_t n_groups, const float* scores, const int32_t* first_site, const int32_t* n_motif,
                                 const np_hmm_job_dev* jobs, const int64_t* read_base, double call_threshold, int64_t n_pos,
                                 int32_t* table, hipStream_t s);
@@ -182,7 +185,7 @@ hipError_t np_launch_mom_fill(int n_reads, np_read_dev* reads, np_read_dev* read
 hipError_t np_launch_cm_build_jobs(int n_reads, const char* seq, const int64_t* seq_off, const uint8_t* read_rc, int alphabet, int k,
                                    int min_separation, int min_flank, const int64_t* group_off, const int64_t* rank_off_cap,
                                    np_hmm_job_dev* jobs, int32_t* kpos, uint16_t* job_ranks, int32_t* first_site, int32_t* last_site,
-                                   int32_t* n_motif, int64_t* group_rank_off, int32_t* n_groups, hipStream_t s);
+                                   int32_t* n_motif, int64_t* group_rank_off, int32_t* n_groups, int write_unused, hipStream_t s);
 hipError_t np_launch_eventalign_chain(const np_ea_args& a, const np_ea_args* a_dev, int n_blocks, int variant, hipStream_t s);
 int np_eventalign_line_bytes(int variant);
 int np_eventalign_max_kmers(int variant);
@@ -194,4 +197,4 @@ hipError_t np_launch_cm_build_jobs_cigar(int n_reads, const char* genome, const 
                                          const int64_t* rank_off_cap, np_hmm_job_dev* jobs, int32_t* kpos, uint16_t* job_ranks,
                                          int32_t* first_site, int32_t* last_site, int32_t* n_motif, int64_t* group_rank_off,
                                          int32_t* n_groups, int32_t* deg_kpos, int32_t* op_ref, int32_t* op_read, void* cig_reads,
-                                         int32_t* group_kpos, hipStream_t s);
+                                         int32_t* group_kpos, int write_unused, hipStream_t s);

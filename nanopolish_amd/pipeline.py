@@ -14,6 +14,7 @@ Inputs are uploaded once; `step()` only enqueues kernels through the C ABI's *_d
 torch is used for device memory only.
 """
 import ctypes as C
+import os
 import numpy as np
 
 from . import lib as _l
@@ -271,6 +272,7 @@ class CallMethylationBatch:
         self.ctx = ctx
         self.hb = hb
         self.stream = None         # raw hipStream_t the step is enqueued on (None: the context's own stream)
+        self.use_job_layout = os.environ.get("NP_JOB_LAYOUT", "1") != "0"     # tests: the same pass with and without np_set_job_layout
         self.n_reads = hb["n"]
         self.n_jobs = len(hb["jobs"])
         dev = torch.device(device)
@@ -370,6 +372,18 @@ class CallMethylationBatch:
         s = C.c_void_p(self.stream) if self.stream else None      # raw hipStream_t (0 / None: the context's own stream)
         ea = self.workload == "eventalign"
         n_jobs = 0 if ea else self.n_jobs
+        # the slot layout of this batch's work items (np_set_job_layout): the kernels between the builder and the scorer visit live items
+        # only.  Declared per call -- a context serves several batches -- and cleared on the way out.
+        slots = self.jobs_on_device and not ea and self.use_job_layout
+        if slots:
+            self.ctx._chk(L.np_set_job_layout(h, self.n_reads, p(self.d_group_off), p(self.d_n_groups), self.n_slots), "np_set_job_layout")
+        try:
+            return self._step(L, h, p, s, ea, n_jobs, stage)
+        finally:
+            if slots:
+                L.np_set_job_layout(h, 0, None, None, 0)
+
+    def _step(self, L, h, p, s, ea, n_jobs, stage):
         if stage == 2:
             self._step_glue(L, h, p, s, ea, n_jobs)
             return self._step_hmm(L, h, p, s, ea)

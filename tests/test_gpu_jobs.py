@@ -99,3 +99,35 @@ def test_whole_chain_on_device_matches_oracle(ctx, orc, models):
             assert got == {int(f): (float(a), float(b)) for f, a, b in zip(want["first"], want["unmeth"], want["meth"])}
             n_scored += len(got)
     assert n_scored > 400
+
+
+def test_slot_layout_changes_nothing(ctx, orc, models):
+    """np_set_job_layout (round 5): the kernels between the work-item builder and the scorer visit the live items of every read's slot range
+    only.  The whole pass -- identity and CIGAR work items, ragged reads, reads without a single site, from events and from raw signal --
+    with the layout declared (the pipeline's default) and without: the same scores in every slot (NaN in the unused ones either way), the
+    same groups, the same per-site table; and a layout that describes another array is refused."""
+    import ctypes as C
+    import torch
+    from nanopolish_amd.pipeline import build_host_batch, tile_host_batch, CallMethylationBatch
+    from nanopolish_amd.sites import site_table_dev
+    for raw in (False, True):
+        hb = build_host_batch(models, list(range(700, 720)), L=[64, 23, 300] + [700 + 211 * i for i in range(17)], raw=raw, with_jobs=False)
+        res = []
+        for use in (True, False, True):
+            b = CallMethylationBatch(ctx, tile_host_batch(hb, 2), "cuda:0", calibrate=True, from_raw=raw, jobs_on_device=True)
+            b.use_job_layout = use
+            b.step(); b.step()
+            sc = b.scores()
+            b.max_len = int(max(len(q) for q in hb["ref_seqs"]))
+            tbl = site_table_dev(ctx, torch, b.d_scores, b.d_first, b.d_n_motif, b.max_len); ctx.sync()
+            groups = [tuple(np.asarray(x).tobytes() for x in b.groups_of(i)) for i in range(b.n_reads)]
+            res.append((sc.tobytes(), tbl.cpu().numpy().tobytes(), groups, int(np.isfinite(sc).sum())))
+            if use:      # a declared layout must describe the array the call works on
+                p = lambda t: C.c_void_p(t.data_ptr())
+                assert ctx.L.np_set_job_layout(ctx.h, b.n_reads, p(b.d_group_off), p(b.d_n_groups), b.n_slots + 1) == 0
+                rc = ctx.L.np_hmm_score_dev(ctx.h, None, b.n_jobs, p(b.d_jobs), p(b.d_reads_b), p(b.d_events), p(b.d_job_ranks), b.m_cpg, p(b.d_scores))
+                assert rc != 0
+                assert ctx.L.np_set_job_layout(ctx.h, 0, None, None, 0) == 0
+            del b
+        assert res[0][3] > 1000
+        assert res[0] == res[1] == res[2]

@@ -59,7 +59,7 @@ def main():
             b.step()
         ctx.sync(); torch.cuda.synchronize()
         jh = b.jobs_host()
-        live = (jh["flags"] & 0x80000000) == 0
+        live = ((jh["flags"] & 0x80000000) == 0) & (jh["n_kmers"] > 0)       # (slots past a read's groups are not written under np_set_job_layout)
         e = np.abs(jh["e_stop"].astype(np.int64) - jh["e_start"].astype(np.int64)) + 1
         n = jh["n_kmers"].astype(np.int64)
         ms = {k: ctx.kernel_time(w)[0] / n_t for k, w in (("event_align", 0), ("hmm_forward", 1), ("glue", 2))}
@@ -90,7 +90,7 @@ def main():
         res = b.eventalign_results()
         out["eventalign"] = dict(reads=b.n_reads, segments=int(sum(r["n_calls"] for r in res)), lattice_cells=int(cells), lattice_rows=int(erows),
                                  lattice_kmers=int(kmers), rows_out=int(sum(len(r["event_idx"]) for r in res)),
-                                 raw_samples=int(b.d_raw_off[-1].item()) if hasattr(b, "d_raw_off") else None,
+                                 raw_samples=int(b.hb["raw_off"][-1]) if "raw_off" in b.hb else None,
                                  unprofiled_chain_ms=round(ctx.kernel_time(6)[0] / n_t, 3),
                                  unprofiled_ms=dict(event_detect_family=round(ctx.kernel_time(4)[0] / n_t, 3), mom_fill=round(ctx.kernel_time(5)[0] / n_t, 3)))
     print(json.dumps(out), flush=True)
