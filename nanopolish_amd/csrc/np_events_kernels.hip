@@ -253,6 +253,55 @@ __global__ void __launch_bounds__(64) np_ed_serial_tstat_kernel(int n_reads, con
 //   CASE 1 (no maximum yet):  a deeper minimum, or a rise of more than peak_height that starts a peak;
 //   CASE 2 (in a peak):       a higher maximum; [short detector] masking of the long one once it is going to fire;
 //                             the fall that validates the peak; emission once the peak is window/2 samples behind.
+// ---- round 5: the t-statistic's last two operations, (float)(|dm| / sqrt(cvw)) in double, without the compiler's range scaling ----------
+// hipcc expands a double sqrt into the rsq + Goldschmidt sequence below WRAPPED in a scale-by-2^256 for arguments under 2^-767 and a
+// class test for 0 / inf, and a double division into div_scale x 2 + rcp + the same Newton steps + div_fmas + div_fixup: ~16 + ~12
+// instructions.  The arguments here are a float's worth of range -- cvw = a float >= FLT_MIN / 14 widened to double, dm a float -- so no
+// intermediate can leave the normal doubles and the wrappers have nothing to do; the core sequences are the ones whose last step is an
+// exact residual correction (correctly rounded: the same values the wrapped expansions produce; tests/test_gpu_events.py compares the
+// detected events of the fused walk with the reference's bit for bit, denormal-variance and near-zero-sample reads included).
+__device__ __forceinline__ double sqrt_f64_normal(double x)       // x > 0, normal, far from the range's ends
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+__device__ __forceinline__ double div_f64_normal(double a, double b)     // b > 0 normal; a >= 0 (0 allowed); the quotient a normal double or 0
+{
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    double q = a * y;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
+
+// tstat_from_sums for the fused walk: the same arithmetic with (1) the two wrappers above, (2) the plain division of a variance clamped to
+// FLT_MIN (a denormal quotient, outside what np_div_exact's correction steps cover) taken only when SOME lane of the wave has such a sample
+// -- a wave-uniform branch instead of an IEEE division expanded next to every exact one.
+__device__ __forceinline__ float tstat_from_sums_fast(double sum1, double sumsq1, double sum2d, double sumsq2d, int i, int n, int w, float w_lengthf,
+                                                      double wd, double rwd, float rwf)
+{
+    const float sum2 = (float)sum2d, sumsq2 = (float)sumsq2d;
+    const float mean1 = (float)div_exact_f64(sum1, wd, rwd);
+    const float mean2 = np_div_exact(sum2, w_lengthf, rwf);
+    float combined_var = (float)(div_exact_f64(sumsq1, wd, rwd) - (double)(mean1 * mean1) + (double)np_div_exact(sumsq2, w_lengthf, rwf) -
+                                 (double)(mean2 * mean2));
+    combined_var = fmaxf(combined_var, 1.17549435e-38f);                       // FLT_MIN
+    const float delta_mean = mean2 - mean1;
+    float cvw = np_div_exact(combined_var, w_lengthf, rwf);
+    if (__builtin_amdgcn_ballot_w64(combined_var < 1e-30f) != 0ull) cvw = combined_var < 1e-30f ? combined_var / w_lengthf : cvw;
+    const float t = (float)div_f64_normal(fabs((double)delta_mean), sqrt_f64_normal((double)cvw));
+    return (n < 2 * w || i < w || i > n - w) ? 0.0f : t;                        // quick return and fudged boundaries
+}
+
 struct detector { int masked_to, peak_pos; float peak_value; int valid_peak; };
 
 template <int K>
@@ -431,16 +480,22 @@ __device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int 
         dst[0] = lo.x; dst[1] = lo.y; dst[2] = lo.z; dst[3] = lo.w; dst[4] = hi.x; dst[5] = hi.y; dst[6] = hi.z; dst[7] = hi.w;
     };
     load_block(blk - 1, W); load_block(blk, W + 8); load_block(blk + 1, W + 16);
-    // window sums at the block's first sample i = 8 blk: left [i - w, i), right [i, i + w)
-    double s3l = 0, q3l = 0, s6l = 0, q6l = 0, s3r = 0, q3r = 0, s6r = 0, q6r = 0;
-#pragma unroll
-    for (int j = 1; j <= WB; ++j) {
-        const float a = W[8 - j], b = W[7 + j];
-        const double ad = (double)a, aq = (double)(a * a), bd = (double)b, bq = (double)(b * b);
-        s6l += ad; q6l += aq; s6r += bd; q6r += bq;
-        if (j <= WA) { s3l += ad; q3l += aq; s3r += bd; q3r += bq; }
-    }
+    // Window sums from THREE-SAMPLE sums (round 5).  S(j) = x[j] + x[j+1] + x[j+2] (and Q(j) of the fp32 squares): every one of the eight
+    // window sums of sample i is one of them or the sum of two --
+    //     left [i-3, i) = S(i-3)     left [i-6, i) = S(i-6) + S(i-3)     right [i, i+3) = S(i)     right [i, i+6) = S(i) + S(i+3)
+    // -- and every addition involved is exact (np_ed_check_kernel's bound covers any sum of the read's samples), so the values are the
+    // reference's prefix-sum differences whatever the order.  Per sample ONE new S and one new Q (S(j+1) = S(j) - x[j] + x[j+3]) and four
+    // additions, instead of eight window sums slid by two operations each.  S[k] / Q[k]: position 8 blk - 6 + k; ten entries are live.
     const int w1 = (int)p.window_length1, w2 = (int)p.window_length2;       // (3, 6) or (6, 3): which statistic feeds which detector
+    const double r3d = 1.0 / 3.0, r6d = 1.0 / 6.0;
+    const float r3f = (float)r3d, r6f = (float)r6d;                         // RN(1/w) in fp32: 1/w is not a rounding tie
+    double S[18], Q[18];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const float a = W[2 + k], b = W[3 + k], d = W[4 + k];
+        S[k] = (double)a + (double)b + (double)d;
+        Q[k] = (double)(a * a) + (double)(b * b) + (double)(d * d);
+    }
     float nxt[8];
     for (int t = 0; t < n_blk; ++t) {
         load_block(blk + 2, nxt);                             // one block ahead of the window
@@ -448,8 +503,8 @@ __device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int 
         for (int q = 0; q < 8; ++q) {
             const int i = blk * 8 + q;
             const bool in = lane_active && i >= begin && i < end;
-            const float ta = tstat_from_sums(s3l, q3l, s3r, q3r, i, n, WA);
-            const float tb = tstat_from_sums(s6l, q6l, s6r, q6r, i, n, WB);
+            const float ta = tstat_from_sums_fast(S[q + 3], Q[q + 3], S[q + 6], Q[q + 6], i, n, WA, 3.0f, 3.0, r3d, r3f);
+            const float tb = tstat_from_sums_fast(S[q] + S[q + 3], Q[q] + Q[q + 3], S[q + 6] + S[q + 9], Q[q + 6] + Q[q + 9], i, n, WB, 6.0f, 6.0, r6d, r6f);
             const float t1 = w1 < w2 ? ta : tb, t2 = w1 < w2 ? tb : ta;
             int pos;
             if (detector_step<0>(st.d0, st.d1, in ? i : -1, t1, p.peak_height, p.threshold1, w1, pos) && RECORD) {
@@ -460,15 +515,13 @@ __device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int 
                 if (cnt < tmp_cap) tmp[cnt] = (uint32_t)pos;
                 cnt++;
             }
-            // slide to i + 1: the sample at i moves from the right windows to the left ones
-            const int c = 8 + q;
-            const float x0 = W[c], l3 = W[c - WA], l6 = W[c - WB], r3 = W[c + WA], r6 = W[c + WB];
-            const double x0d = (double)x0, x0q = (double)(x0 * x0);
-            s3l += x0d - (double)l3; q3l += x0q - (double)(l3 * l3);
-            s6l += x0d - (double)l6; q6l += x0q - (double)(l6 * l6);
-            s3r += (double)r3 - x0d; q3r += (double)(r3 * r3) - x0q;
-            s6r += (double)r6 - x0d; q6r += (double)(r6 * r6) - x0q;
+            // S(i + 4) = S(i + 3) - x[i+3] + x[i+6]
+            const float xo = W[8 + q + 3], xi = W[8 + q + 6];
+            S[q + 10] = S[q + 9] - (double)xo + (double)xi;
+            Q[q + 10] = Q[q + 9] - (double)(xo * xo) + (double)(xi * xi);
         }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) { S[k] = S[k + 8]; Q[k] = Q[k + 8]; }
 #pragma unroll
         for (int j = 0; j < 16; ++j) W[j] = W[j + 8];
 #pragma unroll

@@ -104,4 +104,17 @@ tail -6 $O/pytest.log
 PASS_TIMEOUT=240 bash profiles/collect_r05_pmc.sh r05pmc 8192 2>&1 | tail -14
 }
 
+# detector arithmetic (three-sample sums, unwrapped sqrt / division): the suite, then the from-raw step's kernels
+call_k() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r05${TAG:-k}; mkdir -p $O
+( time timeout 1200 python -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+( timeout 600 python bench.py --from-raw 1 --pool 4000 --tile 25 --steps 4 --warmup 1 --legs 0 --streamed 0 --ragged 0 --cpu-sample 64 ) > $O/bench_raw.json 2> $O/bench_raw.err
+( timeout 600 python tests/gpu_soak.py ) > $O/soak.log 2>&1
+tail -5 $O/pytest.log; tail -4 $O/soak.log; python - <<EOF
+import json
+d=json.loads(open("$O/bench_raw.json").read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"], d["roofline"]["kernel_ms_per_step"], d["cpu_baseline"]["check"], d["cpu_baseline"].get("whole_function"))
+EOF
+}
+
 "call_$1"
