@@ -201,49 +201,87 @@ __global__ void __launch_bounds__(64) np_cm_groups_kernel(int n_reads, const cha
             deg_kpos[2 * r + 1] = cr.first_q < 0 ? -1 : (rc ? rl - cr.last_q - k : cr.last_q);
         }
     }
-    int ng = 0, first = -1, last = -1, cnt = 0;
+    // Round 5: the grouping itself runs on the lanes.  (Rounds 2-4 walked the matches one by one with wave-uniform state: ~45 scalar
+    // instructions per match, 16 000 per read, and a CU issues one scalar instruction per cycle for all its waves -- 2.8 ms per 100 000
+    // reads, bound by exactly that, profiles/r05_pmc.json.)  Per chunk of 64 positions: a match STARTS a group when the previous match
+    // (in the chunk, or the open group's last) is more than min_separation behind it; the matches before the chunk's first start extend
+    // the group left open by the previous chunks; every start but the last closes its group inside the chunk (its matches: up to the
+    // next start), the last one's stays open.  Each closed group is one lane's: it applies the window rules, and the slot index / k-mer
+    // offset of a kept group is the running count / sum plus a prefix over the kept groups before it (position order, as the reference
+    // emits them, basemods.cpp:306-336).
+    int ng = 0;
     int64_t w = 0;
     bool overflow = false;
-    auto close_group = [&]() {
-        if (cnt == 0) return;
+    int o_first = -1, o_last = -1, o_cnt = 0;                    // the open group (wave-uniform)
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // one closed group per lane: window rules, then slot and offset by prefix; `mine`: this lane holds a group; g0_lane: the lane that
+    // holds the group closed FIRST in position order although it is not the lowest lane (the carried group), or -1
+    auto emit = [&](bool mine, int first, int last, int cnt, int g0_lane) {
         const int sub_start = first - min_flank, sub_end = last + min_flank, span = last - first;
-        bool skip = sub_start <= min_separation || span > 200;                               // basemods.cpp:334
+        bool skip = !mine || sub_start <= min_separation || span > 200;                      // basemods.cpp:334
         int q1 = 0, q2 = 0;
         if (!skip) {
             if (by_cigar) skip = !cigar_find_bounds(cv, cr, sub_start, sub_end, q1, q2) || sub_end >= n;
             else skip = sub_start < k || sub_end + k >= n;                                   // alignment_db.cpp:65-71,697-708
         }
-        if (!skip) {
-            const int nk = sub_end - sub_start + 1 - k + 1;
-            if (ng >= cap || w + 2 * (int64_t)nk > rank_cap) { overflow = true; }
-            else {
-                if (writer) {
-                    first_site[g0 + ng] = first; last_site[g0 + ng] = last; n_motif[g0 + ng] = cnt;
-                    group_rank_off[g0 + ng] = rank_off_cap[r] + w;
-                    if (by_cigar) {
-                        group_kpos[2 * (g0 + ng)] = rc ? rl - q1 - k : q1;
-                        group_kpos[2 * (g0 + ng) + 1] = rc ? rl - q2 - k : q2;
-                    }
-                }
-                w += 2 * (int64_t)nk;
-                ng++;
+        const bool keep = !skip;
+        const int nk2 = keep ? 2 * (sub_end - sub_start + 1 - k + 1) : 0;
+        const unsigned long long km = __ballot(keep);
+        if (km == 0ull) return;
+        // order: the carried group first, then ascending lanes
+        const bool is_g0 = lane == g0_lane;
+        const bool g0_kept = g0_lane >= 0 && ((km >> g0_lane) & 1ull);
+        const int nk2_g0 = g0_lane >= 0 ? __shfl(nk2, g0_lane, 64) : 0;
+        const unsigned long long km_rest = g0_lane >= 0 ? km & ~(1ull << g0_lane) : km;
+        int scan = is_g0 ? 0 : nk2;                                                          // inclusive scan over the lanes (the carried group apart)
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(scan, o, 64); if (lane >= o) scan += t; }
+        const int total_rest = __shfl(scan, 63, 64);
+        const int idx = is_g0 ? ng : ng + (g0_kept ? 1 : 0) + __popcll(km_rest & below);
+        const int64_t off = is_g0 ? w : w + (g0_kept ? nk2_g0 : 0) + (scan - nk2);
+        const bool fits = idx < cap && off + nk2 <= rank_cap;
+        if (keep && fits) {
+            first_site[g0 + idx] = first; last_site[g0 + idx] = last; n_motif[g0 + idx] = cnt;
+            group_rank_off[g0 + idx] = rank_off_cap[r] + off;
+            if (by_cigar) {
+                group_kpos[2 * (g0 + idx)] = rc ? rl - q1 - k : q1;
+                group_kpos[2 * (g0 + idx) + 1] = rc ? rl - q2 - k : q2;
             }
         }
-        cnt = 0;
+        if (__ballot(keep && !fits) != 0ull) overflow = true;                               // the read comes back n_groups = -1: its slots are void
+        ng += __popcll(km);
+        w += (int64_t)total_rest + (g0_kept ? nk2_g0 : 0);
     };
     const sites_t S = sites_of(alphabet);
     for (int base = 0; base + 1 < n; base += 64) {
         const int pos = base + lane;
         const bool hit = pos + 1 < n &&
                          (S.len == 2 ? (ref[pos] == s.a && ref[pos + 1] == s.b) : site_at(ref, 0, n, pos, S) >= 0);   // is_motif_match, whole site
-        for (unsigned long long bits = __ballot(hit); bits; bits &= bits - 1) {
-            const int i = base + __builtin_ctzll(bits);
-            if (cnt > 0 && i - last > min_separation) close_group();
-            if (cnt == 0) first = i;
-            last = i; cnt++;
-        }
+        const unsigned long long bits = __ballot(hit);
+        if (bits == 0ull) continue;
+        const unsigned long long pb = bits & below;
+        const bool has_prev = pb != 0ull || o_cnt > 0;
+        const int prev = pb ? base + 63 - __clzll((long long)pb) : o_last;
+        const bool start = hit && (!has_prev || pos - prev > min_separation);
+        const unsigned long long sm = __ballot(start);
+        const int fs = sm ? __builtin_ctzll(sm) : 64;
+        const unsigned long long ext = fs == 64 ? bits : bits & ((1ull << fs) - 1ull);       // matches that still belong to the open group
+        if (ext) { o_last = base + 63 - __clzll((long long)ext); o_cnt += __popcll(ext); }
+        if (sm == 0ull) continue;
+        const int ls = 63 - __clzll((long long)sm);                                           // the last start: its group stays open
+        // this lane's closed group: a start other than the last -> its own segment; the last start's lane -> the group carried in (if any)
+        const unsigned long long later = sm & ~((below << 1) | 1ull);                        // starts above this lane
+        const int ns = later ? __builtin_ctzll(later) : 64;
+        const unsigned long long seg = ns == 64 ? bits & ~below : bits & ~below & ((1ull << ns) - 1ull);
+        const bool own = start && lane != ls;
+        const bool carried = lane == ls && o_cnt > 0;
+        const int g_first = own ? pos : o_first, g_last = own ? base + 63 - __clzll((long long)(seg | 1ull)) : o_last, g_cnt = own ? __popcll(seg) : o_cnt;
+        emit(own || carried, g_first, g_last, g_cnt, o_cnt > 0 ? ls : -1);
+        // the last start opens the new group
+        const unsigned long long tail = bits & ~((1ull << ls) - 1ull);
+        o_first = base + ls; o_last = base + 63 - __clzll((long long)tail); o_cnt = __popcll(tail);
     }
-    close_group();
+    emit(lane == 0 && o_cnt > 0, o_first, o_last, o_cnt, -1);
     if (writer) n_groups[r] = overflow ? -1 : ng;
 }
 
