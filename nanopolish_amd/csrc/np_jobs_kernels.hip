@@ -253,10 +253,19 @@ __global__ void __launch_bounds__(64) np_cm_groups_kernel(int n_reads, const cha
         w += (int64_t)total_rest + (g0_kept ? nk2_g0 : 0);
     };
     const sites_t S = sites_of(alphabet);
+    // (two-base motifs: the next chunk's bytes are requested before this chunk is grouped -- one wave per read, 85 chunks, and the
+    //  stores below keep the compiler from hoisting the loads itself)
+    char nb0 = 0, nb1 = 0;
+    if (S.len == 2) { nb0 = lane + 1 < n ? ref[lane] : 0; nb1 = lane + 1 < n ? ref[lane + 1] : 0; }
     for (int base = 0; base + 1 < n; base += 64) {
         const int pos = base + lane;
-        const bool hit = pos + 1 < n &&
-                         (S.len == 2 ? (ref[pos] == s.a && ref[pos + 1] == s.b) : site_at(ref, 0, n, pos, S) >= 0);   // is_motif_match, whole site
+        bool hit;
+        if (S.len == 2) {
+            const char b0 = nb0, b1 = nb1;
+            const int np_ = pos + 64;
+            nb0 = np_ + 1 < n ? ref[np_] : 0; nb1 = np_ + 1 < n ? ref[np_ + 1] : 0;
+            hit = pos + 1 < n && b0 == s.a && b1 == s.b;                                      // is_motif_match, whole site
+        } else hit = pos + 1 < n && site_at(ref, 0, n, pos, S) >= 0;
         const unsigned long long bits = __ballot(hit);
         if (bits == 0ull) continue;
         const unsigned long long pb = bits & below;
