@@ -81,13 +81,23 @@ __global__ void __launch_bounds__(256) np_ed_check_kernel(int n_reads, const flo
     const int64_t n = raw_off[r + 1] - raw_off[r];
     // bit patterns of non-negative floats order like the floats; inf/nan patterns (>= 0x7f800000) end up in the maximum
     uint32_t amax = 0u, amin = 0xffffffffu, qmax = 0u, qmin = 0xffffffffu;
-    for (int64_t i = threadIdx.x; i < n; i += 256) {
-        const float v = x[i];
+    auto take = [&](float v) {
         const float q = v * v;
         const uint32_t a = __builtin_bit_cast(uint32_t, v) & 0x7fffffffu, b = __builtin_bit_cast(uint32_t, q);
         amax = a > amax ? a : amax; qmax = b > qmax ? b : qmax;
         if (a != 0u) amin = a < amin ? a : amin;
         if (b != 0u) qmin = b < qmin ? b : qmin;
+    };
+    // 16-byte loads from the 16-byte boundary at or below the read's first sample (round 5: 4-byte loads ran at 3.5 TB/s); the up to
+    // three samples before the read and after it are skipped, not read
+    const int mis = (int)((((uintptr_t)x) & 15u) >> 2);
+    for (int64_t g = -(int64_t)mis + 4 * (int64_t)threadIdx.x; g < n; g += 1024) {
+        if (g >= 0 && g + 4 <= n) {
+            const float4 v = *reinterpret_cast<const float4*>(x + g);
+            take(v.x); take(v.y); take(v.z); take(v.w);
+        } else {
+            for (int t = 0; t < 4; ++t) if (g + t >= 0 && g + t < n) take(x[g + t]);
+        }
     }
     __shared__ uint32_t red[4][256];
     red[0][threadIdx.x] = amax; red[1][threadIdx.x] = amin; red[2][threadIdx.x] = qmax; red[3][threadIdx.x] = qmin;
@@ -598,6 +608,25 @@ __global__ void __launch_bounds__(64, 3) np_ed_peaks_par_kernel(int n_reads, con
 // ---------------------------------------------------------------------------------------------------------------
 // create_event (event_detection.c:223-241), one thread per event
 // ---------------------------------------------------------------------------------------------------------------
+// Round 5: the samples reach the events through LDS.  (One thread per event summing its ~5 samples straight from memory -- 4-byte loads, a
+// dependent double accumulation per load -- ran at 1.3 TB/s: 14.6 ms per 100 000 reads for 19 GB.)  The workgroup stages a window of
+// NP_EV_WIN samples with 16-byte loads, finds how many of the next events lie inside it (events come almost sorted: each thread probes its
+// own until one does not fit, the block's minimum is the bound), and every thread sums its events out of LDS; an event that fits no
+// window -- longer than the window, or one of the rare inverted pairs of peaks -- is summed from memory by one thread, as before.
+// Same additions (every one exact: np_ed_check_kernel), same roundings: event tables bit-identical (tests/test_gpu_events.py).
+#define NP_EV_WIN 6144
+__device__ __forceinline__ void ed_event_finish(double s, double q, int64_t start, int64_t end, float* __restrict__ event_length,
+                                                float* __restrict__ event_mean, float* __restrict__ event_stdv, int64_t slot)
+{
+    if (end < start) { s = -s; q = -q; }
+    const float length = (float)((uint64_t)end - (uint64_t)start);
+    const float mean = (float)s / length;
+    const float deltasqr = (float)q;
+    const float var = deltasqr / length - mean * mean;
+    event_length[slot] = length;
+    event_mean[slot] = mean;
+    event_stdv[slot] = sqrtf(fmaxf(var, 0.0f));
+}
 __global__ void __launch_bounds__(256) np_ed_events_kernel(int n_reads, const float* __restrict__ raw, const int64_t* __restrict__ raw_off,
                                                             const int64_t* __restrict__ event_off, const uint32_t* __restrict__ event_start,
                                                             const int32_t* __restrict__ n_events, const int32_t* __restrict__ status,
@@ -609,22 +638,64 @@ __global__ void __launch_bounds__(256) np_ed_events_kernel(int n_reads, const fl
     const float* x = raw + raw_off[r];
     const int64_t n = raw_off[r + 1] - raw_off[r];
     const int64_t eo = event_off[r];
-    for (int e = threadIdx.x; e < n_ev; e += 256) {
-    const int64_t start = event_start[eo + e];
-    const int64_t end = e + 1 < n_ev ? (int64_t)event_start[eo + e + 1] : n;
-    // (peaks come in the order the two detectors emit them; should a later one lie before an earlier one the reference's
-    //  unsigned arithmetic wraps -- sums[end] - sums[start] is then minus the sum in between)
-    double s = 0.0, q = 0.0;
-    const int64_t lo = start < end ? start : end, hi = start < end ? end : start;
-    for (int64_t i = lo; i < hi; ++i) { const float v = x[i]; s += (double)v; q += (double)(v * v); }
-    if (end < start) { s = -s; q = -q; }
-    const float length = (float)((uint64_t)end - (uint64_t)start);
-    const float mean = (float)s / length;
-    const float deltasqr = (float)q;
-    const float var = deltasqr / length - mean * mean;
-    event_length[eo + e] = length;
-    event_mean[eo + e] = mean;
-    event_stdv[eo + e] = sqrtf(fmaxf(var, 0.0f));
+    const uint32_t* es = event_start + eo;
+    __shared__ float win[NP_EV_WIN + 4];
+    __shared__ int s_bound;
+    // (peaks come in the order the two detectors emit them; should a later one lie before an earlier one the reference's unsigned
+    //  arithmetic wraps -- sums[end] - sums[start] is then minus the sum in between: lo / hi below, the sign in ed_event_finish)
+    auto bounds = [&](int e, int64_t& start, int64_t& end) {
+        start = es[e];
+        end = e + 1 < n_ev ? (int64_t)es[e + 1] : n;
+    };
+    int e0 = 0;
+    while (e0 < n_ev) {
+        int64_t st0, en0;
+        bounds(e0, st0, en0);
+        const int64_t w0 = st0 < en0 ? st0 : en0;                       // the window starts at the first unprocessed event ...
+        const int mis = (int)((((uintptr_t)(x + w0)) & 15u) >> 2);      // ... moved down to a 16-byte boundary of the batch's sample array
+        const int64_t wa = w0 - mis, wend = wa + NP_EV_WIN;             // window = samples [wa, wend) of the read (wa may be -1 .. -3 for its first event)
+        if (threadIdx.x == 0) s_bound = n_ev;
+        for (int i4 = threadIdx.x; i4 < NP_EV_WIN / 4; i4 += 256) {
+            const int64_t g = wa + 4 * (int64_t)i4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g >= 0 && g + 4 <= n) v = *reinterpret_cast<const float4*>(x + g);
+            else {
+                if (g >= 0 && g < n) v.x = x[g];
+                if (g + 1 >= 0 && g + 1 < n) v.y = x[g + 1];
+                if (g + 2 >= 0 && g + 2 < n) v.z = x[g + 2];
+                if (g + 3 >= 0 && g + 3 < n) v.w = x[g + 3];
+            }
+            *reinterpret_cast<float4*>(&win[4 * i4]) = v;
+        }
+        __syncthreads();
+        // how many events from e0 on lie inside the window: every thread probes its own events until one does not fit
+        for (int e = e0 + (int)threadIdx.x; e < n_ev; e += 256) {
+            int64_t st, en;
+            bounds(e, st, en);
+            const int64_t lo = st < en ? st : en, hi = st < en ? en : st;
+            if (lo < wa || hi > wend) { atomicMin(&s_bound, e); break; }
+        }
+        __syncthreads();
+        const int e1 = s_bound;
+        for (int e = e0 + (int)threadIdx.x; e < e1; e += 256) {
+            int64_t st, en;
+            bounds(e, st, en);
+            const int64_t lo = st < en ? st : en, hi = st < en ? en : st;
+            double s = 0.0, q = 0.0;
+            for (int i = (int)(lo - wa); i < (int)(hi - wa); ++i) { const float v = win[i]; s += (double)v; q += (double)(v * v); }
+            ed_event_finish(s, q, st, en, event_length, event_mean, event_stdv, eo + e);
+        }
+        if (e1 == e0) {
+            // the first event does not fit the window it opens: summed from memory
+            if (threadIdx.x == 0) {
+                const int64_t lo = st0 < en0 ? st0 : en0, hi = st0 < en0 ? en0 : st0;
+                double s = 0.0, q = 0.0;
+                for (int64_t i = lo; i < hi; ++i) { const float v = x[i]; s += (double)v; q += (double)(v * v); }
+                ed_event_finish(s, q, st0, en0, event_length, event_mean, event_stdv, eo + e0);
+            }
+            e0 += 1;
+        } else e0 = e1;
+        __syncthreads();                                               // (the window and the bound are rewritten by the next round)
     }
 }
 
