@@ -743,68 +743,106 @@ __global__ void __launch_bounds__(64) np_ed_serial_events_kernel(int n_reads, co
 // One wave per read; every sum is accumulated in the reference's order (terms staged 64 at a time in LDS, one lane
 // per sum adds its row front to back).
 // ---------------------------------------------------------------------------------------------------------------
+// Round 5: NP_MOM_R reads per wave.  The three ordered sums are serial chains of one double addition per term -- but a chain needs one
+// LANE, and with one read per wave (rounds 2-4) the 64-step serial phase of every chunk ran with one or two of 64 lanes busy and was 95 %
+// of the kernel's instructions (8.5 ms per 100 000 reads of the from-raw step).  Now the wave stages a 64-term chunk of EACH of its reads
+// (lanes = terms, one LDS tile per read and sum; row stride 65: the serial readers sit on distinct banks) and lane (r, c) adds the 64 terms
+// of sum c of read r: one serial phase per NP_MOM_R reads.  A read shorter than its group's longest contributes zero terms past its end (a
+// zero term leaves a non-negative-zero sum unchanged: every sum here starts at +0 and adds non-negative or finite terms).  Same terms, same
+// order: shift / scale bit-identical (tests/test_gpu_events.py::test_pass_from_raw_signal_matches_oracle).
+#define NP_MOM_R 16
 __global__ void __launch_bounds__(64) np_mom_fill_kernel(int n_reads, np_read_dev* __restrict__ reads, np_read_dev* __restrict__ reads_b,
                                                           const float* __restrict__ event_mean, const int32_t* __restrict__ n_events,
                                                           const uint16_t* __restrict__ ranks, const np_state_dev* __restrict__ model)
 {
-    const int r = blockIdx.x;
-    if (r >= n_reads) return;
+    constexpr int R = NP_MOM_R;
     const int lane = threadIdx.x;
-    np_read_dev* rd = reads + r;
-    const int ne = n_events[r] > 0 ? n_events[r] : 0;
-    const int K = (int)rd->n_kmers;
-    const float* ev = event_mean + rd->event_off;
-    const uint16_t* rk = ranks + rd->rank_off;
-    __shared__ double terms[2][66];
-    double acc = 0.0;                                   // lane 0 / lane 1 own the sums of the current pass
-
-    // pass 1: event_level_sum
-    for (int base = 0; base < ne; base += 64) {
-        const int i = base + lane;
-        __syncthreads();
-        terms[0][lane] = i < ne ? (double)ev[i] : 0.0;
-        __syncthreads();
-        if (lane == 0) { for (int q = 0; q < 64; ++q) acc += terms[0][q]; }
+    __shared__ double terms[R][2][65];
+    int ne[R], K[R];
+    const float* ev[R]; const uint16_t* rk[R];
+    int max_ne = 0, max_K = 0;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int r = blockIdx.x * R + q;
+        ne[q] = 0; K[q] = 0; ev[q] = event_mean; rk[q] = ranks;
+        if (r < n_reads) {
+            const int v = __builtin_amdgcn_readfirstlane(n_events[r]);
+            ne[q] = v > 0 ? v : 0;
+            K[q] = __builtin_amdgcn_readfirstlane((int)reads[r].n_kmers);
+            ev[q] = event_mean + reads[r].event_off; rk[q] = ranks + reads[r].rank_off;
+        }
+        max_ne = ne[q] > max_ne ? ne[q] : max_ne; max_K = K[q] > max_K ? K[q] : max_K;
     }
-    const double event_level_sum = dbl_readlane(acc, 0);
+    // serial-phase roles: one sum per read (passes 1 and 3): lane q < R owns read q; two sums per read (pass 2): lane 2 q + c
+    const int r1 = lane < R ? lane : 0, r2 = lane < 2 * R ? lane >> 1 : 0, c2 = lane & 1;
+    auto fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    double acc = 0.0;
+    // pass 1: event_level_sum
+    for (int base = 0; base < max_ne; base += 64) {
+        const int i = base + lane;
+#pragma unroll
+        for (int q = 0; q < R; ++q) terms[q][0][lane] = i < ne[q] ? (double)ev[q][i] : 0.0;
+        fence();
+        if (lane < R) { const double* row = terms[r1][0]; 
+#pragma unroll 16
+            for (int t = 0; t < 64; ++t) acc += row[t]; }
+        fence();
+    }
+    const double event_level_sum = acc;                 // lane q < R: read q's
     // pass 2: kmer_level_sum, kmer_level_sq_sum (pow(l, 2) == l * l)
     acc = 0.0;
-    for (int base = 0; base < K; base += 64) {
+    for (int base = 0; base < max_K; base += 64) {
         const int i = base + lane;
-        const double l = i < K ? model[rk[i]].level_mean : 0.0;
-        __syncthreads();
-        terms[0][lane] = l; terms[1][lane] = l * l;
-        __syncthreads();
-        if (lane < 2) { const double* row = terms[lane]; for (int q = 0; q < 64; ++q) acc += row[q]; }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const double l = i < K[q] ? model[rk[q][i]].level_mean : 0.0;
+            terms[q][0][lane] = l; terms[q][1][lane] = l * l;
+        }
+        fence();
+        if (lane < 2 * R) { const double* row = terms[r2][c2];
+#pragma unroll 16
+            for (int t = 0; t < 64; ++t) acc += row[t]; }
+        fence();
     }
-    const double kmer_level_sum = dbl_readlane(acc, 0), kmer_level_sq_sum = dbl_readlane(acc, 1);
-    const double shift = event_level_sum / (double)(uint32_t)ne - kmer_level_sum / (double)(uint32_t)K;
-    // pass 3: event_level_sq_sum
+    // read q's two sums sit in lanes 2 q and 2 q + 1: bring them to lane q
+    const double kmer_level_sum = __shfl(acc, 2 * r1, 64), kmer_level_sq_sum = __shfl(acc, 2 * r1 + 1, 64);
+    const int my = blockIdx.x * R + r1;
+    const int my_ne = lane < R && my < n_reads ? (n_events[my] > 0 ? n_events[my] : 0) : 0, my_K = lane < R && my < n_reads ? (int)reads[my].n_kmers : 1;
+    const double shift = event_level_sum / (double)(uint32_t)my_ne - kmer_level_sum / (double)(uint32_t)my_K;
+    // pass 3: event_level_sq_sum (every lane needs the shift of the read whose terms it forms)
+    double shift_q[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) shift_q[q] = dbl_readlane(shift, q);
     acc = 0.0;
-    for (int base = 0; base < ne; base += 64) {
+    for (int base = 0; base < max_ne; base += 64) {
         const int i = base + lane;
-        double t = 0.0;
-        if (i < ne) { const double dlt = (double)ev[i] - shift; t = dlt * dlt; }
-        __syncthreads();
-        terms[0][lane] = t;
-        __syncthreads();
-        if (lane == 0) { for (int q = 0; q < 64; ++q) acc += terms[0][q]; }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            double t = 0.0;
+            if (i < ne[q]) { const double dlt = (double)ev[q][i] - shift_q[q]; t = dlt * dlt; }
+            terms[q][0][lane] = t;
+        }
+        fence();
+        if (lane < R) { const double* row = terms[r1][0];
+#pragma unroll 16
+            for (int t = 0; t < 64; ++t) acc += row[t]; }
+        fence();
     }
-    const double event_level_sq_sum = dbl_readlane(acc, 0);
-    const double scale = (event_level_sq_sum / (double)(uint32_t)ne) / (kmer_level_sq_sum / (double)(uint32_t)K);
-
-    if (lane == 0) {
-        rd->n_events = (uint32_t)ne;
+    const double event_level_sq_sum = acc;
+    if (lane < R && my < n_reads) {
+        np_read_dev* rd = reads + my;
+        const double scale = (event_level_sq_sum / (double)(uint32_t)my_ne) / (kmer_level_sq_sum / (double)(uint32_t)my_K);
+        rd->n_events = (uint32_t)my_ne;
         rd->scale = scale; rd->shift = shift; rd->var = 1.0; rd->log_var = 0.0;      // set4(shift, scale, 0, 1): log(1) == 0
         // raw_loader.cpp:99-108, with glibc's log / exp restated (np_log.h)
-        const double events_per_kmer = (double)(uint32_t)ne / (double)(uint32_t)K;
+        const double events_per_kmer = (double)(uint32_t)my_ne / (double)(uint32_t)my_K;
         const double p_stay = 1 - (1 / (events_per_kmer + 1));
         const double epsilon = 1e-10;
         rd->lp_skip = np_log_glibc(epsilon);
         rd->lp_stay = np_log_glibc(p_stay);
         rd->lp_step = np_log_glibc(1.0 - np_exp_glibc(rd->lp_skip) - np_exp_glibc(rd->lp_stay));
         rd->lp_trim = np_log_glibc(0.01);
-        if (reads_b) reads_b[r].n_events = (uint32_t)ne;
+        if (reads_b) reads_b[my].n_events = (uint32_t)my_ne;
     }
 }
 
@@ -886,6 +924,6 @@ hipError_t np_launch_mom_fill(int n_reads, np_read_dev* reads, np_read_dev* read
                               const uint16_t* ranks, const np_state_dev* model, hipStream_t s)
 {
     if (n_reads <= 0) return hipSuccess;
-    hipLaunchKernelGGL(np_mom_fill_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, reads, reads_b, event_mean, n_events, ranks, model);
+    hipLaunchKernelGGL(np_mom_fill_kernel, dim3((n_reads + NP_MOM_R - 1) / NP_MOM_R), dim3(64), 0, s, n_reads, reads, reads_b, event_mean, n_events, ranks, model);
     return hipGetLastError();
 }
