@@ -1450,7 +1450,7 @@ int np_mom_fill_dev(np_ctx* c, void* stream, int n_reads, np_read_dev* reads, np
     NP_HIP(c, hipSetDevice(c->device));
     stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
     family_timer tm(c, 5, s);
-    NP_HIP(c, np_launch_mom_fill(n_reads, reads, reads_b, event_mean, n_events, kmer_rank, c->models[model].d_states, s));
+    NP_HIP(c, np_launch_mom_fill(n_reads, reads, reads_b, event_mean, n_events, kmer_rank, c->models[model].d_states, c->models[model].n_states, s));
     if (c->host_constants) return host_constants_fix(c, s, n_reads, reads, nullptr, 1);
     return NP_OK;
 }

@@ -750,20 +750,32 @@ __global__ void __launch_bounds__(64) np_ed_serial_events_kernel(int n_reads, co
 // of sum c of read r: one serial phase per NP_MOM_R reads.  A read shorter than its group's longest contributes zero terms past its end (a
 // zero term leaves a non-negative-zero sum unchanged: every sum here starts at +0 and adds non-negative or finite terms).  Same terms, same
 // order: shift / scale bit-identical (tests/test_gpu_events.py::test_pass_from_raw_signal_matches_oracle).
-#define NP_MOM_R 16
-__global__ void __launch_bounds__(64) np_mom_fill_kernel(int n_reads, np_read_dev* __restrict__ reads, np_read_dev* __restrict__ reads_b,
-                                                          const float* __restrict__ event_mean, const int32_t* __restrict__ n_events,
-                                                          const uint16_t* __restrict__ ranks, const np_state_dev* __restrict__ model)
+// (That alone made the kernel SLOWER, 8.5 -> 9.5 ms, as it had the recalibration: the second pass looks level_mean up per k-mer, 64 random
+//  128-byte lines per wave instruction out of a table that does not fit the L1.  So the workgroup -- NP_MOM_W waves -- keeps the base
+//  model's level_mean in LDS: 32 KB for the 4 096 states of a 6-mer model; a larger model is read from memory.)
+#define NP_MOM_R 4
+#define NP_MOM_W 4
+#define NP_MOM_STATES 4096
+__global__ void __launch_bounds__(64 * NP_MOM_W) np_mom_fill_kernel(int n_reads, np_read_dev* __restrict__ reads, np_read_dev* __restrict__ reads_b,
+                                                                    const float* __restrict__ event_mean, const int32_t* __restrict__ n_events,
+                                                                    const uint16_t* __restrict__ ranks, const np_state_dev* __restrict__ model, int n_states)
 {
     constexpr int R = NP_MOM_R;
-    const int lane = threadIdx.x;
-    __shared__ double terms[R][2][65];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    __shared__ double terms_all[NP_MOM_W][R][2][65];
+    __shared__ double level[NP_MOM_STATES];
+    const bool table = n_states <= NP_MOM_STATES;
+    if (table) {
+        for (int q = threadIdx.x; q < n_states; q += 64 * NP_MOM_W) level[q] = model[q].level_mean;
+        __syncthreads();
+    }
+    double (*terms)[2][65] = terms_all[wave];
     int ne[R], K[R];
     const float* ev[R]; const uint16_t* rk[R];
     int max_ne = 0, max_K = 0;
 #pragma unroll
     for (int q = 0; q < R; ++q) {
-        const int r = blockIdx.x * R + q;
+        const int r = (blockIdx.x * NP_MOM_W + wave) * R + q;
         ne[q] = 0; K[q] = 0; ev[q] = event_mean; rk[q] = ranks;
         if (r < n_reads) {
             const int v = __builtin_amdgcn_readfirstlane(n_events[r]);
@@ -795,7 +807,7 @@ __global__ void __launch_bounds__(64) np_mom_fill_kernel(int n_reads, np_read_de
         const int i = base + lane;
 #pragma unroll
         for (int q = 0; q < R; ++q) {
-            const double l = i < K[q] ? model[rk[q][i]].level_mean : 0.0;
+            const double l = i < K[q] ? (table ? level[rk[q][i]] : model[rk[q][i]].level_mean) : 0.0;
             terms[q][0][lane] = l; terms[q][1][lane] = l * l;
         }
         fence();
@@ -806,7 +818,7 @@ __global__ void __launch_bounds__(64) np_mom_fill_kernel(int n_reads, np_read_de
     }
     // read q's two sums sit in lanes 2 q and 2 q + 1: bring them to lane q
     const double kmer_level_sum = __shfl(acc, 2 * r1, 64), kmer_level_sq_sum = __shfl(acc, 2 * r1 + 1, 64);
-    const int my = blockIdx.x * R + r1;
+    const int my = (blockIdx.x * NP_MOM_W + wave) * R + r1;
     const int my_ne = lane < R && my < n_reads ? (n_events[my] > 0 ? n_events[my] : 0) : 0, my_K = lane < R && my < n_reads ? (int)reads[my].n_kmers : 1;
     const double shift = event_level_sum / (double)(uint32_t)my_ne - kmer_level_sum / (double)(uint32_t)my_K;
     // pass 3: event_level_sq_sum (every lane needs the shift of the read whose terms it forms)
@@ -921,9 +933,10 @@ hipError_t np_launch_reverse_events(int n_reads, const int64_t* event_off, const
 }
 
 hipError_t np_launch_mom_fill(int n_reads, np_read_dev* reads, np_read_dev* reads_b, const float* event_mean, const int32_t* n_events,
-                              const uint16_t* ranks, const np_state_dev* model, hipStream_t s)
+                              const uint16_t* ranks, const np_state_dev* model, int n_states, hipStream_t s)
 {
     if (n_reads <= 0) return hipSuccess;
-    hipLaunchKernelGGL(np_mom_fill_kernel, dim3((n_reads + NP_MOM_R - 1) / NP_MOM_R), dim3(64), 0, s, n_reads, reads, reads_b, event_mean, n_events, ranks, model);
+    hipLaunchKernelGGL(np_mom_fill_kernel, dim3((n_reads + NP_MOM_R * NP_MOM_W - 1) / (NP_MOM_R * NP_MOM_W)), dim3(64 * NP_MOM_W), 0, s, n_reads, reads, reads_b, event_mean, n_events, ranks,
+                       model, n_states);
     return hipGetLastError();
 }

@@ -179,7 +179,7 @@ hipError_t np_launch_adc_to_pa(int n_reads, const int16_t* adc, const int64_t* r
 hipError_t np_launch_reverse_events(int n_reads, const int64_t* event_off, const int32_t* n_events, uint32_t* start, float* length, float* mean,
                                     float* stdv, hipStream_t s);
 hipError_t np_launch_mom_fill(int n_reads, np_read_dev* reads, np_read_dev* reads_b, const float* event_mean, const int32_t* n_events,
-                              const uint16_t* ranks, const np_state_dev* model, hipStream_t s);
+                              const uint16_t* ranks, const np_state_dev* model, int n_states, hipStream_t s);
 
 // ---- f3: call-methylation work items of identity-aligned reads (np_jobs_kernels.hip) -----------------------------------
 hipError_t np_launch_cm_build_jobs(int n_reads, const char* seq, const int64_t* seq_off, const uint8_t* read_rc, int alphabet, int k,
