@@ -117,4 +117,18 @@ d=json.loads(open("$O/bench_raw.json").read().strip().splitlines()[-1]); print(d
 EOF
 }
 
+# the round's counter passes on the final code: all families at 8 192 reads per launch; kernels A / B / glue at the benched 100 000
+call_p() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+PASS_TIMEOUT=240 bash profiles/collect_r05_pmc.sh r05pmc 8192 2>&1 | tail -12
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05pmc100k; mkdir -p $O
+W="python $R/tools/pmc_workload.py --reads 100000 --ea-reads 0 --distinct 2000 --reps 1"
+( cd /tmp && timeout 300 $W --timing-reps 3 > $O/units.json 2> $O/units.err ); echo "units rc=$?"
+for p in "sq1:SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
+  n=${p%%:*}; c=${p#*:}
+  ( cd /tmp && timeout 420 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/$n -o $n -- $W > $O/$n.log 2>&1 ); echo "$n rc=$?" | tee -a $O/passes.log
+done
+tail -1 $O/units.json | cut -c1-400
+}
+
 "call_$1"
