@@ -46,7 +46,7 @@ _cal = {c["name"]: c["cycles_per_inst_simd"] for c in json.load(open(os.path.joi
 FAST_CYCLES = round(sum(_cal[k] for k in ("v_add_f32", "v_sub_f32", "v_mul_f32", "v_and_b32", "v_or_b32", "v_mov_b32", "v_add_u32", "v_sub_u32")) / 8, 2)
 FAM = (("event_align", "np_event_align_kernel"), ("hmm_forward", "np_hmm_forward_kernel"), ("chain", "np_eventalign_chain"),
        ("recalibrate", "np_recalibrate_kernel"), ("build_map", "np_build_map_kernel"), ("cm_items", "np_cm_items_kernel"),
-       ("cm_groups", "np_cm_groups_kernel"), ("resolve", "np_resolve_kernel"), ("ed_peaks", "np_ed_peaks_par_kernel"), ("ed_check", "np_ed_check_kernel"),
+       ("cm_groups", "np_cm_groups_kernel"), ("resolve", "np_resolve_"), ("ed_peaks", "np_ed_peaks_par_kernel"), ("ed_check", "np_ed_check_kernel"),
        ("ed_events", "np_ed_events_kernel"), ("mom_fill", "np_mom_fill_kernel"))
 
 
