@@ -309,7 +309,7 @@ def from_raw_leg(ctx, torch, models, hb_raw, tile, steps, warmup, calibrate, cpu
     return out
 
 
-def binding_legs(models, sizes=(512, 8192), distinct=512, read_len=5450, target_reads=65536, cpu_check=True):
+def binding_legs(models, sizes=(512, 8192), distinct=512, read_len=5450, target_reads=262144, cpu_check=True):
     """Reads/s THROUGH the reference-side batched binding (nanopolish_amd/csrc/np_batch_dropin.cpp: NpBatchPipeline linked into the
     reference's read-level build in place of call-methylation's per-record loop, src/common/nanopolish_bam_processor.cpp:90-119,
     INTEGRATION.md section 2): BAM records + int16 raw signal in HOST memory in, the reference's ScoredSite maps out, host wall clock

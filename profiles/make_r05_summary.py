@@ -69,6 +69,18 @@ if d:
         o.append("| variants leg | %.0f calls/s, %.1f ms per step, roofline frac %.4f (traffic %.1f GB), issue %s / %s, cpu %s |" % (
             va["value"], va["ms_per_step"], vr["frac"], (vr.get("traffic") or 0) / 1e9, (vr.get("issue") or {}).get("valu_issue_floor"),
             (vr.get("issue") or {}).get("valu_issue_priced"), json.dumps(va.get("cpu_baseline"))))
+    fr, bl_ = d.get("from_raw") or {}, d.get("binding") or {}
+    if "value" in fr:
+        o.append("| from-raw leg | %.0f reads/s, %.1f ms per 100 000 reads (%s), check %s |" % (fr["value"], fr["ms_per_step"], json.dumps(fr["kernel_ms_per_step"]), json.dumps(fr.get("check"))))
+    for k in ("records_512", "records_8192"):
+        if k in bl_:
+            b = bl_[k]
+            o.append("| binding leg, %d records per batch | %.0f reads/s over %d batches (%.2f ms per batch), records not ok %d, sites match the reference: %s |" % (
+                b["records_per_batch"], b["value"], b["batches"], b["ms_per_batch"], b["records_not_ok"], b.get("sites_match_reference")))
+    rb = d.get("roofline_hmm_forward") or {}
+    if rb:
+        o.append("| kernel B in the same step | HBM frac %s (traffic %.1f GB), roofline_issue frac %s |" % ((rb.get("hbm") or {}).get("frac"), ((rb.get("hbm") or {}).get("traffic") or 0) / 1e9, (rb.get("roofline_issue") or {}).get("frac")))
+    o.append("| roofline_issue (kernel A) | %s |" % json.dumps({k: v for k, v in (r.get("roofline_issue") or {}).items() if k != "source"}))
     o.append("| cpu_baseline | %s |" % json.dumps({k: d["cpu_baseline"][k] for k in ("value", "cores", "kind", "t1_value") if k in d["cpu_baseline"]}))
     o.append("")
 o.append("configs[4]'s per-rank shape on the one GPU (`--gpus 1 --pool 50000 --tile 5 --steps 5 --warmup 2 --legs 0 --streamed 0`: 250 000 reads per step, what every "
