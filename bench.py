@@ -18,6 +18,10 @@ prints:
 Reads shard across ranks with no data-path collective (weak scaling); the only exchange is one all-reduce of the per-site
 table at the end of the timed region (N > 1).
 
+One GPU: the line also carries value_from_raw (the step from int16 raw signal), value_eventalign / value_variants (BASELINE.json configs[2] /
+configs[3]) and value_binding_512 / value_binding_8192 (reads/s through the reference-side batched binding, host memory to ScoredSite maps), each
+with its parity field.  N > 1 GPUs: BASELINE.json configs[4] -- 250 000 reads per rank and step by default (2 M over 8 GPUs).
+
 `--gpus N` without a torch.distributed launcher (no WORLD_SIZE in the environment) starts the N ranks itself.
 `--workload eventalign|variants` runs BASELINE.json configs[2] / configs[3] (tests/bench_eventalign.py, tests/bench_variants.py);
 `--workload cpu-t1` is configs[0]'s plumbing line: the reference's own code on ONE host thread, no GPU.
