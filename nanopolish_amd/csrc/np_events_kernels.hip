@@ -66,7 +66,23 @@ __global__ void __launch_bounds__(256) np_adc_to_pa_kernel(int n_reads, const in
     const float off = offset[r], unit = raw_unit[r];
     const int16_t* in = adc + raw_off[r];
     float* out = raw_pa + raw_off[r];
-    for (int64_t i = base + threadIdx.x; i < n && i < base + 1024; i += 256) out[i] = ((float)in[i] + off) * unit;
+    // (round 5: four samples per thread -- one 8-byte load, one 16-byte store -- from the first sample of the read whose position in the batch
+    //  arrays is a multiple of four: both accesses are then aligned; 2-byte loads and 4-byte stores ran at 3.3 TB/s)
+    const int head = (int)((4 - (raw_off[r] & 3)) & 3);                      // samples before that position
+    const int64_t tile_lo = base, tile_hi = base + 1024 < n ? base + 1024 : n;
+    // the tile [tile_lo, tile_hi) of the read, cut at the aligned positions head + 4 j
+    const int64_t j_lo = tile_lo <= head ? 0 : (tile_lo - head + 3) / 4, j_hi = tile_hi <= head ? 0 : (tile_hi - head) / 4;     // whole groups inside the tile
+    for (int64_t j = j_lo + threadIdx.x; j < j_hi; j += 256) {
+        const int64_t i = head + 4 * j;
+        const short4 v = *reinterpret_cast<const short4*>(in + i);
+        float4 o;
+        o.x = ((float)v.x + off) * unit; o.y = ((float)v.y + off) * unit; o.z = ((float)v.z + off) * unit; o.w = ((float)v.w + off) * unit;
+        *reinterpret_cast<float4*>(out + i) = o;
+    }
+    // what the groups do not cover: before the first group of the tile and after its last
+    const int64_t g_begin = j_lo < j_hi ? head + 4 * j_lo : tile_hi, g_end = j_lo < j_hi ? head + 4 * j_hi : tile_hi;
+    for (int64_t i = tile_lo + threadIdx.x; i < g_begin; i += 256) out[i] = ((float)in[i] + off) * unit;
+    for (int64_t i = g_end + threadIdx.x; i < tile_hi; i += 256) out[i] = ((float)in[i] + off) * unit;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -312,6 +328,11 @@ __device__ __forceinline__ float tstat_from_sums_fast(double sum1, double sumsq1
     return (n < 2 * w || i < w || i > n - w) ? 0.0f : t;                        // quick return and fudged boundaries
 }
 
+#if defined(NP_ED_ABL) && (NP_ED_ABL & 4)
+#define NP_ED_ABL_NOSTORE && false      /* timing ablation: the per-lane event list is not written */
+#else
+#define NP_ED_ABL_NOSTORE
+#endif
 struct detector { int masked_to, peak_pos; float peak_value; int valid_peak; };
 
 template <int K>
@@ -484,7 +505,12 @@ __device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int 
     const int n_blk = (trip + 7) / 8 + 1;                     // a misaligned range of `trip` samples touches at most this many
     float W[24];                                              // blocks blk-1, blk, blk+1
     auto load_block = [&](int b, float* dst) {
+#ifdef NP_ED_ABL      // timing ablation (results wrong): bit 1 = no sample loads at all, bit 2 = every lane reads the SAME segment (coalesced, cached)
+        const bool need = !(NP_ED_ABL & 1) && lane_active && b >= 0 && b * 8 < n;
+        if (NP_ED_ABL & 2) b = b % 96;
+#else
         const bool need = lane_active && b >= 0 && b * 8 < n;
+#endif
         const float4 lo = need ? buf_f32x4(xr, 32 * b) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 hi = need ? buf_f32x4(xr, 32 * b + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
         dst[0] = lo.x; dst[1] = lo.y; dst[2] = lo.z; dst[3] = lo.w; dst[4] = hi.x; dst[5] = hi.y; dst[6] = hi.z; dst[7] = hi.w;
@@ -518,11 +544,11 @@ __device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int 
             const float t1 = w1 < w2 ? ta : tb, t2 = w1 < w2 ? tb : ta;
             int pos;
             if (detector_step<0>(st.d0, st.d1, in ? i : -1, t1, p.peak_height, p.threshold1, w1, pos) && RECORD) {
-                if (cnt < tmp_cap) tmp[cnt] = (uint32_t)pos;
+                if (cnt < tmp_cap NP_ED_ABL_NOSTORE) tmp[cnt] = (uint32_t)pos;
                 cnt++;
             }
             if (detector_step<1>(st.d1, st.d0, in ? i : -1, t2, p.peak_height, p.threshold2, w2, pos) && RECORD) {
-                if (cnt < tmp_cap) tmp[cnt] = (uint32_t)pos;
+                if (cnt < tmp_cap NP_ED_ABL_NOSTORE) tmp[cnt] = (uint32_t)pos;
                 cnt++;
             }
             // S(i + 4) = S(i + 3) - x[i+3] + x[i+6]

@@ -386,25 +386,39 @@ __global__ void __launch_bounds__(256) np_cm_items_kernel(int n_reads, const cha
             }
         } else {
             // the k-mer's digits and its methylated twin's: a base is replaced when it is the first base of a whole site (next base
-            // is the site's second) or the second base of one (previous base is its first), inside the window
-            bool pa = prev == s.a, ca_ = cur == s.a, cb_ = cur == s.b;
-            uint32_t pw = 1;                                           // reverse strand: window position q contributes digit * 5^(q - i)
-            for (int q = i; q < i + k; ++q) {
-                const char nxt = q + 1 < len ? ref[sub_start + q + 1] : 0;
-                const bool na = nxt == s.a, nb = nxt == s.b;
-                const bool site1 = ca_ && nb, site2 = cb_ && pa;
-                if (!rc) {
-                    const uint32_t d = t_dig[(uint8_t)cur];
-                    ru = ru * 5u + d;
-                    rm = rm * 5u + (site1 ? dma : (site2 ? dmb : d));
-                } else {
-                    const uint32_t d = t_dcomp[(uint8_t)cur];
-                    ru += pw * d;
-                    rm += pw * (site1 ? dca : (site2 ? dcb : d));
-                    pw *= 5u;
+            // is the site's second) or the second base of one (previous base is its first), inside the window.
+            // (round 5: the k = 6 case is unrolled at compile time -- the window's eight bytes are then requested together instead of one
+            //  dependent byte load per base: the kernel spent 67 % of its wave-cycles waiting, profiles/r05_pmc.json)
+            auto kmer = [&](auto KC) {
+                constexpr int KK = decltype(KC)::value;                // 0: k at run time
+                const int kk = KK ? KK : k;
+                char w_[KK ? KK + 1 : 1];
+                if (KK) {
+#pragma unroll
+                    for (int q = 0; q < KK; ++q) w_[q + 1] = i + q + 1 < len ? ref[sub_start + i + q + 1] : 0;
                 }
-                pa = ca_; ca_ = na; cb_ = nb; cur = nxt;
-            }
+                bool pa = prev == s.a, ca_ = cur == s.a, cb_ = cur == s.b;
+                char c0 = cur;
+                uint32_t pw = 1;                                       // reverse strand: window position q contributes digit * 5^(q - i)
+#pragma unroll
+                for (int q = 0; q < kk; ++q) {
+                    const char nxt = KK ? w_[q + 1] : (i + q + 1 < len ? ref[sub_start + i + q + 1] : 0);
+                    const bool na = nxt == s.a, nb = nxt == s.b;
+                    const bool site1 = ca_ && nb, site2 = cb_ && pa;
+                    if (!rc) {
+                        const uint32_t d = t_dig[(uint8_t)c0];
+                        ru = ru * 5u + d;
+                        rm = rm * 5u + (site1 ? dma : (site2 ? dmb : d));
+                    } else {
+                        const uint32_t d = t_dcomp[(uint8_t)c0];
+                        ru += pw * d;
+                        rm += pw * (site1 ? dca : (site2 ? dcb : d));
+                        pw *= 5u;
+                    }
+                    pa = ca_; ca_ = na; cb_ = nb; c0 = nxt;
+                }
+            };
+            if (k == 6) kmer(std::integral_constant<int, 6>{}); else kmer(std::integral_constant<int, 0>{});
         }
         job_ranks[ro + i] = (uint16_t)ru;
         job_ranks[ro + nk + i] = (uint16_t)rm;

@@ -131,4 +131,35 @@ done
 tail -1 $O/units.json | cut -c1-400
 }
 
+# detector ablations (results wrong by construction): no sample loads / every lane the same cached segment / no event-list stores
+call_q() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r05${TAG:-q}; mkdir -p $O
+for v in default edabl1 edabl2 edabl4 edabl7; do
+  L=""; [ $v != default ] && L=$PWD/nanopolish_amd/variants/libnp_hip_$v.so
+  ( NP_HIP_LIB=$L timeout 300 python bench.py --from-raw 1 --pool 2000 --tile 50 --steps 3 --warmup 1 --legs 0 --streamed 0 --ragged 0 --cpu-sample 0 ) > $O/$v.json 2> $O/$v.err
+  python - <<EOF
+import json
+try:
+    d=json.loads([l for l in open("$O/$v.json") if l.startswith("{")][-1]); print("$v", d["roofline"]["kernel_ms_per_step"])
+except Exception as e: print("$v", "failed", e)
+EOF
+done
+}
+
+# lean check: the suite, the default step's kernels by name, the from-raw step's families
+call_r() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r05${TAG:-r}; mkdir -p $O
+( time timeout 1200 python -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o p -- python $R/bench.py --steps 3 --warmup 1 --legs 0 --streamed 0 --ragged 0 --cpu-sample 0 > $R/$O/bench.json 2> $R/$O/bench.err )
+python profiles/summarize_rocpd.py $(find $O/prof -name "*_results.db" | head -1) > $O/kernels.txt 2>&1
+( timeout 400 python bench.py --from-raw 1 --pool 2000 --tile 50 --steps 3 --warmup 1 --legs 0 --streamed 0 --ragged 0 --cpu-sample 0 ) > $O/bench_raw.json 2> $O/bench_raw.err
+tail -4 $O/pytest.log; grep -v "at::native\|rocclr\|probe\|np_align_\|hmm_forward\|np_event_align" $O/kernels.txt | head -12 | cut -c1-160; python - <<EOF
+import json
+d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"], d["roofline"]["kernel_ms_per_step"])
+d=json.loads(open("$O/bench_raw.json").read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"], d["roofline"]["kernel_ms_per_step"])
+EOF
+}
+
 "call_$1"
