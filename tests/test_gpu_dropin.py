@@ -150,3 +150,39 @@ def test_concurrent_callers_are_combined_and_score_the_same(dropin, orc, models)
         assert one[j] == orc.hmm_score(mc, S, rd["events"], ranks, J["e_start"][j], J["e_stop"][j], J["stride"][j], J["epb"][0], 1.0, 3)
     dropin.L.np_dropin_error_count.restype = C.c_long
     assert dropin.L.np_dropin_error_count() == 0
+
+
+_ERR_SCRIPT = r'''
+import os, sys
+sys.path.insert(0, os.environ["NP_REPO"]); sys.path.insert(0, os.path.join(os.environ["NP_REPO"], "tests"))
+import numpy as np
+import torch  # noqa: F401
+from oracle import RefOracle, load_models
+from cases import synth_read
+d = RefOracle(os.environ["NP_REF_DROPIN_LIB"])
+rd = synth_read(5, load_models()["nucleotide"], L=1600)
+ok = d.hmm_score("nucleotide", rd["seq"][:40], None, rd["events"], 10, 70, 1, 0, rd["shift"], rd["scale"], rd["var"], 1.5, 1.0, 0)
+print("OK %r" % (ok,), flush=True)
+# 1 200 bases = 1 195 k-mers: more than NP_MAX_KMERS, the library refuses the work item (NP_ERR_UNSUPPORTED)
+bad = d.hmm_score("nucleotide", rd["seq"][:1200], None, rd["events"], 10, 1700, 1, 0, rd["shift"], rd["scale"], rd["var"], 1.5, 1.0, 0)
+print("BAD %r" % (bad,), flush=True)
+'''
+
+
+def test_a_failed_device_call_cannot_end_in_exit_status_0(tmp_path):
+    """ADVICE r4 (medium): the reference's callers link UNCHANGED, so none of them reads np_dropin_error_count().  A work item the library
+    refuses (here: more k-mers than NP_MAX_KMERS) must therefore end the process with a non-zero status -- at once by default (the
+    reference's own convention for unrecoverable conditions, raw_loader.cpp:124-131), or, for a caller adapted to check the count
+    (NP_DROPIN_ERRORS_IN_BAND=1), as -inf in band AND a non-zero status when the process exits."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "err.py"
+    script.write_text(_ERR_SCRIPT)
+    env = dict(os.environ, NP_REPO=root, NP_REF_DROPIN_LIB=DROPIN)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert "OK " in r.stdout and "BAD" not in r.stdout, r.stdout + r.stderr          # the process ended inside the failing call
+    assert r.returncode != 0 and "nanopolish_amd:" in r.stderr and "failed" in r.stderr
+    r = subprocess.run([sys.executable, str(script)], env=dict(env, NP_DROPIN_ERRORS_IN_BAND="1"), capture_output=True, text=True, timeout=600)
+    assert "OK " in r.stdout and "BAD -inf" in r.stdout, r.stdout + r.stderr         # the in-band "no result" ...
+    assert r.returncode != 0 and "device call(s) failed" in r.stderr                  # ... and still no exit status 0
