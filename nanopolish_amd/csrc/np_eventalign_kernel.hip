@@ -363,6 +363,18 @@ struct ea_lds {
 };
 struct ea_walk_result { int cnt0, cnt1, spilled0, spilled1; };
 
+// the lane (of its half) that owns k-mer k = k / BPL, as full-rate instructions (a 32-bit multiply-high is quarter rate); 5 bits, as the
+// shifts that use it take
+template <int BPL> __device__ __forceinline__ uint32_t ea_owner(const uint32_t k)
+{
+    if constexpr (BPL == 3) {                             // exact for k < 512 (k < 96 here)
+        uint32_t p;
+        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(p) : "v"(k), "v"(171u));     // (the compiler takes v_mul_lo_u32 for k * 171 whatever it is told about k)
+        return __builtin_amdgcn_ubfe(p, 9, 5);
+    }
+    else { static_assert((BPL & (BPL - 1)) == 0, "k-mers per lane"); return (k / BPL) & 31u; }
+}
+
 template <int BPL>
 __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const float sv0_, const float sv1_, const uint8_t* __restrict__ bp_,
                                                              uint32_t* __restrict__ path0_, uint32_t* __restrict__ path1_, const int lane)
@@ -378,7 +390,7 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
     const int sl = lane & 31;
     // per-lane state, uniform within a half
     const int e = hi_half ? H1.e : H0.e, n = hi_half ? H1.n : H0.n;
-    int row = e, k3 = n > 0 ? (n - 1) / BPL : 0, kr = n > 0 ? (n - 1) % BPL : 0, ps = 2, cnt = 0, spilled = 0;      // k3: the lane (of the half) that owns the k-mer, kr: its block
+    int row = e, k = n - 1, ps = 2, cnt = 0, spilled = 0;              // k: the k-mer; lane k / BPL (of the half) owns it, as its block k % BPL
     int lo = 0x7fffffff;                                  // no window yet
     // assert(get(vm, row, col) != -INFINITY): no path, nothing to emit
     bool alive = (hi_half ? (H1.ri >= 0 && sv1 != NP_NEG_INF) : (H0.ri >= 0 && sv0 != NP_NEG_INF)) && e > 0 && n > 0;
@@ -389,13 +401,14 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
     lds_u32* dump = (lds_u32*)&L->dump[lane];
     while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
         // ---- per half, by scalar control: refill the window of a walk that is outside it; spill a full list ----
-        const bool need = alive && row + k3 < lo, full = alive && cnt - spilled >= NP_EA_PCAP;
+        const int line0 = (int)((uint32_t)row + (uint32_t)k / BPL);
+        const bool need = alive && line0 < lo, full = alive && cnt - spilled >= NP_EA_PCAP;
         const uint64_t need_m = __builtin_amdgcn_ballot_w64(need), full_m = __builtin_amdgcn_ballot_w64(full);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if ((need_m >> (32 * h)) & 1ull) {
-                const int hi = __builtin_amdgcn_readlane(row + k3, 32 * h);
+                const int hi = __builtin_amdgcn_readlane(line0, 32 * h);
                 const int nlo = hi - (NP_EA_WIN - 1) > 1 ? hi - (NP_EA_WIN - 1) : 1;
                 // dword h of every plane of every line of the window: stage[h][line * PLANES + plane].  PER_LINE 16-byte requests per line
                 // (two planes each), all of a refill in flight at once (three rounds of 64 lanes cover 16 lines), at agent scope: they
@@ -427,35 +440,41 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
-        // ---- steps, while no live walk is outside its window or out of list space ----
-        for (;;) {
-            const int line = row + k3;
-            const bool in = alive && line >= lo && cnt - spilled < NP_EA_PCAP;
-            if (__builtin_amdgcn_ballot_w64(alive && !in) != 0ull || __builtin_amdgcn_ballot_w64(in) == 0ull) break;
-            // the visited state goes to the half's list (lane 0 of the half writes it, the others write their dump slots)
-            const uint32_t entry = (uint32_t)row | ((uint32_t)(BPL * k3 + kr) << 16) | ((uint32_t)ps << 24);
-            lds_u32* wp = (in && sl == 0) ? pb + (cnt - spilled) : dump;
+        // ---- a burst of steps: as many as no live walk can leave its window or fill its list in.  A step lowers row + k / BPL by at
+        //      most 2, so the count is known before the first one and the steps themselves carry no window test, no ballot and no
+        //      branch (round 5: the per-step test and the selects that froze a waiting walk were a third of the chain's instructions)
+        const int room = (int)(((uint32_t)line0 - (uint32_t)lo) >> 1) + 1, space = NP_EA_PCAP - (cnt - spilled);      // (unsigned: a finished walk's numbers are anything)
+        const int mine = alive ? (room < space ? room : space) : 0x7fffffff;
+        const int b0 = __builtin_amdgcn_readlane(mine, 0), b1 = __builtin_amdgcn_readlane(mine, 32);
+        const int burst = b0 < b1 ? b0 : b1;
+        // planes of cell (row, k): stage[(row + k / BPL - lo) * PLANES + (k % BPL) * 6 ...] = stage[6 * (row * BPL + k - lo * BPL) ...]: an
+        // offset that falls by 6 BPL with the row and by 6 with the k-mer.  (A finished walk's offset is anything: the min keeps its
+        // reads inside the window.)
+        uint32_t off = ((uint32_t)row * BPL + (uint32_t)k - (uint32_t)lo * BPL) * 6u;
+        for (int s = 0; s < burst; ++s) {
+            // the visited state goes to the half's list (lane 0 of the half writes it, the others -- and a finished walk -- write their dump slots)
+            const uint32_t entry = (uint32_t)row | ((uint32_t)k << 16) | ((uint32_t)ps << 24);
+            lds_u32* wp = (alive && sl == 0) ? pb + (cnt - spilled) : dump;
             *wp = entry;
             // the move out of this cell
             // every lane reads the six planes of the cell's block itself (the address does not depend on the state walked in) and takes
-            // the bit of the lane that owns the k-mer out of each; the three states' codes are cheap, the state picks one
-            const lds_u32* pw = st + (in ? (line - lo) * PLANES + kr * 6 : 0);
-            const uint32_t x0 = (pw[0] >> k3) & 1u, x1 = (pw[1] >> k3) & 1u, x2 = (pw[2] >> k3) & 1u, x3 = (pw[3] >> k3) & 1u, x4 = (pw[4] >> k3) & 1u,
-                           x5 = (pw[5] >> k3) & 1u;
-            const uint32_t cM = x0 | (x1 << 1) | (x2 << 2), cB = 2u - x3, cK = 6u - x5 - 2u * x4;
-            // (masks, not selects: the two halves walk different states, and a select lets the compiler sink the loads into divergent
-            //  branches -- each half then waits for its own LDS round trip)
-            const uint32_t m2 = 0u - (uint32_t)(ps == 2), m1 = 0u - (uint32_t)(ps == 1);
-            const uint32_t c = (cM & m2) | (cB & m1) | (cK & ~(m2 | m1));
-            const bool stop = c == 7u;                                  // HMT_FROM_SOFT
-            const bool stepped = in && !stop;
-            const int nrow = row - (ps != 0 ? 1 : 0);                   // K states are silent (r9.cpp:176-178)
-            const int dk = (int)(c >> 2);
-            const int t = kr - dk;
-            const int nkr = t < 0 ? BPL - 1 : t, nk3 = t < 0 ? k3 - 1 : k3;
-            cnt += in ? 1 : 0;
-            row = stepped ? nrow : row; k3 = stepped ? nk3 : k3; kr = stepped ? nkr : kr; ps = stepped ? (int)(c & 3u) : ps;
-            alive = alive && !(in && stop) && row > 0 && k3 >= 0;
+            // the bit of the lane that owns the k-mer out of each.  The three states' codes, M: x0 | x1 << 1 | x2 << 2, B: 2 - x3,
+            // K: 6 - x5 - 2 x4, are built side by side in one word (no field borrows: B >= 1, K >= 3) and the state picks its field.
+            const lds_u32* pw = st + (off < (uint32_t)(NP_EA_WIN * PLANES - 6) ? off : (uint32_t)(NP_EA_WIN * PLANES - 6));
+            const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2], w3 = pw[3], w4 = pw[4], w5 = pw[5];
+            const uint32_t k3 = ea_owner<BPL>((uint32_t)k);
+            const uint32_t x0 = __builtin_amdgcn_ubfe(w0, k3, 1), x1 = __builtin_amdgcn_ubfe(w1, k3, 1), x2 = __builtin_amdgcn_ubfe(w2, k3, 1),
+                           x3 = __builtin_amdgcn_ubfe(w3, k3, 1), x4 = __builtin_amdgcn_ubfe(w4, k3, 1), x5 = __builtin_amdgcn_ubfe(w5, k3, 1);
+            const uint32_t up = (((x2 << 1) | x1) << 1) | x0, down = (((x3 << 2) | x4) << 1) | x5;
+            const uint32_t codes = ((up << 6) + 22u) - down;             // K | B << 3 | M << 6
+            const uint32_t c = __builtin_amdgcn_ubfe(codes, (uint32_t)ps * 3u, 3);
+            const uint32_t dk = c >> 2, dr = ps != 0 ? 1u : 0u;           // K states are silent (r9.cpp:176-178)
+            cnt += alive ? 1 : 0;
+            row -= (int)dr;
+            k -= (int)dk;
+            off -= ((c & 4u) != 0u ? 6u : 0u) + (ps != 0 ? 6u * BPL : 0u);
+            ps = (int)(c & 3u);
+            alive = alive && c != 7u /* HMT_FROM_SOFT */ && row > 0 && k >= 0;      // (a finished walk's row, k and state are not used again)
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -162,4 +162,15 @@ d=json.loads(open("$O/bench_raw.json").read().strip().splitlines()[-1]); print(d
 EOF
 }
 
+# chain kernel check: the event-align suites, the eventalign leg's time with its kernels by name, the soak
+call_s() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r05${TAG:-s}; mkdir -p $O
+( time timeout 900 python -m pytest tests/test_gpu_eventalign_dropin.py tests/test_gpu_dropin.py tests/test_gpu_reflevel.py tests/test_gpu_rna.py tests/test_gpu_sites.py tests/test_gpu_fuzz.py -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o p -- python $R/bench.py --workload eventalign --steps 3 --warmup 1 --cpu-sample 0 > $R/$O/bench_ea.json 2> $R/$O/bench_ea.err )
+python profiles/summarize_rocpd.py $(find $O/prof -name "*_results.db" | head -1) > $O/kernels.txt 2>&1
+( timeout 400 python tests/gpu_soak_eventalign.py ) > $O/soak.log 2>&1; echo "soak rc=$?" >> $O/soak.log
+tail -4 $O/pytest.log; grep -v "at::native\|rocclr\|probe" $O/kernels.txt | head -8 | cut -c1-160; tail -3 $O/soak.log; tail -1 $O/bench_ea.json | cut -c1-600
+}
+
 "call_$1"
