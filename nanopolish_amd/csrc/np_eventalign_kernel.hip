@@ -350,13 +350,13 @@ __device__ __attribute__((noinline)) void ea_next_segment(const np_ea_args* __re
 // code, one segment after the other, it took ~550-790 cycles per step and half of this kernel's time (the scalar unit's latency
 // per dependent instruction, ~40-55 of them per step), and two scalar chains interleaved in one loop were no faster.  As vector
 // code the chain is ~25 instructions for BOTH segments, and the back-pointer word is already the move (ea_block).
-// Per half: a window of NP_EA_WIN lines of its 32 dwords staged in LDS (refilled when the walk leaves it) and the list of visited
+// Per half: a window of WIN lines of its planes staged in LDS (refilled when the walk leaves it) and the list of visited
 // states in LDS (NP_EA_PCAP entries; a longer path spills the full buffer to the half's global list and goes on).
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
-#define NP_EA_WIN 16
+#define NP_EA_STAGE 512                   // dwords of a half's window
 #define NP_EA_PCAP 384
 struct ea_lds {
-    uint32_t stage[2][NP_EA_WIN * 32];     // back-pointer windows
+    uint32_t stage[2][NP_EA_STAGE];        // back-pointer windows
     uint32_t pbuf[2][NP_EA_PCAP];          // visited states, oldest first: row | kmer << 16 | state << 24
     uint32_t dump[64];                     // where the lanes that record nothing write
     ea_wave_state W;
@@ -380,7 +380,9 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
                                                              uint32_t* __restrict__ path0_, uint32_t* __restrict__ path1_, const int lane)
 {
     constexpr int LINE = NP_EA2_LINE_BYTES(BPL), PLANES = 6 * BPL, PER_LINE = 3 * BPL;     // PER_LINE: 16-byte pieces (two planes) of a line
-    static_assert(NP_EA_WIN * PER_LINE <= 192 && NP_EA_WIN * PLANES <= NP_EA_WIN * 32, "window staging: three rounds of 64 lanes, 512 dwords per half");
+    // the window: as many lines as three rounds of 64 lanes' 16-byte requests bring in (21 at three blocks per lane, 16 at four)
+    constexpr int WIN = 192 / PER_LINE;
+    static_assert(WIN * PLANES <= NP_EA_STAGE, "window staging");
     const float sv0 = ea_uniform(sv0_), sv1 = ea_uniform(sv1_);
     const uint8_t* __restrict__ bp = ea_uniform(bp_);
 
@@ -409,7 +411,7 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
         for (int h = 0; h < 2; ++h) {
             if ((need_m >> (32 * h)) & 1ull) {
                 const int hi = __builtin_amdgcn_readlane(line0, 32 * h);
-                const int nlo = hi - (NP_EA_WIN - 1) > 1 ? hi - (NP_EA_WIN - 1) : 1;
+                const int nlo = hi - (WIN - 1) > 1 ? hi - (WIN - 1) : 1;
                 // dword h of every plane of every line of the window: stage[h][line * PLANES + plane].  PER_LINE 16-byte requests per line
                 // (two planes each), all of a refill in flight at once (three rounds of 64 lanes cover 16 lines), at agent scope: they
                 // bypass the vector L1, which may still hold the previous segment's lines at these addresses (the sweep wrote the new
@@ -460,7 +462,7 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
             // every lane reads the six planes of the cell's block itself (the address does not depend on the state walked in) and takes
             // the bit of the lane that owns the k-mer out of each.  The three states' codes, M: x0 | x1 << 1 | x2 << 2, B: 2 - x3,
             // K: 6 - x5 - 2 x4, are built side by side in one word (no field borrows: B >= 1, K >= 3) and the state picks its field.
-            const lds_u32* pw = st + (off < (uint32_t)(NP_EA_WIN * PLANES - 6) ? off : (uint32_t)(NP_EA_WIN * PLANES - 6));
+            const lds_u32* pw = st + (off < (uint32_t)(WIN * PLANES - 6) ? off : (uint32_t)(WIN * PLANES - 6));
             const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2], w3 = pw[3], w4 = pw[4], w5 = pw[5];
             const uint32_t k3 = ea_owner<BPL>((uint32_t)k);
             const uint32_t x0 = __builtin_amdgcn_ubfe(w0, k3, 1), x1 = __builtin_amdgcn_ubfe(w1, k3, 1), x2 = __builtin_amdgcn_ubfe(w2, k3, 1),
