@@ -363,15 +363,40 @@ struct ea_lds {
 };
 struct ea_walk_result { int cnt0, cnt1, spilled0, spilled1; };
 
+// The window in LDS holds a block's back-pointers as NINE dwords, three per state: the state's move code bit by bit, so that a walk
+// step reads the three dwords of the state it is in and needs no arithmetic on them (round 5; until then the six planes as the sweep
+// stores them, every step decoding all three states' codes and selecting one: 14 of its 41 vector instructions):
+//   +0..2  KMER_SKIP (state 0):  q3, ~(q3 | q4), ~0   (code 6 - q3 - 2 q4: PREV_K 4 / PREV_B 5 / PREV_M 6)
+//   +3..5  BAD_EVENT (state 1):  pb, ~pb, 0           (code 2 - pb: SAME_B 1 / SAME_M 2)
+//   +6..8  MATCH (state 2):      the three planes of the M cell's code as stored
+// The refill makes the complements; the two constant dwords of every cell are written once per launch (ea_window_init).
+#define NP_EA_CELL 9
+__host__ __device__ constexpr int ea_window_lines(int bpl)
+{
+    // as many lines as three rounds of 64 lanes' 16-byte requests bring in, and as the half's stage holds
+    return (192 / (3 * bpl)) < (NP_EA_STAGE / (NP_EA_CELL * bpl)) ? (192 / (3 * bpl)) : (NP_EA_STAGE / (NP_EA_CELL * bpl));
+}
+template <int BPL> __device__ __forceinline__ void ea_window_init(ea_lds* L, const int lane)
+{
+    for (int i = lane; i < 2 * ea_window_lines(BPL) * BPL; i += 64) {
+        const int h = i / (ea_window_lines(BPL) * BPL), cell = i - h * ea_window_lines(BPL) * BPL;
+        L->stage[h][cell * NP_EA_CELL + 2] = ~0u; L->stage[h][cell * NP_EA_CELL + 5] = 0u;
+    }
+}
+
 // the lane (of its half) that owns k-mer k = k / BPL, as full-rate instructions (a 32-bit multiply-high is quarter rate); 5 bits, as the
 // shifts that use it take
+// (the full-rate 24-bit multiply by name: the compiler takes the quarter-rate v_mul_lo_u32 for these small products whatever it is told
+//  about the operands)
+__device__ __forceinline__ uint32_t ea_mul24(const uint32_t a, const uint32_t b)
+{
+    uint32_t p;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(p) : "v"(a), "v"(b));
+    return p;
+}
 template <int BPL> __device__ __forceinline__ uint32_t ea_owner(const uint32_t k)
 {
-    if constexpr (BPL == 3) {                             // exact for k < 512 (k < 96 here)
-        uint32_t p;
-        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(p) : "v"(k), "v"(171u));     // (the compiler takes v_mul_lo_u32 for k * 171 whatever it is told about k)
-        return __builtin_amdgcn_ubfe(p, 9, 5);
-    }
+    if constexpr (BPL == 3) return __builtin_amdgcn_ubfe(ea_mul24(k, 171u), 9, 5);      // exact for k < 512 (k < 96 here)
     else { static_assert((BPL & (BPL - 1)) == 0, "k-mers per lane"); return (k / BPL) & 31u; }
 }
 
@@ -379,10 +404,8 @@ template <int BPL>
 __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const float sv0_, const float sv1_, const uint8_t* __restrict__ bp_,
                                                              uint32_t* __restrict__ path0_, uint32_t* __restrict__ path1_, const int lane)
 {
-    constexpr int LINE = NP_EA2_LINE_BYTES(BPL), PLANES = 6 * BPL, PER_LINE = 3 * BPL;     // PER_LINE: 16-byte pieces (two planes) of a line
-    // the window: as many lines as three rounds of 64 lanes' 16-byte requests bring in (21 at three blocks per lane, 16 at four)
-    constexpr int WIN = 192 / PER_LINE;
-    static_assert(WIN * PLANES <= NP_EA_STAGE, "window staging");
+    constexpr int LINE = NP_EA2_LINE_BYTES(BPL), PER_LINE = 3 * BPL;      // PER_LINE: 16-byte pieces (two planes) of a line
+    constexpr int CELL = NP_EA_CELL, LSTR = CELL * BPL, WIN = ea_window_lines(BPL);
     const float sv0 = ea_uniform(sv0_), sv1 = ea_uniform(sv1_);
     const uint8_t* __restrict__ bp = ea_uniform(bp_);
 
@@ -401,6 +424,20 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
     const lds_u32* st = (const lds_u32*)&L->stage[hi_half ? 1 : 0][0];
     lds_u32* pb = (lds_u32*)&L->pbuf[hi_half ? 1 : 0][0];
     lds_u32* dump = (lds_u32*)&L->dump[lane];
+    // what this lane does in a refill, whatever the window: piece i = lane + 64 it is 16-byte piece q (planes 2q, 2q + 1) of line ln; of a
+    // block's six planes, pieces 0 / 1 / 2 hold (M0, M1) / (M2, pb) / (q4, q3).  The lane writes two values to g_a, g_a + 1 -- (M0, M1) /
+    // (pb, ~pb) / (q3, ~(q3 | q4)) -- and a third to g_b: piece 1 its M2, the others their second value once more (no dump slot)
+    int g_off[3]; uint32_t g_a[3], g_b[3]; bool g_first[3], g_k[3], g_p[3];
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int i = lane + 64 * it, ln = i / PER_LINE, q = i - PER_LINE * ln, c = q / 3, part = q - 3 * c;
+        g_off[it] = ln * LINE + q * 16;
+        g_a[it] = (uint32_t)((ln * BPL + c) * CELL + (part == 0 ? 6 : part == 1 ? 3 : 0));
+        g_b[it] = part == 1 ? g_a[it] + 5u : g_a[it] + 1u;
+        g_first[it] = part == 0; g_k[it] = part == 2; g_p[it] = part == 1;
+    }
+    const bool g_live2 = (lane + 128) / PER_LINE < WIN;      // the third round's pieces past the window's last line
+    static_assert(127 / PER_LINE < WIN, "the first two rounds' pieces are inside the window");
     while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
         // ---- per half, by scalar control: refill the window of a walk that is outside it; spill a full list ----
         const int line0 = (int)((uint32_t)row + (uint32_t)k / BPL);
@@ -412,23 +449,20 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
             if ((need_m >> (32 * h)) & 1ull) {
                 const int hi = __builtin_amdgcn_readlane(line0, 32 * h);
                 const int nlo = hi - (WIN - 1) > 1 ? hi - (WIN - 1) : 1;
-                // dword h of every plane of every line of the window: stage[h][line * PLANES + plane].  PER_LINE 16-byte requests per line
-                // (two planes each), all of a refill in flight at once (three rounds of 64 lanes cover 16 lines), at agent scope: they
-                // bypass the vector L1, which may still hold the previous segment's lines at these addresses (the sweep wrote the new
-                // ones through the scalar cache)
-                const int n16 = (hi - nlo + 1) * PER_LINE;
+                // dword h of every plane of every line of the window, PER_LINE 16-byte requests per line (two planes each), all of a refill in
+                // flight at once, at agent scope: they bypass the vector L1, which may still hold the previous segment's lines at these
+                // addresses (the sweep wrote the new ones through the scalar cache).  A piece past the window's last line is outside the
+                // descriptor's range and reads as 0 (what it writes, nobody reads).
                 const __amdgpu_buffer_rsrc_t lr = make_rsrc(bp + (size_t)(nlo - 1) * LINE, (uint32_t)(hi - nlo + 1) * LINE);
                 lds_u32* dst = (lds_u32*)&L->stage[h][0];
                 uint4 v[3];
 #pragma unroll
-                for (int it = 0; it < 3; ++it) {
-                    const int i = lane + 64 * it, ln = i / PER_LINE;
-                    v[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(lr, whole_offset(i < n16 ? ln * LINE + (i - PER_LINE * ln) * 16 : -16), 0, 16 /* sc1 */));
-                }
+                for (int it = 0; it < 3; ++it) v[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(lr, whole_offset(g_off[it]), 0, 16 /* sc1 */));
 #pragma unroll
                 for (int it = 0; it < 3; ++it) {
-                    const int i = lane + 64 * it, ln = i / PER_LINE, q = i - PER_LINE * ln;
-                    if (i < n16) { dst[ln * PLANES + 2 * q] = h ? v[it].y : v[it].x; dst[ln * PLANES + 2 * q + 1] = h ? v[it].w : v[it].z; }
+                    const uint32_t pa = h ? v[it].y : v[it].x, pb2 = h ? v[it].w : v[it].z;
+                    const uint32_t w0 = g_first[it] ? pa : pb2, w1 = g_first[it] ? pb2 : ~(pb2 | (g_k[it] ? pa : 0u)), w2 = g_p[it] ? pa : w1;
+                    if (it < 2 || g_live2) { dst[g_a[it]] = w0; dst[g_a[it] + 1] = w1; dst[g_b[it]] = w2; }
                 }
                 lo = (hi_half == (h == 1)) ? nlo : lo;
             }
@@ -449,32 +483,24 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
         const int mine = alive ? (room < space ? room : space) : 0x7fffffff;
         const int b0 = __builtin_amdgcn_readlane(mine, 0), b1 = __builtin_amdgcn_readlane(mine, 32);
         const int burst = b0 < b1 ? b0 : b1;
-        // planes of cell (row, k): stage[(row + k / BPL - lo) * PLANES + (k % BPL) * 6 ...] = stage[6 * (row * BPL + k - lo * BPL) ...]: an
-        // offset that falls by 6 BPL with the row and by 6 with the k-mer.  (A finished walk's offset is anything: the min keeps its
-        // reads inside the window.)
-        uint32_t off = ((uint32_t)row * BPL + (uint32_t)k - (uint32_t)lo * BPL) * 6u;
+        // codes of cell (row, k): stage[(row + k / BPL - lo) * LSTR + (k % BPL) * CELL ...] = stage[CELL * (row * BPL + k - lo * BPL) ...]: an
+        // offset that falls by CELL * BPL with the row and by CELL with the k-mer.  (A finished walk's offset is anything: the min keeps
+        // its reads inside the window.)
+        uint32_t off = ((uint32_t)row * BPL + (uint32_t)k - (uint32_t)lo * BPL) * CELL;
         for (int s = 0; s < burst; ++s) {
             // the visited state goes to the half's list (lane 0 of the half writes it, the others -- and a finished walk -- write their dump slots)
             const uint32_t entry = (uint32_t)row | ((uint32_t)k << 16) | ((uint32_t)ps << 24);
             lds_u32* wp = (alive && sl == 0) ? pb + (cnt - spilled) : dump;
             *wp = entry;
-            // the move out of this cell
-            // every lane reads the six planes of the cell's block itself (the address does not depend on the state walked in) and takes
-            // the bit of the lane that owns the k-mer out of each.  The three states' codes, M: x0 | x1 << 1 | x2 << 2, B: 2 - x3,
-            // K: 6 - x5 - 2 x4, are built side by side in one word (no field borrows: B >= 1, K >= 3) and the state picks its field.
-            const lds_u32* pw = st + (off < (uint32_t)(WIN * PLANES - 6) ? off : (uint32_t)(WIN * PLANES - 6));
-            const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2], w3 = pw[3], w4 = pw[4], w5 = pw[5];
+            // the move out of this cell: the three dwords of the state walked in, of each the bit of the lane that owns the k-mer
+            const lds_u32* pw = st + ((off < (uint32_t)((WIN * BPL - 1) * CELL) ? off : (uint32_t)((WIN * BPL - 1) * CELL)) + ea_mul24((uint32_t)ps, 3u));
+            const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
             const uint32_t k3 = ea_owner<BPL>((uint32_t)k);
-            const uint32_t x0 = __builtin_amdgcn_ubfe(w0, k3, 1), x1 = __builtin_amdgcn_ubfe(w1, k3, 1), x2 = __builtin_amdgcn_ubfe(w2, k3, 1),
-                           x3 = __builtin_amdgcn_ubfe(w3, k3, 1), x4 = __builtin_amdgcn_ubfe(w4, k3, 1), x5 = __builtin_amdgcn_ubfe(w5, k3, 1);
-            const uint32_t up = (((x2 << 1) | x1) << 1) | x0, down = (((x3 << 2) | x4) << 1) | x5;
-            const uint32_t codes = ((up << 6) + 22u) - down;             // K | B << 3 | M << 6
-            const uint32_t c = __builtin_amdgcn_ubfe(codes, (uint32_t)ps * 3u, 3);
-            const uint32_t dk = c >> 2, dr = ps != 0 ? 1u : 0u;           // K states are silent (r9.cpp:176-178)
+            const uint32_t c = __builtin_amdgcn_ubfe(w0, k3, 1) | (__builtin_amdgcn_ubfe(w1, k3, 1) << 1) | (__builtin_amdgcn_ubfe(w2, k3, 1) << 2);
             cnt += alive ? 1 : 0;
-            row -= (int)dr;
-            k -= (int)dk;
-            off -= ((c & 4u) != 0u ? 6u : 0u) + (ps != 0 ? 6u * BPL : 0u);
+            off -= ((c & 4u) != 0u ? (uint32_t)CELL : 0u) + (ps != 0 ? (uint32_t)LSTR : 0u);
+            row -= ps != 0 ? 1 : 0;                                     // K states are silent (r9.cpp:176-178)
+            k -= (int)(c >> 2);
             ps = (int)(c & 3u);
             alive = alive && c != 7u /* HMT_FROM_SOFT */ && row > 0 && k >= 0;      // (a finished walk's row, k and state are not used again)
         }
@@ -554,6 +580,7 @@ __global__ void __launch_bounds__(64, WAVES) np_eventalign_chain2_kernel(const n
     uint32_t* __restrict__ path = a.path + (size_t)wave_slot * a.path_stride;
     const int k = a.k;
     if (lane == 0) { W.h[0].ri = -1; W.h[1].ri = -1; W.drained = 0; }
+    ea_window_init<BPL>(&lds, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
