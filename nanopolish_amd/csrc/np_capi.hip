@@ -1255,7 +1255,7 @@ int np_eventalign_dev(np_ctx* c, void* stream, int n_reads, const np_read_dev* r
     const int variant = k == 5 ? 4 : (c->ea_waves_per_cu > 16 ? 3 : 2);        // (k = 5: four blocks per lane; else the register budget of 5 or 4 waves per SIMD)
     const int waves_per_cu = c->ea_waves_per_cu;
     const int nb = persistent_blocks(c, (n_reads + 1) / 2, 1, waves_per_cu);
-    const size_t bp_stride = ((size_t)rows_cap + 64) * (size_t)np_eventalign_line_bytes(variant), path_stride = 2 * ((size_t)rows_cap + 256);     // one line per sweep step: e + 63 at most; two path lists (one per half-wave in the two-read kernel)
+    const size_t bp_stride = ((size_t)rows_cap + 64) * (size_t)np_eventalign_line_bytes(variant), path_stride = 4 * ((size_t)rows_cap + 256);     // one line per sweep step: e + 63 at most; two path lists (one per half-wave), a 64-bit word per burst of walk steps, e + n bursts at most
     NP_HIP(c, c->ea_bp.reserve((size_t)nb * bp_stride));
     NP_HIP(c, c->ea_path.reserve((size_t)nb * path_stride * sizeof(uint32_t)));
     family_timer tm(c, 6, s);

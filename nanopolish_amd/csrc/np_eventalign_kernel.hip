@@ -351,17 +351,27 @@ __device__ __attribute__((noinline)) void ea_next_segment(const np_ea_args* __re
 // per dependent instruction, ~40-55 of them per step), and two scalar chains interleaved in one loop were no faster.  As vector
 // code the chain is ~25 instructions for BOTH segments, and the back-pointer word is already the move (ea_block).
 // Per half: a window of WIN lines of its planes staged in LDS (refilled when the walk leaves it) and the list of visited
-// states in LDS (NP_EA_PCAP entries; a longer path spills the full buffer to the half's global list and goes on).
+// states in LDS (ea_lds; a longer path spills the full buffer to the half's global list and goes on).
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
-#define NP_EA_STAGE 512                   // dwords of a half's window
-#define NP_EA_PCAP 384
+#ifndef NP_EA_EARLY
+#define NP_EA_EARLY 5                     // refill a window that has fewer than this many lines left (experiment)
+#endif
+#define NP_EA_STAGE 568                   // dwords of a half's window
+#ifndef NP_EA_BCAP
+#define NP_EA_BCAP 176                    // bursts of a half's list that LDS holds (a longer list spills to the half's global list)
+#endif
+#define NP_EA_BURST 10                    // steps of a burst at most: their codes share a dword
+// The list of visited states, per half: one 64-bit word per BURST of walk steps (round 5; until then one dword per visited state, written
+// by every step -- six of a step's vector instructions).  Low dword: the state the burst starts in, row | k-mer << 16 | state << 24, and
+// the number of steps << 26; high dword: the steps' move codes, three bits each, first step lowest.  The emission replays a burst from
+// its first state (row -= state != KMER_SKIP, k-mer -= code >> 2, state = code & 3).
 struct ea_lds {
     uint32_t stage[2][NP_EA_STAGE];        // back-pointer windows
-    uint32_t pbuf[2][NP_EA_PCAP];          // visited states, oldest first: row | kmer << 16 | state << 24
-    uint32_t dump[64];                     // where the lanes that record nothing write
+    uint64_t bursts[2][NP_EA_BCAP];        // oldest first
     ea_wave_state W;
 };
-struct ea_walk_result { int cnt0, cnt1, spilled0, spilled1; };
+typedef __attribute__((address_space(3))) uint64_t lds_u64;
+struct ea_walk_result { int nb0, nb1, spilled0, spilled1; };       // bursts in all, bursts spilled
 
 // The window in LDS holds a block's back-pointers as NINE dwords, three per state: the state's move code bit by bit, so that a walk
 // step reads the three dwords of the state it is in and needs no arithmetic on them (round 5; until then the six planes as the sweep
@@ -415,15 +425,14 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
     const int sl = lane & 31;
     // per-lane state, uniform within a half
     const int e = hi_half ? H1.e : H0.e, n = hi_half ? H1.n : H0.n;
-    int row = e, k = n - 1, ps = 2, cnt = 0, spilled = 0;              // k: the k-mer; lane k / BPL (of the half) owns it, as its block k % BPL
+    int row = e, k = n - 1, ps = 2, nb = 0, spilled = 0;               // nb: bursts recorded; k: the k-mer; lane k / BPL (of the half) owns it, as its block k % BPL
     int lo = 0x7fffffff;                                  // no window yet
     // assert(get(vm, row, col) != -INFINITY): no path, nothing to emit
     bool alive = (hi_half ? (H1.ri >= 0 && sv1 != NP_NEG_INF) : (H0.ri >= 0 && sv0 != NP_NEG_INF)) && e > 0 && n > 0;
     // (L arrives as a generic pointer -- a not-inlined function's argument; without the address space the compiler reads the staged
     //  lines with flat loads behind null checks and 64-bit address arithmetic, in the middle of the walk's dependent chain)
     const lds_u32* st = (const lds_u32*)&L->stage[hi_half ? 1 : 0][0];
-    lds_u32* pb = (lds_u32*)&L->pbuf[hi_half ? 1 : 0][0];
-    lds_u32* dump = (lds_u32*)&L->dump[lane];
+    lds_u64* bl = (lds_u64*)&L->bursts[hi_half ? 1 : 0][0];
     // what this lane does in a refill, whatever the window: piece i = lane + 64 it is 16-byte piece q (planes 2q, 2q + 1) of line ln; of a
     // block's six planes, pieces 0 / 1 / 2 hold (M0, M1) / (M2, pb) / (q4, q3).  The lane writes two values to g_a, g_a + 1 -- (M0, M1) /
     // (pb, ~pb) / (q3, ~(q3 | q4)) -- and a third to g_b: piece 1 its M2, the others their second value once more (no dump slot)
@@ -441,7 +450,7 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
     while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
         // ---- per half, by scalar control: refill the window of a walk that is outside it; spill a full list ----
         const int line0 = (int)((uint32_t)row + (uint32_t)k / BPL);
-        const bool need = alive && line0 < lo, full = alive && cnt - spilled >= NP_EA_PCAP;
+        const bool need = alive && (line0 < lo || (NP_EA_EARLY > 0 && line0 < lo + NP_EA_EARLY && lo > 1)), full = alive && nb - spilled >= NP_EA_BCAP;
         const uint64_t need_m = __builtin_amdgcn_ballot_w64(need), full_m = __builtin_amdgcn_ballot_w64(full);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -468,92 +477,120 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
             }
             if ((full_m >> (32 * h)) & 1ull) {
                 const int sp = __builtin_amdgcn_readlane(spilled, 32 * h);
-                uint32_t* __restrict__ dstp = (h ? path1 : path0) + sp;
-                for (int i = lane; i < NP_EA_PCAP; i += 64) dstp[i] = L->pbuf[h][i];
-                spilled = (hi_half == (h == 1)) ? spilled + NP_EA_PCAP : spilled;
+                uint64_t* __restrict__ dstp = (uint64_t*)(h ? path1 : path0) + sp;
+                for (int i = lane; i < NP_EA_BCAP; i += 64) dstp[i] = L->bursts[h][i];
+                spilled = (hi_half == (h == 1)) ? spilled + NP_EA_BCAP : spilled;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
-        // ---- a burst of steps: as many as no live walk can leave its window or fill its list in.  A step lowers row + k / BPL by at
-        //      most 2, so the count is known before the first one and the steps themselves carry no window test, no ballot and no
-        //      branch (round 5: the per-step test and the selects that froze a waiting walk were a third of the chain's instructions)
-        const int room = (int)(((uint32_t)line0 - (uint32_t)lo) >> 1) + 1, space = NP_EA_PCAP - (cnt - spilled);      // (unsigned: a finished walk's numbers are anything)
-        const int mine = alive ? (room < space ? room : space) : 0x7fffffff;
+        // ---- a burst of steps: as many as no live walk can leave its window in.  A step lowers row + k / BPL by at most 2, so the count
+        //      is known before the first one and the steps themselves carry no window test, no ballot and no branch (round 5: the
+        //      per-step test and the selects that froze a waiting walk were a third of the chain's instructions)
+        const int room = (int)(((uint32_t)line0 - (uint32_t)lo) >> 1) + 1;      // (unsigned: a finished walk's numbers are anything)
+        const int mine = alive ? room : NP_EA_BURST;
         const int b0 = __builtin_amdgcn_readlane(mine, 0), b1 = __builtin_amdgcn_readlane(mine, 32);
-        const int burst = b0 < b1 ? b0 : b1;
+        const int b01 = b0 < b1 ? b0 : b1, burst = b01 < NP_EA_BURST ? b01 : NP_EA_BURST;
         // codes of cell (row, k): stage[(row + k / BPL - lo) * LSTR + (k % BPL) * CELL ...] = stage[CELL * (row * BPL + k - lo * BPL) ...]: an
         // offset that falls by CELL * BPL with the row and by CELL with the k-mer.  (A finished walk's offset is anything: the min keeps
         // its reads inside the window.)
         uint32_t off = ((uint32_t)row * BPL + (uint32_t)k - (uint32_t)lo * BPL) * CELL;
+        const uint32_t first = (uint32_t)row | ((uint32_t)k << 16) | ((uint32_t)ps << 24);
+        uint32_t codes = 0u;
+        int steps = 0;                                    // of this half's walk: those it was alive at
         for (int s = 0; s < burst; ++s) {
-            // the visited state goes to the half's list (lane 0 of the half writes it, the others -- and a finished walk -- write their dump slots)
-            const uint32_t entry = (uint32_t)row | ((uint32_t)k << 16) | ((uint32_t)ps << 24);
-            lds_u32* wp = (alive && sl == 0) ? pb + (cnt - spilled) : dump;
-            *wp = entry;
+            steps = alive ? s + 1 : steps;
             // the move out of this cell: the three dwords of the state walked in, of each the bit of the lane that owns the k-mer
             const lds_u32* pw = st + ((off < (uint32_t)((WIN * BPL - 1) * CELL) ? off : (uint32_t)((WIN * BPL - 1) * CELL)) + ea_mul24((uint32_t)ps, 3u));
             const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
             const uint32_t k3 = ea_owner<BPL>((uint32_t)k);
             const uint32_t c = __builtin_amdgcn_ubfe(w0, k3, 1) | (__builtin_amdgcn_ubfe(w1, k3, 1) << 1) | (__builtin_amdgcn_ubfe(w2, k3, 1) << 2);
-            cnt += alive ? 1 : 0;
+            codes |= c << (3 * s);
             off -= ((c & 4u) != 0u ? (uint32_t)CELL : 0u) + (ps != 0 ? (uint32_t)LSTR : 0u);
             row -= ps != 0 ? 1 : 0;                                     // K states are silent (r9.cpp:176-178)
             k -= (int)(c >> 2);
             ps = (int)(c & 3u);
-            alive = alive && c != 7u /* HMT_FROM_SOFT */ && row > 0 && k >= 0;      // (a finished walk's row, k and state are not used again)
+            // the walk ends at row 0 or k-mer -1.  (HMT_FROM_SOFT, code 7, is the move out of MATCH of (row 1, k-mer 0) only -- the one
+            // cell the sweep offers the soft clip to, ea_fill2 -- and leads to row 0: no test of its own.  A finished walk's row, k and
+            // state are not used again.)
+            alive = alive && row > 0 && k >= 0;
         }
+        if (sl == 0 && steps > 0) bl[nb - spilled] = (uint64_t)(first | ((uint32_t)steps << 26)) | ((uint64_t)codes << 32);
+        nb += steps > 0 ? 1 : 0;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     ea_walk_result r;
-    r.cnt0 = __builtin_amdgcn_readlane(cnt, 0); r.cnt1 = __builtin_amdgcn_readlane(cnt, 32);
+    r.nb0 = __builtin_amdgcn_readlane(nb, 0); r.nb1 = __builtin_amdgcn_readlane(nb, 32);
     r.spilled0 = __builtin_amdgcn_readlane(spilled, 0); r.spilled1 = __builtin_amdgcn_readlane(spilled, 32);
     return r;
 }
 
-// emission (eventalign.cpp:774-812) of half q's segment from its list of visited states (entries [spilled, cnt) in LDS, older ones in
-// the half's global list): ascending order = the list read backwards
-__device__ __attribute__((noinline)) void ea_emit_segment(const np_ea_args* __restrict__ ap_, ea_lds* L, const int q_, const int cnt_, const int spilled_,
+// emission (eventalign.cpp:774-812) of half q's segment from its list of bursts (those from `spilled` on in LDS, older ones in the half's
+// global list).  Ascending order = the list read backwards: a round takes the last 64 bursts not yet seen, lane 0 the last of them; a
+// lane replays its burst from its first state and then goes through the states last to first.
+__device__ __attribute__((noinline)) void ea_emit_segment(const np_ea_args* __restrict__ ap_, ea_lds* L, const int q_, const int nb_, const int spilled_,
                                                           const uint32_t* __restrict__ path_, const int lane)
 {
     const np_ea_args& a = *ea_uniform(ap_);
-    const int q = ea_uniform(q_), cnt = ea_uniform(cnt_), spilled = ea_uniform(spilled_);
-    const uint32_t* __restrict__ path = ea_uniform(path_);
+    const int q = ea_uniform(q_), nb = ea_uniform(nb_), spilled = ea_uniform(spilled_);
+    const uint64_t* __restrict__ path = (const uint64_t*)ea_uniform(path_);
     ea_wave_state* W = &L->W;
     ea_half h = ea_get(W, q);
     const int e_start = h.e_start, stride = h.stride;
     const int64_t o0 = a.out_off[h.ri];
     const int out_cap = (int)(a.out_off[h.ri + 1] - o0);
     int32_t* __restrict__ out_ref = a.out_ref + o0; int32_t* __restrict__ out_event = a.out_event + o0; uint8_t* __restrict__ out_state = a.out_state + o0;
-    const uint32_t* pb = &L->pbuf[q][0];
+    const lds_u64* bl = (const lds_u64*)&L->bursts[q][0];
+    const uint64_t below = (1ull << lane) - 1ull;
     int num_output = 0, last_event_output = 0, last_ref_kmer_output = 0;
-    for (int base = 0; base < cnt && (num_output < 50 || h.last_section); base += 64) {
-        const int i = base + lane;
-        uint32_t pe = 0; bool qq = false; int evi = 0, km = 0, ps = 0;
-        if (i < cnt) {
-            const int j = cnt - 1 - i;
-            pe = j >= spilled ? pb[j - spilled] : path[j];
-            ps = (int)(pe >> 24); km = (int)((pe >> 16) & 0xff); evi = e_start + ((int)(pe & 0xffff) - 1) * stride;
-            qq = ps != 0 && evi != h.curr_start_event;
+    for (int base = 0; base < nb && (num_output < 50 || h.last_section); base += 64) {
+        const int w = nb - 1 - base - lane;
+        uint64_t word = 0ull;                             // (no burst: no steps)
+        if (w >= 0) word = w >= spilled ? bl[w - spilled] : path[w];
+        const uint32_t first = (uint32_t)word, codes = (uint32_t)(word >> 32);
+        const int n = (int)((first >> 26) & 15u);
+        int row = (int)(first & 0xffffu), k = (int)((first >> 16) & 0xffu), ps = (int)((first >> 24) & 3u);
+        int evi[NP_EA_BURST], km[NP_EA_BURST]; bool qq[NP_EA_BURST], is_m[NP_EA_BURST];
+        int mine = 0;                                     // states of this burst that are output candidates: not K, not the start event
+#pragma unroll
+        for (int j = 0; j < NP_EA_BURST; ++j) {
+            evi[j] = e_start + (row - 1) * stride; km[j] = k; is_m[j] = ps == 2;
+            qq[j] = j < n && ps != 0 && evi[j] != h.curr_start_event;
+            mine += qq[j] ? 1 : 0;
+            const uint32_t c = (codes >> (3 * j)) & 7u;
+            row -= ps != 0 ? 1 : 0; k -= (int)(c >> 2); ps = (int)(c & 3u);
         }
-        const uint64_t qm = __builtin_amdgcn_ballot_w64(qq);
-        const int before = __builtin_popcountll(qm & ((1ull << lane) - 1ull));
-        const int pos = num_output + before;
-        const bool wr = qq && (pos < 50 || h.last_section);
-        if (wr && h.n_out + before < out_cap) {
-            out_ref[h.n_out + before] = h.curr_start_ref + km;
-            out_event[h.n_out + before] = evi;
-            out_state[h.n_out + before] = ps == 2 ? (uint8_t)'M' : (uint8_t)'B';
+        // candidates of the lanes before this one, and of the round (mine <= 10: four bits)
+        int before = 0, total = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint64_t m = __builtin_amdgcn_ballot_w64(((mine >> b) & 1) != 0);
+            before += __builtin_popcountll(m & below) << b; total += __builtin_popcountll(m) << b;
         }
-        const uint64_t wm = __builtin_amdgcn_ballot_w64(wr);
-        const int nw = __builtin_popcountll(wm);
-        if (nw > 0) {
+        int pos = num_output + before;
+        bool any = false; int my_event = 0, my_kmer = 0;  // the last state this lane wrote
+#pragma unroll
+        for (int j = NP_EA_BURST - 1; j >= 0; --j) {
+            const bool wr = qq[j] && (pos < 50 || h.last_section);
+            const int o = h.n_out + (pos - num_output);
+            if (wr && o < out_cap) {
+                out_ref[o] = h.curr_start_ref + km[j];
+                out_event[o] = evi[j];
+                out_state[o] = is_m[j] ? (uint8_t)'M' : (uint8_t)'B';
+            }
+            any = any || wr; my_event = wr ? evi[j] : my_event; my_kmer = wr ? km[j] : my_kmer;
+            pos += qq[j] ? 1 : 0;
+        }
+        const uint64_t wm = __builtin_amdgcn_ballot_w64(any);
+        const int left = 50 - num_output;
+        const int nw = h.last_section ? total : (total < left ? total : (left > 0 ? left : 0));
+        if (wm != 0ull) {
             const int last_lane = 63 - __builtin_clzll(wm);
-            last_event_output = __shfl(evi, last_lane, 64);
-            last_ref_kmer_output = h.curr_start_ref + __shfl(km, last_lane, 64);
+            last_event_output = __shfl(my_event, last_lane, 64);
+            last_ref_kmer_output = h.curr_start_ref + __shfl(my_kmer, last_lane, 64);
         }
         if (h.n_out + nw > out_cap) h.status = NP_EA_OVERFLOW;
         h.n_out += nw; num_output += nw;
@@ -638,8 +675,8 @@ __global__ void __launch_bounds__(64, WAVES) np_eventalign_chain2_kernel(const n
         if (prio) __builtin_amdgcn_s_setprio(3);
         uint32_t* path1 = path + (a.path_stride >> 1);
         const ea_walk_result wr = ea_walk2<BPL>(&lds, start_v.x, start_v.y, bp, path, path1, lane);
-        if (H0.ri >= 0) ea_emit_segment(ap, &lds, 0, wr.cnt0, wr.spilled0, path, lane);
-        if (H1.ri >= 0) ea_emit_segment(ap, &lds, 1, wr.cnt1, wr.spilled1, path1, lane);
+        if (H0.ri >= 0) ea_emit_segment(ap, &lds, 0, wr.nb0, wr.spilled0, path, lane);
+        if (H1.ri >= 0) ea_emit_segment(ap, &lds, 1, wr.nb1, wr.spilled1, path1, lane);
         if (prio) __builtin_amdgcn_s_setprio(0);
         t_fin += __builtin_amdgcn_s_memtime() - t2;
     }

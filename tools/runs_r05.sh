@@ -170,7 +170,24 @@ O=gpurun_out/r05${TAG:-s}; mkdir -p $O
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o p -- python $R/bench.py --workload eventalign --steps 3 --warmup 1 --cpu-sample 0 > $R/$O/bench_ea.json 2> $R/$O/bench_ea.err )
 python profiles/summarize_rocpd.py $(find $O/prof -name "*_results.db" | head -1) > $O/kernels.txt 2>&1
 ( timeout 400 python tests/gpu_soak_eventalign.py ) > $O/soak.log 2>&1; echo "soak rc=$?" >> $O/soak.log
+( NP_HIP_LIB=$PWD/nanopolish_amd/variants/libnp_hip_smalllist.so timeout 600 python -m pytest tests/test_gpu_eventalign_dropin.py tests/test_gpu_rna.py -m gpu -x -q ) > $O/pytest_smalllist.log 2>&1; echo "smalllist rc=$?" >> $O/pytest_smalllist.log; tail -2 $O/pytest_smalllist.log
 tail -4 $O/pytest.log; grep -v "at::native\|rocclr\|probe" $O/kernels.txt | head -8 | cut -c1-160; tail -3 $O/soak.log; tail -1 $O/bench_ea.json | cut -c1-600
+}
+
+# chain kernel variants (NP_HIP_LIB): the eventalign leg's chain time for each
+call_t() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r05${TAG:-t}; mkdir -p $O
+for v in default ${VARIANTS:-early3 early5 early7}; do
+  L=""; [ $v != default ] && L=$PWD/nanopolish_amd/variants/libnp_hip_$v.so
+  ( NP_HIP_LIB=$L timeout 300 python bench.py --workload eventalign --steps 3 --warmup 1 --cpu-sample 0 ) > $O/$v.json 2> $O/$v.err
+  python -c "
+import json
+try:
+    d=json.loads([l for l in open('$O/$v.json') if l.startswith('{')][-1]); print('$v', d['value'], d['kernel_ms_per_step']['eventalign_chain'], d['roofline'].get('wave_cycles_by_phase'))
+except Exception as e: print('$v', 'failed', e)
+"
+done
 }
 
 "call_$1"
