@@ -371,6 +371,7 @@ struct ea_lds {
     ea_wave_state W;
 };
 typedef __attribute__((address_space(3))) uint64_t lds_u64;
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
 struct ea_walk_result { int nb0, nb1, spilled0, spilled1; };       // bursts in all, bursts spilled
 
 // The window in LDS holds a block's back-pointers as NINE dwords, three per state: the state's move code bit by bit, so that a walk
@@ -495,29 +496,32 @@ __device__ __attribute__((noinline)) ea_walk_result ea_walk2(ea_lds* L, const fl
         // codes of cell (row, k): stage[(row + k / BPL - lo) * LSTR + (k % BPL) * CELL ...] = stage[CELL * (row * BPL + k - lo * BPL) ...]: an
         // offset that falls by CELL * BPL with the row and by CELL with the k-mer.  (A finished walk's offset is anything: the min keeps
         // its reads inside the window.)
-        uint32_t off = ((uint32_t)row * BPL + (uint32_t)k - (uint32_t)lo * BPL) * CELL;
+        uint32_t off = ((uint32_t)row * BPL + (uint32_t)k - (uint32_t)lo * BPL) * (CELL * 4u);      // (in bytes)
         const uint32_t first = (uint32_t)row | ((uint32_t)k << 16) | ((uint32_t)ps << 24);
         uint32_t codes = 0u;
-        int steps = 0;                                    // of this half's walk: those it was alive at
+        uint32_t steps0 = 0u, steps1 = 0u;                // steps each half's walk was alive at
+        uint64_t am = __builtin_amdgcn_ballot_w64(alive); // inside the burst "alive" is this scalar mask, the counts scalar additions
         for (int s = 0; s < burst; ++s) {
-            steps = alive ? s + 1 : steps;
+            steps0 += (uint32_t)am & 1u; steps1 += (uint32_t)(am >> 32) & 1u;
             // the move out of this cell: the three dwords of the state walked in, of each the bit of the lane that owns the k-mer
-            const lds_u32* pw = st + ((off < (uint32_t)((WIN * BPL - 1) * CELL) ? off : (uint32_t)((WIN * BPL - 1) * CELL)) + ea_mul24((uint32_t)ps, 3u));
+            const lds_u32* pw = (const lds_u32*)((const lds_u8*)st + ((off < (uint32_t)((WIN * BPL - 1) * CELL * 4) ? off : (uint32_t)((WIN * BPL - 1) * CELL * 4)) + ea_mul24((uint32_t)ps, 12u)));
             const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
             const uint32_t k3 = ea_owner<BPL>((uint32_t)k);
             const uint32_t c = __builtin_amdgcn_ubfe(w0, k3, 1) | (__builtin_amdgcn_ubfe(w1, k3, 1) << 1) | (__builtin_amdgcn_ubfe(w2, k3, 1) << 2);
             codes |= c << (3 * s);
-            off -= ((c & 4u) != 0u ? (uint32_t)CELL : 0u) + (ps != 0 ? (uint32_t)LSTR : 0u);
+            off -= ((c & 4u) != 0u ? (uint32_t)(CELL * 4) : 0u) + (ps != 0 ? (uint32_t)(LSTR * 4) : 0u);
             row -= ps != 0 ? 1 : 0;                                     // K states are silent (r9.cpp:176-178)
             k -= (int)(c >> 2);
             ps = (int)(c & 3u);
             // the walk ends at row 0 or k-mer -1.  (HMT_FROM_SOFT, code 7, is the move out of MATCH of (row 1, k-mer 0) only -- the one
             // cell the sweep offers the soft clip to, ea_fill2 -- and leads to row 0: no test of its own.  A finished walk's row, k and
             // state are not used again.)
-            alive = alive && row > 0 && k >= 0;
+            am &= __builtin_amdgcn_ballot_w64(row > 0) & __builtin_amdgcn_ballot_w64(k >= 0);      // (two ballots: each is its compare's own result register)
         }
-        if (sl == 0 && steps > 0) bl[nb - spilled] = (uint64_t)(first | ((uint32_t)steps << 26)) | ((uint64_t)codes << 32);
-        nb += steps > 0 ? 1 : 0;
+        alive = __builtin_amdgcn_inverse_ballot_w64(am);
+        const uint32_t steps = hi_half ? steps1 : steps0;
+        if (sl == 0 && steps > 0u) bl[nb - spilled] = (uint64_t)(first | (steps << 26)) | ((uint64_t)codes << 32);
+        nb += steps > 0u ? 1 : 0;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);

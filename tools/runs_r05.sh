@@ -190,4 +190,14 @@ except Exception as e: print('$v', 'failed', e)
 done
 }
 
+# chain kernel: parity (event-align suites, the always-spilling variant), then the variants' A/B on this box
+call_u() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r05${TAG:-u}; mkdir -p $O
+( time timeout 900 python -m pytest tests/test_gpu_eventalign_dropin.py tests/test_gpu_chain_spill.py tests/test_gpu_rna.py tests/test_gpu_fuzz.py -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+( timeout 400 python tests/gpu_soak_eventalign.py ) > $O/soak.log 2>&1; echo "soak rc=$?" >> $O/soak.log
+tail -3 $O/pytest.log; tail -2 $O/soak.log
+TAG=${TAG:-u} call_t
+}
+
 "call_$1"
