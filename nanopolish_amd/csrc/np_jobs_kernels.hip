@@ -206,17 +206,28 @@ __global__ void __launch_bounds__(64) np_cm_groups_kernel(int n_reads, const cha
     // reads, bound by exactly that, profiles/r05_pmc.json.)  Per chunk of 64 positions: a match STARTS a group when the previous match
     // (in the chunk, or the open group's last) is more than min_separation behind it; the matches before the chunk's first start extend
     // the group left open by the previous chunks; every start but the last closes its group inside the chunk (its matches: up to the
-    // next start), the last one's stays open.  Each closed group is one lane's: it applies the window rules, and the slot index / k-mer
-    // offset of a kept group is the running count / sum plus a prefix over the kept groups before it (position order, as the reference
-    // emits them, basemods.cpp:306-336).
+    // next start), the last one's stays open.
+    // Closed groups are QUEUED (position order: the carried group, then the chunk's own by lane) and taken 64 at a time, one per lane:
+    // the window rules, then the slot index / k-mer offset of a kept group as the running count / sum plus a prefix over the kept groups
+    // before it (as the reference emits them, basemods.cpp:306-336).  Applying the rules chunk by chunk -- two or three groups, i.e.
+    // lanes, at a time, 85 times per read -- was 85 rounds of the CIGAR searches' dependent loads with nothing else to run: 2.25 ms per
+    // 100 000 reads, all of it that latency.
+    constexpr int QCAP = 256;                                    // (a chunk closes at most 33 groups; the queue is emptied from 64 on)
+    __shared__ int q_first[QCAP], q_last[QCAP], q_cnt[QCAP];
+    int q_head = 0, nq = 0;                                      // wave-uniform
     int ng = 0;
     int64_t w = 0;
     bool overflow = false;
     int o_first = -1, o_last = -1, o_cnt = 0;                    // the open group (wave-uniform)
     const unsigned long long below = (1ull << lane) - 1ull;
-    // one closed group per lane: window rules, then slot and offset by prefix; `mine`: this lane holds a group; g0_lane: the lane that
-    // holds the group closed FIRST in position order although it is not the lowest lane (the carried group), or -1
-    auto emit = [&](bool mine, int first, int last, int cnt, int g0_lane) {
+    // the first m <= 64 queued groups, one per lane
+    auto emit = [&](const int m) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const bool mine = lane < m;
+        const int slot = (q_head + lane) & (QCAP - 1);
+        const int first = mine ? q_first[slot] : 0, last = mine ? q_last[slot] : 0, cnt = mine ? q_cnt[slot] : 0;
+        q_head = (q_head + m) & (QCAP - 1); nq -= m;
         const int sub_start = first - min_flank, sub_end = last + min_flank, span = last - first;
         bool skip = !mine || sub_start <= min_separation || span > 200;                      // basemods.cpp:334
         int q1 = 0, q2 = 0;
@@ -228,17 +239,11 @@ __global__ void __launch_bounds__(64) np_cm_groups_kernel(int n_reads, const cha
         const int nk2 = keep ? 2 * (sub_end - sub_start + 1 - k + 1) : 0;
         const unsigned long long km = __ballot(keep);
         if (km == 0ull) return;
-        // order: the carried group first, then ascending lanes
-        const bool is_g0 = lane == g0_lane;
-        const bool g0_kept = g0_lane >= 0 && ((km >> g0_lane) & 1ull);
-        const int nk2_g0 = g0_lane >= 0 ? __shfl(nk2, g0_lane, 64) : 0;
-        const unsigned long long km_rest = g0_lane >= 0 ? km & ~(1ull << g0_lane) : km;
-        int scan = is_g0 ? 0 : nk2;                                                          // inclusive scan over the lanes (the carried group apart)
+        int scan = nk2;                                                                      // inclusive scan over the lanes
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(scan, o, 64); if (lane >= o) scan += t; }
-        const int total_rest = __shfl(scan, 63, 64);
-        const int idx = is_g0 ? ng : ng + (g0_kept ? 1 : 0) + __popcll(km_rest & below);
-        const int64_t off = is_g0 ? w : w + (g0_kept ? nk2_g0 : 0) + (scan - nk2);
+        const int idx = ng + __popcll(km & below);
+        const int64_t off = w + (scan - nk2);
         const bool fits = idx < cap && off + nk2 <= rank_cap;
         if (keep && fits) {
             first_site[g0 + idx] = first; last_site[g0 + idx] = last; n_motif[g0 + idx] = cnt;
@@ -250,11 +255,10 @@ __global__ void __launch_bounds__(64) np_cm_groups_kernel(int n_reads, const cha
         }
         if (__ballot(keep && !fits) != 0ull) overflow = true;                               // the read comes back n_groups = -1: its slots are void
         ng += __popcll(km);
-        w += (int64_t)total_rest + (g0_kept ? nk2_g0 : 0);
+        w += (int64_t)__shfl(scan, 63, 64);
     };
     const sites_t S = sites_of(alphabet);
-    // (two-base motifs: the next chunk's bytes are requested before this chunk is grouped -- one wave per read, 85 chunks, and the
-    //  stores below keep the compiler from hoisting the loads itself)
+    // (two-base motifs: the next chunk's bytes are requested before this chunk is grouped)
     char nb0 = 0, nb1 = 0;
     if (S.len == 2) { nb0 = lane + 1 < n ? ref[lane] : 0; nb1 = lane + 1 < n ? ref[lane + 1] : 0; }
     for (int base = 0; base + 1 < n; base += 64) {
@@ -284,13 +288,25 @@ __global__ void __launch_bounds__(64) np_cm_groups_kernel(int n_reads, const cha
         const unsigned long long seg = ns == 64 ? bits & ~below : bits & ~below & ((1ull << ns) - 1ull);
         const bool own = start && lane != ls;
         const bool carried = lane == ls && o_cnt > 0;
-        const int g_first = own ? pos : o_first, g_last = own ? base + 63 - __clzll((long long)(seg | 1ull)) : o_last, g_cnt = own ? __popcll(seg) : o_cnt;
-        emit(own || carried, g_first, g_last, g_cnt, o_cnt > 0 ? ls : -1);
+        const int n_carried = o_cnt > 0 ? 1 : 0;
+        const unsigned long long om = sm & ~(1ull << ls);                                     // the lanes with a closed group of their own
+        if (own || carried) {
+            const int slot = (q_head + nq + (carried ? 0 : n_carried + __popcll(om & below))) & (QCAP - 1);
+            q_first[slot] = own ? pos : o_first;
+            q_last[slot] = own ? base + 63 - __clzll((long long)(seg | 1ull)) : o_last;
+            q_cnt[slot] = own ? __popcll(seg) : o_cnt;
+        }
+        nq += n_carried + __popcll(om);
+        if (nq >= 64) emit(64);
         // the last start opens the new group
         const unsigned long long tail = bits & ~((1ull << ls) - 1ull);
         o_first = base + ls; o_last = base + 63 - __clzll((long long)tail); o_cnt = __popcll(tail);
     }
-    emit(lane == 0 && o_cnt > 0, o_first, o_last, o_cnt, -1);
+    if (o_cnt > 0) {
+        if (lane == 0) { const int slot = (q_head + nq) & (QCAP - 1); q_first[slot] = o_first; q_last[slot] = o_last; q_cnt[slot] = o_cnt; }
+        nq += 1;
+    }
+    while (nq > 0) emit(nq < 64 ? nq : 64);
     if (writer) n_groups[r] = overflow ? -1 : ng;
 }
 

@@ -200,4 +200,18 @@ tail -3 $O/pytest.log; tail -2 $O/soak.log
 TAG=${TAG:-u} call_t
 }
 
+# work-item builder check: the suites that pin work items and sites, then the default step's kernels by name
+call_v() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r05${TAG:-v}; mkdir -p $O
+( time timeout 900 python -m pytest tests/test_gpu_jobs.py tests/test_gpu_sites.py tests/test_gpu_edges.py tests/test_gpu_fuzz.py tests/test_gpu_batch_dropin.py tests/test_gpu_long_reads.py -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o p -- python $R/bench.py --steps 3 --warmup 1 --legs 0 --streamed 0 --ragged 0 --cpu-sample 0 > $R/$O/bench.json 2> $R/$O/bench.err )
+python profiles/summarize_rocpd.py $(find $O/prof -name "*_results.db" | head -1) > $O/kernels.txt 2>&1
+tail -4 $O/pytest.log; grep -v "at::native\|rocclr\|probe\|np_align_\|hmm_forward\|np_event_align" $O/kernels.txt | head -12 | cut -c1-160
+python -c "
+import json
+d=json.loads(open('$O/bench.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms_per_step'])
+"
+}
+
 "call_$1"
