@@ -387,8 +387,6 @@ __global__ void __launch_bounds__(256) np_cm_items_kernel(int n_reads, const cha
         // len - i - k, i.e. window characters i+k-1 down to i complemented.  Either way the characters are window positions
         // i .. i+k-1, and methylation looks one position to each side INSIDE the window (Alphabet::methylate of the window).
         uint32_t ru = 0, rm = 0;
-        char prev = i > 0 ? ref[sub_start + i - 1] : 0;
-        char cur = ref[sub_start + i];
         if (alphabet > 2) {
             // dam / dcm: sites of 4 and 5 bases (general form; rare alphabets, no fast path)
             const sites_t S = sites_of(alphabet);
@@ -403,15 +401,33 @@ __global__ void __launch_bounds__(256) np_cm_items_kernel(int n_reads, const cha
         } else {
             // the k-mer's digits and its methylated twin's: a base is replaced when it is the first base of a whole site (next base
             // is the site's second) or the second base of one (previous base is its first), inside the window.
-            // (round 5: the k = 6 case is unrolled at compile time -- the window's eight bytes are then requested together instead of one
-            //  dependent byte load per base: the kernel spent 67 % of its wave-cycles waiting, profiles/r05_pmc.json)
+            // (round 5: the k = 6 case is unrolled at compile time and the eight bytes it looks at -- the base before the k-mer, the
+            //  k-mer, the base after -- come from three aligned dword loads and two byte alignments instead of eight byte loads: the kernel
+            //  spent 67 % of its wave-cycles waiting on them, profiles/r05_pmc.json.  The dwords reach up to 3 bytes before and 10 after
+            //  the k-mer's first base: a k-mer closer than that to the end of the read's sequence takes the byte loads.)
             auto kmer = [&](auto KC) {
                 constexpr int KK = decltype(KC)::value;                // 0: k at run time
                 const int kk = KK ? KK : k;
                 char w_[KK ? KK + 1 : 1];
-                if (KK) {
+                char prev, cur;
+                const char* p0 = ref + sub_start + i - 1;               // (sub_start > min_separation >= 0: never before the sequence)
+                if (KK == 6 && sub_start + i + 10 < n) {
+                    const uintptr_t a = (uintptr_t)p0;
+                    const uint32_t* __restrict__ aw = (const uint32_t*)(a & ~(uintptr_t)3);
+                    const uint32_t d0 = aw[0], d1 = aw[1], d2 = aw[2], sh = (uint32_t)(a & 3u);
+                    const uint32_t lo_ = __builtin_amdgcn_alignbyte(d1, d0, sh), hi_ = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                    prev = i > 0 ? (char)(lo_ & 0xffu) : (char)0;
+                    cur = (char)((lo_ >> 8) & 0xffu);
+                    w_[1 % (KK + 1)] = (char)((lo_ >> 16) & 0xffu); w_[2 % (KK + 1)] = (char)(lo_ >> 24);
+                    w_[3 % (KK + 1)] = (char)(hi_ & 0xffu); w_[4 % (KK + 1)] = (char)((hi_ >> 8) & 0xffu); w_[5 % (KK + 1)] = (char)((hi_ >> 16) & 0xffu);
+                    w_[6 % (KK + 1)] = i + 6 < len ? (char)(hi_ >> 24) : (char)0;
+                } else {
+                    prev = i > 0 ? p0[0] : (char)0;
+                    cur = p0[1];
+                    if (KK) {
 #pragma unroll
-                    for (int q = 0; q < KK; ++q) w_[q + 1] = i + q + 1 < len ? ref[sub_start + i + q + 1] : 0;
+                        for (int q = 0; q < KK; ++q) w_[q + 1] = i + q + 1 < len ? ref[sub_start + i + q + 1] : 0;
+                    }
                 }
                 bool pa = prev == s.a, ca_ = cur == s.a, cb_ = cur == s.b;
                 char c0 = cur;
