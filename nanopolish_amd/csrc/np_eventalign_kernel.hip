@@ -1,5 +1,5 @@
 // np_eventalign_kernel.hip -- the eventalign segment chain on the device: align_read_to_ref
-// (src/alignment/nanopolish_eventalign.cpp:612-826) for a batch of reads, one wavefront per read.
+// (src/alignment/nanopolish_eventalign.cpp:612-826) for a batch of reads, two reads per wavefront.
 //
 // The reference realigns a read to its reference in ~100-base segments.  Every segment is one profile_hmm_align (Viterbi
 // fill + back-track, src/hmm/nanopolish_profile_hmm_r9.cpp:73-204, r9.inl:130-197, flags 0) over the events between the
@@ -8,15 +8,15 @@
 // segment to segment but independent between reads, so a persistent wave walks one read's chain from end to end:
 //   * segment geometry from the read's CIGAR without materialising aligned pairs (np_cigar.h; get_end_pair :196-205 is a
 //     "last aligned pair with ref_pos <= x" search), closest events from the read's event map (np_device.h);
-//   * Viterbi fill as an anti-diagonal sweep: lane j owns k-mer blocks 2j, 2j+1 (a segment has <= 96 k-mers), computes row
-//     t - j at step t; previous row in registers, left neighbour through DPP; six candidates in HMMMovementType order,
-//     later index wins ties; only back-pointers leave the wave: 6 bits per block and row (M: 3, B: 1, K: 2), one byte,
-//     one coalesced 128-byte line per sweep STEP (cell (row r, k-mer b) sits in line r + b / 2 at byte b), into a per-wave
-//     scratch that stays in L2; events reach the lanes by one block load per 64 steps + v_readlane + a DPP shift;
-//   * back-track with a wave-uniform (scalar) state over 32 lines at a time staged in LDS, every visited state appended
-//     to a per-wave path list (64 entries per coalesced flush); then the wave reads the tail of the list back and emits
-//     it 64 entries at a time (ballot + prefix count reproduces the reference's "first 50 that are not K and not the
-//     start event" cut).
+//   * Viterbi fill as an anti-diagonal sweep, two segments (of two reads) per wave, one per half-wave: lane j of a half owns three
+//     k-mer blocks (a segment has <= 96 k-mers; four for the k = 5 model), computes row t - j at step t; previous row in registers,
+//     left neighbour through DPP; candidates in HMMMovementType order, later index wins ties; only back-pointers leave the wave, as
+//     64-bit lane masks (six planes per block: the compares' own result registers) written by scalar stores, one line per sweep STEP
+//     (cell (row r, k-mer b) sits in line r + b / BPL), into a per-wave scratch that stays in L2 (ea_fill2);
+//   * back-track of both halves' segments as vector code over a window of lines staged -- and expanded to per-state move codes -- in LDS,
+//     in bursts of steps whose number is known in advance; the visited states go to a per-half list, one 64-bit word per burst
+//     (ea_walk2); then a lane per burst replays it and emits (ballots + prefix counts reproduce the reference's "first 50 that are not K
+//     and not the start event" cut, ea_emit_segment).
 // Output rows are (ref_position relative to the record's pos, event_idx, state 'M'/'B'); ref_kmer / model_kmer of the TSV
 // follow from them on the host (nanopolish_amd/eventalign.py).
 #include "np_kernels.h"
