@@ -64,6 +64,21 @@ if d:
         o.append("| eventalign leg | %.0f reads/s, %.1f ms per 50 000 reads, chain kernel %.1f ms, roofline frac %.4f (traffic %.1f GB), issue %s / %s, cpu %s |" % (
             ea["value"], ea["ms_per_step"], ea["kernel_ms_per_step"]["eventalign_chain"], er["frac"], (er.get("traffic") or 0) / 1e9,
             (er.get("issue") or {}).get("valu_issue_floor"), (er.get("issue") or {}).get("valu_issue_priced"), json.dumps(ea.get("cpu_baseline"))))
+        # the line's `traffic` / `issue` are look-ups into the counter summary committed WHEN THE LINE WAS PRINTED; recomputed here from the committed one
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import pmc_lookup
+            segs = ea.get("hmm_align_calls_per_step")
+            cyc = ea["kernel_ms_per_step"]["eventalign_chain"] * 1e-3 * 2.4e9 * 1024 / segs
+            iss = pmc_lookup.issue("chain", "segment", cyc)
+            if iss and abs(iss["valu_per_unit"] - ((er.get("issue") or {}).get("valu_per_unit") or 0)) > 1:
+                o.append("| (eventalign leg, counters as committed) | the line above was printed with the counter summary collected BEFORE this round's chain-kernel "
+                         "work (%.0f vector instructions per segment); with `r05_pmc.json` as committed (%.0f per segment, counted on the final code): traffic %.1f GB, "
+                         "issue %s / %s, roofline_issue %.3f |" % ((er.get("issue") or {}).get("valu_per_unit") or 0, iss["valu_per_unit"],
+                                                                   pmc_lookup.traffic("chain", "segment", segs) / 1e9, iss["valu_issue_floor"], iss.get("valu_issue_priced"),
+                                                                   pmc_lookup.roofline_issue("chain", "segment", cyc)["frac"]))
+        except Exception as e:  # noqa: BLE001
+            o.append("| (eventalign leg, counters as committed) | not recomputed: %r |" % (e,))
     if "value" in va:
         vr = va["roofline"]
         o.append("| variants leg | %.0f calls/s, %.1f ms per step, roofline frac %.4f (traffic %.1f GB), issue %s / %s, cpu %s |" % (
