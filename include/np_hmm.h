@@ -78,7 +78,8 @@ const char* np_ctx_info(const np_ctx* ctx);
  * repair path -- results never depend on it), "ea_rows_cap" (events per eventalign segment the chain kernel's scratch holds;
  * a longer segment ends its read with NP_EA_OVERFLOW), "ea_waves_per_cu" (persistent grid of the chain kernel), "lse_oor" (0: the forward kernel clamps its log-sum table index;
  * 1: it relies on the LDS out-of-range rule, the default when np_create's probe passes and refused (NP_ERR_UNSUPPORTED) when it did not --
- * scores never depend on it). */
+ * scores never depend on it), "adc_check_fused" (1, the default: np_adc_to_pa_dev also takes the detector's exactness verdicts, see there;
+ * 0: np_detect_events_dev always makes its own pass -- events never depend on it). */
 int np_set_option(np_ctx* ctx, const char* name, int64_t value);
 /* Read-only facts about the context (-1: unknown name): "align_blocks" / "align_scratch_bytes" (persistent grid and per-wave scratch
  * of the most recent event-align launch: the grid shrinks under a 48 GB scratch budget when a batch holds ultra-long reads),
@@ -413,7 +414,11 @@ void np_event_detection_params(np_detector_param* p, int rna);
 /* The signal loaders' conversion of ADC counts to pA, in front of detect_events:
  *     rawptr[i] = ((float)raw_signal[i] + offset) * raw_unit,   raw_unit = range / digitisation  (all fp32)
  * (src/io/nanopolish_fast5_loader.cpp:96-103, src/io/nanopolish_fast5_io.cpp:163-165).  A host-fed batch then uploads int16
- * samples, half the bytes.  adc: int16[total samples]; offset / raw_unit: float[n_reads]; raw_pa: float[total samples] out. */
+ * samples, half the bytes.  adc: int16[total samples]; offset / raw_unit: float[n_reads]; raw_pa: float[total samples] out.
+ * The conversion also takes np_detect_events_dev's exactness verdict of every read from the values on their way out (one pass over the
+ * samples instead of two): a np_detect_events_dev call on exactly this (raw_pa, raw_off, n_reads) -- the context's next one -- uses it.  A
+ * caller that CHANGES the converted samples between the two calls turns that off: np_set_option(ctx, "adc_check_fused", 0) (or
+ * NP_ADC_CHECK_FUSED=0 in the environment at np_create). */
 int np_adc_to_pa_dev(np_ctx* ctx, void* stream, int n_reads, const int16_t* adc, const int64_t* raw_off, int64_t max_samples,
                      const float* offset, const float* raw_unit, float* raw_pa);
 

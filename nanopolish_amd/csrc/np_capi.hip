@@ -78,6 +78,11 @@ struct np_ctx {
     dev_buf b_jobs, b_reads, b_events, b_ranks, b_out, b_pair_off, b_pairs, b_pair_begin, b_n_pairs,
             b_vm, b_bp, b_cell_off, b_state_off, b_states, b_n_states;
     dev_buf ed_status, ed_tstat;      // event detection scratch
+    // np_adc_to_pa_dev also proves the detector's exactness bound for the samples it writes (one pass instead of two); the verdicts in ed_status
+    // belong to exactly this conversion -- np_detect_events_dev on the same (raw, raw_off, n_reads) takes them, once, instead of its own check pass
+    int adc_check_fused = 1;
+    const void *adc_checked_raw = nullptr, *adc_checked_off = nullptr;
+    int adc_checked_n = 0;
     dev_buf cm_group_rank_off, cm_cigar_scratch;        // work-item generation scratch
     dev_buf ea_bp, ea_path, ea_args;                    // eventalign chain: per-wave back-pointer rows and path lists; a device copy of the launch arguments
     int ea_rows_cap = 4096, ea_waves_per_cu = 20;
@@ -407,6 +412,7 @@ np_ctx* np_create(int device, const np_params* params)
     if (const char* v = getenv("NP_HMM_BLOCKS_PER_CU")) c->hmm_blocks_per_cu = std::max(1, atoi(v));
     if (const char* v = getenv("NP_ALIGN_LPT")) c->align_lpt = atoi(v) != 0;
     if (const char* v = getenv("NP_RECAL_SHAPE")) c->recal_shape = std::max(0, std::min(2, atoi(v)));
+    if (const char* v = getenv("NP_ADC_CHECK_FUSED")) c->adc_check_fused = atoi(v) != 0;
     if (const char* v = getenv("NP_ED_WARMUP")) c->ed_warmup = atoi(v);
     if (const char* v = getenv("NP_EA_WAVES_PER_CU")) c->ea_waves_per_cu = std::max(1, atoi(v));
     if (const char* v = getenv("NP_EA_WALK_PRIO")) c->ea_walk_prio = atoi(v);
@@ -744,8 +750,15 @@ int np_adc_to_pa_dev(np_ctx* c, void* stream, int n_reads, const int16_t* adc, c
     std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
     stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
+    int32_t* status = nullptr;
+    c->adc_checked_raw = c->adc_checked_off = nullptr; c->adc_checked_n = 0;
+    if (c->adc_check_fused && n_reads > 0 && max_samples > 0) {
+        NP_HIP(c, c->ed_status.reserve((size_t)n_reads * sizeof(int32_t)));
+        status = c->ed_status.as<int32_t>();
+    }
     family_timer tm(c, 4, s);
-    NP_HIP(c, np_launch_adc_to_pa(n_reads, adc, raw_off, max_samples, offset, raw_unit, raw_pa, s));
+    NP_HIP(c, np_launch_adc_to_pa(n_reads, adc, raw_off, max_samples, offset, raw_unit, raw_pa, status, s));
+    if (status) { c->adc_checked_raw = raw_pa; c->adc_checked_off = raw_off; c->adc_checked_n = n_reads; }
     return NP_OK;
 }
 
@@ -1325,6 +1338,7 @@ int np_set_option(np_ctx* c, const char* name, int64_t value)
     else if (k == "hmm_prio") c->hmm_prio = (int)std::min<int64_t>(2, std::max<int64_t>(0, value));
     else if (k == "hmm_blocks_per_cu") c->hmm_blocks_per_cu = (int)std::max<int64_t>(1, value);
     else if (k == "align_lpt") c->align_lpt = value != 0;
+    else if (k == "adc_check_fused") c->adc_check_fused = value != 0;
     else if (k == "recal_shape") c->recal_shape = (int)std::min<int64_t>(2, std::max<int64_t>(0, value));
     else if (k == "stream_switch_wait") c->stream_switch_wait = value != 0;
     else if (k == "small_batch_path") c->small_batch_path = value != 0;
@@ -1363,9 +1377,12 @@ static int detect_events_locked(np_ctx* c, hipStream_t s, int n_reads, const flo
         NP_HIP(c, c->ed_tstat.reserve((size_t)total_samples_hint * sizeof(float2) + 64));
         tstat = c->ed_tstat.as<float>();
     }
+    // (the verdicts of the conversion that wrote exactly these samples, if that was this context's last conversion; taken once)
+    const bool checked = c->adc_check_fused && n_reads > 0 && raw == c->adc_checked_raw && raw_off == c->adc_checked_off && n_reads == c->adc_checked_n;
+    c->adc_checked_raw = c->adc_checked_off = nullptr; c->adc_checked_n = 0;
     family_timer tm(c, 4, s);
     NP_HIP(c, np_launch_detect_events(n_reads, raw, raw_off, max_samples, p, (float2*)tstat, c->ed_status.as<int32_t>(), event_off,
-                                      max_events, event_start, event_length, event_mean, event_stdv, n_events, c->ed_warmup, s));
+                                      max_events, event_start, event_length, event_mean, event_stdv, n_events, c->ed_warmup, checked, s));
     return NP_OK;
 }
 

@@ -88,35 +88,23 @@ __global__ void __launch_bounds__(256) np_adc_to_pa_kernel(int n_reads, const in
 // ---------------------------------------------------------------------------------------------------------------
 // exactness bound of the prefix sums, one block per read
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) np_ed_check_kernel(int n_reads, const float* __restrict__ raw, const int64_t* __restrict__ raw_off,
-                                                           int32_t* __restrict__ status)
-{
-    const int r = blockIdx.x;
-    if (r >= n_reads) return;
-    const float* x = raw + raw_off[r];
-    const int64_t n = raw_off[r + 1] - raw_off[r];
-    // bit patterns of non-negative floats order like the floats; inf/nan patterns (>= 0x7f800000) end up in the maximum
-    uint32_t amax = 0u, amin = 0xffffffffu, qmax = 0u, qmin = 0xffffffffu;
-    auto take = [&](float v) {
+// bit patterns of non-negative floats order like the floats; inf/nan patterns (>= 0x7f800000) end up in the maximum
+struct ed_range {
+    uint32_t amax = 0u, amin = 0xffffffffu, qmax = 0u, qmin = 0xffffffffu;      // |x| and x^2 (fp32): largest, smallest non-zero
+    __device__ __forceinline__ void take(float v)
+    {
         const float q = v * v;
         const uint32_t a = __builtin_bit_cast(uint32_t, v) & 0x7fffffffu, b = __builtin_bit_cast(uint32_t, q);
         amax = a > amax ? a : amax; qmax = b > qmax ? b : qmax;
         if (a != 0u) amin = a < amin ? a : amin;
         if (b != 0u) qmin = b < qmin ? b : qmin;
-    };
-    // 16-byte loads from the 16-byte boundary at or below the read's first sample (round 5: 4-byte loads ran at 3.5 TB/s); the up to
-    // three samples before the read and after it are skipped, not read
-    const int mis = (int)((((uintptr_t)x) & 15u) >> 2);
-    for (int64_t g = -(int64_t)mis + 4 * (int64_t)threadIdx.x; g < n; g += 1024) {
-        if (g >= 0 && g + 4 <= n) {
-            const float4 v = *reinterpret_cast<const float4*>(x + g);
-            take(v.x); take(v.y); take(v.z); take(v.w);
-        } else {
-            for (int t = 0; t < 4; ++t) if (g + t >= 0 && g + t < n) take(x[g + t]);
-        }
     }
+};
+// the block's ranges combined, and read r's verdict (256 threads)
+__device__ __forceinline__ void ed_check_finish(const ed_range& R, const int64_t n, const int r, int32_t* __restrict__ status)
+{
     __shared__ uint32_t red[4][256];
-    red[0][threadIdx.x] = amax; red[1][threadIdx.x] = amin; red[2][threadIdx.x] = qmax; red[3][threadIdx.x] = qmin;
+    red[0][threadIdx.x] = R.amax; red[1][threadIdx.x] = R.amin; red[2][threadIdx.x] = R.qmax; red[3][threadIdx.x] = R.qmin;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {
@@ -142,6 +130,58 @@ __global__ void __launch_bounds__(256) np_ed_check_kernel(int n_reads, const flo
         // the reference's additions one by one; NP_ED_INEXACT: a non-finite sample (the reference's own result is undefined)
         status[r] = bad ? NP_ED_INEXACT : (ok ? 0 : NP_ED_SERIAL);
     }
+}
+
+__global__ void __launch_bounds__(256) np_ed_check_kernel(int n_reads, const float* __restrict__ raw, const int64_t* __restrict__ raw_off,
+                                                           int32_t* __restrict__ status)
+{
+    const int r = blockIdx.x;
+    if (r >= n_reads) return;
+    const float* x = raw + raw_off[r];
+    const int64_t n = raw_off[r + 1] - raw_off[r];
+    ed_range R;
+    // 16-byte loads from the 16-byte boundary at or below the read's first sample (round 5: 4-byte loads ran at 3.5 TB/s); the up to
+    // three samples before the read and after it are skipped, not read
+    const int mis = (int)((((uintptr_t)x) & 15u) >> 2);
+    for (int64_t g = -(int64_t)mis + 4 * (int64_t)threadIdx.x; g < n; g += 1024) {
+        if (g >= 0 && g + 4 <= n) {
+            const float4 v = *reinterpret_cast<const float4*>(x + g);
+            R.take(v.x); R.take(v.y); R.take(v.z); R.take(v.w);
+        } else {
+            for (int t = 0; t < 4; ++t) if (g + t >= 0 && g + t < n) R.take(x[g + t]);
+        }
+    }
+    ed_check_finish(R, n, r, status);
+}
+
+// ADC counts -> pA AND the exactness bound of the samples written, one block per read (round 5): np_adc_to_pa_kernel followed by
+// np_ed_check_kernel moved 6 + 4 bytes per sample, this one moves 6 -- the check looks at the values on their way out.  Groups of four
+// samples from the first position of the read that is a multiple of four in the batch arrays (8-byte loads, 16-byte stores, aligned).
+__global__ void __launch_bounds__(256) np_adc_to_pa_check_kernel(int n_reads, const int16_t* __restrict__ adc, const int64_t* __restrict__ raw_off,
+                                                                  const float* __restrict__ offset, const float* __restrict__ raw_unit,
+                                                                  float* __restrict__ raw_pa, int32_t* __restrict__ status)
+{
+    const int r = blockIdx.x;
+    if (r >= n_reads) return;
+    const int64_t n = raw_off[r + 1] - raw_off[r];
+    const float off = offset[r], unit = raw_unit[r];
+    const int16_t* in = adc + raw_off[r];
+    float* out = raw_pa + raw_off[r];
+    ed_range R;
+    const int64_t head = (int64_t)((4 - (raw_off[r] & 3)) & 3) < n ? (int64_t)((4 - (raw_off[r] & 3)) & 3) : n;      // samples before the first aligned group
+    const int64_t groups = (n - head) / 4;
+    for (int64_t j = threadIdx.x; j < groups; j += 256) {
+        const int64_t i = head + 4 * j;
+        const short4 v = *reinterpret_cast<const short4*>(in + i);
+        float4 o;
+        o.x = ((float)v.x + off) * unit; o.y = ((float)v.y + off) * unit; o.z = ((float)v.z + off) * unit; o.w = ((float)v.w + off) * unit;
+        *reinterpret_cast<float4*>(out + i) = o;
+        R.take(o.x); R.take(o.y); R.take(o.z); R.take(o.w);
+    }
+    // what the groups do not cover: up to three samples before the first and after the last
+    for (int64_t i = threadIdx.x; i < head; i += 256) { const float o = ((float)in[i] + off) * unit; out[i] = o; R.take(o); }
+    for (int64_t i = head + 4 * groups + threadIdx.x; i < n; i += 256) { const float o = ((float)in[i] + off) * unit; out[i] = o; R.take(o); }
+    ed_check_finish(R, n, r, status);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -887,9 +927,13 @@ __global__ void __launch_bounds__(64 * NP_MOM_W) np_mom_fill_kernel(int n_reads,
 } // namespace
 
 hipError_t np_launch_adc_to_pa(int n_reads, const int16_t* adc, const int64_t* raw_off, int64_t max_samples, const float* offset,
-                               const float* raw_unit, float* raw_pa, hipStream_t s)
+                               const float* raw_unit, float* raw_pa, int32_t* status /* not NULL: also the detector's exactness verdict per read */, hipStream_t s)
 {
     if (n_reads <= 0 || max_samples <= 0) return hipSuccess;
+    if (status) {
+        hipLaunchKernelGGL(np_adc_to_pa_check_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, adc, raw_off, offset, raw_unit, raw_pa, status);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(np_adc_to_pa_kernel, dim3(n_reads, (unsigned)((max_samples + 1023) / 1024)), dim3(256), 0, s, n_reads, adc, raw_off,
                        offset, raw_unit, raw_pa);
     return hipGetLastError();
@@ -897,10 +941,10 @@ hipError_t np_launch_adc_to_pa(int n_reads, const int16_t* adc, const int64_t* r
 
 hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t* raw_off, int64_t max_samples, const np_detector_param& p,
                                    float2* tstat, int32_t* status, const int64_t* event_off, int64_t max_events, uint32_t* event_start,
-                                   float* event_length, float* event_mean, float* event_stdv, int32_t* n_events, int warmup, hipStream_t s)
+                                   float* event_length, float* event_mean, float* event_stdv, int32_t* n_events, int warmup, bool checked, hipStream_t s)
 {
     if (n_reads <= 0) return hipSuccess;
-    hipLaunchKernelGGL(np_ed_check_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, raw, raw_off, status);
+    if (!checked) hipLaunchKernelGGL(np_ed_check_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, raw, raw_off, status);
     const unsigned tiles = (unsigned)((max_samples + NP_ED_TILE - 1) / NP_ED_TILE);
     // reads of NP_ED_PAR_MIN samples and more compute their t-statistics inside the peak walk when the windows are the DNA
     // defaults (3 and 6 samples); other window lengths (RNA: 7 and 14) and short reads go through the t-statistic array

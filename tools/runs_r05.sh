@@ -214,4 +214,34 @@ d=json.loads(open('$O/bench.json').read().strip().splitlines()[-1]); print(d['va
 "
 }
 
+# soak on the round's final code: new seeds through the whole chain against the reference itself, then 512 full-size reads of eventalign rows
+call_w() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r05${TAG:-soak2}; mkdir -p $O
+for seed in ${SEEDS:-1 31 32 33}; do ( timeout 300 python tests/gpu_soak.py --seed $seed ) >> $O/soak.log 2>&1; done
+( timeout 400 python tests/gpu_soak_eventalign.py 512 ) > $O/soak_ea.log 2>&1; echo "soak_ea rc=$?" >> $O/soak_ea.log
+( NP_EA_WALK_PRIO=1 timeout 300 python bench.py --workload eventalign --steps 3 --warmup 1 --cpu-sample 0 ) > $O/ea_prio.json 2> $O/ea_prio.err
+( timeout 300 python bench.py --workload eventalign --steps 3 --warmup 1 --cpu-sample 0 ) > $O/ea_noprio.json 2> $O/ea_noprio.err
+grep "^{" $O/soak.log | cut -c1-230; tail -2 $O/soak_ea.log
+python -c "
+import json
+for n in ('ea_prio','ea_noprio'):
+    d=json.loads([l for l in open('$O/%s.json' % n) if l.startswith('{')][-1]); print(n, d['value'], d['kernel_ms_per_step']['eventalign_chain'])
+"
+}
+
+# detector check: the event suites and the binding (int16 in), then the from-raw step's kernels by name
+call_x() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r05${TAG:-x}; mkdir -p $O
+( time timeout 900 python -m pytest tests/test_gpu_events.py tests/test_gpu_batch_dropin.py tests/test_gpu_rna.py tests/test_gpu_eventalign_dropin.py -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o p -- python $R/bench.py --from-raw 1 --pool 4000 --tile 25 --steps 3 --warmup 1 --legs 0 --streamed 0 --ragged 0 --cpu-sample 64 > $R/$O/bench_raw.json 2> $R/$O/bench_raw.err )
+python profiles/summarize_rocpd.py $(find $O/prof -name "*_results.db" | head -1) > $O/kernels.txt 2>&1
+tail -12 $O/pytest.log; grep "np_ed_\|adc_to_pa\|mom_fill" $O/kernels.txt | cut -c1-150
+python -c "
+import json
+d=json.loads(open('$O/bench_raw.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms_per_step'], d['cpu_baseline'].get('whole_function') or d['cpu_baseline'].get('check'))
+"
+}
+
 "call_$1"
