@@ -713,14 +713,25 @@ __global__ void __launch_bounds__(256) np_ed_events_kernel(int n_reads, const fl
         start = es[e];
         end = e + 1 < n_ev ? (int64_t)es[e + 1] : n;
     };
+    // (round 5, second pass: a thread's events of the round -- e0 + thread + 256 k, k < NP_EV_PER -- have their bounds requested BEFORE the
+    //  window is staged and kept in registers for the probe and for the sums: one round trip to memory per round instead of three; a round
+    //  takes at most 256 NP_EV_PER events)
+    constexpr int NP_EV_PER = 6;
     int e0 = 0;
     while (e0 < n_ev) {
         int64_t st0, en0;
         bounds(e0, st0, en0);
+        uint32_t b_st[NP_EV_PER], b_en[NP_EV_PER];
+#pragma unroll
+        for (int k = 0; k < NP_EV_PER; ++k) {
+            const int e = e0 + (int)threadIdx.x + 256 * k;
+            b_st[k] = e < n_ev ? es[e] : 0u;
+            b_en[k] = e + 1 < n_ev ? es[e + 1] : (uint32_t)n;
+        }
         const int64_t w0 = st0 < en0 ? st0 : en0;                       // the window starts at the first unprocessed event ...
         const int mis = (int)((((uintptr_t)(x + w0)) & 15u) >> 2);      // ... moved down to a 16-byte boundary of the batch's sample array
         const int64_t wa = w0 - mis, wend = wa + NP_EV_WIN;             // window = samples [wa, wend) of the read (wa may be -1 .. -3 for its first event)
-        if (threadIdx.x == 0) s_bound = n_ev;
+        if (threadIdx.x == 0) s_bound = n_ev < e0 + 256 * NP_EV_PER ? n_ev : e0 + 256 * NP_EV_PER;
         for (int i4 = threadIdx.x; i4 < NP_EV_WIN / 4; i4 += 256) {
             const int64_t g = wa + 4 * (int64_t)i4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -735,17 +746,21 @@ __global__ void __launch_bounds__(256) np_ed_events_kernel(int n_reads, const fl
         }
         __syncthreads();
         // how many events from e0 on lie inside the window: every thread probes its own events until one does not fit
-        for (int e = e0 + (int)threadIdx.x; e < n_ev; e += 256) {
-            int64_t st, en;
-            bounds(e, st, en);
+#pragma unroll
+        for (int k = 0; k < NP_EV_PER; ++k) {
+            const int e = e0 + (int)threadIdx.x + 256 * k;
+            if (e >= n_ev) break;
+            const int64_t st = b_st[k], en = b_en[k];
             const int64_t lo = st < en ? st : en, hi = st < en ? en : st;
             if (lo < wa || hi > wend) { atomicMin(&s_bound, e); break; }
         }
         __syncthreads();
         const int e1 = s_bound;
-        for (int e = e0 + (int)threadIdx.x; e < e1; e += 256) {
-            int64_t st, en;
-            bounds(e, st, en);
+#pragma unroll
+        for (int k = 0; k < NP_EV_PER; ++k) {
+            const int e = e0 + (int)threadIdx.x + 256 * k;
+            if (e >= e1) break;
+            const int64_t st = b_st[k], en = b_en[k];
             const int64_t lo = st < en ? st : en, hi = st < en ? en : st;
             double s = 0.0, q = 0.0;
             for (int i = (int)(lo - wa); i < (int)(hi - wa); ++i) { const float v = win[i]; s += (double)v; q += (double)(v * v); }
