@@ -680,7 +680,9 @@ __global__ void __launch_bounds__(64, 3) np_ed_peaks_par_kernel(int n_reads, con
 // own until one does not fit, the block's minimum is the bound), and every thread sums its events out of LDS; an event that fits no
 // window -- longer than the window, or one of the rare inverted pairs of peaks -- is summed from memory by one thread, as before.
 // Same additions (every one exact: np_ed_check_kernel), same roundings: event tables bit-identical (tests/test_gpu_events.py).
+#ifndef NP_EV_WIN
 #define NP_EV_WIN 6144
+#endif
 __device__ __forceinline__ void ed_event_finish(double s, double q, int64_t start, int64_t end, float* __restrict__ event_length,
                                                 float* __restrict__ event_mean, float* __restrict__ event_stdv, int64_t slot)
 {

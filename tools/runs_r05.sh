@@ -244,4 +244,20 @@ d=json.loads(open('$O/bench_raw.json').read().strip().splitlines()[-1]); print(d
 "
 }
 
+# from-raw step with library variants (NP_HIP_LIB): the detector family's time for each
+call_y() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r05${TAG:-y}; mkdir -p $O
+for v in default ${VARIANTS:-evwin3072 evwin4096 evwin9216 evwin12288}; do
+  L=""; [ $v != default ] && L=$PWD/nanopolish_amd/variants/libnp_hip_$v.so
+  ( NP_HIP_LIB=$L timeout 300 python bench.py --from-raw 1 --pool 2000 --tile 50 --steps 3 --warmup 1 --legs 0 --streamed 0 --ragged 0 --cpu-sample 0 ) > $O/$v.json 2> $O/$v.err
+  python -c "
+import json
+try:
+    d=json.loads([l for l in open('$O/$v.json') if l.startswith('{')][-1]); print('$v', d['value'], d['roofline']['kernel_ms_per_step'])
+except Exception as e: print('$v', 'failed', e)
+"
+done
+}
+
 "call_$1"
