@@ -839,6 +839,9 @@ __global__ void __launch_bounds__(64) np_ed_serial_events_kernel(int n_reads, co
 #define NP_MOM_R 4
 #define NP_MOM_W 4
 #define NP_MOM_STATES 4096
+#ifndef NP_MOM_D
+#define NP_MOM_D 4                       // chunks of 64 terms requested ahead
+#endif
 __global__ void __launch_bounds__(64 * NP_MOM_W) np_mom_fill_kernel(int n_reads, np_read_dev* __restrict__ reads, np_read_dev* __restrict__ reads_b,
                                                                     const float* __restrict__ event_mean, const int32_t* __restrict__ n_events,
                                                                     const uint16_t* __restrict__ ranks, const np_state_dev* __restrict__ model, int n_states)
@@ -871,33 +874,76 @@ __global__ void __launch_bounds__(64 * NP_MOM_W) np_mom_fill_kernel(int n_reads,
     // serial-phase roles: one sum per read (passes 1 and 3): lane q < R owns read q; two sums per read (pass 2): lane 2 q + c
     const int r1 = lane < R ? lane : 0, r2 = lane < 2 * R ? lane >> 1 : 0, c2 = lane & 1;
     auto fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    // (round 5, second pass: the terms of the NEXT NP_MOM_D chunks are requested before the current ones are summed.  Chunk by chunk -- load,
+    //  wait, stage, sum -- every one of a read's ~335 chunks exposed a full round trip to memory with four or eight lanes busy: 81 % of the
+    //  wave-cycles waiting, 7.4 ms per 100 000 reads for 0.3 ms of additions.)
+    constexpr int D = NP_MOM_D;
+    auto load_events = [&](const int base, float (&dst)[D][R]) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int i = base + 64 * d + lane;
+#pragma unroll
+            for (int q = 0; q < R; ++q) dst[d][q] = i < ne[q] ? ev[q][i] : 0.0f;
+        }
+    };
+    float cur[D][R], nxt[D][R];
     double acc = 0.0;
     // pass 1: event_level_sum
-    for (int base = 0; base < max_ne; base += 64) {
-        const int i = base + lane;
+    load_events(0, cur);
+    for (int base = 0; base < max_ne; base += 64 * D) {
+        load_events(base + 64 * D, nxt);
 #pragma unroll
-        for (int q = 0; q < R; ++q) terms[q][0][lane] = i < ne[q] ? (double)ev[q][i] : 0.0;
-        fence();
-        if (lane < R) { const double* row = terms[r1][0]; 
+        for (int d = 0; d < D; ++d) {
+            if (base + 64 * d >= max_ne) break;
+#pragma unroll
+            for (int q = 0; q < R; ++q) terms[q][0][lane] = (double)cur[d][q];         // (past a read's end: 0.0f, the zero term)
+            fence();
+            if (lane < R) { const double* row = terms[r1][0];
 #pragma unroll 16
-            for (int t = 0; t < 64; ++t) acc += row[t]; }
-        fence();
+                for (int t = 0; t < 64; ++t) acc += row[t]; }
+            fence();
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int q = 0; q < R; ++q) cur[d][q] = nxt[d][q];
     }
     const double event_level_sum = acc;                 // lane q < R: read q's
     // pass 2: kmer_level_sum, kmer_level_sq_sum (pow(l, 2) == l * l)
     acc = 0.0;
-    for (int base = 0; base < max_K; base += 64) {
-        const int i = base + lane;
+    auto load_ranks = [&](const int base, uint32_t (&dst)[D][R]) {
 #pragma unroll
-        for (int q = 0; q < R; ++q) {
-            const double l = i < K[q] ? (table ? level[rk[q][i]] : model[rk[q][i]].level_mean) : 0.0;
-            terms[q][0][lane] = l; terms[q][1][lane] = l * l;
+        for (int d = 0; d < D; ++d) {
+            const int i = base + 64 * d + lane;
+#pragma unroll
+            for (int q = 0; q < R; ++q) dst[d][q] = i < K[q] ? (uint32_t)rk[q][i] : 0xffffffffu;
         }
-        fence();
-        if (lane < 2 * R) { const double* row = terms[r2][c2];
+    };
+    {
+        uint32_t rc[D][R], rn[D][R];
+        load_ranks(0, rc);
+        for (int base = 0; base < max_K; base += 64 * D) {
+            load_ranks(base + 64 * D, rn);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (base + 64 * d >= max_K) break;
+#pragma unroll
+                for (int q = 0; q < R; ++q) {
+                    const uint32_t rank = rc[d][q];
+                    const double l = rank != 0xffffffffu ? (table ? level[rank] : model[rank].level_mean) : 0.0;
+                    terms[q][0][lane] = l; terms[q][1][lane] = l * l;
+                }
+                fence();
+                if (lane < 2 * R) { const double* row = terms[r2][c2];
 #pragma unroll 16
-            for (int t = 0; t < 64; ++t) acc += row[t]; }
-        fence();
+                    for (int t = 0; t < 64; ++t) acc += row[t]; }
+                fence();
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int q = 0; q < R; ++q) rc[d][q] = rn[d][q];
+        }
     }
     // read q's two sums sit in lanes 2 q and 2 q + 1: bring them to lane q
     const double kmer_level_sum = __shfl(acc, 2 * r1, 64), kmer_level_sq_sum = __shfl(acc, 2 * r1 + 1, 64);
@@ -909,19 +955,29 @@ __global__ void __launch_bounds__(64 * NP_MOM_W) np_mom_fill_kernel(int n_reads,
 #pragma unroll
     for (int q = 0; q < R; ++q) shift_q[q] = dbl_readlane(shift, q);
     acc = 0.0;
-    for (int base = 0; base < max_ne; base += 64) {
-        const int i = base + lane;
+    load_events(0, cur);
+    for (int base = 0; base < max_ne; base += 64 * D) {
+        load_events(base + 64 * D, nxt);
 #pragma unroll
-        for (int q = 0; q < R; ++q) {
-            double t = 0.0;
-            if (i < ne[q]) { const double dlt = (double)ev[q][i] - shift_q[q]; t = dlt * dlt; }
-            terms[q][0][lane] = t;
-        }
-        fence();
-        if (lane < R) { const double* row = terms[r1][0];
+        for (int d = 0; d < D; ++d) {
+            if (base + 64 * d >= max_ne) break;
+            const int i = base + 64 * d + lane;
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                double t = 0.0;
+                if (i < ne[q]) { const double dlt = (double)cur[d][q] - shift_q[q]; t = dlt * dlt; }
+                terms[q][0][lane] = t;
+            }
+            fence();
+            if (lane < R) { const double* row = terms[r1][0];
 #pragma unroll 16
-            for (int t = 0; t < 64; ++t) acc += row[t]; }
-        fence();
+                for (int t = 0; t < 64; ++t) acc += row[t]; }
+            fence();
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int q = 0; q < R; ++q) cur[d][q] = nxt[d][q];
     }
     const double event_level_sq_sum = acc;
     if (lane < R && my < n_reads) {
