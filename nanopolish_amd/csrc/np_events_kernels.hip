@@ -836,8 +836,12 @@ __global__ void __launch_bounds__(64) np_ed_serial_events_kernel(int n_reads, co
 // (That alone made the kernel SLOWER, 8.5 -> 9.5 ms, as it had the recalibration: the second pass looks level_mean up per k-mer, 64 random
 //  128-byte lines per wave instruction out of a table that does not fit the L1.  So the workgroup -- NP_MOM_W waves -- keeps the base
 //  model's level_mean in LDS: 32 KB for the 4 096 states of a 6-mer model; a larger model is read from memory.)
+#ifndef NP_MOM_R
 #define NP_MOM_R 4
+#endif
+#ifndef NP_MOM_W
 #define NP_MOM_W 4
+#endif
 #define NP_MOM_STATES 4096
 #ifndef NP_MOM_D
 #define NP_MOM_D 4                       // chunks of 64 terms requested ahead
