@@ -242,3 +242,22 @@ def test_align_kernel_isa_guard_accepts_the_shipped_build_and_rejects_a_spilling
         assert (r.returncode == 0) == want_ok, r.stderr[-600:]
         if not want_ok:
             assert "may still be in flight" in r.stderr
+
+
+def test_every_option_and_environment_switch_of_the_library_is_documented():
+    """np_set_option's names against include/np_hmm.h, and every NP_* variable the library or the shims read against the header and
+    INTEGRATION.md / DESIGN.md / README.md: a knob a maintainer can trip over has a sentence somewhere."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "nanopolish_amd", "csrc", "np_capi.hip")).read()
+    hdr = open(os.path.join(root, "include", "np_hmm.h")).read()
+    opts = re.findall(r'k == "([a-z_0-9]+)"\) c->', src)
+    assert len(opts) >= 10
+    assert [o for o in opts if '"%s"' % o not in hdr] == []
+    envs = set()
+    for f in sum((glob.glob(os.path.join(root, "nanopolish_amd", "csrc", e)) for e in ("*.hip", "*.cpp", "*.h")), []):
+        envs |= set(re.findall(r'getenv\("(NP_[A-Z_0-9]+)"\)', open(f).read()))
+    docs = hdr + "".join(open(os.path.join(root, n)).read() for n in ("INTEGRATION.md", "DESIGN.md", "README.md"))
+    assert len(envs) >= 15
+    assert sorted(e for e in envs if e not in docs) == []
