@@ -60,10 +60,10 @@ def test_batch_realignment_equals_the_unmodified_reference():
 
 
 def test_oversegmented_reads_long_segments(ctx, models):
-    """Reads with ~3.7 events per base (every k-mer's dwell split into two sub-levels): a 100-base segment then spans 370+ events, its
-    back-track visits more states than the two-read chain kernel's LDS list holds (NP_EA_PCAP), so the list spills to memory on the
-    way -- and the one-read kernel needs several LDS window refills per segment.  Both chain kernels against the reference's own
-    SquiggleRead + align_read_to_ref on the same raw signal."""
+    """Reads with ~3.7 events per base (every k-mer's dwell split into two sub-levels): a 100-base segment then spans 370+ events and its
+    back-track takes ~470 steps over many LDS window refills -- the longest lists of walk bursts the chain kernel sees (whether they
+    outgrow the LDS list, NP_EA_BCAP bursts, depends on the burst lengths; tests/test_gpu_chain_spill.py forces the spill with a build
+    whose list holds 8).  Against the reference's own SquiggleRead + align_read_to_ref on the same raw signal."""
     from nanopolish_amd import api
     from nanopolish_amd.pipeline import build_host_batch_records, CallMethylationBatch
     from nanopolish_amd.synth import BASES, nucleotide_kmer_ranks
