@@ -781,13 +781,18 @@ def main():
         import pmc_lookup
         traffic = pmc_lookup.traffic("event_align", "band", n_bands)
         issue = pmc_lookup.issue("event_align", "band", cyc_per_band) or dict(kind="unavailable", simd_cycles_per_band=round(cyc_per_band, 1))
-        roof = dict(bound="hbm", kernel="np_event_align_kernel", achieved=round(achieved, 2), peak=8000.0, unit="GB/s",
-                    frac=round(achieved / 8000.0, 5), traffic=traffic,
+        # the kernel's own `limiter` says vector issue, so THAT is the line's roofline (bound = "valu_issue": the counters'
+        # vector instructions per band x the guide's 2 cycles per wave64 instruction over the SIMD-cycles this launch spent per band); the HBM
+        # roofline on the algorithmic bytes stays beside it as roofline.hbm, with the counter traffic
+        hbm = dict(bound="hbm", achieved=round(achieved, 2), peak=8000.0, unit="GB/s", frac=round(achieved / 8000.0, 5), traffic=traffic,
+                   algo_bytes_per_launch=algo)
+        ri = pmc_lookup.roofline_issue("event_align", "band", cyc_per_band, "np_event_align_kernel")
+        roof = dict(ri) if ri else dict(hbm)
+        roof.update(kernel="np_event_align_kernel", traffic=traffic, hbm=hbm,
                     algo_bytes_per_launch=algo, avg_launch_ms=round(a_ms / max(a_n, 1), 3),
                     band_cells_per_s=round(res["band_cells"] / a_avg_s / 1e9, 3) if a_avg_s > 0 else 0.0,
                     limiter="vector-instruction issue (one wave per read, ~13.5k dependent band steps; HBM traffic ~0.9 x the algorithmic bytes): see issue",
                     issue=issue, dominant_kernel_by_time=dom,
-                    roofline_issue=pmc_lookup.roofline_issue("event_align", "band", cyc_per_band, "np_event_align_kernel"),
                     kernel_ms_per_step={k: round(v[0] / max(args.steps, 1), 3) for k, v in k_ms.items()})
 
         value = world * n_reads * args.steps / dt
@@ -823,6 +828,7 @@ def main():
                                read_len=args.read_len, mean_events=round(mean_events, 1), jobs_on_device=bool(args.jobs_on_device),
                                groups_per_step_per_gpu=res["n_groups"], reads_aligned_ok=res["n_ok"],
                                calibrate_on_device=bool(args.calibrate), from_raw_signal=bool(args.from_raw),
+                               map_stop=False,   # base_to_event_map[].stop is not built in this step: call-methylation never reads it (the CPU baseline does build it)
                                parallelism="reads sharded over %d GPU(s), 1 process/GPU" % world),
                    cpg_site_groups_per_s=round(world * res["n_groups"] * args.steps / dt, 1),
                    value_streamed=streamed["value"] if streamed else None, streamed=streamed,

@@ -78,12 +78,11 @@ const char* np_ctx_info(const np_ctx* ctx);
  * repair path -- results never depend on it), "ea_rows_cap" (events per eventalign segment the chain kernel's scratch holds;
  * a longer segment ends its read with NP_EA_OVERFLOW), "ea_waves_per_cu" (persistent grid of the chain kernel), "lse_oor" (0: the forward kernel clamps its log-sum table index;
  * 1: it relies on the LDS out-of-range rule, the default when np_create's probe passes and refused (NP_ERR_UNSUPPORTED) when it did not --
- * scores never depend on it), "adc_check_fused" (1, the default: np_adc_to_pa_dev also takes the detector's exactness verdicts, see there;
- * 0: np_detect_events_dev always makes its own pass -- events never depend on it), "hmm_prio" (wave priority of the forward kernels, 0 ... 2),
+ * scores never depend on it), "hmm_prio" (wave priority of the forward kernels, 0 ... 2),
  * "recal_shape" (np_calibrate_resolve_dev's workgroup shape, 0: default, 1 / 2: the alternatives it was measured against), "small_batch_path"
  * (1: np_hmm_score_host sends a small batch as one pinned blob; 0: the general path -- the tests compare the two).
  * Environment, read at np_create (each the option of the same name): NP_ALIGN_BLOCKS_PER_CU, NP_HMM_BLOCKS_PER_CU, NP_ALIGN_LPT, NP_ED_WARMUP,
- * NP_EA_WAVES_PER_CU, NP_RECAL_SHAPE, NP_ADC_CHECK_FUSED; NP_EA_WALK_PRIO=1 runs the chain kernel's back-track at wave priority 3 (measured slower,
+ * NP_EA_WAVES_PER_CU, NP_RECAL_SHAPE; NP_EA_WALK_PRIO=1 runs the chain kernel's back-track at wave priority 3 (measured slower,
  * profiles/r05_soak.md); NP_LSE_CLAMP, NP_HOST_CONSTANTS, NP_VERBOSE as described at np_ctx_info / in INTEGRATION.md. */
 int np_set_option(np_ctx* ctx, const char* name, int64_t value);
 /* Read-only facts about the context (-1: unknown name): "align_blocks" / "align_scratch_bytes" (persistent grid and per-wave scratch
@@ -420,12 +419,20 @@ void np_event_detection_params(np_detector_param* p, int rna);
  *     rawptr[i] = ((float)raw_signal[i] + offset) * raw_unit,   raw_unit = range / digitisation  (all fp32)
  * (src/io/nanopolish_fast5_loader.cpp:96-103, src/io/nanopolish_fast5_io.cpp:163-165).  A host-fed batch then uploads int16
  * samples, half the bytes.  adc: int16[total samples]; offset / raw_unit: float[n_reads]; raw_pa: float[total samples] out.
- * The conversion also takes np_detect_events_dev's exactness verdict of every read from the values on their way out (one pass over the
- * samples instead of two): a np_detect_events_dev call on exactly this (raw_pa, raw_off, n_reads) -- the context's next one -- uses it.  A
- * caller that CHANGES the converted samples between the two calls turns that off: np_set_option(ctx, "adc_check_fused", 0) (or
- * NP_ADC_CHECK_FUSED=0 in the environment at np_create). */
+ * (The detector's exactness verdicts are NOT kept as context state any more -- round 5 matched them to the next np_detect_events_dev by pointer
+ * identity, and a caller that edited raw_pa in place between the two calls silently inherited stale verdicts.  They are an explicit
+ * by-product now: np_adc_to_pa_checked_dev / np_detect_events_checked_dev below.) */
 int np_adc_to_pa_dev(np_ctx* ctx, void* stream, int n_reads, const int16_t* adc, const int64_t* raw_off, int64_t max_samples,
                      const float* offset, const float* raw_unit, float* raw_pa);
+
+/* The same conversion, which also takes the detector's per-read exactness verdict from the values on their way out (one pass over the samples
+ * instead of two: the bound of src/thirdparty/scrappie/event_detection.c:35-58's prefix sums).
+ *   verdict : int32[n_reads], device, out -- opaque; valid for exactly the samples this call wrote.
+ * Hand it to np_detect_events_checked_dev together with the same (raw_pa, raw_off, n_reads).  CONTRACT: the caller must not change raw_pa
+ * between the two calls; one that does passes verdict = NULL there (or calls np_detect_events_dev) and the detector makes its own pass.
+ * Nothing is remembered in the context: a stale verdict can only come from the caller's own hands. */
+int np_adc_to_pa_checked_dev(np_ctx* ctx, void* stream, int n_reads, const int16_t* adc, const int64_t* raw_off, int64_t max_samples,
+                             const float* offset, const float* raw_unit, float* raw_pa, int32_t* verdict);
 
 /* detect_events (src/thirdparty/scrappie/event_detection.c:268-319) on the WHOLE raw table of every read, as
  * SquiggleRead::load_from_raw runs it (src/nanopolish_squiggle_read.cpp:229-236; the trim it computes is discarded there).
@@ -440,6 +447,12 @@ int np_adc_to_pa_dev(np_ctx* ctx, void* stream, int n_reads, const int16_t* adc,
 int np_detect_events_dev(np_ctx* ctx, void* stream, int n_reads, const float* raw, const int64_t* raw_off, int64_t max_samples,
                          const np_detector_param* params, float* tstat, const int64_t* event_off, int64_t max_events,
                          uint32_t* event_start, float* event_length, float* event_mean, float* event_stdv, int32_t* n_events);
+/* The same call with the exactness verdicts np_adc_to_pa_checked_dev produced for exactly these samples (verdict: device int32[n_reads], or
+ * NULL = np_detect_events_dev).  Events are identical either way; with verdicts the detector skips its own bound pass over the samples. */
+int np_detect_events_checked_dev(np_ctx* ctx, void* stream, int n_reads, const float* raw, const int64_t* raw_off, int64_t max_samples,
+                                 const np_detector_param* params, float* tstat, const int64_t* event_off, int64_t max_events,
+                                 uint32_t* event_start, float* event_length, float* event_mean, float* event_stdv, int32_t* n_events,
+                                 const int32_t* verdict);
 /* Host-pointer convenience form for one batch of reads (copies in and out). out_* are concatenated, out_off[n_reads+1]. */
 int np_detect_events_host(np_ctx* ctx, int n_reads, const float* const* raw, const uint32_t* n_samples,
                           const np_detector_param* params, uint32_t* out_start, float* out_length, float* out_mean,

@@ -155,7 +155,7 @@ struct NpBatchPipeline::Impl {
     const faidx_t* fai; const bam_hdr_t* hdr;
     int region_start, region_end;
     std::vector<DevState*> devs;
-    std::vector<Slot*> slots;               // NP_BATCH_SLOTS (16) per device; batch b uses slot b % slots.size()
+    std::vector<Slot*> slots;               // NP_BATCH_SLOTS per device (default: three passes of NP_BATCH_COALESCE records in 512-record batches = 48); batch b uses slot b % slots.size()
     std::vector<Pass*> passes;              // 3 per context: passes[3 * d + j] belongs to devs[d]
     long n_passes;                          // device passes started so far (packer thread only)
     long coalesce_records;                  // a pass takes waiting batches while it holds fewer records than this (NP_BATCH_COALESCE, default 8192)
@@ -204,9 +204,11 @@ void NpBatchPipeline::Impl::open(const std::vector<int>& devices, bool shared_de
     }
     // batches in flight: enough small ones to fill three passes per device (max_in_flight() scales the number handed to the caller with
     // the batch size: large batches stay at three per device, as before)
-    int per_dev = 24;
-    if (const char* v = getenv("NP_BATCH_SLOTS")) per_dev = std::max(3, std::min(64, atoi(v)));
     if (const char* v = getenv("NP_BATCH_COALESCE")) coalesce_records = std::max(1L, atol(v));
+    // three passes of coalesce_records records each, in BamProcessor's 512-record batches: 48 slots at the default 8 192 (24 held 1.5
+    // passes, so pass N+1 was only formed once the device had gone idle and every other pass ran half-size)
+    int per_dev = (int)std::max(24L, std::min(64L, 3 * coalesce_records / 512));
+    if (const char* v = getenv("NP_BATCH_SLOTS")) per_dev = std::max(3, std::min(64, atoi(v)));
     if (!track_builders) per_dev = 3;                  // the synchronous pipeline: one batch at a time
     for (size_t i = 0; i < (size_t)per_dev * devs.size(); ++i) slots.push_back(new Slot());
     // Freed map memory goes back to the allocator, not to the kernel: with glibc's default trim threshold (128 KB) every batch's
@@ -442,6 +444,7 @@ void NpBatchPipeline::Impl::pack(const std::vector<Slot*>& group, int dev)
         for (;;) {
             for (int q = 0; q < 3 && !Pp; ++q) { Pass* C = passes[3 * dev + (int)((n_passes + q) % 3)]; if (!C->on_device && C->unfinished == 0) Pp = C; }
             if (Pp) break;
+            if (stop) return;                         // (the destructor waits for every batch first; a failing run must not park the packer here)
             (void)device_passes(devs[dev]->ordinal);
             cv.wait_for(g, std::chrono::microseconds(200));
         }
@@ -550,7 +553,7 @@ void NpBatchPipeline::Impl::pack(const std::vector<Slot*>& group, int dev)
     const size_t s_pair_begin = ls.add((size_t)n * 4), s_deg = ls.add((size_t)n * 8), s_kpos = ls.add((size_t)n_jobs * 8),
                  s_epb = ls.add((size_t)n * 8), s_jobs = ls.add((size_t)n_jobs * sizeof(np_hmm_job_dev));
     const size_t zero_bytes = ls.size;
-    const size_t s_raw_pa = ls.add(all_adc ? (size_t)raw_off[n] * sizeof(float) : 0);
+    const size_t s_raw_pa = ls.add(all_adc ? (size_t)raw_off[n] * sizeof(float) : 0), s_verdict = ls.add(all_adc ? (size_t)n * 4 : 0);
     const size_t s_tstat = ls.add((size_t)(2 * raw_off[n] + 16) * sizeof(float)), s_ev_len = ls.add((size_t)n_ev * 4), s_ev_mean = ls.add((size_t)n_ev * 4),
                  s_ev_stdv = ls.add((size_t)n_ev * 4), s_ev_start = ls.add((size_t)n_ev * 4), s_map_start = ls.add((size_t)n_rk * 4),
                  s_pairs = ls.add((size_t)pair_off[n] * sizeof(np_pair)),
@@ -648,11 +651,14 @@ void NpBatchPipeline::Impl::pack(const std::vector<Slot*>& group, int dev)
         check(np_cm_build_jobs_cigar_dev(c, NULL, n, genome, ref_begin, ref_len, cigar, d_cigar_off, cigar_off[n], read_len, rc, alphabet, k, MINSEP,
                                          FLANK, d_group_off, n_slots, d_jr_off, jobs, kpos, job_ranks, first, last, n_motif, n_groups, deg),
               "np_cm_build_jobs_cigar_dev");
+        // this pass owns the conversion AND the detection of these samples, nothing edits them in between: the conversion's exactness verdicts
+        // go to the detector explicitly (one pass over the samples instead of two)
+        int32_t* verdict = all_adc ? (int32_t*)(X + s_verdict) : NULL;
         if (all_adc)
-            check(np_adc_to_pa_dev(c, NULL, n, (const int16_t*)(Dv + i_raw), d_raw_off, max_samples, (const float*)(Dv + i_adc_offset),
-                                   (const float*)(Dv + i_adc_unit), raw), "np_adc_to_pa_dev");
-        check(np_detect_events_dev(c, NULL, n, raw, d_raw_off, max_samples, &prm, tstat, d_event_off, max_events, ev_start, ev_len, ev_mean,
-                                   ev_stdv, n_events), "np_detect_events_dev");
+            check(np_adc_to_pa_checked_dev(c, NULL, n, (const int16_t*)(Dv + i_raw), d_raw_off, max_samples, (const float*)(Dv + i_adc_offset),
+                                           (const float*)(Dv + i_adc_unit), raw, verdict), "np_adc_to_pa_checked_dev");
+        check(np_detect_events_checked_dev(c, NULL, n, raw, d_raw_off, max_samples, &prm, tstat, d_event_off, max_events, ev_start, ev_len, ev_mean,
+                                           ev_stdv, n_events, verdict), "np_detect_events_checked_dev");
         check(np_mom_fill_dev(c, NULL, n, reads_a, reads_b, ev_mean, n_events, ranks, m_nuc), "np_mom_fill_dev");
         check(np_event_align_dev(c, NULL, n, reads_a, ev_mean, ranks, m_nuc, max_bands, d_pair_off, pairs, pair_begin, n_pairs), "np_event_align_dev");
         check(np_calibrate_resolve_dev(c, NULL, n, reads_b, ev_mean, ranks, m_nuc, d_pair_off, pairs, pair_begin, n_pairs, map_start, NULL /* .stop: not read on this path */, epb,

@@ -52,7 +52,7 @@ void np_calculate_methylation_for_batch(MethylationCallingResult& result, std::v
 // 512 records that are already waiting are merged, up to NP_BATCH_COALESCE records (default 8 192) per pass; a pass starts as soon as
 // that many records wait or a GPU has nothing to do, so a slow caller is never made to wait for company.  Results are per batch.
 // `max_in_flight()` batches may be in flight: three per device when a batch fills a pass on its own, more when batches are small (up to
-// NP_BATCH_SLOTS, default 24, per device); it can change after a submit() with the size of the batches -- ask again, as the loop below
+// NP_BATCH_SLOTS, default 3 x NP_BATCH_COALESCE / 512 = 48, per device); it can change after a submit() with the size of the batches -- ask again, as the loop below
 // does; before the first submit() it returns the upper bound (the number of record / result vectors to rotate).  submit() with that
 // many in flight is an error.  BamProcessor's loop (bam_processor.cpp:90-119) becomes
 //     while (read a batch into recs[k % n]) { pipe.submit(recs[k % n]); if (pipe.in_flight() >= pipe.max_in_flight()) { pipe.collect(res); write(res); pipe.recycle(res); } ++k; }

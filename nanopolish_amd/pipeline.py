@@ -301,6 +301,9 @@ class CallMethylationBatch:
             self.d_ev_len = torch.empty(nev, dtype=torch.float32, device=dev)
             self.d_ev_stdv = torch.empty(nev, dtype=torch.float32, device=dev)
             self.d_n_events = torch.zeros(self.n_reads, dtype=torch.int32, device=dev)
+            # the conversion's by-product, handed to the detector explicitly (np_adc_to_pa_checked_dev -> np_detect_events_checked_dev):
+            # this batch owns both calls and nothing edits the samples in between
+            self.d_ed_verdict = torch.zeros(self.n_reads, dtype=torch.int32, device=dev)
             self.prm = _l.DetectorParam(); ctx.L.np_event_detection_params(C.byref(self.prm), 1 if self.rna else 0)
         self.d_reads_a = up(hb["reads_a"]); self.d_reads_b = up(hb["reads_b"])
         if self.jobs_on_device:
@@ -390,13 +393,14 @@ class CallMethylationBatch:
         self._step_work_items(L, h, p, s, ea)
         if self.from_raw:
             if self.from_adc:
-                rc = L.np_adc_to_pa_dev(h, s, self.n_reads, p(self.d_adc), p(self.d_raw_off), self.max_samples, p(self.d_adc_offset),
-                                        p(self.d_adc_unit), p(self.d_raw))
-                self.ctx._chk(rc, "np_adc_to_pa_dev")
-            rc = L.np_detect_events_dev(h, s, self.n_reads, p(self.d_raw), p(self.d_raw_off), self.max_samples, C.byref(self.prm),
-                                        p(self.d_tstat), p(self.d_event_off), self.max_events, p(self.d_ev_start), p(self.d_ev_len),
-                                        p(self.d_events), p(self.d_ev_stdv), p(self.d_n_events))
-            self.ctx._chk(rc, "np_detect_events_dev")
+                rc = L.np_adc_to_pa_checked_dev(h, s, self.n_reads, p(self.d_adc), p(self.d_raw_off), self.max_samples, p(self.d_adc_offset),
+                                                p(self.d_adc_unit), p(self.d_raw), p(self.d_ed_verdict))
+                self.ctx._chk(rc, "np_adc_to_pa_checked_dev")
+            rc = L.np_detect_events_checked_dev(h, s, self.n_reads, p(self.d_raw), p(self.d_raw_off), self.max_samples, C.byref(self.prm),
+                                                p(self.d_tstat), p(self.d_event_off), self.max_events, p(self.d_ev_start), p(self.d_ev_len),
+                                                p(self.d_events), p(self.d_ev_stdv), p(self.d_n_events),
+                                                p(self.d_ed_verdict) if self.from_adc else None)
+            self.ctx._chk(rc, "np_detect_events_checked_dev")
             rc = L.np_mom_fill_dev(h, s, self.n_reads, p(self.d_reads_a), p(self.d_reads_b), p(self.d_events), p(self.d_n_events),
                                    p(self.d_ranks), self.m_nuc)
             self.ctx._chk(rc, "np_mom_fill_dev")

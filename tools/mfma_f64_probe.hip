@@ -1,0 +1,201 @@
+// mfma_f64_probe.hip -- can the matrix pipe do kernel A's fp64 additions?  (round 6)
+//
+// v_mfma_f64_4x4x4_4b_f64 computes, in each of four 4x4 blocks, D = C + A B in IEEE fp64.  With A the identity (one lane in four
+// holds 1.0) the product adds exactly one non-zero term per output element, so D[lane] = C[lane] + B[lane]: a per-lane fp64 addition
+// that issues on the MATRIX pipe, which the band loop of np_event_align_kernel leaves idle while its vector port is saturated.
+// This probe answers, on the device:
+//   1. layout   -- which (A lane, B lane) pairs feed which D lane (one-hot sweeps), hence the identity pattern;
+//   2. exact    -- D == C + B bit for bit against v_add_f64 (random operands, -inf / huge / tiny in C, finite B);
+//   3. rates    -- SIMD cycles per wave-instruction of the MFMA alone, and of a band-like VALU mix with its ten fp64 additions
+//                  on the vector port, on the matrix pipe, and removed (the most the move can give), at 8 waves per SIMD.
+// Build + run:  hipcc -O3 --offload-arch=gfx950 tools/mfma_f64_probe.hip -o /tmp/mfma_f64_probe && /tmp/mfma_f64_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include <random>
+#include <cmath>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
+
+__global__ void k_one(double* o, const double* a, const double* b, const double* c)
+{
+    const int l = threadIdx.x;
+    o[l] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[l], b[l], c[l], 0, 0, 0);
+}
+
+// n per-lane additions two ways
+__global__ void k_add(double* o_m, double* o_v, const double* ident, const double* b, const double* c, int n)
+{
+    const int l = threadIdx.x & 63;
+    const double A = ident[l];
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const double B = b[(size_t)i * 64 + l], C = c[(size_t)i * 64 + l];
+        o_m[(size_t)i * 64 + l] = __builtin_amdgcn_mfma_f64_4x4x4f64(A, B, C, 0, 0, 0);
+        double s;
+        asm volatile("v_add_f64 %0, %1, %2" : "=v"(s) : "v"(C), "v"(B));
+        o_v[(size_t)i * 64 + l] = s;
+    }
+}
+
+// MODE 0: ten v_add_f64 + the rest of a band on the vector port; 1: the ten additions as MFMAs; 2: no additions; 3: MFMAs only;
+// 4: the vector rest only counted as in 2 but with ten s_nop (issue slots without a pipe); 5: ten v_add_f64 only
+#define REP10(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9)
+template <int MODE> __global__ void __launch_bounds__(256, 8) k_mix(unsigned long long* out, double* sink, const double* ident, int iters)
+{
+    const int l = threadIdx.x & 63;
+    const double A = ident[l];
+    double B = 1.0 + l * 1e-3;
+    double d0 = l, d1 = l + 1, d2 = l + 2, d3 = l + 3, d4 = l + 4, d5 = l + 5, d6 = l + 6, d7 = l + 7, d8 = l + 8, d9 = l + 9;
+    float a0 = l, a1 = 1.5f, a2 = 2.5f, a3 = 3.5f, a4 = 4.5f, a5 = 5.5f, a6 = 6.5f, a7 = 7.5f;
+    double e0 = 1.0, e1 = 2.0, e2 = 3.0, e3 = 4.0, e4 = 5.0;
+    uint32_t t = 0;
+    const unsigned long long t0 = wall_clock64();
+    const unsigned long long c0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; ++i) {
+#define VADD(n) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d##n) : "v"(B));
+#define MADD(n) d##n = __builtin_amdgcn_mfma_f64_4x4x4f64(A, B, d##n, 0, 0, 0);
+        if (MODE == 0 || MODE == 5) { REP10(VADD) }
+        if (MODE == 1 || MODE == 3) { REP10(MADD) }
+        if (MODE == 4) { asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0"); }
+        if (MODE != 3 && MODE != 5) {
+            // the band's other 44 vector instructions by class: 18 fast fp32, 5 + 6 conversions, 4 compares to scalar pairs + 4 carry adds,
+            // 2 max3, 2 selects, 1 DPP rotate, 2 lane reads
+            asm volatile(
+                "v_fma_f32 %[a0], %[a0], %[a1], %[a2]\n v_fma_f32 %[a1], %[a1], %[a2], %[a3]\n v_fma_f32 %[a2], %[a2], %[a3], %[a4]\n"
+                "v_fma_f32 %[a3], %[a3], %[a4], %[a5]\n v_fma_f32 %[a4], %[a4], %[a5], %[a6]\n v_fma_f32 %[a5], %[a5], %[a6], %[a7]\n"
+                "v_mul_f32 %[a6], %[a6], %[a7]\n v_mul_f32 %[a7], %[a7], %[a0]\n v_sub_f32 %[a0], %[a0], %[a1]\n"
+                "v_fma_f32 %[a0], %[a0], %[a1], %[a2]\n v_fma_f32 %[a1], %[a1], %[a2], %[a3]\n v_fma_f32 %[a2], %[a2], %[a3], %[a4]\n"
+                "v_fma_f32 %[a3], %[a3], %[a4], %[a5]\n v_fma_f32 %[a4], %[a4], %[a5], %[a6]\n v_fma_f32 %[a5], %[a5], %[a6], %[a7]\n"
+                "v_mul_f32 %[a6], %[a6], %[a7]\n v_mul_f32 %[a7], %[a7], %[a0]\n v_sub_f32 %[a0], %[a0], %[a1]\n"
+                "v_cvt_f64_f32 %[e0], %[a0]\n v_cvt_f64_f32 %[e1], %[a1]\n v_cvt_f64_f32 %[e2], %[a2]\n v_cvt_f64_f32 %[e3], %[a3]\n v_cvt_f64_f32 %[e4], %[a4]\n"
+                "v_cvt_f32_f64 %[a0], %[e0]\n v_cvt_f32_f64 %[a1], %[e1]\n v_cvt_f32_f64 %[a2], %[e2]\n v_cvt_f32_f64 %[a3], %[e3]\n v_cvt_f32_f64 %[a4], %[e4]\n v_cvt_f32_f64 %[a5], %[e0]\n"
+                "v_cmp_eq_f32_e64 s[20:21], %[a0], %[a1]\n v_cmp_eq_f32_e64 s[22:23], %[a1], %[a2]\n v_cmp_eq_f32_e64 s[24:25], %[a2], %[a3]\n v_cmp_eq_f32_e64 s[26:27], %[a3], %[a4]\n"
+                "v_addc_co_u32_e64 %[t], s[28:29], %[t], %[t], s[20:21]\n v_addc_co_u32_e64 %[t], s[28:29], %[t], %[t], s[22:23]\n"
+                "v_addc_co_u32_e64 %[t], s[28:29], %[t], %[t], s[24:25]\n v_addc_co_u32_e64 %[t], s[28:29], %[t], %[t], s[26:27]\n"
+                "v_max3_f32 %[a6], %[a6], %[a0], %[a1]\n v_max3_f32 %[a7], %[a7], %[a2], %[a3]\n"
+                "v_cndmask_b32_e64 %[a6], %[a6], %[a4], s[20:21]\n v_cndmask_b32_e64 %[a7], %[a7], %[a5], s[22:23]\n"
+                "v_mov_b32_dpp %[a5], %[a7] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
+                "v_readlane_b32 s30, %[a6], 5\n v_readlane_b32 s31, %[a7], 9\n"
+                : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6), [a7] "+v"(a7),
+                  [e0] "+v"(e0), [e1] "+v"(e1), [e2] "+v"(e2), [e3] "+v"(e3), [e4] "+v"(e4), [t] "+v"(t)
+                : : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
+        }
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    const unsigned long long t1 = wall_clock64();
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = t1 - t0; }
+    sink[blockIdx.x * 256 + threadIdx.x] = d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 + d8 + d9 + a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + e0 + e1 + e2 + e3 + e4 + t;
+}
+
+template <int MODE> static int run_mix(const char* name, const double* ident_d, int waves_per_simd)
+{
+    int dev = 0; hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, dev));
+    const int cus = p.multiProcessorCount;
+    const int blocks = cus * waves_per_simd;          // 256-thread blocks: 4 waves, one per SIMD
+    const int iters = 20000;
+    unsigned long long* out; double* sink;
+    CK(hipMalloc(&out, blocks * 16)); CK(hipMalloc(&sink, (size_t)blocks * 256 * 8));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_mix<MODE>, dim3(blocks), dim3(256), 0, 0, out, sink, ident_d, 200);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_mix<MODE>, dim3(blocks), dim3(256), 0, 0, out, sink, ident_d, iters);
+    CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h(blocks * 2); CK(hipMemcpy(h.data(), out, blocks * 16, hipMemcpyDeviceToHost));
+    double cyc = 0, wc = 0; for (int i = 0; i < blocks; ++i) { cyc += h[2 * i]; wc += h[2 * i + 1]; }
+    cyc /= blocks; wc /= blocks;
+    // per SIMD: waves_per_simd waves, each `iters` iterations, in ms
+    const double ns_per_iter_simd = ms * 1e6 / ((double)iters * waves_per_simd);
+    printf("  %-34s waves/SIMD %d: %8.2f ms  %7.1f ns per iteration and SIMD-wave (= %6.1f cycles at 2.4 GHz)  s_memtime/iter %.1f  wall_clock/iter %.2f\n",
+           name, waves_per_simd, ms, ns_per_iter_simd, ns_per_iter_simd * 2.4, cyc / iters, wc / iters);
+    CK(hipFree(out)); CK(hipFree(sink));
+    return 0;
+}
+
+int main()
+{
+    double *a, *b, *c, *o;
+    CK(hipMalloc(&a, 512)); CK(hipMalloc(&b, 512)); CK(hipMalloc(&c, 512)); CK(hipMalloc(&o, 512));
+    double ha[64], hb[64], hc[64], ho[64];
+    // ---- 1. layout: A one-hot at lane la, B[l] = l + 1, C = 0 -> D[L] = B value of the lane that pairs with la for output L
+    int pairB[64][64]; memset(pairB, -1, sizeof pairB);          // pairB[la][L] = lb
+    for (int la = 0; la < 64; ++la) {
+        for (int l = 0; l < 64; ++l) { ha[l] = l == la ? 1.0 : 0.0; hb[l] = l + 1; hc[l] = 0.0; }
+        CK(hipMemcpy(a, ha, 512, hipMemcpyHostToDevice)); CK(hipMemcpy(b, hb, 512, hipMemcpyHostToDevice)); CK(hipMemcpy(c, hc, 512, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_one, dim3(1), dim3(64), 0, 0, o, a, b, c);
+        CK(hipMemcpy(ho, o, 512, hipMemcpyDeviceToHost));
+        for (int L = 0; L < 64; ++L) if (ho[L] != 0.0) pairB[la][L] = (int)ho[L] - 1;
+    }
+    printf("layout: A lane -> (D lane <- B lane)\n");
+    for (int la = 0; la < 64; ++la) {
+        printf("  A %2d:", la);
+        for (int L = 0; L < 64; ++L) if (pairB[la][L] >= 0) printf(" (%d<-%d)", L, pairB[la][L]);
+        printf("\n");
+    }
+    // identity pattern with B as the addend: A lanes whose every output reads ITS OWN lane of B
+    double identB[64]; int coverB[64] = {0};
+    for (int la = 0; la < 64; ++la) {
+        bool own = true, any = false;
+        for (int L = 0; L < 64; ++L) if (pairB[la][L] >= 0) { any = true; if (pairB[la][L] != L) own = false; }
+        identB[la] = (own && any) ? 1.0 : 0.0;
+        if (own && any) for (int L = 0; L < 64; ++L) if (pairB[la][L] >= 0) coverB[L]++;
+    }
+    bool okB = true; for (int L = 0; L < 64; ++L) if (coverB[L] != 1) okB = false;
+    printf("identity-in-A pattern (D[l] = C[l] + B[l]): %s; lanes with 1.0:", okB ? "EXISTS" : "does not exist");
+    for (int l = 0; l < 64; ++l) if (identB[l] != 0.0) printf(" %d", l);
+    printf("\n");
+    if (!okB) { printf("RESULT: no per-lane addition through A = identity\n"); return 2; }
+
+    double* ident_d; CK(hipMalloc(&ident_d, 512)); CK(hipMemcpy(ident_d, identB, 512, hipMemcpyHostToDevice));
+
+    // ---- 2. exactness
+    {
+        const int n = 1 << 16;
+        std::vector<double> hB((size_t)n * 64), hC((size_t)n * 64), oM((size_t)n * 64), oV((size_t)n * 64);
+        std::mt19937_64 rng(12345);
+        std::uniform_real_distribution<double> u(-1.0, 1.0);
+        for (size_t i = 0; i < hB.size(); ++i) {
+            const int kind = (int)(rng() % 16);
+            double C = u(rng) * std::ldexp(1.0, (int)(rng() % 40) - 10), B = u(rng) * std::ldexp(1.0, (int)(rng() % 30) - 20);
+            if (kind == 0) C = -INFINITY;
+            if (kind == 1) C = (double)(float)C;                       // a float-valued cell
+            if (kind == 2) { C = (double)(float)C; B = (double)(float)B; }
+            if (kind == 3) C = u(rng) * 1e300;
+            if (kind == 4) C = u(rng) * 1e-300;
+            if (kind == 5) B = u(rng) * 1e-310;                        // subnormal addend
+            if (kind == 6) { C = 0.0; }
+            if (kind == 7) { C = -B; }                                  // exact cancellation
+            if (kind == 8) { C = std::nextafter(-B, 0.0); }
+            hB[i] = B; hC[i] = C;
+        }
+        double *dB, *dC, *dM, *dV;
+        CK(hipMalloc(&dB, hB.size() * 8)); CK(hipMalloc(&dC, hB.size() * 8)); CK(hipMalloc(&dM, hB.size() * 8)); CK(hipMalloc(&dV, hB.size() * 8));
+        CK(hipMemcpy(dB, hB.data(), hB.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dC, hC.data(), hB.size() * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_add, dim3(1024), dim3(64), 0, 0, dM, dV, ident_d, dB, dC, n);
+        CK(hipMemcpy(oM.data(), dM, hB.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(oV.data(), dV, hB.size() * 8, hipMemcpyDeviceToHost));
+        size_t bad = 0, bad_host = 0;
+        for (size_t i = 0; i < hB.size(); ++i) {
+            uint64_t x, y, z; const double hs = hC[i] + hB[i];
+            memcpy(&x, &oM[i], 8); memcpy(&y, &oV[i], 8); memcpy(&z, &hs, 8);
+            if (x != y) { if (bad < 8) printf("  MISMATCH C=%a B=%a mfma=%a valu=%a\n", hC[i], hB[i], oM[i], oV[i]); ++bad; }
+            if (y != z && !(hs != hs)) ++bad_host;
+        }
+        printf("exactness: %zu additions, %zu differ between the matrix pipe and v_add_f64 (%zu v_add_f64 results differ from the host's)\n", hB.size(), bad, bad_host);
+        CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dM)); CK(hipFree(dV));
+    }
+
+    // ---- 3. rates
+    printf("rates (per loop iteration of one wave; a SIMD runs waves/SIMD of them side by side):\n");
+    for (int w : {1, 4, 8}) {
+        if (run_mix<3>("10 MFMA f64 4x4x4 only", ident_d, w)) return 1;
+        if (run_mix<5>("10 v_add_f64 only", ident_d, w)) return 1;
+        if (run_mix<2>("band rest (44 vector), no adds", ident_d, w)) return 1;
+        if (run_mix<4>("band rest + 10 s_nop", ident_d, w)) return 1;
+        if (run_mix<0>("band rest + 10 v_add_f64", ident_d, w)) return 1;
+        if (run_mix<1>("band rest + 10 MFMA", ident_d, w)) return 1;
+    }
+    return 0;
+}
