@@ -65,6 +65,9 @@
 #ifndef NP_A_WALK_PRIO
 #define NP_A_WALK_PRIO 3  // wave priority during the back-track (s_setprio): a dependent scalar chain that needs few issue slots but holds a
 #endif                    // wave slot for as long as it takes; 45.6 -> 43.2 ms per 32768 reads
+#ifndef NP_A_M0SEL
+#define NP_A_M0SEL 0      // round 6 experiment: the pair loop keeps the lane select of slot register 1's band end in M0 (v_readlane with an SGPR
+#endif                    // lane select issues in 8.5 cycles, with a constant in 4.5: is M0 the cheap form?)
 #ifndef NP_A_FILL_PRIO
 #define NP_A_FILL_PRIO 1  // ... and, lower, while a band's move decision (v_readlane -> scalar compare -> branch) is in flight: the wave cannot
 #endif                    // issue the next band before it resolves; 43.8 -> 42.6 ms
@@ -185,6 +188,9 @@ __device__ __forceinline__ void right_move_fast(fill_t& F)
         "s_add_i32 %[t], %[s1], 1\n\t"
         "s_mov_b32 %[s1], %[s0]\n\t"
         "s_mov_b32 %[s0], %[t]\n\t"
+#if NP_A_M0SEL
+        "s_mov_b32 m0, %[s1]\n\t"
+#endif
         "s_xor_b32 %[sw], %[sw], 1"
         : [rot] "=&s"(rot), [tmp] "=&s"(tmp), [t] "=&s"(t), [m0] "+s"(F.vm0), [m1] "+s"(F.vm1), [llk] "+s"(F.llk),
           [s0] "+s"(F.sel0), [s1] "+s"(F.sel1), [sw] "+s"(F.swp)
@@ -304,6 +310,10 @@ __device__ __forceinline__ void band_step(fill_t& F, const read_t& R, const int 
         if (POS >= 0) __builtin_amdgcn_s_setprio(NP_A_FILL_PRIO);
 #endif
         xs = __builtin_amdgcn_readlane(__builtin_bit_cast(int, m0), F.sel0);
+#if NP_A_M0SEL
+        if (POS >= 0) asm volatile("v_readlane_b32 %0, %1, m0" : "=s"(ys) : "v"(m1));
+        else
+#endif
         ys = __builtin_amdgcn_readlane(__builtin_bit_cast(int, m1), F.sel1);
         asm volatile("" : "+s"(xs), "+s"(ys));
     }
@@ -541,6 +551,9 @@ __global__ void __launch_bounds__(NP_ALIGN_BLOCK, NP_A_WAVES) np_event_align_ker
                     // compile-time properties of the position
                     if (b & 1) { band_step<false, false, true>(F, R, b, x0, x1, x0, x1); ++b; }
                     float y0, y1;
+#if NP_A_M0SEL
+                    asm volatile("s_mov_b32 m0, %0" : : "s"(F.sel1));
+#endif
                     for (; b + 1 < stop; b += 2) {
                         band_step<false, false, true, 0>(F, R, b, x0, x1, y0, y1); band_step<false, false, true, 1>(F, R, b + 1, y0, y1, x0, x1);
                         F.eo0 += 8; F.eo1 += 8;

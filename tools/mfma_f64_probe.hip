@@ -39,10 +39,15 @@ __global__ void k_add(double* o_m, double* o_v, const double* ident, const doubl
     }
 }
 
+// MODE 6: as 0, but the four compare masks are stored by two s_store_dwordx4 instead of four v_addc (trace as lane-mask planes)
 // MODE 0: ten v_add_f64 + the rest of a band on the vector port; 1: the ten additions as MFMAs; 2: no additions; 3: MFMAs only;
 // 4: the vector rest only counted as in 2 but with ten s_nop (issue slots without a pipe); 5: ten v_add_f64 only
 #define REP10(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9)
-template <int MODE> __global__ void __launch_bounds__(256, 8) k_mix(unsigned long long* out, double* sink, const double* ident, int iters)
+#define TRACE_ADDC "v_addc_co_u32_e64 %[t], s[28:29], %[t], %[t], s[20:21]\n v_addc_co_u32_e64 %[t], s[28:29], %[t], %[t], s[22:23]\n" \
+                   "v_addc_co_u32_e64 %[t], s[28:29], %[t], %[t], s[24:25]\n v_addc_co_u32_e64 %[t], s[28:29], %[t], %[t], s[26:27]\n"
+// the four compare masks leave through the scalar data cache instead (two 16-byte scalar stores per band)
+#define TRACE_SSTORE "s_store_dwordx4 s[20:23], %[sp], 0x0\n s_store_dwordx4 s[24:27], %[sp], 0x10\n"
+template <int MODE> __global__ void __launch_bounds__(256, 8) k_mix(unsigned long long* out, double* sink, const double* ident, int iters, uint64_t* splane = nullptr)
 {
     const int l = threadIdx.x & 63;
     const double A = ident[l];
@@ -56,12 +61,15 @@ template <int MODE> __global__ void __launch_bounds__(256, 8) k_mix(unsigned lon
     for (int i = 0; i < iters; ++i) {
 #define VADD(n) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d##n) : "v"(B));
 #define MADD(n) d##n = __builtin_amdgcn_mfma_f64_4x4x4f64(A, B, d##n, 0, 0, 0);
-        if (MODE == 0 || MODE == 5) { REP10(VADD) }
+        if (MODE == 0 || MODE == 5 || MODE == 6) { REP10(VADD) }
         if (MODE == 1 || MODE == 3) { REP10(MADD) }
         if (MODE == 4) { asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0"); }
         if (MODE != 3 && MODE != 5) {
             // the band's other 44 vector instructions by class: 18 fast fp32, 5 + 6 conversions, 4 compares to scalar pairs + 4 carry adds,
             // 2 max3, 2 selects, 1 DPP rotate, 2 lane reads
+            if (MODE == 6 || MODE == 7) {
+                const uint64_t* sp = splane + ((size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 4096 + (size_t)(i & 1023) * 4);      // 32 B per band, a 32 KB window per wave
+                sp = (const uint64_t*)(((uint64_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)sp >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint64_t)sp));
             asm volatile(
                 "v_fma_f32 %[a0], %[a0], %[a1], %[a2]\n v_fma_f32 %[a1], %[a1], %[a2], %[a3]\n v_fma_f32 %[a2], %[a2], %[a3], %[a4]\n"
                 "v_fma_f32 %[a3], %[a3], %[a4], %[a5]\n v_fma_f32 %[a4], %[a4], %[a5], %[a6]\n v_fma_f32 %[a5], %[a5], %[a6], %[a7]\n"
@@ -72,8 +80,26 @@ template <int MODE> __global__ void __launch_bounds__(256, 8) k_mix(unsigned lon
                 "v_cvt_f64_f32 %[e0], %[a0]\n v_cvt_f64_f32 %[e1], %[a1]\n v_cvt_f64_f32 %[e2], %[a2]\n v_cvt_f64_f32 %[e3], %[a3]\n v_cvt_f64_f32 %[e4], %[a4]\n"
                 "v_cvt_f32_f64 %[a0], %[e0]\n v_cvt_f32_f64 %[a1], %[e1]\n v_cvt_f32_f64 %[a2], %[e2]\n v_cvt_f32_f64 %[a3], %[e3]\n v_cvt_f32_f64 %[a4], %[e4]\n v_cvt_f32_f64 %[a5], %[e0]\n"
                 "v_cmp_eq_f32_e64 s[20:21], %[a0], %[a1]\n v_cmp_eq_f32_e64 s[22:23], %[a1], %[a2]\n v_cmp_eq_f32_e64 s[24:25], %[a2], %[a3]\n v_cmp_eq_f32_e64 s[26:27], %[a3], %[a4]\n"
-                "v_addc_co_u32_e64 %[t], s[28:29], %[t], %[t], s[20:21]\n v_addc_co_u32_e64 %[t], s[28:29], %[t], %[t], s[22:23]\n"
-                "v_addc_co_u32_e64 %[t], s[28:29], %[t], %[t], s[24:25]\n v_addc_co_u32_e64 %[t], s[28:29], %[t], %[t], s[26:27]\n"
+                TRACE_SSTORE
+                "v_max3_f32 %[a6], %[a6], %[a0], %[a1]\n v_max3_f32 %[a7], %[a7], %[a2], %[a3]\n"
+                "v_cndmask_b32_e64 %[a6], %[a6], %[a4], s[20:21]\n v_cndmask_b32_e64 %[a7], %[a7], %[a5], s[22:23]\n"
+                "v_mov_b32_dpp %[a5], %[a7] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
+                "v_readlane_b32 s30, %[a6], 5\n v_readlane_b32 s31, %[a7], 9\n"
+                : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6), [a7] "+v"(a7),
+                  [e0] "+v"(e0), [e1] "+v"(e1), [e2] "+v"(e2), [e3] "+v"(e3), [e4] "+v"(e4), [t] "+v"(t)
+                : [sp] "s"(sp) : "memory", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
+            } else {
+            asm volatile(
+                "v_fma_f32 %[a0], %[a0], %[a1], %[a2]\n v_fma_f32 %[a1], %[a1], %[a2], %[a3]\n v_fma_f32 %[a2], %[a2], %[a3], %[a4]\n"
+                "v_fma_f32 %[a3], %[a3], %[a4], %[a5]\n v_fma_f32 %[a4], %[a4], %[a5], %[a6]\n v_fma_f32 %[a5], %[a5], %[a6], %[a7]\n"
+                "v_mul_f32 %[a6], %[a6], %[a7]\n v_mul_f32 %[a7], %[a7], %[a0]\n v_sub_f32 %[a0], %[a0], %[a1]\n"
+                "v_fma_f32 %[a0], %[a0], %[a1], %[a2]\n v_fma_f32 %[a1], %[a1], %[a2], %[a3]\n v_fma_f32 %[a2], %[a2], %[a3], %[a4]\n"
+                "v_fma_f32 %[a3], %[a3], %[a4], %[a5]\n v_fma_f32 %[a4], %[a4], %[a5], %[a6]\n v_fma_f32 %[a5], %[a5], %[a6], %[a7]\n"
+                "v_mul_f32 %[a6], %[a6], %[a7]\n v_mul_f32 %[a7], %[a7], %[a0]\n v_sub_f32 %[a0], %[a0], %[a1]\n"
+                "v_cvt_f64_f32 %[e0], %[a0]\n v_cvt_f64_f32 %[e1], %[a1]\n v_cvt_f64_f32 %[e2], %[a2]\n v_cvt_f64_f32 %[e3], %[a3]\n v_cvt_f64_f32 %[e4], %[a4]\n"
+                "v_cvt_f32_f64 %[a0], %[e0]\n v_cvt_f32_f64 %[a1], %[e1]\n v_cvt_f32_f64 %[a2], %[e2]\n v_cvt_f32_f64 %[a3], %[e3]\n v_cvt_f32_f64 %[a4], %[e4]\n v_cvt_f32_f64 %[a5], %[e0]\n"
+                "v_cmp_eq_f32_e64 s[20:21], %[a0], %[a1]\n v_cmp_eq_f32_e64 s[22:23], %[a1], %[a2]\n v_cmp_eq_f32_e64 s[24:25], %[a2], %[a3]\n v_cmp_eq_f32_e64 s[26:27], %[a3], %[a4]\n"
+                TRACE_ADDC
                 "v_max3_f32 %[a6], %[a6], %[a0], %[a1]\n v_max3_f32 %[a7], %[a7], %[a2], %[a3]\n"
                 "v_cndmask_b32_e64 %[a6], %[a6], %[a4], s[20:21]\n v_cndmask_b32_e64 %[a7], %[a7], %[a5], s[22:23]\n"
                 "v_mov_b32_dpp %[a5], %[a7] wave_ror:1 row_mask:0xf bank_mask:0xf\n"
@@ -81,12 +107,89 @@ template <int MODE> __global__ void __launch_bounds__(256, 8) k_mix(unsigned lon
                 : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6), [a7] "+v"(a7),
                   [e0] "+v"(e0), [e1] "+v"(e1), [e2] "+v"(e2), [e3] "+v"(e3), [e4] "+v"(e4), [t] "+v"(t)
                 : : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
+            }
+
         }
     }
+    if (MODE == 6 || MODE == 7) asm volatile("s_dcache_wb\n s_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned long long c1 = __builtin_readcyclecounter();
     const unsigned long long t1 = wall_clock64();
     if (threadIdx.x == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = t1 - t0; }
     sink[blockIdx.x * 256 + threadIdx.x] = d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 + d8 + d9 + a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + e0 + e1 + e2 + e3 + e4 + t;
+}
+
+// ---- 4. the multi-read ring as an instruction-stream mock: one band of NS ring slots per lane, every instruction of the
+// real band step with its real dependences (emission: sub, mul, four corrections, three for cl - a^2/2; candidates: 2 conversions in, 5 fp64
+// additions with scalar constants, 3 conversions out; max3; 2 compares to scalar pairs + 2 carry adds; window select), plus per band the
+// left-neighbour transfer (NROT DPP rotates + one conversion) and NRD lane reads with scalar selects (two band ends per read).
+//   NS = 2, NROT = 1, NRD = 2 : the shipped layout (one read per wave, 128-slot ring, 100 live)          -> per read: this
+//   NS = 5, NROT = 3, NRD = 6 : three reads per wave on 21 lanes x 5 slots each (105-slot rings, 100 live) -> per read: this / 3
+// The mock leaves out what the three-read form would ADD (per-read move decisions as vector code or three scalar chains, per-read window
+// masks, per-read re-targets, ragged band counts): it is the most the layout can give.
+template <int NS, int NROT, int NRD, int WAVES> __global__ void __launch_bounds__(256, WAVES) k_ring(unsigned long long* out, float* sink, int iters)
+{
+    const int l = threadIdx.x & 63;
+    float x[NS], g0[NS], g1[NS], g2[NS], g3[NS], p[NS];
+    double d[NS];
+    uint32_t t = l;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { x[i] = 80.f + l + i; g0[i] = 79.f + i; g1[i] = -1.5f - 0.01f * l; g2[i] = -1.3f; g3[i] = 1.f / 1.5f; p[i] = -100.f - l; d[i] = -101.0 - i; }
+    double L = -99.0;
+    float lft = -98.f;
+    const unsigned long long t0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < NROT; ++r) asm volatile("v_mov_b32_dpp %0, %1 wave_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(lft) : "v"(p[NS - 1]));
+        asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(L) : "v"(lft));
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            float n_, q_, e_, em, sd, su, sl, m;
+            double E, P, D, U, Lq;
+            asm volatile("v_sub_f32 %[n], %[x], %[g0]\n v_mul_f32 %[q], %[n], %[g3]\n v_fma_f32 %[e], %[g1], %[q], %[n]\n v_fma_f32 %[q], %[e], %[g3], %[q]\n"
+                         "v_fma_f32 %[e], %[g1], %[q], %[n]\n v_fma_f32 %[q], %[e], %[g3], %[q]\n v_mul_f32 %[e], 0.5, %[q]\n v_mul_f32 %[e], %[e], %[q]\n"
+                         "v_sub_f32 %[em], %[g2], %[e]\n"
+                         "v_cvt_f64_f32 %[E], %[em]\n v_cvt_f64_f32 %[P], %[p]\n"
+                         "v_add_f64 %[D], %[d], s[20:21]\n v_add_f64 %[D], %[D], %[E]\n v_add_f64 %[U], %[P], s[22:23]\n v_add_f64 %[U], %[U], %[E]\n"
+                         "v_add_f64 %[Lq], %[L], s[24:25]\n"
+                         "v_cvt_f32_f64 %[sd], %[D]\n v_cvt_f32_f64 %[su], %[U]\n v_cvt_f32_f64 %[sl], %[Lq]\n"
+                         "v_max3_f32 %[m], %[sd], %[su], %[sl]\n"
+                         "v_cmp_eq_f32_e64 s[26:27], %[m], %[sl]\n v_cmp_eq_f32_e64 s[28:29], %[m], %[su]\n"
+                         "v_addc_co_u32_e64 %[t], s[30:31], %[t], %[t], s[26:27]\n v_addc_co_u32_e64 %[t], s[30:31], %[t], %[t], s[28:29]\n"
+                         "v_cndmask_b32_e64 %[p], %[g2], %[m], s[18:19]\n"
+                         : [n] "=&v"(n_), [q] "=&v"(q_), [e] "=&v"(e_), [em] "=&v"(em), [sd] "=&v"(sd), [su] "=&v"(su), [sl] "=&v"(sl), [m] "=&v"(m),
+                           [E] "=&v"(E), [P] "=&v"(P), [D] "=&v"(D), [U] "=&v"(U), [Lq] "=&v"(Lq), [p] "+v"(p[i]), [t] "+v"(t)
+                         : [x] "v"(x[i]), [g0] "v"(g0[i]), [g1] "v"(g1[i]), [g2] "v"(g2[i]), [g3] "v"(g3[i]), [d] "v"(d[i]), [L] "v"(L)
+                         : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s18", "s19");
+            d[i] = L; L = P;                       // the next slot's left neighbour is this slot's cell; this slot's next diagonal its left (register renames in the real loop)
+        }
+#pragma unroll
+        for (int r = 0; r < NRD; ++r) asm volatile("v_readlane_b32 s14, %0, s15" : : "v"(p[r % NS]) : "s14");
+    }
+    const unsigned long long t1 = wall_clock64();
+    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+    float acc = (float)L + lft + t;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) acc += p[i] + (float)d[i];
+    sink[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+template <int NS, int NROT, int NRD, int WAVES> static int run_ring(const char* name, int reads_per_wave)
+{
+    int dev = 0; hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, dev));
+    const int blocks = pr.multiProcessorCount * WAVES, iters = 20000;
+    unsigned long long* out; float* sink;
+    CK(hipMalloc(&out, blocks * 8)); CK(hipMalloc(&sink, (size_t)blocks * 256 * 4));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_ring<NS, NROT, NRD, WAVES>), dim3(blocks), dim3(256), 0, 0, out, sink, 200);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_ring<NS, NROT, NRD, WAVES>), dim3(blocks), dim3(256), 0, 0, out, sink, iters);
+    CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double ns_band = ms * 1e6 / ((double)iters * WAVES);           // per SIMD: WAVES waves side by side
+    printf("  %-44s waves/SIMD %d: %8.2f ms  %7.1f SIMD-cycles (2.4 GHz) per wave-band = %6.1f per READ-band\n", name, WAVES, ms, ns_band * 2.4, ns_band * 2.4 / reads_per_wave);
+    CK(hipFree(out)); CK(hipFree(sink));
+    return 0;
 }
 
 template <int MODE> static int run_mix(const char* name, const double* ident_d, int waves_per_simd)
@@ -95,13 +198,14 @@ template <int MODE> static int run_mix(const char* name, const double* ident_d, 
     const int cus = p.multiProcessorCount;
     const int blocks = cus * waves_per_simd;          // 256-thread blocks: 4 waves, one per SIMD
     const int iters = 20000;
-    unsigned long long* out; double* sink;
+    unsigned long long* out; double* sink; uint64_t* splane = nullptr;
     CK(hipMalloc(&out, blocks * 16)); CK(hipMalloc(&sink, (size_t)blocks * 256 * 8));
+    if (MODE == 6 || MODE == 7) CK(hipMalloc(&splane, (size_t)blocks * 4 * 4096 * 8));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(k_mix<MODE>, dim3(blocks), dim3(256), 0, 0, out, sink, ident_d, 200);
+    hipLaunchKernelGGL(k_mix<MODE>, dim3(blocks), dim3(256), 0, 0, out, sink, ident_d, 200, splane);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k_mix<MODE>, dim3(blocks), dim3(256), 0, 0, out, sink, ident_d, iters);
+    hipLaunchKernelGGL(k_mix<MODE>, dim3(blocks), dim3(256), 0, 0, out, sink, ident_d, iters, splane);
     CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     std::vector<unsigned long long> h(blocks * 2); CK(hipMemcpy(h.data(), out, blocks * 16, hipMemcpyDeviceToHost));
@@ -111,7 +215,7 @@ template <int MODE> static int run_mix(const char* name, const double* ident_d, 
     const double ns_per_iter_simd = ms * 1e6 / ((double)iters * waves_per_simd);
     printf("  %-34s waves/SIMD %d: %8.2f ms  %7.1f ns per iteration and SIMD-wave (= %6.1f cycles at 2.4 GHz)  s_memtime/iter %.1f  wall_clock/iter %.2f\n",
            name, waves_per_simd, ms, ns_per_iter_simd, ns_per_iter_simd * 2.4, cyc / iters, wc / iters);
-    CK(hipFree(out)); CK(hipFree(sink));
+    CK(hipFree(out)); CK(hipFree(sink)); if (splane) CK(hipFree(splane));
     return 0;
 }
 
@@ -196,6 +300,16 @@ int main()
         if (run_mix<4>("band rest + 10 s_nop", ident_d, w)) return 1;
         if (run_mix<0>("band rest + 10 v_add_f64", ident_d, w)) return 1;
         if (run_mix<1>("band rest + 10 MFMA", ident_d, w)) return 1;
+        if (run_mix<6>("band (adds) - 4 addc + 2 s_store_x4", ident_d, w)) return 1;
     }
+    printf("ring layouts (instruction-stream mock of the FAST band loop, no walk, no loads):\n");
+    if (run_ring<2, 1, 2, 8>("2 slots/lane, 1 read/wave (shipped)", 1)) return 1;
+    if (run_ring<2, 1, 2, 6>("2 slots/lane, 1 read/wave", 1)) return 1;
+    if (run_ring<2, 1, 2, 4>("2 slots/lane, 1 read/wave", 1)) return 1;
+    if (run_ring<5, 3, 6, 4>("5 slots/lane, 3 reads/wave (21 lanes each)", 3)) return 1;
+    if (run_ring<5, 3, 6, 3>("5 slots/lane, 3 reads/wave (21 lanes each)", 3)) return 1;
+    if (run_ring<5, 3, 6, 5>("5 slots/lane, 3 reads/wave (needs <= 96 registers)", 3)) return 1;
+    if (run_ring<7, 1, 8, 4>("7 slots/lane, 4 reads/wave (16-lane DPP rows)", 4)) return 1;
+    if (run_ring<7, 1, 8, 3>("7 slots/lane, 4 reads/wave (16-lane DPP rows)", 4)) return 1;
     return 0;
 }
