@@ -85,6 +85,89 @@ def prep_host_batch(models, lo, hi, lens, raw, workers):
     return concat_host_batches(out)
 
 
+GENOME_LEN = 5_000_000        # the seeded reference of BASELINE.json configs[2] / the eventalign leg; configs[4]'s reads are placed on it too
+_GENOME = {}                  # (codes uint8, contig str) of the forked workers
+
+
+def bench_genome(n=GENOME_LEN):
+    from nanopolish_amd.synth import BASES
+    codes = np.random.default_rng(0x5EED5).integers(0, 4, n).astype(np.uint8)
+    return codes, BASES[codes].tobytes().decode()
+
+
+def _prep_record_chunk(a):
+    from nanopolish_amd import api
+    from nanopolish_amd.pipeline import build_host_batch_records
+    from nanopolish_amd.synth import synth_cigar_read_fast
+    models, ids, read_len = a
+    codes, contig = _GENOME["g"]
+    recs = []
+    for rid in ids:
+        r = synth_cigar_read_fast(int(rid), codes, models["nucleotide"], span=read_len)
+        recs.append(dict(seq=r["seq"], events=r["events"], shift=r["shift"], scale=r["scale"], var=r["var"], rc=int(r["rc"]), pos=int(r["pos"]),
+                         cigar=api.cigar_words(r["cigar_ops"])))
+    hb = build_host_batch_records(models, recs, contig, with_jobs=False)
+    for r, q in zip(hb["reads"], recs):
+        r["contig"] = None                      # (one contig for all: not pickled once per read)
+    hb["genome"] = None
+    return hb
+
+
+def prep_record_batch(models, lo, hi, read_len, workers):
+    """The N > 1 batch (BASELINE.json configs[4]): reads drawn at uniform origins from the seeded 5 Mb genome, both strands,
+    with substitutions / indels / soft clips and the BAM record an aligner would report (nanopolish_amd/synth.py:synth_cigar_read_fast), from
+    pre-detected events like configs[1]'s.  Work items follow the CIGARs on the device (np_cm_build_jobs_cigar_dev) and the per-site table is
+    keyed by GENOME position: ranks hold overlapping reads, the all-reduce adds their counts site by site."""
+    from nanopolish_amd.pipeline import concat_record_batches
+    _GENOME["g"] = bench_genome()
+    ids = np.arange(lo, hi) + (1 << 26)                       # its own id range
+    chunk = 512
+    parts = [(models, ids[i:i + chunk], read_len) for i in range(0, len(ids), chunk)]
+    if workers > 1 and len(parts) > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(workers, len(parts))) as pool:
+            out = pool.map(_prep_record_chunk, parts)
+    else:
+        out = [_prep_record_chunk(p) for p in parts]
+    g = np.frombuffer(_GENOME["g"][1].encode(), np.uint8).copy()
+    for o in out:
+        o["genome"] = g
+    hb = concat_record_batches(out)
+    hb["contig"] = _GENOME["g"][1]
+    return hb
+
+
+def record_sample_parity(models, hb, batch, rank, n_sample=12):
+    """Genome mode: a sample of this rank's reads through the oracle's restatement of the reference's per-read pass ON THE SAME RECORD
+    (oracle/workloads.py:call_methylation_record -- CIGAR walk, event alignment, recalibration, calculate_methylation_for_read's work items and
+    scores) against the GPU batch: scored sites (genome position, n_motif) identical, LLRs compared."""
+    from oracle import Oracle
+    from oracle.workloads import call_methylation_record
+    orc = Oracle()
+    mn, mc = orc.model(models["nucleotide"]), orc.model(models["cpg"])
+    n = len(hb["reads"])
+    pick = sorted(set(np.linspace(0, n - 1, min(n, n_sample)).astype(int).tolist()))
+    bad_sites, groups, missing, d = 0, 0, 0, []
+    for i in pick:
+        r = hb["reads"][i]
+        want = call_methylation_record(orc, mn, mc, r["seq"], None, r["rc"], r["pos"], r["cigar"], hb["contig"], events=r["events"])
+        first, nm, u, m = batch.groups_of(i)
+        keep = np.isfinite(u)
+        got = {(int(f) + r["pos"], int(k)): (float(uu), float(mm)) for f, k, uu, mm in zip(first[keep], nm[keep], u[keep], m[keep])}
+        exp = {(s_["start"], s_["n_motif"]): (s_["ll_unmeth"], s_["ll_meth"]) for s_ in want["sites"]}
+        groups += len(exp)
+        if set(got) != set(exp):
+            bad_sites += 1
+        for key, (eu, em) in exp.items():
+            if key not in got:
+                missing += 1
+            else:
+                d.append((got[key][1] - got[key][0]) - (em - eu))
+    return dict(rank=rank, reads=len(pick), reads_pairs_differ=bad_sites, groups=groups, groups_missing_on_gpu=missing,
+                max_abs_dLLR=float(np.max(np.abs(d))) if d else None,
+                what="reads_pairs_differ counts reads whose SET of scored sites (genome start, n_motif) differs from the oracle's")
+
+
 # ---- CPU baseline ------------------------------------------------------------------------------------------------------
 def cpu_pass(models, hb, idx, thread_list, calibrate, from_raw, repeats=2):
     """One pass of the hot path on the host over reads hb["reads"][idx]: align + 2 x score per group, OpenMP over reads like
@@ -413,6 +496,10 @@ def main():
     ap.add_argument("--ragged-pool", type=int, default=-1, help="distinct reads of the ragged batch (-1: pool / 2, tile x 2)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="cap on the reads of the CPU baseline (-1: 32 per thread, 0: skip)")
     ap.add_argument("--workers", type=int, default=-1, help="host-preparation worker processes (-1: min(32, cores))")
+    ap.add_argument("--genome", type=int, default=-1,
+                    help="1: the reads have a place on the seeded 5 Mb genome (BAM-style records; work items by CIGAR on the device) and the per-site "
+                         "table is keyed by genome position -- what the ranks of an N > 1 run all-reduce; 0: reads identity-aligned to themselves "
+                         "(configs[1]); -1: 1 at --gpus N > 1, 0 at --gpus 1")
     ap.add_argument("--legs", type=int, default=1,
                     help="1: rank 0 of a one-GPU run also measures BASELINE.json configs[2] (eventalign, 50 000 reads per step) and configs[3] "
                          "(variants, 10 kb x 2 000 reads) and folds them into the line as value_eventalign / value_variants, each with its "
@@ -432,6 +519,12 @@ def main():
         args.pool = 20000 if args.gpus == 1 else 50000
     if args.streamed < 0:
         args.streamed = 1 if args.gpus == 1 else 0
+    if args.genome < 0:
+        args.genome = 1 if args.gpus > 1 else 0
+    if args.genome:
+        if args.from_raw:
+            ap.error("--genome 1 starts from events (configs[4] as configs[1]: pre-detected events); the from-raw chain on records is the eventalign leg")
+        args.streamed = 0; args.ragged = 0; args.legs = 0           # (the host-fed / ragged variants and the other workloads are legs of the identity line)
     models = load_models()
     if args.workload == "cpu-t1":
         # BASELINE.json configs[0]: the CPU plumbing line (-t 1), the reference's own code on one host thread, no GPU
@@ -463,7 +556,7 @@ def main():
     from nanopolish_amd.shard import shard_read_ids
     t_prep = time.perf_counter()
     lo, hi = shard_read_ids(world * args.pool, rank, world)          # reads shard by contiguous id range
-    hb = prep_host_batch(models, lo, hi, args.read_len, bool(args.from_raw), workers)
+    hb = prep_record_batch(models, lo, hi, args.read_len, workers) if args.genome else prep_host_batch(models, lo, hi, args.read_len, bool(args.from_raw), workers)
     hb_rag = None
     if args.ragged:
         rp = args.ragged_pool if args.ragged_pool > 0 else max(1, args.pool // 2)
@@ -472,7 +565,7 @@ def main():
         ids = np.arange(rlo, rhi) + (1 << 24)                          # its own id range
         hb_rag = prep_host_batch(models, int(ids[0]), int(ids[-1]) + 1, ragged_lengths(ids, args.read_len), bool(args.from_raw), workers)
     hb_raw = None
-    if world == 1 and args.legs and not args.from_raw:
+    if world == 1 and args.legs and not args.from_raw and not args.genome:
         # the from-raw leg's pool (int16 traces): 4 000 distinct reads, 25 copies in HBM = the same 100 000 reads per step
         hb_raw = prep_host_batch(models, (1 << 25), (1 << 25) + min(4000, args.pool), args.read_len, True, workers)
     t_prep = time.perf_counter() - t_prep
@@ -536,6 +629,13 @@ def main():
     def device_table(b):
         """per-site table of this rank's reads (the all-reduce payload) from the device-resident scores and group metadata
         (np_site_table_dev); skipped groups and unused group slots carry NaN scores"""
+        if args.genome:
+            # keyed (contig, start, end) on the resident genome: [genome length, 6] int32 (np_site_table_genome_dev); the count of groups cut on
+            # both sides rides in the last row's spare cells so that ONE all-reduce carries everything
+            t, ovf = b.genome_site_table()
+            ctx.sync()
+            b.site_overflow = ovf
+            return t
         t = site_table_dev(ctx, torch, b.d_scores, b.d_first, b.d_n_motif, b.max_len)     # on the library's stream, after the steps
         ctx.sync()
         return t
@@ -577,7 +677,12 @@ def main():
 
     dt = max_over_ranks(dt)
     if table is None:
+        t1 = time.perf_counter()
         table = device_table(batch)                 # one rank: the same table, outside the timed region
+        torch.cuda.synchronize()
+        t_reduce = time.perf_counter() - t1         # (reported per rank as table_and_allreduce_ms: the table kernel alone here)
+    batch_overflow = getattr(batch, "site_overflow", None)
+    ovf_total = int(all_reduce(batch_overflow.clone(), dist.ReduceOp.SUM).item()) if batch_overflow is not None else None      # (every rank takes part)
     k_ms = {}
     for name, w in (("event_align", 0), ("hmm_score", 1), ("glue_and_work_items", 2), ("event_detect", 4), ("mom_scalings", 5)):
         k_ms[name] = ctx.kernel_time(w)
@@ -644,10 +749,13 @@ def main():
         if world > 1:
             dist.barrier(group=host_group)
 
-    if world > 1 and args.cpu_sample != 0:
+    if args.genome and args.cpu_sample != 0:
+        rank_check = record_sample_parity(models, hb, batch, rank)          # every rank, its own shard, the oracle on the same records
+        host_barrier()
+    elif world > 1 and args.cpu_sample != 0:
         rank_check = rank_sample_parity(models, hb, batch, bool(args.calibrate), bool(args.from_raw), rank, max(1, cores // world))
         host_barrier()
-    if rank == 0 and args.cpu_sample != 0:
+    if rank == 0 and args.cpu_sample != 0 and not args.genome:
         budget = args.cpu_sample if args.cpu_sample > 0 else 1 << 30
         cpu, cb = cpu_baseline(models, hb, bool(args.calibrate), bool(args.from_raw), budget)
         # parity of the GPU results with the CPU pass on that sample: pairs bit-exact, LLR within 1e-4
@@ -719,13 +827,17 @@ def main():
                      check=dict(reads=int(g[8]), reads_pairs_differ=int(g[9]), groups=int(g[10]), groups_missing_on_gpu=int(g[11]),
                                 max_abs_dLLR=(g[12] if g[12] >= 0 else None)) if g[8] else None) for g in gathered]
     shard_check = None
-    if world > 1 and any(pr["check"] for pr in per_rank):
+    if (world > 1 or args.genome) and any(pr["check"] for pr in per_rank):
         cks = [pr["check"] for pr in per_rank if pr["check"]]
         dls = [c["max_abs_dLLR"] for c in cks if c["max_abs_dLLR"] is not None]
         shard_check = dict(ranks_checked=len(cks), reads=sum(c["reads"] for c in cks), reads_pairs_differ=sum(c["reads_pairs_differ"] for c in cks),
                            groups=sum(c["groups"] for c in cks), groups_missing_on_gpu=sum(c["groups_missing_on_gpu"] for c in cks),
                            max_abs_dLLR=max(dls) if dls else None,
-                           what="every rank: 32 reads of its own shard, GPU pairs and LLRs against the CPU pass")
+                           what=("every rank: 12 reads of its own shard through the oracle's restatement of the reference's per-read pass on the same BAM "
+                                 "record (reads_pairs_differ: reads whose set of scored genome sites differs), LLRs compared" if args.genome else
+                                 "every rank: 32 reads of its own shard, GPU pairs and LLRs against the CPU pass"))
+        if args.genome and max_dllr is None:
+            max_dllr = shard_check["max_abs_dLLR"]
 
     # ---------------- BASELINE.json configs[2] and configs[3], folded into the line (one GPU, rank 0) ----------------
     legs = None
@@ -811,7 +923,12 @@ def main():
                           roofline_issue=pmc_lookup.roofline_issue("hmm_forward", "call", h_s * CLOCK_HZ * N_SIMD / calls, "np_hmm_forward_kernel"))
         # the configuration this line is quoted on (BASELINE.json): one GPU = configs[1] (100 000 reads per step); N GPUs = configs[4]
         # (250 000 reads per rank and step: "2M synthetic R9.4 reads sharded across 8 x MI355X", one all-reduce of the per-site table)
-        if world == 1 and n_reads == 100000:
+        if args.genome:
+            workload_name = ("call-methylation, %s synthetic R9.4 reads placed on a seeded %.0f Mb genome (BAM-style records, both strands, indels / clips; "
+                             "%d per rank and step) sharded across %dxMI355X, one RCCL all-reduce of the per-site table keyed by genome position "
+                             "(BASELINE.json configs[4]%s)" % ("2M" if world * n_reads == 2000000 else "%dk" % (world * n_reads // 1000), GENOME_LEN / 1e6, n_reads, world,
+                                                               "" if world == 8 and n_reads == 250000 else ": its shape on %d GPU(s), %d reads per rank" % (world, n_reads)))
+        elif world == 1 and n_reads == 100000:
             workload_name = "call-methylation, 100k synthetic R9.4 reads (~8k events each), r9.4_450bps CpG model (BASELINE.json configs[1])"
         elif world > 1 and n_reads == 250000:
             workload_name = ("call-methylation, %s synthetic R9.4 reads sharded across %dxMI355X (250 000 per rank and step), RCCL reduction of the "
@@ -828,6 +945,7 @@ def main():
                                read_len=args.read_len, mean_events=round(mean_events, 1), jobs_on_device=bool(args.jobs_on_device),
                                groups_per_step_per_gpu=res["n_groups"], reads_aligned_ok=res["n_ok"],
                                calibrate_on_device=bool(args.calibrate), from_raw_signal=bool(args.from_raw),
+                               genome_records=bool(args.genome),
                                map_stop=False,   # base_to_event_map[].stop is not built in this step: call-methylation never reads it (the CPU baseline does build it)
                                parallelism="reads sharded over %d GPU(s), 1 process/GPU" % world),
                    cpg_site_groups_per_s=round(world * res["n_groups"] * args.steps / dt, 1),
@@ -839,7 +957,20 @@ def main():
             out["shard_check"] = shard_check
         if legs:
             out.update(legs)
-        if table is not None:
+        if table is not None and args.genome:
+            # keys (contig, start, end): columns 0-2 by start (the group ends where its genome cluster ends), 3-5 by end (a read that stops inside a
+            # cluster).  The genome's own cluster count beside it: every cluster some read spans with its flanks shows up as a key.
+            from nanopolish_amd.sites import motif_sites
+            hit = np.flatnonzero(motif_sites(_GENOME["g"][1].encode(), [0, GENOME_LEN]))
+            n_clusters = int(1 + (np.diff(hit) > 10).sum()) if len(hit) else 0
+            out["site_table"] = dict(keyed_by="(contig, start, end) on the genome", sites=int((table[:, 0] > 0).sum().item() + (table[:, 3] > 0).sum().item()),
+                                     sites_keyed_by_end=int((table[:, 3] > 0).sum().item()), genome_cpg_sites=int(len(hit)), genome_cpg_groups=n_clusters,
+                                     num_reads=int(table[:, 0].sum().item() + table[:, 3].sum().item()),
+                                     called_sites=int(table[:, 1].sum().item() + table[:, 4].sum().item()),
+                                     called_sites_methylated=int(table[:, 2].sum().item() + table[:, 5].sum().item()),
+                                     groups_cut_on_both_sides=ovf_total, table_bytes_per_rank=int(table.numel() * 4),
+                                     max_reads_on_one_site=int(table[:, 0].max().item()))
+        elif table is not None:
             out["site_table"] = dict(sites=int((table[:, 0] > 0).sum().item()), num_reads=int(table[:, 0].sum().item()),
                                      called_sites=int(table[:, 1].sum().item()), called_sites_methylated=int(table[:, 2].sum().item()))
         print(json.dumps(out), flush=True)

@@ -270,6 +270,24 @@ int np_site_table_dev(np_ctx* ctx, void* stream, int64_t n_groups, const float* 
                       const int32_t* n_motif, const np_hmm_job_dev* jobs, const int64_t* read_base, double call_threshold,
                       int64_t n_pos, int32_t* table);
 
+/* The same aggregation for reads that overlap on a genome, keyed as the reference keys a site: (contig, start, end) of the group
+ * (src/nanopolish_call_methylation.cpp:532-550; scripts/calculate_methylation_frequency.py:16-23: `key = (c, start, end)`).  A read's groups are the
+ * genome's clusters of motif sites (gaps <= min_separation, src/basemods/nanopolish_basemods.cpp:306-320) cut by the read's segment, so a read that ends
+ * or starts inside a cluster reports a group with another end or start -- a key of its own in the script.
+ *   first_site / last_site : per group, relative to the read's reference segment (what np_cm_build_jobs_cigar_dev writes)
+ *   read_base   : int64[n_reads], genome offset of every read's segment (np_cm_build_jobs_cigar_dev's ref_begin); jobs: the read of group g
+ *   genome / contig_off / n_contigs : the resident contigs (bytes, concatenated) and int64[n_contigs + 1] offsets: clusters do not cross contigs
+ *   alphabet    : 1 cpg, 2 gpc, 3 dam, 4 dcm (np_cm_build_jobs_*_dev's numbering);  min_separation: the builder's (10)
+ *   table       : int32[n_pos][6], ACCUMULATED into (zero it first).  Columns 0-2 = (num_reads, called_sites, called_sites_methylated) of the key
+ *                 (start = row, end = the end of start's cluster); columns 3-5 = the same for the key (start = the start of end's cluster, end = row)
+ *                 with an end BEFORE the cluster's.  Every key a read longer than one cluster can produce is one of the two.
+ *   n_overflow  : uint64, device, ACCUMULATED: groups cut on both sides (left out of the table).
+ * The table is the payload of the job's only inter-GPU exchange, one all-reduce(sum). */
+int np_site_table_genome_dev(np_ctx* ctx, void* stream, int64_t n_groups, const float* scores, const int32_t* first_site, const int32_t* last_site,
+                             const int32_t* n_motif, const np_hmm_job_dev* jobs, const int64_t* read_base, const char* genome,
+                             const int64_t* contig_off, int n_contigs, int alphabet, int min_separation, double call_threshold, int64_t n_pos,
+                             int32_t* table, uint64_t* n_overflow);
+
 /* Read-level glue between the two kernels (src/nanopolish_squiggle_read.cpp:161-186,273-301):
  * builds base_to_event_map[].start for every read from kernel A's pairs, events_per_base and the
  * HMM transitions, then resolves each work item's event bounds

@@ -781,6 +781,23 @@ int np_site_table_dev(np_ctx* c, void* stream, int64_t n_groups, const float* sc
     return NP_OK;
 }
 
+int np_site_table_genome_dev(np_ctx* c, void* stream, int64_t n_groups, const float* scores, const int32_t* first_site, const int32_t* last_site,
+                             const int32_t* n_motif, const np_hmm_job_dev* jobs, const int64_t* read_base, const char* genome,
+                             const int64_t* contig_off, int n_contigs, int alphabet, int min_separation, double call_threshold, int64_t n_pos,
+                             int32_t* table, uint64_t* n_overflow)
+{
+    if (!c || n_groups < 0 || n_pos < 0 || n_contigs < 1 || min_separation < 0 || alphabet < 1 || alphabet > 4 ||
+        (n_groups > 0 && (!scores || !first_site || !last_site || !n_motif || !jobs || !read_base || !genome || !contig_off || !table || !n_overflow)))
+        return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
+    family_timer tm(c, 2, s);
+    NP_HIP(c, np_launch_site_table_genome(n_groups, scores, first_site, last_site, n_motif, jobs, read_base, genome, contig_off, n_contigs, alphabet,
+                                          min_separation, call_threshold, n_pos, table, (unsigned long long*)n_overflow, s));
+    return NP_OK;
+}
+
 int np_hmm_score_set_combine_dev(np_ctx* c, void* stream, int64_t n_sets, const int64_t* set_off, const int64_t* member_idx,
                                  const float* member_scores, float* out_scores)
 {

@@ -8,6 +8,7 @@
 //                           (src/nanopolish_squiggle_read.cpp:332)
 //   * np_classify_kernel  : bins HMM work items into the (lanes, blocks-per-lane) size classes of np_hmm_kernels.hip
 #include "np_kernels.h"
+#include "np_motif.h"
 #include "np_logf.h"
 #include "np_log.h"
 
@@ -675,29 +676,81 @@ namespace {
 // printf's "%.2lf" is the correctly rounded (ties to even) decimal of the exact binary value: r = RN(100 x) as an integer,
 // corrected by the exact residual 100 x - r (one fma: x is a difference of two floats, so 100 x - r is representable);
 // float(text) is then the double nearest to r / 100, i.e. the correctly rounded quotient.
-__global__ void __launch_bounds__(256) np_site_table_kernel(int64_t n_groups, const float* scores, const int32_t* first_site,
-                                                            const int32_t* n_motif, const np_hmm_job_dev* jobs, const int64_t* read_base,
-                                                            double call_threshold, int64_t n_pos, int32_t* table)
+// The TSV's "%.2lf" round trip of the log-likelihood ratio and the frequency script's call rule
+// (src/nanopolish_call_methylation.cpp:531-550, scripts/calculate_methylation_frequency.py:41-49): false = the group does not count
+__device__ __forceinline__ bool site_call(float u, float m, int nm, double call_threshold, bool& methylated)
 {
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= n_groups) return;
-    const float u = scores[2 * g], m = scores[2 * g + 1];
     const double x = (double)m - (double)u;
-    if (!(__builtin_fabs(x) < __builtin_inf())) return;                 // NaN: a skipped group; +-inf never passes a real run
+    if (!(__builtin_fabs(x) < __builtin_inf())) return false;           // NaN: a skipped group; +-inf never passes a real run
     double r = __builtin_rint(x * 100.0);
     const double e = __builtin_fma(x, 100.0, -r);
     const bool odd = __builtin_fmod(__builtin_fabs(r), 2.0) == 1.0;
     if (e > 0.5 || (e == 0.5 && odd)) r += 1.0;
     else if (e < -0.5 || (e == -0.5 && odd)) r -= 1.0;
     const double llr = r / 100.0;
+    if (__builtin_fabs(llr) < call_threshold * (double)nm) return false; // ambiguous call
+    methylated = llr > 0;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) np_site_table_kernel(int64_t n_groups, const float* scores, const int32_t* first_site,
+                                                            const int32_t* n_motif, const np_hmm_job_dev* jobs, const int64_t* read_base,
+                                                            double call_threshold, int64_t n_pos, int32_t* table)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_groups) return;
     const int nm = n_motif[g];
-    if (__builtin_fabs(llr) < call_threshold * (double)nm) return;      // ambiguous call
+    bool meth;
+    if (!site_call(scores[2 * g], scores[2 * g + 1], nm, call_threshold, meth)) return;
     int64_t row = first_site[g];
     if (read_base) row += read_base[jobs[2 * g].read];
     if (row < 0 || row >= n_pos) return;
     atomicAdd(&table[3 * row], 1);
     atomicAdd(&table[3 * row + 1], nm);
-    if (llr > 0) atomicAdd(&table[3 * row + 2], nm);
+    if (meth) atomicAdd(&table[3 * row + 2], nm);
+}
+
+// The same aggregation keyed as the reference keys it: (contig, start, end) of the group (nanopolish_call_methylation.cpp:532-550;
+// calculate_methylation_frequency.py:16-23 -- `key = (c, start, end)`), for reads that OVERLAP on a genome.  A read's groups are its motif sites
+// chained by gaps <= min_separation (basemods.cpp:306-320), i.e. the intersection of a GENOME cluster with the read's segment: a read that ends
+// (or starts) inside a cluster reports a shorter group with another end (start), and the script counts that key on its own.  Two dense tables
+// hold every such key without a hash: a group whose end IS its cluster's end is keyed by its start (columns 0-2: for a given start that end is
+// unique); a group with its cluster's start but an earlier end is keyed by its end (columns 3-5); a group cut on both sides -- a read shorter than
+// one cluster -- is counted in *n_overflow and left out (none in any run so far).  Whether a position ends / starts its cluster is read off the
+// resident genome: no motif site within min_separation after / before it, inside the contig.
+__global__ void __launch_bounds__(256) np_site_table_genome_kernel(int64_t n_groups, const float* scores, const int32_t* first_site, const int32_t* last_site,
+                                                                   const int32_t* n_motif, const np_hmm_job_dev* jobs, const int64_t* read_base,
+                                                                   const char* genome, const int64_t* contig_off, int n_contigs, int alphabet,
+                                                                   int min_separation, double call_threshold, int64_t n_pos, int32_t* table,
+                                                                   unsigned long long* n_overflow)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_groups) return;
+    const int nm = n_motif[g];
+    bool meth;
+    if (!site_call(scores[2 * g], scores[2 * g + 1], nm, call_threshold, meth)) return;
+    const int64_t base = read_base[jobs[2 * g].read];
+    const int64_t s = base + first_site[g], e = base + last_site[g];
+    if (s < 0 || e >= n_pos || e < s) return;
+    int lo = 0, hi = n_contigs;                                            // the contig that holds s: contig_off[lo] <= s < contig_off[lo + 1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (contig_off[mid] <= s) lo = mid; else hi = mid; }
+    const int64_t c0 = contig_off[lo];
+    const int clen = (int)(contig_off[lo + 1] - c0);
+    const char* ref = genome + c0;
+    const sites_t S = sites_of(alphabet);
+    const int ls = (int)(s - c0), le = (int)(e - c0);
+    bool end_is_clusters = true, start_is_clusters = true;
+    for (int d = 1; d <= min_separation; ++d) {
+        if (site_at(ref, 0, clen, le + d, S) >= 0) end_is_clusters = false;
+        if (site_at(ref, 0, clen, ls - d, S) >= 0) start_is_clusters = false;
+    }
+    int32_t* row;
+    if (end_is_clusters) row = table + 6 * s;
+    else if (start_is_clusters) row = table + 6 * e + 3;
+    else { atomicAdd(n_overflow, 1ull); return; }
+    atomicAdd(row, 1);
+    atomicAdd(row + 1, nm);
+    if (meth) atomicAdd(row + 2, nm);
 }
 
 // profile_hmm_score_set's combination (src/hmm/nanopolish_profile_hmm.cpp:41-55): score = (+)_j (score_j - log n) with
@@ -730,6 +783,17 @@ hipError_t np_launch_site_table(int64_t n_groups, const float* scores, const int
     if (n_groups <= 0) return hipSuccess;
     hipLaunchKernelGGL(np_site_table_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, n_groups, scores, first_site,
                        n_motif, jobs, read_base, call_threshold, n_pos, table);
+    return hipGetLastError();
+}
+
+hipError_t np_launch_site_table_genome(int64_t n_groups, const float* scores, const int32_t* first_site, const int32_t* last_site, const int32_t* n_motif,
+                                       const np_hmm_job_dev* jobs, const int64_t* read_base, const char* genome, const int64_t* contig_off, int n_contigs,
+                                       int alphabet, int min_separation, double call_threshold, int64_t n_pos, int32_t* table,
+                                       unsigned long long* n_overflow, hipStream_t s)
+{
+    if (n_groups <= 0) return hipSuccess;
+    hipLaunchKernelGGL(np_site_table_genome_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, n_groups, scores, first_site, last_site,
+                       n_motif, jobs, read_base, genome, contig_off, n_contigs, alphabet, min_separation, call_threshold, n_pos, table, n_overflow);
     return hipGetLastError();
 }
 

@@ -136,6 +136,21 @@ def concat_host_batches(parts):
     return out
 
 
+def concat_record_batches(parts):
+    """Join record batches (build_host_batch_records) built against the SAME contig(s), e.g. by a pool of worker processes: the genome stays
+    one copy, every per-read array is concatenated and the offsets shifted."""
+    if len(parts) == 1:
+        return parts[0]
+    out = concat_host_batches([{k_: v for k_, v in p.items()} for p in parts])
+    nc = np.cumsum([0] + [len(p["cigar"]) for p in parts])
+    out["cigar"] = np.concatenate([p["cigar"] for p in parts])
+    out["cigar_off"] = np.concatenate([p["cigar_off"][:-1] + nc[i] for i, p in enumerate(parts)] + [[nc[-1]]]).astype(np.int64)
+    for key in ("ref_begin", "ref_len", "read_len", "deg_kpos"):
+        out[key] = np.concatenate([p[key] for p in parts])
+    assert all(len(p["genome"]) == len(parts[0]["genome"]) for p in parts), "record batches of different contigs"
+    return out
+
+
 def build_host_batch_records(models, records, contig, k=6, alphabet="cpg", with_jobs=True):
     """Host-side preparation of a batch of reads given EXPLICITLY, each with its raw signal and the BAM record of its
     base-to-reference alignment: records = dicts(seq: the read's own sequence, raw: float32 samples, rc: bam_is_rev,
@@ -143,7 +158,10 @@ def build_host_batch_records(models, records, contig, k=6, alphabet="cpg", with_
     reference the records align to (those without their own).
     The batch starts from raw signal (from_raw) and its work items follow the CIGARs: the host builder's
     items are in hb["jobs"] / hb["kpos"]; the device builder needs hb["cigar"], hb["ref_begin"], ... (same numbering).
-    with_jobs=False: no methylation work items (an eventalign-only batch, e.g. direct-RNA reads: k = 5, base model u_to_t_rna)."""
+    with_jobs=False: no methylation work items (an eventalign-only batch, e.g. direct-RNA reads: k = 5, base model u_to_t_rna).
+    Round 6: a record may carry pre-detected `events` (float32 means, with its `shift` / `scale` / `var`) INSTEAD of `raw`: the batch then starts
+    from events (from_raw=False), MoM scalings taken here on the host as build_host_batch does -- the call-methylation step of the bench on reads
+    that have a place on a genome."""
     L_ = _l.load_library()
     from .synth import nucleotide_kmer_ranks
     lut = np.zeros(256, np.int64); lut[ord("C")] = 1; lut[ord("G")] = 2; lut[ord("T")] = 3
@@ -153,8 +171,14 @@ def build_host_batch_records(models, records, contig, k=6, alphabet="cpg", with_
         cs = r.get("contig", contig)
         if cs not in contig_base:
             contig_base[cs] = sum(len(x) for x in contigs); contigs.append(cs)
+    from_events = len(records) > 0 and "events" in records[0]
     for r in records:
         codes = lut[np.frombuffer(r["seq"].encode(), np.uint8)]
+        if from_events:
+            reads.append(dict(seq=r["seq"], rc=bool(r["rc"]), ranks=nucleotide_kmer_ranks(codes, k), events=np.ascontiguousarray(r["events"], np.float32),
+                              shift=float(r.get("shift", 0.0)), scale=float(r.get("scale", 1.0)), var=float(r.get("var", 1.0)),
+                              pos=int(r["pos"]), cigar=np.ascontiguousarray(r["cigar"], np.uint32), contig=r.get("contig", contig)))
+            continue
         reads.append(dict(seq=r["seq"], rc=bool(r["rc"]), raw=np.ascontiguousarray(r["raw"], np.float32), ranks=nucleotide_kmer_ranks(codes, k),
                           events=np.zeros(len(r["raw"]) // 2 + 2, np.float32), shift=0.0, scale=1.0, var=1.0,
                           pos=int(r["pos"]), cigar=np.ascontiguousarray(r["cigar"], np.uint32), contig=r.get("contig", contig)))
@@ -166,9 +190,12 @@ def build_host_batch_records(models, records, contig, k=6, alphabet="cpg", with_
     deg = np.zeros((n, 2), np.int32)
     ref_begin = np.zeros(n, np.int64); ref_len = np.zeros(n, np.int32)
     jr_off = 0
+    mom = np.zeros((n, 2))
     for i, r in enumerate(reads):
-        for arr in (reads_a, reads_b):
-            L_.np_fill_read_host(C.cast(arr[i:i + 1].ctypes.data, C.POINTER(_l.ReadDev)), 0.0, 1.0, 1.0,
+        sh, sc = api.estimate_scalings_using_mom(models["nucleotide"], r["ranks"], r["events"]) if from_events else (0.0, 1.0)
+        mom[i] = (sh, sc)
+        for arr, (shift, scale, var) in ((reads_a, (sh, sc, 1.0)), (reads_b, (r["shift"], r["scale"], r["var"]))):
+            L_.np_fill_read_host(C.cast(arr[i:i + 1].ctypes.data, C.POINTER(_l.ReadDev)), shift, scale, var,
                                  int(event_off[i]), len(r["events"]), int(rank_off[i]), len(r["ranks"]))
         # the segment calculate_methylation_for_read fetches: contig[pos .. bam_endpos] inclusive, clipped (basemods.cpp:259-270)
         span = int(sum(int(w) >> 4 for w in r["cigar"] if (int(w) & 0xf) in (0, 2, 3, 7, 8)))
@@ -197,11 +224,14 @@ def build_host_batch_records(models, records, contig, k=6, alphabet="cpg", with_
         jranks.append(jb["ranks_unmeth"]); jranks.append(jb["ranks_meth"])
         jr_off += 2 * tot
         meta.append(dict(first=jb["first"], last=jb["last"], n_motif=jb["n_motif"]))
-    raw_off = np.zeros(n + 1, np.int64); raw_off[1:] = np.cumsum([len(r["raw"]) for r in reads])
     cigar_off = np.zeros(n + 1, np.int64); cigar_off[1:] = np.cumsum([len(r["cigar"]) for r in reads])
+    extra = {}
+    if not from_events:
+        raw_off = np.zeros(n + 1, np.int64); raw_off[1:] = np.cumsum([len(r["raw"]) for r in reads])
+        extra = dict(raw=np.concatenate([r["raw"] for r in reads]), raw_off=raw_off)
+    contig_off = np.concatenate([[0], np.cumsum([len(x) for x in contigs])]).astype(np.int64)
     return dict(reads=reads, n=n, events=np.concatenate([r["events"] for r in reads]), ranks=np.concatenate([r["ranks"] for r in reads]).astype(np.uint16),
-                event_off=event_off, rank_off=rank_off, reads_a=reads_a, reads_b=reads_b, mom=np.zeros((n, 2)), ref_seqs=ref_seqs, k=k,
-                raw=np.concatenate([r["raw"] for r in reads]), raw_off=raw_off,
+                event_off=event_off, rank_off=rank_off, reads_a=reads_a, reads_b=reads_b, mom=mom, ref_seqs=ref_seqs, k=k, contig_off=contig_off, **extra,
                 jobs=np.concatenate(jobs) if jobs else np.zeros(0, JOB_DT),
                 kpos=np.concatenate(kpos).astype(np.int32) if kpos else np.zeros((0, 2), np.int32),
                 job_ranks=np.concatenate(jranks).astype(np.uint16) if jranks else np.zeros(0, np.uint16),
@@ -311,7 +341,7 @@ class CallMethylationBatch:
             # per-read capacity offsets (groups are > min_separation apart), two work items per slot
             MINSEP, FLANK = 10, 10
             seqs = hb["ref_seqs"]
-            ln = np.array([len(q) for q in seqs], np.int64)
+            ln = np.asarray(hb["ref_len"], np.int64) if self.by_cigar else np.array([len(q) for q in seqs], np.int64)
 
             self.seq_off = np.zeros(self.n_reads + 1, np.int64); self.seq_off[1:] = np.cumsum(ln)
             gcap = ln // (MINSEP + 1) + 2
@@ -320,7 +350,8 @@ class CallMethylationBatch:
             jr_off = np.zeros(self.n_reads + 1, np.int64); jr_off[1:] = np.cumsum(rcap)
             self.n_slots = int(self.group_off[-1])
             self.n_jobs = 2 * self.n_slots
-            self.d_seq = up(np.frombuffer("".join(seqs).encode(), np.uint8).copy()); self.d_seq_off = up(self.seq_off)
+            if not self.by_cigar:          # (the CIGAR builder reads the resident contigs through ref_begin / ref_len)
+                self.d_seq = up(np.frombuffer("".join(seqs).encode(), np.uint8).copy()); self.d_seq_off = up(self.seq_off)
             self.d_rc = up(np.array([r["rc"] for r in hb["reads"]] * (self.n_reads // len(hb["reads"])), np.uint8))
             self.d_group_off = up(self.group_off); self.d_jr_off = up(jr_off)
             self.d_jobs = torch.zeros(self.n_jobs * JOB_DT.itemsize, dtype=torch.uint8, device=dev)
@@ -549,6 +580,18 @@ class CallMethylationBatch:
     def calibrated(self):
         self.sync()
         return self.d_calibrated.cpu().numpy()
+
+    def genome_site_table(self, out=None, overflow=None, call_threshold=2.0):
+        """The batch's per-site table keyed (contig, start, end) on the resident contigs (np_site_table_genome_dev; sites.site_table_genome_dev):
+        needs a record batch with work items built on the device.  Returns (table int32 [genome length, 6], overflow [1])."""
+        assert self.by_cigar and self.jobs_on_device, "genome-keyed table: a record batch (build_host_batch_records) with jobs_on_device=True"
+        from .sites import site_table_genome_dev
+        if not hasattr(self, "d_contig_off"):
+            self.d_contig_off = self.torch.from_numpy(np.ascontiguousarray(self.hb["contig_off"], np.int64)).to(self.d_scores.device)
+        i32 = lambda t: t.view(self.torch.int32) if t.dtype == self.torch.uint8 else t
+        return site_table_genome_dev(self.ctx, self.torch, self.d_scores, self.d_first, self.d_last, self.d_n_motif, self.d_jobs,
+                                     self.d_ref_begin.view(self.torch.int64), self.d_genome, self.d_contig_off, alphabet=self.alphabet,
+                                     min_separation=self.cm[0], call_threshold=call_threshold, stream=self.stream, out=out, overflow=overflow)
 
     def event_map(self):
         self.sync()

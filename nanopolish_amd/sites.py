@@ -39,3 +39,109 @@ def site_table(torch, first, n_motif, llr, n_pos, call_threshold=2.0):
     table[:, 1].index_add_(0, idx, nm)
     table[:, 2].index_add_(0, idx, meth)
     return table
+
+
+# ---- genome-keyed table: reads that overlap on a reference, keyed (contig, start, end) as the reference keys a site ---------------------
+# (src/nanopolish_call_methylation.cpp:532-550, scripts/calculate_methylation_frequency.py:16-23,41-49).  table: int32 [n_pos, 6];
+# columns 0-2 = (num_reads, called_sites, called_sites_methylated) of the key (start = row, end = the end of start's genome cluster),
+# columns 3-5 = the same for the key (start = the start of end's cluster, end = row) whose end comes BEFORE the cluster's (a read that stops
+# inside a cluster).  np_site_table_genome_dev in include/np_hmm.h has the argument for why these two are all the keys there are.
+MOTIFS = {"cpg": ("CG",), "gpc": ("GC",), "dam": ("GATC",), "dcm": ("CCAGG", "CCTGG")}
+
+
+def site_table_genome_dev(ctx, torch, scores, first, last, n_motif, jobs, read_base, genome, contig_off, alphabet="cpg", min_separation=10,
+                          call_threshold=2.0, stream=None, out=None, overflow=None):
+    """The genome-keyed table of a batch on the device (np_site_table_genome_dev).  scores: float32, 2 per group (NaN = skipped); first / last /
+    n_motif: int32 per group, segment-relative; jobs: the batch's work items (2 per group: the read of a group); read_base: int64 per read, the
+    genome offset of its segment; genome: uint8 device tensor (the contigs, concatenated); contig_off: int64 device tensor [n_contigs + 1].
+    Returns (table int32 [n_pos, 6], overflow uint64-as-int64 [1]); accumulates into `out` / `overflow` when given."""
+    from . import api
+    n_groups = first.numel()
+    n_pos = int(genome.numel())
+    fresh = out is None or overflow is None
+    table = out if out is not None else torch.zeros((n_pos, 6), dtype=torch.int32, device=scores.device)
+    ovf = overflow if overflow is not None else torch.zeros(1, dtype=torch.int64, device=scores.device)
+    if fresh:
+        torch.cuda.current_stream().synchronize()        # the zero-fill ran on torch's stream, the kernel runs on the library's
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    rc = ctx.L.np_site_table_genome_dev(ctx.h, C.c_void_p(stream) if stream else None, n_groups, p(scores), p(first), p(last), p(n_motif), p(jobs),
+                                        p(read_base), p(genome), p(contig_off), int(contig_off.numel()) - 1, api.alphabet_id(alphabet),
+                                        int(min_separation), float(call_threshold), n_pos, p(table), p(ovf))
+    ctx._chk(rc, "np_site_table_genome_dev")
+    return table, ovf
+
+
+def motif_sites(genome, contig_off, alphabet="cpg"):
+    """bool array over the concatenated contigs: a recognition site of the alphabet STARTS here and lies inside its contig
+    (Alphabet::is_motif_match on the contig, src/common/nanopolish_alphabet.h)"""
+    import numpy as np
+    g = genome if isinstance(genome, (bytes, bytearray)) else bytes(genome)
+    hit = np.zeros(len(g), bool)
+    for c in range(len(contig_off) - 1):
+        lo, hi = int(contig_off[c]), int(contig_off[c + 1])
+        seq = g[lo:hi]
+        for m in MOTIFS[alphabet]:
+            mb = m.encode(); i = seq.find(mb)
+            while i >= 0:
+                hit[lo + i] = True
+                i = seq.find(mb, i + 1)
+    return hit
+
+
+def _cluster_bounds(hit, contig_off, min_separation):
+    """per motif site: (start, end) of its genome cluster -- sites chained by gaps <= min_separation inside one contig (basemods.cpp:306-320)"""
+    import numpy as np
+    cstart = np.full(len(hit), -1, np.int64); cend = np.full(len(hit), -1, np.int64)
+    for c in range(len(contig_off) - 1):
+        pos = np.flatnonzero(hit[int(contig_off[c]):int(contig_off[c + 1])]) + int(contig_off[c])
+        if len(pos) == 0:
+            continue
+        brk = np.flatnonzero(np.diff(pos) > min_separation)
+        starts = np.concatenate([[0], brk + 1]); ends = np.concatenate([brk, [len(pos) - 1]])
+        for a, b in zip(starts, ends):
+            cstart[pos[a:b + 1]] = pos[a]; cend[pos[a:b + 1]] = pos[b]
+    return cstart, cend
+
+
+def site_table_genome(torch, start, end, n_motif, llr, genome, contig_off, alphabet="cpg", min_separation=10, call_threshold=2.0):
+    """Host mirror of site_table_genome_dev (CPU; the checker of the device kernel and the per-rank table of the gloo tests).  start / end: int64
+    GENOME positions of every group's first / last motif site; llr: float64 (NaN = skipped).  The text round trip IS printf here.
+    Returns (table int32 [n_pos, 6], overflow int)."""
+    import numpy as np
+    hit = motif_sites(genome, contig_off, alphabet)
+    cstart, cend = _cluster_bounds(hit, contig_off, min_separation)
+    n_pos = len(hit)
+    table = torch.zeros((n_pos, 6), dtype=torch.int32)
+    vals = llr.detach().cpu().tolist()
+    llr2 = np.array([float("%.2f" % v) if v == v and abs(v) != float("inf") else float("nan") for v in vals], np.float64)
+    s = start.cpu().numpy().astype(np.int64); e = end.cpu().numpy().astype(np.int64); nm = n_motif.cpu().numpy().astype(np.int64)
+    keep = np.isfinite(llr2) & ~(np.abs(llr2) < call_threshold * nm) & (s >= 0) & (e < n_pos) & (e >= s)
+    overflow = 0
+    t = table.numpy()
+    for i in np.flatnonzero(keep):
+        if cend[s[i]] == e[i]:
+            row, col = s[i], 0
+        elif cstart[e[i]] == s[i]:
+            row, col = e[i], 3
+        else:
+            overflow += 1
+            continue
+        t[row, col] += 1; t[row, col + 1] += nm[i]
+        if llr2[i] > 0:
+            t[row, col + 2] += nm[i]
+    return table, overflow
+
+
+def genome_table_rows(table, genome, contig_off, alphabet="cpg", min_separation=10):
+    """The keys of a genome-keyed table as the frequency script lists them: sorted [(start, end, num_reads, called_sites, called_sites_methylated)]
+    with GENOME positions (the caller maps them to (contig, position))."""
+    import numpy as np
+    t = table.cpu().numpy()
+    hit = motif_sites(genome, contig_off, alphabet)
+    cstart, cend = _cluster_bounds(hit, contig_off, min_separation)
+    rows = []
+    for r in np.flatnonzero(t[:, 0] > 0):
+        rows.append((int(r), int(cend[r]), int(t[r, 0]), int(t[r, 1]), int(t[r, 2])))
+    for r in np.flatnonzero(t[:, 3] > 0):
+        rows.append((int(cstart[r]), int(r), int(t[r, 3]), int(t[r, 4]), int(t[r, 5])))
+    return sorted(rows)

@@ -82,12 +82,13 @@ def methylation_jobs_record(orc, rc, read_length, cigar, pos, ref_seq, map_start
     return jobs
 
 
-def call_methylation_record(orc, mn, m_meth, read_seq, raw, rc, pos, cigar, contig, alphabet="cpg"):
+def call_methylation_record(orc, mn, m_meth, read_seq, raw, rc, pos, cigar, contig, alphabet="cpg", events=None):
     """The reference's whole per-read pass restated on the oracle, from raw signal and a BAM record:
     SquiggleRead::load_from_raw (src/nanopolish_squiggle_read.cpp:189-336: detect_events, MoM scalings, event alignment,
     base_to_event_map, recalibrate_model, QC gates) then calculate_methylation_for_read.
     mn / m_meth: oracle model handles (nucleotide / the methylation alphabet's).  Returns a dict with the read-level state
-    (events, scalings, events_per_base, event map) and the scored sites in ascending start position."""
+    (events, scalings, events_per_base, event map) and the scored sites in ascending start position.
+    events: pre-detected event means (raw is then ignored): the same pass from the event table on, as a read loaded from an events file."""
     L = len(read_seq)
     codes = np.frombuffer(read_seq.encode(), np.uint8)
     lut = np.zeros(256, np.int64); lut[ord("C")] = 1; lut[ord("G")] = 2; lut[ord("T")] = 3
@@ -97,8 +98,11 @@ def call_methylation_record(orc, mn, m_meth, read_seq, raw, rc, pos, cigar, cont
     for j in range(K):                                           # Alphabet::kmer_rank of every read k-mer (nucleotide)
         ranks = ranks * 4 + c[j:j + n_kmers]
     ranks = ranks.astype(np.uint32)
-    ev = orc.detect_events(raw)
-    events = ev["mean"] if isinstance(ev, dict) else ev[0]
+    if events is None:
+        ev = orc.detect_events(raw)
+        events = ev["mean"] if isinstance(ev, dict) else ev[0]
+    else:
+        events = np.ascontiguousarray(events, np.float32)
     out = dict(n_events=0, events=events, scalings=None, epb=0.0, map_start=None, map_stop=None, sites=[], jobs=[])
     sh, sc = orc.estimate_scalings_mom(mn, ranks, events)
     pairs = orc.event_align(mn, orc.scalings(sh, sc, 1.0), events, ranks)

@@ -116,3 +116,69 @@ def test_score_set_combination_on_the_device(ctx, orc, models):
         assert np.array_equal(d_out.cpu().numpy(), want)
     for q, s in enumerate(sets):
         assert want[q] == np.float32(orc.combine_score_set(singles[off[q]:off[q + 1]]))
+
+
+def _genome_batch(ctx, models, n_reads, G, span, seed=0x9E0, tile=1, first_id=0):
+    from nanopolish_amd import api
+    from nanopolish_amd.synth import synth_cigar_read_fast, BASES
+    from nanopolish_amd.pipeline import build_host_batch_records, tile_host_batch, CallMethylationBatch
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(0, 4, G).astype(np.uint8)
+    for i in rng.integers(0, G - 1, G // 12):                  # CpG-rich: clusters of several sites, so that reads end inside clusters
+        genome[i] = 1; genome[i + 1] = 2
+    contig = BASES[genome].tobytes().decode()
+    recs = []
+    for rid in range(first_id, first_id + n_reads):
+        r = synth_cigar_read_fast(rid, genome, models["nucleotide"], span=span)
+        recs.append(dict(seq=r["seq"], events=r["events"], shift=r["shift"], scale=r["scale"], var=r["var"], rc=int(r["rc"]), pos=int(r["pos"]),
+                         cigar=api.cigar_words(r["cigar_ops"])))
+    hb = build_host_batch_records(models, recs, contig, with_jobs=False)
+    b = CallMethylationBatch(ctx, tile_host_batch(hb, tile), "cuda:0", calibrate=True, from_raw=False, jobs_on_device=True, map_stop=False)
+    return contig, recs, hb, b
+
+
+def test_genome_keyed_site_table_on_the_device(ctx, orc, models):
+    """Round 6.  Reads with a PLACE on a genome (BAM-style records: position, CIGAR with substitutions / indels / clips, both
+    strands), from pre-detected events, through the step the bench times -- work items by CIGAR on the device, alignment, recalibration, scoring --
+    then np_site_table_genome_dev.  (a) every read's scored sites (genome start / end, n_motif, both log-likelihoods) equal the oracle's
+    calculate_methylation_for_read restatement on the same record, bit for bit; (b) the device table equals the host mirror fed with the ORACLE's
+    sites -- the mirror itself is pinned to the reference's frequency script by tests/test_output.py -- including the keys of reads that stop
+    inside a cluster (columns 3-5); (c) a tiled batch (every read twice) gives exactly twice the table; nothing overflows."""
+    import torch
+    from oracle.workloads import call_methylation_record
+    from nanopolish_amd.sites import site_table_genome, genome_table_rows
+    G = 24000
+    contig, recs, hb, b = _genome_batch(ctx, models, 36, G, 1500)
+    b.step()
+    table, ovf = b.genome_site_table()
+    ctx.sync()
+    mn, mc = orc.model(models["nucleotide"]), orc.model(models["cpg"])
+    S, E, NM, LLR = [], [], [], []
+    n_sites = 0
+    for i, r in enumerate(recs):
+        want = call_methylation_record(orc, mn, mc, r["seq"], None, r["rc"], r["pos"], r["cigar"], contig, events=r["events"])
+        first, nm, u, m = b.groups_of(i)
+        keep = np.isfinite(u)
+        got = [(int(f) + r["pos"], int(k), float(uu), float(mm)) for f, k, uu, mm in zip(first[keep], nm[keep], u[keep], m[keep])]
+        exp = [(s["start"], s["n_motif"], s["ll_unmeth"], s["ll_meth"]) for s in want["sites"]]
+        assert got == exp, "read %d" % i
+        n_sites += len(exp)
+        for s in want["sites"]:
+            S.append(s["start"]); E.append(s["end"]); NM.append(s["n_motif"]); LLR.append(np.float64(np.float32(s["ll_meth"])) - np.float64(np.float32(s["ll_unmeth"])))
+    assert n_sites > 1500
+    contig_off = np.array([0, G], np.int64)
+    want_t, want_ovf = site_table_genome(torch, torch.tensor(S), torch.tensor(E), torch.tensor(NM), torch.tensor(LLR, dtype=torch.float64),
+                                         contig.encode(), contig_off)
+    assert int(ovf.cpu()[0]) == 0 and want_ovf == 0
+    t = table.cpu().numpy()
+    assert np.array_equal(t, want_t.numpy())
+    assert (t[:, 0] > 1).sum() > 50                      # sites seen by several overlapping reads
+    assert (t[:, 3] > 0).sum() >= 1                      # a read that stops inside a cluster: a key of its own, as in the frequency script
+    rows = genome_table_rows(table, contig.encode(), contig_off)
+    assert sum(r[2] for r in rows) == int(t[:, 0].sum() + t[:, 3].sum())
+    del b
+    contig2, recs2, hb2, b2 = _genome_batch(ctx, models, 36, G, 1500, tile=2)
+    b2.step()
+    t2, ovf2 = b2.genome_site_table()
+    ctx.sync()
+    assert np.array_equal(t2.cpu().numpy(), 2 * t) and int(ovf2.cpu()[0]) == 0

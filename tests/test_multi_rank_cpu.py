@@ -57,6 +57,62 @@ def test_two_rank_site_reduction_equals_single_process(tmp_path):
     assert torch.equal(got, want)
 
 
+# ---- the genome-keyed reduction (round 6): ranks hold reads that OVERLAP on the same contigs ---------------------------------------------
+def _genome_rank_table(lo, hi):
+    """per-rank table of the golden generator's reads lo..hi-1 (records grouped by read), keyed (contig, start, end) -- sites.site_table_genome"""
+    from gen_golden_frequency import synthetic_genome_calls
+    from nanopolish_amd.sites import site_table_genome
+    lines, recs, contigs = synthetic_genome_calls()
+    contig_off = np.concatenate([[0], np.cumsum([len(c) for c in contigs])]).astype(np.int64)
+    # the generator emits records read by read: recover the read of every record from the TSV lines (column 4 = read name)
+    names = [ln.split("\t")[4] for ln in lines[1:]]
+    assert len(names) == len(recs)
+    mine = [r for r, nme in zip(recs, names) if lo <= int(nme.split("_")[1]) < hi]
+    t = lambda f, dt: torch.tensor([f(r) for r in mine], dtype=dt)
+    table, ovf = site_table_genome(torch, t(lambda r: int(contig_off[r["contig"]]) + r["start_position"], torch.int64),
+                                   t(lambda r: int(contig_off[r["contig"]]) + r["end_position"], torch.int64), t(lambda r: r["n_motif"], torch.int64),
+                                   t(lambda r: (r["ll_methylated"][0] + r["ll_methylated"][1]) - (r["ll_unmethylated"][0] + r["ll_unmethylated"][1]), torch.float64),
+                                   "".join(contigs).encode(), contig_off)
+    assert ovf == 0
+    return table, contigs, contig_off
+
+
+def _gworker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_read_ids(70, rank, world)
+    t = reduce_site_table(_genome_rank_table(lo, hi)[0])
+    if rank == 0:
+        torch.save(t, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_genome_keyed_reduction_equals_the_reference_script(tmp_path):
+    """70 reads that overlap on two contigs, sharded over two ranks by read id; each rank's table is keyed by GENOME position
+    ((contig, start, end), the two-column-block layout of np_site_table_genome_dev), one all-reduce(sum) -- the N > 1 line's only collective.
+    The reduced table equals the single-process one and, key by key, what scripts/calculate_methylation_frequency.py printed for all 70
+    reads' calls (tests/golden/golden_frequency_genome.tsv): sites covered by reads of BOTH ranks add up."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from nanopolish_amd.sites import genome_table_rows
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "gtable.pt")
+    mp.spawn(_gworker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    want, contigs, contig_off = _genome_rank_table(0, 70)
+    assert torch.equal(got, want)
+    a, _, _ = _genome_rank_table(0, 35); b, _, _ = _genome_rank_table(35, 70)
+    assert int(((a[:, 0] > 0) & (b[:, 0] > 0)).sum()) > 20            # keys both ranks contribute to
+    gold = []
+    for ln in open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_frequency_genome.tsv")).read().splitlines()[1:]:
+        f = ln.split("\t")
+        base = int(contig_off[int(f[0][len("contig"):]) - 1])
+        gold.append((base + int(f[1]), base + int(f[2]), int(f[4]), int(f[5])))
+    rows = [(s_, e_, c_, m_) for s_, e_, _, c_, m_ in genome_table_rows(got, "".join(contigs).encode(), contig_off)]
+    assert rows == sorted(gold)
+
+
 # ---- variants (BASELINE config 4): per-variant totals over reads, reads sharded over ranks -----------------------------------
 N_VREADS = 6
 

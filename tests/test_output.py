@@ -59,3 +59,49 @@ def test_device_site_table_equals_text_aggregation():
         assert table[s, 1] == called and table[s, 2] == meth
         seen += 1
     assert seen > 30 and int((table[:, 1] > 0).sum()) == seen
+
+
+def _genome_case():
+    import torch
+    from gen_golden_frequency import synthetic_genome_calls
+    lines, recs, contigs = synthetic_genome_calls()
+    contig_off = np.concatenate([[0], np.cumsum([len(c) for c in contigs])]).astype(np.int64)
+    genome = "".join(contigs).encode()
+    start = torch.tensor([contig_off[r["contig"]] + r["start_position"] for r in recs], dtype=torch.int64)
+    end = torch.tensor([contig_off[r["contig"]] + r["end_position"] for r in recs], dtype=torch.int64)
+    nm = torch.tensor([r["n_motif"] for r in recs], dtype=torch.int64)
+    llr = torch.tensor([(r["ll_methylated"][0] + r["ll_methylated"][1]) - (r["ll_unmethylated"][0] + r["ll_unmethylated"][1]) for r in recs],
+                       dtype=torch.float64)
+    return lines, recs, contigs, contig_off, genome, start, end, nm, llr
+
+
+def _golden_genome_rows(contig_off):
+    want = []
+    for ln in open(os.path.join(GOLD, "golden_frequency_genome.tsv")).read().splitlines()[1:]:
+        f = ln.split("\t")
+        base = int(contig_off[int(f[0][len("contig"):]) - 1])
+        want.append((base + int(f[1]), base + int(f[2]), int(f[4]), int(f[5])))
+    return sorted(want)
+
+
+def test_genome_keyed_site_table_equals_reference_script_on_overlapping_reads():
+    """Round 6: reads that overlap on a genome, keyed (contig, start, end) as scripts/calculate_methylation_frequency.py:16-23
+    keys them.  Reads that stop or start inside a cluster of sites report groups with another end / start: keys of their own in the script,
+    columns 3-5 / a different row of the two-table layout here.  The host mirror's rows equal the reference script's output (golden), key by
+    key, over two contigs (a CG across the contig boundary is not a site); nothing overflows."""
+    import torch
+    from nanopolish_amd.sites import site_table_genome, genome_table_rows
+    lines, recs, contigs, contig_off, genome, start, end, nm, llr = _genome_case()
+    assert "".join(lines) == open(os.path.join(GOLD, "golden_calls_genome.tsv")).read()
+    assert calculate_methylation_frequency(lines) == open(os.path.join(GOLD, "golden_frequency_genome.tsv")).read().splitlines()
+    table, overflow = site_table_genome(torch, start, end, nm, llr, genome, contig_off)
+    assert overflow == 0
+    got = [(s, e, called, meth) for s, e, _, called, meth in genome_table_rows(table, genome, contig_off)]
+    want = _golden_genome_rows(contig_off)
+    assert got == want and len(want) > 100
+    t = table.numpy()
+    assert (t[:, 3] > 0).sum() >= 3 and (t[:, 0] > 0).sum() > 100          # both key forms occur
+    starts = {}
+    for s, e, _, _ in want:
+        starts.setdefault(s, set()).add(e)
+    assert any(len(v) > 1 for v in starts.values())                       # one start, several ends: what a start-keyed table would merge

@@ -19,4 +19,30 @@ O=gpurun_out/r06b; mkdir -p $O
 tail -5 $O/pytest.log; grep "waves/SIMD 8" $O/probe.log; cat $O/valu_l.log; cat $O/align_ab.log; head -c 600 $O/bench.json; tail -3 $O/bench.err
 }
 
+show_line() {      # rank 0's JSON line of a bench run: value, site table, shard check, per-rank rates
+python - "$1" <<'PYEOF'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(d["value"], d["ms_per_step"], d["n_gpus"], d["config"]["workload"][:100]); print(d.get("site_table")); print(d.get("shard_check"))
+    print([(p["rank"], p["value"], p["table_and_allreduce_ms"]) for p in d["per_rank"]]); print(d["roofline"]["kernel_ms_per_step"])
+except Exception as e:
+    print("no line:", e)
+PYEOF
+}
+
+# the genome-keyed N > 1 line: the new GPU tests, then bench.py in genome mode -- one rank small; 2 and 8 ranks over gloo on the
+# one device of the lease (NP_BENCH_BACKEND=gloo: the N > 1 code path with host-side collectives); one rank at configs[4]'s 250 000 reads
+call_d() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r06d; mkdir -p $O
+( time timeout 900 python -m pytest tests/test_gpu_sites.py tests/test_gpu_events.py tests/test_gpu_jobs.py -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+( time timeout 600 python bench.py --gpus 1 --genome 1 --pool 2000 --tile 5 --steps 3 --warmup 1 ) > $O/genome_n1_small.json 2> $O/genome_n1_small.err; echo "rc=$?" >> $O/genome_n1_small.err
+( time NP_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --pool 2000 --tile 5 --steps 3 --warmup 1 ) > $O/genome_gloo2.json 2> $O/genome_gloo2.err; echo "rc=$?" >> $O/genome_gloo2.err
+( time NP_BENCH_BACKEND=gloo timeout 1200 python bench.py --gpus 8 --pool 1000 --tile 5 --steps 3 --warmup 1 --cpu-sample 0 ) > $O/genome_gloo8.json 2> $O/genome_gloo8.err; echo "rc=$?" >> $O/genome_gloo8.err
+( time timeout 1500 python bench.py --gpus 1 --genome 1 --pool 50000 --tile 5 --steps 3 --warmup 1 ) > $O/genome_n1_250k.json 2> $O/genome_n1_250k.err; echo "rc=$?" >> $O/genome_n1_250k.err
+tail -5 $O/pytest.log
+for f in genome_n1_small genome_gloo2 genome_gloo8 genome_n1_250k; do echo "== $f"; tail -4 $O/$f.err; show_line $O/$f.json; done
+}
+
 "call_$1"
