@@ -173,7 +173,8 @@ def test_genome_keyed_site_table_on_the_device(ctx, orc, models):
     t = table.cpu().numpy()
     assert np.array_equal(t, want_t.numpy())
     assert (t[:, 0] > 1).sum() > 50                      # sites seen by several overlapping reads
-    assert (t[:, 3] > 0).sum() >= 1                      # a read that stops inside a cluster: a key of its own, as in the frequency script
+    # (no key of the second form here: a group cut by its read's end lies within min_flank of that end, and calculate_methylation_for_read's
+    #  window rules drop it -- basemods.cpp:334, alignment_db.cpp:697-708.  test_genome_table_kernel_on_cut_groups feeds the kernel such groups.)
     rows = genome_table_rows(table, contig.encode(), contig_off)
     assert sum(r[2] for r in rows) == int(t[:, 0].sum() + t[:, 3].sum())
     del b
@@ -182,3 +183,48 @@ def test_genome_keyed_site_table_on_the_device(ctx, orc, models):
     t2, ovf2 = b2.genome_site_table()
     ctx.sync()
     assert np.array_equal(t2.cpu().numpy(), 2 * t) and int(ovf2.cpu()[0]) == 0
+
+
+def test_genome_table_kernel_on_cut_groups(ctx):
+    """np_site_table_genome_dev on the golden generator's calls (tests/gen_golden_frequency.py:synthetic_genome_calls): reads on TWO contigs whose
+    groups are cut by the read's start or end -- keys (start', cluster end) and (cluster start, end'), the second form in columns 3-5 -- and
+    LLRs on the text round trip's decision points.  The device table equals the host mirror and, key by key, the REFERENCE SCRIPT's output
+    for the same calls (tests/golden/golden_frequency_genome.tsv)."""
+    import os
+    import torch
+    from gen_golden_frequency import synthetic_genome_calls
+    from nanopolish_amd.pipeline import JOB_DT
+    from nanopolish_amd.sites import site_table_genome, site_table_genome_dev, genome_table_rows
+    lines, recs, contigs = synthetic_genome_calls()
+    contig_off = np.concatenate([[0], np.cumsum([len(c) for c in contigs])]).astype(np.int64)
+    genome = "".join(contigs).encode()
+    dev = torch.device("cuda:0")
+    # every record is its own "read" whose segment starts 7 bases before the group (read_base + segment-relative positions, as the builder writes them)
+    base = np.array([contig_off[r["contig"]] + r["start_position"] - 7 for r in recs], np.int64)
+    first = np.full(len(recs), 7, np.int32)
+    last = np.array([7 + r["end_position"] - r["start_position"] for r in recs], np.int32)
+    nm = np.array([r["n_motif"] for r in recs], np.int32)
+    # device scores are floats: unmethylated 0, methylated = the TSV's own two-decimal text as a float -- its "%.2lf" round trip is that text again,
+    # so the device decides on exactly the numbers the reference script parsed
+    text = np.array([float(ln.split("\t")[5]) for ln in lines[1:]], np.float64)
+    assert len(text) == len(recs)
+    uf = np.zeros(len(recs), np.float32); mf = text.astype(np.float32)
+    llr = mf.astype(np.float64) - uf.astype(np.float64)
+    assert all("%.2f" % a == "%.2f" % b for a, b in zip(llr, text))
+    jobs = np.zeros(2 * len(recs), JOB_DT); jobs["read"] = np.repeat(np.arange(len(recs), dtype=np.uint32), 2)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+    sc = np.stack([uf, mf], 1).reshape(-1)
+    table, ovf = site_table_genome_dev(ctx, torch, up(sc).view(torch.float32), up(first).view(torch.int32), up(last).view(torch.int32), up(nm).view(torch.int32),
+                                       up(jobs), up(base).view(torch.int64), up(np.frombuffer(genome, np.uint8)), up(contig_off).view(torch.int64))
+    ctx.sync()
+    t = lambda a, dt: torch.tensor(a, dtype=dt)
+    want, want_ovf = site_table_genome(torch, t(base + 7, torch.int64), t(base + last, torch.int64), t(nm, torch.int64), t(llr, torch.float64), genome, contig_off)
+    got = table.cpu().numpy()
+    assert np.array_equal(got, want.numpy()) and int(ovf.cpu()[0]) == want_ovf == 0
+    assert (got[:, 3] > 0).sum() >= 3 and (got[:, 0] > 0).sum() > 100
+    gold = []
+    for ln in open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_frequency_genome.tsv")).read().splitlines()[1:]:
+        f = ln.split("\t")
+        b = int(contig_off[int(f[0][len("contig"):]) - 1])
+        gold.append((b + int(f[1]), b + int(f[2]), int(f[4]), int(f[5])))
+    assert [(s_, e_, c_, m_) for s_, e_, _, c_, m_ in genome_table_rows(table, genome, contig_off)] == sorted(gold)
