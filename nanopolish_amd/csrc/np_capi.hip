@@ -409,7 +409,7 @@ np_ctx* np_create(int device, const np_params* params)
     if (const char* v = getenv("NP_ALIGN_BLOCKS_PER_CU")) c->align_blocks_per_cu = std::max(1, atoi(v));
     if (const char* v = getenv("NP_HMM_BLOCKS_PER_CU")) c->hmm_blocks_per_cu = std::max(1, atoi(v));
     if (const char* v = getenv("NP_ALIGN_LPT")) c->align_lpt = atoi(v) != 0;
-    if (const char* v = getenv("NP_RECAL_SHAPE")) c->recal_shape = std::max(0, std::min(2, atoi(v)));
+    if (const char* v = getenv("NP_RECAL_SHAPE")) c->recal_shape = std::max(0, std::min(3, atoi(v)));
     if (const char* v = getenv("NP_ED_WARMUP")) c->ed_warmup = atoi(v);
     if (const char* v = getenv("NP_EA_WAVES_PER_CU")) c->ea_waves_per_cu = std::max(1, atoi(v));
     if (const char* v = getenv("NP_EA_WALK_PRIO")) c->ea_walk_prio = atoi(v);
@@ -1361,7 +1361,7 @@ int np_set_option(np_ctx* c, const char* name, int64_t value)
     else if (k == "hmm_prio") c->hmm_prio = (int)std::min<int64_t>(2, std::max<int64_t>(0, value));
     else if (k == "hmm_blocks_per_cu") c->hmm_blocks_per_cu = (int)std::max<int64_t>(1, value);
     else if (k == "align_lpt") c->align_lpt = value != 0;
-    else if (k == "recal_shape") c->recal_shape = (int)std::min<int64_t>(2, std::max<int64_t>(0, value));
+    else if (k == "recal_shape") c->recal_shape = (int)std::min<int64_t>(3, std::max<int64_t>(0, value));
     else if (k == "stream_switch_wait") c->stream_switch_wait = value != 0;
     else if (k == "small_batch_path") c->small_batch_path = value != 0;
     else if (k == "ed_warmup") c->ed_warmup = (int)value;

@@ -321,6 +321,172 @@ __global__ void __launch_bounds__(64 * W) np_recalibrate_kernel(int n_reads, np_
     }
 }
 
+// Round 6.  The kernel above holds 148 736 B of LDS per 512-thread workgroup -- the 64 KB table plus 83 KB of term tiles --
+// so a CU runs ONE workgroup, two waves per SIMD, and those waves wait on a counter for 54 % of their cycles (profiles/r05_glue.md).  The table
+// cannot shrink (two doubles per state: the model's levels are decimal fractions); the tiles can: here a chunk is 32 k-mers and the two HALVES
+// of a wave form the terms of two different reads at once (lanes 0-31: read 2p, lanes 32-63: read 2p + 1), so a read's tile is 5 x 33 doubles
+// instead of 5 x 65 and SIXTEEN waves of four reads fit beside the table (84 480 + 65 536 B): one 1 024-thread workgroup = four waves per
+// SIMD.  Per 64 k-mers of a read the wave issues what it issued before -- half as many term-forming instructions per chunk (each covers two
+// reads), twice as many chunks, the ordered additions 32 at a time -- and the terms, their order and every rounding are unchanged.
+template <int W, int R>
+__global__ void __launch_bounds__(64 * W) np_recalibrate_half_kernel(int n_reads, np_read_dev* reads, const float* event_mean,
+                                                                     const uint16_t* ranks, const np_state_dev* model, int n_states,
+                                                                     const int32_t* n_pairs, const int32_t* map_start,
+                                                                     int32_t* calibrated, const uint32_t* order)
+{
+    static_assert(R % 2 == 0 && 5 * R <= 64, "reads per wave: an even number, five adder lanes each");
+    constexpr int P = R / 2, CH = 32;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int half = lane >> 5, hl = lane & 31;
+    __shared__ double terms[W][R][5][CH + 1];
+    __shared__ double2 table[NP_RC_STATES];                     // .x = level_mean, .y = 1 / level_stdv^2 (pass 0) or level_stdv^2 (pass 1)
+    int ri[R], K[R]; bool live[R];
+    int maxK = 0;
+    // this lane's read of pair p is 2 p + half: its arrays, length and liveness as per-lane values
+    const int32_t* msl[P]; const uint16_t* rkl[P]; const float* evl[P]; int Kl[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { msl[p] = nullptr; rkl[p] = nullptr; evl[p] = nullptr; Kl[p] = 0; }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int slot = (blockIdx.x * W + wave) * R + r;
+        ri[r] = slot < n_reads ? __builtin_amdgcn_readfirstlane(order ? (int)order[slot] : slot) : -1;
+        live[r] = false; K[r] = 0;
+        if (ri[r] >= 0) {
+            if (__builtin_amdgcn_readfirstlane(n_pairs[ri[r]]) <= 0) { if (lane == 0) calibrated[ri[r]] = 0; }
+            else {
+                const np_read_dev* rd = reads + ri[r];
+                live[r] = true; K[r] = __builtin_amdgcn_readfirstlane((int)rd->n_kmers);
+                const int64_t ro = uniform_i64(rd->rank_off), eo = uniform_i64(rd->event_off);
+                if (half == (r & 1)) { msl[r >> 1] = map_start + ro; rkl[r >> 1] = ranks + ro; evl[r >> 1] = event_mean + eo; Kl[r >> 1] = K[r]; }
+                maxK = K[r] > maxK ? K[r] : maxK;
+            }
+        }
+    }
+    double shift[R], scale[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { shift[r] = 0.0; scale[r] = 0.0; }
+    int nl[P];                                                   // 'M' entries of this lane's read of pair p so far (equal in all lanes of a half)
+#pragma unroll
+    for (int p = 0; p < P; ++p) nl[p] = 0;
+    const int sr0 = lane / 5, sc0 = lane - 5 * sr0;             // pass 0: lane 5 r + c owns sum c of read r; pass 1: lane r owns read r's residual sum
+    const uint32_t below = (1u << hl) - 1u;
+    double acc = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) __syncthreads();                          // every wave is done with the first pass's table
+        for (int q = threadIdx.x; q < n_states; q += 64 * W) {
+            const double ls = model[q].level_stdv, v = ls * ls;
+            table[q] = double2{model[q].level_mean, pass == 0 ? 1. / v : v};
+        }
+        __syncthreads();
+        int carry[P];                                            // prev_kmer_rank = -1 (squiggle_read.cpp:351), per half
+        double shl[P], scl[P];                                   // this lane's read's shift / scale (pass 1)
+#pragma unroll
+        for (int p = 0; p < P; ++p) { carry[p] = -1; shl[p] = half ? shift[2 * p + 1] : shift[2 * p]; scl[p] = half ? scale[2 * p + 1] : scale[2 * p]; }
+        const double* row = pass == 0 ? &terms[wave][sr0 < R ? sr0 : 0][sc0][0] : &terms[wave][lane < R ? lane : 0][0][0];
+        const bool adder = pass == 0 ? lane < 5 * R : lane < R;
+        // two chunks in flight ahead of the one being consumed (as in the kernel above): chunk c + 2's map entries and ranks, chunk c + 1's event means
+        int st_a[P], rank_a[P];
+        int st_c[P], rank_c[P]; float e_c[P];
+        auto request = [&](int base0) {
+            const int ki = base0 + hl;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const bool in = ki < Kl[p];                      // (a dead read has Kl = 0)
+                st_a[p] = in ? msl[p][ki] : -1;
+                rank_a[p] = in ? (int)rkl[p][ki] : 0;
+            }
+        };
+        auto gather = [&]() {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                st_c[p] = st_a[p]; rank_c[p] = rank_a[p];
+                e_c[p] = st_c[p] != -1 ? evl[p][st_c[p]] : 0.0f;
+            }
+        };
+        request(0);
+        gather();
+        request(CH);
+        for (int base0 = 0; base0 < maxK; base0 += CH) {
+            int st_[P], rank_[P]; float e_[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) { st_[p] = st_c[p]; rank_[p] = rank_c[p]; e_[p] = e_c[p]; }
+            if (base0 + CH < maxK) { gather(); request(base0 + 2 * CH); }
+            unsigned long long any = 0ull;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const bool has = st_[p] != -1;
+                const double2 t = table[rank_[p]];
+                const int rank = has ? rank_[p] : -1;
+                const unsigned long long hm64 = __ballot(has);
+                const uint32_t hm = half ? (uint32_t)(hm64 >> 32) : (uint32_t)hm64;          // the 'has' lanes of this lane's half
+                const uint32_t before = hm & below;
+                const int src = (half << 5) + (before ? 31 - __clz((int)before) : 0);
+                const int prev = __shfl(rank, src, 64);
+                const bool isM = has && rank != (before ? prev : carry[p]);
+                const double mu = t.x, e = (double)e_[p];
+                double t0, t1 = 0., t2 = 0., t3 = 0., t4 = 0.;
+                if (pass == 0) {
+                    const double inv_var = isM ? t.y : 0.0;     // 1. / (ls * ls)
+                    t0 = inv_var; t1 = mu * inv_var; t2 = mu * mu * inv_var; t3 = e * inv_var; t4 = mu * e * inv_var;
+                } else {
+                    const double yi = (e - shl[p] - scl[p] * mu);
+                    t0 = (isM ? yi * yi : 0.0) / t.y;            // / (ls * ls)
+                }
+                double (*tile)[CH + 1] = terms[wave][2 * p + half];
+                tile[0][hl] = t0;
+                if (pass == 0) { tile[1][hl] = t1; tile[2][hl] = t2; tile[3][hl] = t3; tile[4][hl] = t4; }
+                const unsigned long long mm64 = __ballot(isM);
+                nl[p] += __popc(half ? (uint32_t)(mm64 >> 32) : (uint32_t)mm64);
+                any |= mm64;
+                // the rank of the half's last k-mer with events carries into the next chunk
+                const int last = __shfl(rank, (half << 5) + (hm ? 31 - __clz((int)hm) : 0), 64);
+                if (hm) carry[p] = last;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (any && adder) {
+#pragma unroll 16
+                for (int q = 0; q < CH; ++q) acc += row[q];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (pass == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (!live[r]) continue;
+                const int n_r = __builtin_amdgcn_readlane(nl[r >> 1], (r & 1) << 5);
+                if (n_r < 200) {                                 // minNumEventsToRescale: not recalibrated
+                    if (lane == 0) calibrated[ri[r]] = 0;
+                    live[r] = false;
+                    if (half == (r & 1)) Kl[r >> 1] = 0;
+                    continue;
+                }
+                const double a00 = readlane_f64(acc, 5 * r), a01 = readlane_f64(acc, 5 * r + 1), a11 = readlane_f64(acc, 5 * r + 2);
+                const double b0 = readlane_f64(acc, 5 * r + 3), b1 = readlane_f64(acc, 5 * r + 4);
+                fullpivlu_solve_2x2(a00, a01, a01, a11, b0, b1, shift[r], scale[r]);
+            }
+#pragma unroll
+            for (int p = 0; p < P; ++p) nl[p] = 0;
+            acc = 0.0;
+            maxK = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) if (live[r] && K[r] > maxK) maxK = K[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (!live[r]) continue;
+        const int n_r = __builtin_amdgcn_readlane(nl[r >> 1], (r & 1) << 5);
+        double var = readlane_f64(acc, r);
+        var /= (double)(unsigned long long)n_r;
+        var = sqrt(var);
+        if (lane == 0) {
+            np_read_dev* rd = reads + ri[r];
+            rd->shift = shift[r]; rd->scale = scale[r]; rd->var = var; rd->log_var = np_log_glibc(var);   // set4 (squiggle_read.cpp:38-65), glibc's log restated
+            calibrated[ri[r]] = var > 2.5 ? 0 : 1;                                          // MIN_CALIBRATION_VAR (:320)
+        }
+    }
+}
+
 // Thread per work item.  The two sequences of a methylation group (unmethylated, methylated) sit side by side and share their window
 // bounds: the odd lane takes the even lane's result (DPP) instead of repeating the two closest-event searches -- checked per pair, not
 // assumed: neighbours of different reads or bounds each search for themselves.  Only the item's second half (e_start, e_stop, stride,
@@ -838,6 +1004,11 @@ hipError_t np_launch_recalibrate(int n_reads, np_read_dev* reads, const float* e
                                  int32_t* calibrated, const uint32_t* order, int shape, hipStream_t s)
 {
     if (n_reads <= 0) return hipSuccess;
+    if (shape == 3 && n_states <= NP_RC_STATES) {          // round 6: half-wave chunks, sixteen waves x four reads, four waves per SIMD
+        const int nb = (n_reads + 16 * 4 - 1) / (16 * 4);
+        hipLaunchKernelGGL((np_recalibrate_half_kernel<16, 4>), dim3(nb), dim3(1024), 0, s, n_reads, reads, event_mean, ranks, model, n_states, n_pairs, map_start, calibrated, order);
+        return hipGetLastError();
+    }
     if (shape == 1) return launch_recal<16, 2>(n_reads, reads, event_mean, ranks, model, n_states, n_pairs, map_start, calibrated, order, s);
     if (shape == 2) return launch_recal<12, 3>(n_reads, reads, event_mean, ranks, model, n_states, n_pairs, map_start, calibrated, order, s);
     return launch_recal<NP_RC_W, NP_RC_R>(n_reads, reads, event_mean, ranks, model, n_states, n_pairs, map_start, calibrated, order, s);

@@ -360,3 +360,28 @@ def test_variant_screening_scores_match_oracle(ctx, orc, models, lse):
             vg, vw = got[i + v * nr:i + (v + 1) * nr].astype(np.float64), want[i + v * nr:i + (v + 1) * nr].astype(np.float64)
             assert np.sum(vg - base_g) == np.sum(vw - base_w)
         i += nr * len(it["seqs"])
+
+
+def test_recalibration_shapes_agree(ctx, models):
+    """np_recalibrate_kernel's workgroup shapes (option recal_shape): 0 = 8 waves x 4 reads with 64-k-mer chunks, 1 / 2 = 16 x 2 and 12 x 3,
+    3 = round 6's half-wave form (16 waves x 4 reads, 32-k-mer chunks, two reads per chunk: four waves per SIMD beside the 64 KB table).  Every
+    shape forms the same terms and adds them in the same order: shift / scale / var / log_var, the calibrated flags and every score are the
+    same BITS -- on ragged reads (groups of four reads of different length run for the longest), a read too short to calibrate, and more reads
+    than one workgroup holds."""
+    from nanopolish_amd.pipeline import build_host_batch, tile_host_batch, CallMethylationBatch
+    hb = build_host_batch(models, list(range(900, 937)), L=[150, 260, 700] + [900 + 173 * i for i in range(34)], with_jobs=False)
+    res = []
+    try:
+        for shape in (0, 3, 1, 2, 3):
+            ctx.set_option("recal_shape", shape)
+            b = CallMethylationBatch(ctx, tile_host_batch(hb, 3), "cuda:0", calibrate=True, jobs_on_device=True)
+            b.step(); b.step()
+            rds = b.reads_scored()
+            res.append((shape, rds["shift"].tobytes(), rds["scale"].tobytes(), rds["var"].tobytes(), rds["log_var"].tobytes(), b.calibrated().tobytes(),
+                        b.scores().tobytes(), int(np.isfinite(b.scores()).sum()), int(b.calibrated().sum())))
+            del b
+    finally:
+        ctx.set_option("recal_shape", 0)
+    assert res[0][7] > 5000 and 0 < res[0][8] < 3 * 37          # scored items; some reads calibrate, the shortest do not
+    for r in res[1:]:
+        assert r[1:] == res[0][1:], "recal_shape %d differs from shape 0" % r[0]

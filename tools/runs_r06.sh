@@ -45,4 +45,13 @@ tail -5 $O/pytest.log
 for f in genome_n1_small genome_gloo2 genome_gloo8 genome_n1_250k; do echo "== $f"; tail -4 $O/$f.err; show_line $O/$f.json; done
 }
 
+# the half-wave recalibration kernel (recal_shape 3: 16 waves x 4 reads, four waves per SIMD): bit-equality across shapes, then the glue family A/B/A/B
+call_e() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r06e; mkdir -p $O
+( time timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_sites.py -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+( timeout 900 python tools/hmm_ab.py --pool 4000 --tile 25 "@NP_RECAL_SHAPE=0" "@NP_RECAL_SHAPE=3" "@NP_RECAL_SHAPE=0" "@NP_RECAL_SHAPE=3" ) > $O/recal_ab.log 2>&1
+tail -5 $O/pytest.log; cat $O/recal_ab.log
+}
+
 "call_$1"
