@@ -79,7 +79,7 @@ const char* np_ctx_info(const np_ctx* ctx);
  * a longer segment ends its read with NP_EA_OVERFLOW), "ea_waves_per_cu" (persistent grid of the chain kernel), "lse_oor" (0: the forward kernel clamps its log-sum table index;
  * 1: it relies on the LDS out-of-range rule, the default when np_create's probe passes and refused (NP_ERR_UNSUPPORTED) when it did not --
  * scores never depend on it), "hmm_prio" (wave priority of the forward kernels, 0 ... 2),
- * "recal_shape" (np_calibrate_resolve_dev's workgroup shape, 0: default, 1 ... 3: the alternatives it was measured against -- results never depend on it), "small_batch_path"
+ * "recal_shape" (np_calibrate_resolve_dev's workgroup shape, 3: the default -- sixteen waves x four reads, 32-k-mer chunks --, 0 ... 2: the shapes it was measured against; results never depend on it), "small_batch_path"
  * (1: np_hmm_score_host sends a small batch as one pinned blob; 0: the general path -- the tests compare the two).
  * Environment, read at np_create (each the option of the same name): NP_ALIGN_BLOCKS_PER_CU, NP_HMM_BLOCKS_PER_CU, NP_ALIGN_LPT, NP_ED_WARMUP,
  * NP_EA_WAVES_PER_CU, NP_RECAL_SHAPE; NP_EA_WALK_PRIO=1 runs the chain kernel's back-track at wave priority 3 (measured slower,

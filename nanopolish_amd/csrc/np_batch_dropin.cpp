@@ -114,8 +114,8 @@ struct Pass {
     int dev;                                // index into Impl::devs
     Blob in, out;
     void *ev_h2d, *ev_cmp, *ev_d2h;
-    std::map<int, std::string> union_seq;   // tid -> the reference stretch the pass's records on that contig cover
-    std::map<int, int> union_lo;
+    std::map<int, std::shared_ptr<const std::string> > union_seq;   // tid -> the reference stretch the pass's records on that contig cover (shared with
+    std::map<int, int> union_lo;                                    // the packer's stretch cache: alive for as long as any pass's views point into it)
     std::vector<int64_t> group_off;         // group slots of the pass's device records
     size_t o_scores, o_first, o_last, o_n_motif, o_n_groups, o_n_events, o_n_pairs, o_calibrated, out_bytes;   // offsets into `out`
     int unfinished;                         // member batches whose maps are not built yet (under Impl::m): 0 = free for the packer
@@ -166,6 +166,12 @@ struct NpBatchPipeline::Impl {
     std::mutex m; std::condition_variable cv;
     long n_submitted, n_packed, n_claimed, n_finished, n_collected;      // batches that have passed each stage (under m); n_claimed: taken by a finisher
     bool stop;
+    // Round 6: the reference stretches the packer fetched last, one per contig (packer thread only; cleared by configure()).  Consecutive passes of
+    // a sorted BAM cover overlapping stretches, and faidx_fetch_seq -- serial, under the reference's lock, a line-by-line copy out of the FASTA --
+    // was 10 of the 15 ms phase 1a took per 8 192-record pass: a pass whose span lies inside the cached stretch fetches nothing, one that reaches
+    // past it fetches the union (while that stays under the 64 MB a pass may hold) and replaces the entry.
+    struct RefStretch { int lo, hi; std::shared_ptr<const std::string> seq; };
+    std::map<int, RefStretch> ref_cache;
     std::mutex tm; double t[8];
     // which pool worker allocated the map of a record handed out by collect(): recycle() sends every map back to ITS worker, so that a
     // heap block is freed by the thread that allocated it (glibc keeps an arena per thread: a free from another thread takes that
@@ -289,6 +295,7 @@ void NpBatchPipeline::configure(const MethylationCallingParameters& calling_para
 {
     if (in_flight() != 0) die("NpBatchPipeline::configure with batches in flight");
     p->params = calling_parameters; p->kit = kit; p->fai = fai; p->hdr = hdr; p->region_start = region_start; p->region_end = region_end;
+    p->ref_cache.clear();                    // (another FASTA index may stand behind the same contig ids)
 }
 
 int NpBatchPipeline::in_flight() const { std::lock_guard<std::mutex> g(p->m); return (int)(p->n_submitted - p->n_collected); }
@@ -478,9 +485,23 @@ void NpBatchPipeline::Impl::pack(const std::vector<Slot*>& group, int dev)
     for (std::map<int, std::pair<int, int> >::const_iterator it = span.begin(); it != span.end(); ++it) {
         const int64_t len = (int64_t)it->second.second - it->second.first + 1;
         if (len <= (64 << 20) && len <= 4 * covered[it->first] + (1 << 20)) {
-            int fetched_len = 0;
-            P.union_seq[it->first] = get_reference_region_ts(fai, hdr->target_name[it->first], it->second.first, it->second.second, &fetched_len);
-            P.union_lo[it->first] = it->second.first;
+            int lo = it->second.first, hi = it->second.second;
+            std::map<int, RefStretch>::iterator ce = ref_cache.find(it->first);
+            if (ce != ref_cache.end() && ce->second.lo <= lo && hi <= ce->second.hi) {          // inside the cached stretch: nothing to fetch
+                P.union_seq[it->first] = ce->second.seq; P.union_lo[it->first] = ce->second.lo;
+            } else {
+                if (ce != ref_cache.end() && std::max(hi, ce->second.hi) - (int64_t)std::min(lo, ce->second.lo) + 1 <= (64 << 20) &&
+                    lo <= ce->second.hi + 1 && ce->second.lo <= hi + 1) { lo = std::min(lo, ce->second.lo); hi = std::max(hi, ce->second.hi); }
+                int fetched_len = 0;
+                RefStretch st;
+                st.lo = lo; st.hi = hi;
+                st.seq = std::make_shared<const std::string>(get_reference_region_ts(fai, hdr->target_name[it->first], lo, hi, &fetched_len));
+                size_t held = 0;
+                for (std::map<int, RefStretch>::const_iterator q = ref_cache.begin(); q != ref_cache.end(); ++q) held += q->second.seq->size();
+                if (held + st.seq->size() > ((size_t)512 << 20)) ref_cache.clear();              // (a bound on what the cache keeps alive)
+                ref_cache[it->first] = st;
+                P.union_seq[it->first] = st.seq; P.union_lo[it->first] = lo;
+            }
         }
     }
     for (int q = 0; q < n; ++q) {                          // records no union serves: the reference's own per-record fetch (serial: faidx)
@@ -495,12 +516,12 @@ void NpBatchPipeline::Impl::pack(const std::vector<Slot*>& group, int dev)
     pool->run(n, 32, [&](int q) {
         Slot& S = *idx[q].S; const int i = idx[q].i;
         const bam1_t* record = rd(q).record;
-        std::map<int, std::string>::const_iterator u = P.union_seq.find(record->core.tid);
+        std::map<int, std::shared_ptr<const std::string> >::const_iterator u = P.union_seq.find(record->core.tid);
         RefView v;
         if (u != P.union_seq.end()) {
             const int64_t off = (int64_t)record->core.pos - P.union_lo.find(record->core.tid)->second, want = (int64_t)bam_endpos(record) - record->core.pos + 1;
-            const int64_t have = (int64_t)u->second.size() - off;
-            if (have > 0) { v.p = u->second.data() + off; v.n = (size_t)std::min(want, have); }
+            const int64_t have = (int64_t)u->second->size() - off;
+            if (have > 0) { v.p = u->second->data() + off; v.n = (size_t)std::min(want, have); }
         } else { v.p = S.own_seq[i].data(); v.n = S.own_seq[i].size(); }
         bool plain = true;
         for (size_t t = 0; t < v.n; ++t) if (base_code(v.p[t]) > 3) { plain = false; break; }

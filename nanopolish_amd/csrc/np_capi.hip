@@ -91,7 +91,7 @@ struct np_ctx {
     bool host_constants = false;      // the per-read constants that go through libm are computed on the HOST with the process's own log / exp / logf (np_create)
     double* d_log_n = nullptr;        // host_constants: log(1 .. 64) for profile_hmm_score_set's penalty
     np_slots lay = {nullptr, nullptr, 0}; int64_t lay_total = 0;   // np_set_job_layout: the slot layout of the work-item arrays of the calls that follow
-    int recal_shape = 0;              // np_recalibrate_kernel's workgroup shape (0: default; 1, 2: A/B alternatives, same results)
+    int recal_shape = 3;              // the recalibration kernel's workgroup shape (3: round 6's half-wave form, the default; 0 ... 2: rounds 5's shapes, same results)
     int align_lpt = 1;                // issue the event aligner's reads longest first
     int stream_switch_wait = 1;       // a call on a new stream waits for the tail of the stream the context used before (0: the caller orders its streams itself)
     int ed_warmup = -1;               // parallel peak walk: samples of warm-up per segment (< 0: the kernel's default)

@@ -381,7 +381,7 @@ def test_recalibration_shapes_agree(ctx, models):
                         b.scores().tobytes(), int(np.isfinite(b.scores()).sum()), int(b.calibrated().sum())))
             del b
     finally:
-        ctx.set_option("recal_shape", 0)
+        ctx.set_option("recal_shape", 3)
     assert res[0][7] > 5000 and 0 < res[0][8] < 3 * 37          # scored items; some reads calibrate, the shortest do not
     for r in res[1:]:
         assert r[1:] == res[0][1:], "recal_shape %d differs from shape 0" % r[0]
