@@ -54,4 +54,13 @@ O=gpurun_out/r06e; mkdir -p $O
 tail -5 $O/pytest.log; cat $O/recal_ab.log
 }
 
+# the whole GPU suite on the round's code so far, then the reference-side batched binding after the packer's stretch cache (512 / 8 192 records)
+call_f() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r06${TAG:-f}; mkdir -p $O
+( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+( time timeout 900 python tests/bench_batch_dropin.py --sizes 512,8192 --target-reads 262144 --skip pipelined,pipelined_adc_ref_writer,pipelined_adc_2ctx,sync ) > $O/binding.log 2>&1
+tail -5 $O/pytest.log; grep "^{" $O/binding.log | cut -c1-1200
+}
+
 "call_$1"
