@@ -63,4 +63,23 @@ O=gpurun_out/r06${TAG:-f}; mkdir -p $O
 tail -5 $O/pytest.log; grep "^{" $O/binding.log | cut -c1-1200
 }
 
+# the batched binding, same box: default (48 slots, two contexts) against 24 slots / one context / other pool sizes, at 512 and 8 192 records
+call_g() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r06g; mkdir -p $O
+( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+B="python tests/bench_batch_dropin.py --target-reads 262144 --skip pipelined,pipelined_adc_ref_writer,pipelined_adc_2ctx,sync"
+for cfg in "default:" "slots24:NP_BATCH_SLOTS=24" "ctx1:NP_BATCH_CONTEXTS=1" "threads16:NP_HOST_THREADS=16" "threads32:NP_HOST_THREADS=32" "default2:"; do
+  name=${cfg%%:*}; envs=${cfg#*:}
+  ( env $envs timeout 600 $B --sizes 512,8192 ) > $O/binding_$name.log 2>&1
+done
+tail -5 $O/pytest.log
+for f in $O/binding_*.log; do echo "== $f"; grep "^{" $f | python -c "
+import sys, json
+for ln in sys.stdin:
+    d = json.loads(ln); p = d['pipelined_adc']
+    print(d['batch_size'], p['value'], p['ms_per_batch'], {k: v for k, v in p['host_ms_per_batch'].items() if k in ('phase1a_fetch_sizes','phase1b_pack','finisher_wait_device','phase3_maps','collect_wait')})
+"; done
+}
+
 "call_$1"
