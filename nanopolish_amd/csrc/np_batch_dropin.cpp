@@ -32,6 +32,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <fstream>
 #include <map>
 #include <memory>
@@ -133,9 +134,10 @@ struct Slot {
     std::vector<int> ref_start, dev_index, status;     // dev_index: the record's index among the PASS's device records
     std::vector<std::map<int, ScoredSite> > built;      // phase 3's output, swapped into the caller's result by collect()
     std::vector<int> builder;               // the pool worker that built (allocated) each record's map
+    size_t first;                           // index, in the caller's vector, of this piece's first record (round 6: a large batch travels in pieces)
     int n_dev;
     bool finished;                          // phase 3 done, not collected yet (under Impl::m)
-    Slot() : pass(NULL), caller(NULL), n_dev(0), finished(false) {}
+    Slot() : pass(NULL), caller(NULL), first(0), n_dev(0), finished(false) {}
 };
 
 struct DevState {
@@ -160,6 +162,13 @@ struct NpBatchPipeline::Impl {
     long n_passes;                          // device passes started so far (packer thread only)
     long coalesce_records;                  // a pass takes waiting batches while it holds fewer records than this (NP_BATCH_COALESCE, default 8192)
     long last_batch_records;                // size of the most recently submitted batch (under m): max_in_flight() scales with it
+    // Round 6: a submitted batch of more than 2 x piece_records records is cut into PIECES of piece_records (NP_BATCH_PIECE, default 1 024), each in a
+    // slot of its own, and collect() hands the batch back when its last piece is finished.  Everything between submit() and collect() -- pass
+    // formation, map building by two finishers, pass buffers freed piece by piece -- then works at the granularity that measured best: through
+    // one box's binding 8 192-record batches ran at 158 k reads/s against 314 k for 512-record ones (gpurun r06g), the same records in the same
+    // 8 192-record device passes, because a whole-batch slot builds 1.5 M map nodes in one job and holds its pass buffers until the last one.
+    long piece_records;
+    std::deque<int> batch_pieces;           // pieces of every caller batch in flight, oldest first (under m)
     bool presized;                          // the buffers have been sized for a full merged pass (packer thread only)
     Pool* pool;
     std::thread packer, finisher[2];        // two finishers: one waits for batch k+1's read-back while the other builds batch k's maps
@@ -179,7 +188,7 @@ struct NpBatchPipeline::Impl {
     // maps take 9 ms to build).  collect() and recycle() are the caller's: one thread.
     std::map<const bam1_t*, int> builder_of;
     bool track_builders;          // false: the synchronous pipeline (nobody recycles: nothing to remember)
-    Impl() : fai(NULL), hdr(NULL), region_start(-1), region_end(-1), pool(NULL), n_submitted(0), n_packed(0), n_claimed(0), n_finished(0), n_collected(0), stop(false) { n_passes = 0; coalesce_records = 8192; last_batch_records = 0; presized = false; track_builders = true; for (int i = 0; i < 8; ++i) t[i] = 0.0; }
+    Impl() : fai(NULL), hdr(NULL), region_start(-1), region_end(-1), pool(NULL), n_submitted(0), n_packed(0), n_claimed(0), n_finished(0), n_collected(0), stop(false) { n_passes = 0; coalesce_records = 8192; last_batch_records = 0; piece_records = 1024; presized = false; track_builders = true; for (int i = 0; i < 8; ++i) t[i] = 0.0; }
     void add_time(int i, double s) { std::lock_guard<std::mutex> g(tm); t[i] += s; }
     void open(const std::vector<int>& devices, bool shared_default, int host_threads);
     void pack(const std::vector<Slot*>& group, int dev);
@@ -215,7 +224,8 @@ void NpBatchPipeline::Impl::open(const std::vector<int>& devices, bool shared_de
     // passes, so pass N+1 was only formed once the device had gone idle and every other pass ran half-size)
     int per_dev = (int)std::max(24L, std::min(64L, 3 * coalesce_records / 512));
     if (const char* v = getenv("NP_BATCH_SLOTS")) per_dev = std::max(3, std::min(64, atoi(v)));
-    if (!track_builders) per_dev = 3;                  // the synchronous pipeline: one batch at a time
+    if (const char* v = getenv("NP_BATCH_PIECE")) piece_records = std::max(1L, atol(v));
+    if (!track_builders) { per_dev = 3; piece_records = 1L << 40; }      // the synchronous pipeline: one batch at a time, whole
     for (size_t i = 0; i < (size_t)per_dev * devs.size(); ++i) slots.push_back(new Slot());
     // Freed map memory goes back to the allocator, not to the kernel: with glibc's default trim threshold (128 KB) every batch's
     // 300 MB of released nodes is unmapped page by page and faulted in again by the next batch (seen as system time, and as a 7 ms
@@ -298,7 +308,8 @@ void NpBatchPipeline::configure(const MethylationCallingParameters& calling_para
     p->ref_cache.clear();                    // (another FASTA index may stand behind the same contig ids)
 }
 
-int NpBatchPipeline::in_flight() const { std::lock_guard<std::mutex> g(p->m); return (int)(p->n_submitted - p->n_collected); }
+int NpBatchPipeline::in_flight() const { std::lock_guard<std::mutex> g(p->m); return (int)p->batch_pieces.size(); }
+static long pieces_of(long records, long piece) { return records > 2 * piece ? (records + piece - 1) / piece : 1; }
 // Batches the caller may keep in flight: three device passes per device, each of up to NP_BATCH_COALESCE records -- three batches per device
 // when a batch fills a pass on its own, more (up to the slots there are) when batches are small.  Before the first submit(): the upper bound.
 int NpBatchPipeline::max_in_flight() const
@@ -307,7 +318,8 @@ int NpBatchPipeline::max_in_flight() const
     const long n_dev = (long)p->devs.size(), last = p->last_batch_records;
     if (last <= 0) return (int)p->slots.size();
     const long per_dev = std::max(3L, (3 * p->coalesce_records + last - 1) / last);
-    return (int)std::min((long)p->slots.size(), per_dev * n_dev);
+    const long by_slots = std::max(1L, (long)p->slots.size() / pieces_of(last, p->piece_records));
+    return (int)std::min(by_slots, per_dev * n_dev);
 }
 int NpBatchPipeline::devices() const { return (int)p->devs.size(); }
 void NpBatchPipeline::host_seconds(double out[8]) const { std::lock_guard<std::mutex> g(p->tm); for (int i = 0; i < 8; ++i) out[i] = p->t[i]; }
@@ -317,12 +329,18 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
     const double t0 = now();
     {
         std::lock_guard<std::mutex> g(p->m);
-        if (p->n_submitted - p->n_collected >= (long)p->slots.size()) die("NpBatchPipeline::submit: max_in_flight() batches are in flight already (collect one first)");
-        Slot& S = *p->slots[p->n_submitted % (long)p->slots.size()];
-        S.caller = &reads;
-        S.rec = reads;                     // (the records, sequences and samples they point to stay the caller's until collect())
-        p->last_batch_records = (long)reads.size();
-        p->n_submitted += 1;
+        const long n = (long)reads.size(), np_ = pieces_of(n, p->piece_records), len = np_ > 1 ? p->piece_records : n;
+        if (p->n_submitted - p->n_collected + np_ > (long)p->slots.size()) die("NpBatchPipeline::submit: max_in_flight() batches are in flight already (collect one first)");
+        for (long q = 0; q < np_; ++q) {
+            Slot& S = *p->slots[(p->n_submitted + q) % (long)p->slots.size()];
+            S.caller = &reads;
+            S.first = (size_t)(q * len);
+            // (the records, sequences and samples they point to stay the caller's until collect())
+            S.rec.assign(reads.begin() + S.first, reads.begin() + std::min(n, (q + 1) * len));
+        }
+        p->last_batch_records = n;
+        p->n_submitted += np_;
+        p->batch_pieces.push_back((int)np_);
     }
     p->cv.notify_all();
     p->add_time(7, now() - t0);
@@ -769,27 +787,35 @@ void NpBatchPipeline::Impl::finish(Slot& S)
 
 bool NpBatchPipeline::collect(MethylationCallingResult& result)
 {
-    Slot* Sp;
-    const double t0 = now();
+    int pieces;
     {
-        std::unique_lock<std::mutex> g(p->m);
-        if (p->n_collected >= p->n_submitted) return false;
-        Sp = p->slots[p->n_collected % (long)p->slots.size()];
-        while (!Sp->finished) p->cv.wait(g);                    // (the two finishers may end out of order: collect() keeps submission order)
+        std::lock_guard<std::mutex> g(p->m);
+        if (p->batch_pieces.empty()) return false;
+        pieces = p->batch_pieces.front();
     }
-    p->add_time(6, now() - t0);
-    Slot& S = *Sp;
-    std::vector<NpBatchRead>& reads = *S.caller;
-    const int n = (int)S.rec.size();
-    for (int i = 0; i < n; ++i) {
-        reads[i].status = S.status[i];
-        if (S.status[i] == NP_BATCH_HOST_PATH) continue;                 // the caller's per-record function fills (and creates) its map
-        result[S.rec[i].record].swap(S.built[i]);                         // the (possibly empty) map of the record, basemods.cpp:253-256
-        if (p->track_builders) p->builder_of[S.rec[i].record] = S.builder[i];
+    for (int q = 0; q < pieces; ++q) {                              // the oldest batch's pieces, in order
+        Slot* Sp;
+        const double t0 = now();
+        {
+            std::unique_lock<std::mutex> g(p->m);
+            Sp = p->slots[p->n_collected % (long)p->slots.size()];
+            while (!Sp->finished) p->cv.wait(g);                    // (the two finishers may end out of order: collect() keeps submission order)
+        }
+        p->add_time(6, now() - t0);
+        Slot& S = *Sp;
+        std::vector<NpBatchRead>& reads = *S.caller;
+        const int n = (int)S.rec.size();
+        for (int i = 0; i < n; ++i) {
+            reads[S.first + i].status = S.status[i];
+            if (S.status[i] == NP_BATCH_HOST_PATH) continue;                 // the caller's per-record function fills (and creates) its map
+            result[S.rec[i].record].swap(S.built[i]);                         // the (possibly empty) map of the record, basemods.cpp:253-256
+            if (p->track_builders) p->builder_of[S.rec[i].record] = S.builder[i];
+        }
+        S.built.clear();
+        { std::lock_guard<std::mutex> g(p->m); S.finished = false; p->n_collected += 1; }
+        p->cv.notify_all();
     }
-    S.built.clear();
-    { std::lock_guard<std::mutex> g(p->m); S.finished = false; p->n_collected += 1; }
-    p->cv.notify_all();
+    { std::lock_guard<std::mutex> g(p->m); p->batch_pieces.pop_front(); }
     return true;
 }
 

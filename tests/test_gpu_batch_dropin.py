@@ -96,6 +96,31 @@ def test_pipelined_batches_equal_the_unmodified_reference(coalesce, monkeypatch)
             _assert_golden(g, i, out[i])
 
 
+@pytest.mark.parametrize("piece", ["1", "2"])
+def test_large_batches_travel_in_pieces(piece, monkeypatch):
+    """Round 6: a submitted batch of more than 2 x NP_BATCH_PIECE records (default 1 024) is cut into pieces that go through the pipeline like
+    small batches (slots, device passes, map building, pass buffers freed piece by piece) and collect() hands the BATCH back when its last
+    piece is done.  With pieces of 1 and 2 records the golden records, in batches of all of them, of 5, of 3 and of 1, come back batch by batch,
+    in order, statuses at the caller's indices, every map equal to the unmodified reference's."""
+    from oracle.ref_full import call_methylation_pipeline
+    import torch  # noqa: F401
+    monkeypatch.setenv("NP_BATCH_PIECE", piece)
+    g = np.load(GOLD)
+    recs = _golden_records(g)
+    for bs in (len(recs), 5, 3, 1):
+        out, status = call_methylation_pipeline(recs, _s(g["contig"]), bs)
+        for i in range(len(recs)):
+            assert status[i] in (0, 1)
+            assert (status[i] == 1) == (int(g["r%d_n_events" % i]) == 0)
+            _assert_golden(g, i, out[i])
+    out, status = call_methylation_pipeline(recs, _s(g["contig"]), len(recs), rna=[1])          # a host-path record inside a piece
+    for i in range(len(recs)):
+        if i == 1:
+            assert status[i] == 2 and len(out[i]["start"]) == 0
+        else:
+            _assert_golden(g, i, out[i])
+
+
 def test_two_contexts_on_one_device_deal_batches_round_robin():
     """The multi-GPU form of NpBatchPipeline (devices = {0, 0}: two library contexts of the pipeline's own, here on one GPU; batches dealt
     round-robin, three slots per context, results in submission order): batches of 1, 2 and 3 records, i.e. up to 12 batches through 6

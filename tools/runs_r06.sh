@@ -82,4 +82,23 @@ for ln in sys.stdin:
 "; done
 }
 
+# batches in pieces (NP_BATCH_PIECE): the binding's tests, then 512 / 2 048 / 8 192 / 32 768 records per batch on one box, pieces on and off
+call_h() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r06h; mkdir -p $O
+( time timeout 900 python -m pytest tests/test_gpu_batch_dropin.py tests/test_gpu_sanitizers.py -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+B="python tests/bench_batch_dropin.py --target-reads 262144 --skip pipelined,pipelined_adc_ref_writer,pipelined_adc_2ctx,sync"
+for cfg in "pieces:" "whole:NP_BATCH_PIECE=1000000" "pieces2:" "pieces512:NP_BATCH_PIECE=512" "pieces2048:NP_BATCH_PIECE=2048"; do
+  name=${cfg%%:*}; envs=${cfg#*:}
+  ( env $envs timeout 600 $B --sizes 512,2048,8192,32768 ) > $O/binding_$name.log 2>&1
+done
+tail -5 $O/pytest.log
+for f in $O/binding_*.log; do echo "== $f"; grep "^{" $f | python -c "
+import sys, json
+for ln in sys.stdin:
+    d = json.loads(ln); p = d['pipelined_adc']
+    print(d['batch_size'], p['value'], p['ms_per_batch'], {k: v for k, v in p['host_ms_per_batch'].items() if k in ('phase1a_fetch_sizes','phase1b_pack','finisher_wait_device','phase3_maps','collect_wait')})
+"; done
+}
+
 "call_$1"
