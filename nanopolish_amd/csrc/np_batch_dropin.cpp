@@ -162,10 +162,10 @@ struct NpBatchPipeline::Impl {
     long n_passes;                          // device passes started so far (packer thread only)
     long coalesce_records;                  // a pass takes waiting batches while it holds fewer records than this (NP_BATCH_COALESCE, default 8192)
     long last_batch_records;                // size of the most recently submitted batch (under m): max_in_flight() scales with it
-    // Round 6: a submitted batch of more than 2 x piece_records records is cut into PIECES of piece_records (NP_BATCH_PIECE, default 1 024), each in a
+    // Round 6: a submitted batch of more than 2 x piece_records records is cut into PIECES of piece_records (NP_BATCH_PIECE, default 512: BamProcessor's own batch size; at most a third of the slots per batch), each in a
     // slot of its own, and collect() hands the batch back when its last piece is finished.  Everything between submit() and collect() -- pass
     // formation, map building by two finishers, pass buffers freed piece by piece -- then works at the granularity that measured best: through
-    // one box's binding 8 192-record batches ran at 158 k reads/s against 314 k for 512-record ones (gpurun r06g), the same records in the same
+    // one box's binding 8 192-record batches ran at 157 k reads/s whole, 169-192 k in pieces of 1 024 and 245 k in pieces of 512, against 312 k for 512-record batches (gpurun r06g, r06h), the same records in the same
     // 8 192-record device passes, because a whole-batch slot builds 1.5 M map nodes in one job and holds its pass buffers until the last one.
     long piece_records;
     std::deque<int> batch_pieces;           // pieces of every caller batch in flight, oldest first (under m)
@@ -188,7 +188,7 @@ struct NpBatchPipeline::Impl {
     // maps take 9 ms to build).  collect() and recycle() are the caller's: one thread.
     std::map<const bam1_t*, int> builder_of;
     bool track_builders;          // false: the synchronous pipeline (nobody recycles: nothing to remember)
-    Impl() : fai(NULL), hdr(NULL), region_start(-1), region_end(-1), pool(NULL), n_submitted(0), n_packed(0), n_claimed(0), n_finished(0), n_collected(0), stop(false) { n_passes = 0; coalesce_records = 8192; last_batch_records = 0; piece_records = 1024; presized = false; track_builders = true; for (int i = 0; i < 8; ++i) t[i] = 0.0; }
+    Impl() : fai(NULL), hdr(NULL), region_start(-1), region_end(-1), pool(NULL), n_submitted(0), n_packed(0), n_claimed(0), n_finished(0), n_collected(0), stop(false) { n_passes = 0; coalesce_records = 8192; last_batch_records = 0; piece_records = 512; presized = false; track_builders = true; for (int i = 0; i < 8; ++i) t[i] = 0.0; }
     void add_time(int i, double s) { std::lock_guard<std::mutex> g(tm); t[i] += s; }
     void open(const std::vector<int>& devices, bool shared_default, int host_threads);
     void pack(const std::vector<Slot*>& group, int dev);
@@ -309,7 +309,8 @@ void NpBatchPipeline::configure(const MethylationCallingParameters& calling_para
 }
 
 int NpBatchPipeline::in_flight() const { std::lock_guard<std::mutex> g(p->m); return (int)p->batch_pieces.size(); }
-static long pieces_of(long records, long piece) { return records > 2 * piece ? (records + piece - 1) / piece : 1; }
+// pieces a batch of `records` travels in: of `piece` records each, but never more than a third of the slots (three such batches stay in flight)
+static long pieces_of(long records, long piece, long n_slots) { return records > 2 * piece ? std::max(1L, std::min((records + piece - 1) / piece, n_slots / 3)) : 1; }
 // Batches the caller may keep in flight: three device passes per device, each of up to NP_BATCH_COALESCE records -- three batches per device
 // when a batch fills a pass on its own, more (up to the slots there are) when batches are small.  Before the first submit(): the upper bound.
 int NpBatchPipeline::max_in_flight() const
@@ -318,7 +319,7 @@ int NpBatchPipeline::max_in_flight() const
     const long n_dev = (long)p->devs.size(), last = p->last_batch_records;
     if (last <= 0) return (int)p->slots.size();
     const long per_dev = std::max(3L, (3 * p->coalesce_records + last - 1) / last);
-    const long by_slots = std::max(1L, (long)p->slots.size() / pieces_of(last, p->piece_records));
+    const long by_slots = std::max(1L, (long)p->slots.size() / pieces_of(last, p->piece_records, (long)p->slots.size()));
     return (int)std::min(by_slots, per_dev * n_dev);
 }
 int NpBatchPipeline::devices() const { return (int)p->devs.size(); }
@@ -329,7 +330,8 @@ void NpBatchPipeline::submit(std::vector<NpBatchRead>& reads)
     const double t0 = now();
     {
         std::lock_guard<std::mutex> g(p->m);
-        const long n = (long)reads.size(), np_ = pieces_of(n, p->piece_records), len = np_ > 1 ? p->piece_records : n;
+        const long n = (long)reads.size(), np0 = pieces_of(n, p->piece_records, (long)p->slots.size()), len = np0 > 1 ? (n + np0 - 1) / np0 : n;
+        const long np_ = np0 > 1 ? (n + len - 1) / len : 1;               // (no empty pieces)
         if (p->n_submitted - p->n_collected + np_ > (long)p->slots.size()) die("NpBatchPipeline::submit: max_in_flight() batches are in flight already (collect one first)");
         for (long q = 0; q < np_; ++q) {
             Slot& S = *p->slots[(p->n_submitted + q) % (long)p->slots.size()];

@@ -536,6 +536,9 @@ __device__ __forceinline__ void walk_segment(const float2* __restrict__ ts_all, 
 // and slides the eight window sums -- sample and fp32-square sums of the 3- and 6-sample windows left and right of the
 // position -- by one sample per step: np_ed_check_kernel has proved every such addition exact, so the slid sums ARE the
 // window sums, and tstat_from_sums is the arithmetic of np_ed_tstat_kernel.
+#ifndef NP_ED_UNROLL2
+#define NP_ED_UNROLL2 0     // 1: two blocks per iteration, ring-indexed sums (round 6 experiment)
+#endif
 template <bool RECORD>
 __device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int n, int begin, int end, int trip, bool lane_active,
                                                  walk_state& st, const np_detector_param& p, uint32_t* tmp, int tmp_cap, int& cnt)
@@ -572,6 +575,52 @@ __device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int 
         S[k] = (double)a + (double)b + (double)d;
         Q[k] = (double)(a * a) + (double)(b * b) + (double)(d * d);
     }
+#if NP_ED_UNROLL2
+    // Round 6: two blocks per loop iteration, the three-sample sums in a RING of sixteen (S(j) at index j & 15 relative to the iteration's first
+    // block): ten entries are live at any step and the one being formed overwrites one that died six steps earlier, so the sums are never moved --
+    // the single-block loop below copies twenty doubles (and the compiler a few more) from S[k + 8] to S[k] after every eight samples, 20 of its
+    // ~240 vector instructions per sample are moves.  The raw samples: the steps of a block read x[i + 3] and x[i + 6] only, i.e. the current and
+    // the next block; the block after that is in flight.  (Same sums, same order of operations per sum: events bit-identical.)
+    double RS[16], RQ[16];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { RS[k] = S[k]; RQ[k] = Q[k]; }
+    float A[8], B[8], C[8], D[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { A[j] = W[8 + j]; B[j] = W[16 + j]; }
+    for (int t = 0; t < n_blk; t += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float* cur = h ? B : A; float* nx = h ? C : B;
+            if (h == 0) load_block(blk + 2, C); else load_block(blk + 2, D);          // one block ahead of the window
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int o = 8 * h + q;
+                const int i = blk * 8 + q;
+                const bool in = lane_active && i >= begin && i < end;
+                const float ta = tstat_from_sums_fast(RS[(o + 3) & 15], RQ[(o + 3) & 15], RS[(o + 6) & 15], RQ[(o + 6) & 15], i, n, WA, 3.0f, 3.0, r3d, r3f);
+                const float tb = tstat_from_sums_fast(RS[o & 15] + RS[(o + 3) & 15], RQ[o & 15] + RQ[(o + 3) & 15], RS[(o + 6) & 15] + RS[(o + 9) & 15],
+                                                      RQ[(o + 6) & 15] + RQ[(o + 9) & 15], i, n, WB, 6.0f, 6.0, r6d, r6f);
+                const float t1 = w1 < w2 ? ta : tb, t2 = w1 < w2 ? tb : ta;
+                int pos;
+                if (detector_step<0>(st.d0, st.d1, in ? i : -1, t1, p.peak_height, p.threshold1, w1, pos) && RECORD) {
+                    if (cnt < tmp_cap NP_ED_ABL_NOSTORE) tmp[cnt] = (uint32_t)pos;
+                    cnt++;
+                }
+                if (detector_step<1>(st.d1, st.d0, in ? i : -1, t2, p.peak_height, p.threshold2, w2, pos) && RECORD) {
+                    if (cnt < tmp_cap NP_ED_ABL_NOSTORE) tmp[cnt] = (uint32_t)pos;
+                    cnt++;
+                }
+                // S(i + 4) = S(i + 3) - x[i+3] + x[i+6]
+                const float xo = q + 3 < 8 ? cur[q + 3] : nx[q + 3 - 8], xi = q + 6 < 8 ? cur[q + 6] : nx[q + 6 - 8];
+                RS[(o + 10) & 15] = RS[(o + 9) & 15] - (double)xo + (double)xi;
+                RQ[(o + 10) & 15] = RQ[(o + 9) & 15] - (double)(xo * xo) + (double)(xi * xi);
+            }
+            blk += 1;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { A[j] = C[j]; B[j] = D[j]; }
+    }
+#else
     float nxt[8];
     for (int t = 0; t < n_blk; ++t) {
         load_block(blk + 2, nxt);                             // one block ahead of the window
@@ -604,6 +653,7 @@ __device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int 
         for (int j = 0; j < 8; ++j) W[16 + j] = nxt[j];
         blk += 1;
     }
+#endif
 }
 
 template <bool FUSED>

@@ -98,7 +98,7 @@ def test_pipelined_batches_equal_the_unmodified_reference(coalesce, monkeypatch)
 
 @pytest.mark.parametrize("piece", ["1", "2"])
 def test_large_batches_travel_in_pieces(piece, monkeypatch):
-    """Round 6: a submitted batch of more than 2 x NP_BATCH_PIECE records (default 1 024) is cut into pieces that go through the pipeline like
+    """Round 6: a submitted batch of more than 2 x NP_BATCH_PIECE records (default 512) is cut into pieces that go through the pipeline like
     small batches (slots, device passes, map building, pass buffers freed piece by piece) and collect() hands the BATCH back when its last
     piece is done.  With pieces of 1 and 2 records the golden records, in batches of all of them, of 5, of 3 and of 1, come back batch by batch,
     in order, statuses at the caller's indices, every map equal to the unmodified reference's."""

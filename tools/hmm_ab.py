@@ -20,19 +20,22 @@ def child(args):
     from nanopolish_amd.api import Context
     from nanopolish_amd.pipeline import tile_host_batch, CallMethylationBatch
     models = bench.load_models()
-    hb = bench.prep_host_batch(models, 0, args.pool, args.read_len, False, 8)
+    hb = bench.prep_host_batch(models, 0, args.pool, args.read_len, bool(args.from_raw), 8)
     ctx = Context(0)
     ctx.register_model(models["nucleotide"], "nucleotide"); ctx.register_model(models["cpg"], "cpg")
-    b = CallMethylationBatch(ctx, tile_host_batch(hb, args.tile), "cuda:0", calibrate=True, jobs_on_device=True)
+    b = CallMethylationBatch(ctx, tile_host_batch(hb, args.tile), "cuda:0", calibrate=True, jobs_on_device=True, from_raw=bool(args.from_raw))
     b.step(); ctx.sync()
-    for w in (0, 1, 2):
+    for w in (0, 1, 2, 4, 5):
         ctx.kernel_time(w, reset=True)
     for _ in range(args.reps):
         b.step()
     ctx.sync(); torch.cuda.synchronize()
-    ms = {n: round(ctx.kernel_time(w)[0] / args.reps, 3) for w, n in ((0, "event_align"), (1, "hmm_forward"), (2, "glue"))}
-    print(json.dumps(dict(lib=os.path.basename(os.environ.get("NP_HIP_LIB", "default")), env=os.environ.get("NP_AB_ENV", ""), reads=b.n_reads, ms=ms,
-                          scores_crc="%08x" % zlib.crc32(b.scores().tobytes()))))
+    ms = {n: round(ctx.kernel_time(w)[0] / args.reps, 3) for w, n in ((0, "event_align"), (1, "hmm_forward"), (2, "glue"), (4, "event_detect"), (5, "mom_scalings"))}
+    out = dict(lib=os.path.basename(os.environ.get("NP_HIP_LIB", "default")), env=os.environ.get("NP_AB_ENV", ""), reads=b.n_reads, ms=ms,
+               scores_crc="%08x" % zlib.crc32(b.scores().tobytes()))
+    if args.from_raw:          # the detected events themselves: counts, means, starts
+        out["events_crc"] = "%08x" % (zlib.crc32(b.d_n_events.cpu().numpy().tobytes()) ^ zlib.crc32(b.d_events.cpu().numpy().tobytes()) ^ zlib.crc32(b.d_ev_start.cpu().numpy().tobytes()))
+    print(json.dumps(out))
 
 
 def main():
@@ -41,6 +44,7 @@ def main():
     ap.add_argument("--tile", type=int, default=10)
     ap.add_argument("--read-len", type=int, default=5450)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--from-raw", type=int, default=0, help="1: the step starts from int16 raw signal (event detection on the device)")
     ap.add_argument("--child", action="store_true")
     ap.add_argument("libs", nargs="*")
     args = ap.parse_args()
@@ -56,7 +60,7 @@ def main():
         if lib:
             env["NP_HIP_LIB"] = os.path.abspath(lib)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--pool", str(args.pool), "--tile", str(args.tile),
-                            "--read-len", str(args.read_len), "--reps", str(args.reps)], env=env, capture_output=True, text=True, timeout=600)
+                            "--read-len", str(args.read_len), "--reps", str(args.reps), "--from-raw", str(args.from_raw)], env=env, capture_output=True, text=True, timeout=600)
         out = [l for l in r.stdout.splitlines() if l.startswith("{")]
         print(out[-1] if out else "FAILED %s: %s" % (lib, r.stderr[-400:]), flush=True)
 

@@ -101,4 +101,23 @@ for ln in sys.stdin:
 "; done
 }
 
+# pieces of 512 by default (at most a third of the slots per batch): the binding's tests, the four batch sizes twice; then the detector's
+# two-block ring loop against the shipped one (from-raw step, A/B/A/B) and the whole suite on the variant
+call_i() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r06i; mkdir -p $O
+( time timeout 900 python -m pytest tests/test_gpu_batch_dropin.py -m gpu -x -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+B="python tests/bench_batch_dropin.py --target-reads 262144 --skip pipelined,pipelined_adc_ref_writer,pipelined_adc_2ctx,sync"
+for name in a b; do ( timeout 600 $B --sizes 512,2048,8192,32768 ) > $O/binding_$name.log 2>&1; done
+( timeout 900 python tools/hmm_ab.py --from-raw 1 --pool 2000 --tile 25 "" "$V/libnp_hip_edunroll.so" "" "$V/libnp_hip_edunroll.so" ) > $O/ed_ab.log 2>&1
+( NP_HIP_LIB=$PWD/$V/libnp_hip_edunroll.so timeout 900 python -m pytest tests/test_gpu_events.py tests/test_gpu_reflevel.py -m gpu -x -q ) > $O/pytest_edunroll.log 2>&1; echo "pytest rc=$?" >> $O/pytest_edunroll.log
+tail -4 $O/pytest.log; tail -3 $O/pytest_edunroll.log; cat $O/ed_ab.log
+for f in $O/binding_*.log; do echo "== $f"; grep "^{" $f | python -c "
+import sys, json
+for ln in sys.stdin:
+    d = json.loads(ln); p = d['pipelined_adc']
+    print(d['batch_size'], p['value'], p['ms_per_batch'], {k: v for k, v in p['host_ms_per_batch'].items() if k in ('phase1a_fetch_sizes','phase1b_pack','finisher_wait_device','collect_wait')})
+"; done
+}
+
 "call_$1"
