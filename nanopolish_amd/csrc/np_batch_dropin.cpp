@@ -171,7 +171,8 @@ struct NpBatchPipeline::Impl {
     std::deque<int> batch_pieces;           // pieces of every caller batch in flight, oldest first (under m)
     bool presized;                          // the buffers have been sized for a full merged pass (packer thread only)
     Pool* pool;
-    std::thread packer, finisher[2];        // two finishers: one waits for batch k+1's read-back while the other builds batch k's maps
+    std::thread packer;
+    std::vector<std::thread> finisher;      // NP_BATCH_FINISHERS (default 2): one waits for batch k+1's read-back while another builds batch k's maps
     std::mutex m; std::condition_variable cv;
     long n_submitted, n_packed, n_claimed, n_finished, n_collected;      // batches that have passed each stage (under m); n_claimed: taken by a finisher
     bool stop;
@@ -237,7 +238,9 @@ void NpBatchPipeline::Impl::open(const std::vector<int>& devices, bool shared_de
                                                                                 //  measured 7 % over 16, 24 no better -- profiles/r04_batch_binding.md)
     pool = new Pool(std::min(nt, 256));
     packer = std::thread(&Impl::packer_loop, this);
-    for (int i = 0; i < 2; ++i) finisher[i] = std::thread(&Impl::finisher_loop, this);
+    int nf = 2;
+    if (const char* v = getenv("NP_BATCH_FINISHERS")) nf = std::max(1, std::min(16, atoi(v)));
+    for (int i = 0; i < nf; ++i) finisher.push_back(std::thread(&Impl::finisher_loop, this));
 }
 
 NpBatchPipeline::NpBatchPipeline(const MethylationCallingParameters& calling_parameters, const std::string& kit, const faidx_t* fai,
@@ -278,7 +281,8 @@ NpBatchPipeline::~NpBatchPipeline()
         p->stop = true;
     }
     p->cv.notify_all();
-    p->packer.join(); p->finisher[0].join(); p->finisher[1].join();
+    p->packer.join();
+    for (size_t i = 0; i < p->finisher.size(); ++i) p->finisher[i].join();
     p->pool->drain();
     delete p->pool;
     for (size_t i = 0; i < p->passes.size(); ++i) {

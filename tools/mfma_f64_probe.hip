@@ -192,6 +192,56 @@ template <int NS, int NROT, int NRD, int WAVES> static int run_ring(const char* 
     return 0;
 }
 
+// ---- 5. the log-sum table gather of kernel B: ds_read_b32 against ds_read_b64 banking ---------------------------------------
+// A 64 000-byte table in LDS, 512 threads per workgroup, two workgroups per CU (four waves per SIMD, kernel B's shape); every thread runs eight
+// independent chains of look-ups at pseudo-random entries (the index of the next look-up depends on the value read, as a log-sum's does on the
+// previous sum).  B64 = 0: ds_read_b32 at 4 i (bank (a / 4) mod 32 per 32-lane group); 1: ds_read_b64 at the aligned pair 8 (i / 2) and a select of
+// the wanted half (bank PAIR (a / 8) mod 32: 32 lanes onto 32 pairs -- the same balls-in-bins as 32 lanes onto 32 banks -- plus one more vector
+// instruction per look-up).
+template <int B64> __global__ void __launch_bounds__(512, 4) k_gather(float* sink, int iters)
+{
+    __shared__ float tbl[16000];
+    for (int i = threadIdx.x; i < 16000; i += 512) tbl[i] = (float)((i * 2654435761u) >> 8 & 0xffff) * 1e-4f;
+    __syncthreads();
+    uint32_t x[8]; float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { x[c] = threadIdx.x * 7919u + c * 104729u + blockIdx.x; acc[c] = 0.f; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            x[c] = x[c] * 1664525u + 1013904223u + (uint32_t)__builtin_bit_cast(int, acc[c]);
+            const uint32_t i = (x[c] >> 8) % 15700u;
+            float v;
+            if (B64) {
+                const float2 pr = *reinterpret_cast<const float2*>(&tbl[i & ~1u]);
+                v = (i & 1u) ? pr.y : pr.x;
+            } else v = tbl[i];
+            acc[c] += v;
+        }
+    }
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) a += acc[c];
+    sink[blockIdx.x * 512 + threadIdx.x] = a;
+}
+template <int B64> static int run_gather(const char* name)
+{
+    int dev = 0; hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, dev));
+    const int blocks = pr.multiProcessorCount * 2, iters = 4000;
+    float* sink; CK(hipMalloc(&sink, (size_t)blocks * 512 * 4));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_gather<B64>, dim3(blocks), dim3(512), 0, 0, sink, 50);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_gather<B64>, dim3(blocks), dim3(512), 0, 0, sink, iters);
+    CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double wave_gathers_per_cu = 16.0 * 8.0 * iters;        // 16 waves per CU, 8 look-ups per iteration
+    printf("  %-40s %8.3f ms  %6.2f CU-cycles (2.4 GHz) per wave-instruction of look-ups\n", name, ms, ms * 1e-3 * 2.4e9 / wave_gathers_per_cu);
+    CK(hipFree(sink));
+    return 0;
+}
+
 template <int MODE> static int run_mix(const char* name, const double* ident_d, int waves_per_simd)
 {
     int dev = 0; hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, dev));
@@ -311,5 +361,10 @@ int main()
     if (run_ring<5, 3, 6, 5>("5 slots/lane, 3 reads/wave (needs <= 96 registers)", 3)) return 1;
     if (run_ring<7, 1, 8, 4>("7 slots/lane, 4 reads/wave (16-lane DPP rows)", 4)) return 1;
     if (run_ring<7, 1, 8, 3>("7 slots/lane, 4 reads/wave (16-lane DPP rows)", 4)) return 1;
+    printf("log-sum table gather (16 000 floats in LDS, random entries, four waves per SIMD):\n");
+    if (run_gather<0>("ds_read_b32 (shipped)")) return 1;
+    if (run_gather<1>("ds_read_b64 pair + select")) return 1;
+    if (run_gather<0>("ds_read_b32 (shipped)")) return 1;
+    if (run_gather<1>("ds_read_b64 pair + select")) return 1;
     return 0;
 }
