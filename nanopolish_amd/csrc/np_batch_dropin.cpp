@@ -320,8 +320,20 @@ static long pieces_of(long records, long piece, long n_slots) { return records >
 int NpBatchPipeline::max_in_flight() const
 {
     std::lock_guard<std::mutex> g(p->m);
-    const long n_dev = (long)p->devs.size(), last = p->last_batch_records;
+    const long last = p->last_batch_records;
     if (last <= 0) return (int)p->slots.size();
+    const long n_dev = (long)p->devs.size();
+    const long per_dev = std::max(3L, (3 * p->coalesce_records + last - 1) / last);
+    const long by_slots = std::max(1L, (long)p->slots.size() / pieces_of(last, p->piece_records, (long)p->slots.size()));
+    return (int)std::min(by_slots, per_dev * n_dev);
+}
+// what max_in_flight() will answer once batches of `batch_records` records are being submitted: the number of record / result vectors a caller
+// that knows its batch size has to rotate (the upper bound max_in_flight() gives before the first submit() is 96 vectors -- of 8 192 records each
+// that is 786 000 records held for six that are ever in flight)
+int NpBatchPipeline::max_in_flight_for(size_t batch_records) const
+{
+    std::lock_guard<std::mutex> g(p->m);
+    const long last = std::max(1L, (long)batch_records), n_dev = (long)p->devs.size();
     const long per_dev = std::max(3L, (3 * p->coalesce_records + last - 1) / last);
     const long by_slots = std::max(1L, (long)p->slots.size() / pieces_of(last, p->piece_records, (long)p->slots.size()));
     return (int)std::min(by_slots, per_dev * n_dev);

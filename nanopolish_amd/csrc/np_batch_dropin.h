@@ -77,6 +77,7 @@ public:
     void recycle(MethylationCallingResult& result);
     int in_flight() const;
     int max_in_flight() const;
+    int max_in_flight_for(size_t batch_records) const;        // max_in_flight() for batches of that size: how many record / result vectors to rotate
     int devices() const;
     // host wall-clock seconds spent in the phases since construction (diagnostics; tests/bench_batch_dropin.py prints them):
     // [0] phase 1a reference fetch + sizes, [1] phase 1b packing the pinned blob, [2] enqueueing copies and kernels,

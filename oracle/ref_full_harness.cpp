@@ -397,7 +397,7 @@ double npfull_bench_batch(int n_distinct, const char* const* read_seqs, const fl
     first->lens[0] = (uint32_t)strlen(contig_seq);
     pipe = n_contexts <= 0 ? new NpBatchPipeline(params, "r9.4_450bps", &first->fai, &first->hdr, -1, -1)
                            : new NpBatchPipeline(params, "r9.4_450bps", &first->fai, &first->hdr, -1, -1, std::vector<int>(n_contexts, 0), 0);
-    const int n_sets = pipelined ? pipe->max_in_flight() : 1;
+    const int n_sets = pipelined ? pipe->max_in_flight_for((size_t)batch_size) : 1;      // (the vectors a caller that knows its batch size rotates)
     std::vector<std::vector<Record*> > recs(n_sets);
     std::vector<std::vector<NpBatchRead> > reads(n_sets);
     for(int s = 0; s < n_sets; ++s) {
