@@ -500,6 +500,7 @@ def main():
                     help="1: the reads have a place on the seeded 5 Mb genome (BAM-style records; work items by CIGAR on the device) and the per-site "
                          "table is keyed by genome position -- what the ranks of an N > 1 run all-reduce; 0: reads identity-aligned to themselves "
                          "(configs[1]); -1: 1 at --gpus N > 1, 0 at --gpus 1")
+    ap.add_argument("--parity-reads", type=int, default=12, help="genome mode: reads of every rank's shard checked against the oracle on the same BAM record")
     ap.add_argument("--legs", type=int, default=1,
                     help="1: rank 0 of a one-GPU run also measures BASELINE.json configs[2] (eventalign, 50 000 reads per step) and configs[3] "
                          "(variants, 10 kb x 2 000 reads) and folds them into the line as value_eventalign / value_variants, each with its "
@@ -750,7 +751,7 @@ def main():
             dist.barrier(group=host_group)
 
     if args.genome and args.cpu_sample != 0:
-        rank_check = record_sample_parity(models, hb, batch, rank)          # every rank, its own shard, the oracle on the same records
+        rank_check = record_sample_parity(models, hb, batch, rank, n_sample=args.parity_reads)          # every rank, its own shard, the oracle on the same records
         host_barrier()
     elif world > 1 and args.cpu_sample != 0:
         rank_check = rank_sample_parity(models, hb, batch, bool(args.calibrate), bool(args.from_raw), rank, max(1, cores // world))
@@ -833,7 +834,7 @@ def main():
         shard_check = dict(ranks_checked=len(cks), reads=sum(c["reads"] for c in cks), reads_pairs_differ=sum(c["reads_pairs_differ"] for c in cks),
                            groups=sum(c["groups"] for c in cks), groups_missing_on_gpu=sum(c["groups_missing_on_gpu"] for c in cks),
                            max_abs_dLLR=max(dls) if dls else None,
-                           what=("every rank: 12 reads of its own shard through the oracle's restatement of the reference's per-read pass on the same BAM "
+                           what=("every rank: a sample of its own shard (--parity-reads) through the oracle's restatement of the reference's per-read pass on the same BAM "
                                  "record (reads_pairs_differ: reads whose set of scored genome sites differs), LLRs compared" if args.genome else
                                  "every rank: 32 reads of its own shard, GPU pairs and LLRs against the CPU pass"))
         if args.genome and max_dllr is None:

@@ -1,12 +1,12 @@
 """Per-unit counter figures of the shipped kernels for the bench lines' `roofline.traffic` / `issue` fields, read from the committed
-summary of this round's counter passes (profiles/r05_pmc.json <- profiles/collect_r05_pmc.sh + profiles/pmc_summary_r05.py).  The passes
+summary of this round's counter passes (profiles/r06_pmc.json <- profiles/collect_r06_pmc.sh + profiles/pmc_summary_r06.py).  The passes
 run at a launch size they finish at (8 192 reads); a bench line scales the PER-UNIT figures (bytes per band / call / segment) by the
 units its own launch processed, and says so in `source`."""
 import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILE = os.path.join("profiles", "r05_pmc.json")
+FILE = os.path.join("profiles", "r06_pmc.json")
 
 
 def family(name):
@@ -16,7 +16,7 @@ def family(name):
     except Exception:  # noqa: BLE001
         return {}
     out = {k: v for k, v in d.items() if not k.endswith("_per_step") and k != "loop_class_mix"}
-    out["source"] = FILE + " (rocprofv3 --pmc over the shipped kernel at 8 192 reads per launch, profiles/collect_r05_pmc.sh; per-unit figures x this launch's units)"
+    out["source"] = FILE + " (rocprofv3 --pmc over the shipped kernel at 8 192 reads per launch, profiles/collect_r06_pmc.sh; per-unit figures x this launch's units)"
     return out
 
 
