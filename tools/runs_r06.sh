@@ -120,4 +120,14 @@ for ln in sys.stdin:
 "; done
 }
 
+# soak against the reference itself on the round's kernels (the half-wave recalibration is on that chain), and the genome-placed batch's
+# parity on 300 reads (the oracle's restatement of the per-read pass on the same BAM record)
+call_m() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r06m; mkdir -p $O
+for seed in 31 32 33; do ( time timeout 900 python tests/gpu_soak.py --reads 1500 --seed $seed ) > $O/soak_$seed.log 2>&1; tail -4 $O/soak_$seed.log | head -1 | cut -c1-400; done
+( time timeout 900 python tests/gpu_soak_eventalign.py 512 ) > $O/soak_ea.log 2>&1; grep "^{" $O/soak_ea.log | cut -c1-400
+( time timeout 1200 python bench.py --gpus 1 --genome 1 --pool 4000 --tile 5 --steps 2 --warmup 1 --parity-reads 300 ) > $O/genome_parity300.json 2> $O/genome_parity300.err; echo "rc=$?"; show_line $O/genome_parity300.json
+}
+
 "call_$1"
