@@ -396,19 +396,9 @@ def from_raw_leg(ctx, torch, models, hb_raw, tile, steps, warmup, calibrate, cpu
     return out
 
 
-def binding_legs(models, sizes=(512, 8192), distinct=512, read_len=5450, target_reads=262144, cpu_check=True):
-    """Reads/s THROUGH the reference-side batched binding (nanopolish_amd/csrc/np_batch_dropin.cpp: NpBatchPipeline linked into the
-    reference's read-level build in place of call-methylation's per-record loop, src/common/nanopolish_bam_processor.cpp:90-119,
-    INTEGRATION.md section 2): BAM records + int16 raw signal in HOST memory in, the reference's ScoredSite maps out, host wall clock
-    around the whole loop, at BamProcessor's default batch size (512 records) and at 8 192.  The harness that plays the caller
-    (oracle/ref_full_harness.cpp) and the reference objects live under oracle/_ref; what is timed is the product's binding + library.
-    Parity: the sites written must equal, in number, what the reference's whole per-read function finds for the same records."""
-    from oracle.ref_full import have_batch, bench_batch
-    if not have_batch():
-        return dict(error="oracle/_ref/libnp_ref_full_batch.so did not travel with the repository")
-    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores()[2])))
+def _binding_records(models, distinct, read_len):
     from nanopolish_amd import api
-    from nanopolish_amd.synth import synth_raw, ADC_OFFSET, ADC_UNIT
+    from nanopolish_amd.synth import synth_raw
     recs, contig, pos = [], [], 0
     for r in range(distinct):
         rd = synth_raw(r, models["nucleotide"], L=read_len, k=6, adc=True)
@@ -416,26 +406,57 @@ def binding_legs(models, sizes=(512, 8192), distinct=512, read_len=5450, target_
         recs.append(dict(seq=rd["seq"], raw=rd["raw"].astype(np.float32), adc=rd["adc"], rc=int(rd["rc"]), pos=pos,
                          cigar=np.array([(len(ref) << 4) | 0], np.uint32), bam_seq=ref))
         contig.append(ref); pos += len(ref)
-    contig = "".join(contig)
+    return recs, "".join(contig)
+
+
+def binding_child(bs, distinct, read_len, target_reads):
+    """One batch size through the binding in a process of its own (`python bench.py --binding-child ...`): the caller of NpBatchPipeline is a
+    nanopolish process, not one that also holds torch's allocator, three other workloads' buffers and their thread pools -- inside bench.py's own
+    process the binding's host phases (packing, map building: all 16 CPUs) ran 25-40 % slower than in a clean one (profiles/r06_batch_binding.md)."""
+    from oracle.ref_full import bench_batch
+    from nanopolish_amd.synth import ADC_OFFSET, ADC_UNIT
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores()[2])))
+    recs, contig = _binding_records(load_models(), distinct, read_len)
+    nb = max(8, -(-target_reads // bs))
+    # (warm-up: every slot of the pipeline used twice and the passes' buffers grown to their steady size)
+    sec, sites, bad, hs = bench_batch(recs, contig, bs, nb, warmup=max(7, min(192, 98304 // bs)), pipelined=True, adc=(float(ADC_OFFSET), float(ADC_UNIT)), contexts=0, consumer=1)
+    return dict(value=round(bs * nb / sec, 1), unit="reads/s", records_per_batch=bs, batches=nb, ms_per_batch=round(sec / nb * 1e3, 2),
+                records_not_ok=bad, sites_written=sites, host_ms_per_batch={k: round(v / nb * 1e3, 2) for k, v in hs.items()})
+
+
+def binding_legs(models, sizes=(512, 8192), distinct=512, read_len=5450, target_reads=262144, cpu_check=True):
+    """Reads/s THROUGH the reference-side batched binding (nanopolish_amd/csrc/np_batch_dropin.cpp: NpBatchPipeline linked into the
+    reference's read-level build in place of call-methylation's per-record loop, src/common/nanopolish_bam_processor.cpp:90-119,
+    INTEGRATION.md section 2): BAM records + int16 raw signal in HOST memory in, the reference's ScoredSite maps out, host wall clock
+    around the whole loop, at BamProcessor's default batch size (512 records) and at 8 192.  The harness that plays the caller
+    (oracle/ref_full_harness.cpp) and the reference objects live under oracle/_ref; what is timed is the product's binding + library.
+    Every size runs in a process of its own (binding_child).
+    Parity: the sites written must equal, in number, what the reference's whole per-read function finds for the same records."""
+    from oracle.ref_full import have_batch
+    if not have_batch():
+        return dict(error="oracle/_ref/libnp_ref_full_batch.so did not travel with the repository")
     want_sites = None
     if cpu_check:
         try:
             from oracle.ref_full import FullRef, have_full
             if have_full():
+                recs, _ = _binding_records(models, distinct, read_len)
                 sites, _ = FullRef().many_identity(1, [r["seq"] for r in recs], [r["raw"] for r in recs], [r["rc"] for r in recs], max(1, usable_cores()[2]))
                 want_sites = int(np.sum(sites))
         except Exception:  # noqa: BLE001
             want_sites = None
     out = dict(distinct_reads=distinct, read_len=read_len, what="NpBatchPipeline (default construction: two contexts on the device), int16 samples from host memory, "
-                                                              "ScoredSite maps handed over and recycled; host wall clock")
+                                                              "ScoredSite maps handed over and recycled; host wall clock; each batch size in a process of its own")
     for bs in sizes:
-        nb = max(8, -(-target_reads // bs))
-        # (warm-up: every slot of the pipeline used once and the passes' buffers grown to their steady size)
-        sec, sites, bad, hs = bench_batch(recs, contig, bs, nb, warmup=48 if bs <= 1024 else 7, pipelined=True, adc=(float(ADC_OFFSET), float(ADC_UNIT)), contexts=0, consumer=1)
-        d = dict(value=round(bs * nb / sec, 1), unit="reads/s", records_per_batch=bs, batches=nb, ms_per_batch=round(sec / nb * 1e3, 2),
-                 records_not_ok=bad, sites_written=sites, host_ms_per_batch={k: round(v / nb * 1e3, 2) for k, v in hs.items()})
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--binding-child", "%d,%d,%d,%d" % (bs, distinct, read_len, target_reads)],
+                           capture_output=True, text=True, timeout=900)
+        ls = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not ls:
+            out["records_%d" % bs] = dict(error="binding child failed (rc %d): %s" % (r.returncode, r.stderr[-400:]))
+            continue
+        d = json.loads(ls[-1])
         if want_sites is not None and bs % distinct == 0:
-            d["sites_match_reference"] = bool(sites == want_sites * (bs // distinct) * nb)
+            d["sites_match_reference"] = bool(d["sites_written"] == want_sites * (bs // distinct) * d["batches"])
         out["records_%d" % bs] = d
     return out
 
@@ -501,12 +522,17 @@ def main():
                          "table is keyed by genome position -- what the ranks of an N > 1 run all-reduce; 0: reads identity-aligned to themselves "
                          "(configs[1]); -1: 1 at --gpus N > 1, 0 at --gpus 1")
     ap.add_argument("--parity-reads", type=int, default=12, help="genome mode: reads of every rank's shard checked against the oracle on the same BAM record")
+    ap.add_argument("--binding-child", default="", help=argparse.SUPPRESS)       # "bs,distinct,read_len,target_reads": binding_child in this process
     ap.add_argument("--legs", type=int, default=1,
                     help="1: rank 0 of a one-GPU run also measures BASELINE.json configs[2] (eventalign, 50 000 reads per step) and configs[3] "
                          "(variants, 10 kb x 2 000 reads) and folds them into the line as value_eventalign / value_variants, each with its "
                          "parity fields and its own roofline")
     args, extra = ap.parse_known_args()
 
+    if args.binding_child:
+        import torch  # noqa: F401  (one HIP runtime per process, loaded before the binding's library)
+        print(json.dumps(binding_child(*[int(x) for x in args.binding_child.split(",")])), flush=True)
+        return
     if args.workload in ("eventalign", "variants"):
         # BASELINE.json configs[2] / configs[3]: their own tools (one JSON line each), same --steps / --warmup
         import runpy
@@ -871,7 +897,7 @@ def main():
             bl = binding_legs(models, cpu_check=args.cpu_sample != 0)
             legs["binding"] = bl
             for bs in (512, 8192):
-                if "records_%d" % bs in bl:
+                if "value" in (bl.get("records_%d" % bs) or {}):
                     legs["value_binding_%d" % bs] = bl["records_%d" % bs]["value"]
         except Exception as e:  # noqa: BLE001
             legs["binding"] = dict(error=repr(e))

@@ -72,7 +72,7 @@ def main():
                                                           ("sync", False, None, 0, 0)):
             if name in args.skip.split(","):
                 continue
-            sec, sites, bad, hs = bench_batch(recs, contig, bs, nb, warmup=48 if bs <= 1024 else 7, pipelined=pipelined, adc=adc, contexts=contexts, consumer=consumer)
+            sec, sites, bad, hs = bench_batch(recs, contig, bs, nb, warmup=max(7, min(192, 98304 // bs)), pipelined=pipelined, adc=adc, contexts=contexts, consumer=consumer)
             line[name] = dict(value=round(bs * nb / sec, 1), ms_per_batch=round(sec / nb * 1e3, 2), sites_per_read=round(sites / (bs * nb), 2),
                               records_not_ok=bad, h2d_GBps=round(bs * nb * raw_bytes * (0.5 if adc else 1.0) / sec / 1e9, 2))
             if pipelined:
