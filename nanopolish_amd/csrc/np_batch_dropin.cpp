@@ -168,6 +168,7 @@ struct NpBatchPipeline::Impl {
     // one box's binding 8 192-record batches ran at 157 k reads/s whole, 169-192 k in pieces of 1 024 and 245 k in pieces of 512, against 312 k for 512-record batches (gpurun r06g, r06h), the same records in the same
     // 8 192-record device passes, because a whole-batch slot builds 1.5 M map nodes in one job and holds its pass buffers until the last one.
     long piece_records;
+    bool maps_first;                        // NP_BATCH_MAPS_FIRST (default 1): the map-building loops go ahead of the packing loops in the pool
     std::deque<int> batch_pieces;           // pieces of every caller batch in flight, oldest first (under m)
     bool presized;                          // the buffers have been sized for a full merged pass (packer thread only)
     Pool* pool;
@@ -189,7 +190,7 @@ struct NpBatchPipeline::Impl {
     // maps take 9 ms to build).  collect() and recycle() are the caller's: one thread.
     std::map<const bam1_t*, int> builder_of;
     bool track_builders;          // false: the synchronous pipeline (nobody recycles: nothing to remember)
-    Impl() : fai(NULL), hdr(NULL), region_start(-1), region_end(-1), pool(NULL), n_submitted(0), n_packed(0), n_claimed(0), n_finished(0), n_collected(0), stop(false) { n_passes = 0; coalesce_records = 8192; last_batch_records = 0; piece_records = 512; presized = false; track_builders = true; for (int i = 0; i < 8; ++i) t[i] = 0.0; }
+    Impl() : fai(NULL), hdr(NULL), region_start(-1), region_end(-1), pool(NULL), n_submitted(0), n_packed(0), n_claimed(0), n_finished(0), n_collected(0), stop(false) { n_passes = 0; coalesce_records = 8192; last_batch_records = 0; piece_records = 512; maps_first = true; presized = false; track_builders = true; for (int i = 0; i < 8; ++i) t[i] = 0.0; }
     void add_time(int i, double s) { std::lock_guard<std::mutex> g(tm); t[i] += s; }
     void open(const std::vector<int>& devices, bool shared_default, int host_threads);
     void pack(const std::vector<Slot*>& group, int dev);
@@ -226,6 +227,7 @@ void NpBatchPipeline::Impl::open(const std::vector<int>& devices, bool shared_de
     int per_dev = (int)std::max(24L, std::min(64L, 3 * coalesce_records / 512));
     if (const char* v = getenv("NP_BATCH_SLOTS")) per_dev = std::max(3, std::min(64, atoi(v)));
     if (const char* v = getenv("NP_BATCH_PIECE")) piece_records = std::max(1L, atol(v));
+    if (const char* v = getenv("NP_BATCH_MAPS_FIRST")) maps_first = atoi(v) != 0;
     if (!track_builders) { per_dev = 3; piece_records = 1L << 40; }      // the synchronous pipeline: one batch at a time, whole
     for (size_t i = 0; i < (size_t)per_dev * devs.size(); ++i) slots.push_back(new Slot());
     // Freed map memory goes back to the allocator, not to the kernel: with glibc's default trim threshold (128 KB) every batch's
@@ -799,7 +801,7 @@ void NpBatchPipeline::Impl::finish(Slot& S)
             iter->second.ll_methylated[strand_idx] = methylated_score;
             iter->second.strands_scored += 1;
         }
-    }, false /* on the workers only: see Impl::builder_of */);
+    }, false /* on the workers only: see Impl::builder_of */, maps_first);
     add_time(4, now() - tm0);
 }
 

@@ -41,13 +41,17 @@ public:
     // takes chunks too.  Loops submitted concurrently from several threads share the workers, oldest first.
     // participate = false: the submitter only waits -- every index then runs on a WORKER (what the binding's result builder wants:
     // the heap blocks a worker allocates are later freed by the same worker, post_to).  Without workers the submitter runs the loop.
-    void run(int n, int chunk, const std::function<void(int)>& fn, bool participate = true)
+    // urgent = true: the loop goes to the FRONT of the queue -- the workers finish it before they return to older loops (what the tail of a
+    // pipeline wants: its loops release what the stages behind it wait for).
+    void run(int n, int chunk, const std::function<void(int)>& fn, bool participate = true, bool urgent = false)
     {
         if (n <= 0) return;
         if (chunk < 1) chunk = 1;
         std::shared_ptr<Job> j = std::make_shared<Job>(n, chunk, fn);
         if (!workers_.empty() && (n > chunk || !participate)) {
-            { std::lock_guard<std::mutex> g(m_); jobs_.push_back(j); }
+            j->urgent = urgent;
+            if (urgent) urgent_open_.fetch_add(1);
+            { std::lock_guard<std::mutex> g(m_); if (urgent) jobs_.push_front(j); else jobs_.push_back(j); }
             cv_.notify_all();
         }
         if (participate || workers_.empty()) work_on(*j);
@@ -97,6 +101,8 @@ private:
         std::function<void()> after;
         std::atomic<int> next;
         bool posted;
+        bool urgent = false;                // queued ahead of the others; workers leave a non-urgent loop for it between chunks
+        std::atomic<bool> closed{false};    // (urgent) its last chunk has been handed out
         int done;                       // chunks finished (under m)
         std::mutex m; std::condition_variable cv;
         Job(int n_, int chunk_, const std::function<void(int)>& f) : n(n_), chunk(chunk_), n_chunks((n_ + chunk_ - 1) / chunk_), fn(f), next(0), posted(false), done(0) {}
@@ -106,9 +112,14 @@ private:
     void work_on(Job& j)
     {
         int mine = 0;
+        const bool worker = who().pool == this;
         for (;;) {
+            if (worker && !j.urgent && urgent_open_.load(std::memory_order_relaxed) > 0) break;      // an urgent loop waits: back to the queue's front
             const int c = j.next.fetch_add(1);
-            if (c >= j.n_chunks) break;
+            if (c >= j.n_chunks) {
+                if (j.urgent && !j.closed.exchange(true)) urgent_open_.fetch_sub(1);
+                break;
+            }
             const int lo = c * j.chunk, hi = lo + j.chunk < j.n ? lo + j.chunk : j.n;
             for (int i = lo; i < hi; ++i) j.fn(i);
             ++mine;
@@ -158,6 +169,7 @@ private:
     std::mutex m_;
     std::condition_variable cv_, idle_;
     int posted_ = 0;                    // posted loops not finished yet
+    std::atomic<int> urgent_open_{0};   // urgent loops that still have chunks to hand out
     bool stop_;
 };
 
