@@ -168,7 +168,9 @@ struct NpBatchPipeline::Impl {
     // one box's binding 8 192-record batches ran at 157 k reads/s whole, 169-192 k in pieces of 1 024 and 245 k in pieces of 512, against 312 k for 512-record batches (gpurun r06g, r06h), the same records in the same
     // 8 192-record device passes, because a whole-batch slot builds 1.5 M map nodes in one job and holds its pass buffers until the last one.
     long piece_records;
-    bool maps_first;                        // NP_BATCH_MAPS_FIRST (default 1): the map-building loops go ahead of the packing loops in the pool
+    bool maps_first, pack_first;            // NP_BATCH_MAPS_FIRST / NP_BATCH_PACK_FIRST (default 0 / 0: first come, first served): which loops go to the front of the pool's queue.
+                                            // Measured (gpurun r06o): maps first 172-184 k reads/s at 512 records against 284-320 k -- the maps get quicker and the packer, which feeds
+                                            // the device, starves
     std::deque<int> batch_pieces;           // pieces of every caller batch in flight, oldest first (under m)
     bool presized;                          // the buffers have been sized for a full merged pass (packer thread only)
     Pool* pool;
@@ -190,7 +192,7 @@ struct NpBatchPipeline::Impl {
     // maps take 9 ms to build).  collect() and recycle() are the caller's: one thread.
     std::map<const bam1_t*, int> builder_of;
     bool track_builders;          // false: the synchronous pipeline (nobody recycles: nothing to remember)
-    Impl() : fai(NULL), hdr(NULL), region_start(-1), region_end(-1), pool(NULL), n_submitted(0), n_packed(0), n_claimed(0), n_finished(0), n_collected(0), stop(false) { n_passes = 0; coalesce_records = 8192; last_batch_records = 0; piece_records = 512; maps_first = true; presized = false; track_builders = true; for (int i = 0; i < 8; ++i) t[i] = 0.0; }
+    Impl() : fai(NULL), hdr(NULL), region_start(-1), region_end(-1), pool(NULL), n_submitted(0), n_packed(0), n_claimed(0), n_finished(0), n_collected(0), stop(false) { n_passes = 0; coalesce_records = 8192; last_batch_records = 0; piece_records = 512; maps_first = false; pack_first = false; presized = false; track_builders = true; for (int i = 0; i < 8; ++i) t[i] = 0.0; }
     void add_time(int i, double s) { std::lock_guard<std::mutex> g(tm); t[i] += s; }
     void open(const std::vector<int>& devices, bool shared_default, int host_threads);
     void pack(const std::vector<Slot*>& group, int dev);
@@ -228,6 +230,7 @@ void NpBatchPipeline::Impl::open(const std::vector<int>& devices, bool shared_de
     if (const char* v = getenv("NP_BATCH_SLOTS")) per_dev = std::max(3, std::min(64, atoi(v)));
     if (const char* v = getenv("NP_BATCH_PIECE")) piece_records = std::max(1L, atol(v));
     if (const char* v = getenv("NP_BATCH_MAPS_FIRST")) maps_first = atoi(v) != 0;
+    if (const char* v = getenv("NP_BATCH_PACK_FIRST")) pack_first = atoi(v) != 0;
     if (!track_builders) { per_dev = 3; piece_records = 1L << 40; }      // the synchronous pipeline: one batch at a time, whole
     for (size_t i = 0; i < (size_t)per_dev * devs.size(); ++i) slots.push_back(new Slot());
     // Freed map memory goes back to the allocator, not to the kernel: with glibc's default trim threshold (128 KB) every batch's
@@ -668,7 +671,7 @@ void NpBatchPipeline::Impl::pack(const std::vector<Slot*>& group, int dev)
         memcpy(h_cigar + cigar_off[q], bam_get_cigar(record), 4 * (size_t)record->core.n_cigar);
         h_read_len[q] = (int32_t)seq.size();
         h_rc[q] = bam_is_rev(record) ? 1 : 0;
-    });
+    }, true, pack_first);
     memcpy(H + i_raw_off, raw_off.data(), (size_t)(n + 1) * 8); memcpy(H + i_event_off, event_off.data(), (size_t)(n + 1) * 8);
     memcpy(H + i_cigar_off, cigar_off.data(), (size_t)(n + 1) * 8); memcpy(H + i_group_off, group_off.data(), (size_t)(n + 1) * 8);
     memcpy(H + i_jr_off, jr_off.data(), (size_t)(n + 1) * 8); memcpy(H + i_pair_off, pair_off.data(), (size_t)(n + 1) * 8);

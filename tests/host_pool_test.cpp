@@ -55,6 +55,19 @@ int main()
             for (int i = 0; i < 8; ++i) ok = ok && seen_by_pool[i] == -1 && seen_by_other[i] >= 0 && seen_by_other[i] < 2;
             bad += check(ok, "a worker of another pool is not a worker of this pool");
         }
+        // (7) urgent loops: submitted while a long loop runs, they go first -- the workers leave the long loop between chunks -- and both loops
+        //     still cover every index exactly once
+        {
+            std::vector<int> slow(60000, 0), fast(6000, 0);
+            std::atomic<int> slow_done_when_fast_ended(-1), slow_count(0);
+            std::thread a([&]() { pool.run((int)slow.size(), 8, [&](int i) { volatile double x = 0; for (int q = 0; q < 400; ++q) x += q * 1e-3; slow[i] += 1; slow_count.fetch_add(1); }); });
+            while (slow_count.load() < 200) std::this_thread::yield();
+            std::thread b([&]() { for (int rep = 0; rep < 3; ++rep) pool.run((int)fast.size(), 8, [&](int i) { fast[i] += 1; }, false, true); slow_done_when_fast_ended = slow_count.load(); });
+            a.join(); b.join();
+            bad += check(*std::min_element(slow.begin(), slow.end()) == 1 && *std::max_element(slow.begin(), slow.end()) == 1, "the long loop still covers every index once");
+            bad += check(*std::min_element(fast.begin(), fast.end()) == 3 && *std::max_element(fast.begin(), fast.end()) == 3, "urgent loops cover every index once each");
+            if (nt > 0) bad += check(slow_done_when_fast_ended.load() < (int)slow.size(), "urgent loops finish before the long loop they interrupted");
+        }
         // (4) empty loops
         pool.run(0, 8, [&](int) { bad += 1; });
         int called = 0;
