@@ -130,4 +130,15 @@ for seed in 31 32 33; do ( time timeout 900 python tests/gpu_soak.py --reads 150
 ( time timeout 1200 python bench.py --gpus 1 --genome 1 --pool 4000 --tile 5 --steps 2 --warmup 1 --parity-reads 300 ) > $O/genome_parity300.json 2> $O/genome_parity300.err; echo "rc=$?"; show_line $O/genome_parity300.json
 }
 
+# more soak on the round's final binaries: six more seeds of 1 500 records through the whole chain against the reference, 2 048 full-size reads of
+# eventalign rows, and the GPU suite once more on the rebuilt artefacts
+call_q() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r06q; mkdir -p $O
+( time timeout 900 python -m pytest tests -m gpu -q ) > $O/pytest.log 2>&1; grep -h "passed\|failed" $O/pytest.log
+for seed in 34 35 36 37 38 39; do ( timeout 900 python tests/gpu_soak.py --reads 1500 --seed $seed ) > $O/soak_$seed.log 2>&1; grep "^{" $O/soak_$seed.log | cut -c1-330; done
+( timeout 1200 python tests/gpu_soak_eventalign.py 2048 ) > $O/soak_ea.log 2>&1; tail -2 $O/soak_ea.log | cut -c1-300
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+}
+
 "call_$1"
