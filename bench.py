@@ -521,6 +521,9 @@ def main():
                     help="1: the reads have a place on the seeded 5 Mb genome (BAM-style records; work items by CIGAR on the device) and the per-site "
                          "table is keyed by genome position -- what the ranks of an N > 1 run all-reduce; 0: reads identity-aligned to themselves "
                          "(configs[1]); -1: 1 at --gpus N > 1, 0 at --gpus 1")
+    ap.add_argument("--site-rows", choices=("site", "base"), default="site",
+                    help="genome mode: rows of the all-reduced table -- one per motif site of the genome (np_genome_site_index_dev's ordinals; 24 bytes x "
+                         "sites) or one per base (24 bytes x bases)")
     ap.add_argument("--parity-reads", type=int, default=12, help="genome mode: reads of every rank's shard checked against the oracle on the same BAM record")
     ap.add_argument("--binding-child", default="", help=argparse.SUPPRESS)       # "bs,distinct,read_len,target_reads": binding_child in this process
     ap.add_argument("--legs", type=int, default=1,
@@ -657,9 +660,9 @@ def main():
         """per-site table of this rank's reads (the all-reduce payload) from the device-resident scores and group metadata
         (np_site_table_dev); skipped groups and unused group slots carry NaN scores"""
         if args.genome:
-            # keyed (contig, start, end) on the resident genome: [genome length, 6] int32 (np_site_table_genome_dev); the count of groups cut on
-            # both sides rides in the last row's spare cells so that ONE all-reduce carries everything
-            t, ovf = b.genome_site_table()
+            # keyed (contig, start, end) on the resident genome: int32 [rows, 6], one row per motif site of the genome (or per base:
+            # --site-rows) -- np_site_table_genome_indexed_dev / np_site_table_genome_dev; groups cut on both sides are counted beside it
+            t, ovf = b.genome_site_table(per_site=args.site_rows == "site")
             ctx.sync()
             b.site_overflow = ovf
             return t
@@ -996,6 +999,7 @@ def main():
                                      called_sites=int(table[:, 1].sum().item() + table[:, 4].sum().item()),
                                      called_sites_methylated=int(table[:, 2].sum().item() + table[:, 5].sum().item()),
                                      groups_cut_on_both_sides=ovf_total, table_bytes_per_rank=int(table.numel() * 4),
+                                     rows="one per motif site of the genome" if args.site_rows == "site" else "one per base", table_rows=int(table.shape[0]),
                                      max_reads_on_one_site=int(table[:, 0].max().item()))
         elif table is not None:
             out["site_table"] = dict(sites=int((table[:, 0] > 0).sum().item()), num_reads=int(table[:, 0].sum().item()),

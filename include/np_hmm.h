@@ -288,6 +288,24 @@ int np_site_table_genome_dev(np_ctx* ctx, void* stream, int64_t n_groups, const 
                              const int64_t* contig_off, int n_contigs, int alphabet, int min_separation, double call_threshold, int64_t n_pos,
                              int32_t* table, uint64_t* n_overflow);
 
+/* The motif sites of the resident genome as a rank structure, for a genome-keyed table with one row per SITE instead of one per base: both keys of
+ * np_site_table_genome_dev are positions of motif sites (a group's first and last), so the table and the all-reduce payload shrink from
+ * 24 bytes x bases to 24 bytes x sites (5 Mb at the bench's site density: 120 MB -> 7.5 MB; a 3.1 Gb genome: 74 GB -> under 1 GB).
+ *   site_mask : uint64[ceil(n_pos / 64)], bit (p & 63) of word p >> 6 = a recognition site of the alphabet starts at p, inside its contig
+ *               (Alphabet::is_motif_match on the contig, src/common/nanopolish_alphabet.h -- the test np_site_table_genome_dev applies)
+ *   word_rank : uint32[ceil(n_pos / 64) + 1], the number of sites before every word; the last entry is the total
+ *   n_sites   : int64, device: the total.
+ * The ordinal of the site at p is word_rank[p >> 6] + popcount(site_mask[p >> 6] & ((1 << (p & 63)) - 1)).  Built once per genome. */
+int np_genome_site_index_dev(np_ctx* ctx, void* stream, const char* genome, const int64_t* contig_off, int n_contigs, int alphabet, int64_t n_pos,
+                             uint64_t* site_mask, uint32_t* word_rank, int64_t* n_sites);
+
+/* np_site_table_genome_dev into a table with one row per motif site: table int32[n_sites][6], row = the ordinal of the key's site
+ * (np_genome_site_index_dev's site_mask / word_rank, of the same genome and alphabet).  Everything else as np_site_table_genome_dev. */
+int np_site_table_genome_indexed_dev(np_ctx* ctx, void* stream, int64_t n_groups, const float* scores, const int32_t* first_site, const int32_t* last_site,
+                                     const int32_t* n_motif, const np_hmm_job_dev* jobs, const int64_t* read_base, const char* genome,
+                                     const int64_t* contig_off, int n_contigs, int alphabet, int min_separation, double call_threshold, int64_t n_pos,
+                                     const uint64_t* site_mask, const uint32_t* word_rank, int32_t* table, uint64_t* n_overflow);
+
 /* Read-level glue between the two kernels (src/nanopolish_squiggle_read.cpp:161-186,273-301):
  * builds base_to_event_map[].start for every read from kernel A's pairs, events_per_base and the
  * HMM transitions, then resolves each work item's event bounds

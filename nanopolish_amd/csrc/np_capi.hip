@@ -71,6 +71,7 @@ struct np_ctx {
     std::vector<float> h_logsum;
     float* d_flank = nullptr;
     uint32_t* d_counters = nullptr;   // [0..7] class counts, [8..15] work-queue heads, [16] align queue head, [17] chain queue head, [18] back-track queue head, [32] self-test, [1024 .. 1024 + 2 * 4096) work-item bins (np_launch_classify)
+    dev_buf site_scan;                // np_genome_site_index_dev: the chunk totals of its prefix scan
     dev_buf order, trace, kparams, align_order, recal_order;   // (recal_order: the recalibration's own issue order -- the persistent aligner of another batch may still be pulling from align_order)
     void* small_h = nullptr; size_t small_h_cap = 0; dev_buf small_d;     // np_hmm_score_host's small-batch path: one pinned blob, its device twin
     int small_batch_path = 1;         // np_hmm_score_host: batches of <= NP_SMALL_BATCH items as one pinned blob (0: the general path; tests compare the two)
@@ -481,7 +482,7 @@ void np_destroy(np_ctx* c)
     dev_buf* bufs[] = {&c->order, &c->trace, &c->kparams, &c->b_jobs, &c->b_reads, &c->b_events, &c->b_ranks, &c->b_out, &c->b_pair_off,
                        &c->b_pairs, &c->b_pair_begin, &c->b_n_pairs, &c->b_vm, &c->b_bp, &c->b_cell_off, &c->b_state_off,
                        &c->b_states, &c->b_n_states, &c->ed_status, &c->ed_tstat, &c->b_raw, &c->b_raw_off, &c->b_ev_off, &c->b_ev_start,
-                       &c->b_ev_len, &c->b_ev_mean, &c->b_ev_stdv, &c->b_n_events, &c->cm_group_rank_off, &c->cm_cigar_scratch, &c->ea_bp, &c->ea_path, &c->ea_args, &c->align_order, &c->recal_order};
+                       &c->b_ev_len, &c->b_ev_mean, &c->b_ev_stdv, &c->b_n_events, &c->cm_group_rank_off, &c->cm_cigar_scratch, &c->ea_bp, &c->ea_path, &c->ea_args, &c->align_order, &c->recal_order, &c->site_scan};
     for (dev_buf* b : bufs) b->release();
     c->small_d.release();
     if (c->small_h) (void)hipHostFree(c->small_h);
@@ -781,6 +782,19 @@ int np_site_table_dev(np_ctx* c, void* stream, int64_t n_groups, const float* sc
     return NP_OK;
 }
 
+static int site_table_genome_locked(np_ctx* c, void* stream, int64_t n_groups, const float* scores, const int32_t* first_site, const int32_t* last_site,
+                                    const int32_t* n_motif, const np_hmm_job_dev* jobs, const int64_t* read_base, const char* genome,
+                                    const int64_t* contig_off, int n_contigs, int alphabet, int min_separation, double call_threshold, int64_t n_pos,
+                                    int32_t* table, uint64_t* n_overflow, const uint64_t* site_mask, const uint32_t* word_rank)
+{
+    NP_HIP(c, hipSetDevice(c->device));
+    stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
+    family_timer tm(c, 2, s);
+    NP_HIP(c, np_launch_site_table_genome(n_groups, scores, first_site, last_site, n_motif, jobs, read_base, genome, contig_off, n_contigs, alphabet,
+                                          min_separation, call_threshold, n_pos, table, (unsigned long long*)n_overflow, site_mask, word_rank, s));
+    return NP_OK;
+}
+
 int np_site_table_genome_dev(np_ctx* c, void* stream, int64_t n_groups, const float* scores, const int32_t* first_site, const int32_t* last_site,
                              const int32_t* n_motif, const np_hmm_job_dev* jobs, const int64_t* read_base, const char* genome,
                              const int64_t* contig_off, int n_contigs, int alphabet, int min_separation, double call_threshold, int64_t n_pos,
@@ -790,11 +804,34 @@ int np_site_table_genome_dev(np_ctx* c, void* stream, int64_t n_groups, const fl
         (n_groups > 0 && (!scores || !first_site || !last_site || !n_motif || !jobs || !read_base || !genome || !contig_off || !table || !n_overflow)))
         return NP_ERR_INVALID;
     std::lock_guard<std::mutex> g(c->lock);
+    return site_table_genome_locked(c, stream, n_groups, scores, first_site, last_site, n_motif, jobs, read_base, genome, contig_off, n_contigs, alphabet,
+                                    min_separation, call_threshold, n_pos, table, n_overflow, nullptr, nullptr);
+}
+
+int np_site_table_genome_indexed_dev(np_ctx* c, void* stream, int64_t n_groups, const float* scores, const int32_t* first_site, const int32_t* last_site,
+                                     const int32_t* n_motif, const np_hmm_job_dev* jobs, const int64_t* read_base, const char* genome,
+                                     const int64_t* contig_off, int n_contigs, int alphabet, int min_separation, double call_threshold, int64_t n_pos,
+                                     const uint64_t* site_mask, const uint32_t* word_rank, int32_t* table, uint64_t* n_overflow)
+{
+    if (!c || n_groups < 0 || n_pos < 0 || n_contigs < 1 || min_separation < 0 || alphabet < 1 || alphabet > 4 || !site_mask || !word_rank ||
+        (n_groups > 0 && (!scores || !first_site || !last_site || !n_motif || !jobs || !read_base || !genome || !contig_off || !table || !n_overflow)))
+        return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    return site_table_genome_locked(c, stream, n_groups, scores, first_site, last_site, n_motif, jobs, read_base, genome, contig_off, n_contigs, alphabet,
+                                    min_separation, call_threshold, n_pos, table, n_overflow, site_mask, word_rank);
+}
+
+int np_genome_site_index_dev(np_ctx* c, void* stream, const char* genome, const int64_t* contig_off, int n_contigs, int alphabet, int64_t n_pos,
+                             uint64_t* site_mask, uint32_t* word_rank, int64_t* n_sites)
+{
+    if (!c || n_pos < 0 || n_contigs < 1 || alphabet < 1 || alphabet > 4 || !n_sites || (n_pos > 0 && (!genome || !contig_off || !site_mask || !word_rank)))
+        return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
     NP_HIP(c, hipSetDevice(c->device));
     stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
+    NP_HIP(c, c->site_scan.reserve((size_t)std::max<int64_t>(1, np_site_rank_chunks(n_pos)) * sizeof(uint32_t)));
     family_timer tm(c, 2, s);
-    NP_HIP(c, np_launch_site_table_genome(n_groups, scores, first_site, last_site, n_motif, jobs, read_base, genome, contig_off, n_contigs, alphabet,
-                                          min_separation, call_threshold, n_pos, table, (unsigned long long*)n_overflow, s));
+    NP_HIP(c, np_launch_genome_site_index(genome, contig_off, n_contigs, alphabet, n_pos, site_mask, word_rank, n_sites, c->site_scan.as<uint32_t>(), s));
     return NP_OK;
 }
 

@@ -876,6 +876,78 @@ __global__ void __launch_bounds__(256) np_site_table_kernel(int64_t n_groups, co
     if (meth) atomicAdd(&table[3 * row + 2], nm);
 }
 
+// ---- the motif sites of the resident genome as a rank structure: one bit per base (a recognition site starts here, inside its contig) and the
+// number of sites before every 64-base word.  rank(pos) = word_rank[pos >> 6] + popcount(mask[pos >> 6] below pos): the row of a site in a table
+// that has one row per SITE (312 679 for the bench's 5 Mb genome: 7.5 MB instead of 120 MB; a 3.1 Gb genome: 28 M sites, 672 MB instead of 74 GB).
+__global__ void __launch_bounds__(256) np_site_mask_kernel(const char* genome, const int64_t* contig_off, int n_contigs, int alphabet, int64_t n_pos, uint64_t* mask)
+{
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool hit = false;
+    if (p < n_pos) {
+        int lo = 0, hi = n_contigs;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (contig_off[mid] <= p) lo = mid; else hi = mid; }
+        const int64_t c0 = contig_off[lo];
+        const sites_t S = sites_of(alphabet);
+        hit = site_at(genome + c0, 0, (int)(contig_off[lo + 1] - c0), (int)(p - c0), S) >= 0;
+    }
+    const unsigned long long b = __ballot(hit);
+    if ((threadIdx.x & 63) == 0 && (p >> 6) < (n_pos + 63) / 64) mask[p >> 6] = b;
+}
+#define NP_RANK_CHUNK 2048        // words per workgroup of the scan
+// pass 1: word_rank[w] = sites before word w INSIDE its chunk; chunk_total[c]
+__global__ void __launch_bounds__(256) np_site_rank_local_kernel(const uint64_t* mask, int64_t n_words, uint32_t* word_rank, uint32_t* chunk_total)
+{
+    __shared__ uint32_t part[256];
+    const int64_t w0 = (int64_t)blockIdx.x * NP_RANK_CHUNK + threadIdx.x * 8;
+    uint32_t cnt[8], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { cnt[j] = w0 + j < n_words ? (uint32_t)__popcll(mask[w0 + j]) : 0u; sum += cnt[j]; }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { if (w0 + j < n_words) word_rank[w0 + j] = run; run += cnt[j]; }
+    if (threadIdx.x == 255) chunk_total[blockIdx.x] = part[255];
+}
+// pass 2, one workgroup: chunk_total -> exclusive prefix in place; *n_sites = the total
+__global__ void __launch_bounds__(1024) np_site_rank_chunks_kernel(uint32_t* chunk_total, int64_t n_chunks, int64_t* n_sites)
+{
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t c0 = 0; c0 < n_chunks; c0 += 1024) {
+        const int64_t c = c0 + threadIdx.x;
+        const uint32_t mine = c < n_chunks ? chunk_total[c] : 0u;
+        part[threadIdx.x] = mine;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        if (c < n_chunks) chunk_total[c] = carry + part[threadIdx.x] - mine;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_sites = (int64_t)carry;
+}
+// pass 3: add the chunk's base; word_rank[n_words] = the total
+__global__ void __launch_bounds__(256) np_site_rank_add_kernel(uint32_t* word_rank, const uint32_t* chunk_total, int64_t n_words, const int64_t* n_sites)
+{
+    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w < n_words) word_rank[w] += chunk_total[w / NP_RANK_CHUNK];
+    if (w == n_words) word_rank[w] = (uint32_t)*n_sites;
+}
+
 // The same aggregation keyed as the reference keys it: (contig, start, end) of the group (nanopolish_call_methylation.cpp:532-550;
 // calculate_methylation_frequency.py:16-23 -- `key = (c, start, end)`), for reads that OVERLAP on a genome.  A read's groups are its motif sites
 // chained by gaps <= min_separation (basemods.cpp:306-320), i.e. the intersection of a GENOME cluster with the read's segment: a read that ends
@@ -888,7 +960,7 @@ __global__ void __launch_bounds__(256) np_site_table_genome_kernel(int64_t n_gro
                                                                    const int32_t* n_motif, const np_hmm_job_dev* jobs, const int64_t* read_base,
                                                                    const char* genome, const int64_t* contig_off, int n_contigs, int alphabet,
                                                                    int min_separation, double call_threshold, int64_t n_pos, int32_t* table,
-                                                                   unsigned long long* n_overflow)
+                                                                   unsigned long long* n_overflow, const uint64_t* site_mask, const uint32_t* word_rank)
 {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= n_groups) return;
@@ -910,9 +982,16 @@ __global__ void __launch_bounds__(256) np_site_table_genome_kernel(int64_t n_gro
         if (site_at(ref, 0, clen, le + d, S) >= 0) end_is_clusters = false;
         if (site_at(ref, 0, clen, ls - d, S) >= 0) start_is_clusters = false;
     }
+    // the row of a key: its position -- or, with a site index (np_genome_site_index_dev), the ORDINAL of the motif site at that position: a table of
+    // n_sites rows instead of one row per base (both keys' positions are motif sites: a group's first and last)
+    auto row_of = [&](int64_t pos) -> int64_t {
+        if (!site_mask) return pos;
+        const uint64_t w = site_mask[pos >> 6];
+        return (int64_t)word_rank[pos >> 6] + __popcll(w & ((1ull << (pos & 63)) - 1ull));
+    };
     int32_t* row;
-    if (end_is_clusters) row = table + 6 * s;
-    else if (start_is_clusters) row = table + 6 * e + 3;
+    if (end_is_clusters) row = table + 6 * row_of(s);
+    else if (start_is_clusters) row = table + 6 * row_of(e) + 3;
     else { atomicAdd(n_overflow, 1ull); return; }
     atomicAdd(row, 1);
     atomicAdd(row + 1, nm);
@@ -955,13 +1034,28 @@ hipError_t np_launch_site_table(int64_t n_groups, const float* scores, const int
 hipError_t np_launch_site_table_genome(int64_t n_groups, const float* scores, const int32_t* first_site, const int32_t* last_site, const int32_t* n_motif,
                                        const np_hmm_job_dev* jobs, const int64_t* read_base, const char* genome, const int64_t* contig_off, int n_contigs,
                                        int alphabet, int min_separation, double call_threshold, int64_t n_pos, int32_t* table,
-                                       unsigned long long* n_overflow, hipStream_t s)
+                                       unsigned long long* n_overflow, const uint64_t* site_mask, const uint32_t* word_rank, hipStream_t s)
 {
     if (n_groups <= 0) return hipSuccess;
     hipLaunchKernelGGL(np_site_table_genome_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, n_groups, scores, first_site, last_site,
-                       n_motif, jobs, read_base, genome, contig_off, n_contigs, alphabet, min_separation, call_threshold, n_pos, table, n_overflow);
+                       n_motif, jobs, read_base, genome, contig_off, n_contigs, alphabet, min_separation, call_threshold, n_pos, table, n_overflow,
+                       site_mask, word_rank);
     return hipGetLastError();
 }
+
+// chunk_scratch: uint32[ceil(n_words / NP_RANK_CHUNK)]
+hipError_t np_launch_genome_site_index(const char* genome, const int64_t* contig_off, int n_contigs, int alphabet, int64_t n_pos, uint64_t* site_mask,
+                                       uint32_t* word_rank, int64_t* n_sites, uint32_t* chunk_scratch, hipStream_t s)
+{
+    const int64_t n_words = (n_pos + 63) / 64, n_chunks = (n_words + NP_RANK_CHUNK - 1) / NP_RANK_CHUNK;
+    if (n_pos <= 0) return hipMemsetAsync(n_sites, 0, sizeof(int64_t), s);
+    hipLaunchKernelGGL(np_site_mask_kernel, dim3((unsigned)((n_words * 64 + 255) / 256)), dim3(256), 0, s, genome, contig_off, n_contigs, alphabet, n_pos, site_mask);
+    hipLaunchKernelGGL(np_site_rank_local_kernel, dim3((unsigned)n_chunks), dim3(256), 0, s, site_mask, n_words, word_rank, chunk_scratch);
+    hipLaunchKernelGGL(np_site_rank_chunks_kernel, dim3(1), dim3(1024), 0, s, chunk_scratch, n_chunks, n_sites);
+    hipLaunchKernelGGL(np_site_rank_add_kernel, dim3((unsigned)((n_words + 1 + 255) / 256)), dim3(256), 0, s, word_rank, chunk_scratch, n_words, n_sites);
+    return hipGetLastError();
+}
+int64_t np_site_rank_chunks(int64_t n_pos) { const int64_t n_words = (n_pos + 63) / 64; return (n_words + NP_RANK_CHUNK - 1) / NP_RANK_CHUNK; }
 
 hipError_t np_launch_score_set_combine(int64_t n_sets, const int64_t* set_off, const int64_t* member_idx, const float* member_scores,
                                        const float* logsum, const double* log_n, float* out, hipStream_t s)

@@ -168,7 +168,10 @@ hipError_t np_launch_site_table(int64_t n_groups, const float* scores, const int
 hipError_t np_launch_site_table_genome(int64_t n_groups, const float* scores, const int32_t* first_site, const int32_t* last_site, const int32_t* n_motif,
                                        const np_hmm_job_dev* jobs, const int64_t* read_base, const char* genome, const int64_t* contig_off, int n_contigs,
                                        int alphabet, int min_separation, double call_threshold, int64_t n_pos, int32_t* table,
-                                       unsigned long long* n_overflow, hipStream_t s);
+                                       unsigned long long* n_overflow, const uint64_t* site_mask, const uint32_t* word_rank, hipStream_t s);
+hipError_t np_launch_genome_site_index(const char* genome, const int64_t* contig_off, int n_contigs, int alphabet, int64_t n_pos, uint64_t* site_mask,
+                                       uint32_t* word_rank, int64_t* n_sites, uint32_t* chunk_scratch, hipStream_t s);
+int64_t np_site_rank_chunks(int64_t n_pos);
 hipError_t np_launch_score_set_combine(int64_t n_sets, const int64_t* set_off, const int64_t* member_idx, const float* member_scores,
                                        const float* logsum, const double* log_n /* host-constants mode: log(0 .. 64) by the process's libm; else null */, float* out, hipStream_t s);
 hipError_t np_launch_selftest_div(uint64_t n_samples, uint64_t seed, unsigned long long* d_mismatches, hipStream_t s);

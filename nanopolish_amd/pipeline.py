@@ -581,17 +581,20 @@ class CallMethylationBatch:
         self.sync()
         return self.d_calibrated.cpu().numpy()
 
-    def genome_site_table(self, out=None, overflow=None, call_threshold=2.0):
+    def genome_site_table(self, out=None, overflow=None, call_threshold=2.0, per_site=False):
         """The batch's per-site table keyed (contig, start, end) on the resident contigs (np_site_table_genome_dev; sites.site_table_genome_dev):
-        needs a record batch with work items built on the device.  Returns (table int32 [genome length, 6], overflow [1])."""
+        needs a record batch with work items built on the device.  per_site: one row per motif SITE of the genome (the rank structure of
+        np_genome_site_index_dev, built on first use) instead of one per base.  Returns (table int32 [genome length or sites, 6], overflow [1])."""
         assert self.by_cigar and self.jobs_on_device, "genome-keyed table: a record batch (build_host_batch_records) with jobs_on_device=True"
-        from .sites import site_table_genome_dev
+        from .sites import site_table_genome_dev, genome_site_index_dev
         if not hasattr(self, "d_contig_off"):
             self.d_contig_off = self.torch.from_numpy(np.ascontiguousarray(self.hb["contig_off"], np.int64)).to(self.d_scores.device)
-        i32 = lambda t: t.view(self.torch.int32) if t.dtype == self.torch.uint8 else t
+        if per_site and getattr(self, "site_index", None) is None:
+            self.site_index = genome_site_index_dev(self.ctx, self.torch, self.d_genome, self.d_contig_off, alphabet=self.alphabet, stream=self.stream)
         return site_table_genome_dev(self.ctx, self.torch, self.d_scores, self.d_first, self.d_last, self.d_n_motif, self.d_jobs,
                                      self.d_ref_begin.view(self.torch.int64), self.d_genome, self.d_contig_off, alphabet=self.alphabet,
-                                     min_separation=self.cm[0], call_threshold=call_threshold, stream=self.stream, out=out, overflow=overflow)
+                                     min_separation=self.cm[0], call_threshold=call_threshold, stream=self.stream, out=out, overflow=overflow,
+                                     index=self.site_index if per_site else None)
 
     def event_map(self):
         self.sync()

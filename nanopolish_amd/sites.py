@@ -49,25 +49,50 @@ def site_table(torch, first, n_motif, llr, n_pos, call_threshold=2.0):
 MOTIFS = {"cpg": ("CG",), "gpc": ("GC",), "dam": ("GATC",), "dcm": ("CCAGG", "CCTGG")}
 
 
+def genome_site_index_dev(ctx, torch, genome, contig_off, alphabet="cpg", stream=None):
+    """The motif sites of the resident genome as a rank structure (np_genome_site_index_dev), built once per genome: returns
+    (site_mask int64-viewed uint64 [ceil(n_pos/64)], word_rank int32-viewed uint32 [ceil(n_pos/64) + 1], n_sites int).  Pass the pair as `index`
+    to site_table_genome_dev for a table with one row per SITE."""
+    from . import api
+    n_pos = int(genome.numel()); n_words = (n_pos + 63) // 64
+    mask = torch.empty(max(1, n_words), dtype=torch.int64, device=genome.device)
+    rank = torch.empty(n_words + 1, dtype=torch.int32, device=genome.device)
+    total = torch.zeros(1, dtype=torch.int64, device=genome.device)
+    torch.cuda.current_stream().synchronize()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rc = ctx.L.np_genome_site_index_dev(ctx.h, C.c_void_p(stream) if stream else None, p(genome), p(contig_off), int(contig_off.numel()) - 1,
+                                        api.alphabet_id(alphabet), n_pos, p(mask), p(rank), p(total))
+    ctx._chk(rc, "np_genome_site_index_dev")
+    ctx.sync()
+    return mask, rank, int(total.item())
+
+
 def site_table_genome_dev(ctx, torch, scores, first, last, n_motif, jobs, read_base, genome, contig_off, alphabet="cpg", min_separation=10,
-                          call_threshold=2.0, stream=None, out=None, overflow=None):
+                          call_threshold=2.0, stream=None, out=None, overflow=None, index=None):
     """The genome-keyed table of a batch on the device (np_site_table_genome_dev).  scores: float32, 2 per group (NaN = skipped); first / last /
     n_motif: int32 per group, segment-relative; jobs: the batch's work items (2 per group: the read of a group); read_base: int64 per read, the
     genome offset of its segment; genome: uint8 device tensor (the contigs, concatenated); contig_off: int64 device tensor [n_contigs + 1].
-    Returns (table int32 [n_pos, 6], overflow uint64-as-int64 [1]); accumulates into `out` / `overflow` when given."""
+    index = genome_site_index_dev's (site_mask, word_rank, n_sites): one row per motif SITE (np_site_table_genome_indexed_dev) instead of per base.
+    Returns (table int32 [n_pos or n_sites, 6], overflow uint64-as-int64 [1]); accumulates into `out` / `overflow` when given."""
     from . import api
     n_groups = first.numel()
     n_pos = int(genome.numel())
     fresh = out is None or overflow is None
-    table = out if out is not None else torch.zeros((n_pos, 6), dtype=torch.int32, device=scores.device)
+    n_rows = n_pos if index is None else int(index[2])
+    table = out if out is not None else torch.zeros((n_rows, 6), dtype=torch.int32, device=scores.device)
+    if table.shape[0] != n_rows:
+        raise ValueError("table has %d rows, the key space has %d" % (table.shape[0], n_rows))
     ovf = overflow if overflow is not None else torch.zeros(1, dtype=torch.int64, device=scores.device)
     if fresh:
         torch.cuda.current_stream().synchronize()        # the zero-fill ran on torch's stream, the kernel runs on the library's
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-    rc = ctx.L.np_site_table_genome_dev(ctx.h, C.c_void_p(stream) if stream else None, n_groups, p(scores), p(first), p(last), p(n_motif), p(jobs),
-                                        p(read_base), p(genome), p(contig_off), int(contig_off.numel()) - 1, api.alphabet_id(alphabet),
-                                        int(min_separation), float(call_threshold), n_pos, p(table), p(ovf))
-    ctx._chk(rc, "np_site_table_genome_dev")
+    head = (ctx.h, C.c_void_p(stream) if stream else None, n_groups, p(scores), p(first), p(last), p(n_motif), p(jobs),
+            p(read_base), p(genome), p(contig_off), int(contig_off.numel()) - 1, api.alphabet_id(alphabet),
+            int(min_separation), float(call_threshold), n_pos)
+    if index is None:
+        ctx._chk(ctx.L.np_site_table_genome_dev(*head, p(table), p(ovf)), "np_site_table_genome_dev")
+    else:
+        ctx._chk(ctx.L.np_site_table_genome_indexed_dev(*head, p(index[0]), p(index[1]), p(table), p(ovf)), "np_site_table_genome_indexed_dev")
     return table, ovf
 
 
@@ -103,15 +128,17 @@ def _cluster_bounds(hit, contig_off, min_separation):
     return cstart, cend
 
 
-def site_table_genome(torch, start, end, n_motif, llr, genome, contig_off, alphabet="cpg", min_separation=10, call_threshold=2.0):
+def site_table_genome(torch, start, end, n_motif, llr, genome, contig_off, alphabet="cpg", min_separation=10, call_threshold=2.0, compact=False):
     """Host mirror of site_table_genome_dev (CPU; the checker of the device kernel and the per-rank table of the gloo tests).  start / end: int64
     GENOME positions of every group's first / last motif site; llr: float64 (NaN = skipped).  The text round trip IS printf here.
-    Returns (table int32 [n_pos, 6], overflow int)."""
+    compact: one row per motif SITE (row = the site's ordinal in the genome), the layout of site_table_genome_dev(index=...).
+    Returns (table int32 [n_pos or n_sites, 6], overflow int)."""
     import numpy as np
     hit = motif_sites(genome, contig_off, alphabet)
     cstart, cend = _cluster_bounds(hit, contig_off, min_separation)
     n_pos = len(hit)
-    table = torch.zeros((n_pos, 6), dtype=torch.int32)
+    ordinal = np.cumsum(hit) - 1
+    table = torch.zeros((int(hit.sum()) if compact else n_pos, 6), dtype=torch.int32)
     vals = llr.detach().cpu().tolist()
     llr2 = np.array([float("%.2f" % v) if v == v and abs(v) != float("inf") else float("nan") for v in vals], np.float64)
     s = start.cpu().numpy().astype(np.int64); e = end.cpu().numpy().astype(np.int64); nm = n_motif.cpu().numpy().astype(np.int64)
@@ -126,6 +153,8 @@ def site_table_genome(torch, start, end, n_motif, llr, genome, contig_off, alpha
         else:
             overflow += 1
             continue
+        if compact:
+            row = ordinal[row]
         t[row, col] += 1; t[row, col + 1] += nm[i]
         if llr2[i] > 0:
             t[row, col + 2] += nm[i]
@@ -134,14 +163,20 @@ def site_table_genome(torch, start, end, n_motif, llr, genome, contig_off, alpha
 
 def genome_table_rows(table, genome, contig_off, alphabet="cpg", min_separation=10):
     """The keys of a genome-keyed table as the frequency script lists them: sorted [(start, end, num_reads, called_sites, called_sites_methylated)]
-    with GENOME positions (the caller maps them to (contig, position))."""
+    with GENOME positions (the caller maps them to (contig, position)).  A table with one row per motif site (fewer rows than bases) is
+    recognised by its length."""
     import numpy as np
     t = table.cpu().numpy()
     hit = motif_sites(genome, contig_off, alphabet)
     cstart, cend = _cluster_bounds(hit, contig_off, min_separation)
+    pos_of = np.arange(len(hit)) if t.shape[0] == len(hit) else np.flatnonzero(hit)
+    if len(pos_of) != t.shape[0]:
+        raise ValueError("table has %d rows; the genome has %d bases and %d motif sites" % (t.shape[0], len(hit), int(hit.sum())))
     rows = []
     for r in np.flatnonzero(t[:, 0] > 0):
-        rows.append((int(r), int(cend[r]), int(t[r, 0]), int(t[r, 1]), int(t[r, 2])))
+        g = int(pos_of[r])
+        rows.append((g, int(cend[g]), int(t[r, 0]), int(t[r, 1]), int(t[r, 2])))
     for r in np.flatnonzero(t[:, 3] > 0):
-        rows.append((int(cstart[r]), int(r), int(t[r, 3]), int(t[r, 4]), int(t[r, 5])))
+        g = int(pos_of[r])
+        rows.append((int(cstart[g]), g, int(t[r, 3]), int(t[r, 4]), int(t[r, 5])))
     return sorted(rows)

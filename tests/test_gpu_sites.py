@@ -228,3 +228,43 @@ def test_genome_table_kernel_on_cut_groups(ctx):
         b = int(contig_off[int(f[0][len("contig"):]) - 1])
         gold.append((b + int(f[1]), b + int(f[2]), int(f[4]), int(f[5])))
     assert [(s_, e_, c_, m_) for s_, e_, _, c_, m_ in genome_table_rows(table, genome, contig_off)] == sorted(gold)
+    # ---- one row per motif SITE (np_genome_site_index_dev + np_site_table_genome_indexed_dev): the same keys, the rows of the sites only
+    from nanopolish_amd.sites import genome_site_index_dev, motif_sites
+    d_genome = up(np.frombuffer(genome, np.uint8)); d_off = up(contig_off).view(torch.int64)
+    mask, rank, n_sites = genome_site_index_dev(ctx, torch, d_genome, d_off)
+    hit = motif_sites(genome, contig_off)
+    assert n_sites == int(hit.sum())
+    bits = np.unpackbits(mask.cpu().numpy().view(np.uint8), bitorder="little")[:len(hit)].astype(bool)
+    assert np.array_equal(bits, hit)                                                      # (a CG across the contig boundary is not a site)
+    words = np.add.reduceat(hit.astype(np.int64), np.arange(0, len(hit), 64))
+    assert np.array_equal(rank.cpu().numpy().view(np.uint32), np.concatenate([[0], np.cumsum(words)]).astype(np.uint32))
+    compact, ovf_c = site_table_genome_dev(ctx, torch, up(sc).view(torch.float32), up(first).view(torch.int32), up(last).view(torch.int32),
+                                           up(nm).view(torch.int32), up(jobs), up(base).view(torch.int64), d_genome, d_off, index=(mask, rank, n_sites))
+    ctx.sync()
+    assert compact.shape == (n_sites, 6) and int(ovf_c.cpu()[0]) == 0
+    assert np.array_equal(compact.cpu().numpy(), got[hit]) and int(got[~hit].sum()) == 0
+    want_c, _ = site_table_genome(torch, t(base + 7, torch.int64), t(base + last, torch.int64), t(nm, torch.int64), t(llr, torch.float64), genome, contig_off,
+                                  compact=True)
+    assert np.array_equal(compact.cpu().numpy(), want_c.numpy())
+    assert genome_table_rows(compact, genome, contig_off) == genome_table_rows(table, genome, contig_off)
+
+
+@pytest.mark.parametrize("n_pos", [1, 63, 64, 65, 2048 * 64 - 1, 2048 * 64 * 3 + 77, 140_000_011])
+def test_genome_site_index_sizes(ctx, n_pos):
+    """np_genome_site_index_dev across the scan's seams: one word, one chunk of 2 048 words, several chunks, more chunks than the second pass's
+    1 024 threads (140 Mb = 1 069 chunks), several contigs with sites cut by their boundaries, for every alphabet."""
+    import torch
+    from nanopolish_amd.sites import genome_site_index_dev, motif_sites
+    rng = np.random.default_rng(n_pos)
+    g = rng.choice(np.frombuffer(b"ACGT", np.uint8), n_pos)
+    cuts = np.unique(np.concatenate([[0, n_pos], rng.integers(0, n_pos + 1, 5)])).astype(np.int64)
+    dev = torch.device("cuda:0")
+    d_g = torch.from_numpy(g).to(dev); d_off = torch.from_numpy(cuts).to(dev)
+    for alphabet in (("cpg", "gpc", "dam", "dcm") if n_pos < 10_000_000 else ("cpg",)):
+        mask, rank, n_sites = genome_site_index_dev(ctx, torch, d_g, d_off, alphabet=alphabet)
+        hit = motif_sites(g.tobytes(), cuts, alphabet)
+        assert n_sites == int(hit.sum())
+        bits = np.unpackbits(mask.cpu().numpy().view(np.uint8), bitorder="little")[:n_pos].astype(bool)
+        assert np.array_equal(bits, hit)
+        words = np.add.reduceat(hit.astype(np.int64), np.arange(0, n_pos, 64))
+        assert np.array_equal(rank.cpu().numpy().view(np.uint32), np.concatenate([[0], np.cumsum(words)]).astype(np.uint32))

@@ -59,7 +59,8 @@ def test_two_rank_site_reduction_equals_single_process(tmp_path):
 
 # ---- the genome-keyed reduction (round 6): ranks hold reads that OVERLAP on the same contigs ---------------------------------------------
 def _genome_rank_table(lo, hi):
-    """per-rank table of the golden generator's reads lo..hi-1 (records grouped by read), keyed (contig, start, end) -- sites.site_table_genome"""
+    """per-rank table of the golden generator's reads lo..hi-1 (records grouped by read), keyed (contig, start, end), one row per motif site of the
+    genome (the bench's layout: np_site_table_genome_indexed_dev) -- sites.site_table_genome(compact=True)"""
     from gen_golden_frequency import synthetic_genome_calls
     from nanopolish_amd.sites import site_table_genome
     lines, recs, contigs = synthetic_genome_calls()
@@ -72,7 +73,7 @@ def _genome_rank_table(lo, hi):
     table, ovf = site_table_genome(torch, t(lambda r: int(contig_off[r["contig"]]) + r["start_position"], torch.int64),
                                    t(lambda r: int(contig_off[r["contig"]]) + r["end_position"], torch.int64), t(lambda r: r["n_motif"], torch.int64),
                                    t(lambda r: (r["ll_methylated"][0] + r["ll_methylated"][1]) - (r["ll_unmethylated"][0] + r["ll_unmethylated"][1]), torch.float64),
-                                   "".join(contigs).encode(), contig_off)
+                                   "".join(contigs).encode(), contig_off, compact=True)
     assert ovf == 0
     return table, contigs, contig_off
 

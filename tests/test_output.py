@@ -105,3 +105,10 @@ def test_genome_keyed_site_table_equals_reference_script_on_overlapping_reads():
     for s, e, _, _ in want:
         starts.setdefault(s, set()).add(e)
     assert any(len(v) > 1 for v in starts.values())                       # one start, several ends: what a start-keyed table would merge
+    # one row per motif SITE (the layout of np_site_table_genome_indexed_dev): the same keys from a table of the sites' rows only
+    from nanopolish_amd.sites import motif_sites
+    hit = motif_sites(genome, contig_off)
+    compact, ovf_c = site_table_genome(torch, start, end, nm, llr, genome, contig_off, compact=True)
+    assert ovf_c == 0 and compact.shape[0] == int(hit.sum()) < len(genome) // 4
+    assert np.array_equal(compact.numpy(), t[hit]) and int(t[~hit].sum()) == 0
+    assert genome_table_rows(compact, genome, contig_off) == genome_table_rows(table, genome, contig_off)

@@ -141,4 +141,19 @@ for seed in 34 35 36 37 38 39; do ( timeout 900 python tests/gpu_soak.py --reads
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 }
 
+# the genome-keyed table with one row per motif site (np_genome_site_index_dev + np_site_table_genome_indexed_dev): the GPU suite, then the
+# genome line at one rank with both row layouts (table_and_allreduce_ms: the zero fill + the table kernel), the gloo rehearsal at 2 ranks,
+# and the 250 000-read line
+call_s() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r06s; mkdir -p $O
+( time timeout 1500 python -m pytest tests -m gpu -q ) > $O/pytest.log 2>&1; grep -h "passed\|failed" $O/pytest.log; grep -B30 "^FAILED\|Error" $O/pytest.log | tail -60
+for rows in site base; do
+( time timeout 600 python bench.py --gpus 1 --genome 1 --site-rows $rows --pool 2000 --tile 5 --steps 3 --warmup 1 --cpu-sample 0 ) > $O/genome_n1_$rows.json 2> $O/genome_n1_$rows.err; echo "rc=$?"; show_line $O/genome_n1_$rows.json
+done
+( time NP_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --pool 2000 --tile 5 --steps 3 --warmup 1 --cpu-sample 0 ) > $O/genome_gloo2.json 2> $O/genome_gloo2.err; echo "rc=$?"; show_line $O/genome_gloo2.json
+( time timeout 1500 python bench.py --gpus 1 --genome 1 --pool 50000 --tile 5 --steps 3 --warmup 1 --cpu-sample 0 ) > $O/genome_n1_250k.json 2> $O/genome_n1_250k.err; echo "rc=$?"; show_line $O/genome_n1_250k.json
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+}
+
 "call_$1"
