@@ -156,4 +156,15 @@ done
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 }
 
+# kernel A with the next band's emissions threaded through the band's tail (NP_A_PIPE) against the shipped build: A/B/A/B on one box (pairs crc),
+# then the aligner's own GPU tests on the pipelined build and a short headline run
+call_u() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r06u; mkdir -p $O
+( timeout 900 python tools/align_ab.py --pool 2048 --tile 16 $V/libnp_hip_base.so $V/libnp_hip_pipe.so $V/libnp_hip_base.so $V/libnp_hip_pipe.so ) > $O/align_ab.log 2>&1; cat $O/align_ab.log | tail -8
+( timeout 900 python tools/align_ab.py --pool 2048 --tile 16 --ragged 1 $V/libnp_hip_base.so $V/libnp_hip_pipe.so ) > $O/align_ab_ragged.log 2>&1; cat $O/align_ab_ragged.log | tail -4
+( time timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_long_reads.py tests/test_gpu_fallbacks.py tests/test_gpu_edges.py -m gpu -x -q ) > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+( time timeout 600 python bench.py --steps 5 --warmup 2 --legs 0 --streamed 0 --ragged 0 ) > $O/bench.json 2> $O/bench.err; head -c 700 $O/bench.json; tail -3 $O/bench.err
+}
+
 "call_$1"

@@ -12,6 +12,7 @@
 template <int OP> __global__ void k(unsigned long long* out, float* sink, int iters)
 {
     float a0 = threadIdx.x, a1 = 1.5f, a2 = 2.5f, a3 = 3.5f, a4 = 4.5f, a5 = 5.5f, a6 = 6.5f, a7 = 7.5f;
+    float b0 = 0.5f, b1 = 1.25f, b2 = 2.25f, b3 = 3.25f, b4 = 4.25f, b5 = 5.25f, b6 = 6.25f, b7 = 7.25f;
     double d0 = 1.0, d1 = 2.0, d2 = 3.0, d3 = 4.0, d4 = 5.0, d5 = 6.0, d6 = 7.0, d7 = 8.0;
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 p0 = {1.f, 2.f}, p1 = p0, p2 = p0, p3 = p0, p4 = p0, p5 = p0, p6 = p0, p7 = p0;
@@ -108,6 +109,33 @@ template <int OP> __global__ void k(unsigned long long* out, float* sink, int it
 #define RDLNM0S(n) asm volatile("s_mov_b32 m0, %2\n v_readlane_b32 %0, %1, m0" : "=s"(s0) : "v"(a##n), "s"(q##n) : "m0");
 #define RDFIRST(n) asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(s0) : "v"(a##n));
 #define MAX3F(n) asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(a##n) : "v"(a##n), "v"(a0), "v"(a1));
+// ---- round 6: a slow-class op and a fast-class op ALTERNATING (do the classes share one port, or does the short op issue in the long one's shadow?)
+#define FB(n) "v_fma_f32 %1, %1, %1, %1\n"
+#define PAIR(NAME, SLOW) asm volatile(SLOW "\n v_fma_f32 %1, %1, %1, %1" : "+v"(a##NAME), "+v"(b##NAME));
+#define PX_MAX3(n) asm volatile("v_max3_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1" : "+v"(a##n), "+v"(b##n));
+#define PX_CMP64(n) asm volatile("v_cmp_eq_f32_e64 s[10:11], %0, %0\n v_fma_f32 %1, %1, %1, %1" : "+v"(a##n), "+v"(b##n) : : "s10", "s11");
+#define PX_CMP32(n) asm volatile("v_cmp_eq_f32_e32 vcc, %0, %0\n v_fma_f32 %1, %1, %1, %1" : "+v"(a##n), "+v"(b##n) : : "vcc");
+#define PX_ADDC64(n) asm volatile("v_addc_co_u32_e64 %0, s[12:13], %0, %0, s[10:11]\n v_fma_f32 %1, %1, %1, %1" : "+v"(a##n), "+v"(b##n) : : "s12", "s13");
+#define PX_CND64(n) asm volatile("v_cndmask_b32_e64 %0, %0, %2, s[10:11]\n v_fma_f32 %1, %1, %1, %1" : "+v"(a##n), "+v"(b##n) : "v"(a0));
+#define PX_DPP(n) asm volatile("v_mov_b32_dpp %0, %0 wave_ror:1 row_mask:0xf bank_mask:0xf\n v_fma_f32 %1, %1, %1, %1" : "+v"(a##n), "+v"(b##n));
+#define PX_ADD64(n) asm volatile("v_add_f64 %0, %0, %0\n v_fma_f32 %1, %1, %1, %1" : "+v"(d##n), "+v"(b##n));
+#define PX_CVT32(n) asm volatile("v_cvt_f32_f64 %0, %2\n v_fma_f32 %1, %1, %1, %1" : "=v"(a##n), "+v"(b##n) : "v"(d##n));
+#define PX_CVT64(n) asm volatile("v_cvt_f64_f32 %0, %2\n v_fma_f32 %1, %1, %1, %1" : "=v"(d##n), "+v"(b##n) : "v"(a##n));
+#define PX_RDLNS(n) asm volatile("v_readlane_b32 %0, %2, %3\n v_fma_f32 %1, %1, %1, %1" : "=s"(s0), "+v"(b##n) : "v"(a##n), "s"(q##n));
+// one slow op, TWO fast ones
+#define P2_MAX3(n) asm volatile("v_max3_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_add_f32 %2, %2, %2" : "+v"(a##n), "+v"(b##n), "+v"(p##n.x));
+#define P2_ADD64(n) asm volatile("v_add_f64 %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_add_f32 %2, %2, %2" : "+v"(d##n), "+v"(b##n), "+v"(a##n));
+#define P2_CMP64(n) asm volatile("v_cmp_eq_f32_e64 s[10:11], %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_add_f32 %2, %2, %2" : "+v"(a##n), "+v"(b##n), "+v"(p##n.x) : : "s10", "s11");
+// two DIFFERENT slow ops alternating: the reference's fp64 sums beside the compare / select / carry kind
+#define SS_ADD64_CMP64(n) asm volatile("v_add_f64 %0, %0, %0\n v_cmp_eq_f32_e64 s[10:11], %1, %1" : "+v"(d##n) : "v"(a##n) : "s10", "s11");
+#define SS_ADD64_MAX3(n) asm volatile("v_add_f64 %0, %0, %0\n v_max3_f32 %1, %1, %1, %1" : "+v"(d##n), "+v"(a##n));
+#define SS_ADD64_ADDC(n) asm volatile("v_add_f64 %0, %0, %0\n v_addc_co_u32_e64 %1, s[12:13], %1, %1, s[10:11]" : "+v"(d##n), "+v"(a##n) : : "s12", "s13");
+#define SS_ADD64_CND(n) asm volatile("v_add_f64 %0, %0, %0\n v_cndmask_b32_e64 %1, %1, %2, s[10:11]" : "+v"(d##n), "+v"(a##n) : "v"(b0));
+#define SS_ADD64_DPP(n) asm volatile("v_add_f64 %0, %0, %0\n v_mov_b32_dpp %1, %1 wave_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(d##n), "+v"(a##n));
+#define SS_CVT64_CMP64(n) asm volatile("v_cvt_f64_f32 %0, %1\n v_cmp_eq_f32_e64 s[10:11], %2, %2" : "=v"(d##n) : "v"(b##n), "v"(a##n) : "s10", "s11");
+#define SS_CVT32_ADDC(n) asm volatile("v_cvt_f32_f64 %0, %2\n v_addc_co_u32_e64 %1, s[12:13], %1, %1, s[10:11]" : "=v"(b##n), "+v"(a##n) : "v"(d##n) : "s12", "s13");
+#define SS_CMP64_ADDC(n) asm volatile("v_cmp_eq_f32_e64 s[14:15], %0, %0\n v_addc_co_u32_e64 %1, s[12:13], %1, %1, s[10:11]" : : "v"(b##n), "v"(a##n) : "s12", "s13", "s14", "s15");
+#define SS_MAX3_CMP64(n) asm volatile("v_max3_f32 %0, %0, %0, %0\n v_cmp_eq_f32_e64 s[14:15], %1, %1" : "+v"(a##n) : "v"(b##n) : "s14", "s15");
         if (OP == 0) { REP8(CVT64) REP8(CVT64) }
         if (OP == 1) { REP8(CVT32) REP8(CVT32) }
         if (OP == 2) { REP8(ADD64) REP8(ADD64) }
@@ -191,10 +219,33 @@ template <int OP> __global__ void k(unsigned long long* out, float* sink, int it
         if (OP == 97) { REP8(RDLNM0S) REP8(RDLNM0S) }
         if (OP == 98) { REP8(RDFIRST) REP8(RDFIRST) }
         if (OP == 16) { REP8(CVTI) REP8(CVTI) }
+        if (OP == 100) { REP8(PX_MAX3) }
+        if (OP == 101) { REP8(PX_CMP64) }
+        if (OP == 102) { REP8(PX_CMP32) }
+        if (OP == 103) { REP8(PX_ADDC64) }
+        if (OP == 104) { REP8(PX_CND64) }
+        if (OP == 105) { REP8(PX_DPP) }
+        if (OP == 106) { REP8(PX_ADD64) }
+        if (OP == 107) { REP8(PX_CVT32) }
+        if (OP == 108) { REP8(PX_CVT64) }
+        if (OP == 109) { REP8(PX_RDLNS) }
+        if (OP == 110) { REP8(SS_ADD64_CMP64) }
+        if (OP == 111) { REP8(SS_ADD64_MAX3) }
+        if (OP == 112) { REP8(SS_ADD64_ADDC) }
+        if (OP == 113) { REP8(SS_ADD64_CND) }
+        if (OP == 114) { REP8(SS_ADD64_DPP) }
+        if (OP == 115) { REP8(SS_CVT64_CMP64) }
+        if (OP == 116) { REP8(SS_CVT32_ADDC) }
+        if (OP == 117) { REP8(SS_CMP64_ADDC) }
+        if (OP == 118) { REP8(SS_MAX3_CMP64) }
+        if (OP == 120) { P2_MAX3(0) P2_MAX3(1) P2_MAX3(2) P2_MAX3(3) P2_MAX3(4) P2_ADD64(5) }
+        if (OP == 121) { P2_ADD64(0) P2_ADD64(1) P2_ADD64(2) P2_ADD64(3) P2_ADD64(4) P2_MAX3(5) }
+        if (OP == 122) { P2_CMP64(0) P2_CMP64(1) P2_CMP64(2) P2_CMP64(3) P2_CMP64(4) P2_MAX3(5) }
+
     }
     unsigned long long t1 = __builtin_readcyclecounter();
     if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
-    sink[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7) +
+    sink[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7 + (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7) +
                                           p0.x + p1.y + p2.x + p3.y + p4.x + p5.x + p6.x + p7.x + s0 + q0 + q1 + q2 + q3 + q4 + q5 + q6 + q7;
 }
 
@@ -227,6 +278,16 @@ int main(int argc, char** argv)
         run<44>("v_mul_f32", w); run<90>("v_mul_f32 literal", w); run<91>("v_mul_f32 |v|, s", w); run<40>("v_cvt_u32_f32", w); run<92>("v_cvt_u32_f32 |v| e64", w);
         run<9>("v_readlane const", w); run<64>("v_readlane sgpr sel", w); run<96>("v_readlane m0", w); run<97>("s_mov m0 + v_readlane m0", w); run<98>("v_readfirstlane", w);
         run<93>("v_add_f32 literal", w); run<47>("v_and_b32", w); run<94>("v_and_b32 literal", w); run<95>("v_and_b32 inline -4", w);
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'm') {          // "m": round 6, slow-class ops alternating with fast ones and with each other (16 instructions per iteration)
+        const int w = 8;
+        run<3>("v_fma_f32", w); run<2>("v_add_f64", w); run<6>("v_max3_f32", w); run<24>("v_cmp_e64 sgpr", w); run<62>("v_addc_co e64 sgpr", w);
+        run<100>("max3 | fma", w); run<101>("cmp_e64 | fma", w); run<102>("cmp_e32 vcc | fma", w); run<103>("addc_e64 | fma", w); run<104>("cnd_e64 | fma", w);
+        run<105>("dpp ror | fma", w); run<106>("add_f64 | fma", w); run<107>("cvt_f32_f64 | fma", w); run<108>("cvt_f64_f32 | fma", w); run<109>("readlane s | fma", w);
+        run<110>("add_f64 | cmp_e64", w); run<111>("add_f64 | max3", w); run<112>("add_f64 | addc_e64", w); run<113>("add_f64 | cnd_e64", w); run<114>("add_f64 | dpp", w);
+        run<115>("cvt_f64 | cmp_e64", w); run<116>("cvt_f32 | addc_e64", w); run<117>("cmp_e64 | addc_e64", w); run<118>("max3 | cmp_e64", w);
+        run<120>("5x(max3,fma,add)+(add64,fma,add) /18", w); run<121>("5x(add64,fma,add)+(max3,..) /18", w); run<122>("5x(cmp64,fma,add)+(max3,..) /18", w);
         return 0;
     }
     for (int w : {8, 4, 2, 1}) {
