@@ -167,4 +167,13 @@ O=gpurun_out/r06u; mkdir -p $O
 ( time timeout 600 python bench.py --steps 5 --warmup 2 --legs 0 --streamed 0 --ragged 0 ) > $O/bench.json 2> $O/bench.err; head -c 700 $O/bench.json; tail -3 $O/bench.err
 }
 
+# soak on the tree as it stands after the genome site index (kernels of the headline path unchanged; the library rebuilt): six new seeds of 1 500
+# records through the whole chain against the reference compiled in place, 1 024 full-size eventalign reads
+call_y() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r06y; mkdir -p $O
+for seed in 40 41 42 43 44 45; do ( timeout 900 python tests/gpu_soak.py --reads 1500 --seed $seed ) > $O/soak_$seed.log 2>&1; grep "^{" $O/soak_$seed.log | cut -c1-330; done
+( timeout 1200 python tests/gpu_soak_eventalign.py 1024 ) > $O/soak_ea.log 2>&1; tail -2 $O/soak_ea.log | cut -c1-300
+}
+
 "call_$1"
