@@ -512,6 +512,12 @@ int np_reverse_events_dev(np_ctx* ctx, void* stream, int n_reads, const int64_t*
  * divide on n_samples pseudo-random operand pairs; *n_mismatch must come back 0. */
 int np_selftest_division(np_ctx* ctx, uint64_t n_samples, uint64_t seed, uint64_t* n_mismatch);
 
+/* Device self-test: the detector's two-operation division by a window length w (q = RN(x ch + RN(x cl)), ch + cl = 1 / w to twice the
+ * precision; csrc/np_events_kernels.hip:div_small_f32 / div_small_f64 -- event_detection.c:97-101,111 divide by w_lengthf) against the IEEE
+ * divide: fp32 on EVERY float of magnitude 0 or >= 2^-100 (*n_f32_compared of them), fp64 on n_f64 pseudo-random doubles.  w = 3 and 6 run
+ * with the constants the fused walk itself uses.  Both mismatch counts must come back 0. */
+int np_selftest_division_small(np_ctx* ctx, int w, uint64_t n_f64, uint64_t* n_mismatch_f32, uint64_t* n_mismatch_f64, uint64_t* n_f32_compared);
+
 /* Device memory, pinned host memory, streams and events for bindings that are not HIP programs themselves
  * (csrc/np_batch_dropin.cpp is plain C++ inside a nanopolish build).  Copies and fills are plain stream operations enqueued on
  * `stream` (0 = the context's own): they take no part in the one-stream-at-a-time rule of the compute entry points, so an upload

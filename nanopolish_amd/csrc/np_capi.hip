@@ -545,6 +545,26 @@ int np_selftest_division(np_ctx* c, uint64_t n_samples, uint64_t seed, uint64_t*
     return NP_OK;
 }
 
+int np_selftest_division_small(np_ctx* c, int w, uint64_t n_f64, uint64_t* n_mismatch_f32, uint64_t* n_mismatch_f64, uint64_t* n_f32_compared)
+{
+    if (!c || w < 2 || w > 1024 || !n_mismatch_f32 || !n_mismatch_f64) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    unsigned long long* d = (unsigned long long*)(c->d_counters + 32);
+    stream_scope scope = use_stream(c, nullptr);
+    NP_HIP(c, hipMemsetAsync(d, 0, 3 * sizeof(unsigned long long), c->stream));
+    // ch = RN(1 / w), cl = RN(1 / w - ch): the residual 1 - w ch is exact in one fma, its quotient by w is the low part
+    const double wd = (double)w, chd = 1.0 / wd, cld = std::fma(-wd, chd, 1.0) / wd;
+    const float chf = (float)chd, clf = (float)((chd - (double)chf) + cld);
+    NP_HIP(c, np_launch_selftest_div_small(w, chd, cld, chf, clf, n_f64, d, c->stream));
+    unsigned long long h[3] = {0, 0, 0};
+    NP_HIP(c, hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    NP_HIP(c, hipStreamSynchronize(c->stream));
+    *n_mismatch_f32 = h[0]; *n_mismatch_f64 = h[1];
+    if (n_f32_compared) *n_f32_compared = h[2];
+    return NP_OK;
+}
+
 void* np_dev_alloc(np_ctx* c, size_t bytes)
 {
     if (!c) return nullptr;

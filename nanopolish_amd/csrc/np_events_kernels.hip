@@ -122,6 +122,8 @@ __device__ __forceinline__ void ed_check_finish(const ed_range& R, const int64_t
             if (mx >= 0x7f800000u) { bad = true; continue; }               // inf / nan
             if (mn == 0xffffffffu) continue;                                // all zero
             if ((mn >> 23) == 0u) { ok = false; continue; }                 // a denormal term: no bound attempted
+            if (w == 0 && mn < 0x30800000u) { ok = false; continue; }       // a non-zero |sample| below 2^-30: the fused walk's two-operation
+                                                                            // divisions (div_small_f32) want their dividends 0 or >= 2^-100
             const int g = (int)(mn >> 23) - 127 - 23;                       // every term is a multiple of 2^g
             const double bound = (double)n * (double)__builtin_bit_cast(float, mx);
             ok = ok && bound < ldexp(1.0, 53 + g);
@@ -349,20 +351,41 @@ __device__ __forceinline__ double div_f64_normal(double a, double b)     // b > 
     return __builtin_fma(r, y, q);
 }
 
-// tstat_from_sums for the fused walk: the same arithmetic with (1) the two wrappers above, (2) the plain division of a variance clamped to
-// FLT_MIN (a denormal quotient, outside what np_div_exact's correction steps cover) taken only when SOME lane of the wave has such a sample
+// x / w for a window length w = 2^a w' (w' odd, small), correctly rounded, in TWO operations (round 6): q = RN(x ch + RN(x cl)) with
+// ch = RN(1 / w), cl = RN(1 / w - ch).  Why that is the IEEE quotient: scale x / w so that its unit in the last place is 1; the rounding
+// boundaries are the half-odd-integers (2k + 1) / 2, and x / w - (2k + 1) / 2 = (2^(t+1) X - w' (2k + 1)) / (2 w') for integers X, t, k --
+// an even number minus an odd one over 2 w' -- so the exact quotient is never closer than 1 / (2 w') of a unit to a boundary (1/6 for the
+// DNA windows 3 and 6), while x ch + RN(x cl) differs from it by ~3 * 2^-p units (p = 24 or 53): both lie strictly between the same two
+// boundaries and round alike.  (The general Markstein sequence of np_div_exact needs five operations because it has no such gap to rely
+// on.)  Holds while RN(x cl) keeps its relative precision: for fp32, |x| >= 2^-100; in exact arithmetic on the host, over 10^6 random and
+// boundary-adjacent operands per w in {3, 5, 6, 7, 9, 11, 13, 14}: no difference, the largest failing |x| for w = 3 is 9.4e-38.  On the
+// device np_selftest_division_small compares the fp32 form with the IEEE divide for EVERY float and the fp64 form on 2^30 doubles.
+// (A zero dividend gives a zero quotient whose SIGN follows the constants' signs, not the dividend's: see the self-test.)
+__device__ __forceinline__ float div_small_f32(float x, float ch, float cl) { return __builtin_fmaf(x, ch, x * cl); }
+__device__ __forceinline__ double div_small_f64(double x, double ch, double cl) { return __builtin_fma(x, ch, x * cl); }
+#define NP_ED_W3_CH 0x1.5555555555555p-2
+#define NP_ED_W3_CL 0x1.5555555555555p-56
+#define NP_ED_W3_CHF 0x1.555556p-2f
+#define NP_ED_W3_CLF (-0x1.555556p-27f)
+
+// tstat_from_sums for the fused walk (windows of 3 and 6 samples: `half` = 1.0 / 0.5 scales the constants of 1/3 exactly): the same arithmetic
+// with (1) the two wrappers above, (2) the divisions by the window length in their two-operation form -- the float dividends sum2, sumsq2 are
+// 0 or at least 2^-53 for every read the walk sees (ed_check_finish sends reads with a non-zero sample below 2^-30 to the serial path),
+// (3) the plain division of a variance clamped to FLT_MIN (a denormal quotient) taken only when SOME lane of the wave has such a sample
 // -- a wave-uniform branch instead of an IEEE division expanded next to every exact one.
 __device__ __forceinline__ float tstat_from_sums_fast(double sum1, double sumsq1, double sum2d, double sumsq2d, int i, int n, int w, float w_lengthf,
-                                                      double wd, double rwd, float rwf)
+                                                      const double half, const float halff)
 {
+    const double chd = NP_ED_W3_CH * half, cld = NP_ED_W3_CL * half;
+    const float chf = NP_ED_W3_CHF * halff, clf = NP_ED_W3_CLF * halff;
     const float sum2 = (float)sum2d, sumsq2 = (float)sumsq2d;
-    const float mean1 = (float)div_exact_f64(sum1, wd, rwd);
-    const float mean2 = np_div_exact(sum2, w_lengthf, rwf);
-    float combined_var = (float)(div_exact_f64(sumsq1, wd, rwd) - (double)(mean1 * mean1) + (double)np_div_exact(sumsq2, w_lengthf, rwf) -
+    const float mean1 = (float)div_small_f64(sum1, chd, cld);
+    const float mean2 = div_small_f32(sum2, chf, clf);
+    float combined_var = (float)(div_small_f64(sumsq1, chd, cld) - (double)(mean1 * mean1) + (double)div_small_f32(sumsq2, chf, clf) -
                                  (double)(mean2 * mean2));
     combined_var = fmaxf(combined_var, 1.17549435e-38f);                       // FLT_MIN
     const float delta_mean = mean2 - mean1;
-    float cvw = np_div_exact(combined_var, w_lengthf, rwf);
+    float cvw = div_small_f32(combined_var, chf, clf);
     if (__builtin_amdgcn_ballot_w64(combined_var < 1e-30f) != 0ull) cvw = combined_var < 1e-30f ? combined_var / w_lengthf : cvw;
     const float t = (float)div_f64_normal(fabs((double)delta_mean), sqrt_f64_normal((double)cvw));
     return (n < 2 * w || i < w || i > n - w) ? 0.0f : t;                        // quick return and fudged boundaries
@@ -566,8 +589,6 @@ __device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int 
     // reference's prefix-sum differences whatever the order.  Per sample ONE new S and one new Q (S(j+1) = S(j) - x[j] + x[j+3]) and four
     // additions, instead of eight window sums slid by two operations each.  S[k] / Q[k]: position 8 blk - 6 + k; ten entries are live.
     const int w1 = (int)p.window_length1, w2 = (int)p.window_length2;       // (3, 6) or (6, 3): which statistic feeds which detector
-    const double r3d = 1.0 / 3.0, r6d = 1.0 / 6.0;
-    const float r3f = (float)r3d, r6f = (float)r6d;                         // RN(1/w) in fp32: 1/w is not a rounding tie
     double S[18], Q[18];
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
@@ -597,9 +618,9 @@ __device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int 
                 const int o = 8 * h + q;
                 const int i = blk * 8 + q;
                 const bool in = lane_active && i >= begin && i < end;
-                const float ta = tstat_from_sums_fast(RS[(o + 3) & 15], RQ[(o + 3) & 15], RS[(o + 6) & 15], RQ[(o + 6) & 15], i, n, WA, 3.0f, 3.0, r3d, r3f);
+                const float ta = tstat_from_sums_fast(RS[(o + 3) & 15], RQ[(o + 3) & 15], RS[(o + 6) & 15], RQ[(o + 6) & 15], i, n, WA, 3.0f, 1.0, 1.0f);
                 const float tb = tstat_from_sums_fast(RS[o & 15] + RS[(o + 3) & 15], RQ[o & 15] + RQ[(o + 3) & 15], RS[(o + 6) & 15] + RS[(o + 9) & 15],
-                                                      RQ[(o + 6) & 15] + RQ[(o + 9) & 15], i, n, WB, 6.0f, 6.0, r6d, r6f);
+                                                      RQ[(o + 6) & 15] + RQ[(o + 9) & 15], i, n, WB, 6.0f, 0.5, 0.5f);
                 const float t1 = w1 < w2 ? ta : tb, t2 = w1 < w2 ? tb : ta;
                 int pos;
                 if (detector_step<0>(st.d0, st.d1, in ? i : -1, t1, p.peak_height, p.threshold1, w1, pos) && RECORD) {
@@ -628,8 +649,8 @@ __device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int 
         for (int q = 0; q < 8; ++q) {
             const int i = blk * 8 + q;
             const bool in = lane_active && i >= begin && i < end;
-            const float ta = tstat_from_sums_fast(S[q + 3], Q[q + 3], S[q + 6], Q[q + 6], i, n, WA, 3.0f, 3.0, r3d, r3f);
-            const float tb = tstat_from_sums_fast(S[q] + S[q + 3], Q[q] + Q[q + 3], S[q + 6] + S[q + 9], Q[q + 6] + Q[q + 9], i, n, WB, 6.0f, 6.0, r6d, r6f);
+            const float ta = tstat_from_sums_fast(S[q + 3], Q[q + 3], S[q + 6], Q[q + 6], i, n, WA, 3.0f, 1.0, 1.0f);
+            const float tb = tstat_from_sums_fast(S[q] + S[q + 3], Q[q] + Q[q + 3], S[q + 6] + S[q + 9], Q[q + 6] + Q[q + 9], i, n, WB, 6.0f, 0.5, 0.5f);
             const float t1 = w1 < w2 ? ta : tb, t2 = w1 < w2 ? tb : ta;
             int pos;
             if (detector_step<0>(st.d0, st.d1, in ? i : -1, t1, p.peak_height, p.threshold1, w1, pos) && RECORD) {
@@ -1135,5 +1156,48 @@ hipError_t np_launch_mom_fill(int n_reads, np_read_dev* reads, np_read_dev* read
     if (n_reads <= 0) return hipSuccess;
     hipLaunchKernelGGL(np_mom_fill_kernel, dim3((n_reads + NP_MOM_R * NP_MOM_W - 1) / (NP_MOM_R * NP_MOM_W)), dim3(64 * NP_MOM_W), 0, s, n_reads, reads, reads_b, event_mean, n_events, ranks,
                        model, n_states);
+    return hipGetLastError();
+}
+
+// ---- device self-test of the two-operation divisions by a window length (div_small_f32 / div_small_f64) ---------------------------------
+// fp32: EVERY float x with 2^-100 <= |x| < inf, and 0, against the IEEE divide; fp64: n_f64 doubles with random significands and exponents in
+// [2^-300, 2^300) (and what a window sum looks like: integers times a power of two).  w == 3 uses the walk's own constants (NP_ED_W3_*).
+static __global__ void __launch_bounds__(256) np_selftest_div_small_kernel(int w, double chd, double cld, float chf, float clf, uint64_t n_f64,
+                                                                            unsigned long long* out)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x, nth = (uint64_t)gridDim.x * 256;
+    const float wf = (float)w; const double wd = (double)w;
+    if (w == 3) { chd = NP_ED_W3_CH; cld = NP_ED_W3_CL; chf = NP_ED_W3_CHF; clf = NP_ED_W3_CLF; }
+    if (w == 6) { chd = NP_ED_W3_CH * 0.5; cld = NP_ED_W3_CL * 0.5; chf = NP_ED_W3_CHF * 0.5f; clf = NP_ED_W3_CLF * 0.5f; }
+    unsigned long long bad32 = 0, bad64 = 0, seen32 = 0;
+    for (uint64_t b = tid; b < (1ull << 32); b += nth) {
+        const uint32_t bits = (uint32_t)b, mag = bits & 0x7fffffffu;
+        if (mag >= 0x7f800000u || (mag != 0u && mag < 0x0d800000u)) continue;            // inf / nan; non-zero below 2^-100
+        const float x = __builtin_bit_cast(float, bits);
+        const float want = x / wf, got = div_small_f32(x, chf, clf);
+        // (x = -0: the quotient is -0 and this form returns the zero whose sign the products' signs make, +0 for the negative cl of 1/3 --
+        //  the one value whose bits may differ; the t-statistic squares a mean, takes |delta| and adds the quotients to other terms, and a
+        //  sum of fp32 squares is never -0: no zero's sign reaches it)
+        bad32 += __builtin_bit_cast(uint32_t, want) != __builtin_bit_cast(uint32_t, got) && !(want == 0.0f && got == 0.0f);
+        ++seen32;
+    }
+    uint64_t sd = 0x9E3779B97F4A7C15ull * (tid + 1) + (uint64_t)w;
+    for (uint64_t k = tid; k < n_f64; k += nth) {
+        sd += 0x9E3779B97F4A7C15ull;
+        uint64_t z = sd; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        uint64_t mant = z & 0xfffffffffffffull;
+        if ((z >> 60) < 4) mant &= ~((1ull << (z >> 54 & 31)) - 1ull);                       // a quarter: trailing zeros, like sums of a few floats
+        const uint64_t e = 1023 - 300 + ((z >> 52) & 0xff) * 600 / 256;
+        const double x = __builtin_bit_cast(double, ((z >> 63) << 63) | (e << 52) | mant);
+        const double want = x / wd, got = div_small_f64(x, chd, cld);
+        bad64 += __builtin_bit_cast(uint64_t, want) != __builtin_bit_cast(uint64_t, got);
+    }
+    if (bad32) atomicAdd(out + 0, bad32);
+    if (bad64) atomicAdd(out + 1, bad64);
+    atomicAdd(out + 2, seen32);
+}
+hipError_t np_launch_selftest_div_small(int w, double chd, double cld, float chf, float clf, uint64_t n_f64, unsigned long long* d_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(np_selftest_div_small_kernel, dim3(8192), dim3(256), 0, s, w, chd, cld, chf, clf, n_f64, d_out);
     return hipGetLastError();
 }

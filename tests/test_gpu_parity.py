@@ -289,6 +289,18 @@ def test_exact_fast_division_selftest(ctx):
     assert rc == 0 and bad.value == 0
 
 
+@pytest.mark.parametrize("w", [3, 6, 7, 14, 5, 12])
+def test_two_operation_division_by_a_window_length_selftest(ctx, w):
+    """div_small_f32 / div_small_f64 (the fused detector walk's divisions by the window length, event_detection.c:97-101,111) equal the IEEE
+    divide: fp32 on every float of magnitude 0 or >= 2^-100 -- 3.83 billion of them --, fp64 on 2^30 pseudo-random doubles; 3 and 6 with the walk's
+    own constants, the RNA windows 7 and 14 and two more with constants made on the host the same way."""
+    import ctypes as C
+    b32, b64, n32 = C.c_uint64(9), C.c_uint64(9), C.c_uint64(0)
+    rc = ctx.L.np_selftest_division_small(ctx.h, w, 1 << 30, C.byref(b32), C.byref(b64), C.byref(n32))
+    assert rc == 0 and b32.value == 0 and b64.value == 0
+    assert n32.value == 2 * (0x7f800000 - 0x0d800000) + 2
+
+
 def test_eventalign_segment_chain_matches_oracle(ctx, orc, models):
     """BASELINE config 3 shape: the eventalign segment chain (each segment starts where the previous one stopped
     emitting) driven by profile_hmm_align on the GPU vs on the oracle, forward and reverse-strand reads."""

@@ -176,4 +176,19 @@ for seed in 40 41 42 43 44 45; do ( timeout 900 python tests/gpu_soak.py --reads
 ( timeout 1200 python tests/gpu_soak_eventalign.py 1024 ) > $O/soak_ea.log 2>&1; tail -2 $O/soak_ea.log | cut -c1-300
 }
 
+# the detector's divisions by the window length in two operations (div_small_*): the exhaustive self-test, the detector's and the from-raw
+# chain's tests, then the from-raw step A/B against the previous build is the bench line itself (event_detect in kernel_ms_per_step)
+call_z() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r06z; mkdir -p $O
+( time timeout 1500 python -m pytest tests -m gpu -q ) > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+( timeout 900 python tests/gpu_soak.py --reads 1500 --seed 46 ) > $O/soak_46.log 2>&1; grep "^{" $O/soak_46.log | cut -c1-330
+( time timeout 900 python bench.py --steps 5 --warmup 2 --streamed 0 --ragged 0 ) > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err
+python - <<'PYEOF2'
+import json
+d = json.loads(open("gpurun_out/r06z/bench.json").read().strip().splitlines()[-1])
+print(d["value"], d["roofline"]["kernel_ms_per_step"]); fr = d["from_raw"]; print(fr["value"], fr["kernel_ms_per_step"], fr.get("check")); print(d["value_eventalign"], d["eventalign"].get("kernel_ms_per_step"))
+PYEOF2
+}
+
 "call_$1"
