@@ -489,6 +489,21 @@ int np_detect_events_checked_dev(np_ctx* ctx, void* stream, int n_reads, const f
                                  const np_detector_param* params, float* tstat, const int64_t* event_off, int64_t max_events,
                                  uint32_t* event_start, float* event_length, float* event_mean, float* event_stdv, int32_t* n_events,
                                  const int32_t* verdict);
+
+/* The two calls above as ONE, for a caller that keeps the counts: int16 ADC counts in, events out (the loaders' conversion,
+ * src/io/nanopolish_fast5_loader.cpp:96-103, and scrappie's detect_events, src/thirdparty/scrappie/event_detection.c:268-319, as
+ * SquiggleRead::load_from_raw chains them).  Events are bit-identical to np_adc_to_pa_checked_dev + np_detect_events_checked_dev on the same counts.
+ * With the DNA windows (3 and 6 samples) a read of 2 048 samples or more never exists as pA values: the conversion's pass only takes the
+ * exactness verdict, the peak walk and the event sums convert the counts they load -- 2 bytes per sample read where the two calls write 4 and
+ * read them back twice.
+ *   adc      : 4-byte aligned; raw_off / max_samples / offset / raw_unit as np_adc_to_pa_dev
+ *   raw_pa   : float scratch with the counts' layout (raw_off): written for reads shorter than 2 048 samples and for reads whose prefix sums are
+ *              not provably exact (the serial path), unspecified elsewhere; every read's with other window lengths (RNA: the two-call form inside)
+ *   the rest as np_detect_events_dev. */
+int np_detect_events_adc_dev(np_ctx* ctx, void* stream, int n_reads, const int16_t* adc, const int64_t* raw_off, int64_t max_samples,
+                             const float* offset, const float* raw_unit, float* raw_pa, const np_detector_param* params, float* tstat,
+                             const int64_t* event_off, int64_t max_events, uint32_t* event_start, float* event_length, float* event_mean,
+                             float* event_stdv, int32_t* n_events);
 /* Host-pointer convenience form for one batch of reads (copies in and out). out_* are concatenated, out_off[n_reads+1]. */
 int np_detect_events_host(np_ctx* ctx, int n_reads, const float* const* raw, const uint32_t* n_samples,
                           const np_detector_param* params, uint32_t* out_start, float* out_length, float* out_mean,

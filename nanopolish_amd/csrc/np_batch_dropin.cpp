@@ -615,7 +615,7 @@ void NpBatchPipeline::Impl::pack(const std::vector<Slot*>& group, int dev)
     const size_t s_pair_begin = ls.add((size_t)n * 4), s_deg = ls.add((size_t)n * 8), s_kpos = ls.add((size_t)n_jobs * 8),
                  s_epb = ls.add((size_t)n * 8), s_jobs = ls.add((size_t)n_jobs * sizeof(np_hmm_job_dev));
     const size_t zero_bytes = ls.size;
-    const size_t s_raw_pa = ls.add(all_adc ? (size_t)raw_off[n] * sizeof(float) : 0), s_verdict = ls.add(all_adc ? (size_t)n * 4 : 0);
+    const size_t s_raw_pa = ls.add(all_adc ? (size_t)raw_off[n] * sizeof(float) : 0);
     const size_t s_tstat = ls.add((size_t)(2 * raw_off[n] + 16) * sizeof(float)), s_ev_len = ls.add((size_t)n_ev * 4), s_ev_mean = ls.add((size_t)n_ev * 4),
                  s_ev_stdv = ls.add((size_t)n_ev * 4), s_ev_start = ls.add((size_t)n_ev * 4), s_map_start = ls.add((size_t)n_rk * 4),
                  s_pairs = ls.add((size_t)pair_off[n] * sizeof(np_pair)),
@@ -713,14 +713,15 @@ void NpBatchPipeline::Impl::pack(const std::vector<Slot*>& group, int dev)
         check(np_cm_build_jobs_cigar_dev(c, NULL, n, genome, ref_begin, ref_len, cigar, d_cigar_off, cigar_off[n], read_len, rc, alphabet, k, MINSEP,
                                          FLANK, d_group_off, n_slots, d_jr_off, jobs, kpos, job_ranks, first, last, n_motif, n_groups, deg),
               "np_cm_build_jobs_cigar_dev");
-        // this pass owns the conversion AND the detection of these samples, nothing edits them in between: the conversion's exactness verdicts
-        // go to the detector explicitly (one pass over the samples instead of two)
-        int32_t* verdict = all_adc ? (int32_t*)(X + s_verdict) : NULL;
+        // counts in, events out: with the DNA windows the long reads never exist as pA values (np_detect_events_adc_dev; `raw` is its scratch for
+        // the short and the serial-path reads)
         if (all_adc)
-            check(np_adc_to_pa_checked_dev(c, NULL, n, (const int16_t*)(Dv + i_raw), d_raw_off, max_samples, (const float*)(Dv + i_adc_offset),
-                                           (const float*)(Dv + i_adc_unit), raw, verdict), "np_adc_to_pa_checked_dev");
-        check(np_detect_events_checked_dev(c, NULL, n, raw, d_raw_off, max_samples, &prm, tstat, d_event_off, max_events, ev_start, ev_len, ev_mean,
-                                           ev_stdv, n_events, verdict), "np_detect_events_checked_dev");
+            check(np_detect_events_adc_dev(c, NULL, n, (const int16_t*)(Dv + i_raw), d_raw_off, max_samples, (const float*)(Dv + i_adc_offset),
+                                           (const float*)(Dv + i_adc_unit), raw, &prm, tstat, d_event_off, max_events, ev_start, ev_len, ev_mean,
+                                           ev_stdv, n_events), "np_detect_events_adc_dev");
+        else
+            check(np_detect_events_dev(c, NULL, n, raw, d_raw_off, max_samples, &prm, tstat, d_event_off, max_events, ev_start, ev_len, ev_mean,
+                                       ev_stdv, n_events), "np_detect_events_dev");
         check(np_mom_fill_dev(c, NULL, n, reads_a, reads_b, ev_mean, n_events, ranks, m_nuc), "np_mom_fill_dev");
         check(np_event_align_dev(c, NULL, n, reads_a, ev_mean, ranks, m_nuc, max_bands, d_pair_off, pairs, pair_begin, n_pairs), "np_event_align_dev");
         check(np_calibrate_resolve_dev(c, NULL, n, reads_b, ev_mean, ranks, m_nuc, d_pair_off, pairs, pair_begin, n_pairs, map_start, NULL /* .stop: not read on this path */, epb,

@@ -1493,6 +1493,29 @@ int np_detect_events_checked_dev(np_ctx* c, void* stream, int n_reads, const flo
                                 event_start, event_length, event_mean, event_stdv, n_events, verdict);
 }
 
+int np_detect_events_adc_dev(np_ctx* c, void* stream, int n_reads, const int16_t* adc, const int64_t* raw_off, int64_t max_samples,
+                             const float* offset, const float* raw_unit, float* raw_pa, const np_detector_param* params, float* tstat,
+                             const int64_t* event_off, int64_t max_events, uint32_t* event_start, float* event_length, float* event_mean,
+                             float* event_stdv, int32_t* n_events)
+{
+    if (!c || n_reads < 0 || (n_reads > 0 && (!adc || !raw_off || !offset || !raw_unit || !raw_pa || !tstat || !event_off || !event_start || !event_length ||
+                                             !event_mean || !event_stdv || !n_events))) return NP_ERR_INVALID;
+    if (n_reads == 0) return NP_OK;
+    std::lock_guard<std::mutex> g(c->lock);
+    if (((uintptr_t)adc & 3u) || ((uintptr_t)tstat & 63u)) { c->err = "np_detect_events_adc_dev: adc must be 4-byte aligned, tstat 64-byte aligned"; return NP_ERR_INVALID; }
+    NP_HIP(c, hipSetDevice(c->device));
+    np_detector_param p;
+    if (params) p = *params; else np_event_detection_params(&p, 0);
+    if (p.window_length1 > 16 || p.window_length2 > 16) { c->err = "np_detect_events: window length > 16"; return NP_ERR_UNSUPPORTED; }
+    stream_scope scope = use_stream(c, stream); hipStream_t s = scope.s;
+    NP_HIP(c, c->ed_status.reserve((size_t)n_reads * sizeof(int32_t)));
+    c->ed_last_reads = n_reads;
+    family_timer tm(c, 4, s);
+    NP_HIP(c, np_launch_detect_events_adc(n_reads, adc, raw_off, max_samples, offset, raw_unit, raw_pa, p, (float2*)tstat, c->ed_status.as<int32_t>(),
+                                          event_off, max_events, event_start, event_length, event_mean, event_stdv, n_events, c->ed_warmup, s));
+    return NP_OK;
+}
+
 int np_detect_events_host(np_ctx* c, int n_reads, const float* const* raw, const uint32_t* n_samples, const np_detector_param* params,
                           uint32_t* out_start, float* out_length, float* out_mean, float* out_stdv, int64_t cap, int64_t* out_off)
 {

@@ -159,13 +159,16 @@ __global__ void __launch_bounds__(256) np_ed_check_kernel(int n_reads, const flo
 // ADC counts -> pA AND the exactness bound of the samples written, one block per read (round 5): np_adc_to_pa_kernel followed by
 // np_ed_check_kernel moved 6 + 4 bytes per sample, this one moves 6 -- the check looks at the values on their way out.  Groups of four
 // samples from the first position of the read that is a multiple of four in the batch arrays (8-byte loads, 16-byte stores, aligned).
+// write_below (round 6, np_detect_events_adc_dev): the pA values are stored only for reads SHORTER than this many samples -- the longer ones are
+// walked and summed straight from the counts (np_ed_peaks_par_kernel<true, true>, np_ed_events_kernel<true>), and their verdict needs no store.
 __global__ void __launch_bounds__(256) np_adc_to_pa_check_kernel(int n_reads, const int16_t* __restrict__ adc, const int64_t* __restrict__ raw_off,
                                                                   const float* __restrict__ offset, const float* __restrict__ raw_unit,
-                                                                  float* __restrict__ raw_pa, int32_t* __restrict__ status)
+                                                                  float* __restrict__ raw_pa, int32_t* __restrict__ status, int64_t write_below)
 {
     const int r = blockIdx.x;
     if (r >= n_reads) return;
     const int64_t n = raw_off[r + 1] - raw_off[r];
+    const bool wr = n < write_below;
     const float off = offset[r], unit = raw_unit[r];
     const int16_t* in = adc + raw_off[r];
     float* out = raw_pa + raw_off[r];
@@ -177,13 +180,27 @@ __global__ void __launch_bounds__(256) np_adc_to_pa_check_kernel(int n_reads, co
         const short4 v = *reinterpret_cast<const short4*>(in + i);
         float4 o;
         o.x = ((float)v.x + off) * unit; o.y = ((float)v.y + off) * unit; o.z = ((float)v.z + off) * unit; o.w = ((float)v.w + off) * unit;
-        *reinterpret_cast<float4*>(out + i) = o;
+        if (wr) *reinterpret_cast<float4*>(out + i) = o;
         R.take(o.x); R.take(o.y); R.take(o.z); R.take(o.w);
     }
     // what the groups do not cover: up to three samples before the first and after the last
-    for (int64_t i = threadIdx.x; i < head; i += 256) { const float o = ((float)in[i] + off) * unit; out[i] = o; R.take(o); }
-    for (int64_t i = head + 4 * groups + threadIdx.x; i < n; i += 256) { const float o = ((float)in[i] + off) * unit; out[i] = o; R.take(o); }
+    for (int64_t i = threadIdx.x; i < head; i += 256) { const float o = ((float)in[i] + off) * unit; if (wr) out[i] = o; R.take(o); }
+    for (int64_t i = head + 4 * groups + threadIdx.x; i < n; i += 256) { const float o = ((float)in[i] + off) * unit; if (wr) out[i] = o; R.take(o); }
     ed_check_finish(R, n, r, status);
+}
+// ... and the reads of at least `from` samples that the verdict sends to the SERIAL path get their pA values after all (the serial kernels read them)
+__global__ void __launch_bounds__(256) np_adc_to_pa_serial_kernel(int n_reads, const int16_t* __restrict__ adc, const int64_t* __restrict__ raw_off,
+                                                                   const float* __restrict__ offset, const float* __restrict__ raw_unit,
+                                                                   float* __restrict__ raw_pa, const int32_t* __restrict__ status, int64_t from)
+{
+    const int r = blockIdx.x;
+    if (r >= n_reads || status[r] != NP_ED_SERIAL) return;
+    const int64_t n = raw_off[r + 1] - raw_off[r];
+    if (n < from) return;
+    const float off = offset[r], unit = raw_unit[r];
+    const int16_t* in = adc + raw_off[r];
+    float* out = raw_pa + raw_off[r];
+    for (int64_t i = threadIdx.x; i < n; i += 256) out[i] = ((float)in[i] + off) * unit;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -562,9 +579,14 @@ __device__ __forceinline__ void walk_segment(const float2* __restrict__ ts_all, 
 #ifndef NP_ED_UNROLL2
 #define NP_ED_UNROLL2 0     // 1: two blocks per iteration, ring-indexed sums (round 6 experiment)
 #endif
-template <bool RECORD>
+// ADC (round 6): xr describes the read's int16 COUNTS from the 4-byte boundary at or below its first sample (`lead` = 1 when the first sample is the
+// upper half of that word); a block of eight samples is four words (five when lead), converted as the signal loaders do: (count + off) * unit.
+// Words past the read come back 0 and convert to off * unit where the float form reads 0.0f: both only ever feed t-statistics of positions
+// within a window of the read's ends, which compute_tstat fudges to 0.
+template <bool RECORD, bool ADC = false>
 __device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int n, int begin, int end, int trip, bool lane_active,
-                                                 walk_state& st, const np_detector_param& p, uint32_t* tmp, int tmp_cap, int& cnt)
+                                                 walk_state& st, const np_detector_param& p, uint32_t* tmp, int tmp_cap, int& cnt,
+                                                 const int lead = 0, const float adc_off = 0.0f, const float adc_unit = 1.0f)
 {
     constexpr int WA = 3, WB = 6;
     int blk = begin >> 3;                                     // this lane's first block of 8 samples (read-relative)
@@ -577,6 +599,27 @@ __device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int 
 #else
         const bool need = lane_active && b >= 0 && b * 8 < n;
 #endif
+        if (ADC) {
+            // samples [8 b, 8 b + 8) = bytes [16 b + 2 lead, + 16) of the word-aligned stream
+            uint32_t d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u, d4 = 0u;
+            if (need) {
+                const float4 w = buf_f32x4(xr, 16 * b);
+                d0 = __builtin_bit_cast(uint32_t, w.x); d1 = __builtin_bit_cast(uint32_t, w.y); d2 = __builtin_bit_cast(uint32_t, w.z); d3 = __builtin_bit_cast(uint32_t, w.w);
+                if (lead) d4 = __builtin_bit_cast(uint32_t, buf_f32(xr, 16 * b + 16));        // (wave-uniform: one read per wave)
+            }
+            if (lead) {
+                d0 = __builtin_amdgcn_alignbit(d1, d0, 16); d1 = __builtin_amdgcn_alignbit(d2, d1, 16);
+                d2 = __builtin_amdgcn_alignbit(d3, d2, 16); d3 = __builtin_amdgcn_alignbit(d4, d3, 16);
+            }
+            const uint32_t d[4] = {d0, d1, d2, d3};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a = (float)(int16_t)(d[k] & 0xffffu), c = (float)((int32_t)d[k] >> 16);
+                dst[2 * k] = need ? (a + adc_off) * adc_unit : 0.0f;
+                dst[2 * k + 1] = need ? (c + adc_off) * adc_unit : 0.0f;
+            }
+            return;
+        }
         const float4 lo = need ? buf_f32x4(xr, 32 * b) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 hi = need ? buf_f32x4(xr, 32 * b + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
         dst[0] = lo.x; dst[1] = lo.y; dst[2] = lo.z; dst[3] = lo.w; dst[4] = hi.x; dst[5] = hi.y; dst[6] = hi.z; dst[7] = hi.w;
@@ -677,9 +720,10 @@ __device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int 
 #endif
 }
 
-template <bool FUSED>
+template <bool FUSED, bool ADC = false>
 __global__ void __launch_bounds__(64, 3) np_ed_peaks_par_kernel(int n_reads, const int64_t* __restrict__ raw_off, const float2* __restrict__ tstat,
-                                                              const float* __restrict__ raw,
+                                                              const float* __restrict__ raw, const int16_t* __restrict__ adc,
+                                                              const float* __restrict__ adc_offset, const float* __restrict__ adc_unit,
                                                               const int32_t* __restrict__ status, np_detector_param p,
                                                               const int64_t* __restrict__ event_off, uint32_t* __restrict__ event_start,
                                                               uint32_t* __restrict__ scratch_a, uint32_t* __restrict__ scratch_b,
@@ -707,11 +751,18 @@ __global__ void __launch_bounds__(64, 3) np_ed_peaks_par_kernel(int n_reads, con
     const detector fresh = {0, -1, 3.40282347e+38f, 0};            // DEF_PEAK_POS, DEF_PEAK_VAL = FLT_MAX
     walk_state st = {fresh, fresh};
     int cnt = 0;
-    const __amdgpu_buffer_rsrc_t xr = make_rsrc(raw + base, (uint32_t)n * 4u);
-    if (FUSED) walk_segment_raw<false>(xr, n, begin, start, warmup, start < end, st, p, tmp, tmp_cap, cnt);
+    static_assert(!ADC || FUSED, "the walk reads counts only in its fused form");
+    // ADC: the descriptor starts at the 4-byte boundary at or below the read's first count (the batch's count array is 4-byte aligned) and ends
+    // at the one at or above its last: every load is word-aligned and none leaves the word that holds the read's last count
+    const uintptr_t a0 = ADC ? (uintptr_t)(adc + base) : 0;
+    const int lead = ADC ? (int)((a0 >> 1) & 1) : 0;
+    const float a_off = ADC ? adc_offset[r] : 0.0f, a_unit = ADC ? adc_unit[r] : 1.0f;
+    const __amdgpu_buffer_rsrc_t xr = ADC ? make_rsrc((const void*)(a0 & ~(uintptr_t)3), (uint32_t)((2 * (n + lead) + 3) & ~3))
+                                          : make_rsrc(raw + base, (uint32_t)n * 4u);
+    if (FUSED) walk_segment_raw<false, ADC>(xr, n, begin, start, warmup, start < end, st, p, tmp, tmp_cap, cnt, lead, a_off, a_unit);
     else walk_segment<false>(tstat, base, begin, start, warmup, start < end, st, p, tmp, tmp_cap, cnt);   // warm-up, nothing recorded
     walk_state entry = st;                                                                           // state at the segment's first sample
-    if (FUSED) walk_segment_raw<true>(xr, n, start, end, S, start < end, st, p, tmp, tmp_cap, cnt);
+    if (FUSED) walk_segment_raw<true, ADC>(xr, n, start, end, S, start < end, st, p, tmp, tmp_cap, cnt, lead, a_off, a_unit);
     else walk_segment<true>(tstat, base, start, end, S, start < end, st, p, tmp, tmp_cap, cnt);
 
     // verification / repair rounds
@@ -724,7 +775,7 @@ __global__ void __launch_bounds__(64, 3) np_ed_peaks_par_kernel(int n_reads, con
         if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;
         walk_state redo = left;
         int c2 = 0;
-        if (FUSED) walk_segment_raw<true>(xr, n, start, end, S, bad, redo, p, tmp, tmp_cap, c2);
+        if (FUSED) walk_segment_raw<true, ADC>(xr, n, start, end, S, bad, redo, p, tmp, tmp_cap, c2, lead, a_off, a_unit);
         else walk_segment<true>(tstat, base, start, end, S, bad, redo, p, tmp, tmp_cap, c2);
         if (bad) { st = redo; entry = left; cnt = c2; }
     }
@@ -766,7 +817,11 @@ __device__ __forceinline__ void ed_event_finish(double s, double q, int64_t star
     event_mean[slot] = mean;
     event_stdv[slot] = sqrtf(fmaxf(var, 0.0f));
 }
-__global__ void __launch_bounds__(256) np_ed_events_kernel(int n_reads, const float* __restrict__ raw, const int64_t* __restrict__ raw_off,
+// ADC (round 6): the window is staged from the int16 counts, four per 8-byte load, converted on the way into LDS as the signal loaders do.
+template <bool ADC>
+__global__ void __launch_bounds__(256) np_ed_events_kernel(int n_reads, const float* __restrict__ raw, const int16_t* __restrict__ adc,
+                                                            const float* __restrict__ adc_offset, const float* __restrict__ adc_unit,
+                                                            const int64_t* __restrict__ raw_off,
                                                             const int64_t* __restrict__ event_off, const uint32_t* __restrict__ event_start,
                                                             const int32_t* __restrict__ n_events, const int32_t* __restrict__ status,
                                                             float* __restrict__ event_length, float* __restrict__ event_mean, float* __restrict__ event_stdv)
@@ -774,7 +829,10 @@ __global__ void __launch_bounds__(256) np_ed_events_kernel(int n_reads, const fl
     const int r = blockIdx.x;
     if (r >= n_reads || status[r] != 0) return;              // (serial reads: np_ed_serial_events_kernel)
     const int n_ev = n_events[r];
-    const float* x = raw + raw_off[r];
+    const float* x = ADC ? nullptr : raw + raw_off[r];
+    const int16_t* ax = ADC ? adc + raw_off[r] : nullptr;
+    const float a_off = ADC ? adc_offset[r] : 0.0f, a_unit = ADC ? adc_unit[r] : 1.0f;
+    auto sample = [&](int64_t i) -> float { return ADC ? ((float)ax[i] + a_off) * a_unit : x[i]; };
     const int64_t n = raw_off[r + 1] - raw_off[r];
     const int64_t eo = event_off[r];
     const uint32_t* es = event_start + eo;
@@ -802,18 +860,23 @@ __global__ void __launch_bounds__(256) np_ed_events_kernel(int n_reads, const fl
             b_en[k] = e + 1 < n_ev ? es[e + 1] : (uint32_t)n;
         }
         const int64_t w0 = st0 < en0 ? st0 : en0;                       // the window starts at the first unprocessed event ...
-        const int mis = (int)((((uintptr_t)(x + w0)) & 15u) >> 2);      // ... moved down to a 16-byte boundary of the batch's sample array
+        const int mis = ADC ? (int)((((uintptr_t)(ax + w0)) & 7u) >> 1)  // ... moved down to an 8-byte boundary of the batch's count array
+                            : (int)((((uintptr_t)(x + w0)) & 15u) >> 2);    // ... resp. to a 16-byte boundary of its sample array
         const int64_t wa = w0 - mis, wend = wa + NP_EV_WIN;             // window = samples [wa, wend) of the read (wa may be -1 .. -3 for its first event)
         if (threadIdx.x == 0) s_bound = n_ev < e0 + 256 * NP_EV_PER ? n_ev : e0 + 256 * NP_EV_PER;
         for (int i4 = threadIdx.x; i4 < NP_EV_WIN / 4; i4 += 256) {
             const int64_t g = wa + 4 * (int64_t)i4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g >= 0 && g + 4 <= n) v = *reinterpret_cast<const float4*>(x + g);
-            else {
-                if (g >= 0 && g < n) v.x = x[g];
-                if (g + 1 >= 0 && g + 1 < n) v.y = x[g + 1];
-                if (g + 2 >= 0 && g + 2 < n) v.z = x[g + 2];
-                if (g + 3 >= 0 && g + 3 < n) v.w = x[g + 3];
+            if (g >= 0 && g + 4 <= n) {
+                if (ADC) {
+                    const short4 c = *reinterpret_cast<const short4*>(ax + g);
+                    v = make_float4(((float)c.x + a_off) * a_unit, ((float)c.y + a_off) * a_unit, ((float)c.z + a_off) * a_unit, ((float)c.w + a_off) * a_unit);
+                } else v = *reinterpret_cast<const float4*>(x + g);
+            } else {
+                if (g >= 0 && g < n) v.x = sample(g);
+                if (g + 1 >= 0 && g + 1 < n) v.y = sample(g + 1);
+                if (g + 2 >= 0 && g + 2 < n) v.z = sample(g + 2);
+                if (g + 3 >= 0 && g + 3 < n) v.w = sample(g + 3);
             }
             *reinterpret_cast<float4*>(&win[4 * i4]) = v;
         }
@@ -844,7 +907,7 @@ __global__ void __launch_bounds__(256) np_ed_events_kernel(int n_reads, const fl
             if (threadIdx.x == 0) {
                 const int64_t lo = st0 < en0 ? st0 : en0, hi = st0 < en0 ? en0 : st0;
                 double s = 0.0, q = 0.0;
-                for (int64_t i = lo; i < hi; ++i) { const float v = x[i]; s += (double)v; q += (double)(v * v); }
+                for (int64_t i = lo; i < hi; ++i) { const float v = sample(i); s += (double)v; q += (double)(v * v); }
                 ed_event_finish(s, q, st0, en0, event_length, event_mean, event_stdv, eo + e0);
             }
             e0 += 1;
@@ -1079,7 +1142,7 @@ hipError_t np_launch_adc_to_pa(int n_reads, const int16_t* adc, const int64_t* r
 {
     if (n_reads <= 0 || max_samples <= 0) return hipSuccess;
     if (status) {
-        hipLaunchKernelGGL(np_adc_to_pa_check_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, adc, raw_off, offset, raw_unit, raw_pa, status);
+        hipLaunchKernelGGL(np_adc_to_pa_check_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, adc, raw_off, offset, raw_unit, raw_pa, status, INT64_MAX);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(np_adc_to_pa_kernel, dim3(n_reads, (unsigned)((max_samples + 1023) / 1024)), dim3(256), 0, s, n_reads, adc, raw_off,
@@ -1110,16 +1173,54 @@ hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t*
                        event_start, n_events);
     if (max_samples >= NP_ED_PAR_MIN) {
         if (fused)
-            hipLaunchKernelGGL(np_ed_peaks_par_kernel<true>, dim3(n_reads), dim3(64), 0, s, n_reads, raw_off, tstat, raw, status, p, event_off, event_start,
+            hipLaunchKernelGGL((np_ed_peaks_par_kernel<true, false>), dim3(n_reads), dim3(64), 0, s, n_reads, raw_off, tstat, raw, (const int16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, status, p, event_off, event_start,
                                (uint32_t*)event_length, (uint32_t*)event_mean, (uint32_t*)event_stdv, n_events, warmup < 0 ? NP_ED_WARMUP : warmup);
         else
-            hipLaunchKernelGGL(np_ed_peaks_par_kernel<false>, dim3(n_reads), dim3(64), 0, s, n_reads, raw_off, tstat, raw, status, p, event_off, event_start,
+            hipLaunchKernelGGL((np_ed_peaks_par_kernel<false, false>), dim3(n_reads), dim3(64), 0, s, n_reads, raw_off, tstat, raw, (const int16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, status, p, event_off, event_start,
                                (uint32_t*)event_length, (uint32_t*)event_mean, (uint32_t*)event_stdv, n_events, warmup < 0 ? NP_ED_WARMUP : warmup);
     }
     (void)max_events;
-    hipLaunchKernelGGL(np_ed_events_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, raw, raw_off, event_off, event_start,
-                       n_events, status, event_length, event_mean, event_stdv);
+    hipLaunchKernelGGL(np_ed_events_kernel<false>, dim3(n_reads), dim3(256), 0, s, n_reads, raw, (const int16_t*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, raw_off, event_off, event_start, n_events, status, event_length, event_mean, event_stdv);
     hipLaunchKernelGGL(np_ed_serial_events_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, raw, raw_off, event_off, event_start,
+                       n_events, status, event_length, event_mean, event_stdv);
+    return hipGetLastError();
+}
+
+// np_detect_events_adc_dev: int16 counts in, events out.  With the DNA windows the long reads never exist as pA values: the conversion's pass only
+// takes the exactness verdict (2 bytes per sample read, nothing written), the walk and the event sums convert the counts they load.  raw_pa is
+// written for what still goes through the un-fused kernels: reads shorter than NP_ED_PAR_MIN samples and reads on the serial path.  Other window
+// lengths (RNA): the two-call form.
+hipError_t np_launch_detect_events_adc(int n_reads, const int16_t* adc, const int64_t* raw_off, int64_t max_samples, const float* offset, const float* raw_unit,
+                                       float* raw_pa, const np_detector_param& p, float2* tstat, int32_t* status, const int64_t* event_off, int64_t max_events,
+                                       uint32_t* event_start, float* event_length, float* event_mean, float* event_stdv, int32_t* n_events, int warmup, hipStream_t s)
+{
+    if (n_reads <= 0) return hipSuccess;
+    const bool fused = NP_ED_FUSED && ((p.window_length1 == 3 && p.window_length2 == 6) || (p.window_length1 == 6 && p.window_length2 == 3));
+    if (!fused || max_samples <= 0) {
+        const hipError_t e = np_launch_adc_to_pa(n_reads, adc, raw_off, max_samples, offset, raw_unit, raw_pa, status, s);
+        if (e != hipSuccess) return e;
+        return np_launch_detect_events(n_reads, raw_pa, raw_off, max_samples, p, tstat, status, event_off, max_events, event_start, event_length, event_mean,
+                                       event_stdv, n_events, warmup, max_samples > 0, s);
+    }
+    hipLaunchKernelGGL(np_adc_to_pa_check_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, adc, raw_off, offset, raw_unit, raw_pa, status, (int64_t)NP_ED_PAR_MIN);
+    hipLaunchKernelGGL(np_adc_to_pa_serial_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, adc, raw_off, offset, raw_unit, raw_pa, status, (int64_t)NP_ED_PAR_MIN);
+    const unsigned tiles = (unsigned)((max_samples + NP_ED_TILE - 1) / NP_ED_TILE);
+    const unsigned t_tiles = std::min<unsigned>(tiles, (NP_ED_PAR_MIN + NP_ED_TILE - 1) / NP_ED_TILE);
+    if (t_tiles > 0)
+        hipLaunchKernelGGL(np_ed_tstat_kernel, dim3(n_reads, t_tiles), dim3(NP_ED_TILE), 0, s, n_reads, raw_pa, raw_off, status,
+                           (int)p.window_length1, (int)p.window_length2, tstat, (int64_t)NP_ED_PAR_MIN);
+    hipLaunchKernelGGL(np_ed_serial_tstat_kernel, dim3(n_reads), dim3(64), 0, s, n_reads, raw_pa, raw_off, status, (int)p.window_length1,
+                       (int)p.window_length2, tstat);
+    hipLaunchKernelGGL(np_ed_peaks_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, raw_off, tstat, status, p, event_off, event_start, n_events);
+    if (max_samples >= NP_ED_PAR_MIN)
+        hipLaunchKernelGGL((np_ed_peaks_par_kernel<true, true>), dim3(n_reads), dim3(64), 0, s, n_reads, raw_off, tstat, (const float*)nullptr, adc, offset, raw_unit,
+                           status, p, event_off, event_start, (uint32_t*)event_length, (uint32_t*)event_mean, (uint32_t*)event_stdv, n_events,
+                           warmup < 0 ? NP_ED_WARMUP : warmup);
+    (void)max_events;
+    hipLaunchKernelGGL(np_ed_events_kernel<true>, dim3(n_reads), dim3(256), 0, s, n_reads, (const float*)nullptr, adc, offset, raw_unit, raw_off, event_off,
+                       event_start, n_events, status, event_length, event_mean, event_stdv);
+    hipLaunchKernelGGL(np_ed_serial_events_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, raw_pa, raw_off, event_off, event_start,
                        n_events, status, event_length, event_mean, event_stdv);
     return hipGetLastError();
 }

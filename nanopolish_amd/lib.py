@@ -20,7 +20,7 @@ SYMBOLS = [
     "np_alphabet_id", "np_alphabet_size", "np_kmer_rank", "np_reverse_complement", "np_methylate", "np_unmethylate",
     "np_is_motif_match", "np_sequence_kmer_ranks", "np_calculate_transitions", "np_estimate_scalings_mom",
     "np_scan_motif_groups", "np_cm_build_jobs_identity", "np_fill_read_host", "np_hmm_score_host", "np_hmm_score_set_host", "np_hmm_align_host", "np_event_align_host",
-    "np_event_align_dev", "np_hmm_score_dev", "np_resolve_jobs_dev", "np_calibrate_resolve_dev", "np_event_detection_params", "np_detect_events_dev", "np_detect_events_host", "np_mom_fill_dev", "np_cm_build_jobs_identity_dev", "np_cm_build_jobs_cigar_dev", "np_cm_discard_degenerate_dev", "np_set_job_layout", "np_cigar_aligned_bases", "np_cm_build_jobs_cigar", "np_eventalign_dev", "np_aligner_constants", "np_restated_log_exp", "np_selftest_libm", "np_site_table_genome_dev", "np_site_table_genome_indexed_dev", "np_genome_site_index_dev", "np_adc_to_pa_dev", "np_adc_to_pa_checked_dev", "np_detect_events_checked_dev", "np_sync", "np_last_kernel_ms", "np_kernel_time", "np_selftest_division", "np_selftest_division_small",
+    "np_event_align_dev", "np_hmm_score_dev", "np_resolve_jobs_dev", "np_calibrate_resolve_dev", "np_event_detection_params", "np_detect_events_dev", "np_detect_events_host", "np_mom_fill_dev", "np_cm_build_jobs_identity_dev", "np_cm_build_jobs_cigar_dev", "np_cm_discard_degenerate_dev", "np_set_job_layout", "np_cigar_aligned_bases", "np_cm_build_jobs_cigar", "np_eventalign_dev", "np_aligner_constants", "np_restated_log_exp", "np_selftest_libm", "np_site_table_genome_dev", "np_site_table_genome_indexed_dev", "np_genome_site_index_dev", "np_adc_to_pa_dev", "np_adc_to_pa_checked_dev", "np_detect_events_checked_dev", "np_detect_events_adc_dev", "np_sync", "np_last_kernel_ms", "np_kernel_time", "np_selftest_division", "np_selftest_division_small",
 ]
 
 
@@ -141,6 +141,7 @@ def load_library():
     L.np_event_detection_params.restype = None
     L.np_detect_events_dev.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int64, C.POINTER(DetectorParam), vp, vp, C.c_int64, vp, vp, vp, vp, vp]
     L.np_detect_events_checked_dev.argtypes = L.np_detect_events_dev.argtypes + [vp]
+    L.np_detect_events_adc_dev.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int64, vp, vp, vp, C.POINTER(DetectorParam), vp, vp, C.c_int64, vp, vp, vp, vp, vp]
     L.np_detect_events_host.argtypes = [vp, C.c_int, C.POINTER(c_f32p), C.POINTER(C.c_uint32), C.POINTER(DetectorParam),
                                         C.POINTER(C.c_uint32), c_f32p, c_f32p, c_f32p, C.c_int64, c_i64p]
     L.np_mom_fill_dev.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int]

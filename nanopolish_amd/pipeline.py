@@ -280,7 +280,7 @@ def tile_host_batch(hb, tile):
 
 class CallMethylationBatch:
     def __init__(self, ctx, hb, device="cuda:0", calibrate=False, from_raw=False, jobs_on_device=False, workload="call-methylation", rna=False,
-                 base_model="nucleotide", map_stop=True):
+                 base_model="nucleotide", map_stop=True, adc_one_call=True):
         """calibrate=False: kernel B scores with the scalings the caller put in hb["reads_b"] (a read whose
         calibration was done elsewhere).  calibrate=True: the pass recalibrates every read on the device from its
         own event alignment, as load_from_raw does (squiggle_read.cpp:304-323), and reads_b is overwritten.
@@ -288,7 +288,8 @@ class CallMethylationBatch:
         the RNA detector parameters, the events reversed after the MoM scalings, the base model registered as `base_model`
         (r9.4_70bps / u_to_t_rna / 5-mers; hb built with k = 5).
         map_stop=False (calibrate=True): base_to_event_map[].stop is not built -- recalibration and the window bounds read .start only
-        (squiggle_read.cpp:161-186,339-389); the eventalign workload, which hands the map back to the reference, always builds it."""
+        (squiggle_read.cpp:161-186,339-389); the eventalign workload, which hands the map back to the reference, always builds it.
+        adc_one_call (a batch of ADC counts): np_detect_events_adc_dev; False: np_adc_to_pa_checked_dev + np_detect_events_checked_dev (same events)."""
         import torch
         self.torch = torch
         self.calibrate = bool(calibrate)
@@ -296,6 +297,7 @@ class CallMethylationBatch:
         self.rna = bool(rna)
         assert not self.rna or (self.from_raw and workload == "eventalign"), "rna=True: from raw signal, eventalign workload"
         self.from_adc = False
+        self.adc_one_call = bool(adc_one_call)
         self.jobs_on_device = bool(jobs_on_device)
         self.workload = workload       # "eventalign": a step ends with the segment chain instead of the methylation scoring
         self.by_cigar = "cigar" in hb          # work items follow BAM CIGARs (build_host_batch_records)
@@ -423,15 +425,23 @@ class CallMethylationBatch:
             return self._step_hmm(L, h, p, s, ea)
         self._step_work_items(L, h, p, s, ea)
         if self.from_raw:
-            if self.from_adc:
-                rc = L.np_adc_to_pa_checked_dev(h, s, self.n_reads, p(self.d_adc), p(self.d_raw_off), self.max_samples, p(self.d_adc_offset),
-                                                p(self.d_adc_unit), p(self.d_raw), p(self.d_ed_verdict))
-                self.ctx._chk(rc, "np_adc_to_pa_checked_dev")
-            rc = L.np_detect_events_checked_dev(h, s, self.n_reads, p(self.d_raw), p(self.d_raw_off), self.max_samples, C.byref(self.prm),
-                                                p(self.d_tstat), p(self.d_event_off), self.max_events, p(self.d_ev_start), p(self.d_ev_len),
-                                                p(self.d_events), p(self.d_ev_stdv), p(self.d_n_events),
-                                                p(self.d_ed_verdict) if self.from_adc else None)
-            self.ctx._chk(rc, "np_detect_events_checked_dev")
+            if self.from_adc and self.adc_one_call:
+                # counts in, events out: the long reads are never written as pA values (np_detect_events_adc_dev)
+                rc = L.np_detect_events_adc_dev(h, s, self.n_reads, p(self.d_adc), p(self.d_raw_off), self.max_samples, p(self.d_adc_offset),
+                                                p(self.d_adc_unit), p(self.d_raw), C.byref(self.prm), p(self.d_tstat), p(self.d_event_off),
+                                                self.max_events, p(self.d_ev_start), p(self.d_ev_len), p(self.d_events), p(self.d_ev_stdv),
+                                                p(self.d_n_events))
+                self.ctx._chk(rc, "np_detect_events_adc_dev")
+            else:
+                if self.from_adc:
+                    rc = L.np_adc_to_pa_checked_dev(h, s, self.n_reads, p(self.d_adc), p(self.d_raw_off), self.max_samples, p(self.d_adc_offset),
+                                                    p(self.d_adc_unit), p(self.d_raw), p(self.d_ed_verdict))
+                    self.ctx._chk(rc, "np_adc_to_pa_checked_dev")
+                rc = L.np_detect_events_checked_dev(h, s, self.n_reads, p(self.d_raw), p(self.d_raw_off), self.max_samples, C.byref(self.prm),
+                                                    p(self.d_tstat), p(self.d_event_off), self.max_events, p(self.d_ev_start), p(self.d_ev_len),
+                                                    p(self.d_events), p(self.d_ev_stdv), p(self.d_n_events),
+                                                    p(self.d_ed_verdict) if self.from_adc else None)
+                self.ctx._chk(rc, "np_detect_events_checked_dev")
             rc = L.np_mom_fill_dev(h, s, self.n_reads, p(self.d_reads_a), p(self.d_reads_b), p(self.d_events), p(self.d_n_events),
                                    p(self.d_ranks), self.m_nuc)
             self.ctx._chk(rc, "np_mom_fill_dev")

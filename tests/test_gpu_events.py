@@ -199,11 +199,19 @@ def test_adc_counts_to_pa_on_the_device(ctx, orc, models):
     from nanopolish_amd.pipeline import build_host_batch, CallMethylationBatch
     hb = build_host_batch(models, list(range(120, 124)), L=1500, raw=True, adc=True)
     assert hb["adc"].dtype == np.int16
+    two = CallMethylationBatch(ctx, hb, "cuda:0", calibrate=True, from_raw=True, jobs_on_device=True, adc_one_call=False)
+    assert two.from_adc
+    two.step()
+    two.sync()
+    assert np.array_equal(two.d_raw.cpu().numpy().view(np.float32), hb["raw"])
+    # counts in, events out (np_detect_events_adc_dev: the default of a batch of counts) -- reads of 2 048 samples and more are not written as pA
     batch = CallMethylationBatch(ctx, hb, "cuda:0", calibrate=True, from_raw=True, jobs_on_device=True)
-    assert batch.from_adc
+    assert batch.from_adc and batch.adc_one_call
     batch.step()
     batch.sync()
-    assert np.array_equal(batch.d_raw.cpu().numpy().view(np.float32), hb["raw"])
+    for i in range(len(hb["reads"])):
+        a, b = batch.detected(i), two.detected(i)
+        assert a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))
     # the same reads with the pA values uploaded directly
     hb2 = {k: v for k, v in hb.items() if not k.startswith("adc")}
     ref = CallMethylationBatch(ctx, hb2, "cuda:0", calibrate=True, from_raw=True, jobs_on_device=True)
@@ -290,6 +298,77 @@ def test_conversion_that_also_proves_the_bound_equals_the_two_passes(ctx, orc):
     for i, n in enumerate(lens):                                          # and the events are the reference's
         want = orc.detect_events(want_pa[raw_off[i]:raw_off[i + 1]], **ED_DEFAULTS)
         assert one[1][i] == len(want["mean"]) and np.array_equal(one[4][ev_off[i]:ev_off[i] + one[1][i]], want["mean"])
+
+
+@pytest.mark.parametrize("rna", [False, True])
+def test_counts_in_events_out_equals_the_two_calls(ctx, orc, rna):
+    """np_detect_events_adc_dev (round 6): with the DNA windows a read of 2 048 samples or more is never written as pA values -- the verdict pass
+    only reads the counts, the walk and the event sums convert what they load (four words per block of eight samples, five and a funnel shift
+    when the read starts on an odd count).  Same event tables as np_adc_to_pa_checked_dev + np_detect_events_checked_dev: reads of 1 ... 60 001
+    samples in an order that puts long reads on odd AND even positions of the count array, reads with a few near-zero pA samples (serial path: their
+    pA values are written after all), per-read offsets and units, an offset that drives counts negative; and with the RNA
+    windows (7 / 14), where the entry falls back to the two-call form.  The DNA tables are the reference's."""
+    import ctypes as C
+    import torch
+    from nanopolish_amd import lib as _l
+    rng = np.random.default_rng(91)
+    lens = [1, 2049, 3, 60001, 7, 1500, 2048, 5, 4000, 30000, 2500, 2051, 9999, 2, 12345]
+    offset = 10.0
+    adcs = _adc_batch(rng, lens, offset)
+    raw_off = np.zeros(len(lens) + 1, np.int64); raw_off[1:] = np.cumsum(lens)
+    long_starts = [int(raw_off[i]) & 1 for i, n in enumerate(lens) if n >= 2048]
+    assert 0 in long_starts and 1 in long_starts
+    adc = np.concatenate(adcs)
+    offs = np.full(len(lens), offset, np.float32); units = np.full(len(lens), 1400.0 / 8192.0, np.float32)
+    offs[4:] += np.float32(3.0); units[6:] = np.float32(1467.6 / 8192.0)
+    offs[12] = np.float32(-700.0)                                          # counts + offset < 0: negative pA values
+    want_pa = np.concatenate([((a.astype(np.float32) + offs[i]) * units[i]).astype(np.float32) for i, a in enumerate(adcs)])
+    dev = "cuda:0"
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    d_adc, d_off, d_o, d_u = up(adc), up(raw_off), up(offs), up(units)
+    ev_off = np.zeros(len(lens) + 1, np.int64); ev_off[1:] = np.cumsum([n // 2 + 2 for n in lens])
+    d_ev_off = up(ev_off); cap = int(ev_off[-1])
+    prm = _l.DetectorParam(); ctx.L.np_event_detection_params(C.byref(prm), 1 if rna else 0)
+
+    def run(one_call):
+        d_raw = torch.full((len(adc),), -777.0, dtype=torch.float32, device=dev)
+        d_tstat = torch.zeros(2 * len(adc) + 16, dtype=torch.float32, device=dev)
+        st = torch.zeros(cap, dtype=torch.int32, device=dev); ln = torch.zeros(cap, dtype=torch.float32, device=dev)
+        mn = torch.zeros(cap, dtype=torch.float32, device=dev); sd = torch.zeros(cap, dtype=torch.float32, device=dev)
+        ne = torch.zeros(len(lens), dtype=torch.int32, device=dev)
+        mx = max(lens); mev = max(n // 2 + 2 for n in lens)
+        if one_call:
+            ctx._chk(ctx.L.np_detect_events_adc_dev(ctx.h, None, len(lens), p(d_adc), p(d_off), mx, p(d_o), p(d_u), p(d_raw), C.byref(prm), p(d_tstat), p(d_ev_off), mev,
+                                                    p(st), p(ln), p(mn), p(sd), p(ne)), "np_detect_events_adc_dev")
+        else:
+            verdict = torch.zeros(len(lens), dtype=torch.int32, device=dev)
+            ctx._chk(ctx.L.np_adc_to_pa_checked_dev(ctx.h, None, len(lens), p(d_adc), p(d_off), mx, p(d_o), p(d_u), p(d_raw), p(verdict)), "np_adc_to_pa_checked_dev")
+            ctx._chk(ctx.L.np_detect_events_checked_dev(ctx.h, None, len(lens), p(d_raw), p(d_off), mx, C.byref(prm), p(d_tstat), p(d_ev_off), mev,
+                                                        p(st), p(ln), p(mn), p(sd), p(ne), p(verdict)), "np_detect_events_checked_dev")
+        ctx.sync()
+        return d_raw.cpu().numpy(), ne.cpu().numpy(), st.cpu().numpy(), ln.cpu().numpy(), mn.cpu().numpy(), sd.cpu().numpy(), ctx.get_stat("ed_serial_reads")
+
+    two, one = run(False), run(True)
+    assert np.array_equal(two[0], want_pa) and two[6] >= 1 and one[6] == two[6]       # (the read with 0.17 pA samples; counts near -offset make more)
+    assert np.array_equal(one[1], two[1]) and (two[1] > 0).sum() >= len(lens) - 6
+    written_long = []
+    for i, n in enumerate(lens):
+        k = int(two[1][i]); a, b = int(ev_off[i]), int(ev_off[i]) + max(k, 0)
+        for x, y in zip(one[2:6], two[2:6]):
+            assert np.array_equal(x[a:b], y[a:b]), (i, n)
+        pa = one[0][raw_off[i]:raw_off[i + 1]]
+        if rna or n < 2048:                                # what the un-fused kernels read: written
+            assert np.array_equal(pa, want_pa[raw_off[i]:raw_off[i + 1]]), (i, n)
+        elif np.array_equal(pa, want_pa[raw_off[i]:raw_off[i + 1]]):
+            written_long.append(i)                         # a serial-path read: written after the verdict
+        else:                                              # the long reads of the fused form: never written
+            assert np.all(pa == np.float32(-777.0)), (i, n)
+        if not rna:
+            want = orc.detect_events(want_pa[raw_off[i]:raw_off[i + 1]], **ED_DEFAULTS)
+            assert k == len(want["mean"]) and np.array_equal(one[4][a:b], want["mean"]) and np.array_equal(one[5][a:b], want["stdv"])
+    if not rna:
+        assert 1 <= len(written_long) <= one[6]            # the serial-path reads among the long ones (small counts + offset: the bound fails)
 
 
 def test_samples_edited_between_conversion_and_detection(ctx, orc):

@@ -191,4 +191,12 @@ print(d["value"], d["roofline"]["kernel_ms_per_step"]); fr = d["from_raw"]; prin
 PYEOF2
 }
 
+# counts in, events out (np_detect_events_adc_dev) against the two calls, same box, alternating; then the GPU suite
+call_aa() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r06aa; mkdir -p $O
+( timeout 900 python tools/detect_ab.py ) > $O/detect_ab.log 2>&1; grep "^rep" $O/detect_ab.log
+( time timeout 1500 python -m pytest tests -m gpu -q ) > $O/pytest.log 2>&1; grep -h "passed\|failed" $O/pytest.log; grep "^FAILED" $O/pytest.log
+}
+
 "call_$1"
