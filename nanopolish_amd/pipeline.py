@@ -154,8 +154,9 @@ def concat_record_batches(parts):
 def build_host_batch_records(models, records, contig, k=6, alphabet="cpg", with_jobs=True):
     """Host-side preparation of a batch of reads given EXPLICITLY, each with its raw signal and the BAM record of its
     base-to-reference alignment: records = dicts(seq: the read's own sequence, raw: float32 samples, rc: bam_is_rev,
-    pos: 0-based leftmost reference position, cigar: uint32 BAM words[, contig: this record's own reference]).  contig: the
-    reference the records align to (those without their own).
+    pos: 0-based leftmost reference position, cigar: uint32 BAM words[, contig: this record's own reference][, adc: the int16 counts `raw`
+    is the conversion of (synth.adc_quantise): when every record has them the batch uploads counts]).  contig: the reference the records align
+    to (those without their own).
     The batch starts from raw signal (from_raw) and its work items follow the CIGARs: the host builder's
     items are in hb["jobs"] / hb["kpos"]; the device builder needs hb["cigar"], hb["ref_begin"], ... (same numbering).
     with_jobs=False: no methylation work items (an eventalign-only batch, e.g. direct-RNA reads: k = 5, base model u_to_t_rna).
@@ -229,6 +230,11 @@ def build_host_batch_records(models, records, contig, k=6, alphabet="cpg", with_
     if not from_events:
         raw_off = np.zeros(n + 1, np.int64); raw_off[1:] = np.cumsum([len(r["raw"]) for r in reads])
         extra = dict(raw=np.concatenate([r["raw"] for r in reads]), raw_off=raw_off)
+        if n > 0 and all("adc" in r for r in records):
+            # the traces as a sequencer stores them (int16 counts, synth.adc_quantise: "raw" is what they convert to): the batch uploads the counts
+            from .synth import ADC_OFFSET, ADC_UNIT
+            extra.update(adc=np.concatenate([np.ascontiguousarray(r["adc"], np.int16) for r in records]), adc_offset=np.full(n, ADC_OFFSET, np.float32),
+                         adc_unit=np.full(n, ADC_UNIT, np.float32))
     contig_off = np.concatenate([[0], np.cumsum([len(x) for x in contigs])]).astype(np.int64)
     return dict(reads=reads, n=n, events=np.concatenate([r["events"] for r in reads]), ranks=np.concatenate([r["ranks"] for r in reads]).astype(np.uint16),
                 event_off=event_off, rank_off=rank_off, reads_a=reads_a, reads_b=reads_b, mom=mom, ref_seqs=ref_seqs, k=k, contig_off=contig_off, **extra,

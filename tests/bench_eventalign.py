@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[2] (eventalign) on one MI355X: reads/s of the whole realignment of a batch of synthetic R9.4 reads,
-raw signal resident in HBM -> scrappie event detection -> MoM scalings -> adaptive banded event alignment -> event map +
+raw signal (int16 ADC counts) resident in HBM -> scrappie event detection -> MoM scalings -> adaptive banded event alignment -> event map +
 recalibration -> align_read_to_ref's segment chain (np_eventalign_dev), beside the reference's own code on the host cores
 (SquiggleRead from raw + align_read_to_ref, oracle/_ref/libnp_ref_full.so, one read per thread).  Prints one JSON line.
 This is a measurement tool for DESIGN.md / profiles/, not the driver's bench (bench.py keeps the call-methylation metric); it
@@ -37,7 +37,7 @@ def run(pool=5000, tile=10, read_len=5450, steps=3, warmup=1, cpu_sample=-1, ctx
     from nanopolish_amd.api import Context
     from nanopolish_amd.hostinfo import usable_cores
     from nanopolish_amd.pipeline import build_host_batch_records, tile_host_batch, CallMethylationBatch
-    from nanopolish_amd.synth import synth_cigar_read, BASES
+    from nanopolish_amd.synth import synth_cigar_read, adc_quantise, BASES
     models = load_models()
     own = ctx is None
     if own:
@@ -49,7 +49,8 @@ def run(pool=5000, tile=10, read_len=5450, steps=3, warmup=1, cpu_sample=-1, ctx
 
     def make(rid):
         r = synth_cigar_read(rid, genome, models["nucleotide"], span=read_len, **CIGAR_MIX)
-        return dict(seq=r["seq"], raw=r["raw"], rc=int(r["rc"]), pos=int(r["pos"]), cigar=api.cigar_words(r["cigar_ops"]), bam_seq=r["bam_seq"])
+        adc, raw = adc_quantise(r["raw"])            # the trace as a sequencer stores it: int16 counts resident, converted on the device
+        return dict(seq=r["seq"], raw=raw, adc=adc, rc=int(r["rc"]), pos=int(r["pos"]), cigar=api.cigar_words(r["cigar_ops"]), bam_seq=r["bam_seq"])
     with ThreadPoolExecutor(max(1, usable_cores()[2])) as ex:          # (threads: the HIP runtime is up, a forked pool is not an option)
         recs = list(ex.map(make, range(pool)))
     n_ops = np.array([len(r["cigar"]) for r in recs])
