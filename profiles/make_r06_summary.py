@@ -31,7 +31,7 @@ o = []
 o.append("# Round 6 -- end-of-round measurement set (MI355X, 1 GPU)\n")
 o.append("Collected through gpurun with `bash profiles/collect_r06_final.sh %s`; counters from `bash profiles/collect_r06_pmc.sh` (`r06_pmc.json`, "
          "`pmc_summary_r06.py`).  Raw outputs live under `gpurun_out/` (scratch); this file is `profiles/make_r06_summary.py %s`.  Beside it: "
-         "`r06_kernel_a.md` (six experiments on the band step), `r06_genome_reduction.md` (the N > 1 line as a genome-level reduction), `r06_batch_binding.md` (batches in pieces, "
+         "`r06_kernel_a.md` (eight experiments on the band step), `r06_genome_reduction.md` (the N > 1 line as a genome-level reduction), `r06_batch_binding.md` (batches in pieces, "
          "the stretch cache), `r06_detector.md`, `r06_kernel_b_lds.md`, `r06_soak.md`, `r06_boxes.md` (the same commands on several boxes); issue-cycle calibration: "
          "`r04_valu_calibration.json`.\n" % (TAG, TAG))
 ps = [l for l in text("pytest.log").splitlines() if " passed" in l or " failed" in l]

@@ -46,6 +46,9 @@ __global__ void k_add(double* o_m, double* o_v, const double* ident, const doubl
 #define TRACE_ADDC "v_addc_co_u32_e64 %[t], s[28:29], %[t], %[t], s[20:21]\n v_addc_co_u32_e64 %[t], s[28:29], %[t], %[t], s[22:23]\n" \
                    "v_addc_co_u32_e64 %[t], s[28:29], %[t], %[t], s[24:25]\n v_addc_co_u32_e64 %[t], s[28:29], %[t], %[t], s[26:27]\n"
 // the four compare masks leave through the scalar data cache instead (two 16-byte scalar stores per band)
+#define TRACE_FLOAT "v_sub_f32 %[x0], %[a6], %[a0]\n v_sub_f32 %[x1], %[a6], %[a1]\n v_sub_f32 %[x2], %[a7], %[a2]\n v_sub_f32 %[x3], %[a7], %[a3]\n" \
+                    "v_fma_f32 %[x0], %[x0], %[big], %[one] clamp\n v_fma_f32 %[x1], %[x1], %[big], %[one] clamp\n v_fma_f32 %[x2], %[x2], %[big], %[one] clamp\n v_fma_f32 %[x3], %[x3], %[big], %[one] clamp\n" \
+                    "v_fma_f32 %[x0], %[x0], %[two], %[x1]\n v_fma_f32 %[x2], %[x2], %[two], %[x3]\n v_fma_f32 %[f0], %[f0], %[four], %[x0]\n v_fma_f32 %[f1], %[f1], %[four], %[x2]\n"
 #define TRACE_SSTORE "s_store_dwordx4 s[20:23], %[sp], 0x0\n s_store_dwordx4 s[24:27], %[sp], 0x10\n"
 template <int MODE> __global__ void __launch_bounds__(256, 8) k_mix(unsigned long long* out, double* sink, const double* ident, int iters, uint64_t* splane = nullptr)
 {
@@ -56,12 +59,13 @@ template <int MODE> __global__ void __launch_bounds__(256, 8) k_mix(unsigned lon
     float a0 = l, a1 = 1.5f, a2 = 2.5f, a3 = 3.5f, a4 = 4.5f, a5 = 5.5f, a6 = 6.5f, a7 = 7.5f;
     double e0 = 1.0, e1 = 2.0, e2 = 3.0, e3 = 4.0, e4 = 5.0;
     uint32_t t = 0;
+    float f0 = 0.0f, f1 = 0.0f;
     const unsigned long long t0 = wall_clock64();
     const unsigned long long c0 = __builtin_readcyclecounter();
     for (int i = 0; i < iters; ++i) {
 #define VADD(n) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d##n) : "v"(B));
 #define MADD(n) d##n = __builtin_amdgcn_mfma_f64_4x4x4f64(A, B, d##n, 0, 0, 0);
-        if (MODE == 0 || MODE == 5 || MODE == 6) { REP10(VADD) }
+        if (MODE == 0 || MODE == 5 || MODE == 6 || MODE == 8 || MODE == 9) { REP10(VADD) }
         if (MODE == 1 || MODE == 3) { REP10(MADD) }
         if (MODE == 4) { asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0"); }
         if (MODE != 3 && MODE != 5) {
@@ -88,6 +92,33 @@ template <int MODE> __global__ void __launch_bounds__(256, 8) k_mix(unsigned lon
                 : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6), [a7] "+v"(a7),
                   [e0] "+v"(e0), [e1] "+v"(e1), [e2] "+v"(e2), [e3] "+v"(e3), [e4] "+v"(e4), [t] "+v"(t)
                 : [sp] "s"(sp) : "memory", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31");
+            } else if (MODE == 8 || MODE == 9) {
+            // MODE 8 (round 6, late): the trace WITHOUT compares and carry adds -- per candidate a float difference, a clamped fma that turns
+            // "difference == 0" into 1.0 / 0.0, and per cell two fmas that shift the two bits into a float accumulator: 12 fast-class
+            // instructions for the 8 slow ones.  MODE 9: no trace instructions at all (the bound).
+#define BAND_HEAD \
+                "v_fma_f32 %[a0], %[a0], %[a1], %[a2]\n v_fma_f32 %[a1], %[a1], %[a2], %[a3]\n v_fma_f32 %[a2], %[a2], %[a3], %[a4]\n" \
+                "v_fma_f32 %[a3], %[a3], %[a4], %[a5]\n v_fma_f32 %[a4], %[a4], %[a5], %[a6]\n v_fma_f32 %[a5], %[a5], %[a6], %[a7]\n" \
+                "v_mul_f32 %[a6], %[a6], %[a7]\n v_mul_f32 %[a7], %[a7], %[a0]\n v_sub_f32 %[a0], %[a0], %[a1]\n" \
+                "v_fma_f32 %[a0], %[a0], %[a1], %[a2]\n v_fma_f32 %[a1], %[a1], %[a2], %[a3]\n v_fma_f32 %[a2], %[a2], %[a3], %[a4]\n" \
+                "v_fma_f32 %[a3], %[a3], %[a4], %[a5]\n v_fma_f32 %[a4], %[a4], %[a5], %[a6]\n v_fma_f32 %[a5], %[a5], %[a6], %[a7]\n" \
+                "v_mul_f32 %[a6], %[a6], %[a7]\n v_mul_f32 %[a7], %[a7], %[a0]\n v_sub_f32 %[a0], %[a0], %[a1]\n" \
+                "v_cvt_f64_f32 %[e0], %[a0]\n v_cvt_f64_f32 %[e1], %[a1]\n v_cvt_f64_f32 %[e2], %[a2]\n v_cvt_f64_f32 %[e3], %[a3]\n v_cvt_f64_f32 %[e4], %[a4]\n" \
+                "v_cvt_f32_f64 %[a0], %[e0]\n v_cvt_f32_f64 %[a1], %[e1]\n v_cvt_f32_f64 %[a2], %[e2]\n v_cvt_f32_f64 %[a3], %[e3]\n v_cvt_f32_f64 %[a4], %[e4]\n v_cvt_f32_f64 %[a5], %[e0]\n" \
+                "v_max3_f32 %[a6], %[a6], %[a0], %[a1]\n v_max3_f32 %[a7], %[a7], %[a2], %[a3]\n"
+#define BAND_TAIL \
+                "v_cndmask_b32_e64 %[a6], %[a6], %[a4], s[20:21]\n v_cndmask_b32_e64 %[a7], %[a7], %[a5], s[22:23]\n" \
+                "v_mov_b32_dpp %[a5], %[a7] wave_ror:1 row_mask:0xf bank_mask:0xf\n" \
+                "v_readlane_b32 s30, %[a6], 5\n v_readlane_b32 s31, %[a7], 9\n"
+#define BAND_OPS \
+                : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6), [a7] "+v"(a7), \
+                  [e0] "+v"(e0), [e1] "+v"(e1), [e2] "+v"(e2), [e3] "+v"(e3), [e4] "+v"(e4), [t] "+v"(t), [f0] "+v"(f0), [f1] "+v"(f1), \
+                  [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3) \
+                : [one] "v"(1.0f), [big] "v"(-1.2676506e30f), [two] "v"(2.0f), [four] "v"(4.0f) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31"
+            float x0, x1, x2, x3;
+            if (MODE == 8) asm volatile(BAND_HEAD TRACE_FLOAT BAND_TAIL BAND_OPS);
+            else asm volatile(BAND_HEAD BAND_TAIL BAND_OPS);
+            if ((i & 7) == 7) { f0 = 0.0f; f1 = 0.0f; }       // (the accumulators start over every eight bands; the real kernel converts and stores them there)
             } else {
             asm volatile(
                 "v_fma_f32 %[a0], %[a0], %[a1], %[a2]\n v_fma_f32 %[a1], %[a1], %[a2], %[a3]\n v_fma_f32 %[a2], %[a2], %[a3], %[a4]\n"
@@ -115,7 +146,7 @@ template <int MODE> __global__ void __launch_bounds__(256, 8) k_mix(unsigned lon
     const unsigned long long c1 = __builtin_readcyclecounter();
     const unsigned long long t1 = wall_clock64();
     if (threadIdx.x == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = t1 - t0; }
-    sink[blockIdx.x * 256 + threadIdx.x] = d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 + d8 + d9 + a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + e0 + e1 + e2 + e3 + e4 + t;
+    sink[blockIdx.x * 256 + threadIdx.x] = d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 + d8 + d9 + a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + e0 + e1 + e2 + e3 + e4 + t + f0 + f1;
 }
 
 // ---- 4. the multi-read ring as an instruction-stream mock: one band of NS ring slots per lane, every instruction of the
@@ -350,6 +381,9 @@ int main()
         if (run_mix<4>("band rest + 10 s_nop", ident_d, w)) return 1;
         if (run_mix<0>("band rest + 10 v_add_f64", ident_d, w)) return 1;
         if (run_mix<1>("band rest + 10 MFMA", ident_d, w)) return 1;
+        if (run_mix<8>("band, trace as 12 fast fp32 ops", ident_d, w)) return 1;
+        if (run_mix<9>("band, no trace at all", ident_d, w)) return 1;
+        if (run_mix<0>("band rest + 10 v_add_f64 (again)", ident_d, w)) return 1;
         if (run_mix<6>("band (adds) - 4 addc + 2 s_store_x4", ident_d, w)) return 1;
     }
     printf("ring layouts (instruction-stream mock of the FAST band loop, no walk, no loads):\n");

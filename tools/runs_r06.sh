@@ -199,4 +199,21 @@ O=gpurun_out/r06aa; mkdir -p $O
 ( time timeout 1500 python -m pytest tests -m gpu -q ) > $O/pytest.log 2>&1; grep -h "passed\|failed" $O/pytest.log; grep "^FAILED" $O/pytest.log
 }
 
+# the emission's division in four operations (np_div_exact2) in kernel A and the chain: A/B of kernel A, the GPU suite (the division self-test with
+# its enumeration of the edge divisors), a soak seed, the bench line
+call_ad() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r06ad; mkdir -p $O
+( timeout 900 python tools/align_ab.py --pool 2048 --tile 16 $V/libnp_hip_base.so $V/libnp_hip_div2.so $V/libnp_hip_base.so $V/libnp_hip_div2.so ) > $O/align_ab.log 2>&1; cat $O/align_ab.log | tail -4
+( time timeout 1500 python -m pytest tests -m gpu -q ) > $O/pytest.log 2>&1; grep -h "passed\|failed" $O/pytest.log; grep "^FAILED" $O/pytest.log
+( timeout 900 python tests/gpu_soak.py --reads 1500 --seed 47 ) > $O/soak_47.log 2>&1; grep "^{" $O/soak_47.log | cut -c1-330
+( timeout 900 python tests/gpu_soak_eventalign.py 512 ) > $O/soak_ea.log 2>&1; tail -1 $O/soak_ea.log | cut -c1-200
+( time timeout 900 python bench.py --steps 10 --warmup 3 --streamed 0 --ragged 0 ) > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err
+python - <<'PYEOF2'
+import json
+d = json.loads(open("gpurun_out/r06ad/bench.json").read().strip().splitlines()[-1])
+print(d["value"], d["roofline"]["kernel_ms_per_step"], d["max_abs_dLLR_vs_cpu"], d["cpu_baseline"]["check"]); fr = d["from_raw"]; print(fr["value"], fr["kernel_ms_per_step"], fr.get("check")); print(d["value_eventalign"], d["eventalign"].get("kernel_ms_per_step"))
+PYEOF2
+}
+
 "call_$1"
