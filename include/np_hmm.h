@@ -533,6 +533,14 @@ int np_selftest_division(np_ctx* ctx, uint64_t n_samples, uint64_t seed, uint64_
  * with the constants the fused walk itself uses.  Both mismatch counts must come back 0. */
 int np_selftest_division_small(np_ctx* ctx, int w, uint64_t n_f64, uint64_t* n_mismatch_f32, uint64_t* n_mismatch_f64, uint64_t* n_f32_compared);
 
+/* Device self-test: the fused detector walk's last step, (float)(|delta_mean| / sqrt(combined_var / w)) in double (event_detection.c:111), as
+ * it is FILTERED (csrc/np_events_kernels.hip:ed_ratio_filtered: a reciprocal square root refined once, trusted only where the product stays clear
+ * of every float rounding boundary by 2^-39, the exact sequence elsewhere) against the exact sequence on n_samples pseudo-random operand pairs,
+ * a third of them steered to within 2^-24 of a boundary.  *n_mismatch (trusted values that differ) must come back 0; *n_sent_to_exact counts
+ * the values the filter handed to the exact sequence; *farthest_disagreement is the largest distance from a boundary, in units of 2^-53, at
+ * which an UNFILTERED value differed -- against the filter's band of 16384. */
+int np_selftest_tstat_ratio(np_ctx* ctx, uint64_t n_samples, uint64_t seed, uint64_t* n_mismatch, uint64_t* n_sent_to_exact, uint64_t* farthest_disagreement);
+
 /* Device memory, pinned host memory, streams and events for bindings that are not HIP programs themselves
  * (csrc/np_batch_dropin.cpp is plain C++ inside a nanopolish build).  Copies and fills are plain stream operations enqueued on
  * `stream` (0 = the context's own): they take no part in the one-stream-at-a-time rule of the compute entry points, so an upload

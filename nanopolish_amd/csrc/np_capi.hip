@@ -545,6 +545,24 @@ int np_selftest_division(np_ctx* c, uint64_t n_samples, uint64_t seed, uint64_t*
     return NP_OK;
 }
 
+int np_selftest_tstat_ratio(np_ctx* c, uint64_t n_samples, uint64_t seed, uint64_t* n_mismatch, uint64_t* n_sent_to_exact, uint64_t* farthest_disagreement)
+{
+    if (!c || !n_mismatch) return NP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(c->lock);
+    NP_HIP(c, hipSetDevice(c->device));
+    unsigned long long* d = (unsigned long long*)(c->d_counters + 32);
+    stream_scope scope = use_stream(c, nullptr);
+    NP_HIP(c, hipMemsetAsync(d, 0, 3 * sizeof(unsigned long long), c->stream));
+    NP_HIP(c, np_launch_selftest_ratio(n_samples, seed, d, c->stream));
+    unsigned long long h[3] = {0, 0, 0};
+    NP_HIP(c, hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    NP_HIP(c, hipStreamSynchronize(c->stream));
+    *n_mismatch = h[0];
+    if (n_sent_to_exact) *n_sent_to_exact = h[1];
+    if (farthest_disagreement) *farthest_disagreement = h[2];
+    return NP_OK;
+}
+
 int np_selftest_division_small(np_ctx* c, int w, uint64_t n_f64, uint64_t* n_mismatch_f32, uint64_t* n_mismatch_f64, uint64_t* n_f32_compared)
 {
     if (!c || w < 2 || w > 1024 || !n_mismatch_f32 || !n_mismatch_f64) return NP_ERR_INVALID;

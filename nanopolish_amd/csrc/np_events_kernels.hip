@@ -390,8 +390,47 @@ __device__ __forceinline__ double div_small_f64(double x, double ch, double cl) 
 // 0 or at least 2^-53 for every read the walk sees (ed_check_finish sends reads with a non-zero sample below 2^-30 to the serial path),
 // (3) the plain division of a variance clamped to FLT_MIN (a denormal quotient) taken only when SOME lane of the wave has such a sample
 // -- a wave-uniform branch instead of an IEEE division expanded next to every exact one.
+// ---- round 6, late: the t-statistic's last step, (float)(|dm| / sqrt(cvw)) evaluated in double (event_detection.c:111), FILTERED --------------
+// The reference's value is T = RN32(Qd), Qd = RN64(A / RN64(sqrt(c))) with A = |dm| and c = cvw widened to double: Qd is within 2^-52 (relative)
+// of the real R = A / sqrt(c).  q below -- one v_rsq_f64 (good to 2^-23 by the ISA's accuracy statement), ONE Newton step, one product -- is within
+// E < 2^-44 of R.  A float rounding boundary is a double whose low 29 significand bits read 0x10000000; if q's low 29 bits are farther than
+// 2^14 from that pattern, q is at least 2^14 * 2^-53 = 2^-39 (relative) from every boundary, R and Qd lie on q's side of it, and RN32(q) = T.
+// Otherwise (`near`: 2^-14 of the values; also when q is below the normal floats, where the boundaries sit elsewhere) the caller evaluates the
+// exact sequence -- for the whole wave, behind a wave-uniform branch.  6 fp64 instructions instead of 18 per window.  np_selftest_tstat_ratio
+// compares the two on 2^32 operand pairs and reports how far from a boundary the farthest disagreement of the UNFILTERED q sat (the margin
+// the accuracy assumption leaves).
+#define NP_ED_RATIO_BAND 16384u
+__device__ __forceinline__ float ed_ratio_exact(float dm, float cvw) { return (float)div_f64_normal(fabs((double)dm), sqrt_f64_normal((double)cvw)); }
+__device__ __forceinline__ double ed_ratio_approx(float dm, float cvw)
+{
+    const double A = fabs((double)dm), c = (double)cvw;
+    double y = __builtin_amdgcn_rsq(c);
+    const double cy = c * y;
+    const double r = __builtin_fma(-cy, y, 1.0);          // 1 - c y^2
+    y = __builtin_fma(0.5 * y, r, y);                     // y (1 + r / 2)
+    return A * y;
+}
+__device__ __forceinline__ bool ed_ratio_near(double q)
+{
+    const uint64_t b = __builtin_bit_cast(uint64_t, q);
+    const uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32);
+    const bool near_mid = ((lo & 0x1fffffffu) - (0x10000000u - NP_ED_RATIO_BAND)) <= 2u * NP_ED_RATIO_BAND;
+    const bool below_normal = (hi - 0x00100000u) < (0x38100000u - 0x00100000u);          // 0 < q < 2^-126 (q >= 0; q == 0 is exact)
+    return near_mid || below_normal;
+}
+__device__ __forceinline__ float ed_ratio_filtered(float dm, float cvw, bool& near)
+{
+#if defined(NP_ED_RATIO_EXACT) && NP_ED_RATIO_EXACT        // A/B builds: the exact sequence for every value
+    near = false;
+    return ed_ratio_exact(dm, cvw);
+#endif
+    const double q = ed_ratio_approx(dm, cvw);
+    near = ed_ratio_near(q);
+    return (float)q;
+}
+
 __device__ __forceinline__ float tstat_from_sums_fast(double sum1, double sumsq1, double sum2d, double sumsq2d, int i, int n, int w, float w_lengthf,
-                                                      const double half, const float halff)
+                                                      const double half, const float halff, float& dm_out, float& cvw_out, bool& near)
 {
     const double chd = NP_ED_W3_CH * half, cld = NP_ED_W3_CL * half;
     const float chf = NP_ED_W3_CHF * halff, clf = NP_ED_W3_CLF * halff;
@@ -404,8 +443,8 @@ __device__ __forceinline__ float tstat_from_sums_fast(double sum1, double sumsq1
     const float delta_mean = mean2 - mean1;
     float cvw = div_small_f32(combined_var, chf, clf);
     if (__builtin_amdgcn_ballot_w64(combined_var < 1e-30f) != 0ull) cvw = combined_var < 1e-30f ? combined_var / w_lengthf : cvw;
-    const float t = (float)div_f64_normal(fabs((double)delta_mean), sqrt_f64_normal((double)cvw));
-    return (n < 2 * w || i < w || i > n - w) ? 0.0f : t;                        // quick return and fudged boundaries
+    dm_out = delta_mean; cvw_out = cvw;
+    return ed_ratio_filtered(delta_mean, cvw, near);      // (the caller applies compute_tstat's boundary rule and, where `near`, ed_ratio_exact)
 }
 
 #if defined(NP_ED_ABL) && (NP_ED_ABL & 4)
@@ -661,9 +700,12 @@ __device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int 
                 const int o = 8 * h + q;
                 const int i = blk * 8 + q;
                 const bool in = lane_active && i >= begin && i < end;
-                const float ta = tstat_from_sums_fast(RS[(o + 3) & 15], RQ[(o + 3) & 15], RS[(o + 6) & 15], RQ[(o + 6) & 15], i, n, WA, 3.0f, 1.0, 1.0f);
-                const float tb = tstat_from_sums_fast(RS[o & 15] + RS[(o + 3) & 15], RQ[o & 15] + RQ[(o + 3) & 15], RS[(o + 6) & 15] + RS[(o + 9) & 15],
-                                                      RQ[(o + 6) & 15] + RQ[(o + 9) & 15], i, n, WB, 6.0f, 0.5, 0.5f);
+                float dma, cva, dmb, cvb; bool na, nb;
+                float ta = tstat_from_sums_fast(RS[(o + 3) & 15], RQ[(o + 3) & 15], RS[(o + 6) & 15], RQ[(o + 6) & 15], i, n, WA, 3.0f, 1.0, 1.0f, dma, cva, na);
+                float tb = tstat_from_sums_fast(RS[o & 15] + RS[(o + 3) & 15], RQ[o & 15] + RQ[(o + 3) & 15], RS[(o + 6) & 15] + RS[(o + 9) & 15],
+                                                RQ[(o + 6) & 15] + RQ[(o + 9) & 15], i, n, WB, 6.0f, 0.5, 0.5f, dmb, cvb, nb);
+                if (__builtin_amdgcn_ballot_w64(na || nb) != 0ull) { ta = ed_ratio_exact(dma, cva); tb = ed_ratio_exact(dmb, cvb); }
+                ta = (n < 2 * WA || i < WA || i > n - WA) ? 0.0f : ta; tb = (n < 2 * WB || i < WB || i > n - WB) ? 0.0f : tb;      // quick return and fudged boundaries
                 const float t1 = w1 < w2 ? ta : tb, t2 = w1 < w2 ? tb : ta;
                 int pos;
                 if (detector_step<0>(st.d0, st.d1, in ? i : -1, t1, p.peak_height, p.threshold1, w1, pos) && RECORD) {
@@ -692,8 +734,13 @@ __device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int 
         for (int q = 0; q < 8; ++q) {
             const int i = blk * 8 + q;
             const bool in = lane_active && i >= begin && i < end;
-            const float ta = tstat_from_sums_fast(S[q + 3], Q[q + 3], S[q + 6], Q[q + 6], i, n, WA, 3.0f, 1.0, 1.0f);
-            const float tb = tstat_from_sums_fast(S[q] + S[q + 3], Q[q] + Q[q + 3], S[q + 6] + S[q + 9], Q[q + 6] + Q[q + 9], i, n, WB, 6.0f, 0.5, 0.5f);
+            float dma, cva, dmb, cvb; bool na, nb;
+            float ta = tstat_from_sums_fast(S[q + 3], Q[q + 3], S[q + 6], Q[q + 6], i, n, WA, 3.0f, 1.0, 1.0f, dma, cva, na);
+            float tb = tstat_from_sums_fast(S[q] + S[q + 3], Q[q] + Q[q + 3], S[q + 6] + S[q + 9], Q[q + 6] + Q[q + 9], i, n, WB, 6.0f, 0.5, 0.5f, dmb, cvb, nb);
+            // (where the filter cannot vouch for a lane -- 2^-14 of the values -- the whole wave takes the exact sequence: it agrees with the
+            //  filtered one wherever that was trusted)
+            if (__builtin_amdgcn_ballot_w64(na || nb) != 0ull) { ta = ed_ratio_exact(dma, cva); tb = ed_ratio_exact(dmb, cvb); }
+            ta = (n < 2 * WA || i < WA || i > n - WA) ? 0.0f : ta; tb = (n < 2 * WB || i < WB || i > n - WB) ? 0.0f : tb;          // quick return and fudged boundaries
             const float t1 = w1 < w2 ? ta : tb, t2 = w1 < w2 ? tb : ta;
             int pos;
             if (detector_step<0>(st.d0, st.d1, in ? i : -1, t1, p.peak_height, p.threshold1, w1, pos) && RECORD) {
@@ -1300,5 +1347,57 @@ static __global__ void __launch_bounds__(256) np_selftest_div_small_kernel(int w
 hipError_t np_launch_selftest_div_small(int w, double chd, double cld, float chf, float clf, uint64_t n_f64, unsigned long long* d_out, hipStream_t s)
 {
     hipLaunchKernelGGL(np_selftest_div_small_kernel, dim3(8192), dim3(256), 0, s, w, chd, cld, chf, clf, n_f64, d_out);
+    return hipGetLastError();
+}
+
+// ---- device self-test of the filtered t-statistic ratio (ed_ratio_filtered against ed_ratio_exact) ------------------------------------------
+// Pseudo-random (|dm|, cvw) pairs over the floats' range as the walk meets them (cvw from FLT_MIN / 6 up, dm from denormals up, zeros now and
+// then), plus pairs steered towards rounding boundaries: dm = RN32(m sqrt(cvw)) for a 25-bit midpoint m, so that the quotient lands within
+// 2^-24 of a boundary.  out[0]: values the filter TRUSTED whose float differs from the exact sequence's (must be 0); out[1]: values it sent to
+// the exact sequence; out[2]: the largest distance (in units of 2^-53) from a boundary pattern at which the UNFILTERED value disagreed -- the
+// band is 16384, so this is the margin the accuracy assumption leaves.
+static __global__ void __launch_bounds__(256) np_selftest_ratio_kernel(uint64_t n_per_thread, uint64_t seed, unsigned long long* out)
+{
+    uint64_t sd = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)blockIdx.x * 256 + threadIdx.x + 1);
+    unsigned long long bad = 0, nnear = 0, far = 0;
+    for (uint64_t i = 0; i < n_per_thread; ++i) {
+        sd += 0x9E3779B97F4A7C15ull;
+        uint64_t z = sd; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        // cvw: exponent in [2^-128, 2^40), random significand (the lowest values are denormal floats: FLT_MIN / 6)
+        const uint32_t ce = (uint32_t)((z >> 23) % 168u);
+        float c = __builtin_bit_cast(float, (ce << 23) | ((uint32_t)z & 0x7fffffu));
+        if (c < 1.9e-39f) c = 1.9e-39f;
+        float dm;
+        if ((z >> 60) < 6) {                 // steered: the quotient within 2^-24 of a float midpoint
+            const uint32_t me = 100u + (uint32_t)((z >> 40) % 60u);
+            const double m = (double)__builtin_bit_cast(float, (me << 23) | ((uint32_t)(z >> 32) & 0x7fffffu)) * (1.0 + 5.9604644775390625e-08);      // x (1 + 2^-24): a midpoint
+            dm = (float)(m * sqrt((double)c));
+        } else {
+            const uint32_t de = (uint32_t)((z >> 48) % 200u);
+            dm = __builtin_bit_cast(float, (de << 23) | ((uint32_t)(z >> 25) & 0x7fffffu));
+            if ((z >> 56 & 0xff) == 0) dm = 0.0f;
+        }
+        const double q = ed_ratio_approx(dm, c);
+        const bool near = ed_ratio_near(q);
+        const float got = (float)q, want = ed_ratio_exact(dm, c);
+        const bool differ = __builtin_bit_cast(uint32_t, got) != __builtin_bit_cast(uint32_t, want);
+        bad += differ && !near;
+        nnear += near;
+        if (differ) {
+            const uint32_t L = (uint32_t)__builtin_bit_cast(uint64_t, q) & 0x1fffffffu;
+            const uint32_t dist = L > 0x10000000u ? L - 0x10000000u : 0x10000000u - L;
+            const bool normal = ((uint32_t)(__builtin_bit_cast(uint64_t, q) >> 32) >= 0x38100000u);
+            if (normal) far = far > dist ? far : dist;
+        }
+    }
+    if (bad) atomicAdd(out + 0, bad);
+    atomicAdd(out + 1, nnear);
+    atomicMax(out + 2, far);
+}
+hipError_t np_launch_selftest_ratio(uint64_t n_samples, uint64_t seed, unsigned long long* d_out, hipStream_t s)
+{
+    const unsigned blocks = 8192;
+    const uint64_t per_thread = (n_samples + (uint64_t)blocks * 256 - 1) / ((uint64_t)blocks * 256);
+    hipLaunchKernelGGL(np_selftest_ratio_kernel, dim3(blocks), dim3(256), 0, s, per_thread, seed, d_out);
     return hipGetLastError();
 }

@@ -175,6 +175,7 @@ int64_t np_site_rank_chunks(int64_t n_pos);
 hipError_t np_launch_score_set_combine(int64_t n_sets, const int64_t* set_off, const int64_t* member_idx, const float* member_scores,
                                        const float* logsum, const double* log_n /* host-constants mode: log(0 .. 64) by the process's libm; else null */, float* out, hipStream_t s);
 hipError_t np_launch_selftest_div(uint64_t n_samples, uint64_t seed, unsigned long long* d_mismatches, hipStream_t s);
+hipError_t np_launch_selftest_ratio(uint64_t n_samples, uint64_t seed, unsigned long long* d_out, hipStream_t s);
 hipError_t np_launch_selftest_div_small(int w, double chd, double cld, float chf, float clf, uint64_t n_f64, unsigned long long* d_out, hipStream_t s);
 
 // ---- f2: event detection + method-of-moments scalings (np_events_kernels.hip) ------------------------------------

@@ -20,7 +20,7 @@ SYMBOLS = [
     "np_alphabet_id", "np_alphabet_size", "np_kmer_rank", "np_reverse_complement", "np_methylate", "np_unmethylate",
     "np_is_motif_match", "np_sequence_kmer_ranks", "np_calculate_transitions", "np_estimate_scalings_mom",
     "np_scan_motif_groups", "np_cm_build_jobs_identity", "np_fill_read_host", "np_hmm_score_host", "np_hmm_score_set_host", "np_hmm_align_host", "np_event_align_host",
-    "np_event_align_dev", "np_hmm_score_dev", "np_resolve_jobs_dev", "np_calibrate_resolve_dev", "np_event_detection_params", "np_detect_events_dev", "np_detect_events_host", "np_mom_fill_dev", "np_cm_build_jobs_identity_dev", "np_cm_build_jobs_cigar_dev", "np_cm_discard_degenerate_dev", "np_set_job_layout", "np_cigar_aligned_bases", "np_cm_build_jobs_cigar", "np_eventalign_dev", "np_aligner_constants", "np_restated_log_exp", "np_selftest_libm", "np_site_table_genome_dev", "np_site_table_genome_indexed_dev", "np_genome_site_index_dev", "np_adc_to_pa_dev", "np_adc_to_pa_checked_dev", "np_detect_events_checked_dev", "np_detect_events_adc_dev", "np_sync", "np_last_kernel_ms", "np_kernel_time", "np_selftest_division", "np_selftest_division_small",
+    "np_event_align_dev", "np_hmm_score_dev", "np_resolve_jobs_dev", "np_calibrate_resolve_dev", "np_event_detection_params", "np_detect_events_dev", "np_detect_events_host", "np_mom_fill_dev", "np_cm_build_jobs_identity_dev", "np_cm_build_jobs_cigar_dev", "np_cm_discard_degenerate_dev", "np_set_job_layout", "np_cigar_aligned_bases", "np_cm_build_jobs_cigar", "np_eventalign_dev", "np_aligner_constants", "np_restated_log_exp", "np_selftest_libm", "np_site_table_genome_dev", "np_site_table_genome_indexed_dev", "np_genome_site_index_dev", "np_adc_to_pa_dev", "np_adc_to_pa_checked_dev", "np_detect_events_checked_dev", "np_detect_events_adc_dev", "np_sync", "np_last_kernel_ms", "np_kernel_time", "np_selftest_division", "np_selftest_division_small", "np_selftest_tstat_ratio",
 ]
 
 
@@ -134,6 +134,7 @@ def load_library():
     L.np_hmm_score_dev.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, C.c_int, vp]
     L.np_resolve_jobs_dev.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int64, vp, vp]
     L.np_selftest_division.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.np_selftest_tstat_ratio.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.np_selftest_division_small.argtypes = [vp, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.np_set_job_layout.argtypes = [vp, C.c_int, vp, vp, C.c_int64]
     L.np_calibrate_resolve_dev.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int64, vp, vp]

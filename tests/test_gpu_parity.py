@@ -301,6 +301,17 @@ def test_two_operation_division_by_a_window_length_selftest(ctx, w):
     assert n32.value == 2 * (0x7f800000 - 0x0d800000) + 2
 
 
+def test_filtered_tstat_ratio_selftest(ctx):
+    """ed_ratio_filtered (the fused walk's (float)(|dm| / sqrt(cvw)), event_detection.c:111: one refined v_rsq_f64 where the result stays clear of
+    every float rounding boundary, the exact square root and division elsewhere) never trusts a value that differs from the exact sequence:
+    2^32 operand pairs, a third steered next to a boundary; and the unfiltered value's disagreements all sit deep inside the filter's band."""
+    import ctypes as C
+    bad, near, far = C.c_uint64(7), C.c_uint64(0), C.c_uint64(0)
+    rc = ctx.L.np_selftest_tstat_ratio(ctx.h, 1 << 32, 20260930, C.byref(bad), C.byref(near), C.byref(far))
+    assert rc == 0 and bad.value == 0
+    assert 0 < near.value < (1 << 32) // 2 and far.value < 16384 // 8, (near.value, far.value)
+
+
 def test_eventalign_segment_chain_matches_oracle(ctx, orc, models):
     """BASELINE config 3 shape: the eventalign segment chain (each segment starts where the previous one stopped
     emitting) driven by profile_hmm_align on the GPU vs on the oracle, forward and reverse-strand reads."""

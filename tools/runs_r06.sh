@@ -216,4 +216,26 @@ print(d["value"], d["roofline"]["kernel_ms_per_step"], d["max_abs_dLLR_vs_cpu"],
 PYEOF2
 }
 
+# the filtered t-statistic ratio: the GPU suite (its self-test among them), the randomised detection comparison, two soak seeds, the bench line
+call_am() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r06am; mkdir -p $O
+( time timeout 1500 python -m pytest tests -m gpu -q ) > $O/pytest.log 2>&1; grep -h "passed\|failed" $O/pytest.log; grep "^FAILED\|^E  " $O/pytest.log | head
+python - <<'PYEOF2'
+import ctypes as C
+from nanopolish_amd.api import Context
+c = Context(0); bad, near, far = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+for seed in (1, 2, 3):
+    c.L.np_selftest_tstat_ratio(c.h, 1 << 32, seed, C.byref(bad), C.byref(near), C.byref(far)); print("ratio selftest seed", seed, "trusted mismatches", bad.value, "sent to exact", near.value, "farthest unfiltered disagreement", far.value)
+PYEOF2
+( timeout 900 python tools/fuzz_detect_adc.py --batches 60 --seed 9 ) > $O/fuzz.log 2>&1; tail -1 $O/fuzz.log
+for seed in 48 49; do ( timeout 900 python tests/gpu_soak.py --reads 1500 --seed $seed ) > $O/soak_$seed.log 2>&1; grep "^{" $O/soak_$seed.log | cut -c1-330; done
+( time timeout 900 python bench.py --steps 10 --warmup 3 --streamed 0 --ragged 0 ) > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err
+python - <<'PYEOF2'
+import json
+d = json.loads(open("gpurun_out/r06am/bench.json").read().strip().splitlines()[-1])
+print(d["value"], d["roofline"]["kernel_ms_per_step"], d["max_abs_dLLR_vs_cpu"]); fr = d["from_raw"]; print(fr["value"], fr["kernel_ms_per_step"], fr.get("check")); print(d["value_eventalign"], d["eventalign"].get("kernel_ms_per_step"))
+PYEOF2
+}
+
 "call_$1"
