@@ -75,13 +75,15 @@ const char* np_ctx_info(const np_ctx* ctx);
  * sizes), "align_lpt" (1: the event aligner takes the batch's reads longest first; 0: in index order),
  * "stream_switch_wait" (1: a call on another stream than the context's previous call waits for that stream's tail; 0: the caller orders
  * the streams it uses with one context by its own events), "ed_warmup" (samples each segment of the parallel peak walk starts early; 0 forces every segment through the
- * repair path -- results never depend on it), "ea_rows_cap" (events per eventalign segment the chain kernel's scratch holds;
+ * repair path -- results never depend on it), "ed_ratio_exact" (1: the fused walk evaluates the t-statistic's (float)(|dm| / sqrt(cvw)) by the exact
+ * square root and division for every value; 0, the default when np_create's probe passes: by a once-refined v_rsq_f64 wherever that provably
+ * rounds to the same float -- events never depend on it), "ea_rows_cap" (events per eventalign segment the chain kernel's scratch holds;
  * a longer segment ends its read with NP_EA_OVERFLOW), "ea_waves_per_cu" (persistent grid of the chain kernel), "lse_oor" (0: the forward kernel clamps its log-sum table index;
  * 1: it relies on the LDS out-of-range rule, the default when np_create's probe passes and refused (NP_ERR_UNSUPPORTED) when it did not --
  * scores never depend on it), "hmm_prio" (wave priority of the forward kernels, 0 ... 2),
  * "recal_shape" (np_calibrate_resolve_dev's workgroup shape, 3: the default -- sixteen waves x four reads, 32-k-mer chunks --, 0 ... 2: the shapes it was measured against; results never depend on it), "small_batch_path"
  * (1: np_hmm_score_host sends a small batch as one pinned blob; 0: the general path -- the tests compare the two).
- * Environment, read at np_create (each the option of the same name): NP_ALIGN_BLOCKS_PER_CU, NP_HMM_BLOCKS_PER_CU, NP_ALIGN_LPT, NP_ED_WARMUP,
+ * Environment, read at np_create (each the option of the same name): NP_ALIGN_BLOCKS_PER_CU, NP_HMM_BLOCKS_PER_CU, NP_ALIGN_LPT, NP_ED_WARMUP, NP_ED_RATIO_EXACT,
  * NP_EA_WAVES_PER_CU, NP_RECAL_SHAPE; NP_EA_WALK_PRIO=1 runs the chain kernel's back-track at wave priority 3 (measured slower,
  * profiles/r05_soak.md); NP_LSE_CLAMP, NP_HOST_CONSTANTS, NP_VERBOSE as described at np_ctx_info / in INTEGRATION.md. */
 int np_set_option(np_ctx* ctx, const char* name, int64_t value);

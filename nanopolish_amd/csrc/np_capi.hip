@@ -96,6 +96,7 @@ struct np_ctx {
     int align_lpt = 1;                // issue the event aligner's reads longest first
     int stream_switch_wait = 1;       // a call on a new stream waits for the tail of the stream the context used before (0: the caller orders its streams itself)
     int ed_warmup = -1;               // parallel peak walk: samples of warm-up per segment (< 0: the kernel's default)
+    bool ed_ratio_exact = false;      // the fused walk's (float)(|dm| / sqrt(cvw)) by the exact sequence for every value (np_create's probe failed, or the option)
     int64_t last_align_blocks = 0, last_align_scratch = 0;
     int ed_last_reads = 0;            // np_get_stat("ed_serial_reads"): reads of the most recent event-detection call      // np_get_stat: grid and scratch of the most recent event-align launch
 };
@@ -448,6 +449,19 @@ np_ctx* np_create(int device, const np_params* params)
     }
     g_create_err.clear();
     if (!probe_hardware(c)) { np_destroy(c); return nullptr; }
+    {
+        // the fused detector walk trusts a once-refined v_rsq_f64 for the t-statistic's last step wherever the result stays clear of the float
+        // rounding boundaries (np_events_kernels.hip:ed_ratio_filtered); that rests on the instruction's accuracy: checked here on 2^22 operand
+        // pairs -- a device on which a trusted value differs from the exact sequence runs the exact sequence for every value instead
+        uint64_t bad = 0, near = 0, far = 0;
+        const int rc = np_selftest_tstat_ratio(c, 1ull << 22, 20260930, &bad, &near, &far);
+        c->ed_ratio_exact = rc != NP_OK || bad != 0 || far >= 4096;
+        if (const char* v = getenv("NP_ED_RATIO_EXACT")) c->ed_ratio_exact = atoi(v) != 0;
+        char line[200];
+        snprintf(line, sizeof(line), "; t-statistic ratio: %s (probe: %llu trusted values differ, farthest unfiltered disagreement %llu of a band of 16384)",
+                 c->ed_ratio_exact ? "exact sequence for every value" : "filtered", (unsigned long long)bad, (unsigned long long)far);
+        c->info += line;
+    }
     {
         uint64_t bad = 0;
         (void)np_selftest_libm(100000, 20260925, &bad);
@@ -1440,6 +1454,7 @@ int np_set_option(np_ctx* c, const char* name, int64_t value)
     else if (k == "stream_switch_wait") c->stream_switch_wait = value != 0;
     else if (k == "small_batch_path") c->small_batch_path = value != 0;
     else if (k == "ed_warmup") c->ed_warmup = (int)value;
+    else if (k == "ed_ratio_exact") c->ed_ratio_exact = value != 0;
     else if (k == "ea_rows_cap") c->ea_rows_cap = (int)std::min<int64_t>(65535, std::max<int64_t>(16, value));
     else if (k == "lse_oor") {                                   // tests: both log-sum lookups must give the same scores
         if (value != 0 && !c->lse_probe_ok) { c->err = "lse_oor: the hardware probe of this context failed; the clamp-free log-sum is not available"; return NP_ERR_UNSUPPORTED; }
@@ -1480,7 +1495,7 @@ static int detect_events_locked(np_ctx* c, hipStream_t s, int n_reads, const flo
     if (checked) NP_HIP(c, hipMemcpyAsync(c->ed_status.p, verdict, (size_t)n_reads * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     family_timer tm(c, 4, s);
     NP_HIP(c, np_launch_detect_events(n_reads, raw, raw_off, max_samples, p, (float2*)tstat, c->ed_status.as<int32_t>(), event_off,
-                                      max_events, event_start, event_length, event_mean, event_stdv, n_events, c->ed_warmup, checked, s));
+                                      max_events, event_start, event_length, event_mean, event_stdv, n_events, c->ed_warmup, checked, s, c->ed_ratio_exact ? 1 : 0));
     return NP_OK;
 }
 
@@ -1530,7 +1545,7 @@ int np_detect_events_adc_dev(np_ctx* c, void* stream, int n_reads, const int16_t
     c->ed_last_reads = n_reads;
     family_timer tm(c, 4, s);
     NP_HIP(c, np_launch_detect_events_adc(n_reads, adc, raw_off, max_samples, offset, raw_unit, raw_pa, p, (float2*)tstat, c->ed_status.as<int32_t>(),
-                                          event_off, max_events, event_start, event_length, event_mean, event_stdv, n_events, c->ed_warmup, s));
+                                          event_off, max_events, event_start, event_length, event_mean, event_stdv, n_events, c->ed_warmup, s, c->ed_ratio_exact ? 1 : 0));
     return NP_OK;
 }
 

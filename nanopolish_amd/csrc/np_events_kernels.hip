@@ -625,7 +625,7 @@ __device__ __forceinline__ void walk_segment(const float2* __restrict__ ts_all, 
 template <bool RECORD, bool ADC = false>
 __device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int n, int begin, int end, int trip, bool lane_active,
                                                  walk_state& st, const np_detector_param& p, uint32_t* tmp, int tmp_cap, int& cnt,
-                                                 const int lead = 0, const float adc_off = 0.0f, const float adc_unit = 1.0f)
+                                                 const int lead = 0, const float adc_off = 0.0f, const float adc_unit = 1.0f, const bool ratio_exact = false)
 {
     constexpr int WA = 3, WB = 6;
     int blk = begin >> 3;                                     // this lane's first block of 8 samples (read-relative)
@@ -704,7 +704,7 @@ __device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int 
                 float ta = tstat_from_sums_fast(RS[(o + 3) & 15], RQ[(o + 3) & 15], RS[(o + 6) & 15], RQ[(o + 6) & 15], i, n, WA, 3.0f, 1.0, 1.0f, dma, cva, na);
                 float tb = tstat_from_sums_fast(RS[o & 15] + RS[(o + 3) & 15], RQ[o & 15] + RQ[(o + 3) & 15], RS[(o + 6) & 15] + RS[(o + 9) & 15],
                                                 RQ[(o + 6) & 15] + RQ[(o + 9) & 15], i, n, WB, 6.0f, 0.5, 0.5f, dmb, cvb, nb);
-                if (__builtin_amdgcn_ballot_w64(na || nb) != 0ull) { ta = ed_ratio_exact(dma, cva); tb = ed_ratio_exact(dmb, cvb); }
+                if (ratio_exact || __builtin_amdgcn_ballot_w64(na || nb) != 0ull) { ta = ed_ratio_exact(dma, cva); tb = ed_ratio_exact(dmb, cvb); }
                 ta = (n < 2 * WA || i < WA || i > n - WA) ? 0.0f : ta; tb = (n < 2 * WB || i < WB || i > n - WB) ? 0.0f : tb;      // quick return and fudged boundaries
                 const float t1 = w1 < w2 ? ta : tb, t2 = w1 < w2 ? tb : ta;
                 int pos;
@@ -739,7 +739,7 @@ __device__ __forceinline__ void walk_segment_raw(__amdgpu_buffer_rsrc_t xr, int 
             float tb = tstat_from_sums_fast(S[q] + S[q + 3], Q[q] + Q[q + 3], S[q + 6] + S[q + 9], Q[q + 6] + Q[q + 9], i, n, WB, 6.0f, 0.5, 0.5f, dmb, cvb, nb);
             // (where the filter cannot vouch for a lane -- 2^-14 of the values -- the whole wave takes the exact sequence: it agrees with the
             //  filtered one wherever that was trusted)
-            if (__builtin_amdgcn_ballot_w64(na || nb) != 0ull) { ta = ed_ratio_exact(dma, cva); tb = ed_ratio_exact(dmb, cvb); }
+            if (ratio_exact || __builtin_amdgcn_ballot_w64(na || nb) != 0ull) { ta = ed_ratio_exact(dma, cva); tb = ed_ratio_exact(dmb, cvb); }
             ta = (n < 2 * WA || i < WA || i > n - WA) ? 0.0f : ta; tb = (n < 2 * WB || i < WB || i > n - WB) ? 0.0f : tb;          // quick return and fudged boundaries
             const float t1 = w1 < w2 ? ta : tb, t2 = w1 < w2 ? tb : ta;
             int pos;
@@ -774,12 +774,15 @@ __global__ void __launch_bounds__(64, 3) np_ed_peaks_par_kernel(int n_reads, con
                                                               const int32_t* __restrict__ status, np_detector_param p,
                                                               const int64_t* __restrict__ event_off, uint32_t* __restrict__ event_start,
                                                               uint32_t* __restrict__ scratch_a, uint32_t* __restrict__ scratch_b,
-                                                              uint32_t* __restrict__ scratch_c, int32_t* __restrict__ n_events, int warmup)
+                                                              uint32_t* __restrict__ scratch_c, int32_t* __restrict__ n_events, int warmup, int ratio_exact_mode)
 {
     const int r = blockIdx.x;
     if (r >= n_reads) return;
     const int64_t n64 = raw_off[r + 1] - raw_off[r];
     if (n64 < NP_ED_PAR_MIN || status[r] != 0) return;            // short reads / declined reads: the other kernel
+    // (ratio_exact_mode: the t-statistic's last step by the exact sequence for every value -- a context whose probe of ed_ratio_filtered
+    //  failed at np_create, or the option "ed_ratio_exact")
+    const bool ratio_exact = ratio_exact_mode != 0;
     const int n = (int)n64;
     const int lane = threadIdx.x;
     const int64_t base = raw_off[r];
@@ -806,10 +809,10 @@ __global__ void __launch_bounds__(64, 3) np_ed_peaks_par_kernel(int n_reads, con
     const float a_off = ADC ? adc_offset[r] : 0.0f, a_unit = ADC ? adc_unit[r] : 1.0f;
     const __amdgpu_buffer_rsrc_t xr = ADC ? make_rsrc((const void*)(a0 & ~(uintptr_t)3), (uint32_t)((2 * (n + lead) + 3) & ~3))
                                           : make_rsrc(raw + base, (uint32_t)n * 4u);
-    if (FUSED) walk_segment_raw<false, ADC>(xr, n, begin, start, warmup, start < end, st, p, tmp, tmp_cap, cnt, lead, a_off, a_unit);
+    if (FUSED) walk_segment_raw<false, ADC>(xr, n, begin, start, warmup, start < end, st, p, tmp, tmp_cap, cnt, lead, a_off, a_unit, ratio_exact);
     else walk_segment<false>(tstat, base, begin, start, warmup, start < end, st, p, tmp, tmp_cap, cnt);   // warm-up, nothing recorded
     walk_state entry = st;                                                                           // state at the segment's first sample
-    if (FUSED) walk_segment_raw<true, ADC>(xr, n, start, end, S, start < end, st, p, tmp, tmp_cap, cnt, lead, a_off, a_unit);
+    if (FUSED) walk_segment_raw<true, ADC>(xr, n, start, end, S, start < end, st, p, tmp, tmp_cap, cnt, lead, a_off, a_unit, ratio_exact);
     else walk_segment<true>(tstat, base, start, end, S, start < end, st, p, tmp, tmp_cap, cnt);
 
     // verification / repair rounds
@@ -822,7 +825,7 @@ __global__ void __launch_bounds__(64, 3) np_ed_peaks_par_kernel(int n_reads, con
         if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;
         walk_state redo = left;
         int c2 = 0;
-        if (FUSED) walk_segment_raw<true, ADC>(xr, n, start, end, S, bad, redo, p, tmp, tmp_cap, c2, lead, a_off, a_unit);
+        if (FUSED) walk_segment_raw<true, ADC>(xr, n, start, end, S, bad, redo, p, tmp, tmp_cap, c2, lead, a_off, a_unit, ratio_exact);
         else walk_segment<true>(tstat, base, start, end, S, bad, redo, p, tmp, tmp_cap, c2);
         if (bad) { st = redo; entry = left; cnt = c2; }
     }
@@ -1199,7 +1202,7 @@ hipError_t np_launch_adc_to_pa(int n_reads, const int16_t* adc, const int64_t* r
 
 hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t* raw_off, int64_t max_samples, const np_detector_param& p,
                                    float2* tstat, int32_t* status, const int64_t* event_off, int64_t max_events, uint32_t* event_start,
-                                   float* event_length, float* event_mean, float* event_stdv, int32_t* n_events, int warmup, bool checked, hipStream_t s)
+                                   float* event_length, float* event_mean, float* event_stdv, int32_t* n_events, int warmup, bool checked, hipStream_t s, int ratio_exact)
 {
     if (n_reads <= 0) return hipSuccess;
     if (!checked) hipLaunchKernelGGL(np_ed_check_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, raw, raw_off, status);
@@ -1221,10 +1224,10 @@ hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t*
     if (max_samples >= NP_ED_PAR_MIN) {
         if (fused)
             hipLaunchKernelGGL((np_ed_peaks_par_kernel<true, false>), dim3(n_reads), dim3(64), 0, s, n_reads, raw_off, tstat, raw, (const int16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, status, p, event_off, event_start,
-                               (uint32_t*)event_length, (uint32_t*)event_mean, (uint32_t*)event_stdv, n_events, warmup < 0 ? NP_ED_WARMUP : warmup);
+                               (uint32_t*)event_length, (uint32_t*)event_mean, (uint32_t*)event_stdv, n_events, warmup < 0 ? NP_ED_WARMUP : warmup, ratio_exact);
         else
             hipLaunchKernelGGL((np_ed_peaks_par_kernel<false, false>), dim3(n_reads), dim3(64), 0, s, n_reads, raw_off, tstat, raw, (const int16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, status, p, event_off, event_start,
-                               (uint32_t*)event_length, (uint32_t*)event_mean, (uint32_t*)event_stdv, n_events, warmup < 0 ? NP_ED_WARMUP : warmup);
+                               (uint32_t*)event_length, (uint32_t*)event_mean, (uint32_t*)event_stdv, n_events, warmup < 0 ? NP_ED_WARMUP : warmup, ratio_exact);
     }
     (void)max_events;
     hipLaunchKernelGGL(np_ed_events_kernel<false>, dim3(n_reads), dim3(256), 0, s, n_reads, raw, (const int16_t*)nullptr, (const float*)nullptr,
@@ -1240,7 +1243,7 @@ hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t*
 // lengths (RNA): the two-call form.
 hipError_t np_launch_detect_events_adc(int n_reads, const int16_t* adc, const int64_t* raw_off, int64_t max_samples, const float* offset, const float* raw_unit,
                                        float* raw_pa, const np_detector_param& p, float2* tstat, int32_t* status, const int64_t* event_off, int64_t max_events,
-                                       uint32_t* event_start, float* event_length, float* event_mean, float* event_stdv, int32_t* n_events, int warmup, hipStream_t s)
+                                       uint32_t* event_start, float* event_length, float* event_mean, float* event_stdv, int32_t* n_events, int warmup, hipStream_t s, int ratio_exact)
 {
     if (n_reads <= 0) return hipSuccess;
     const bool fused = NP_ED_FUSED && ((p.window_length1 == 3 && p.window_length2 == 6) || (p.window_length1 == 6 && p.window_length2 == 3));
@@ -1248,7 +1251,7 @@ hipError_t np_launch_detect_events_adc(int n_reads, const int16_t* adc, const in
         const hipError_t e = np_launch_adc_to_pa(n_reads, adc, raw_off, max_samples, offset, raw_unit, raw_pa, status, s);
         if (e != hipSuccess) return e;
         return np_launch_detect_events(n_reads, raw_pa, raw_off, max_samples, p, tstat, status, event_off, max_events, event_start, event_length, event_mean,
-                                       event_stdv, n_events, warmup, max_samples > 0, s);
+                                       event_stdv, n_events, warmup, max_samples > 0, s, ratio_exact);
     }
     hipLaunchKernelGGL(np_adc_to_pa_check_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, adc, raw_off, offset, raw_unit, raw_pa, status, (int64_t)NP_ED_PAR_MIN);
     hipLaunchKernelGGL(np_adc_to_pa_serial_kernel, dim3(n_reads), dim3(256), 0, s, n_reads, adc, raw_off, offset, raw_unit, raw_pa, status, (int64_t)NP_ED_PAR_MIN);
@@ -1263,7 +1266,7 @@ hipError_t np_launch_detect_events_adc(int n_reads, const int16_t* adc, const in
     if (max_samples >= NP_ED_PAR_MIN)
         hipLaunchKernelGGL((np_ed_peaks_par_kernel<true, true>), dim3(n_reads), dim3(64), 0, s, n_reads, raw_off, tstat, (const float*)nullptr, adc, offset, raw_unit,
                            status, p, event_off, event_start, (uint32_t*)event_length, (uint32_t*)event_mean, (uint32_t*)event_stdv, n_events,
-                           warmup < 0 ? NP_ED_WARMUP : warmup);
+                           warmup < 0 ? NP_ED_WARMUP : warmup, ratio_exact);
     (void)max_events;
     hipLaunchKernelGGL(np_ed_events_kernel<true>, dim3(n_reads), dim3(256), 0, s, n_reads, (const float*)nullptr, adc, offset, raw_unit, raw_off, event_off,
                        event_start, n_events, status, event_length, event_mean, event_stdv);

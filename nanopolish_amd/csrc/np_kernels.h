@@ -182,10 +182,10 @@ hipError_t np_launch_selftest_div_small(int w, double chd, double cld, float chf
 hipError_t np_launch_detect_events(int n_reads, const float* raw, const int64_t* raw_off, int64_t max_samples, const np_detector_param& p,
                                    float2* tstat, int32_t* status, const int64_t* event_off, int64_t max_events, uint32_t* event_start,
                                    float* event_length, float* event_mean, float* event_stdv, int32_t* n_events, int warmup /* < 0: default */,
-                                   bool checked /* status already holds these samples' exactness verdicts (np_launch_adc_to_pa) */, hipStream_t s);
+                                   bool checked /* status already holds these samples' exactness verdicts (np_launch_adc_to_pa) */, hipStream_t s, int ratio_exact = 0);
 hipError_t np_launch_detect_events_adc(int n_reads, const int16_t* adc, const int64_t* raw_off, int64_t max_samples, const float* offset, const float* raw_unit,
                                        float* raw_pa, const np_detector_param& p, float2* tstat, int32_t* status, const int64_t* event_off, int64_t max_events,
-                                       uint32_t* event_start, float* event_length, float* event_mean, float* event_stdv, int32_t* n_events, int warmup, hipStream_t s);
+                                       uint32_t* event_start, float* event_length, float* event_mean, float* event_stdv, int32_t* n_events, int warmup, hipStream_t s, int ratio_exact = 0);
 hipError_t np_launch_adc_to_pa(int n_reads, const int16_t* adc, const int64_t* raw_off, int64_t max_samples, const float* offset,
                                const float* raw_unit, float* raw_pa, int32_t* status /* optional */, hipStream_t s);
 hipError_t np_launch_reverse_events(int n_reads, const int64_t* event_off, const int32_t* n_events, uint32_t* start, float* length, float* mean,
