@@ -16,6 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=1500)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--adc", type=int, default=0, help="1: the traces as int16 ADC counts (the reference sees what they convert to): the counts-in form of the detector")
     args = ap.parse_args()
     from oracle import load_models
     from oracle.ref_full import FullRef
@@ -36,7 +37,11 @@ def main():
         rd = synth_cigar_read(50000 + 7919 * args.seed + rid, g, nuc, span=int(rng.integers(300, 6000)), p_sub=float(rng.choice([0.0, 0.02, 0.06])),
                               p_ins=float(rng.choice([0.0, 0.02, 0.05])), p_del=float(rng.choice([0.0, 0.02, 0.05])),
                               max_indel=int(rng.integers(1, 12)), soft_clip=(0, int(rng.integers(0, 40))))
-        recs.append(dict(seq=rd["seq"], raw=rd["raw"], rc=rd["rc"], pos=rd["pos"], cigar=api.cigar_words(rd["cigar_ops"]), bam_seq=rd["bam_seq"]))
+        rec = dict(seq=rd["seq"], raw=rd["raw"], rc=rd["rc"], pos=rd["pos"], cigar=api.cigar_words(rd["cigar_ops"]), bam_seq=rd["bam_seq"])
+        if args.adc:
+            from nanopolish_amd.synth import adc_quantise
+            rec["adc"], rec["raw"] = adc_quantise(rd["raw"])
+        recs.append(rec)
     t_synth = time.time() - t0
     ctx = Context(0); ctx.register_model(nuc, "nucleotide"); ctx.register_model(models["cpg"], "cpg")
     hb = build_host_batch_records(models, recs, contig)

@@ -238,4 +238,14 @@ print(d["value"], d["roofline"]["kernel_ms_per_step"], d["max_abs_dLLR_vs_cpu"])
 PYEOF2
 }
 
+# soak on the round's final binaries: eight seeds of 1 500 records from int16 counts (the counts-in detector), four from float samples, and
+# 1 024 full-size eventalign reads, all against the reference compiled in place
+call_ao() {
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r06ao; mkdir -p $O
+for seed in 50 51 52 53 54 55 56 57; do ( timeout 900 python tests/gpu_soak.py --reads 1500 --seed $seed --adc 1 ) > $O/soak_adc_$seed.log 2>&1; grep "^{" $O/soak_adc_$seed.log | cut -c1-330; done
+for seed in 58 59 60 61; do ( timeout 900 python tests/gpu_soak.py --reads 1500 --seed $seed ) > $O/soak_$seed.log 2>&1; grep "^{" $O/soak_$seed.log | cut -c1-330; done
+( timeout 1200 python tests/gpu_soak_eventalign.py 1024 ) > $O/soak_ea.log 2>&1; tail -1 $O/soak_ea.log | cut -c1-200
+}
+
 "call_$1"
